@@ -1,0 +1,89 @@
+"""ctypes binding of libgvpm_host.so (synthetic hosts, host_api.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libgvpm_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C gvpm_amd/csrc`) first")
+        L = C.CDLL(path)
+        L.gvpm_synth_create.restype = C.c_void_p
+        L.gvpm_synth_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32]
+        L.gvpm_synth_destroy.argtypes = [C.c_void_p]
+        L.gvpm_synth_params.argtypes = [C.c_void_p, C.POINTER(abi.Params)]
+        L.gvpm_synth_medium.argtypes = [C.c_void_p, C.POINTER(abi.Medium)]
+        L.gvpm_synth_triangles.argtypes = [C.c_void_p, C.POINTER(abi.Triangles)]
+        L.gvpm_synth_shoot.restype = C.c_uint64
+        L.gvpm_synth_shoot.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(abi.PhotonSoA),
+                                       C.POINTER(C.c_uint64)]
+        L.gvpm_synth_beams.restype = C.c_uint64
+        L.gvpm_synth_beams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)]
+        _LIB = L
+    return _LIB
+
+
+class SynthScene:
+    """Closed-form scene + light-path / camera-beam generators (synth.h)."""
+
+    def __init__(self, name="cbox", width=64, height=64, seed=0x6776706D):
+        self._h = lib().gvpm_synth_create(name.encode(), width, height, seed)
+        if not self._h:
+            raise ValueError(f"unknown synthetic scene {name!r} or bad size")
+        self.name, self.width, self.height = name, width, height
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gvpm_synth_destroy(self._h)
+            self._h = None
+
+    def params(self):
+        p = abi.Params()
+        lib().gvpm_synth_params(self._h, C.byref(p))
+        return p
+
+    def medium(self):
+        m = abi.Medium()
+        lib().gvpm_synth_medium(self._h, C.byref(m))
+        return m
+
+    def triangles(self):
+        """(v0, e1, e2) as (n,3) float32 arrays."""
+        t = abi.Triangles()
+        lib().gvpm_synth_triangles(self._h, C.byref(t))
+        n = t.n
+        out = []
+        for ptr in (t.v0, t.e1, t.e2):
+            buf = (C.c_float * (3 * n)).from_address(ptr)
+            out.append(np.array(buf, np.float32).reshape(n, 3).copy())
+        return tuple(out)
+
+    def shoot_photons(self, iteration, capacity):
+        """-> (abi.Photons, nb_paths)"""
+        soa = abi.PhotonSoA()
+        nb = C.c_uint64(0)
+        lib().gvpm_synth_shoot(self._h, iteration, capacity, C.byref(soa), C.byref(nb))
+        return abi.Photons.from_soa(soa), int(nb.value)
+
+    def camera_beams(self, iteration, x0=0, y0=0, x1=None, y1=None):
+        """-> structured array (n_sets, 5) of gvpm_camera_ray"""
+        x1 = self.width if x1 is None else x1
+        y1 = self.height if y1 is None else y1
+        ptr = C.c_void_p()
+        n = lib().gvpm_synth_beams(self._h, iteration, x0, y0, x1, y1, C.byref(ptr))
+        if n == 0:
+            return np.zeros((0, 5), abi.CAMERA_RAY_DTYPE)
+        buf = (C.c_char * (n * 5 * 64)).from_address(ptr.value)
+        return np.frombuffer(buf, abi.CAMERA_RAY_DTYPE).reshape(n, 5).copy()

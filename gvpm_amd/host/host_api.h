@@ -1,0 +1,26 @@
+/* C ABI of libgvpm_host.so: synthetic hosts (scene, light paths, camera beams)
+ * and the GPMIntegrator mirror.  Used by bench.py / tests through ctypes and
+ * by C++ callers directly. */
+#ifndef GVPM_HOST_API_H
+#define GVPM_HOST_API_H
+#include "../../include/gvpm_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct gvpm_synth gvpm_synth;
+gvpm_synth *gvpm_synth_create(const char *scene, int width, int height, uint32_t seed);
+void gvpm_synth_destroy(gvpm_synth *s);
+int gvpm_synth_params(const gvpm_synth *s, gvpm_params *out);
+int gvpm_synth_medium(const gvpm_synth *s, gvpm_medium *out);
+int gvpm_synth_triangles(gvpm_synth *s, gvpm_triangles *out);
+/* shoots light paths of iteration `it` until `capacity` photons are stored;
+ * *out points into buffers owned by `s` (valid until the next shoot) */
+uint64_t gvpm_synth_shoot(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_soa *out,
+                          uint64_t *nb_paths);
+/* camera beam sets of the pixel rectangle; returns the number of sets */
+uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
+                          const gvpm_camera_ray **out);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+// Synthetic closed-form hosts: what Mitsuba's scene + libbidir produce for the
+// gvpm integrator, restated for scenes simple enough that no Mitsuba is
+// needed on the GPU box (SURVEY 7 step 3, 8d "Synthetic inputs").
+//
+// The generators emit exactly the inputs of the C ABI (include/gvpm_hip.h):
+//  * light paths: Path::randomWalk(EImportance) conventions of
+//    src/libbidir/vertex.cpp:35-332, edge.cpp:27-84, path.cpp:471-501, flattened
+//    like GPhotonMap::tryAppend (gvpm/gvpm_accel.h:119-199);
+//  * camera beams: randomWalkFromPixelToFirstDiffuse long-beam camera paths
+//    (gvpm/gvpm_gatherpoint.h:22-170) with the SVertexPDF caches of
+//    GatherPoint::generateVertexInfo (gvpm/gvpm_struct.h:523-565) for the base
+//    and ShiftGatherPoint::generate/trace (gvpm/shift/shift_cameraPath.h) for
+//    the four offset pixels.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gvpm_hip.h"
+#include "vecmath.h"
+
+namespace gvpm {
+
+enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1 };
+
+struct SynthTri {
+  V3 v0, e1, e2, n;  // n: geometric normal (front side)
+  int mat;
+};
+struct SynthMat {
+  int kind;
+  V3 albedo;
+};
+
+struct SynthScene {
+  std::string name;
+  std::vector<SynthTri> tris;
+  std::vector<SynthMat> mats;
+  // one square area light (AreaLight, src/emitters/area.cpp)
+  V3 lightC, lightU, lightV, lightN, radiance;
+  double lightArea;
+  // homogeneous medium filling the box [bmin,bmax]
+  gvpm_medium medium;
+  V3 bmin, bmax;
+  // pinhole (perspective) sensor
+  V3 camPos;
+  double tanHalfFovX;
+  int width, height;
+  uint32_t seed;
+  // light-path walk parameters (GPMConfig maxDepth, rrDepth, minDepth)
+  int maxDepth, rrDepth, minDepth;
+  double cameraSphere;  // world units, already scaled as in gvpm.cpp:162
+
+  double bsphereRadius() const;
+  void addQuad(V3 a, V3 b, V3 c, V3 d, int mat);  // a,b,c,d counter-clockwise seen from the front
+};
+
+bool makeScene(const std::string &name, int width, int height, uint32_t seed, SynthScene &out);
+
+struct PhotonBuffers {
+  std::vector<float> pos, wi, flux, parent_pos, parent_n, prefix_w, parent_scat, parent_wi;
+  std::vector<float> parent_pdf, edge_pdf, parent_rr, parent_g;
+  std::vector<uint32_t> flags, path_id;
+  uint64_t n = 0;
+  void clear();
+  void view(gvpm_photon_soa &out) const;
+};
+
+// Shoot light paths until `capacity` photons are stored (gvpm_proc.cpp:278-350).
+// Returns the number of light paths shot (m_numShotVolume).
+uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out);
+
+// Camera beam sets (5 rays each) for the pixels [x0,x1) x [y0,y1) of iteration
+// `iteration`; pixels whose camera path has no medium edge produce no set.
+void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,
+                 std::vector<gvpm_camera_ray> &out);
+
+void defaultParams(const SynthScene &sc, gvpm_params &p);
+
+}  // namespace gvpm

@@ -1,0 +1,308 @@
+/*
+ * gvpm_hip.h -- C ABI of libgvpm_hip.so: the MI355X (gfx950) photon-gather +
+ * gradient-domain shift path of the `gvpm` integrator.
+ *
+ * This is the seam a Mitsuba-side `gvpm` Integrator shim binds instead of the
+ * `switch (m_config.volTechnique)` at
+ *   src/integrators/photonmapper/gvpm/gvpm.cpp:456-474
+ * (computeVolumeGradientPhoton / ...PhotonBRE / ...Beams / ...Planes), and of
+ * the per-pixel assembly that follows it (gvpm.cpp:480-532, 1205-1306).
+ * All citations below are relative to the reference tree
+ * (gvpm/ = src/integrators/photonmapper/gvpm/).
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes, no torch / HIP types in any signature;
+ *  - every call returns int: 0 = GVPM_OK, negative = gvpm_status; the text of
+ *    the last failure of a handle is available through gvpm_last_error();
+ *    nothing throws or aborts (Mitsuba's SLog(EError) throws; a shim converts);
+ *  - the caller owns every host buffer passed in; the library copies during
+ *    the call (uploads are synchronous with respect to the host buffer);
+ *  - a handle is single-owner (call it from the RenderJob thread only);
+ *    kernels are stream-ordered; gvpm_download_* block until results are ready;
+ *  - the `_dev` variants take DEVICE pointers (already resident in HBM, e.g.
+ *    a torch tensor's data_ptr()) and do no PCIe traffic.
+ *
+ * All floating-point payload is fp32 (the reference's SCons default
+ * SINGLE_PRECISION build, build/config-linux-gcc.py:7); the device computes in
+ * fp32.
+ */
+#ifndef GVPM_HIP_H
+#define GVPM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVPM_ABI_VERSION 1
+
+/* ---- status codes --------------------------------------------------------*/
+typedef enum gvpm_status {
+  GVPM_OK = 0,
+  GVPM_ERR_INVALID_ARG = -1,  /* null pointer, bad enum, inconsistent sizes   */
+  GVPM_ERR_NO_DEVICE = -2,    /* no gfx950 device / HIP runtime failure       */
+  GVPM_ERR_HIP = -3,          /* a HIP call failed (see gvpm_last_error)      */
+  GVPM_ERR_STATE = -4,        /* call order violated (e.g. gather w/o photons)*/
+  GVPM_ERR_UNSUPPORTED = -5,  /* flag combination the reference itself rejects
+                                 (GPMConfig::load SLog(EError) cases,
+                                 gvpm/gvpm_struct.h:291-331) or a branch that
+                                 is host-only (manifold shift)                */
+  GVPM_ERR_COMM = -6          /* RCCL failure                                 */
+} gvpm_status;
+
+/* ---- enums mirrored from the reference -----------------------------------*/
+/* EVolumeTechnique, src/integrators/volume_utils.h:12-21 (same order).      */
+typedef enum gvpm_technique {
+  GVPM_VOL_BRE2D = 0,
+  GVPM_VOL_BRE3D = 1,
+  GVPM_DISTANCE = 2,          /* G-VPM, 3D point kernel                       */
+  GVPM_BEAM_BEAM_1D = 3,
+  GVPM_BEAM_BEAM_3D_NAIVE = 4,
+  GVPM_BEAM_BEAM_3D_EGSR = 5,
+  GVPM_BEAM_BEAM_3D_OPTIMIZED = 6,
+  GVPM_VOL_PLANE0D = 7
+} gvpm_technique;
+
+/* EPixel, gvpm/gvpm_struct.h:354-359; offsets from generateOffsetPos,
+ * gvpm/shift/shift_utilities.h:255-261: L=(-1,0) R=(+1,0) T=(0,+1) B=(0,-1). */
+enum { GVPM_LEFT = 0, GVPM_RIGHT = 1, GVPM_TOP = 2, GVPM_BOTTOM = 3 };
+
+/* ELightShiftType, gvpm/gvpm_struct.h:30-37 (values kept).                   */
+enum {
+  GVPM_SHIFT_ALL = 0,
+  GVPM_SHIFT_DIFFUSE = 1 << 1,
+  GVPM_SHIFT_MANIFOLD = 1 << 2,
+  GVPM_SHIFT_NULL = 1 << 4,
+  GVPM_SHIFT_MEDIUM = 1 << 5,
+  GVPM_SHIFT_INVALID = 1 << 6
+};
+
+/* ELightingEffects, src/integrators/volume_utils.h:94-103.                   */
+enum {
+  GVPM_SURF2SURF = 1 << 1,
+  GVPM_SURF2MEDIA = 1 << 2,
+  GVPM_MEDIA2SURF = 1 << 3,
+  GVPM_MEDIA2MEDIA = 1 << 4
+};
+
+/* BSDF::EBSDFType bits used by bsdfInteractionMode
+ * (include/mitsuba/render/bsdf.h; parse in volume_utils.h:120-151).          */
+enum {
+  GVPM_BSDF_DIFFUSE_REFLECTION = 0x00002,
+  GVPM_BSDF_ALL = 0x1FFFF
+};
+
+/* ---- photon record flags (one uint32 per photon) -------------------------*/
+/* parent = light-path vertex (vertexId-1), the vertex the photon is
+ * re-connected from (gvpm/shift/shift_volume_photon.cpp:389-390).            */
+#define GVPM_PARENT_EMITTER 0u  /* PathVertex::EEmitterSample (area light)    */
+#define GVPM_PARENT_SURFACE 1u  /* ESurfaceInteraction, Lambertian closed set */
+#define GVPM_PARENT_MEDIUM 2u   /* EMediumInteraction                         */
+#define GVPM_PF_PARENT_TYPE(f) ((f) & 3u)
+/* result of getTypeShift() (gvpm/shift/shift_utilities.h:112-136) -- a pure
+ * function of the light path, evaluated by the host at flattening time:
+ * 0 invalid, 1 diffuse, 2 medium, 3 manifold                                 */
+#define GVPM_PF_SHIFT_TYPE(f) (((f) >> 2) & 7u)
+#define GVPM_PF_EDGE_IN_MEDIUM(f) (((f) >> 5) & 1u) /* edge(vertexId-1)->medium != 0 */
+#define GVPM_PF_DEPTH(f) (((f) >> 8) & 0xFFu)        /* vertexId - 1            */
+/* getVertexComponentType(vPrev) (shift_utilities.h:219-229), low 16 bits of
+ * BSDF::EBSDFType                                                            */
+#define GVPM_PF_PREV_COMPONENT(f) (((f) >> 16) & 0xFFFFu)
+#define GVPM_PF_MAKE(parent, shift, edge_medium, depth, comp)                  \
+  (((uint32_t)(parent) & 3u) | (((uint32_t)(shift) & 7u) << 2) |               \
+   (((uint32_t)(edge_medium) & 1u) << 5) | (((uint32_t)(depth) & 0xFFu) << 8) | \
+   (((uint32_t)(comp) & 0xFFFFu) << 16))
+
+/* ---- configuration: the GPMConfig flags the kernels read -----------------*/
+/* gvpm/gvpm_struct.h:107-333 (same names, snake_case).                       */
+typedef struct gvpm_params {
+  int32_t abi_version;          /* = GVPM_ABI_VERSION                          */
+  int32_t width, height;        /* film crop size                              */
+  int32_t vol_technique;        /* gvpm_technique                              */
+  int32_t max_depth;            /* maxDepth; <= 0: no limit (the functors test
+                                   `config.maxDepth > 0`)                      */
+  int32_t min_depth;            /* minDepth                                    */
+  int32_t use_mis;              /* useMIS: 1 "area", 0 "none"                  */
+  int32_t use_shift_null;       /* useShiftNull                                */
+  int32_t path_set;             /* pathSet                                     */
+  int32_t power_heuristic;      /* powerHeuristic                              */
+  int32_t no_medium_shift;      /* noMediumShift (must be 1: shiftPhotonMedium
+                                   is SAssert(false), shift_volume_photon.cpp:307) */
+  int32_t use_manifold;         /* useManifold: manifold shifts are host-only;
+                                   the device treats them as the reference does
+                                   with useManifold=false (failed shift)       */
+  int32_t debug_shift;          /* debugShift, ELightShiftType value           */
+  int32_t lighting_interaction_mode; /* ELightingEffects bits                 */
+  int32_t bsdf_interaction_mode;     /* BSDF type mask, GVPM_BSDF_ALL = "all"  */
+  int32_t nb_camera_samples;    /* nbCameraSamples (G-VPM)                     */
+  int32_t visibility_as_written;/* 1: shadow ray maxt = lProj*ShadowEpsilon as
+                                   written at shift_volume_photon.cpp:396;
+                                   0: lProj*(1-ShadowEpsilon)                  */
+  float alpha;                  /* alpha (radius reduction)                    */
+  float initial_scale_volume;   /* initialScaleVolume                          */
+  float bsphere_radius;         /* m_smokeAABB.getBSphere().radius             */
+  float epsilon;                /* Epsilon, include/mitsuba/core/constants.h   */
+  float shadow_epsilon;         /* ShadowEpsilon                               */
+  int32_t reserved[8];
+} gvpm_params;
+
+/* ---- medium (homogeneous, "balance" strategy) ----------------------------*/
+/* src/medium/homogeneous.cpp:432-513, src/phase/{isotropic,hg}.cpp.          */
+typedef struct gvpm_medium {
+  float sigma_a[3];
+  float sigma_s[3];
+  float sigma_t[3];             /* must be equal across channels (:196-200)    */
+  float g;                      /* HG mean cosine, 0 = isotropic               */
+  float medium_sampling_weight; /* 1 after computeOnlyVolumeInteraction()      */
+  float reserved[5];
+} gvpm_medium;
+
+/* ---- scene occluders for scene->rayIntersect(Ray) ------------------------*/
+/* call sites shift_volume_photon.cpp:398, shift_volume_beams.cpp:421.
+ * Triangle i = (v0, v0+e1, v0+e2); arrays of 3*n floats.                     */
+typedef struct gvpm_triangles {
+  const float *v0, *e1, *e2;
+  uint32_t n;
+} gvpm_triangles;
+
+/* ---- volume photons: one record per stored light-path vertex -------------*/
+/* Host-side flattening of GPhotonNodeData + the Path it points to
+ * (gvpm/gvpm_accel.h:17-65,119-199). SoA, n elements per array, 3-vectors
+ * packed xyz.  c = vertexId, parent = vertex(c-1).                            */
+typedef struct gvpm_photon_soa {
+  const float *pos;         /* 3n  vertex(c) position                          */
+  const float *wi;          /* 3n  -edge(c-1)->d  (towards the parent)         */
+  const float *flux;        /* 3n  GPhotonNodeData::weight                     */
+  const float *parent_pos;  /* 3n  vertex(c-1) position                        */
+  const float *parent_n;    /* 3n  geometric (= shading) normal of a surface or
+                                   emitter parent; ignored for a medium parent */
+  const float *prefix_w;    /* 3n  prod_{i<c-1} v_i.weight*v_i.rrWeight*e_i.weight
+                                   (shift_volume_photon.cpp:415-422)           */
+  const float *parent_scat; /* 3n  surface: diffuse reflectance; medium: sigma_s */
+  const float *parent_wi;   /* 3n  unit direction parent -> vertex(c-2)        */
+  const float *parent_pdf;  /* n   vertex(c-1)->pdf[EImportance] (area measure) */
+  const float *edge_pdf;    /* n   edge(c-1)->pdf[EImportance]                 */
+  const float *parent_rr;   /* n   vertex(c-1)->rrWeight                       */
+  const float *parent_g;    /* n   HG g of the parent's medium (medium parent) */
+  const uint32_t *flags;    /* n   GVPM_PF_*                                   */
+  const uint32_t *path_id;  /* n   GPhotonNodeData::pathID                     */
+  uint64_t n;
+} gvpm_photon_soa;
+
+/* ---- camera beams ---------------------------------------------------------*/
+/* One gvpm_camera_ray = one medium edge of a camera path (base, or the same
+ * edge of the path re-traced through an offset pixel by
+ * ShiftGatherPoint::generate, gvpm/shift/shift_cameraPath.h:29-133), with the
+ * SVertexPDF cache entries the functors read (gvpm/gvpm_struct.h:361-370,
+ * 585-631).  64 bytes.  A beam SET = 5 consecutive rays: base, L, R, T, B.   */
+typedef struct gvpm_camera_ray {
+  float o[3];        /* vertex(e) position                                     */
+  float len;         /* edge(e)->length                                        */
+  float d[3];        /* -edge(e)->d, unit, pointing away from the camera       */
+  float pdf;         /* getVertexInfo(e).pdf                                   */
+  float eye[3];      /* getWeightBeam(e-1) * getWeightVertex(e)                */
+  float jacobian;    /* getVertexInfo(e).jacobian                              */
+  float gop;         /* GOp(e) = geometryOpposingTerm(path, e, e+1)            */
+  uint32_t info;     /* bit0: validVolumeEdge(e, medium) (always 1 for base);
+                        bits 8..15: edge index e                               */
+  float rand;        /* base ray only: the sampler->next1D() of this beam
+                        (gvpm.cpp:1042 BRE; :1156 VPM)                         */
+  uint32_t pixel;    /* base ray only: px | py << 16                           */
+} gvpm_camera_ray;
+
+#define GVPM_RAY_VALID(info) ((info) & 1u)
+#define GVPM_RAY_EDGE(info) (((info) >> 8) & 0xFFu)
+#define GVPM_RAY_INFO(valid, edge) (((uint32_t)(valid) & 1u) | (((uint32_t)(edge) & 0xFFu) << 8))
+
+/* G-VPM only: extra per-sample data (gvpm.cpp:1117-1172): the base ray's
+ * `rand` is randSample, `pdf_sel` = selBeam[sampleIndex].                     */
+typedef struct gvpm_vpm_sample {
+  float pdf_sel;
+  uint32_t reserved;
+} gvpm_vpm_sample;
+
+/* ---- per-pixel accumulators (what GatherPoint keeps across iterations) ---*/
+/* gvpm/gvpm_struct.h:429-441: mediumFlux, shiftedMediumFlux[4],
+ * weightedMediumFlux[4]; each RGB => 27 floats per pixel, row-major pixels.   */
+#define GVPM_ACCUM_FLOATS 27
+
+typedef struct gvpm_stats {
+  uint64_t evaluations;   /* functor invocations that produced a base
+                             contribution + 4 shift attempts       */
+  uint64_t candidates;    /* (beam, photon) pairs tested geometrically         */
+  uint64_t null_shifts, diffuse_shifts, failed_shifts;
+  uint64_t reserved[3];
+} gvpm_stats;
+
+typedef struct gvpm_context gvpm_context;
+
+/* ---- lifecycle ------------------------------------------------------------*/
+/* device: HIP device ordinal.  *out receives the handle.                     */
+int gvpm_create(const gvpm_params *params, int device, gvpm_context **out);
+int gvpm_destroy(gvpm_context *h);
+const char *gvpm_last_error(const gvpm_context *h);
+int gvpm_abi_version(void);
+
+/* Reset per-pixel accumulators and the APA radius scale to
+ * initialScaleVolume (GPMIntegrator::render, gvpm.cpp:272-291).              */
+int gvpm_reset(gvpm_context *h);
+
+/* ---- uploads --------------------------------------------------------------*/
+int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *tris);
+int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *medium);
+/* per iteration: replaces the proc->getPhotonVolumeMap() of gvpm.cpp:450-454  */
+int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *photons);
+/* per iteration: n_sets beam sets (5 rays each). Replaces GatherPoint[] +
+ * ShiftGatherPoint[4] for the medium edges of every pixel.  Sets may come in
+ * any order; several sets may address the same pixel (several medium edges). */
+int gvpm_upload_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays,
+                             uint64_t n_sets);
+/* the same, source buffers already in device memory                          */
+int gvpm_upload_photons_dev(gvpm_context *h, const gvpm_photon_soa *photons_dev);
+int gvpm_upload_camera_beams_dev(gvpm_context *h,
+                                 const gvpm_camera_ray *rays_dev,
+                                 uint64_t n_sets);
+
+/* ---- the hot path ---------------------------------------------------------*/
+/* One SPPM iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079;
+ * vol_technique BRE2D/BRE3D) or computeVolumeGradientPhoton (:1081-1203;
+ * DISTANCE): builds the acceleration structure over the uploaded photons,
+ * gathers every uploaded beam set, normalises by nb_paths, folds the result
+ * into the APA running mean with iteration `it` (1-based) and applies
+ * scaleVolumeAPA(it) (gvpm.cpp:181-215).  Asynchronous on the handle's stream. */
+int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths);
+
+/* current kernel radius R*0.01*globalScaleVolume (gvpm.cpp:989)              */
+int gvpm_get_radius(gvpm_context *h, float *radius);
+int gvpm_set_global_scale(gvpm_context *h, float global_scale_volume);
+int gvpm_get_stats(gvpm_context *h, gvpm_stats *out);
+/* average duration in ms of the gather kernel launches since the last call,
+ * measured with HIP events on the handle's stream, and their number          */
+int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches);
+
+/* ---- results --------------------------------------------------------------*/
+/* 27 floats per pixel (GVPM_ACCUM_FLOATS), width*height pixels               */
+int gvpm_download_accum(gvpm_context *h, float *accum);
+/* throughput (gvpm.cpp:480-500 with reusePrimal :503-532 when reuse_primal)
+ * and the gradient images of computeGradient (gvpm.cpp:1205-1306), each
+ * width*height*3 floats; emission may be NULL (else added as emission/it).   */
+int gvpm_download_film(gvpm_context *h, int it, int reuse_primal,
+                       const float *emission, float *throughput, float *dx,
+                       float *dy);
+int gvpm_synchronize(gvpm_context *h);
+
+/* ---- multi-GPU (image-tile sharding) --------------------------*/
+/* Each rank gathers only the beam sets of its own pixels; before
+ * reconstruction the 27-float accumulators (disjoint supports) are summed
+ * across ranks.  comm_id is the 128-byte ncclUniqueId produced on rank 0 by
+ * gvpm_comm_unique_id and distributed by the host (e.g. torch.distributed).  */
+int gvpm_comm_unique_id(void *id128);
+int gvpm_comm_init(gvpm_context *h, const void *id128, int rank, int world);
+int gvpm_allreduce_accum(gvpm_context *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVPM_HIP_H */

@@ -1,0 +1,138 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see gvpm_oracle.hpp header).
+// C entry points used by tests/ and bench.py's cpu_baseline leg via ctypes.
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "gvpm_oracle.hpp"
+
+using namespace oracle;
+
+namespace {
+
+template <typename F>
+int gatherBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
+              const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it, uint64_t nbPaths, int useAccel,
+              int threads, double *accum, uint64_t *counters, double *seconds) {
+  Gatherer<F> g;
+  g.setup(*p, *m, *t);
+  g.map.load(*ph);
+  auto t0 = std::chrono::steady_clock::now();
+  if (useAccel) g.map.buildBRE((F)radius);
+  else g.map.radius = (F)radius;
+  const size_t P = (size_t)p->width * p->height;
+  std::vector<F> perSet((size_t)nsets * 27, (F)0);
+  Counters total;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  // BlockScheduler (photonmapper/utilities/block_sched.h:87-113): threads pull
+  // work dynamically; here a work item is a run of 256 consecutive beam sets
+#pragma omp parallel
+  {
+    Counters local;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t s = 0; s < (int64_t)nsets; ++s) g.gatherSetBRE(rays + 5 * s, useAccel != 0, &perSet[(size_t)s * 27], local);
+#pragma omp critical
+    total.add(local);
+  }
+  // per pixel: sum over medium edges (gvpm.cpp:1044-1050), normalise (:1055-1059), APA (:1063-1069)
+  std::vector<F> iter(P * 27, (F)0);
+  for (uint64_t s = 0; s < nsets; ++s) {
+    const gvpm_camera_ray &b = rays[5 * s];
+    size_t px = b.pixel & 0xFFFFu, py = b.pixel >> 16;
+    if (px >= (size_t)p->width || py >= (size_t)p->height) return GVPM_ERR_INVALID_ARG;
+    F *dst = &iter[(py * p->width + px) * 27];
+    for (int k = 0; k < 27; ++k) dst[k] += perSet[(size_t)s * 27 + k];
+  }
+  for (size_t i = 0; i < P * 27; ++i) {
+    F v = iter[i];
+    v /= (F)nbPaths;  // Spectrum /= size_t -> Float
+    F prev = (F)accum[i];
+    accum[i] = (double)((prev * (F)(it - 1) + v) / (F)it);
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (counters) {
+    counters[0] = total.evaluations; counters[1] = total.candidates; counters[2] = total.nullShifts;
+    counters[3] = total.diffuseShifts; counters[4] = total.failedShifts;
+  }
+  return GVPM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079) on the CPU.
+// precision: 32 or 64; use_accel: 1 = kd-tree -> BRE BVH stack traversal (reference),
+// 0 = brute-force O(B*N) over the same hit predicate.  accum: width*height*27 doubles
+// (in/out, the APA running mean).  counters: 5 x uint64 {evaluations, candidates,
+// null, diffuse, failed}.
+int oracle_gather_bre(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                      const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
+                      uint64_t nb_paths, int precision, int use_accel, int threads, double *accum,
+                      uint64_t *counters, double *seconds) {
+  if (!p || !m || !t || !ph || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_VOL_BRE2D && p->vol_technique != GVPM_VOL_BRE3D) return GVPM_ERR_INVALID_ARG;
+  if (p->use_shift_null && p->vol_technique == GVPM_VOL_BRE2D) return GVPM_ERR_UNSUPPORTED;  // gvpm_struct.h:310-313
+  if (precision == 32)
+    return gatherBRE<float>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds);
+  return gatherBRE<double>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds);
+}
+
+double oracle_scale_volume_apa(double global_scale, int it, double alpha, int technique) {
+  return scaleVolumeAPA(global_scale, it, alpha, technique);
+}
+
+// Throughput + gradient assembly: gvpm.cpp:480-532 (normalise, reusePrimal) and
+// computeGradient, gvpm.cpp:1205-1306, for an APA volume estimator
+// (isAPAVolumeEstimator(): no division by the emitted count).
+// accum: P*27 doubles; emission: P*3 doubles or NULL; outputs P*3 doubles each.
+int oracle_assemble(int width, int height, int it, int reuse_primal, const double *accum, const double *emission,
+                    double *throughput, double *dx, double *dy) {
+  if (!accum || !throughput || !dx || !dy) return GVPM_ERR_INVALID_ARG;
+  auto A = [&](int x, int y, int k, int c) { return accum[((size_t)y * width + x) * 27 + k * 3 + c]; };
+  // k: 0 mediumFlux, 1+i shifted[i], 5+i weighted[i]
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x)
+      for (int c = 0; c < 3; ++c) {
+        size_t o = ((size_t)y * width + x) * 3 + c;
+        double em = emission ? emission[o] / it : 0.0;
+        double v = A(x, y, 0, c) + 0.0 + em;  // fluxMedia + fluxSurface + emission/it
+        if (reuse_primal) {
+          double T = 0;
+          if (x != width - 1) T += A(x + 1, y, 1 + GVPM_LEFT, c);
+          if (x != 0) T += A(x - 1, y, 1 + GVPM_RIGHT, c);
+          if (y != height - 1) T += A(x, y + 1, 1 + GVPM_BOTTOM, c);
+          if (y != 0) T += A(x, y - 1, 1 + GVPM_TOP, c);
+          T += A(x, y, 5 + GVPM_BOTTOM, c) + A(x, y, 5 + GVPM_TOP, c) + A(x, y, 5 + GVPM_RIGHT, c) +
+               A(x, y, 5 + GVPM_LEFT, c);
+          v = T / 4.0;
+        }
+        throughput[o] = v;
+        double gx, gy;
+        if (x == width - 1) gx = A(x, y, 1 + GVPM_RIGHT, c) - A(x, y, 5 + GVPM_RIGHT, c);
+        else gx = (A(x, y, 1 + GVPM_RIGHT, c) - A(x, y, 5 + GVPM_RIGHT, c)) +
+                  (A(x + 1, y, 5 + GVPM_LEFT, c) - A(x + 1, y, 1 + GVPM_LEFT, c));
+        if (y == height - 1) gy = A(x, y, 1 + GVPM_TOP, c) - A(x, y, 5 + GVPM_TOP, c);
+        else gy = (A(x, y, 1 + GVPM_TOP, c) - A(x, y, 5 + GVPM_TOP, c)) +
+                  (A(x, y + 1, 5 + GVPM_BOTTOM, c) - A(x, y + 1, 1 + GVPM_BOTTOM, c));
+        dx[o] = gx;
+        dy[o] = gy;
+      }
+  return GVPM_OK;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+}

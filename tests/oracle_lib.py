@@ -1,0 +1,84 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU restatement of the reference
+algorithm.  TEST INFRASTRUCTURE: imported only from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from gvpm_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIBS = {}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib(fast=False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name not in _LIBS:
+        path = os.path.join(ORACLE_DIR, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_gather_bre.argtypes = [
+            C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+            C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_scale_volume_apa.restype = C.c_double
+        L.oracle_scale_volume_apa.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int]
+        L.oracle_assemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_max_threads.restype = C.c_int
+        _LIBS[name] = L
+    return _LIBS[name]
+
+
+COUNTER_NAMES = ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts")
+
+
+def gather_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, precision=64, use_accel=True,
+               threads=0, accum=None, fast=False):
+    """One iteration of computeVolumeGradientPhotonBRE on the CPU.
+
+    tris: (v0,e1,e2) arrays; photons: abi.Photons; rays: (n_sets,5) CAMERA_RAY_DTYPE.
+    Returns (accum[H,W,27] float64, counters dict, seconds)."""
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = photons.soa()
+    rays = np.ascontiguousarray(rays)
+    P = params.width * params.height
+    if accum is None:
+        accum = np.zeros(P * 27, np.float64)
+    else:
+        accum = np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    secs = C.c_double(0)
+    rc = lib(fast).oracle_gather_bre(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
+                                     rays.ctypes.data, rays.shape[0], float(radius), it, nb_paths, precision,
+                                     1 if use_accel else 0, threads, accum.ctypes.data, counters.ctypes.data,
+                                     C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_bre failed: {rc}")
+    return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
+            secs.value)
+
+
+def scale_volume_apa(scale, it, alpha, technique):
+    return lib().oracle_scale_volume_apa(scale, it, alpha, technique)
+
+
+def assemble(accum, it=1, reuse_primal=True, emission=None):
+    H, W = accum.shape[:2]
+    a = np.ascontiguousarray(accum, np.float64)
+    out = [np.zeros((H, W, 3), np.float64) for _ in range(3)]
+    em = None if emission is None else np.ascontiguousarray(emission, np.float64)
+    rc = lib().oracle_assemble(W, H, it, 1 if reuse_primal else 0, a.ctypes.data,
+                               None if em is None else em.ctypes.data, out[0].ctypes.data, out[1].ctypes.data,
+                               out[2].ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_assemble failed: {rc}")
+    return tuple(out)
