@@ -1,0 +1,207 @@
+// Device-side acceleration-structure build for gfx950.
+//
+// Replaces GPhotonMap::build() (PointKDTree sliding midpoint, serial on the CPU;
+// gvpm/gvpm_accel.h:201-203, include/mitsuba/core/kdtree.h:326-395) and the
+// GradientBeamRadianceEstimator constructor (gvpm/gvpm_accel.cpp:10-54).  Every
+// photon of a BRE pass has the same radius (gvpm.cpp:989,  gvpm_accel.cpp:27), so a
+// uniform grid sorted by cell index (x fastest) gives x-contiguous photon ranges
+// for any axis-aligned cell box -- the access pattern the gather kernel streams.
+//
+// Also orders the camera beam sets by image tile so that one wave works on a
+// coherent bundle of beams (the role of BlockScheduler's image blocks,
+// photonmapper/utilities/block_sched.h:19-136).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "device_types.h"
+#include "vec.h"
+
+namespace gvpm {
+
+// ---- bounds: per-block min/max of the photon positions -----------------------------------
+__global__ __launch_bounds__(256) void bounds_kernel(const float *__restrict__ pos, uint32_t n, float *partial) {
+  __shared__ float red[6][4];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = pos[3 * (size_t)i + c];
+      mn[c] = fminf(mn[c], v);
+      mx[c] = fmaxf(mx[c], v);
+    }
+  }
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a = wave_min(mn[c]), b = wave_max(mx[c]);
+    if (lane == 0) {
+      red[c][wave] = a;
+      red[3 + c][wave] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int c = threadIdx.x;
+    float v = red[c][0];
+    for (int w = 1; w < 4; ++w) v = c < 3 ? fminf(v, red[c][w]) : fmaxf(v, red[c][w]);
+    partial[blockIdx.x * 6 + c] = v;
+  }
+}
+
+__global__ void bounds_final_kernel(const float *partial, int nblocks, float *out6) {
+  const int c = threadIdx.x;
+  if (c >= 6) return;
+  float v = partial[c];
+  for (int b = 1; b < nblocks; ++b) v = c < 3 ? fminf(v, partial[b * 6 + c]) : fmaxf(v, partial[b * 6 + c]);
+  out6[c] = v;
+}
+
+// ---- cell keys ---------------------------------------------------------------------------
+__device__ __forceinline__ int cellCoord(float p, float org, float inv, int dim) {
+  int c = (int)floorf((p - org) * inv);
+  return min(max(c, 0), dim - 1);
+}
+
+__global__ __launch_bounds__(256) void cell_key_kernel(const float *__restrict__ pos, uint32_t n, Grid g,
+                                                       uint32_t *keys, uint32_t *vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cx = cellCoord(pos[3 * (size_t)i + 0], g.org[0], g.invCell, g.dim[0]);
+  const int cy = cellCoord(pos[3 * (size_t)i + 1], g.org[1], g.invCell, g.dim[1]);
+  const int cz = cellCoord(pos[3 * (size_t)i + 2], g.org[2], g.invCell, g.dim[2]);
+  keys[i] = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+  vals[i] = i;
+}
+
+// ---- reorder: SoA upload layout -> sorted hot/cold planes ----------------------------------
+struct RawPhotons {
+  const float *pos, *wi, *flux, *parent_pos, *parent_n, *prefix_w, *parent_scat, *parent_wi;
+  const float *parent_pdf, *edge_pdf, *parent_rr, *parent_g;
+  const uint32_t *flags, *path_id;
+};
+
+__device__ __forceinline__ float4 ld3(const float *p, uint32_t i, float w) {
+  return make_float4(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2], w);
+}
+
+// computeVolumeContribution (gvpm/shift/shift_utilities.h:231-253) and the debugShift filter
+// (shift_volume_photon.cpp:680-687) depend only on the photon and the configuration: fold
+// them into bit 6 of the hot record.
+__device__ __forceinline__ bool photonContributes(uint32_t flags, const gvpm_params &cfg) {
+  const int mode = cfg.lighting_interaction_mode;
+  const uint32_t ptype = GVPM_PF_PARENT_TYPE(flags);
+  if (!((mode & GVPM_SURF2MEDIA) && (mode & GVPM_MEDIA2MEDIA))) {
+    if (ptype == GVPM_PARENT_MEDIUM && !(mode & GVPM_MEDIA2MEDIA)) return false;
+    if (ptype != GVPM_PARENT_MEDIUM && !(mode & GVPM_SURF2MEDIA)) return false;
+  }
+  const int compo = (int)GVPM_PF_PREV_COMPONENT(flags);
+  if (cfg.bsdf_interaction_mode != GVPM_BSDF_ALL && compo > 0 && !(compo & cfg.bsdf_interaction_mode)) return false;
+  if (cfg.debug_shift != GVPM_SHIFT_ALL && cfg.debug_shift != GVPM_SHIFT_NULL) {
+    int st;
+    switch (GVPM_PF_SHIFT_TYPE(flags)) {
+      case 1: st = GVPM_SHIFT_DIFFUSE; break;
+      case 2: st = GVPM_SHIFT_MEDIUM; break;
+      case 3: st = GVPM_SHIFT_MANIFOLD; break;
+      default: st = GVPM_SHIFT_INVALID; break;
+    }
+    if (cfg.debug_shift != st) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ order, uint32_t n,
+                                                      gvpm_params cfg, float4 *hot, float4 *cold) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t src = order[i];
+  uint32_t bits = r.flags[src] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
+  if (photonContributes(bits, cfg)) bits |= 1u << 6;
+  bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
+  hot[i] = ld3(r.pos, src, __uint_as_float(bits));
+  const size_t N = n;
+  cold[0 * N + i] = ld3(r.wi, src, r.parent_pdf[src]);
+  cold[1 * N + i] = ld3(r.flux, src, r.edge_pdf[src]);
+  cold[2 * N + i] = ld3(r.parent_pos, src, r.parent_rr[src]);
+  cold[3 * N + i] = ld3(r.parent_n, src, r.parent_g[src]);
+  cold[4 * N + i] = ld3(r.prefix_w, src, 0.f);
+  cold[5 * N + i] = ld3(r.parent_scat, src, 0.f);
+  cold[6 * N + i] = ld3(r.parent_wi, src, 0.f);
+}
+
+// ---- segment starts of a sorted key array: start[c] = first i with key[i] >= c --------------
+__global__ __launch_bounds__(256) void segment_start_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                            uint32_t nseg, uint32_t shift, uint32_t *start) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const uint32_t prev = (i == 0) ? 0u : (keys[i - 1] >> shift) + 1u;
+  const uint32_t cur = (i == n) ? nseg + 1u : (keys[i] >> shift) + 1u;
+  // segments prev .. cur-1 start at i
+  for (uint32_t c = prev; c < cur && c <= nseg; ++c) start[c] = i;
+}
+
+// ---- camera beam sets: tile keys -------------------------------------------------------------
+// key = ((tileIndex * tilePixels + pixelInTile) << 3 | (edge & 7)); tile index = key >> tileShift
+__global__ __launch_bounds__(256) void beam_key_kernel(const gvpm_camera_ray *__restrict__ rays, uint32_t nsets,
+                                                       int width, int tw, int th, uint32_t *keys, uint32_t *vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsets) return;
+  const gvpm_camera_ray &b = rays[(size_t)i * 5];
+  const uint32_t px = b.pixel & 0xFFFFu, py = b.pixel >> 16;
+  const uint32_t tilesX = (width + tw - 1) / tw;
+  const uint32_t tile = (py / th) * tilesX + px / tw;
+  const uint32_t inTile = (py % th) * tw + px % tw;
+  keys[i] = ((tile * (uint32_t)(tw * th) + inTile) << 3) | (GVPM_RAY_EDGE(b.info) & 7u);
+  vals[i] = i;
+}
+
+// ---- host-side drivers -------------------------------------------------------------------------
+
+static hipError_t ensureTemp(SortTemp &t, size_t need) {
+  if (need <= t.bytes) return hipSuccess;
+  if (t.d) (void)hipFree(t.d);
+  t.d = nullptr;
+  t.bytes = 0;
+  hipError_t e = hipMalloc(&t.d, need);
+  if (e == hipSuccess) t.bytes = need;
+  return e;
+}
+
+hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut,
+                        uint32_t n, int endBit, hipStream_t s) {
+  size_t need = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
+  if (e != hipSuccess) return e;
+  e = ensureTemp(tmp, need);
+  if (e != hipSuccess) return e;
+  return hipcub::DeviceRadixSort::SortPairs(tmp.d, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
+}
+
+void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s) {
+  hipLaunchKernelGGL(bounds_kernel, dim3(nblocks), dim3(256), 0, s, pos, n, partial);
+  hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6);
+}
+
+void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {
+  hipLaunchKernelGGL(cell_key_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, vals);
+}
+
+void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
+                    float4 *hot, float4 *cold, hipStream_t s) {
+  RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
+               raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
+               raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
+  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, order, n, cfg, hot, cold);
+}
+
+void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(segment_start_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, keys, n, nseg, shift, start);
+}
+
+void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
+                      uint32_t *vals, hipStream_t s) {
+  hipLaunchKernelGGL(beam_key_kernel, dim3((nsets + 255) / 256), dim3(256), 0, s, rays, nsets, width, tw, th, keys,
+                     vals);
+}
+
+}  // namespace gvpm

@@ -1,0 +1,628 @@
+// C ABI of libgvpm_hip.so (include/gvpm_hip.h): handle, uploads, per-iteration driver.
+// Mirrors the driver logic of GPMIntegrator::photonMapPass / computeVolumeGradientPhotonBRE
+// (gvpm/gvpm.cpp:383-500, 988-1079) and scaleVolumeAPA (gvpm.cpp:181-215).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+
+namespace gvpm {
+hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut,
+                        uint32_t n, int endBit, hipStream_t s);
+void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s);
+void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
+void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
+                    float4 *hot, float4 *cold, hipStream_t s);
+void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
+                          hipStream_t s);
+void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
+                      uint32_t *vals, hipStream_t s);
+void launch_gather_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, hipStream_t stream);
+void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
+void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float *thr,
+                 float *dx, float *dy, hipStream_t s);
+}  // namespace gvpm
+
+using namespace gvpm;
+
+namespace {
+
+template <typename T> struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct RcclApi {
+  void *dl = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  bool load() {
+    if (dl) return true;
+    dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return false;
+    getUniqueId = (decltype(getUniqueId))dlsym(dl, "ncclGetUniqueId");
+    commInitRank = (decltype(commInitRank))dlsym(dl, "ncclCommInitRank");
+    allReduce = (decltype(allReduce))dlsym(dl, "ncclAllReduce");
+    commDestroy = (decltype(commDestroy))dlsym(dl, "ncclCommDestroy");
+    return getUniqueId && commInitRank && allReduce && commDestroy;
+  }
+};
+RcclApi g_rccl;
+
+}  // namespace
+
+struct gvpm_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  gvpm_params cfg;
+  gvpm_medium medium;
+  bool haveMedium = false;
+  std::string err;
+
+  // scene
+  DevBuf<float> triV0, triE1, triE2;
+  uint32_t ntri = 0;
+
+  // photons: raw upload (owned copies or borrowed device pointers) and the built grid
+  DevBuf<float> rawF;      // 28 floats per photon when owned
+  DevBuf<uint32_t> rawU;   // 2 per photon
+  gvpm_photon_soa rawDev;  // device pointers
+  uint32_t nph = 0;
+  bool havePhotons = false, photonsDirty = false;
+  float builtRadius = -1.f;
+  DevBuf<float4> hot, cold;
+  DevBuf<uint32_t> cellStart, keysA, keysB, valsA, valsB;
+  DevBuf<float> boundsPartial, bounds6;
+  Grid grid;
+  SortTemp sortTmp;
+
+  // camera beams
+  DevBuf<gvpm_camera_ray> raysOwned;
+  const gvpm_camera_ray *raysDev = nullptr;
+  uint32_t nsets = 0;
+  bool haveBeams = false, beamsDirty = false;
+  DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
+  uint32_t ntiles = 0;
+
+  // film
+  DevBuf<float> accum, accumAll, iter, filmOut, emission;
+  bool useAll = false;  // accumAll holds the all-reduced film until the next gather
+  size_t npix = 0;
+  float globalScaleVolume = 1.f;
+
+  // stats / timing
+  DevBuf<unsigned long long> stats;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t eventsUsed = 0;
+
+  int beamsPerWave = 32;
+  float cellScale = 1.0f;
+
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+};
+
+#define CHECK_H(h)                                \
+  if (!(h)) return GVPM_ERR_INVALID_ARG;          \
+  if (hipSetDevice((h)->device) != hipSuccess) {  \
+    (h)->err = "hipSetDevice failed";             \
+    return GVPM_ERR_HIP;                          \
+  }
+
+#define HIP_TRY(h, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+      return GVPM_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+static int fail(gvpm_context *h, int code, const char *msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+// GPMConfig::load SLog(EError) cases that concern this path (gvpm/gvpm_struct.h:291-313)
+static const char *validateParams(const gvpm_params *p) {
+  if (p->abi_version != GVPM_ABI_VERSION) return "abi_version mismatch";
+  if (p->width <= 0 || p->height <= 0 || p->width > 65535 || p->height > 65535) return "bad film size";
+  if (p->vol_technique < GVPM_VOL_BRE2D || p->vol_technique > GVPM_VOL_PLANE0D) return "unknown vol_technique";
+  const bool use3D = p->vol_technique == GVPM_DISTANCE || p->vol_technique == GVPM_VOL_BRE3D ||
+                     (p->vol_technique >= GVPM_BEAM_BEAM_3D_NAIVE && p->vol_technique <= GVPM_BEAM_BEAM_3D_OPTIMIZED);
+  if (p->use_shift_null && !use3D && p->vol_technique != GVPM_BEAM_BEAM_1D)
+    return "Not possible to shift null without using 3D kernel";
+  if (p->max_depth <= 1 && p->max_depth != -1 && p->max_depth != 0) return "Maximum depth must be set to \"2\" or higher!";
+  if (!(p->bsphere_radius > 0.f)) return "bsphere_radius must be positive";
+  if (!(p->epsilon > 0.f) || !(p->shadow_epsilon > 0.f)) return "epsilon / shadow_epsilon must be positive";
+  if (!p->no_medium_shift) return "noMediumShift=false is not supported (shiftPhotonMedium is SAssert(false))";
+  return nullptr;
+}
+
+extern "C" {
+
+int gvpm_abi_version(void) { return GVPM_ABI_VERSION; }
+
+const char *gvpm_last_error(const gvpm_context *h) { return h ? h->err.c_str() : "null handle"; }
+
+int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
+  if (!params || !out) return GVPM_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (validateParams(params)) {
+    // parameter errors the reference raises at load time
+    const char *m = validateParams(params);
+    return (strstr(m, "shift null") || strstr(m, "noMediumShift")) ? GVPM_ERR_UNSUPPORTED : GVPM_ERR_INVALID_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return GVPM_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return GVPM_ERR_NO_DEVICE;
+  gvpm_context *h = new gvpm_context();
+  h->device = device;
+  h->cfg = *params;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return GVPM_ERR_HIP;
+  }
+  if (const char *e = getenv("GVPM_BEAMS_PER_WAVE")) {
+    int v = atoi(e);
+    if (v == 16 || v == 32 || v == 64) h->beamsPerWave = v;
+  }
+  if (const char *e = getenv("GVPM_CELL_SCALE")) {
+    float v = (float)atof(e);
+    if (v >= 0.25f && v <= 8.f) h->cellScale = v;
+  }
+  h->npix = (size_t)params->width * params->height;
+  if (h->accum.ensure(h->npix * 27) != hipSuccess || h->iter.ensure(h->npix * 27) != hipSuccess ||
+      h->stats.ensure(8) != hipSuccess) {
+    gvpm_destroy(h);
+    return GVPM_ERR_HIP;
+  }
+  *out = h;
+  int rc = gvpm_reset(h);
+  if (rc != GVPM_OK) {
+    gvpm_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int gvpm_destroy(gvpm_context *h) {
+  if (!h) return GVPM_ERR_INVALID_ARG;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.commDestroy) g_rccl.commDestroy(h->comm);
+  for (auto &e : h->events) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  h->triV0.release(); h->triE1.release(); h->triE2.release();
+  h->rawF.release(); h->rawU.release(); h->hot.release(); h->cold.release();
+  h->cellStart.release(); h->keysA.release(); h->keysB.release(); h->valsA.release(); h->valsB.release();
+  h->boundsPartial.release(); h->bounds6.release();
+  if (h->sortTmp.d) (void)hipFree(h->sortTmp.d);
+  h->raysOwned.release(); h->bKeysA.release(); h->bKeysB.release(); h->bValsA.release();
+  h->setPerm.release(); h->tileStart.release();
+  h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return GVPM_OK;
+}
+
+int gvpm_reset(gvpm_context *h) {
+  CHECK_H(h);
+  HIP_TRY(h, hipMemsetAsync(h->accum.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * sizeof(unsigned long long), h->stream));
+  h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
+  h->eventsUsed = 0;
+  h->useAll = false;
+  return GVPM_OK;
+}
+
+int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *t) {
+  CHECK_H(h);
+  if (!t || (t->n && (!t->v0 || !t->e1 || !t->e2))) return fail(h, GVPM_ERR_INVALID_ARG, "null triangle arrays");
+  HIP_TRY(h, h->triV0.ensure(3 * (size_t)t->n + 4));
+  HIP_TRY(h, h->triE1.ensure(3 * (size_t)t->n + 4));
+  HIP_TRY(h, h->triE2.ensure(3 * (size_t)t->n + 4));
+  if (t->n) {
+    HIP_TRY(h, hipMemcpyAsync(h->triV0.p, t->v0, 3 * (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->triE1.p, t->e1, 3 * (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->triE2.p, t->e2, 3 * (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  h->ntri = t->n;
+  return GVPM_OK;
+}
+
+int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *m) {
+  CHECK_H(h);
+  if (!m) return fail(h, GVPM_ERR_INVALID_ARG, "null medium");
+  // homogeneous.cpp:196-200: the balance strategy requires equal sigma_t across channels
+  if (m->sigma_t[0] != m->sigma_t[1] || m->sigma_t[0] != m->sigma_t[2])
+    return fail(h, GVPM_ERR_UNSUPPORTED, "Not possible to have different albedo values...");
+  if (!(m->sigma_t[0] > 0.f)) return fail(h, GVPM_ERR_INVALID_ARG, "sigma_t must be positive");
+  h->medium = *m;
+  h->haveMedium = true;
+  return GVPM_OK;
+}
+
+static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool fromDevice) {
+  if (!p) return fail(h, GVPM_ERR_INVALID_ARG, "null photon soa");
+  if (p->n > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many photons");
+  const uint32_t n = (uint32_t)p->n;
+  if (n) {
+    const void *ptrs[] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat,
+                          p->parent_wi, p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g, p->flags, p->path_id};
+    for (const void *q : ptrs)
+      if (!q) return fail(h, GVPM_ERR_INVALID_ARG, "null photon array");
+  }
+  if (fromDevice) {
+    h->rawDev = *p;
+  } else {
+    HIP_TRY(h, h->rawF.ensure((size_t)n * 28 + 4));
+    HIP_TRY(h, h->rawU.ensure((size_t)n * 2 + 4));
+    float *f = h->rawF.p;
+    const float *src3[8] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat, p->parent_wi};
+    const float *src1[4] = {p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g};
+    const float **dst3[8] = {&h->rawDev.pos, &h->rawDev.wi, &h->rawDev.flux, &h->rawDev.parent_pos, &h->rawDev.parent_n,
+                             &h->rawDev.prefix_w, &h->rawDev.parent_scat, &h->rawDev.parent_wi};
+    const float **dst1[4] = {&h->rawDev.parent_pdf, &h->rawDev.edge_pdf, &h->rawDev.parent_rr, &h->rawDev.parent_g};
+    for (int k = 0; k < 8; ++k) {
+      if (n) HIP_TRY(h, hipMemcpyAsync(f, src3[k], (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+      *dst3[k] = f;
+      f += (size_t)n * 3;
+    }
+    for (int k = 0; k < 4; ++k) {
+      if (n) HIP_TRY(h, hipMemcpyAsync(f, src1[k], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+      *dst1[k] = f;
+      f += n;
+    }
+    if (n) {
+      HIP_TRY(h, hipMemcpyAsync(h->rawU.p, p->flags, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->rawU.p + n, p->path_id, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    h->rawDev.flags = h->rawU.p;
+    h->rawDev.path_id = h->rawU.p + n;
+    h->rawDev.n = n;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller may reuse its buffers
+  }
+  h->nph = n;
+  h->havePhotons = true;
+  h->photonsDirty = true;
+  return GVPM_OK;
+}
+
+int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *p) {
+  CHECK_H(h);
+  return uploadPhotonsCommon(h, p, false);
+}
+int gvpm_upload_photons_dev(gvpm_context *h, const gvpm_photon_soa *p) {
+  CHECK_H(h);
+  return uploadPhotonsCommon(h, p, true);
+}
+
+static int uploadBeamsCommon(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t nsets, bool fromDevice) {
+  if (nsets && !rays) return fail(h, GVPM_ERR_INVALID_ARG, "null camera rays");
+  if (nsets > 0x0FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "too many beam sets");
+  if (fromDevice) {
+    h->raysDev = rays;
+  } else {
+    HIP_TRY(h, h->raysOwned.ensure((size_t)nsets * 5 + 1));
+    if (nsets) {
+      HIP_TRY(h, hipMemcpyAsync(h->raysOwned.p, rays, (size_t)nsets * 5 * sizeof(gvpm_camera_ray),
+                                hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->raysDev = h->raysOwned.p;
+  }
+  h->nsets = (uint32_t)nsets;
+  h->haveBeams = true;
+  h->beamsDirty = true;
+  return GVPM_OK;
+}
+
+int gvpm_upload_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t n_sets) {
+  CHECK_H(h);
+  return uploadBeamsCommon(h, rays, n_sets, false);
+}
+int gvpm_upload_camera_beams_dev(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t n_sets) {
+  CHECK_H(h);
+  return uploadBeamsCommon(h, rays, n_sets, true);
+}
+
+static float currentRadius(const gvpm_context *h) {
+  // breInitSize = bsphere.radius * globalScaleVolume * POURCENTAGE_BS, gvpm.cpp:989 (Float = float)
+  return h->cfg.bsphere_radius * h->globalScaleVolume * 0.01f;
+}
+
+static int ilog2ceil(uint32_t v) {
+  int b = 0;
+  while ((1ull << b) < v) ++b;
+  return b;
+}
+
+// uniform grid over the photons for kernel radius r
+static int buildGrid(gvpm_context *h, float r) {
+  const uint32_t n = h->nph;
+  if (n == 0) {
+    h->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
+    HIP_TRY(h, h->cellStart.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->cellStart.p, 0, 2 * sizeof(uint32_t), h->stream));
+    return GVPM_OK;
+  }
+  const int nblocks = 256;
+  HIP_TRY(h, h->boundsPartial.ensure(nblocks * 6));
+  HIP_TRY(h, h->bounds6.ensure(8));
+  launch_bounds(h->rawDev.pos, n, h->boundsPartial.p, nblocks, h->bounds6.p, h->stream);
+  float b6[6];
+  HIP_TRY(h, hipMemcpyAsync(b6, h->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float ext = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
+    ext = fmaxf(ext, b6[3 + c] - b6[c]);
+  }
+  Grid g;
+  float cell = fmaxf(h->cellScale * r, ext / 384.f);
+  if (!(cell > 0.f)) cell = 1.f;
+  g.cell = cell;
+  g.invCell = 1.f / cell;
+  uint64_t nc = 1;
+  for (int c = 0; c < 3; ++c) {
+    g.org[c] = b6[c] - 0.5f * cell;
+    g.dim[c] = (int)floorf((b6[3 + c] - g.org[c]) * g.invCell) + 2;
+    nc *= (uint64_t)g.dim[c];
+  }
+  if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
+  g.ncells = (uint32_t)nc;
+  h->grid = g;
+  HIP_TRY(h, h->keysA.ensure(n));
+  HIP_TRY(h, h->keysB.ensure(n));
+  HIP_TRY(h, h->valsA.ensure(n));
+  HIP_TRY(h, h->valsB.ensure(n));
+  HIP_TRY(h, h->hot.ensure(n));
+  HIP_TRY(h, h->cold.ensure((size_t)n * GVPM_COLD_PLANES));
+  HIP_TRY(h, h->cellStart.ensure((size_t)g.ncells + 2));
+  launch_cell_keys(h->rawDev.pos, n, g, h->keysA.p, h->valsA.p, h->stream);
+  HIP_TRY(h, sortPairsU32(h->sortTmp, h->keysA.p, h->keysB.p, h->valsA.p, h->valsB.p, n,
+                          ilog2ceil(g.ncells + 1), h->stream));
+  launch_reorder(h->rawDev, h->valsB.p, n, h->cfg, h->hot.p, h->cold.p, h->stream);
+  launch_segment_start(h->keysB.p, n, g.ncells, 0, h->cellStart.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
+static int sortBeams(gvpm_context *h) {
+  const uint32_t n = h->nsets;
+  int tw = 8, th = 4;
+  if (h->beamsPerWave == 64) th = 8;
+  if (h->beamsPerWave == 16) tw = 4;
+  const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
+  h->ntiles = tilesX * tilesY;
+  HIP_TRY(h, h->tileStart.ensure((size_t)h->ntiles + 2));
+  HIP_TRY(h, h->bKeysA.ensure(n + 1));
+  HIP_TRY(h, h->bKeysB.ensure(n + 1));
+  HIP_TRY(h, h->bValsA.ensure(n + 1));
+  HIP_TRY(h, h->setPerm.ensure(n + 1));
+  if (n) {
+    launch_beam_keys(h->raysDev, n, h->cfg.width, tw, th, h->bKeysA.p, h->bValsA.p, h->stream);
+    const int tileShift = ilog2ceil(tw * th) + 3;
+    const int bits = ilog2ceil(h->ntiles + 1) + tileShift;
+    HIP_TRY(h, sortPairsU32(h->sortTmp, h->bKeysA.p, h->bKeysB.p, h->bValsA.p, h->setPerm.p, n,
+                            bits > 32 ? 32 : bits, h->stream));
+    launch_segment_start(h->bKeysB.p, n, h->ntiles, tileShift, h->tileStart.p, h->stream);
+  } else {
+    HIP_TRY(h, hipMemsetAsync(h->tileStart.p, 0, ((size_t)h->ntiles + 1) * sizeof(uint32_t), h->stream));
+  }
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
+int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
+  CHECK_H(h);
+  if (it < 1 || nb_paths == 0) return fail(h, GVPM_ERR_INVALID_ARG, "it must be >= 1 and nb_paths > 0");
+  if (!h->haveMedium || !h->havePhotons || !h->haveBeams)
+    return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
+  if (h->cfg.vol_technique != GVPM_VOL_BRE2D && h->cfg.vol_technique != GVPM_VOL_BRE3D)
+    return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
+  const float r = currentRadius(h);
+  if (h->photonsDirty || r != h->builtRadius) {
+    int rc = buildGrid(h, r);
+    if (rc != GVPM_OK) return rc;
+    h->photonsDirty = false;
+    h->builtRadius = r;
+  }
+  if (h->beamsDirty) {
+    int rc = sortBeams(h);
+    if (rc != GVPM_OK) return rc;
+    h->beamsDirty = false;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  h->useAll = false;
+  GatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.hot = h->hot.p;
+  a.cold = h->cold.p;
+  a.cellStart = h->cellStart.p;
+  a.nph = h->nph;
+  a.grid = h->grid;
+  a.rays = h->raysDev;
+  a.setPerm = h->setPerm.p;
+  a.tileStart = h->tileStart.p;
+  a.nsets = h->nsets;
+  a.triV0 = h->triV0.p;
+  a.triE1 = h->triE1.p;
+  a.triE2 = h->triE2.p;
+  a.ntri = h->ntri;
+  for (int c = 0; c < 3; ++c) {
+    a.med.sigmaS[c] = h->medium.sigma_s[c];
+    a.med.sigmaT[c] = h->medium.sigma_t[c];
+  }
+  a.med.g = h->medium.g;
+  a.med.msw = h->medium.medium_sampling_weight;
+  a.cfg = h->cfg;
+  a.radius = r;
+  a.iter = h->iter.p;
+  a.stats = h->stats.p;
+  // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved)
+  if (h->eventsUsed == h->events.size()) {
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    h->events.emplace_back(e0, e1);
+  }
+  auto &ev = h->events[h->eventsUsed++];
+  HIP_TRY(h, hipEventRecord(ev.first, h->stream));
+  launch_gather_bre(a, h->beamsPerWave, h->ntiles, h->stream);
+  HIP_TRY(h, hipEventRecord(ev.second, h->stream));
+  launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
+  {
+    const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
+    double f = ratio;
+    if (h->cfg.vol_technique == GVPM_VOL_BRE3D) f = std::cbrt(ratio);
+    else if (h->cfg.vol_technique == GVPM_VOL_BRE2D) f = std::sqrt(ratio);
+    h->globalScaleVolume = (float)(h->globalScaleVolume * f);
+  }
+  return GVPM_OK;
+}
+
+int gvpm_get_radius(gvpm_context *h, float *radius) {
+  if (!h || !radius) return GVPM_ERR_INVALID_ARG;
+  *radius = currentRadius(h);
+  return GVPM_OK;
+}
+
+int gvpm_set_global_scale(gvpm_context *h, float s) {
+  if (!h || !(s > 0.f)) return GVPM_ERR_INVALID_ARG;
+  h->globalScaleVolume = s;
+  return GVPM_OK;
+}
+
+int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
+  CHECK_H(h);
+  if (!out) return GVPM_ERR_INVALID_ARG;
+  unsigned long long v[8];
+  HIP_TRY(h, hipMemcpyAsync(v, h->stats.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  memset(out, 0, sizeof(*out));
+  out->evaluations = v[0];
+  out->candidates = v[1];
+  out->null_shifts = v[2];
+  out->diffuse_shifts = v[3];
+  out->failed_shifts = v[4];
+  return GVPM_OK;
+}
+
+int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches) {
+  CHECK_H(h);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double total = 0;
+  for (size_t i = 0; i < h->eventsUsed; ++i) {
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+    total += ms;
+  }
+  if (avg_ms) *avg_ms = h->eventsUsed ? (float)(total / h->eventsUsed) : 0.f;
+  if (launches) *launches = (uint32_t)h->eventsUsed;
+  h->eventsUsed = 0;
+  return GVPM_OK;
+}
+
+int gvpm_download_accum(gvpm_context *h, float *accum) {
+  CHECK_H(h);
+  if (!accum) return GVPM_ERR_INVALID_ARG;
+  HIP_TRY(h, hipMemcpyAsync(accum, h->useAll ? h->accumAll.p : h->accum.p, h->npix * 27 * sizeof(float),
+                            hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GVPM_OK;
+}
+
+int gvpm_download_film(gvpm_context *h, int it, int reuse_primal, const float *emission, float *throughput, float *dx,
+                       float *dy) {
+  CHECK_H(h);
+  if (!throughput || !dx || !dy || it < 1) return GVPM_ERR_INVALID_ARG;
+  const size_t n = h->npix * 3;
+  HIP_TRY(h, h->filmOut.ensure(3 * n));
+  const float *em = nullptr;
+  if (emission) {
+    HIP_TRY(h, h->emission.ensure(n));
+    HIP_TRY(h, hipMemcpyAsync(h->emission.p, emission, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    em = h->emission.p;
+  }
+  launch_film(h->useAll ? h->accumAll.p : h->accum.p, em, h->cfg.width, h->cfg.height, it, reuse_primal, h->filmOut.p, h->filmOut.p + n,
+              h->filmOut.p + 2 * n, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(throughput, h->filmOut.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(dx, h->filmOut.p + n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(dy, h->filmOut.p + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GVPM_OK;
+}
+
+int gvpm_synchronize(gvpm_context *h) {
+  CHECK_H(h);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GVPM_OK;
+}
+
+// ---- multi-GPU: RCCL all-reduce of the accumulators over xGMI -----------------------------
+int gvpm_comm_unique_id(void *id128) {
+  if (!id128) return GVPM_ERR_INVALID_ARG;
+  if (!g_rccl.load()) return GVPM_ERR_COMM;
+  ncclUniqueId id;
+  if (g_rccl.getUniqueId(&id) != ncclSuccess) return GVPM_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, 128);
+  return GVPM_OK;
+}
+
+int gvpm_comm_init(gvpm_context *h, const void *id128, int rank, int world) {
+  CHECK_H(h);
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(h, GVPM_ERR_INVALID_ARG, "bad comm arguments");
+  if (!g_rccl.load()) return fail(h, GVPM_ERR_COMM, "librccl.so not loadable");
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  if (g_rccl.commInitRank(&h->comm, world, id, rank) != ncclSuccess) return fail(h, GVPM_ERR_COMM, "ncclCommInitRank failed");
+  return GVPM_OK;
+}
+
+int gvpm_allreduce_accum(gvpm_context *h) {
+  CHECK_H(h);
+  if (!h->comm) return fail(h, GVPM_ERR_STATE, "gvpm_comm_init not called");
+  // out of place: the per-rank running means keep their disjoint supports for later iterations
+  HIP_TRY(h, h->accumAll.ensure(h->npix * 27));
+  if (g_rccl.allReduce(h->accum.p, h->accumAll.p, h->npix * 27, ncclFloat, ncclSum, h->comm, h->stream) != ncclSuccess)
+    return fail(h, GVPM_ERR_COMM, "ncclAllReduce failed");
+  h->useAll = true;
+  return GVPM_OK;
+}
+
+}  // extern "C"

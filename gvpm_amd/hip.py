@@ -1,0 +1,176 @@
+"""ctypes binding of libgvpm_hip.so -- the C ABI of include/gvpm_hip.h.
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is
+visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgvpm_hip.so")
+_LIB = None
+
+# every symbol include/gvpm_hip.h declares
+SYMBOLS = [
+    "gvpm_create", "gvpm_destroy", "gvpm_last_error", "gvpm_abi_version", "gvpm_reset",
+    "gvpm_upload_scene", "gvpm_upload_medium", "gvpm_upload_photons", "gvpm_upload_camera_beams",
+    "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_gather", "gvpm_get_radius",
+    "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_download_accum",
+    "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
+    "gvpm_allreduce_accum",
+]
+
+
+class GvpmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gvpm error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing -- the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gvpm_amd/csrc`). "
+                "There is no CPU fallback for the gather path.")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.gvpm_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(vp)]
+        L.gvpm_destroy.argtypes = [vp]
+        L.gvpm_last_error.argtypes = [vp]
+        L.gvpm_last_error.restype = C.c_char_p
+        L.gvpm_reset.argtypes = [vp]
+        L.gvpm_upload_scene.argtypes = [vp, C.POINTER(abi.Triangles)]
+        L.gvpm_upload_medium.argtypes = [vp, C.POINTER(abi.Medium)]
+        L.gvpm_upload_photons.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
+        L.gvpm_upload_photons_dev.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
+        L.gvpm_upload_camera_beams.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_camera_beams_dev.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_gather.argtypes = [vp, C.c_int, C.c_uint64]
+        L.gvpm_get_radius.argtypes = [vp, C.POINTER(C.c_float)]
+        L.gvpm_set_global_scale.argtypes = [vp, C.c_float]
+        L.gvpm_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+        L.gvpm_get_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.gvpm_download_accum.argtypes = [vp, vp]
+        L.gvpm_download_film.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.gvpm_synchronize.argtypes = [vp]
+        L.gvpm_comm_unique_id.argtypes = [vp]
+        L.gvpm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.gvpm_allreduce_accum.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+class Context:
+    """One gvpm handle (single owner; calls are stream ordered)."""
+
+    def __init__(self, params, device=0):
+        self._h = C.c_void_p()
+        self.params = params.copy()
+        rc = lib().gvpm_create(C.byref(self.params), device, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise GvpmError(rc, "gvpm_create failed")
+        self._keep = []
+
+    def _check(self, rc):
+        if rc != 0:
+            raise GvpmError(rc, lib().gvpm_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().gvpm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._check(lib().gvpm_reset(self._h))
+
+    def upload_scene(self, v0, e1, e2):
+        t, keep = abi.triangles_struct(v0, e1, e2)
+        self._check(lib().gvpm_upload_scene(self._h, C.byref(t)))
+
+    def upload_medium(self, medium):
+        self._check(lib().gvpm_upload_medium(self._h, C.byref(medium)))
+
+    def upload_photons(self, photons):
+        soa = photons.soa()
+        self._check(lib().gvpm_upload_photons(self._h, C.byref(soa)))
+
+    def upload_photons_dev(self, soa):
+        """soa: abi.PhotonSoA whose pointers are device addresses; the caller keeps them alive."""
+        self._check(lib().gvpm_upload_photons_dev(self._h, C.byref(soa)))
+
+    def upload_camera_beams(self, rays):
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype == abi.CAMERA_RAY_DTYPE
+        n = rays.size // 5
+        self._check(lib().gvpm_upload_camera_beams(self._h, rays.ctypes.data if n else None, n))
+
+    def upload_camera_beams_dev(self, dev_ptr, n_sets):
+        self._check(lib().gvpm_upload_camera_beams_dev(self._h, dev_ptr, n_sets))
+
+    def gather(self, it, nb_paths):
+        self._check(lib().gvpm_gather(self._h, it, nb_paths))
+
+    def radius(self):
+        r = C.c_float()
+        self._check(lib().gvpm_get_radius(self._h, C.byref(r)))
+        return r.value
+
+    def set_global_scale(self, s):
+        self._check(lib().gvpm_set_global_scale(self._h, s))
+
+    def stats(self):
+        s = abi.Stats()
+        self._check(lib().gvpm_get_stats(self._h, C.byref(s)))
+        return {k: int(getattr(s, k)) for k in
+                ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts")}
+
+    def kernel_time(self):
+        ms, n = C.c_float(), C.c_uint32()
+        self._check(lib().gvpm_get_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def download_accum(self):
+        out = np.zeros((self.params.height, self.params.width, 27), np.float32)
+        self._check(lib().gvpm_download_accum(self._h, out.ctypes.data))
+        return out
+
+    def download_film(self, it, reuse_primal=True, emission=None):
+        H, W = self.params.height, self.params.width
+        thr, dx, dy = (np.zeros((H, W, 3), np.float32) for _ in range(3))
+        em = None if emission is None else np.ascontiguousarray(emission, np.float32)
+        self._check(lib().gvpm_download_film(self._h, it, 1 if reuse_primal else 0,
+                                             None if em is None else em.ctypes.data,
+                                             thr.ctypes.data, dx.ctypes.data, dy.ctypes.data))
+        return thr, dx, dy
+
+    def synchronize(self):
+        self._check(lib().gvpm_synchronize(self._h))
+
+    def comm_init(self, id128, rank, world):
+        buf = (C.c_char * 128).from_buffer_copy(id128)
+        self._check(lib().gvpm_comm_init(self._h, buf, rank, world))
+
+    def allreduce_accum(self):
+        self._check(lib().gvpm_allreduce_accum(self._h))
+
+
+def comm_unique_id():
+    buf = (C.c_char * 128)()
+    rc = lib().gvpm_comm_unique_id(buf)
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_comm_unique_id failed")
+    return bytes(buf)

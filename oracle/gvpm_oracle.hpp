@@ -806,10 +806,18 @@ template <typename F> struct PhotonMap {
     }
   }
 
-  // Accel-free statement of the same hit set (SURVEY 8c viii): a photon is
-  // visited iff every ancestor AABB passes the slab test; ancestors' boxes are
-  // supersets of the photon's own sphere box and the slab test is monotone
-  // under box inclusion, so the visited set == photons whose own box passes.
+  // Accel-free hit set: a photon is a candidate iff its OWN sphere box passes the slab test
+  // against [ray.mint, ray.maxt].  For every photon whose projection falls inside the beam
+  // (mint < diskDistance <= maxt) this is exactly what the reference BVH visits (the closest
+  // ray point lies in the photon's own box, and every ancestor box contains it).  The two
+  // differ only BEYOND the beam end: the reference tests an inner-node photon whenever the box
+  // of its whole SUBTREE is hit (gvpm_accel.h:279-294), so photons with diskDistance > maxt are
+  // accepted or not depending on where the kd-tree build happened to place them.  The 3D functor
+  // rejects them again (t' > edge length, shift_volume_photon.cpp:719-721; residual measure
+  // ~Epsilon/r); the 2D functor's far check is an empty block (:726-731), so BRE-2D inherits
+  // the tree-dependent extras (the authors' comment there: "Not possible").  The device uses
+  // this accel-independent definition; tests compare bit-exact against it and bound the
+  // difference to the BVH walk.
   template <typename Q> void queryBrute(const Ray<F> &ray, Q &queryRequest, F randValue) const {
     for (uint32_t i = 0; i < photons.size(); ++i) {
       V c = photons[i].pos;
