@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: G-BRE 3D photon gather + gradient-domain shift (BASELINE.json configs[1]).
+
+One "step" = one SPPM iteration of the hot path (device acceleration-structure build + beam
+ordering + gather/shift kernel + normalisation/APA fold) over one batch of synthetic input
+already resident in HBM.  Metric: M photon-gather+shift evaluations / s.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: image-tile sharding, photon map replicated, one film all-reduce (RCCL through
+torch.distributed) at the end of the timed region.  Weak scaling: every rank owns one
+512x512 tile of a (tiles_x*512) x (tiles_y*512) frame of the same scene.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def tile_grid(n):
+    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(n, (n, 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tile", type=int, default=512, help="pixels per side of one rank's tile")
+    ap.add_argument("--photons", type=int, default=1000000)
+    ap.add_argument("--scene", default="cbox")
+    ap.add_argument("--scale", type=float, default=1.0, help="initialScaleVolume")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct pre-generated iterations (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-window", type=int, default=128)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+
+    import torch
+    import torch.distributed as dist
+    from gvpm_amd import abi, hip
+    from gvpm_amd.host import SynthScene
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the gather path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl")
+
+    tx, ty = tile_grid(world)
+    W, H = args.tile * tx, args.tile * ty
+    x0, y0 = (rank % tx) * args.tile, (rank // tx) * args.tile
+    sc = SynthScene(args.scene, W, H)
+    p = sc.params()
+    p.vol_technique = abi.GVPM_VOL_BRE3D
+    p.initial_scale_volume = args.scale
+    m, tris = sc.medium(), sc.triangles()
+    ctx = hip.Context(p, device=local_rank)
+    ctx.upload_scene(*tris)
+    ctx.upload_medium(m)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    K, Wu = args.steps, args.warmup
+    ndist = max(1, min(args.distinct, max(K, Wu)))
+    inputs = []
+    keep = []
+    host0 = None
+    for i in range(ndist):
+        ph, nb = sc.shoot_photons(i + 1, args.photons)
+        rays = sc.camera_beams(i + 1, x0, y0, x0 + args.tile, y0 + args.tile)
+        if i == 0 and rank == 0:
+            host0 = (ph, nb, rays)
+        soa = abi.PhotonSoA()
+        for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
+            a = getattr(ph, k)
+            t = torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+            keep.append(t)
+            setattr(soa, k, t.data_ptr())
+        soa.n = ph.n
+        rt = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+        keep.append(rt)
+        inputs.append((soa, ph.n, nb, rt.data_ptr(), rays.shape[0]))
+    torch.cuda.synchronize()
+
+    def step(it):
+        soa, nph, nb, rptr, nsets = inputs[(it - 1) % ndist]
+        ctx.upload_photons_dev(soa)
+        ctx.upload_camera_beams_dev(rptr, nsets)
+        ctx.gather(it, nb)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(1, Wu + 1):
+        step(it)
+    ctx.synchronize()
+    ctx.reset()
+    ctx.kernel_time()
+    ev0 = ctx.stats()["evaluations"]
+    film = torch.zeros(W * H * 27, dtype=torch.float32, device="cuda") if world > 1 else None
+
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(1, K + 1):
+        step(it)
+    if world > 1:
+        # one film all-reduce before reconstruction (gvpm.cpp:535)
+        ctx.download_accum_dev(film.data_ptr())
+        dist.all_reduce(film)
+    ctx.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    elapsed = t1 - t0
+    st = ctx.stats()
+    evals = st["evaluations"] - ev0
+    kms, klaunches = ctx.kernel_time()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        te = torch.tensor([evals], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.SUM)
+        evals_total = float(te.item())
+    else:
+        evals_total = float(evals)
+
+    if rank == 0:
+        nsets_avg = float(np.mean([x[4] for x in inputs]))
+        nph_avg = float(np.mean([x[1] for x in inputs]))
+        P = args.tile * args.tile
+        # algorithmic bytes per gather-kernel launch (BASELINE.md / SURVEY 8d convention)
+        bytes_alg = 128.0 * (evals / K) + 320.0 * nsets_avg + 108.0 * P + 128.0 * nph_avg
+        achieved = bytes_alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out = {
+            "metric": "photon gather+shift evaluations per second (G-BRE 3D)",
+            "value": evals_total / elapsed / 1e6,
+            "unit": "Mevals/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wu,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: S-{args.scene} + homogeneous medium, G-BRE 3D kernel, "
+                            f"{args.tile}x{args.tile} px per GPU ({W}x{H} frame), {args.photons} photons/iter, "
+                            f"{K} SPPM iters, initialScaleVolume {args.scale}",
+                "technique": "bre3d", "frame": [W, H], "tile_per_gpu": [args.tile, args.tile],
+                "photons_per_iter": args.photons, "iterations": K, "sharding": f"image tiles x{world}",
+                "evaluations": evals_total, "evals_per_iter_per_gpu": evals / K,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": None,
+                "kernel": "gather_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
+                "bytes_alg_per_launch": bytes_alg,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, p, m, tris, host0, args)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, p, m, tris, host0, args):
+    """The oracle (fp32, fast-math, kd-tree -> BVH walk as the reference) timed on this box's
+    host cores on a bounded sample: iteration 1, a centred pixel window, the full photon map."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    ph, nb, rays = host0
+    w = min(args.cpu_window, args.tile)
+    px = rays["pixel"][:, 0] & 0xFFFF
+    py = rays["pixel"][:, 0] >> 16
+    lo = (args.tile - w) // 2
+    sel = (px >= lo) & (px < lo + w) & (py >= lo) & (py < lo + w)
+    sample = np.ascontiguousarray(rays[sel])
+    r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
+    cores = os.cpu_count() or 1
+    _, cnt, secs = O.gather_bre(p, m, tris, ph, sample, r, 1, nb, precision=32, use_accel=True, threads=cores,
+                                fast=True)
+    return {
+        "value": cnt["evaluations"] / secs / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
+        "sample": f"iteration 1, centred {w}x{w} px window ({sample.shape[0]} beam sets), full {ph.n}-photon map, "
+                  f"kd-tree + BVH build included ({secs:.2f} s, {cnt['evaluations']} evaluations)",
+    }
+
+
+if __name__ == "__main__":
+    main()

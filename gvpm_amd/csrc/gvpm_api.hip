@@ -565,6 +565,15 @@ int gvpm_download_accum(gvpm_context *h, float *accum) {
   return GVPM_OK;
 }
 
+int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
+  CHECK_H(h);
+  if (!accum_dev) return GVPM_ERR_INVALID_ARG;
+  HIP_TRY(h, hipMemcpyAsync(accum_dev, h->useAll ? h->accumAll.p : h->accum.p, h->npix * 27 * sizeof(float),
+                            hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GVPM_OK;
+}
+
 int gvpm_download_film(gvpm_context *h, int it, int reuse_primal, const float *emission, float *throughput, float *dx,
                        float *dy) {
   CHECK_H(h);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "gvpm_upload_scene", "gvpm_upload_medium", "gvpm_upload_photons", "gvpm_upload_camera_beams",
     "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_download_accum",
-    "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
+    "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
     "gvpm_allreduce_accum",
 ]
 
@@ -58,6 +58,7 @@ def lib():
         L.gvpm_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
         L.gvpm_get_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gvpm_download_accum.argtypes = [vp, vp]
+        L.gvpm_download_accum_dev.argtypes = [vp, vp]
         L.gvpm_download_film.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.gvpm_synchronize.argtypes = [vp]
         L.gvpm_comm_unique_id.argtypes = [vp]
@@ -147,6 +148,9 @@ class Context:
         out = np.zeros((self.params.height, self.params.width, 27), np.float32)
         self._check(lib().gvpm_download_accum(self._h, out.ctypes.data))
         return out
+
+    def download_accum_dev(self, dev_ptr):
+        self._check(lib().gvpm_download_accum_dev(self._h, dev_ptr))
 
     def download_film(self, it, reuse_primal=True, emission=None):
         H, W = self.params.height, self.params.width

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "philox.h"
 
@@ -417,63 +418,102 @@ static int typeShift(const SynthScene &sc, const std::vector<LVertex> &p, size_t
   return 3;
 }
 
+struct PhotonRec {
+  V3 pos, wi, flux, parentPos, parentN, prefixW, parentScat, parentWi;
+  float parentPdf, edgePdf, parentRR, parentG;
+  uint32_t flags;
+};
+
+// GPhotonMap::tryAppend (gvpm/gvpm_accel.h:119-199) without the capacity / pathID bookkeeping
+static void flattenPath(const SynthScene &sc, const std::vector<LVertex> &path, std::vector<PhotonRec> &recs) {
+  recs.clear();
+  const size_t startIndex = (size_t)std::max(2, sc.minDepth + 1);
+  // generatePath(): reject paths with a zero interior pdf (gvpm_proc.cpp:138-143)
+  for (size_t i = 1; i + 1 < path.size(); ++i)
+    if (path[i].pdf == 0.0) return;
+  if (path.size() <= startIndex) return;
+  V3 w(1.0);
+  for (size_t i = 0; i < startIndex - 1; ++i) w = w * path[i].weight * path[i].rr * path[i].eWeight;
+  for (size_t i = startIndex; i < path.size(); ++i) {
+    V3 prefix = w;
+    w = w * path[i - 1].weight * path[i - 1].rr * path[i - 1].eWeight;
+    if (path[i].type != VT_MEDIUM) continue;
+    if (cameraHit(sc, path[i - 1].pos, path[i].pos)) continue;
+    const LVertex &par = path[i - 1];
+    PhotonRec r;
+    r.pos = path[i].pos;
+    r.wi = normalize(par.pos - path[i].pos);
+    r.flux = w;
+    r.parentPos = par.pos;
+    r.parentN = par.n;
+    r.prefixW = prefix;
+    r.parentScat = V3(0.0);
+    r.parentWi = V3(1.0, 0.0, 0.0);
+    uint32_t ptype = GVPM_PARENT_EMITTER, comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+    if (par.type == VT_SURFACE) {
+      ptype = GVPM_PARENT_SURFACE;
+      r.parentScat = par.albedo;
+      r.parentWi = normalize(path[i - 2].pos - par.pos);
+    } else if (par.type == VT_MEDIUM) {
+      ptype = GVPM_PARENT_MEDIUM;
+      r.parentScat = V3(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
+      r.parentWi = normalize(path[i - 2].pos - par.pos);
+    }
+    r.parentPdf = (float)par.pdf;
+    r.edgePdf = (float)par.ePdf;
+    r.parentRR = (float)par.rr;
+    r.parentG = sc.medium.g;
+    r.flags = GVPM_PF_MAKE(ptype, typeShift(sc, path, i), par.eMedium ? 1 : 0, i - 1, comp);
+    recs.push_back(r);
+  }
+}
+
 uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out) {
   out.clear();
-  std::vector<LVertex> path;
   uint64_t nbPaths = 0;
   uint32_t nbLightPathAdded = 0;
-  const size_t startIndex = (size_t)std::max(2, sc.minDepth + 1);
+  // Paths are keyed by their index, so chunks of them can be generated by worker threads and
+  // appended in index order: the result is identical to the sequential loop
+  // (`deterministic` mode of the reference, gvpm.cpp:399-409).
+  const uint64_t CH = 8192;
+  unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::vector<PhotonRec>> chunk(CH);
   while (out.n < capacity) {
-    Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)nbPaths, (uint32_t)(nbPaths >> 32));
-    randomWalk(sc, rng, path);
-    nbPaths++;
-    // generatePath(): reject paths with a zero interior pdf (gvpm_proc.cpp:138-143);
-    // they still count as shot (pushVolumeLT(nullptr), gvpm_proc.cpp:302-307)
-    bool ok = true;
-    for (size_t i = 1; i + 1 < path.size(); ++i)
-      if (path[i].pdf == 0.0) ok = false;
-    if (!ok || path.size() <= startIndex) continue;
-    // GPhotonMap::tryAppend, gvpm/gvpm_accel.h:119-199
-    V3 w(1.0);
-    for (size_t i = 0; i < startIndex - 1; ++i) w = w * path[i].weight * path[i].rr * path[i].eWeight;
-    int nbAppend = 0;
-    for (size_t i = startIndex; i < path.size(); ++i) {
-      V3 prefix = w;
-      w = w * path[i - 1].weight * path[i - 1].rr * path[i - 1].eWeight;
-      if (path[i].type != VT_MEDIUM) continue;
-      if (out.n >= capacity) continue;
-      if (cameraHit(sc, path[i - 1].pos, path[i].pos)) continue;
-      const LVertex &par = path[i - 1];
-      V3 wiPhoton = normalize(par.pos - path[i].pos);
-      push3(out.pos, path[i].pos);
-      push3(out.wi, wiPhoton);
-      push3(out.flux, w);
-      push3(out.parent_pos, par.pos);
-      push3(out.parent_n, par.n);
-      push3(out.prefix_w, prefix);
-      V3 scat(0.0), pwi(1.0, 0.0, 0.0);
-      uint32_t ptype = GVPM_PARENT_EMITTER, comp = GVPM_BSDF_DIFFUSE_REFLECTION;
-      if (par.type == VT_SURFACE) {
-        ptype = GVPM_PARENT_SURFACE;
-        scat = par.albedo;
-        pwi = normalize(path[i - 2].pos - par.pos);
-      } else if (par.type == VT_MEDIUM) {
-        ptype = GVPM_PARENT_MEDIUM;
-        scat = V3(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
-        pwi = normalize(path[i - 2].pos - par.pos);
+    const uint64_t base = nbPaths;
+    auto worker = [&](unsigned tid) {
+      std::vector<LVertex> path;
+      for (uint64_t k = tid; k < CH; k += nthreads) {
+        const uint64_t idx = base + k;
+        Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32));
+        randomWalk(sc, rng, path);
+        flattenPath(sc, path, chunk[k]);
       }
-      push3(out.parent_scat, scat);
-      push3(out.parent_wi, pwi);
-      out.parent_pdf.push_back((float)par.pdf);
-      out.edge_pdf.push_back((float)par.ePdf);
-      out.parent_rr.push_back((float)par.rr);
-      out.parent_g.push_back(sc.medium.g);
-      out.flags.push_back(GVPM_PF_MAKE(ptype, typeShift(sc, path, i), par.eMedium ? 1 : 0, i - 1, comp));
-      out.path_id.push_back(nbLightPathAdded);
-      out.n++;
-      nbAppend++;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : th) t.join();
+    for (uint64_t k = 0; k < CH && out.n < capacity; ++k) {
+      // paths that store nothing still count as shot (pushVolumeLT(nullptr), gvpm_proc.cpp:302-307)
+      nbPaths++;
+      int nbAppend = 0;
+      for (const PhotonRec &r : chunk[k]) {
+        if (out.n >= capacity) continue;
+        push3(out.pos, r.pos); push3(out.wi, r.wi); push3(out.flux, r.flux);
+        push3(out.parent_pos, r.parentPos); push3(out.parent_n, r.parentN);
+        push3(out.prefix_w, r.prefixW); push3(out.parent_scat, r.parentScat);
+        push3(out.parent_wi, r.parentWi);
+        out.parent_pdf.push_back(r.parentPdf);
+        out.edge_pdf.push_back(r.edgePdf);
+        out.parent_rr.push_back(r.parentRR);
+        out.parent_g.push_back(r.parentG);
+        out.flags.push_back(r.flags);
+        out.path_id.push_back(nbLightPathAdded);
+        out.n++;
+        nbAppend++;
+      }
+      if (nbAppend != 0) nbLightPathAdded++;
     }
-    if (nbAppend != 0) nbLightPathAdded++;
   }
   return nbPaths;
 }

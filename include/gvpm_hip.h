@@ -285,6 +285,8 @@ int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches);
 /* ---- results --------------------------------------------------------------*/
 /* 27 floats per pixel (GVPM_ACCUM_FLOATS), width*height pixels               */
 int gvpm_download_accum(gvpm_context *h, float *accum);
+/* the same into DEVICE memory (e.g. a tensor that torch.distributed all-reduces) */
+int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev);
 /* throughput (gvpm.cpp:480-500 with reusePrimal :503-532 when reuse_primal)
  * and the gradient images of computeGradient (gvpm.cpp:1205-1306), each
  * width*height*3 floats; emission may be NULL (else added as emission/it).   */

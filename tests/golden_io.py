@@ -1,0 +1,31 @@
+"""Load/store the small golden fixtures of tests/golden (inputs + fp64 oracle outputs)."""
+import ctypes as C
+
+import numpy as np
+
+from gvpm_amd import abi
+
+
+class Golden:
+    pass
+
+
+def save(path, p, m, tris, ph, rays, r, it, nb, accum, evaluations):
+    d = {k: getattr(ph, k) for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1}
+    d.update(params=np.frombuffer(bytes(p), np.uint8), medium=np.frombuffer(bytes(m), np.uint8),
+             v0=tris[0], e1=tris[1], e2=tris[2], rays=rays.view(np.uint8), radius=np.float64(r),
+             it=np.int64(it), nb=np.int64(nb), accum=accum.astype(np.float64), evaluations=np.int64(evaluations))
+    np.savez_compressed(path, **d)
+
+
+def load(path):
+    z = np.load(path)
+    g = Golden()
+    g.p = abi.Params.from_buffer_copy(z["params"].tobytes())
+    g.m = abi.Medium.from_buffer_copy(z["medium"].tobytes())
+    g.tris = (z["v0"], z["e1"], z["e2"])
+    g.ph = abi.Photons.load(z)
+    g.rays = z["rays"].view(abi.CAMERA_RAY_DTYPE).reshape(-1, 5)
+    g.r, g.it, g.nb = float(z["radius"]), int(z["it"]), int(z["nb"])
+    g.accum, g.evaluations = z["accum"], int(z["evaluations"])
+    return g

@@ -1,0 +1,268 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the fp64 CPU oracle on the same
+seeded inputs.  Run on the GPU box with `pytest -m gpu`.
+
+Bars (BASELINE.md "Parity bar"):
+  * evaluation count == oracle count exactly (the device evaluates the reference hit
+    predicate in fp64 without contraction);
+  * per-pixel L2 of the 27 accumulators / throughput / dx / dy against the fp64 oracle,
+    normalised by the mean reference luminance, < 1e-3 (measured ~1e-6; asserted < 1e-4).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+from gvpm_amd import abi, hip
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def l2(a, ref, lum):
+    return float(np.sqrt(((a.astype(np.float64) - ref) ** 2).mean()) / lum)
+
+
+def device_gather(c, rays=None, ph=None, p=None, iters=None, beams_per_wave=None):
+    """Returns (accum float32 [H,W,27], stats, film tuple) after running the case on the device."""
+    p = c.p if p is None else p
+    old = os.environ.get("GVPM_BEAMS_PER_WAVE")
+    if beams_per_wave:
+        os.environ["GVPM_BEAMS_PER_WAVE"] = str(beams_per_wave)
+    try:
+        ctx = hip.Context(p, device=0)
+    finally:
+        if beams_per_wave:
+            if old is None:
+                os.environ.pop("GVPM_BEAMS_PER_WAVE")
+            else:
+                os.environ["GVPM_BEAMS_PER_WAVE"] = old
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_photons(c.ph if ph is None else ph)
+    ctx.upload_camera_beams(c.rays if rays is None else rays)
+    assert abs(ctx.radius() - c.r) == 0.0
+    ctx.gather(c.it, c.nb)
+    acc = ctx.download_accum()
+    st = ctx.stats()
+    film = ctx.download_film(c.it, True)
+    ctx.close()
+    return acc, st, film
+
+
+def check(c, p=None, rays=None, ph=None, use_accel=False, **kw):
+    p = c.p if p is None else p
+    acc, st, film = device_gather(c, rays=rays, ph=ph, p=p, **kw)
+    ref, cnt, _ = O.gather_bre(p, c.m, c.tris, c.ph if ph is None else ph, c.rays if rays is None else rays, c.r,
+                               c.it, c.nb, 64, use_accel=use_accel)
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert st["evaluations"] == cnt["evaluations"]
+    for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert st[k] == cnt[k], (k, st, cnt)
+    err = l2(acc, ref, lum)
+    assert err < TOL, err
+    rthr, rdx, rdy = O.assemble(ref, c.it, True)
+    for a, b in zip(film, (rthr, rdx, rdy)):
+        assert l2(a, b, lum) < TOL
+    return acc, ref, st
+
+
+@pytest.fixture(scope="module")
+def case():
+    return cases.make_case("cbox", 40, 36, 30000, 2.5)
+
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg"])
+@pytest.mark.parametrize("bpw", [16, 32, 64])
+def test_bre3d_matches_fp64_oracle(scene, bpw):
+    c = cases.make_case(scene, 40, 36, 30000, 2.5)
+    acc, ref, st = check(c, beams_per_wave=bpw)
+    assert st["evaluations"] > 10000
+
+
+def test_bre3d_matches_reference_bvh_walk(case):
+    """Against the literal kd-tree -> BVH traversal of the reference (3D: same hit set)."""
+    check(case, use_accel=True)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(use_mis=0), dict(power_heuristic=1), dict(path_set=0), dict(use_shift_null=0),
+    dict(visibility_as_written=0), dict(debug_shift=abi.GVPM_SHIFT_DIFFUSE), dict(debug_shift=abi.GVPM_SHIFT_NULL),
+    dict(debug_shift=abi.GVPM_SHIFT_MANIFOLD), dict(max_depth=3), dict(min_depth=3), dict(max_depth=0),
+    dict(lighting_interaction_mode=abi.GVPM_SURF2MEDIA), dict(lighting_interaction_mode=abi.GVPM_MEDIA2MEDIA),
+    dict(bsdf_interaction_mode=0x00008),
+])
+def test_flag_sweep(case, kw):
+    p = case.p.copy()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    check(case, p=p)
+
+
+def test_bre2d_matches_own_box_oracle():
+    c = cases.make_case("cbox", 40, 36, 30000, 2.5, vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0)
+    check(c, use_accel=False)
+    # the reference BVH adds tree-dependent photons beyond the beam end (oracle header): bounded
+    acc, st, _ = device_gather(c)
+    ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, 1, c.nb, 64, use_accel=True)
+    assert 0 <= cnt["evaluations"] - st["evaluations"] <= 0.01 * st["evaluations"]
+
+
+@pytest.mark.parametrize("name", ["cbox_bre3d", "cbox_hg_bre3d", "cbox_bre2d"])
+def test_golden_fixtures(name):
+    import golden_io
+    g = golden_io.load(os.path.join(GOLD, name + ".npz"))
+    g.sc = None
+    acc, st, _ = device_gather(g)
+    assert st["evaluations"] == g.evaluations
+    assert l2(acc, g.accum, g.accum[..., 0:3].mean()) < TOL
+
+
+def test_three_iterations_apa_and_radius_schedule():
+    c = cases.make_case("cbox", 32, 32, 20000, 3.0)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ref = None
+    scale = c.p.initial_scale_volume
+    total = 0
+    for it in (1, 2, 3):
+        ph, nb = c.sc.shoot_photons(it, 20000)
+        rays = c.sc.camera_beams(it)
+        r = ctx.radius()
+        assert r == cases.radius_of(c.p, np.float32(scale))
+        ctx.upload_photons(ph)
+        ctx.upload_camera_beams(rays)
+        ctx.gather(it, nb)
+        ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, ph, rays, r, it, nb, 64, use_accel=False, accum=ref)
+        total += cnt["evaluations"]
+        scale = np.float32(O.scale_volume_apa(float(scale), it, float(c.p.alpha), c.p.vol_technique))
+    acc = ctx.download_accum()
+    assert ctx.stats()["evaluations"] == total
+    assert l2(acc, ref, ref[..., 0:3].mean()) < TOL
+    ctx.reset()
+    assert ctx.radius() == c.r and not ctx.download_accum().any()
+    ctx.close()
+
+
+def test_empty_and_ragged_inputs(case):
+    c = case
+    none = c.ph.subset(np.zeros(0, np.int64))
+    acc, st, _ = device_gather(c, ph=none)
+    assert st["evaluations"] == 0 and not acc.any()
+    acc, st, _ = device_gather(c, rays=c.rays[:0])
+    assert st["evaluations"] == 0 and not acc.any()
+    # ragged: a handful of sets in random order, one pixel addressed by three sets, invalid shifted rays
+    rng = np.random.default_rng(7)
+    sel = rng.permutation(c.rays.shape[0])[:37]
+    rays = c.rays[sel].copy()
+    rays = np.concatenate([rays, rays[:1], rays[:1]])
+    rays[3, 2]["info"] = abi.ray_info(0, 2)
+    rays[5, 1:]["info"] = abi.ray_info(0, 2)
+    check(c, rays=rays)
+    # a single photon / a single beam
+    check(c, ph=c.ph.subset(np.arange(1)))
+    check(c, rays=c.rays[100:101])
+
+
+def test_identical_shifted_beams_zero_gradient_on_device(case):
+    c = case
+    rays = cases.rays_shift_equals_base(c.rays)
+    acc, ref, st = check(c, rays=rays)
+    H, W = acc.shape[:2]
+    flux, wt = acc[..., 0:3], acc[..., 15:27].reshape(H, W, 4, 3)
+    assert np.allclose(wt[:-1, :-1], 0.5 * flux[:-1, :-1, None, :], rtol=1e-5, atol=1e-9)
+
+
+def test_dev_upload_equals_host_upload(case):
+    torch = pytest.importorskip("torch")
+    c = case
+    acc_host, st_host, _ = device_gather(c)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    keep, soa = [], abi.PhotonSoA()
+    for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
+        a = getattr(c.ph, k)
+        t = torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+        keep.append(t)
+        setattr(soa, k, t.data_ptr())
+    soa.n = c.ph.n
+    rt = torch.from_numpy(c.rays.view(np.uint8).reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    ctx.upload_photons_dev(soa)
+    ctx.upload_camera_beams_dev(rt.data_ptr(), c.rays.shape[0])
+    ctx.gather(1, c.nb)
+    acc = ctx.download_accum()
+    assert ctx.stats()["evaluations"] == st_host["evaluations"]
+    assert np.allclose(acc, acc_host, rtol=1e-5, atol=1e-9)
+    out = torch.zeros(acc.size, dtype=torch.float32, device="cuda")
+    ctx.download_accum_dev(out.data_ptr())
+    assert np.array_equal(out.cpu().numpy().reshape(acc.shape), acc)
+    ctx.close()
+
+
+def test_error_behaviour(case):
+    c = case
+    ctx = hip.Context(c.p, device=0)
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.gather(1, 10)
+    assert e.value.code == abi.GVPM_ERR_STATE
+    ctx.upload_medium(c.m)
+    bad = c.sc.medium()
+    bad.sigma_t[0] = 2.0
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.upload_medium(bad)
+    assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
+    ctx.upload_scene(*c.tris)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    with pytest.raises(hip.GvpmError):
+        ctx.gather(0, 10)
+    ctx.close()
+    p = c.p.copy()
+    p.vol_technique = abi.GVPM_VOL_PLANE0D
+    p.use_shift_null = 0
+    ctx = hip.Context(p, device=0)
+    ctx.upload_medium(c.m)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.gather(1, 10)
+    assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
+    ctx.close()
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] size (512x512, 1M photons): size-independent properties + a windowed
+    oracle comparison of the same frame."""
+    c = cases.make_case("cbox", 512, 512, 1000000, 1.0)
+    acc, st, _ = device_gather(c)
+    assert st["evaluations"] > 10_000_000
+    # (1) a 48x48 window of the same frame against the fp64 oracle (full photon map)
+    px, py = cases.pixels_of(c.rays)
+    sel = (px >= 232) & (px < 280) & (py >= 232) & (py < 280)
+    ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, np.ascontiguousarray(c.rays[sel]), c.r, 1, c.nb, 64,
+                               use_accel=True)
+    win, rwin = acc[232:280, 232:280], ref[232:280, 232:280]
+    assert l2(win, rwin, rwin[..., 0:3].mean()) < TOL
+    # (2) run-to-run reproducibility
+    acc2, st2, _ = device_gather(c)
+    assert st2["evaluations"] == st["evaluations"]
+    assert np.allclose(acc2, acc, rtol=2e-5, atol=1e-9)
+    # (3) linearity in the photon flux
+    ph2 = c.ph.subset(np.arange(c.ph.n))
+    ph2.flux = ph2.flux * 2
+    ph2.prefix_w = ph2.prefix_w * 2
+    acc3, st3, _ = device_gather(c, ph=ph2)
+    assert st3["evaluations"] == st["evaluations"]
+    assert np.allclose(acc3, 2 * acc, rtol=2e-5, atol=1e-9)
+    # (4) weights in [0,1]: 0 <= weighted <= flux
+    H, W = acc.shape[:2]
+    flux, wt = acc[..., 0:3], acc[..., 15:27].reshape(H, W, 4, 3)
+    assert (wt >= 0).all() and (wt <= flux[:, :, None, :] * (1 + 1e-4) + 1e-12).all()
+    # (5) border rule
+    assert np.allclose(wt[H - 1, :, abi.GVPM_TOP], flux[H - 1], rtol=1e-4, atol=1e-12)
