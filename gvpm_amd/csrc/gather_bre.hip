@@ -11,16 +11,20 @@
 //   HomogeneousMedium::eval, phase eval             src/medium/homogeneous.cpp:432-513, src/phase/*.cpp
 //
 // Execution model (one 64-lane wave per workgroup, no MFMA: gather / divergent math):
-//   * a wave owns a TILE of B camera-beam sets (B = 16/32/64, 64/B lanes per beam) that the
-//     host-side ordering made spatially coherent (8x8 / 8x4 / 4x4 pixel tiles);
+//   * a TILE is a bundle of B camera-beam sets (B = 16/32/64, 64/B lanes per beam) that the
+//     tile sort made spatially coherent (8x8 / 8x4 / 4x4 pixel tiles);
 //   * the photon map is a uniform grid (all photons share one radius, gvpm.cpp:989) sorted by
-//     cell with x fastest; the wave walks the grid in thick slabs along the tile's major axis,
-//     wave-reduces the fattened footprint of its beams into a cell box, turns the box into
-//     x-contiguous photon ranges and copies those 16-byte hot records coalesced into an LDS
-//     stage (photons staged into LDS tiles);
-//   * every lane tests the staged photons against its own beam (LDS broadcast reads): fp32
-//     conservative pre-test, then the reference predicate in fp64 without contraction, so the
-//     hit set equals the fp64 oracle's bit for bit;
+//     cell with x fastest; a tile walks the grid in thick slabs along its major axis,
+//     wave-reduces the fattened footprint of its beams into a cell box and turns the box into
+//     x-contiguous photon ranges;
+//   * plan_kernel walks every tile once WITHOUT touching photons (cellStart differences only) and
+//     cuts it into work items of roughly equal candidate count -- the load balancer that replaces
+//     BlockScheduler's dynamic image blocks (photonmapper/utilities/block_sched.h:87-113);
+//   * gather_bre_kernel is persistent: waves pull items from an atomic queue; for each slab
+//     step the 16-byte hot photon records of the ranges are copied coalesced into an LDS stage
+//     (photons staged into LDS tiles) and every lane tests them against its own beam (LDS
+//     broadcast reads): fp32 conservative pre-test, then the reference predicate in fp64
+//     without contraction, so the hit set equals the fp64 oracle's bit for bit;
 //   * hits are compacted with __ballot / popcount prefix sums into an LDS ring of
 //     (photon, beam) pairs; whenever 64 are pending every lane evaluates one of them: base
 //     contribution + 4 shifts (null shift, or offset-path reconnection with shadow ray,
@@ -35,9 +39,11 @@ namespace gvpm {
 #define INV_PI_F 0.31830988618379067154f
 #define INV_FOURPI_F 0.07957747154594766788f
 
-constexpr int RAYF = 14;  // o3 d3 len pdf eye3 jac gop valid
+constexpr int RAYF = 13;  // o3 d3 len(<0: invalid) pdf eye3 jac gop
 constexpr int STAGE = 256;
 constexpr int QCAP = 128;
+constexpr int MAXTRI_LDS = 32;
+constexpr int PLAN_MAX_ITEMS = 64;  // per tile chunk
 
 template <int B> struct TileLds {
   float ray[5][RAYF][B];
@@ -45,6 +51,7 @@ template <int B> struct TileLds {
   float4 stage[STAGE];
   uint32_t stageIdx[STAGE];
   uint2 queue[QCAP];
+  float4 tri[MAXTRI_LDS][3];  // {v0,n.x} {e1,n.y} {e2,n.z}
   float rnd[B];
   uint32_t pix[B];
   uint32_t edge[B];
@@ -60,12 +67,13 @@ template <int B> __device__ __forceinline__ RayReg loadRay(const TileLds<B> &s, 
   RayReg r;
   r.o = mk3(s.ray[k][0][b], s.ray[k][1][b], s.ray[k][2][b]);
   r.d = mk3(s.ray[k][3][b], s.ray[k][4][b], s.ray[k][5][b]);
-  r.len = s.ray[k][6][b];
+  const float l = s.ray[k][6][b];
+  r.len = fabsf(l);
+  r.valid = l >= 0.f;
   r.pdf = s.ray[k][7][b];
   r.eye = mk3(s.ray[k][8][b], s.ray[k][9][b], s.ray[k][10][b]);
   r.jac = s.ray[k][11][b];
   r.gop = s.ray[k][12][b];
-  r.valid = s.ray[k][13][b] != 0.f;
   return r;
 }
 
@@ -74,40 +82,42 @@ struct HitGeom {
   double disk, distSqr;
 };
 
-__device__ __forceinline__ bool exactHit(f3 pf, f3 of, f3 df, double mint, double maxt, double radius, HitGeom &g) {
+// diskDistance / distSqr of gvpm_accel.h:296-299 in the reference's operation order
+__device__ __forceinline__ HitGeom hitGeom(f3 pf, f3 of, f3 df) {
 #pragma clang fp contract(off)
   const double px = pf.x, py = pf.y, pz = pf.z;
   const double ox = of.x, oy = of.y, oz = of.z;
   const double dx = df.x, dy = df.y, dz = df.z;
-  // own sphere box vs ray segment (what every ancestor AABB of the reference BVH implies)
-  double nearT = -INFINITY, farT = INFINITY;
-  {
-    const double o3[3] = {ox, oy, oz}, dd[3] = {dx, dy, dz}, c3[3] = {px, py, pz};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double minVal = c3[i] - radius, maxVal = c3[i] + radius;
-      if (dd[i] == 0.0) {
-        if (o3[i] < minVal || o3[i] > maxVal) return false;
-      } else {
-        const double rcp = 1.0 / dd[i];
-        double t1 = (minVal - o3[i]) * rcp;
-        double t2 = (maxVal - o3[i]) * rcp;
-        if (t1 > t2) { double t = t1; t1 = t2; t2 = t; }
-        nearT = fmax(t1, nearT);
-        farT = fmin(t2, farT);
-        if (!(nearT <= farT)) return false;
-      }
-    }
-    if (farT < mint || nearT > maxt) return false;
-  }
   const double cx = px - ox, cy = py - oy, cz = pz - oz;
-  const double disk = cx * dx + cy * dy + cz * dz;
-  const double qx = ox + dx * disk, qy = oy + dy * disk, qz = oz + dz * disk;
+  HitGeom g;
+  g.disk = cx * dx + cy * dy + cz * dz;
+  const double qx = ox + dx * g.disk, qy = oy + dy * g.disk, qz = oz + dz * g.disk;
   const double vx = qx - px, vy = qy - py, vz = qz - pz;
-  const double distSqr = vx * vx + vy * vy + vz * vz;
-  g.disk = disk;
-  g.distSqr = distSqr;
-  return disk > mint && distSqr < radius * radius;
+  g.distSqr = vx * vx + vy * vy + vz * vz;
+  return g;
+}
+
+// own sphere box vs ray segment: what every ancestor AABB of the reference BVH implies
+__device__ __forceinline__ bool ownBoxHit(f3 pf, f3 of, f3 df, d3 rcp, double mint, double maxt, double radius) {
+#pragma clang fp contract(off)
+  double nearT = -INFINITY, farT = INFINITY;
+  const double o3[3] = {of.x, of.y, of.z}, dd[3] = {df.x, df.y, df.z}, c3[3] = {pf.x, pf.y, pf.z};
+  const double r3[3] = {rcp.x, rcp.y, rcp.z};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double minVal = c3[i] - radius, maxVal = c3[i] + radius;
+    if (dd[i] == 0.0) {
+      if (o3[i] < minVal || o3[i] > maxVal) return false;
+    } else {
+      double t1 = (minVal - o3[i]) * r3[i];
+      double t2 = (maxVal - o3[i]) * r3[i];
+      if (t1 > t2) { double t = t1; t1 = t2; t2 = t; }
+      nearT = fmax(t1, nearT);
+      farT = fmin(t2, farT);
+      if (!(nearT <= farT)) return false;
+    }
+  }
+  return !(farT < mint || nearT > maxt);
 }
 
 // 3D-kernel resample of the camera distance, shift_volume_photon.cpp:707-726
@@ -126,36 +136,55 @@ __device__ __forceinline__ float phaseEval(float g, f3 wi, f3 wo) {
   return INV_FOURPI_F * (1.f - g * g) / (temp * sqrtf(temp));
 }
 
-// HomogeneousMedium::eval over a distance (balance strategy, uniform or per-channel sigma_t)
+// HomogeneousMedium::eval over a distance (balance strategy)
 __device__ __forceinline__ void mediumEval(const MediumDev &m, float dist, f3 &tr, float &pdfSuccess) {
-  tr.x = expf(-m.sigmaT[0] * dist);
-  tr.y = expf(-m.sigmaT[1] * dist);
-  tr.z = expf(-m.sigmaT[2] * dist);
+  tr.x = __expf(-m.sigmaT[0] * dist);
+  tr.y = __expf(-m.sigmaT[1] * dist);
+  tr.z = __expf(-m.sigmaT[2] * dist);
   pdfSuccess = (m.sigmaT[0] * tr.x + m.sigmaT[1] * tr.y + m.sigmaT[2] * tr.z) * (1.f / 3.f) * m.msw;
   if (maxc(tr) < 1e-20f) tr = mk3(0.f);
 }
 
-// scene->rayIntersect(ray): Moeller-Trumbore any-hit, triangle.h:109-145 + skdtree.h:318-320.
-// The triangle index is wave-uniform, so the triangle data comes through scalar loads.
-__device__ __forceinline__ bool anyHit(const GatherArgs &a, f3 o, f3 d, float mint, float maxt) {
+// Moeller-Trumbore, triangle.h:109-145 + interval test skdtree.h:318-320
+__device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt) {
+  const f3 pvec = cross(d, e2);
+  const float det = dot(e1, pvec);
+  if (det == 0.f) return false;
+  const float inv = 1.0f / det;
+  const f3 tvec = o - v0;
+  const float u = dot(tvec, pvec) * inv;
+  if (u < 0.f || u > 1.f) return false;
+  const f3 qvec = cross(tvec, e1);
+  const float v = dot(d, qvec) * inv;
+  if (v >= 0.f && u + v <= 1.f) {
+    const float t = dot(e2, qvec) * inv;
+    return t >= mint && t <= maxt;
+  }
+  return false;
+}
+
+// scene->rayIntersect(ray), any-hit over the occluder list.  Triangles sit in LDS (broadcast
+// reads); a plane-distance early-out skips triangles the segment [mint,maxt] cannot reach.
+template <int B>
+__device__ __forceinline__ bool anyHit(const GatherArgs &a, const TileLds<B> &s, f3 o, f3 d, float mint, float maxt) {
   bool hit = false;
-  for (uint32_t i = 0; i < a.ntri; ++i) {
+  const uint32_t nl = min(a.ntri, (uint32_t)MAXTRI_LDS);
+  for (uint32_t i = 0; i < nl; ++i) {
+    const float4 t0 = s.tri[i][0], t1 = s.tri[i][1], t2 = s.tri[i][2];
+    const f3 v0 = mk3(t0.x, t0.y, t0.z), n = mk3(t0.w, t1.w, t2.w);
+    const float dist0 = dot(n, o - v0);
+    const float dn = dot(n, d);
+    // signed plane distances at both segment ends; no sign change (with margin) => no hit
+    const float da = dist0 + mint * dn, db = dist0 + maxt * dn;
+    const float margin = 1e-4f * (fabsf(dist0) + maxt) + 1e-7f;
+    if ((da > margin && db > margin) || (da < -margin && db < -margin)) continue;
+    if (triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+  }
+  for (uint32_t i = nl; i < a.ntri; ++i) {
     const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
     const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
     const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
-    const f3 pvec = cross(d, e2);
-    const float det = dot(e1, pvec);
-    if (det == 0.f) continue;
-    const float inv = 1.0f / det;
-    const f3 tvec = o - v0;
-    const float u = dot(tvec, pvec) * inv;
-    if (u < 0.f || u > 1.f) continue;
-    const f3 qvec = cross(tvec, e1);
-    const float v = dot(d, qvec) * inv;
-    if (v >= 0.f && u + v <= 1.f) {
-      const float t = dot(e2, qvec) * inv;
-      if (t >= mint && t <= maxt) hit = true;
-    }
+    if (triHit(v0, e1, e2, o, d, mint, maxt)) hit = true;
   }
   return hit;
 }
@@ -196,9 +225,11 @@ __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx
 }
 
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.
-__device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonCold &ph, uint32_t bits, d3 offsetPos,
-                                              const RayReg &sh, const RayReg &base, uint32_t edge, f3 trShift,
-                                              float pdfBaseRay, float pdfShiftRay, f3 &shiftedFlux, bool &ok) {
+template <int B>
+__device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const TileLds<B> &s, const PhotonCold &ph,
+                                              uint32_t bits, d3 offsetPos, const RayReg &sh, const RayReg &base,
+                                              uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
+                                              f3 &shiftedFlux, bool &ok) {
   ok = false;
   shiftedFlux = mk3(0.f);
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
@@ -208,7 +239,7 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const float lProj = (float)lProjD;
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
-  if (anyHit(a, ph.parentPos, dProj, eps, vmax)) return 1.f;
+  if (anyHit<B>(a, s, ph.parentPos, dProj, eps, vmax)) return 1.f;
   if (ptype != GVPM_PARENT_MEDIUM) {
     const float signDot = dot(ph.parentN, dProj) / dot(ph.parentN, -ph.wi);
     if (signDot < 0.f) return 1.f;
@@ -286,11 +317,9 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const double radius = (double)a.radius;
   const double mint = (double)a.cfg.epsilon;
-  const float eps = a.cfg.epsilon;
 
   // geometry of the hit, recomputed exactly as in the test phase
-  HitGeom g;
-  exactHit(pos, base.o, base.d, mint, (double)base.len - mint, radius, g);
+  const HitGeom g = hitGeom(pos, base.o, base.d);
   double tPrime = g.disk, deltaT = 0.0;
   double kernelVolD = 3.14159265358979323846 * radius * radius;
   float pdfCam = 1.f;
@@ -303,17 +332,20 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
   const float scale = rr / ((float)kernelVolD * pdfCam);
 
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
-  // base contribution, shift_volume_photon.cpp:735-751
-  f3 trBase;
+  // base contribution, shift_volume_photon.cpp:735-751; the base and the four shifted rays
+  // all carry mint = Epsilon and maxt = t' (:769-770), hence one transmittance
+  f3 trT;
   float dummy;
-  mediumEval(a.med, (float)(tPrime - mint), trBase, dummy);
-  const f3 baseContrib = trBase * (sigS * ph.flux * phaseEval(a.med.g, ph.wi, -base.d)) * base.eye;
+  mediumEval(a.med, (float)(tPrime - mint), trT, dummy);
+  const f3 photonIn = sigS * ph.flux;
+  const f3 baseContrib = trT * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * base.eye;
   atomicAdd(&s.acc[0][b], baseContrib.x * scale);
   atomicAdd(&s.acc[1][b], baseContrib.y * scale);
   atomicAdd(&s.acc[2][b], baseContrib.z * scale);
 
   const d3 pD = tod(pos);
   const d3 basePt = tod(base.o) + tod(base.d) * tPrime;  // baseRay(t')
+  const d3 rel = pD - basePt;
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
     const RayReg sh = loadRay(s, 1 + i, b);
@@ -323,9 +355,6 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
       const d3 shO = tod(sh.o), shD = tod(sh.d);
       const d3 zP = shO + shD * tPrime;  // shiftRay(t')
       bool alreadyShift = false;
-      // transmittance along the shifted ray: Ray(o, d, Epsilon, t')
-      f3 trShift;
-      mediumEval(a.med, (float)(tPrime - mint), trShift, dummy);
       if (a.cfg.use_shift_null) {
         const double ZPtoY = len2(zP - pD);
         if (ZPtoY < radius * radius && tPrime < (double)sh.len) {
@@ -334,7 +363,7 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
           const double distSqrS = len2((shO + shD * diskS) - pD);
           const double deltaS = sqrt(fmax(0.0, radius * radius - distSqrS));
           const float pdfShiftPos = (float)(1.0 / fmax(2.0 * deltaS, 0.0001));
-          sflux = trShift * (sigS * ph.flux * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
+          sflux = trT * (photonIn * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
           w = 0.5f;
           if (a.cfg.use_mis) {
             if (pdfShiftPos == 0.f || pdfCam == 0.f) w = 1.f;
@@ -346,13 +375,12 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
       }
       if (!alreadyShift && (double)sh.len >= tPrime) {
         // getShiftPos, shift_volume_photon.cpp:858-896
-        d3 offsetPos = zP + (pD - basePt);
+        d3 offsetPos = zP + rel;
         if (!use3D) {
           d3 bn = tod(base.d), bs, bt, nn = shD, ns, nt;
           coherentFrame(bn, bs, bt);
           coherentFrame(nn, ns, nt);
-          const d3 v = pD - basePt;
-          const double lx = dot(v, bs), ly = dot(v, bt), lz = dot(v, bn);
+          const double lx = dot(rel, bs), ly = dot(rel, bt), lz = dot(rel, bn);
           offsetPos = zP + (ns * lx + nt * ly + nn * lz);
         }
         if (a.cfg.use_shift_null) {
@@ -376,7 +404,7 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
           const uint32_t st = GVPM_PF_SHIFT_TYPE(bits);
           bool ok = false;
           if (st == 1u || st == 2u) {
-            w = shiftDiffuse(a, ph, bits, offsetPos, sh, base, edge, trShift, pdfCam, pdfShiftPos, sflux, ok);
+            w = shiftDiffuse<B>(a, s, ph, bits, offsetPos, sh, base, edge, trT, pdfCam, pdfShiftPos, sflux, ok);
           }
           if (ok) nDiff++; else nFail++;
         }
@@ -396,22 +424,24 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
   }
 }
 
-template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherArgs a, uint32_t ntiles) {
-  constexpr int LPB = 64 / B;
-  __shared__ TileLds<B> s;
-  const int lane = threadIdx.x;
-  // XCD-aware tile order: consecutive (spatially adjacent) tiles share an XCD's L2
-  const uint32_t perXcd = (ntiles + 7u) / 8u;
-  const uint32_t tile = (blockIdx.x % 8u) * perXcd + blockIdx.x / 8u;
-  if (tile >= ntiles) return;
-  // a tile = all beam sets whose base pixel lies in one image tile (usually <= B of them)
-  const uint32_t tileBeg = a.tileStart[tile], tileEnd = a.tileStart[tile + 1];
-  uint32_t nEval = 0, nCand = 0, nNull = 0, nDiff = 0, nFail = 0, nbTotal = 0;
-  for (uint32_t setBase = tileBeg; setBase < tileEnd; setBase += B) {
-  const uint32_t nb = min((uint32_t)B, tileEnd - setBase);
-  nbTotal += nb;
+// ------------------------------------------------------------------------------------------
+// Tile traversal state shared by the planner and the gather kernel
+// ------------------------------------------------------------------------------------------
+struct TileWalk {
+  // per lane
+  RayReg base;
+  bool beamValid;
+  float oA, dA, oU, dU, oV, dV, t0, t1;
+  // wave-uniform
+  int A, cA0, cA1, K;
+  float orgA, orgU, orgV, pad;
+  int dimU, dimV;
+  bool any;
+};
 
-  // ---- load the tile's 5*B rays into LDS (coalesced 16-byte loads) ----
+template <int B>
+__device__ __forceinline__ void loadTileRays(const GatherArgs &a, TileLds<B> &s, uint32_t setBase, uint32_t nb,
+                                             int lane) {
   for (int idx = lane; idx < B * 20; idx += 64) {
     const int b = idx / 20, k = (idx % 20) / 4, q = idx % 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -425,7 +455,6 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
     else {
       s.ray[k][12][b] = v.x;
       const uint32_t info = __float_as_uint(v.y);
-      s.ray[k][13][b] = ((uint32_t)b < nb && GVPM_RAY_VALID(info)) ? 1.f : 0.f;
       if (k == 0) {
         s.rnd[b] = v.z;
         s.pix[b] = __float_as_uint(v.w);
@@ -433,110 +462,258 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
       }
     }
   }
-  for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
   __syncthreads();
+  // fold the valid bit into the sign of len (written by the q == 0 lanes above)
+  for (int idx = lane; idx < B * 5; idx += 64) {
+    const int b = idx / 5, k = idx % 5;
+    bool valid = false;
+    if ((uint32_t)b < nb) {
+      const uint32_t set = a.setPerm[setBase + b];
+      valid = GVPM_RAY_VALID(a.rays[(size_t)set * 5 + k].info) != 0;
+    }
+    const float l = fabsf(s.ray[k][6][b]);
+    s.ray[k][6][b] = valid ? l : -fmaxf(l, 1e-30f);
+  }
+  __syncthreads();
+}
 
-  const int b = lane % B, sub = lane / B;
-  const bool beamValid = (uint32_t)b < nb && s.ray[0][13][b] != 0.f;
-  const RayReg base = loadRay(s, 0, b);
-  const float r = a.radius;
-  const float eps = a.cfg.epsilon;
-  const float mint = eps, maxt = base.len - eps;
-  const double mintD = (double)eps, maxtD = (double)base.len - (double)eps;
-  const float rnd = s.rnd[b];
-  const uint32_t edge = s.edge[b];
-  const uint32_t pixv = s.pix[b];
-  const uint32_t pixParity = ((pixv & 0xFFFFu) + (pixv >> 16)) & 1u;
-  const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
-
-  // ---- choose the slab axis by majority vote over the tile's beams ----
+template <int B>
+__device__ __forceinline__ void tileSetup(const GatherArgs &a, const TileLds<B> &s, uint32_t nb, int lane,
+                                          TileWalk &w) {
+  const int b = lane % B;
+  w.base = loadRay(s, 0, b);
+  w.beamValid = (uint32_t)b < nb && w.base.valid;
+  const float r = a.radius, eps = a.cfg.epsilon;
+  const float mint = eps, maxt = w.base.len - eps;
   int A;
   {
-    const float ax = fabsf(base.d.x), ay = fabsf(base.d.y), az = fabsf(base.d.z);
+    const float ax = fabsf(w.base.d.x), ay = fabsf(w.base.d.y), az = fabsf(w.base.d.z);
     const int my = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-    const int n0 = __popcll(__ballot(beamValid && my == 0));
-    const int n1 = __popcll(__ballot(beamValid && my == 1));
-    const int n2 = __popcll(__ballot(beamValid && my == 2));
+    const int n0 = __popcll(__ballot(w.beamValid && my == 0));
+    const int n1 = __popcll(__ballot(w.beamValid && my == 1));
+    const int n2 = __popcll(__ballot(w.beamValid && my == 2));
     A = (n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2);
   }
+  w.A = A;
   const int U = (A + 1) % 3, V = (A + 2) % 3;
-  const float oA = comp(base.o, A), dA = comp(base.d, A);
-  const float oU = comp(base.o, U), dU = comp(base.d, U);
-  const float oV = comp(base.o, V), dV = comp(base.d, V);
-  const Grid gr = a.grid;
-  const float orgA = comp(mk3(gr.org[0], gr.org[1], gr.org[2]), A);
-  const float orgU = comp(mk3(gr.org[0], gr.org[1], gr.org[2]), U);
-  const float orgV = comp(mk3(gr.org[0], gr.org[1], gr.org[2]), V);
-  const int dimA = A == 0 ? gr.dim[0] : (A == 1 ? gr.dim[1] : gr.dim[2]);
-  const int dimU = U == 0 ? gr.dim[0] : (U == 1 ? gr.dim[1] : gr.dim[2]);
-  const int dimV = V == 0 ? gr.dim[0] : (V == 1 ? gr.dim[1] : gr.dim[2]);
-  const float pad = r * 1.01f + 1e-6f;
-  // fattened parameter range of the beam: photons may hit with diskDistance up to ~maxt + sqrt(3) r
-  const float t0 = mint - 2.f * r, t1 = maxt + 2.f * r;
+  w.oA = comp(w.base.o, A); w.dA = comp(w.base.d, A);
+  w.oU = comp(w.base.o, U); w.dU = comp(w.base.d, U);
+  w.oV = comp(w.base.o, V); w.dV = comp(w.base.d, V);
+  const f3 org = mk3(a.grid.org[0], a.grid.org[1], a.grid.org[2]);
+  w.orgA = comp(org, A); w.orgU = comp(org, U); w.orgV = comp(org, V);
+  const int dimA = A == 0 ? a.grid.dim[0] : (A == 1 ? a.grid.dim[1] : a.grid.dim[2]);
+  w.dimU = U == 0 ? a.grid.dim[0] : (U == 1 ? a.grid.dim[1] : a.grid.dim[2]);
+  w.dimV = V == 0 ? a.grid.dim[0] : (V == 1 ? a.grid.dim[1] : a.grid.dim[2]);
+  w.pad = r * 1.01f + 1e-6f;
+  // fattened parameter range: photons may hit with diskDistance up to ~maxt + sqrt(3) r
+  w.t0 = mint - 2.f * r;
+  w.t1 = maxt + 2.f * r;
   float aLo = INFINITY, aHi = -INFINITY;
-  if (beamValid) {
-    const float e0 = oA + dA * t0, e1 = oA + dA * t1;
-    aLo = fminf(e0, e1) - pad;
-    aHi = fmaxf(e0, e1) + pad;
+  if (w.beamValid) {
+    const float e0 = w.oA + w.dA * w.t0, e1 = w.oA + w.dA * w.t1;
+    aLo = fminf(e0, e1) - w.pad;
+    aHi = fmaxf(e0, e1) + w.pad;
   }
   aLo = wave_min(aLo);
   aHi = wave_max(aHi);
+  w.any = aLo <= aHi && a.nph > 0;
+  w.cA0 = 1;
+  w.cA1 = 0;
+  if (w.any) {
+    w.cA0 = max(0, (int)floorf((aLo - w.orgA) * a.grid.invCell));
+    w.cA1 = min(dimA - 1, (int)floorf((aHi - w.orgA) * a.grid.invCell));
+  }
+  // layers per step: thicker slabs when the contiguous (x) axis is the slab axis
+  w.K = (A == 0) ? 8 : 4;
+}
 
-  uint32_t qHead = 0, qCount = 0;  // wave-uniform ring state
-  uint32_t candTile = 0;
+struct CellBox {
+  int bx0, bx1, by0, by1, bz0, bz1;
+};
 
-  if (aLo <= aHi && a.nph > 0) {
-    int cA0 = max(0, (int)floorf((aLo - orgA) * gr.invCell));
-    int cA1 = min(dimA - 1, (int)floorf((aHi - orgA) * gr.invCell));
-    // layers per step: thicker slabs when the contiguous axis is the slab axis
-    const int K = (A == 0) ? 8 : 4;
-    for (int cA = cA0; cA <= cA1; cA += K) {
-      const int cAe = min(cA + K - 1, cA1);
-      const float lo = orgA + cA * gr.cell - pad, hi = orgA + (cAe + 1) * gr.cell + pad;
-      // clip this lane's fat segment to the slab and bound it in U, V
-      float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
-      if (beamValid) {
-        float ta = t0, tb = t1;
-        bool act = true;
-        if (fabsf(dA) > 1e-12f) {
-          const float inv = 1.f / dA;
-          const float s0 = (lo - oA) * inv, s1 = (hi - oA) * inv;
-          ta = fmaxf(ta, fminf(s0, s1));
-          tb = fminf(tb, fmaxf(s0, s1));
-          act = ta <= tb;
-        } else {
-          act = oA >= lo && oA <= hi;
-        }
-        if (act) {
-          const float u0 = oU + dU * ta, u1 = oU + dU * tb, v0 = oV + dV * ta, v1 = oV + dV * tb;
-          uLo = fminf(u0, u1) - pad; uHi = fmaxf(u0, u1) + pad;
-          vLo = fminf(v0, v1) - pad; vHi = fmaxf(v0, v1) + pad;
-        }
+// cell box of the slab layers [cA, cAe]; false when no beam of the tile reaches the slab
+__device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, int cA, int cAe, CellBox &bx) {
+  const float lo = w.orgA + cA * a.grid.cell - w.pad, hi = w.orgA + (cAe + 1) * a.grid.cell + w.pad;
+  float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
+  if (w.beamValid) {
+    float ta = w.t0, tb = w.t1;
+    bool act = true;
+    if (fabsf(w.dA) > 1e-12f) {
+      const float inv = 1.f / w.dA;
+      const float s0 = (lo - w.oA) * inv, s1 = (hi - w.oA) * inv;
+      ta = fmaxf(ta, fminf(s0, s1));
+      tb = fminf(tb, fmaxf(s0, s1));
+      act = ta <= tb;
+    } else {
+      act = w.oA >= lo && w.oA <= hi;
+    }
+    if (act) {
+      const float u0 = w.oU + w.dU * ta, u1 = w.oU + w.dU * tb, v0 = w.oV + w.dV * ta, v1 = w.oV + w.dV * tb;
+      uLo = fminf(u0, u1) - w.pad; uHi = fmaxf(u0, u1) + w.pad;
+      vLo = fminf(v0, v1) - w.pad; vHi = fmaxf(v0, v1) + w.pad;
+    }
+  }
+  uLo = wave_min(uLo); uHi = wave_max(uHi);
+  vLo = wave_min(vLo); vHi = wave_max(vHi);
+  if (!(uLo <= uHi)) return false;
+  const int cU0 = max(0, (int)floorf((uLo - w.orgU) * a.grid.invCell));
+  const int cU1 = min(w.dimU - 1, (int)floorf((uHi - w.orgU) * a.grid.invCell));
+  const int cV0 = max(0, (int)floorf((vLo - w.orgV) * a.grid.invCell));
+  const int cV1 = min(w.dimV - 1, (int)floorf((vHi - w.orgV) * a.grid.invCell));
+  if (cU0 > cU1 || cV0 > cV1) return false;
+  // (A,U,V) -> (x,y,z): A=0: x=A y=U z=V; A=1: x=V y=A z=U; A=2: x=U y=V z=A
+  const int A = w.A;
+  bx.bx0 = A == 0 ? cA : (A == 1 ? cV0 : cU0); bx.bx1 = A == 0 ? cAe : (A == 1 ? cV1 : cU1);
+  bx.by0 = A == 0 ? cU0 : (A == 1 ? cA : cV0); bx.by1 = A == 0 ? cU1 : (A == 1 ? cAe : cV1);
+  bx.bz0 = A == 0 ? cV0 : (A == 1 ? cU0 : cA); bx.bz1 = A == 0 ? cV1 : (A == 1 ? cU1 : cAe);
+  return true;
+}
+
+// x-contiguous photon range of this lane for range index ri of the box
+__device__ __forceinline__ void boxRange(const GatherArgs &a, const CellBox &bx, int ri, int nranges, uint32_t &start,
+                                         uint32_t &count) {
+  start = 0;
+  count = 0;
+  if (ri < nranges) {
+    const int nyr = bx.by1 - bx.by0 + 1;
+    const int y = bx.by0 + ri % nyr, z = bx.bz0 + ri / nyr;
+    const uint32_t row = ((uint32_t)z * a.grid.dim[1] + y) * a.grid.dim[0];
+    start = a.cellStart[row + bx.bx0];
+    count = a.cellStart[row + bx.bx1 + 1] - start;
+  }
+}
+
+// number of photons staged for a slab step (sum over the box's ranges), wave-uniform
+__device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox &bx, int lane) {
+  const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
+  uint32_t c = 0;
+  for (int rbase = 0; rbase < nranges; rbase += 64) {
+    uint32_t st, cnt;
+    boxRange(a, bx, rbase + lane, nranges, st, cnt);
+    c += cnt;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// plan: cut every tile chunk into work items of ~equal candidate count
+// item = {setBase, nb, firstLayer, lastLayer}
+// ------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
+                                                  uint32_t *itemCount) {
+  __shared__ TileLds<B> s;
+  const int lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  const uint32_t tileBeg = a.tileStart[tile], tileEnd = a.tileStart[tile + 1];
+  for (uint32_t setBase = tileBeg; setBase < tileEnd; setBase += B) {
+    const uint32_t nb = min((uint32_t)B, tileEnd - setBase);
+    loadTileRays<B>(a, s, setBase, nb, lane);
+    TileWalk w;
+    tileSetup<B>(a, s, nb, lane, w);
+    if (!w.any) continue;
+    // pass A: total candidates of the chunk
+    uint32_t total = 0;
+    for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
+      CellBox bx;
+      if (slabBox(a, w, cA, min(cA + w.K - 1, w.cA1), bx)) total += boxCount(a, bx, lane);
+    }
+    if (total == 0) continue;
+    const uint32_t nItems = min((uint32_t)PLAN_MAX_ITEMS, (total + target - 1) / target);
+    const uint32_t per = (total + nItems - 1) / nItems;
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(itemCount, nItems);
+    slot = __shfl(slot, 0, 64);
+    // pass B: emit items at the crossings of k * per
+    uint32_t run = 0, emitted = 0;
+    int first = w.cA0;
+    for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
+      const int cAe = min(cA + w.K - 1, w.cA1);
+      CellBox bx;
+      if (slabBox(a, w, cA, cAe, bx)) run += boxCount(a, bx, lane);
+      const bool last = cAe == w.cA1;
+      if ((run >= per && emitted + 1 < nItems) || last) {
+        if (lane == 0) items[slot + emitted] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
+        emitted++;
+        run = 0;
+        first = cAe + 1;
       }
-      uLo = wave_min(uLo); uHi = wave_max(uHi);
-      vLo = wave_min(vLo); vHi = wave_max(vHi);
-      if (!(uLo <= uHi)) continue;
-      const int cU0 = max(0, (int)floorf((uLo - orgU) * gr.invCell));
-      const int cU1 = min(dimU - 1, (int)floorf((uHi - orgU) * gr.invCell));
-      const int cV0 = max(0, (int)floorf((vLo - orgV) * gr.invCell));
-      const int cV1 = min(dimV - 1, (int)floorf((vHi - orgV) * gr.invCell));
-      if (cU0 > cU1 || cV0 > cV1) continue;
-      // (A,U,V) -> (x,y,z): A=0: x=A y=U z=V; A=1: x=V y=A z=U; A=2: x=U y=V z=A
-      const int bx0 = A == 0 ? cA : (A == 1 ? cV0 : cU0), bx1 = A == 0 ? cAe : (A == 1 ? cV1 : cU1);
-      const int by0 = A == 0 ? cU0 : (A == 1 ? cA : cV0), by1 = A == 0 ? cU1 : (A == 1 ? cAe : cV1);
-      const int bz0 = A == 0 ? cV0 : (A == 1 ? cU0 : cA), bz1 = A == 0 ? cV1 : (A == 1 ? cU1 : cAe);
-      const int nyr = by1 - by0 + 1, nzr = bz1 - bz0 + 1;
-      const int nranges = nyr * nzr;
+    }
+    // unused reserved slots (possible when the crossings come late): mark empty
+    for (uint32_t e = emitted + lane; e < nItems; e += 64) items[slot + e] = make_uint4(setBase, 0u, 1u, 0u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// gather: persistent waves pulling work items
+// ------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
+                                                           const uint32_t *__restrict__ itemCount,
+                                                           uint32_t *queueHead) {
+  constexpr int LPB = 64 / B;
+  __shared__ TileLds<B> s;
+  const int lane = threadIdx.x;
+  const uint32_t nItems = *itemCount;
+  const int b = lane % B, sub = lane / B;
+  const float r = a.radius;
+  const float eps = a.cfg.epsilon;
+  const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
+
+  // occluders -> LDS, with the unit normal for the plane early-out
+  for (uint32_t i = lane; i < min(a.ntri, (uint32_t)MAXTRI_LDS); i += 64) {
+    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
+    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
+    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
+    f3 n = cross(e1, e2);
+    const float l = sqrtf(dot(n, n));
+    n = l > 0.f ? n * (1.f / l) : mk3(0.f);
+    s.tri[i][0] = make_float4(v0.x, v0.y, v0.z, n.x);
+    s.tri[i][1] = make_float4(e1.x, e1.y, e1.z, n.y);
+    s.tri[i][2] = make_float4(e2.x, e2.y, e2.z, n.z);
+  }
+
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+  unsigned long long nCand = 0;
+
+  for (;;) {
+    uint32_t it = 0;
+    if (lane == 0) it = atomicAdd(queueHead, 1u);
+    it = __shfl(it, 0, 64);
+    if (it >= nItems) break;
+    const uint4 item = items[it];
+    const uint32_t setBase = item.x, nb = item.y;
+    if (nb == 0) continue;
+    __syncthreads();
+    loadTileRays<B>(a, s, setBase, nb, lane);
+    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+    __syncthreads();
+    TileWalk w;
+    tileSetup<B>(a, s, nb, lane, w);
+    const RayReg base = w.base;
+    const bool beamValid = w.beamValid;
+    const float mint = eps, maxt = base.len - eps;
+    const double mintD = (double)eps, maxtD = (double)base.len - (double)eps;
+    const d3 rcpD = mkd(1.0 / (double)base.d.x, 1.0 / (double)base.d.y, 1.0 / (double)base.d.z);
+    const float rnd = s.rnd[b];
+    const uint32_t edge = s.edge[b];
+    const uint32_t pixv = s.pix[b];
+    const uint32_t pixParity = ((pixv & 0xFFFFu) + (pixv >> 16)) & 1u;
+    uint32_t qHead = 0, qCount = 0;  // wave-uniform ring state
+    uint32_t staged = 0;
+
+    const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
+    for (int cA = cBeg; cA <= cEnd; cA += w.K) {
+      const int cAe = min(cA + w.K - 1, cEnd);
+      CellBox bx;
+      if (!slabBox(a, w, cA, cAe, bx)) continue;
+      const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
       for (int rbase = 0; rbase < nranges; rbase += 64) {
-        // one x-contiguous photon range per lane
-        uint32_t start = 0, count = 0;
-        const int ri = rbase + lane;
-        if (ri < nranges) {
-          const int y = by0 + ri % nyr, z = bz0 + ri / nyr;
-          const uint32_t row = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
-          start = a.cellStart[row + bx0];
-          count = a.cellStart[row + bx1 + 1] - start;
-        }
+        uint32_t start, count;
+        boxRange(a, bx, rbase + lane, nranges, start, count);
         const uint32_t incl = wave_scan_incl(count, lane);
         const uint32_t excl = incl - count;
         const uint32_t total = __shfl(incl, 63, 64);
@@ -552,7 +729,7 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
           }
           __syncthreads();
           const uint32_t nst = min((uint32_t)STAGE, total - win);
-          candTile += nst;
+          staged += nst;
           const uint32_t iters = (nst + LPB - 1) / LPB;
           for (uint32_t jj = 0; jj < iters; ++jj) {
             const uint32_t j = jj * LPB + sub;
@@ -561,21 +738,22 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
             if (beamValid && j < nst) {
               const float4 hp = s.stage[j];
               const f3 p = mk3(hp.x, hp.y, hp.z);
-              const f3 w = p - base.o;
-              const float disk = dot(w, base.d);
-              const f3 v = w - base.d * disk;
+              const f3 wv = p - base.o;
+              const float disk = dot(wv, base.d);
+              const f3 v = wv - base.d * disk;
               const float d2 = dot(v, v);
               // conservative fp32 pre-test
               if (d2 < r * r * 1.002f + 1e-12f && disk > mint - 1e-3f && disk < maxt + 2.f * r) {
-                HitGeom g;
-                if (exactHit(p, base.o, base.d, mintD, maxtD, (double)r, g)) {
+                const HitGeom g = hitGeom(p, base.o, base.d);
+                if (g.disk > mintD && g.distSqr < (double)r * (double)r &&
+                    ownBoxHit(p, base.o, base.d, rcpD, mintD, maxtD, (double)r)) {
                   const uint32_t bits = __float_as_uint(hp.w);
                   // filters, shift_volume_photon.cpp:670-697
                   const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
                   bool keep = true;
                   if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) keep = false;
                   if (a.cfg.min_depth != 0 && depth < a.cfg.min_depth) keep = false;
-                  if (!((bits >> 6) & 1u)) keep = false;  // computeVolumeContribution + debugShift, see grid_build
+                  if (!((bits >> 6) & 1u)) keep = false;  // computeVolumeContribution + debugShift (grid_build)
                   if (a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) keep = false;
                   if (keep && use3D) {
                     double tp, dt;
@@ -608,31 +786,28 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
         }
       }
     }
-  }
-  // ---- flush the partial batch ----
-  __syncthreads();
-  if ((uint32_t)lane < qCount) {
-    const uint2 e = s.queue[(qHead + lane) % QCAP];
-    evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
-    nEval++;
-  }
-  __syncthreads();
-
-  // ---- write out: 27 sums per beam set into the iteration buffer ----
-  for (int idx = lane; idx < 27 * B; idx += 64) {
-    const int k = idx / B, bb = idx % B;
-    if ((uint32_t)bb < nb && s.ray[0][13][bb] != 0.f) {
-      const float v = s.acc[k][bb];
-      if (v != 0.f) {
-        const uint32_t pv = s.pix[bb];
-        const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
-        atomicAdd(&a.iter[p * 27 + k], v);
+    // ---- flush the partial batch ----
+    __syncthreads();
+    if ((uint32_t)lane < qCount) {
+      const uint2 e = s.queue[(qHead + lane) % QCAP];
+      evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
+      nEval++;
+    }
+    __syncthreads();
+    // ---- write out: 27 partial sums per beam set into the iteration buffer ----
+    for (int idx = lane; idx < 27 * B; idx += 64) {
+      const int k = idx / B, bb = idx % B;
+      if ((uint32_t)bb < nb) {
+        const float v = s.acc[k][bb];
+        if (v != 0.f) {
+          const uint32_t pv = s.pix[bb];
+          const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+          atomicAdd(&a.iter[p * 27 + k], v);
+        }
       }
     }
+    nCand += (unsigned long long)staged * nb;
   }
-  nCand += candTile * nb;
-  __syncthreads();
-  }  // chunk loop
   // ---- statistics ----
   {
     unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
@@ -643,9 +818,9 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
       di += __shfl_xor(di, o, 64);
       fa += __shfl_xor(fa, o, 64);
     }
-    if (lane == 0) {
+    if (lane == 0 && (ev | nCand)) {
       atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[1], (unsigned long long)nCand);
+      atomicAdd(&a.stats[1], nCand);
       atomicAdd(&a.stats[2], nu);
       atomicAdd(&a.stats[3], di);
       atomicAdd(&a.stats[4], fa);
@@ -653,20 +828,37 @@ template <int B> __global__ __launch_bounds__(64) void gather_bre_kernel(GatherA
   }
 }
 
-// explicit instantiations used by the launcher
-template __global__ void gather_bre_kernel<64>(GatherArgs, uint32_t);
-template __global__ void gather_bre_kernel<32>(GatherArgs, uint32_t);
-template __global__ void gather_bre_kernel<16>(GatherArgs, uint32_t);
+template <int B>
+static void launchT(const GatherArgs &a, uint32_t ntiles, uint32_t target, uint4 *items, uint32_t *itemCount,
+                    uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
+  hipLaunchKernelGGL(plan_kernel<B>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount);
+  hipLaunchKernelGGL(gather_bre_kernel<B>, dim3(nwaves), dim3(64), 0, stream, a, (const uint4 *)items,
+                     (const uint32_t *)itemCount, queueHead);
+}
 
-void launch_gather_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, hipStream_t stream) {
+// itemCount / queueHead must be zero on entry (memset on the same stream)
+void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
+                     uint32_t *itemCount, hipStream_t stream) {
   if (a.nsets == 0 || ntiles == 0) return;
-  const uint32_t grid = ((ntiles + 7u) / 8u) * 8u;
-  (void)beamsPerWave;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(gather_bre_kernel<64>, dim3(grid), dim3(64), 0, stream, a, ntiles); break;
-    case 16: hipLaunchKernelGGL(gather_bre_kernel<16>, dim3(grid), dim3(64), 0, stream, a, ntiles); break;
-    default: hipLaunchKernelGGL(gather_bre_kernel<32>, dim3(grid), dim3(64), 0, stream, a, ntiles); break;
+    case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
+    case 16: hipLaunchKernelGGL(plan_kernel<16>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
+    default: hipLaunchKernelGGL(plan_kernel<32>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
   }
+}
+
+void launch_gather_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
+                       uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
+  if (a.nsets == 0) return;
+  switch (beamsPerWave) {
+    case 64: hipLaunchKernelGGL(gather_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    case 16: hipLaunchKernelGGL(gather_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    default: hipLaunchKernelGGL(gather_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+  }
+}
+
+uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave) {
+  return (ntiles + nsets / (uint32_t)beamsPerWave + 1u) * (uint32_t)PLAN_MAX_ITEMS;
 }
 
 }  // namespace gvpm

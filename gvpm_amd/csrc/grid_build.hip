@@ -128,15 +128,20 @@ __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32
   cold[6 * N + i] = ld3(r.parent_wi, src, 0.f);
 }
 
-// ---- segment starts of a sorted key array: start[c] = first i with key[i] >= c --------------
+// ---- segment starts of a sorted key array: start[c] = first i with (key[i] >> shift) >= c ----
+// one thread per segment, binary search (segments far outnumber the long empty runs a
+// per-element scatter would serialise on)
 __global__ __launch_bounds__(256) void segment_start_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                             uint32_t nseg, uint32_t shift, uint32_t *start) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  const uint32_t prev = (i == 0) ? 0u : (keys[i - 1] >> shift) + 1u;
-  const uint32_t cur = (i == n) ? nseg + 1u : (keys[i] >> shift) + 1u;
-  // segments prev .. cur-1 start at i
-  for (uint32_t c = prev; c < cur && c <= nseg; ++c) start[c] = i;
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nseg) return;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((keys[mid] >> shift) < c) lo = mid + 1;
+    else hi = mid;
+  }
+  start[c] = lo;
 }
 
 // ---- camera beam sets: tile keys -------------------------------------------------------------
@@ -195,7 +200,7 @@ void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t 
 
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
                           hipStream_t s) {
-  hipLaunchKernelGGL(segment_start_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s, keys, n, nseg, shift, start);
+  hipLaunchKernelGGL(segment_start_kernel, dim3((nseg + 1 + 255) / 256), dim3(256), 0, s, keys, n, nseg, shift, start);
 }
 
 void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,

@@ -25,7 +25,11 @@ void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint3
                           hipStream_t s);
 void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
                       uint32_t *vals, hipStream_t s);
-void launch_gather_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, hipStream_t stream);
+void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
+                     uint32_t *itemCount, hipStream_t stream);
+void launch_gather_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
+                       uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
+uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float *thr,
                  float *dx, float *dy, hipStream_t s);
@@ -123,6 +127,10 @@ struct gvpm_context {
 
   int beamsPerWave = 32;
   float cellScale = 1.0f;
+  uint32_t planTarget = 4096;  // staged photons per work item
+  uint32_t nwaves = 2048;      // persistent gather waves
+  DevBuf<uint4> items;
+  DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -193,6 +201,19 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     int v = atoi(e);
     if (v == 16 || v == 32 || v == 64) h->beamsPerWave = v;
   }
+  if (const char *e = getenv("GVPM_PLAN_TARGET")) {
+    int v = atoi(e);
+    if (v >= 64 && v <= (1 << 24)) h->planTarget = (uint32_t)v;
+  }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      h->nwaves = (uint32_t)prop.multiProcessorCount * 8u;
+    if (const char *e = getenv("GVPM_WAVES_PER_CU")) {
+      int v = atoi(e);
+      if (v >= 1 && v <= 32 && prop.multiProcessorCount > 0) h->nwaves = (uint32_t)prop.multiProcessorCount * v;
+    }
+  }
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -227,7 +248,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->boundsPartial.release(); h->bounds6.release();
   if (h->sortTmp.d) (void)hipFree(h->sortTmp.d);
   h->raysOwned.release(); h->bKeysA.release(); h->bKeysB.release(); h->bValsA.release();
-  h->setPerm.release(); h->tileStart.release();
+  h->setPerm.release(); h->tileStart.release(); h->items.release(); h->queueCtl.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -498,8 +519,12 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     h->events.emplace_back(e0, e1);
   }
   auto &ev = h->events[h->eventsUsed++];
+  HIP_TRY(h, h->items.ensure(plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave)));
+  HIP_TRY(h, h->queueCtl.ensure(4));
+  HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
+  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->stream);
   HIP_TRY(h, hipEventRecord(ev.first, h->stream));
-  launch_gather_bre(a, h->beamsPerWave, h->ntiles, h->stream);
+  launch_gather_bre(a, h->beamsPerWave, h->items.p, h->queueCtl.p, h->queueCtl.p + 1, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev.second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
