@@ -39,14 +39,14 @@ namespace gvpm {
 #define INV_PI_F 0.31830988618379067154f
 #define INV_FOURPI_F 0.07957747154594766788f
 
-constexpr int RAYF = 13;  // o3 d3 len(<0: invalid) pdf eye3 jac gop
 constexpr int STAGE = 256;
 constexpr int QCAP = 128;
 constexpr int MAXTRI_LDS = 32;
-constexpr int PLAN_MAX_ITEMS = 64;  // per tile chunk
+constexpr int PLAN_MAX_ITEMS = 256;  // per tile chunk
 
 template <int B> struct TileLds {
-  float ray[5][RAYF][B];
+  float4 ray4[5][3][B];  // {o, len (<0: invalid)} {d, pdf} {eye, jacobian}
+  float gop[5][B];
   float acc[27][B];
   float4 stage[STAGE];
   uint32_t stageIdx[STAGE];
@@ -65,15 +65,15 @@ struct RayReg {
 
 template <int B> __device__ __forceinline__ RayReg loadRay(const TileLds<B> &s, int k, int b) {
   RayReg r;
-  r.o = mk3(s.ray[k][0][b], s.ray[k][1][b], s.ray[k][2][b]);
-  r.d = mk3(s.ray[k][3][b], s.ray[k][4][b], s.ray[k][5][b]);
-  const float l = s.ray[k][6][b];
-  r.len = fabsf(l);
-  r.valid = l >= 0.f;
-  r.pdf = s.ray[k][7][b];
-  r.eye = mk3(s.ray[k][8][b], s.ray[k][9][b], s.ray[k][10][b]);
-  r.jac = s.ray[k][11][b];
-  r.gop = s.ray[k][12][b];
+  const float4 q0 = s.ray4[k][0][b], q1 = s.ray4[k][1][b], q2 = s.ray4[k][2][b];
+  r.o = mk3(q0.x, q0.y, q0.z);
+  r.len = fabsf(q0.w);
+  r.valid = q0.w >= 0.f;
+  r.d = mk3(q1.x, q1.y, q1.z);
+  r.pdf = q1.w;
+  r.eye = mk3(q2.x, q2.y, q2.z);
+  r.jac = q2.w;
+  r.gop = s.gop[k][b];
   return r;
 }
 
@@ -137,12 +137,13 @@ __device__ __forceinline__ float phaseEval(float g, f3 wi, f3 wo) {
 }
 
 // HomogeneousMedium::eval over a distance (balance strategy)
+// (sigma_t is equal across channels -- homogeneous.cpp:196-200, enforced by gvpm_upload_medium --
+// so the three channel exponentials are one)
 __device__ __forceinline__ void mediumEval(const MediumDev &m, float dist, f3 &tr, float &pdfSuccess) {
-  tr.x = __expf(-m.sigmaT[0] * dist);
-  tr.y = __expf(-m.sigmaT[1] * dist);
-  tr.z = __expf(-m.sigmaT[2] * dist);
-  pdfSuccess = (m.sigmaT[0] * tr.x + m.sigmaT[1] * tr.y + m.sigmaT[2] * tr.z) * (1.f / 3.f) * m.msw;
-  if (maxc(tr) < 1e-20f) tr = mk3(0.f);
+  float e = __expf(-m.sigmaT[0] * dist);
+  pdfSuccess = m.sigmaT[0] * e * m.msw;
+  if (e < 1e-20f) e = 0.f;
+  tr = mk3(e);
 }
 
 // Moeller-Trumbore, triangle.h:109-145 + interval test skdtree.h:318-320
@@ -189,6 +190,32 @@ __device__ __forceinline__ bool anyHit(const GatherArgs &a, const TileLds<B> &s,
   return hit;
 }
 
+// As written (shift_volume_photon.cpp:396) the shadow segment is [Epsilon, lProj*ShadowEpsilon]
+// from the photon's parent: only occluders within that distance of the parent can be hit.  The
+// grid build lists them per photon (reorder_kernel), so the any-hit loop touches 0-4 triangles.
+template <int B>
+__device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const TileLds<B> &s, uint32_t nearList, f3 o,
+                                              f3 d, float mint, float maxt) {
+  if (!a.cfg.visibility_as_written || (nearList >> 24) == 0xFEu) return anyHit<B>(a, s, o, d, mint, maxt);
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = (nearList >> (8 * k)) & 0xFFu;
+    if (i == 0xFFu) continue;
+    f3 v0, e1, e2;
+    if (i < (uint32_t)MAXTRI_LDS) {
+      const float4 t0 = s.tri[i][0], t1 = s.tri[i][1], t2 = s.tri[i][2];
+      v0 = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
+    } else {
+      v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
+      e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
+      e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
+    }
+    if (triHit(v0, e1, e2, o, d, mint, maxt)) hit = true;
+  }
+  return hit;
+}
+
 // GatherPoint::sensorMIS, gvpm_struct.h:608-631 (sDist == bDist for BRE: same t')
 __device__ __forceinline__ float sensorMIS(const RayReg &s, const RayReg &b, uint32_t edge) {
   float jacobian = s.jac;
@@ -203,6 +230,7 @@ __device__ __forceinline__ float sensorMIS(const RayReg &s, const RayReg &b, uin
 struct PhotonCold {
   f3 wi, flux, parentPos, parentN, prefixW, parentScat, parentWi;
   float parentPdf, edgePdf, parentRR, parentG;
+  uint32_t nearList;  // up to 4 occluder indices near the parent (0xFF = none); top byte 0xFE: overflow
 };
 
 __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx) {
@@ -219,6 +247,7 @@ __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx
   c.parentPos = mk3(c2.x, c2.y, c2.z); c.parentRR = c2.w;
   c.parentN = mk3(c3.x, c3.y, c3.z); c.parentG = c3.w;
   c.prefixW = mk3(c4.x, c4.y, c4.z);
+  c.nearList = __float_as_uint(c4.w);
   c.parentScat = mk3(c5.x, c5.y, c5.z);
   c.parentWi = mk3(c6.x, c6.y, c6.z);
   return c;
@@ -227,19 +256,17 @@ __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.
 template <int B>
 __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const TileLds<B> &s, const PhotonCold &ph,
-                                              uint32_t bits, d3 offsetPos, const RayReg &sh, const RayReg &base,
+                                              uint32_t bits, f3 dProjU, const RayReg &sh, const RayReg &base,
                                               uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
                                               f3 &shiftedFlux, bool &ok) {
   ok = false;
   shiftedFlux = mk3(0.f);
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
-  const d3 dProjD = offsetPos - tod(ph.parentPos);
-  const double lProjD = sqrt(len2(dProjD));
-  const f3 dProj = tof(dProjD / lProjD);
-  const float lProj = (float)lProjD;
+  const float lProj = sqrtf(dot(dProjU, dProjU));
+  const f3 dProj = dProjU * (1.f / lProj);
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
-  if (anyHit<B>(a, s, ph.parentPos, dProj, eps, vmax)) return 1.f;
+  if (shadowBlocked<B>(a, s, ph.nearList, ph.parentPos, dProj, eps, vmax)) return 1.f;
   if (ptype != GVPM_PARENT_MEDIUM) {
     const float signDot = dot(ph.parentN, dProj) / dot(ph.parentN, -ph.wi);
     if (signDot < 0.f) return 1.f;
@@ -293,16 +320,21 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const TileLds
   return w;
 }
 
-// coordinateSystemCoherent (float intermediates), src/libcore/util.cpp:592-599
-__device__ __forceinline__ void coherentFrame(d3 n, d3 &b1, d3 &b2) {
-  const float sign = copysignf(1.0f, (float)n.z);
-  const float aa = (float)(-1.0 / ((double)sign + n.z));
-  const float bb = (float)(n.x * n.y * (double)aa);
-  b1 = mkd(1.0 + (double)sign * n.x * n.x * (double)aa, (double)sign * (double)bb, -(double)sign * n.x);
-  b2 = mkd((double)bb, (double)sign + n.y * n.y * (double)aa, -n.y);
+// coordinateSystemCoherent, src/libcore/util.cpp:592-599 (its intermediates are float)
+__device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
+  const float sign = copysignf(1.0f, n.z);
+  const float aa = -1.0f / (sign + n.z);
+  const float bb = n.x * n.y * aa;
+  b1 = mk3(1.0f + sign * n.x * n.x * aa, sign * bb, -sign * n.x);
+  b2 = mk3(bb, sign + n.y * n.y * aa, -n.y);
 }
 
 // One evaluation: VolumeGradientBREQuery::operator() after the filters.
+//
+// Numerics: every quantity that the reference obtains by subtracting O(1) positions to get an
+// O(radius) vector (photon - ray point, shifted ray point - base ray point) is formed in fp64 and
+// then carried as a small fp32 vector; everything downstream of those differences (kernel chord
+// lengths sqrt(r^2 - d^2), pdfs, BSDF / phase / transmittance products, MIS weights) is fp32.
 template <int B>
 __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uint32_t pidx, uint32_t b,
                                          uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
@@ -315,54 +347,58 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
   const uint32_t pix = s.pix[b];
   const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
-  const double radius = (double)a.radius;
-  const double mint = (double)a.cfg.epsilon;
+  const float r = a.radius, r2 = r * r;
+  const float eps = a.cfg.epsilon;
 
-  // geometry of the hit, recomputed exactly as in the test phase
-  const HitGeom g = hitGeom(pos, base.o, base.d);
-  double tPrime = g.disk, deltaT = 0.0;
-  double kernelVolD = 3.14159265358979323846 * radius * radius;
+  // hit geometry (gvpm_accel.h:296-299): disk in fp64, the perpendicular offset as a small vector
+  const d3 pD = tod(pos), boD = tod(base.o), bdD = tod(base.d);
+  const d3 wD = pD - boD;
+  const double disk = dot(wD, bdD);
+  const f3 perp = tof(wD - bdD * disk);
+  const float distSqr = dot(perp, perp);
+  double tPrime = disk;
+  float kernelVol = 3.14159265358979323846f * r2;
   float pdfCam = 1.f;
   if (use3D) {
-    resample3D(g, radius, (double)s.rnd[b], mint, (double)base.len, tPrime, deltaT);
-    kernelVolD = (4.0 / 3.0) * 3.14159265358979323846 * radius * radius * radius;
-    pdfCam = (float)(1.0 / fmax(deltaT * 2.0, 0.0001));
+    // shift_volume_photon.cpp:707-726
+    const float deltaT = sqrtf(fmaxf(0.f, r2 - distSqr));
+    tPrime = (disk - (double)deltaT) + (double)(2.f * deltaT * s.rnd[b]);
+    kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r;
+    pdfCam = 1.f / fmaxf(deltaT * 2.f, 0.0001f);
   }
   const float rr = a.cfg.path_set ? 2.f : 1.f;
-  const float scale = rr / ((float)kernelVolD * pdfCam);
+  const float scale = rr / (kernelVol * pdfCam);
 
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
   // base contribution, shift_volume_photon.cpp:735-751; the base and the four shifted rays
   // all carry mint = Epsilon and maxt = t' (:769-770), hence one transmittance
   f3 trT;
   float dummy;
-  mediumEval(a.med, (float)(tPrime - mint), trT, dummy);
+  mediumEval(a.med, (float)tPrime - eps, trT, dummy);
   const f3 photonIn = sigS * ph.flux;
   const f3 baseContrib = trT * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * base.eye;
   atomicAdd(&s.acc[0][b], baseContrib.x * scale);
   atomicAdd(&s.acc[1][b], baseContrib.y * scale);
   atomicAdd(&s.acc[2][b], baseContrib.z * scale);
 
-  const d3 pD = tod(pos);
-  const d3 basePt = tod(base.o) + tod(base.d) * tPrime;  // baseRay(t')
-  const d3 rel = pD - basePt;
+  const d3 basePt = boD + bdD * tPrime;  // baseRay(t')
+  const f3 rel = tof(pD - basePt);       // photon relative to the base ray point
+  const float tPf = (float)tPrime;
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
     const RayReg sh = loadRay(s, 1 + i, b);
     float w = 1.f;
     f3 sflux = mk3(0.f);
     if (sh.valid) {
-      const d3 shO = tod(sh.o), shD = tod(sh.d);
-      const d3 zP = shO + shD * tPrime;  // shiftRay(t')
+      const d3 zP = tod(sh.o) + tod(sh.d) * tPrime;  // shiftRay(t')
+      const f3 y = tof(pD - zP);                     // photon relative to the shifted ray point
       bool alreadyShift = false;
       if (a.cfg.use_shift_null) {
-        const double ZPtoY = len2(zP - pD);
-        if (ZPtoY < radius * radius && tPrime < (double)sh.len) {
+        if (dot(y, y) < r2 && tPf < sh.len) {
           // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
-          const double diskS = dot(pD - shO, shD);
-          const double distSqrS = len2((shO + shD * diskS) - pD);
-          const double deltaS = sqrt(fmax(0.0, radius * radius - distSqrS));
-          const float pdfShiftPos = (float)(1.0 / fmax(2.0 * deltaS, 0.0001));
+          const f3 yp = y - sh.d * dot(y, sh.d);
+          const float deltaS = sqrtf(fmaxf(0.f, r2 - dot(yp, yp)));
+          const float pdfShiftPos = 1.f / fmaxf(2.f * deltaS, 0.0001f);
           sflux = trT * (photonIn * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
           w = 0.5f;
           if (a.cfg.use_mis) {
@@ -373,38 +409,36 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
           nNull++;
         }
       }
-      if (!alreadyShift && (double)sh.len >= tPrime) {
-        // getShiftPos, shift_volume_photon.cpp:858-896
-        d3 offsetPos = zP + rel;
+      if (!alreadyShift && sh.len >= tPf) {
+        // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
+        f3 offRel = rel;
         if (!use3D) {
-          d3 bn = tod(base.d), bs, bt, nn = shD, ns, nt;
-          coherentFrame(bn, bs, bt);
-          coherentFrame(nn, ns, nt);
-          const double lx = dot(rel, bs), ly = dot(rel, bt), lz = dot(rel, bn);
-          offsetPos = zP + (ns * lx + nt * ly + nn * lz);
+          f3 bs, bt, ns, nt;
+          coherentFrame(base.d, bs, bt);
+          coherentFrame(sh.d, ns, nt);
+          offRel = ns * dot(rel, bs) + nt * dot(rel, bt) + sh.d * dot(rel, base.d);
         }
         if (a.cfg.use_shift_null) {
-          const double offDistSqr = len2(basePt - offsetPos);
-          if (offDistSqr < radius * radius) {
-            d3 dShift = zP - basePt;
-            dShift = dShift / sqrt(len2(dShift));
-            const double cosD = dot(dShift, -(offsetPos - zP));
-            offsetPos = offsetPos + dShift * (cosD * 2.0);
+          const f3 dS = tof(zP - basePt);  // shiftRay(t') - baseRay(t')
+          const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
+          if (dot(bo, bo) < r2) {
+            const float cosD2 = -2.f * dot(dS, offRel) / dot(dS, dS);
+            offRel = offRel + dS * cosD2;
           }
         }
         float pdfShiftPos = 1.f;
         if (use3D) {
-          const double diskO = dot(offsetPos - shO, shD);
-          const double distSqrO = len2((shO + shD * diskO) - offsetPos);
-          const double deltaO = sqrt(fmax(0.0, radius * radius - distSqrO));
-          pdfShiftPos = (float)(1.0 / fmax(2.0 * deltaO, 0.0001));
+          const f3 op = offRel - sh.d * dot(offRel, sh.d);
+          const float deltaO = sqrtf(fmaxf(0.f, r2 - dot(op, op)));
+          pdfShiftPos = 1.f / fmaxf(2.f * deltaO, 0.0001f);
         }
         if (a.cfg.debug_shift != GVPM_SHIFT_NULL) {
           // shiftPhoton dispatch, shift_volume_photon.cpp:49-117
           const uint32_t st = GVPM_PF_SHIFT_TYPE(bits);
           bool ok = false;
           if (st == 1u || st == 2u) {
-            w = shiftDiffuse<B>(a, s, ph, bits, offsetPos, sh, base, edge, trT, pdfCam, pdfShiftPos, sflux, ok);
+            const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
+            w = shiftDiffuse<B>(a, s, ph, bits, dProjU, sh, base, edge, trT, pdfCam, pdfShiftPos, sflux, ok);
           }
           if (ok) nDiff++; else nFail++;
         }
@@ -445,34 +479,28 @@ __device__ __forceinline__ void loadTileRays(const GatherArgs &a, TileLds<B> &s,
   for (int idx = lane; idx < B * 20; idx += 64) {
     const int b = idx / 20, k = (idx % 20) / 4, q = idx % 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((uint32_t)b < nb) {
-      const uint32_t set = a.setPerm[setBase + b];
-      v = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5 + k)[q];
-    }
-    if (q == 0) { s.ray[k][0][b] = v.x; s.ray[k][1][b] = v.y; s.ray[k][2][b] = v.z; s.ray[k][6][b] = v.w; }
-    else if (q == 1) { s.ray[k][3][b] = v.x; s.ray[k][4][b] = v.y; s.ray[k][5][b] = v.z; s.ray[k][7][b] = v.w; }
-    else if (q == 2) { s.ray[k][8][b] = v.x; s.ray[k][9][b] = v.y; s.ray[k][10][b] = v.z; s.ray[k][11][b] = v.w; }
-    else {
-      s.ray[k][12][b] = v.x;
-      const uint32_t info = __float_as_uint(v.y);
-      if (k == 0) {
-        s.rnd[b] = v.z;
-        s.pix[b] = __float_as_uint(v.w);
-        s.edge[b] = GVPM_RAY_EDGE(info);
-      }
-    }
-  }
-  __syncthreads();
-  // fold the valid bit into the sign of len (written by the q == 0 lanes above)
-  for (int idx = lane; idx < B * 5; idx += 64) {
-    const int b = idx / 5, k = idx % 5;
     bool valid = false;
     if ((uint32_t)b < nb) {
       const uint32_t set = a.setPerm[setBase + b];
-      valid = GVPM_RAY_VALID(a.rays[(size_t)set * 5 + k].info) != 0;
+      const gvpm_camera_ray *ray = a.rays + (size_t)set * 5 + k;
+      v = reinterpret_cast<const float4 *>(ray)[q];
+      if (q == 0) valid = GVPM_RAY_VALID(ray->info) != 0;
     }
-    const float l = fabsf(s.ray[k][6][b]);
-    s.ray[k][6][b] = valid ? l : -fmaxf(l, 1e-30f);
+    if (q == 0) {
+      // the valid bit rides on the sign of len
+      const float l = fabsf(v.w);
+      v.w = valid ? l : -fmaxf(l, 1e-30f);
+      s.ray4[k][0][b] = v;
+    } else if (q < 3) {
+      s.ray4[k][q][b] = v;
+    } else {
+      s.gop[k][b] = v.x;
+      if (k == 0) {
+        s.rnd[b] = v.z;
+        s.pix[b] = __float_as_uint(v.w);
+        s.edge[b] = GVPM_RAY_EDGE(__float_as_uint(v.y));
+      }
+    }
   }
   __syncthreads();
 }
@@ -524,7 +552,7 @@ __device__ __forceinline__ void tileSetup(const GatherArgs &a, const TileLds<B> 
     w.cA1 = min(dimA - 1, (int)floorf((aHi - w.orgA) * a.grid.invCell));
   }
   // layers per step: thicker slabs when the contiguous (x) axis is the slab axis
-  w.K = (A == 0) ? 8 : 4;
+  w.K = (A == 0) ? 8 : a.cfg.reserved[1] ? a.cfg.reserved[1] : 4;
 }
 
 struct CellBox {
@@ -660,6 +688,7 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
   const float r = a.radius;
+  const float r2f = r * r;
   const float eps = a.cfg.epsilon;
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
 
@@ -721,7 +750,16 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
           // stage [win, win + STAGE) of the concatenated ranges
           {
             const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
-            for (uint32_t i = lo_i; i < hi_i; ++i) {
+            uint32_t i = lo_i;
+            // four independent 16-byte loads in flight per lane before the LDS writes
+            for (; i + 4 <= hi_i; i += 4) {
+              const uint32_t gi = start + (i - excl);
+              const float4 v0 = a.hot[gi], v1 = a.hot[gi + 1], v2 = a.hot[gi + 2], v3 = a.hot[gi + 3];
+              s.stage[i - win] = v0; s.stage[i - win + 1] = v1; s.stage[i - win + 2] = v2; s.stage[i - win + 3] = v3;
+              s.stageIdx[i - win] = gi; s.stageIdx[i - win + 1] = gi + 1;
+              s.stageIdx[i - win + 2] = gi + 2; s.stageIdx[i - win + 3] = gi + 3;
+            }
+            for (; i < hi_i; ++i) {
               const uint32_t gi = start + (i - excl);
               s.stage[i - win] = a.hot[gi];
               s.stageIdx[i - win] = gi;
@@ -742,24 +780,39 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
               const float disk = dot(wv, base.d);
               const f3 v = wv - base.d * disk;
               const float d2 = dot(v, v);
-              // conservative fp32 pre-test
-              if (d2 < r * r * 1.002f + 1e-12f && disk > mint - 1e-3f && disk < maxt + 2.f * r) {
-                const HitGeom g = hitGeom(p, base.o, base.d);
-                if (g.disk > mintD && g.distSqr < (double)r * (double)r &&
-                    ownBoxHit(p, base.o, base.d, rcpD, mintD, maxtD, (double)r)) {
-                  const uint32_t bits = __float_as_uint(hp.w);
-                  // filters, shift_volume_photon.cpp:670-697
-                  const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
-                  bool keep = true;
-                  if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) keep = false;
-                  if (a.cfg.min_depth != 0 && depth < a.cfg.min_depth) keep = false;
-                  if (!((bits >> 6) & 1u)) keep = false;  // computeVolumeContribution + debugShift (grid_build)
-                  if (a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) keep = false;
-                  if (keep && use3D) {
-                    double tp, dt;
-                    keep = resample3D(g, (double)r, (double)rnd, mintD, (double)base.len, tp, dt);
+              // fp32 with a rigorous error band: E bounds |disk - disk_exact|, band |d2 - d2_exact|
+              const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
+              const float band = 4.f * r * E + r2f * 2e-6f;
+              if (d2 < r2f + band && disk > mint - E && disk < maxt + 2.f * r) {
+                const uint32_t bits = __float_as_uint(hp.w);
+                // filters, shift_volume_photon.cpp:670-697
+                const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
+                bool keep = true;
+                if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) keep = false;
+                if (a.cfg.min_depth != 0 && depth < a.cfg.min_depth) keep = false;
+                if (!((bits >> 6) & 1u)) keep = false;  // computeVolumeContribution + debugShift (grid_build)
+                if (a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) keep = false;
+                if (keep) {
+                  // decided in fp32 when the error band cannot change the reference's decision ...
+                  bool sure = d2 < r2f - band && disk > mint + E && disk < maxt - E;
+                  if (sure && use3D) {
+                    const float dTup = sqrtf(r2f - d2 + band) * 1.000001f;  // >= exact deltaT
+                    sure = disk - dTup > mint + 2.f * E && disk + dTup < base.len - 2.f * E;
                   }
-                  hit = keep;
+                  if (sure) {
+                    hit = true;
+                  } else {
+                    // ... otherwise the reference predicate itself, fp64, uncontracted
+                    const HitGeom g = hitGeom(p, base.o, base.d);
+                    if (g.disk > mintD && g.distSqr < (double)r * (double)r &&
+                        ownBoxHit(p, base.o, base.d, rcpD, mintD, maxtD, (double)r)) {
+                      hit = true;
+                      if (use3D) {
+                        double tp, dt;
+                        hit = resample3D(g, (double)r, (double)rnd, mintD, (double)base.len, tp, dt);
+                      }
+                    }
+                  }
                   gi = s.stageIdx[j];
                 }
               }
@@ -774,7 +827,7 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
               if (qCount >= 64u) {
                 __syncthreads();
                 const uint2 e = s.queue[(qHead + lane) % QCAP];
-                evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
+                if (!(a.cfg.reserved[0] & 1)) evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
                 nEval++;
                 qHead = (qHead + 64u) % QCAP;
                 qCount -= 64u;
@@ -790,7 +843,7 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
     __syncthreads();
     if ((uint32_t)lane < qCount) {
       const uint2 e = s.queue[(qHead + lane) % QCAP];
-      evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
+      if (!(a.cfg.reserved[0] & 1)) evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
       nEval++;
     }
     __syncthreads();
@@ -828,22 +881,14 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
   }
 }
 
-template <int B>
-static void launchT(const GatherArgs &a, uint32_t ntiles, uint32_t target, uint4 *items, uint32_t *itemCount,
-                    uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
-  hipLaunchKernelGGL(plan_kernel<B>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount);
-  hipLaunchKernelGGL(gather_bre_kernel<B>, dim3(nwaves), dim3(64), 0, stream, a, (const uint4 *)items,
-                     (const uint32_t *)itemCount, queueHead);
-}
-
 // itemCount / queueHead must be zero on entry (memset on the same stream)
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
                      uint32_t *itemCount, hipStream_t stream) {
   if (a.nsets == 0 || ntiles == 0) return;
   switch (beamsPerWave) {
     case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
-    case 16: hipLaunchKernelGGL(plan_kernel<16>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
-    default: hipLaunchKernelGGL(plan_kernel<32>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
+    case 32: hipLaunchKernelGGL(plan_kernel<32>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
+    default: hipLaunchKernelGGL(plan_kernel<16>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
   }
 }
 
@@ -852,8 +897,8 @@ void launch_gather_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items
   if (a.nsets == 0) return;
   switch (beamsPerWave) {
     case 64: hipLaunchKernelGGL(gather_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
-    case 16: hipLaunchKernelGGL(gather_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
-    default: hipLaunchKernelGGL(gather_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    case 32: hipLaunchKernelGGL(gather_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    default: hipLaunchKernelGGL(gather_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
   }
 }
 

@@ -109,8 +109,42 @@ __device__ __forceinline__ bool photonContributes(uint32_t flags, const gvpm_par
   return true;
 }
 
+// Occluders a shadow segment of length <= dmax starting at the photon's parent can reach:
+// parent within dmax of the triangle's plane and of its (dmax-inflated) bounding box.
+// Packs up to four 8-bit indices (0xFF = empty slot); 0xFE in the top byte = overflow / too many
+// occluders for 8-bit indices: the kernel then falls back to the full any-hit loop.
+__device__ __forceinline__ uint32_t nearOccluders(f3 P, const float *v0, const float *e1, const float *e2,
+                                                  uint32_t ntri, float dmax) {
+  if (ntri > 254u) return 0xFEFFFFFFu;
+  uint32_t list = 0xFFFFFFFFu, cnt = 0;
+  for (uint32_t i = 0; i < ntri; ++i) {
+    const f3 a = mk3(v0[3 * i], v0[3 * i + 1], v0[3 * i + 2]);
+    const f3 b = mk3(e1[3 * i], e1[3 * i + 1], e1[3 * i + 2]);
+    const f3 c = mk3(e2[3 * i], e2[3 * i + 1], e2[3 * i + 2]);
+    f3 n = cross(b, c);
+    const float l = sqrtf(dot(n, n));
+    if (l > 0.f) {
+      if (fabsf(dot(n, P - a)) > dmax * l) continue;
+    }
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float ak = comp(a, k), bk = comp(b, k), ck = comp(c, k), pk = comp(P, k);
+      const float lo = ak + fminf(0.f, fminf(bk, ck)), hi = ak + fmaxf(0.f, fmaxf(bk, ck));
+      if (pk < lo - dmax || pk > hi + dmax) out = true;
+    }
+    if (out) continue;
+    if (cnt == 4u) return 0xFEFFFFFFu;
+    list = (list & ~(0xFFu << (8 * cnt))) | (i << (8 * cnt));
+    cnt++;
+  }
+  return list;
+}
+
 __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ order, uint32_t n,
-                                                      gvpm_params cfg, float4 *hot, float4 *cold) {
+                                                      gvpm_params cfg, const float *triV0, const float *triE1,
+                                                      const float *triE2, uint32_t ntri, float dmax, float4 *hot,
+                                                      float4 *cold) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t src = order[i];
@@ -123,7 +157,8 @@ __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32
   cold[1 * N + i] = ld3(r.flux, src, r.edge_pdf[src]);
   cold[2 * N + i] = ld3(r.parent_pos, src, r.parent_rr[src]);
   cold[3 * N + i] = ld3(r.parent_n, src, r.parent_g[src]);
-  cold[4 * N + i] = ld3(r.prefix_w, src, 0.f);
+  const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
+  cold[4 * N + i] = ld3(r.prefix_w, src, __uint_as_float(nearOccluders(P, triV0, triE1, triE2, ntri, dmax)));
   cold[5 * N + i] = ld3(r.parent_scat, src, 0.f);
   cold[6 * N + i] = ld3(r.parent_wi, src, 0.f);
 }
@@ -191,11 +226,13 @@ void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *key
 }
 
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
+                    const float *triV0, const float *triE1, const float *triE2, uint32_t ntri, float dmax,
                     float4 *hot, float4 *cold, hipStream_t s) {
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, order, n, cfg, hot, cold);
+  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, order, n, cfg, triV0, triE1, triE2, ntri, dmax,
+                     hot, cold);
 }
 
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,

@@ -20,6 +20,7 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
+                    const float *triV0, const float *triE1, const float *triE2, uint32_t ntri, float dmax,
                     float4 *hot, float4 *cold, hipStream_t s);
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
                           hipStream_t s);
@@ -92,6 +93,7 @@ struct gvpm_context {
   // scene
   DevBuf<float> triV0, triE1, triE2;
   uint32_t ntri = 0;
+  float triMin[3] = {0, 0, 0}, triMax[3] = {0, 0, 0};  // occluder bounds (host side, at upload)
 
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid
   DevBuf<float> rawF;      // 28 floats per photon when owned
@@ -125,9 +127,9 @@ struct gvpm_context {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t eventsUsed = 0;
 
-  int beamsPerWave = 32;
+  int beamsPerWave = 16;
   float cellScale = 1.0f;
-  uint32_t planTarget = 4096;  // staged photons per work item
+  uint32_t planTarget = 1024;  // staged photons per work item
   uint32_t nwaves = 2048;      // persistent gather waves
   DevBuf<uint4> items;
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead
@@ -201,6 +203,11 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     int v = atoi(e);
     if (v == 16 || v == 32 || v == 64) h->beamsPerWave = v;
   }
+  // development switch (perf attribution only): bit 0 = skip the evaluations, keep the traversal
+  h->cfg.reserved[0] = 0;
+  if (const char *e = getenv("GVPM_DEBUG_FLAGS")) h->cfg.reserved[0] = atoi(e);
+  h->cfg.reserved[1] = 0;  // slab layers per step (0 = default)
+  if (const char *e = getenv("GVPM_SLAB_LAYERS")) h->cfg.reserved[1] = atoi(e);
   if (const char *e = getenv("GVPM_PLAN_TARGET")) {
     int v = atoi(e);
     if (v >= 64 && v <= (1 << 24)) h->planTarget = (uint32_t)v;
@@ -278,6 +285,17 @@ int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *t) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
   h->ntri = t->n;
+  for (int c = 0; c < 3; ++c) {
+    h->triMin[c] = INFINITY;
+    h->triMax[c] = -INFINITY;
+  }
+  for (uint32_t i = 0; i < t->n; ++i)
+    for (int c = 0; c < 3; ++c) {
+      const float a = t->v0[3 * i + c], b = a + t->e1[3 * i + c], d = a + t->e2[3 * i + c];
+      h->triMin[c] = fminf(h->triMin[c], fminf(a, fminf(b, d)));
+      h->triMax[c] = fmaxf(h->triMax[c], fmaxf(a, fmaxf(b, d)));
+    }
+  h->photonsDirty = h->havePhotons;  // the near-occluder lists depend on the scene
   return GVPM_OK;
 }
 
@@ -433,7 +451,16 @@ static int buildGrid(gvpm_context *h, float r) {
   launch_cell_keys(h->rawDev.pos, n, g, h->keysA.p, h->valsA.p, h->stream);
   HIP_TRY(h, sortPairsU32(h->sortTmp, h->keysA.p, h->keysB.p, h->valsA.p, h->valsB.p, n,
                           ilog2ceil(g.ncells + 1), h->stream));
-  launch_reorder(h->rawDev, h->valsB.p, n, h->cfg, h->hot.p, h->cold.p, h->stream);
+  // longest possible reconnection segment: diagonal of (occluders U photons), generously padded
+  float diag2 = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float lo = fminf(b6[c], h->ntri ? h->triMin[c] : b6[c]), hi = fmaxf(b6[3 + c], h->ntri ? h->triMax[c] : b6[3 + c]);
+    diag2 += (hi - lo) * (hi - lo);
+  }
+  const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
+  const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
+  launch_reorder(h->rawDev, h->valsB.p, n, h->cfg, h->triV0.p, h->triE1.p, h->triE2.p, h->ntri, dmax, h->hot.p,
+                 h->cold.p, h->stream);
   launch_segment_start(h->keysB.p, n, g.ncells, 0, h->cellStart.p, h->stream);
   HIP_TRY(h, hipGetLastError());
   return GVPM_OK;
