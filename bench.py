@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="initialScaleVolume")
     ap.add_argument("--distinct", type=int, default=16, help="distinct pre-generated iterations (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-window", type=int, default=128)
+    ap.add_argument("--cpu-window", type=int, default=512)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

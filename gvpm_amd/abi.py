@@ -114,6 +114,12 @@ CAMERA_RAY_DTYPE = np.dtype([
 assert CAMERA_RAY_DTYPE.itemsize == 64
 
 
+# gvpm_vpm_sample, 16 bytes
+VPM_SAMPLE_DTYPE = np.dtype([("set", np.uint32), ("rand", np.float32), ("pdf_sel", np.float32),
+                             ("reserved", np.uint32)])
+assert VPM_SAMPLE_DTYPE.itemsize == 16
+
+
 class Photons:
     """Host-side photon SoA as numpy arrays (owning), convertible to gvpm_photon_soa."""
 

@@ -25,13 +25,14 @@ __device__ __forceinline__ float A(const float *acc, int w, int x, int y, int k,
 }
 
 __global__ __launch_bounds__(256) void film_kernel(const float *__restrict__ acc, const float *__restrict__ emission,
-                                                   int w, int h, float it, int reusePrimal, float *thr, float *dx,
-                                                   float *dy) {
+                                                   int w, int h, float it, int reusePrimal, float invDiv,
+                                                   float *thr, float *dx, float *dy) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)w * h * 3) return;
   const int c = (int)(i % 3);
   const int x = (int)((i / 3) % w), y = (int)(i / 3 / w);
-  float v = A(acc, w, x, y, 0, c) + (emission ? emission[i] / it : 0.f);
+  // invDiv = 1 for APA estimators, 1/m_totalEmittedVolume otherwise (gvpm.cpp:489-492,526-528)
+  float v = A(acc, w, x, y, 0, c) * invDiv + (emission ? emission[i] / it : 0.f);
   if (reusePrimal) {
     float T = 0.f;
     if (x != w - 1) T += A(acc, w, x + 1, y, 1 + GVPM_LEFT, c);
@@ -40,15 +41,15 @@ __global__ __launch_bounds__(256) void film_kernel(const float *__restrict__ acc
     if (y != 0) T += A(acc, w, x, y - 1, 1 + GVPM_TOP, c);
     T += A(acc, w, x, y, 5 + GVPM_BOTTOM, c) + A(acc, w, x, y, 5 + GVPM_TOP, c) + A(acc, w, x, y, 5 + GVPM_RIGHT, c) +
          A(acc, w, x, y, 5 + GVPM_LEFT, c);
-    v = T / 4.0f;
+    v = (T / 4.0f) * invDiv;
   }
   thr[i] = v;
   float gx = A(acc, w, x, y, 1 + GVPM_RIGHT, c) - A(acc, w, x, y, 5 + GVPM_RIGHT, c);
   if (x != w - 1) gx += A(acc, w, x + 1, y, 5 + GVPM_LEFT, c) - A(acc, w, x + 1, y, 1 + GVPM_LEFT, c);
   float gy = A(acc, w, x, y, 1 + GVPM_TOP, c) - A(acc, w, x, y, 5 + GVPM_TOP, c);
   if (y != h - 1) gy += A(acc, w, x, y + 1, 5 + GVPM_BOTTOM, c) - A(acc, w, x, y + 1, 1 + GVPM_BOTTOM, c);
-  dx[i] = gx;
-  dy[i] = gy;
+  dx[i] = gx * invDiv;
+  dy[i] = gy * invDiv;
 }
 
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s) {
@@ -56,11 +57,11 @@ void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t
                      (float)it, 1.0f / (float)nbPaths);
 }
 
-void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float *thr,
-                 float *dx, float *dy, hipStream_t s) {
+void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
+                 float *thr, float *dx, float *dy, hipStream_t s) {
   const size_t n = (size_t)w * h * 3;
   hipLaunchKernelGGL(film_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, emission, w, h, (float)it,
-                     reusePrimal, thr, dx, dy);
+                     reusePrimal, invDiv, thr, dx, dy);
 }
 
 }  // namespace gvpm

@@ -53,6 +53,11 @@ struct GatherArgs {
   // config
   gvpm_params cfg;
   float radius;
+  // G-VPM only
+  const gvpm_vpm_sample *samples;
+  uint32_t nsamples;
+  const float *scaleVol;     // per pixel GatherPoint::scaleVol (read)
+  float *mvol;               // per pixel photons found this iteration (MVol, atomically added)
   // outputs
   float *iter;               // P * 27, this iteration's un-normalised sums
   unsigned long long *stats; // 8 counters (gvpm_stats order)

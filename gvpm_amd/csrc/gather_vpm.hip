@@ -1,0 +1,399 @@
+// G-VPM (3D point kernel) gather + gradient-domain shift for gfx950, hand-written HIP.
+//
+// Replaces, for one SPPM iteration, the body of
+//   GPMIntegrator::computeVolumeGradientPhoton        gvpm/gvpm.cpp:1081-1203
+//   PointKDTree::executeQuery (radius query)          include/mitsuba/core/kdtree.h:675-731
+//   VolumeGradientPositionQuery::operator()           gvpm/shift/shift_volume_photon.cpp:489-655
+//   VolumeGradientDistanceQuery pdfs                  gvpm/shift/shift_volume_photon.h:162-197
+//   HomogeneousMedium::sampleDistance(EDistanceAlwaysValid) / eval(EDistanceAlwaysValid)
+//                                                     src/medium/homogeneous.cpp:293-430,432-513
+// and shares shiftNull / shiftPhotonDiffuse / diffuseReconnection / getShiftPos / sensorMIS with the
+// BRE kernel (shift_device.h).
+//
+// One wave handles 64 consecutive camera samples (the host emits the nbCameraSamples samples of a
+// pixel consecutively, so a wave covers 1-2 pixels and its five-ray beam sets stay L1/LDS hot).
+// Every lane walks the <= 3x3x3 grid cells its query sphere touches, one candidate photon per
+// loop trip; hits are compacted (ballot + popcount) into an LDS ring and evaluated 64 at a time,
+// exactly like the BRE kernel.  The radius is per pixel (gp.scaleVol), the grid cell is the
+// largest radius of the iteration.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "shift_device.h"
+#include "vec.h"
+
+namespace gvpm {
+
+constexpr int VQ = 128;  // hit ring capacity
+
+struct VpmLds {
+  float4 ray4[5][3][64];
+  float gop[5][64];
+  float acc[27][64];
+  float4 tri[MAXTRI_LDS][3];
+  uint2 queue[VQ];
+  double t[64];        // sampled camera distance (mRec.t)
+  float pdfBase[64];   // pdfBaseRay() = mRec.pdfSuccess * pdfSel
+  float pdfSel[64];
+  float trBase[64];    // exp(-sigma_t (t - mint))
+  float radius[64];
+  uint32_t pix[64];
+  uint32_t edge[64];
+};
+
+__device__ __forceinline__ RayReg loadRayV(const VpmLds &s, int k, int b) {
+  RayReg r;
+  const float4 q0 = s.ray4[k][0][b], q1 = s.ray4[k][1][b], q2 = s.ray4[k][2][b];
+  r.o = mk3(q0.x, q0.y, q0.z);
+  r.len = fabsf(q0.w);
+  r.valid = q0.w >= 0.f;
+  r.d = mk3(q1.x, q1.y, q1.z);
+  r.pdf = q1.w;
+  r.eye = mk3(q2.x, q2.y, q2.z);
+  r.jac = q2.w;
+  r.gop = s.gop[k][b];
+  return r;
+}
+
+// One evaluation: VolumeGradientPositionQuery::operator() after the filters.
+__device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
+                                            uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+  const float4 hot = a.hot[pidx];
+  const uint32_t bits = __float_as_uint(hot.w);
+  const f3 pos = mk3(hot.x, hot.y, hot.z);
+  const PhotonCold ph = loadCold(a, pidx);
+  const RayReg base = loadRayV(s, 0, b);
+  const uint32_t edge = s.edge[b];
+  const uint32_t pix = s.pix[b];
+  const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
+  const float r = s.radius[b], r2 = r * r;
+  const double t = s.t[b];
+  const float tf = (float)t;
+  const float pdfBase = s.pdfBase[b], pdfSel = s.pdfSel[b];
+  const float sigT = a.med.sigmaT[0];
+  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r;
+  const float scale = norm / (kernelVol * pdfBase);
+
+  const f3 photonIn = sigS * ph.flux;
+  const f3 baseContrib = base.eye * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * s.trBase[b];
+  atomicAdd(&s.acc[0][b], baseContrib.x * scale);
+  atomicAdd(&s.acc[1][b], baseContrib.y * scale);
+  atomicAdd(&s.acc[2][b], baseContrib.z * scale);
+
+  const d3 pD = tod(pos);
+  const d3 basePt = tod(base.o) + tod(base.d) * t;  // baseRay(maxt)
+  const f3 rel = tof(pD - basePt);
+  // shiftMRec: Medium::eval(shiftRay, EDistanceAlwaysValid) with mRec.t = t: Tr = exp(-sigma_t t)
+  float trS = __expf(-sigT * tf);
+  if (trS < 1e-20f) trS = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const RayReg sh = loadRayV(s, 1 + i, b);
+    float w = 1.f;
+    f3 sflux = mk3(0.f);
+    // validShiftDist: valid edge and shiftDistMax >= baseRay.maxt (shift_volume_photon.cpp:546-566)
+    if (sh.valid && sh.len >= tf) {
+      // pdfShiftRay = shiftMRec.pdfSuccess * pdfSel, normalised over [Epsilon, shiftDistMax]
+      const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
+      const float pdfShift = (sigT / normS) * __expf(-sigT * tf) * pdfSel;
+      const f3 trShift = mk3(trS);
+      const d3 zP = tod(sh.o) + tod(sh.d) * t;
+      const f3 y = tof(pD - zP);
+      bool alreadyShifted = false;
+      if (a.cfg.use_shift_null && dot(y, y) < r2) {
+        // shiftNull, shift_volume_photon.cpp:119-158
+        alreadyShifted = true;
+        sflux = trShift * (photonIn * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
+        w = 0.5f;
+        if (a.cfg.use_mis) {
+          if (pdfShift == 0.f || pdfBase == 0.f) w = 1.f;
+          else w = 1.f / (1.f + sensorMIS(sh, base, edge) * pdfShift / pdfBase);
+        }
+        nNull++;
+      }
+      if (!alreadyShifted) {
+        // getShiftPos (coherent = false), shift_volume_photon.cpp:858-896
+        f3 offRel = rel;
+        if (a.cfg.use_shift_null) {
+          const f3 dS = tof(zP - basePt);
+          const f3 bo = dS + offRel;
+          if (dot(bo, bo) < r2) offRel = offRel + dS * (-2.f * dot(dS, offRel) / dot(dS, dS));
+        }
+        if (a.cfg.debug_shift != GVPM_SHIFT_NULL) {
+          const uint32_t st = GVPM_PF_SHIFT_TYPE(bits);
+          bool ok = false;
+          if (st == 1u || st == 2u) {
+            const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;
+            w = shiftDiffuse(a, s.tri, ph, bits, dProjU, sh, base, edge, trShift, pdfBase, pdfShift, sflux, ok);
+          }
+          if (ok) nDiff++; else nFail++;
+        }
+      }
+    }
+    if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
+    const float ws = w * scale;
+    if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+      atomicAdd(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
+      atomicAdd(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
+      atomicAdd(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+    }
+    atomicAdd(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
+    atomicAdd(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
+    atomicAdd(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
+  }
+}
+
+__global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
+  __shared__ VpmLds s;
+  const int lane = threadIdx.x;
+  const uint32_t sBase = blockIdx.x * 64u;
+  const uint32_t ns = min(64u, a.nsamples - sBase);
+  const float norm = 1.f / (float)a.cfg.nb_camera_samples;
+  const float eps = a.cfg.epsilon;
+
+  for (uint32_t i = lane; i < min(a.ntri, (uint32_t)MAXTRI_LDS); i += 64) {
+    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
+    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
+    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
+    f3 n = cross(e1, e2);
+    const float l = sqrtf(dot(n, n));
+    n = l > 0.f ? n * (1.f / l) : mk3(0.f);
+    s.tri[i][0] = make_float4(v0.x, v0.y, v0.z, n.x);
+    s.tri[i][1] = make_float4(e1.x, e1.y, e1.z, n.y);
+    s.tri[i][2] = make_float4(e2.x, e2.y, e2.z, n.z);
+  }
+  for (int idx = lane; idx < 27 * 64; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+
+  // ---- this lane's sample: rays -> LDS, distance sampling ----
+  bool active = (uint32_t)lane < ns;
+  uint32_t set = 0;
+  float rnd = 0.f, pdfSel = 1.f;
+  if (active) {
+    const gvpm_vpm_sample sm = a.samples[sBase + lane];
+    set = sm.set;
+    rnd = sm.rand;
+    pdfSel = sm.pdf_sel;
+    if (set >= a.nsets) active = false;
+  }
+  {
+    const int b = lane;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+      float4 q0 = make_float4(0, 0, 0, -1e-30f), q1 = make_float4(0, 0, 1, 0), q2 = make_float4(0, 0, 0, 0),
+             q3 = make_float4(0, 0, 0, 0);
+      if (active) {
+        const float4 *rp = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5 + k);
+        q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
+        const bool valid = GVPM_RAY_VALID(__float_as_uint(q3.y)) != 0;
+        const float l = fabsf(q0.w);
+        q0.w = valid ? l : -fmaxf(l, 1e-30f);
+      }
+      s.ray4[k][0][b] = q0; s.ray4[k][1][b] = q1; s.ray4[k][2][b] = q2;
+      s.gop[k][b] = q3.x;
+      if (k == 0) {
+        s.pix[b] = __float_as_uint(q3.w);
+        s.edge[b] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
+      }
+    }
+  }
+  __syncthreads();
+  const RayReg base = loadRayV(s, 0, lane);
+  active = active && base.valid;
+  // HomogeneousMedium::sampleDistance(Ray(o, d, Epsilon, beamDist), EDistanceAlwaysValid, rand),
+  // homogeneous.cpp:293-430 (balance strategy, currentMediumSampling = 1)
+  const double sigT = (double)a.med.sigmaT[1];
+  double t = 0.0;
+  float pdfBase = 0.f, trBase = 0.f;
+  const uint32_t pixv = s.pix[lane];
+  const uint32_t pixIdx = (pixv >> 16) * (uint32_t)a.cfg.width + (pixv & 0xFFFFu);
+  float radius = 0.f;
+  if (active) {
+    const double mint = (double)eps, maxt = (double)base.len;
+    const double maxDist = fmax((maxt - mint) - (double)eps, 0.0);
+    const double normalization = 1.0 - exp(-sigT * maxDist);
+    const double sampled = -log(1.0 - (double)rnd * normalization) / sigT;
+    const double distSurf = maxt - mint;
+    if (sampled < distSurf) {
+      t = sampled + mint;
+      const double nrm2 = 1.0 - exp(-sigT * distSurf);
+      const double e = exp(-sigT * sampled);
+      pdfBase = (float)((sigT / nrm2) * e) * pdfSel;  // mRec.pdfSuccess * pdfSel
+      trBase = (float)e;
+      if (trBase < 1e-20f) trBase = 0.f;
+      // querySize = R * POURCENTAGE_BS * gp.scaleVol, gvpm.cpp:1082,1132
+      radius = (a.cfg.bsphere_radius * 0.01f) * a.scaleVol[pixIdx];
+    } else {
+      active = false;  // "Failed to sample the distance" (cannot happen for rand < 1)
+    }
+  }
+  s.t[lane] = t;
+  s.pdfBase[lane] = pdfBase;
+  s.pdfSel[lane] = pdfSel;
+  s.trBase[lane] = trBase;
+  s.radius[lane] = radius;
+  __syncthreads();
+
+  // ---- cell box of the query sphere ----
+  const d3 qD = tod(base.o) + tod(base.d) * t;
+  const f3 q = tof(qD);
+  const Grid gr = a.grid;
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, bz0 = 0, bz1 = -1;
+  if (active && a.nph > 0) {
+    const float pad = radius * 1.0001f + 1e-6f;
+    bx0 = max(0, (int)floorf((q.x - pad - gr.org[0]) * gr.invCell));
+    bx1 = min(gr.dim[0] - 1, (int)floorf((q.x + pad - gr.org[0]) * gr.invCell));
+    by0 = max(0, (int)floorf((q.y - pad - gr.org[1]) * gr.invCell));
+    by1 = min(gr.dim[1] - 1, (int)floorf((q.y + pad - gr.org[1]) * gr.invCell));
+    bz0 = max(0, (int)floorf((q.z - pad - gr.org[2]) * gr.invCell));
+    bz1 = min(gr.dim[2] - 1, (int)floorf((q.z + pad - gr.org[2]) * gr.invCell));
+  }
+  const int nyr = by1 - by0 + 1, nzr = bz1 - bz0 + 1;
+  const int nrows = (bx1 >= bx0 && nyr > 0 && nzr > 0) ? nyr * nzr : 0;
+  int row = 0;
+  uint32_t cur = 0, end = 0;
+  const float r2f = radius * radius;
+  const double r2D = (double)radius * (double)radius;
+  const uint32_t edge = s.edge[lane];
+  uint32_t qHead = 0, qCount = 0;
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0, found = 0;
+  unsigned long long nCand = 0;
+
+  for (;;) {
+    // advance to the next non-empty row
+    while (cur >= end && row < nrows) {
+      const int y = by0 + row % nyr, z = bz0 + row / nyr;
+      const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
+      cur = a.cellStart[rb + bx0];
+      end = a.cellStart[rb + bx1 + 1];
+      row++;
+    }
+    const bool have = cur < end;
+    if (!__any(have)) break;
+    bool hit = false;
+    uint32_t gi = cur;
+    if (have) {
+      const float4 hp = a.hot[cur];
+      cur++;
+      nCand++;
+      const f3 p = mk3(hp.x, hp.y, hp.z);
+      const f3 dv = p - q;
+      const float d2 = dot(dv, dv);
+      // pointDistSquared < distSquared (kdtree.h:722) decided in fp32 unless within the error band
+      const float E = 3e-7f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
+      const float band = 4.f * radius * E + r2f * 2e-6f;
+      bool inside = d2 < r2f - band;
+      if (!inside && d2 < r2f + band) {
+#pragma clang fp contract(off)
+        const double dx = (double)p.x - qD.x, dy = (double)p.y - qD.y, dz = (double)p.z - qD.z;
+        inside = dx * dx + dy * dy + dz * dz < r2D;
+      }
+      if (inside) {
+        found++;
+        const uint32_t bits = __float_as_uint(hp.w);
+        // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
+        const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
+        hit = true;
+        if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
+        if (!((bits >> 6) & 1u)) hit = false;
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      if (hit) {
+        const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+        s.queue[(qHead + qCount + off) % VQ] = make_uint2(gi, (uint32_t)lane);
+      }
+      qCount += __popcll(m);
+      if (qCount >= 64u) {
+        __syncthreads();
+        const uint2 e = s.queue[(qHead + lane) % VQ];
+        evaluateVpm(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
+        nEval++;
+        qHead = (qHead + 64u) % VQ;
+        qCount -= 64u;
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  if ((uint32_t)lane < qCount) {
+    const uint2 e = s.queue[(qHead + lane) % VQ];
+    evaluateVpm(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
+    nEval++;
+  }
+  __syncthreads();
+  // ---- write out ----
+  for (int idx = lane; idx < 27 * 64; idx += 64) {
+    const int k = idx / 64, bb = idx % 64;
+    if ((uint32_t)bb < ns) {
+      const float v = s.acc[k][bb];
+      if (v != 0.f) {
+        const uint32_t pv = s.pix[bb];
+        const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+        atomicAdd(&a.iter[p * 27 + k], v);
+      }
+    }
+  }
+  if (found) atomicAdd(&a.mvol[pixIdx], (float)found);
+  {
+    unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail, ca = nCand;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ev += __shfl_xor(ev, o, 64);
+      nu += __shfl_xor(nu, o, 64);
+      di += __shfl_xor(di, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+      ca += __shfl_xor(ca, o, 64);
+    }
+    if (lane == 0 && (ev | ca)) {
+      atomicAdd(&a.stats[0], ev);
+      atomicAdd(&a.stats[1], ca);
+      atomicAdd(&a.stats[2], nu);
+      atomicAdd(&a.stats[3], di);
+      atomicAdd(&a.stats[4], fa);
+    }
+  }
+}
+
+// SPPM statistics of G-VPM, gvpm.cpp:1191-1195 (per pixel) + the largest scale for the next grid
+__global__ __launch_bounds__(256) void vpm_update_kernel(float *scaleVol, float *nVol, const float *mvol, size_t n,
+                                                         float alpha, uint32_t *maxScaleBits) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float sc = 0.f;
+  if (i < n) {
+    sc = scaleVol[i];
+    const float M = mvol[i], N = nVol[i];
+    if (M + N != 0.f) {
+      const float ratio = (N + alpha * M) / (N + M);
+      sc = sc * cbrtf(ratio);
+      scaleVol[i] = sc;
+      nVol[i] = N + alpha * M;
+    }
+  }
+  sc = wave_max(sc);
+  if ((threadIdx.x & 63) == 0) atomicMax(maxScaleBits, __float_as_uint(sc));  // positive floats order as uints
+}
+
+__global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ accum, const float *__restrict__ iter,
+                                                         size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) accum[i] += iter[i];
+}
+
+void launch_gather_vpm(const GatherArgs &a, hipStream_t stream) {
+  if (a.nsamples == 0) return;
+  hipLaunchKernelGGL(gather_vpm_kernel, dim3((a.nsamples + 63u) / 64u), dim3(64), 0, stream, a);
+}
+
+void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(vpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scaleVol, nVol, mvol, n,
+                     alpha, maxScaleBits);
+}
+
+void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, accum, iter, n);
+}
+
+}  // namespace gvpm

@@ -32,8 +32,12 @@ void launch_gather_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items
                        uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
-void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float *thr,
-                 float *dx, float *dy, hipStream_t s);
+void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
+                 float *thr, float *dx, float *dy, hipStream_t s);
+void launch_gather_vpm(const GatherArgs &a, hipStream_t stream);
+void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
+                       hipStream_t stream);
+void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);
 }  // namespace gvpm
 
 using namespace gvpm;
@@ -115,6 +119,15 @@ struct gvpm_context {
   bool haveBeams = false, beamsDirty = false;
   DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
   uint32_t ntiles = 0;
+
+  // G-VPM: camera samples + per-pixel SPPM state
+  DevBuf<gvpm_vpm_sample> samplesOwned;
+  const gvpm_vpm_sample *samplesDev = nullptr;
+  uint32_t nsamples = 0;
+  bool haveSamples = false;
+  DevBuf<float> scaleVol, nVol, mvol;
+  DevBuf<uint32_t> maxScaleBits;
+  double totalEmitted = 0;   // m_totalEmittedVolume
 
   // film
   DevBuf<float> accum, accumAll, iter, filmOut, emission;
@@ -227,7 +240,9 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   }
   h->npix = (size_t)params->width * params->height;
   if (h->accum.ensure(h->npix * 27) != hipSuccess || h->iter.ensure(h->npix * 27) != hipSuccess ||
-      h->stats.ensure(8) != hipSuccess) {
+      h->stats.ensure(8) != hipSuccess || h->scaleVol.ensure(h->npix) != hipSuccess ||
+      h->nVol.ensure(h->npix) != hipSuccess || h->mvol.ensure(h->npix) != hipSuccess ||
+      h->maxScaleBits.ensure(2) != hipSuccess) {
     gvpm_destroy(h);
     return GVPM_ERR_HIP;
   }
@@ -256,6 +271,7 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->sortTmp.d) (void)hipFree(h->sortTmp.d);
   h->raysOwned.release(); h->bKeysA.release(); h->bKeysB.release(); h->bValsA.release();
   h->setPerm.release(); h->tileStart.release(); h->items.release(); h->queueCtl.release();
+  h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -269,6 +285,18 @@ int gvpm_reset(gvpm_context *h) {
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
   h->eventsUsed = 0;
   h->useAll = false;
+  h->totalEmitted = 0;
+  {
+    // newGP.scaleVol = initialScaleVolume, NVol = 0 (gvpm.cpp:285-288)
+    std::vector<float> init(h->npix, h->cfg.initial_scale_volume);
+    HIP_TRY(h, hipMemcpyAsync(h->scaleVol.p, init.data(), h->npix * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->nVol.p, 0, h->npix * sizeof(float), h->stream));
+    uint32_t bits;
+    const float sc = h->cfg.initial_scale_volume;
+    memcpy(&bits, &sc, 4);
+    HIP_TRY(h, hipMemcpyAsync(h->maxScaleBits.p, &bits, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   return GVPM_OK;
 }
 
@@ -395,6 +423,33 @@ int gvpm_upload_camera_beams_dev(gvpm_context *h, const gvpm_camera_ray *rays, u
   return uploadBeamsCommon(h, rays, n_sets, true);
 }
 
+static int uploadSamplesCommon(gvpm_context *h, const gvpm_vpm_sample *smp, uint64_t n, bool fromDevice) {
+  if (n && !smp) return fail(h, GVPM_ERR_INVALID_ARG, "null vpm samples");
+  if (n > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many vpm samples");
+  if (fromDevice) {
+    h->samplesDev = smp;
+  } else {
+    HIP_TRY(h, h->samplesOwned.ensure(n + 1));
+    if (n) {
+      HIP_TRY(h, hipMemcpyAsync(h->samplesOwned.p, smp, n * sizeof(gvpm_vpm_sample), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->samplesDev = h->samplesOwned.p;
+  }
+  h->nsamples = (uint32_t)n;
+  h->haveSamples = true;
+  return GVPM_OK;
+}
+
+int gvpm_upload_vpm_samples(gvpm_context *h, const gvpm_vpm_sample *samples, uint64_t n) {
+  CHECK_H(h);
+  return uploadSamplesCommon(h, samples, n, false);
+}
+int gvpm_upload_vpm_samples_dev(gvpm_context *h, const gvpm_vpm_sample *samples, uint64_t n) {
+  CHECK_H(h);
+  return uploadSamplesCommon(h, samples, n, true);
+}
+
 static float currentRadius(const gvpm_context *h) {
   // breInitSize = bsphere.radius * globalScaleVolume * POURCENTAGE_BS, gvpm.cpp:989 (Float = float)
   return h->cfg.bsphere_radius * h->globalScaleVolume * 0.01f;
@@ -492,28 +547,7 @@ static int sortBeams(gvpm_context *h) {
   return GVPM_OK;
 }
 
-int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
-  CHECK_H(h);
-  if (it < 1 || nb_paths == 0) return fail(h, GVPM_ERR_INVALID_ARG, "it must be >= 1 and nb_paths > 0");
-  if (!h->haveMedium || !h->havePhotons || !h->haveBeams)
-    return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
-  if (h->cfg.vol_technique != GVPM_VOL_BRE2D && h->cfg.vol_technique != GVPM_VOL_BRE3D)
-    return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
-  const float r = currentRadius(h);
-  if (h->photonsDirty || r != h->builtRadius) {
-    int rc = buildGrid(h, r);
-    if (rc != GVPM_OK) return rc;
-    h->photonsDirty = false;
-    h->builtRadius = r;
-  }
-  if (h->beamsDirty) {
-    int rc = sortBeams(h);
-    if (rc != GVPM_OK) return rc;
-    h->beamsDirty = false;
-  }
-  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
-  h->useAll = false;
-  GatherArgs a;
+static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   memset(&a, 0, sizeof(a));
   a.hot = h->hot.p;
   a.cold = h->cold.p;
@@ -538,6 +572,13 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   a.radius = r;
   a.iter = h->iter.p;
   a.stats = h->stats.p;
+  a.samples = h->samplesDev;
+  a.nsamples = h->nsamples;
+  a.scaleVol = h->scaleVol.p;
+  a.mvol = h->mvol.p;
+}
+
+static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev) {
   // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved)
   if (h->eventsUsed == h->events.size()) {
     hipEvent_t e0, e1;
@@ -545,14 +586,37 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, hipEventCreate(&e1));
     h->events.emplace_back(e0, e1);
   }
-  auto &ev = h->events[h->eventsUsed++];
+  *ev = &h->events[h->eventsUsed++];
+  return GVPM_OK;
+}
+
+// computeVolumeGradientPhotonBRE, gvpm.cpp:988-1079
+static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
+  const float r = currentRadius(h);
+  if (h->photonsDirty || r != h->builtRadius) {
+    int rc = buildGrid(h, r);
+    if (rc != GVPM_OK) return rc;
+    h->photonsDirty = false;
+    h->builtRadius = r;
+  }
+  if (h->beamsDirty) {
+    int rc = sortBeams(h);
+    if (rc != GVPM_OK) return rc;
+    h->beamsDirty = false;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  GatherArgs a;
+  fillArgs(h, a, r);
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
   HIP_TRY(h, h->items.ensure(plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave)));
   HIP_TRY(h, h->queueCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
   launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->stream);
-  HIP_TRY(h, hipEventRecord(ev.first, h->stream));
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   launch_gather_bre(a, h->beamsPerWave, h->items.p, h->queueCtl.p, h->queueCtl.p + 1, h->nwaves, h->stream);
-  HIP_TRY(h, hipEventRecord(ev.second, h->stream));
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
   // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
@@ -563,6 +627,65 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     else if (h->cfg.vol_technique == GVPM_VOL_BRE2D) f = std::sqrt(ratio);
     h->globalScaleVolume = (float)(h->globalScaleVolume * f);
   }
+  return GVPM_OK;
+}
+
+// computeVolumeGradientPhoton (G-VPM), gvpm.cpp:1081-1203
+static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
+  (void)it;
+  if (!h->haveSamples) return fail(h, GVPM_ERR_STATE, "G-VPM gather needs gvpm_upload_vpm_samples");
+  if (h->cfg.nb_camera_samples <= 0) return fail(h, GVPM_ERR_INVALID_ARG, "nb_camera_samples must be positive");
+  // grid cell = the largest per-pixel radius R * 0.01 * max(scaleVol)
+  uint32_t bits = 0;
+  HIP_TRY(h, hipMemcpyAsync(&bits, h->maxScaleBits.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float maxScale;
+  memcpy(&maxScale, &bits, 4);
+  const float rmax = (h->cfg.bsphere_radius * 0.01f) * maxScale;
+  if (h->photonsDirty || rmax != h->builtRadius) {
+    int rc = buildGrid(h, rmax);
+    if (rc != GVPM_OK) return rc;
+    h->photonsDirty = false;
+    h->builtRadius = rmax;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->maxScaleBits.p, 0, 4, h->stream));
+  GatherArgs a;
+  fillArgs(h, a, rmax);
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+  launch_gather_vpm(a, h->stream);
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->stream);
+  launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  h->totalEmitted += (double)nb_paths;  // m_totalEmittedVolume, gvpm.cpp:434
+  return GVPM_OK;
+}
+
+int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
+  CHECK_H(h);
+  if (it < 1 || nb_paths == 0) return fail(h, GVPM_ERR_INVALID_ARG, "it must be >= 1 and nb_paths > 0");
+  if (!h->haveMedium || !h->havePhotons || !h->haveBeams)
+    return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
+  h->useAll = false;
+  switch (h->cfg.vol_technique) {
+    case GVPM_VOL_BRE2D:
+    case GVPM_VOL_BRE3D: return gatherBRE(h, it, nb_paths);
+    case GVPM_DISTANCE: return gatherVPM(h, it, nb_paths);
+    default: return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
+  }
+}
+
+int gvpm_download_vpm_state(gvpm_context *h, float *scale_vol, float *n_vol) {
+  CHECK_H(h);
+  if (!scale_vol || !n_vol) return GVPM_ERR_INVALID_ARG;
+  HIP_TRY(h, hipMemcpyAsync(scale_vol, h->scaleVol.p, h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(n_vol, h->nVol.p, h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GVPM_OK;
 }
 
@@ -638,8 +761,11 @@ int gvpm_download_film(gvpm_context *h, int it, int reuse_primal, const float *e
     HIP_TRY(h, hipMemcpyAsync(h->emission.p, emission, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     em = h->emission.p;
   }
-  launch_film(h->useAll ? h->accumAll.p : h->accum.p, em, h->cfg.width, h->cfg.height, it, reuse_primal, h->filmOut.p, h->filmOut.p + n,
-              h->filmOut.p + 2 * n, h->stream);
+  // non-APA estimators are normalised by the emitted path count (gvpm.cpp:489-492)
+  float invDiv = 1.f;
+  if (h->cfg.vol_technique == GVPM_DISTANCE) invDiv = h->totalEmitted > 0 ? (float)(1.0 / h->totalEmitted) : 0.f;
+  launch_film(h->useAll ? h->accumAll.p : h->accum.p, em, h->cfg.width, h->cfg.height, it, reuse_primal, invDiv,
+              h->filmOut.p, h->filmOut.p + n, h->filmOut.p + 2 * n, h->stream);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(throughput, h->filmOut.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(dx, h->filmOut.p + n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -18,7 +18,8 @@ _LIB = None
 SYMBOLS = [
     "gvpm_create", "gvpm_destroy", "gvpm_last_error", "gvpm_abi_version", "gvpm_reset",
     "gvpm_upload_scene", "gvpm_upload_medium", "gvpm_upload_photons", "gvpm_upload_camera_beams",
-    "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_gather", "gvpm_get_radius",
+    "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_upload_vpm_samples",
+    "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
     "gvpm_allreduce_accum",
@@ -52,6 +53,9 @@ def lib():
         L.gvpm_upload_photons_dev.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
         L.gvpm_upload_camera_beams.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_camera_beams_dev.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_vpm_samples.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_vpm_samples_dev.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_download_vpm_state.argtypes = [vp, vp, vp]
         L.gvpm_gather.argtypes = [vp, C.c_int, C.c_uint64]
         L.gvpm_get_radius.argtypes = [vp, C.POINTER(C.c_float)]
         L.gvpm_set_global_scale.argtypes = [vp, C.c_float]
@@ -121,6 +125,20 @@ class Context:
 
     def upload_camera_beams_dev(self, dev_ptr, n_sets):
         self._check(lib().gvpm_upload_camera_beams_dev(self._h, dev_ptr, n_sets))
+
+    def upload_vpm_samples(self, samples):
+        samples = np.ascontiguousarray(samples)
+        assert samples.dtype == abi.VPM_SAMPLE_DTYPE
+        self._check(lib().gvpm_upload_vpm_samples(self._h, samples.ctypes.data if samples.size else None, samples.size))
+
+    def upload_vpm_samples_dev(self, dev_ptr, n):
+        self._check(lib().gvpm_upload_vpm_samples_dev(self._h, dev_ptr, n))
+
+    def download_vpm_state(self):
+        H, W = self.params.height, self.params.width
+        sv, nv = np.zeros((H, W), np.float32), np.zeros((H, W), np.float32)
+        self._check(lib().gvpm_download_vpm_state(self._h, sv.ctypes.data, nv.ctypes.data))
+        return sv, nv
 
     def gather(self, it, nb_paths):
         self._check(lib().gvpm_gather(self._h, it, nb_paths))

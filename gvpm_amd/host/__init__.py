@@ -31,6 +31,8 @@ def lib():
         L.gvpm_synth_beams.restype = C.c_uint64
         L.gvpm_synth_beams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_void_p)]
+        L.gvpm_synth_vpm_samples.restype = C.c_uint64
+        L.gvpm_synth_vpm_samples.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
 
@@ -87,3 +89,13 @@ class SynthScene:
             return np.zeros((0, 5), abi.CAMERA_RAY_DTYPE)
         buf = (C.c_char * (n * 5 * 64)).from_address(ptr.value)
         return np.frombuffer(buf, abi.CAMERA_RAY_DTYPE).reshape(n, 5).copy()
+
+    def camera_beams_and_vpm_samples(self, iteration, nb_camera_samples, x0=0, y0=0, x1=None, y1=None):
+        """-> (rays (n_sets,5), samples (n_sets*nb,) VPM_SAMPLE_DTYPE) for one G-VPM iteration"""
+        rays = self.camera_beams(iteration, x0, y0, x1, y1)
+        ptr = C.c_void_p()
+        n = lib().gvpm_synth_vpm_samples(self._h, iteration, nb_camera_samples, C.byref(ptr))
+        if n == 0:
+            return rays, np.zeros(0, abi.VPM_SAMPLE_DTYPE)
+        buf = (C.c_char * (n * 16)).from_address(ptr.value)
+        return rays, np.frombuffer(buf, abi.VPM_SAMPLE_DTYPE).copy()

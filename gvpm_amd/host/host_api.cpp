@@ -9,6 +9,7 @@ struct gvpm_synth {
   gvpm::PhotonBuffers photons;
   std::vector<gvpm_camera_ray> rays;
   std::vector<float> v0, e1, e2;
+  std::vector<gvpm_vpm_sample> samples;
 };
 
 extern "C" {
@@ -68,5 +69,12 @@ uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
   gvpm::cameraBeams(s->scene, it, x0, y0, x1, y1, s->rays);
   *out = s->rays.data();
   return s->rays.size() / 5;
+}
+
+uint64_t gvpm_synth_vpm_samples(gvpm_synth *s, int it, int nb_camera_samples, const gvpm_vpm_sample **out) {
+  if (!s || !out || nb_camera_samples <= 0) return 0;
+  gvpm::cameraSamplesVPM(s->scene, it, s->rays, nb_camera_samples, s->samples);
+  *out = s->samples.data();
+  return s->samples.size();
 }
 }

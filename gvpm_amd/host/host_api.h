@@ -20,6 +20,8 @@ uint64_t gvpm_synth_shoot(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_
 /* camera beam sets of the pixel rectangle; returns the number of sets */
 uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
                           const gvpm_camera_ray **out);
+/* G-VPM camera samples for the beam sets of the LAST gvpm_synth_beams call */
+uint64_t gvpm_synth_vpm_samples(gvpm_synth *s, int it, int nb_camera_samples, const gvpm_vpm_sample **out);
 #ifdef __cplusplus
 }
 #endif

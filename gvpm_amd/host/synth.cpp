@@ -616,4 +616,23 @@ void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, in
   }
 }
 
+void cameraSamplesVPM(const SynthScene &sc, int iteration, const std::vector<gvpm_camera_ray> &rays,
+                      int nbCameraSamples, std::vector<gvpm_vpm_sample> &out) {
+  out.clear();
+  const size_t nsets = rays.size() / 5;
+  for (size_t s = 0; s < nsets; ++s) {
+    const uint32_t pix = rays[5 * s].pixel;
+    const uint32_t idx = (pix >> 16) * (uint32_t)sc.width + (pix & 0xFFFFu);
+    Philox rng(sc.seed, 0x5a3fu, (uint32_t)iteration, idx);
+    for (int k = 0; k < nbCameraSamples; ++k) {
+      gvpm_vpm_sample sm;
+      sm.set = (uint32_t)s;
+      sm.rand = rng.next1D();  // sampleReuse over a single-entry CDF leaves the sample unchanged
+      sm.pdf_sel = 1.f;
+      sm.reserved = 0;
+      out.push_back(sm);
+    }
+  }
+}
+
 }  // namespace gvpm

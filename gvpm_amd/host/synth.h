@@ -75,6 +75,11 @@ uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, Ph
 void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,
                  std::vector<gvpm_camera_ray> &out);
 
+// G-VPM camera samples for beam sets produced by cameraBeams(): nbCameraSamples records per set,
+// consecutive per pixel (gvpm.cpp:1143-1172 with a one-edge camera path: selBeam = {1}).
+void cameraSamplesVPM(const SynthScene &sc, int iteration, const std::vector<gvpm_camera_ray> &rays,
+                      int nbCameraSamples, std::vector<gvpm_vpm_sample> &out);
+
 void defaultParams(const SynthScene &sc, gvpm_params &p);
 
 }  // namespace gvpm

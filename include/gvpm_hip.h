@@ -216,10 +216,16 @@ typedef struct gvpm_camera_ray {
 #define GVPM_RAY_EDGE(info) (((info) >> 8) & 0xFFu)
 #define GVPM_RAY_INFO(valid, edge) (((uint32_t)(valid) & 1u) | (((uint32_t)(edge) & 0xFFu) << 8))
 
-/* G-VPM only: extra per-sample data (gvpm.cpp:1117-1172): the base ray's
- * `rand` is randSample, `pdf_sel` = selBeam[sampleIndex].                     */
+/* G-VPM only: one record per camera sample (gvpm.cpp:1143-1180).  The host keeps the
+ * per-path part of the loop -- the CDF over the medium edges of the pixel's camera path
+ * (selBeam, :1117-1129) and sampleReuse (:1148) -- and hands over, per sample, which beam
+ * set was selected, the re-used random number that drives sampleDistance(EDistanceAlwaysValid)
+ * (:1168) and the selection probability selBeam[sampleIndex].  Samples of one pixel must be
+ * consecutive (they are summed in order).                                                  */
 typedef struct gvpm_vpm_sample {
-  float pdf_sel;
+  uint32_t set;      /* index of the beam set (pixel, medium edge) in the uploaded rays      */
+  float rand;        /* randSample after sampleReuse                                        */
+  float pdf_sel;     /* selBeam[sampleIndex]                                                */
   uint32_t reserved;
 } gvpm_vpm_sample;
 
@@ -259,25 +265,35 @@ int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *photons);
  * any order; several sets may address the same pixel (several medium edges). */
 int gvpm_upload_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays,
                              uint64_t n_sets);
+/* G-VPM: the camera samples of this iteration (n = pixels_with_medium * nbCameraSamples)   */
+int gvpm_upload_vpm_samples(gvpm_context *h, const gvpm_vpm_sample *samples, uint64_t n);
 /* the same, source buffers already in device memory                          */
 int gvpm_upload_photons_dev(gvpm_context *h, const gvpm_photon_soa *photons_dev);
 int gvpm_upload_camera_beams_dev(gvpm_context *h,
                                  const gvpm_camera_ray *rays_dev,
                                  uint64_t n_sets);
+int gvpm_upload_vpm_samples_dev(gvpm_context *h, const gvpm_vpm_sample *samples_dev, uint64_t n);
 
 /* ---- the hot path ---------------------------------------------------------*/
 /* One SPPM iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079;
- * vol_technique BRE2D/BRE3D) or computeVolumeGradientPhoton (:1081-1203;
- * DISTANCE): builds the acceleration structure over the uploaded photons,
- * gathers every uploaded beam set, normalises by nb_paths, folds the result
- * into the APA running mean with iteration `it` (1-based) and applies
- * scaleVolumeAPA(it) (gvpm.cpp:181-215).  Asynchronous on the handle's stream. */
+ * vol_technique BRE2D/BRE3D): builds the acceleration structure over the
+ * uploaded photons, gathers every uploaded beam set, normalises by nb_paths,
+ * folds the result into the APA running mean with iteration `it` (1-based) and
+ * applies scaleVolumeAPA(it) (gvpm.cpp:181-215).
+ * vol_technique DISTANCE: computeVolumeGradientPhoton (gvpm.cpp:1081-1203):
+ * gathers every uploaded camera sample with the per-pixel radius
+ * R*0.01*scaleVol, ADDS the result (x 1/nbCameraSamples) to the accumulators
+ * (plain sums; gvpm_download_film divides by the total emitted path count as
+ * gvpm.cpp:489-492 does) and applies the per-pixel SPPM update of scaleVol /
+ * NVol (:1191-1195).  Asynchronous on the handle's stream.                   */
 int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths);
 
 /* current kernel radius R*0.01*globalScaleVolume (gvpm.cpp:989)              */
 int gvpm_get_radius(gvpm_context *h, float *radius);
 int gvpm_set_global_scale(gvpm_context *h, float global_scale_volume);
 int gvpm_get_stats(gvpm_context *h, gvpm_stats *out);
+/* G-VPM per-pixel SPPM state (GatherPoint::scaleVol / NVol), width*height floats each */
+int gvpm_download_vpm_state(gvpm_context *h, float *scale_vol, float *n_vol);
 /* average duration in ms of the gather kernel launches since the last call,
  * measured with HIP events on the handle's stream, and their number          */
 int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches);

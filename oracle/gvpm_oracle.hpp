@@ -652,6 +652,94 @@ template <typename F> struct VolumeGradientRecord {
       shiftedMediumFlux[i] += result.shiftedFlux * (rrGlobalWeight * result.weight) / (kernelVol * pdfCameraPos);
     }
   }
+
+  // ---- G-VPM: VolumeGradientPositionQuery / VolumeGradientDistanceQuery state,
+  // shift_volume_photon.h:124-197
+  F searchRadius = 0;
+  MRec<F> baseMRec;           // from sampleDistance(EDistanceAlwaysValid)
+  F baseDistPDF = 0, pdfSelSection = 1;
+  MRec<F> shiftMRec[4];
+  bool shiftMRecIntialized = false;
+  bool validShiftDist[4] = {false, false, false, false};
+  F shiftDistCamera[4] = {-1, -1, -1, -1};
+
+  void resetMediumRecCache() {
+    for (int i = 0; i < 4; ++i) {
+      validShiftDist[i] = false;
+      shiftDistCamera[i] = -1.f;
+    }
+    shiftMRecIntialized = false;
+  }
+  F pdfBaseRay() const { return baseDistPDF * pdfSelSection; }
+  F pdfShiftRay(int id) const { return shiftMRec[id].pdfSuccess * pdfSelSection; }
+
+  // VolumeGradientPositionQuery::operator(), shift_volume_photon.cpp:489-655
+  void vpmFunctor(const Photon<F> &ph) {
+    const double M_PI_D = 3.14159265358979323846;
+    const gvpm_params &config = ctx.cfg;
+    V pos = baseRay(baseRay.maxt);
+    F lengthSqr = (pos - ph.pos).lengthSquared();
+    if ((searchRadius * searchRadius - lengthSqr) < 0) return;
+    const int depth = (int)GVPM_PF_DEPTH(ph.flags);
+    size_t pathLength = (size_t)(currEdge + depth);
+    if ((config.max_depth > 0 && pathLength > (size_t)config.max_depth)) return;
+    if (!computeVolumeContribution(ph)) return;
+    if (config.debug_shift != GVPM_SHIFT_ALL && config.debug_shift != GVPM_SHIFT_NULL) {
+      if (config.debug_shift != shiftTypeEnum(ph)) return;
+    }
+    V photonContrib = getVolumePhotonContrib(ph.flux, baseMRec, ph.wi, -baseRay.d);
+    V eyeContrib = baseGather->eye;
+    V baseContrib = eyeContrib * baseMRec.transmittance * photonContrib;
+    F kernelVol = (F)((4.0 / 3.0) * M_PI_D * std::pow((double)searchRadius, 3));
+    mediumFlux += baseContrib / (kernelVol * pdfBaseRay());
+    cnt.evaluations++;
+
+    for (int i = 0; i < 4; ++i) {
+      GradientSamplingResult<F> result;
+      F additionalJacobian = 1.f;
+      if (shiftGPs[i].valid && !shiftMRecIntialized) {
+        const CamRay<F> &shiftGather = shiftGPs[i];
+        V shiftDir = shiftGather.d;
+        F shiftDistMax = shiftGather.len;
+        if (shiftDistMax >= baseRay.maxt) {
+          validShiftDist[i] = true;
+          shiftDistCamera[i] = baseRay.maxt;
+          Ray<F> shiftRay(shiftGather.o, shiftDir, ctx.Epsilon, shiftDistMax);
+          shiftMRec[i].t = shiftDistCamera[i];
+          ctx.medium.eval(shiftRay, shiftMRec[i], true);
+        }
+      }
+      if (validShiftDist[i]) {
+        const CamRay<F> &shiftGather = shiftGPs[i];
+        Ray<F> shiftRay(shiftGather.o, shiftGather.d, ctx.Epsilon, shiftDistCamera[i]);
+        bool alreadyShifted = false;
+        if (config.use_shift_null) {
+          F distSqr = (ph.pos - shiftRay(shiftRay.maxt)).lengthSquared();
+          if (distSqr < searchRadius * searchRadius) {
+            alreadyShifted = true;
+            shiftNull(ph.flux, ph.wi, shiftGather, shiftRay, shiftMRec[i], result, pdfBaseRay(), pdfShiftRay(i),
+                      additionalJacobian);
+          }
+        }
+        if (!alreadyShifted) {
+          V offsetPos = getShiftPos(shiftRay, searchRadius, ph.pos);
+          if (config.debug_shift != GVPM_SHIFT_NULL) {
+            shiftPhoton(offsetPos, ph, shiftGather, shiftRay, shiftMRec[i], result, pdfBaseRay(), pdfShiftRay(i),
+                        additionalJacobian);
+          }
+        }
+      } else {
+        result.weight = 1.f;
+      }
+      if ((i == GVPM_RIGHT && baseGather->px == config.width - 1) ||
+          (i == GVPM_TOP && baseGather->py == config.height - 1)) {
+        result.weight = 1.0f;
+      }
+      shiftedMediumFlux[i] += result.shiftedFlux * result.weight / (kernelVol * pdfBaseRay());
+      weightedMediumFlux[i] += baseContrib * result.weight / (kernelVol * pdfBaseRay());
+    }
+    shiftMRecIntialized = true;
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -806,6 +894,62 @@ template <typename F> struct PhotonMap {
     }
   }
 
+  // PointKDTree::executeQuery(p, searchRadius, functor), include/mitsuba/core/kdtree.h:675-731.
+  // Returns the number of functor invocations (MVol).
+  template <typename Q> size_t executeQuery(const V &p, F searchRadius, Q &functor) const {
+    if (photons.empty()) return 0;
+    std::vector<uint32_t> stackStorage(depth + 2);
+    uint32_t *stack = stackStorage.data();
+    uint32_t index = 0, stackPos = 1, found = 0;
+    F distSquared = searchRadius * searchRadius;
+    stack[0] = 0;
+    while (stackPos > 0) {
+      const uint32_t cur = index;
+      uint32_t nextIndex;
+      if (!isLeaf(cur)) {
+        const int axis = nodeFlags[cur] & 0x0F;
+        F distToPlane = p[axis] - photons[cur].pos[axis];
+        bool searchBoth = distToPlane * distToPlane <= distSquared;
+        const bool hasRight = right[cur] != 0;
+        if (distToPlane > 0) {
+          if (hasRight) {
+            if (searchBoth) stack[stackPos++] = cur + 1;
+            nextIndex = right[cur];
+          } else if (searchBoth) {
+            nextIndex = cur + 1;
+          } else {
+            nextIndex = stack[--stackPos];
+          }
+        } else {
+          if (searchBoth && hasRight) stack[stackPos++] = right[cur];
+          nextIndex = cur + 1;
+        }
+      } else {
+        nextIndex = stack[--stackPos];
+      }
+      const F pointDistSquared = (photons[cur].pos - p).lengthSquared();
+      functor.cnt.candidates++;
+      if (pointDistSquared < distSquared) {
+        ++found;
+        functor.vpmFunctor(photons[cur]);
+      }
+      index = nextIndex;
+    }
+    return (size_t)found;
+  }
+  template <typename Q> size_t executeQueryBrute(const V &p, F searchRadius, Q &functor) const {
+    size_t found = 0;
+    F distSquared = searchRadius * searchRadius;
+    for (uint32_t i = 0; i < photons.size(); ++i) {
+      functor.cnt.candidates++;
+      if ((photons[i].pos - p).lengthSquared() < distSquared) {
+        ++found;
+        functor.vpmFunctor(photons[i]);
+      }
+    }
+    return found;
+  }
+
   // Accel-free hit set: a photon is a candidate iff its OWN sphere box passes the slab test
   // against [ray.mint, ray.maxt].  For every photon whose projection falls inside the beam
   // (mint < diskDistance <= maxt) this is exactly what the reference BVH visits (the closest
@@ -872,6 +1016,41 @@ template <typename F> struct Gatherer {
     cnt.add(gRec.cnt);
   }
 };
+
+// One camera sample of computeVolumeGradientPhoton's inner loop, gvpm.cpp:1143-1180.
+// iter: 27 F values of the pixel (already multiplied by `normalization`); returns MVol of the sample.
+template <typename F>
+inline size_t gatherSampleVPM(const Gatherer<F> &g, const gvpm_camera_ray *set, F rand, F pdfSel, F querySize,
+                              F normalization, bool useAccel, F *iter, Counters &cnt) {
+  CamRay<F> base(set[0]);
+  CamRay<F> shifts[4] = {CamRay<F>(set[1]), CamRay<F>(set[2]), CamRay<F>(set[3]), CamRay<F>(set[4])};
+  // Ray ray(oBeam, dBeam, Epsilon, beamDist), gvpm.cpp:1165
+  Ray<F> ray(base.o, base.d, g.ctx.Epsilon, base.len);
+  MRec<F> mRec;
+  mRec.t = 0;
+  if (!g.ctx.medium.sampleDistanceAlwaysValid(ray, mRec, rand, g.ctx.Epsilon)) return 0;
+  ray.maxt = mRec.t;
+  VolumeGradientRecord<F> gRec(g.ctx, &base, shifts);
+  // changeEdge + newRayBase(ray, mRec, querySize, mRec.pdfSuccess), shift_volume_photon.h:134-176
+  gRec.pdfSelSection = pdfSel;
+  gRec.baseRay = ray;
+  gRec.resetMediumRecCache();
+  gRec.baseMRec = mRec;
+  gRec.searchRadius = querySize;
+  gRec.baseDistPDF = mRec.pdfSuccess;
+  gRec.clear();
+  const Vec3<F> p = ray.o + ray.d * mRec.t;
+  size_t found = useAccel ? g.map.executeQuery(p, querySize, gRec) : g.map.executeQueryBrute(p, querySize, gRec);
+  for (int c = 0; c < 3; ++c) {
+    iter[c] += gRec.mediumFlux[c] * normalization;
+    for (int k = 0; k < 4; ++k) {
+      iter[3 + 3 * k + c] += gRec.shiftedMediumFlux[k][c] * normalization;
+      iter[15 + 3 * k + c] += gRec.weightedMediumFlux[k][c] * normalization;
+    }
+  }
+  cnt.add(gRec.cnt);
+  return found;
+}
 
 // scaleVolumeAPA, gvpm.cpp:181-215 (m_independentScale == false, forceAPA empty)
 inline double scaleVolumeAPA(double globalScaleVolume, int it, double alpha, int technique) {

@@ -64,9 +64,93 @@ int gatherBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
   return GVPM_OK;
 }
 
+// One iteration of computeVolumeGradientPhoton (G-VPM), gvpm.cpp:1081-1203
+template <typename F>
+int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
+              const gvpm_camera_ray *rays, uint64_t nsets, const gvpm_vpm_sample *samples, uint64_t nsamples,
+              int useAccel, int threads, double *accum, double *scaleVol, double *nVol, uint64_t *counters,
+              double *seconds) {
+  Gatherer<F> g;
+  g.setup(*p, *m, *t);
+  g.map.load(*ph);
+  auto t0 = std::chrono::steady_clock::now();
+  if (useAccel) g.map.buildKD();
+  const size_t P = (size_t)p->width * p->height;
+  // BBPourcentageCONST = bsphere radius * POURCENTAGE_BS (gvpm.cpp:1082), Float arithmetic
+  const F BBPourcentageCONST = (F)p->bsphere_radius * (F)0.01;
+  const F normalization = 1.f / p->nb_camera_samples;
+  std::vector<F> perSample((size_t)nsamples * 27, (F)0);
+  std::vector<uint32_t> found(nsamples, 0);
+  Counters total;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  int bad = 0;
+#pragma omp parallel
+  {
+    Counters local;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t s = 0; s < (int64_t)nsamples; ++s) {
+      const gvpm_vpm_sample &sm = samples[s];
+      if (sm.set >= nsets) { bad = 1; continue; }
+      const gvpm_camera_ray *set = rays + 5 * (size_t)sm.set;
+      const size_t px = set[0].pixel & 0xFFFFu, py = set[0].pixel >> 16;
+      if (px >= (size_t)p->width || py >= (size_t)p->height) { bad = 1; continue; }
+      const F querySize = BBPourcentageCONST * (F)scaleVol[py * p->width + px];  // gvpm.cpp:1132
+      found[s] = (uint32_t)gatherSampleVPM<F>(g, set, (F)sm.rand, (F)sm.pdf_sel, querySize, normalization,
+                                              useAccel != 0, &perSample[(size_t)s * 27], local);
+    }
+#pragma omp critical
+    total.add(local);
+  }
+  if (bad) return GVPM_ERR_INVALID_ARG;
+  // gp.mediumFlux += gRec.mediumFlux * normalization, in sample order (gvpm.cpp:1174-1179)
+  std::vector<F> MVol(P, (F)0);
+  for (uint64_t s = 0; s < nsamples; ++s) {
+    const gvpm_camera_ray &b = rays[5 * (size_t)samples[s].set];
+    const size_t pix = (size_t)(b.pixel >> 16) * p->width + (b.pixel & 0xFFFFu);
+    for (int k = 0; k < 27; ++k) accum[pix * 27 + k] = (double)((F)accum[pix * 27 + k] + perSample[(size_t)s * 27 + k]);
+    MVol[pix] += (F)found[s];
+  }
+  // SPPM update, gvpm.cpp:1191-1195
+  for (size_t i = 0; i < P; ++i) {
+    F NV = (F)nVol[i], M = MVol[i], sc = (F)scaleVol[i];
+    if (M + NV != 0) {
+      F ratioVol = (NV + (F)p->alpha * M) / (NV + M);
+      sc = sc * std::cbrt(ratioVol);
+      NV = NV + (F)p->alpha * M;
+      scaleVol[i] = (double)sc;
+      nVol[i] = (double)NV;
+    }
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (counters) {
+    counters[0] = total.evaluations; counters[1] = total.candidates; counters[2] = total.nullShifts;
+    counters[3] = total.diffuseShifts; counters[4] = total.failedShifts;
+  }
+  return GVPM_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// One iteration of computeVolumeGradientPhoton (gvpm.cpp:1081-1203) on the CPU.  accum: P*27
+// doubles (in/out, plain sums); scale_vol / n_vol: P doubles each (in/out GatherPoint state).
+int oracle_gather_vpm(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                      const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets,
+                      const gvpm_vpm_sample *samples, uint64_t nsamples, int precision, int use_accel, int threads,
+                      double *accum, double *scale_vol, double *n_vol, uint64_t *counters, double *seconds) {
+  if (!p || !m || !t || !ph || (!rays && nsets) || (!samples && nsamples) || !accum || !scale_vol || !n_vol)
+    return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_DISTANCE) return GVPM_ERR_INVALID_ARG;
+  if (precision == 32)
+    return gatherVPM<float>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol,
+                            counters, seconds);
+  return gatherVPM<double>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol,
+                           counters, seconds);
+}
 
 // One iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079) on the CPU.
 // precision: 32 or 64; use_accel: 1 = kd-tree -> BRE BVH stack traversal (reference),
@@ -93,9 +177,18 @@ double oracle_scale_volume_apa(double global_scale, int it, double alpha, int te
 // computeGradient, gvpm.cpp:1205-1306, for an APA volume estimator
 // (isAPAVolumeEstimator(): no division by the emitted count).
 // accum: P*27 doubles; emission: P*3 doubles or NULL; outputs P*3 doubles each.
+// total_emitted > 0: non-APA estimator (G-VPM): volume terms are divided by m_totalEmittedVolume
+// (gvpm.cpp:489-492, 526-528, 1252-1253, 1296-1297); 0: APA estimator.
+int oracle_assemble_ex(int width, int height, int it, int reuse_primal, double total_emitted, const double *accum,
+                       const double *emission, double *throughput, double *dx, double *dy);
 int oracle_assemble(int width, int height, int it, int reuse_primal, const double *accum, const double *emission,
                     double *throughput, double *dx, double *dy) {
+  return oracle_assemble_ex(width, height, it, reuse_primal, 0.0, accum, emission, throughput, dx, dy);
+}
+int oracle_assemble_ex(int width, int height, int it, int reuse_primal, double total_emitted, const double *accum,
+                       const double *emission, double *throughput, double *dx, double *dy) {
   if (!accum || !throughput || !dx || !dy) return GVPM_ERR_INVALID_ARG;
+  const double div = total_emitted > 0 ? total_emitted : 1.0;
   auto A = [&](int x, int y, int k, int c) { return accum[((size_t)y * width + x) * 27 + k * 3 + c]; };
   // k: 0 mediumFlux, 1+i shifted[i], 5+i weighted[i]
   for (int y = 0; y < height; ++y)
@@ -103,7 +196,7 @@ int oracle_assemble(int width, int height, int it, int reuse_primal, const doubl
       for (int c = 0; c < 3; ++c) {
         size_t o = ((size_t)y * width + x) * 3 + c;
         double em = emission ? emission[o] / it : 0.0;
-        double v = A(x, y, 0, c) + 0.0 + em;  // fluxMedia + fluxSurface + emission/it
+        double v = A(x, y, 0, c) / div + 0.0 + em;  // fluxMedia + fluxSurface + emission/it
         if (reuse_primal) {
           double T = 0;
           if (x != width - 1) T += A(x + 1, y, 1 + GVPM_LEFT, c);
@@ -112,7 +205,7 @@ int oracle_assemble(int width, int height, int it, int reuse_primal, const doubl
           if (y != 0) T += A(x, y - 1, 1 + GVPM_TOP, c);
           T += A(x, y, 5 + GVPM_BOTTOM, c) + A(x, y, 5 + GVPM_TOP, c) + A(x, y, 5 + GVPM_RIGHT, c) +
                A(x, y, 5 + GVPM_LEFT, c);
-          v = T / 4.0;
+          v = (T / 4.0) / div;
         }
         throughput[o] = v;
         double gx, gy;
@@ -122,8 +215,8 @@ int oracle_assemble(int width, int height, int it, int reuse_primal, const doubl
         if (y == height - 1) gy = A(x, y, 1 + GVPM_TOP, c) - A(x, y, 5 + GVPM_TOP, c);
         else gy = (A(x, y, 1 + GVPM_TOP, c) - A(x, y, 5 + GVPM_TOP, c)) +
                   (A(x, y + 1, 5 + GVPM_BOTTOM, c) - A(x, y + 1, 1 + GVPM_BOTTOM, c));
-        dx[o] = gx;
-        dy[o] = gy;
+        dx[o] = gx / div;
+        dy[o] = gy / div;
       }
   return GVPM_OK;
 }

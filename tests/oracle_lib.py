@@ -34,6 +34,12 @@ def lib(fast=False):
         L.oracle_assemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_gather_vpm.argtypes = [
+            C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_assemble_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -67,16 +73,41 @@ def gather_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, pr
             secs.value)
 
 
+def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_accel=True, threads=0, accum=None,
+               scale_vol=None, n_vol=None, fast=False):
+    """One iteration of computeVolumeGradientPhoton (G-VPM) on the CPU.
+    Returns (accum[H,W,27] sums, scale_vol[H,W], n_vol[H,W], counters, seconds)."""
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = photons.soa()
+    rays = np.ascontiguousarray(rays)
+    samples = np.ascontiguousarray(samples)
+    H, W = params.height, params.width
+    accum = np.zeros(H * W * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    scale_vol = (np.full(H * W, params.initial_scale_volume, np.float64) if scale_vol is None
+                 else np.ascontiguousarray(scale_vol, np.float64).reshape(-1).copy())
+    n_vol = np.zeros(H * W, np.float64) if n_vol is None else np.ascontiguousarray(n_vol, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    secs = C.c_double(0)
+    rc = lib(fast).oracle_gather_vpm(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
+                                     rays.ctypes.data, rays.shape[0], samples.ctypes.data, samples.shape[0],
+                                     precision, 1 if use_accel else 0, threads, accum.ctypes.data,
+                                     scale_vol.ctypes.data, n_vol.ctypes.data, counters.ctypes.data, C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_vpm failed: {rc}")
+    return (accum.reshape(H, W, 27), scale_vol.reshape(H, W), n_vol.reshape(H, W),
+            dict(zip(COUNTER_NAMES, map(int, counters))), secs.value)
+
+
 def scale_volume_apa(scale, it, alpha, technique):
     return lib().oracle_scale_volume_apa(scale, it, alpha, technique)
 
 
-def assemble(accum, it=1, reuse_primal=True, emission=None):
+def assemble(accum, it=1, reuse_primal=True, emission=None, total_emitted=0.0):
     H, W = accum.shape[:2]
     a = np.ascontiguousarray(accum, np.float64)
     out = [np.zeros((H, W, 3), np.float64) for _ in range(3)]
     em = None if emission is None else np.ascontiguousarray(emission, np.float64)
-    rc = lib().oracle_assemble(W, H, it, 1 if reuse_primal else 0, a.ctypes.data,
+    rc = lib().oracle_assemble_ex(W, H, it, 1 if reuse_primal else 0, float(total_emitted), a.ctypes.data,
                                None if em is None else em.ctypes.data, out[0].ctypes.data, out[1].ctypes.data,
                                out[2].ctypes.data)
     if rc != 0:

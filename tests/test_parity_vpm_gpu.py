@@ -1,0 +1,86 @@
+"""G-VPM parity: HIP path vs the fp64 oracle (computeVolumeGradientPhoton)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+from gvpm_amd import abi, hip
+from test_oracle_vpm import make_vpm_case
+from test_parity_gpu import l2, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def device_vpm(c, iters=1, p=None, rays=None):
+    p = c.p if p is None else p
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ref = sv = nv = None
+    total = 0
+    emitted = 0
+    for it in range(1, iters + 1):
+        if it == 1:
+            ph, nb, r, smp = c.ph, c.nb, (c.rays if rays is None else rays), c.samples
+        else:
+            ph, nb = c.sc.shoot_photons(it, c.ph.n)
+            r, smp = c.sc.camera_beams_and_vpm_samples(it, p.nb_camera_samples)
+        ctx.upload_photons(ph)
+        ctx.upload_camera_beams(r)
+        ctx.upload_vpm_samples(smp)
+        ctx.gather(it, nb)
+        emitted += nb
+        ref, sv, nv, cnt, _ = O.gather_vpm(p, c.m, c.tris, ph, r, smp, 64, use_accel=False, accum=ref, scale_vol=sv,
+                                           n_vol=nv)
+        total += cnt["evaluations"]
+    acc = ctx.download_accum()
+    st = ctx.stats()
+    dsv, dnv = ctx.download_vpm_state()
+    film = ctx.download_film(iters, True)
+    ctx.close()
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert st["evaluations"] == total
+    assert l2(acc, ref, lum) < TOL
+    assert np.allclose(dsv, sv, rtol=1e-6) and np.allclose(dnv, nv, rtol=1e-6)
+    rfilm = O.assemble(ref, iters, True, total_emitted=emitted)
+    for a, b in zip(film, rfilm):
+        assert l2(a, b, lum / emitted) < TOL
+    return acc, ref, st
+
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg"])
+def test_vpm_matches_fp64_oracle(scene):
+    c = make_vpm_case(scene, 32, 28, 40000, 5.0, nb=10)
+    acc, ref, st = device_vpm(c)
+    assert st["evaluations"] > 5000
+
+
+def test_vpm_three_iterations_sppm_state():
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=8)
+    device_vpm(c, iters=3)
+
+
+@pytest.mark.parametrize("kw", [dict(use_mis=0), dict(use_shift_null=0), dict(power_heuristic=1), dict(max_depth=3),
+                                dict(debug_shift=abi.GVPM_SHIFT_NULL), dict(visibility_as_written=0),
+                                dict(lighting_interaction_mode=abi.GVPM_MEDIA2MEDIA)])
+def test_vpm_flag_sweep(kw):
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=8)
+    p = c.p.copy()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    device_vpm(c, p=p)
+
+
+def test_vpm_paper_radius_and_empty_inputs():
+    # initialScaleVolume 0.15 (paper setting): almost every query is empty
+    c = make_vpm_case("cbox", 32, 32, 50000, 0.15, nb=40)
+    device_vpm(c)
+    c2 = make_vpm_case("cbox", 16, 16, 5000, 5.0, nb=4)
+    c2.samples = c2.samples[:0]
+    device_vpm(c2)
+    ctx = hip.Context(c2.p, device=0)
+    ctx.upload_scene(*c2.tris); ctx.upload_medium(c2.m); ctx.upload_photons(c2.ph); ctx.upload_camera_beams(c2.rays)
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.gather(1, 10)   # samples not uploaded
+    assert e.value.code == abi.GVPM_ERR_STATE
+    ctx.close()
