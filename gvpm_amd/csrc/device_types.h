@@ -53,6 +53,11 @@ struct GatherArgs {
   // config
   gvpm_params cfg;
   float radius;
+  // G-Beams only: a.radius is the traversal radius (kernel radius + half a sub-beam),
+  // cold holds 9 planes of `nbeams`, hot holds the sub-beam centres {xyz, beam | sub << 24}
+  float kernelRadius;
+  float subLen;              // target sub-beam length used by the build
+  uint32_t nbeams;
   // G-VPM only
   const gvpm_vpm_sample *samples;
   uint32_t nsamples;

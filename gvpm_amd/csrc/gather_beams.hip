@@ -1,0 +1,773 @@
+// G-Beams (beam x beam) gather + gradient-domain shift for gfx950, hand-written HIP.
+//
+// Replaces, for one SPPM iteration, the body of
+//   GPMIntegrator::computeVolumeGradientBeams     gvpm/gvpm.cpp:880-986
+//   SubBeamBVH (build + query)                    pm/beams_accel.h:82-267
+//   BeamGradRadianceQuery::operator()             gvpm/shift/shift_volume_beams.cpp:139-353
+//   BeamKernelRecord (1D, 3D "optimized")         gvpm/shift/shift_volume_beams.h:24-338
+//   PhotonBeam::rayIntersectInternal1D/getContrib pm/beams_struct.h:250-311,136-185
+//   cylinderIntersection                          pm/beams_3d_intersections.h:77-140
+//   getShiftPos / getShiftPos1D / shift           shift_volume_beams.cpp:37-137
+//   shiftBeam / shiftBeamDiffuse / shiftNull3D    shift_volume_beams.cpp:355-539,748-786
+//   diffuseReconnectionPhotonBeam                 gvpm/shift/operation/shift_diffuse.cpp:136-268
+// (pm/ = src/integrators/photonmapper/).
+//
+// Acceleration structure: like the reference, every photon beam is cut into sub-beams (here of
+// about one grid cell) and each sub-beam is binned ONCE, by its centre, into the same sorted
+// uniform grid the photon kernels use; the camera tile walks the grid with the kernel radius
+// inflated by half a sub-beam.  A (camera ray, beam) pair is evaluated by the one sub-beam that
+// owns the intersection -- the reference's own rule (1D: v in (t1,t2], beams_struct.h:297-299;
+// 3D: tNear in (t1,t2), shift_volume_beams.h:213-220) -- so the result does not depend on how
+// beams are cut.  Traversal, LDS staging, ballot compaction and the work queue are those of the
+// BRE kernel (tile_walk.h).  The evaluation itself runs in fp64 (half rate on CDNA4): it is a
+// literal transcription of the reference with its float intermediates; an fp32 fast path is
+// future work.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "shift_device.h"
+#include "tile_walk.h"
+#include "vec.h"
+
+namespace gvpm {
+
+struct RayD {
+  d3 o, d;
+  double mint, maxt;
+};
+__device__ __forceinline__ d3 at(const RayD &r, double t) { return r.o + r.d * t; }
+__device__ __forceinline__ d3 crossd(d3 a, d3 b) {
+  return mkd(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ d3 operator*(double s, d3 a) { return a * s; }
+
+struct BeamD {
+  d3 p1, p2, dir;
+  double len;
+  d3 flux, prefixW, parentScat;
+  d3 parentN, parentWi, endN;
+  double parentPdf, parentRR, parentG;
+  uint32_t flags;
+  bool endOnSurface;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t &o0, uint32_t &o1) {
+  uint32_t c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o0 = c0;
+  o1 = c1;
+}
+
+// HomogeneousMedium::eval over [0, dist], homogeneous.cpp:432-513 (equal sigma_t per channel)
+struct MRecD {
+  double tr, pdfSuccess, pdfFailure;
+};
+__device__ __forceinline__ MRecD mediumEvalD(const MediumDev &m, double dist) {
+  MRecD r;
+  const double st = (double)m.sigmaT[0], msw = (double)m.msw;
+  double e = exp(-st * dist);
+  r.pdfSuccess = st * e * msw;
+  r.pdfFailure = e * msw + (1.0 - msw);
+  if (e < 1e-20) e = 0.0;
+  r.tr = e;
+  return r;
+}
+
+__device__ __forceinline__ double phaseD(double g, d3 wi, d3 wo) {
+  const double INV_FOURPI = 0.07957747154594766788;
+  if (g == 0.0) return INV_FOURPI;
+  const double temp = 1.0 + g * g + 2.0 * g * dot(wi, wo);
+  return INV_FOURPI * (1.0 - g * g) / (temp * sqrt(temp));
+}
+
+// coordinateSystem, src/libcore/util.cpp:600-609
+__device__ __forceinline__ void coordSys(d3 a, d3 &b, d3 &c) {
+  if (fabs(a.x) > fabs(a.y)) {
+    const double invLen = 1.0 / sqrt(a.x * a.x + a.z * a.z);
+    c = mkd(a.z * invLen, 0.0, -a.x * invLen);
+  } else {
+    const double invLen = 1.0 / sqrt(a.y * a.y + a.z * a.z);
+    c = mkd(0.0, a.z * invLen, -a.y * invLen);
+  }
+  b = crossd(c, a);
+}
+// coordinateSystemCoherent (float intermediates), util.cpp:592-599
+__device__ __forceinline__ void coordSysCoherent(d3 n, d3 &b1, d3 &b2) {
+  const float sign = copysignf(1.0f, (float)n.z);
+  const float aa = (float)(-1.0f / ((double)sign + n.z));
+  const float bb = (float)(n.x * n.y * (double)aa);
+  b1 = mkd(1.0 + (double)sign * n.x * n.x * (double)aa, (double)sign * (double)bb, -(double)sign * n.x);
+  b2 = mkd((double)bb, (double)sign + n.y * n.y * (double)aa, -n.y);
+}
+
+__device__ __forceinline__ bool solveQuadraticD(double a, double b, double c, double &x0, double &x1) {
+  if (a == 0) {
+    if (b != 0) {
+      x0 = x1 = -c / b;
+      return true;
+    }
+    return false;
+  }
+  const double discrim = b * b - 4.0 * a * c;
+  if (discrim < 0) return false;
+  const double sq = sqrt(discrim);
+  const double temp = b < 0 ? -0.5 * (b - sq) : -0.5 * (b + sq);
+  x0 = temp / a;
+  x1 = c / temp;
+  if (x0 > x1) { const double t = x0; x0 = x1; x1 = t; }
+  return true;
+}
+
+// cylinderIntersection(rCylinder, view, radius), pm/beams_3d_intersections.h:77-140
+__device__ __forceinline__ bool cylinderIntersection(const RayD &cyl, const RayD &view, double radius, double &tNear,
+                                                     double &tFar) {
+  const d3 d1d2c = crossd(view.d, cyl.d);
+  const float sinThetaSqr = (float)dot(d1d2c, d1d2c);
+  const float ad = (float)dot(cyl.o - view.o, d1d2c);
+  if ((double)(ad * ad) >= (radius * radius) * (double)sinThetaSqr) return false;
+  d3 s, t;
+  coordSys(cyl.d, s, t);
+  const double lMax = cyl.maxt;
+  const d3 rel = view.o - cyl.o;
+  const double ox = dot(s, rel), oy = dot(t, rel), oz = dot(cyl.d, rel);
+  const double dx = dot(s, view.d), dy = dot(t, view.d), dz = dot(cyl.d, view.d);
+  const double A = dx * dx + dy * dy;
+  const double Bq = 2 * (dx * ox + dy * oy);
+  const double C = ox * ox + oy * oy - radius * radius;
+  if (!solveQuadraticD(A, Bq, C, tNear, tFar)) return false;
+  if (tNear > view.maxt || tFar < 0) return false;
+  const double zPosNear = oz + dz * tNear, zPosFar = oz + dz * tFar;
+  if (zPosNear < 0) {
+    if (zPosFar < 0) return false;
+    tNear = (double)(float)(tNear + (tFar - tNear) * (zPosNear) / (zPosNear - zPosFar));
+    return true;
+  } else if (zPosNear >= 0 && zPosNear < lMax) {
+    return true;
+  } else if (zPosNear > lMax) {
+    if (zPosFar > lMax) return false;
+    tNear = (double)(float)(tNear + (tFar - tNear) * (zPosNear - lMax) / (zPosNear - zPosFar));
+    return true;
+  }
+  return false;
+}
+
+struct KRecD {
+  double radius, v, w, pdfKernel, pdfEdgeFailure, u, weightKernel, beamTrans;
+  d3 contrib;
+  bool valid;
+};
+__device__ __forceinline__ double kpdf(const KRecD &k) { return k.pdfEdgeFailure * k.pdfKernel; }
+
+// PhotonBeam::rayIntersectInternal1D, pm/beams_struct.h:250-311 (float intermediates as written)
+__device__ __forceinline__ bool rayIntersect1D(const BeamD &b, double radius, const RayD &ray, double tminBeam,
+                                               double tmaxBeam, double &u, double &v, double &w, double &sinTheta) {
+  const d3 d1d2c = crossd(ray.d, b.dir);
+  const float sinThetaSqr = (float)dot(d1d2c, d1d2c);
+  const float ad = (float)dot(b.p1 - ray.o, d1d2c);
+  if ((double)(ad * ad) >= (radius * radius) * (double)sinThetaSqr) return false;
+  const float d1d2 = (float)dot(ray.d, b.dir);
+  const float d1d2Sqr = d1d2 * d1d2;
+  const float d1d2SqrMinus1 = d1d2Sqr - 1.0f;
+  if (d1d2SqrMinus1 < 1e-5f && d1d2SqrMinus1 > -1e-5f) return false;
+  const float d1O1 = (float)dot(ray.d, ray.o);
+  const float d1O2 = (float)dot(ray.d, b.p1);
+  w = ((double)(d1O1 - d1O2) - (double)d1d2 * (dot(b.dir, ray.o) - dot(b.dir, b.p1))) / (double)d1d2SqrMinus1;
+  if (w <= ray.mint || w >= ray.maxt) return false;
+  v = (w + (double)d1O1 - (double)d1O2) / (double)d1d2;
+  if (v <= 0.0 || v >= b.len || isnan(v)) return false;
+  if (tminBeam >= v || tmaxBeam < v) return false;
+  const float sinThetaConst = sqrtf(sinThetaSqr);
+  u = (double)(fabsf(ad) / sinThetaConst);
+  sinTheta = (double)sinThetaConst;
+  return true;
+}
+
+// BeamKernelRecord::eval, shift_volume_beams.h:157-290 (short beams)
+__device__ __forceinline__ void krecEval(const GatherArgs &a, const BeamD &b, const RayD &cam, double tmin, double tmax,
+                                         double uv, double uw, int technique, KRecD &k) {
+  const d3 sigS = mkd(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  k.valid = false;
+  if (tmax > b.len) tmax = b.len;
+  if (technique == GVPM_BEAM_BEAM_1D) {
+    if (!rayIntersect1D(b, k.radius, cam, tmin, tmax, k.u, k.v, k.w, k.pdfKernel)) return;
+    const MRecD mCam = mediumEvalD(a.med, k.w);
+    k.weightKernel = 0.5 / k.radius;
+    const MRecD mB = mediumEvalD(a.med, k.v);
+    k.beamTrans = mB.tr;
+    k.pdfEdgeFailure = mB.pdfFailure;
+    if (mB.pdfFailure == 0.0 && mB.tr != 0.0) return;
+    const double ph = phaseD((double)a.med.g, -b.dir, -cam.d);
+    const double sc = mB.tr * mCam.tr * ph / mB.pdfFailure / k.pdfKernel;
+    k.contrib = mkd(sigS.x * b.flux.x * sc, sigS.y * b.flux.y * sc, sigS.z * b.flux.z * sc);
+  } else {
+    const RayD _cam{at(cam, cam.mint), cam.d, 0.0, cam.maxt - cam.mint};
+    const RayD _beam{b.p1, b.dir, 0.0, b.len};
+    double tN, tF;
+    if (!cylinderIntersection(_cam, _beam, k.radius, tN, tF)) return;
+    if (tN < 0 && tmin <= (double)a.cfg.epsilon) {
+    } else if (tN > tmin && tN < tmax) {
+    } else {
+      return;
+    }
+    k.v = tN + (tF - tN) * uv;
+    k.pdfKernel = 1.0 / fmax(tF - tN, 0.0001);
+    if (k.v < 0 || k.v > b.len) return;
+    const d3 kc = b.p1 + b.dir * k.v;
+    const double distToProj = dot(kc - cam.o, cam.d);
+    const double distSqr = len2(at(cam, distToProj) - kc);
+    const double radSqr = k.radius * k.radius;
+    if (distSqr >= radSqr) return;
+    const double deltaT = sqrt(fmax(0.0, radSqr - distSqr));
+    k.w = distToProj - deltaT + 2 * deltaT * uw;
+    k.pdfKernel *= 1.0 / fmax(2.0 * deltaT, 0.0001);
+    if (k.w < cam.mint || k.w > cam.maxt) return;
+    const MRecD mB = mediumEvalD(a.med, k.v);
+    const MRecD mCam = mediumEvalD(a.med, k.w);
+    const double ph = phaseD((double)a.med.g, -b.dir, -cam.d);
+    const double kernelVol = (4.0 / 3.0) * 3.14159265358979323846 * k.radius * k.radius * k.radius;
+    const double sc = mB.tr * mCam.tr * ph / k.pdfKernel / mB.pdfFailure;
+    k.contrib = mkd(b.flux.x * sigS.x * sc, b.flux.y * sigS.y * sc, b.flux.z * sigS.z * sc);
+    k.weightKernel = 1.0 / kernelVol;
+    k.beamTrans = mB.tr;
+    k.pdfEdgeFailure = mB.pdfFailure;
+  }
+  k.valid = !(k.contrib.x == 0 && k.contrib.y == 0 && k.contrib.z == 0);
+}
+
+// BeamKernelRecord copy-shift constructor (3D), shift_volume_beams.h:40-144
+__device__ __forceinline__ void krecShifted(const KRecD &ori, const BeamD &b, const RayD &cam, KRecD &k) {
+  k = ori;
+  k.u = 0;
+  k.contrib = mkd(0, 0, 0);
+  k.valid = false;
+  const RayD _cam{at(cam, cam.mint), cam.d, 0.0, cam.maxt - cam.mint};
+  const RayD _beam{b.p1, b.dir, 0.0, b.len};
+  double tN, tF;
+  if (!cylinderIntersection(_cam, _beam, k.radius, tN, tF)) return;
+  k.v = ori.v;
+  k.pdfKernel = 1.0 / fmax(tF - tN, 0.0001);
+  if (k.v < 0 || k.v > b.len) return;
+  const d3 kc = b.p1 + b.dir * k.v;
+  const double distToProj = dot(kc - cam.o, cam.d);
+  const double distSqr = len2(at(cam, distToProj) - kc);
+  const double radSqr = k.radius * k.radius;
+  if (distSqr >= radSqr) return;
+  const double deltaT = sqrt(fmax(0.0, radSqr - distSqr));
+  k.w = ori.w;
+  k.pdfKernel *= 1.0 / fmax(2.0 * deltaT, 0.0001);
+  if (k.w < cam.mint || k.w > cam.maxt) return;
+  k.contrib = ori.contrib * (ori.pdfKernel / k.pdfKernel);
+  k.valid = !(k.contrib.x == 0 && k.contrib.y == 0 && k.contrib.z == 0);
+}
+
+// BeamKernelRecord::kernelPDF, shift_volume_beams.h:300-336
+__device__ __forceinline__ double kernelPDF(const KRecD &k, int technique, const RayD &cam, d3 orgBeam, d3 dBeam,
+                                            double newDLength) {
+  if (technique == GVPM_BEAM_BEAM_1D) return sqrt(len2(crossd(cam.d, dBeam)));
+  const RayD _beam{orgBeam, dBeam, 0.0, INFINITY};
+  const RayD _cam{cam.o, cam.d, 0.0, cam.maxt};
+  double tN, tF;
+  if (cylinderIntersection(_cam, _beam, k.radius, tN, tF)) {
+    double pk = 1.0 / fmax(tF - tN, 0.0001);
+    const d3 kc = orgBeam + dBeam * newDLength;
+    const double distToProj = dot(kc - cam.o, cam.d);
+    const double distSqr = len2(at(cam, distToProj) - kc);
+    const double radSqr = k.radius * k.radius;
+    if (distSqr < radSqr) {
+      const double deltaT = sqrt(fmax(0.0, radSqr - distSqr));
+      pk *= 1.0 / fmax(2.0 * deltaT, 0.0001);
+      return pk;
+    }
+    return 0.0;
+  }
+  return 0.0;
+}
+
+// shift(), shift_volume_beams.cpp:47-79 with localMatrix (:37-42)
+__device__ __forceinline__ d3 shiftPoint(const RayD &r, d3 a, double u, double w, bool flip) {
+  const double d = dot(a - r.o, r.d);
+  d3 sv = a - at(r, d);
+  sv = sv / sqrt(len2(sv));
+  const d3 tv = crossd(r.d, sv);
+  // Frame{s = r.d, t = sv, n = tv}
+  const d3 av = a - at(r, d);
+  const double ly = dot(av, sv);
+  const double x = u / fabs(ly);
+  double phi = 1.57079632679489661923 - asin(fmin(1.0, fmax(-1.0, x)));
+  if (flip) phi = -phi;
+  const double lwy = u * cos(phi), lwz = u * sin(phi);
+  return at(r, w) + (sv * lwy + tv * lwz);
+}
+
+__device__ __forceinline__ d3 getShiftPos1D(const RayD &bRay, const RayD &sRay, d3 a, d3 bBeamDir, double w, double u) {
+  d3 back = shiftPoint(bRay, a, u, w, false) - a;
+  back = back / sqrt(len2(back));
+  const bool flip = len2(back - bBeamDir) > 0.001;
+  return shiftPoint(sRay, a, u, w, flip);
+}
+
+__device__ __forceinline__ d3 getShiftPos3D(const GatherArgs &a, const RayD &bRay, const RayD &sRay, double w, d3 u,
+                                            double radius, double newW) {
+  d3 bs, bt, ns, nt;
+  coordSysCoherent(bRay.d, bs, bt);
+  coordSysCoherent(sRay.d, ns, nt);
+  const double lx = dot(u, bs), ly = dot(u, bt), lz = dot(u, bRay.d);
+  d3 newPos = at(sRay, newW) + (ns * lx + nt * ly + sRay.d * lz);
+  if (a.cfg.use_shift_null) {
+    const d3 bCamW = at(bRay, w);
+    if (len2(bCamW - newPos) < radius * radius) {
+      d3 dShift = at(sRay, newW) - bCamW;
+      dShift = dShift / sqrt(len2(dShift));
+      const double cosD = dot(dShift, -(newPos - at(sRay, newW)));
+      newPos = newPos + dShift * (cosD * 2.0);
+    }
+  }
+  return newPos;
+}
+
+// shiftBeamDiffuse + diffuseReconnectionPhotonBeam.  Returns the MIS weight.
+template <int B>
+__device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const TileLds<B> &s, const BeamD &b,
+                                                   const RayReg &sh, const RayReg &base, uint32_t edge,
+                                                   const RayD &shiftRay, double shiftW, const KRecD &kRec, d3 newPos,
+                                                   int technique, d3 &shiftedFlux, bool &ok) {
+  const double INV_PI = 0.31830988618379067154;
+  ok = false;
+  shiftedFlux = mkd(0, 0, 0);
+  d3 newPBDir = newPos - b.p1;
+  const double newPBDist = sqrt(len2(newPBDir));
+  newPBDir = newPBDir / newPBDist;
+  // visibility over the whole new beam [Epsilon, newPBDist], shift_volume_beams.cpp:420-426
+  if (anyHit(a, s.tri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist)) return 1.0;
+  const d3 basePos = b.p1 + b.dir * kRec.v;
+  const double pdfKernelAndDist = kpdf(kRec);
+  // diffuseReconnectionPhotonBeam, shift_diffuse.cpp:136-268
+  const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
+  d3 thr;
+  double pdfValueSA;
+  if (ptype == GVPM_PARENT_SURFACE) {
+    const double cosWo = dot(b.parentN, newPBDir), cosWi = dot(b.parentN, b.parentWi);
+    if (cosWi <= 0 || cosWo <= 0) return 1.0;  // eval = pdf = 0 (or the shading-normal reject): sRec.pdf == 0
+    thr = b.parentScat * (INV_PI * cosWo);
+    pdfValueSA = INV_PI * cosWo;
+  } else if (ptype == GVPM_PARENT_MEDIUM) {
+    const double p = phaseD(b.parentG, b.parentWi, newPBDir);
+    thr = b.parentScat * p;
+    pdfValueSA = p;
+  } else {
+    double dp = dot(newPBDir, b.parentN);
+    if (dp < 0) dp = 0.0;
+    thr = mkd(INV_PI * dp, INV_PI * dp, INV_PI * dp);
+    pdfValueSA = INV_PI * dp;
+  }
+  const double GOpNew = 1.0 / (newPBDist * newPBDist);
+  double sPdf = pdfValueSA * GOpNew;
+  thr = thr * GOpNew;
+  double pdfBasePos = b.parentPdf * len2(b.p1 - b.p2);
+  if (b.endOnSurface) pdfBasePos /= fabs(dot(b.endN, b.dir));
+  pdfBasePos *= 1.0 / len2(b.p1 - basePos);
+  if (pdfBasePos == 0.0) return 1.0;
+  thr = thr * (b.parentRR / pdfBasePos);
+  if (GVPM_PF_EDGE_IN_MEDIUM(b.flags)) {
+    const MRecD m = mediumEvalD(a.med, newPBDist);
+    sPdf *= m.pdfFailure;
+    thr = thr * (m.tr / pdfKernelAndDist);
+  }
+  if (sPdf == 0.0) return 1.0;
+  const double shiftKernelPDF = kernelPDF(kRec, technique, shiftRay, b.p1, newPBDir, newPBDist);
+  if (shiftKernelPDF == 0) return 1.0;
+  const d3 sigS = mkd(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  const MRecD mS = mediumEvalD(a.med, shiftW);
+  const double ph = phaseD((double)a.med.g, -newPBDir, -shiftRay.d) * mS.tr;
+  const d3 eye = tod(sh.eye);
+  shiftedFlux = mkd(b.prefixW.x * thr.x * sigS.x * ph * eye.x, b.prefixW.y * thr.y * sigS.y * ph * eye.y,
+                    b.prefixW.z * thr.z * sigS.z * ph * eye.z);
+  ok = true;
+  double w = 0.5;
+  if (a.cfg.use_mis) {
+    double basePdf = b.parentPdf * len2(b.p1 - b.p2);
+    if (b.endOnSurface) basePdf /= fabs(dot(b.endN, b.dir));
+    basePdf /= len2(b.p1 - basePos);
+    basePdf *= pdfKernelAndDist;
+    const double offsetPdf = shiftKernelPDF * sPdf;
+    if (offsetPdf == 0.0 || basePdf == 0.0) {
+      ok = false;
+      return 1.0;
+    }
+    // sensorMIS(currCameraEdge, base, shiftW, kRec.w): the two distances are equal
+    const double x = (double)sensorMIS(sh, base, edge) * offsetPdf / basePdf;
+    w = a.cfg.power_heuristic ? 1.0 / (1.0 + x * x) : 1.0 / (1.0 + x);
+  }
+  return w;
+}
+
+__device__ __forceinline__ BeamD loadBeam(const GatherArgs &a, uint32_t idx) {
+  const size_t N = a.nbeams;
+  const float4 c0 = a.cold[0 * N + idx], c1 = a.cold[1 * N + idx], c2 = a.cold[2 * N + idx], c3 = a.cold[3 * N + idx];
+  const float4 c4 = a.cold[4 * N + idx], c5 = a.cold[5 * N + idx], c6 = a.cold[6 * N + idx], c7 = a.cold[7 * N + idx];
+  const float4 c8 = a.cold[8 * N + idx];
+  BeamD b;
+  b.parentPdf = c0.w;
+  b.flux = mkd(c1.x, c1.y, c1.z);
+  b.p1 = mkd(c2.x, c2.y, c2.z); b.parentRR = c2.w;
+  b.parentN = mkd(c3.x, c3.y, c3.z); b.parentG = c3.w;
+  b.prefixW = mkd(c4.x, c4.y, c4.z);
+  b.parentScat = mkd(c5.x, c5.y, c5.z);
+  b.parentWi = mkd(c6.x, c6.y, c6.z);
+  b.p2 = mkd(c7.x, c7.y, c7.z); b.flags = __float_as_uint(c7.w);
+  b.endN = mkd(c8.x, c8.y, c8.z);
+  b.endOnSurface = !(c8.x == 0.f && c8.y == 0.f && c8.z == 0.f);
+  // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81
+  b.dir = b.p2 - b.p1;
+  b.len = sqrt(len2(b.dir));
+  b.dir = b.dir / b.len;
+  return b;
+}
+
+// number of sub-beams of a beam of length len for target length ls (shared with the grid build)
+__device__ __forceinline__ uint32_t subBeamCount(float len, float ls) {
+  const float n = ceilf(len / ls);
+  return (uint32_t)fminf(fmaxf(n, 1.f), 255.f);
+}
+
+// One (camera ray, sub-beam) candidate: BeamGradRadianceQuery::operator().  Returns true when it
+// produced a contribution (an evaluation).
+template <int B>
+__device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s, uint32_t id, uint32_t bIdx,
+                                             uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+  const uint32_t beamIdx = id & 0xFFFFFFu, sub = id >> 24;
+  const BeamD b = loadBeam(a, beamIdx);
+  const RayReg base = loadRay(s, 0, bIdx);
+  const uint32_t edge = s.edge[bIdx];
+  const uint32_t pix = s.pix[bIdx];
+  const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
+  const int technique = a.cfg.vol_technique;
+  // filters, shift_volume_beams.cpp:142-184
+  const int pathLength = (int)edge + (int)GVPM_PF_DEPTH(b.flags);
+  if (a.cfg.max_depth > 0 && pathLength > a.cfg.max_depth) return false;
+  if (!((b.flags >> 6) & 1u)) return false;  // computeVolumeContribution (folded at build time)
+  double rr = 1.0;
+  if (a.cfg.path_set) {
+    if (((b.flags >> GVPM_HOT_PARITY_BIT) & 1u) != (uint32_t)((px + py) & 1)) return false;
+    rr = 2.0;
+  }
+  // the sub-beam [tmin, tmax) of this candidate (SubBeamBVH, pm/beams_accel.h:119-131)
+  const uint32_t nSub = subBeamCount((float)b.len, a.subLen);
+  const float ls = (float)b.len / (float)nSub;
+  const double tmin = (double)(ls * (float)sub);
+  const double tmax = (sub + 1u >= nSub) ? INFINITY : (double)(ls * (float)(sub + 1u));
+  const double eps = (double)a.cfg.epsilon;
+  const RayD cam{tod(base.o), tod(base.d), eps, (double)base.len - eps};
+  uint32_t o0, o1;
+  philox4x32_10(__float_as_uint(s.rnd[bIdx]), 0x6265616du, beamIdx, o0, o1);
+  const double uv = (double)((float)(o0 >> 8) * (1.0f / 16777216.0f));
+  const double uw = (double)((float)(o1 >> 8) * (1.0f / 16777216.0f));
+  KRecD kRec;
+  kRec.radius = (double)a.kernelRadius;
+  kRec.v = kRec.w = kRec.pdfKernel = kRec.pdfEdgeFailure = kRec.u = kRec.weightKernel = kRec.beamTrans = 0;
+  kRec.contrib = mkd(0, 0, 0);
+  krecEval(a, b, cam, tmin, tmax, uv, uw, technique, kRec);
+  if (!kRec.valid) return false;
+  const d3 eyeB = tod(base.eye);
+  const d3 baseContrib = mkd(eyeB.x * kRec.contrib.x, eyeB.y * kRec.contrib.y, eyeB.z * kRec.contrib.z) * kRec.weightKernel;
+  atomicAdd(&s.acc[0][bIdx], (float)(baseContrib.x * rr));
+  atomicAdd(&s.acc[1][bIdx], (float)(baseContrib.y * rr));
+  atomicAdd(&s.acc[2][bIdx], (float)(baseContrib.z * rr));
+  const uint32_t st = GVPM_PF_SHIFT_TYPE(b.flags);
+  if (a.cfg.debug_shift != GVPM_SHIFT_ALL && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
+    const int cur = st == 1u ? GVPM_SHIFT_DIFFUSE : st == 2u ? GVPM_SHIFT_MEDIUM : st == 3u ? GVPM_SHIFT_MANIFOLD : GVPM_SHIFT_INVALID;
+    if (a.cfg.debug_shift != cur) return false;  // base contribution kept, no shifts (shift_volume_beams.cpp:210-216)
+  }
+  const double radius = kRec.radius;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const RayReg sh = loadRay(s, 1 + i, bIdx);
+    double w = 1.0;
+    d3 sflux = mkd(0, 0, 0);
+    if (sh.valid) {
+      const double shiftDistMAX = (double)sh.len;
+      const RayD shiftRay{tod(sh.o), tod(sh.d), eps, shiftDistMAX};
+      const double shiftW = kRec.w;
+      bool alreadyShift = false;
+      if (a.cfg.use_shift_null && technique != GVPM_BEAM_BEAM_1D) {
+        const d3 kernelPos = b.p1 + b.dir * kRec.v;
+        const double ZPtoY = len2(at(shiftRay, shiftW) - kernelPos);
+        if (ZPtoY < radius * radius && kRec.w <= shiftDistMAX) {
+          KRecD kS;
+          krecShifted(kRec, b, shiftRay, kS);
+          if (kS.valid) {
+            // shiftNull3D, shift_volume_beams.cpp:748-786
+            nNull++;
+            const d3 eyeS = tod(sh.eye);
+            const double f = kpdf(kS) / kpdf(kRec);
+            sflux = mkd(kS.contrib.x * f * eyeS.x, kS.contrib.y * f * eyeS.y, kS.contrib.z * f * eyeS.z);
+            w = 0.5;
+            if (a.cfg.use_mis) {
+              const double basePdf = kpdf(kRec), offsetPdf = kpdf(kS);
+              if (offsetPdf == 0.0 || basePdf == 0.0) w = 1.0;
+              else {
+                const double x = (double)sensorMIS(sh, base, edge) * (offsetPdf / basePdf);
+                w = a.cfg.power_heuristic ? 1.0 / (1.0 + x * x) : 1.0 / (1.0 + x);
+              }
+            }
+            alreadyShift = true;
+          }
+        }
+      }
+      if (!alreadyShift && kRec.w <= shiftDistMAX) {
+        bool doShift = true;
+        d3 offsetPos;
+        if (technique != GVPM_BEAM_BEAM_1D) {  // newShiftBeam == false
+          const double minDistSqr = len2(b.p1 - at(shiftRay, dot(b.p1 - shiftRay.o, shiftRay.d)));
+          if (minDistSqr > kRec.u * kRec.u) {
+            offsetPos = getShiftPos3D(a, cam, shiftRay, kRec.w, (b.p1 + b.dir * kRec.v) - at(cam, kRec.w), radius, shiftW);
+          } else {
+            doShift = false;  // result.weight = 1
+          }
+        } else {
+          offsetPos = getShiftPos1D(cam, shiftRay, b.p1, b.dir, kRec.w, kRec.u);
+        }
+        if (doShift) {
+          // shiftBeam dispatch, shift_volume_beams.cpp:355-408
+          if (a.cfg.debug_shift == GVPM_SHIFT_NULL || shiftW > shiftRay.maxt) {
+            w = 1.0;
+          } else {
+            bool ok = false;
+            if (st == 1u || st == 2u)
+              w = shiftBeamDiffuse<B>(a, s, b, sh, base, edge, shiftRay, shiftW, kRec, offsetPos, technique, sflux, ok);
+            if (ok) nDiff++; else nFail++;
+          }
+        }
+      }
+    }
+    if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.0;
+    const double ws = w * rr;
+    if (sflux.x != 0 || sflux.y != 0 || sflux.z != 0) {
+      const double wk = ws * kRec.weightKernel;
+      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (float)(sflux.x * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (float)(sflux.y * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (float)(sflux.z * wk));
+    }
+    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (float)(baseContrib.x * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (float)(baseContrib.y * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (float)(baseContrib.z * ws));
+  }
+  return true;
+}
+
+template <int B>
+__global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const uint4 *__restrict__ items,
+                                                             const uint32_t *__restrict__ itemCount,
+                                                             uint32_t *queueHead) {
+  constexpr int LPB = 64 / B;
+  __shared__ TileLds<B> s;
+  const int lane = threadIdx.x;
+  const uint32_t nItems = *itemCount;
+  const int b = lane % B, sub = lane / B;
+  const float rT = a.radius;  // test radius = kernel radius + half a sub-beam
+  const float eps = a.cfg.epsilon;
+
+  for (uint32_t i = lane; i < min(a.ntri, (uint32_t)MAXTRI_LDS); i += 64) {
+    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
+    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
+    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
+    f3 n = cross(e1, e2);
+    const float l = sqrtf(dot(n, n));
+    n = l > 0.f ? n * (1.f / l) : mk3(0.f);
+    s.tri[i][0] = make_float4(v0.x, v0.y, v0.z, n.x);
+    s.tri[i][1] = make_float4(e1.x, e1.y, e1.z, n.y);
+    s.tri[i][2] = make_float4(e2.x, e2.y, e2.z, n.z);
+  }
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+  unsigned long long nCand = 0;
+
+  for (;;) {
+    uint32_t it = 0;
+    if (lane == 0) it = atomicAdd(queueHead, 1u);
+    it = __shfl(it, 0, 64);
+    if (it >= nItems) break;
+    const uint4 item = items[it];
+    const uint32_t setBase = item.x, nb = item.y;
+    if (nb == 0) continue;
+    __syncthreads();
+    loadTileRays<B>(a, s, setBase, nb, lane);
+    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+    __syncthreads();
+    TileWalk w;
+    tileSetup<B>(a, s, nb, lane, w);
+    const RayReg base = w.base;
+    const bool beamValid = w.beamValid;
+    const float mint = eps, maxt = base.len - eps;
+    uint32_t qHead = 0, qCount = 0;
+    const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
+    for (int cA = cBeg; cA <= cEnd; cA += w.K) {
+      const int cAe = min(cA + w.K - 1, cEnd);
+      CellBox bx;
+      if (!slabBox(a, w, cA, cAe, bx)) continue;
+      const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
+      for (int rbase = 0; rbase < nranges; rbase += 64) {
+        uint32_t start, count;
+        boxRange(a, bx, rbase + lane, nranges, start, count);
+        const uint32_t incl = wave_scan_incl(count, lane);
+        const uint32_t excl = incl - count;
+        const uint32_t total = __shfl(incl, 63, 64);
+        for (uint32_t win = 0; win < total; win += STAGE) {
+          {
+            const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
+            for (uint32_t i = lo_i; i < hi_i; ++i) s.stage[i - win] = a.hot[start + (i - excl)];
+          }
+          __syncthreads();
+          const uint32_t nst = min((uint32_t)STAGE, total - win);
+          const uint32_t iters = (nst + LPB - 1) / LPB;
+          for (uint32_t jj = 0; jj < iters; ++jj) {
+            const uint32_t j = jj * LPB + sub;
+            bool hit = false;
+            uint32_t id = 0;
+            if (beamValid && j < nst) {
+              const float4 hp = s.stage[j];
+              const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
+              const float disk = dot(wv, base.d);
+              const f3 v = wv - base.d * disk;
+              // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment
+              hit = dot(v, v) < rT * rT * 1.001f && disk > mint - rT * 1.001f && disk < maxt + rT * 1.001f;
+              id = __float_as_uint(hp.w);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+              if (hit) {
+                const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+                s.queue[(qHead + qCount + off) % QCAP] = make_uint2(id, (uint32_t)b);
+              }
+              qCount += __popcll(m);
+              nCand += __popcll(m);
+              if (qCount >= 64u) {
+                __syncthreads();
+                const uint2 e = s.queue[(qHead + lane) % QCAP];
+                if (evaluateBeam<B>(a, s, e.x, e.y, nNull, nDiff, nFail)) nEval++;
+                qHead = (qHead + 64u) % QCAP;
+                qCount -= 64u;
+                __syncthreads();
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+    if ((uint32_t)lane < qCount) {
+      const uint2 e = s.queue[(qHead + lane) % QCAP];
+      if (evaluateBeam<B>(a, s, e.x, e.y, nNull, nDiff, nFail)) nEval++;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < 27 * B; idx += 64) {
+      const int k = idx / B, bb = idx % B;
+      if ((uint32_t)bb < nb) {
+        const float v = s.acc[k][bb];
+        if (v != 0.f) {
+          const uint32_t pv = s.pix[bb];
+          const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+          atomicAdd(&a.iter[p * 27 + k], v);
+        }
+      }
+    }
+  }
+  {
+    unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ev += __shfl_xor(ev, o, 64);
+      nu += __shfl_xor(nu, o, 64);
+      di += __shfl_xor(di, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+    }
+    if (lane == 0 && (ev | nCand)) {
+      atomicAdd(&a.stats[0], ev);
+      atomicAdd(&a.stats[1], nCand);
+      atomicAdd(&a.stats[2], nu);
+      atomicAdd(&a.stats[3], di);
+      atomicAdd(&a.stats[4], fa);
+    }
+  }
+}
+
+void launch_gather_beams(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
+                         uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
+  if (a.nsets == 0) return;
+  switch (beamsPerWave) {
+    case 64: hipLaunchKernelGGL(gather_beams_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    case 32: hipLaunchKernelGGL(gather_beams_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    default: hipLaunchKernelGGL(gather_beams_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+  }
+}
+
+// ---- grid build helpers for sub-beams ------------------------------------------------------
+// counts[i] = number of sub-beams of beam i; maxLs = longest sub-beam (float bits, atomicMax)
+__global__ __launch_bounds__(256) void beam_subcount_kernel(const float *__restrict__ p2, const float *__restrict__ p1,
+                                                            uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  float sub = 0.f;
+  if (i < n) {
+    const double dx = (double)p2[3 * (size_t)i] - (double)p1[3 * (size_t)i];
+    const double dy = (double)p2[3 * (size_t)i + 1] - (double)p1[3 * (size_t)i + 1];
+    const double dz = (double)p2[3 * (size_t)i + 2] - (double)p1[3 * (size_t)i + 2];
+    const float len = (float)sqrt(dx * dx + dy * dy + dz * dz);
+    const uint32_t c = subBeamCount(len, ls);
+    counts[i] = c;
+    sub = len / (float)c;
+  }
+  sub = wave_max(sub);
+  if ((threadIdx.x & 63) == 0) atomicMax(maxLs, __float_as_uint(sub));
+}
+
+// centres[j] (xyz) and ids[j] = beam | sub << 24 for every sub-beam j = offsets[beam] + sub
+__global__ __launch_bounds__(256) void beam_expand_kernel(const float *__restrict__ p2, const float *__restrict__ p1,
+                                                          uint32_t n, const uint32_t *__restrict__ counts,
+                                                          const uint32_t *__restrict__ offsets, float *centres,
+                                                          uint32_t *ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = counts[i], o = offsets[i];
+  const f3 a = mk3(p1[3 * (size_t)i], p1[3 * (size_t)i + 1], p1[3 * (size_t)i + 2]);
+  const f3 b = mk3(p2[3 * (size_t)i], p2[3 * (size_t)i + 1], p2[3 * (size_t)i + 2]);
+  for (uint32_t k = 0; k < c; ++k) {
+    const float t = ((float)k + 0.5f) / (float)c;
+    const f3 m = a + (b - a) * t;
+    centres[3 * (size_t)(o + k)] = m.x;
+    centres[3 * (size_t)(o + k) + 1] = m.y;
+    centres[3 * (size_t)(o + k) + 2] = m.z;
+    ids[o + k] = i | (k << 24);
+  }
+}
+
+__global__ __launch_bounds__(256) void sub_hot_kernel(const float *__restrict__ centres, const uint32_t *__restrict__ ids,
+                                                      const uint32_t *__restrict__ order, uint32_t n, float4 *hot) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t src = order[j];
+  hot[j] = make_float4(centres[3 * (size_t)src], centres[3 * (size_t)src + 1], centres[3 * (size_t)src + 2],
+                       __uint_as_float(ids[src]));
+}
+
+void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(beam_subcount_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, ls, counts, maxLs);
+}
+void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint32_t *counts, const uint32_t *offsets,
+                        float *centres, uint32_t *ids, hipStream_t s) {
+  hipLaunchKernelGGL(beam_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, counts, offsets, centres, ids);
+}
+void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, float4 *hot,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, centres, ids, order, n, hot);
+}
+
+}  // namespace gvpm

@@ -33,40 +33,10 @@
 
 #include "device_types.h"
 #include "shift_device.h"
+#include "tile_walk.h"
 #include "vec.h"
 
 namespace gvpm {
-
-constexpr int STAGE = 256;
-constexpr int QCAP = 128;
-constexpr int PLAN_MAX_ITEMS = 256;  // per tile chunk
-
-template <int B> struct TileLds {
-  float4 ray4[5][3][B];  // {o, len (<0: invalid)} {d, pdf} {eye, jacobian}
-  float gop[5][B];
-  float acc[27][B];
-  float4 stage[STAGE];
-  uint32_t stageIdx[STAGE];
-  uint2 queue[QCAP];
-  float4 tri[MAXTRI_LDS][3];  // {v0,n.x} {e1,n.y} {e2,n.z}
-  float rnd[B];
-  uint32_t pix[B];
-  uint32_t edge[B];
-};
-
-template <int B> __device__ __forceinline__ RayReg loadRay(const TileLds<B> &s, int k, int b) {
-  RayReg r;
-  const float4 q0 = s.ray4[k][0][b], q1 = s.ray4[k][1][b], q2 = s.ray4[k][2][b];
-  r.o = mk3(q0.x, q0.y, q0.z);
-  r.len = fabsf(q0.w);
-  r.valid = q0.w >= 0.f;
-  r.d = mk3(q1.x, q1.y, q1.z);
-  r.pdf = q1.w;
-  r.eye = mk3(q2.x, q2.y, q2.z);
-  r.jac = q2.w;
-  r.gop = s.gop[k][b];
-  return r;
-}
 
 // ---- exact predicate (fp64, no contraction): gvpm_accel.h:279-301 + aabb.h:310-340 ----
 struct HitGeom {
@@ -256,223 +226,6 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
     atomicAdd(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
     atomicAdd(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
     atomicAdd(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Tile traversal state shared by the planner and the gather kernel
-// ------------------------------------------------------------------------------------------
-struct TileWalk {
-  // per lane
-  RayReg base;
-  bool beamValid;
-  float oA, dA, oU, dU, oV, dV, t0, t1;
-  // wave-uniform
-  int A, cA0, cA1, K;
-  float orgA, orgU, orgV, pad;
-  int dimU, dimV;
-  bool any;
-};
-
-template <int B>
-__device__ __forceinline__ void loadTileRays(const GatherArgs &a, TileLds<B> &s, uint32_t setBase, uint32_t nb,
-                                             int lane) {
-  for (int idx = lane; idx < B * 20; idx += 64) {
-    const int b = idx / 20, k = (idx % 20) / 4, q = idx % 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool valid = false;
-    if ((uint32_t)b < nb) {
-      const uint32_t set = a.setPerm[setBase + b];
-      const gvpm_camera_ray *ray = a.rays + (size_t)set * 5 + k;
-      v = reinterpret_cast<const float4 *>(ray)[q];
-      if (q == 0) valid = GVPM_RAY_VALID(ray->info) != 0;
-    }
-    if (q == 0) {
-      // the valid bit rides on the sign of len
-      const float l = fabsf(v.w);
-      v.w = valid ? l : -fmaxf(l, 1e-30f);
-      s.ray4[k][0][b] = v;
-    } else if (q < 3) {
-      s.ray4[k][q][b] = v;
-    } else {
-      s.gop[k][b] = v.x;
-      if (k == 0) {
-        s.rnd[b] = v.z;
-        s.pix[b] = __float_as_uint(v.w);
-        s.edge[b] = GVPM_RAY_EDGE(__float_as_uint(v.y));
-      }
-    }
-  }
-  __syncthreads();
-}
-
-template <int B>
-__device__ __forceinline__ void tileSetup(const GatherArgs &a, const TileLds<B> &s, uint32_t nb, int lane,
-                                          TileWalk &w) {
-  const int b = lane % B;
-  w.base = loadRay(s, 0, b);
-  w.beamValid = (uint32_t)b < nb && w.base.valid;
-  const float r = a.radius, eps = a.cfg.epsilon;
-  const float mint = eps, maxt = w.base.len - eps;
-  int A;
-  {
-    const float ax = fabsf(w.base.d.x), ay = fabsf(w.base.d.y), az = fabsf(w.base.d.z);
-    const int my = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-    const int n0 = __popcll(__ballot(w.beamValid && my == 0));
-    const int n1 = __popcll(__ballot(w.beamValid && my == 1));
-    const int n2 = __popcll(__ballot(w.beamValid && my == 2));
-    A = (n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2);
-  }
-  w.A = A;
-  const int U = (A + 1) % 3, V = (A + 2) % 3;
-  w.oA = comp(w.base.o, A); w.dA = comp(w.base.d, A);
-  w.oU = comp(w.base.o, U); w.dU = comp(w.base.d, U);
-  w.oV = comp(w.base.o, V); w.dV = comp(w.base.d, V);
-  const f3 org = mk3(a.grid.org[0], a.grid.org[1], a.grid.org[2]);
-  w.orgA = comp(org, A); w.orgU = comp(org, U); w.orgV = comp(org, V);
-  const int dimA = A == 0 ? a.grid.dim[0] : (A == 1 ? a.grid.dim[1] : a.grid.dim[2]);
-  w.dimU = U == 0 ? a.grid.dim[0] : (U == 1 ? a.grid.dim[1] : a.grid.dim[2]);
-  w.dimV = V == 0 ? a.grid.dim[0] : (V == 1 ? a.grid.dim[1] : a.grid.dim[2]);
-  w.pad = r * 1.01f + 1e-6f;
-  // fattened parameter range: photons may hit with diskDistance up to ~maxt + sqrt(3) r
-  w.t0 = mint - 2.f * r;
-  w.t1 = maxt + 2.f * r;
-  float aLo = INFINITY, aHi = -INFINITY;
-  if (w.beamValid) {
-    const float e0 = w.oA + w.dA * w.t0, e1 = w.oA + w.dA * w.t1;
-    aLo = fminf(e0, e1) - w.pad;
-    aHi = fmaxf(e0, e1) + w.pad;
-  }
-  aLo = wave_min(aLo);
-  aHi = wave_max(aHi);
-  w.any = aLo <= aHi && a.nph > 0;
-  w.cA0 = 1;
-  w.cA1 = 0;
-  if (w.any) {
-    w.cA0 = max(0, (int)floorf((aLo - w.orgA) * a.grid.invCell));
-    w.cA1 = min(dimA - 1, (int)floorf((aHi - w.orgA) * a.grid.invCell));
-  }
-  // layers per step: thicker slabs when the contiguous (x) axis is the slab axis
-  w.K = (A == 0) ? 8 : a.cfg.reserved[1] ? a.cfg.reserved[1] : 4;
-}
-
-struct CellBox {
-  int bx0, bx1, by0, by1, bz0, bz1;
-};
-
-// cell box of the slab layers [cA, cAe]; false when no beam of the tile reaches the slab
-__device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, int cA, int cAe, CellBox &bx) {
-  const float lo = w.orgA + cA * a.grid.cell - w.pad, hi = w.orgA + (cAe + 1) * a.grid.cell + w.pad;
-  float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
-  if (w.beamValid) {
-    float ta = w.t0, tb = w.t1;
-    bool act = true;
-    if (fabsf(w.dA) > 1e-12f) {
-      const float inv = 1.f / w.dA;
-      const float s0 = (lo - w.oA) * inv, s1 = (hi - w.oA) * inv;
-      ta = fmaxf(ta, fminf(s0, s1));
-      tb = fminf(tb, fmaxf(s0, s1));
-      act = ta <= tb;
-    } else {
-      act = w.oA >= lo && w.oA <= hi;
-    }
-    if (act) {
-      const float u0 = w.oU + w.dU * ta, u1 = w.oU + w.dU * tb, v0 = w.oV + w.dV * ta, v1 = w.oV + w.dV * tb;
-      uLo = fminf(u0, u1) - w.pad; uHi = fmaxf(u0, u1) + w.pad;
-      vLo = fminf(v0, v1) - w.pad; vHi = fmaxf(v0, v1) + w.pad;
-    }
-  }
-  uLo = wave_min(uLo); uHi = wave_max(uHi);
-  vLo = wave_min(vLo); vHi = wave_max(vHi);
-  if (!(uLo <= uHi)) return false;
-  const int cU0 = max(0, (int)floorf((uLo - w.orgU) * a.grid.invCell));
-  const int cU1 = min(w.dimU - 1, (int)floorf((uHi - w.orgU) * a.grid.invCell));
-  const int cV0 = max(0, (int)floorf((vLo - w.orgV) * a.grid.invCell));
-  const int cV1 = min(w.dimV - 1, (int)floorf((vHi - w.orgV) * a.grid.invCell));
-  if (cU0 > cU1 || cV0 > cV1) return false;
-  // (A,U,V) -> (x,y,z): A=0: x=A y=U z=V; A=1: x=V y=A z=U; A=2: x=U y=V z=A
-  const int A = w.A;
-  bx.bx0 = A == 0 ? cA : (A == 1 ? cV0 : cU0); bx.bx1 = A == 0 ? cAe : (A == 1 ? cV1 : cU1);
-  bx.by0 = A == 0 ? cU0 : (A == 1 ? cA : cV0); bx.by1 = A == 0 ? cU1 : (A == 1 ? cAe : cV1);
-  bx.bz0 = A == 0 ? cV0 : (A == 1 ? cU0 : cA); bx.bz1 = A == 0 ? cV1 : (A == 1 ? cU1 : cAe);
-  return true;
-}
-
-// x-contiguous photon range of this lane for range index ri of the box
-__device__ __forceinline__ void boxRange(const GatherArgs &a, const CellBox &bx, int ri, int nranges, uint32_t &start,
-                                         uint32_t &count) {
-  start = 0;
-  count = 0;
-  if (ri < nranges) {
-    const int nyr = bx.by1 - bx.by0 + 1;
-    const int y = bx.by0 + ri % nyr, z = bx.bz0 + ri / nyr;
-    const uint32_t row = ((uint32_t)z * a.grid.dim[1] + y) * a.grid.dim[0];
-    start = a.cellStart[row + bx.bx0];
-    count = a.cellStart[row + bx.bx1 + 1] - start;
-  }
-}
-
-// number of photons staged for a slab step (sum over the box's ranges), wave-uniform
-__device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox &bx, int lane) {
-  const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
-  uint32_t c = 0;
-  for (int rbase = 0; rbase < nranges; rbase += 64) {
-    uint32_t st, cnt;
-    boxRange(a, bx, rbase + lane, nranges, st, cnt);
-    c += cnt;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  return c;
-}
-
-// ------------------------------------------------------------------------------------------
-// plan: cut every tile chunk into work items of ~equal candidate count
-// item = {setBase, nb, firstLayer, lastLayer}
-// ------------------------------------------------------------------------------------------
-template <int B>
-__global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
-                                                  uint32_t *itemCount) {
-  __shared__ TileLds<B> s;
-  const int lane = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  const uint32_t tileBeg = a.tileStart[tile], tileEnd = a.tileStart[tile + 1];
-  for (uint32_t setBase = tileBeg; setBase < tileEnd; setBase += B) {
-    const uint32_t nb = min((uint32_t)B, tileEnd - setBase);
-    loadTileRays<B>(a, s, setBase, nb, lane);
-    TileWalk w;
-    tileSetup<B>(a, s, nb, lane, w);
-    if (!w.any) continue;
-    // pass A: total candidates of the chunk
-    uint32_t total = 0;
-    for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
-      CellBox bx;
-      if (slabBox(a, w, cA, min(cA + w.K - 1, w.cA1), bx)) total += boxCount(a, bx, lane);
-    }
-    if (total == 0) continue;
-    const uint32_t nItems = min((uint32_t)PLAN_MAX_ITEMS, (total + target - 1) / target);
-    const uint32_t per = (total + nItems - 1) / nItems;
-    uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(itemCount, nItems);
-    slot = __shfl(slot, 0, 64);
-    // pass B: emit items at the crossings of k * per
-    uint32_t run = 0, emitted = 0;
-    int first = w.cA0;
-    for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
-      const int cAe = min(cA + w.K - 1, w.cA1);
-      CellBox bx;
-      if (slabBox(a, w, cA, cAe, bx)) run += boxCount(a, bx, lane);
-      const bool last = cAe == w.cA1;
-      if ((run >= per && emitted + 1 < nItems) || last) {
-        if (lane == 0) items[slot + emitted] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
-        emitted++;
-        run = 0;
-        first = cAe + 1;
-      }
-    }
-    // unused reserved slots (possible when the crossings come late): mark empty
-    for (uint32_t e = emitted + lane; e < nItems; e += 64) items[slot + e] = make_uint4(setBase, 0u, 1u, 0u);
   }
 }
 

@@ -14,6 +14,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "device_types.h"
+#include "shift_device.h"
 #include "vec.h"
 
 namespace gvpm {
@@ -82,31 +83,6 @@ struct RawPhotons {
 
 __device__ __forceinline__ float4 ld3(const float *p, uint32_t i, float w) {
   return make_float4(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2], w);
-}
-
-// computeVolumeContribution (gvpm/shift/shift_utilities.h:231-253) and the debugShift filter
-// (shift_volume_photon.cpp:680-687) depend only on the photon and the configuration: fold
-// them into bit 6 of the hot record.
-__device__ __forceinline__ bool photonContributes(uint32_t flags, const gvpm_params &cfg) {
-  const int mode = cfg.lighting_interaction_mode;
-  const uint32_t ptype = GVPM_PF_PARENT_TYPE(flags);
-  if (!((mode & GVPM_SURF2MEDIA) && (mode & GVPM_MEDIA2MEDIA))) {
-    if (ptype == GVPM_PARENT_MEDIUM && !(mode & GVPM_MEDIA2MEDIA)) return false;
-    if (ptype != GVPM_PARENT_MEDIUM && !(mode & GVPM_SURF2MEDIA)) return false;
-  }
-  const int compo = (int)GVPM_PF_PREV_COMPONENT(flags);
-  if (cfg.bsdf_interaction_mode != GVPM_BSDF_ALL && compo > 0 && !(compo & cfg.bsdf_interaction_mode)) return false;
-  if (cfg.debug_shift != GVPM_SHIFT_ALL && cfg.debug_shift != GVPM_SHIFT_NULL) {
-    int st;
-    switch (GVPM_PF_SHIFT_TYPE(flags)) {
-      case 1: st = GVPM_SHIFT_DIFFUSE; break;
-      case 2: st = GVPM_SHIFT_MEDIUM; break;
-      case 3: st = GVPM_SHIFT_MANIFOLD; break;
-      default: st = GVPM_SHIFT_INVALID; break;
-    }
-    if (cfg.debug_shift != st) return false;
-  }
-  return true;
 }
 
 // Occluders a shadow segment of length <= dmax starting at the photon's parent can reach:
@@ -214,6 +190,47 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
   e = ensureTemp(tmp, need);
   if (e != hipSuccess) return e;
   return hipcub::DeviceRadixSort::SortPairs(tmp.d, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
+}
+
+hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s) {
+  size_t need = 0;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, s);
+  if (e != hipSuccess) return e;
+  e = ensureTemp(tmp, need);
+  if (e != hipSuccess) return e;
+  return hipcub::DeviceScan::ExclusiveSum(tmp.d, need, in, out, (int)n, s);
+}
+
+// cold planes of photon beams (indexed by beam, not sorted): the 7 photon planes + {p2, bits} + {endN, -}
+__global__ __launch_bounds__(256) void beam_cold_kernel(RawPhotons r, const float *__restrict__ endN, uint32_t n,
+                                                        gvpm_params cfg, float4 *cold) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t bits = r.flags[i] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
+  // for beams the debugShift filter only suppresses the shifts (shift_volume_beams.cpp:210-216),
+  // so only computeVolumeContribution is folded into bit 6
+  gvpm_params c2 = cfg;
+  c2.debug_shift = GVPM_SHIFT_ALL;
+  if (photonContributes(bits, c2)) bits |= 1u << 6;
+  bits |= (r.path_id[i] & 1u) << GVPM_HOT_PARITY_BIT;
+  const size_t N = n;
+  cold[0 * N + i] = ld3(r.wi, i, r.parent_pdf[i]);
+  cold[1 * N + i] = ld3(r.flux, i, r.edge_pdf[i]);
+  cold[2 * N + i] = ld3(r.parent_pos, i, r.parent_rr[i]);
+  cold[3 * N + i] = ld3(r.parent_n, i, r.parent_g[i]);
+  cold[4 * N + i] = ld3(r.prefix_w, i, 0.f);
+  cold[5 * N + i] = ld3(r.parent_scat, i, 0.f);
+  cold[6 * N + i] = ld3(r.parent_wi, i, 0.f);
+  cold[7 * N + i] = ld3(r.pos, i, __uint_as_float(bits));
+  cold[8 * N + i] = ld3(endN, i, 0.f);
+}
+
+void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg, float4 *cold,
+                      hipStream_t s) {
+  RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
+               raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
+               raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
+  hipLaunchKernelGGL(beam_cold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, endN, n, cfg, cold);
 }
 
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s) {

@@ -38,6 +38,17 @@ void launch_gather_vpm(const GatherArgs &a, hipStream_t stream);
 void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
                        hipStream_t stream);
 void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);
+hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s);
+void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg, float4 *cold,
+                      hipStream_t s);
+void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
+                          hipStream_t s);
+void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint32_t *counts, const uint32_t *offsets,
+                        float *centres, uint32_t *ids, hipStream_t s);
+void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, float4 *hot,
+                    hipStream_t s);
+void launch_gather_beams(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
+                         uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
 }  // namespace gvpm
 
 using namespace gvpm;
@@ -119,6 +130,14 @@ struct gvpm_context {
   bool haveBeams = false, beamsDirty = false;
   DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
   uint32_t ntiles = 0;
+
+  // G-Beams: raw upload shares rawF/rawU/rawDev with the photons; end normals + sub-beam build
+  DevBuf<float> endNOwned, subCentres;
+  const float *endNDev = nullptr;
+  bool haveBeamsMap = false;
+  DevBuf<uint32_t> subCounts, subOffsets, subIds, beamCtl;
+  uint32_t nsub = 0;
+  float subLen = 0.f, maxSubLen = 0.f;
 
   // G-VPM: camera samples + per-pixel SPPM state
   DevBuf<gvpm_vpm_sample> samplesOwned;
@@ -271,6 +290,8 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->sortTmp.d) (void)hipFree(h->sortTmp.d);
   h->raysOwned.release(); h->bKeysA.release(); h->bKeysB.release(); h->bValsA.release();
   h->setPerm.release(); h->tileStart.release(); h->items.release(); h->queueCtl.release();
+  h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
+  h->subIds.release(); h->beamCtl.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -392,6 +413,34 @@ int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *p) {
 int gvpm_upload_photons_dev(gvpm_context *h, const gvpm_photon_soa *p) {
   CHECK_H(h);
   return uploadPhotonsCommon(h, p, true);
+}
+
+static int uploadPhotonBeamsCommon(gvpm_context *h, const gvpm_photon_soa *b, const float *end_n, bool fromDevice) {
+  if (b && b->n && !end_n) return fail(h, GVPM_ERR_INVALID_ARG, "null end_n");
+  if (b && b->n > 0xFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "too many beams (24-bit beam index)");
+  int rc = uploadPhotonsCommon(h, b, fromDevice);
+  if (rc != GVPM_OK) return rc;
+  if (fromDevice) {
+    h->endNDev = end_n;
+  } else {
+    HIP_TRY(h, h->endNOwned.ensure((size_t)h->nph * 3 + 4));
+    if (h->nph) {
+      HIP_TRY(h, hipMemcpyAsync(h->endNOwned.p, end_n, (size_t)h->nph * 12, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->endNDev = h->endNOwned.p;
+  }
+  h->haveBeamsMap = true;
+  return GVPM_OK;
+}
+
+int gvpm_upload_beams(gvpm_context *h, const gvpm_photon_soa *beams, const float *end_n) {
+  CHECK_H(h);
+  return uploadPhotonBeamsCommon(h, beams, end_n, false);
+}
+int gvpm_upload_beams_dev(gvpm_context *h, const gvpm_photon_soa *beams, const float *end_n) {
+  CHECK_H(h);
+  return uploadPhotonBeamsCommon(h, beams, end_n, true);
 }
 
 static int uploadBeamsCommon(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t nsets, bool fromDevice) {
@@ -576,6 +625,9 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.nsamples = h->nsamples;
   a.scaleVol = h->scaleVol.p;
   a.mvol = h->mvol.p;
+  a.kernelRadius = r;
+  a.subLen = 0.f;
+  a.nbeams = 0;
 }
 
 static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev) {
@@ -630,6 +682,130 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   return GVPM_OK;
 }
 
+// sub-beam grid for photon beams of kernel radius r
+static int buildBeamGrid(gvpm_context *h, float r) {
+  const uint32_t n = h->nph;
+  h->nsub = 0;
+  h->maxSubLen = 0.f;
+  HIP_TRY(h, h->cold.ensure((size_t)(n + 1) * 9));
+  if (n == 0) {
+    h->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
+    HIP_TRY(h, h->cellStart.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->cellStart.p, 0, 2 * sizeof(uint32_t), h->stream));
+    h->subLen = r;
+    return GVPM_OK;
+  }
+  // bounds of the beam end points and origins
+  const int nblocks = 256;
+  HIP_TRY(h, h->boundsPartial.ensure(nblocks * 6));
+  HIP_TRY(h, h->bounds6.ensure(16));
+  launch_bounds(h->rawDev.pos, n, h->boundsPartial.p, nblocks, h->bounds6.p, h->stream);
+  launch_bounds(h->rawDev.parent_pos, n, h->boundsPartial.p, nblocks, h->bounds6.p + 6, h->stream);
+  float b12[12];
+  HIP_TRY(h, hipMemcpyAsync(b12, h->bounds6.p, sizeof(b12), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float b6[6], ext = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    b6[c] = fminf(b12[c], b12[6 + c]);
+    b6[3 + c] = fmaxf(b12[3 + c], b12[9 + c]);
+    if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite beam position");
+    ext = fmaxf(ext, b6[3 + c] - b6[c]);
+  }
+  Grid g;
+  float cell = fmaxf(1.5f * h->cellScale * r, ext / 256.f);
+  if (!(cell > 0.f)) cell = 1.f;
+  g.cell = cell;
+  g.invCell = 1.f / cell;
+  uint64_t nc = 1;
+  for (int c = 0; c < 3; ++c) {
+    g.org[c] = b6[c] - 0.5f * cell;
+    g.dim[c] = (int)floorf((b6[3 + c] - g.org[c]) * g.invCell) + 2;
+    nc *= (uint64_t)g.dim[c];
+  }
+  if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
+  g.ncells = (uint32_t)nc;
+  h->grid = g;
+  h->subLen = cell;
+  // cut the beams into sub-beams of about one cell
+  HIP_TRY(h, h->subCounts.ensure(n + 1));
+  HIP_TRY(h, h->subOffsets.ensure(n + 1));
+  HIP_TRY(h, h->beamCtl.ensure(4));
+  HIP_TRY(h, hipMemsetAsync(h->beamCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
+  launch_beam_subcount(h->rawDev.pos, h->rawDev.parent_pos, n, h->subLen, h->subCounts.p, h->beamCtl.p, h->stream);
+  HIP_TRY(h, exclusiveSumU32(h->sortTmp, h->subCounts.p, h->subOffsets.p, n, h->stream));
+  uint32_t lastOff = 0, lastCnt = 0, maxBits = 0;
+  HIP_TRY(h, hipMemcpyAsync(&lastOff, h->subOffsets.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&lastCnt, h->subCounts.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&maxBits, h->beamCtl.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const uint64_t S = (uint64_t)lastOff + lastCnt;
+  if (S > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many sub-beams");
+  h->nsub = (uint32_t)S;
+  memcpy(&h->maxSubLen, &maxBits, 4);
+  HIP_TRY(h, h->subCentres.ensure(S * 3 + 4));
+  HIP_TRY(h, h->subIds.ensure(S + 1));
+  HIP_TRY(h, h->keysA.ensure(S));
+  HIP_TRY(h, h->keysB.ensure(S));
+  HIP_TRY(h, h->valsA.ensure(S));
+  HIP_TRY(h, h->valsB.ensure(S));
+  HIP_TRY(h, h->hot.ensure(S));
+  HIP_TRY(h, h->cellStart.ensure((size_t)g.ncells + 2));
+  launch_beam_expand(h->rawDev.pos, h->rawDev.parent_pos, n, h->subCounts.p, h->subOffsets.p, h->subCentres.p,
+                     h->subIds.p, h->stream);
+  launch_cell_keys(h->subCentres.p, h->nsub, g, h->keysA.p, h->valsA.p, h->stream);
+  HIP_TRY(h, sortPairsU32(h->sortTmp, h->keysA.p, h->keysB.p, h->valsA.p, h->valsB.p, h->nsub,
+                          ilog2ceil(g.ncells + 1), h->stream));
+  launch_sub_hot(h->subCentres.p, h->subIds.p, h->valsB.p, h->nsub, h->hot.p, h->stream);
+  launch_segment_start(h->keysB.p, h->nsub, g.ncells, 0, h->cellStart.p, h->stream);
+  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->cold.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
+// computeVolumeGradientBeams, gvpm.cpp:880-986
+static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
+  if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
+  const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
+  if (h->photonsDirty || r != h->builtRadius) {
+    int rc = buildBeamGrid(h, r);
+    if (rc != GVPM_OK) return rc;
+    h->photonsDirty = false;
+    h->builtRadius = r;
+  }
+  if (h->beamsDirty) {
+    int rc = sortBeams(h);
+    if (rc != GVPM_OK) return rc;
+    h->beamsDirty = false;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  GatherArgs a;
+  fillArgs(h, a, r);
+  a.kernelRadius = r;
+  a.radius = r + 0.5f * h->maxSubLen * 1.001f + 1e-6f;  // traversal radius: sub-beams are binned by their centre
+  a.subLen = h->subLen;
+  a.nbeams = h->nph;
+  a.nph = h->nsub;
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, h->items.ensure(plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave)));
+  HIP_TRY(h, h->queueCtl.ensure(4));
+  HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
+  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->stream);
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+  launch_gather_beams(a, h->beamsPerWave, h->items.p, h->queueCtl.p, h->queueCtl.p + 1, h->nwaves, h->stream);
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  {
+    // scaleVolumeAPA(it): cube root for the 3D kernels, linear for the 1D kernel (gvpm.cpp:195-201)
+    const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
+    const double f = h->cfg.vol_technique == GVPM_BEAM_BEAM_1D ? ratio : std::cbrt(ratio);
+    h->globalScaleVolume = (float)(h->globalScaleVolume * f);
+  }
+  return GVPM_OK;
+}
+
 // computeVolumeGradientPhoton (G-VPM), gvpm.cpp:1081-1203
 static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   (void)it;
@@ -676,6 +852,8 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     case GVPM_VOL_BRE2D:
     case GVPM_VOL_BRE3D: return gatherBRE(h, it, nb_paths);
     case GVPM_DISTANCE: return gatherVPM(h, it, nb_paths);
+    case GVPM_BEAM_BEAM_1D:
+    case GVPM_BEAM_BEAM_3D_OPTIMIZED: return gatherBeams(h, it, nb_paths);
     default: return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
   }
 }

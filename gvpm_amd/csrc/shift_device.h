@@ -206,4 +206,30 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const float4 
   return w;
 }
 
+// computeVolumeContribution (gvpm/shift/shift_utilities.h:231-253) and the debugShift filter
+// (shift_volume_photon.cpp:680-687) depend only on the photon and the configuration: fold
+// them into bit 6 of the hot record.
+__device__ __forceinline__ bool photonContributes(uint32_t flags, const gvpm_params &cfg) {
+  const int mode = cfg.lighting_interaction_mode;
+  const uint32_t ptype = GVPM_PF_PARENT_TYPE(flags);
+  if (!((mode & GVPM_SURF2MEDIA) && (mode & GVPM_MEDIA2MEDIA))) {
+    if (ptype == GVPM_PARENT_MEDIUM && !(mode & GVPM_MEDIA2MEDIA)) return false;
+    if (ptype != GVPM_PARENT_MEDIUM && !(mode & GVPM_SURF2MEDIA)) return false;
+  }
+  const int compo = (int)GVPM_PF_PREV_COMPONENT(flags);
+  if (cfg.bsdf_interaction_mode != GVPM_BSDF_ALL && compo > 0 && !(compo & cfg.bsdf_interaction_mode)) return false;
+  if (cfg.debug_shift != GVPM_SHIFT_ALL && cfg.debug_shift != GVPM_SHIFT_NULL) {
+    int st;
+    switch (GVPM_PF_SHIFT_TYPE(flags)) {
+      case 1: st = GVPM_SHIFT_DIFFUSE; break;
+      case 2: st = GVPM_SHIFT_MEDIUM; break;
+      case 3: st = GVPM_SHIFT_MANIFOLD; break;
+      default: st = GVPM_SHIFT_INVALID; break;
+    }
+    if (cfg.debug_shift != st) return false;
+  }
+  return true;
+}
+
+
 }  // namespace gvpm

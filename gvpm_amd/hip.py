@@ -19,6 +19,7 @@ SYMBOLS = [
     "gvpm_create", "gvpm_destroy", "gvpm_last_error", "gvpm_abi_version", "gvpm_reset",
     "gvpm_upload_scene", "gvpm_upload_medium", "gvpm_upload_photons", "gvpm_upload_camera_beams",
     "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_upload_vpm_samples",
+    "gvpm_upload_beams", "gvpm_upload_beams_dev",
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
@@ -53,6 +54,8 @@ def lib():
         L.gvpm_upload_photons_dev.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
         L.gvpm_upload_camera_beams.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_camera_beams_dev.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_beams.argtypes = [vp, C.POINTER(abi.PhotonSoA), vp]
+        L.gvpm_upload_beams_dev.argtypes = [vp, C.POINTER(abi.PhotonSoA), vp]
         L.gvpm_upload_vpm_samples.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_vpm_samples_dev.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_download_vpm_state.argtypes = [vp, vp, vp]
@@ -125,6 +128,12 @@ class Context:
 
     def upload_camera_beams_dev(self, dev_ptr, n_sets):
         self._check(lib().gvpm_upload_camera_beams_dev(self._h, dev_ptr, n_sets))
+
+    def upload_beams(self, beams, end_n):
+        """beams: abi.Photons re-read as photon beams; end_n: (n,3) float32"""
+        soa = beams.soa()
+        end_n = np.ascontiguousarray(end_n, np.float32)
+        self._check(lib().gvpm_upload_beams(self._h, C.byref(soa), end_n.ctypes.data if beams.n else None))
 
     def upload_vpm_samples(self, samples):
         samples = np.ascontiguousarray(samples)

@@ -33,6 +33,9 @@ def lib():
                                        C.POINTER(C.c_void_p)]
         L.gvpm_synth_vpm_samples.restype = C.c_uint64
         L.gvpm_synth_vpm_samples.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.gvpm_synth_shoot_beams.restype = C.c_uint64
+        L.gvpm_synth_shoot_beams.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(abi.PhotonSoA),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         _LIB = L
     return _LIB
 
@@ -78,6 +81,17 @@ class SynthScene:
         nb = C.c_uint64(0)
         lib().gvpm_synth_shoot(self._h, iteration, capacity, C.byref(soa), C.byref(nb))
         return abi.Photons.from_soa(soa), int(nb.value)
+
+    def shoot_beams(self, iteration, capacity):
+        """-> (abi.Photons re-read as photon beams, end_n (n,3) float32, nb_paths)"""
+        soa = abi.PhotonSoA()
+        nb = C.c_uint64(0)
+        ptr = C.c_void_p()
+        n = lib().gvpm_synth_shoot_beams(self._h, iteration, capacity, C.byref(soa), C.byref(ptr), C.byref(nb))
+        beams = abi.Photons.from_soa(soa)
+        end_n = (np.array((C.c_float * (3 * n)).from_address(ptr.value), np.float32).reshape(n, 3).copy()
+                 if n else np.zeros((0, 3), np.float32))
+        return beams, end_n, int(nb.value)
 
     def camera_beams(self, iteration, x0=0, y0=0, x1=None, y1=None):
         """-> structured array (n_sets, 5) of gvpm_camera_ray"""

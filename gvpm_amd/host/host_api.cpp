@@ -10,6 +10,7 @@ struct gvpm_synth {
   std::vector<gvpm_camera_ray> rays;
   std::vector<float> v0, e1, e2;
   std::vector<gvpm_vpm_sample> samples;
+  std::vector<float> endN;
 };
 
 extern "C" {
@@ -60,6 +61,16 @@ uint64_t gvpm_synth_shoot(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_
   uint64_t np = gvpm::shootPhotons(s->scene, it, capacity, s->photons);
   if (nb_paths) *nb_paths = np;
   s->photons.view(*out);
+  return s->photons.n;
+}
+
+uint64_t gvpm_synth_shoot_beams(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_soa *out,
+                                const float **end_n, uint64_t *nb_paths) {
+  if (!s || !out || !end_n) return 0;
+  uint64_t np = gvpm::shootBeams(s->scene, it, capacity, s->photons, s->endN);
+  if (nb_paths) *nb_paths = np;
+  s->photons.view(*out);
+  *end_n = s->endN.data();
   return s->photons.n;
 }
 

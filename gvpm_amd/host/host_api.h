@@ -17,6 +17,9 @@ int gvpm_synth_triangles(gvpm_synth *s, gvpm_triangles *out);
  * *out points into buffers owned by `s` (valid until the next shoot) */
 uint64_t gvpm_synth_shoot(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_soa *out,
                           uint64_t *nb_paths);
+/* photon beams of iteration `it` (see gvpm_upload_beams); *end_n: 3 floats per beam */
+uint64_t gvpm_synth_shoot_beams(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_soa *out,
+                                const float **end_n, uint64_t *nb_paths);
 /* camera beam sets of the pixel rectangle; returns the number of sets */
 uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
                           const gvpm_camera_ray **out);

@@ -419,10 +419,64 @@ static int typeShift(const SynthScene &sc, const std::vector<LVertex> &p, size_t
 }
 
 struct PhotonRec {
-  V3 pos, wi, flux, parentPos, parentN, prefixW, parentScat, parentWi;
+  V3 pos, wi, flux, parentPos, parentN, prefixW, parentScat, parentWi, endN;
   float parentPdf, edgePdf, parentRR, parentG;
   uint32_t flags;
 };
+
+static void fillParent(const SynthScene &sc, const std::vector<LVertex> &path, size_t ip, PhotonRec &r,
+                       uint32_t &ptype) {
+  const LVertex &par = path[ip];
+  r.parentPos = par.pos;
+  r.parentN = par.n;
+  r.parentScat = V3(0.0);
+  r.parentWi = V3(1.0, 0.0, 0.0);
+  ptype = GVPM_PARENT_EMITTER;
+  if (par.type == VT_SURFACE) {
+    ptype = GVPM_PARENT_SURFACE;
+    r.parentScat = par.albedo;
+    r.parentWi = normalize(path[ip - 1].pos - par.pos);
+  } else if (par.type == VT_MEDIUM) {
+    ptype = GVPM_PARENT_MEDIUM;
+    r.parentScat = V3(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
+    r.parentWi = normalize(path[ip - 1].pos - par.pos);
+  }
+  r.parentPdf = (float)par.pdf;
+  r.edgePdf = (float)par.ePdf;
+  r.parentRR = (float)par.rr;
+  r.parentG = sc.medium.g;
+}
+
+// LTBeamMap::tryAppendLT + LTPhotonBeam (gvpm/gvpm_beams.h:18-84) without capacity / pathID bookkeeping.
+// Returns false when the path had medium edges but all of them were culled by the camera sphere
+// (tryAppendLT returns -1: the path is then not counted as shot, gvpm_proc.cpp:330-336).
+static bool flattenBeams(const SynthScene &sc, const std::vector<LVertex> &path, std::vector<PhotonRec> &recs) {
+  recs.clear();
+  for (size_t i = 1; i + 1 < path.size(); ++i)
+    if (path[i].pdf == 0.0) return true;
+  const size_t first = (size_t)std::max(sc.minDepth, 1);
+  V3 w(1.0);
+  for (size_t k = 0; k < first && k < path.size(); ++k) w = w * path[k].weight * path[k].rr * path[k].eWeight;
+  bool any = false;
+  for (size_t i = first; i + 1 < path.size(); ++i) {
+    const V3 prefix = w;  // prod_{k<i}
+    w = w * path[i].weight * path[i].rr * path[i].eWeight;
+    if (!path[i].eMedium) continue;
+    any = true;
+    if (cameraHit(sc, path[i].pos, path[i + 1].pos)) continue;
+    PhotonRec r;
+    uint32_t ptype;
+    fillParent(sc, path, i, r, ptype);
+    r.pos = path[i + 1].pos;
+    r.wi = normalize(path[i].pos - path[i + 1].pos);
+    r.flux = prefix * path[i].weight * path[i].rr;  // without the transmittance of edge i
+    r.prefixW = prefix;
+    r.endN = path[i + 1].type == VT_SURFACE ? path[i + 1].n : V3(0.0);
+    r.flags = GVPM_PF_MAKE(ptype, typeShift(sc, path, i + 1), 1, i, GVPM_BSDF_DIFFUSE_REFLECTION);
+    recs.push_back(r);
+  }
+  return !(any && recs.empty());
+}
 
 // GPhotonMap::tryAppend (gvpm/gvpm_accel.h:119-199) without the capacity / pathID bookkeeping
 static void flattenPath(const SynthScene &sc, const std::vector<LVertex> &path, std::vector<PhotonRec> &recs) {
@@ -468,8 +522,22 @@ static void flattenPath(const SynthScene &sc, const std::vector<LVertex> &path, 
   }
 }
 
+static uint64_t shootCommon(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out, bool beams,
+                            std::vector<float> *endN);
+
 uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out) {
+  return shootCommon(sc, iteration, capacity, out, false, nullptr);
+}
+
+uint64_t shootBeams(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out,
+                    std::vector<float> &endN) {
+  return shootCommon(sc, iteration, capacity, out, true, &endN);
+}
+
+static uint64_t shootCommon(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out, bool beams,
+                            std::vector<float> *endN) {
   out.clear();
+  if (endN) endN->clear();
   uint64_t nbPaths = 0;
   uint32_t nbLightPathAdded = 0;
   // Paths are keyed by their index, so chunks of them can be generated by worker threads and
@@ -478,15 +546,19 @@ uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, Ph
   const uint64_t CH = 8192;
   unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::vector<PhotonRec>> chunk(CH);
+  std::vector<uint8_t> counted(CH, 1);
+  uint64_t nextIndex = 0;  // index of the next light path (keys its random stream)
   while (out.n < capacity) {
-    const uint64_t base = nbPaths;
+    const uint64_t base = nextIndex;
     auto worker = [&](unsigned tid) {
       std::vector<LVertex> path;
       for (uint64_t k = tid; k < CH; k += nthreads) {
+        counted[k] = 1;
         const uint64_t idx = base + k;
         Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32));
         randomWalk(sc, rng, path);
-        flattenPath(sc, path, chunk[k]);
+        if (beams) counted[k] = flattenBeams(sc, path, chunk[k]) ? 1 : 0;
+        else flattenPath(sc, path, chunk[k]);
       }
     };
     std::vector<std::thread> th;
@@ -495,7 +567,8 @@ uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, Ph
     for (auto &t : th) t.join();
     for (uint64_t k = 0; k < CH && out.n < capacity; ++k) {
       // paths that store nothing still count as shot (pushVolumeLT(nullptr), gvpm_proc.cpp:302-307)
-      nbPaths++;
+      nextIndex++;
+      if (counted[k]) nbPaths++;
       int nbAppend = 0;
       for (const PhotonRec &r : chunk[k]) {
         if (out.n >= capacity) continue;
@@ -509,6 +582,7 @@ uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, Ph
         out.parent_g.push_back(r.parentG);
         out.flags.push_back(r.flags);
         out.path_id.push_back(nbLightPathAdded);
+        if (endN) push3(*endN, r.endN);
         out.n++;
         nbAppend++;
       }

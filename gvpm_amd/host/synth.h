@@ -70,6 +70,12 @@ struct PhotonBuffers {
 // Returns the number of light paths shot (m_numShotVolume).
 uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out);
 
+// Photon beams (G-Beams): one record per medium edge of a light path (LTBeamMap::tryAppendLT,
+// gvpm/gvpm_beams.h:54-84), flattened into the photon SoA re-read as documented for
+// gvpm_upload_beams; end_n = geometric normal of the beam's end vertex (zero in the medium).
+uint64_t shootBeams(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out,
+                    std::vector<float> &endN);
+
 // Camera beam sets (5 rays each) for the pixels [x0,x1) x [y0,y1) of iteration
 // `iteration`; pixels whose camera path has no medium edge produce no set.
 void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,

@@ -260,6 +260,18 @@ int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *tris);
 int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *medium);
 /* per iteration: replaces the proc->getPhotonVolumeMap() of gvpm.cpp:450-454  */
 int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *photons);
+/* G-Beams, per iteration: replaces proc->getBeamMap() (gvpm.cpp:449).  One record per LTPhotonBeam
+ * (gvpm/gvpm_beams.h:18-43), i.e. per medium edge i of a light path, in the photon SoA re-read as:
+ *   pos = vertex(i+1) (beam end), parent_* = vertex(i) (beam origin), wi = -edge(i)->d,
+ *   flux = LTPhotonBeam::flux (without the transmittance of edge i), prefix_w = prod_{k<i},
+ *   parent_pdf = vertex(i)->pdf[EImportance], flags: depth = i, shift type = getTypeShift(path, i+1),
+ *   path_id = LTPhotonBeam::pathID;
+ * end_n: 3 floats per beam, geometric normal of vertex(i+1), all zero when it is a medium interaction.
+ * The beam radius is R*0.01*globalScaleVolume (gvpm.cpp:391,881), kept by the handle.
+ * Per-hit randoms (v and w samples of the 3D kernel) are Philox4x32-10 with
+ * key = {bits(base ray rand), 0x6265616d}, counter = {beam index, 0, 0, 0}.                    */
+int gvpm_upload_beams(gvpm_context *h, const gvpm_photon_soa *beams, const float *end_n);
+int gvpm_upload_beams_dev(gvpm_context *h, const gvpm_photon_soa *beams_dev, const float *end_n_dev);
 /* per iteration: n_sets beam sets (5 rays each). Replaces GatherPoint[] +
  * ShiftGatherPoint[4] for the medium edges of every pixel.  Sets may come in
  * any order; several sets may address the same pixel (several medium edges). */
@@ -285,7 +297,10 @@ int gvpm_upload_vpm_samples_dev(gvpm_context *h, const gvpm_vpm_sample *samples_
  * R*0.01*scaleVol, ADDS the result (x 1/nbCameraSamples) to the accumulators
  * (plain sums; gvpm_download_film divides by the total emitted path count as
  * gvpm.cpp:489-492 does) and applies the per-pixel SPPM update of scaleVol /
- * NVol (:1191-1195).  Asynchronous on the handle's stream.                   */
+ * NVol (:1191-1195).
+ * vol_technique BEAM_BEAM_1D / BEAM_BEAM_3D_OPTIMIZED: computeVolumeGradientBeams
+ * (gvpm.cpp:880-986) over the uploaded photon beams (APA fold as for BRE).
+ * Asynchronous on the handle's stream.                                        */
 int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths);
 
 /* current kernel radius R*0.01*globalScaleVolume (gvpm.cpp:989)              */

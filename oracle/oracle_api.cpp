@@ -9,6 +9,7 @@
 #endif
 
 #include "gvpm_oracle.hpp"
+#include "gvpm_oracle_beams.hpp"
 
 using namespace oracle;
 
@@ -132,9 +133,76 @@ int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
   return GVPM_OK;
 }
 
+// One iteration of computeVolumeGradientBeams, gvpm.cpp:880-986
+template <typename F>
+int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *beams,
+                const float *endN, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
+                uint64_t nbPaths, double subBeamSize, int threads, double *accum, uint64_t *counters,
+                double *seconds) {
+  Gatherer<F> g;
+  g.setup(*p, *m, *t);
+  BeamMapO<F> map;
+  map.load(*beams, endN);
+  auto t0 = std::chrono::steady_clock::now();
+  const size_t P = (size_t)p->width * p->height;
+  std::vector<F> perSet((size_t)nsets * 27, (F)0);
+  Counters total;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+  {
+    Counters local;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t s = 0; s < (int64_t)nsets; ++s)
+      gatherSetBeams<F>(g.ctx, map, (F)radius, rays + 5 * s, (F)subBeamSize, &perSet[(size_t)s * 27], local);
+#pragma omp critical
+    total.add(local);
+  }
+  std::vector<F> iter(P * 27, (F)0);
+  for (uint64_t s = 0; s < nsets; ++s) {
+    const gvpm_camera_ray &b = rays[5 * s];
+    size_t px = b.pixel & 0xFFFFu, py = b.pixel >> 16;
+    if (px >= (size_t)p->width || py >= (size_t)p->height) return GVPM_ERR_INVALID_ARG;
+    F *dst = &iter[(py * p->width + px) * 27];
+    for (int k = 0; k < 27; ++k) dst[k] += perSet[(size_t)s * 27 + k];
+  }
+  // normalisation by nbPathBeams and APA fold, gvpm.cpp:959-975
+  for (size_t i = 0; i < P * 27; ++i) {
+    F v = iter[i];
+    v /= (F)nbPaths;
+    F prev = (F)accum[i];
+    accum[i] = (double)((prev * (F)(it - 1) + v) / (F)it);
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (counters) {
+    counters[0] = total.evaluations; counters[1] = total.candidates; counters[2] = total.nullShifts;
+    counters[3] = total.diffuseShifts; counters[4] = total.failedShifts;
+  }
+  return GVPM_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// One iteration of computeVolumeGradientBeams (gvpm.cpp:880-986) on the CPU with the reference's
+// ENoAccel loop over all beams (pm/beams.h:289-294).  sub_beam_size > 0: every beam is also cut
+// into sub-beams of that length, exercising the ownership rule of SubBeamBVH (pm/beams_accel.h:98-131).
+int oracle_gather_beams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                        const gvpm_photon_soa *beams, const float *end_n, const gvpm_camera_ray *rays,
+                        uint64_t nsets, double radius, int it, uint64_t nb_paths, int precision,
+                        double sub_beam_size, int threads, double *accum, uint64_t *counters, double *seconds) {
+  if (!p || !m || !t || !beams || (beams->n && !end_n) || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_BEAM_BEAM_1D && p->vol_technique != GVPM_BEAM_BEAM_3D_OPTIMIZED)
+    return GVPM_ERR_UNSUPPORTED;  // BeamKernelRecord::eval: SAssert(false) for the other variants
+  if (precision == 32)
+    return gatherBeams<float>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, threads, accum,
+                              counters, seconds);
+  return gatherBeams<double>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, threads, accum,
+                             counters, seconds);
+}
 
 // One iteration of computeVolumeGradientPhoton (gvpm.cpp:1081-1203) on the CPU.  accum: P*27
 // doubles (in/out, plain sums); scale_vol / n_vol: P doubles each (in/out GatherPoint state).

@@ -40,6 +40,10 @@ def lib(fast=False):
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.oracle_assemble_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_gather_beams.argtypes = [
+            C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+            C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -96,6 +100,27 @@ def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_a
         raise RuntimeError(f"oracle_gather_vpm failed: {rc}")
     return (accum.reshape(H, W, 27), scale_vol.reshape(H, W), n_vol.reshape(H, W),
             dict(zip(COUNTER_NAMES, map(int, counters))), secs.value)
+
+
+def gather_beams(params, medium, tris, beams, end_n, rays, radius, it=1, nb_paths=1, precision=64, sub_beam_size=0.0,
+                 threads=0, accum=None, fast=False):
+    """One iteration of computeVolumeGradientBeams on the CPU -> (accum[H,W,27], counters, seconds)."""
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = beams.soa()
+    end_n = np.ascontiguousarray(end_n, np.float32)
+    rays = np.ascontiguousarray(rays)
+    P = params.width * params.height
+    accum = np.zeros(P * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    secs = C.c_double(0)
+    rc = lib(fast).oracle_gather_beams(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
+                                       end_n.ctypes.data, rays.ctypes.data, rays.shape[0], float(radius), it,
+                                       nb_paths, precision, float(sub_beam_size), threads, accum.ctypes.data,
+                                       counters.ctypes.data, C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_beams failed: {rc}")
+    return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
+            secs.value)
 
 
 def scale_volume_apa(scale, it, alpha, technique):

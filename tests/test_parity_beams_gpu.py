@@ -1,0 +1,84 @@
+"""G-Beams parity: HIP path vs the fp64 oracle (computeVolumeGradientBeams)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+from gvpm_amd import abi, hip
+from test_oracle_beams import make_beam_case, TECHS
+from test_parity_gpu import l2, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def device_beams(c, p=None, rays=None, iters=1):
+    p = c.p if p is None else p
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ref = None
+    total = 0
+    for it in range(1, iters + 1):
+        if it == 1:
+            beams, en, nb, r = c.beams, c.end_n, c.nb, (c.rays if rays is None else rays)
+        else:
+            beams, en, nb = c.sc.shoot_beams(it, c.beams.n)
+            r = c.sc.camera_beams(it)
+        rad = ctx.radius()
+        ctx.upload_beams(beams, en)
+        ctx.upload_camera_beams(r)
+        ctx.gather(it, nb)
+        ref, cnt, _ = O.gather_beams(p, c.m, c.tris, beams, en, r, rad, it, nb, 64, accum=ref)
+        total += cnt["evaluations"]
+    acc = ctx.download_accum()
+    st = ctx.stats()
+    film = ctx.download_film(iters, True)
+    ctx.close()
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    # ownership boundaries (measure zero) and the float intermediates of the reference may move a
+    # handful of intersections across a validity test
+    assert abs(st["evaluations"] - total) <= max(2, 2e-4 * total), (st, total)
+    assert l2(acc, ref, lum) < 1e-3
+    rfilm = O.assemble(ref, iters, True)
+    for a, b in zip(film, rfilm):
+        assert l2(a, b, lum) < 1e-3
+    return acc, ref, st
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg"])
+def test_beams_match_fp64_oracle(tech, scene):
+    c = make_beam_case(scene, 32, 28, 12000, 2.5, technique=tech)
+    acc, ref, st = device_beams(c)
+    assert st["evaluations"] > 20000
+
+
+@pytest.mark.parametrize("tech", TECHS)
+def test_beams_two_iterations(tech):
+    c = make_beam_case("cbox", 24, 20, 6000, 3.0, technique=tech)
+    device_beams(c, iters=2)
+
+
+@pytest.mark.parametrize("kw", [dict(use_mis=0), dict(use_shift_null=0), dict(power_heuristic=1), dict(max_depth=3),
+                                dict(path_set=0), dict(debug_shift=abi.GVPM_SHIFT_NULL),
+                                dict(debug_shift=abi.GVPM_SHIFT_MANIFOLD),
+                                dict(lighting_interaction_mode=abi.GVPM_MEDIA2MEDIA)])
+def test_beams_flag_sweep(kw):
+    c = make_beam_case("cbox", 24, 20, 6000, 3.0)
+    p = c.p.copy()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    device_beams(c, p=p)
+
+
+def test_beams_fine_image_null_shifts_and_empty():
+    # pixel spacing below the kernel radius: the null-shift branch (shiftNull3D) is exercised
+    c = make_beam_case("cbox", 96, 96, 4000, 4.0)
+    c.rays = c.rays[(cases.pixels_of(c.rays)[0] < 40) & (cases.pixels_of(c.rays)[1] < 60)]
+    acc, ref, st = device_beams(c)
+    assert st["null_shifts"] > 1000
+    c2 = make_beam_case("cbox", 16, 12, 500, 3.0)
+    c2.beams = c2.beams.subset(np.zeros(0, np.int64))
+    c2.end_n = c2.end_n[:0]
+    acc, ref, st = device_beams(c2)
+    assert st["evaluations"] == 0 and not acc.any()
