@@ -49,6 +49,15 @@ void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *o
                     hipStream_t s);
 void launch_gather_beams(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
                          uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
+struct PlaneArgs {
+  const float4 *test;
+  const float *ori, *end, *flux, *w1, *len1;
+  const uint32_t *flags;
+  uint32_t nplanes, planesPerItem;
+};
+void launch_plane_records(const PlaneArgs &pa, float4 *out, hipStream_t stream);
+void launch_gather_planes(const GatherArgs &a, const PlaneArgs &pa, uint32_t ntiles, uint32_t nchunks,
+                          hipStream_t stream);
 }  // namespace gvpm
 
 using namespace gvpm;
@@ -139,6 +148,12 @@ struct gvpm_context {
   uint32_t nsub = 0;
   float subLen = 0.f, maxSubLen = 0.f;
 
+  // G-Planes: second edge of every plane + the 48-byte test records
+  DevBuf<float> w1Owned, len1Owned;
+  const float *w1Dev = nullptr, *len1Dev = nullptr;
+  DevBuf<float4> planeTest;
+  bool havePlanes = false;
+
   // G-VPM: camera samples + per-pixel SPPM state
   DevBuf<gvpm_vpm_sample> samplesOwned;
   const gvpm_vpm_sample *samplesDev = nullptr;
@@ -203,6 +218,7 @@ static const char *validateParams(const gvpm_params *p) {
   if (p->max_depth <= 1 && p->max_depth != -1 && p->max_depth != 0) return "Maximum depth must be set to \"2\" or higher!";
   if (!(p->bsphere_radius > 0.f)) return "bsphere_radius must be positive";
   if (!(p->epsilon > 0.f) || !(p->shadow_epsilon > 0.f)) return "epsilon / shadow_epsilon must be positive";
+  if (p->vol_technique == GVPM_VOL_PLANE0D && p->min_depth < 2) return "Impossible to use plane with minDepth smaller than 2";
   if (!p->no_medium_shift) return "noMediumShift=false is not supported (shiftPhotonMedium is SAssert(false))";
   return nullptr;
 }
@@ -292,6 +308,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->setPerm.release(); h->tileStart.release(); h->items.release(); h->queueCtl.release();
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release();
+  h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -434,6 +451,38 @@ static int uploadPhotonBeamsCommon(gvpm_context *h, const gvpm_photon_soa *b, co
   return GVPM_OK;
 }
 
+static int uploadPlanesCommon(gvpm_context *h, const gvpm_photon_soa *b, const float *w1, const float *len1,
+                              bool fromDevice) {
+  if (b && b->n && (!w1 || !len1)) return fail(h, GVPM_ERR_INVALID_ARG, "null w1 / len1");
+  int rc = uploadPhotonsCommon(h, b, fromDevice);
+  if (rc != GVPM_OK) return rc;
+  if (fromDevice) {
+    h->w1Dev = w1;
+    h->len1Dev = len1;
+  } else {
+    HIP_TRY(h, h->w1Owned.ensure((size_t)h->nph * 3 + 4));
+    HIP_TRY(h, h->len1Owned.ensure((size_t)h->nph + 4));
+    if (h->nph) {
+      HIP_TRY(h, hipMemcpyAsync(h->w1Owned.p, w1, (size_t)h->nph * 12, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->len1Owned.p, len1, (size_t)h->nph * 4, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->w1Dev = h->w1Owned.p;
+    h->len1Dev = h->len1Owned.p;
+  }
+  h->havePlanes = true;
+  return GVPM_OK;
+}
+
+int gvpm_upload_planes(gvpm_context *h, const gvpm_photon_soa *beams, const float *w1, const float *len1) {
+  CHECK_H(h);
+  return uploadPlanesCommon(h, beams, w1, len1, false);
+}
+int gvpm_upload_planes_dev(gvpm_context *h, const gvpm_photon_soa *beams, const float *w1, const float *len1) {
+  CHECK_H(h);
+  return uploadPlanesCommon(h, beams, w1, len1, true);
+}
+
 int gvpm_upload_beams(gvpm_context *h, const gvpm_photon_soa *beams, const float *end_n) {
   CHECK_H(h);
   return uploadPhotonBeamsCommon(h, beams, end_n, false);
@@ -570,11 +619,12 @@ static int buildGrid(gvpm_context *h, float r) {
   return GVPM_OK;
 }
 
-static int sortBeams(gvpm_context *h) {
+static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
   const uint32_t n = h->nsets;
+  if (!beamsPerWave) beamsPerWave = h->beamsPerWave;
   int tw = 8, th = 4;
-  if (h->beamsPerWave == 64) th = 8;
-  if (h->beamsPerWave == 16) tw = 4;
+  if (beamsPerWave == 64) th = 8;
+  if (beamsPerWave == 16) tw = 4;
   const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
   h->ntiles = tilesX * tilesY;
   HIP_TRY(h, h->tileStart.ensure((size_t)h->ntiles + 2));
@@ -806,6 +856,59 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   return GVPM_OK;
 }
 
+// computeVolumeGradientPlanes, gvpm.cpp:782-878
+static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
+  if (!h->havePlanes) return fail(h, GVPM_ERR_STATE, "G-Planes gather needs gvpm_upload_planes");
+  PlaneArgs pa;
+  pa.ori = h->rawDev.parent_pos;
+  pa.end = h->rawDev.pos;
+  pa.flux = h->rawDev.flux;
+  pa.flags = h->rawDev.flags;
+  pa.w1 = h->w1Dev;
+  pa.len1 = h->len1Dev;
+  pa.nplanes = h->nph;
+  pa.planesPerItem = h->nph;
+  if (h->photonsDirty) {
+    HIP_TRY(h, h->planeTest.ensure((size_t)h->nph * 3 + 1));
+    pa.test = h->planeTest.p;
+    launch_plane_records(pa, h->planeTest.p, h->stream);
+    h->photonsDirty = false;
+    h->builtRadius = -1.f;
+  }
+  pa.test = h->planeTest.p;
+  if (h->beamsDirty) {
+    int rc = sortBeams(h, 64);  // one camera ray per lane: 8x8 pixel tiles
+    if (rc != GVPM_OK) return rc;
+    h->beamsDirty = false;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  GatherArgs a;
+  fillArgs(h, a, 0.f);
+  // enough (tile, plane chunk) items to fill the chip; chunks of at least 256 planes
+  uint32_t nchunks = 1;
+  if (h->ntiles && h->nph) {
+    nchunks = (4u * h->nwaves + h->ntiles - 1) / h->ntiles;
+    nchunks = std::max(1u, std::min(nchunks, (h->nph + 255u) / 256u));
+    nchunks = std::min(nchunks, 65535u);
+    pa.planesPerItem = (h->nph + nchunks - 1) / nchunks;
+    nchunks = (h->nph + pa.planesPerItem - 1) / pa.planesPerItem;
+  }
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+  launch_gather_planes(a, pa, h->ntiles, nchunks, h->stream);
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  {
+    // scaleVolumeAPA(it): the plane estimator takes the linear ratio (gvpm.cpp:195-201)
+    const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
+    h->globalScaleVolume = (float)(h->globalScaleVolume * ratio);
+  }
+  return GVPM_OK;
+}
+
 // computeVolumeGradientPhoton (G-VPM), gvpm.cpp:1081-1203
 static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   (void)it;
@@ -854,6 +957,7 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     case GVPM_DISTANCE: return gatherVPM(h, it, nb_paths);
     case GVPM_BEAM_BEAM_1D:
     case GVPM_BEAM_BEAM_3D_OPTIMIZED: return gatherBeams(h, it, nb_paths);
+    case GVPM_VOL_PLANE0D: return gatherPlanes(h, it, nb_paths);
     default: return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
   }
 }

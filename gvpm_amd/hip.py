@@ -19,7 +19,7 @@ SYMBOLS = [
     "gvpm_create", "gvpm_destroy", "gvpm_last_error", "gvpm_abi_version", "gvpm_reset",
     "gvpm_upload_scene", "gvpm_upload_medium", "gvpm_upload_photons", "gvpm_upload_camera_beams",
     "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_upload_vpm_samples",
-    "gvpm_upload_beams", "gvpm_upload_beams_dev",
+    "gvpm_upload_beams", "gvpm_upload_beams_dev", "gvpm_upload_planes", "gvpm_upload_planes_dev",
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
@@ -56,6 +56,8 @@ def lib():
         L.gvpm_upload_camera_beams_dev.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_beams.argtypes = [vp, C.POINTER(abi.PhotonSoA), vp]
         L.gvpm_upload_beams_dev.argtypes = [vp, C.POINTER(abi.PhotonSoA), vp]
+        L.gvpm_upload_planes.argtypes = [vp, C.POINTER(abi.PhotonSoA), vp, vp]
+        L.gvpm_upload_planes_dev.argtypes = [vp, C.POINTER(abi.PhotonSoA), vp, vp]
         L.gvpm_upload_vpm_samples.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_vpm_samples_dev.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_download_vpm_state.argtypes = [vp, vp, vp]
@@ -134,6 +136,15 @@ class Context:
         soa = beams.soa()
         end_n = np.ascontiguousarray(end_n, np.float32)
         self._check(lib().gvpm_upload_beams(self._h, C.byref(soa), end_n.ctypes.data if beams.n else None))
+
+    def upload_planes(self, beams, w1, len1):
+        """beams: abi.Photons re-read as photon beams; w1: (n,3), len1: (n,) float32 second plane edge"""
+        soa = beams.soa()
+        w1 = np.ascontiguousarray(w1, np.float32)
+        len1 = np.ascontiguousarray(len1, np.float32)
+        assert w1.size == 3 * beams.n and len1.size == beams.n
+        self._check(lib().gvpm_upload_planes(self._h, C.byref(soa), w1.ctypes.data if beams.n else None,
+                                             len1.ctypes.data if beams.n else None))
 
     def upload_vpm_samples(self, samples):
         samples = np.ascontiguousarray(samples)

@@ -36,6 +36,8 @@ def lib():
         L.gvpm_synth_shoot_beams.restype = C.c_uint64
         L.gvpm_synth_shoot_beams.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(abi.PhotonSoA),
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.gvpm_synth_planes.restype = C.c_uint64
+        L.gvpm_synth_planes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
 
@@ -92,6 +94,17 @@ class SynthScene:
         end_n = (np.array((C.c_float * (3 * n)).from_address(ptr.value), np.float32).reshape(n, 3).copy()
                  if n else np.zeros((0, 3), np.float32))
         return beams, end_n, int(nb.value)
+
+    def shoot_planes(self, iteration, capacity):
+        """-> (beams, end_n, w1 (n,3), len1 (n,), nb_paths): photon planes = beams + second edge"""
+        beams, end_n, nb = self.shoot_beams(iteration, capacity)
+        p1, p2 = C.c_void_p(), C.c_void_p()
+        n = lib().gvpm_synth_planes(self._h, iteration, C.byref(p1), C.byref(p2))
+        if n == 0:
+            return beams, end_n, np.zeros((0, 3), np.float32), np.zeros(0, np.float32), nb
+        w1 = np.array((C.c_float * (3 * n)).from_address(p1.value), np.float32).reshape(n, 3).copy()
+        len1 = np.array((C.c_float * n).from_address(p2.value), np.float32).copy()
+        return beams, end_n, w1, len1, nb
 
     def camera_beams(self, iteration, x0=0, y0=0, x1=None, y1=None):
         """-> structured array (n_sets, 5) of gvpm_camera_ray"""

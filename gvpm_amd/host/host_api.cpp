@@ -10,7 +10,7 @@ struct gvpm_synth {
   std::vector<gvpm_camera_ray> rays;
   std::vector<float> v0, e1, e2;
   std::vector<gvpm_vpm_sample> samples;
-  std::vector<float> endN;
+  std::vector<float> endN, w1, len1;
 };
 
 extern "C" {
@@ -71,6 +71,14 @@ uint64_t gvpm_synth_shoot_beams(gvpm_synth *s, int it, uint64_t capacity, gvpm_p
   if (nb_paths) *nb_paths = np;
   s->photons.view(*out);
   *end_n = s->endN.data();
+  return s->photons.n;
+}
+
+uint64_t gvpm_synth_planes(gvpm_synth *s, int it, const float **w1, const float **len1) {
+  if (!s || !w1 || !len1) return 0;
+  gvpm::planesFromBeams(s->scene, it, s->photons, s->w1, s->len1);
+  *w1 = s->w1.data();
+  *len1 = s->len1.data();
   return s->photons.n;
 }
 

@@ -86,6 +86,7 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
   s.bmax = V3(1, 1, 1);
   s.camPos = V3(0, 0, 3.9);
   s.tanHalfFovX = std::tan(0.5 * 39.0 * kPi / 180.0);
+  s.cameraInside = false;
   s.maxDepth = 12;  // scripts/scene/generatorGVPM.py:39-85 paper settings
   s.rrDepth = 1;
   s.minDepth = 0;
@@ -104,6 +105,14 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, 0.7);
+  } else if (name == "cbox_in") {
+    // closed room, sensor inside the fog (what the plane estimator requires, gvpm.cpp:784-788)
+    addBoxRoom(s, 0, 0, 0, 1, 2, 0);
+    setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
+    setMedium(s, 0.5, 0.5, 0.0);
+    s.camPos = V3(0, 0, 0.95);
+    s.tanHalfFovX = std::tan(0.5 * 60.0 * kPi / 180.0);
+    s.cameraInside = true;
   } else if (name == "laser") {
     // S-laser: sigma_t = 0.5, small emitter behind an aperture plate
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
@@ -619,6 +628,16 @@ static void traceCamera(const SynthScene &sc, double sx, double sy, CamPath &cp)
   Hit h;
   if (!closestHit(sc, sc.camPos, d, kEpsilon, h)) return;
   const SynthTri &t2 = sc.tris[h.tri];
+  if (sc.cameraInside) {
+    // sensor inside the medium: edge 1 (sensor sample -> first surface) is the medium edge
+    if (sc.mats[t2.mat].kind == MAT_NULL) return;
+    cp.v2 = sc.camPos;
+    cp.v3 = sc.camPos + d * h.t;
+    cp.n2 = cp.n3 = t2.n;
+    cp.len1 = cp.len2 = h.t;
+    cp.hasBeam = true;
+    return;
+  }
   if (sc.mats[t2.mat].kind != MAT_NULL) return;  // did not enter through the medium boundary
   cp.v2 = sc.camPos + d * h.t;
   cp.n2 = t2.n;
@@ -633,10 +652,10 @@ static void traceCamera(const SynthScene &sc, double sx, double sy, CamPath &cp)
   cp.hasBeam = true;
 }
 
-static void fillRay(gvpm_camera_ray &r, const CamPath &cp, double pdf, double jac, bool valid) {
+static void fillRay(gvpm_camera_ray &r, const CamPath &cp, double pdf, double jac, bool valid, int edge) {
   std::memset(&r, 0, sizeof(r));
   if (!valid) {
-    r.info = GVPM_RAY_INFO(0, 2);
+    r.info = GVPM_RAY_INFO(0, edge);
     return;
   }
   r.o[0] = (float)cp.v2.x; r.o[1] = (float)cp.v2.y; r.o[2] = (float)cp.v2.z;
@@ -647,7 +666,7 @@ static void fillRay(gvpm_camera_ray &r, const CamPath &cp, double pdf, double ja
   r.jacobian = (float)jac;
   // GOp(e) = geometryOpposingTerm(path, 2, 3), gvpm/gvpm_geoOps.h:17-26
   r.gop = (float)(std::fabs(dot(cp.n3, cp.d)) / (cp.len2 * cp.len2));
-  r.info = GVPM_RAY_INFO(1, 2);
+  r.info = GVPM_RAY_INFO(1, edge);
 }
 
 void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,
@@ -666,7 +685,8 @@ void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, in
       // vertex 2 (vertex.cpp:403-408); jacobian = 1
       double gopBase12 = std::fabs(dot(base.n2, base.d)) / (base.len1 * base.len1);
       gvpm_camera_ray r;
-      fillRay(r, base, base.pdfDir * gopBase12, 1.0, true);
+      const int edge = sc.cameraInside ? 1 : 2;
+      fillRay(r, base, base.pdfDir * gopBase12, 1.0, true, edge);
       r.rand = randValue;
       r.pixel = (uint32_t)px | ((uint32_t)py << 16);
       out.push_back(r);
@@ -674,14 +694,14 @@ void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, in
         CamPath sh;
         traceCamera(sc, px + offX[k] + jx, py + offY[k] + jy, sh);
         if (!sh.hasBeam) {
-          fillRay(r, sh, 0, 0, false);
+          fillRay(r, sh, 0, 0, false, edge);
         } else {
           // ShiftGatherPoint::trace/generate, shift_cameraPath.h:76-116,191-242
           double pdf1 = base.pdfDir, pdf2 = sh.pdfDir;
           double gopNew12 = std::fabs(dot(sh.n2, sh.d)) / (sh.len1 * sh.len1);
           double pdf = (pdf2 == 0.0 ? pdf1 : pdf2) * gopNew12;
           double jac = (pdf2 == 0.0 ? 1.0 : pdf1 / pdf2) * (gopBase12 / gopNew12);
-          fillRay(r, sh, pdf, jac, true);
+          fillRay(r, sh, pdf, jac, true, edge);
         }
         r.pixel = 0;  // base ray only
         out.push_back(r);
@@ -706,6 +726,36 @@ void cameraSamplesVPM(const SynthScene &sc, int iteration, const std::vector<gvp
       sm.reserved = 0;
       out.push_back(sm);
     }
+  }
+}
+
+// LTPhotonPlane::transformBeam, gvpm/gvpm_plane.h:53-73: a second distance along the beam's medium and a
+// phase-sampled direction turn every photon beam into a photon plane (host side, gvpm.cpp:793-797).
+void planesFromBeams(const SynthScene &sc, int iteration, const PhotonBuffers &beams, std::vector<float> &w1,
+                     std::vector<float> &len1) {
+  w1.clear();
+  len1.clear();
+  const double sigT = sc.medium.sigma_t[1], g = sc.medium.g;
+  for (uint64_t i = 0; i < beams.n; ++i) {
+    Philox rng(sc.seed, 0x91a7eu, (uint32_t)iteration, (uint32_t)i);
+    // sampleDistance(Ray(o, d, 0.f) -> mint = Epsilon, maxt = inf), homogeneous.cpp:293-360
+    const double t = -std::log(1.0 - rng.next1D()) / sigT + kEpsilon;
+    V3 d = normalize(V3(beams.pos[3 * i] - beams.parent_pos[3 * i], beams.pos[3 * i + 1] - beams.parent_pos[3 * i + 1],
+                        beams.pos[3 * i + 2] - beams.parent_pos[3 * i + 2]));
+    V3 wo;
+    do {
+      const double a = rng.next1D(), b = rng.next1D();
+      if (std::fabs(g) < kEpsilon) {
+        wo = uniformSphere(a, b);
+      } else {
+        double sqrTerm = (1 - g * g) / (1 - g + 2 * g * a);
+        double cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+        double sinTheta = std::sqrt(std::fmax(0.0, 1.0 - cosTheta * cosTheta));
+        wo = toWorld(d, V3(sinTheta * std::cos(2 * kPi * b), sinTheta * std::sin(2 * kPi * b), cosTheta));
+      }
+    } while (std::fabs(dot(d, wo)) == 1.0);
+    push3(w1, wo);
+    len1.push_back((float)t);
   }
 }
 

@@ -47,6 +47,7 @@ struct SynthScene {
   double tanHalfFovX;
   int width, height;
   uint32_t seed;
+  bool cameraInside;  // sensor inside the medium: the medium edge of the camera path is edge 1
   // light-path walk parameters (GPMConfig maxDepth, rrDepth, minDepth)
   int maxDepth, rrDepth, minDepth;
   double cameraSphere;  // world units, already scaled as in gvpm.cpp:162
@@ -75,6 +76,10 @@ uint64_t shootPhotons(const SynthScene &sc, int iteration, uint64_t capacity, Ph
 // gvpm_upload_beams; end_n = geometric normal of the beam's end vertex (zero in the medium).
 uint64_t shootBeams(const SynthScene &sc, int iteration, uint64_t capacity, PhotonBuffers &out,
                     std::vector<float> &endN);
+
+// Photon planes from photon beams (LTPhotonPlane::transformBeam): w1 (3 floats) and length1 per beam.
+void planesFromBeams(const SynthScene &sc, int iteration, const PhotonBuffers &beams, std::vector<float> &w1,
+                     std::vector<float> &len1);
 
 // Camera beam sets (5 rays each) for the pixels [x0,x1) x [y0,y1) of iteration
 // `iteration`; pixels whose camera path has no medium edge produce no set.

@@ -272,6 +272,15 @@ int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *photons);
  * key = {bits(base ray rand), 0x6265616d}, counter = {beam index, 0, 0, 0}.                    */
 int gvpm_upload_beams(gvpm_context *h, const gvpm_photon_soa *beams, const float *end_n);
 int gvpm_upload_beams_dev(gvpm_context *h, const gvpm_photon_soa *beams_dev, const float *end_n_dev);
+/* G-Planes (0D kernel), per iteration: replaces the LTPhotonPlane list of gvpm.cpp:790-800.  One
+ * plane per photon beam (same SoA reading as gvpm_upload_beams: ori = parent_pos, w0 length0 =
+ * pos - parent_pos, flux, flags depth = edgeID) plus the second edge drawn by
+ * LTPhotonPlane::transformBeam (gvpm/gvpm_plane.h:53-73): w1 (3 floats, unit) and len1 (1 float)
+ * per plane.  Preconditions of the reference hold: sensor inside the medium (gvpm.cpp:784-788,
+ * i.e. camera rays with medium edge 1), min_depth >= 2 (gvpm.cpp:163-166), no null shift.       */
+int gvpm_upload_planes(gvpm_context *h, const gvpm_photon_soa *beams, const float *w1, const float *len1);
+int gvpm_upload_planes_dev(gvpm_context *h, const gvpm_photon_soa *beams_dev, const float *w1_dev,
+                           const float *len1_dev);
 /* per iteration: n_sets beam sets (5 rays each). Replaces GatherPoint[] +
  * ShiftGatherPoint[4] for the medium edges of every pixel.  Sets may come in
  * any order; several sets may address the same pixel (several medium edges). */

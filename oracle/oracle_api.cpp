@@ -10,6 +10,7 @@
 
 #include "gvpm_oracle.hpp"
 #include "gvpm_oracle_beams.hpp"
+#include "gvpm_oracle_planes.hpp"
 
 using namespace oracle;
 
@@ -183,9 +184,69 @@ int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles
   return GVPM_OK;
 }
 
+// One iteration of computeVolumeGradientPlanes, gvpm.cpp:782-878
+template <typename F>
+int gatherPlanes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *beams,
+                 const float *w1, const float *len1, const gvpm_camera_ray *rays, uint64_t nsets, int it,
+                 uint64_t nbPaths, int threads, double *accum, uint64_t *counters, double *seconds) {
+  Gatherer<F> g;
+  g.setup(*p, *m, *t);
+  PlaneMapO<F> map;
+  map.load(*beams, w1, len1);
+  auto t0 = std::chrono::steady_clock::now();
+  const size_t P = (size_t)p->width * p->height;
+  std::vector<F> perSet((size_t)nsets * 27, (F)0);
+  Counters total;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+  {
+    Counters local;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t s = 0; s < (int64_t)nsets; ++s)
+      gatherSetPlanes<F>(g.ctx, map, rays + 5 * s, &perSet[(size_t)s * 27], local);
+#pragma omp critical
+    total.add(local);
+  }
+  std::vector<F> iter(P * 27, (F)0);
+  for (uint64_t s = 0; s < nsets; ++s) {
+    const gvpm_camera_ray &b = rays[5 * s];
+    size_t px = b.pixel & 0xFFFFu, py = b.pixel >> 16;
+    if (px >= (size_t)p->width || py >= (size_t)p->height) return GVPM_ERR_INVALID_ARG;
+    F *dst = &iter[(py * p->width + px) * 27];
+    for (int k = 0; k < 27; ++k) dst[k] += perSet[(size_t)s * 27 + k];
+  }
+  for (size_t i = 0; i < P * 27; ++i) {  // gvpm.cpp:850-866
+    F v = iter[i];
+    v /= (F)nbPaths;
+    F prev = (F)accum[i];
+    accum[i] = (double)((prev * (F)(it - 1) + v) / (F)it);
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (counters) {
+    counters[0] = total.evaluations; counters[1] = total.candidates; counters[2] = total.nullShifts;
+    counters[3] = total.diffuseShifts; counters[4] = total.failedShifts;
+  }
+  return GVPM_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// One iteration of computeVolumeGradientPlanes (gvpm.cpp:782-878) on the CPU (loop over all planes).
+int oracle_gather_planes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                         const gvpm_photon_soa *beams, const float *w1, const float *len1,
+                         const gvpm_camera_ray *rays, uint64_t nsets, int it, uint64_t nb_paths, int precision,
+                         int threads, double *accum, uint64_t *counters, double *seconds) {
+  if (!p || !m || !t || !beams || (beams->n && (!w1 || !len1)) || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_VOL_PLANE0D) return GVPM_ERR_INVALID_ARG;
+  if (precision == 32)
+    return gatherPlanes<float>(p, m, t, beams, w1, len1, rays, nsets, it, nb_paths, threads, accum, counters, seconds);
+  return gatherPlanes<double>(p, m, t, beams, w1, len1, rays, nsets, it, nb_paths, threads, accum, counters, seconds);
+}
 
 // One iteration of computeVolumeGradientBeams (gvpm.cpp:880-986) on the CPU with the reference's
 // ENoAccel loop over all beams (pm/beams.h:289-294).  sub_beam_size > 0: every beam is also cut

@@ -44,6 +44,10 @@ def lib(fast=False):
             C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
             C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_gather_planes.argtypes = [
+            C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -119,6 +123,28 @@ def gather_beams(params, medium, tris, beams, end_n, rays, radius, it=1, nb_path
                                        counters.ctypes.data, C.byref(secs))
     if rc != 0:
         raise RuntimeError(f"oracle_gather_beams failed: {rc}")
+    return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
+            secs.value)
+
+
+def gather_planes(params, medium, tris, beams, w1, len1, rays, it=1, nb_paths=1, precision=64, threads=0, accum=None,
+                  fast=False):
+    """One iteration of computeVolumeGradientPlanes on the CPU -> (accum[H,W,27], counters, seconds)."""
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = beams.soa()
+    w1 = np.ascontiguousarray(w1, np.float32)
+    len1 = np.ascontiguousarray(len1, np.float32)
+    rays = np.ascontiguousarray(rays)
+    P = params.width * params.height
+    accum = np.zeros(P * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    secs = C.c_double(0)
+    rc = lib(fast).oracle_gather_planes(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
+                                        w1.ctypes.data, len1.ctypes.data, rays.ctypes.data, rays.shape[0], it,
+                                        nb_paths, precision, threads, accum.ctypes.data, counters.ctypes.data,
+                                        C.byref(secs))
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_planes failed: {rc}")
     return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
             secs.value)
 
