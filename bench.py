@@ -169,13 +169,16 @@ def main():
                 "technique": "bre3d", "frame": [W, H], "tile_per_gpu": [args.tile, args.tile],
                 "photons_per_iter": args.photons, "iterations": K, "sharding": f"image tiles x{world}",
                 "evaluations": evals_total, "evals_per_iter_per_gpu": evals / K,
+                "tests_per_iter_per_gpu": st["candidates"] / K,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": None,
-                "kernel": "gather_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
+                "kernel": "evaluate_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
+                "traverse_avg_ms": ctx.phase_time(1)[0], "build_avg_ms": ctx.phase_time(2)[0],
                 "bytes_alg_per_launch": bytes_alg,
             },
+            "stats": st,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, p, m, tris, host0, args)

@@ -9,12 +9,13 @@ namespace gvpm {
 
 // Photon records after the grid build, sorted by cell (x fastest):
 //   hot[i]      = {pos.xyz, bits}         16 B  -- streamed by the hit test
-//   cold[k][i], k = 0..6                  7 x 16 B planes -- gathered per evaluation
-//     0 {wi, parentPdf} 1 {flux, edgePdf} 2 {parentPos, parentRR} 3 {parentN, parentG}
-//     4 {prefixW, -}    5 {parentScat, -} 6 {parentWi, -}
+//   cold[i][k], k = 0..7                  one 128 B record -- read once per evaluation
+//     0 {pos, bits} 1 {wi, parentPdf} 2 {flux, edgePdf} 3 {parentPos, parentRR} 4 {parentN, parentG}
+//     5 {prefixW, nearOccluders} 6 {parentScat, -} 7 {parentWi, -}
 // bits = GVPM_PF_* flags of the ABI with bit 7 = pathID & 1.
+// (G-Beams keeps 9 planes of nbeams float4 in the same buffer, see gather_beams.hip.)
 #define GVPM_HOT_PARITY_BIT 7
-#define GVPM_COLD_PLANES 7
+#define GVPM_REC_QUADS 8
 
 struct Grid {
   float org[3];    // world position of cell (0,0,0)'s lower corner
@@ -37,7 +38,7 @@ struct MediumDev {
 struct GatherArgs {
   // photons
   const float4 *hot;
-  const float4 *cold;        // GVPM_COLD_PLANES planes of `nph` float4
+  const float4 *cold;        // nph records of GVPM_REC_QUADS float4
   const uint32_t *cellStart; // ncells + 1
   uint32_t nph;
   Grid grid;
@@ -47,7 +48,8 @@ struct GatherArgs {
   const uint32_t *tileStart; // ntiles + 1 offsets into setPerm
   uint32_t nsets;
   // scene
-  const float *triV0, *triE1, *triE2;  // 3 * ntri each
+  const float4 *tri4;        // 3 float4 per triangle {v0,n.x} {e1,n.y} {e2,n.z}, BVH leaf order
+  const float4 *bvh;         // 2 float4 per node (scene_bvh.h)
   uint32_t ntri;
   MediumDev med;
   // config

@@ -315,7 +315,7 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
   const double newPBDist = sqrt(len2(newPBDir));
   newPBDir = newPBDir / newPBDist;
   // visibility over the whole new beam [Epsilon, newPBDist], shift_volume_beams.cpp:420-426
-  if (anyHit(a, s.tri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist)) return 1.0;
+  if (anyHitScene(a.bvh, a.tri4, a.ntri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist)) return 1.0;
   const d3 basePos = b.p1 + b.dir * kRec.v;
   const double pdfKernelAndDist = kpdf(kRec);
   // diffuseReconnectionPhotonBeam, shift_diffuse.cpp:136-268
@@ -544,17 +544,6 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
   const float rT = a.radius;  // test radius = kernel radius + half a sub-beam
   const float eps = a.cfg.epsilon;
 
-  for (uint32_t i = lane; i < min(a.ntri, (uint32_t)MAXTRI_LDS); i += 64) {
-    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
-    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
-    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
-    f3 n = cross(e1, e2);
-    const float l = sqrtf(dot(n, n));
-    n = l > 0.f ? n * (1.f / l) : mk3(0.f);
-    s.tri[i][0] = make_float4(v0.x, v0.y, v0.z, n.x);
-    s.tri[i][1] = make_float4(e1.x, e1.y, e1.z, n.y);
-    s.tri[i][2] = make_float4(e2.x, e2.y, e2.z, n.z);
-  }
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   unsigned long long nCand = 0;
 

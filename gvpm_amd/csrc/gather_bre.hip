@@ -20,15 +20,20 @@
 //   * plan_kernel walks every tile once WITHOUT touching photons (cellStart differences only) and
 //     cuts it into work items of roughly equal candidate count -- the load balancer that replaces
 //     BlockScheduler's dynamic image blocks (photonmapper/utilities/block_sched.h:87-113);
-//   * gather_bre_kernel is persistent: waves pull items from an atomic queue; for each slab
-//     step the 16-byte hot photon records of the ranges are copied coalesced into an LDS stage
-//     (photons staged into LDS tiles) and every lane tests them against its own beam (LDS
-//     broadcast reads): fp32 conservative pre-test, then the reference predicate in fp64
-//     without contraction, so the hit set equals the fp64 oracle's bit for bit;
-//   * hits are compacted with __ballot / popcount prefix sums into an LDS ring of
-//     (photon, beam) pairs; whenever 64 are pending every lane evaluates one of them: base
-//     contribution + 4 shifts (null shift, or offset-path reconnection with shadow ray,
-//     Jacobian and MIS weight) and adds 27 partial sums to the beam's LDS accumulators.
+//   * traverse_bre_kernel is persistent (waves pull items from an atomic queue) and holds no
+//     evaluation state, so it runs at high occupancy: for each slab step the 16-byte hot photon
+//     records of the ranges are copied coalesced into an LDS stage and every lane tests them
+//     against its own beam (LDS broadcast reads): fp32 test with a rigorous error band, the
+//     reference predicate in uncontracted fp64 only when the band could change the decision, so
+//     the hit set equals the fp64 oracle's bit for bit.  Hits are compacted with __ballot /
+//     popcount and appended as (photon, beam) pairs to the item's region of the pair buffer
+//     (the region is sized by the planner's upper bound; ~8 bytes written per hit);
+//   * evaluate_bre_kernel, also persistent, takes an item's pairs 64 at a time: every lane
+//     evaluates one (photon record = one 128-byte line): base contribution + 4 shifts (null
+//     shift, or offset-path reconnection with shadow ray, Jacobian and MIS weight), adds 27
+//     partial sums to the beam's LDS accumulators and flushes them with global atomics at the
+//     end of the item.  Splitting the two phases gives each its own register budget (the fused
+//     kernel sat at 256 VGPRs with spills and 2 waves/SIMD).
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -106,13 +111,12 @@ __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
 // O(radius) vector (photon - ray point, shifted ray point - base ray point) is formed in fp64 and
 // then carried as a small fp32 vector; everything downstream of those differences (kernel chord
 // lengths sqrt(r^2 - d^2), pdfs, BSDF / phase / transmittance products, MIS weights) is fp32.
-template <int B>
+template <int B, bool FULLVIS>
 __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uint32_t pidx, uint32_t b,
                                          uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
-  const float4 hot = a.hot[pidx];
-  const uint32_t bits = __float_as_uint(hot.w);
-  const f3 pos = mk3(hot.x, hot.y, hot.z);
   const PhotonCold ph = loadCold(a, pidx);
+  const uint32_t bits = ph.bits;
+  const f3 pos = ph.pos;
   const RayReg base = loadRay(s, 0, b);
   const uint32_t edge = s.edge[b];
   const uint32_t pix = s.pix[b];
@@ -209,7 +213,7 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
           bool ok = false;
           if (st == 1u || st == 2u) {
             const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
-            w = shiftDiffuse(a, s.tri, ph, bits, dProjU, sh, base, edge, trT, pdfCam, pdfShiftPos, sflux, ok);
+            w = shiftDiffuse<FULLVIS>(a, ph, bits, dProjU, sh, base, edge, trT, pdfCam, pdfShiftPos, sflux, ok);
           }
           if (ok) nDiff++; else nFail++;
         }
@@ -230,14 +234,20 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
 }
 
 // ------------------------------------------------------------------------------------------
-// gather: persistent waves pulling work items
+// traversal: persistent waves pulling work items, (photon, beam) pairs out
 // ------------------------------------------------------------------------------------------
+struct TravLds {
+  float4 stage[STAGE];
+  uint32_t stageIdx[STAGE];
+};
+
 template <int B>
-__global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
-                                                           const uint32_t *__restrict__ itemCount,
-                                                           uint32_t *queueHead) {
+__global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
+                                                          const uint2 *__restrict__ itemOff,
+                                                          const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
+                                                          uint2 *__restrict__ pairs, uint32_t *__restrict__ pairCnt) {
   constexpr int LPB = 64 / B;
-  __shared__ TileLds<B> s;
+  __shared__ TravLds s;
   const int lane = threadIdx.x;
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
@@ -245,22 +255,7 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
   const float r2f = r * r;
   const float eps = a.cfg.epsilon;
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
-
-  // occluders -> LDS, with the unit normal for the plane early-out
-  for (uint32_t i = lane; i < min(a.ntri, (uint32_t)MAXTRI_LDS); i += 64) {
-    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
-    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
-    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
-    f3 n = cross(e1, e2);
-    const float l = sqrtf(dot(n, n));
-    n = l > 0.f ? n * (1.f / l) : mk3(0.f);
-    s.tri[i][0] = make_float4(v0.x, v0.y, v0.z, n.x);
-    s.tri[i][1] = make_float4(e1.x, e1.y, e1.z, n.y);
-    s.tri[i][2] = make_float4(e2.x, e2.y, e2.z, n.z);
-  }
-
-  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
-  unsigned long long nCand = 0;
+  unsigned long long nCand = 0, nOver = 0;
 
   for (;;) {
     uint32_t it = 0;
@@ -269,24 +264,22 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
     if (it >= nItems) break;
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y;
-    if (nb == 0) continue;
-    __syncthreads();
-    loadTileRays<B>(a, s, setBase, nb, lane);
-    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
-    __syncthreads();
+    if (nb == 0) {
+      if (lane == 0) pairCnt[it] = 0u;
+      continue;
+    }
+    const uint2 reg = itemOff[it];
+    uint2 *out = pairs + (size_t)reg.x * 64u;
+    const uint32_t cap = reg.y * 64u;
+    BaseInfo bi;
+    const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
     TileWalk w;
-    tileSetup<B>(a, s, nb, lane, w);
-    const RayReg base = w.base;
+    tileSetupFrom(a, base, base.valid, w);
     const bool beamValid = w.beamValid;
     const float mint = eps, maxt = base.len - eps;
-    const double mintD = (double)eps, maxtD = (double)base.len - (double)eps;
-    const d3 rcpD = mkd(1.0 / (double)base.d.x, 1.0 / (double)base.d.y, 1.0 / (double)base.d.z);
-    const float rnd = s.rnd[b];
-    const uint32_t edge = s.edge[b];
-    const uint32_t pixv = s.pix[b];
-    const uint32_t pixParity = ((pixv & 0xFFFFu) + (pixv >> 16)) & 1u;
-    uint32_t qHead = 0, qCount = 0;  // wave-uniform ring state
-    uint32_t staged = 0;
+    const uint32_t edge = bi.edge;
+    const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
+    uint32_t written = 0, staged = 0;  // wave-uniform
 
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
@@ -302,6 +295,7 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
         const uint32_t total = __shfl(incl, 63, 64);
         for (uint32_t win = 0; win < total; win += STAGE) {
           // stage [win, win + STAGE) of the concatenated ranges
+          __syncthreads();
           {
             const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
             uint32_t i = lo_i;
@@ -326,7 +320,6 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
           for (uint32_t jj = 0; jj < iters; ++jj) {
             const uint32_t j = jj * LPB + sub;
             bool hit = false;
-            uint32_t gi = 0;
             if (beamValid && j < nst) {
               const float4 hp = s.stage[j];
               const f3 p = mk3(hp.x, hp.y, hp.z);
@@ -357,48 +350,83 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
                     hit = true;
                   } else {
                     // ... otherwise the reference predicate itself, fp64, uncontracted
+                    const double mintD = (double)eps, maxtD = (double)base.len - (double)eps;
+                    const d3 rcpD = mkd(1.0 / (double)base.d.x, 1.0 / (double)base.d.y, 1.0 / (double)base.d.z);
                     const HitGeom g = hitGeom(p, base.o, base.d);
                     if (g.disk > mintD && g.distSqr < (double)r * (double)r &&
                         ownBoxHit(p, base.o, base.d, rcpD, mintD, maxtD, (double)r)) {
                       hit = true;
                       if (use3D) {
                         double tp, dt;
-                        hit = resample3D(g, (double)r, (double)rnd, mintD, (double)base.len, tp, dt);
+                        hit = resample3D(g, (double)r, (double)bi.rnd, mintD, (double)base.len, tp, dt);
                       }
                     }
                   }
-                  gi = s.stageIdx[j];
                 }
               }
             }
             const unsigned long long m = __ballot(hit);
             if (m) {
               if (hit) {
-                const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-                s.queue[(qHead + qCount + off) % QCAP] = make_uint2(gi, (uint32_t)b);
+                const uint32_t off = written + __popcll(m & ((1ull << lane) - 1ull));
+                if (off < cap) out[off] = make_uint2(s.stageIdx[j], (uint32_t)b);
+                else nOver++;
               }
-              qCount += __popcll(m);
-              if (qCount >= 64u) {
-                __syncthreads();
-                const uint2 e = s.queue[(qHead + lane) % QCAP];
-                if (!(a.cfg.reserved[0] & 1)) evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
-                nEval++;
-                qHead = (qHead + 64u) % QCAP;
-                qCount -= 64u;
-                __syncthreads();
-              }
+              written += __popcll(m);
             }
           }
-          __syncthreads();
         }
       }
     }
-    // ---- flush the partial batch ----
+    if (lane == 0) pairCnt[it] = min(written, cap);
+    nCand += (unsigned long long)staged * nb;
+  }
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nOver += __shfl_xor(nOver, o, 64);
+    if (lane == 0 && (nCand | nOver)) {
+      atomicAdd(&a.stats[1], nCand);
+      if (nOver) atomicAdd(&a.stats[7], nOver);  // must stay 0: the planner's bound is exact
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// evaluation: persistent waves, one item's pairs at a time, 64 evaluations per step
+// ------------------------------------------------------------------------------------------
+template <int B, bool FULLVIS>
+__global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
+                                                          const uint2 *__restrict__ itemOff,
+                                                          const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
+                                                          const uint2 *__restrict__ pairs,
+                                                          const uint32_t *__restrict__ pairCnt) {
+  __shared__ TileLds<B> s;
+  const int lane = threadIdx.x;
+  const uint32_t nItems = *itemCount;
+
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+
+  for (;;) {
+    uint32_t it = 0;
+    if (lane == 0) it = atomicAdd(queueHead, 1u);
+    it = __shfl(it, 0, 64);
+    if (it >= nItems) break;
+    const uint4 item = items[it];
+    const uint32_t setBase = item.x, nb = item.y;
+    if (nb == 0) continue;
+    const uint32_t cnt = pairCnt[it];
+    if (cnt == 0) continue;
+    const uint2 *in = pairs + (size_t)itemOff[it].x * 64u;
     __syncthreads();
-    if ((uint32_t)lane < qCount) {
-      const uint2 e = s.queue[(qHead + lane) % QCAP];
-      if (!(a.cfg.reserved[0] & 1)) evaluate<B>(a, s, e.x, e.y, nNull, nDiff, nFail);
-      nEval++;
+    loadTileRays<B>(a, s, setBase, nb, lane);
+    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+    __syncthreads();
+    for (uint32_t i = 0; i < cnt; i += 64) {
+      if (i + lane < cnt) {
+        const uint2 e = in[i + lane];
+        if (!(a.cfg.reserved[0] & 1)) evaluate<B, FULLVIS>(a, s, e.x, e.y, nNull, nDiff, nFail);
+        nEval++;
+      }
     }
     __syncthreads();
     // ---- write out: 27 partial sums per beam set into the iteration buffer ----
@@ -413,7 +441,6 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
         }
       }
     }
-    nCand += (unsigned long long)staged * nb;
   }
   // ---- statistics ----
   {
@@ -425,9 +452,8 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
       di += __shfl_xor(di, o, 64);
       fa += __shfl_xor(fa, o, 64);
     }
-    if (lane == 0 && (ev | nCand)) {
+    if (lane == 0 && ev) {
       atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[1], nCand);
       atomicAdd(&a.stats[2], nu);
       atomicAdd(&a.stats[3], di);
       atomicAdd(&a.stats[4], fa);
@@ -435,25 +461,47 @@ __global__ __launch_bounds__(64, 2) void gather_bre_kernel(GatherArgs a, const u
   }
 }
 
-// itemCount / queueHead must be zero on entry (memset on the same stream)
+// itemCount / blockTotal must be zero on entry (memset on the same stream)
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
-                     uint32_t *itemCount, hipStream_t stream) {
+                     uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream) {
   if (a.nsets == 0 || ntiles == 0) return;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
-    case 32: hipLaunchKernelGGL(plan_kernel<32>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
-    default: hipLaunchKernelGGL(plan_kernel<16>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount); break;
+    case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
+    case 32: hipLaunchKernelGGL(plan_kernel<32>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
+    default: hipLaunchKernelGGL(plan_kernel<16>, dim3(ntiles), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
   }
 }
 
-void launch_gather_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
-                       uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
+// queueHead must be zero on entry
+void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
+                         const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCnt,
+                         uint32_t nwaves, hipStream_t stream) {
   if (a.nsets == 0) return;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(gather_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
-    case 32: hipLaunchKernelGGL(gather_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
-    default: hipLaunchKernelGGL(gather_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
   }
+}
+
+template <bool FULLVIS>
+static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
+                           const uint32_t *itemCount, uint32_t *queueHead, const uint2 *pairs, const uint32_t *pairCnt,
+                           uint32_t nwaves, hipStream_t stream) {
+  switch (beamsPerWave) {
+    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+  }
+}
+
+// fullVis: shadow rays walk the occluder BVH (intended visibility, > 254 occluders, near-list overflow)
+void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
+                         const uint32_t *itemCount, uint32_t *queueHead, const uint2 *pairs, const uint32_t *pairCnt,
+                         uint32_t nwaves, hipStream_t stream) {
+  if (a.nsets == 0) return;
+  if (fullVis) launchEvaluate<true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, stream);
+  else launchEvaluate<false>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, stream);
 }
 
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave) {

@@ -30,7 +30,6 @@ struct VpmLds {
   float4 ray4[5][3][64];
   float gop[5][64];
   float acc[27][64];
-  float4 tri[MAXTRI_LDS][3];
   uint2 queue[VQ];
   double t[64];        // sampled camera distance (mRec.t)
   float pdfBase[64];   // pdfBaseRay() = mRec.pdfSuccess * pdfSel
@@ -56,12 +55,12 @@ __device__ __forceinline__ RayReg loadRayV(const VpmLds &s, int k, int b) {
 }
 
 // One evaluation: VolumeGradientPositionQuery::operator() after the filters.
+template <bool FULLVIS>
 __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
                                             uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
-  const float4 hot = a.hot[pidx];
-  const uint32_t bits = __float_as_uint(hot.w);
-  const f3 pos = mk3(hot.x, hot.y, hot.z);
   const PhotonCold ph = loadCold(a, pidx);
+  const uint32_t bits = ph.bits;
+  const f3 pos = ph.pos;
   const RayReg base = loadRayV(s, 0, b);
   const uint32_t edge = s.edge[b];
   const uint32_t pix = s.pix[b];
@@ -125,7 +124,7 @@ __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint
           bool ok = false;
           if (st == 1u || st == 2u) {
             const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;
-            w = shiftDiffuse(a, s.tri, ph, bits, dProjU, sh, base, edge, trShift, pdfBase, pdfShift, sflux, ok);
+            w = shiftDiffuse<FULLVIS>(a, ph, bits, dProjU, sh, base, edge, trShift, pdfBase, pdfShift, sflux, ok);
           }
           if (ok) nDiff++; else nFail++;
         }
@@ -144,6 +143,7 @@ __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint
   }
 }
 
+template <bool FULLVIS>
 __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   __shared__ VpmLds s;
   const int lane = threadIdx.x;
@@ -152,17 +152,6 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   const float norm = 1.f / (float)a.cfg.nb_camera_samples;
   const float eps = a.cfg.epsilon;
 
-  for (uint32_t i = lane; i < min(a.ntri, (uint32_t)MAXTRI_LDS); i += 64) {
-    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
-    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
-    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
-    f3 n = cross(e1, e2);
-    const float l = sqrtf(dot(n, n));
-    n = l > 0.f ? n * (1.f / l) : mk3(0.f);
-    s.tri[i][0] = make_float4(v0.x, v0.y, v0.z, n.x);
-    s.tri[i][1] = make_float4(e1.x, e1.y, e1.z, n.y);
-    s.tri[i][2] = make_float4(e2.x, e2.y, e2.z, n.z);
-  }
   for (int idx = lane; idx < 27 * 64; idx += 64) (&s.acc[0][0])[idx] = 0.f;
 
   // ---- this lane's sample: rays -> LDS, distance sampling ----
@@ -308,7 +297,7 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
       if (qCount >= 64u) {
         __syncthreads();
         const uint2 e = s.queue[(qHead + lane) % VQ];
-        evaluateVpm(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
+        evaluateVpm<FULLVIS>(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
         nEval++;
         qHead = (qHead + 64u) % VQ;
         qCount -= 64u;
@@ -319,7 +308,7 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   __syncthreads();
   if ((uint32_t)lane < qCount) {
     const uint2 e = s.queue[(qHead + lane) % VQ];
-    evaluateVpm(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
+    evaluateVpm<FULLVIS>(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
     nEval++;
   }
   __syncthreads();
@@ -381,9 +370,10 @@ __global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ acc
   if (i < n) accum[i] += iter[i];
 }
 
-void launch_gather_vpm(const GatherArgs &a, hipStream_t stream) {
+void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream) {
   if (a.nsamples == 0) return;
-  hipLaunchKernelGGL(gather_vpm_kernel, dim3((a.nsamples + 63u) / 64u), dim3(64), 0, stream, a);
+  if (fullVis) hipLaunchKernelGGL(gather_vpm_kernel<true>, dim3((a.nsamples + 63u) / 64u), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(gather_vpm_kernel<false>, dim3((a.nsamples + 63u) / 64u), dim3(64), 0, stream, a);
 }
 
 void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,

@@ -87,21 +87,21 @@ __device__ __forceinline__ float4 ld3(const float *p, uint32_t i, float w) {
 
 // Occluders a shadow segment of length <= dmax starting at the photon's parent can reach:
 // parent within dmax of the triangle's plane and of its (dmax-inflated) bounding box.
-// Packs up to four 8-bit indices (0xFF = empty slot); 0xFE in the top byte = overflow / too many
-// occluders for 8-bit indices: the kernel then falls back to the full any-hit loop.
-__device__ __forceinline__ uint32_t nearOccluders(f3 P, const float *v0, const float *e1, const float *e2,
-                                                  uint32_t ntri, float dmax) {
-  if (ntri > 254u) return 0xFEFFFFFFu;
-  uint32_t list = 0xFFFFFFFFu, cnt = 0;
+// Packs up to twelve 8-bit indices into three words (0xFF = empty slot); 0xFE in the top byte of the
+// first word = overflow / too many occluders for 8-bit indices: such photons need the BVH kernels.
+__device__ __forceinline__ void nearOccluders(f3 P, const float4 *tri4, uint32_t ntri, float dmax, uint32_t &w0,
+                                              uint32_t &w1, uint32_t &w2) {
+  w0 = w1 = w2 = 0xFFFFFFFFu;
+  if (ntri > 254u) {
+    w0 = 0xFEFFFFFFu;
+    return;
+  }
+  uint32_t cnt = 0;
   for (uint32_t i = 0; i < ntri; ++i) {
-    const f3 a = mk3(v0[3 * i], v0[3 * i + 1], v0[3 * i + 2]);
-    const f3 b = mk3(e1[3 * i], e1[3 * i + 1], e1[3 * i + 2]);
-    const f3 c = mk3(e2[3 * i], e2[3 * i + 1], e2[3 * i + 2]);
-    f3 n = cross(b, c);
-    const float l = sqrtf(dot(n, n));
-    if (l > 0.f) {
-      if (fabsf(dot(n, P - a)) > dmax * l) continue;
-    }
+    const float4 t0 = tri4[3 * i], t1 = tri4[3 * i + 1], t2 = tri4[3 * i + 2];
+    const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t1.x, t1.y, t1.z), c = mk3(t2.x, t2.y, t2.z);
+    const f3 n = mk3(t0.w, t1.w, t2.w);  // unit normal (zero for a degenerate triangle)
+    if (fabsf(dot(n, P - a)) > dmax * 1.0001f) continue;
     bool out = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -110,17 +110,21 @@ __device__ __forceinline__ uint32_t nearOccluders(f3 P, const float *v0, const f
       if (pk < lo - dmax || pk > hi + dmax) out = true;
     }
     if (out) continue;
-    if (cnt == 4u) return 0xFEFFFFFFu;
-    list = (list & ~(0xFFu << (8 * cnt))) | (i << (8 * cnt));
+    if (cnt == 12u) {
+      w0 = 0xFEFFFFFFu;
+      return;
+    }
+    const uint32_t sh = 8u * (cnt & 3u), m = ~(0xFFu << sh), v = i << sh;
+    if (cnt < 4u) w0 = (w0 & m) | v;
+    else if (cnt < 8u) w1 = (w1 & m) | v;
+    else w2 = (w2 & m) | v;
     cnt++;
   }
-  return list;
 }
 
 __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ order, uint32_t n,
-                                                      gvpm_params cfg, const float *triV0, const float *triE1,
-                                                      const float *triE2, uint32_t ntri, float dmax, float4 *hot,
-                                                      float4 *cold) {
+                                                      gvpm_params cfg, const float4 *tri4, uint32_t ntri,
+                                                      float dmax, float4 *hot, float4 *cold, uint32_t *overflow) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t src = order[i];
@@ -128,15 +132,20 @@ __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32
   if (photonContributes(bits, cfg)) bits |= 1u << 6;
   bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
   hot[i] = ld3(r.pos, src, __uint_as_float(bits));
-  const size_t N = n;
-  cold[0 * N + i] = ld3(r.wi, src, r.parent_pdf[src]);
-  cold[1 * N + i] = ld3(r.flux, src, r.edge_pdf[src]);
-  cold[2 * N + i] = ld3(r.parent_pos, src, r.parent_rr[src]);
-  cold[3 * N + i] = ld3(r.parent_n, src, r.parent_g[src]);
+  // one 128-byte record per photon: an evaluation touches exactly one cache line
+  float4 *rec = cold + (size_t)i * GVPM_REC_QUADS;
+  rec[0] = hot[i];
+  rec[1] = ld3(r.wi, src, r.parent_pdf[src]);
+  rec[2] = ld3(r.flux, src, r.edge_pdf[src]);
+  rec[3] = ld3(r.parent_pos, src, r.parent_rr[src]);
+  rec[4] = ld3(r.parent_n, src, r.parent_g[src]);
   const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
-  cold[4 * N + i] = ld3(r.prefix_w, src, __uint_as_float(nearOccluders(P, triV0, triE1, triE2, ntri, dmax)));
-  cold[5 * N + i] = ld3(r.parent_scat, src, 0.f);
-  cold[6 * N + i] = ld3(r.parent_wi, src, 0.f);
+  uint32_t w0, w1, w2;
+  nearOccluders(P, tri4, ntri, dmax, w0, w1, w2);
+  if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
+  rec[5] = ld3(r.prefix_w, src, __uint_as_float(w0));
+  rec[6] = ld3(r.parent_scat, src, __uint_as_float(w1));
+  rec[7] = ld3(r.parent_wi, src, __uint_as_float(w2));
 }
 
 // ---- segment starts of a sorted key array: start[c] = first i with (key[i] >> shift) >= c ----
@@ -243,13 +252,13 @@ void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *key
 }
 
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
-                    const float *triV0, const float *triE1, const float *triE2, uint32_t ntri, float dmax,
-                    float4 *hot, float4 *cold, hipStream_t s) {
+                    const float4 *tri4, uint32_t ntri, float dmax, float4 *hot, float4 *cold, uint32_t *overflow,
+                    hipStream_t s) {
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, order, n, cfg, triV0, triE1, triE2, ntri, dmax,
-                     hot, cold);
+  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, order, n, cfg, tri4, ntri, dmax, hot, cold,
+                     overflow);
 }
 
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,

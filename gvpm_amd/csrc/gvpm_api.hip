@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "device_types.h"
+#include "scene_bvh.h"
 
 namespace gvpm {
 hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut,
@@ -20,21 +21,25 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
-                    const float *triV0, const float *triE1, const float *triE2, uint32_t ntri, float dmax,
-                    float4 *hot, float4 *cold, hipStream_t s);
+                    const float4 *tri4, uint32_t ntri, float dmax, float4 *hot, float4 *cold, uint32_t *overflow,
+                    hipStream_t s);
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
                           hipStream_t s);
 void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
                       uint32_t *vals, hipStream_t s);
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
-                     uint32_t *itemCount, hipStream_t stream);
-void launch_gather_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
-                       uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
+                     uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream);
+void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
+                         const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCnt,
+                         uint32_t nwaves, hipStream_t stream);
+void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
+                         const uint32_t *itemCount, uint32_t *queueHead, const uint2 *pairs, const uint32_t *pairCnt,
+                         uint32_t nwaves, hipStream_t stream);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
-void launch_gather_vpm(const GatherArgs &a, hipStream_t stream);
+void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream);
 void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
                        hipStream_t stream);
 void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);
@@ -106,6 +111,8 @@ RcclApi g_rccl;
 
 }  // namespace
 
+#define GVPM_PHASES 3
+
 struct gvpm_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -115,7 +122,7 @@ struct gvpm_context {
   std::string err;
 
   // scene
-  DevBuf<float> triV0, triE1, triE2;
+  DevBuf<float4> tri4, bvh;   // packed triangles in BVH leaf order + nodes (scene_bvh.h)
   uint32_t ntri = 0;
   float triMin[3] = {0, 0, 0}, triMax[3] = {0, 0, 0};  // occluder bounds (host side, at upload)
 
@@ -127,8 +134,16 @@ struct gvpm_context {
   bool havePhotons = false, photonsDirty = false;
   float builtRadius = -1.f;
   DevBuf<float4> hot, cold;
+  DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
+  bool nearOverflow = false;
   DevBuf<uint32_t> cellStart, keysA, keysB, valsA, valsB;
   DevBuf<float> boundsPartial, bounds6;
+  // G-BRE keeps its per-step host syncs to one: the photon bounds of step N are read back with the
+  // planner's counters and size the grid of step N+1 (photons outside the grid sit in its border cells)
+  float cachedB6[6] = {0, 0, 0, 0, 0, 0};
+  bool haveCachedBounds = false, boundsPending = false;
+  float *pinB6 = nullptr;      // pinned host staging: 6 floats + 2 uint32
+  uint32_t *pinCtl = nullptr;
   Grid grid;
   SortTemp sortTmp;
 
@@ -171,15 +186,21 @@ struct gvpm_context {
 
   // stats / timing
   DevBuf<unsigned long long> stats;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  size_t eventsUsed = 0;
+  // HIP event brackets per phase: 0 = dominant kernel, 1 = BRE traversal, 2 = build (grid + sorts + plan)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events[GVPM_PHASES];
+  size_t eventsUsed[GVPM_PHASES] = {0, 0, 0};
 
   int beamsPerWave = 16;
   float cellScale = 1.0f;
   uint32_t planTarget = 1024;  // staged photons per work item
   uint32_t nwaves = 2048;      // persistent gather waves
+  uint32_t ncu = 256;
+  uint32_t nwavesTrav = 4096;  // persistent traversal waves (G-BRE)
   DevBuf<uint4> items;
-  DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead
+  DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
+  // G-BRE: (photon, beam) pairs between the traversal and the evaluation kernel
+  DevBuf<uint2> itemOff, pairs;
+  DevBuf<uint32_t> pairCnt;
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -263,11 +284,16 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-      h->nwaves = (uint32_t)prop.multiProcessorCount * 8u;
+      h->nwaves = (uint32_t)prop.multiProcessorCount * 8u, h->ncu = (uint32_t)prop.multiProcessorCount;
     if (const char *e = getenv("GVPM_WAVES_PER_CU")) {
       int v = atoi(e);
       if (v >= 1 && v <= 32 && prop.multiProcessorCount > 0) h->nwaves = (uint32_t)prop.multiProcessorCount * v;
     }
+  }
+  h->nwavesTrav = h->ncu * 16u;
+  if (const char *e = getenv("GVPM_TRAV_WAVES_PER_CU")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 32) h->nwavesTrav = h->ncu * (uint32_t)v;
   }
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
@@ -295,12 +321,14 @@ int gvpm_destroy(gvpm_context *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.commDestroy) g_rccl.commDestroy(h->comm);
-  for (auto &e : h->events) {
-    (void)hipEventDestroy(e.first);
-    (void)hipEventDestroy(e.second);
-  }
-  h->triV0.release(); h->triE1.release(); h->triE2.release();
-  h->rawF.release(); h->rawU.release(); h->hot.release(); h->cold.release();
+  for (auto &v : h->events)
+    for (auto &e : v) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+  h->itemOff.release(); h->pairs.release(); h->pairCnt.release();
+  h->tri4.release(); h->bvh.release();
+  h->rawF.release(); h->rawU.release(); h->hot.release(); h->cold.release(); h->overflowCtr.release();
   h->cellStart.release(); h->keysA.release(); h->keysB.release(); h->valsA.release(); h->valsB.release();
   h->boundsPartial.release(); h->bounds6.release();
   if (h->sortTmp.d) (void)hipFree(h->sortTmp.d);
@@ -311,6 +339,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
+  if (h->pinB6) (void)hipHostFree(h->pinB6);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return GVPM_OK;
@@ -321,7 +350,7 @@ int gvpm_reset(gvpm_context *h) {
   HIP_TRY(h, hipMemsetAsync(h->accum.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * sizeof(unsigned long long), h->stream));
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
-  h->eventsUsed = 0;
+  for (size_t &u : h->eventsUsed) u = 0;
   h->useAll = false;
   h->totalEmitted = 0;
   {
@@ -341,15 +370,30 @@ int gvpm_reset(gvpm_context *h) {
 int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *t) {
   CHECK_H(h);
   if (!t || (t->n && (!t->v0 || !t->e1 || !t->e2))) return fail(h, GVPM_ERR_INVALID_ARG, "null triangle arrays");
-  HIP_TRY(h, h->triV0.ensure(3 * (size_t)t->n + 4));
-  HIP_TRY(h, h->triE1.ensure(3 * (size_t)t->n + 4));
-  HIP_TRY(h, h->triE2.ensure(3 * (size_t)t->n + 4));
-  if (t->n) {
-    HIP_TRY(h, hipMemcpyAsync(h->triV0.p, t->v0, 3 * (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->triE1.p, t->e1, 3 * (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->triE2.p, t->e2, 3 * (size_t)t->n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // occluder BVH on the host; triangles packed {v0,n.x} {e1,n.y} {e2,n.z} in leaf order
+  BvhBuild bvh;
+  buildSceneBvh(t->v0, t->e1, t->e2, t->n, bvh);
+  std::vector<float> packed(12 * (size_t)t->n + 12, 0.f);
+  for (uint32_t k = 0; k < t->n; ++k) {
+    const uint32_t i = bvh.order[k];
+    const float *a = t->v0 + 3 * (size_t)i, *b = t->e1 + 3 * (size_t)i, *c = t->e2 + 3 * (size_t)i;
+    float n[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+    const float l = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int q = 0; q < 3; ++q) n[q] = l > 0.f ? n[q] / l : 0.f;
+    float *o = packed.data() + 12 * (size_t)k;
+    for (int q = 0; q < 3; ++q) {
+      o[q] = a[q];
+      o[4 + q] = b[q];
+      o[8 + q] = c[q];
+      o[4 * q + 3] = n[q];
+    }
   }
+  HIP_TRY(h, h->tri4.ensure(3 * (size_t)t->n + 3));
+  HIP_TRY(h, h->bvh.ensure(bvh.nodes.size() / 4 + 2));
+  HIP_TRY(h, hipMemcpyAsync(h->tri4.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->bvh.p, bvh.nodes.data(), bvh.nodes.size() * sizeof(float), hipMemcpyHostToDevice,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->ntri = t->n;
   for (int c = 0; c < 3; ++c) {
     h->triMin[c] = INFINITY;
@@ -559,9 +603,11 @@ static int ilog2ceil(uint32_t v) {
   return b;
 }
 
-// uniform grid over the photons for kernel radius r
-static int buildGrid(gvpm_context *h, float r) {
+// uniform grid over the photons for kernel radius r.  deferred: use the bounds of the previous
+// photon set when there is one and leave this set's bounds in flight (pinB6) for the caller's sync.
+static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   const uint32_t n = h->nph;
+  h->boundsPending = false;
   if (n == 0) {
     h->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
     HIP_TRY(h, h->cellStart.ensure(2));
@@ -573,8 +619,20 @@ static int buildGrid(gvpm_context *h, float r) {
   HIP_TRY(h, h->bounds6.ensure(8));
   launch_bounds(h->rawDev.pos, n, h->boundsPartial.p, nblocks, h->bounds6.p, h->stream);
   float b6[6];
-  HIP_TRY(h, hipMemcpyAsync(b6, h->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!h->pinB6) {
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocDefault));
+    h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
+  }
+  if (deferred && h->haveCachedBounds) {
+    HIP_TRY(h, hipMemcpyAsync(h->pinB6, h->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->stream));
+    h->boundsPending = true;
+    memcpy(b6, h->cachedB6, sizeof(b6));
+  } else {
+    HIP_TRY(h, hipMemcpyAsync(b6, h->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(h->cachedB6, b6, sizeof(b6));
+    h->haveCachedBounds = true;
+  }
   float ext = 0.f;
   for (int c = 0; c < 3; ++c) {
     if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
@@ -599,7 +657,7 @@ static int buildGrid(gvpm_context *h, float r) {
   HIP_TRY(h, h->valsA.ensure(n));
   HIP_TRY(h, h->valsB.ensure(n));
   HIP_TRY(h, h->hot.ensure(n));
-  HIP_TRY(h, h->cold.ensure((size_t)n * GVPM_COLD_PLANES));
+  HIP_TRY(h, h->cold.ensure((size_t)n * GVPM_REC_QUADS));
   HIP_TRY(h, h->cellStart.ensure((size_t)g.ncells + 2));
   launch_cell_keys(h->rawDev.pos, n, g, h->keysA.p, h->valsA.p, h->stream);
   HIP_TRY(h, sortPairsU32(h->sortTmp, h->keysA.p, h->keysB.p, h->valsA.p, h->valsB.p, n,
@@ -612,10 +670,19 @@ static int buildGrid(gvpm_context *h, float r) {
   }
   const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
-  launch_reorder(h->rawDev, h->valsB.p, n, h->cfg, h->triV0.p, h->triE1.p, h->triE2.p, h->ntri, dmax, h->hot.p,
-                 h->cold.p, h->stream);
+  HIP_TRY(h, h->overflowCtr.ensure(2));
+  HIP_TRY(h, hipMemsetAsync(h->overflowCtr.p, 0, 4, h->stream));
+  launch_reorder(h->rawDev, h->valsB.p, n, h->cfg, h->tri4.p, h->ntri, dmax, h->hot.p, h->cold.p, h->overflowCtr.p,
+                 h->stream);
   launch_segment_start(h->keysB.p, n, g.ncells, 0, h->cellStart.p, h->stream);
   HIP_TRY(h, hipGetLastError());
+  h->nearOverflow = false;
+  if (!deferred && h->cfg.visibility_as_written && h->ntri <= 254u) {
+    uint32_t over = 0;
+    HIP_TRY(h, hipMemcpyAsync(&over, h->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->nearOverflow = over != 0;
+  }
   return GVPM_OK;
 }
 
@@ -646,6 +713,11 @@ static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
   return GVPM_OK;
 }
 
+// shadow rays through the occluder BVH instead of the per-photon near-occluder lists
+static bool needFullVis(const gvpm_context *h) {
+  return !h->cfg.visibility_as_written || h->ntri > 254u || h->nearOverflow;
+}
+
 static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   memset(&a, 0, sizeof(a));
   a.hot = h->hot.p;
@@ -657,9 +729,8 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.setPerm = h->setPerm.p;
   a.tileStart = h->tileStart.p;
   a.nsets = h->nsets;
-  a.triV0 = h->triV0.p;
-  a.triE1 = h->triE1.p;
-  a.triE2 = h->triE2.p;
+  a.tri4 = h->tri4.p;
+  a.bvh = h->bvh.p;
   a.ntri = h->ntri;
   for (int c = 0; c < 3; ++c) {
     a.med.sigmaS[c] = h->medium.sigma_s[c];
@@ -680,45 +751,80 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.nbeams = 0;
 }
 
-static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev) {
-  // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved)
-  if (h->eventsUsed == h->events.size()) {
+static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, int phase = 0) {
+  // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved) and the other phases
+  if (h->eventsUsed[phase] == h->events[phase].size()) {
     hipEvent_t e0, e1;
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    h->events.emplace_back(e0, e1);
+    h->events[phase].emplace_back(e0, e1);
   }
-  *ev = &h->events[h->eventsUsed++];
+  *ev = &h->events[phase][h->eventsUsed[phase]++];
   return GVPM_OK;
 }
 
 // computeVolumeGradientPhotonBRE, gvpm.cpp:988-1079
 static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   const float r = currentRadius(h);
+  std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav, *evEval;
+  int rc = nextEvents(h, &evBuild, 2);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, hipEventRecord(evBuild->first, h->stream));
+  bool rebuilt = false;
   if (h->photonsDirty || r != h->builtRadius) {
-    int rc = buildGrid(h, r);
+    rc = buildGrid(h, r, true);
     if (rc != GVPM_OK) return rc;
     h->photonsDirty = false;
     h->builtRadius = r;
+    rebuilt = h->nph > 0;
   }
   if (h->beamsDirty) {
-    int rc = sortBeams(h);
+    rc = sortBeams(h);
     if (rc != GVPM_OK) return rc;
     h->beamsDirty = false;
   }
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   GatherArgs a;
   fillArgs(h, a, r);
-  std::pair<hipEvent_t, hipEvent_t> *ev;
-  int rc = nextEvents(h, &ev);
-  if (rc != GVPM_OK) return rc;
-  HIP_TRY(h, h->items.ensure(plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave)));
+  const uint32_t itemCap = plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave);
+  HIP_TRY(h, h->items.ensure(itemCap));
+  HIP_TRY(h, h->itemOff.ensure(itemCap));
+  HIP_TRY(h, h->pairCnt.ensure(itemCap));
   HIP_TRY(h, h->queueCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
-  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->stream);
-  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_bre(a, h->beamsPerWave, h->items.p, h->queueCtl.p, h->queueCtl.p + 1, h->nwaves, h->stream);
-  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->itemOff.p,
+                  h->queueCtl.p + 3, h->stream);
+  // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only)
+  // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
+  if (!h->pinB6) {
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocDefault));
+    h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->pinCtl, h->queueCtl.p + 3, 4, hipMemcpyDeviceToHost, h->stream));
+  if (rebuilt) HIP_TRY(h, hipMemcpyAsync(h->pinCtl + 1, h->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const uint32_t blocks = h->pinCtl[0];
+  if (rebuilt) h->nearOverflow = h->cfg.visibility_as_written && h->ntri <= 254u && h->pinCtl[1] != 0;
+  if (h->boundsPending) {
+    h->boundsPending = false;
+    for (int c = 0; c < 6; ++c)
+      if (!std::isfinite(h->pinB6[c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
+    memcpy(h->cachedB6, h->pinB6, sizeof(h->cachedB6));
+  }
+  HIP_TRY(h, h->pairs.ensure((size_t)blocks * 64u + 64u));
+  HIP_TRY(h, hipEventRecord(evBuild->second, h->stream));
+  rc = nextEvents(h, &evTrav, 1);
+  if (rc != GVPM_OK) return rc;
+  rc = nextEvents(h, &evEval, 0);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, hipEventRecord(evTrav->first, h->stream));
+  launch_traverse_bre(a, h->beamsPerWave, h->items.p, h->itemOff.p, h->queueCtl.p, h->queueCtl.p + 1, h->pairs.p,
+                      h->pairCnt.p, h->nwavesTrav, h->stream);
+  HIP_TRY(h, hipEventRecord(evTrav->second, h->stream));
+  HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
+  launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->items.p, h->itemOff.p, h->queueCtl.p, h->queueCtl.p + 2, h->pairs.p,
+                      h->pairCnt.p, h->nwaves, h->stream);
+  HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
   // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
@@ -841,7 +947,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   HIP_TRY(h, h->items.ensure(plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave)));
   HIP_TRY(h, h->queueCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
-  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->stream);
+  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, nullptr, nullptr, h->stream);
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   launch_gather_beams(a, h->beamsPerWave, h->items.p, h->queueCtl.p, h->queueCtl.p + 1, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
@@ -936,7 +1042,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_vpm(a, h->stream);
+  launch_gather_vpm(a, needFullVis(h), h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->stream);
   launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
@@ -998,19 +1104,24 @@ int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   return GVPM_OK;
 }
 
-int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches) {
+int gvpm_get_phase_time(gvpm_context *h, int phase, float *avg_ms, uint32_t *launches) {
   CHECK_H(h);
+  if (phase < 0 || phase >= GVPM_PHASES) return fail(h, GVPM_ERR_INVALID_ARG, "unknown phase");
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   double total = 0;
-  for (size_t i = 0; i < h->eventsUsed; ++i) {
+  for (size_t i = 0; i < h->eventsUsed[phase]; ++i) {
     float ms = 0;
-    HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->events[phase][i].first, h->events[phase][i].second));
     total += ms;
   }
-  if (avg_ms) *avg_ms = h->eventsUsed ? (float)(total / h->eventsUsed) : 0.f;
-  if (launches) *launches = (uint32_t)h->eventsUsed;
-  h->eventsUsed = 0;
+  if (avg_ms) *avg_ms = h->eventsUsed[phase] ? (float)(total / h->eventsUsed[phase]) : 0.f;
+  if (launches) *launches = (uint32_t)h->eventsUsed[phase];
+  h->eventsUsed[phase] = 0;
   return GVPM_OK;
+}
+
+int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches) {
+  return gvpm_get_phase_time(h, 0, avg_ms, launches);
 }
 
 int gvpm_download_accum(gvpm_context *h, float *accum) {

@@ -11,7 +11,6 @@ namespace gvpm {
 #define INV_PI_F 0.31830988618379067154f
 #define INV_FOURPI_F 0.07957747154594766788f
 
-constexpr int MAXTRI_LDS = 32;
 
 struct RayReg {
   f3 o, d, eye;
@@ -53,52 +52,65 @@ __device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mi
   return false;
 }
 
-// scene->rayIntersect(ray), any-hit over the occluder list.  Triangles sit in LDS (broadcast
-// reads); a plane-distance early-out skips triangles the segment [mint,maxt] cannot reach.
-__device__ __forceinline__ bool anyHit(const GatherArgs &a, const float4 (*tri)[3], f3 o, f3 d, float mint, float maxt) {
-  bool hit = false;
-  const uint32_t nl = min(a.ntri, (uint32_t)MAXTRI_LDS);
-  for (uint32_t i = 0; i < nl; ++i) {
-    const float4 t0 = tri[i][0], t1 = tri[i][1], t2 = tri[i][2];
-    const f3 v0 = mk3(t0.x, t0.y, t0.z), n = mk3(t0.w, t1.w, t2.w);
-    const float dist0 = dot(n, o - v0);
-    const float dn = dot(n, d);
-    // signed plane distances at both segment ends; no sign change (with margin) => no hit
-    const float da = dist0 + mint * dn, db = dist0 + maxt * dn;
-    const float margin = 1e-4f * (fabsf(dist0) + maxt) + 1e-7f;
-    if ((da > margin && db > margin) || (da < -margin && db < -margin)) continue;
-    if (triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+// scene->rayIntersect(ray), any-hit: stack walk of the occluder BVH (scene_bvh.h), triangles as
+// {v0,n.x} {e1,n.y} {e2,n.z} in leaf order.  Deliberately not inlined: it is the rare path (the
+// as-written shadow segment is served by the per-photon near-occluder list below) and inlining
+// it cost the evaluation kernels ~160 VGPRs.
+static __device__ __noinline__ bool anyHitScene(const float4 *bvh, const float4 *tri4, uint32_t ntri, f3 o, f3 d, float mint,
+                                         float maxt) {
+  if (ntri == 0u) return false;
+  const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  uint32_t stack[32];
+  int sp = 0;
+  uint32_t cur = 0;
+  for (;;) {
+    const float4 lo = bvh[2 * (size_t)cur], hi = bvh[2 * (size_t)cur + 1];
+    // slab test; fminf/fmaxf drop the NaNs of 0 * inf
+    const float tx0 = (lo.x - o.x) * inv.x, tx1 = (hi.x - o.x) * inv.x;
+    const float ty0 = (lo.y - o.y) * inv.y, ty1 = (hi.y - o.y) * inv.y;
+    const float tz0 = (lo.z - o.z) * inv.z, tz1 = (hi.z - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), mint));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), maxt));
+    bool descend = false;
+    if (tn <= tf) {
+      const uint32_t first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+      if (count == 0u) {
+        if (sp < 32) stack[sp++] = first + 1u;
+        cur = first;
+        descend = true;
+      } else {
+        for (uint32_t i = first; i < first + count; ++i) {
+          const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
+          if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) return true;
+        }
+      }
+    }
+    if (!descend) {
+      if (sp == 0) return false;
+      cur = stack[--sp];
+    }
   }
-  for (uint32_t i = nl; i < a.ntri; ++i) {
-    const f3 v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
-    const f3 e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
-    const f3 e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
-    if (triHit(v0, e1, e2, o, d, mint, maxt)) hit = true;
-  }
-  return hit;
 }
 
 // As written (shift_volume_photon.cpp:396) the shadow segment is [Epsilon, lProj*ShadowEpsilon]
 // from the photon's parent: only occluders within that distance of the parent can be hit.  The
-// grid build lists them per photon (reorder_kernel), so the any-hit loop touches 0-4 triangles.
-__device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const float4 (*tri)[3], uint32_t nearList, f3 o,
+// grid build lists them per photon (reorder_kernel: up to 12 byte indices in the three spare
+// words of the record), so the loop touches 0-12 triangles.  FULLVIS kernels (intended visibility,
+// more than 254 occluders, or a photon whose list overflowed) walk the BVH instead; the fast
+// kernels carry no call, which is worth ~30 VGPRs.
+template <bool FULLVIS>
+__device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o,
                                               f3 d, float mint, float maxt) {
-  if (!a.cfg.visibility_as_written || (nearList >> 24) == 0xFEu) return anyHit(a, tri, o, d, mint, maxt);
+  if (FULLVIS) return anyHitScene(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
   bool hit = false;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t i = (nearList >> (8 * k)) & 0xFFu;
-    if (i == 0xFFu) continue;
-    f3 v0, e1, e2;
-    if (i < (uint32_t)MAXTRI_LDS) {
-      const float4 t0 = tri[i][0], t1 = tri[i][1], t2 = tri[i][2];
-      v0 = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
-    } else {
-      v0 = mk3(a.triV0[3 * i], a.triV0[3 * i + 1], a.triV0[3 * i + 2]);
-      e1 = mk3(a.triE1[3 * i], a.triE1[3 * i + 1], a.triE1[3 * i + 2]);
-      e2 = mk3(a.triE2[3 * i], a.triE2[3 * i + 1], a.triE2[3 * i + 2]);
-    }
-    if (triHit(v0, e1, e2, o, d, mint, maxt)) hit = true;
+  uint32_t l = nl0;
+#pragma unroll 1
+  for (int k = 0; k < 12; ++k) {
+    const uint32_t i = l & 0xFFu;
+    if (i == 0xFFu) break;
+    l = k == 3 ? nl1 : (k == 7 ? nl2 : (l >> 8) | 0xFF000000u);
+    const float4 t0 = a.tri4[3 * i], t1 = a.tri4[3 * i + 1], t2 = a.tri4[3 * i + 2];
+    if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
   }
   return hit;
 }
@@ -115,33 +127,34 @@ __device__ __forceinline__ float sensorMIS(const RayReg &s, const RayReg &b, uin
 }
 
 struct PhotonCold {
-  f3 wi, flux, parentPos, parentN, prefixW, parentScat, parentWi;
+  f3 pos, wi, flux, parentPos, parentN, prefixW, parentScat, parentWi;
   float parentPdf, edgePdf, parentRR, parentG;
-  uint32_t nearList;  // up to 4 occluder indices near the parent (0xFF = none); top byte 0xFE: overflow
+  uint32_t bits;
+  uint32_t nl0, nl1, nl2;  // up to 12 occluder indices near the parent (0xFF = none); top byte of nl0 0xFE: overflow
 };
 
+// the photon's 128-byte record (one cache line)
 __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx) {
   PhotonCold c;
-  const float4 c0 = a.cold[0 * (size_t)a.nph + idx];
-  const float4 c1 = a.cold[1 * (size_t)a.nph + idx];
-  const float4 c2 = a.cold[2 * (size_t)a.nph + idx];
-  const float4 c3 = a.cold[3 * (size_t)a.nph + idx];
-  const float4 c4 = a.cold[4 * (size_t)a.nph + idx];
-  const float4 c5 = a.cold[5 * (size_t)a.nph + idx];
-  const float4 c6 = a.cold[6 * (size_t)a.nph + idx];
-  c.wi = mk3(c0.x, c0.y, c0.z); c.parentPdf = c0.w;
-  c.flux = mk3(c1.x, c1.y, c1.z); c.edgePdf = c1.w;
-  c.parentPos = mk3(c2.x, c2.y, c2.z); c.parentRR = c2.w;
-  c.parentN = mk3(c3.x, c3.y, c3.z); c.parentG = c3.w;
-  c.prefixW = mk3(c4.x, c4.y, c4.z);
-  c.nearList = __float_as_uint(c4.w);
-  c.parentScat = mk3(c5.x, c5.y, c5.z);
-  c.parentWi = mk3(c6.x, c6.y, c6.z);
+  const float4 *rec = a.cold + (size_t)idx * GVPM_REC_QUADS;
+  const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2], c3 = rec[3], c4 = rec[4], c5 = rec[5], c6 = rec[6], c7 = rec[7];
+  c.pos = mk3(c0.x, c0.y, c0.z); c.bits = __float_as_uint(c0.w);
+  c.wi = mk3(c1.x, c1.y, c1.z); c.parentPdf = c1.w;
+  c.flux = mk3(c2.x, c2.y, c2.z); c.edgePdf = c2.w;
+  c.parentPos = mk3(c3.x, c3.y, c3.z); c.parentRR = c3.w;
+  c.parentN = mk3(c4.x, c4.y, c4.z); c.parentG = c4.w;
+  c.prefixW = mk3(c5.x, c5.y, c5.z);
+  c.nl0 = __float_as_uint(c5.w);
+  c.parentScat = mk3(c6.x, c6.y, c6.z);
+  c.nl1 = __float_as_uint(c6.w);
+  c.parentWi = mk3(c7.x, c7.y, c7.z);
+  c.nl2 = __float_as_uint(c7.w);
   return c;
 }
 
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.
-__device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const float4 (*tri)[3], const PhotonCold &ph,
+template <bool FULLVIS>
+__device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonCold &ph,
                                               uint32_t bits, f3 dProjU, const RayReg &sh, const RayReg &base,
                                               uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
                                               f3 &shiftedFlux, bool &ok) {
@@ -152,7 +165,7 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const float4 
   const f3 dProj = dProjU * (1.f / lProj);
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
-  if (shadowBlocked(a, tri, ph.nearList, ph.parentPos, dProj, eps, vmax)) return 1.f;
+  if (shadowBlocked<FULLVIS>(a, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax)) return 1.f;
   if (ptype != GVPM_PARENT_MEDIUM) {
     const float signDot = dot(ph.parentN, dProj) / dot(ph.parentN, -ph.wi);
     if (signDot < 0.f) return 1.f;

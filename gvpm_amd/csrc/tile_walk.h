@@ -21,7 +21,6 @@ template <int B> struct TileLds {
   float4 stage[STAGE];
   uint32_t stageIdx[STAGE];
   uint2 queue[QCAP];
-  float4 tri[MAXTRI_LDS][3];  // {v0,n.x} {e1,n.y} {e2,n.z}
   float rnd[B];
   uint32_t pix[B];
   uint32_t edge[B];
@@ -52,7 +51,7 @@ struct TileWalk {
   // wave-uniform
   int A, cA0, cA1, K;
   float orgA, orgU, orgV, pad;
-  int dimU, dimV;
+  int dimA, dimU, dimV;
   bool any;
 };
 
@@ -88,12 +87,54 @@ __device__ __forceinline__ void loadTileRays(const GatherArgs &a, TileLds<B> &s,
   __syncthreads();
 }
 
+// the base ray of beam set (setBase + lane % B), straight from global memory (no LDS tile)
+struct BaseInfo {
+  float rnd;
+  uint32_t pix, edge;
+};
+template <int B>
+__device__ __forceinline__ RayReg loadBaseDirect(const GatherArgs &a, uint32_t setBase, uint32_t nb, int lane,
+                                                 BaseInfo &bi) {
+  RayReg r;
+  r.o = r.d = r.eye = mk3(0.f);
+  r.len = r.pdf = r.jac = r.gop = 0.f;
+  r.valid = false;
+  bi.rnd = 0.f;
+  bi.pix = bi.edge = 0u;
+  const int b = lane % B;
+  if ((uint32_t)b < nb) {
+    const uint32_t set = a.setPerm[setBase + b];
+    const float4 *ray = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5);
+    const float4 q0 = ray[0], q1 = ray[1], q2 = ray[2], q3 = ray[3];
+    r.o = mk3(q0.x, q0.y, q0.z);
+    r.len = fabsf(q0.w);
+    r.d = mk3(q1.x, q1.y, q1.z);
+    r.pdf = q1.w;
+    r.eye = mk3(q2.x, q2.y, q2.z);
+    r.jac = q2.w;
+    r.gop = q3.x;
+    const uint32_t info = __float_as_uint(q3.y);
+    r.valid = GVPM_RAY_VALID(info) != 0;
+    bi.edge = GVPM_RAY_EDGE(info);
+    bi.rnd = q3.z;
+    bi.pix = __float_as_uint(q3.w);
+  }
+  return r;
+}
+
+__device__ __forceinline__ void tileSetupFrom(const GatherArgs &a, const RayReg &base, bool valid, TileWalk &w);
+
 template <int B>
 __device__ __forceinline__ void tileSetup(const GatherArgs &a, const TileLds<B> &s, uint32_t nb, int lane,
                                           TileWalk &w) {
   const int b = lane % B;
-  w.base = loadRay(s, 0, b);
-  w.beamValid = (uint32_t)b < nb && w.base.valid;
+  const RayReg base = loadRay(s, 0, b);
+  tileSetupFrom(a, base, (uint32_t)b < nb && base.valid, w);
+}
+
+__device__ __forceinline__ void tileSetupFrom(const GatherArgs &a, const RayReg &base, bool valid, TileWalk &w) {
+  w.base = base;
+  w.beamValid = valid;
   const float r = a.radius, eps = a.cfg.epsilon;
   const float mint = eps, maxt = w.base.len - eps;
   int A;
@@ -130,9 +171,11 @@ __device__ __forceinline__ void tileSetup(const GatherArgs &a, const TileLds<B> 
   w.any = aLo <= aHi && a.nph > 0;
   w.cA0 = 1;
   w.cA1 = 0;
+  w.dimA = dimA;
   if (w.any) {
-    w.cA0 = max(0, (int)floorf((aLo - w.orgA) * a.grid.invCell));
-    w.cA1 = min(dimA - 1, (int)floorf((aHi - w.orgA) * a.grid.invCell));
+    // photons outside the grid bounds sit (clamped) in its border cells: clamp both ends alike
+    w.cA0 = min(max(0, (int)floorf((aLo - w.orgA) * a.grid.invCell)), dimA - 1);
+    w.cA1 = min(max(0, (int)floorf((aHi - w.orgA) * a.grid.invCell)), dimA - 1);
   }
   // layers per step: thicker slabs when the contiguous (x) axis is the slab axis
   w.K = (A == 0) ? 8 : a.cfg.reserved[1] ? a.cfg.reserved[1] : 4;
@@ -144,7 +187,9 @@ struct CellBox {
 
 // cell box of the slab layers [cA, cAe]; false when no beam of the tile reaches the slab
 __device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, int cA, int cAe, CellBox &bx) {
-  const float lo = w.orgA + cA * a.grid.cell - w.pad, hi = w.orgA + (cAe + 1) * a.grid.cell + w.pad;
+  // border layers extend to infinity (they hold the clamped photons)
+  const float lo = cA == 0 ? -INFINITY : w.orgA + cA * a.grid.cell - w.pad;
+  const float hi = cAe == w.dimA - 1 ? INFINITY : w.orgA + (cAe + 1) * a.grid.cell + w.pad;
   float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
   if (w.beamValid) {
     float ta = w.t0, tb = w.t1;
@@ -167,11 +212,10 @@ __device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, 
   uLo = wave_min(uLo); uHi = wave_max(uHi);
   vLo = wave_min(vLo); vHi = wave_max(vHi);
   if (!(uLo <= uHi)) return false;
-  const int cU0 = max(0, (int)floorf((uLo - w.orgU) * a.grid.invCell));
-  const int cU1 = min(w.dimU - 1, (int)floorf((uHi - w.orgU) * a.grid.invCell));
-  const int cV0 = max(0, (int)floorf((vLo - w.orgV) * a.grid.invCell));
-  const int cV1 = min(w.dimV - 1, (int)floorf((vHi - w.orgV) * a.grid.invCell));
-  if (cU0 > cU1 || cV0 > cV1) return false;
+  const int cU0 = min(max(0, (int)floorf((uLo - w.orgU) * a.grid.invCell)), w.dimU - 1);
+  const int cU1 = min(max(0, (int)floorf((uHi - w.orgU) * a.grid.invCell)), w.dimU - 1);
+  const int cV0 = min(max(0, (int)floorf((vLo - w.orgV) * a.grid.invCell)), w.dimV - 1);
+  const int cV1 = min(max(0, (int)floorf((vHi - w.orgV) * a.grid.invCell)), w.dimV - 1);
   // (A,U,V) -> (x,y,z): A=0: x=A y=U z=V; A=1: x=V y=A z=U; A=2: x=U y=V z=A
   const int A = w.A;
   bx.bx0 = A == 0 ? cA : (A == 1 ? cV0 : cU0); bx.bx1 = A == 0 ? cAe : (A == 1 ? cV1 : cU1);
@@ -212,19 +256,21 @@ __device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox 
 // plan: cut every tile chunk into work items of ~equal candidate count
 // item = {setBase, nb, firstLayer, lastLayer}
 // ------------------------------------------------------------------------------------------
+// itemOff (optional): per item {first 64-pair block of its region in the pair buffer, blocks}; the
+// region holds the item's upper bound of (photon, beam) pairs = staged photons x beams
 template <int B>
 __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
-                                                  uint32_t *itemCount) {
-  __shared__ TileLds<B> s;
+                                                  uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal) {
   const int lane = threadIdx.x;
   const uint32_t tile = blockIdx.x;
   if (tile >= ntiles) return;
   const uint32_t tileBeg = a.tileStart[tile], tileEnd = a.tileStart[tile + 1];
   for (uint32_t setBase = tileBeg; setBase < tileEnd; setBase += B) {
     const uint32_t nb = min((uint32_t)B, tileEnd - setBase);
-    loadTileRays<B>(a, s, setBase, nb, lane);
+    BaseInfo bi;
+    const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
     TileWalk w;
-    tileSetup<B>(a, s, nb, lane, w);
+    tileSetupFrom(a, base, base.valid, w);
     if (!w.any) continue;
     // pass A: total candidates of the chunk
     uint32_t total = 0;
@@ -247,14 +293,23 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       if (slabBox(a, w, cA, cAe, bx)) run += boxCount(a, bx, lane);
       const bool last = cAe == w.cA1;
       if ((run >= per && emitted + 1 < nItems) || last) {
-        if (lane == 0) items[slot + emitted] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
+        if (lane == 0) {
+          items[slot + emitted] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
+          if (itemOff) {
+            const uint32_t blocks = (uint32_t)(((unsigned long long)run * nb + 63ull) / 64ull);
+            itemOff[slot + emitted] = make_uint2(blocks ? atomicAdd(blockTotal, blocks) : 0u, blocks);
+          }
+        }
         emitted++;
         run = 0;
         first = cAe + 1;
       }
     }
     // unused reserved slots (possible when the crossings come late): mark empty
-    for (uint32_t e = emitted + lane; e < nItems; e += 64) items[slot + e] = make_uint4(setBase, 0u, 1u, 0u);
+    for (uint32_t e = emitted + lane; e < nItems; e += 64) {
+      items[slot + e] = make_uint4(setBase, 0u, 1u, 0u);
+      if (itemOff) itemOff[slot + e] = make_uint2(0u, 0u);
+    }
   }
 }
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_upload_vpm_samples",
     "gvpm_upload_beams", "gvpm_upload_beams_dev", "gvpm_upload_planes", "gvpm_upload_planes_dev",
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
-    "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_download_accum",
+    "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_get_phase_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
     "gvpm_allreduce_accum",
 ]
@@ -66,6 +66,7 @@ def lib():
         L.gvpm_set_global_scale.argtypes = [vp, C.c_float]
         L.gvpm_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
         L.gvpm_get_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.gvpm_get_phase_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gvpm_download_accum.argtypes = [vp, vp]
         L.gvpm_download_accum_dev.argtypes = [vp, vp]
         L.gvpm_download_film.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -180,6 +181,11 @@ class Context:
     def kernel_time(self):
         ms, n = C.c_float(), C.c_uint32()
         self._check(lib().gvpm_get_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def phase_time(self, phase):
+        ms, n = C.c_float(), C.c_uint32()
+        self._check(lib().gvpm_get_phase_time(self._h, phase, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def download_accum(self):

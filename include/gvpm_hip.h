@@ -321,6 +321,9 @@ int gvpm_download_vpm_state(gvpm_context *h, float *scale_vol, float *n_vol);
 /* average duration in ms of the gather kernel launches since the last call,
  * measured with HIP events on the handle's stream, and their number          */
 int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches);
+/* the same for one phase of gvpm_gather: 0 = dominant kernel (as above; G-BRE: the evaluation
+ * kernel), 1 = G-BRE traversal kernel, 2 = build (photon grid, beam sort, planner)             */
+int gvpm_get_phase_time(gvpm_context *h, int phase, float *avg_ms, uint32_t *launches);
 
 /* ---- results --------------------------------------------------------------*/
 /* 27 floats per pixel (GVPM_ACCUM_FLOATS), width*height pixels               */

@@ -224,8 +224,7 @@ def test_error_behaviour(case):
         ctx.gather(0, 10)
     ctx.close()
     p = c.p.copy()
-    p.vol_technique = abi.GVPM_VOL_PLANE0D
-    p.use_shift_null = 0
+    p.vol_technique = abi.GVPM_BEAM_BEAM_3D_NAIVE  # SAssert(false) in the reference's BeamKernelRecord::eval
     ctx = hip.Context(p, device=0)
     ctx.upload_medium(c.m)
     ctx.upload_scene(*c.tris)
@@ -267,3 +266,27 @@ def test_full_size_properties():
     assert (wt >= 0).all() and (wt <= flux[:, :, None, :] * (1 + 1e-4) + 1e-12).all()
     # (5) border rule
     assert np.allclose(wt[H - 1, :, abi.GVPM_TOP], flux[H - 1], rtol=1e-4, atol=1e-12)
+
+
+def test_grid_bounds_carried_from_previous_photon_set():
+    """The grid of a step is sized by the previous step's photon bounds (one host sync per step):
+    photons outside it sit in the border cells and must still be found, bit for bit."""
+    c = cases.make_case("cbox", 32, 28, 20000, 3.0)
+    pos = c.ph.pos
+    small = np.nonzero((np.abs(pos[:, 0]) < 0.3) & (np.abs(pos[:, 1]) < 0.3) & (np.abs(pos[:, 2]) < 0.3))[0]
+    assert 200 < small.size < c.ph.n // 2
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_camera_beams(c.rays)
+    ctx.upload_photons(c.ph.subset(small))   # step 1: a small box in the middle -> small cached bounds
+    ctx.gather(1, c.nb)
+    ctx.reset()
+    ctx.upload_photons(c.ph)                 # step 2: the full set, most of it outside the cached bounds
+    ctx.gather(1, c.nb)
+    acc = ctx.download_accum()
+    st = ctx.stats()
+    ctx.close()
+    ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, 1, c.nb, 64, use_accel=False)
+    assert st["evaluations"] == cnt["evaluations"]
+    assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < TOL
