@@ -105,28 +105,50 @@ __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
   b2 = mk3(bb, sign + n.y * n.y * aa, -n.y);
 }
 
-// One evaluation: VolumeGradientBREQuery::operator() after the filters.
+// One evaluation = VolumeGradientBREQuery::operator() after the filters, in two phases so that
+// the expensive, divergent part runs on full waves:
+//   phase 1 (one lane per (photon, beam) pair): base contribution, then for each of the four
+//     shifted rays the null shift if it applies (cheap); a shift that needs the offset-path
+//     reconnection is only QUEUED in LDS as (photon, beam, shift, t', pdf, base contribution);
+//   phase 2 (one lane per queued shift, 64 at a time): the diffuse reconnection with its
+//     shadow ray, Jacobian and MIS weight.
+// At C2 ~70 % of the shifts are null shifts: running both branches on every lane of a mixed
+// wave cost ~1.5x the VALU work of this arrangement.
 //
 // Numerics: every quantity that the reference obtains by subtracting O(1) positions to get an
 // O(radius) vector (photon - ray point, shifted ray point - base ray point) is formed in fp64 and
 // then carried as a small fp32 vector; everything downstream of those differences (kernel chord
 // lengths sqrt(r^2 - d^2), pdfs, BSDF / phase / transmittance products, MIS weights) is fp32.
-template <int B, bool FULLVIS>
-__device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uint32_t pidx, uint32_t b,
-                                         uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
-  const PhotonCold ph = loadCold(a, pidx);
-  const uint32_t bits = ph.bits;
-  const f3 pos = ph.pos;
-  const RayReg base = loadRay(s, 0, b);
-  const uint32_t edge = s.edge[b];
-  const uint32_t pix = s.pix[b];
+constexpr int DQCAP = 320;  // diffuse-shift queue: < 64 left over + up to 4 * 64 new per step
+
+template <int B> struct EvalLds : RayTile<B> {
+  float acc[27][B];
+  uint2 qId[DQCAP];      // {photon, beam | shift << 8}
+  double qT[DQCAP];      // t'
+  float4 qC[DQCAP];      // {baseContrib * scale, pdfCam}
+};
+
+template <int B>
+__device__ __forceinline__ void borderRule(const GatherArgs &a, uint32_t pix, int i, float &w) {
+  // no reverse shift at the right and top borders, shift_volume_photon.cpp:843-846
   const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
+  if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
+}
+
+// phase 1; returns the number of shifts this lane queued (0..4) through qn, entries through e*
+template <int B>
+__device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t b,
+                                           uint32_t qBase, uint32_t &nNull, uint32_t &nFail, uint32_t &qMask,
+                                           double &tPrimeOut, float4 &qcOut) {
+  const PhotonFront ph = loadFront(a, pidx);
+  const RayReg base = loadRay(s, 0, b);
+  const uint32_t pix = s.pix[b];
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const float r = a.radius, r2 = r * r;
   const float eps = a.cfg.epsilon;
 
   // hit geometry (gvpm_accel.h:296-299): disk in fp64, the perpendicular offset as a small vector
-  const d3 pD = tod(pos), boD = tod(base.o), bdD = tod(base.d);
+  const d3 pD = tod(ph.pos), boD = tod(base.o), bdD = tod(base.d);
   const d3 wD = pD - boD;
   const double disk = dot(wD, bdD);
   const f3 perp = tof(wD - bdD * disk);
@@ -151,14 +173,16 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
   float dummy;
   mediumEval(a.med, (float)tPrime - eps, trT, dummy);
   const f3 photonIn = sigS * ph.flux;
-  const f3 baseContrib = trT * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * base.eye;
-  atomicAdd(&s.acc[0][b], baseContrib.x * scale);
-  atomicAdd(&s.acc[1][b], baseContrib.y * scale);
-  atomicAdd(&s.acc[2][b], baseContrib.z * scale);
+  const f3 bc = trT * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * base.eye * scale;  // scaled base contribution
+  atomicAdd(&s.acc[0][b], bc.x);
+  atomicAdd(&s.acc[1][b], bc.y);
+  atomicAdd(&s.acc[2][b], bc.z);
+  tPrimeOut = tPrime;
+  qcOut = make_float4(bc.x, bc.y, bc.z, pdfCam);
+  qMask = 0u;
 
-  const d3 basePt = boD + bdD * tPrime;  // baseRay(t')
-  const f3 rel = tof(pD - basePt);       // photon relative to the base ray point
   const float tPf = (float)tPrime;
+  const uint32_t st = GVPM_PF_SHIFT_TYPE(ph.bits);
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
     const RayReg sh = loadRay(s, 1 + i, b);
@@ -178,59 +202,98 @@ __device__ __forceinline__ void evaluate(const GatherArgs &a, TileLds<B> &s, uin
           w = 0.5f;
           if (a.cfg.use_mis) {
             if (pdfShiftPos == 0.f || pdfCam == 0.f) w = 1.f;
-            else w = 1.f / (1.f + sensorMIS(sh, base, edge) * pdfShiftPos / pdfCam);
+            else w = 1.f / (1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos / pdfCam);
           }
           alreadyShift = true;
           nNull++;
         }
       }
-      if (!alreadyShift && sh.len >= tPf) {
-        // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
-        f3 offRel = rel;
-        if (!use3D) {
-          f3 bs, bt, ns, nt;
-          coherentFrame(base.d, bs, bt);
-          coherentFrame(sh.d, ns, nt);
-          offRel = ns * dot(rel, bs) + nt * dot(rel, bt) + sh.d * dot(rel, base.d);
+      if (!alreadyShift && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
+        // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
+        if (st == 1u || st == 2u) {
+          qMask |= 1u << i;
+          continue;
         }
-        if (a.cfg.use_shift_null) {
-          const f3 dS = tof(zP - basePt);  // shiftRay(t') - baseRay(t')
-          const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
-          if (dot(bo, bo) < r2) {
-            const float cosD2 = -2.f * dot(dS, offRel) / dot(dS, dS);
-            offRel = offRel + dS * cosD2;
-          }
-        }
-        float pdfShiftPos = 1.f;
-        if (use3D) {
-          const f3 op = offRel - sh.d * dot(offRel, sh.d);
-          const float deltaO = sqrtf(fmaxf(0.f, r2 - dot(op, op)));
-          pdfShiftPos = 1.f / fmaxf(2.f * deltaO, 0.0001f);
-        }
-        if (a.cfg.debug_shift != GVPM_SHIFT_NULL) {
-          // shiftPhoton dispatch, shift_volume_photon.cpp:49-117
-          const uint32_t st = GVPM_PF_SHIFT_TYPE(bits);
-          bool ok = false;
-          if (st == 1u || st == 2u) {
-            const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
-            w = shiftDiffuse<FULLVIS>(a, ph, bits, dProjU, sh, base, edge, trT, pdfCam, pdfShiftPos, sflux, ok);
-          }
-          if (ok) nDiff++; else nFail++;
-        }
+        nFail++;
       }
     }
-    // no reverse shift at the right and top borders, shift_volume_photon.cpp:843-846
-    if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
-    const float ws = w * scale;
+    borderRule<B>(a, pix, i, w);
     if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+      const float ws = w * scale;
       atomicAdd(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
       atomicAdd(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
       atomicAdd(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
     }
-    atomicAdd(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
-    atomicAdd(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
-    atomicAdd(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
+    atomicAdd(&s.acc[15 + 3 * i + 0][b], bc.x * w);
+    atomicAdd(&s.acc[15 + 3 * i + 1][b], bc.y * w);
+    atomicAdd(&s.acc[15 + 3 * i + 2][b], bc.z * w);
   }
+}
+
+// phase 2: one queued reconnection shift (shiftPhotonDiffuse through getShiftPos)
+template <int B, bool FULLVIS>
+__device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t q, uint32_t &nDiff,
+                                           uint32_t &nFail) {
+  const uint2 id = s.qId[q];
+  const double tPrime = s.qT[q];
+  const float4 qc = s.qC[q];
+  const uint32_t pidx = id.x, b = id.y & 0xFFu;
+  const int i = (int)(id.y >> 8);
+  const PhotonCold ph = loadCold(a, pidx);
+  const RayReg base = loadRay(s, 0, b);
+  const RayReg sh = loadRay(s, 1 + i, b);
+  const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
+  const float r = a.radius, r2 = r * r;
+  const float eps = a.cfg.epsilon;
+  const float pdfCam = qc.w;
+  const float rr = a.cfg.path_set ? 2.f : 1.f;
+  const float kernelVol = use3D ? (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r : 3.14159265358979323846f * r2;
+  const float scale = rr / (kernelVol * pdfCam);
+  f3 trT;
+  float dummy;
+  mediumEval(a.med, (float)tPrime - eps, trT, dummy);
+
+  const d3 pD = tod(ph.pos);
+  const d3 basePt = tod(base.o) + tod(base.d) * tPrime;  // baseRay(t')
+  const f3 rel = tof(pD - basePt);                       // photon relative to the base ray point
+  const d3 zP = tod(sh.o) + tod(sh.d) * tPrime;          // shiftRay(t')
+  // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
+  f3 offRel = rel;
+  if (!use3D) {
+    f3 bs, bt, ns, nt;
+    coherentFrame(base.d, bs, bt);
+    coherentFrame(sh.d, ns, nt);
+    offRel = ns * dot(rel, bs) + nt * dot(rel, bt) + sh.d * dot(rel, base.d);
+  }
+  if (a.cfg.use_shift_null) {
+    const f3 dS = tof(zP - basePt);  // shiftRay(t') - baseRay(t')
+    const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
+    if (dot(bo, bo) < r2) {
+      const float cosD2 = -2.f * dot(dS, offRel) / dot(dS, dS);
+      offRel = offRel + dS * cosD2;
+    }
+  }
+  float pdfShiftPos = 1.f;
+  if (use3D) {
+    const f3 op = offRel - sh.d * dot(offRel, sh.d);
+    const float deltaO = sqrtf(fmaxf(0.f, r2 - dot(op, op)));
+    pdfShiftPos = 1.f / fmaxf(2.f * deltaO, 0.0001f);
+  }
+  bool ok = false;
+  f3 sflux;
+  const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
+  float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok);
+  if (ok) nDiff++; else nFail++;
+  borderRule<B>(a, s.pix[b], i, w);
+  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+    const float ws = w * scale;
+    atomicAdd(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
+    atomicAdd(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
+    atomicAdd(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+  }
+  atomicAdd(&s.acc[15 + 3 * i + 0][b], qc.x * w);
+  atomicAdd(&s.acc[15 + 3 * i + 1][b], qc.y * w);
+  atomicAdd(&s.acc[15 + 3 * i + 2][b], qc.z * w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -400,10 +463,10 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
                                                           const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
                                                           const uint2 *__restrict__ pairs,
                                                           const uint32_t *__restrict__ pairCnt) {
-  __shared__ TileLds<B> s;
+  __shared__ EvalLds<B> s;
   const int lane = threadIdx.x;
   const uint32_t nItems = *itemCount;
-
+  const bool skip = (a.cfg.reserved[0] & 1) != 0;  // development switch: count, do not evaluate
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
 
   for (;;) {
@@ -421,13 +484,39 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
     loadTileRays<B>(a, s, setBase, nb, lane);
     for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
     __syncthreads();
+    uint32_t qHead = 0, qCount = 0;  // wave-uniform ring state of the reconnection queue
     for (uint32_t i = 0; i < cnt; i += 64) {
+      uint32_t qMask = 0;
+      double tP = 0.0;
+      float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint2 e = make_uint2(0u, 0u);
       if (i + lane < cnt) {
-        const uint2 e = in[i + lane];
-        if (!(a.cfg.reserved[0] & 1)) evaluate<B, FULLVIS>(a, s, e.x, e.y, nNull, nDiff, nFail);
+        e = in[i + lane];
+        if (!skip) evalPhase1<B>(a, s, e.x, e.y, 0u, nNull, nFail, qMask, tP, qc);
         nEval++;
       }
+      // append this step's reconnection shifts: wave prefix sum of the per-lane counts
+      const uint32_t mine = __popc(qMask);
+      const uint32_t incl = wave_scan_incl(mine, lane);
+      uint32_t slot = qHead + qCount + (incl - mine);
+      for (uint32_t m = qMask; m; m &= m - 1u) {
+        const uint32_t sh = (uint32_t)__ffs(m) - 1u;
+        const uint32_t q = slot % DQCAP;
+        s.qId[q] = make_uint2(e.x, e.y | (sh << 8));
+        s.qT[q] = tP;
+        s.qC[q] = qc;
+        slot++;
+      }
+      qCount += __shfl(incl, 63, 64);
+      __syncthreads();
+      while (qCount >= 64u) {
+        evalPhase2<B, FULLVIS>(a, s, (qHead + lane) % DQCAP, nDiff, nFail);
+        qHead = (qHead + 64u) % DQCAP;
+        qCount -= 64u;
+      }
+      __syncthreads();
     }
+    if ((uint32_t)lane < qCount) evalPhase2<B, FULLVIS>(a, s, (qHead + lane) % DQCAP, nDiff, nFail);
     __syncthreads();
     // ---- write out: 27 partial sums per beam set into the iteration buffer ----
     for (int idx = lane; idx < 27 * B; idx += 64) {

@@ -77,7 +77,7 @@ template <typename T> struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = n + n / 8 + 64;
+    size_t want = n + n / 2 + 64;  // generous: a regrowth is a device-wide sync
     hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
     if (e == hipSuccess) cap = want;
     return e;

@@ -133,6 +133,21 @@ struct PhotonCold {
   uint32_t nl0, nl1, nl2;  // up to 12 occluder indices near the parent (0xFF = none); top byte of nl0 0xFE: overflow
 };
 
+// the front of the record: all the base contribution and the null shifts need
+struct PhotonFront {
+  f3 pos, wi, flux;
+  uint32_t bits;
+};
+__device__ __forceinline__ PhotonFront loadFront(const GatherArgs &a, uint32_t idx) {
+  PhotonFront c;
+  const float4 *rec = a.cold + (size_t)idx * GVPM_REC_QUADS;
+  const float4 c0 = rec[0], c1 = rec[1], c2 = rec[2];
+  c.pos = mk3(c0.x, c0.y, c0.z); c.bits = __float_as_uint(c0.w);
+  c.wi = mk3(c1.x, c1.y, c1.z);
+  c.flux = mk3(c2.x, c2.y, c2.z);
+  return c;
+}
+
 // the photon's 128-byte record (one cache line)
 __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx) {
   PhotonCold c;

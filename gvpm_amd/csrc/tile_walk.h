@@ -14,19 +14,23 @@ constexpr int STAGE = 256;
 constexpr int QCAP = 128;
 constexpr int PLAN_MAX_ITEMS = 256;  // per tile chunk
 
-template <int B> struct TileLds {
+// the camera-beam sets of a tile: base + 4 shifted rays each
+template <int B> struct RayTile {
   float4 ray4[5][3][B];  // {o, len (<0: invalid)} {d, pdf} {eye, jacobian}
   float gop[5][B];
-  float acc[27][B];
-  float4 stage[STAGE];
-  uint32_t stageIdx[STAGE];
-  uint2 queue[QCAP];
   float rnd[B];
   uint32_t pix[B];
   uint32_t edge[B];
 };
 
-template <int B> __device__ __forceinline__ RayReg loadRay(const TileLds<B> &s, int k, int b) {
+template <int B> struct TileLds : RayTile<B> {
+  float acc[27][B];
+  float4 stage[STAGE];
+  uint32_t stageIdx[STAGE];
+  uint2 queue[QCAP];
+};
+
+template <int B> __device__ __forceinline__ RayReg loadRay(const RayTile<B> &s, int k, int b) {
   RayReg r;
   const float4 q0 = s.ray4[k][0][b], q1 = s.ray4[k][1][b], q2 = s.ray4[k][2][b];
   r.o = mk3(q0.x, q0.y, q0.z);
@@ -56,7 +60,7 @@ struct TileWalk {
 };
 
 template <int B>
-__device__ __forceinline__ void loadTileRays(const GatherArgs &a, TileLds<B> &s, uint32_t setBase, uint32_t nb,
+__device__ __forceinline__ void loadTileRays(const GatherArgs &a, RayTile<B> &s, uint32_t setBase, uint32_t nb,
                                              int lane) {
   for (int idx = lane; idx < B * 20; idx += 64) {
     const int b = idx / 20, k = (idx % 20) / 4, q = idx % 4;
@@ -125,7 +129,7 @@ __device__ __forceinline__ RayReg loadBaseDirect(const GatherArgs &a, uint32_t s
 __device__ __forceinline__ void tileSetupFrom(const GatherArgs &a, const RayReg &base, bool valid, TileWalk &w);
 
 template <int B>
-__device__ __forceinline__ void tileSetup(const GatherArgs &a, const TileLds<B> &s, uint32_t nb, int lane,
+__device__ __forceinline__ void tileSetup(const GatherArgs &a, const RayTile<B> &s, uint32_t nb, int lane,
                                           TileWalk &w) {
   const int b = lane % B;
   const RayReg base = loadRay(s, 0, b);
