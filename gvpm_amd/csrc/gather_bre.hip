@@ -96,10 +96,24 @@ __device__ __forceinline__ bool resample3D(const HitGeom &g, double radius, doub
   return !(tPrime < mint || tPrime > edgeLen);
 }
 
+// The reference's hit decision for one (photon, beam) candidate, in its own operation order.  Rare
+// (only candidates inside the fp32 error band get here) and register hungry (fp64 divisions and
+// square root), hence not inlined into the traversal loop.
+static __device__ __noinline__ bool exactHit(f3 p, f3 o, f3 d, float len, float r, float rnd, float eps, bool use3D) {
+  const double mintD = (double)eps, maxtD = (double)len - (double)eps;
+  const d3 rcpD = mkd(1.0 / (double)d.x, 1.0 / (double)d.y, 1.0 / (double)d.z);
+  const HitGeom g = hitGeom(p, o, d);
+  if (!(g.disk > mintD && g.distSqr < (double)r * (double)r && ownBoxHit(p, o, d, rcpD, mintD, maxtD, (double)r)))
+    return false;
+  if (!use3D) return true;
+  double tp, dt;
+  return resample3D(g, (double)r, (double)rnd, mintD, (double)len, tp, dt);
+}
+
 // coordinateSystemCoherent, src/libcore/util.cpp:592-599 (its intermediates are float)
 __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
   const float sign = copysignf(1.0f, n.z);
-  const float aa = -1.0f / (sign + n.z);
+  const float aa = -frcp(sign + n.z);
   const float bb = n.x * n.y * aa;
   b1 = mk3(1.0f + sign * n.x * n.x * aa, sign * bb, -sign * n.x);
   b2 = mk3(bb, sign + n.y * n.y * aa, -n.y);
@@ -158,13 +172,13 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
   float pdfCam = 1.f;
   if (use3D) {
     // shift_volume_photon.cpp:707-726
-    const float deltaT = sqrtf(fmaxf(0.f, r2 - distSqr));
+    const float deltaT = fsqrt(fmaxf(0.f, r2 - distSqr));
     tPrime = (disk - (double)deltaT) + (double)(2.f * deltaT * s.rnd[b]);
     kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r;
-    pdfCam = 1.f / fmaxf(deltaT * 2.f, 0.0001f);
+    pdfCam = frcp(fmaxf(deltaT * 2.f, 0.0001f));
   }
   const float rr = a.cfg.path_set ? 2.f : 1.f;
-  const float scale = rr / (kernelVol * pdfCam);
+  const float scale = rr * frcp(kernelVol * pdfCam);
 
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
   // base contribution, shift_volume_photon.cpp:735-751; the base and the four shifted rays
@@ -196,13 +210,13 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
         if (dot(y, y) < r2 && tPf < sh.len) {
           // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
           const f3 yp = y - sh.d * dot(y, sh.d);
-          const float deltaS = sqrtf(fmaxf(0.f, r2 - dot(yp, yp)));
-          const float pdfShiftPos = 1.f / fmaxf(2.f * deltaS, 0.0001f);
+          const float deltaS = fsqrt(fmaxf(0.f, r2 - dot(yp, yp)));
+          const float pdfShiftPos = frcp(fmaxf(2.f * deltaS, 0.0001f));
           sflux = trT * (photonIn * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
           w = 0.5f;
           if (a.cfg.use_mis) {
             if (pdfShiftPos == 0.f || pdfCam == 0.f) w = 1.f;
-            else w = 1.f / (1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos / pdfCam);
+            else w = frcp(1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos * frcp(pdfCam));
           }
           alreadyShift = true;
           nNull++;
@@ -248,7 +262,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   const float pdfCam = qc.w;
   const float rr = a.cfg.path_set ? 2.f : 1.f;
   const float kernelVol = use3D ? (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r : 3.14159265358979323846f * r2;
-  const float scale = rr / (kernelVol * pdfCam);
+  const float scale = rr * frcp(kernelVol * pdfCam);
   f3 trT;
   float dummy;
   mediumEval(a.med, (float)tPrime - eps, trT, dummy);
@@ -269,15 +283,15 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
     const f3 dS = tof(zP - basePt);  // shiftRay(t') - baseRay(t')
     const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
     if (dot(bo, bo) < r2) {
-      const float cosD2 = -2.f * dot(dS, offRel) / dot(dS, dS);
+      const float cosD2 = -2.f * dot(dS, offRel) * frcp(dot(dS, dS));
       offRel = offRel + dS * cosD2;
     }
   }
   float pdfShiftPos = 1.f;
   if (use3D) {
     const f3 op = offRel - sh.d * dot(offRel, sh.d);
-    const float deltaO = sqrtf(fmaxf(0.f, r2 - dot(op, op)));
-    pdfShiftPos = 1.f / fmaxf(2.f * deltaO, 0.0001f);
+    const float deltaO = fsqrt(fmaxf(0.f, r2 - dot(op, op)));
+    pdfShiftPos = frcp(fmaxf(2.f * deltaO, 0.0001f));
   }
   bool ok = false;
   f3 sflux;
@@ -413,17 +427,7 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
                     hit = true;
                   } else {
                     // ... otherwise the reference predicate itself, fp64, uncontracted
-                    const double mintD = (double)eps, maxtD = (double)base.len - (double)eps;
-                    const d3 rcpD = mkd(1.0 / (double)base.d.x, 1.0 / (double)base.d.y, 1.0 / (double)base.d.z);
-                    const HitGeom g = hitGeom(p, base.o, base.d);
-                    if (g.disk > mintD && g.distSqr < (double)r * (double)r &&
-                        ownBoxHit(p, base.o, base.d, rcpD, mintD, maxtD, (double)r)) {
-                      hit = true;
-                      if (use3D) {
-                        double tp, dt;
-                        hit = resample3D(g, (double)r, (double)bi.rnd, mintD, (double)base.len, tp, dt);
-                      }
-                    }
+                    hit = exactHit(p, base.o, base.d, base.len, r, bi.rnd, eps, use3D);
                   }
                 }
               }

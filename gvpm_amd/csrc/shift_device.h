@@ -21,7 +21,7 @@ struct RayReg {
 __device__ __forceinline__ float phaseEval(float g, f3 wi, f3 wo) {
   if (g == 0.f) return INV_FOURPI_F;
   const float temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
-  return INV_FOURPI_F * (1.f - g * g) / (temp * sqrtf(temp));
+  return INV_FOURPI_F * (1.f - g * g) * frcp(temp * fsqrt(temp));
 }
 
 // HomogeneousMedium::eval over a distance (balance strategy)
@@ -39,7 +39,7 @@ __device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mi
   const f3 pvec = cross(d, e2);
   const float det = dot(e1, pvec);
   if (det == 0.f) return false;
-  const float inv = 1.0f / det;
+  const float inv = frcp(det);
   const f3 tvec = o - v0;
   const float u = dot(tvec, pvec) * inv;
   if (u < 0.f || u > 1.f) return false;
@@ -118,10 +118,10 @@ __device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, uint32_t nl0,
 // GatherPoint::sensorMIS, gvpm_struct.h:608-631 (sDist == bDist for BRE: same t')
 __device__ __forceinline__ float sensorMIS(const RayReg &s, const RayReg &b, uint32_t edge) {
   float jacobian = s.jac;
-  float ratio = s.pdf / b.pdf;
+  float ratio = fdiv(s.pdf, b.pdf);
   if (edge != 1u) {
-    jacobian *= s.gop / b.gop;
-    ratio *= b.gop / s.gop;
+    jacobian *= fdiv(s.gop, b.gop);
+    ratio *= fdiv(b.gop, s.gop);
   }
   return ratio * jacobian;
 }
@@ -176,14 +176,15 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   ok = false;
   shiftedFlux = mk3(0.f);
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
-  const float lProj = sqrtf(dot(dProjU, dProjU));
-  const f3 dProj = dProjU * (1.f / lProj);
+  const float l2Proj = dot(dProjU, dProjU);
+  const float lProj = fsqrt(l2Proj);
+  const f3 dProj = dProjU * frcp(lProj);
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
   if (shadowBlocked<FULLVIS>(a, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax)) return 1.f;
   if (ptype != GVPM_PARENT_MEDIUM) {
-    const float signDot = dot(ph.parentN, dProj) / dot(ph.parentN, -ph.wi);
-    if (signDot < 0.f) return 1.f;
+    // sign of dot(n, dProj) / dot(n, -wi)
+    if (dot(ph.parentN, dProj) * dot(ph.parentN, -ph.wi) < 0.f) return 1.f;
   }
   f3 thr;
   float pdfValue;
@@ -202,17 +203,17 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
     thr = mk3(INV_PI_F * dp);
     pdfValue = INV_PI_F * dp;
   }
-  const float gop = 1.f / (lProj * lProj);
+  const float gop = frcp(lProj * lProj);
   float sPdf = pdfValue * gop;
   thr = thr * gop;
   if (ph.parentPdf == 0.f) return 1.f;
-  thr = thr * (ph.parentRR / ph.parentPdf);
+  thr = thr * fdiv(ph.parentRR, ph.parentPdf);
   if (GVPM_PF_EDGE_IN_MEDIUM(bits)) {
     f3 tr;
     float pdfSuccess;
     mediumEval(a.med, lProj, tr, pdfSuccess);
     sPdf *= pdfSuccess;
-    thr = thr * tr * (1.f / ph.edgePdf);
+    thr = thr * tr * frcp(ph.edgePdf);
   }
   if (sPdf == 0.f) return 1.f;
   const f3 photonWeight = ph.prefixW * thr;
@@ -228,8 +229,8 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
       ok = false;
       return 1.f;
     }
-    const float v = sensorMIS(sh, base, edge) * (offsetPdf / basePdf);
-    w = a.cfg.power_heuristic ? 1.f / (1.f + v * v) : 1.f / (1.f + v);
+    const float v = sensorMIS(sh, base, edge) * fdiv(offsetPdf, basePdf);
+    w = a.cfg.power_heuristic ? frcp(1.f + v * v) : frcp(1.f + v);
   }
   return w;
 }

@@ -276,19 +276,7 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
     TileWalk w;
     tileSetupFrom(a, base, base.valid, w);
     if (!w.any) continue;
-    // pass A: total candidates of the chunk
-    uint32_t total = 0;
-    for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
-      CellBox bx;
-      if (slabBox(a, w, cA, min(cA + w.K - 1, w.cA1), bx)) total += boxCount(a, bx, lane);
-    }
-    if (total == 0) continue;
-    const uint32_t nItems = min((uint32_t)PLAN_MAX_ITEMS, (total + target - 1) / target);
-    const uint32_t per = (total + nItems - 1) / nItems;
-    uint32_t slot = 0;
-    if (lane == 0) slot = atomicAdd(itemCount, nItems);
-    slot = __shfl(slot, 0, 64);
-    // pass B: emit items at the crossings of k * per
+    // one pass: cut an item whenever ~target photons have been staged (at most PLAN_MAX_ITEMS per chunk)
     uint32_t run = 0, emitted = 0;
     int first = w.cA0;
     for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
@@ -296,23 +284,19 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       CellBox bx;
       if (slabBox(a, w, cA, cAe, bx)) run += boxCount(a, bx, lane);
       const bool last = cAe == w.cA1;
-      if ((run >= per && emitted + 1 < nItems) || last) {
+      if ((run >= target && emitted + 1 < (uint32_t)PLAN_MAX_ITEMS) || (last && run > 0)) {
         if (lane == 0) {
-          items[slot + emitted] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
+          const uint32_t slot = atomicAdd(itemCount, 1u);
+          items[slot] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
           if (itemOff) {
             const uint32_t blocks = (uint32_t)(((unsigned long long)run * nb + 63ull) / 64ull);
-            itemOff[slot + emitted] = make_uint2(blocks ? atomicAdd(blockTotal, blocks) : 0u, blocks);
+            itemOff[slot] = make_uint2(atomicAdd(blockTotal, blocks), blocks);
           }
         }
         emitted++;
         run = 0;
         first = cAe + 1;
       }
-    }
-    // unused reserved slots (possible when the crossings come late): mark empty
-    for (uint32_t e = emitted + lane; e < nItems; e += 64) {
-      items[slot + e] = make_uint4(setBase, 0u, 1u, 0u);
-      if (itemOff) itemOff[slot + e] = make_uint2(0u, 0u);
     }
   }
 }

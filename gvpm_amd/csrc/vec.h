@@ -48,6 +48,13 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// single-instruction reciprocal / square root (1 ulp; the parity bar is set against the fp64 oracle, so
+// the ~10-instruction IEEE division and the denormal-safe sqrt expansions buy nothing here)
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 // inclusive prefix sum over the wave
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
 #pragma unroll
