@@ -123,88 +123,115 @@ __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
 // the expensive, divergent part runs on full waves:
 //   phase 1 (one lane per (photon, beam) pair): base contribution, then for each of the four
 //     shifted rays the null shift if it applies (cheap); a shift that needs the offset-path
-//     reconnection is only QUEUED in LDS as (photon, beam, shift, t', pdf, base contribution);
-//   phase 2 (one lane per queued shift, 64 at a time): the diffuse reconnection with its
-//     shadow ray, Jacobian and MIS weight.
+//     reconnection is only QUEUED (per lane, in LDS) as (photon, beam, shift, t', pdf);
+//   phase 2 (one lane per queued shift): the diffuse reconnection with its shadow ray, Jacobian
+//     and MIS weight; it runs whenever most lanes have an entry pending.
 // At C2 ~70 % of the shifts are null shifts: running both branches on every lane of a mixed
 // wave cost ~1.5x the VALU work of this arrangement.
+//
+// Accumulation: LDS float atomics (ds_add_f32) retire about one lane per clock on CDNA4 -- 24 of
+// them per evaluation were half of this kernel's time.  The traversal therefore writes one photon
+// list PER BEAM, the evaluation wave cuts the concatenated lists of an item into 64 equal chunks
+// (perfect balance) and every lane sums its 27 outputs in REGISTERS; a lane touches the LDS
+// accumulators only when its chunk crosses into the next beam and at the end of the item.
 //
 // Numerics: every quantity that the reference obtains by subtracting O(1) positions to get an
 // O(radius) vector (photon - ray point, shifted ray point - base ray point) is formed in fp64 and
 // then carried as a small fp32 vector; everything downstream of those differences (kernel chord
 // lengths sqrt(r^2 - d^2), pdfs, BSDF / phase / transmittance products, MIS weights) is fp32.
-constexpr int DQCAP = 320;  // diffuse-shift queue: < 64 left over + up to 4 * 64 new per step
+constexpr int QD = 8;  // per-lane reconnection queue depth (a step adds at most 4)
 
 template <int B> struct EvalLds : RayTile<B> {
   float acc[27][B];
-  uint2 qId[DQCAP];      // {photon, beam | shift << 8}
-  double qT[DQCAP];      // t'
-  float4 qC[DQCAP];      // {baseContrib * scale, pdfCam}
+  uint32_t boff[B + 1];      // prefix offsets of the item's per-beam lists
+  uint32_t qPh[QD][64];      // per-lane queues, [slot][lane]: photon
+  uint32_t qMeta[QD][64];    //   beam | shift << 8
+  float qPdf[QD][64];        //   pdfCam
+  double qT[QD][64];         //   t'
 };
 
-template <int B>
+// the 27 per-beam outputs of one lane, in registers
+struct Acc27 {
+  float v[27];
+};
+
 __device__ __forceinline__ void borderRule(const GatherArgs &a, uint32_t pix, int i, float &w) {
   // no reverse shift at the right and top borders, shift_volume_photon.cpp:843-846
   const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
   if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
 }
 
-// phase 1; returns the number of shifts this lane queued (0..4) through qn, entries through e*
+struct BaseTerms {
+  double tPrime;
+  float pdfCam, scale, tr;  // tr: transmittance over [Epsilon, t'] (equal in the three channels)
+  f3 bc;                    // base contribution * scale
+};
+
+// hit geometry + base contribution of a (photon, beam) pair, shift_volume_photon.cpp:701-751
 template <int B>
-__device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t b,
-                                           uint32_t qBase, uint32_t &nNull, uint32_t &nFail, uint32_t &qMask,
-                                           double &tPrimeOut, float4 &qcOut) {
-  const PhotonFront ph = loadFront(a, pidx);
-  const RayReg base = loadRay(s, 0, b);
-  const uint32_t pix = s.pix[b];
+__device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const EvalLds<B> &s, f3 pos, f3 wi, f3 flux,
+                                               const RayReg &base, uint32_t b) {
+  BaseTerms t;
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const float r = a.radius, r2 = r * r;
-  const float eps = a.cfg.epsilon;
-
-  // hit geometry (gvpm_accel.h:296-299): disk in fp64, the perpendicular offset as a small vector
-  const d3 pD = tod(ph.pos), boD = tod(base.o), bdD = tod(base.d);
-  const d3 wD = pD - boD;
+  // gvpm_accel.h:296-299: disk in fp64, the perpendicular offset as a small vector
+  const d3 wD = tod(pos) - tod(base.o), bdD = tod(base.d);
   const double disk = dot(wD, bdD);
   const f3 perp = tof(wD - bdD * disk);
   const float distSqr = dot(perp, perp);
-  double tPrime = disk;
+  t.tPrime = disk;
   float kernelVol = 3.14159265358979323846f * r2;
-  float pdfCam = 1.f;
+  t.pdfCam = 1.f;
   if (use3D) {
     // shift_volume_photon.cpp:707-726
     const float deltaT = fsqrt(fmaxf(0.f, r2 - distSqr));
-    tPrime = (disk - (double)deltaT) + (double)(2.f * deltaT * s.rnd[b]);
+    t.tPrime = (disk - (double)deltaT) + (double)(2.f * deltaT * s.rnd[b]);
     kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r;
-    pdfCam = frcp(fmaxf(deltaT * 2.f, 0.0001f));
+    t.pdfCam = frcp(fmaxf(deltaT * 2.f, 0.0001f));
   }
   const float rr = a.cfg.path_set ? 2.f : 1.f;
-  const float scale = rr * frcp(kernelVol * pdfCam);
-
-  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
-  // base contribution, shift_volume_photon.cpp:735-751; the base and the four shifted rays
-  // all carry mint = Epsilon and maxt = t' (:769-770), hence one transmittance
+  t.scale = rr * frcp(kernelVol * t.pdfCam);
+  // the base and the four shifted rays all carry mint = Epsilon and maxt = t' (:769-770): one transmittance
   f3 trT;
   float dummy;
-  mediumEval(a.med, (float)tPrime - eps, trT, dummy);
-  const f3 photonIn = sigS * ph.flux;
-  const f3 bc = trT * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * base.eye * scale;  // scaled base contribution
-  atomicAdd(&s.acc[0][b], bc.x);
-  atomicAdd(&s.acc[1][b], bc.y);
-  atomicAdd(&s.acc[2][b], bc.z);
-  tPrimeOut = tPrime;
-  qcOut = make_float4(bc.x, bc.y, bc.z, pdfCam);
+  mediumEval(a.med, (float)t.tPrime - a.cfg.epsilon, trT, dummy);
+  t.tr = trT.x;
+  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  t.bc = (sigS * flux) * (t.tr * phaseEval(a.med.g, wi, -base.d) * t.scale) * base.eye;
+  return t;
+}
+
+// phase 1: base contribution + the four shift attempts of one pair; reconnections are returned in qMask
+template <int B>
+__device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t b, Acc27 &acc,
+                                           uint32_t &nNull, uint32_t &nFail, uint32_t &qMask, double &tPrimeOut,
+                                           float &pdfCamOut) {
+  const PhotonFront ph = loadFront(a, pidx);
+  const RayReg base = loadRay(s, 0, b);
+  const uint32_t pix = s.pix[b];
+  const float r2 = a.radius * a.radius;
+  const BaseTerms bt = baseTerms<B>(a, s, ph.pos, ph.wi, ph.flux, base, b);
+  const f3 bc = bt.bc;
+  acc.v[0] += bc.x;
+  acc.v[1] += bc.y;
+  acc.v[2] += bc.z;
+  tPrimeOut = bt.tPrime;
+  pdfCamOut = bt.pdfCam;
   qMask = 0u;
 
-  const float tPf = (float)tPrime;
+  const d3 pD = tod(ph.pos);
+  const f3 photonIn = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]) * ph.flux;
+  const float tPf = (float)bt.tPrime;
   const uint32_t st = GVPM_PF_SHIFT_TYPE(ph.bits);
-#pragma unroll 1
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
     const RayReg sh = loadRay(s, 1 + i, b);
     float w = 1.f;
     f3 sflux = mk3(0.f);
+    bool queued = false;
     if (sh.valid) {
-      const d3 zP = tod(sh.o) + tod(sh.d) * tPrime;  // shiftRay(t')
-      const f3 y = tof(pD - zP);                     // photon relative to the shifted ray point
+      const d3 zP = tod(sh.o) + tod(sh.d) * bt.tPrime;  // shiftRay(t')
+      const f3 y = tof(pD - zP);                        // photon relative to the shifted ray point
       bool alreadyShift = false;
       if (a.cfg.use_shift_null) {
         if (dot(y, y) < r2 && tPf < sh.len) {
@@ -212,11 +239,11 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
           const f3 yp = y - sh.d * dot(y, sh.d);
           const float deltaS = fsqrt(fmaxf(0.f, r2 - dot(yp, yp)));
           const float pdfShiftPos = frcp(fmaxf(2.f * deltaS, 0.0001f));
-          sflux = trT * (photonIn * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
+          sflux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
           w = 0.5f;
           if (a.cfg.use_mis) {
-            if (pdfShiftPos == 0.f || pdfCam == 0.f) w = 1.f;
-            else w = frcp(1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos * frcp(pdfCam));
+            if (pdfShiftPos == 0.f || bt.pdfCam == 0.f) w = 1.f;
+            else w = frcp(1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos * frcp(bt.pdfCam));
           }
           alreadyShift = true;
           nNull++;
@@ -226,46 +253,46 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
         // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
         if (st == 1u || st == 2u) {
           qMask |= 1u << i;
-          continue;
+          queued = true;
+        } else {
+          nFail++;
         }
-        nFail++;
       }
     }
-    borderRule<B>(a, pix, i, w);
-    if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-      const float ws = w * scale;
-      atomicAdd(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
-      atomicAdd(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
-      atomicAdd(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+    if (!queued) {
+      borderRule(a, pix, i, w);
+      const float ws = w * bt.scale;
+      acc.v[3 + 3 * i + 0] += sflux.x * ws;
+      acc.v[3 + 3 * i + 1] += sflux.y * ws;
+      acc.v[3 + 3 * i + 2] += sflux.z * ws;
+      acc.v[15 + 3 * i + 0] += bc.x * w;
+      acc.v[15 + 3 * i + 1] += bc.y * w;
+      acc.v[15 + 3 * i + 2] += bc.z * w;
     }
-    atomicAdd(&s.acc[15 + 3 * i + 0][b], bc.x * w);
-    atomicAdd(&s.acc[15 + 3 * i + 1][b], bc.y * w);
-    atomicAdd(&s.acc[15 + 3 * i + 2][b], bc.z * w);
   }
 }
 
-// phase 2: one queued reconnection shift (shiftPhotonDiffuse through getShiftPos)
+// phase 2: one queued reconnection shift (shiftPhotonDiffuse through getShiftPos); the result goes to
+// the lane's registers when it belongs to the lane's current beam, else straight to the LDS accumulators
 template <int B, bool FULLVIS>
-__device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t q, uint32_t &nDiff,
+__device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t meta,
+                                           double tPrime, float pdfCam, uint32_t curBeam, Acc27 &acc, uint32_t &nDiff,
                                            uint32_t &nFail) {
-  const uint2 id = s.qId[q];
-  const double tPrime = s.qT[q];
-  const float4 qc = s.qC[q];
-  const uint32_t pidx = id.x, b = id.y & 0xFFu;
-  const int i = (int)(id.y >> 8);
+  const uint32_t b = meta & 0xFFu;
+  const int i = (int)(meta >> 8);
   const PhotonCold ph = loadCold(a, pidx);
   const RayReg base = loadRay(s, 0, b);
   const RayReg sh = loadRay(s, 1 + i, b);
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const float r = a.radius, r2 = r * r;
-  const float eps = a.cfg.epsilon;
-  const float pdfCam = qc.w;
   const float rr = a.cfg.path_set ? 2.f : 1.f;
   const float kernelVol = use3D ? (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r : 3.14159265358979323846f * r2;
   const float scale = rr * frcp(kernelVol * pdfCam);
   f3 trT;
   float dummy;
-  mediumEval(a.med, (float)tPrime - eps, trT, dummy);
+  mediumEval(a.med, (float)tPrime - a.cfg.epsilon, trT, dummy);
+  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  const f3 bc = (sigS * ph.flux) * (trT.x * phaseEval(a.med.g, ph.wi, -base.d) * scale) * base.eye;
 
   const d3 pD = tod(ph.pos);
   const d3 basePt = tod(base.o) + tod(base.d) * tPrime;  // baseRay(t')
@@ -298,16 +325,37 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
   float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok);
   if (ok) nDiff++; else nFail++;
-  borderRule<B>(a, s.pix[b], i, w);
-  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-    const float ws = w * scale;
-    atomicAdd(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
-    atomicAdd(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
-    atomicAdd(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+  borderRule(a, s.pix[b], i, w);
+  const float ws = w * scale;
+  const f3 sf = sflux * ws, wb = bc * w;
+  if (b == curBeam) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const float m = ii == i ? 1.f : 0.f;
+      acc.v[3 + 3 * ii + 0] += m * sf.x;
+      acc.v[3 + 3 * ii + 1] += m * sf.y;
+      acc.v[3 + 3 * ii + 2] += m * sf.z;
+      acc.v[15 + 3 * ii + 0] += m * wb.x;
+      acc.v[15 + 3 * ii + 1] += m * wb.y;
+      acc.v[15 + 3 * ii + 2] += m * wb.z;
+    }
+  } else {
+    atomicAdd(&s.acc[3 + 3 * i + 0][b], sf.x);
+    atomicAdd(&s.acc[3 + 3 * i + 1][b], sf.y);
+    atomicAdd(&s.acc[3 + 3 * i + 2][b], sf.z);
+    atomicAdd(&s.acc[15 + 3 * i + 0][b], wb.x);
+    atomicAdd(&s.acc[15 + 3 * i + 1][b], wb.y);
+    atomicAdd(&s.acc[15 + 3 * i + 2][b], wb.z);
   }
-  atomicAdd(&s.acc[15 + 3 * i + 0][b], qc.x * w);
-  atomicAdd(&s.acc[15 + 3 * i + 1][b], qc.y * w);
-  atomicAdd(&s.acc[15 + 3 * i + 2][b], qc.z * w);
+}
+
+// a lane's register sums -> the LDS accumulators of `beam`
+template <int B> __device__ __forceinline__ void flushAcc(EvalLds<B> &s, Acc27 &acc, uint32_t beam) {
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    if (acc.v[k] != 0.f) atomicAdd(&s.acc[k][beam], acc.v[k]);
+    acc.v[k] = 0.f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -322,7 +370,7 @@ template <int B>
 __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
                                                           const uint2 *__restrict__ itemOff,
                                                           const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
-                                                          uint2 *__restrict__ pairs, uint32_t *__restrict__ pairCnt) {
+                                                          uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairCnt) {
   constexpr int LPB = 64 / B;
   __shared__ TravLds s;
   const int lane = threadIdx.x;
@@ -341,13 +389,12 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
     if (it >= nItems) break;
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y;
-    if (nb == 0) {
-      if (lane == 0) pairCnt[it] = 0u;
-      continue;
-    }
+    if (nb == 0) continue;
+    // the item's region: one list of up to `cap` photon indices per beam of the tile
     const uint2 reg = itemOff[it];
-    uint2 *out = pairs + (size_t)reg.x * 64u;
-    const uint32_t cap = reg.y * 64u;
+    const uint32_t cap = reg.y;
+    uint32_t *out = pairs + (size_t)reg.x * 64u + (size_t)b * cap;
+    uint32_t mine = 0;  // hits of this lane's beam so far (equal in the LPB lanes of the beam)
     BaseInfo bi;
     const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
     TileWalk w;
@@ -356,7 +403,7 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
     const float mint = eps, maxt = base.len - eps;
     const uint32_t edge = bi.edge;
     const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
-    uint32_t written = 0, staged = 0;  // wave-uniform
+    uint32_t staged = 0;  // wave-uniform
 
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
@@ -434,18 +481,21 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
             }
             const unsigned long long m = __ballot(hit);
             if (m) {
+              // the hits of my beam in this step sit in lanes b, b + B, ...: append in lane order
+              constexpr unsigned long long GROUP = B == 16 ? 0x0001000100010001ull : (B == 32 ? 0x0000000100000001ull : 1ull);
+              const unsigned long long g = (m >> b) & GROUP;
               if (hit) {
-                const uint32_t off = written + __popcll(m & ((1ull << lane) - 1ull));
-                if (off < cap) out[off] = make_uint2(s.stageIdx[j], (uint32_t)b);
+                const uint32_t off = mine + __popcll(g & ((1ull << (sub * B)) - 1ull));
+                if (off < cap) out[off] = s.stageIdx[j];
                 else nOver++;
               }
-              written += __popcll(m);
+              mine += __popcll(g);
             }
           }
         }
       }
     }
-    if (lane == 0) pairCnt[it] = min(written, cap);
+    if (sub == 0) pairCnt[(size_t)it * B + b] = (uint32_t)b < nb ? min(mine, cap) : 0u;
     nCand += (unsigned long long)staged * nb;
   }
   {
@@ -465,7 +515,7 @@ template <int B, bool FULLVIS>
 __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
                                                           const uint2 *__restrict__ itemOff,
                                                           const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
-                                                          const uint2 *__restrict__ pairs,
+                                                          const uint32_t *__restrict__ pairs,
                                                           const uint32_t *__restrict__ pairCnt) {
   __shared__ EvalLds<B> s;
   const int lane = threadIdx.x;
@@ -481,46 +531,75 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y;
     if (nb == 0) continue;
-    const uint32_t cnt = pairCnt[it];
-    if (cnt == 0) continue;
-    const uint2 *in = pairs + (size_t)itemOff[it].x * 64u;
+    // prefix offsets of the per-beam lists
+    const uint32_t cntb = (uint32_t)lane < nb ? pairCnt[(size_t)it * B + lane] : 0u;
+    const uint32_t incl = wave_scan_incl(cntb, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0) continue;
+    const uint2 reg = itemOff[it];
+    const uint32_t *lists = pairs + (size_t)reg.x * 64u;
+    const uint32_t cap = reg.y;
     __syncthreads();
+    if (lane < B) s.boff[lane + 1] = incl;
+    if (lane == 0) s.boff[0] = 0u;
     loadTileRays<B>(a, s, setBase, nb, lane);
     for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
     __syncthreads();
-    uint32_t qHead = 0, qCount = 0;  // wave-uniform ring state of the reconnection queue
-    for (uint32_t i = 0; i < cnt; i += 64) {
-      uint32_t qMask = 0;
-      double tP = 0.0;
-      float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint2 e = make_uint2(0u, 0u);
-      if (i + lane < cnt) {
-        e = in[i + lane];
-        if (!skip) evalPhase1<B>(a, s, e.x, e.y, 0u, nNull, nFail, qMask, tP, qc);
-        nEval++;
+
+    // my chunk [g0, g1) of the concatenated lists
+    const uint32_t chunk = (total + 63u) / 64u;
+    const uint32_t g0 = min(total, (uint32_t)lane * chunk), g1 = min(total, g0 + chunk);
+    uint32_t cur = 0;  // current beam
+    if (g0 < g1)
+      while (s.boff[cur + 1] <= g0) cur++;
+    Acc27 acc;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc.v[k] = 0.f;
+    uint32_t qHead = 0, qCount = 0;  // this lane's reconnection queue
+
+    for (uint32_t t = 0; t <= chunk; ++t) {
+      const bool last = t == chunk;
+      if (!last) {
+        const uint32_t g = g0 + t;
+        uint32_t qMask = 0;
+        double tP = 0.0;
+        float pdfCam = 0.f;
+        uint32_t pidx = 0;
+        if (g < g1) {
+          if (g >= s.boff[cur + 1]) {
+            flushAcc<B>(s, acc, cur);
+            do cur++; while (s.boff[cur + 1] <= g);
+          }
+          pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
+          if (!skip) evalPhase1<B>(a, s, pidx, cur, acc, nNull, nFail, qMask, tP, pdfCam);
+          nEval++;
+        }
+        for (uint32_t m = qMask; m; m &= m - 1u) {
+          const uint32_t sh = (uint32_t)__ffs(m) - 1u;
+          const uint32_t q = (qHead + qCount) % QD;
+          s.qPh[q][lane] = pidx;
+          s.qMeta[q][lane] = cur | (sh << 8);
+          s.qPdf[q][lane] = pdfCam;
+          s.qT[q][lane] = tP;
+          qCount++;
+        }
       }
-      // append this step's reconnection shifts: wave prefix sum of the per-lane counts
-      const uint32_t mine = __popc(qMask);
-      const uint32_t incl = wave_scan_incl(mine, lane);
-      uint32_t slot = qHead + qCount + (incl - mine);
-      for (uint32_t m = qMask; m; m &= m - 1u) {
-        const uint32_t sh = (uint32_t)__ffs(m) - 1u;
-        const uint32_t q = slot % DQCAP;
-        s.qId[q] = make_uint2(e.x, e.y | (sh << 8));
-        s.qT[q] = tP;
-        s.qC[q] = qc;
-        slot++;
+      // reconnections: run while most lanes have one pending, or a queue could overflow next step;
+      // after the last step drain everything
+      for (;;) {
+        const unsigned long long pending = __ballot(qCount > 0u);
+        if (!pending) break;
+        if (!last && __popcll(pending) < 48 && !__ballot(qCount > (uint32_t)(QD - 4))) break;
+        if (qCount > 0u) {
+          const uint32_t q = qHead;
+          evalPhase2<B, FULLVIS>(a, s, s.qPh[q][lane], s.qMeta[q][lane], s.qT[q][lane], s.qPdf[q][lane], cur, acc,
+                                 nDiff, nFail);
+          qHead = (qHead + 1u) % QD;
+          qCount--;
+        }
       }
-      qCount += __shfl(incl, 63, 64);
-      __syncthreads();
-      while (qCount >= 64u) {
-        evalPhase2<B, FULLVIS>(a, s, (qHead + lane) % DQCAP, nDiff, nFail);
-        qHead = (qHead + 64u) % DQCAP;
-        qCount -= 64u;
-      }
-      __syncthreads();
     }
-    if ((uint32_t)lane < qCount) evalPhase2<B, FULLVIS>(a, s, (qHead + lane) % DQCAP, nDiff, nFail);
+    if (g0 < g1) flushAcc<B>(s, acc, cur);
     __syncthreads();
     // ---- write out: 27 partial sums per beam set into the iteration buffer ----
     for (int idx = lane; idx < 27 * B; idx += 64) {
@@ -567,7 +646,7 @@ void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uin
 
 // queueHead must be zero on entry
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
-                         const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCnt,
+                         const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
                          uint32_t nwaves, hipStream_t stream) {
   if (a.nsets == 0) return;
   switch (beamsPerWave) {
@@ -579,7 +658,7 @@ void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *ite
 
 template <bool FULLVIS>
 static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
-                           const uint32_t *itemCount, uint32_t *queueHead, const uint2 *pairs, const uint32_t *pairCnt,
+                           const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                            uint32_t nwaves, hipStream_t stream) {
   switch (beamsPerWave) {
     case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
@@ -590,7 +669,7 @@ static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *i
 
 // fullVis: shadow rays walk the occluder BVH (intended visibility, > 254 occluders, near-list overflow)
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
-                         const uint32_t *itemCount, uint32_t *queueHead, const uint2 *pairs, const uint32_t *pairCnt,
+                         const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                          uint32_t nwaves, hipStream_t stream) {
   if (a.nsets == 0) return;
   if (fullVis) launchEvaluate<true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, stream);

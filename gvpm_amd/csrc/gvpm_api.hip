@@ -30,10 +30,10 @@ void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, in
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
                      uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream);
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
-                         const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCnt,
+                         const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
                          uint32_t nwaves, hipStream_t stream);
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
-                         const uint32_t *itemCount, uint32_t *queueHead, const uint2 *pairs, const uint32_t *pairCnt,
+                         const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                          uint32_t nwaves, hipStream_t stream);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
@@ -199,8 +199,8 @@ struct gvpm_context {
   DevBuf<uint4> items;
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
   // G-BRE: (photon, beam) pairs between the traversal and the evaluation kernel
-  DevBuf<uint2> itemOff, pairs;
-  DevBuf<uint32_t> pairCnt;
+  DevBuf<uint2> itemOff;
+  DevBuf<uint32_t> pairs, pairCnt;  // per item and beam: photon index lists + their lengths
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -789,7 +789,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   const uint32_t itemCap = plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave);
   HIP_TRY(h, h->items.ensure(itemCap));
   HIP_TRY(h, h->itemOff.ensure(itemCap));
-  HIP_TRY(h, h->pairCnt.ensure(itemCap));
+  HIP_TRY(h, h->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
   HIP_TRY(h, h->queueCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
   launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->itemOff.p,

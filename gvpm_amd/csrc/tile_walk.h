@@ -260,8 +260,8 @@ __device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox 
 // plan: cut every tile chunk into work items of ~equal candidate count
 // item = {setBase, nb, firstLayer, lastLayer}
 // ------------------------------------------------------------------------------------------
-// itemOff (optional): per item {first 64-pair block of its region in the pair buffer, blocks}; the
-// region holds the item's upper bound of (photon, beam) pairs = staged photons x beams
+// itemOff (optional): per item {first 64-entry block of its region in the pair buffer, staged photons};
+// the region holds one list of up to `staged` photon indices for each of the item's beams
 template <int B>
 __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
                                                   uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
           items[slot] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
           if (itemOff) {
             const uint32_t blocks = (uint32_t)(((unsigned long long)run * nb + 63ull) / 64ull);
-            itemOff[slot] = make_uint2(atomicAdd(blockTotal, blocks), blocks);
+            itemOff[slot] = make_uint2(atomicAdd(blockTotal, blocks), run);
           }
         }
         emitted++;

@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgvpm_hip.so")
+LIB_PATH = os.environ.get("GVPM_HIP_LIB", os.path.join(_HERE, "libgvpm_hip.so"))  # override: A/B probes only
 _LIB = None
 
 # every symbol include/gvpm_hip.h declares

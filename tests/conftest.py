@@ -22,4 +22,12 @@ def _native_built():
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gvpm_amd", "csrc")])
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    # torch ships its own HIP runtime: it must initialise before libgvpm_hip.so touches the GPU,
+    # otherwise a later torch.cuda init in the same process finds no device
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     yield
