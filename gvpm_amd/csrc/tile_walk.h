@@ -189,32 +189,40 @@ struct CellBox {
   int bx0, bx1, by0, by1, bz0, bz1;
 };
 
-// cell box of the slab layers [cA, cAe]; false when no beam of the tile reaches the slab
-__device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, int cA, int cAe, CellBox &bx) {
-  // border layers extend to infinity (they hold the clamped photons)
-  const float lo = cA == 0 ? -INFINITY : w.orgA + cA * a.grid.cell - w.pad;
-  const float hi = cAe == w.dimA - 1 ? INFINITY : w.orgA + (cAe + 1) * a.grid.cell + w.pad;
-  float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
-  if (w.beamValid) {
-    float ta = w.t0, tb = w.t1;
-    bool act = true;
-    if (fabsf(w.dA) > 1e-12f) {
-      const float inv = 1.f / w.dA;
-      const float s0 = (lo - w.oA) * inv, s1 = (hi - w.oA) * inv;
-      ta = fmaxf(ta, fminf(s0, s1));
-      tb = fminf(tb, fmaxf(s0, s1));
-      act = ta <= tb;
-    } else {
-      act = w.oA >= lo && w.oA <= hi;
-    }
-    if (act) {
-      const float u0 = w.oU + w.dU * ta, u1 = w.oU + w.dU * tb, v0 = w.oV + w.dV * ta, v1 = w.oV + w.dV * tb;
-      uLo = fminf(u0, u1) - w.pad; uHi = fmaxf(u0, u1) + w.pad;
-      vLo = fminf(v0, v1) - w.pad; vHi = fmaxf(v0, v1) + w.pad;
-    }
+// the (U,V) footprint of ONE beam inside the slab [lo, hi] along A; false when it does not reach it
+struct BeamSlab {
+  float oA, dA, oU, dU, oV, dV, t0, t1;
+};
+__device__ __forceinline__ bool beamFootprint(const BeamSlab &q, float lo, float hi, float pad, float &uLo, float &uHi,
+                                              float &vLo, float &vHi) {
+  float ta = q.t0, tb = q.t1;
+  bool act = true;
+  if (fabsf(q.dA) > 1e-12f) {
+    const float inv = 1.f / q.dA;
+    const float s0 = (lo - q.oA) * inv, s1 = (hi - q.oA) * inv;
+    ta = fmaxf(ta, fminf(s0, s1));
+    tb = fminf(tb, fmaxf(s0, s1));
+    act = ta <= tb;
+  } else {
+    act = q.oA >= lo && q.oA <= hi;
   }
-  uLo = wave_min(uLo); uHi = wave_max(uHi);
-  vLo = wave_min(vLo); vHi = wave_max(vHi);
+  if (!act) return false;
+  const float u0 = q.oU + q.dU * ta, u1 = q.oU + q.dU * tb, v0 = q.oV + q.dV * ta, v1 = q.oV + q.dV * tb;
+  uLo = fminf(u0, u1) - pad; uHi = fmaxf(u0, u1) + pad;
+  vLo = fminf(v0, v1) - pad; vHi = fmaxf(v0, v1) + pad;
+  return true;
+}
+
+// slab [cA, cAe] along A -> its [lo, hi] in world units; border layers extend to infinity (they hold
+// the clamped photons)
+__device__ __forceinline__ void slabRange(const GatherArgs &a, const TileWalk &w, int cA, int cAe, float &lo, float &hi) {
+  lo = cA == 0 ? -INFINITY : w.orgA + cA * a.grid.cell - w.pad;
+  hi = cAe == w.dimA - 1 ? INFINITY : w.orgA + (cAe + 1) * a.grid.cell + w.pad;
+}
+
+// cell box from the union footprint of the tile's beams
+__device__ __forceinline__ bool boxFromFootprint(const GatherArgs &a, const TileWalk &w, int cA, int cAe, float uLo,
+                                                 float uHi, float vLo, float vHi, CellBox &bx) {
   if (!(uLo <= uHi)) return false;
   const int cU0 = min(max(0, (int)floorf((uLo - w.orgU) * a.grid.invCell)), w.dimU - 1);
   const int cU1 = min(max(0, (int)floorf((uHi - w.orgU) * a.grid.invCell)), w.dimU - 1);
@@ -226,6 +234,24 @@ __device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, 
   bx.by0 = A == 0 ? cU0 : (A == 1 ? cA : cV0); bx.by1 = A == 0 ? cU1 : (A == 1 ? cAe : cV1);
   bx.bz0 = A == 0 ? cV0 : (A == 1 ? cU0 : cA); bx.bz1 = A == 0 ? cV1 : (A == 1 ? cU1 : cAe);
   return true;
+}
+
+// cell box of the slab layers [cA, cAe] (every lane holds one beam; wave-uniform result);
+// false when no beam of the tile reaches the slab
+__device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, int cA, int cAe, CellBox &bx) {
+  float lo, hi;
+  slabRange(a, w, cA, cAe, lo, hi);
+  float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
+  if (w.beamValid) {
+    const BeamSlab q{w.oA, w.dA, w.oU, w.dU, w.oV, w.dV, w.t0, w.t1};
+    float a0, a1, b0, b1;
+    if (beamFootprint(q, lo, hi, w.pad, a0, a1, b0, b1)) {
+      uLo = a0; uHi = a1; vLo = b0; vHi = b1;
+    }
+  }
+  uLo = wave_min(uLo); uHi = wave_max(uHi);
+  vLo = wave_min(vLo); vHi = wave_max(vHi);
+  return boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx);
 }
 
 // x-contiguous photon range of this lane for range index ri of the box
@@ -257,14 +283,19 @@ __device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox 
 }
 
 // ------------------------------------------------------------------------------------------
-// plan: cut every tile chunk into work items of ~equal candidate count
+// plan: cut every tile chunk into work items of ~target staged photons
 // item = {setBase, nb, firstLayer, lastLayer}
-// ------------------------------------------------------------------------------------------
 // itemOff (optional): per item {first 64-entry block of its region in the pair buffer, staged photons};
-// the region holds one list of up to `staged` photon indices for each of the item's beams
+// the region holds one list of up to `staged` photon indices for each of the item's beams.
+// One wave per tile; the slab steps of a chunk are spread over the LANES (each lane loops over the
+// tile's beams, held in LDS, and over the cell rows of its own slab box), so the whole walk of a
+// chunk is a handful of dependent steps instead of one per slab.
+// ------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
                                                   uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal) {
+  __shared__ float pb[8][B];
+  __shared__ uint32_t pvalid[B];
   const int lane = threadIdx.x;
   const uint32_t tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -276,26 +307,66 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
     TileWalk w;
     tileSetupFrom(a, base, base.valid, w);
     if (!w.any) continue;
-    // one pass: cut an item whenever ~target photons have been staged (at most PLAN_MAX_ITEMS per chunk)
-    uint32_t run = 0, emitted = 0;
-    int first = w.cA0;
-    for (int cA = w.cA0; cA <= w.cA1; cA += w.K) {
-      const int cAe = min(cA + w.K - 1, w.cA1);
-      CellBox bx;
-      if (slabBox(a, w, cA, cAe, bx)) run += boxCount(a, bx, lane);
-      const bool last = cAe == w.cA1;
-      if ((run >= target && emitted + 1 < (uint32_t)PLAN_MAX_ITEMS) || (last && run > 0)) {
-        if (lane == 0) {
-          const uint32_t slot = atomicAdd(itemCount, 1u);
-          items[slot] = make_uint4(setBase, nb, (uint32_t)first, (uint32_t)cAe);
-          if (itemOff) {
-            const uint32_t blocks = (uint32_t)(((unsigned long long)run * nb + 63ull) / 64ull);
-            itemOff[slot] = make_uint2(atomicAdd(blockTotal, blocks), run);
+    __syncthreads();
+    if (lane < B) {
+      pb[0][lane] = w.oA; pb[1][lane] = w.dA; pb[2][lane] = w.oU; pb[3][lane] = w.dU;
+      pb[4][lane] = w.oV; pb[5][lane] = w.dV; pb[6][lane] = w.t0; pb[7][lane] = w.t1;
+      pvalid[lane] = w.beamValid ? 1u : 0u;
+    }
+    __syncthreads();
+    const int nsteps = (w.cA1 - w.cA0 + w.K) / w.K;
+    for (int sbase = 0; sbase < nsteps; sbase += 64) {
+      const int step = sbase + lane;
+      const bool live = step < nsteps;
+      const int cA = w.cA0 + step * w.K, cAe = min(cA + w.K - 1, w.cA1);
+      uint32_t cnt = 0;
+      if (live) {
+        float lo, hi;
+        slabRange(a, w, cA, cAe, lo, hi);
+        float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
+        for (uint32_t j = 0; j < nb; ++j) {
+          if (!pvalid[j]) continue;
+          const BeamSlab q{pb[0][j], pb[1][j], pb[2][j], pb[3][j], pb[4][j], pb[5][j], pb[6][j], pb[7][j]};
+          float a0, a1, b0, b1;
+          if (beamFootprint(q, lo, hi, w.pad, a0, a1, b0, b1)) {
+            uLo = fminf(uLo, a0); uHi = fmaxf(uHi, a1);
+            vLo = fminf(vLo, b0); vHi = fmaxf(vHi, b1);
           }
         }
-        emitted++;
-        run = 0;
-        first = cAe + 1;
+        CellBox bx;
+        if (boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx)) {
+          const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
+          for (int ri = 0; ri < nranges; ++ri) {
+            uint32_t st, c;
+            boxRange(a, bx, ri, nranges, st, c);
+            cnt += c;
+          }
+        }
+      }
+      // greedy cut, in parallel: step s belongs to item floor(exclusive_cumulative(s) / target); items do
+      // not span groups of 64 steps (tiles rarely have that many)
+      const uint32_t incl = wave_scan_incl(cnt, lane);
+      const uint32_t excl = incl - cnt;
+      const uint32_t id = excl / target;
+      const uint32_t idPrev = __shfl_up(id, 1, 64), idNext = __shfl_down(id, 1, 64);
+      const bool first = live && (lane == 0 || id != idPrev);
+      const bool liveNext = lane < 63 && step + 1 < nsteps;
+      const bool closes = live && (!liveNext || idNext != id);
+      const unsigned long long firstMask = __ballot(first);
+      const unsigned long long below = firstMask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+      const int fl = below ? 63 - __clzll(below) : 0;
+      const uint32_t exclFirst = __shfl(excl, fl, 64);
+      const int cAFirst = __shfl(cA, fl, 64);
+      if (closes) {
+        const uint32_t staged = incl - exclFirst;
+        if (staged > 0u) {
+          const uint32_t slot = atomicAdd(itemCount, 1u);
+          items[slot] = make_uint4(setBase, nb, (uint32_t)cAFirst, (uint32_t)cAe);
+          if (itemOff) {
+            const uint32_t blocks = (uint32_t)(((unsigned long long)staged * nb + 63ull) / 64ull);
+            itemOff[slot] = make_uint2(atomicAdd(blockTotal, blocks), staged);
+          }
+        }
       }
     }
   }
