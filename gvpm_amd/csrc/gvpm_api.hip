@@ -113,9 +113,43 @@ RcclApi g_rccl;
 
 #define GVPM_PHASES 3
 
+// Everything a gather reads that is rebuilt per photon set / beam set.  Two of them: G-BRE builds
+// step N+1 (grid, sorts, planner) on a second stream while the evaluation kernel of step N runs.
+struct BuildSet {
+  float builtRadius = -1.f;
+  DevBuf<float4> hot, cold;
+  DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
+  DevBuf<uint32_t> cellStart, keysA, keysB, valsA, valsB;
+  DevBuf<float> boundsPartial, bounds6;
+  Grid grid;
+  SortTemp sortTmp;
+  DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
+  uint32_t ntiles = 0;
+  DevBuf<uint4> items;
+  DevBuf<uint2> itemOff;
+  DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
+  hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
+  bool used = false;
+  void release() {
+    hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); keysA.release(); keysB.release();
+    valsA.release(); valsB.release(); boundsPartial.release(); bounds6.release(); bKeysA.release(); bKeysB.release();
+    bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); queueCtl.release();
+    if (sortTmp.d) (void)hipFree(sortTmp.d);
+    sortTmp.d = nullptr;
+    sortTmp.bytes = 0;
+    if (lastUse) (void)hipEventDestroy(lastUse);
+    lastUse = nullptr;
+  }
+};
+
 struct gvpm_context {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // gather stream: traversal, evaluation, film
+  hipStream_t streamB = nullptr;  // build stream of the G-BRE pipeline
+  hipStream_t bstream = nullptr;  // where the current gather builds (stream, or streamB for G-BRE)
+  BuildSet sets[2];
+  BuildSet *bs = &sets[0];
+  int setIdx = 0;
   gvpm_params cfg;
   gvpm_medium medium;
   bool haveMedium = false;
@@ -132,28 +166,19 @@ struct gvpm_context {
   gvpm_photon_soa rawDev;  // device pointers
   uint32_t nph = 0;
   bool havePhotons = false, photonsDirty = false;
-  float builtRadius = -1.f;
-  DevBuf<float4> hot, cold;
-  DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
   bool nearOverflow = false;
-  DevBuf<uint32_t> cellStart, keysA, keysB, valsA, valsB;
-  DevBuf<float> boundsPartial, bounds6;
   // G-BRE keeps its per-step host syncs to one: the photon bounds of step N are read back with the
   // planner's counters and size the grid of step N+1 (photons outside the grid sit in its border cells)
   float cachedB6[6] = {0, 0, 0, 0, 0, 0};
   bool haveCachedBounds = false, boundsPending = false;
   float *pinB6 = nullptr;      // pinned host staging: 6 floats + 2 uint32
   uint32_t *pinCtl = nullptr;
-  Grid grid;
-  SortTemp sortTmp;
 
   // camera beams
   DevBuf<gvpm_camera_ray> raysOwned;
   const gvpm_camera_ray *raysDev = nullptr;
   uint32_t nsets = 0;
   bool haveBeams = false, beamsDirty = false;
-  DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
-  uint32_t ntiles = 0;
 
   // G-Beams: raw upload shares rawF/rawU/rawDev with the photons; end normals + sub-beam build
   DevBuf<float> endNOwned, subCentres;
@@ -196,10 +221,7 @@ struct gvpm_context {
   uint32_t nwaves = 2048;      // persistent gather waves
   uint32_t ncu = 256;
   uint32_t nwavesTrav = 4096;  // persistent traversal waves (G-BRE)
-  DevBuf<uint4> items;
-  DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
-  // G-BRE: (photon, beam) pairs between the traversal and the evaluation kernel
-  DevBuf<uint2> itemOff;
+  // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
   DevBuf<uint32_t> pairs, pairCnt;  // per item and beam: photon index lists + their lengths
 
   // multi-GPU
@@ -264,10 +286,14 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   gvpm_context *h = new gvpm_context();
   h->device = device;
   h->cfg = *params;
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete h;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->streamB, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->sets[0].lastUse, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->sets[1].lastUse, hipEventDisableTiming) != hipSuccess) {
+    gvpm_destroy(h);
     return GVPM_ERR_HIP;
   }
+  h->bstream = h->stream;
   if (const char *e = getenv("GVPM_BEAMS_PER_WAVE")) {
     int v = atoi(e);
     if (v == 16 || v == 32 || v == 64) h->beamsPerWave = v;
@@ -326,14 +352,12 @@ int gvpm_destroy(gvpm_context *h) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
-  h->itemOff.release(); h->pairs.release(); h->pairCnt.release();
+  if (h->streamB) (void)hipStreamSynchronize(h->streamB);
+  for (BuildSet &b : h->sets) b.release();
+  h->pairs.release(); h->pairCnt.release();
   h->tri4.release(); h->bvh.release();
-  h->rawF.release(); h->rawU.release(); h->hot.release(); h->cold.release(); h->overflowCtr.release();
-  h->cellStart.release(); h->keysA.release(); h->keysB.release(); h->valsA.release(); h->valsB.release();
-  h->boundsPartial.release(); h->bounds6.release();
-  if (h->sortTmp.d) (void)hipFree(h->sortTmp.d);
-  h->raysOwned.release(); h->bKeysA.release(); h->bKeysB.release(); h->bValsA.release();
-  h->setPerm.release(); h->tileStart.release(); h->items.release(); h->queueCtl.release();
+  h->rawF.release(); h->rawU.release();
+  h->raysOwned.release();
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
@@ -341,6 +365,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->streamB) (void)hipStreamDestroy(h->streamB);
   delete h;
   return GVPM_OK;
 }
@@ -431,6 +456,10 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
     for (const void *q : ptrs)
       if (!q) return fail(h, GVPM_ERR_INVALID_ARG, "null photon array");
   }
+  // G-BRE reads the raw arrays only from its build stream (and is done with them when gvpm_gather
+  // returns), so the copy need not wait for the evaluation kernel still running on the gather stream
+  const bool bre = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
+  hipStream_t up = bre ? h->streamB : h->stream;
   if (fromDevice) {
     h->rawDev = *p;
   } else {
@@ -443,23 +472,23 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
                              &h->rawDev.prefix_w, &h->rawDev.parent_scat, &h->rawDev.parent_wi};
     const float **dst1[4] = {&h->rawDev.parent_pdf, &h->rawDev.edge_pdf, &h->rawDev.parent_rr, &h->rawDev.parent_g};
     for (int k = 0; k < 8; ++k) {
-      if (n) HIP_TRY(h, hipMemcpyAsync(f, src3[k], (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+      if (n) HIP_TRY(h, hipMemcpyAsync(f, src3[k], (size_t)n * 12, hipMemcpyHostToDevice, up));
       *dst3[k] = f;
       f += (size_t)n * 3;
     }
     for (int k = 0; k < 4; ++k) {
-      if (n) HIP_TRY(h, hipMemcpyAsync(f, src1[k], (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+      if (n) HIP_TRY(h, hipMemcpyAsync(f, src1[k], (size_t)n * 4, hipMemcpyHostToDevice, up));
       *dst1[k] = f;
       f += n;
     }
     if (n) {
-      HIP_TRY(h, hipMemcpyAsync(h->rawU.p, p->flags, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(h, hipMemcpyAsync(h->rawU.p + n, p->path_id, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->rawU.p, p->flags, (size_t)n * 4, hipMemcpyHostToDevice, up));
+      HIP_TRY(h, hipMemcpyAsync(h->rawU.p + n, p->path_id, (size_t)n * 4, hipMemcpyHostToDevice, up));
     }
     h->rawDev.flags = h->rawU.p;
     h->rawDev.path_id = h->rawU.p + n;
     h->rawDev.n = n;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller may reuse its buffers
+    HIP_TRY(h, hipStreamSynchronize(up));  // the caller may reuse its buffers
   }
   h->nph = n;
   h->havePhotons = true;
@@ -609,27 +638,27 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   const uint32_t n = h->nph;
   h->boundsPending = false;
   if (n == 0) {
-    h->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
-    HIP_TRY(h, h->cellStart.ensure(2));
-    HIP_TRY(h, hipMemsetAsync(h->cellStart.p, 0, 2 * sizeof(uint32_t), h->stream));
+    h->bs->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
+    HIP_TRY(h, h->bs->cellStart.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->bs->cellStart.p, 0, 2 * sizeof(uint32_t), h->bstream));
     return GVPM_OK;
   }
   const int nblocks = 256;
-  HIP_TRY(h, h->boundsPartial.ensure(nblocks * 6));
-  HIP_TRY(h, h->bounds6.ensure(8));
-  launch_bounds(h->rawDev.pos, n, h->boundsPartial.p, nblocks, h->bounds6.p, h->stream);
+  HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
+  HIP_TRY(h, h->bs->bounds6.ensure(8));
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, h->bstream);
   float b6[6];
   if (!h->pinB6) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocDefault));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   if (deferred && h->haveCachedBounds) {
-    HIP_TRY(h, hipMemcpyAsync(h->pinB6, h->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pinB6, h->bs->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->bstream));
     h->boundsPending = true;
     memcpy(b6, h->cachedB6, sizeof(b6));
   } else {
-    HIP_TRY(h, hipMemcpyAsync(b6, h->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(b6, h->bs->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->bstream));
+    HIP_TRY(h, hipStreamSynchronize(h->bstream));
     memcpy(h->cachedB6, b6, sizeof(b6));
     h->haveCachedBounds = true;
   }
@@ -651,17 +680,17 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   }
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
-  h->grid = g;
-  HIP_TRY(h, h->keysA.ensure(n));
-  HIP_TRY(h, h->keysB.ensure(n));
-  HIP_TRY(h, h->valsA.ensure(n));
-  HIP_TRY(h, h->valsB.ensure(n));
-  HIP_TRY(h, h->hot.ensure(n));
-  HIP_TRY(h, h->cold.ensure((size_t)n * GVPM_REC_QUADS));
-  HIP_TRY(h, h->cellStart.ensure((size_t)g.ncells + 2));
-  launch_cell_keys(h->rawDev.pos, n, g, h->keysA.p, h->valsA.p, h->stream);
-  HIP_TRY(h, sortPairsU32(h->sortTmp, h->keysA.p, h->keysB.p, h->valsA.p, h->valsB.p, n,
-                          ilog2ceil(g.ncells + 1), h->stream));
+  h->bs->grid = g;
+  HIP_TRY(h, h->bs->keysA.ensure(n));
+  HIP_TRY(h, h->bs->keysB.ensure(n));
+  HIP_TRY(h, h->bs->valsA.ensure(n));
+  HIP_TRY(h, h->bs->valsB.ensure(n));
+  HIP_TRY(h, h->bs->hot.ensure(n));
+  HIP_TRY(h, h->bs->cold.ensure((size_t)n * GVPM_REC_QUADS));
+  HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
+  launch_cell_keys(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bstream);
+  HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, n,
+                          ilog2ceil(g.ncells + 1), h->bstream));
   // longest possible reconnection segment: diagonal of (occluders U photons), generously padded
   float diag2 = 0.f;
   for (int c = 0; c < 3; ++c) {
@@ -670,17 +699,17 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   }
   const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
-  HIP_TRY(h, h->overflowCtr.ensure(2));
-  HIP_TRY(h, hipMemsetAsync(h->overflowCtr.p, 0, 4, h->stream));
-  launch_reorder(h->rawDev, h->valsB.p, n, h->cfg, h->tri4.p, h->ntri, dmax, h->hot.p, h->cold.p, h->overflowCtr.p,
-                 h->stream);
-  launch_segment_start(h->keysB.p, n, g.ncells, 0, h->cellStart.p, h->stream);
+  HIP_TRY(h, h->bs->overflowCtr.ensure(2));
+  HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
+  launch_reorder(h->rawDev, h->bs->valsB.p, n, h->cfg, h->tri4.p, h->ntri, dmax, h->bs->hot.p, h->bs->cold.p, h->bs->overflowCtr.p,
+                 h->bstream);
+  launch_segment_start(h->bs->keysB.p, n, g.ncells, 0, h->bs->cellStart.p, h->bstream);
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
   if (!deferred && h->cfg.visibility_as_written && h->ntri <= 254u) {
     uint32_t over = 0;
-    HIP_TRY(h, hipMemcpyAsync(&over, h->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&over, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
+    HIP_TRY(h, hipStreamSynchronize(h->bstream));
     h->nearOverflow = over != 0;
   }
   return GVPM_OK;
@@ -693,21 +722,21 @@ static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
   if (beamsPerWave == 64) th = 8;
   if (beamsPerWave == 16) tw = 4;
   const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
-  h->ntiles = tilesX * tilesY;
-  HIP_TRY(h, h->tileStart.ensure((size_t)h->ntiles + 2));
-  HIP_TRY(h, h->bKeysA.ensure(n + 1));
-  HIP_TRY(h, h->bKeysB.ensure(n + 1));
-  HIP_TRY(h, h->bValsA.ensure(n + 1));
-  HIP_TRY(h, h->setPerm.ensure(n + 1));
+  h->bs->ntiles = tilesX * tilesY;
+  HIP_TRY(h, h->bs->tileStart.ensure((size_t)h->bs->ntiles + 2));
+  HIP_TRY(h, h->bs->bKeysA.ensure(n + 1));
+  HIP_TRY(h, h->bs->bKeysB.ensure(n + 1));
+  HIP_TRY(h, h->bs->bValsA.ensure(n + 1));
+  HIP_TRY(h, h->bs->setPerm.ensure(n + 1));
   if (n) {
-    launch_beam_keys(h->raysDev, n, h->cfg.width, tw, th, h->bKeysA.p, h->bValsA.p, h->stream);
+    launch_beam_keys(h->raysDev, n, h->cfg.width, tw, th, h->bs->bKeysA.p, h->bs->bValsA.p, h->bstream);
     const int tileShift = ilog2ceil(tw * th) + 3;
-    const int bits = ilog2ceil(h->ntiles + 1) + tileShift;
-    HIP_TRY(h, sortPairsU32(h->sortTmp, h->bKeysA.p, h->bKeysB.p, h->bValsA.p, h->setPerm.p, n,
-                            bits > 32 ? 32 : bits, h->stream));
-    launch_segment_start(h->bKeysB.p, n, h->ntiles, tileShift, h->tileStart.p, h->stream);
+    const int bits = ilog2ceil(h->bs->ntiles + 1) + tileShift;
+    HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->bKeysA.p, h->bs->bKeysB.p, h->bs->bValsA.p, h->bs->setPerm.p, n,
+                            bits > 32 ? 32 : bits, h->bstream));
+    launch_segment_start(h->bs->bKeysB.p, n, h->bs->ntiles, tileShift, h->bs->tileStart.p, h->bstream);
   } else {
-    HIP_TRY(h, hipMemsetAsync(h->tileStart.p, 0, ((size_t)h->ntiles + 1) * sizeof(uint32_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->bs->tileStart.p, 0, ((size_t)h->bs->ntiles + 1) * sizeof(uint32_t), h->bstream));
   }
   HIP_TRY(h, hipGetLastError());
   return GVPM_OK;
@@ -720,14 +749,14 @@ static bool needFullVis(const gvpm_context *h) {
 
 static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   memset(&a, 0, sizeof(a));
-  a.hot = h->hot.p;
-  a.cold = h->cold.p;
-  a.cellStart = h->cellStart.p;
+  a.hot = h->bs->hot.p;
+  a.cold = h->bs->cold.p;
+  a.cellStart = h->bs->cellStart.p;
   a.nph = h->nph;
-  a.grid = h->grid;
+  a.grid = h->bs->grid;
   a.rays = h->raysDev;
-  a.setPerm = h->setPerm.p;
-  a.tileStart = h->tileStart.p;
+  a.setPerm = h->bs->setPerm.p;
+  a.tileStart = h->bs->tileStart.p;
   a.nsets = h->nsets;
   a.tri4 = h->tri4.p;
   a.bvh = h->bvh.p;
@@ -763,46 +792,56 @@ static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, i
   return GVPM_OK;
 }
 
-// computeVolumeGradientPhotonBRE, gvpm.cpp:988-1079
+// computeVolumeGradientPhotonBRE, gvpm.cpp:988-1079.
+// Pipeline: the build of this step (grid, beam sort, planner) runs on streamB into the build set
+// the previous step is NOT reading, so it overlaps the previous step's evaluation kernel; the
+// host waits once (planner counters) and then queues traversal + evaluation on the gather stream.
 static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   const float r = currentRadius(h);
   std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav, *evEval;
   int rc = nextEvents(h, &evBuild, 2);
   if (rc != GVPM_OK) return rc;
-  HIP_TRY(h, hipEventRecord(evBuild->first, h->stream));
+  h->bstream = h->streamB;
   bool rebuilt = false;
-  if (h->photonsDirty || r != h->builtRadius) {
+  if (h->photonsDirty || h->beamsDirty || r != h->bs->builtRadius) {
+    // the other set; wait until the kernels that last read it are done
+    h->setIdx ^= 1;
+    h->bs = &h->sets[h->setIdx];
+    if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
+    HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
     rc = buildGrid(h, r, true);
-    if (rc != GVPM_OK) return rc;
+    if (rc == GVPM_OK) rc = sortBeams(h);
+    if (rc != GVPM_OK) {
+      h->bstream = h->stream;
+      return rc;
+    }
     h->photonsDirty = false;
-    h->builtRadius = r;
-    rebuilt = h->nph > 0;
-  }
-  if (h->beamsDirty) {
-    rc = sortBeams(h);
-    if (rc != GVPM_OK) return rc;
     h->beamsDirty = false;
+    h->bs->builtRadius = r;
+    rebuilt = h->nph > 0;
+  } else {
+    HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
   }
-  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   GatherArgs a;
   fillArgs(h, a, r);
-  const uint32_t itemCap = plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave);
-  HIP_TRY(h, h->items.ensure(itemCap));
-  HIP_TRY(h, h->itemOff.ensure(itemCap));
-  HIP_TRY(h, h->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
-  HIP_TRY(h, h->queueCtl.ensure(4));
-  HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
-  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, h->itemOff.p,
-                  h->queueCtl.p + 3, h->stream);
-  // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only)
+  const uint32_t itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
+  HIP_TRY(h, h->bs->items.ensure(itemCap));
+  HIP_TRY(h, h->bs->itemOff.ensure(itemCap));
+  HIP_TRY(h, h->bs->queueCtl.ensure(4));
+  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->bstream));
+  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,
+                  h->bs->queueCtl.p + 3, h->bstream);
+  // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only) ...
   // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
   if (!h->pinB6) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocDefault));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
-  HIP_TRY(h, hipMemcpyAsync(h->pinCtl, h->queueCtl.p + 3, 4, hipMemcpyDeviceToHost, h->stream));
-  if (rebuilt) HIP_TRY(h, hipMemcpyAsync(h->pinCtl + 1, h->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->pinCtl, h->bs->queueCtl.p + 3, 4, hipMemcpyDeviceToHost, h->bstream));
+  if (rebuilt) HIP_TRY(h, hipMemcpyAsync(h->pinCtl + 1, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
+  HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
+  HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  h->bstream = h->stream;
   const uint32_t blocks = h->pinCtl[0];
   if (rebuilt) h->nearOverflow = h->cfg.visibility_as_written && h->ntri <= 254u && h->pinCtl[1] != 0;
   if (h->boundsPending) {
@@ -811,20 +850,26 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
       if (!std::isfinite(h->pinB6[c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
     memcpy(h->cachedB6, h->pinB6, sizeof(h->cachedB6));
   }
+  // the pair buffer and the per-item counts live on the gather stream only
+  if ((size_t)blocks * 64u + 64u > h->pairs.cap || (size_t)itemCap * h->beamsPerWave > h->pairCnt.cap)
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // a regrowth frees memory the previous step may still read
   HIP_TRY(h, h->pairs.ensure((size_t)blocks * 64u + 64u));
-  HIP_TRY(h, hipEventRecord(evBuild->second, h->stream));
+  HIP_TRY(h, h->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   rc = nextEvents(h, &evTrav, 1);
   if (rc != GVPM_OK) return rc;
   rc = nextEvents(h, &evEval, 0);
   if (rc != GVPM_OK) return rc;
   HIP_TRY(h, hipEventRecord(evTrav->first, h->stream));
-  launch_traverse_bre(a, h->beamsPerWave, h->items.p, h->itemOff.p, h->queueCtl.p, h->queueCtl.p + 1, h->pairs.p,
+  launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->pairs.p,
                       h->pairCnt.p, h->nwavesTrav, h->stream);
   HIP_TRY(h, hipEventRecord(evTrav->second, h->stream));
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
-  launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->items.p, h->itemOff.p, h->queueCtl.p, h->queueCtl.p + 2, h->pairs.p,
-                      h->pairCnt.p, h->nwaves, h->stream);
+  launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
+                      h->bs->queueCtl.p + 2, h->pairs.p, h->pairCnt.p, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
+  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
+  h->bs->used = true;
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
   // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
@@ -843,22 +888,22 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   const uint32_t n = h->nph;
   h->nsub = 0;
   h->maxSubLen = 0.f;
-  HIP_TRY(h, h->cold.ensure((size_t)(n + 1) * 9));
+  HIP_TRY(h, h->bs->cold.ensure((size_t)(n + 1) * 9));
   if (n == 0) {
-    h->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
-    HIP_TRY(h, h->cellStart.ensure(2));
-    HIP_TRY(h, hipMemsetAsync(h->cellStart.p, 0, 2 * sizeof(uint32_t), h->stream));
+    h->bs->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
+    HIP_TRY(h, h->bs->cellStart.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->bs->cellStart.p, 0, 2 * sizeof(uint32_t), h->stream));
     h->subLen = r;
     return GVPM_OK;
   }
   // bounds of the beam end points and origins
   const int nblocks = 256;
-  HIP_TRY(h, h->boundsPartial.ensure(nblocks * 6));
-  HIP_TRY(h, h->bounds6.ensure(16));
-  launch_bounds(h->rawDev.pos, n, h->boundsPartial.p, nblocks, h->bounds6.p, h->stream);
-  launch_bounds(h->rawDev.parent_pos, n, h->boundsPartial.p, nblocks, h->bounds6.p + 6, h->stream);
+  HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
+  HIP_TRY(h, h->bs->bounds6.ensure(16));
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, h->stream);
+  launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, h->stream);
   float b12[12];
-  HIP_TRY(h, hipMemcpyAsync(b12, h->bounds6.p, sizeof(b12), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(b12, h->bs->bounds6.p, sizeof(b12), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   float b6[6], ext = 0.f;
   for (int c = 0; c < 3; ++c) {
@@ -880,7 +925,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   }
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
-  h->grid = g;
+  h->bs->grid = g;
   h->subLen = cell;
   // cut the beams into sub-beams of about one cell
   HIP_TRY(h, h->subCounts.ensure(n + 1));
@@ -888,7 +933,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   HIP_TRY(h, h->beamCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->beamCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
   launch_beam_subcount(h->rawDev.pos, h->rawDev.parent_pos, n, h->subLen, h->subCounts.p, h->beamCtl.p, h->stream);
-  HIP_TRY(h, exclusiveSumU32(h->sortTmp, h->subCounts.p, h->subOffsets.p, n, h->stream));
+  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->subCounts.p, h->subOffsets.p, n, h->stream));
   uint32_t lastOff = 0, lastCnt = 0, maxBits = 0;
   HIP_TRY(h, hipMemcpyAsync(&lastOff, h->subOffsets.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(&lastCnt, h->subCounts.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
@@ -900,20 +945,20 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   memcpy(&h->maxSubLen, &maxBits, 4);
   HIP_TRY(h, h->subCentres.ensure(S * 3 + 4));
   HIP_TRY(h, h->subIds.ensure(S + 1));
-  HIP_TRY(h, h->keysA.ensure(S));
-  HIP_TRY(h, h->keysB.ensure(S));
-  HIP_TRY(h, h->valsA.ensure(S));
-  HIP_TRY(h, h->valsB.ensure(S));
-  HIP_TRY(h, h->hot.ensure(S));
-  HIP_TRY(h, h->cellStart.ensure((size_t)g.ncells + 2));
+  HIP_TRY(h, h->bs->keysA.ensure(S));
+  HIP_TRY(h, h->bs->keysB.ensure(S));
+  HIP_TRY(h, h->bs->valsA.ensure(S));
+  HIP_TRY(h, h->bs->valsB.ensure(S));
+  HIP_TRY(h, h->bs->hot.ensure(S));
+  HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
   launch_beam_expand(h->rawDev.pos, h->rawDev.parent_pos, n, h->subCounts.p, h->subOffsets.p, h->subCentres.p,
                      h->subIds.p, h->stream);
-  launch_cell_keys(h->subCentres.p, h->nsub, g, h->keysA.p, h->valsA.p, h->stream);
-  HIP_TRY(h, sortPairsU32(h->sortTmp, h->keysA.p, h->keysB.p, h->valsA.p, h->valsB.p, h->nsub,
+  launch_cell_keys(h->subCentres.p, h->nsub, g, h->bs->keysA.p, h->bs->valsA.p, h->stream);
+  HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, h->nsub,
                           ilog2ceil(g.ncells + 1), h->stream));
-  launch_sub_hot(h->subCentres.p, h->subIds.p, h->valsB.p, h->nsub, h->hot.p, h->stream);
-  launch_segment_start(h->keysB.p, h->nsub, g.ncells, 0, h->cellStart.p, h->stream);
-  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->cold.p, h->stream);
+  launch_sub_hot(h->subCentres.p, h->subIds.p, h->bs->valsB.p, h->nsub, h->bs->hot.p, h->stream);
+  launch_segment_start(h->bs->keysB.p, h->nsub, g.ncells, 0, h->bs->cellStart.p, h->stream);
+  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->bs->cold.p, h->stream);
   HIP_TRY(h, hipGetLastError());
   return GVPM_OK;
 }
@@ -922,11 +967,11 @@ static int buildBeamGrid(gvpm_context *h, float r) {
 static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
   const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
-  if (h->photonsDirty || r != h->builtRadius) {
+  if (h->photonsDirty || r != h->bs->builtRadius) {
     int rc = buildBeamGrid(h, r);
     if (rc != GVPM_OK) return rc;
     h->photonsDirty = false;
-    h->builtRadius = r;
+    h->bs->builtRadius = r;
   }
   if (h->beamsDirty) {
     int rc = sortBeams(h);
@@ -944,12 +989,12 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
-  HIP_TRY(h, h->items.ensure(plan_items_capacity(h->nsets, h->ntiles, h->beamsPerWave)));
-  HIP_TRY(h, h->queueCtl.ensure(4));
-  HIP_TRY(h, hipMemsetAsync(h->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
-  launch_plan_bre(a, h->beamsPerWave, h->ntiles, h->planTarget, h->items.p, h->queueCtl.p, nullptr, nullptr, h->stream);
+  HIP_TRY(h, h->bs->items.ensure(plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave)));
+  HIP_TRY(h, h->bs->queueCtl.ensure(4));
+  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
+  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr, h->stream);
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_beams(a, h->beamsPerWave, h->items.p, h->queueCtl.p, h->queueCtl.p + 1, h->nwaves, h->stream);
+  launch_gather_beams(a, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
@@ -979,7 +1024,7 @@ static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
     pa.test = h->planeTest.p;
     launch_plane_records(pa, h->planeTest.p, h->stream);
     h->photonsDirty = false;
-    h->builtRadius = -1.f;
+    h->bs->builtRadius = -1.f;
   }
   pa.test = h->planeTest.p;
   if (h->beamsDirty) {
@@ -992,8 +1037,8 @@ static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
   fillArgs(h, a, 0.f);
   // enough (tile, plane chunk) items to fill the chip; chunks of at least 256 planes
   uint32_t nchunks = 1;
-  if (h->ntiles && h->nph) {
-    nchunks = (4u * h->nwaves + h->ntiles - 1) / h->ntiles;
+  if (h->bs->ntiles && h->nph) {
+    nchunks = (4u * h->nwaves + h->bs->ntiles - 1) / h->bs->ntiles;
     nchunks = std::max(1u, std::min(nchunks, (h->nph + 255u) / 256u));
     nchunks = std::min(nchunks, 65535u);
     pa.planesPerItem = (h->nph + nchunks - 1) / nchunks;
@@ -1003,7 +1048,7 @@ static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_planes(a, pa, h->ntiles, nchunks, h->stream);
+  launch_gather_planes(a, pa, h->bs->ntiles, nchunks, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
@@ -1027,11 +1072,11 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   float maxScale;
   memcpy(&maxScale, &bits, 4);
   const float rmax = (h->cfg.bsphere_radius * 0.01f) * maxScale;
-  if (h->photonsDirty || rmax != h->builtRadius) {
+  if (h->photonsDirty || rmax != h->bs->builtRadius) {
     int rc = buildGrid(h, rmax);
     if (rc != GVPM_OK) return rc;
     h->photonsDirty = false;
-    h->builtRadius = rmax;
+    h->bs->builtRadius = rmax;
   }
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
@@ -1057,6 +1102,7 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   if (!h->haveMedium || !h->havePhotons || !h->haveBeams)
     return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
   h->useAll = false;
+  h->bstream = h->stream;
   switch (h->cfg.vol_technique) {
     case GVPM_VOL_BRE2D:
     case GVPM_VOL_BRE3D: return gatherBRE(h, it, nb_paths);

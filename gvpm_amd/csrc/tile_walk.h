@@ -335,11 +335,14 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
         }
         CellBox bx;
         if (boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx)) {
-          const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
-          for (int ri = 0; ri < nranges; ++ri) {
-            uint32_t st, c;
-            boxRange(a, bx, ri, nranges, st, c);
-            cnt += c;
+          // all the row reads of the box are independent: keep several in flight
+          for (int z = bx.bz0; z <= bx.bz1; ++z) {
+            const uint32_t rowz = (uint32_t)z * a.grid.dim[1];
+#pragma unroll 4
+            for (int y = bx.by0; y <= bx.by1; ++y) {
+              const uint32_t row = (rowz + y) * a.grid.dim[0];
+              cnt += a.cellStart[row + bx.bx1 + 1] - a.cellStart[row + bx.bx0];
+            }
           }
         }
       }
@@ -357,15 +360,25 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       const int fl = below ? 63 - __clzll(below) : 0;
       const uint32_t exclFirst = __shfl(excl, fl, 64);
       const int cAFirst = __shfl(cA, fl, 64);
-      if (closes) {
-        const uint32_t staged = incl - exclFirst;
-        if (staged > 0u) {
-          const uint32_t slot = atomicAdd(itemCount, 1u);
+      // one pair of atomics per wave: the closing lanes share the reserved slots / blocks
+      const uint32_t staged = incl - exclFirst;
+      const bool emit = closes && staged > 0u;
+      const unsigned long long emitMask = __ballot(emit);
+      if (emitMask) {
+        const uint32_t blocks = emit ? (uint32_t)(((unsigned long long)staged * nb + 63ull) / 64ull) : 0u;
+        const uint32_t bIncl = wave_scan_incl(blocks, lane);
+        const uint32_t bTotal = __shfl(bIncl, 63, 64);
+        uint32_t slot0 = 0, blk0 = 0;
+        if (lane == 0) {
+          slot0 = atomicAdd(itemCount, (uint32_t)__popcll(emitMask));
+          if (itemOff) blk0 = atomicAdd(blockTotal, bTotal);
+        }
+        slot0 = __shfl(slot0, 0, 64);
+        blk0 = __shfl(blk0, 0, 64);
+        if (emit) {
+          const uint32_t slot = slot0 + (uint32_t)__popcll(emitMask & ((1ull << lane) - 1ull));
           items[slot] = make_uint4(setBase, nb, (uint32_t)cAFirst, (uint32_t)cAe);
-          if (itemOff) {
-            const uint32_t blocks = (uint32_t)(((unsigned long long)staged * nb + 63ull) / 64ull);
-            itemOff[slot] = make_uint2(atomicAdd(blockTotal, blocks), staged);
-          }
+          if (itemOff) itemOff[slot] = make_uint2(blk0 + (bIncl - blocks), staged);
         }
       }
     }
