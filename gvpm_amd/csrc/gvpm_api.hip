@@ -128,6 +128,9 @@ struct BuildSet {
   DevBuf<uint4> items;
   DevBuf<uint2> itemOff;
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
+  // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
+  DevBuf<uint32_t> pairs, pairCnt;
+  hipEvent_t traversed = nullptr;  // recorded on the build stream after the traversal kernel
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
   void release() {
@@ -137,8 +140,10 @@ struct BuildSet {
     if (sortTmp.d) (void)hipFree(sortTmp.d);
     sortTmp.d = nullptr;
     sortTmp.bytes = 0;
+    pairs.release(); pairCnt.release();
     if (lastUse) (void)hipEventDestroy(lastUse);
-    lastUse = nullptr;
+    if (traversed) (void)hipEventDestroy(traversed);
+    lastUse = traversed = nullptr;
   }
 };
 
@@ -221,8 +226,7 @@ struct gvpm_context {
   uint32_t nwaves = 2048;      // persistent gather waves
   uint32_t ncu = 256;
   uint32_t nwavesTrav = 4096;  // persistent traversal waves (G-BRE)
-  // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
-  DevBuf<uint32_t> pairs, pairCnt;  // per item and beam: photon index lists + their lengths
+  // per item and beam: photon index lists + their lengths
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -289,7 +293,9 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->streamB, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[0].lastUse, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->sets[1].lastUse, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->sets[1].lastUse, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->sets[0].traversed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->sets[1].traversed, hipEventDisableTiming) != hipSuccess) {
     gvpm_destroy(h);
     return GVPM_ERR_HIP;
   }
@@ -354,7 +360,6 @@ int gvpm_destroy(gvpm_context *h) {
     }
   if (h->streamB) (void)hipStreamSynchronize(h->streamB);
   for (BuildSet &b : h->sets) b.release();
-  h->pairs.release(); h->pairCnt.release();
   h->tri4.release(); h->bvh.release();
   h->rawF.release(); h->rawU.release();
   h->raysOwned.release();
@@ -841,32 +846,38 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   if (rebuilt) HIP_TRY(h, hipMemcpyAsync(h->pinCtl + 1, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
   HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
-  h->bstream = h->stream;
   const uint32_t blocks = h->pinCtl[0];
   if (rebuilt) h->nearOverflow = h->cfg.visibility_as_written && h->ntri <= 254u && h->pinCtl[1] != 0;
   if (h->boundsPending) {
     h->boundsPending = false;
     for (int c = 0; c < 6; ++c)
-      if (!std::isfinite(h->pinB6[c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
+      if (!std::isfinite(h->pinB6[c])) {
+        h->bstream = h->stream;
+        return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
+      }
     memcpy(h->cachedB6, h->pinB6, sizeof(h->cachedB6));
   }
-  // the pair buffer and the per-item counts live on the gather stream only
-  if ((size_t)blocks * 64u + 64u > h->pairs.cap || (size_t)itemCap * h->beamsPerWave > h->pairCnt.cap)
-    HIP_TRY(h, hipStreamSynchronize(h->stream));  // a regrowth frees memory the previous step may still read
-  HIP_TRY(h, h->pairs.ensure((size_t)blocks * 64u + 64u));
-  HIP_TRY(h, h->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
-  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  // the traversal also runs on the build stream (this set's own pair buffer): only the evaluation
+  // kernels of consecutive steps are serialised on the gather stream
+  HIP_TRY(h, h->bs->pairs.ensure((size_t)blocks * 64u + 64u));
+  HIP_TRY(h, h->bs->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
   rc = nextEvents(h, &evTrav, 1);
-  if (rc != GVPM_OK) return rc;
-  rc = nextEvents(h, &evEval, 0);
-  if (rc != GVPM_OK) return rc;
-  HIP_TRY(h, hipEventRecord(evTrav->first, h->stream));
-  launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->pairs.p,
-                      h->pairCnt.p, h->nwavesTrav, h->stream);
-  HIP_TRY(h, hipEventRecord(evTrav->second, h->stream));
+  if (rc == GVPM_OK) rc = nextEvents(h, &evEval, 0);
+  if (rc != GVPM_OK) {
+    h->bstream = h->stream;
+    return rc;
+  }
+  HIP_TRY(h, hipEventRecord(evTrav->first, h->bstream));
+  launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
+                      h->bs->pairs.p, h->bs->pairCnt.p, h->nwavesTrav, h->bstream);
+  HIP_TRY(h, hipEventRecord(evTrav->second, h->bstream));
+  HIP_TRY(h, hipEventRecord(h->bs->traversed, h->bstream));
+  h->bstream = h->stream;
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
   launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
-                      h->bs->queueCtl.p + 2, h->pairs.p, h->pairCnt.p, h->nwaves, h->stream);
+                      h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
   HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
   h->bs->used = true;
