@@ -1,7 +1,7 @@
 #!/bin/bash
 # bash scripts/sweep.sh "VAR=a,b,c" "VAR2=x,y" ...  -> runs bench.py for the cartesian product
 run() {
-  out=$(env "$@" timeout 300 python bench.py --steps 4 --warmup 1 --distinct 2 --no-cpu-baseline 2>/dev/null | tail -1)
+  out=$(env "$@" timeout 300 python bench.py ${SWEEP_ARGS:---steps 4 --warmup 1 --distinct 2} --no-cpu-baseline 2>/dev/null | tail -1)
   echo "$* :: $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("%.0f Mev/s step %.2f ms kernel %.2f ms" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_avg_ms"]))')"
 }
 combos=("")
