@@ -74,6 +74,19 @@ __global__ __launch_bounds__(256) void cell_key_kernel(const float *__restrict__
   vals[i] = i;
 }
 
+// counting sort, pass 1: key of every photon, its arrival rank within the cell, photons per cell
+__global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict__ pos, uint32_t n, Grid g,
+                                                         uint32_t *keys, uint32_t *rank, uint32_t *count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cx = cellCoord(pos[3 * (size_t)i + 0], g.org[0], g.invCell, g.dim[0]);
+  const int cy = cellCoord(pos[3 * (size_t)i + 1], g.org[1], g.invCell, g.dim[1]);
+  const int cz = cellCoord(pos[3 * (size_t)i + 2], g.org[2], g.invCell, g.dim[2]);
+  const uint32_t k = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+  keys[i] = k;
+  rank[i] = atomicAdd(&count[k], 1u);
+}
+
 // ---- reorder: SoA upload layout -> sorted hot/cold planes ----------------------------------
 struct RawPhotons {
   const float *pos, *wi, *flux, *parent_pos, *parent_n, *prefix_w, *parent_scat, *parent_wi;
@@ -122,12 +135,16 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *tri4, uint32_t
   }
 }
 
-__global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ order, uint32_t n,
+// counting sort, pass 3: photon `src` (reads in upload order: coalesced) goes to slot cellStart[key] + rank
+// (whole 128-byte records: full-line writes)
+__global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ rank,
+                                                      const uint32_t *__restrict__ cellStart, uint32_t n,
                                                       gvpm_params cfg, const float4 *tri4, uint32_t ntri,
                                                       float dmax, float4 *hot, float4 *cold, uint32_t *overflow) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t src = order[i];
+  const uint32_t src = blockIdx.x * blockDim.x + threadIdx.x;
+  if (src >= n) return;
+  const uint32_t i = cellStart[keys[src]] + rank[src];
   uint32_t bits = r.flags[src] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
   if (photonContributes(bits, cfg)) bits |= 1u << 6;
   bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
@@ -177,6 +194,39 @@ __global__ __launch_bounds__(256) void beam_key_kernel(const gvpm_camera_ray *__
   const uint32_t inTile = (py % th) * tw + px % tw;
   keys[i] = ((tile * (uint32_t)(tw * th) + inTile) << 3) | (GVPM_RAY_EDGE(b.info) & 7u);
   vals[i] = i;
+}
+
+// counting sort of the beam sets by the same key
+__global__ __launch_bounds__(256) void beam_count_kernel(const gvpm_camera_ray *__restrict__ rays, uint32_t nsets,
+                                                         int width, int tw, int th, uint32_t *keys, uint32_t *rank,
+                                                         uint32_t *count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsets) return;
+  const gvpm_camera_ray &b = rays[(size_t)i * 5];
+  const uint32_t px = b.pixel & 0xFFFFu, py = b.pixel >> 16;
+  const uint32_t tilesX = (width + tw - 1) / tw;
+  const uint32_t tile = (py / th) * tilesX + px / tw;
+  const uint32_t inTile = (py % th) * tw + px % tw;
+  const uint32_t k = ((tile * (uint32_t)(tw * th) + inTile) << 3) | (GVPM_RAY_EDGE(b.info) & 7u);
+  keys[i] = k;
+  rank[i] = atomicAdd(&count[k], 1u);
+}
+
+__global__ __launch_bounds__(256) void beam_scatter_kernel(const uint32_t *__restrict__ keys,
+                                                           const uint32_t *__restrict__ rank,
+                                                           const uint32_t *__restrict__ start, uint32_t n,
+                                                           uint32_t *setPerm) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  setPerm[start[keys[i]] + rank[i]] = i;
+}
+
+// tileStart[t] = first slot of tile t = start[t << shift]; start has (ntiles << shift) + 1 entries
+__global__ __launch_bounds__(256) void tile_start_kernel(const uint32_t *__restrict__ start, uint32_t ntiles,
+                                                         uint32_t shift, uint32_t *tileStart) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  tileStart[t] = start[(size_t)t << shift];
 }
 
 // ---- host-side drivers -------------------------------------------------------------------------
@@ -251,19 +301,37 @@ void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *key
   hipLaunchKernelGGL(cell_key_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, vals);
 }
 
-void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
-                    const float4 *tri4, uint32_t ntri, float dmax, float4 *hot, float4 *cold, uint32_t *overflow,
-                    hipStream_t s) {
+void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(cell_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, rank, count);
+}
+
+void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
+                    uint32_t n, const gvpm_params &cfg, const float4 *tri4, uint32_t ntri, float dmax, float4 *hot,
+                    float4 *cold, uint32_t *overflow, hipStream_t s) {
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, order, n, cfg, tri4, ntri, dmax, hot, cold,
-                     overflow);
+  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, keys, rank, cellStart, n, cfg, tri4, ntri,
+                     dmax, hot, cold, overflow);
 }
 
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
                           hipStream_t s) {
   hipLaunchKernelGGL(segment_start_kernel, dim3((nseg + 1 + 255) / 256), dim3(256), 0, s, keys, n, nseg, shift, start);
+}
+
+void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
+                       uint32_t *rank, uint32_t *count, hipStream_t s) {
+  hipLaunchKernelGGL(beam_count_kernel, dim3((nsets + 255) / 256), dim3(256), 0, s, rays, nsets, width, tw, th, keys,
+                     rank, count);
+}
+void launch_beam_scatter(const uint32_t *keys, const uint32_t *rank, const uint32_t *start, uint32_t n,
+                         uint32_t *setPerm, hipStream_t s) {
+  hipLaunchKernelGGL(beam_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, rank, start, n, setPerm);
+}
+void launch_tile_start(const uint32_t *start, uint32_t ntiles, uint32_t shift, uint32_t *tileStart, hipStream_t s) {
+  hipLaunchKernelGGL(tile_start_kernel, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, s, start, ntiles, shift, tileStart);
 }
 
 void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,

@@ -20,9 +20,16 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
                         uint32_t n, int endBit, hipStream_t s);
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
-void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *order, uint32_t n, const gvpm_params &cfg,
-                    const float4 *tri4, uint32_t ntri, float dmax, float4 *hot, float4 *cold, uint32_t *overflow,
-                    hipStream_t s);
+void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
+                       hipStream_t s);
+void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
+                    uint32_t n, const gvpm_params &cfg, const float4 *tri4, uint32_t ntri, float dmax, float4 *hot,
+                    float4 *cold, uint32_t *overflow, hipStream_t s);
+void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
+                       uint32_t *rank, uint32_t *count, hipStream_t s);
+void launch_beam_scatter(const uint32_t *keys, const uint32_t *rank, const uint32_t *start, uint32_t n,
+                         uint32_t *setPerm, hipStream_t s);
+void launch_tile_start(const uint32_t *start, uint32_t ntiles, uint32_t shift, uint32_t *tileStart, hipStream_t s);
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
                           hipStream_t s);
 void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
@@ -119,7 +126,8 @@ struct BuildSet {
   float builtRadius = -1.f;
   DevBuf<float4> hot, cold;
   DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
-  DevBuf<uint32_t> cellStart, keysA, keysB, valsA, valsB;
+  DevBuf<uint32_t> cellStart, cellCount, keysA, keysB, valsA, valsB;
+  DevBuf<uint32_t> beamCount, beamStart;  // counting sort of the beam sets
   DevBuf<float> boundsPartial, bounds6;
   Grid grid;
   SortTemp sortTmp;
@@ -134,7 +142,8 @@ struct BuildSet {
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
   void release() {
-    hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); keysA.release(); keysB.release();
+    hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); cellCount.release();
+    beamCount.release(); beamStart.release(); keysA.release(); keysB.release();
     valsA.release(); valsB.release(); boundsPartial.release(); bounds6.release(); bKeysA.release(); bKeysB.release();
     bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); queueCtl.release();
     if (sortTmp.d) (void)hipFree(sortTmp.d);
@@ -155,6 +164,7 @@ struct gvpm_context {
   BuildSet sets[2];
   BuildSet *bs = &sets[0];
   int setIdx = 0;
+  bool pipeline = true;           // GVPM_PIPELINE=0: everything on the gather stream (isolated kernel timings)
   gvpm_params cfg;
   gvpm_medium medium;
   bool haveMedium = false;
@@ -327,6 +337,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     int v = atoi(e);
     if (v >= 1 && v <= 32) h->nwavesTrav = h->ncu * (uint32_t)v;
   }
+  if (const char *e = getenv("GVPM_PIPELINE")) h->pipeline = atoi(e) != 0;
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -464,7 +475,7 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
   // G-BRE reads the raw arrays only from its build stream (and is done with them when gvpm_gather
   // returns), so the copy need not wait for the evaluation kernel still running on the gather stream
   const bool bre = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
-  hipStream_t up = bre ? h->streamB : h->stream;
+  hipStream_t up = bre && h->pipeline ? h->streamB : h->stream;
   if (fromDevice) {
     h->rawDev = *p;
   } else {
@@ -686,16 +697,16 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
   h->bs->grid = g;
+  // counting sort by cell (x fastest): count + rank, exclusive scan, scatter
   HIP_TRY(h, h->bs->keysA.ensure(n));
-  HIP_TRY(h, h->bs->keysB.ensure(n));
   HIP_TRY(h, h->bs->valsA.ensure(n));
-  HIP_TRY(h, h->bs->valsB.ensure(n));
   HIP_TRY(h, h->bs->hot.ensure(n));
   HIP_TRY(h, h->bs->cold.ensure((size_t)n * GVPM_REC_QUADS));
+  HIP_TRY(h, h->bs->cellCount.ensure((size_t)g.ncells + 2));
   HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
-  launch_cell_keys(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bstream);
-  HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, n,
-                          ilog2ceil(g.ncells + 1), h->bstream));
+  HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
+  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, h->bstream);
+  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
   // longest possible reconnection segment: diagonal of (occluders U photons), generously padded
   float diag2 = 0.f;
   for (int c = 0; c < 3; ++c) {
@@ -706,9 +717,8 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
   HIP_TRY(h, h->bs->overflowCtr.ensure(2));
   HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
-  launch_reorder(h->rawDev, h->bs->valsB.p, n, h->cfg, h->tri4.p, h->ntri, dmax, h->bs->hot.p, h->bs->cold.p, h->bs->overflowCtr.p,
-                 h->bstream);
-  launch_segment_start(h->bs->keysB.p, n, g.ncells, 0, h->bs->cellStart.p, h->bstream);
+  launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->tri4.p, h->ntri, dmax,
+                 h->bs->hot.p, h->bs->cold.p, h->bs->overflowCtr.p, h->bstream);
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
   if (!deferred && h->cfg.visibility_as_written && h->ntri <= 254u) {
@@ -730,16 +740,20 @@ static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
   h->bs->ntiles = tilesX * tilesY;
   HIP_TRY(h, h->bs->tileStart.ensure((size_t)h->bs->ntiles + 2));
   HIP_TRY(h, h->bs->bKeysA.ensure(n + 1));
-  HIP_TRY(h, h->bs->bKeysB.ensure(n + 1));
   HIP_TRY(h, h->bs->bValsA.ensure(n + 1));
   HIP_TRY(h, h->bs->setPerm.ensure(n + 1));
   if (n) {
-    launch_beam_keys(h->raysDev, n, h->cfg.width, tw, th, h->bs->bKeysA.p, h->bs->bValsA.p, h->bstream);
+    // counting sort by (tile, pixel in tile, edge): count + rank, exclusive scan, scatter
     const int tileShift = ilog2ceil(tw * th) + 3;
-    const int bits = ilog2ceil(h->bs->ntiles + 1) + tileShift;
-    HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->bKeysA.p, h->bs->bKeysB.p, h->bs->bValsA.p, h->bs->setPerm.p, n,
-                            bits > 32 ? 32 : bits, h->bstream));
-    launch_segment_start(h->bs->bKeysB.p, n, h->bs->ntiles, tileShift, h->bs->tileStart.p, h->bstream);
+    const uint64_t nkeys = (uint64_t)h->bs->ntiles << tileShift;
+    if (nkeys > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "film too large for the beam sort");
+    HIP_TRY(h, h->bs->beamCount.ensure(nkeys + 2));
+    HIP_TRY(h, h->bs->beamStart.ensure(nkeys + 2));
+    HIP_TRY(h, hipMemsetAsync(h->bs->beamCount.p, 0, (nkeys + 1) * sizeof(uint32_t), h->bstream));
+    launch_beam_count(h->raysDev, n, h->cfg.width, tw, th, h->bs->bKeysA.p, h->bs->bValsA.p, h->bs->beamCount.p, h->bstream);
+    HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->beamCount.p, h->bs->beamStart.p, (uint32_t)nkeys + 1, h->bstream));
+    launch_beam_scatter(h->bs->bKeysA.p, h->bs->bValsA.p, h->bs->beamStart.p, n, h->bs->setPerm.p, h->bstream);
+    launch_tile_start(h->bs->beamStart.p, h->bs->ntiles, (uint32_t)tileShift, h->bs->tileStart.p, h->bstream);
   } else {
     HIP_TRY(h, hipMemsetAsync(h->bs->tileStart.p, 0, ((size_t)h->bs->ntiles + 1) * sizeof(uint32_t), h->bstream));
   }
@@ -806,7 +820,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav, *evEval;
   int rc = nextEvents(h, &evBuild, 2);
   if (rc != GVPM_OK) return rc;
-  h->bstream = h->streamB;
+  h->bstream = h->pipeline ? h->streamB : h->stream;
   bool rebuilt = false;
   if (h->photonsDirty || h->beamsDirty || r != h->bs->builtRadius) {
     // the other set; wait until the kernels that last read it are done
