@@ -49,12 +49,24 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float *__restrict__ p
   }
 }
 
-__global__ void bounds_final_kernel(const float *partial, int nblocks, float *out6) {
+// hostOut (optional): device-visible pinned host memory -- the result lands there without a copy
+// operation in the stream (copy engines and the streams' kernels do not overlap reliably)
+__global__ void bounds_final_kernel(const float *partial, int nblocks, float *out6, float *hostOut) {
   const int c = threadIdx.x;
   if (c >= 6) return;
   float v = partial[c];
   for (int b = 1; b < nblocks; ++b) v = c < 3 ? fminf(v, partial[b * 6 + c]) : fmaxf(v, partial[b * 6 + c]);
   out6[c] = v;
+  if (hostOut) hostOut[c] = v;
+}
+
+// counters -> pinned host memory (same reason)
+__global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, uint32_t *hostOut) {
+  if (threadIdx.x == 0) {
+    hostOut[0] = a ? *a : 0u;
+    hostOut[1] = b ? *b : 0u;
+    __threadfence_system();
+  }
 }
 
 // ---- cell keys ---------------------------------------------------------------------------
@@ -251,6 +263,14 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
   return hipcub::DeviceRadixSort::SortPairs(tmp.d, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
 }
 
+// make the temporary large enough for scans of up to n elements
+hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n) {
+  size_t need = 0;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0);
+  if (e != hipSuccess) return e;
+  return ensureTemp(tmp, need);
+}
+
 hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s) {
   size_t need = 0;
   hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, s);
@@ -292,9 +312,14 @@ void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n,
   hipLaunchKernelGGL(beam_cold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, endN, n, cfg, cold);
 }
 
-void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s) {
+void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
+                   hipStream_t s) {
   hipLaunchKernelGGL(bounds_kernel, dim3(nblocks), dim3(256), 0, s, pos, n, partial);
-  hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6);
+  hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6, hostOut);
+}
+
+void launch_export_u32(const uint32_t *a, const uint32_t *b, uint32_t *hostOut, hipStream_t s) {
+  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, hostOut);
 }
 
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {

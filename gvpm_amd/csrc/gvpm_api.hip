@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -18,7 +20,10 @@
 namespace gvpm {
 hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut,
                         uint32_t n, int endBit, hipStream_t s);
-void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, hipStream_t s);
+void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
+                   hipStream_t s);
+hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, uint32_t *hostOut, hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
                        hipStream_t s);
@@ -133,6 +138,7 @@ struct BuildSet {
   SortTemp sortTmp;
   DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
   uint32_t ntiles = 0;
+  bool scanSized = false;
   DevBuf<uint4> items;
   DevBuf<uint2> itemOff;
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
@@ -164,6 +170,7 @@ struct gvpm_context {
   BuildSet sets[2];
   BuildSet *bs = &sets[0];
   int setIdx = 0;
+  bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
   bool pipeline = true;           // GVPM_PIPELINE=0: everything on the gather stream (isolated kernel timings)
   gvpm_params cfg;
   gvpm_medium medium;
@@ -338,6 +345,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     if (v >= 1 && v <= 32) h->nwavesTrav = h->ncu * (uint32_t)v;
   }
   if (const char *e = getenv("GVPM_PIPELINE")) h->pipeline = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -662,14 +670,15 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   const int nblocks = 256;
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
   HIP_TRY(h, h->bs->bounds6.ensure(8));
-  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, h->bstream);
   float b6[6];
   if (!h->pinB6) {
-    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
-  if (deferred && h->haveCachedBounds) {
-    HIP_TRY(h, hipMemcpyAsync(h->pinB6, h->bs->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->bstream));
+  const bool defer = deferred && h->haveCachedBounds;
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, defer ? h->pinB6 : nullptr,
+                h->bstream);
+  if (defer) {
     h->boundsPending = true;
     memcpy(b6, h->cachedB6, sizeof(b6));
   } else {
@@ -702,8 +711,16 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   HIP_TRY(h, h->bs->valsA.ensure(n));
   HIP_TRY(h, h->bs->hot.ensure(n));
   HIP_TRY(h, h->bs->cold.ensure((size_t)n * GVPM_REC_QUADS));
-  HIP_TRY(h, h->bs->cellCount.ensure((size_t)g.ncells + 2));
-  HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
+  // the radius shrinks every iteration, so the grid grows: size the cell arrays (and the scan's temporary)
+  // for the finest grid the cell rule allows (386^3 cells, 230 MB each) once -- a regrowth is a hipFree,
+  // i.e. a device-wide sync in the middle of the pipeline
+  const size_t worstCells = (size_t)386 * 386 * 386 + 2;
+  HIP_TRY(h, h->bs->cellCount.ensure(std::max((size_t)g.ncells + 2, worstCells)));
+  HIP_TRY(h, h->bs->cellStart.ensure(std::max((size_t)g.ncells + 2, worstCells)));
+  if (!h->bs->scanSized) {
+    HIP_TRY(h, reserveScanTemp(h->bs->sortTmp, (uint32_t)worstCells));
+    h->bs->scanSized = true;
+  }
   HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
   launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, h->bstream);
   HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
@@ -817,6 +834,14 @@ static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, i
 // host waits once (planner counters) and then queues traversal + evaluation on the gather stream.
 static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   const float r = currentRadius(h);
+  static const bool traceHost = getenv("GVPM_TRACE_HOST") != nullptr;
+  auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!traceHost) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host] it=%d %-10s %8.1f us\n", it, what, std::chrono::duration<double, std::micro>(t - T0).count());
+    T0 = t;
+  };
   std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav, *evEval;
   int rc = nextEvents(h, &evBuild, 2);
   if (rc != GVPM_OK) return rc;
@@ -828,8 +853,11 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->bs = &h->sets[h->setIdx];
     if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
     HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
+    lap("waitevent");
     rc = buildGrid(h, r, true);
+    lap("buildGrid");
     if (rc == GVPM_OK) rc = sortBeams(h);
+    lap("sortBeams");
     if (rc != GVPM_OK) {
       h->bstream = h->stream;
       return rc;
@@ -853,13 +881,14 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only) ...
   // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
   if (!h->pinB6) {
-    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
-  HIP_TRY(h, hipMemcpyAsync(h->pinCtl, h->bs->queueCtl.p + 3, 4, hipMemcpyDeviceToHost, h->bstream));
-  if (rebuilt) HIP_TRY(h, hipMemcpyAsync(h->pinCtl + 1, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
+  launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, h->pinCtl, h->bstream);
   HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
+  lap("plan");
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  lap("syncB");
   const uint32_t blocks = h->pinCtl[0];
   if (rebuilt) h->nearOverflow = h->cfg.visibility_as_written && h->ntri <= 254u && h->pinCtl[1] != 0;
   if (h->boundsPending) {
@@ -881,11 +910,12 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->bstream = h->stream;
     return rc;
   }
-  HIP_TRY(h, hipEventRecord(evTrav->first, h->bstream));
+  hipStream_t ts = h->travOnBuild ? h->bstream : h->stream;
+  HIP_TRY(h, hipEventRecord(evTrav->first, ts));
   launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
-                      h->bs->pairs.p, h->bs->pairCnt.p, h->nwavesTrav, h->bstream);
-  HIP_TRY(h, hipEventRecord(evTrav->second, h->bstream));
-  HIP_TRY(h, hipEventRecord(h->bs->traversed, h->bstream));
+                      h->bs->pairs.p, h->bs->pairCnt.p, h->nwavesTrav, ts);
+  HIP_TRY(h, hipEventRecord(evTrav->second, ts));
+  HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
   h->bstream = h->stream;
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
@@ -897,6 +927,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   h->bs->used = true;
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
+  lap("launchK");
   // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
   {
     const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
@@ -925,8 +956,8 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   const int nblocks = 256;
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
   HIP_TRY(h, h->bs->bounds6.ensure(16));
-  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, h->stream);
-  launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, h->stream);
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, nullptr, h->stream);
+  launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, nullptr, h->stream);
   float b12[12];
   HIP_TRY(h, hipMemcpyAsync(b12, h->bs->bounds6.p, sizeof(b12), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
