@@ -441,20 +441,41 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
           const uint32_t nst = min((uint32_t)STAGE, total - win);
           staged += nst;
           const uint32_t iters = (nst + LPB - 1) / LPB;
-          for (uint32_t jj = 0; jj < iters; ++jj) {
-            const uint32_t j = jj * LPB + sub;
-            bool hit = false;
-            if (beamValid && j < nst) {
-              const float4 hp = s.stage[j];
-              const f3 p = mk3(hp.x, hp.y, hp.z);
-              const f3 wv = p - base.o;
-              const float disk = dot(wv, base.d);
-              const f3 v = wv - base.d * disk;
-              const float d2 = dot(v, v);
-              // fp32 with a rigorous error band: E bounds |disk - disk_exact|, band |d2 - d2_exact|
-              const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
-              const float band = 4.f * r * E + r2f * 2e-6f;
-              if (d2 < r2f + band && disk > mint - E && disk < maxt + 2.f * r) {
+          // groups of G staged photons per lane: a branch-free coarse pass marks the candidates (the G LDS
+          // reads overlap), then the wave resolves candidates one per lane and round (~1.5 rounds per
+          // group instead of G passes through the divergent code)
+          constexpr uint32_t G = 4;
+          for (uint32_t jj = 0; jj < iters; jj += G) {
+            uint32_t cm = 0;
+            if (beamValid) {
+#pragma unroll
+              for (uint32_t u = 0; u < G; ++u) {
+                const uint32_t j = (jj + u) * LPB + sub;
+                const float4 hp = s.stage[min(j, (uint32_t)STAGE - 1u)];
+                const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
+                const float disk = dot(wv, base.d);
+                const f3 v = wv - base.d * disk;
+                const float d2 = dot(v, v);
+                const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
+                const float band = 4.f * r * E + r2f * 2e-6f;
+                if (j < nst && d2 < r2f + band && disk > mint - E && disk < maxt + 2.f * r) cm |= 1u << u;
+              }
+            }
+            while (__ballot(cm != 0u)) {
+              bool hit = false, amb = false;
+              uint32_t j = 0;
+              if (cm) {
+                j = (jj + (uint32_t)__ffs(cm) - 1u) * LPB + sub;
+                cm &= cm - 1u;
+                const float4 hp = s.stage[j];
+                const f3 p = mk3(hp.x, hp.y, hp.z);
+                const f3 wv = p - base.o;
+                const float disk = dot(wv, base.d);
+                const f3 v = wv - base.d * disk;
+                const float d2 = dot(v, v);
+                // fp32 with a rigorous error band: E bounds |disk - disk_exact|, band |d2 - d2_exact|
+                const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
+                const float band = 4.f * r * E + r2f * 2e-6f;
                 const uint32_t bits = __float_as_uint(hp.w);
                 // filters, shift_volume_photon.cpp:670-697
                 const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
@@ -465,31 +486,37 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
                 if (a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) keep = false;
                 if (keep) {
                   // decided in fp32 when the error band cannot change the reference's decision ...
-                  bool sure = d2 < r2f - band && disk > mint + E && disk < maxt - E;
-                  if (sure && use3D) {
-                    const float dTup = sqrtf(r2f - d2 + band) * 1.000001f;  // >= exact deltaT
-                    sure = disk - dTup > mint + 2.f * E && disk + dTup < base.len - 2.f * E;
+                  bool in = d2 < r2f - band && disk > mint + E && disk < maxt - E;
+                  bool out = false;
+                  if (in && use3D) {
+                    // t' = (disk - deltaT) + 2 deltaT rnd must lie in [mint, len] (shift_volume_photon.cpp:707-726):
+                    // bracket it with deltaT in [dTlo, dTup]
+                    const float q = r2f - d2;
+                    const float dTup = fsqrt(q + band) * 1.000001f, dTlo = fsqrt(fmaxf(q - band, 0.f)) * 0.999999f;
+                    const float slop = 2.f * E + 4e-7f * (fabsf(disk) + dTup);
+                    const float tLo = (disk - dTup) + 2.f * dTlo * bi.rnd - slop;
+                    const float tHi = (disk - dTlo) + 2.f * dTup * bi.rnd + slop;
+                    in = tLo > mint && tHi < base.len;
+                    out = tHi < mint || tLo > base.len;
                   }
-                  if (sure) {
-                    hit = true;
-                  } else {
-                    // ... otherwise the reference predicate itself, fp64, uncontracted
-                    hit = exactHit(p, base.o, base.d, base.len, r, bi.rnd, eps, use3D);
-                  }
+                  // ... otherwise the pair is passed on flagged: the evaluation kernel runs the reference
+                  // predicate itself (fp64, uncontracted) on it -- about one candidate in 10^5
+                  hit = !out;
+                  amb = !in && !out;
                 }
               }
-            }
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-              // the hits of my beam in this step sit in lanes b, b + B, ...: append in lane order
-              constexpr unsigned long long GROUP = B == 16 ? 0x0001000100010001ull : (B == 32 ? 0x0000000100000001ull : 1ull);
-              const unsigned long long g = (m >> b) & GROUP;
-              if (hit) {
-                const uint32_t off = mine + __popcll(g & ((1ull << (sub * B)) - 1ull));
-                if (off < cap) out[off] = s.stageIdx[j];
-                else nOver++;
+              const unsigned long long m = __ballot(hit);
+              if (m) {
+                // the hits of my beam in this round sit in lanes b, b + B, ...: append in lane order
+                constexpr unsigned long long GROUP = B == 16 ? 0x0001000100010001ull : (B == 32 ? 0x0000000100000001ull : 1ull);
+                const unsigned long long g = (m >> b) & GROUP;
+                if (hit) {
+                  const uint32_t off = mine + __popcll(g & ((1ull << (sub * B)) - 1ull));
+                  if (off < cap) out[off] = s.stageIdx[j] | (amb ? 0x80000000u : 0u);
+                  else nOver++;
+                }
+                mine += __popcll(g);
               }
-              mine += __popcll(g);
             }
           }
         }
@@ -571,8 +598,19 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
             do cur++; while (s.boff[cur + 1] <= g);
           }
           pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
-          if (!skip) evalPhase1<B>(a, s, pidx, cur, acc, nNull, nFail, qMask, tP, pdfCam);
-          nEval++;
+          bool ok = true;
+          if (pidx & 0x80000000u) {
+            // the traversal could not decide this pair in fp32: the reference predicate, fp64, uncontracted
+            pidx &= 0x7FFFFFFFu;
+            const float4 c0 = a.cold[(size_t)pidx * GVPM_REC_QUADS];
+            const RayReg br = loadRay(s, 0, cur);
+            ok = exactHit(mk3(c0.x, c0.y, c0.z), br.o, br.d, br.len, a.radius, s.rnd[cur], a.cfg.epsilon,
+                          a.cfg.vol_technique == GVPM_VOL_BRE3D);
+          }
+          if (ok) {
+            if (!skip) evalPhase1<B>(a, s, pidx, cur, acc, nNull, nFail, qMask, tP, pdfCam);
+            nEval++;
+          }
         }
         for (uint32_t m = qMask; m; m &= m - 1u) {
           const uint32_t sh = (uint32_t)__ffs(m) - 1u;

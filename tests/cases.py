@@ -118,3 +118,15 @@ def numpy_base_flux(c, dtype=np.float64):
         contrib = (tr * phase / (kv * pdf) * rr)[:, None] * flux[idx] * sig_s * b["eye"].astype(dtype)
         out[py, px] += contrib.sum(0)
     return out, evals
+
+
+def tessellate(tris, levels):
+    """Split every triangle (v0, e1, e2 arrays) into 4^levels congruent ones: the same occluder
+    surface with many more primitives (exercises the occluder BVH)."""
+    v0, e1, e2 = (np.asarray(t, np.float64) for t in tris)
+    a, b, c = v0, v0 + e1, v0 + e2
+    for _ in range(levels):
+        ab, bc, ca = (a + b) / 2, (b + c) / 2, (c + a) / 2
+        a, b, c = (np.concatenate(x) for x in ((a, ab, ca, ab), (ab, b, bc, bc), (ca, bc, c, ca)))
+    f = np.float32
+    return np.ascontiguousarray(a, f), np.ascontiguousarray(b - a, f), np.ascontiguousarray(c - a, f)
