@@ -40,6 +40,7 @@ struct GatherArgs {
   const float4 *hot;
   const float4 *cold;        // nph records of GVPM_REC_QUADS float4
   const uint32_t *cellStart; // ncells + 1
+  const uint32_t *sat;       // summed-volume table of the cell counts (planner), (dimx+1)(dimy+1)(dimz+1)
   uint32_t nph;
   Grid grid;
   // camera beam sets (5 x 64 B each), visited through the tile permutation

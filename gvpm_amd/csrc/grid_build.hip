@@ -52,12 +52,26 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float *__restrict__ p
 // hostOut (optional): device-visible pinned host memory -- the result lands there without a copy
 // operation in the stream (copy engines and the streams' kernels do not overlap reliably)
 __global__ void bounds_final_kernel(const float *partial, int nblocks, float *out6, float *hostOut) {
-  const int c = threadIdx.x;
-  if (c >= 6) return;
-  float v = partial[c];
-  for (int b = 1; b < nblocks; ++b) v = c < 3 ? fminf(v, partial[b * 6 + c]) : fmaxf(v, partial[b * 6 + c]);
-  out6[c] = v;
-  if (hostOut) hostOut[c] = v;
+  const int lane = threadIdx.x;  // one wave
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int b = lane; b < nblocks; b += 64)
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = fminf(lo[c], partial[b * 6 + c]);
+      hi[c] = fmaxf(hi[c], partial[b * 6 + 3 + c]);
+    }
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = wave_min(lo[c]);
+    hi[c] = wave_max(hi[c]);
+  }
+  if (lane == 0)
+    for (int c = 0; c < 3; ++c) {
+      out6[c] = lo[c];
+      out6[3 + c] = hi[c];
+      if (hostOut) {
+        hostOut[c] = lo[c];
+        hostOut[3 + c] = hi[c];
+      }
+    }
 }
 
 // counters -> pinned host memory (same reason)
@@ -97,6 +111,41 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict
   const uint32_t k = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
   keys[i] = k;
   rank[i] = atomicAdd(&count[k], 1u);
+}
+
+// ---- summed-volume table over the cell counts: T(x,y,z) = photons in cells {x' < x, y' < y, z' < z},
+// (dimx+1)(dimy+1)(dimz+1) entries, x fastest.  The planner counts the photons of a cell box with 8
+// reads instead of two per cell row.
+// pass Y: S1(x,y,z) = sum_{y' < y} rowPrefix(x,y',z), one thread per (x,z); the row prefixes come
+// straight from cellStart (an exclusive prefix in x-fastest order)
+__global__ __launch_bounds__(256) void sat_y_kernel(const uint32_t *__restrict__ cellStart, Grid g, uint32_t *sat) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nx1 = g.dim[0] + 1, ny1 = g.dim[1] + 1;
+  if (t >= nx1 * (uint32_t)g.dim[2]) return;
+  const uint32_t x = t % nx1, z = t / nx1;
+  uint32_t run = 0;
+  sat[((size_t)z * ny1 + 0) * nx1 + x] = 0u;
+#pragma unroll 8
+  for (int y = 0; y < g.dim[1]; ++y) {
+    const size_t row = ((size_t)z * g.dim[1] + y) * g.dim[0];
+    run += cellStart[row + x] - cellStart[row];
+    sat[((size_t)z * ny1 + (y + 1)) * nx1 + x] = run;
+  }
+}
+// pass Z (in place): T(x,y,z) = sum_{z' < z} S1(x,y,z'), one thread per (x,y)
+__global__ __launch_bounds__(256) void sat_z_kernel(Grid g, uint32_t *sat) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nx1 = g.dim[0] + 1, ny1 = g.dim[1] + 1;
+  if (t >= nx1 * ny1) return;
+  const size_t layer = (size_t)nx1 * ny1;
+  uint32_t run = 0;
+#pragma unroll 8
+  for (int z = 0; z < g.dim[2]; ++z) {
+    const uint32_t v = sat[(size_t)z * layer + t];
+    sat[(size_t)z * layer + t] = run;
+    run += v;
+  }
+  sat[(size_t)g.dim[2] * layer + t] = run;
 }
 
 // ---- reorder: SoA upload layout -> sorted hot/cold planes ----------------------------------
@@ -324,6 +373,12 @@ void launch_export_u32(const uint32_t *a, const uint32_t *b, uint32_t *hostOut, 
 
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {
   hipLaunchKernelGGL(cell_key_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, vals);
+}
+
+void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s) {
+  const uint32_t nx1 = g.dim[0] + 1, ny1 = g.dim[1] + 1;
+  hipLaunchKernelGGL(sat_y_kernel, dim3((nx1 * g.dim[2] + 255) / 256), dim3(256), 0, s, cellStart, g, sat);
+  hipLaunchKernelGGL(sat_z_kernel, dim3((nx1 * ny1 + 255) / 256), dim3(256), 0, s, g, sat);
 }
 
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,

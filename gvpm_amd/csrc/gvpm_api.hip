@@ -25,6 +25,7 @@ void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, fl
 hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
 void launch_export_u32(const uint32_t *a, const uint32_t *b, uint32_t *hostOut, hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
+void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
                        hipStream_t s);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
@@ -131,7 +132,7 @@ struct BuildSet {
   float builtRadius = -1.f;
   DevBuf<float4> hot, cold;
   DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
-  DevBuf<uint32_t> cellStart, cellCount, keysA, keysB, valsA, valsB;
+  DevBuf<uint32_t> cellStart, cellCount, sat, keysA, keysB, valsA, valsB;
   DevBuf<uint32_t> beamCount, beamStart;  // counting sort of the beam sets
   DevBuf<float> boundsPartial, bounds6;
   Grid grid;
@@ -148,7 +149,7 @@ struct BuildSet {
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
   void release() {
-    hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); cellCount.release();
+    hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); cellCount.release(); sat.release();
     beamCount.release(); beamStart.release(); keysA.release(); keysB.release();
     valsA.release(); valsB.release(); boundsPartial.release(); bounds6.release(); bKeysA.release(); bKeysB.release();
     bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); queueCtl.release();
@@ -724,6 +725,12 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
   launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, h->bstream);
   HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
+  if (deferred) {
+    // G-BRE: summed-volume table for the planner (sized once for the finest grid, like the cell arrays)
+    const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
+    HIP_TRY(h, h->bs->sat.ensure(std::max(satCells, (size_t)387 * 387 * 387)));
+    launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->bstream);
+  }
   // longest possible reconnection segment: diagonal of (occluders U photons), generously padded
   float diag2 = 0.f;
   for (int c = 0; c < 3; ++c) {
@@ -788,6 +795,7 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.hot = h->bs->hot.p;
   a.cold = h->bs->cold.p;
   a.cellStart = h->bs->cellStart.p;
+  a.sat = h->bs->sat.p;
   a.nph = h->nph;
   a.grid = h->bs->grid;
   a.rays = h->raysDev;
@@ -1014,6 +1022,11 @@ static int buildBeamGrid(gvpm_context *h, float r) {
                           ilog2ceil(g.ncells + 1), h->stream));
   launch_sub_hot(h->subCentres.p, h->subIds.p, h->bs->valsB.p, h->nsub, h->bs->hot.p, h->stream);
   launch_segment_start(h->bs->keysB.p, h->nsub, g.ncells, 0, h->bs->cellStart.p, h->stream);
+  {
+    const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
+    HIP_TRY(h, h->bs->sat.ensure(satCells));
+    launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->stream);
+  }
   launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->bs->cold.p, h->stream);
   HIP_TRY(h, hipGetLastError());
   return GVPM_OK;
