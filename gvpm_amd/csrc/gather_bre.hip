@@ -529,8 +529,9 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nOver += __shfl_xor(nOver, o, 64);
     if (lane == 0 && (nCand | nOver)) {
-      atomicAdd(&a.stats[1], nCand);
-      if (nOver) atomicAdd(&a.stats[7], nOver);  // must stay 0: the planner's bound is exact
+      unsigned long long *row = a.stats + 8 * (size_t)blockIdx.x;  // this wave's own row
+      row[1] += nCand;
+      if (nOver) row[7] += nOver;  // must stay 0: the planner's bound is exact
     }
   }
 }
@@ -663,10 +664,11 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
       fa += __shfl_xor(fa, o, 64);
     }
     if (lane == 0 && ev) {
-      atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[2], nu);
-      atomicAdd(&a.stats[3], di);
-      atomicAdd(&a.stats[4], fa);
+      unsigned long long *row = a.stats + 8 * (size_t)blockIdx.x;  // this wave's own row
+      row[0] += ev;
+      row[2] += nu;
+      row[3] += di;
+      row[4] += fa;
     }
   }
 }

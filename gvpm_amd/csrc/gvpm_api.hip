@@ -125,6 +125,8 @@ RcclApi g_rccl;
 }  // namespace
 
 #define GVPM_PHASES 3
+// counters: one row of 8 per persistent wave (plain adds, no same-address atomics at kernel end), summed on read
+#define GVPM_STAT_ROWS 8192
 
 // Everything a gather reads that is rebuilt per photon set / beam set.  Two of them: G-BRE builds
 // step N+1 (grid, sorts, planner) on a second stream while the evaluation kernel of step N runs.
@@ -345,6 +347,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     int v = atoi(e);
     if (v >= 1 && v <= 32) h->nwavesTrav = h->ncu * (uint32_t)v;
   }
+  {
+    if (h->nwavesTrav > GVPM_STAT_ROWS) h->nwavesTrav = GVPM_STAT_ROWS;
+    if (h->nwaves > GVPM_STAT_ROWS) h->nwaves = GVPM_STAT_ROWS;
+  }
   if (const char *e = getenv("GVPM_PIPELINE")) h->pipeline = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
@@ -353,7 +359,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   }
   h->npix = (size_t)params->width * params->height;
   if (h->accum.ensure(h->npix * 27) != hipSuccess || h->iter.ensure(h->npix * 27) != hipSuccess ||
-      h->stats.ensure(8) != hipSuccess || h->scaleVol.ensure(h->npix) != hipSuccess ||
+      h->stats.ensure(8 * GVPM_STAT_ROWS) != hipSuccess || h->scaleVol.ensure(h->npix) != hipSuccess ||
       h->nVol.ensure(h->npix) != hipSuccess || h->mvol.ensure(h->npix) != hipSuccess ||
       h->maxScaleBits.ensure(2) != hipSuccess) {
     gvpm_destroy(h);
@@ -398,7 +404,7 @@ int gvpm_destroy(gvpm_context *h) {
 int gvpm_reset(gvpm_context *h) {
   CHECK_H(h);
   HIP_TRY(h, hipMemsetAsync(h->accum.p, 0, h->npix * 27 * sizeof(float), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * sizeof(unsigned long long), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * GVPM_STAT_ROWS * sizeof(unsigned long long), h->stream));
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
   for (size_t &u : h->eventsUsed) u = 0;
   h->useAll = false;
@@ -1207,9 +1213,13 @@ int gvpm_set_global_scale(gvpm_context *h, float s) {
 int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   CHECK_H(h);
   if (!out) return GVPM_ERR_INVALID_ARG;
-  unsigned long long v[8];
-  HIP_TRY(h, hipMemcpyAsync(v, h->stats.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+  std::vector<unsigned long long> rows(8 * (size_t)GVPM_STAT_ROWS);
+  HIP_TRY(h, hipMemcpyAsync(rows.data(), h->stats.p, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                            h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (size_t r = 0; r < GVPM_STAT_ROWS; ++r)
+    for (int k = 0; k < 8; ++k) v[k] += rows[8 * r + k];
   memset(out, 0, sizeof(*out));
   out->evaluations = v[0];
   out->candidates = v[1];
