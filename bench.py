@@ -149,6 +149,16 @@ def main():
         # algorithmic bytes per gather-kernel launch (BASELINE.md / SURVEY 8d convention)
         bytes_alg = 128.0 * (evals / K) + 320.0 * nsets_avg + 108.0 * P + 128.0 * nph_avg
         achieved = bytes_alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC passes of scripts/profile.sh on this same
+        # command (2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes), recorded under profiles/
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and args.tile == 512 and args.photons == 1000000:
+            try:
+                traffic = json.load(open(tj))["evaluate_bre_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/profile.sh)"
+            except (KeyError, ValueError):
+                pass
         out = {
             "metric": "photon gather+shift evaluations per second (G-BRE 3D)",
             "value": evals_total / elapsed / 1e6,
@@ -173,9 +183,11 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "evaluate_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
                 "traverse_avg_ms": ctx.phase_time(1)[0], "build_avg_ms": ctx.phase_time(2)[0],
+                "note": "build + traversal of step N+1 run on a second stream while this kernel evaluates step N: "
+                        "the durations include that sharing (GVPM_PIPELINE=0 gives the isolated ones)",
                 "bytes_alg_per_launch": bytes_alg,
             },
             "stats": st,
