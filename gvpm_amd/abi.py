@@ -186,3 +186,10 @@ def triangles_struct(v0, e1, e2):
     t = Triangles()
     t.v0, t.e1, t.e2, t.n = v0.ctypes.data, e1.ctypes.data, e2.ctypes.data, v0.shape[0]
     return t, (v0, e1, e2)
+
+
+class PoissonParams(C.Structure):
+    """gvpm_poisson_params: Solver::Params' solver configuration (poisson_solver/Solver.hpp:81-88)."""
+    _fields_ = [("alpha", C.c_float), ("irls_iter_max", C.c_int32), ("irls_reg_init", C.c_float),
+                ("irls_reg_iter", C.c_float), ("cg_iter_max", C.c_int32), ("cg_iter_check", C.c_int32),
+                ("cg_precond", C.c_int32), ("cg_tolerance", C.c_float)]

@@ -49,6 +49,9 @@ void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, co
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                          uint32_t nwaves, hipStream_t stream);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
+hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, const float *dx, const float *dy,
+                                const float *tp, const float *direct, float *out, void *scratch, hipStream_t s);
+size_t poisson_scratch_bytes(int W, int H);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
@@ -248,6 +251,9 @@ struct gvpm_context {
   uint32_t nwavesTrav = 4096;  // persistent traversal waves (G-BRE)
   // per item and beam: photon index lists + their lengths
 
+  // reconstruction scratch
+  DevBuf<float> poissonScratch, poissonIO;
+
   // multi-GPU
   ncclComm_t comm = nullptr;
 };
@@ -393,6 +399,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->subIds.release(); h->beamCtl.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
+  h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1299,6 +1306,57 @@ int gvpm_synchronize(gvpm_context *h) {
 }
 
 // ---- multi-GPU: RCCL all-reduce of the accumulators over xGMI -----------------------------
+int gvpm_poisson_preset(const char *preset, gvpm_poisson_params *p) {
+  if (!preset || !p) return GVPM_ERR_INVALID_ARG;
+  // base config, Solver.cpp:95-101
+  p->alpha = 0.2f;
+  p->irls_iter_max = 1; p->irls_reg_init = 0.f; p->irls_reg_iter = 0.f;
+  p->cg_iter_max = 1; p->cg_iter_check = 100; p->cg_precond = 0; p->cg_tolerance = 0.f;
+  if (!strcmp(preset, "L1D")) { p->irls_iter_max = 20; p->irls_reg_init = 0.05f; p->irls_reg_iter = 0.5f; p->cg_iter_max = 50; return GVPM_OK; }
+  if (!strcmp(preset, "L1Q")) { p->irls_iter_max = 64; p->irls_reg_init = 1.0f; p->irls_reg_iter = 0.7f; p->cg_iter_max = 1000; return GVPM_OK; }
+  if (!strcmp(preset, "L1L")) { p->irls_iter_max = 7; p->irls_reg_init = 1.0e-4f; p->irls_reg_iter = 1.0e-1f; p->cg_iter_max = 20000; p->cg_tolerance = 1.0e-20f; return GVPM_OK; }
+  if (!strcmp(preset, "L2D")) { p->cg_iter_max = 50; return GVPM_OK; }
+  if (!strcmp(preset, "L2Q")) { p->cg_iter_max = 500; return GVPM_OK; }
+  return GVPM_ERR_INVALID_ARG;
+}
+
+static int poissonCommon(gvpm_context *h, const gvpm_poisson_params *prm, int W, int H, const float *dx, const float *dy,
+                         const float *tp, const float *direct, float *out, bool fromDevice) {
+  if (!prm || !dx || !dy || !out) return fail(h, GVPM_ERR_INVALID_ARG, "null argument");
+  if (W <= 0 || H <= 0 || (uint64_t)W * H > 0x7FFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "bad image size");
+  if (prm->cg_precond) return fail(h, GVPM_ERR_UNSUPPORTED, "cgPrecond is not supported (no preset of the reference enables it)");
+  const size_t n3 = (size_t)W * H * 3;
+  HIP_TRY(h, h->poissonScratch.ensure(poisson_scratch_bytes(W, H) / sizeof(float) + 16));
+  const float *ddx = dx, *ddy = dy, *dtp = tp, *ddir = direct;
+  float *dout = out;
+  if (!fromDevice) {
+    HIP_TRY(h, h->poissonIO.ensure(5 * n3));
+    float *io = h->poissonIO.p;
+    HIP_TRY(h, hipMemcpyAsync(io, dx, n3 * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(io + n3, dy, n3 * 4, hipMemcpyHostToDevice, h->stream));
+    if (tp) HIP_TRY(h, hipMemcpyAsync(io + 2 * n3, tp, n3 * 4, hipMemcpyHostToDevice, h->stream));
+    if (direct) HIP_TRY(h, hipMemcpyAsync(io + 3 * n3, direct, n3 * 4, hipMemcpyHostToDevice, h->stream));
+    ddx = io; ddy = io + n3; dtp = tp ? io + 2 * n3 : nullptr; ddir = direct ? io + 3 * n3 : nullptr; dout = io + 4 * n3;
+  }
+  HIP_TRY(h, poisson_solve_device(*prm, W, H, ddx, ddy, dtp, ddir, dout, h->poissonScratch.p, h->stream));
+  if (!fromDevice) {
+    HIP_TRY(h, hipMemcpyAsync(out, dout, n3 * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return GVPM_OK;
+}
+
+int gvpm_poisson_solve(gvpm_context *h, const gvpm_poisson_params *params, int width, int height, const float *dx,
+                       const float *dy, const float *throughput, const float *direct, float *out) {
+  CHECK_H(h);
+  return poissonCommon(h, params, width, height, dx, dy, throughput, direct, out, false);
+}
+int gvpm_poisson_solve_dev(gvpm_context *h, const gvpm_poisson_params *params, int width, int height, const float *dx,
+                           const float *dy, const float *throughput, const float *direct, float *out) {
+  CHECK_H(h);
+  return poissonCommon(h, params, width, height, dx, dy, throughput, direct, out, true);
+}
+
 int gvpm_comm_unique_id(void *id128) {
   if (!id128) return GVPM_ERR_INVALID_ARG;
   if (!g_rccl.load()) return GVPM_ERR_COMM;

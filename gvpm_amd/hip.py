@@ -23,7 +23,7 @@ SYMBOLS = [
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_get_phase_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
-    "gvpm_allreduce_accum",
+    "gvpm_allreduce_accum", "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
 ]
 
 
@@ -74,6 +74,9 @@ def lib():
         L.gvpm_comm_unique_id.argtypes = [vp]
         L.gvpm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         L.gvpm_allreduce_accum.argtypes = [vp]
+        L.gvpm_poisson_preset.argtypes = [C.c_char_p, C.POINTER(abi.PoissonParams)]
+        L.gvpm_poisson_solve.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.gvpm_poisson_solve_dev.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -212,8 +215,31 @@ class Context:
         buf = (C.c_char * 128).from_buffer_copy(id128)
         self._check(lib().gvpm_comm_init(self._h, buf, rank, world))
 
+    def poisson_solve(self, dx, dy, throughput, direct=None, preset="L1D", alpha=0.2, params=None):
+        """Screened-Poisson reconstruction (H, W, 3) float32 -> (H, W, 3); params overrides the preset."""
+        if params is None:
+            params = poisson_preset(preset)
+            params.alpha = alpha
+        dx, dy = (np.ascontiguousarray(a, np.float32) for a in (dx, dy))
+        tp = None if throughput is None else np.ascontiguousarray(throughput, np.float32)
+        di = None if direct is None else np.ascontiguousarray(direct, np.float32)
+        H, W = dx.shape[:2]
+        out = np.zeros((H, W, 3), np.float32)
+        self._check(lib().gvpm_poisson_solve(self._h, C.byref(params), W, H, dx.ctypes.data, dy.ctypes.data,
+                                             None if tp is None else tp.ctypes.data,
+                                             None if di is None else di.ctypes.data, out.ctypes.data))
+        return out
+
     def allreduce_accum(self):
         self._check(lib().gvpm_allreduce_accum(self._h))
+
+
+def poisson_preset(name):
+    p = abi.PoissonParams()
+    rc = lib().gvpm_poisson_preset(name.encode(), C.byref(p))
+    if rc != 0:
+        raise GvpmError(rc, f"unknown Poisson preset {name}")
+    return p
 
 
 def comm_unique_id():

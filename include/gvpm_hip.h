@@ -338,6 +338,35 @@ int gvpm_download_film(gvpm_context *h, int it, int reuse_primal,
                        float *dy);
 int gvpm_synchronize(gvpm_context *h);
 
+/* ---- reconstruction -----------------------------------*/
+/* Screened-Poisson reconstruction of the final image from throughput + gradients: replaces
+ * poisson::Solver as gvpm.cpp:610-690 drives it (importImagesMTS, setupBackend, solveIndirect,
+ * exportImagesMTS; src/integrators/poisson_solver/Solver.cpp:376-497, Backend.cpp:154-384).
+ * The fields are Solver::Params' solver configuration (Solver.hpp:81-88); cg_precond must be 0
+ * (no preset of the reference enables the preconditioner).                                    */
+typedef struct gvpm_poisson_params {
+  float alpha;               /* weight of the primal image, reconstructAlpha (0.2)   */
+  int32_t irls_iter_max;     /* 1 = L2, > 1 = L1 by IRLS                              */
+  float irls_reg_init;
+  float irls_reg_iter;
+  int32_t cg_iter_max;
+  int32_t cg_iter_check;
+  int32_t cg_precond;
+  float cg_tolerance;
+} gvpm_poisson_params;
+/* Solver::Params::setConfigPreset (Solver.cpp:91-164): "L1D", "L1Q", "L1L", "L2D", "L2Q";
+ * alpha is set to the reference's default 0.2.  GVPM_ERR_INVALID_ARG for an unknown preset.   */
+int gvpm_poisson_preset(const char *preset, gvpm_poisson_params *out);
+/* dx, dy, throughput, direct (may be NULL), out: width*height*3 floats, RGB triplets, row major.
+ * out = reconstruction (+ direct), i.e. what exportImagesMTS returns.                          */
+int gvpm_poisson_solve(gvpm_context *h, const gvpm_poisson_params *params, int width, int height,
+                       const float *dx, const float *dy, const float *throughput, const float *direct,
+                       float *out);
+/* the same with every image in device memory (a device-side producer)      */
+int gvpm_poisson_solve_dev(gvpm_context *h, const gvpm_poisson_params *params, int width, int height,
+                           const float *dx, const float *dy, const float *throughput,
+                           const float *direct, float *out);
+
 /* ---- multi-GPU (image-tile sharding) --------------------------*/
 /* Each rank gathers only the beam sets of its own pixels; before
  * reconstruction the 27-float accumulators (disjoint supports) are summed

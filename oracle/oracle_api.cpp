@@ -11,6 +11,7 @@
 #include "gvpm_oracle.hpp"
 #include "gvpm_oracle_beams.hpp"
 #include "gvpm_oracle_planes.hpp"
+#include "poisson_oracle.hpp"
 
 using namespace oracle;
 
@@ -356,5 +357,16 @@ int oracle_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+// Screened-Poisson reconstruction with one of the reference's presets ("L1D", "L2D", ...); returns -1 for an
+// unknown preset.  direct may be NULL.
+int oracle_poisson_solve(const char *preset, float alpha, int width, int height, const float *dx, const float *dy,
+                         const float *throughput, const float *direct, float *out) {
+  oracle::PoissonParams p;
+  if (!preset || !oracle::poissonPreset(preset, p)) return -1;
+  p.alpha = alpha;
+  oracle::poissonSolve(p, width, height, dx, dy, throughput, direct, out);
+  return 0;
 }
 }

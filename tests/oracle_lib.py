@@ -48,6 +48,8 @@ def lib(fast=False):
             C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_poisson_solve.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -164,3 +166,37 @@ def assemble(accum, it=1, reuse_primal=True, emission=None, total_emitted=0.0):
     if rc != 0:
         raise RuntimeError(f"oracle_assemble failed: {rc}")
     return tuple(out)
+
+
+def poisson_solve(dx, dy, throughput, direct=None, preset="L1D", alpha=0.2):
+    """The reference's screened-Poisson solver restated (naive backend, sequential float sums)."""
+    dx, dy, tp = (np.ascontiguousarray(a, np.float32) for a in (dx, dy, throughput))
+    di = None if direct is None else np.ascontiguousarray(direct, np.float32)
+    H, W = dx.shape[:2]
+    out = np.zeros((H, W, 3), np.float32)
+    rc = lib().oracle_poisson_solve(preset.encode(), alpha, W, H, dx.ctypes.data, dy.ctypes.data, tp.ctypes.data,
+                                    None if di is None else di.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_poisson_solve failed: {rc}")
+    return out
+
+
+REF_POISSON = os.path.join(ROOT, "oracle", "_ref", "libref_poisson.so")
+_REF = None
+
+
+def ref_poisson_solve(dx, dy, throughput, direct=None, preset="L1D", alpha=0.2, backend="Naive"):
+    """The REFERENCE's own solver (oracle/_ref, built from the reference sources by oracle/Makefile.ref)."""
+    global _REF
+    if _REF is None:
+        _REF = C.CDLL(REF_POISSON)
+        _REF.ref_poisson_solve.argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5
+    dx, dy, tp = (np.array(a, np.float32, order="C") for a in (dx, dy, throughput))
+    di = None if direct is None else np.array(direct, np.float32, order="C")
+    H, W = dx.shape[:2]
+    out = np.zeros((H, W, 3), np.float32)
+    rc = _REF.ref_poisson_solve(preset.encode(), backend.encode(), alpha, W, H, dx.ctypes.data, dy.ctypes.data,
+                                tp.ctypes.data, None if di is None else di.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ref_poisson_solve failed: {rc}")
+    return out
