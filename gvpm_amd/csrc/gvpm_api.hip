@@ -49,8 +49,17 @@ void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, co
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                          uint32_t nwaves, hipStream_t stream);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
+struct PoissonGraphCache {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  void *scratch = nullptr;
+  int W = 0, H = 0, cgMax = 0;
+  float alpha = 0.f;
+};
+void poisson_graph_release(PoissonGraphCache &c);
 hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, const float *dx, const float *dy,
-                                const float *tp, const float *direct, float *out, void *scratch, hipStream_t s);
+                                const float *tp, const float *direct, float *out, void *scratch,
+                                PoissonGraphCache &cache, hipStream_t s);
 size_t poisson_scratch_bytes(int W, int H);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
@@ -253,6 +262,7 @@ struct gvpm_context {
 
   // reconstruction scratch
   DevBuf<float> poissonScratch, poissonIO;
+  PoissonGraphCache poissonGraph;
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -399,6 +409,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->subIds.release(); h->beamCtl.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
+  poisson_graph_release(h->poissonGraph);
   h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
@@ -1338,7 +1349,7 @@ static int poissonCommon(gvpm_context *h, const gvpm_poisson_params *prm, int W,
     if (direct) HIP_TRY(h, hipMemcpyAsync(io + 3 * n3, direct, n3 * 4, hipMemcpyHostToDevice, h->stream));
     ddx = io; ddy = io + n3; dtp = tp ? io + 2 * n3 : nullptr; ddir = direct ? io + 3 * n3 : nullptr; dout = io + 4 * n3;
   }
-  HIP_TRY(h, poisson_solve_device(*prm, W, H, ddx, ddy, dtp, ddir, dout, h->poissonScratch.p, h->stream));
+  HIP_TRY(h, poisson_solve_device(*prm, W, H, ddx, ddy, dtp, ddir, dout, h->poissonScratch.p, h->poissonGraph, h->stream));
   if (!fromDevice) {
     HIP_TRY(h, hipMemcpyAsync(out, dout, n3 * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -95,11 +95,14 @@ __global__ __launch_bounds__(PB) void poisson_w2_kernel(PoissonBufs q, float reg
   const double t = blockSum(acc, sh);
   if (threadIdx.x == 0) q.part[blockIdx.x * 3] = t;
 }
-__global__ void poisson_w2coef_kernel(PoissonBufs q, int nparts) {
+__global__ __launch_bounds__(64) void poisson_w2coef_kernel(PoissonBufs q, int nparts) {
+  const int lane = threadIdx.x;
   double s = 0.0;
-  for (int k = 0; k < nparts; ++k) s += q.part[k * 3];
+  for (int k = lane; k < nparts; k += 64) s += q.part[k * 3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   const size_t m = (size_t)q.W * q.H * 3;
-  *q.w2coef = (float)m / (float)s;  // normalise so that average(w2) = 1
+  if (lane == 0) *q.w2coef = (float)m / (float)s;  // normalise so that average(w2) = 1
 }
 __global__ __launch_bounds__(PB) void poisson_w2scale_kernel(PoissonBufs q) {
   const size_t m = (size_t)q.W * q.H * 3;
@@ -142,15 +145,16 @@ __global__ __launch_bounds__(PB) void poisson_dot_kernel(PoissonBufs q, const fl
   }
 }
 
-// finish a reduction: dst = sum of the partials (fixed order); optionally copy rz -> rz2 first
-// (the `swap(rz, rz2)` of Solver.cpp:456)
-__global__ void poisson_finish_kernel(PoissonBufs q, float *dst, int nparts, int saveRz) {
-  const int c = threadIdx.x;
-  if (c >= 3) return;
-  if (saveRz) q.rz2[c] = q.rz[c];
+// finish a reduction: dst = sum of the partials (fixed order: deterministic); optionally copy rz -> rz2 first
+// (the `swap(rz, rz2)` of Solver.cpp:456).  One block of 192 threads: one wave per channel.
+__global__ __launch_bounds__(192) void poisson_finish_kernel(PoissonBufs q, float *dst, int nparts, int saveRz) {
+  const int c = threadIdx.x / 64, lane = threadIdx.x % 64;
+  if (saveRz && lane == 0) q.rz2[c] = q.rz[c];
   double s = 0.0;
-  for (int k = 0; k < nparts; ++k) s += q.part[k * 3 + c];
-  dst[c] = (float)s;
+  for (int k = lane; k < nparts; k += 64) s += q.part[k * 3 + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) dst[c] = (float)s;
 }
 
 // Ap = A p with A = P' diag(w2) P, and the partials of p'Ap (calc_Ax_xAx)
@@ -250,16 +254,31 @@ __global__ __launch_bounds__(PB) void poisson_export_kernel(PoissonBufs q, const
 
 static void cgIteration(const PoissonBufs &q, int grid, hipStream_t s) {
   hipLaunchKernelGGL(poisson_Ap_kernel, dim3(grid), dim3(PB), 0, s, q);
-  hipLaunchKernelGGL(poisson_finish_kernel, dim3(1), dim3(64), 0, s, q, q.pAp, grid, 1);  // pAp; rz2 = rz
+  hipLaunchKernelGGL(poisson_finish_kernel, dim3(1), dim3(192), 0, s, q, q.pAp, grid, 1);  // pAp; rz2 = rz
   hipLaunchKernelGGL(poisson_r_kernel, dim3(grid), dim3(PB), 0, s, q);
-  hipLaunchKernelGGL(poisson_finish_kernel, dim3(1), dim3(64), 0, s, q, q.rz, grid, 0);   // rz = r'r
+  hipLaunchKernelGGL(poisson_finish_kernel, dim3(1), dim3(192), 0, s, q, q.rz, grid, 0);  // rz = r'r
   hipLaunchKernelGGL(poisson_xp_kernel, dim3(grid), dim3(PB), 0, s, q);
 }
 
 // dx, dy, throughput (nullable), direct (nullable), out: device pointers, W*H*3 floats.  scratch: device
 // memory of poisson_scratch_bytes(W, H).  Solver::solveIndirect, Solver.cpp:376-497 (cgPrecond = false).
+// the captured CG run of the last solve, kept by the caller: valid while scratch, size, alpha and cgIterMax stay
+struct PoissonGraphCache {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  void *scratch = nullptr;
+  int W = 0, H = 0, cgMax = 0;
+  float alpha = 0.f;
+};
+void poisson_graph_release(PoissonGraphCache &c) {
+  if (c.exec) (void)hipGraphExecDestroy(c.exec);
+  if (c.graph) (void)hipGraphDestroy(c.graph);
+  c = PoissonGraphCache();
+}
+
 hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, const float *dx, const float *dy,
-                                const float *tp, const float *direct, float *out, void *scratch, hipStream_t s) {
+                                const float *tp, const float *direct, float *out, void *scratch,
+                                PoissonGraphCache &cache, hipStream_t s) {
   const size_t n = (size_t)W * H, n3 = 3 * n;
   PoissonBufs q;
   q.part = reinterpret_cast<double *>(scratch);
@@ -286,14 +305,19 @@ hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, co
   hipLaunchKernelGGL(poisson_setup_kernel, dim3(grid), dim3(PB), 0, s, q, dx, dy, tp);
   // one CG run without host checks = cgMax iterations: capture once, replay per IRLS iteration
   const bool hostChecks = tol > 0.f;
-  hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   if (!hostChecks && cgMax > 1) {
-    PT(hipStreamSynchronize(s));
-    PT(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    for (int k = 0; k < cgMax; ++k) cgIteration(q, grid, s);
-    PT(hipStreamEndCapture(s, &graph));
-    PT(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    if (!(cache.exec && cache.scratch == scratch && cache.W == W && cache.H == H && cache.cgMax == cgMax &&
+          cache.alpha == q.alpha)) {
+      poisson_graph_release(cache);
+      PT(hipStreamSynchronize(s));
+      PT(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      for (int k = 0; k < cgMax; ++k) cgIteration(q, grid, s);
+      PT(hipStreamEndCapture(s, &cache.graph));
+      PT(hipGraphInstantiate(&cache.exec, cache.graph, nullptr, nullptr, 0));
+      cache.scratch = scratch; cache.W = W; cache.H = H; cache.cgMax = cgMax; cache.alpha = q.alpha;
+    }
+    exec = cache.exec;
   }
   hipError_t rc = hipSuccess;
   for (int irls = 0; irls < irlsMax && rc == hipSuccess; ++irls) {
@@ -303,12 +327,12 @@ hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, co
     } else {
       const float reg = fmaxf(prm.irls_reg_init, 0.f) * powf(fmaxf(prm.irls_reg_iter, 0.f), (float)(irls - 1));
       hipLaunchKernelGGL(poisson_w2_kernel, dim3(grid), dim3(PB), 0, s, q, reg);
-      hipLaunchKernelGGL(poisson_w2coef_kernel, dim3(1), dim3(1), 0, s, q, grid);
+      hipLaunchKernelGGL(poisson_w2coef_kernel, dim3(1), dim3(64), 0, s, q, grid);
       hipLaunchKernelGGL(poisson_w2scale_kernel, dim3(grid), dim3(PB), 0, s, q);
     }
     hipLaunchKernelGGL(poisson_rhs_kernel, dim3(grid), dim3(PB), 0, s, q);
     hipLaunchKernelGGL(poisson_dot_kernel, dim3(grid), dim3(PB), 0, s, q, q.r, q.r);
-    hipLaunchKernelGGL(poisson_finish_kernel, dim3(1), dim3(64), 0, s, q, q.rz, grid, 0);
+    hipLaunchKernelGGL(poisson_finish_kernel, dim3(1), dim3(192), 0, s, q, q.rz, grid, 0);
     if (exec) {
       rc = hipGraphLaunch(exec, s);
     } else {
@@ -329,11 +353,6 @@ hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, co
   if (rc == hipSuccess) {
     hipLaunchKernelGGL(poisson_export_kernel, dim3(grid), dim3(PB), 0, s, q, direct, out);
     rc = hipGetLastError();
-  }
-  if (exec) {
-    (void)hipStreamSynchronize(s);
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
   }
   return rc;
 }
