@@ -28,7 +28,28 @@ SPECS = {
                        use_shift_null=0),
 }
 
+def other_techniques():
+    """G-VPM, G-Beams (3D and 1D) and G-Planes fixtures: same idea, technique-specific inputs in `extra`."""
+    from test_oracle_vpm import make_vpm_case
+    from test_oracle_beams import make_beam_case
+    from test_oracle_planes import make_plane_case
+    c = make_vpm_case("cbox", 14, 10, 4000, 6.0, nb=4)
+    acc, sv, nv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=False)
+    yield "cbox_vpm", c, c.ph, acc, cnt, dict(samples=c.samples.view("u1"), scale_vol=sv, n_vol=nv)
+    for name, tech in (("cbox_beams3d", abi.GVPM_BEAM_BEAM_3D_OPTIMIZED), ("cbox_beams1d", abi.GVPM_BEAM_BEAM_1D)):
+        c = make_beam_case("cbox", 14, 10, 1200, 3.0, technique=tech)
+        acc, cnt, _ = O.gather_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, c.r, 1, c.nb, 64)
+        yield name, c, c.beams, acc, cnt, dict(end_n=c.end_n)
+    c = make_plane_case("cbox_in", 14, 10, 800)
+    acc, cnt, _ = O.gather_planes(c.p, c.m, c.tris, c.beams, c.w1, c.len1, c.rays, 1, c.nb, 64)
+    yield "cbox_in_planes0d", c, c.beams, acc, cnt, dict(end_n=c.end_n, w1=c.w1, len1=c.len1)
+
+
 if __name__ == "__main__":
+    for name, c, ph, acc, cnt, extra in other_techniques():
+        path = os.path.join(HERE, name + ".npz")
+        golden_io.save(path, c.p, c.m, c.tris, ph, c.rays, c.r, 1, c.nb, acc, cnt["evaluations"], extra)
+        print(name, cnt, os.path.getsize(path), "bytes")
     for name, spec in SPECS.items():
         c = cases.make_case(**spec)
         acc, cnt, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, 1, c.nb, 64, use_accel=False)
