@@ -225,50 +225,38 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
   const uint32_t st = GVPM_PF_SHIFT_TYPE(ph.bits);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    // branch-free: the null-shift arithmetic is cheap and some lane of the wave needs it anyway; a wave
+    // spends more on exec-mask bookkeeping and taken branches than on the arithmetic they would skip
     const RayReg sh = loadRay(s, 1 + i, b);
-    float w = 1.f;
-    f3 sflux = mk3(0.f);
-    bool queued = false;
-    if (sh.valid) {
-      const d3 zP = tod(sh.o) + tod(sh.d) * bt.tPrime;  // shiftRay(t')
-      const f3 y = tof(pD - zP);                        // photon relative to the shifted ray point
-      bool alreadyShift = false;
-      if (a.cfg.use_shift_null) {
-        if (dot(y, y) < r2 && tPf < sh.len) {
-          // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
-          const f3 yp = y - sh.d * dot(y, sh.d);
-          const float deltaS = fsqrt(fmaxf(0.f, r2 - dot(yp, yp)));
-          const float pdfShiftPos = frcp(fmaxf(2.f * deltaS, 0.0001f));
-          sflux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
-          w = 0.5f;
-          if (a.cfg.use_mis) {
-            if (pdfShiftPos == 0.f || bt.pdfCam == 0.f) w = 1.f;
-            else w = frcp(1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos * frcp(bt.pdfCam));
-          }
-          alreadyShift = true;
-          nNull++;
-        }
-      }
-      if (!alreadyShift && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
-        // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
-        if (st == 1u || st == 2u) {
-          qMask |= 1u << i;
-          queued = true;
-        } else {
-          nFail++;
-        }
-      }
-    }
-    if (!queued) {
-      borderRule(a, pix, i, w);
-      const float ws = w * bt.scale;
-      acc.v[3 + 3 * i + 0] += sflux.x * ws;
-      acc.v[3 + 3 * i + 1] += sflux.y * ws;
-      acc.v[3 + 3 * i + 2] += sflux.z * ws;
-      acc.v[15 + 3 * i + 0] += bc.x * w;
-      acc.v[15 + 3 * i + 1] += bc.y * w;
-      acc.v[15 + 3 * i + 2] += bc.z * w;
-    }
+    const d3 zP = tod(sh.o) + tod(sh.d) * bt.tPrime;  // shiftRay(t')
+    const f3 y = tof(pD - zP);                        // photon relative to the shifted ray point
+    // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
+    const bool isNull = sh.valid && a.cfg.use_shift_null && dot(y, y) < r2 && tPf < sh.len;
+    const f3 yp = y - sh.d * dot(y, sh.d);
+    const float deltaS = fsqrt(fmaxf(0.f, r2 - dot(yp, yp)));
+    const float pdfShiftPos = frcp(fmaxf(2.f * deltaS, 0.0001f));
+    float wNull = 0.5f;
+    if (a.cfg.use_mis)
+      wNull = (pdfShiftPos == 0.f || bt.pdfCam == 0.f)
+                  ? 1.f
+                  : frcp(1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos * frcp(bt.pdfCam));
+    const f3 nullFlux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
+    // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
+    const bool wantsShift = sh.valid && !isNull && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL;
+    const bool queued = wantsShift && (st == 1u || st == 2u);
+    nNull += isNull ? 1u : 0u;
+    nFail += (wantsShift && !queued) ? 1u : 0u;
+    qMask |= queued ? (1u << i) : 0u;
+    float w = isNull ? wNull : 1.f;
+    borderRule(a, pix, i, w);
+    const float keep = queued ? 0.f : 1.f;         // a queued shift adds nothing here
+    const float ws = isNull ? w * bt.scale : 0.f;  // only the null shift has a shifted flux in phase 1
+    acc.v[3 + 3 * i + 0] += nullFlux.x * ws;
+    acc.v[3 + 3 * i + 1] += nullFlux.y * ws;
+    acc.v[3 + 3 * i + 2] += nullFlux.z * ws;
+    acc.v[15 + 3 * i + 0] += bc.x * (w * keep);
+    acc.v[15 + 3 * i + 1] += bc.y * (w * keep);
+    acc.v[15 + 3 * i + 2] += bc.z * (w * keep);
   }
 }
 
