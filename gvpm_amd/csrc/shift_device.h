@@ -168,46 +168,37 @@ __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx
 }
 
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.
+// Written branch-free apart from the shadow-ray loop: every early `return false` of the reference
+// (shift_volume_photon.cpp:398-412, shift_diffuse.cpp:43-47, 100-104, :463-470) clears `good`, the
+// arithmetic runs for all lanes and the result is selected at the end.
 template <bool FULLVIS>
 __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonCold &ph,
                                               uint32_t bits, f3 dProjU, const RayReg &sh, const RayReg &base,
                                               uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
                                               f3 &shiftedFlux, bool &ok) {
-  ok = false;
-  shiftedFlux = mk3(0.f);
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
   const float l2Proj = dot(dProjU, dProjU);
   const float lProj = fsqrt(l2Proj);
   const f3 dProj = dProjU * frcp(lProj);
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
-  if (shadowBlocked<FULLVIS>(a, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax)) return 1.f;
-  if (ptype != GVPM_PARENT_MEDIUM) {
-    // sign of dot(n, dProj) / dot(n, -wi)
-    if (dot(ph.parentN, dProj) * dot(ph.parentN, -ph.wi) < 0.f) return 1.f;
-  }
-  f3 thr;
-  float pdfValue;
-  if (ptype == GVPM_PARENT_SURFACE) {
-    const float cosWo = dot(ph.parentN, dProj), cosWi = dot(ph.parentN, ph.parentWi);
-    if (cosWi <= 0.f || cosWo <= 0.f) return 1.f;  // eval/pdf = 0 or the shading-normal reject: sRec.pdf == 0
-    thr = ph.parentScat * (INV_PI_F * cosWo);
-    pdfValue = INV_PI_F * cosWo;
-  } else if (ptype == GVPM_PARENT_MEDIUM) {
-    const float p = phaseEval(ph.parentG, ph.parentWi, dProj);
-    thr = ph.parentScat * p;
-    pdfValue = p;
-  } else {
-    float dp = dot(dProj, ph.parentN);
-    if (dp < 0.f) dp = 0.f;
-    thr = mk3(INV_PI_F * dp);
-    pdfValue = INV_PI_F * dp;
-  }
-  const float gop = frcp(lProj * lProj);
+  bool good = !shadowBlocked<FULLVIS>(a, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
+  const float cosWo = dot(ph.parentN, dProj);
+  // surface / emitter parents: the offset direction must leave on the side the photon left (sign of
+  // dot(n, dProj) / dot(n, -wi))
+  const bool isMedium = ptype == GVPM_PARENT_MEDIUM, isSurface = ptype == GVPM_PARENT_SURFACE;
+  good = good && (isMedium || cosWo * dot(ph.parentN, -ph.wi) >= 0.f);
+  // eval / pdf of the parent towards the offset position (diffuse.cpp:110-127, phase eval, area.cpp:132-150)
+  const float cosWi = dot(ph.parentN, ph.parentWi);
+  good = good && (!isSurface || (cosWi > 0.f && cosWo > 0.f));  // eval/pdf = 0 or the shading-normal reject
+  const float lam = INV_PI_F * fmaxf(cosWo, 0.f);
+  const float pMed = phaseEval(ph.parentG, ph.parentWi, dProj);
+  const float pdfValue = isMedium ? pMed : lam;
+  f3 thr = isSurface ? ph.parentScat * lam : (isMedium ? ph.parentScat * pMed : mk3(lam));
+  const float gop = frcp(l2Proj);
   float sPdf = pdfValue * gop;
-  thr = thr * gop;
-  if (ph.parentPdf == 0.f) return 1.f;
-  thr = thr * fdiv(ph.parentRR, ph.parentPdf);
+  good = good && ph.parentPdf != 0.f;
+  thr = thr * (gop * ph.parentRR * frcp(ph.parentPdf));
   if (GVPM_PF_EDGE_IN_MEDIUM(bits)) {
     f3 tr;
     float pdfSuccess;
@@ -215,24 +206,23 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
     sPdf *= pdfSuccess;
     thr = thr * tr * frcp(ph.edgePdf);
   }
-  if (sPdf == 0.f) return 1.f;
+  good = good && sPdf != 0.f;
   const f3 photonWeight = ph.prefixW * thr;
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
   const f3 contrib = sigS * photonWeight * phaseEval(a.med.g, -dProj, -sh.d);
-  shiftedFlux = trShift * contrib * sh.eye;  // jacobian == 1
-  ok = true;
   float w = 0.5f;
+  bool misOk = true;
   if (a.cfg.use_mis) {
     const float basePdf = pdfBaseRay * ph.parentPdf * ph.edgePdf;
     const float offsetPdf = sPdf * pdfShiftRay;
-    if (offsetPdf == 0.f || basePdf == 0.f) {
-      ok = false;
-      return 1.f;
-    }
+    misOk = !(offsetPdf == 0.f || basePdf == 0.f);
     const float v = sensorMIS(sh, base, edge) * fdiv(offsetPdf, basePdf);
     w = a.cfg.power_heuristic ? frcp(1.f + v * v) : frcp(1.f + v);
   }
-  return w;
+  // a failed MIS keeps the flux it computed and takes weight 1 (shift_volume_photon.cpp:463-470)
+  shiftedFlux = good ? trShift * contrib * sh.eye : mk3(0.f);  // jacobian == 1
+  ok = good && misOk;
+  return ok ? w : 1.f;
 }
 
 // computeVolumeContribution (gvpm/shift/shift_utilities.h:231-253) and the debugShift filter
