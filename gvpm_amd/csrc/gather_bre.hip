@@ -297,10 +297,8 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   if (a.cfg.use_shift_null) {
     const f3 dS = tof(zP - basePt);  // shiftRay(t') - baseRay(t')
     const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
-    if (dot(bo, bo) < r2) {
-      const float cosD2 = -2.f * dot(dS, offRel) * frcp(dot(dS, dS));
-      offRel = offRel + dS * cosD2;
-    }
+    const float cosD2 = dot(bo, bo) < r2 ? -2.f * dot(dS, offRel) * frcp(dot(dS, dS)) : 0.f;
+    offRel = offRel + dS * cosD2;
   }
   float pdfShiftPos = 1.f;
   if (use3D) {
@@ -341,7 +339,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
 template <int B> __device__ __forceinline__ void flushAcc(EvalLds<B> &s, Acc27 &acc, uint32_t beam) {
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    if (acc.v[k] != 0.f) atomicAdd(&s.acc[k][beam], acc.v[k]);
+    atomicAdd(&s.acc[k][beam], acc.v[k]);
     acc.v[k] = 0.f;
   }
 }

@@ -34,22 +34,18 @@ __device__ __forceinline__ void mediumEval(const MediumDev &m, float dist, f3 &t
   tr = mk3(e);
 }
 
-// Moeller-Trumbore, triangle.h:109-145 + interval test skdtree.h:318-320
+// Moeller-Trumbore, triangle.h:109-145 + interval test skdtree.h:318-320 (branch-free: the tests of the
+// reference are and-ed; a zero determinant gives inf / NaN, which fail the comparisons like the early return)
 __device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt) {
   const f3 pvec = cross(d, e2);
   const float det = dot(e1, pvec);
-  if (det == 0.f) return false;
   const float inv = frcp(det);
   const f3 tvec = o - v0;
   const float u = dot(tvec, pvec) * inv;
-  if (u < 0.f || u > 1.f) return false;
   const f3 qvec = cross(tvec, e1);
   const float v = dot(d, qvec) * inv;
-  if (v >= 0.f && u + v <= 1.f) {
-    const float t = dot(e2, qvec) * inv;
-    return t >= mint && t <= maxt;
-  }
-  return false;
+  const float t = dot(e2, qvec) * inv;
+  return det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= mint && t <= maxt;
 }
 
 // scene->rayIntersect(ray), any-hit: stack walk of the occluder BVH (scene_bvh.h), triangles as
