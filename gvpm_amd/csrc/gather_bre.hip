@@ -448,49 +448,43 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
               }
             }
             while (__ballot(cm != 0u)) {
-              bool hit = false, amb = false;
-              uint32_t j = 0;
-              if (cm) {
-                j = (jj + (uint32_t)__ffs(cm) - 1u) * LPB + sub;
-                cm &= cm - 1u;
-                const float4 hp = s.stage[j];
-                const f3 p = mk3(hp.x, hp.y, hp.z);
-                const f3 wv = p - base.o;
-                const float disk = dot(wv, base.d);
-                const f3 v = wv - base.d * disk;
-                const float d2 = dot(v, v);
-                // fp32 with a rigorous error band: E bounds |disk - disk_exact|, band |d2 - d2_exact|
-                const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
-                const float band = 4.f * r * E + r2f * 2e-6f;
-                const uint32_t bits = __float_as_uint(hp.w);
-                // filters, shift_volume_photon.cpp:670-697
-                const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
-                bool keep = true;
-                if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) keep = false;
-                if (a.cfg.min_depth != 0 && depth < a.cfg.min_depth) keep = false;
-                if (!((bits >> 6) & 1u)) keep = false;  // computeVolumeContribution + debugShift (grid_build)
-                if (a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) keep = false;
-                if (keep) {
-                  // decided in fp32 when the error band cannot change the reference's decision ...
-                  bool in = d2 < r2f - band && disk > mint + E && disk < maxt - E;
-                  bool out = false;
-                  if (in && use3D) {
-                    // t' = (disk - deltaT) + 2 deltaT rnd must lie in [mint, len] (shift_volume_photon.cpp:707-726):
-                    // bracket it with deltaT in [dTlo, dTup]
-                    const float q = r2f - d2;
-                    const float dTup = fsqrt(q + band) * 1.000001f, dTlo = fsqrt(fmaxf(q - band, 0.f)) * 0.999999f;
-                    const float slop = 2.f * E + 4e-7f * (fabsf(disk) + dTup);
-                    const float tLo = (disk - dTup) + 2.f * dTlo * bi.rnd - slop;
-                    const float tHi = (disk - dTlo) + 2.f * dTup * bi.rnd + slop;
-                    in = tLo > mint && tHi < base.len;
-                    out = tHi < mint || tLo > base.len;
-                  }
-                  // ... otherwise the pair is passed on flagged: the evaluation kernel runs the reference
-                  // predicate itself (fp64, uncontracted) on it -- about one candidate in 10^5
-                  hit = !out;
-                  amb = !in && !out;
-                }
+              // straight-line, predicated (a lane without a candidate computes on entry 0 and discards)
+              const bool active = cm != 0u;
+              const uint32_t j = min((jj + (active ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)STAGE - 1u);
+              cm &= cm - 1u;
+              const float4 hp = s.stage[j];
+              const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
+              const float disk = dot(wv, base.d);
+              const f3 v = wv - base.d * disk;
+              const float d2 = dot(v, v);
+              // fp32 with a rigorous error band: E bounds |disk - disk_exact|, band |d2 - d2_exact|
+              const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
+              const float band = 4.f * r * E + r2f * 2e-6f;
+              const uint32_t bits = __float_as_uint(hp.w);
+              // filters, shift_volume_photon.cpp:670-697
+              const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
+              const bool keep = active && !(a.cfg.max_depth > 0 && depth > a.cfg.max_depth) &&
+                                !(a.cfg.min_depth != 0 && depth < a.cfg.min_depth) &&
+                                ((bits >> 6) & 1u) &&  // computeVolumeContribution + debugShift (grid_build)
+                                !(a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity);
+              // decided in fp32 when the error band cannot change the reference's decision ...
+              const bool in0 = d2 < r2f - band && disk > mint + E && disk < maxt - E;
+              bool in = in0, outside = false;
+              if (use3D) {
+                // t' = (disk - deltaT) + 2 deltaT rnd must lie in [mint, len] (shift_volume_photon.cpp:707-726):
+                // bracket it with deltaT in [dTlo, dTup]
+                const float q = r2f - d2;
+                const float dTup = fsqrt(fmaxf(q + band, 0.f)) * 1.000001f, dTlo = fsqrt(fmaxf(q - band, 0.f)) * 0.999999f;
+                const float slop = 2.f * E + 4e-7f * (fabsf(disk) + dTup);
+                const float tLo = (disk - dTup) + 2.f * dTlo * bi.rnd - slop;
+                const float tHi = (disk - dTlo) + 2.f * dTup * bi.rnd + slop;
+                in = in0 && tLo > mint && tHi < base.len;
+                outside = in0 && (tHi < mint || tLo > base.len);
               }
+              // ... otherwise the pair is passed on flagged: the evaluation kernel runs the reference
+              // predicate itself (fp64, uncontracted) on it -- about one candidate in 10^5
+              const bool hit = keep && !outside;
+              const bool amb = keep && !in && !outside;
               const unsigned long long m = __ballot(hit);
               if (m) {
                 // the hits of my beam in this round sit in lanes b, b + B, ...: append in lane order

@@ -18,8 +18,8 @@ struct RayReg {
   bool valid;
 };
 
+// g == 0 (isotropic) needs no special case: temp = 1 and the formula returns 1/4pi exactly
 __device__ __forceinline__ float phaseEval(float g, f3 wi, f3 wo) {
-  if (g == 0.f) return INV_FOURPI_F;
   const float temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
   return INV_FOURPI_F * (1.f - g * g) * frcp(temp * fsqrt(temp));
 }
