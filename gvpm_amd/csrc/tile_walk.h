@@ -182,7 +182,8 @@ __device__ __forceinline__ void tileSetupFrom(const GatherArgs &a, const RayReg 
     w.cA1 = min(max(0, (int)floorf((aHi - w.orgA) * a.grid.invCell)), dimA - 1);
   }
   // layers per step: thicker slabs when the contiguous (x) axis is the slab axis
-  w.K = (A == 0) ? 8 : a.cfg.reserved[1] ? a.cfg.reserved[1] : 4;
+  // (development overrides: reserved[1] = layers for A != 0, reserved[2] = layers for A == 0)
+  w.K = (A == 0) ? (a.cfg.reserved[2] ? a.cfg.reserved[2] : 8) : (a.cfg.reserved[1] ? a.cfg.reserved[1] : 6);
 }
 
 struct CellBox {
