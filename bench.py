@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct pre-generated iterations (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-window", type=int, default=512)
+    ap.add_argument("--emulate-gpus", type=int, default=0,
+                    help="single-GPU run of rank 0's shard of an N-GPU frame (sizing probe, e.g. BASELINE configs[3]: "
+                         "--emulate-gpus 8 --tile 362 --photons 4000000); not a bench line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,7 +64,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl")
 
-    tx, ty = tile_grid(world)
+    tx, ty = tile_grid(args.emulate_gpus if (args.emulate_gpus and world == 1) else world)
     W, H = args.tile * tx, args.tile * ty
     x0, y0 = (rank % tx) * args.tile, (rank // tx) * args.tile
     sc = SynthScene(args.scene, W, H)
