@@ -8,9 +8,10 @@ already resident in HBM.  Metric: M photon-gather+shift evaluations / s (SURVEY 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: image-tile sharding, photon map replicated, one film all-reduce (RCCL through
-torch.distributed) at the end of the timed region.  Weak scaling: every rank owns one
-512x512 tile of a (tiles_x*512) x (tiles_y*512) frame of the same scene.
+N > 1: image sharding (the frame's 4x4-pixel tiles dealt round-robin to the ranks), photon map
+replicated, one all-reduce of the film's 3 planes {throughput, dx, dy} (RCCL through
+torch.distributed) at the end of the timed region.  Weak scaling: every rank owns
+512x512 pixels of a (tiles_x*512) x (tiles_y*512) frame of the same scene.
 """
 import argparse
 import ctypes as C
@@ -64,9 +65,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl")
 
-    tx, ty = tile_grid(args.emulate_gpus if (args.emulate_gpus and world == 1) else world)
-    W, H = args.tile * tx, args.tile * ty
-    x0, y0 = (rank % tx) * args.tile, (rank // tx) * args.tile
+    nshards = args.emulate_gpus if (args.emulate_gpus and world == 1) else world
+    tx, ty = tile_grid(nshards)
+    W, H = args.tile * tx, args.tile * ty  # weak scaling: tile^2 pixels per rank
     sc = SynthScene(args.scene, W, H)
     p = sc.params()
     p.vol_technique = abi.GVPM_VOL_BRE3D
@@ -84,7 +85,9 @@ def main():
     host0 = None
     for i in range(ndist):
         ph, nb = sc.shoot_photons(i + 1, args.photons)
-        rays = sc.camera_beams(i + 1, x0, y0, x0 + args.tile, y0 + args.tile)
+        # image sharding: the frame's 4x4-pixel tiles are dealt round-robin to the ranks -- contiguous blocks
+        # split S-cbox 2.5:1 unevenly (scripts/shard_balance.py: mean/max 0.41 vs 0.99 interleaved)
+        rays = sc.camera_beams_interleaved(i + 1, nshards, rank) if nshards > 1 else sc.camera_beams(i + 1)
         if i == 0 and rank == 0:
             host0 = (ph, nb, rays)
         soa = abi.PhotonSoA()
@@ -117,15 +120,19 @@ def main():
     ctx.reset()
     ctx.kernel_time()
     ev0 = ctx.stats()["evaluations"]
-    film = torch.zeros(W * H * 27, dtype=torch.float32, device="cuda") if world > 1 else None
+    film = torch.zeros(W * H * 9, dtype=torch.float32, device="cuda") if world > 1 else None
+    if world > 1:
+        dist.all_reduce(film)  # untimed: RCCL sets its channels and buffers up for this message size
 
     barrier()
     t0 = time.perf_counter()
     for it in range(1, K + 1):
         step(it)
     if world > 1:
-        # one film all-reduce before reconstruction (gvpm.cpp:535)
-        ctx.download_accum_dev(film.data_ptr())
+        # one all-reduce of {throughput, dx, dy} before reconstruction (gvpm.cpp:535); each rank's
+        # partial film is computeGradient over its own accumulators (zero elsewhere), the sum is the frame's
+        ctx.download_film_dev(K, film.data_ptr())
+        ctx.synchronize()  # the film kernel ran on the context's stream, the collective runs on torch's
         dist.all_reduce(film)
     ctx.synchronize()
     barrier()
@@ -180,7 +187,8 @@ def main():
                             f"{args.tile}x{args.tile} px per GPU ({W}x{H} frame), {args.photons} photons/iter, "
                             f"{K} SPPM iters, initialScaleVolume {args.scale}",
                 "technique": "bre3d", "frame": [W, H], "tile_per_gpu": [args.tile, args.tile],
-                "photons_per_iter": args.photons, "iterations": K, "sharding": f"image tiles x{world}",
+                "photons_per_iter": args.photons, "iterations": K,
+                "sharding": f"4x4-pixel tiles round-robin over {nshards} ranks" if nshards > 1 else "none",
                 "evaluations": evals_total, "evals_per_iter_per_gpu": evals / K,
                 "tests_per_iter_per_gpu": st["candidates"] / K,
             },

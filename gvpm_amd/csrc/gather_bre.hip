@@ -657,7 +657,9 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
                      uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream) {
   if (a.nsets == 0 || ntiles == 0) return;
-  const uint32_t nwg = ntiles < 4096u ? ntiles : 4096u;  // waves stride over the tiles
+  // waves stride over the tiles; the stride is prime because image-sharded input owns every N-th tile, and a
+  // stride that is a multiple of N would leave all the work to 1/N of the blocks
+  const uint32_t nwg = ntiles < 4093u ? ntiles : 4093u;
   switch (beamsPerWave) {
     case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
     case 32: hipLaunchKernelGGL(plan_kernel<32>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;

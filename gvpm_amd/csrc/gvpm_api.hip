@@ -62,6 +62,8 @@ hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, co
                                 PoissonGraphCache &cache, hipStream_t s);
 size_t poisson_scratch_bytes(int W, int H);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
+void launch_finalize_tiles(float *accum, float *iter, const uint32_t *tileStart, unsigned char *touched, uint32_t ntiles,
+                           int tw, int th, int width, int height, int it, uint64_t nbPaths, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream);
@@ -153,6 +155,7 @@ struct BuildSet {
   SortTemp sortTmp;
   DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
   uint32_t ntiles = 0;
+  int tileW = 4, tileH = 4;
   bool scanSized = false;
   DevBuf<uint4> items;
   DevBuf<uint2> itemOff;
@@ -245,6 +248,10 @@ struct gvpm_context {
   bool useAll = false;  // accumAll holds the all-reduced film until the next gather
   size_t npix = 0;
   float globalScaleVolume = 1.f;
+  // G-BRE: the image tiles touched since the last reset (everything outside is exactly zero): the per-iteration
+  // buffer is folded and cleared only there -- a rank of an image-sharded run owns a fraction of the frame
+  DevBuf<unsigned char> tileTouched;
+  uint32_t tileTouchedTiles = 0;
 
   // stats / timing
   DevBuf<unsigned long long> stats;
@@ -412,6 +419,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   poisson_graph_release(h->poissonGraph);
+  h->tileTouched.release();
   h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
@@ -426,6 +434,8 @@ int gvpm_reset(gvpm_context *h) {
   HIP_TRY(h, hipMemsetAsync(h->accum.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * GVPM_STAT_ROWS * sizeof(unsigned long long), h->stream));
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
+  h->tileTouchedTiles = 0;  // forget the touched tiles
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   for (size_t &u : h->eventsUsed) u = 0;
   h->useAll = false;
   h->totalEmitted = 0;
@@ -788,6 +798,8 @@ static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
   if (beamsPerWave == 16) tw = 4;
   const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
   h->bs->ntiles = tilesX * tilesY;
+  h->bs->tileW = tw;
+  h->bs->tileH = th;
   HIP_TRY(h, h->bs->tileStart.ensure((size_t)h->bs->ntiles + 2));
   HIP_TRY(h, h->bs->bKeysA.ensure(n + 1));
   HIP_TRY(h, h->bs->bValsA.ensure(n + 1));
@@ -951,15 +963,21 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   HIP_TRY(h, hipEventRecord(evTrav->second, ts));
   HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
   h->bstream = h->stream;
-  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
   launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
                       h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
-  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
+  // fold + clear only the image tiles this handle touches (iter is all zero outside the gathers)
+  HIP_TRY(h, h->tileTouched.ensure((size_t)h->bs->ntiles + 1));
+  if (h->tileTouchedTiles != h->bs->ntiles) {
+    HIP_TRY(h, hipMemsetAsync(h->tileTouched.p, 0, (size_t)h->bs->ntiles + 1, h->stream));
+    h->tileTouchedTiles = h->bs->ntiles;
+  }
+  launch_finalize_tiles(h->accum.p, h->iter.p, h->bs->tileStart.p, h->tileTouched.p, h->bs->ntiles, h->bs->tileW,
+                        h->bs->tileH, h->cfg.width, h->cfg.height, it, nb_paths, h->stream);
+  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));  // the fold reads this set's tileStart too
   h->bs->used = true;
-  launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
   lap("launchK");
   // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
@@ -1287,6 +1305,18 @@ int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
   return GVPM_OK;
 }
 
+// throughput | dx | dy planes into filmOut (device); emission already on the device or null
+static int filmToDevice(gvpm_context *h, int it, int reuse_primal, const float *emissionDev, float *out) {
+  const size_t n = h->npix * 3;
+  // non-APA estimators are normalised by the emitted path count (gvpm.cpp:489-492)
+  float invDiv = 1.f;
+  if (h->cfg.vol_technique == GVPM_DISTANCE) invDiv = h->totalEmitted > 0 ? (float)(1.0 / h->totalEmitted) : 0.f;
+  launch_film(h->useAll ? h->accumAll.p : h->accum.p, emissionDev, h->cfg.width, h->cfg.height, it, reuse_primal, invDiv,
+              out, out + n, out + 2 * n, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
 int gvpm_download_film(gvpm_context *h, int it, int reuse_primal, const float *emission, float *throughput, float *dx,
                        float *dy) {
   CHECK_H(h);
@@ -1299,17 +1329,18 @@ int gvpm_download_film(gvpm_context *h, int it, int reuse_primal, const float *e
     HIP_TRY(h, hipMemcpyAsync(h->emission.p, emission, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     em = h->emission.p;
   }
-  // non-APA estimators are normalised by the emitted path count (gvpm.cpp:489-492)
-  float invDiv = 1.f;
-  if (h->cfg.vol_technique == GVPM_DISTANCE) invDiv = h->totalEmitted > 0 ? (float)(1.0 / h->totalEmitted) : 0.f;
-  launch_film(h->useAll ? h->accumAll.p : h->accum.p, em, h->cfg.width, h->cfg.height, it, reuse_primal, invDiv,
-              h->filmOut.p, h->filmOut.p + n, h->filmOut.p + 2 * n, h->stream);
-  HIP_TRY(h, hipGetLastError());
+  if (int rc = filmToDevice(h, it, reuse_primal, em, h->filmOut.p)) return rc;
   HIP_TRY(h, hipMemcpyAsync(throughput, h->filmOut.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(dx, h->filmOut.p + n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(dy, h->filmOut.p + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GVPM_OK;
+}
+
+int gvpm_download_film_dev(gvpm_context *h, int it, int reuse_primal, const float *emission_dev, float *film_dev) {
+  CHECK_H(h);
+  if (!film_dev || it < 1) return GVPM_ERR_INVALID_ARG;
+  return filmToDevice(h, it, reuse_primal, emission_dev, film_dev);
 }
 
 int gvpm_synchronize(gvpm_context *h) {
@@ -1398,6 +1429,15 @@ int gvpm_allreduce_accum(gvpm_context *h) {
   if (g_rccl.allReduce(h->accum.p, h->accumAll.p, h->npix * 27, ncclFloat, ncclSum, h->comm, h->stream) != ncclSuccess)
     return fail(h, GVPM_ERR_COMM, "ncclAllReduce failed");
   h->useAll = true;
+  return GVPM_OK;
+}
+
+int gvpm_allreduce_film(gvpm_context *h, float *film_dev) {
+  CHECK_H(h);
+  if (!film_dev) return GVPM_ERR_INVALID_ARG;
+  if (!h->comm) return fail(h, GVPM_ERR_STATE, "gvpm_comm_init not called");
+  if (g_rccl.allReduce(film_dev, film_dev, h->npix * 9, ncclFloat, ncclSum, h->comm, h->stream) != ncclSuccess)
+    return fail(h, GVPM_ERR_COMM, "ncclAllReduce failed");
   return GVPM_OK;
 }
 

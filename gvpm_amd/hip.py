@@ -23,7 +23,7 @@ SYMBOLS = [
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_get_phase_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
-    "gvpm_allreduce_accum", "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
+    "gvpm_allreduce_accum", "gvpm_allreduce_film", "gvpm_download_film_dev", "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
 ]
 
 
@@ -74,6 +74,8 @@ def lib():
         L.gvpm_comm_unique_id.argtypes = [vp]
         L.gvpm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         L.gvpm_allreduce_accum.argtypes = [vp]
+        L.gvpm_allreduce_film.argtypes = [vp, vp]
+        L.gvpm_download_film_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.gvpm_poisson_preset.argtypes = [C.c_char_p, C.POINTER(abi.PoissonParams)]
         L.gvpm_poisson_solve.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.gvpm_poisson_solve_dev.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
@@ -207,6 +209,13 @@ class Context:
                                              None if em is None else em.ctypes.data,
                                              thr.ctypes.data, dx.ctypes.data, dy.ctypes.data))
         return thr, dx, dy
+
+    def download_film_dev(self, it, film_dev_ptr, reuse_primal=False, emission_dev_ptr=None):
+        """throughput | dx | dy (9*W*H floats) into device memory, on the context's stream."""
+        self._check(lib().gvpm_download_film_dev(self._h, it, 1 if reuse_primal else 0, emission_dev_ptr, film_dev_ptr))
+
+    def allreduce_film(self, film_dev_ptr):
+        self._check(lib().gvpm_allreduce_film(self._h, film_dev_ptr))
 
     def synchronize(self):
         self._check(lib().gvpm_synchronize(self._h))

@@ -36,6 +36,8 @@ def lib():
         L.gvpm_synth_shoot_beams.restype = C.c_uint64
         L.gvpm_synth_shoot_beams.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(abi.PhotonSoA),
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.gvpm_synth_beams_interleaved.restype = C.c_uint64
+        L.gvpm_synth_beams_interleaved.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gvpm_synth_planes.restype = C.c_uint64
         L.gvpm_synth_planes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         _LIB = L
@@ -112,6 +114,15 @@ class SynthScene:
         y1 = self.height if y1 is None else y1
         ptr = C.c_void_p()
         n = lib().gvpm_synth_beams(self._h, iteration, x0, y0, x1, y1, C.byref(ptr))
+        if n == 0:
+            return np.zeros((0, 5), abi.CAMERA_RAY_DTYPE)
+        buf = (C.c_char * (n * 5 * 64)).from_address(ptr.value)
+        return np.frombuffer(buf, abi.CAMERA_RAY_DTYPE).reshape(n, 5).copy()
+
+    def camera_beams_interleaved(self, iteration, tile_mod, tile_rem):
+        """The beam sets of the 4x4-pixel tiles t with t % tile_mod == tile_rem (image-sharded ranks)."""
+        ptr = C.c_void_p()
+        n = lib().gvpm_synth_beams_interleaved(self._h, iteration, tile_mod, tile_rem, C.byref(ptr))
         if n == 0:
             return np.zeros((0, 5), abi.CAMERA_RAY_DTYPE)
         buf = (C.c_char * (n * 5 * 64)).from_address(ptr.value)

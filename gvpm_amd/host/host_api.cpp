@@ -90,6 +90,13 @@ uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
   return s->rays.size() / 5;
 }
 
+uint64_t gvpm_synth_beams_interleaved(gvpm_synth *s, int it, int tile_mod, int tile_rem, const gvpm_camera_ray **out) {
+  if (!s || !out || tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) return 0;
+  gvpm::cameraBeams(s->scene, it, 0, 0, s->scene.width, s->scene.height, s->rays, tile_mod, tile_rem);
+  *out = s->rays.data();
+  return s->rays.size() / 5;
+}
+
 uint64_t gvpm_synth_vpm_samples(gvpm_synth *s, int it, int nb_camera_samples, const gvpm_vpm_sample **out) {
   if (!s || !out || nb_camera_samples <= 0) return 0;
   gvpm::cameraSamplesVPM(s->scene, it, s->rays, nb_camera_samples, s->samples);

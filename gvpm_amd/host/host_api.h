@@ -20,6 +20,8 @@ uint64_t gvpm_synth_shoot(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_
 /* photon beams of iteration `it` (see gvpm_upload_beams); *end_n: 3 floats per beam */
 uint64_t gvpm_synth_shoot_beams(gvpm_synth *s, int it, uint64_t capacity, gvpm_photon_soa *out,
                                 const float **end_n, uint64_t *nb_paths);
+/* the beam sets of the 4x4-pixel tiles t with t % tile_mod == tile_rem, whole frame (image-sharded ranks) */
+uint64_t gvpm_synth_beams_interleaved(gvpm_synth *s, int it, int tile_mod, int tile_rem, const gvpm_camera_ray **out);
 /* photon planes for the beams of the LAST gvpm_synth_shoot_beams call (see gvpm_upload_planes) */
 uint64_t gvpm_synth_planes(gvpm_synth *s, int it, const float **w1, const float **len1);
 /* camera beam sets of the pixel rectangle; returns the number of sets */

@@ -670,11 +670,14 @@ static void fillRay(gvpm_camera_ray &r, const CamPath &cp, double pdf, double ja
 }
 
 void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,
-                 std::vector<gvpm_camera_ray> &out) {
+                 std::vector<gvpm_camera_ray> &out, int tileMod, int tileRem) {
   out.clear();
   static const int offX[4] = {-1, 1, 0, 0}, offY[4] = {0, 0, 1, -1};  // L R T B
+  const int tilesX = (sc.width + 3) / 4;
   for (int py = y0; py < y1; ++py) {
     for (int px = x0; px < x1; ++px) {
+      // image-sharded hosts: 4x4-pixel tiles dealt round-robin to the ranks (an even split of the work)
+      if (tileMod > 1 && ((py / 4) * tilesX + px / 4) % tileMod != tileRem) continue;
       Philox rng(sc.seed, 0xca3eu, (uint32_t)iteration, (uint32_t)(py * sc.width + px));
       double jx = rng.next1D(), jy = rng.next1D();
       float randValue = rng.next1D();

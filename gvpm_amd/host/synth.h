@@ -84,7 +84,7 @@ void planesFromBeams(const SynthScene &sc, int iteration, const PhotonBuffers &b
 // Camera beam sets (5 rays each) for the pixels [x0,x1) x [y0,y1) of iteration
 // `iteration`; pixels whose camera path has no medium edge produce no set.
 void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,
-                 std::vector<gvpm_camera_ray> &out);
+                 std::vector<gvpm_camera_ray> &out, int tileMod = 1, int tileRem = 0);
 
 // G-VPM camera samples for beam sets produced by cameraBeams(): nbCameraSamples records per set,
 // consecutive per pixel (gvpm.cpp:1143-1172 with a one-edge camera path: selBeam = {1}).

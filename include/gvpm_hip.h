@@ -336,6 +336,13 @@ int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev);
 int gvpm_download_film(gvpm_context *h, int it, int reuse_primal,
                        const float *emission, float *throughput, float *dx,
                        float *dy);
+/* the same three images, back to back (throughput | dx | dy, 9*width*height
+ * floats) in DEVICE memory on the context's stream: what an image-sharded rank
+ * hands to the film all-reduce and gvpm_poisson_solve_dev.  emission_dev may
+ * be NULL.  Asynchronous: film_dev must not be in flight on another stream, and
+ * gvpm_synchronize orders it before a consumer on one.                         */
+int gvpm_download_film_dev(gvpm_context *h, int it, int reuse_primal,
+                           const float *emission_dev, float *film_dev);
 int gvpm_synchronize(gvpm_context *h);
 
 /* ---- reconstruction -----------------------------------*/
@@ -375,6 +382,13 @@ int gvpm_poisson_solve_dev(gvpm_context *h, const gvpm_poisson_params *params, i
 int gvpm_comm_unique_id(void *id128);
 int gvpm_comm_init(gvpm_context *h, const void *id128, int rank, int world);
 int gvpm_allreduce_accum(gvpm_context *h);
+/* SURVEY 8e's collective: sum the 3 film planes (gvpm_download_film_dev's
+ * layout, 9*width*height floats) in place.  computeGradient adds one term from
+ * the pixel and one from its +x / +y neighbour (gvpm.cpp:1223,1266), so the sum
+ * of the ranks' partial films is bit-identical to the single-GPU film for dx, dy
+ * and throughput; with reuse_primal the throughput's 8-term sum is associated
+ * differently (a few ulp).  A third of gvpm_allreduce_accum's bytes.            */
+int gvpm_allreduce_film(gvpm_context *h, float *film_dev);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
-"""N > 1 path on CPU: two gloo ranks each gather their own image tile (oracle standing in for
-the device kernel), all-reduce the accumulators and must reproduce the single-rank film
-(disjoint supports: sum == gather)."""
+"""N > 1 path on CPU: two gloo ranks each gather their own share of the image -- the 4x4-pixel tiles dealt
+round-robin, as bench.py shards -- (oracle standing in for the device kernel), all-reduce the accumulators
+and must reproduce the single-rank film (disjoint supports: sum == gather)."""
 import os
 import socket
 import sys
@@ -34,15 +34,14 @@ def _worker(rank, world, port, out_dir):
     tile = 16
     tx, ty = bench.tile_grid(world)
     c = cases.make_case("cbox", tile * tx, tile * ty, 4000, 5.0)
-    x0, y0 = (rank % tx) * tile, (rank // tx) * tile
     acc = None
     for it in (1, 2):
         ph, nb = c.sc.shoot_photons(it, 4000)           # photon map replicated on every rank
-        rays = c.sc.camera_beams(it, x0, y0, x0 + tile, y0 + tile)  # beams sharded by tile
+        rays = c.sc.camera_beams_interleaved(it, world, rank)  # beam sets sharded: 4x4 tiles round-robin
         acc, _, _ = O.gather_bre(c.p, c.m, c.tris, ph, rays, c.r, it, nb, 64, accum=acc)
-    own = np.zeros(acc.shape[:2], bool)
-    own[y0:y0 + tile, x0:x0 + tile] = True
-    assert not acc[~own].any()
+    yy, xx = np.mgrid[0:acc.shape[0], 0:acc.shape[1]]
+    own = ((yy // 4) * ((acc.shape[1] + 3) // 4) + xx // 4) % world == rank
+    assert not acc[~own].any() and acc[own].any()
     t = torch.from_numpy(acc.copy())
     dist.all_reduce(t)
     if rank == 0:

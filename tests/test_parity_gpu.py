@@ -315,3 +315,79 @@ def test_many_occluders_walk_the_bvh(as_written):
     for k in ("diffuse_shifts", "failed_shifts"):
         assert abs(st[k] - cnt[k]) <= max(4, 2e-4 * cnt["diffuse_shifts"]), (k, st, cnt)
     assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
+
+
+def test_row_sharded_film_and_moving_shards():
+    """A handle only clears / folds the film rows it has touched since the last reset (image-sharded ranks own
+    a fraction of the frame): two shard handles must add up to the full-frame result, and a handle whose beam
+    sets move to other rows must still apply the APA fold to the rows it left."""
+    c = cases.make_case("cbox", 32, 28, 20000, 3.0)
+    py = cases.pixels_of(c.rays)[1]
+    top, bot = c.rays[py < 14], c.rays[py >= 14]
+    full, _, _ = device_gather(c)
+    a1, _, _ = device_gather(c, rays=top)
+    a2, _, _ = device_gather(c, rays=bot)
+    assert np.allclose(a1 + a2, full, rtol=1e-5, atol=1e-9)
+    assert not a1[14:].any() and not a2[:14].any()
+    # iteration 1 on the top rows, iteration 2 on the bottom rows, same handle
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(top)
+    r1 = ctx.radius()
+    ctx.gather(1, c.nb)
+    ctx.upload_camera_beams(bot)
+    r2 = ctx.radius()
+    ctx.gather(2, c.nb)
+    acc = ctx.download_accum()
+    ctx.close()
+    ref, _, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, top, r1, 1, c.nb, 64, use_accel=False)
+    ref, _, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, bot, r2, 2, c.nb, 64, use_accel=False, accum=ref)
+    assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < TOL
+    assert np.allclose(acc[:14], 0.5 * a1[:14], rtol=1e-5, atol=1e-9)  # the rows left behind decayed by (it-1)/it
+
+
+def test_partial_films_of_interleaved_shards_sum_to_the_frames_film():
+    """SURVEY 8e's collective: every rank runs computeGradient over its own accumulators (zero elsewhere) and the
+    3 film planes are summed.  dx, dy and the non-reusePrimal throughput add one term per rank at most twice per
+    pixel, so the sum must be BIT-identical to the film of the summed accumulators."""
+    import torch
+    c = cases.make_case("cbox", 36, 28, 20000, 3.0)
+    world, n = 3, 36 * 28 * 3
+    accs, films = [], []
+    for rank in range(world):
+        rays = c.sc.camera_beams_interleaved(c.it, world, rank)
+        ctx = hip.Context(c.p, device=0)
+        ctx.upload_scene(*c.tris)
+        ctx.upload_medium(c.m)
+        ctx.upload_photons(c.ph)
+        ctx.upload_camera_beams(rays)
+        ctx.gather(c.it, c.nb)
+        accs.append(ctx.download_accum())
+        t = torch.zeros(3 * n, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the film kernel on the context's
+        ctx.download_film_dev(c.it, t.data_ptr(), reuse_primal=False)
+        ctx.synchronize()
+        films.append(t.cpu().numpy())
+        ctx.close()
+    yy, xx = np.mgrid[0:28, 0:36]
+    owner = ((yy // 4) * 9 + xx // 4) % world
+    for rank in range(world):
+        assert not accs[rank][owner != rank].any() and accs[rank][owner == rank].any()
+    total = accs[0] + accs[1] + accs[2]  # disjoint supports: exact
+    # computeGradient in fp32 exactly as film_kernel associates it (gvpm.cpp:1223,1266); slots: 0 flux,
+    # 1+i shifted, 5+i weighted, i = L R T B
+    sh, wt = total[..., 3:15].reshape(28, 36, 4, 3), total[..., 15:27].reshape(28, 36, 4, 3)
+    dx = sh[:, :, 1] - wt[:, :, 1]
+    dx[:, :-1] += wt[:, 1:, 0] - sh[:, 1:, 0]
+    dy = sh[:, :, 2] - wt[:, :, 2]
+    dy[:-1] += wt[1:, :, 3] - sh[1:, :, 3]
+    fsum = (films[0] + films[1]) + films[2]
+    for k, ref in enumerate((total[..., 0:3], dx, dy)):
+        got = fsum[k * n:(k + 1) * n].reshape(28, 36, 3)
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, (k, len(bad), bad[:6].tolist(), [(got[tuple(b)], ref[tuple(b)]) for b in bad[:6]])
+    o = O.assemble(total, c.it, False)
+    for k in range(3):
+        assert np.allclose(fsum[k * n:(k + 1) * n].reshape(28, 36, 3), o[k], rtol=1e-5, atol=1e-12)
