@@ -407,6 +407,72 @@ __device__ __forceinline__ uint32_t subBeamCount(float len, float ls) {
   return (uint32_t)fminf(fmaxf(n, 1.f), 255.f);
 }
 
+// fp32 necessary condition for evaluateBeam to produce anything for (camera ray, sub-beam): the two lines pass
+// within the kernel radius and the parameter that decides ownership (3D: where the beam enters the camera ray's
+// capped cylinder, shift_volume_beams.h:213-220; 1D: the closest approach, beams_struct.h:297-299) falls in this
+// sub-beam's range, fattened by a margin that covers the fp32 error.  Everything is measured from the sub-beam's
+// centre, which the sphere test already placed within radius + half a sub-beam of the ray, so the operands are small
+// and well conditioned; near-parallel pairs are passed through.  The fp64 evaluation that follows repeats the
+// reference's tests exactly: the prefilter only removes pairs it would reject (~7 of 8: each beam crosses the ray's
+// neighbourhood with several sub-beams and exactly one owns the pair).
+__device__ __forceinline__ bool beamPrefilter(const GatherArgs &a, const RayReg &base, uint32_t id, int technique) {
+  const uint32_t beamIdx = id & 0xFFFFFFu, sub = id >> 24;
+  const size_t N = a.nbeams;
+  const float4 c2 = a.cold[2 * N + beamIdx], c7 = a.cold[7 * N + beamIdx];
+  const f3 p1 = mk3(c2.x, c2.y, c2.z), p2 = mk3(c7.x, c7.y, c7.z);
+  // the sub-beam count must be the evaluation's: same fp64 length rounded to float (loadBeam)
+  const d3 dD = tod(p2) - tod(p1);
+  const double lenD = sqrt(len2(dD));
+  const float len = (float)lenD;
+  const uint32_t nSub = subBeamCount(len, a.subLen);
+  const float ls = len / (float)nSub;
+  const f3 bd = (p2 - p1) * frcp(len);
+  const float tc = ls * ((float)sub + 0.5f);
+  const f3 C = p1 + bd * tc;
+  const float r = a.kernelRadius;
+  const float eps = a.cfg.epsilon;
+  const f3 co = C - base.o;
+  const float sC = dot(co, base.d);
+  const f3 D0 = co - base.d * sC;  // centre relative to its projection on the camera line
+  const float bdd = dot(bd, base.d);
+  const float sin2 = fmaxf(1.f - bdd * bdd, 0.f);
+  if (sin2 < 1e-5f) return true;
+  const float inv = frcp(sin2);
+  const float tau0 = -(dot(D0, bd) - dot(D0, base.d) * bdd) * inv;  // closest approach, from the centre
+  const f3 cr = cross(bd, base.d);
+  const float ad = dot(D0, cr);
+  const float dmin2 = ad * ad * inv;
+  if (dmin2 >= r * r * 1.002f) return false;
+  const float delta = 0.01f * ls + 1e-5f * (r + ls) * inv;
+  const float half = 0.5f * ls;
+  float tau;
+  if (technique == GVPM_BEAM_BEAM_1D) {
+    // tmin < v <= tmax; the reference derives v from float dot products of absolute positions divided by d1.d2
+    // (beams_struct.h:275-290): its own rounding error grows as 1/|d1.d2|, so near-perpendicular pairs go through
+    if (fabsf(bdd) < 0.05f) return true;
+    tau = tau0;
+    return tau > -half - delta && tau < half + delta;
+  }
+  const float hw = fsqrt(fmaxf(r * r - dmin2, 0.f) * inv);
+  float tN = tau0 - hw, tF = tau0 + hw;
+  // caps of the camera ray's cylinder [mint, maxt] (cylinderIntersection, beams_3d_intersections.h:118-137)
+  const float lMax = base.len - 2.f * eps;
+  const float zc = sC - eps;
+  const float zN = zc + tN * bdd, zF = zc + tF * bdd;
+  const float zmarg = 1e-4f * (fabsf(zc) + r);
+  if (zN < 0.f) {
+    if (zF < -zmarg) return false;
+    if (zN != zF) tN = tN + (tF - tN) * fminf(fmaxf(zN / (zN - zF), 0.f), 1.f);
+  } else if (zN > lMax) {
+    if (zF > lMax + zmarg) return false;
+    if (zN != zF) tN = tN + (tF - tN) * fminf(fmaxf((zN - lMax) / (zN - zF), 0.f), 1.f);
+  }
+  tau = tN;
+  // owner: tmin < tN < tmax, or the first sub-beam when the ray's cylinder already contains the beam's origin
+  if (tau > -half - delta && tau < half + delta) return true;
+  return sub == 0u && tau < -half + delta;
+}
+
 // One (camera ray, sub-beam) candidate: BeamGradRadianceQuery::operator().  Returns true when it
 // produced a contribution (an evaluation).
 template <int B>
@@ -538,7 +604,9 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
                                                              uint32_t *queueHead) {
   constexpr int LPB = 64 / B;
   __shared__ TileLds<B> s;
+  __shared__ uint2 queue2[QCAP];  // candidates that passed the fp32 prefilter
   const int lane = threadIdx.x;
+  const int technique = a.cfg.vol_technique;
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
   const float rT = a.radius;  // test radius = kernel radius + half a sub-beam
@@ -564,7 +632,29 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
     const RayReg base = w.base;
     const bool beamValid = w.beamValid;
     const float mint = eps, maxt = base.len - eps;
-    uint32_t qHead = 0, qCount = 0;
+    uint32_t qHead = 0, qCount = 0, q2Head = 0, q2Count = 0;
+    // 64 (or the last n) sphere-test survivors -> prefilter -> queue2 -> 64 at a time -> evaluation
+    auto refine = [&](uint32_t n) {
+      bool keep = false;
+      uint2 e = make_uint2(0u, 0u);
+      if ((uint32_t)lane < n) {
+        e = s.queue[(qHead + lane) % QCAP];
+        keep = (a.cfg.reserved[0] & 2) ? false : beamPrefilter(a, loadRay(s, 0, (int)e.y), e.x, technique);
+      }
+      const unsigned long long km = __ballot(keep);
+      if (keep) queue2[(q2Head + q2Count + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) % QCAP] = e;
+      q2Count += (uint32_t)__popcll(km);
+      qHead = (qHead + n) % QCAP;
+      qCount -= n;
+      __syncthreads();
+      if (q2Count >= 64u) {
+        const uint2 e2 = queue2[(q2Head + lane) % QCAP];
+        if (!(a.cfg.reserved[0] & 1) && evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)) nEval++;
+        q2Head = (q2Head + 64u) % QCAP;
+        q2Count -= 64u;
+        __syncthreads();
+      }
+    };
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
       const int cAe = min(cA + w.K - 1, cEnd);
@@ -608,11 +698,7 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
               nCand += __popcll(m);
               if (qCount >= 64u) {
                 __syncthreads();
-                const uint2 e = s.queue[(qHead + lane) % QCAP];
-                if (evaluateBeam<B>(a, s, e.x, e.y, nNull, nDiff, nFail)) nEval++;
-                qHead = (qHead + 64u) % QCAP;
-                qCount -= 64u;
-                __syncthreads();
+                refine(64u);
               }
             }
           }
@@ -621,9 +707,10 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
       }
     }
     __syncthreads();
-    if ((uint32_t)lane < qCount) {
-      const uint2 e = s.queue[(qHead + lane) % QCAP];
-      if (evaluateBeam<B>(a, s, e.x, e.y, nNull, nDiff, nFail)) nEval++;
+    if (qCount) refine(qCount);
+    if ((uint32_t)lane < q2Count) {
+      const uint2 e2 = queue2[(q2Head + lane) % QCAP];
+      if (evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)) nEval++;
     }
     __syncthreads();
     for (int idx = lane; idx < 27 * B; idx += 64) {
