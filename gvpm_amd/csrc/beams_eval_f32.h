@@ -1,0 +1,153 @@
+// fp32 evaluation of one (camera ray, sub-beam) pair for the G-Beams kernels: the same functions as the fp64
+// transcription in gather_beams.hip (BeamKernelRecord, shiftNull3D, shiftBeamDiffuse, kernelPDF, getShiftPos*),
+// re-derived in a LOCAL frame so that single precision is enough.
+//
+// Why a local frame.  The reference works on absolute coordinates (scene extent ~10^3, kernel radius ~1): the
+// cylinder quadratic  C = ox^2 + oy^2 - r^2  then cancels six digits and fp32 would leave ~1 % noise on the chord
+// ends.  Here every point is expressed relative to the sub-beam's centre Cb, which the traversal already placed
+// within radius + half a sub-beam of the camera ray, and every ray through its foot point A = o + sC*d with
+// sC = (Cb - o).d.  The only large-operand reductions -- Cb - o, sC and the perpendicular offset D0 = Cb - A, per
+// ray -- are done in fp64 (a dozen FMAs) and rounded once; everything after that has operands of the order of the
+// kernel radius.  Decisions that determine WHICH sub-beam evaluates a pair (ownership) are flagged when they fall
+// inside the fp32 error band and are then settled by the fp64 transcription (beamOwnerExact), so the evaluated set
+// is the reference's; the contribution itself agrees with the fp64 path to ~1e-6 relative.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "shift_device.h"
+#include "vec.h"
+
+namespace gvpm {
+
+struct BeamF {
+  f3 p1, p2, bd;
+  float len;
+  f3 flux, prefixW, parentScat, parentN, parentWi, endN;
+  float parentPdf, parentRR, parentG;
+  uint32_t flags;
+  bool endOnSurface;
+};
+
+__device__ __forceinline__ BeamF loadBeamF(const GatherArgs &a, uint32_t idx) {
+  const size_t N = a.nbeams;
+  const float4 c0 = a.cold[0 * N + idx], c1 = a.cold[1 * N + idx], c2 = a.cold[2 * N + idx], c3 = a.cold[3 * N + idx];
+  const float4 c4 = a.cold[4 * N + idx], c5 = a.cold[5 * N + idx], c6 = a.cold[6 * N + idx], c7 = a.cold[7 * N + idx];
+  const float4 c8 = a.cold[8 * N + idx];
+  BeamF b;
+  b.parentPdf = c0.w;
+  b.flux = mk3(c1.x, c1.y, c1.z);
+  b.p1 = mk3(c2.x, c2.y, c2.z); b.parentRR = c2.w;
+  b.parentN = mk3(c3.x, c3.y, c3.z); b.parentG = c3.w;
+  b.prefixW = mk3(c4.x, c4.y, c4.z);
+  b.parentScat = mk3(c5.x, c5.y, c5.z);
+  b.parentWi = mk3(c6.x, c6.y, c6.z);
+  b.p2 = mk3(c7.x, c7.y, c7.z); b.flags = __float_as_uint(c7.w);
+  b.endN = mk3(c8.x, c8.y, c8.z);
+  b.endOnSurface = !(c8.x == 0.f && c8.y == 0.f && c8.z == 0.f);
+  // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81: the length (hence the sub-beam count) is the fp64 path's
+  const d3 dD = tod(b.p2) - tod(b.p1);
+  const double lenD = sqrt(len2(dD));
+  b.len = (float)lenD;
+  b.bd = tof(dD * (1.0 / lenD));
+  return b;
+}
+
+// A ray seen from the local origin Cb: foot point A = o + s0*d, D0 = Cb - A (perpendicular to d)
+struct LocalRay {
+  f3 d, D0;
+  double s0;     // parameter of the foot point
+  float s0f;
+  float mint, maxt;
+};
+__device__ __forceinline__ LocalRay localRay(f3 o, f3 d, float mint, float maxt, f3 Cb) {
+  LocalRay r;
+  const d3 c = tod(Cb) - tod(o), dd = tod(d);
+  r.s0 = dot(c, dd);
+  r.D0 = tof(c - dd * r.s0);
+  r.d = d;
+  r.s0f = (float)r.s0;
+  r.mint = mint;
+  r.maxt = maxt;
+  return r;
+}
+// point of the ray at absolute parameter (s0 + sigma), relative to Cb
+__device__ __forceinline__ f3 atLocal(const LocalRay &r, float sigma) { return r.d * sigma - r.D0; }
+
+// cylinderIntersection (pm/beams_3d_intersections.h:77-140) for a view line V + t*dv against the cylinder of
+// radius r around A + z*da, z in [z0, z1]; rel = V - A.  tLo / tHi: the view ray's 0 and maxt, measured from V.
+__device__ __forceinline__ bool cylLocal(f3 rel, f3 dv, f3 da, float z0, float z1, float r, float tLo, float tHi,
+                                         float &tN, float &tF) {
+  const float dd = dot(dv, da);
+  const float rz = dot(rel, da);
+  const float A = 1.f - dd * dd;
+  const float Bh = dot(rel, dv) - rz * dd;
+  const float C = dot(rel, rel) - rz * rz - r * r;
+  const float disc = Bh * Bh - A * C;
+  if (!(A > 0.f) || !(disc > 0.f)) return false;  // lines farther apart than r (or parallel)
+  const float sq = fsqrt(disc);
+  const float q = Bh < 0.f ? (sq - Bh) : -(Bh + sq);
+  float x0 = fdiv(q, A), x1 = fdiv(C, q);
+  if (x0 > x1) { const float t = x0; x0 = x1; x1 = t; }
+  tN = x0;
+  tF = x1;
+  if (tN > tHi || tF < tLo) return false;
+  const float zN = rz + dd * tN, zF = rz + dd * tF;
+  if (zN < z0) {
+    if (zF < z0) return false;
+    tN = tN + (tF - tN) * fdiv(zN - z0, zN - zF);
+    return true;
+  } else if (zN < z1) {
+    return true;
+  } else if (zN > z1) {
+    if (zF > z1) return false;
+    tN = tN + (tF - tN) * fdiv(zN - z1, zN - zF);
+    return true;
+  }
+  return false;
+}
+
+struct MRecF {
+  float tr, pdfFailure;
+};
+__device__ __forceinline__ MRecF mediumEvalF(const MediumDev &m, float dist) {
+  MRecF r;
+  float e = __expf(-m.sigmaT[0] * dist);
+  r.pdfFailure = e * m.msw + (1.f - m.msw);
+  if (e < 1e-20f) e = 0.f;
+  r.tr = e;
+  return r;
+}
+
+// coordinateSystemCoherent, util.cpp:592-599
+__device__ __forceinline__ void coordSysCoherentF(f3 n, f3 &b1, f3 &b2) {
+  const float sign = copysignf(1.0f, n.z);
+  const float aa = -frcp(sign + n.z);
+  const float bb = n.x * n.y * aa;
+  b1 = mk3(1.0f + sign * n.x * n.x * aa, sign * bb, -sign * n.x);
+  b2 = mk3(bb, sign + n.y * n.y * aa, -n.y);
+}
+
+struct KRecF {
+  float tauV;     // v - tc
+  float v, w;     // absolute parameters on the beam / on the camera ray
+  float sigmaW;   // w - (camera foot parameter)
+  float pdfKernel, pdfEdgeFailure, u, weightKernel;
+  f3 contrib;
+};
+
+// shift(), shift_volume_beams.cpp:47-79: the point at distance u from the line r (at parameter w) in the plane
+// through the line and `a`, on a's side (phi = pi/2 - asin(u/|ly|): cos phi = u/|ly|, sin phi = +-sqrt(1 - cos^2)).
+// aRel = a - (foot point of r); returns the point relative to that foot point.
+__device__ __forceinline__ f3 shiftPointLocal(f3 dr, f3 aRel, float u, float sigma, bool flip) {
+  const f3 av = aRel - dr * dot(aRel, dr);
+  const float ly = fsqrt(dot(av, av));
+  const f3 sv = av * frcp(ly);
+  const f3 tv = cross(dr, sv);
+  const float x = fminf(1.f, fmaxf(-1.f, fdiv(u, ly)));
+  float sn = fsqrt(fmaxf(0.f, 1.f - x * x));
+  if (flip) sn = -sn;
+  return dr * sigma + sv * (u * x) + tv * (u * sn);
+}
+
+}  // namespace gvpm

@@ -24,6 +24,7 @@
 // future work.
 #include <hip/hip_runtime.h>
 
+#include "beams_eval_f32.h"
 #include "device_types.h"
 #include "dmath.h"
 #include "shift_device.h"
@@ -598,14 +599,393 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
   return true;
 }
 
+// The reference's decision whether sub-beam `sub` evaluates this (camera ray, beam) pair, in the fp64 transcription
+// (3D: cylinderIntersection + the ownership rule of BeamKernelRecord::eval; 1D: all of rayIntersectInternal1D).
+// Called for the few pairs whose fp32 ownership parameter falls inside its own error band.
+static __device__ __noinline__ bool beamOwnerExact(f3 p1f, f3 p2f, f3 of, f3 df, float camLen, float eps, float radius,
+                                                   uint32_t sub, float subLen, int technique) {
+  BeamD b;
+  b.p1 = tod(p1f);
+  b.p2 = tod(p2f);
+  b.dir = b.p2 - b.p1;
+  b.len = sqrt(len2(b.dir));
+  b.dir = b.dir / b.len;
+  const uint32_t nSub = subBeamCount((float)b.len, subLen);
+  const float ls = (float)b.len / (float)nSub;
+  const double tmin = (double)(ls * (float)sub);
+  double tmax = (sub + 1u >= nSub) ? INFINITY : (double)(ls * (float)(sub + 1u));
+  if (tmax > b.len) tmax = b.len;
+  const RayD cam{tod(of), tod(df), (double)eps, (double)camLen - (double)eps};
+  if (technique == GVPM_BEAM_BEAM_1D) {
+    double u, v, w, st;
+    return rayIntersect1D(b, (double)radius, cam, tmin, tmax, u, v, w, st);
+  }
+  const RayD _cam{at(cam, cam.mint), cam.d, 0.0, cam.maxt - cam.mint};
+  const RayD _beam{b.p1, b.dir, 0.0, b.len};
+  double tN, tF;
+  if (!cylinderIntersection(_cam, _beam, (double)radius, tN, tF)) return false;
+  return (tN < 0 && tmin <= (double)eps) || (tN > tmin && tN < tmax);
+}
+
+// Occluders of a small scene staged in LDS once per (persistent) workgroup: the visibility test of the beam
+// reconnection then is a wave-uniform loop over every triangle (broadcast LDS reads, no divergence, no memory
+// latency) instead of a per-lane stack walk of the BVH in global memory, which at one or two waves per SIMD was
+// latency-bound and cost more than the rest of the evaluation together.
+constexpr uint32_t SCENE_LDS_TRIS = 128;
+__device__ __forceinline__ bool anyHitLds(const float4 *tri, uint32_t ntri, f3 o, f3 d, float mint, float maxt) {
+  bool hit = false;
+  for (uint32_t i = 0; i < ntri; ++i) {
+    const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
+    hit |= triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt);
+  }
+  return hit;
+}
+
+// shiftBeamDiffuse + diffuseReconnectionPhotonBeam (shift_volume_beams.cpp:410-539, shift_diffuse.cpp:136-268) in
+// the local frame.  newPos: the offset position relative to the local origin; p1rel = p1 - origin.
 template <int B>
-__global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const uint4 *__restrict__ items,
+__device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const BeamF &b, const RayReg &sh,
+                                                   const RayReg &base, uint32_t edge, const LocalRay &sr, float shiftW,
+                                                   const KRecF &k, f3 newPos, f3 p1rel, int technique,
+                                                   const float4 *ldsTri, f3 &shiftedFlux, bool &ok) {
+  ok = false;
+  shiftedFlux = mk3(0.f);
+  f3 nd = newPos - p1rel;
+  const float dist2 = dot(nd, nd);
+  const float dist = fsqrt(dist2);
+  nd = nd * frcp(dist);
+  // visibility over the whole new beam [Epsilon, dist], shift_volume_beams.cpp:420-426
+  if (ldsTri ? anyHitLds(ldsTri, a.ntri, b.p1, nd, a.cfg.epsilon, dist)
+             : anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist))
+    return 1.f;
+  const float pdfKernelAndDist = k.pdfEdgeFailure * k.pdfKernel;
+  const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
+  f3 thr;
+  float pdfValueSA;
+  if (ptype == GVPM_PARENT_SURFACE) {
+    const float cosWo = dot(b.parentN, nd), cosWi = dot(b.parentN, b.parentWi);
+    if (cosWi <= 0.f || cosWo <= 0.f) return 1.f;
+    thr = b.parentScat * (INV_PI_F * cosWo);
+    pdfValueSA = INV_PI_F * cosWo;
+  } else if (ptype == GVPM_PARENT_MEDIUM) {
+    const float ph = phaseEval(b.parentG, b.parentWi, nd);
+    thr = b.parentScat * ph;
+    pdfValueSA = ph;
+  } else {
+    const float dp = fmaxf(dot(nd, b.parentN), 0.f);
+    thr = mk3(INV_PI_F * dp);
+    pdfValueSA = INV_PI_F * dp;
+  }
+  const float GOpNew = frcp(dist2);
+  float sPdf = pdfValueSA * GOpNew;
+  thr = thr * GOpNew;
+  // pdf of the base position from the parent: parentPdf * |p1 - p2|^2 [/ |n_end . d|] / v^2
+  float pdfBasePos = b.parentPdf * (b.len * b.len);
+  if (b.endOnSurface) pdfBasePos = fdiv(pdfBasePos, fabsf(dot(b.endN, b.bd)));
+  pdfBasePos *= frcp(k.v * k.v);
+  if (pdfBasePos == 0.f) return 1.f;
+  thr = thr * fdiv(b.parentRR, pdfBasePos);
+  if (GVPM_PF_EDGE_IN_MEDIUM(b.flags)) {
+    const MRecF m = mediumEvalF(a.med, dist);
+    sPdf *= m.pdfFailure;
+    thr = thr * fdiv(m.tr, pdfKernelAndDist);
+  }
+  if (sPdf == 0.f) return 1.f;
+  // BeamKernelRecord::kernelPDF of the new beam p1 -> newPos against the shifted ray (shift_volume_beams.h:300-336)
+  float shiftKernelPDF = 0.f;
+  if (technique == GVPM_BEAM_BEAM_1D) {
+    const f3 c = cross(sr.d, nd);
+    shiftKernelPDF = fsqrt(dot(c, c));
+  } else {
+    const f3 q = newPos + sr.D0;  // newPos from the shifted ray's foot point
+    const float zq = dot(q, sr.d);
+    const f3 D0n = q - sr.d * zq;
+    const float z0 = (float)(-sr.s0) - zq, z1 = (float)((double)sr.maxt - sr.s0) - zq;
+    float tN, tF;
+    if (cylLocal(D0n, nd, sr.d, z0, z1, a.kernelRadius, -dist, INFINITY, tN, tF)) {
+      const float radSqr = a.kernelRadius * a.kernelRadius, distSqr = dot(D0n, D0n);
+      if (distSqr < radSqr)
+        shiftKernelPDF = frcp(fmaxf(tF - tN, 0.0001f)) * frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
+    }
+  }
+  if (shiftKernelPDF == 0.f) return 1.f;
+  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  const MRecF mS = mediumEvalF(a.med, shiftW);
+  const float ph = phaseEval(a.med.g, -nd, -sr.d) * mS.tr;
+  shiftedFlux = b.prefixW * thr * sigS * sh.eye * ph;
+  ok = true;
+  float w = 0.5f;
+  if (a.cfg.use_mis) {
+    const float basePdf = pdfBasePos * pdfKernelAndDist;
+    const float offsetPdf = shiftKernelPDF * sPdf;
+    if (offsetPdf == 0.f || basePdf == 0.f) {
+      ok = false;
+      return 1.f;
+    }
+    const float x = sensorMIS(sh, base, edge) * fdiv(offsetPdf, basePdf);
+    w = a.cfg.power_heuristic ? frcp(1.f + x * x) : frcp(1.f + x);
+  }
+  return w;
+}
+
+// One (camera ray, sub-beam) candidate in fp32 (beams_eval_f32.h): BeamGradRadianceQuery::operator().
+template <int B>
+__device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s, const float4 *ldsTri, uint32_t id,
+                                              uint32_t bIdx, uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+  const uint32_t beamIdx = id & 0xFFFFFFu, sub = id >> 24;
+  const BeamF b = loadBeamF(a, beamIdx);
+  const RayReg base = loadRay(s, 0, bIdx);
+  const uint32_t edge = s.edge[bIdx];
+  const uint32_t pix = s.pix[bIdx];
+  const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
+  const int technique = a.cfg.vol_technique;
+  const bool is1D = technique == GVPM_BEAM_BEAM_1D;
+  // filters, shift_volume_beams.cpp:142-184
+  const int pathLength = (int)edge + (int)GVPM_PF_DEPTH(b.flags);
+  if (a.cfg.max_depth > 0 && pathLength > a.cfg.max_depth) return false;
+  if (!((b.flags >> 6) & 1u)) return false;
+  float rr = 1.f;
+  if (a.cfg.path_set) {
+    if (((b.flags >> GVPM_HOT_PARITY_BIT) & 1u) != (uint32_t)((px + py) & 1)) return false;
+    rr = 2.f;
+  }
+  const float r = a.kernelRadius, eps = a.cfg.epsilon;
+  const uint32_t nSub = subBeamCount(b.len, a.subLen);
+  const float ls = b.len / (float)nSub;
+  const float tmin = ls * (float)sub;
+  const float tmax = (sub + 1u >= nSub) ? b.len : fminf(ls * (float)(sub + 1u), b.len);
+  const float tc = ls * ((float)sub + 0.5f);
+  // local origin: the sub-beam's centre, kept in fp64 so that it lies on the beam's line
+  const d3 p1D = tod(b.p1);
+  const d3 O = p1D + (tod(b.p2) - p1D) * ((double)tc / (double)b.len);
+  LocalRay cam;
+  {
+    const d3 c = O - tod(base.o), dd = tod(base.d);
+    cam.s0 = dot(c, dd);
+    cam.D0 = tof(c - dd * cam.s0);
+    cam.d = base.d;
+    cam.s0f = (float)cam.s0;
+    cam.mint = eps;
+    cam.maxt = base.len - eps;
+  }
+  const f3 p1rel = b.bd * (-tc);
+  const float bdd = dot(b.bd, base.d);
+  const float sin2 = fmaxf(1.f - bdd * bdd, 0.f);
+  uint32_t o0, o1;
+  philox4x32_10(__float_as_uint(s.rnd[bIdx]), 0x6265616du, beamIdx, o0, o1);
+  const float uv = (float)(o0 >> 8) * (1.0f / 16777216.0f);
+  const float uw = (float)(o1 >> 8) * (1.0f / 16777216.0f);
+  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+
+  KRecF k;
+  k.u = 0.f;
+  const float band0 = 2e-6f * (r + ls) * frcp(fmaxf(sin2, 1e-12f));
+  if (is1D) {
+    // PhotonBeam::rayIntersectInternal1D (pm/beams_struct.h:250-311): closest approach of the two lines
+    const f3 cr = cross(base.d, b.bd);
+    const float ad = dot(cam.D0, cr);
+    if (ad * ad >= r * r * sin2) return false;
+    if (sin2 < 1e-5f) return false;  // |d1.d2^2 - 1| < 1e-5
+    const float d0d = dot(cam.D0, base.d);
+    const float tau0 = -(dot(cam.D0, b.bd) - d0d * bdd) * frcp(sin2);
+    const float sig0 = d0d + tau0 * bdd;
+    const float v = tc + tau0;
+    const float w = (float)(cam.s0 + (double)sig0);
+    const float band = band0 + 1e-5f * (fabsf(v) + ls);
+    const bool amb = fabsf(v - tmin) < band || fabsf(v - tmax) < band || fabsf(bdd) < 0.05f;
+    if (amb) {
+      if (!beamOwnerExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique)) return false;
+    } else {
+      if (w <= cam.mint || w >= cam.maxt) return false;
+      if (v <= 0.f || v >= b.len) return false;
+      if (tmin >= v || tmax < v) return false;
+    }
+    const float sinT = fsqrt(sin2);
+    k.u = fdiv(fabsf(ad), sinT);
+    k.tauV = tau0;
+    k.v = v;
+    k.w = w;
+    k.sigmaW = sig0;
+    k.pdfKernel = sinT;
+    const MRecF mCam = mediumEvalF(a.med, w), mB = mediumEvalF(a.med, v);
+    k.weightKernel = 0.5f * frcp(r);
+    k.pdfEdgeFailure = mB.pdfFailure;
+    if (mB.pdfFailure == 0.f && mB.tr != 0.f) return false;
+    const float sc = fdiv(mB.tr * mCam.tr * phaseEval(a.med.g, -b.bd, -base.d), mB.pdfFailure * k.pdfKernel);
+    k.contrib = sigS * b.flux * sc;
+  } else {
+    // BeamKernelRecord::eval, shift_volume_beams.h:157-290
+    float tN, tF;
+    const float z0 = (float)((double)cam.mint - cam.s0), z1 = (float)((double)cam.maxt - cam.s0);
+    if (!cylLocal(cam.D0, b.bd, base.d, z0, z1, r, -tc, b.len - tc, tN, tF)) return false;
+    const float tNa = tc + tN;
+    const float band = band0 + 1e-5f * (fabsf(tNa) + ls);
+    const bool amb = fabsf(tNa - tmin) < band || fabsf(tNa - tmax) < band || (sub == 0u && fabsf(tNa) < band);
+    const bool own = amb ? beamOwnerExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique)
+                         : ((tNa < 0.f && tmin <= eps) || (tNa > tmin && tNa < tmax));
+    if (!own) return false;
+    k.tauV = tN + (tF - tN) * uv;
+    k.v = tc + k.tauV;
+    k.pdfKernel = frcp(fmaxf(tF - tN, 0.0001f));
+    if (k.v < 0.f || k.v > b.len) return false;
+    f3 perp = cam.D0 + (b.bd - base.d * bdd) * k.tauV;
+    perp = perp - base.d * dot(perp, base.d);
+    const float distSqr = dot(perp, perp), radSqr = r * r;
+    if (distSqr >= radSqr) return false;
+    const float deltaT = fsqrt(fmaxf(0.f, radSqr - distSqr));
+    // distToProj = s0 + dot(D0, d) + tauV * (b.d): the kernel centre's parameter on the camera ray
+    k.sigmaW = (dot(cam.D0, base.d) + k.tauV * bdd) - deltaT + 2.f * deltaT * uw;
+    k.w = (float)(cam.s0 + (double)k.sigmaW);
+    k.pdfKernel *= frcp(fmaxf(2.f * deltaT, 0.0001f));
+    if (k.w < cam.mint || k.w > cam.maxt) return false;
+    const MRecF mB = mediumEvalF(a.med, k.v), mCam = mediumEvalF(a.med, k.w);
+    const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
+    const float sc = fdiv(mB.tr * mCam.tr * phaseEval(a.med.g, -b.bd, -base.d), k.pdfKernel * mB.pdfFailure);
+    k.contrib = b.flux * sigS * sc;
+    k.weightKernel = frcp(kernelVol);
+    k.pdfEdgeFailure = mB.pdfFailure;
+  }
+  if (k.contrib.x == 0.f && k.contrib.y == 0.f && k.contrib.z == 0.f) return false;
+  if (!(k.contrib.x == k.contrib.x)) return false;
+
+  const f3 baseContrib = base.eye * k.contrib * k.weightKernel;
+  atomicAdd(&s.acc[0][bIdx], baseContrib.x * rr);
+  atomicAdd(&s.acc[1][bIdx], baseContrib.y * rr);
+  atomicAdd(&s.acc[2][bIdx], baseContrib.z * rr);
+  const uint32_t st = GVPM_PF_SHIFT_TYPE(b.flags);
+  if (a.cfg.debug_shift != GVPM_SHIFT_ALL && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
+    const int cur = st == 1u ? GVPM_SHIFT_DIFFUSE : st == 2u ? GVPM_SHIFT_MEDIUM : st == 3u ? GVPM_SHIFT_MANIFOLD : GVPM_SHIFT_INVALID;
+    if (a.cfg.debug_shift != cur) return false;  // base contribution kept, no shifts (shift_volume_beams.cpp:210-216)
+  }
+  const double wD = cam.s0 + (double)k.sigmaW;
+  const f3 kc = b.bd * k.tauV;                 // kernel centre on the beam, local
+  const f3 camW = atLocal(cam, k.sigmaW);      // camera ray at w, local
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const RayReg sh = loadRay(s, 1 + i, bIdx);
+    float w = 1.f;
+    f3 sflux = mk3(0.f);
+    if (sh.valid) {
+      const float shiftDistMAX = sh.len;
+      LocalRay sr;
+      {
+        const d3 c = O - tod(sh.o), dd = tod(sh.d);
+        sr.s0 = dot(c, dd);
+        sr.D0 = tof(c - dd * sr.s0);
+        sr.d = sh.d;
+        sr.s0f = (float)sr.s0;
+        sr.mint = eps;
+        sr.maxt = shiftDistMAX;
+      }
+      const float sigS_w = (float)(wD - sr.s0);  // the same distance w on the shifted ray, from its foot point
+      const f3 shW = atLocal(sr, sigS_w);
+      bool alreadyShift = false;
+      if (a.cfg.use_shift_null && !is1D) {
+        const f3 dz = shW - kc;
+        if (dot(dz, dz) < r * r && k.w <= shiftDistMAX) {
+          // BeamKernelRecord copy-shift constructor (shift_volume_beams.h:40-144) + shiftNull3D (.cpp:748-786)
+          float tN, tF;
+          const float z0 = (float)((double)eps - sr.s0), z1 = (float)((double)shiftDistMAX - sr.s0);
+          if (cylLocal(sr.D0, b.bd, sr.d, z0, z1, r, -tc, b.len - tc, tN, tF)) {
+            float pdfK = frcp(fmaxf(tF - tN, 0.0001f));
+            const float bds = dot(b.bd, sr.d);
+            f3 perp = sr.D0 + (b.bd - sr.d * bds) * k.tauV;
+            perp = perp - sr.d * dot(perp, sr.d);
+            const float distSqr = dot(perp, perp), radSqr = r * r;
+            if (distSqr < radSqr && !(k.w < sr.mint || k.w > sr.maxt)) {
+              pdfK *= frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
+              nNull++;
+              sflux = k.contrib * sh.eye;  // kS.contrib * kpdf(kS) / kpdf(kRec): the pdf ratios cancel
+              w = 0.5f;
+              if (a.cfg.use_mis) {
+                const float x = sensorMIS(sh, base, edge) * fdiv(pdfK, k.pdfKernel);
+                w = a.cfg.power_heuristic ? frcp(1.f + x * x) : frcp(1.f + x);
+              }
+              alreadyShift = true;
+            }
+          }
+        }
+      }
+      if (!alreadyShift && k.w <= shiftDistMAX) {
+        bool doShift = true;
+        f3 offsetPos;
+        if (!is1D) {
+          // distance of the beam's origin to the shifted ray against kRec.u (= 0 for the 3D kernel)
+          f3 pv = p1rel + sr.D0;
+          pv = pv - sr.d * dot(pv, sr.d);
+          if (dot(pv, pv) > k.u * k.u) {
+            // getShiftPos (3D), shift_volume_beams.cpp:93-137: the kernel offset in the base ray's coherent frame,
+            // replayed in the shifted ray's
+            const f3 u = kc - camW;
+            f3 bs, bt, ns, nt;
+            coordSysCoherentF(base.d, bs, bt);
+            coordSysCoherentF(sr.d, ns, nt);
+            const float lx = dot(u, bs), ly = dot(u, bt), lz = dot(u, base.d);
+            offsetPos = shW + (ns * lx + nt * ly + sr.d * lz);
+            if (a.cfg.use_shift_null) {
+              const f3 dv = camW - offsetPos;
+              if (dot(dv, dv) < r * r) {
+                f3 dShift = shW - camW;
+                dShift = dShift * frsq(dot(dShift, dShift));
+                const float cosD = dot(dShift, shW - offsetPos);
+                offsetPos = offsetPos + dShift * (cosD * 2.0f);
+              }
+            }
+          } else {
+            doShift = false;
+          }
+        } else {
+          // getShiftPos1D, shift_volume_beams.cpp:81-91
+          const f3 aCam = p1rel + cam.D0;  // p1 from the base ray's foot point
+          f3 back = shiftPointLocal(base.d, aCam, k.u, k.sigmaW, false) - aCam;
+          back = back * frsq(dot(back, back));
+          const f3 df = back - b.bd;
+          const bool flip = dot(df, df) > 0.001f;
+          offsetPos = shiftPointLocal(sr.d, p1rel + sr.D0, k.u, sigS_w, flip) - sr.D0;
+        }
+        if (doShift) {
+          if (a.cfg.debug_shift == GVPM_SHIFT_NULL || k.w > sr.maxt) {
+            w = 1.f;
+          } else {
+            bool ok = false;
+            if (st == 1u || st == 2u)
+              w = shiftBeamDiffuseF<B>(a, b, sh, base, edge, sr, k.w, k, offsetPos, p1rel, technique, ldsTri, sflux, ok);
+            if (ok) nDiff++; else nFail++;
+          }
+        }
+      }
+    }
+    if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
+    const float ws = w * rr;
+    if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+      const float wk = ws * k.weightKernel;
+      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], sflux.x * wk);
+      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], sflux.y * wk);
+      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], sflux.z * wk);
+    }
+    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], baseContrib.x * ws);
+    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], baseContrib.y * ws);
+    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], baseContrib.z * ws);
+  }
+  return true;
+}
+
+
+template <int B, bool EXACT>
+__global__ __launch_bounds__(64, EXACT ? 1 : 2) void gather_beams_kernel(GatherArgs a, const uint4 *__restrict__ items,
                                                              const uint32_t *__restrict__ itemCount,
                                                              uint32_t *queueHead) {
   constexpr int LPB = 64 / B;
   __shared__ TileLds<B> s;
   __shared__ uint2 queue2[QCAP];  // candidates that passed the fp32 prefilter
+  __shared__ float4 sceneTri[EXACT ? 1 : 3 * SCENE_LDS_TRIS];
   const int lane = threadIdx.x;
+  const float4 *ldsTri = nullptr;
+  if (!EXACT && a.ntri <= SCENE_LDS_TRIS) {
+    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
+    ldsTri = sceneTri;
+    __syncthreads();
+  }
   const int technique = a.cfg.vol_technique;
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
@@ -639,7 +1019,7 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
       uint2 e = make_uint2(0u, 0u);
       if ((uint32_t)lane < n) {
         e = s.queue[(qHead + lane) % QCAP];
-        keep = (a.cfg.reserved[0] & 2) ? false : beamPrefilter(a, loadRay(s, 0, (int)e.y), e.x, technique);
+        keep = beamPrefilter(a, loadRay(s, 0, (int)e.y), e.x, technique);
       }
       const unsigned long long km = __ballot(keep);
       if (keep) queue2[(q2Head + q2Count + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) % QCAP] = e;
@@ -649,7 +1029,9 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
       __syncthreads();
       if (q2Count >= 64u) {
         const uint2 e2 = queue2[(q2Head + lane) % QCAP];
-        if (!(a.cfg.reserved[0] & 1) && evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)) nEval++;
+        if (EXACT ? evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)
+                  : evaluateBeamF<B>(a, s, ldsTri, e2.x, e2.y, nNull, nDiff, nFail))
+          nEval++;
         q2Head = (q2Head + 64u) % QCAP;
         q2Count -= 64u;
         __syncthreads();
@@ -710,7 +1092,9 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
     if (qCount) refine(qCount);
     if ((uint32_t)lane < q2Count) {
       const uint2 e2 = queue2[(q2Head + lane) % QCAP];
-      if (evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)) nEval++;
+      if (EXACT ? evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)
+                : evaluateBeamF<B>(a, s, ldsTri, e2.x, e2.y, nNull, nDiff, nFail))
+        nEval++;
     }
     __syncthreads();
     for (int idx = lane; idx < 27 * B; idx += 64) {
@@ -744,14 +1128,25 @@ __global__ __launch_bounds__(64, 1) void gather_beams_kernel(GatherArgs a, const
   }
 }
 
-void launch_gather_beams(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
+void launch_gather_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint4 *items, const uint32_t *itemCount,
                          uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
   if (a.nsets == 0) return;
-  switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(gather_beams_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
-    case 32: hipLaunchKernelGGL(gather_beams_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
-    default: hipLaunchKernelGGL(gather_beams_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead); break;
+#define GVPM_LAUNCH_BEAMS(BB, EX) \
+  hipLaunchKernelGGL((gather_beams_kernel<BB, EX>), dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead)
+  if (exact) {
+    switch (beamsPerWave) {
+      case 64: GVPM_LAUNCH_BEAMS(64, true); break;
+      case 32: GVPM_LAUNCH_BEAMS(32, true); break;
+      default: GVPM_LAUNCH_BEAMS(16, true); break;
+    }
+  } else {
+    switch (beamsPerWave) {
+      case 64: GVPM_LAUNCH_BEAMS(64, false); break;
+      case 32: GVPM_LAUNCH_BEAMS(32, false); break;
+      default: GVPM_LAUNCH_BEAMS(16, false); break;
+    }
   }
+#undef GVPM_LAUNCH_BEAMS
 }
 
 // ---- grid build helpers for sub-beams ------------------------------------------------------

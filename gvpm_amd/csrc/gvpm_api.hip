@@ -79,7 +79,7 @@ void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint
                         float *centres, uint32_t *ids, hipStream_t s);
 void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, float4 *hot,
                     hipStream_t s);
-void launch_gather_beams(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint32_t *itemCount,
+void launch_gather_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint4 *items, const uint32_t *itemCount,
                          uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
 struct PlaneArgs {
   const float4 *test;
@@ -189,6 +189,7 @@ struct gvpm_context {
   BuildSet *bs = &sets[0];
   int setIdx = 0;
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
+  bool beamsExact = false;        // G-Beams: the literal fp64 evaluation instead of the local-frame fp32 one
   bool pipeline = true;           // GVPM_PIPELINE=0: everything on the gather stream (isolated kernel timings)
   gvpm_params cfg;
   gvpm_medium medium;
@@ -378,6 +379,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   }
   if (const char *e = getenv("GVPM_PIPELINE")) h->pipeline = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -1107,7 +1109,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
   launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr, h->stream);
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_beams(a, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->nwaves, h->stream);
+  launch_gather_beams(a, h->beamsPerWave, h->beamsExact, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
