@@ -416,22 +416,8 @@ __device__ __forceinline__ uint32_t subBeamCount(float len, float ls) {
 // and well conditioned; near-parallel pairs are passed through.  The fp64 evaluation that follows repeats the
 // reference's tests exactly: the prefilter only removes pairs it would reject (~7 of 8: each beam crosses the ray's
 // neighbourhood with several sub-beams and exactly one owns the pair).
-__device__ __forceinline__ bool beamPrefilter(const GatherArgs &a, const RayReg &base, uint32_t id, int technique) {
-  const uint32_t beamIdx = id & 0xFFFFFFu, sub = id >> 24;
-  const size_t N = a.nbeams;
-  const float4 c2 = a.cold[2 * N + beamIdx], c7 = a.cold[7 * N + beamIdx];
-  const f3 p1 = mk3(c2.x, c2.y, c2.z), p2 = mk3(c7.x, c7.y, c7.z);
-  // the sub-beam count must be the evaluation's: same fp64 length rounded to float (loadBeam)
-  const d3 dD = tod(p2) - tod(p1);
-  const double lenD = sqrt(len2(dD));
-  const float len = (float)lenD;
-  const uint32_t nSub = subBeamCount(len, a.subLen);
-  const float ls = len / (float)nSub;
-  const f3 bd = (p2 - p1) * frcp(len);
-  const float tc = ls * ((float)sub + 0.5f);
-  const f3 C = p1 + bd * tc;
-  const float r = a.kernelRadius;
-  const float eps = a.cfg.epsilon;
+__device__ __forceinline__ bool beamPrefilter(const RayReg &base, f3 C, f3 bd, float ls, uint32_t sub, float r, float eps,
+                                              int technique) {
   const f3 co = C - base.o;
   const float sC = dot(co, base.d);
   const f3 D0 = co - base.d * sC;  // centre relative to its projection on the camera line
@@ -971,28 +957,35 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
 }
 
 
-template <int B, bool EXACT>
-__global__ __launch_bounds__(64, EXACT ? 1 : 2) void gather_beams_kernel(GatherArgs a, const uint4 *__restrict__ items,
-                                                             const uint32_t *__restrict__ itemCount,
-                                                             uint32_t *queueHead) {
+// ---- traversal: (camera ray, sub-beam) pairs that survive the sphere test and the fp32 prefilter ---------------
+// Persistent waves over the planner's items (tile_walk.h), built like the BRE traversal: the sub-beam records of a
+// slab box -- {centre, beam | sub << 24} {direction, sub-beam length} + the beam's filter bits, 36 bytes -- are
+// staged in LDS; every lane (ray b = lane % B, slot = lane / B) sphere-tests G staged records branch-free, then the
+// wave resolves the marked ones one per lane and round: flag filters (contribution, checkerboard parity, depth) and
+// the ownership prefilter, straight from LDS and the lane's own ray registers.  Survivors are compacted by ballot
+// into an LDS ring and appended to the global pair list 64 at a time (one atomic per 64 pairs; the tail of an item
+// is padded with empty pairs so that a block of 64 never mixes tiles).  pair = {beam | sub << 24, sorted set index}.
+struct BeamTravLds {
+  float4 st0[STAGE], st1[STAGE];
+  uint32_t stF[STAGE];
+  uint2 outq[QCAP];
+};
+
+template <int B>
+__global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const uint32_t *__restrict__ hotFlags,
+                                                            const uint4 *__restrict__ items,
+                                                            const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
+                                                            uint2 *__restrict__ pairs, uint32_t *pairCount,
+                                                            uint32_t pairCap) {
   constexpr int LPB = 64 / B;
-  __shared__ TileLds<B> s;
-  __shared__ uint2 queue2[QCAP];  // candidates that passed the fp32 prefilter
-  __shared__ float4 sceneTri[EXACT ? 1 : 3 * SCENE_LDS_TRIS];
+  __shared__ BeamTravLds s;
   const int lane = threadIdx.x;
-  const float4 *ldsTri = nullptr;
-  if (!EXACT && a.ntri <= SCENE_LDS_TRIS) {
-    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
-    ldsTri = sceneTri;
-    __syncthreads();
-  }
   const int technique = a.cfg.vol_technique;
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
   const float rT = a.radius;  // test radius = kernel radius + half a sub-beam
+  const float r = a.kernelRadius;
   const float eps = a.cfg.epsilon;
-
-  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   unsigned long long nCand = 0;
 
   for (;;) {
@@ -1003,39 +996,23 @@ __global__ __launch_bounds__(64, EXACT ? 1 : 2) void gather_beams_kernel(GatherA
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y;
     if (nb == 0) continue;
-    __syncthreads();
-    loadTileRays<B>(a, s, setBase, nb, lane);
-    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
-    __syncthreads();
+    BaseInfo bi;
+    const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
     TileWalk w;
-    tileSetup<B>(a, s, nb, lane, w);
-    const RayReg base = w.base;
+    tileSetupFrom(a, base, base.valid, w);
     const bool beamValid = w.beamValid;
     const float mint = eps, maxt = base.len - eps;
-    uint32_t qHead = 0, qCount = 0, q2Head = 0, q2Count = 0;
-    // 64 (or the last n) sphere-test survivors -> prefilter -> queue2 -> 64 at a time -> evaluation
-    auto refine = [&](uint32_t n) {
-      bool keep = false;
-      uint2 e = make_uint2(0u, 0u);
-      if ((uint32_t)lane < n) {
-        e = s.queue[(qHead + lane) % QCAP];
-        keep = beamPrefilter(a, loadRay(s, 0, (int)e.y), e.x, technique);
-      }
-      const unsigned long long km = __ballot(keep);
-      if (keep) queue2[(q2Head + q2Count + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) % QCAP] = e;
-      q2Count += (uint32_t)__popcll(km);
+    const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
+    const int edge = (int)bi.edge;
+    uint32_t qHead = 0, qCount = 0;
+    auto emit = [&](uint32_t n) {  // n <= 64 pairs of the ring -> one block of 64 in the global list
+      uint32_t slot = 0;
+      if (lane == 0) slot = atomicAdd(pairCount, 64u);
+      slot = __shfl(slot, 0, 64);
+      const uint2 e = (uint32_t)lane < n ? s.outq[(qHead + lane) % QCAP] : make_uint2(0xFFFFFFFFu, 0u);
+      if (slot + 64u <= pairCap) pairs[slot + lane] = e;  // past the capacity: counted, not written (host regrows)
       qHead = (qHead + n) % QCAP;
       qCount -= n;
-      __syncthreads();
-      if (q2Count >= 64u) {
-        const uint2 e2 = queue2[(q2Head + lane) % QCAP];
-        if (EXACT ? evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)
-                  : evaluateBeamF<B>(a, s, ldsTri, e2.x, e2.y, nNull, nDiff, nFail))
-          nEval++;
-        q2Head = (q2Head + 64u) % QCAP;
-        q2Count -= 64u;
-        __syncthreads();
-      }
     };
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
@@ -1050,50 +1027,122 @@ __global__ __launch_bounds__(64, EXACT ? 1 : 2) void gather_beams_kernel(GatherA
         const uint32_t excl = incl - count;
         const uint32_t total = __shfl(incl, 63, 64);
         for (uint32_t win = 0; win < total; win += STAGE) {
+          __syncthreads();
           {
             const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
-            for (uint32_t i = lo_i; i < hi_i; ++i) s.stage[i - win] = a.hot[start + (i - excl)];
+            uint32_t i = lo_i;
+            for (; i + 2 <= hi_i; i += 2) {  // two records (four 16-byte loads) in flight per lane
+              const uint32_t gi = start + (i - excl);
+              const float4 v0 = a.hot[2 * (size_t)gi], v1 = a.hot[2 * (size_t)gi + 1];
+              const float4 v2 = a.hot[2 * (size_t)gi + 2], v3 = a.hot[2 * (size_t)gi + 3];
+              const uint32_t f0 = hotFlags[gi], f1 = hotFlags[gi + 1];
+              s.st0[i - win] = v0; s.st1[i - win] = v1; s.stF[i - win] = f0;
+              s.st0[i - win + 1] = v2; s.st1[i - win + 1] = v3; s.stF[i - win + 1] = f1;
+            }
+            for (; i < hi_i; ++i) {
+              const uint32_t gi = start + (i - excl);
+              s.st0[i - win] = a.hot[2 * (size_t)gi];
+              s.st1[i - win] = a.hot[2 * (size_t)gi + 1];
+              s.stF[i - win] = hotFlags[gi];
+            }
           }
           __syncthreads();
           const uint32_t nst = min((uint32_t)STAGE, total - win);
           const uint32_t iters = (nst + LPB - 1) / LPB;
-          for (uint32_t jj = 0; jj < iters; ++jj) {
-            const uint32_t j = jj * LPB + sub;
-            bool hit = false;
-            uint32_t id = 0;
-            if (beamValid && j < nst) {
-              const float4 hp = s.stage[j];
-              const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
-              const float disk = dot(wv, base.d);
-              const f3 v = wv - base.d * disk;
-              // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment
-              hit = dot(v, v) < rT * rT * 1.001f && disk > mint - rT * 1.001f && disk < maxt + rT * 1.001f;
-              id = __float_as_uint(hp.w);
+          constexpr uint32_t G = 4;
+          for (uint32_t jj = 0; jj < iters; jj += G) {
+            uint32_t cm = 0;
+            if (beamValid) {
+#pragma unroll
+              for (uint32_t u = 0; u < G; ++u) {
+                const uint32_t j = (jj + u) * LPB + sub;
+                const float4 hp = s.st0[min(j, (uint32_t)STAGE - 1u)];
+                const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
+                const float disk = dot(wv, base.d);
+                const f3 v = wv - base.d * disk;
+                // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment
+                if (j < nst && dot(v, v) < rT * rT * 1.001f && disk > mint - rT * 1.001f && disk < maxt + rT * 1.001f)
+                  cm |= 1u << u;
+              }
             }
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-              if (hit) {
-                const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-                s.queue[(qHead + qCount + off) % QCAP] = make_uint2(id, (uint32_t)b);
+            unsigned long long any = __ballot(cm != 0u);
+            while (any) {
+              const bool active = cm != 0u;
+              const uint32_t j = min((jj + (active ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)STAGE - 1u);
+              cm &= cm - 1u;
+              nCand += __popcll(any);
+              const float4 h0 = s.st0[j], h1 = s.st1[j];
+              const uint32_t fl = s.stF[j], id = __float_as_uint(h0.w);
+              bool keep = active && ((fl >> 6) & 1u) != 0u &&
+                          !(a.cfg.path_set && ((fl >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) &&
+                          !(a.cfg.max_depth > 0 && edge + (int)GVPM_PF_DEPTH(fl) > a.cfg.max_depth);
+              keep = keep && beamPrefilter(base, mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z), h1.w, id >> 24, r, eps, technique);
+              const unsigned long long km = __ballot(keep);
+              if (km) {
+                if (keep)
+                  s.outq[(qHead + qCount + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) % QCAP] =
+                      make_uint2(id, setBase + (uint32_t)b);
+                qCount += (uint32_t)__popcll(km);
+                if (qCount >= 64u) {
+                  __syncthreads();
+                  emit(64u);
+                  __syncthreads();
+                }
               }
-              qCount += __popcll(m);
-              nCand += __popcll(m);
-              if (qCount >= 64u) {
-                __syncthreads();
-                refine(64u);
-              }
+              any = __ballot(cm != 0u);
             }
           }
-          __syncthreads();
         }
       }
     }
     __syncthreads();
-    if (qCount) refine(qCount);
-    if ((uint32_t)lane < q2Count) {
-      const uint2 e2 = queue2[(q2Head + lane) % QCAP];
-      if (EXACT ? evaluateBeam<B>(a, s, e2.x, e2.y, nNull, nDiff, nFail)
-                : evaluateBeamF<B>(a, s, ldsTri, e2.x, e2.y, nNull, nDiff, nFail))
+    if (qCount) emit(qCount);
+    __syncthreads();
+  }
+  if (lane == 0 && nCand) atomicAdd(&a.stats[1], nCand);
+}
+
+// ---- evaluation: one pair per lane, blocks of 64 pairs of one tile --------------------------------------------
+// The block's camera-beam sets (at most B consecutive sorted sets) are loaded into LDS, the lanes evaluate their
+// pairs (fp32 local-frame evaluation, or the literal fp64 one when EXACT) into the block's LDS accumulators, and
+// the touched accumulators go to the film with one global atomic each.
+template <int B, bool EXACT>
+__global__ __launch_bounds__(64, EXACT ? 1 : 2) void evaluate_beams_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
+                                                                           const uint32_t *__restrict__ pairCount,
+                                                                           uint32_t pairCap, uint32_t *queueHead) {
+  __shared__ TileLds<B> s;
+  __shared__ float4 sceneTri[EXACT ? 1 : 3 * SCENE_LDS_TRIS];
+  const int lane = threadIdx.x;
+  const float4 *ldsTri = nullptr;
+  if (!EXACT && a.ntri <= SCENE_LDS_TRIS) {
+    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
+    ldsTri = sceneTri;
+    __syncthreads();
+  }
+  const uint32_t nBlocks = min(*pairCount, pairCap) / 64u;
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+  for (;;) {
+    uint32_t blk = 0;
+    if (lane == 0) blk = atomicAdd(queueHead, 1u);
+    blk = __shfl(blk, 0, 64);
+    if (blk >= nBlocks) break;
+    const uint2 e = pairs[(size_t)blk * 64u + lane];
+    const bool live = e.x != 0xFFFFFFFFu;
+    uint32_t lo = live ? e.y : 0xFFFFFFFFu, hi = live ? e.y : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor(lo, o, 64));
+      hi = max(hi, (uint32_t)__shfl_xor(hi, o, 64));
+    }
+    if (lo == 0xFFFFFFFFu) continue;
+    const uint32_t nb = min(hi - lo + 1u, (uint32_t)B);
+    __syncthreads();
+    loadTileRays<B>(a, s, lo, nb, lane);
+    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+    __syncthreads();
+    if (live && e.y - lo < (uint32_t)B) {
+      if (EXACT ? evaluateBeam<B>(a, s, e.x, e.y - lo, nNull, nDiff, nFail)
+                : evaluateBeamF<B>(a, s, ldsTri, e.x, e.y - lo, nNull, nDiff, nFail))
         nEval++;
     }
     __syncthreads();
@@ -1118,9 +1167,8 @@ __global__ __launch_bounds__(64, EXACT ? 1 : 2) void gather_beams_kernel(GatherA
       di += __shfl_xor(di, o, 64);
       fa += __shfl_xor(fa, o, 64);
     }
-    if (lane == 0 && (ev | nCand)) {
+    if (lane == 0 && ev) {
       atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[1], nCand);
       atomicAdd(&a.stats[2], nu);
       atomicAdd(&a.stats[3], di);
       atomicAdd(&a.stats[4], fa);
@@ -1128,11 +1176,22 @@ __global__ __launch_bounds__(64, EXACT ? 1 : 2) void gather_beams_kernel(GatherA
   }
 }
 
-void launch_gather_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint4 *items, const uint32_t *itemCount,
-                         uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
+void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
+                           const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
+                           uint32_t pairCap, uint32_t nwaves, hipStream_t stream) {
+  if (a.nsets == 0) return;
+  switch (beamsPerWave) {
+    case 64: hipLaunchKernelGGL(traverse_beams_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, queueHead, pairs, pairCount, pairCap); break;
+    case 32: hipLaunchKernelGGL(traverse_beams_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, queueHead, pairs, pairCount, pairCap); break;
+    default: hipLaunchKernelGGL(traverse_beams_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, queueHead, pairs, pairCount, pairCap); break;
+  }
+}
+
+void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint2 *pairs, const uint32_t *pairCount,
+                           uint32_t pairCap, uint32_t *queueHead, uint32_t nwaves, hipStream_t stream) {
   if (a.nsets == 0) return;
 #define GVPM_LAUNCH_BEAMS(BB, EX) \
-  hipLaunchKernelGGL((gather_beams_kernel<BB, EX>), dim3(nwaves), dim3(64), 0, stream, a, items, itemCount, queueHead)
+  hipLaunchKernelGGL((evaluate_beams_kernel<BB, EX>), dim3(nwaves), dim3(64), 0, stream, a, pairs, pairCount, pairCap, queueHead)
   if (exact) {
     switch (beamsPerWave) {
       case 64: GVPM_LAUNCH_BEAMS(64, true); break;
@@ -1188,13 +1247,26 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(const float *__restric
   }
 }
 
+// sorted sub-beam records for the traversal: {centre, beam | sub << 24} {beam direction, sub-beam length} and the
+// beam's filter bits (cold word 7.w: contribution, parity, depth).  The length is the evaluation's (fp64 norm
+// rounded to float), so that sub-beam ranges agree.
 __global__ __launch_bounds__(256) void sub_hot_kernel(const float *__restrict__ centres, const uint32_t *__restrict__ ids,
-                                                      const uint32_t *__restrict__ order, uint32_t n, float4 *hot) {
+                                                      const uint32_t *__restrict__ order, uint32_t n,
+                                                      const float4 *__restrict__ cold, uint32_t nbeams,
+                                                      const uint32_t *__restrict__ counts, float4 *hot, uint32_t *hotFlags) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const uint32_t src = order[j];
-  hot[j] = make_float4(centres[3 * (size_t)src], centres[3 * (size_t)src + 1], centres[3 * (size_t)src + 2],
-                       __uint_as_float(ids[src]));
+  const uint32_t id = ids[src], beam = id & 0xFFFFFFu;
+  const float4 c2 = cold[2 * (size_t)nbeams + beam], c7 = cold[7 * (size_t)nbeams + beam];
+  const double dx = (double)c7.x - (double)c2.x, dy = (double)c7.y - (double)c2.y, dz = (double)c7.z - (double)c2.z;
+  const double lenD = sqrt(dx * dx + dy * dy + dz * dz);
+  const double inv = 1.0 / lenD;
+  const float ls = (float)lenD / (float)counts[beam];
+  hot[2 * (size_t)j] = make_float4(centres[3 * (size_t)src], centres[3 * (size_t)src + 1], centres[3 * (size_t)src + 2],
+                                   __uint_as_float(id));
+  hot[2 * (size_t)j + 1] = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), ls);
+  hotFlags[j] = __float_as_uint(c7.w);
 }
 
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
@@ -1205,9 +1277,10 @@ void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint
                         float *centres, uint32_t *ids, hipStream_t s) {
   hipLaunchKernelGGL(beam_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, counts, offsets, centres, ids);
 }
-void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, float4 *hot,
-                    hipStream_t s) {
-  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, centres, ids, order, n, hot);
+void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *cold,
+                    uint32_t nbeams, const uint32_t *counts, float4 *hot, uint32_t *hotFlags, hipStream_t s) {
+  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, centres, ids, order, n, cold, nbeams, counts,
+                     hot, hotFlags);
 }
 
 }  // namespace gvpm

@@ -77,10 +77,13 @@ void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls
                           hipStream_t s);
 void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint32_t *counts, const uint32_t *offsets,
                         float *centres, uint32_t *ids, hipStream_t s);
-void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, float4 *hot,
-                    hipStream_t s);
-void launch_gather_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint4 *items, const uint32_t *itemCount,
-                         uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
+void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *cold,
+                    uint32_t nbeams, const uint32_t *counts, float4 *hot, uint32_t *hotFlags, hipStream_t s);
+void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
+                           const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
+                           uint32_t pairCap, uint32_t nwaves, hipStream_t stream);
+void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint2 *pairs, const uint32_t *pairCount,
+                           uint32_t pairCap, uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
 struct PlaneArgs {
   const float4 *test;
   const float *ori, *end, *flux, *w1, *len1;
@@ -233,6 +236,8 @@ struct gvpm_context {
   DevBuf<float> w1Owned, len1Owned;
   const float *w1Dev = nullptr, *len1Dev = nullptr;
   DevBuf<float4> planeTest;
+  DevBuf<uint32_t> subFlags;      // G-Beams: filter bits per sorted sub-beam
+  DevBuf<uint2> beamPairs;        // G-Beams: (beam | sub << 24, sorted set) pairs between traversal and evaluation
   bool havePlanes = false;
 
   // G-VPM: camera samples + per-pixel SPPM state
@@ -418,7 +423,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->raysOwned.release();
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release();
-  h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release();
+  h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   poisson_graph_release(h->poissonGraph);
   h->tileTouched.release();
@@ -1023,7 +1028,9 @@ static int buildBeamGrid(gvpm_context *h, float r) {
     ext = fmaxf(ext, b6[3 + c] - b6[c]);
   }
   Grid g;
-  float cell = fmaxf(1.5f * h->cellScale * r, ext / 256.f);
+  // sub-beams (and cells) of 3/4 of the kernel radius: the traversal cost follows the number of sphere tests, which
+  // shrinks with the cell until the ext/256 floor (measured: 34 ms at 1.5 r, 23.5 ms at 0.75 r and below)
+  float cell = fmaxf(0.75f * h->cellScale * r, ext / 256.f);
   if (!(cell > 0.f)) cell = 1.f;
   g.cell = cell;
   g.invCell = 1.f / cell;
@@ -1059,21 +1066,23 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   HIP_TRY(h, h->bs->keysB.ensure(S));
   HIP_TRY(h, h->bs->valsA.ensure(S));
   HIP_TRY(h, h->bs->valsB.ensure(S));
-  HIP_TRY(h, h->bs->hot.ensure(S));
+  HIP_TRY(h, h->bs->hot.ensure(2 * S));
+  HIP_TRY(h, h->subFlags.ensure(S + 1));
   HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
   launch_beam_expand(h->rawDev.pos, h->rawDev.parent_pos, n, h->subCounts.p, h->subOffsets.p, h->subCentres.p,
                      h->subIds.p, h->stream);
   launch_cell_keys(h->subCentres.p, h->nsub, g, h->bs->keysA.p, h->bs->valsA.p, h->stream);
   HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, h->nsub,
                           ilog2ceil(g.ncells + 1), h->stream));
-  launch_sub_hot(h->subCentres.p, h->subIds.p, h->bs->valsB.p, h->nsub, h->bs->hot.p, h->stream);
+  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->bs->cold.p, h->stream);
+  launch_sub_hot(h->subCentres.p, h->subIds.p, h->bs->valsB.p, h->nsub, h->bs->cold.p, n, h->subCounts.p, h->bs->hot.p,
+                 h->subFlags.p, h->stream);
   launch_segment_start(h->bs->keysB.p, h->nsub, g.ncells, 0, h->bs->cellStart.p, h->stream);
   {
     const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
     HIP_TRY(h, h->bs->sat.ensure(satCells));
     launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->stream);
   }
-  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->bs->cold.p, h->stream);
   HIP_TRY(h, hipGetLastError());
   return GVPM_OK;
 }
@@ -1097,6 +1106,10 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   GatherArgs a;
   fillArgs(h, a, r);
   a.kernelRadius = r;
+  // one cell layer per slab step (the box of a thicker slab grows with the tile's perspective spread, and the
+  // traversal cost follows the number of sphere tests: 5.1 ms at 1 layer, 6.2 at 2, 8.9 at 4/6)
+  if (!a.cfg.reserved[1]) a.cfg.reserved[1] = 1;
+  if (!a.cfg.reserved[2]) a.cfg.reserved[2] = 1;
   a.radius = r + 0.5f * h->maxSubLen * 1.001f + 1e-6f;  // traversal radius: sub-beams are binned by their centre
   a.subLen = h->subLen;
   a.nbeams = h->nph;
@@ -1105,11 +1118,37 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
   HIP_TRY(h, h->bs->items.ensure(plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave)));
-  HIP_TRY(h, h->bs->queueCtl.ensure(4));
-  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
+  HIP_TRY(h, h->bs->queueCtl.ensure(8));
+  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
   launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr, h->stream);
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_beams(a, h->beamsPerWave, h->beamsExact, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->nwaves, h->stream);
+  // traversal -> pair list (blocks of 64) -> evaluation.  The list has no useful a-priori bound (the planner's is
+  // sub-beams x rays per slab box, ~100x the survivors): it starts at 16 M pairs and, when the traversal reports
+  // more than fit, is regrown to what it counted and the traversal repeated (deterministic, first iterations only).
+  // queueCtl: [0] items, [1] item queue head, [2] pairs (multiple of 64), [3] block queue head
+  if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure((size_t)16 << 20));
+  for (int attempt = 0;; ++attempt) {
+    const uint32_t cap = (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u);
+    launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->beamPairs.p,
+                          h->bs->queueCtl.p + 2, cap, h->nwavesTrav, h->stream);
+    uint32_t npairs = 0;
+    HIP_TRY(h, hipMemcpyAsync(&npairs, h->bs->queueCtl.p + 2, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (getenv("GVPM_BEAMS_TRACE")) {
+      uint32_t q[4];
+      (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[beams] items %u pairs %u (cap %u) nsub %u nsets %u tiles %u cell %.3f r %.3f dims %d %d %d\n", q[0], npairs, cap,
+              h->nsub, h->nsets, h->bs->ntiles, h->bs->grid.cell, r, h->bs->grid.dim[0], h->bs->grid.dim[1], h->bs->grid.dim[2]);
+    }
+    if (npairs <= cap) break;
+    if (attempt > 0) return fail(h, GVPM_ERR_HIP, "beam pair list overflowed twice");
+    HIP_TRY(h, h->beamPairs.ensure((size_t)npairs + (npairs >> 2) + 64));
+    HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 1, 0, 2 * sizeof(uint32_t), h->stream));
+    // the candidate count of the discarded pass
+    HIP_TRY(h, hipMemsetAsync(a.stats + 1, 0, sizeof(unsigned long long), h->stream));
+  }
+  launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact, h->beamPairs.p, h->bs->queueCtl.p + 2,
+                        (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u), h->bs->queueCtl.p + 3, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());

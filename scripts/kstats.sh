@@ -4,7 +4,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/ks_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 bench.py "$@" --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 ${KS_SCRIPT:-bench.py} "$@" ${KS_EXTRA---no-cpu-baseline} > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("$OUT/**/*kernel_stats.csv",recursive=True)[0]
