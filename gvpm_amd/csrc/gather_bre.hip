@@ -139,7 +139,11 @@ __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
 // O(radius) vector (photon - ray point, shifted ray point - base ray point) is formed in fp64 and
 // then carried as a small fp32 vector; everything downstream of those differences (kernel chord
 // lengths sqrt(r^2 - d^2), pdfs, BSDF / phase / transmittance products, MIS weights) is fp32.
-constexpr int QD = 8;  // per-lane reconnection queue depth (a step adds at most 4)
+#ifndef GVPM_QD
+#define GVPM_QD 8
+#endif
+constexpr int QD = GVPM_QD;  // per-lane reconnection queue depth (a step adds at most 4)
+constexpr uint32_t EVAL_LDS_TRIS = 64;  // occluders staged in the evaluation kernel's LDS when the scene has no more
 
 template <int B> struct EvalLds : RayTile<B> {
   float acc[27][B];
@@ -265,7 +269,7 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
 template <int B, bool FULLVIS>
 __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t meta,
                                            double tPrime, float pdfCam, uint32_t curBeam, Acc27 &acc, uint32_t &nDiff,
-                                           uint32_t &nFail) {
+                                           uint32_t &nFail, const float4 *ldsTri) {
   const uint32_t b = meta & 0xFFu;
   const int i = (int)(meta >> 8);
   const PhotonCold ph = loadCold(a, pidx);
@@ -309,7 +313,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   bool ok = false;
   f3 sflux;
   const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
-  float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok);
+  float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok, ldsTri);
   if (ok) nDiff++; else nFail++;
   borderRule(a, s.pix[b], i, w);
   const float ws = w * scale;
@@ -526,7 +530,17 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
                                                           const uint32_t *__restrict__ pairs,
                                                           const uint32_t *__restrict__ pairCnt) {
   __shared__ EvalLds<B> s;
+  // the occluders of a small scene live in LDS: the near-occluder loop of the reconnection then reads LDS instead
+  // of (L1/L2-resident) global memory, whose latency two waves per SIMD cannot hide
+  // (dynamic shared memory, sized by the launcher: 48 bytes per occluder, nothing for larger scenes)
+  extern __shared__ float4 sceneTri[];
   const int lane = threadIdx.x;
+  const float4 *ldsTri = nullptr;
+  if (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) {
+    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
+    ldsTri = sceneTri;
+    __syncthreads();
+  }
   const uint32_t nItems = *itemCount;
   const bool skip = (a.cfg.reserved[0] & 1) != 0;  // development switch: count, do not evaluate
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
         if (qCount > 0u) {
           const uint32_t q = qHead;
           evalPhase2<B, FULLVIS>(a, s, s.qPh[q][lane], s.qMeta[q][lane], s.qT[q][lane], s.qPdf[q][lane], cur, acc,
-                                 nDiff, nFail);
+                                 nDiff, nFail, ldsTri);
           qHead = (qHead + 1u) % QD;
           qCount--;
         }
@@ -683,10 +697,11 @@ template <bool FULLVIS>
 static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                            uint32_t nwaves, hipStream_t stream) {
+  const size_t dyn = (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) ? (size_t)a.ntri * 48u : 0u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS>), dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
   }
 }
 

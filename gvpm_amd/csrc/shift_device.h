@@ -94,10 +94,8 @@ static __device__ __noinline__ bool anyHitScene(const float4 *bvh, const float4 
 // words of the record), so the loop touches 0-12 triangles.  FULLVIS kernels (intended visibility,
 // more than 254 occluders, or a photon whose list overflowed) walk the BVH instead; the fast
 // kernels carry no call, which is worth ~30 VGPRs.
-template <bool FULLVIS>
-__device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o,
-                                              f3 d, float mint, float maxt) {
-  if (FULLVIS) return anyHitScene(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
+__device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
+                                            float mint, float maxt) {
   bool hit = false;
   uint32_t l = nl0;
 #pragma unroll 1
@@ -105,10 +103,17 @@ __device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, uint32_t nl0,
     const uint32_t i = l & 0xFFu;
     if (i == 0xFFu) break;
     l = k == 3 ? nl1 : (k == 7 ? nl2 : (l >> 8) | 0xFF000000u);
-    const float4 t0 = a.tri4[3 * i], t1 = a.tri4[3 * i + 1], t2 = a.tri4[3 * i + 2];
+    const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
     if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
   }
   return hit;
+}
+// ldsTri: the occluders staged in LDS by the kernel (small scenes), or null
+template <bool FULLVIS>
+__device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const float4 *ldsTri, uint32_t nl0, uint32_t nl1,
+                                              uint32_t nl2, f3 o, f3 d, float mint, float maxt) {
+  if (FULLVIS) return anyHitScene(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
+  return ldsTri ? nearListHit(ldsTri, nl0, nl1, nl2, o, d, mint, maxt) : nearListHit(a.tri4, nl0, nl1, nl2, o, d, mint, maxt);
 }
 
 // GatherPoint::sensorMIS, gvpm_struct.h:608-631 (sDist == bDist for BRE: same t')
@@ -171,14 +176,14 @@ template <bool FULLVIS>
 __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonCold &ph,
                                               uint32_t bits, f3 dProjU, const RayReg &sh, const RayReg &base,
                                               uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
-                                              f3 &shiftedFlux, bool &ok) {
+                                              f3 &shiftedFlux, bool &ok, const float4 *ldsTri = nullptr) {
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
   const float l2Proj = dot(dProjU, dProjU);
   const float lProj = fsqrt(l2Proj);
   const f3 dProj = dProjU * frcp(lProj);
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
-  bool good = !shadowBlocked<FULLVIS>(a, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
+  bool good = !shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
   const float cosWo = dot(ph.parentN, dProj);
   // surface / emitter parents: the offset direction must leave on the side the photon left (sign of
   // dot(n, dProj) / dot(n, -wi))
