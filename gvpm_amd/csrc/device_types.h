@@ -15,6 +15,10 @@ namespace gvpm {
 // bits = GVPM_PF_* flags of the ABI with bit 7 = pathID & 1.
 // (G-Beams keeps 9 planes of nbeams float4 in the same buffer, see gather_beams.hip.)
 #define GVPM_HOT_PARITY_BIT 7
+// per-photon near-occluder lists (grid_build.hip, nearOccluders): 8-bit indices up to NARROW_MAX occluders, 16-bit up
+// to WIDE_MAX (the top byte of word 0 must stay below the 0xFD / 0xFE marks), extension lists beyond
+#define GVPM_NEAR_NARROW_MAX 253u
+#define GVPM_NEAR_WIDE_MAX 64767u
 #define GVPM_REC_QUADS 8
 
 struct Grid {
@@ -51,6 +55,7 @@ struct GatherArgs {
   // scene
   const float4 *tri4;        // 3 float4 per triangle {v0,n.x} {e1,n.y} {e2,n.z}, BVH leaf order
   const float4 *bvh;         // 2 float4 per node (scene_bvh.h)
+  const uint32_t *nearExt;   // extension lists of the per-photon near-occluder lists {count, index...}
   uint32_t ntri;
   MediumDev med;
   // config

@@ -75,10 +75,11 @@ __global__ void bounds_final_kernel(const float *partial, int nblocks, float *ou
 }
 
 // counters -> pinned host memory (same reason)
-__global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, uint32_t *hostOut) {
+__global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *hostOut) {
   if (threadIdx.x == 0) {
     hostOut[0] = a ? *a : 0u;
     hostOut[1] = b ? *b : 0u;
+    hostOut[2] = c ? *c : 0u;
     __threadfence_system();
   }
 }
@@ -163,37 +164,97 @@ __device__ __forceinline__ float4 ld3(const float *p, uint32_t i, float w) {
 // parent within dmax of the triangle's plane and of its (dmax-inflated) bounding box.
 // Packs up to twelve 8-bit indices into three words (0xFF = empty slot); 0xFE in the top byte of the
 // first word = overflow / too many occluders for 8-bit indices: such photons need the BVH kernels.
-__device__ __forceinline__ void nearOccluders(f3 P, const float4 *tri4, uint32_t ntri, float dmax, uint32_t &w0,
-                                              uint32_t &w1, uint32_t &w2) {
+// Three formats, chosen by the occluder count (GVPM_NEAR_* in device_types.h):
+//   narrow  (<= 253)    twelve 8-bit indices in the three words, 0xFF = empty
+//   wide    (<= 64767)  six 16-bit indices, 0xFFFF = empty
+//   ext                 word 0 = 0xFD << 24, word 1 = offset into the extension array {count, index...}: lists too long for
+//                       the inline slots, and every non-empty list of a scene too large for 16-bit indices
+// 0xFE in the top byte of word 0 = the extension array is full: such photons need the BVH kernels.
+// Near = within dmax of the triangle's plane and of its (dmax-inflated) bounding box; found by a linear scan for
+// small scenes, else by a point query of the occluder BVH (boxes inflated by dmax): the as-written segment is a
+// thousandth of the reconnection distance, so the query touches a handful of leaves whatever the scene size.
+__device__ __forceinline__ bool nearTriangle(f3 P, const float4 *tri4, uint32_t i, float dmax) {
+  const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
+  const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t1.x, t1.y, t1.z), c = mk3(t2.x, t2.y, t2.z);
+  const f3 n = mk3(t0.w, t1.w, t2.w);  // unit normal (zero for a degenerate triangle)
+  if (fabsf(dot(n, P - a)) > dmax * 1.0001f) return false;
+  bool out = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float ak = comp(a, k), bk = comp(b, k), ck = comp(c, k), pk = comp(P, k);
+    const float lo = ak + fminf(0.f, fminf(bk, ck)), hi = ak + fmaxf(0.f, fmaxf(bk, ck));
+    if (pk < lo - dmax || pk > hi + dmax) out = true;
+  }
+  return !out;
+}
+template <class F>
+__device__ __forceinline__ void nearVisit(f3 P, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax, F f) {
+  if (ntri <= 64u) {
+    for (uint32_t i = 0; i < ntri; ++i)
+      if (nearTriangle(P, tri4, i, dmax)) f(i);
+    return;
+  }
+  uint32_t stack[32];
+  int sp = 0;
+  uint32_t cur = 0;
+  const float pad = dmax * 1.0001f;
+  for (;;) {
+    const float4 lo = bvh[2 * (size_t)cur], hi = bvh[2 * (size_t)cur + 1];
+    bool descend = false;
+    if (P.x >= lo.x - pad && P.x <= hi.x + pad && P.y >= lo.y - pad && P.y <= hi.y + pad && P.z >= lo.z - pad &&
+        P.z <= hi.z + pad) {
+      const uint32_t first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+      if (count == 0u) {
+        if (sp < 32) stack[sp++] = first + 1u;  // (the host builder's depth is far below 32)
+        cur = first;
+        descend = true;
+      } else {
+        for (uint32_t i = first; i < first + count; ++i)
+          if (nearTriangle(P, tri4, i, dmax)) f(i);
+      }
+    }
+    if (!descend) {
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+  }
+}
+__device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
+                                              uint32_t *ext, uint32_t extCap, uint32_t &w0, uint32_t &w1,
+                                              uint32_t &w2) {
   w0 = w1 = w2 = 0xFFFFFFFFu;
-  if (ntri > 254u) {
+  if (ntri == 0u) return;
+  const bool narrow = ntri <= GVPM_NEAR_NARROW_MAX, wide = !narrow && ntri <= GVPM_NEAR_WIDE_MAX;
+  const uint32_t cap = narrow ? 12u : (wide ? 6u : 0u);
+  uint32_t cnt = 0, a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
+  nearVisit(P, bvh, tri4, ntri, dmax, [&](uint32_t i) {
+    if (cnt < cap) {
+      uint32_t word, sh, m;
+      if (narrow) { word = cnt >> 2; sh = 8u * (cnt & 3u); m = ~(0xFFu << sh); }
+      else        { word = cnt >> 1; sh = 16u * (cnt & 1u); m = ~(0xFFFFu << sh); }
+      const uint32_t v = i << sh;
+      if (word == 0u) a0 = (a0 & m) | v;
+      else if (word == 1u) a1 = (a1 & m) | v;
+      else a2 = (a2 & m) | v;
+    }
+    cnt++;
+  });
+  if (cnt == 0u) return;
+  if (cnt <= cap) {
+    w0 = a0; w1 = a1; w2 = a2;
+    return;
+  }
+  // extension list {count, indices}
+  const uint32_t off = atomicAdd(ext, cnt + 1u);  // ext[0] = the allocation cursor (starts at 1)
+  if ((unsigned long long)off + cnt + 1u > extCap) {
     w0 = 0xFEFFFFFFu;
     return;
   }
-  uint32_t cnt = 0;
-  for (uint32_t i = 0; i < ntri; ++i) {
-    const float4 t0 = tri4[3 * i], t1 = tri4[3 * i + 1], t2 = tri4[3 * i + 2];
-    const f3 a = mk3(t0.x, t0.y, t0.z), b = mk3(t1.x, t1.y, t1.z), c = mk3(t2.x, t2.y, t2.z);
-    const f3 n = mk3(t0.w, t1.w, t2.w);  // unit normal (zero for a degenerate triangle)
-    if (fabsf(dot(n, P - a)) > dmax * 1.0001f) continue;
-    bool out = false;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float ak = comp(a, k), bk = comp(b, k), ck = comp(c, k), pk = comp(P, k);
-      const float lo = ak + fminf(0.f, fminf(bk, ck)), hi = ak + fmaxf(0.f, fmaxf(bk, ck));
-      if (pk < lo - dmax || pk > hi + dmax) out = true;
-    }
-    if (out) continue;
-    if (cnt == 12u) {
-      w0 = 0xFEFFFFFFu;
-      return;
-    }
-    const uint32_t sh = 8u * (cnt & 3u), m = ~(0xFFu << sh), v = i << sh;
-    if (cnt < 4u) w0 = (w0 & m) | v;
-    else if (cnt < 8u) w1 = (w1 & m) | v;
-    else w2 = (w2 & m) | v;
-    cnt++;
-  }
+  ext[off] = cnt;
+  uint32_t k = 0;
+  nearVisit(P, bvh, tri4, ntri, dmax, [&](uint32_t i) { ext[off + 1u + (k++)] = i; });
+  w0 = 0xFDFFFFFFu;
+  w1 = off;
 }
 
 // counting sort, pass 3: photon `src` (reads in upload order: coalesced) goes to slot cellStart[key] + rank
@@ -201,8 +262,9 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *tri4, uint32_t
 __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ rank,
                                                       const uint32_t *__restrict__ cellStart, uint32_t n,
-                                                      gvpm_params cfg, const float4 *tri4, uint32_t ntri,
-                                                      float dmax, float4 *hot, float4 *cold, uint32_t *overflow) {
+                                                      gvpm_params cfg, const float4 *bvh, const float4 *tri4,
+                                                      uint32_t ntri, float dmax, uint32_t *nearExt, uint32_t extCap,
+                                                      float4 *hot, float4 *cold, uint32_t *overflow) {
   const uint32_t src = blockIdx.x * blockDim.x + threadIdx.x;
   if (src >= n) return;
   const uint32_t i = cellStart[keys[src]] + rank[src];
@@ -219,7 +281,7 @@ __global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32
   rec[4] = ld3(r.parent_n, src, r.parent_g[src]);
   const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
   uint32_t w0, w1, w2;
-  nearOccluders(P, tri4, ntri, dmax, w0, w1, w2);
+  nearOccluders(P, bvh, tri4, ntri, dmax, nearExt, extCap, w0, w1, w2);
   if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
   rec[5] = ld3(r.prefix_w, src, __uint_as_float(w0));
   rec[6] = ld3(r.parent_scat, src, __uint_as_float(w1));
@@ -367,8 +429,8 @@ void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, fl
   hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6, hostOut);
 }
 
-void launch_export_u32(const uint32_t *a, const uint32_t *b, uint32_t *hostOut, hipStream_t s) {
-  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, hostOut);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *hostOut, hipStream_t s) {
+  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, c, hostOut);
 }
 
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {
@@ -387,13 +449,13 @@ void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *ke
 }
 
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
-                    uint32_t n, const gvpm_params &cfg, const float4 *tri4, uint32_t ntri, float dmax, float4 *hot,
-                    float4 *cold, uint32_t *overflow, hipStream_t s) {
+                    uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
+                    uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow, hipStream_t s) {
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, keys, rank, cellStart, n, cfg, tri4, ntri,
-                     dmax, hot, cold, overflow);
+  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, keys, rank, cellStart, n, cfg, bvh, tri4,
+                     ntri, dmax, nearExt, extCap, hot, cold, overflow);
 }
 
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,

@@ -23,14 +23,14 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
                    hipStream_t s);
 hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
-void launch_export_u32(const uint32_t *a, const uint32_t *b, uint32_t *hostOut, hipStream_t s);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *hostOut, hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
                        hipStream_t s);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
-                    uint32_t n, const gvpm_params &cfg, const float4 *tri4, uint32_t ntri, float dmax, float4 *hot,
-                    float4 *cold, uint32_t *overflow, hipStream_t s);
+                    uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
+                    uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow, hipStream_t s);
 void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
                        uint32_t *rank, uint32_t *count, hipStream_t s);
 void launch_beam_scatter(const uint32_t *keys, const uint32_t *rank, const uint32_t *start, uint32_t n,
@@ -164,7 +164,7 @@ struct BuildSet {
   DevBuf<uint2> itemOff;
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
   // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
-  DevBuf<uint32_t> pairs, pairCnt;
+  DevBuf<uint32_t> pairs, pairCnt, nearExt;
   hipEvent_t traversed = nullptr;  // recorded on the build stream after the traversal kernel
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
@@ -176,7 +176,7 @@ struct BuildSet {
     if (sortTmp.d) (void)hipFree(sortTmp.d);
     sortTmp.d = nullptr;
     sortTmp.bytes = 0;
-    pairs.release(); pairCnt.release();
+    pairs.release(); pairCnt.release(); nearExt.release();
     if (lastUse) (void)hipEventDestroy(lastUse);
     if (traversed) (void)hipEventDestroy(traversed);
     lastUse = traversed = nullptr;
@@ -211,6 +211,7 @@ struct gvpm_context {
   uint32_t nph = 0;
   bool havePhotons = false, photonsDirty = false;
   bool nearOverflow = false;
+  size_t nearExtWant = 0;         // entries the near-occluder extension lists asked for so far
   // G-BRE keeps its per-step host syncs to one: the photon bounds of step N are read back with the
   // planner's counters and size the grid of step N+1 (photons outside the grid sit in its border cells)
   float cachedB6[6] = {0, 0, 0, 0, 0, 0};
@@ -784,11 +785,17 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
   HIP_TRY(h, h->bs->overflowCtr.ensure(2));
   HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
-  launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->tri4.p, h->ntri, dmax,
-                 h->bs->hot.p, h->bs->cold.p, h->bs->overflowCtr.p, h->bstream);
+  // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only);
+  // word 0 is the allocation cursor
+  const size_t extWant = std::min<size_t>(std::max<size_t>((size_t)n * 8u + 4096u, h->nearExtWant), 0xFFFFFF00u);
+  HIP_TRY(h, h->bs->nearExt.ensure(extWant));
+  HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->bs->nearExt.p, 1, 1, h->bstream));
+  launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
+                 h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
+                 h->bs->cold.p, h->bs->overflowCtr.p, h->bstream);
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
-  if (!deferred && h->cfg.visibility_as_written && h->ntri <= 254u) {
+  if (!deferred && h->cfg.visibility_as_written) {
     uint32_t over = 0;
     HIP_TRY(h, hipMemcpyAsync(&over, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
     HIP_TRY(h, hipStreamSynchronize(h->bstream));
@@ -832,7 +839,7 @@ static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
 
 // shadow rays through the occluder BVH instead of the per-photon near-occluder lists
 static bool needFullVis(const gvpm_context *h) {
-  return !h->cfg.visibility_as_written || h->ntri > 254u || h->nearOverflow;
+  return !h->cfg.visibility_as_written || h->nearOverflow;
 }
 
 static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
@@ -840,6 +847,7 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.hot = h->bs->hot.p;
   a.cold = h->bs->cold.p;
   a.cellStart = h->bs->cellStart.p;
+  a.nearExt = h->bs->nearExt.p;
   a.sat = h->bs->sat.p;
   a.nph = h->nph;
   a.grid = h->bs->grid;
@@ -937,13 +945,21 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
-  launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, h->pinCtl, h->bstream);
+  launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, rebuilt ? h->bs->nearExt.p : nullptr,
+                    h->pinCtl, h->bstream);
   HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
   lap("plan");
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
   lap("syncB");
   const uint32_t blocks = h->pinCtl[0];
-  if (rebuilt) h->nearOverflow = h->cfg.visibility_as_written && h->ntri <= 254u && h->pinCtl[1] != 0;
+  if (rebuilt) {
+    h->nearOverflow = h->cfg.visibility_as_written && h->pinCtl[1] != 0;
+    // what the extension lists asked for (the cursor keeps counting past the capacity): sizes the next build's
+    h->nearExtWant = std::max<size_t>(h->nearExtWant, (size_t)h->pinCtl[2] + h->pinCtl[2] / 4);
+    if (getenv("GVPM_TRACE_VIS"))
+      fprintf(stderr, "[vis] ntri %u photons %u: %u lists overflowed, extension cursor %u of %zu, fullvis %d\n", h->ntri, h->nph,
+              h->pinCtl[1], h->pinCtl[2], h->bs->nearExt.cap, (int)needFullVis(h));
+  }
   if (h->boundsPending) {
     h->boundsPending = false;
     for (int c = 0; c < 6; ++c)

@@ -108,11 +108,44 @@ __device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uin
   }
   return hit;
 }
+// the same for scenes of more than 254 occluders: six 16-bit indices (grid_build.hip, nearOccluders)
+__device__ __forceinline__ bool nearListHitWide(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
+                                                float mint, float maxt) {
+  bool hit = false;
+  uint32_t l = nl0;
+#pragma unroll 1
+  for (int k = 0; k < 6; ++k) {
+    const uint32_t i = l & 0xFFFFu;
+    if (i == 0xFFFFu) break;
+    l = k == 1 ? nl1 : (k == 3 ? nl2 : (l >> 16) | 0xFFFF0000u);
+    const float4 t0 = tri[3 * (size_t)i], t1 = tri[3 * (size_t)i + 1], t2 = tri[3 * (size_t)i + 2];
+    if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+  }
+  return hit;
+}
+// extension list (lists longer than the inline slots; every list of a scene beyond 16-bit indices)
+__device__ __forceinline__ bool nearListHitExt(const float4 *tri, const uint32_t *ext, uint32_t off, f3 o, f3 d,
+                                               float mint, float maxt) {
+  bool hit = false;
+  const uint32_t n = ext[off];
+#pragma unroll 1
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t i = ext[off + 1u + k];
+    const float4 t0 = tri[3 * (size_t)i], t1 = tri[3 * (size_t)i + 1], t2 = tri[3 * (size_t)i + 2];
+    if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+  }
+  return hit;
+}
 // ldsTri: the occluders staged in LDS by the kernel (small scenes), or null
 template <bool FULLVIS>
 __device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const float4 *ldsTri, uint32_t nl0, uint32_t nl1,
                                               uint32_t nl2, f3 o, f3 d, float mint, float maxt) {
   if (FULLVIS) return anyHitScene(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
+  if (a.ntri > GVPM_NEAR_NARROW_MAX) {
+    if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
+    return nearListHitWide(a.tri4, nl0, nl1, nl2, o, d, mint, maxt);
+  }
+  if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
   return ldsTri ? nearListHit(ldsTri, nl0, nl1, nl2, o, d, mint, maxt) : nearListHit(a.tri4, nl0, nl1, nl2, o, d, mint, maxt);
 }
 

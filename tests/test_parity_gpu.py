@@ -317,6 +317,32 @@ def test_many_occluders_walk_the_bvh(as_written):
     assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
 
 
+@pytest.mark.parametrize("levels,seps", [(1, 0.05), (3, 0.01), (3, 0.2), (7, 0.0002)])
+def test_near_occluder_list_formats(levels, seps):
+    """The as-written shadow segment (first ShadowEpsilon of the reconnection distance) is served by per-photon
+    near-occluder lists: 8-bit indices up to 253 occluders, 16-bit beyond, extension lists when a list outgrows
+    its inline slots.  A large ShadowEpsilon makes the lists long: extension lists in the narrow format (56
+    occluders) and in the wide one (896), and at 0.2 more than the extension array holds, which sends the step
+    through the BVH kernels; 229 376 occluders are beyond 16-bit indices (every list an extension list).  The result must stay the oracle's, which tests every occluder."""
+    c = cases.make_case("cbox", 32, 28, 20000, 3.0, shadow_epsilon=seps)
+    fine = cases.tessellate(c.tris, levels) if levels else c.tris
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*fine)
+    ctx.upload_medium(c.m)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(1, c.nb)
+    acc = ctx.download_accum()
+    st = ctx.stats()
+    ctx.close()
+    ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, 1, c.nb, 64, use_accel=False)
+    assert st["evaluations"] == cnt["evaluations"]
+    assert cnt["failed_shifts"] > 0
+    for k in ("diffuse_shifts", "failed_shifts"):
+        assert abs(st[k] - cnt[k]) <= max(4, 2e-4 * cnt["diffuse_shifts"]), (k, st, cnt)
+    assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
+
+
 def test_row_sharded_film_and_moving_shards():
     """A handle only clears / folds the film rows it has touched since the last reset (image-sharded ranks own
     a fraction of the frame): two shard handles must add up to the full-frame result, and a handle whose beam
