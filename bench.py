@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--emulate-gpus", type=int, default=0,
                     help="single-GPU run of rank 0's shard of an N-GPU frame (sizing probe, e.g. BASELINE configs[3]: "
                          "--emulate-gpus 8 --tile 362 --photons 4000000); not a bench line")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to smoke-test "
+                                                      "the N > 1 code path on a one-GPU box together with --single-device")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (smoke test, not a bench line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,9 +64,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the gather path)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl")
+        dist.init_process_group(args.backend)
 
     nshards = args.emulate_gpus if (args.emulate_gpus and world == 1) else world
     tx, ty = tile_grid(nshards)
