@@ -14,8 +14,9 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--beams", type=int, default=200000)
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--scene", default="cbox")
 args = ap.parse_args()
-sc = SynthScene("cbox", args.size, args.size)
+sc = SynthScene(args.scene, args.size, args.size)
 p = sc.params()
 p.vol_technique = abi.GVPM_BEAM_BEAM_3D_OPTIMIZED if args.tech == "3d" else abi.GVPM_BEAM_BEAM_1D
 p.initial_scale_volume = args.scale
