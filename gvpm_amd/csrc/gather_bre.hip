@@ -148,10 +148,11 @@ constexpr uint32_t EVAL_LDS_TRIS = 64;  // occluders staged in the evaluation ke
 template <int B> struct EvalLds : RayTile<B> {
   float acc[27][B];
   uint32_t boff[B + 1];      // prefix offsets of the item's per-beam lists
-  uint32_t qPh[QD][64];      // per-lane queues, [slot][lane]: photon
-  uint32_t qMeta[QD][64];    //   beam | shift << 8
-  float qPdf[QD][64];        //   pdfCam
-  double qT[QD][64];         //   t'
+  // per-lane queues, [slot][lane]: photon and beam | shift << 8.  t' and pdfCam are recomputed by the reconnection
+  // (a dozen fp64 operations) rather than queued: 12 bytes less per entry is 6 KB of LDS per wave, the difference
+  // between 8 and 12 resident waves per CU
+  uint32_t qPh[QD][64];
+  uint32_t qMeta[QD][64];
 };
 
 // the 27 per-beam outputs of one lane, in registers
@@ -268,8 +269,8 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
 // the lane's registers when it belongs to the lane's current beam, else straight to the LDS accumulators
 template <int B, bool FULLVIS>
 __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t meta,
-                                           double tPrime, float pdfCam, uint32_t curBeam, Acc27 &acc, uint32_t &nDiff,
-                                           uint32_t &nFail, const float4 *ldsTri) {
+                                           uint32_t curBeam, Acc27 &acc, uint32_t &nDiff, uint32_t &nFail,
+                                           const float4 *ldsTri) {
   const uint32_t b = meta & 0xFFu;
   const int i = (int)(meta >> 8);
   const PhotonCold ph = loadCold(a, pidx);
@@ -277,6 +278,20 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   const RayReg sh = loadRay(s, 1 + i, b);
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const float r = a.radius, r2 = r * r;
+  // t' and pdfCameraPos exactly as phase 1 derived them (baseTerms)
+  double tPrime;
+  float pdfCam = 1.f;
+  {
+    const d3 wD = tod(ph.pos) - tod(base.o), bdD = tod(base.d);
+    const double disk = dot(wD, bdD);
+    tPrime = disk;
+    if (use3D) {
+      const f3 perp = tof(wD - bdD * disk);
+      const float deltaT = fsqrt(fmaxf(0.f, r2 - dot(perp, perp)));
+      tPrime = (disk - (double)deltaT) + (double)(2.f * deltaT * s.rnd[b]);
+      pdfCam = frcp(fmaxf(deltaT * 2.f, 0.0001f));
+    }
+  }
   const float rr = a.cfg.path_set ? 2.f : 1.f;
   const float kernelVol = use3D ? (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r : 3.14159265358979323846f * r2;
   const float scale = rr * frcp(kernelVol * pdfCam);
@@ -612,8 +627,6 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
           const uint32_t q = (qHead + qCount) % QD;
           s.qPh[q][lane] = pidx;
           s.qMeta[q][lane] = cur | (sh << 8);
-          s.qPdf[q][lane] = pdfCam;
-          s.qT[q][lane] = tP;
           qCount++;
         }
       }
@@ -625,8 +638,7 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
         if (!last && __popcll(pending) < 48 && !__ballot(qCount > (uint32_t)(QD - 4))) break;
         if (qCount > 0u) {
           const uint32_t q = qHead;
-          evalPhase2<B, FULLVIS>(a, s, s.qPh[q][lane], s.qMeta[q][lane], s.qT[q][lane], s.qPdf[q][lane], cur, acc,
-                                 nDiff, nFail, ldsTri);
+          evalPhase2<B, FULLVIS>(a, s, s.qPh[q][lane], s.qMeta[q][lane], cur, acc, nDiff, nFail, ldsTri);
           qHead = (qHead + 1u) % QD;
           qCount--;
         }
