@@ -117,6 +117,16 @@ template <typename T> struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  // at least `c` elements, no slack (mirrors another buffer's capacity)
+  hipError_t reserveExact(size_t c) {
+    if (c <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, c * sizeof(T));
+    if (e == hipSuccess) cap = c;
+    return e;
+  }
 };
 
 struct RcclApi {
@@ -168,6 +178,20 @@ struct BuildSet {
   hipEvent_t traversed = nullptr;  // recorded on the build stream after the traversal kernel
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
+  // Give this (so far unused) set the capacities of the set that just ran its first step, so that the second
+  // step of a run does not stop for gigabytes of hipMalloc in the middle of the pipeline.
+  hipError_t mirrorFrom(const BuildSet &o) {
+    hipError_t e = hipSuccess;
+#define GVPM_MIRROR(X) if (e == hipSuccess) e = X.reserveExact(o.X.cap)
+    GVPM_MIRROR(hot); GVPM_MIRROR(cold); GVPM_MIRROR(overflowCtr); GVPM_MIRROR(cellStart); GVPM_MIRROR(cellCount);
+    GVPM_MIRROR(sat); GVPM_MIRROR(keysA); GVPM_MIRROR(keysB); GVPM_MIRROR(valsA); GVPM_MIRROR(valsB);
+    GVPM_MIRROR(beamCount); GVPM_MIRROR(beamStart); GVPM_MIRROR(boundsPartial); GVPM_MIRROR(bounds6);
+    GVPM_MIRROR(bKeysA); GVPM_MIRROR(bKeysB); GVPM_MIRROR(bValsA); GVPM_MIRROR(setPerm); GVPM_MIRROR(tileStart);
+    GVPM_MIRROR(items); GVPM_MIRROR(itemOff); GVPM_MIRROR(queueCtl); GVPM_MIRROR(pairs); GVPM_MIRROR(pairCnt);
+    GVPM_MIRROR(nearExt);
+#undef GVPM_MIRROR
+    return e;
+  }
   void release() {
     hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); cellCount.release(); sat.release();
     beamCount.release(); beamStart.release(); keysA.release(); keysB.release();
@@ -1000,6 +1024,10 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   launch_finalize_tiles(h->accum.p, h->iter.p, h->bs->tileStart.p, h->tileTouched.p, h->bs->ntiles, h->bs->tileW,
                         h->bs->tileH, h->cfg.width, h->cfg.height, it, nb_paths, h->stream);
   HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));  // the fold reads this set's tileStart too
+  if (h->pipeline) {
+    BuildSet &other = h->sets[h->bs == &h->sets[0] ? 1 : 0];
+    if (!other.used && !h->bs->used) HIP_TRY(h, other.mirrorFrom(*h->bs));
+  }
   h->bs->used = true;
   HIP_TRY(h, hipGetLastError());
   lap("launchK");
