@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--emulate-gpus", type=int, default=0,
                     help="single-GPU run of rank 0's shard of an N-GPU frame (sizing probe, e.g. BASELINE configs[3]: "
                          "--emulate-gpus 8 --tile 362 --photons 4000000); not a bench line")
+    ap.add_argument("--device-gen", action="store_true",
+                    help="probe (SURVEY 8f3): every step shoots its photons and generates its camera beams on the GPU "
+                         "(gvpm_devgen_*) inside the timed region instead of reading pre-generated inputs from HBM")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to smoke-test "
                                                       "the N > 1 code path on a one-GPU box together with --single-device")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (smoke test, not a bench line)")
@@ -88,7 +91,8 @@ def main():
     inputs = []
     keep = []
     host0 = None
-    for i in range(ndist):
+    gen = hip.DeviceGenerator(sc, device=local_rank) if args.device_gen else None
+    for i in range(0 if gen else ndist):
         ph, nb = sc.shoot_photons(i + 1, args.photons)
         # image sharding: the frame's 4x4-pixel tiles are dealt round-robin to the ranks -- contiguous blocks
         # split S-cbox 2.5:1 unevenly (scripts/shard_balance.py: mean/max 0.41 vs 0.99 interleaved)
@@ -107,8 +111,16 @@ def main():
         inputs.append((soa, ph.n, nb, rt.data_ptr(), rays.shape[0]))
     torch.cuda.synchronize()
 
+    gen_sets, gen_ph = [], []
+
     def step(it):
-        soa, nph, nb, rptr, nsets = inputs[(it - 1) % ndist]
+        if gen:
+            soa, nb = gen.shoot_photons((it - 1) % ndist + 1, args.photons)
+            rptr, nsets = gen.camera_beams((it - 1) % ndist + 1, nshards, rank)
+            gen_sets.append(nsets)
+            gen_ph.append(int(soa.n))
+        else:
+            soa, nph, nb, rptr, nsets = inputs[(it - 1) % ndist]
         ctx.upload_photons_dev(soa)
         ctx.upload_camera_beams_dev(rptr, nsets)
         ctx.gather(it, nb)
@@ -158,8 +170,8 @@ def main():
         evals_total = float(evals)
 
     if rank == 0:
-        nsets_avg = float(np.mean([x[4] for x in inputs]))
-        nph_avg = float(np.mean([x[1] for x in inputs]))
+        nsets_avg = float(np.mean(gen_sets if gen else [x[4] for x in inputs]))
+        nph_avg = float(np.mean(gen_ph if gen else [x[1] for x in inputs]))
         P = args.tile * args.tile
         # algorithmic bytes per gather-kernel launch (BASELINE.md / SURVEY 8d convention)
         bytes_alg = 128.0 * (evals / K) + 320.0 * nsets_avg + 108.0 * P + 128.0 * nph_avg
@@ -186,7 +198,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic (generated on the device inside every step)" if gen else "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: S-{args.scene} + homogeneous medium, G-BRE 3D kernel, "
                             f"{args.tile}x{args.tile} px per GPU ({W}x{H} frame), {args.photons} photons/iter, "
@@ -208,7 +220,7 @@ def main():
             },
             "stats": st,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not gen:
             out["cpu_baseline"] = cpu_baseline(sc, p, m, tris, host0, args)
         print(json.dumps(out), flush=True)
     ctx.close()

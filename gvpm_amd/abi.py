@@ -193,3 +193,15 @@ class PoissonParams(C.Structure):
     _fields_ = [("alpha", C.c_float), ("irls_iter_max", C.c_int32), ("irls_reg_init", C.c_float),
                 ("irls_reg_iter", C.c_float), ("cg_iter_max", C.c_int32), ("cg_iter_check", C.c_int32),
                 ("cg_precond", C.c_int32), ("cg_tolerance", C.c_float)]
+
+
+class DevgenScene(C.Structure):
+    """gvpm_devgen_scene: a closed-form scene as the device-side generators take it."""
+    _fields_ = [("n_tris", C.c_uint32), ("n_mats", C.c_uint32), ("tris", C.c_void_p), ("tri_mat", C.c_void_p),
+                ("mat_kind", C.c_void_p), ("mat_albedo", C.c_void_p),
+                ("light_c", C.c_double * 3), ("light_u", C.c_double * 3), ("light_v", C.c_double * 3),
+                ("light_n", C.c_double * 3), ("radiance", C.c_double * 3), ("light_area", C.c_double),
+                ("medium", Medium), ("cam_pos", C.c_double * 3), ("tan_half_fov_x", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32), ("seed", C.c_uint32), ("camera_inside", C.c_int32),
+                ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("min_depth", C.c_int32),
+                ("camera_sphere", C.c_double)]

@@ -23,7 +23,9 @@ SYMBOLS = [
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
     "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_get_phase_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
-    "gvpm_allreduce_accum", "gvpm_allreduce_film", "gvpm_download_film_dev", "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
+    "gvpm_allreduce_accum", "gvpm_allreduce_film", "gvpm_download_film_dev", "gvpm_devgen_create",
+    "gvpm_devgen_destroy", "gvpm_devgen_shoot_photons", "gvpm_devgen_shoot_beams", "gvpm_devgen_camera_beams", "gvpm_devgen_read",
+    "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
 ]
 
 
@@ -75,6 +77,13 @@ def lib():
         L.gvpm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         L.gvpm_allreduce_accum.argtypes = [vp]
         L.gvpm_allreduce_film.argtypes = [vp, vp]
+        L.gvpm_devgen_create.argtypes = [C.POINTER(abi.DevgenScene), C.c_int, C.POINTER(vp)]
+        L.gvpm_devgen_destroy.argtypes = [vp]
+        L.gvpm_devgen_shoot_photons.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(abi.PhotonSoA), C.POINTER(C.c_uint64)]
+        L.gvpm_devgen_shoot_beams.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(abi.PhotonSoA), C.POINTER(vp),
+                                              C.POINTER(C.c_uint64)]
+        L.gvpm_devgen_camera_beams.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.gvpm_devgen_read.argtypes = [vp, vp, vp, C.c_uint64]
         L.gvpm_download_film_dev.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.gvpm_poisson_preset.argtypes = [C.c_char_p, C.POINTER(abi.PoissonParams)]
         L.gvpm_poisson_solve.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
@@ -241,6 +250,60 @@ class Context:
 
     def allreduce_accum(self):
         self._check(lib().gvpm_allreduce_accum(self._h))
+
+
+class DeviceGenerator:
+    """Device-side photon shooting and camera-beam generation for a closed-form scene (gvpm_devgen_*).
+    Outputs are device pointers owned by the generator, valid until its next call of the same kind."""
+
+    def __init__(self, synth_scene, device=0):
+        self._scene = synth_scene  # keeps the host arrays alive during create
+        self._h = C.c_void_p()
+        d = synth_scene.devgen_scene()
+        rc = lib().gvpm_devgen_create(C.byref(d), device, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise GvpmError(f"gvpm_devgen_create failed: {rc}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gvpm_devgen_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def shoot_photons(self, iteration, capacity):
+        """-> (abi.PhotonSoA of device pointers, nb_paths)"""
+        soa, nb = abi.PhotonSoA(), C.c_uint64(0)
+        rc = lib().gvpm_devgen_shoot_photons(self._h, iteration, capacity, C.byref(soa), C.byref(nb))
+        if rc != 0:
+            raise GvpmError(f"gvpm_devgen_shoot_photons failed: {rc}")
+        return soa, int(nb.value)
+
+    def shoot_beams(self, iteration, capacity):
+        """-> (abi.PhotonSoA of device pointers, end_n device pointer, nb_paths)"""
+        soa, nb, en = abi.PhotonSoA(), C.c_uint64(0), C.c_void_p()
+        rc = lib().gvpm_devgen_shoot_beams(self._h, iteration, capacity, C.byref(soa), C.byref(en), C.byref(nb))
+        if rc != 0:
+            raise GvpmError(f"gvpm_devgen_shoot_beams failed: {rc}")
+        return soa, en.value, int(nb.value)
+
+    def read(self, dev_ptr, count, dtype):
+        """Copy `count` items of `dtype` of a generator output to a numpy array."""
+        out = np.empty(count, dtype)
+        rc = lib().gvpm_devgen_read(self._h, dev_ptr, out.ctypes.data, out.nbytes)
+        if rc != 0:
+            raise GvpmError(f"gvpm_devgen_read failed: {rc}")
+        return out
+
+    def camera_beams(self, iteration, tile_mod=1, tile_rem=0):
+        """-> (device pointer to n_sets * 5 gvpm_camera_ray, n_sets)"""
+        ptr, n = C.c_void_p(), C.c_uint64(0)
+        rc = lib().gvpm_devgen_camera_beams(self._h, iteration, tile_mod, tile_rem, C.byref(ptr), C.byref(n))
+        if rc != 0:
+            raise GvpmError(f"gvpm_devgen_camera_beams failed: {rc}")
+        return ptr.value, int(n.value)
 
 
 def poisson_preset(name):

@@ -22,6 +22,7 @@ def lib():
         L.gvpm_synth_create.restype = C.c_void_p
         L.gvpm_synth_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32]
         L.gvpm_synth_destroy.argtypes = [C.c_void_p]
+        L.gvpm_synth_devgen_scene.argtypes = [C.c_void_p, C.POINTER(abi.DevgenScene)]
         L.gvpm_synth_params.argtypes = [C.c_void_p, C.POINTER(abi.Params)]
         L.gvpm_synth_medium.argtypes = [C.c_void_p, C.POINTER(abi.Medium)]
         L.gvpm_synth_triangles.argtypes = [C.c_void_p, C.POINTER(abi.Triangles)]
@@ -78,6 +79,14 @@ class SynthScene:
             buf = (C.c_float * (3 * n)).from_address(ptr)
             out.append(np.array(buf, np.float32).reshape(n, 3).copy())
         return tuple(out)
+
+    def devgen_scene(self):
+        """The scene as gvpm_devgen_create takes it (arrays owned by this object: keep it alive)."""
+        d = abi.DevgenScene()
+        rc = lib().gvpm_synth_devgen_scene(self._h, C.byref(d))
+        if rc != 0:
+            raise RuntimeError(f"gvpm_synth_devgen_scene failed: {rc}")
+        return d
 
     def shoot_photons(self, iteration, capacity):
         """-> (abi.Photons, nb_paths)"""

@@ -11,6 +11,8 @@ struct gvpm_synth {
   std::vector<float> v0, e1, e2;
   std::vector<gvpm_vpm_sample> samples;
   std::vector<float> endN, w1, len1;
+  std::vector<double> dgTris, dgAlbedo;  // gvpm_devgen_scene arrays
+  std::vector<int32_t> dgTriMat, dgMatKind;
 };
 
 extern "C" {
@@ -33,6 +35,40 @@ gvpm_synth *gvpm_synth_create(const char *scene, int width, int height, uint32_t
 }
 
 void gvpm_synth_destroy(gvpm_synth *s) { delete s; }
+
+int gvpm_synth_devgen_scene(gvpm_synth *s, gvpm_devgen_scene *out) {
+  if (!s || !out) return GVPM_ERR_INVALID_ARG;
+  const gvpm::SynthScene &sc = s->scene;
+  s->dgTris.clear(); s->dgAlbedo.clear(); s->dgTriMat.clear(); s->dgMatKind.clear();
+  for (const auto &t : sc.tris) {
+    const gvpm::V3 v[4] = {t.v0, t.e1, t.e2, t.n};
+    for (const auto &q : v) { s->dgTris.push_back(q.x); s->dgTris.push_back(q.y); s->dgTris.push_back(q.z); }
+    s->dgTriMat.push_back(t.mat);
+  }
+  for (const auto &m : sc.mats) {
+    s->dgMatKind.push_back(m.kind);
+    s->dgAlbedo.push_back(m.albedo.x); s->dgAlbedo.push_back(m.albedo.y); s->dgAlbedo.push_back(m.albedo.z);
+  }
+  out->n_tris = (uint32_t)sc.tris.size();
+  out->n_mats = (uint32_t)sc.mats.size();
+  out->tris = s->dgTris.data();
+  out->tri_mat = s->dgTriMat.data();
+  out->mat_kind = s->dgMatKind.data();
+  out->mat_albedo = s->dgAlbedo.data();
+  auto put = [](double *d, gvpm::V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+  put(out->light_c, sc.lightC); put(out->light_u, sc.lightU); put(out->light_v, sc.lightV); put(out->light_n, sc.lightN);
+  put(out->radiance, sc.radiance);
+  out->light_area = sc.lightArea;
+  out->medium = sc.medium;
+  put(out->cam_pos, sc.camPos);
+  out->tan_half_fov_x = sc.tanHalfFovX;
+  out->width = sc.width; out->height = sc.height;
+  out->seed = sc.seed;
+  out->camera_inside = sc.cameraInside ? 1 : 0;
+  out->max_depth = sc.maxDepth; out->rr_depth = sc.rrDepth; out->min_depth = sc.minDepth;
+  out->camera_sphere = sc.cameraSphere;
+  return GVPM_OK;
+}
 
 int gvpm_synth_params(const gvpm_synth *s, gvpm_params *out) {
   if (!s || !out) return GVPM_ERR_INVALID_ARG;

@@ -10,6 +10,8 @@ extern "C" {
 typedef struct gvpm_synth gvpm_synth;
 gvpm_synth *gvpm_synth_create(const char *scene, int width, int height, uint32_t seed);
 void gvpm_synth_destroy(gvpm_synth *s);
+/* the scene as the device-side generators take it (gvpm_devgen_create, include/gvpm_hip.h); the arrays stay owned by `s` */
+int gvpm_synth_devgen_scene(gvpm_synth *s, gvpm_devgen_scene *out);
 int gvpm_synth_params(const gvpm_synth *s, gvpm_params *out);
 int gvpm_synth_medium(const gvpm_synth *s, gvpm_medium *out);
 int gvpm_synth_triangles(gvpm_synth *s, gvpm_triangles *out);

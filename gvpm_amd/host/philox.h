@@ -6,6 +6,8 @@
 #pragma once
 #include <cstdint>
 
+#include "vecmath.h"  // GVPM_HD
+
 namespace gvpm {
 
 struct Philox {
@@ -14,7 +16,7 @@ struct Philox {
   uint32_t out[4];
   int have;
 
-  Philox(uint32_t seed, uint32_t stream, uint32_t a, uint32_t b, uint32_t c = 0) {
+  GVPM_HD Philox(uint32_t seed, uint32_t stream, uint32_t a, uint32_t b, uint32_t c = 0) {
     key[0] = seed;
     key[1] = stream;
     ctr[0] = 0;
@@ -24,13 +26,13 @@ struct Philox {
     have = 0;
   }
 
-  static inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+  GVPM_HD static inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
     uint64_t p = (uint64_t)a * b;
     hi = (uint32_t)(p >> 32);
     lo = (uint32_t)p;
   }
 
-  void refill() {
+  GVPM_HD void refill() {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
     for (int r = 0; r < 10; ++r) {
@@ -50,12 +52,12 @@ struct Philox {
     have = 4;
   }
 
-  uint32_t nextU32() {
+  GVPM_HD uint32_t nextU32() {
     if (have == 0) refill();
     return out[4 - (have--)];
   }
   // uniform in [0,1): 24 random bits, exactly representable in fp32
-  float next1D() { return (float)(nextU32() >> 8) * (1.0f / 16777216.0f); }
+  GVPM_HD float next1D() { return (float)(nextU32() >> 8) * (1.0f / 16777216.0f); }
 };
 
 }  // namespace gvpm

@@ -17,20 +17,10 @@
 #include <vector>
 
 #include "../../include/gvpm_hip.h"
+#include "synth_core.h"
 #include "vecmath.h"
 
 namespace gvpm {
-
-enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1 };
-
-struct SynthTri {
-  V3 v0, e1, e2, n;  // n: geometric normal (front side)
-  int mat;
-};
-struct SynthMat {
-  int kind;
-  V3 albedo;
-};
 
 struct SynthScene {
   std::string name;
@@ -53,6 +43,7 @@ struct SynthScene {
   double cameraSphere;  // world units, already scaled as in gvpm.cpp:162
 
   double bsphereRadius() const;
+  SceneView view() const;  // what the generators (host or device) read
   void addQuad(V3 a, V3 b, V3 c, V3 d, int mat);  // a,b,c,d counter-clockwise seen from the front
 };
 

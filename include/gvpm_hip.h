@@ -374,6 +374,47 @@ int gvpm_poisson_solve_dev(gvpm_context *h, const gvpm_poisson_params *params, i
                            const float *dx, const float *dy, const float *throughput,
                            const float *direct, float *out);
 
+/* ---- device-side producers for closed-form scenes -------*/
+/* Photon shooting (GPMIntegrator's photon pass: gvpm_proc.cpp:125-209,278-350 with GPhotonMap::tryAppend /
+ * LTBeamMap::tryAppendLT flattening) and camera-beam generation (randomWalkFromPixelToFirstDiffuse +
+ * ShiftGatherPoint::generate, gvpm_gatherpoint.h:22-170, shift_cameraPath.h:29-133) on the GPU for scenes the
+ * device can intersect itself: a triangle list, Lambertian / index-matched materials, one quad area light, one
+ * homogeneous medium, a pinhole sensor.  The outputs are device-resident and go straight into
+ * gvpm_upload_photons_dev / gvpm_upload_beams_dev / gvpm_upload_camera_beams_dev: nothing crosses PCIe.
+ * Same counter-based streams as the host generators of gvpm_amd/host (keyed by path / pixel index), so the
+ * device reproduces the sequential host loop: same photon count, same path count, same order.              */
+typedef struct gvpm_devgen_scene {
+  uint32_t n_tris, n_mats;
+  const double *tris;        /* 12 per triangle: v0, e1, e2, geometric normal   */
+  const int32_t *tri_mat;    /* material index per triangle                      */
+  const int32_t *mat_kind;   /* 0 Lambertian, 1 index-matched medium boundary    */
+  const double *mat_albedo;  /* 3 per material                                   */
+  double light_c[3], light_u[3], light_v[3], light_n[3], radiance[3], light_area;
+  gvpm_medium medium;
+  double cam_pos[3], tan_half_fov_x;
+  int32_t width, height;
+  uint32_t seed;
+  int32_t camera_inside;     /* sensor inside the medium: edge 1 is the medium edge */
+  int32_t max_depth, rr_depth, min_depth;  /* GPMConfig maxDepth, rrDepth, minDepth */
+  double camera_sphere;      /* world units (gvpm.cpp:162)                        */
+} gvpm_devgen_scene;
+typedef struct gvpm_devgen gvpm_devgen;
+int gvpm_devgen_create(const gvpm_devgen_scene *scene, int device, gvpm_devgen **out);
+int gvpm_devgen_destroy(gvpm_devgen *g);
+/* shoots light paths 0, 1, 2, ... of `iteration` until `capacity` photons are stored; *dev_soa receives device
+ * pointers owned by the generator (valid until its next shoot), *nb_paths the number of paths shot             */
+int gvpm_devgen_shoot_photons(gvpm_devgen *g, int iteration, uint64_t capacity, gvpm_photon_soa *dev_soa,
+                              uint64_t *nb_paths);
+/* photon beams (one record per medium edge, see gvpm_upload_beams) + the end normals                           */
+int gvpm_devgen_shoot_beams(gvpm_devgen *g, int iteration, uint64_t capacity, gvpm_photon_soa *dev_soa,
+                            const float **end_n_dev, uint64_t *nb_paths);
+/* beam sets (5 rays each) of the pixels whose 4x4 tile t has t % tile_mod == tile_rem (1, 0: the whole frame),
+ * row-major pixel order; *rays_dev is owned by the generator (valid until its next call)                        */
+int gvpm_devgen_camera_beams(gvpm_devgen *g, int iteration, int tile_mod, int tile_rem,
+                             const gvpm_camera_ray **rays_dev, uint64_t *n_sets);
+/* copies `bytes` of a generator output back to the host (inspection, tests)                                     */
+int gvpm_devgen_read(gvpm_devgen *g, const void *dev, void *host, uint64_t bytes);
+
 /* ---- multi-GPU (image-tile sharding) --------------------------*/
 /* Each rank gathers only the beam sets of its own pixels; before
  * reconstruction the 27-float accumulators (disjoint supports) are summed
