@@ -212,7 +212,9 @@ struct gvpm_context {
   hipStream_t stream = nullptr;   // gather stream: traversal, evaluation, film
   hipStream_t streamB = nullptr;  // build stream of the G-BRE pipeline
   hipStream_t bstream = nullptr;  // where the current gather builds (stream, or streamB for G-BRE)
-  BuildSet sets[2];
+  hipStream_t streamC = nullptr;  // traversal stream of the three-stage pipeline
+  bool travStream = true;         // traversal on its own stream, three build sets (GVPM_TRAV_STREAM=0: two stages)
+  BuildSet sets[3];
   BuildSet *bs = &sets[0];
   int setIdx = 0;
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
@@ -366,10 +368,13 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   h->cfg = *params;
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->streamB, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->streamC, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[0].lastUse, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[1].lastUse, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->sets[2].lastUse, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[0].traversed, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->sets[1].traversed, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&h->sets[1].traversed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->sets[2].traversed, hipEventDisableTiming) != hipSuccess) {
     gvpm_destroy(h);
     return GVPM_ERR_HIP;
   }
@@ -409,6 +414,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   }
   if (const char *e = getenv("GVPM_PIPELINE")) h->pipeline = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_TRAV_STREAM")) h->travStream = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
@@ -442,6 +448,7 @@ int gvpm_destroy(gvpm_context *h) {
       (void)hipEventDestroy(e.second);
     }
   if (h->streamB) (void)hipStreamSynchronize(h->streamB);
+  if (h->streamC) (void)hipStreamSynchronize(h->streamC);
   for (BuildSet &b : h->sets) b.release();
   h->tri4.release(); h->bvh.release();
   h->rawF.release(); h->rawU.release();
@@ -457,6 +464,7 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->pinB6) (void)hipHostFree(h->pinB6);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->streamB) (void)hipStreamDestroy(h->streamB);
+  if (h->streamC) (void)hipStreamDestroy(h->streamC);
   delete h;
   return GVPM_OK;
 }
@@ -934,7 +942,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   bool rebuilt = false;
   if (h->photonsDirty || h->beamsDirty || r != h->bs->builtRadius) {
     // the other set; wait until the kernels that last read it are done
-    h->setIdx ^= 1;
+    h->setIdx = (h->setIdx + 1) % (h->pipeline && h->travStream ? 3 : 2);
     h->bs = &h->sets[h->setIdx];
     if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
     HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
@@ -1003,7 +1011,9 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->bstream = h->stream;
     return rc;
   }
-  hipStream_t ts = h->travOnBuild ? h->bstream : h->stream;
+  // three stages: the traversal has its own stream, so that the build of the NEXT step (which starts on the build
+  // stream as soon as this call returns) overlaps it; the build stream is idle here, the host has just synchronised it
+  hipStream_t ts = h->pipeline && h->travStream ? h->streamC : (h->travOnBuild ? h->bstream : h->stream);
   HIP_TRY(h, hipEventRecord(evTrav->first, ts));
   launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
                       h->bs->pairs.p, h->bs->pairCnt.p, h->nwavesTrav, ts);
@@ -1025,8 +1035,10 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
                         h->bs->tileH, h->cfg.width, h->cfg.height, it, nb_paths, h->stream);
   HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));  // the fold reads this set's tileStart too
   if (h->pipeline) {
-    BuildSet &other = h->sets[h->bs == &h->sets[0] ? 1 : 0];
-    if (!other.used && !h->bs->used) HIP_TRY(h, other.mirrorFrom(*h->bs));
+    for (int k = 0; k < (h->travStream ? 3 : 2); ++k) {
+      BuildSet &other = h->sets[k];
+      if (&other != h->bs && !other.used && !h->bs->used) HIP_TRY(h, other.mirrorFrom(*h->bs));
+    }
   }
   h->bs->used = true;
   HIP_TRY(h, hipGetLastError());
