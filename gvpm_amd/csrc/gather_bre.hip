@@ -153,6 +153,11 @@ template <int B> struct EvalLds : RayTile<B> {
   // between 8 and 12 resident waves per CU
   uint32_t qPh[QD][64];
   uint32_t qMeta[QD][64];
+  // per (shift, beam), derived once per item: the shifted ray RELATIVE to the base ray {o_s - o_b, sensorMIS} and
+  // {d_s - d_b, -}.  shiftRay(t') - baseRay(t') = dO + dD t' then is a small fp32 vector (pixel spacing at depth t'),
+  // accurate to ~1e-10: the per-evaluation fp64 evaluation of shiftRay(t') (3 cvt + 3 fma + 3 add fp64 per shift)
+  // goes away, and so do the three divisions of sensorMIS
+  float4 relO[4][B], relD[4][B];
 };
 
 // the 27 per-beam outputs of one lane, in registers
@@ -167,6 +172,7 @@ __device__ __forceinline__ void borderRule(const GatherArgs &a, uint32_t pix, in
 }
 
 struct BaseTerms {
+  f3 rel;  // photon - baseRay(t')
   double tPrime;
   float pdfCam, scale, tr;  // tr: transmittance over [Epsilon, t'] (equal in the three channels)
   f3 bc;                    // base contribution * scale
@@ -194,6 +200,7 @@ __device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const EvalLd
     kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r;
     t.pdfCam = frcp(fmaxf(deltaT * 2.f, 0.0001f));
   }
+  t.rel = perp + base.d * (float)(disk - t.tPrime);
   const float rr = a.cfg.path_set ? 2.f : 1.f;
   t.scale = rr * frcp(kernelVol * t.pdfCam);
   // the base and the four shifted rays all carry mint = Epsilon and maxt = t' (:769-770): one transmittance
@@ -224,7 +231,6 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
   pdfCamOut = bt.pdfCam;
   qMask = 0u;
 
-  const d3 pD = tod(ph.pos);
   const f3 photonIn = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]) * ph.flux;
   const float tPf = (float)bt.tPrime;
   const uint32_t st = GVPM_PF_SHIFT_TYPE(ph.bits);
@@ -233,8 +239,9 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
     // branch-free: the null-shift arithmetic is cheap and some lane of the wave needs it anyway; a wave
     // spends more on exec-mask bookkeeping and taken branches than on the arithmetic they would skip
     const RayReg sh = loadRay(s, 1 + i, b);
-    const d3 zP = tod(sh.o) + tod(sh.d) * bt.tPrime;  // shiftRay(t')
-    const f3 y = tof(pD - zP);                        // photon relative to the shifted ray point
+    const float4 ro = s.relO[i][b], rd = s.relD[i][b];
+    // photon relative to shiftRay(t') = (photon - baseRay(t')) - (shiftRay(t') - baseRay(t'))
+    const f3 y = bt.rel - (mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * tPf);
     // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
     const bool isNull = sh.valid && a.cfg.use_shift_null && dot(y, y) < r2 && tPf < sh.len;
     const f3 yp = y - sh.d * dot(y, sh.d);
@@ -244,7 +251,7 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
     if (a.cfg.use_mis)
       wNull = (pdfShiftPos == 0.f || bt.pdfCam == 0.f)
                   ? 1.f
-                  : frcp(1.f + sensorMIS(sh, base, s.edge[b]) * pdfShiftPos * frcp(bt.pdfCam));
+                  : frcp(1.f + ro.w * pdfShiftPos * frcp(bt.pdfCam));
     const f3 nullFlux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
     // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
     const bool wantsShift = sh.valid && !isNull && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL;
@@ -304,7 +311,8 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   const d3 pD = tod(ph.pos);
   const d3 basePt = tod(base.o) + tod(base.d) * tPrime;  // baseRay(t')
   const f3 rel = tof(pD - basePt);                       // photon relative to the base ray point
-  const d3 zP = tod(sh.o) + tod(sh.d) * tPrime;          // shiftRay(t')
+  const float4 ro = s.relO[i][b], rd = s.relD[i][b];
+  const f3 dS = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * (float)tPrime;  // shiftRay(t') - baseRay(t')
   // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
   f3 offRel = rel;
   if (!use3D) {
@@ -314,7 +322,6 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
     offRel = ns * dot(rel, bs) + nt * dot(rel, bt) + sh.d * dot(rel, base.d);
   }
   if (a.cfg.use_shift_null) {
-    const f3 dS = tof(zP - basePt);  // shiftRay(t') - baseRay(t')
     const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
     const float cosD2 = dot(bo, bo) < r2 ? -2.f * dot(dS, offRel) * frcp(dot(dS, dS)) : 0.f;
     offRel = offRel + dS * cosD2;
@@ -327,8 +334,9 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   }
   bool ok = false;
   f3 sflux;
-  const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;  // offsetPos - parent
-  float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok, ldsTri);
+  const f3 dProjU = ((tof(basePt) + dS) - ph.parentPos) + offRel;  // offsetPos - parent
+  float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok, ldsTri,
+                                 ro.w);
   if (ok) nDiff++; else nFail++;
   borderRule(a, s.pix[b], i, w);
   const float ws = w * scale;
@@ -581,6 +589,13 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
     if (lane == 0) s.boff[0] = 0u;
     loadTileRays<B>(a, s, setBase, nb, lane);
     for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+    for (int idx = lane; idx < 4 * B; idx += 64) {
+      const int i = idx / B, bb = idx % B;
+      const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
+      const f3 dO = tof(tod(sr.o) - tod(br.o)), dD = tof(tod(sr.d) - tod(br.d));
+      s.relO[i][bb] = make_float4(dO.x, dO.y, dO.z, sensorMIS(sr, br, s.edge[bb]));
+      s.relD[i][bb] = make_float4(dD.x, dD.y, dD.z, 0.f);
+    }
     __syncthreads();
 
     // my chunk [g0, g1) of the concatenated lists

@@ -209,7 +209,8 @@ template <bool FULLVIS>
 __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonCold &ph,
                                               uint32_t bits, f3 dProjU, const RayReg &sh, const RayReg &base,
                                               uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
-                                              f3 &shiftedFlux, bool &ok, const float4 *ldsTri = nullptr) {
+                                              f3 &shiftedFlux, bool &ok, const float4 *ldsTri = nullptr,
+                                              float sensorMisPre = -1.f) {
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
   const float l2Proj = dot(dProjU, dProjU);
   const float lProj = fsqrt(l2Proj);
@@ -250,7 +251,8 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
     const float basePdf = pdfBaseRay * ph.parentPdf * ph.edgePdf;
     const float offsetPdf = sPdf * pdfShiftRay;
     misOk = !(offsetPdf == 0.f || basePdf == 0.f);
-    const float v = sensorMIS(sh, base, edge) * fdiv(offsetPdf, basePdf);
+    // (sensorMisPre: the caller's per-(shift, beam) value, when it keeps one)
+    const float v = (sensorMisPre >= 0.f ? sensorMisPre : sensorMIS(sh, base, edge)) * fdiv(offsetPdf, basePdf);
     w = a.cfg.power_heuristic ? frcp(1.f + v * v) : frcp(1.f + v);
   }
   // a failed MIS keeps the flux it computed and takes weight 1 (shift_volume_photon.cpp:463-470)

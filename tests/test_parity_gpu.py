@@ -416,4 +416,5 @@ def test_partial_films_of_interleaved_shards_sum_to_the_frames_film():
         assert bad.size == 0, (k, len(bad), bad[:6].tolist(), [(got[tuple(b)], ref[tuple(b)]) for b in bad[:6]])
     o = O.assemble(total, c.it, False)
     for k in range(3):
-        assert np.allclose(fsum[k * n:(k + 1) * n].reshape(28, 36, 3), o[k], rtol=1e-5, atol=1e-12)
+        # (fp32 sums of up to four terms against the fp64 assembly of the same accumulators)
+        assert np.allclose(fsum[k * n:(k + 1) * n].reshape(28, 36, 3), o[k], rtol=1e-4, atol=1e-6 * np.abs(o[k]).max())
