@@ -285,19 +285,21 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   const RayReg sh = loadRay(s, 1 + i, b);
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const float r = a.radius, r2 = r * r;
-  // t' and pdfCameraPos exactly as phase 1 derived them (baseTerms)
+  // t', pdfCameraPos and the photon relative to baseRay(t') exactly as phase 1 derived them (baseTerms)
   double tPrime;
   float pdfCam = 1.f;
+  f3 rel;
   {
     const d3 wD = tod(ph.pos) - tod(base.o), bdD = tod(base.d);
     const double disk = dot(wD, bdD);
+    const f3 perp = tof(wD - bdD * disk);
     tPrime = disk;
     if (use3D) {
-      const f3 perp = tof(wD - bdD * disk);
       const float deltaT = fsqrt(fmaxf(0.f, r2 - dot(perp, perp)));
       tPrime = (disk - (double)deltaT) + (double)(2.f * deltaT * s.rnd[b]);
       pdfCam = frcp(fmaxf(deltaT * 2.f, 0.0001f));
     }
+    rel = perp + base.d * (float)(disk - tPrime);
   }
   const float rr = a.cfg.path_set ? 2.f : 1.f;
   const float kernelVol = use3D ? (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r : 3.14159265358979323846f * r2;
@@ -308,9 +310,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
   const f3 bc = (sigS * ph.flux) * (trT.x * phaseEval(a.med.g, ph.wi, -base.d) * scale) * base.eye;
 
-  const d3 pD = tod(ph.pos);
-  const d3 basePt = tod(base.o) + tod(base.d) * tPrime;  // baseRay(t')
-  const f3 rel = tof(pD - basePt);                       // photon relative to the base ray point
+  const f3 basePt = base.o + base.d * (float)tPrime;  // baseRay(t'), absolute (for the segment to the parent)
   const float4 ro = s.relO[i][b], rd = s.relD[i][b];
   const f3 dS = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * (float)tPrime;  // shiftRay(t') - baseRay(t')
   // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
@@ -334,7 +334,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   }
   bool ok = false;
   f3 sflux;
-  const f3 dProjU = ((tof(basePt) + dS) - ph.parentPos) + offRel;  // offsetPos - parent
+  const f3 dProjU = ((basePt + dS) - ph.parentPos) + offRel;  // offsetPos - parent
   float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok, ldsTri,
                                  ro.w);
   if (ok) nDiff++; else nFail++;
