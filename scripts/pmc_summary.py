@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-for name, title in (("kernel_stats.csv", "kernel stats, default two-stream pipeline (rocprofv3 --kernel-trace --stats)"),
+for name, title in (("kernel_stats.csv", "kernel stats, default pipeline (build, traversal and evaluation streams) (rocprofv3 --kernel-trace --stats)"),
                     ("kernel_stats_single_stream.csv", "kernel stats, GVPM_PIPELINE=0 (single stream: isolated kernel durations)")):
     ks = os.path.join(out, name)
     if os.path.exists(ks):
