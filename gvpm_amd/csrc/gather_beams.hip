@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
 // pairs (fp32 local-frame evaluation, or the literal fp64 one when EXACT) into the block's LDS accumulators, and
 // the touched accumulators go to the film with one global atomic each.
 template <int B, bool EXACT>
-__global__ __launch_bounds__(64, EXACT ? 1 : 2) void evaluate_beams_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
+__global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
                                                                            const uint32_t *__restrict__ pairCount,
                                                                            uint32_t pairCap, uint32_t *queueHead) {
   __shared__ TileLds<B> s;
