@@ -259,33 +259,47 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const flo
 
 // counting sort, pass 3: photon `src` (reads in upload order: coalesced) goes to slot cellStart[key] + rank
 // (whole 128-byte records: full-line writes)
-__global__ __launch_bounds__(256) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ rank,
                                                       const uint32_t *__restrict__ cellStart, uint32_t n,
                                                       gvpm_params cfg, const float4 *bvh, const float4 *tri4,
                                                       uint32_t ntri, float dmax, uint32_t *nearExt, uint32_t extCap,
                                                       float4 *hot, float4 *cold, uint32_t *overflow) {
+  // The record is assembled in LDS and written by EIGHT lanes (one 16-byte quad each): a store instruction then
+  // covers eight whole 128-byte lines instead of sixty-four 16-byte pieces of sixty-four lines.
+  __shared__ float4 stg[64][GVPM_REC_QUADS + 1];  // +1: odd stride against bank conflicts (9 KB: one wave a block)
+  __shared__ uint32_t dstIdx[64];
   const uint32_t src = blockIdx.x * blockDim.x + threadIdx.x;
-  if (src >= n) return;
-  const uint32_t i = cellStart[keys[src]] + rank[src];
-  uint32_t bits = r.flags[src] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
-  if (photonContributes(bits, cfg)) bits |= 1u << 6;
-  bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
-  hot[i] = ld3(r.pos, src, __uint_as_float(bits));
-  // one 128-byte record per photon: an evaluation touches exactly one cache line
-  float4 *rec = cold + (size_t)i * GVPM_REC_QUADS;
-  rec[0] = hot[i];
-  rec[1] = ld3(r.wi, src, r.parent_pdf[src]);
-  rec[2] = ld3(r.flux, src, r.edge_pdf[src]);
-  rec[3] = ld3(r.parent_pos, src, r.parent_rr[src]);
-  rec[4] = ld3(r.parent_n, src, r.parent_g[src]);
-  const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
-  uint32_t w0, w1, w2;
-  nearOccluders(P, bvh, tri4, ntri, dmax, nearExt, extCap, w0, w1, w2);
-  if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
-  rec[5] = ld3(r.prefix_w, src, __uint_as_float(w0));
-  rec[6] = ld3(r.parent_scat, src, __uint_as_float(w1));
-  rec[7] = ld3(r.parent_wi, src, __uint_as_float(w2));
+  const int t = threadIdx.x;
+  dstIdx[t] = 0xFFFFFFFFu;
+  if (src < n) {
+    const uint32_t i = cellStart[keys[src]] + rank[src];
+    uint32_t bits = r.flags[src] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
+    if (photonContributes(bits, cfg)) bits |= 1u << 6;
+    bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
+    const float4 h0 = ld3(r.pos, src, __uint_as_float(bits));
+    hot[i] = h0;
+    // one 128-byte record per photon: an evaluation touches exactly one cache line
+    stg[t][0] = h0;
+    stg[t][1] = ld3(r.wi, src, r.parent_pdf[src]);
+    stg[t][2] = ld3(r.flux, src, r.edge_pdf[src]);
+    stg[t][3] = ld3(r.parent_pos, src, r.parent_rr[src]);
+    stg[t][4] = ld3(r.parent_n, src, r.parent_g[src]);
+    const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
+    uint32_t w0, w1, w2;
+    nearOccluders(P, bvh, tri4, ntri, dmax, nearExt, extCap, w0, w1, w2);
+    if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
+    stg[t][5] = ld3(r.prefix_w, src, __uint_as_float(w0));
+    stg[t][6] = ld3(r.parent_scat, src, __uint_as_float(w1));
+    stg[t][7] = ld3(r.parent_wi, src, __uint_as_float(w2));
+    dstIdx[t] = i;
+  }
+  __syncthreads();
+  for (int e = t; e < 64 * GVPM_REC_QUADS; e += 64) {
+    const int rec = e / GVPM_REC_QUADS, part = e % GVPM_REC_QUADS;
+    const uint32_t i = dstIdx[rec];
+    if (i != 0xFFFFFFFFu) cold[(size_t)i * GVPM_REC_QUADS + part] = stg[rec][part];
+  }
 }
 
 // ---- segment starts of a sorted key array: start[c] = first i with (key[i] >> shift) >= c ----
@@ -454,7 +468,7 @@ void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(reorder_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, keys, rank, cellStart, n, cfg, bvh, tri4,
+  hipLaunchKernelGGL(reorder_kernel, dim3((n + 63) / 64), dim3(64), 0, s, r, keys, rank, cellStart, n, cfg, bvh, tri4,
                      ntri, dmax, nearExt, extCap, hot, cold, overflow);
 }
 

@@ -369,7 +369,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   // stream priorities (lower = more urgent): the traversal of step N+1 is what the next evaluation waits for, the
   // build of step N+2 is two steps ahead.  With equal priorities about one process in four ran the build's small
   // kernels in front of the traversal's workgroups and lost the third stage's gain (5.5 instead of 5.8 G/s);
-  // 18 of 18 runs were fast with these
+  // these priorities make that rarer
   int prA = 0, prB = 1, prC = -1;  // gather / build / traversal
   {
     int least = 0, greatest = 0;
