@@ -31,6 +31,10 @@
 #include "tile_walk.h"
 #include "vec.h"
 
+#ifndef GVPM_BSTAGE
+#define GVPM_BSTAGE 128
+#endif
+
 namespace gvpm {
 
 struct BeamD {
@@ -965,9 +969,12 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
 // the ownership prefilter, straight from LDS and the lane's own ray registers.  Survivors are compacted by ballot
 // into an LDS ring and appended to the global pair list 64 at a time (one atomic per 64 pairs; the tail of an item
 // is padded with empty pairs so that a block of 64 never mixes tiles).  pair = {beam | sub << 24, sorted set index}.
+// (a stage of 128: the one-layer slab boxes hold ~100 sub-beams, and 6 KB of LDS per wave instead of 10 leaves room
+// for more resident waves, which is what hides the per-slab latency chain)
+constexpr int BSTAGE = GVPM_BSTAGE;
 struct BeamTravLds {
-  float4 st0[STAGE], st1[STAGE];
-  uint32_t stF[STAGE];
+  float4 st0[BSTAGE], st1[BSTAGE];
+  uint32_t stF[BSTAGE];
   uint2 outq[QCAP];
 };
 
@@ -986,6 +993,8 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
   const float rT = a.radius;  // test radius = kernel radius + half a sub-beam
   const float r = a.kernelRadius;
   const float eps = a.cfg.epsilon;
+  const bool pathSet = a.cfg.path_set != 0;
+  const int maxDepth = a.cfg.max_depth;
   unsigned long long nCand = 0;
 
   for (;;) {
@@ -1026,28 +1035,33 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
         const uint32_t incl = wave_scan_incl(count, lane);
         const uint32_t excl = incl - count;
         const uint32_t total = __shfl(incl, 63, 64);
-        for (uint32_t win = 0; win < total; win += STAGE) {
+        for (uint32_t win = 0; win < total; win += BSTAGE) {
           __syncthreads();
-          {
-            const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
-            uint32_t i = lo_i;
-            for (; i + 2 <= hi_i; i += 2) {  // two records (four 16-byte loads) in flight per lane
-              const uint32_t gi = start + (i - excl);
-              const float4 v0 = a.hot[2 * (size_t)gi], v1 = a.hot[2 * (size_t)gi + 1];
-              const float4 v2 = a.hot[2 * (size_t)gi + 2], v3 = a.hot[2 * (size_t)gi + 3];
-              const uint32_t f0 = hotFlags[gi], f1 = hotFlags[gi + 1];
-              s.st0[i - win] = v0; s.st1[i - win] = v1; s.stF[i - win] = f0;
-              s.st0[i - win + 1] = v2; s.st1[i - win + 1] = v3; s.stF[i - win + 1] = f1;
+          const uint32_t nst = min((uint32_t)BSTAGE, total - win);
+          // Staging: entry k of the window is element win + k of the concatenated ranges.  Consecutive LANES take
+          // consecutive entries (the range an entry falls in is found by a 6-step search over the exclusive scan,
+          // through ds_bpermute), so a load instruction reads a few contiguous runs of records instead of 64
+          // separate ones -- with ~80 sub-beams per range (C3: 47 M sub-beams) the per-lane copy loops had made the
+          // staging alone 58 of the traversal's 104 ms.
+#pragma unroll
+          for (uint32_t k = (uint32_t)lane; k < (uint32_t)BSTAGE; k += 64u) {
+            const uint32_t e = win + k;
+            uint32_t rr = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+              const uint32_t cand = rr + step;
+              const uint32_t v = (uint32_t)__shfl((int)excl, (int)(cand & 63u), 64);
+              if (v <= e) rr = cand;
             }
-            for (; i < hi_i; ++i) {
-              const uint32_t gi = start + (i - excl);
-              s.st0[i - win] = a.hot[2 * (size_t)gi];
-              s.st1[i - win] = a.hot[2 * (size_t)gi + 1];
-              s.stF[i - win] = hotFlags[gi];
+            const uint32_t rStart = (uint32_t)__shfl((int)start, (int)rr, 64), rExcl = (uint32_t)__shfl((int)excl, (int)rr, 64);
+            if (k < nst) {
+              const uint32_t gi = rStart + (e - rExcl);
+              s.st0[k] = a.hot[2 * (size_t)gi];
+              s.st1[k] = a.hot[2 * (size_t)gi + 1];
+              s.stF[k] = hotFlags[gi];
             }
           }
           __syncthreads();
-          const uint32_t nst = min((uint32_t)STAGE, total - win);
           const uint32_t iters = (nst + LPB - 1) / LPB;
           constexpr uint32_t G = 4;
           for (uint32_t jj = 0; jj < iters; jj += G) {
@@ -1056,26 +1070,30 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
 #pragma unroll
               for (uint32_t u = 0; u < G; ++u) {
                 const uint32_t j = (jj + u) * LPB + sub;
-                const float4 hp = s.st0[min(j, (uint32_t)STAGE - 1u)];
+                const float4 hp = s.st0[min(j, (uint32_t)BSTAGE - 1u)];
                 const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
                 const float disk = dot(wv, base.d);
                 const f3 v = wv - base.d * disk;
-                // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment
-                if (j < nst && dot(v, v) < rT * rT * 1.001f && disk > mint - rT * 1.001f && disk < maxt + rT * 1.001f)
+                // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment; the
+                // beam's filter bits (contribution, checkerboard parity, depth) are tested here too: they halve
+                // the pairs that reach the ownership prefilter
+                const uint32_t fl = s.stF[min(j, (uint32_t)BSTAGE - 1u)];
+                const bool flagsOk = ((fl >> 6) & 1u) != 0u && !(pathSet && ((fl >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) &&
+                                     !(maxDepth > 0 && edge + (int)GVPM_PF_DEPTH(fl) > maxDepth);
+                if (j < nst && flagsOk && dot(v, v) < rT * rT * 1.001f && disk > mint - rT * 1.001f &&
+                    disk < maxt + rT * 1.001f)
                   cm |= 1u << u;
               }
             }
             unsigned long long any = __ballot(cm != 0u);
             while (any) {
               const bool active = cm != 0u;
-              const uint32_t j = min((jj + (active ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)STAGE - 1u);
+              const uint32_t j = min((jj + (active ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)BSTAGE - 1u);
               cm &= cm - 1u;
               nCand += __popcll(any);
               const float4 h0 = s.st0[j], h1 = s.st1[j];
-              const uint32_t fl = s.stF[j], id = __float_as_uint(h0.w);
-              bool keep = active && ((fl >> 6) & 1u) != 0u &&
-                          !(a.cfg.path_set && ((fl >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) &&
-                          !(a.cfg.max_depth > 0 && edge + (int)GVPM_PF_DEPTH(fl) > a.cfg.max_depth);
+              const uint32_t id = __float_as_uint(h0.w);
+              bool keep = active;
               keep = keep && beamPrefilter(base, mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z), h1.w, id >> 24, r, eps, technique);
               const unsigned long long km = __ballot(keep);
               if (km) {
