@@ -81,9 +81,10 @@ void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *o
                     uint32_t nbeams, const uint32_t *counts, float4 *hot, uint32_t *hotFlags, hipStream_t s);
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
                            const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
-                           uint32_t pairCap, uint32_t nwaves, hipStream_t stream);
-void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint2 *pairs, const uint32_t *pairCount,
-                           uint32_t pairCap, uint32_t *queueHead, uint32_t nwaves, hipStream_t stream);
+                           uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream);
+void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint2 *pairs, const uint32_t *sortedKey,
+                           const uint32_t *sortedBlock, uint32_t nBlocks, uint32_t *queueHead, uint32_t nwaves,
+                           hipStream_t stream);
 struct PlaneArgs {
   const float4 *test;
   const float *ori, *end, *flux, *w1, *len1;
@@ -264,6 +265,7 @@ struct gvpm_context {
   const float *w1Dev = nullptr, *len1Dev = nullptr;
   DevBuf<float4> planeTest;
   DevBuf<uint32_t> subFlags;      // G-Beams: filter bits per sorted sub-beam
+  DevBuf<uint32_t> blockKeyA, blockKeyB, blockValA, blockValB;  // G-Beams: pair blocks and their tiles, unsorted / sorted
   DevBuf<uint2> beamPairs;        // G-Beams: (beam | sub << 24, sorted set) pairs between traversal and evaluation
   bool havePlanes = false;
 
@@ -469,6 +471,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release();
+  h->blockKeyA.release(); h->blockKeyB.release(); h->blockValA.release(); h->blockValB.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   poisson_graph_release(h->poissonGraph);
   h->tileTouched.release();
@@ -1196,11 +1199,13 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   // more than fit, is regrown to what it counted and the traversal repeated (deterministic, first iterations only).
   // queueCtl: [0] items, [1] item queue head, [2] pairs (multiple of 64), [3] block queue head
   if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure((size_t)16 << 20));
+  uint32_t npairs = 0;
   for (int attempt = 0;; ++attempt) {
     const uint32_t cap = (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u);
-    launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->beamPairs.p,
-                          h->bs->queueCtl.p + 2, cap, h->nwavesTrav, h->stream);
-    uint32_t npairs = 0;
+    const size_t nblkCap = cap / 64u + 1u;
+    for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nblkCap));
+    launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
+                          h->beamPairs.p, h->bs->queueCtl.p + 2, cap, h->blockKeyA.p, h->blockValA.p, h->nwavesTrav, h->stream);
     HIP_TRY(h, hipMemcpyAsync(&npairs, h->bs->queueCtl.p + 2, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (getenv("GVPM_BEAMS_TRACE")) {
@@ -1216,8 +1221,13 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     // the candidate count of the discarded pass
     HIP_TRY(h, hipMemsetAsync(a.stats + 1, 0, sizeof(unsigned long long), h->stream));
   }
-  launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact, h->beamPairs.p, h->bs->queueCtl.p + 2,
-                        (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u), h->bs->queueCtl.p + 3, h->nwaves, h->stream);
+  // blocks of 64 pairs, sorted by tile: the evaluation loads a tile's rays once per run of its blocks
+  const uint32_t nBlocks = npairs / 64u;
+  if (nBlocks)
+    HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBlocks,
+                            ilog2ceil(h->nsets + 1), h->stream));
+  launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
+                        h->bs->queueCtl.p + 3, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
