@@ -393,6 +393,7 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
   const float r2f = r * r;
   const float eps = a.cfg.epsilon;
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
+  const uint32_t coalesceAt = a.cfg.reserved[3] ? (uint32_t)a.cfg.reserved[3] : 512u;  // photons in a box row set
   unsigned long long nCand = 0, nOver = 0;
 
   for (;;) {
@@ -433,6 +434,29 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
         for (uint32_t win = 0; win < total; win += STAGE) {
           // stage [win, win + STAGE) of the concatenated ranges
           __syncthreads();
+          const uint32_t nst = min((uint32_t)STAGE, total - win);
+          if (total >= coalesceAt) {
+            // dense boxes (C4: 4 M photons): consecutive LANES take consecutive entries of the window (the range an
+            // entry falls in: a 6-step search over the exclusive scan, through ds_bpermute), so a load instruction
+            // reads a few contiguous runs of records instead of 64 separate ones
+#pragma unroll
+            for (uint32_t k = (uint32_t)lane; k < (uint32_t)STAGE; k += 64u) {
+              const uint32_t e = win + k;
+              uint32_t rr = 0;
+#pragma unroll
+              for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t cand = rr + step;
+                const uint32_t v = (uint32_t)__shfl((int)excl, (int)(cand & 63u), 64);
+                if (v <= e) rr = cand;
+              }
+              const uint32_t rStart = (uint32_t)__shfl((int)start, (int)rr, 64), rExcl = (uint32_t)__shfl((int)excl, (int)rr, 64);
+              if (k < nst) {
+                const uint32_t gi = rStart + (e - rExcl);
+                s.stage[k] = a.hot[gi];
+                s.stageIdx[k] = gi;
+              }
+            }
+          } else
           {
             const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
             uint32_t i = lo_i;
@@ -451,7 +475,6 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
             }
           }
           __syncthreads();
-          const uint32_t nst = min((uint32_t)STAGE, total - win);
           staged += nst;
           const uint32_t iters = (nst + LPB - 1) / LPB;
           // groups of G staged photons per lane: a branch-free coarse pass marks the candidates (the G LDS

@@ -405,6 +405,8 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_SLAB_LAYERS")) h->cfg.reserved[1] = atoi(e);
   h->cfg.reserved[2] = 0;  // slab layers per step when x is the major axis (0 = default)
   if (const char *e = getenv("GVPM_SLAB_LAYERS_X")) h->cfg.reserved[2] = atoi(e);
+  h->cfg.reserved[3] = 0;  // G-BRE traversal: staged photons per box row set from which the staging is lane-coalesced (0 = default)
+  if (const char *e = getenv("GVPM_COALESCE_AT")) h->cfg.reserved[3] = atoi(e);
   if (const char *e = getenv("GVPM_PLAN_TARGET")) {
     int v = atoi(e);
     if (v >= 64 && v <= (1 << 24)) h->planTarget = (uint32_t)v;
