@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--tile", type=int, default=512, help="pixels per side of one rank's tile")
     ap.add_argument("--photons", type=int, default=1000000)
     ap.add_argument("--scene", default="cbox")
+    ap.add_argument("--technique", default="bre3d", choices=["bre3d", "bre2d"],
+                    help="bre3d = BASELINE configs[1] (the bench line); bre2d: the 2D-kernel BRE of the same path (probe)")
     ap.add_argument("--scale", type=float, default=1.0, help="initialScaleVolume")
     ap.add_argument("--distinct", type=int, default=16, help="distinct pre-generated iterations (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,7 +80,9 @@ def main():
     W, H = args.tile * tx, args.tile * ty  # weak scaling: tile^2 pixels per rank
     sc = SynthScene(args.scene, W, H)
     p = sc.params()
-    p.vol_technique = abi.GVPM_VOL_BRE3D
+    p.vol_technique = abi.GVPM_VOL_BRE3D if args.technique == "bre3d" else abi.GVPM_VOL_BRE2D
+    if args.technique == "bre2d":
+        p.use_shift_null = 0  # GPMConfig::load rejects useShiftNull for the 2D kernel (gvpm_struct.h:310-313)
     p.initial_scale_volume = args.scale
     m, tris = sc.medium(), sc.triangles()
     ctx = hip.Context(p, device=local_rank)
@@ -187,7 +191,7 @@ def main():
             except (KeyError, ValueError):
                 pass
         out = {
-            "metric": "photon gather+shift evaluations per second (G-BRE 3D)",
+            "metric": "photon gather+shift evaluations per second (G-BRE %s)" % ("3D" if args.technique == "bre3d" else "2D"),
             "value": evals_total / elapsed / 1e6,
             "unit": "Mevals/s",
             "n_gpus": world,
@@ -200,10 +204,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic (generated on the device inside every step)" if gen else "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: S-{args.scene} + homogeneous medium, G-BRE 3D kernel, "
+                "workload": f"BASELINE configs[1]: S-{args.scene} + homogeneous medium, G-BRE {args.technique[3:].upper()} kernel, "
                             f"{args.tile}x{args.tile} px per GPU ({W}x{H} frame), {args.photons} photons/iter, "
                             f"{K} SPPM iters, initialScaleVolume {args.scale}",
-                "technique": "bre3d", "frame": [W, H], "tile_per_gpu": [args.tile, args.tile],
+                "technique": args.technique, "frame": [W, H], "tile_per_gpu": [args.tile, args.tile],
                 "photons_per_iter": args.photons, "iterations": K,
                 "sharding": f"4x4-pixel tiles round-robin over {nshards} ranks" if nshards > 1 else "none",
                 "evaluations": evals_total, "evals_per_iter_per_gpu": evals / K,
