@@ -52,38 +52,13 @@ __global__ __launch_bounds__(256) void film_kernel(const float *__restrict__ acc
   dy[i] = gy * invDiv;
 }
 
-// The same fold for the image tiles this handle has ever touched (an image-sharded rank owns a fraction of the
-// frame; everything else is exactly zero), clearing the per-iteration sums on the way out so that no
-// frame-sized memset is needed.  One wave per tile (4 per block); touched[] is sticky until gvpm_reset.
-__global__ __launch_bounds__(256) void finalize_tiles_kernel(float *__restrict__ accum, float *__restrict__ iter,
-                                                            const uint32_t *__restrict__ tileStart,
-                                                            unsigned char *__restrict__ touched, uint32_t ntiles, int tw,
-                                                            int th, int width, int height, float it, float invPaths) {
-  const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (tile >= ntiles) return;
-  const bool now = tileStart[tile + 1] > tileStart[tile];
-  if (!now && !touched[tile]) return;
-  if (now && lane == 0) touched[tile] = 1;
-  const uint32_t tilesX = (width + tw - 1) / tw;
-  const int x0 = (int)(tile % tilesX) * tw, y0 = (int)(tile / tilesX) * th;
-  const int n = tw * th * 27;
-  for (int idx = lane; idx < n; idx += 64) {
-    const int pix = idx / 27, k = idx % 27;
-    const int x = x0 + pix % tw, y = y0 + pix / tw;
-    if (x >= width || y >= height) continue;
-    const size_t i = ((size_t)y * width + x) * 27 + k;
-    const float v = iter[i] * invPaths;
-    iter[i] = 0.f;
-    accum[i] = (accum[i] * (it - 1.f) + v) / it;
-  }
+// out = in * scale (the G-BRE accumulators hold the running SUM over iterations; the APA mean is sum / it)
+__global__ __launch_bounds__(256) void scale_kernel(const float *in, float *out, size_t n, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * scale;
 }
-
-void launch_finalize_tiles(float *accum, float *iter, const uint32_t *tileStart, unsigned char *touched, uint32_t ntiles,
-                           int tw, int th, int width, int height, int it, uint64_t nbPaths, hipStream_t s) {
-  if (ntiles == 0) return;
-  hipLaunchKernelGGL(finalize_tiles_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, s, accum, iter, tileStart, touched, ntiles, tw, th,
-                     width, height, (float)it, 1.0f / (float)nbPaths);
+void launch_scale(const float *in, float *out, size_t n, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, scale);
 }
 
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s) {

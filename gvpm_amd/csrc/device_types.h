@@ -72,7 +72,8 @@ struct GatherArgs {
   const float *scaleVol;     // per pixel GatherPoint::scaleVol (read)
   float *mvol;               // per pixel photons found this iteration (MVol, atomically added)
   // outputs
-  float *iter;               // P * 27, this iteration's un-normalised sums
+  float *iter;               // P * 27: this iteration's un-normalised sums (G-BRE: the running SUM over iterations)
+  float iterScale;           // G-BRE: 1 / nb_paths of this iteration, applied when a partial sum is added
   unsigned long long *stats; // 8 counters (gvpm_stats order)
 };
 

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
         if (v != 0.f) {
           const uint32_t pv = s.pix[bb];
           const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
-          atomicAdd(&a.iter[p * 27 + k], v);
+          atomicAdd(&a.iter[p * 27 + k], v * a.iterScale);
         }
       }
     }

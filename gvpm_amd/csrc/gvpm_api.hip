@@ -62,8 +62,7 @@ hipError_t poisson_solve_device(const gvpm_poisson_params &prm, int W, int H, co
                                 PoissonGraphCache &cache, hipStream_t s);
 size_t poisson_scratch_bytes(int W, int H);
 void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t nbPaths, hipStream_t s);
-void launch_finalize_tiles(float *accum, float *iter, const uint32_t *tileStart, unsigned char *touched, uint32_t ntiles,
-                           int tw, int th, int width, int height, int it, uint64_t nbPaths, hipStream_t s);
+void launch_scale(const float *in, float *out, size_t n, float scale, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream);
@@ -285,8 +284,12 @@ struct gvpm_context {
   float globalScaleVolume = 1.f;
   // G-BRE: the image tiles touched since the last reset (everything outside is exactly zero): the per-iteration
   // buffer is folded and cleared only there -- a rank of an image-sharded run owns a fraction of the frame
-  DevBuf<unsigned char> tileTouched;
-  uint32_t tileTouchedTiles = 0;
+  // G-BRE keeps the running SUM of the per-iteration estimates in `accum` (the evaluation kernel adds straight into
+  // it): the APA running mean (gvpm.cpp:1055-1069) is sum / it, applied by the readers.  No per-iteration buffer, no
+  // fold kernel between two evaluation kernels.
+  bool sumMode = false;
+  int sumIt = 0;                  // `it` of the last gather (0: nothing accumulated)
+  DevBuf<float> accumTmp;         // scaled copy for host downloads
 
   // stats / timing
   DevBuf<unsigned long long> stats;
@@ -476,7 +479,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->blockKeyA.release(); h->blockKeyB.release(); h->blockValA.release(); h->blockValB.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   poisson_graph_release(h->poissonGraph);
-  h->tileTouched.release();
+  h->accumTmp.release();
   h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
@@ -492,7 +495,7 @@ int gvpm_reset(gvpm_context *h) {
   HIP_TRY(h, hipMemsetAsync(h->accum.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * GVPM_STAT_ROWS * sizeof(unsigned long long), h->stream));
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
-  h->tileTouchedTiles = 0;  // forget the touched tiles
+  h->sumIt = 0;
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   for (size_t &u : h->eventsUsed) u = 0;
   h->useAll = false;
@@ -982,6 +985,16 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   }
   GatherArgs a;
   fillArgs(h, a, r);
+  // the evaluation adds this iteration's estimate (1 / nb_paths per partial sum) straight into the running sum
+  h->sumMode = true;
+  a.iter = h->accum.p;
+  a.iterScale = 1.0f / (float)nb_paths;
+  if (h->sumIt != 0 && it - 1 != h->sumIt) {
+    // not the successor of the last iteration: the reference's fold (mean * (it - 1) + v) / it then weighs the old
+    // mean by (it - 1) / it, i.e. the sum by (it - 1) / last
+    launch_scale(h->accum.p, h->accum.p, h->npix * 27, (float)((double)(it - 1) / (double)h->sumIt), h->stream);
+  }
+  h->sumIt = it;
   const uint32_t itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
   HIP_TRY(h, h->bs->items.ensure(itemCap));
   HIP_TRY(h, h->bs->itemOff.ensure(itemCap));
@@ -1043,15 +1056,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
                       h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
-  // fold + clear only the image tiles this handle touches (iter is all zero outside the gathers)
-  HIP_TRY(h, h->tileTouched.ensure((size_t)h->bs->ntiles + 1));
-  if (h->tileTouchedTiles != h->bs->ntiles) {
-    HIP_TRY(h, hipMemsetAsync(h->tileTouched.p, 0, (size_t)h->bs->ntiles + 1, h->stream));
-    h->tileTouchedTiles = h->bs->ntiles;
-  }
-  launch_finalize_tiles(h->accum.p, h->iter.p, h->bs->tileStart.p, h->tileTouched.p, h->bs->ntiles, h->bs->tileW,
-                        h->bs->tileH, h->cfg.width, h->cfg.height, it, nb_paths, h->stream);
-  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));  // the fold reads this set's tileStart too
+  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
   if (h->pipeline) {
     for (int k = 0; k < (h->travStream ? 3 : 2); ++k) {
       BuildSet &other = h->sets[k];
@@ -1409,10 +1414,19 @@ int gvpm_get_kernel_time(gvpm_context *h, float *avg_ms, uint32_t *launches) {
   return gvpm_get_phase_time(h, 0, avg_ms, launches);
 }
 
+// G-BRE: accum holds the sum over iterations, the mean is sum / it
+static float accumScale(const gvpm_context *h) { return h->sumMode && h->sumIt > 0 ? (float)(1.0 / (double)h->sumIt) : 1.f; }
+
 int gvpm_download_accum(gvpm_context *h, float *accum) {
   CHECK_H(h);
   if (!accum) return GVPM_ERR_INVALID_ARG;
-  HIP_TRY(h, hipMemcpyAsync(accum, h->useAll ? h->accumAll.p : h->accum.p, h->npix * 27 * sizeof(float),
+  const float *src = h->useAll ? h->accumAll.p : h->accum.p;
+  if (accumScale(h) != 1.f) {
+    HIP_TRY(h, h->accumTmp.ensure(h->npix * 27));
+    launch_scale(src, h->accumTmp.p, h->npix * 27, accumScale(h), h->stream);
+    src = h->accumTmp.p;
+  }
+  HIP_TRY(h, hipMemcpyAsync(accum, src, h->npix * 27 * sizeof(float),
                             hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GVPM_OK;
@@ -1421,8 +1435,7 @@ int gvpm_download_accum(gvpm_context *h, float *accum) {
 int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
   CHECK_H(h);
   if (!accum_dev) return GVPM_ERR_INVALID_ARG;
-  HIP_TRY(h, hipMemcpyAsync(accum_dev, h->useAll ? h->accumAll.p : h->accum.p, h->npix * 27 * sizeof(float),
-                            hipMemcpyDeviceToDevice, h->stream));
+  launch_scale(h->useAll ? h->accumAll.p : h->accum.p, accum_dev, h->npix * 27, accumScale(h), h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GVPM_OK;
 }
@@ -1433,6 +1446,7 @@ static int filmToDevice(gvpm_context *h, int it, int reuse_primal, const float *
   // non-APA estimators are normalised by the emitted path count (gvpm.cpp:489-492)
   float invDiv = 1.f;
   if (h->cfg.vol_technique == GVPM_DISTANCE) invDiv = h->totalEmitted > 0 ? (float)(1.0 / h->totalEmitted) : 0.f;
+  invDiv *= accumScale(h);
   launch_film(h->useAll ? h->accumAll.p : h->accum.p, emissionDev, h->cfg.width, h->cfg.height, it, reuse_primal, invDiv,
               out, out + n, out + 2 * n, h->stream);
   HIP_TRY(h, hipGetLastError());
