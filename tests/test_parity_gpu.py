@@ -418,3 +418,26 @@ def test_partial_films_of_interleaved_shards_sum_to_the_frames_film():
     for k in range(3):
         # (fp32 sums of up to four terms against the fp64 assembly of the same accumulators)
         assert np.allclose(fsum[k * n:(k + 1) * n].reshape(28, 36, 3), o[k], rtol=1e-4, atol=1e-6 * np.abs(o[k]).max())
+
+
+def test_non_consecutive_iteration_numbers_fold_like_the_reference():
+    """The device keeps the running SUM over iterations; when `it` is not the successor of the previous call the
+    reference's fold (mean * (it - 1) + v) / it weighs the old mean differently, and the sum has to be rescaled."""
+    c = cases.make_case("cbox", 24, 20, 8000, 3.0)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    ref = None
+    for it in (1, 3, 4, 9):
+        r = ctx.radius()
+        ctx.gather(it, c.nb)
+        ref, _, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, r, it, c.nb, 64, use_accel=False, accum=ref)
+    acc = ctx.download_accum()
+    film = ctx.download_film(9, True)
+    ctx.close()
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert l2(acc, ref, lum) < TOL
+    for a, b in zip(film, O.assemble(ref, 9, True)):
+        assert l2(a, b, lum) < TOL
