@@ -110,9 +110,24 @@ __device__ __forceinline__ double invJacobian(const PlaneD &pl, d3 k) { return 1
 
 // One queued (plane, camera ray) pair: PlaneGradRadianceQuery::operator().  True when the pair
 // produced a contribution (an evaluation).
+struct MRecP {
+  float tr, pdfSuccess, pdfFailure;
+};
+__device__ __forceinline__ MRecP mediumEvalP(const MediumDev &m, float dist) {
+  MRecP r;
+  float e = __expf(-m.sigmaT[0] * dist);
+  r.pdfSuccess = m.sigmaT[0] * e * m.msw;
+  r.pdfFailure = e * m.msw + (1.f - m.msw);
+  if (e < 1e-20f) e = 0.f;
+  r.tr = e;
+  return r;
+}
+
+// The lane evaluates hits of ITS OWN ray (bIdx = lane): the 27 sums stay in registers (acc) -- no LDS atomics, whose
+// ~1 lane per clock and CU had been a third of this kernel -- and the ray columns it reads are its own.
 template <int B>
 __device__ __forceinline__ bool evaluatePlane(const GatherArgs &a, const PlaneArgs &pa, TileLds<B> &s, uint32_t planeIdx,
-                                              uint32_t bIdx, uint32_t &nDiff, uint32_t &nFail) {
+                                              uint32_t bIdx, float (&acc)[27], uint32_t &nDiff, uint32_t &nFail) {
   const PlaneD pl = loadPlane(pa, planeIdx);
   const RayReg base = loadRay(s, 0, bIdx);
   const uint32_t edge = s.edge[bIdx];
@@ -120,34 +135,31 @@ __device__ __forceinline__ bool evaluatePlane(const GatherArgs &a, const PlaneAr
   const RayD cam{tod(base.o), tod(base.d), eps, (double)base.len - eps};
   PlaneIts bRec;
   if (!intersectPlane0D(pl, cam, bRec)) return false;
-  const double g = (double)a.med.g;
+  // From here on the RADIOMETRY is fp32 (transmittances, phase functions, pdf and Jacobian ratios, MIS weights: ~56
+  // divisions and square roots per pair in the fp64 transcription, ~28 instructions each): operands are O(1) and the
+  // results go to fp32 accumulators anyway.  The geometry feeding it -- the base pierce point, the rotated plane, the
+  // shifted pierce point and its acceptance tests, the Jacobian determinants -- stays fp64.
+  const float g = a.med.g;
+  const float tCamF = (float)bRec.tCam, t0F = (float)bRec.t0, t1F = (float)bRec.t1;
   // getContrib0D, pm/plane_struct.h:150-192
-  const MRecD mCam = mediumEvalD(a.med, bRec.tCam);
-  const MRecD m0 = mediumEvalD(a.med, bRec.t0);
-  const MRecD m1 = mediumEvalD(a.med, bRec.t1);
-  const double pBase = phaseD(g, pl.w1 * -1.0, cam.d * -1.0);
-  const double invJBase = invJacobian(pl, cam.d);
-  d3 baseContrib;
-  {
-    const double k = mCam.tr * pBase;
-    baseContrib = mkd(k * (double)a.med.sigmaS[0] * (double)a.med.sigmaS[0] * pl.flux.x,
-                      k * (double)a.med.sigmaS[1] * (double)a.med.sigmaS[1] * pl.flux.y,
-                      k * (double)a.med.sigmaS[2] * (double)a.med.sigmaS[2] * pl.flux.z);
-    baseContrib = baseContrib * (m1.tr * m0.tr);
-    baseContrib = baseContrib * (1.0 / m0.pdfFailure);
-    baseContrib = baseContrib * (1.0 / m1.pdfFailure);
-    baseContrib = baseContrib * invJBase;
-  }
-  atomicAdd(&s.acc[0][bIdx], (float)baseContrib.x);
-  atomicAdd(&s.acc[1][bIdx], (float)baseContrib.y);
-  atomicAdd(&s.acc[2][bIdx], (float)baseContrib.z);
+  const MRecP mCam = mediumEvalP(a.med, tCamF), m0 = mediumEvalP(a.med, t0F), m1 = mediumEvalP(a.med, t1F);
+  const f3 w1F = tof(pl.w1);
+  const float pBase = phaseEval(g, -w1F, -base.d);
+  const float jBase = (float)fabs(dot(pl.w0, crossd(pl.w1, cam.d)));
+  const float invJBase = frcp(jBase);
+  const f3 sig2 = mk3(a.med.sigmaS[0] * a.med.sigmaS[0], a.med.sigmaS[1] * a.med.sigmaS[1], a.med.sigmaS[2] * a.med.sigmaS[2]);
+  const f3 baseContrib = sig2 * tof(pl.flux) * (fdiv(mCam.tr * pBase * m1.tr * m0.tr, m0.pdfFailure * m1.pdfFailure) * invJBase);
+  acc[0] += baseContrib.x;
+  acc[1] += baseContrib.y;
+  acc[2] += baseContrib.z;
   const double w0Dot = dot(pl.w0, pl.w1);
   const double sinW = sqrt(1.0 - w0Dot * w0Dot);
+  const float invM0 = frcp(m0.tr), invM1 = frcp(m1.tr);
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
     const RayReg sh = loadRay(s, 1 + i, bIdx);
-    double w = 1.0;
-    d3 sflux = mkd(0, 0, 0);
+    float w = 1.f;
+    f3 sflux = mk3(0.f);
     if (sh.valid) {
       // specularShift (BETTERSHIFT 0), shift_volume_planes.h:263-416
       const RayD shiftRay{tod(sh.o), tod(sh.d), eps, (double)sh.len};
@@ -159,39 +171,39 @@ __device__ __forceinline__ bool evaluatePlane(const GatherArgs &a, const PlaneAr
       if (!intersectionUnit(shiftRay, pl.ori, pl.w0, newW1, tCamNew, t0New, t1New)) {
         nFail++;
       } else {
-        const MRecD m1s = mediumEvalD(a.med, t1New);
-        const MRecD m0s = mediumEvalD(a.med, t0New);
-        const double jShift = fabs(dot(pl.w0, crossd(newW1, shiftRay.d)));
-        double f = (m0s.tr * (1.0 / m0.tr)) * (m1s.tr * (1.0 / m1.tr));
-        f = f / invJBase;
-        f = f * (1.0 / jShift);
-        double jac = invJBase * jShift;
-        jac /= t1New / bRec.t1;
-        if (pl.edgeID != 1) jac /= t0New / bRec.t0;
-        const double pNew = phaseD(g, newW1 * -1.0, shiftRay.d * -1.0);
-        f = f * pNew / pBase;
-        w = 0.5;
+        const float t0N = (float)t0New, t1N = (float)t1New;
+        const MRecP m1s = mediumEvalP(a.med, t1N), m0s = mediumEvalP(a.med, t0N);
+        const float jShift = (float)fabs(dot(pl.w0, crossd(newW1, shiftRay.d)));
+        float f = (m0s.tr * invM0) * (m1s.tr * invM1);
+        f = fdiv(f * jBase, jShift);
+        float jac = invJBase * jShift;
+        jac = fdiv(jac * t1F, t1N);
+        if (pl.edgeID != 1) jac = fdiv(jac * t0F, t0N);
+        const float pNew = phaseEval(g, -tof(newW1), -sh.d);
+        f = fdiv(f * pNew, pBase);
+        w = 0.5f;
         sflux = baseContrib * (f * jac);
         nDiff++;
         if (a.cfg.use_mis) {
-          const double basePdf = m0.pdfSuccess * m1.pdfSuccess * pBase;
-          const double offsetPdf = m0s.pdfSuccess * m1s.pdfSuccess * pNew;
-          if (offsetPdf == 0.0 || basePdf == 0.0) {
-            w = 1.0;
-          } else {
-            w = 1.0 / (1.0 + (double)sensorMIS(sh, base, edge) * jac * offsetPdf / basePdf);
-          }
+          const float basePdf = m0.pdfSuccess * m1.pdfSuccess * pBase;
+          const float offsetPdf = m0s.pdfSuccess * m1s.pdfSuccess * pNew;
+          if (offsetPdf == 0.f || basePdf == 0.f) w = 1.f;
+          else w = frcp(1.f + sensorMIS(sh, base, edge) * jac * fdiv(offsetPdf, basePdf));
         }
       }
     }
-    if (sflux.x != 0 || sflux.y != 0 || sflux.z != 0) {
-      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (float)(sflux.x * w));
-      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (float)(sflux.y * w));
-      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (float)(sflux.z * w));
+    // (register arrays need constant indices: the shift's slots are selected by a mask)
+    const f3 sw = sflux * w, bw = baseContrib * w;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const float m = ii == i ? 1.f : 0.f;
+      acc[3 + 3 * ii + 0] += m * sw.x;
+      acc[3 + 3 * ii + 1] += m * sw.y;
+      acc[3 + 3 * ii + 2] += m * sw.z;
+      acc[15 + 3 * ii + 0] += m * bw.x;
+      acc[15 + 3 * ii + 1] += m * bw.y;
+      acc[15 + 3 * ii + 2] += m * bw.z;
     }
-    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (float)(baseContrib.x * w));
-    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (float)(baseContrib.y * w));
-    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (float)(baseContrib.z * w));
   }
   return true;
 }
@@ -220,7 +232,14 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
     if (!__ballot(rayValid)) continue;
     const float mint = eps, maxt = base.len - eps;
     const f3 o = base.o, d = base.d;
+    // per-lane hit queues (ring of QD plane indices in this lane's LDS column): a lane only evaluates hits of its
+    // own ray; the wave evaluates when most lanes have one pending, or a queue is about to fill
+    constexpr uint32_t QD = 8;
+    uint32_t *hitQ = reinterpret_cast<uint32_t *>(s.stage);  // [QD][64]
     uint32_t qHead = 0, qCount = 0;
+    float acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
     nCand += (unsigned long long)__popcll(__ballot(rayValid)) * (p1 - p0);
     for (uint32_t p = p0; p < p1; ++p) {
       // wave-uniform record: scalar loads
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
       const f3 Q = cross(T, e0);
       const float v = dot(d, Q);
       const float c = dot(e1, Q);
-      const float nT = sqrtf(dot(T, T));
+      const float nT = fabsf(T.x) + fabsf(T.y) + fabsf(T.z);  // >= |T|: the band only has to be conservative
       // conservative acceptance: every quantity carries a relative error <= K of its magnitude bound
       const float K = 4e-6f;
       const float D = fabsf(det);
@@ -247,39 +266,33 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
       bool hit = rayValid && D + eD >= 0.99999e-5f;
       hit = hit && us >= -eU && us <= D + eU && vs >= -eV && vs <= D + eV;
       hit = hit && cs > mint * D - eC - mint * eD && cs < maxt * D + eC + maxt * eD;
-      const unsigned long long m = __ballot(hit);
-      if (m) {
-        if (hit) {
-          const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-          s.queue[(qHead + qCount + off) % QCAP] = make_uint2(p, (uint32_t)lane);
-        }
-        qCount += __popcll(m);
-        if (qCount >= 64u) {
-          __syncthreads();
-          const uint2 e = s.queue[(qHead + lane) % QCAP];
-          if (evaluatePlane<B>(a, pa, s, e.x, e.y, nDiff, nFail)) nEval++;
-          qHead = (qHead + 64u) % QCAP;
-          qCount -= 64u;
-          __syncthreads();
+      if (hit) {
+        hitQ[((qHead + qCount) % QD) * 64u + (uint32_t)lane] = p;
+        qCount++;
+      }
+      const unsigned long long pending = __ballot(qCount > 0u);
+      if (__popcll(pending) >= 48 || __ballot(qCount >= QD - 1u)) {
+        if (qCount > 0u) {
+          if (evaluatePlane<B>(a, pa, s, hitQ[qHead * 64u + (uint32_t)lane], (uint32_t)lane, acc, nDiff, nFail)) nEval++;
+          qHead = (qHead + 1u) % QD;
+          qCount--;
         }
       }
     }
-    __syncthreads();
-    if ((uint32_t)lane < qCount) {
-      const uint2 e = s.queue[(qHead + lane) % QCAP];
-      if (evaluatePlane<B>(a, pa, s, e.x, e.y, nDiff, nFail)) nEval++;
-    }
-    __syncthreads();
-    for (int idx = lane; idx < 27 * B; idx += 64) {
-      const int k = idx / B, bb = idx % B;
-      if ((uint32_t)bb < nb) {
-        const float val = s.acc[k][bb];
-        if (val != 0.f) {
-          const uint32_t pv = s.pix[bb];
-          const size_t pix = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
-          atomicAdd(&a.iter[pix * 27 + k], val);
-        }
+    while (__ballot(qCount > 0u)) {
+      if (qCount > 0u) {
+        if (evaluatePlane<B>(a, pa, s, hitQ[qHead * 64u + (uint32_t)lane], (uint32_t)lane, acc, nDiff, nFail)) nEval++;
+        qHead = (qHead + 1u) % QD;
+        qCount--;
       }
+    }
+    // this lane's 27 sums -> the film (other plane chunks add to the same pixel)
+    if ((uint32_t)lane < nb) {
+      const uint32_t pv = s.pix[lane];
+      const size_t pix = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if (acc[k] != 0.f) atomicAdd(&a.iter[pix * 27 + k], acc[k]);
     }
   }
   {
