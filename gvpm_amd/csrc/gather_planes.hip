@@ -234,44 +234,54 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
     const f3 o = base.o, d = base.d;
     // per-lane hit queues (ring of QD plane indices in this lane's LDS column): a lane only evaluates hits of its
     // own ray; the wave evaluates when most lanes have one pending, or a queue is about to fill
-    constexpr uint32_t QD = 8;
+    constexpr uint32_t QD = 16;
     uint32_t *hitQ = reinterpret_cast<uint32_t *>(s.stage);  // [QD][64]
     uint32_t qHead = 0, qCount = 0;
     float acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.f;
     nCand += (unsigned long long)__popcll(__ballot(rayValid)) * (p1 - p0);
-    for (uint32_t p = p0; p < p1; ++p) {
-      // wave-uniform record: scalar loads
-      const float4 r0 = pa.test[3 * (size_t)p + 0];
-      const float4 r1 = pa.test[3 * (size_t)p + 1];
-      const float4 r2 = pa.test[3 * (size_t)p + 2];
-      const f3 e0 = mk3(r1.x, r1.y, r1.z), e1 = mk3(r2.x, r2.y, r2.z);
-      const float n0 = r0.w, n1 = r1.w;
-      const f3 T = o - mk3(r0.x, r0.y, r0.z);
-      const f3 P = cross(d, e1);
-      const float det = dot(e0, P);
-      const float u = dot(T, P);
-      const f3 Q = cross(T, e0);
-      const float v = dot(d, Q);
-      const float c = dot(e1, Q);
-      const float nT = fabsf(T.x) + fabsf(T.y) + fabsf(T.z);  // >= |T|: the band only has to be conservative
-      // conservative acceptance: every quantity carries a relative error <= K of its magnitude bound
-      const float K = 4e-6f;
-      const float D = fabsf(det);
-      const float sgn = det < 0.f ? -1.f : 1.f;
-      const float eD = K * n0 * n1;
-      const float us = u * sgn, vs = v * sgn, cs = c * sgn;
-      const float eU = K * nT * n1 + eD, eV = K * nT * n0 + eD, eC = K * nT * n0 * n1;
-      bool hit = rayValid && D + eD >= 0.99999e-5f;
-      hit = hit && us >= -eU && us <= D + eU && vs >= -eV && vs <= D + eV;
-      hit = hit && cs > mint * D - eC - mint * eD && cs < maxt * D + eC + maxt * eD;
-      if (hit) {
-        hitQ[((qHead + qCount) % QD) * 64u + (uint32_t)lane] = p;
+    // four planes per step: the twelve scalar loads and the four test chains overlap
+    constexpr uint32_t G = 8;
+    for (uint32_t pb = p0; pb < p1; pb += G) {
+      uint32_t hm = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < G; ++g) {
+        const uint32_t p = min(pb + g, p1 - 1u);
+        // wave-uniform record: scalar loads
+        const float4 r0 = pa.test[3 * (size_t)p + 0];
+        const float4 r1 = pa.test[3 * (size_t)p + 1];
+        const float4 r2 = pa.test[3 * (size_t)p + 2];
+        const f3 e0 = mk3(r1.x, r1.y, r1.z), e1 = mk3(r2.x, r2.y, r2.z);
+        const float n0 = r0.w, n1 = r1.w;
+        const f3 T = o - mk3(r0.x, r0.y, r0.z);
+        const f3 P = cross(d, e1);
+        const float det = dot(e0, P);
+        const float u = dot(T, P);
+        const f3 Q = cross(T, e0);
+        const float v = dot(d, Q);
+        const float c = dot(e1, Q);
+        const float nT = fabsf(T.x) + fabsf(T.y) + fabsf(T.z);  // >= |T|: the band only has to be conservative
+        // conservative acceptance: every quantity carries a relative error <= K of its magnitude bound
+        const float K = 4e-6f;
+        const float D = fabsf(det);
+        const float sgn = det < 0.f ? -1.f : 1.f;
+        const float eD = K * n0 * n1;
+        const float us = u * sgn, vs = v * sgn, cs = c * sgn;
+        const float eU = K * nT * n1 + eD, eV = K * nT * n0 + eD, eC = K * nT * n0 * n1;
+        bool hit = rayValid && pb + g < p1 && D + eD >= 0.99999e-5f;
+        hit = hit && us >= -eU && us <= D + eU && vs >= -eV && vs <= D + eV;
+        hit = hit && cs > mint * D - eC - mint * eD && cs < maxt * D + eC + maxt * eD;
+        hm |= hit ? (1u << g) : 0u;
+      }
+      // push this lane's hits (0 - 4), then evaluate while most lanes have one pending or a ring could fill
+      for (uint32_t m = hm; m; m &= m - 1u) {
+        hitQ[((qHead + qCount) % QD) * 64u + (uint32_t)lane] = pb + (uint32_t)__ffs(m) - 1u;
         qCount++;
       }
-      const unsigned long long pending = __ballot(qCount > 0u);
-      if (__popcll(pending) >= 48 || __ballot(qCount >= QD - 1u)) {
+      for (;;) {
+        const unsigned long long pending = __ballot(qCount > 0u);
+        if (!(__popcll(pending) >= 48 || __ballot(qCount > QD - G))) break;
         if (qCount > 0u) {
           if (evaluatePlane<B>(a, pa, s, hitQ[qHead * 64u + (uint32_t)lane], (uint32_t)lane, acc, nDiff, nFail)) nEval++;
           qHead = (qHead + 1u) % QD;
