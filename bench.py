@@ -225,6 +225,30 @@ def main():
             },
             "stats": st,
         }
+        if world == 1 and not gen:
+            # the same kernel without the other streams' kernels beside it (a second handle with GVPM_PIPELINE=0,
+            # a few untimed steps after the timed region): reported next to the live figure, which is the one `frac` uses
+            os.environ["GVPM_PIPELINE"] = "0"
+            try:
+                iso = hip.Context(p, device=local_rank)
+                iso.upload_scene(*tris)
+                iso.upload_medium(m)
+                for it in range(1, 7):
+                    soa, nph, nb, rptr, nsets = inputs[(it - 1) % ndist]
+                    if it == 3:
+                        iso.synchronize()
+                        iso.kernel_time()
+                    iso.upload_photons_dev(soa)
+                    iso.upload_camera_beams_dev(rptr, nsets)
+                    iso.gather(it, nb)
+                iso.synchronize()
+                ims, _ = iso.kernel_time()
+                iso.close()
+                if ims > 0:
+                    out["roofline"]["kernel_isolated_ms"] = ims
+                    out["roofline"]["frac_isolated"] = bytes_alg / (ims * 1e-3) / 1e9 / 8000.0
+            finally:
+                os.environ.pop("GVPM_PIPELINE", None)
         if world == 1 and not args.no_cpu_baseline and not gen:
             out["cpu_baseline"] = cpu_baseline(sc, p, m, tris, host0, args)
         print(json.dumps(out), flush=True)
