@@ -50,6 +50,12 @@ struct PlaneIts {
   double tCam, t0, t1, invDet;
 };
 
+// the tile's rays + the per-lane hit rings: 19 KB a wave (8 waves per CU, what the registers allow; the generic tile structure with its stage
+// and accumulators was 30 KB)
+template <int B> struct PlaneLds : RayTile<B> {
+  uint32_t hitQ[8][64];
+};
+
 __device__ __forceinline__ PlaneD loadPlane(const PlaneArgs &pa, uint32_t i) {
   PlaneD p;
   p.ori = mkd(pa.ori[3 * (size_t)i], pa.ori[3 * (size_t)i + 1], pa.ori[3 * (size_t)i + 2]);
@@ -126,7 +132,7 @@ __device__ __forceinline__ MRecP mediumEvalP(const MediumDev &m, float dist) {
 // The lane evaluates hits of ITS OWN ray (bIdx = lane): the 27 sums stay in registers (acc) -- no LDS atomics, whose
 // ~1 lane per clock and CU had been a third of this kernel -- and the ray columns it reads are its own.
 template <int B>
-__device__ __forceinline__ bool evaluatePlane(const GatherArgs &a, const PlaneArgs &pa, TileLds<B> &s, uint32_t planeIdx,
+__device__ __forceinline__ bool evaluatePlane(const GatherArgs &a, const PlaneArgs &pa, PlaneLds<B> &s, uint32_t planeIdx,
                                               uint32_t bIdx, float (&acc)[27], uint32_t &nDiff, uint32_t &nFail) {
   const PlaneD pl = loadPlane(pa, planeIdx);
   const RayReg base = loadRay(s, 0, bIdx);
@@ -211,7 +217,7 @@ __device__ __forceinline__ bool evaluatePlane(const GatherArgs &a, const PlaneAr
 // grid: x = image tile, y = plane chunk
 __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, PlaneArgs pa) {
   constexpr int B = 64;
-  __shared__ TileLds<B> s;
+  __shared__ PlaneLds<B> s;
   const int lane = threadIdx.x;
   const uint32_t tile = blockIdx.x;
   const uint32_t p0 = blockIdx.y * pa.planesPerItem;
@@ -225,7 +231,6 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
     const uint32_t nb = min((uint32_t)B, tileEnd - setBase);
     __syncthreads();
     loadTileRays<B>(a, s, setBase, nb, lane);
-    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
     __syncthreads();
     const RayReg base = loadRay(s, 0, lane);
     const bool rayValid = (uint32_t)lane < nb && base.valid;
@@ -234,15 +239,15 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
     const f3 o = base.o, d = base.d;
     // per-lane hit queues (ring of QD plane indices in this lane's LDS column): a lane only evaluates hits of its
     // own ray; the wave evaluates when most lanes have one pending, or a queue is about to fill
-    constexpr uint32_t QD = 16;
-    uint32_t *hitQ = reinterpret_cast<uint32_t *>(s.stage);  // [QD][64]
+    constexpr uint32_t QD = 8;
+    uint32_t *hitQ = &s.hitQ[0][0];  // [QD][64]
     uint32_t qHead = 0, qCount = 0;
     float acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.f;
     nCand += (unsigned long long)__popcll(__ballot(rayValid)) * (p1 - p0);
     // four planes per step: the twelve scalar loads and the four test chains overlap
-    constexpr uint32_t G = 8;
+    constexpr uint32_t G = 4;
     for (uint32_t pb = p0; pb < p1; pb += G) {
       uint32_t hm = 0;
 #pragma unroll
