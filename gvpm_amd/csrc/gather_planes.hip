@@ -54,6 +54,7 @@ struct PlaneIts {
 // and accumulators was 30 KB)
 template <int B> struct PlaneLds : RayTile<B> {
   uint32_t hitQ[8][64];
+  uint32_t cull[64];  // planes of the current batch of 64 that the tile's frustum can reach
 };
 
 __device__ __forceinline__ PlaneD loadPlane(const PlaneArgs &pa, uint32_t i) {
@@ -245,52 +246,110 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
     float acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-    nCand += (unsigned long long)__popcll(__ballot(rayValid)) * (p1 - p0);
-    // four planes per step: the twelve scalar loads and the four test chains overlap
+    // ---- tile-frustum cull ----------------------------------------------------------------------------------
+    // With a common ray origin O (a pinhole sensor's first edge) the quantities of the pierce test are linear in the
+    // ray direction:  det = d.(e1 x e0),  u det = d.(e1 x T),  v det = d.(T x e0),  t det = e1.(T x e0),  T = O - ori.
+    // Over the componentwise bounds [dlo, dhi] of the tile's 64 directions each has an interval; a plane whose
+    // intervals put u, v or t outside its acceptance range for EVERY direction of the box (with the test's own error
+    // band as slack) cannot be pierced by any ray of the tile.  One lane culls one plane, 64 planes a batch; the
+    // survivors (a few per cent: a ray pierces ~5 % of the planes) go through the per-ray test below.
+    const unsigned long long validMask = __ballot(rayValid);
+    const int firstValid = __ffsll((long long)validMask) - 1;
+    const f3 o0 = mk3(__shfl(o.x, firstValid, 64), __shfl(o.y, firstValid, 64), __shfl(o.z, firstValid, 64));
+    const bool cullOk = !__ballot(rayValid && (o.x != o0.x || o.y != o0.y || o.z != o0.z));
+    const f3 dlo = mk3(wave_min(rayValid ? d.x : INFINITY), wave_min(rayValid ? d.y : INFINITY), wave_min(rayValid ? d.z : INFINITY));
+    const f3 dhi = mk3(wave_max(rayValid ? d.x : -INFINITY), wave_max(rayValid ? d.y : -INFINITY), wave_max(rayValid ? d.z : -INFINITY));
+    const float maxtAll = wave_max(rayValid ? maxt : -INFINITY);
+    auto range = [&](f3 A, float &lo, float &hi) {
+      lo = fminf(A.x * dlo.x, A.x * dhi.x) + fminf(A.y * dlo.y, A.y * dhi.y) + fminf(A.z * dlo.z, A.z * dhi.z);
+      hi = fmaxf(A.x * dlo.x, A.x * dhi.x) + fmaxf(A.y * dlo.y, A.y * dhi.y) + fmaxf(A.z * dlo.z, A.z * dhi.z);
+    };
     constexpr uint32_t G = 4;
-    for (uint32_t pb = p0; pb < p1; pb += G) {
-      uint32_t hm = 0;
-#pragma unroll
-      for (uint32_t g = 0; g < G; ++g) {
-        const uint32_t p = min(pb + g, p1 - 1u);
-        // wave-uniform record: scalar loads
-        const float4 r0 = pa.test[3 * (size_t)p + 0];
-        const float4 r1 = pa.test[3 * (size_t)p + 1];
-        const float4 r2 = pa.test[3 * (size_t)p + 2];
+    for (uint32_t pb0 = p0; pb0 < p1; pb0 += 64u) {
+      const uint32_t pmine = pb0 + (uint32_t)lane;
+      bool keep = pmine < p1;
+      if (keep && cullOk) {
+        const float4 r0 = pa.test[3 * (size_t)pmine + 0], r1 = pa.test[3 * (size_t)pmine + 1], r2 = pa.test[3 * (size_t)pmine + 2];
         const f3 e0 = mk3(r1.x, r1.y, r1.z), e1 = mk3(r2.x, r2.y, r2.z);
         const float n0 = r0.w, n1 = r1.w;
-        const f3 T = o - mk3(r0.x, r0.y, r0.z);
-        const f3 P = cross(d, e1);
-        const float det = dot(e0, P);
-        const float u = dot(T, P);
-        const f3 Q = cross(T, e0);
-        const float v = dot(d, Q);
-        const float c = dot(e1, Q);
-        const float nT = fabsf(T.x) + fabsf(T.y) + fabsf(T.z);  // >= |T|: the band only has to be conservative
-        // conservative acceptance: every quantity carries a relative error <= K of its magnitude bound
-        const float K = 4e-6f;
-        const float D = fabsf(det);
-        const float sgn = det < 0.f ? -1.f : 1.f;
-        const float eD = K * n0 * n1;
-        const float us = u * sgn, vs = v * sgn, cs = c * sgn;
-        const float eU = K * nT * n1 + eD, eV = K * nT * n0 + eD, eC = K * nT * n0 * n1;
-        bool hit = rayValid && pb + g < p1 && D + eD >= 0.99999e-5f;
-        hit = hit && us >= -eU && us <= D + eU && vs >= -eV && vs <= D + eV;
-        hit = hit && cs > mint * D - eC - mint * eD && cs < maxt * D + eC + maxt * eD;
-        hm |= hit ? (1u << g) : 0u;
+        const f3 T = o0 - mk3(r0.x, r0.y, r0.z);
+        const float nT = fabsf(T.x) + fabsf(T.y) + fabsf(T.z);
+        const float K = 8e-6f;  // twice the per-ray test's band
+        const float eD = K * n0 * n1, eU = K * nT * n1 + eD, eV = K * nT * n0 + eD, eC = K * nT * n0 * n1;
+        const f3 AD = cross(e1, e0), AU = cross(e1, T), AV = cross(T, e0);
+        const float Ct = dot(e1, AV);
+        float Dlo, Dhi, Ulo, Uhi, Vlo, Vhi, UDlo, UDhi, VDlo, VDhi;
+        range(AD, Dlo, Dhi);
+        range(AU, Ulo, Uhi);
+        range(AV, Vlo, Vhi);
+        range(AU - AD, UDlo, UDhi);
+        range(AV - AD, VDlo, VDhi);
+        if (Dlo - eD > 0.f) {
+          // det > 0 for every ray of the tile
+          if (Uhi + eU < 0.f || UDlo - eU - eD > 0.f || Vhi + eV < 0.f || VDlo - eV - eD > 0.f) keep = false;
+          if (Ct + eC < mint * (Dlo - eD) || Ct - eC > maxtAll * (Dhi + eD)) keep = false;
+        } else if (Dhi + eD < 0.f) {
+          if (Ulo - eU > 0.f || UDhi + eU + eD < 0.f || Vlo - eV > 0.f || VDhi + eV + eD < 0.f) keep = false;
+          if (-Ct + eC < mint * (-Dhi - eD) || -Ct - eC > maxtAll * (-Dlo + eD)) keep = false;
+        }
       }
-      // push this lane's hits (0 - 4), then evaluate while most lanes have one pending or a ring could fill
-      for (uint32_t m = hm; m; m &= m - 1u) {
-        hitQ[((qHead + qCount) % QD) * 64u + (uint32_t)lane] = pb + (uint32_t)__ffs(m) - 1u;
-        qCount++;
-      }
-      for (;;) {
-        const unsigned long long pending = __ballot(qCount > 0u);
-        if (!(__popcll(pending) >= 48 || __ballot(qCount > QD - G))) break;
-        if (qCount > 0u) {
-          if (evaluatePlane<B>(a, pa, s, hitQ[qHead * 64u + (uint32_t)lane], (uint32_t)lane, acc, nDiff, nFail)) nEval++;
-          qHead = (qHead + 1u) % QD;
-          qCount--;
+      const unsigned long long km = __ballot(keep);
+      const uint32_t nk = (uint32_t)__popcll(km);
+      __syncthreads();
+      if (keep) s.cull[__popcll(km & ((1ull << lane) - 1ull))] = pmine;
+      __syncthreads();
+      nCand += (unsigned long long)__popcll(validMask) * nk;  // per-ray pierce tests actually made
+      // ---- per-ray pierce test of the survivors, four planes per step (twelve scalar loads and four test chains
+      // in flight)
+      for (uint32_t kb = 0; kb < nk; kb += G) {
+        uint32_t hm = 0;
+        uint32_t pidx[G];
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+          const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.cull[min(kb + g, nk - 1u)]);
+          pidx[g] = p;
+          // wave-uniform record: scalar loads
+          const float4 r0 = pa.test[3 * (size_t)p + 0];
+          const float4 r1 = pa.test[3 * (size_t)p + 1];
+          const float4 r2 = pa.test[3 * (size_t)p + 2];
+          const f3 e0 = mk3(r1.x, r1.y, r1.z), e1 = mk3(r2.x, r2.y, r2.z);
+          const float n0 = r0.w, n1 = r1.w;
+          const f3 T = o - mk3(r0.x, r0.y, r0.z);
+          const f3 P = cross(d, e1);
+          const float det = dot(e0, P);
+          const float u = dot(T, P);
+          const f3 Q = cross(T, e0);
+          const float v = dot(d, Q);
+          const float c = dot(e1, Q);
+          const float nT = fabsf(T.x) + fabsf(T.y) + fabsf(T.z);  // >= |T|: the band only has to be conservative
+          // conservative acceptance: every quantity carries a relative error <= K of its magnitude bound
+          const float K = 4e-6f;
+          const float D = fabsf(det);
+          const float sgn = det < 0.f ? -1.f : 1.f;
+          const float eD = K * n0 * n1;
+          const float us = u * sgn, vs = v * sgn, cs = c * sgn;
+          const float eU = K * nT * n1 + eD, eV = K * nT * n0 + eD, eC = K * nT * n0 * n1;
+          bool hit = rayValid && kb + g < nk && D + eD >= 0.99999e-5f;
+          hit = hit && us >= -eU && us <= D + eU && vs >= -eV && vs <= D + eV;
+          hit = hit && cs > mint * D - eC - mint * eD && cs < maxt * D + eC + maxt * eD;
+          hm |= hit ? (1u << g) : 0u;
+        }
+        // push this lane's hits (0 - 4), then evaluate while most lanes have one pending or a ring could fill
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+          if ((hm >> g) & 1u) {
+            hitQ[((qHead + qCount) % QD) * 64u + (uint32_t)lane] = pidx[g];
+            qCount++;
+          }
+        }
+        for (;;) {
+          const unsigned long long pending = __ballot(qCount > 0u);
+          if (!(__popcll(pending) >= 48 || __ballot(qCount > QD - G))) break;
+          if (qCount > 0u) {
+            if (evaluatePlane<B>(a, pa, s, hitQ[qHead * 64u + (uint32_t)lane], (uint32_t)lane, acc, nDiff, nFail)) nEval++;
+            qHead = (qHead + 1u) % QD;
+            qCount--;
+          }
         }
       }
     }
