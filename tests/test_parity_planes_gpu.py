@@ -109,3 +109,14 @@ def test_planes_identical_shift_empty_and_preconditions():
     with pytest.raises(hip.GvpmError):
         ctx.gather(1, c.nb)
     ctx.close()
+
+
+def test_planes_without_a_common_ray_origin():
+    """The tile-frustum cull needs the tile's rays to share their origin; when they do not (camera edges beyond the
+    first) the kernel tests every plane against every ray.  Jittered origins: same result as the oracle."""
+    c = make_plane_case("cbox_in", 32, 28, 4000)
+    rng = np.random.default_rng(5)
+    rays = c.rays.copy()
+    rays["o"] += rng.uniform(-2e-3, 2e-3, size=rays["o"].shape[:1] + (1, 3)).astype(np.float32)
+    acc, ref, st = device_planes(c, rays=rays)
+    assert st["evaluations"] > 10000
