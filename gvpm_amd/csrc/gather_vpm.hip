@@ -26,9 +26,11 @@ namespace gvpm {
 
 constexpr int VQ = 128;  // hit ring capacity
 
+// The rays are NOT staged in LDS: the 64 camera samples of a workgroup belong to one or two pixels (40 samples per
+// pixel at C1), i.e. to one or two beam sets, so the 5 x 64 bytes of a set are L1-resident broadcast reads -- and 17 KB
+// of LDS a wave held the kernel at 6 waves per CU.
 struct VpmLds {
-  float4 ray4[5][3][64];
-  float gop[5][64];
+  uint32_t set[64];    // beam set of the sample (0xFFFFFFFF: none)
   float acc[27][64];
   uint2 queue[VQ];
   double t[64];        // sampled camera distance (mRec.t)
@@ -40,17 +42,27 @@ struct VpmLds {
   uint32_t edge[64];
 };
 
-__device__ __forceinline__ RayReg loadRayV(const VpmLds &s, int k, int b) {
+__device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s, int k, int b) {
   RayReg r;
-  const float4 q0 = s.ray4[k][0][b], q1 = s.ray4[k][1][b], q2 = s.ray4[k][2][b];
+  const uint32_t set = s.set[b];
+  if (set == 0xFFFFFFFFu) {
+    r.o = r.eye = mk3(0.f);
+    r.d = mk3(0.f, 0.f, 1.f);
+    r.len = 1e-30f;
+    r.pdf = r.jac = r.gop = 0.f;
+    r.valid = false;
+    return r;
+  }
+  const float4 *rp = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5 + k);
+  const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
   r.o = mk3(q0.x, q0.y, q0.z);
   r.len = fabsf(q0.w);
-  r.valid = q0.w >= 0.f;
+  r.valid = GVPM_RAY_VALID(__float_as_uint(q3.y)) != 0;
   r.d = mk3(q1.x, q1.y, q1.z);
   r.pdf = q1.w;
   r.eye = mk3(q2.x, q2.y, q2.z);
   r.jac = q2.w;
-  r.gop = s.gop[k][b];
+  r.gop = q3.x;
   return r;
 }
 
@@ -61,7 +73,7 @@ __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint
   const PhotonCold ph = loadCold(a, pidx);
   const uint32_t bits = ph.bits;
   const f3 pos = ph.pos;
-  const RayReg base = loadRayV(s, 0, b);
+  const RayReg base = loadRayV(a, s, 0, b);
   const uint32_t edge = s.edge[b];
   const uint32_t pix = s.pix[b];
   const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
@@ -88,7 +100,7 @@ __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint
   if (trS < 1e-20f) trS = 0.f;
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
-    const RayReg sh = loadRayV(s, 1 + i, b);
+    const RayReg sh = loadRayV(a, s, 1 + i, b);
     float w = 1.f;
     f3 sflux = mk3(0.f);
     // validShiftDist: valid edge and shiftDistMax >= baseRay.maxt (shift_volume_photon.cpp:546-566)
@@ -165,29 +177,15 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
     pdfSel = sm.pdf_sel;
     if (set >= a.nsets) active = false;
   }
+  s.set[lane] = active ? set : 0xFFFFFFFFu;
   {
-    const int b = lane;
-#pragma unroll 1
-    for (int k = 0; k < 5; ++k) {
-      float4 q0 = make_float4(0, 0, 0, -1e-30f), q1 = make_float4(0, 0, 1, 0), q2 = make_float4(0, 0, 0, 0),
-             q3 = make_float4(0, 0, 0, 0);
-      if (active) {
-        const float4 *rp = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5 + k);
-        q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
-        const bool valid = GVPM_RAY_VALID(__float_as_uint(q3.y)) != 0;
-        const float l = fabsf(q0.w);
-        q0.w = valid ? l : -fmaxf(l, 1e-30f);
-      }
-      s.ray4[k][0][b] = q0; s.ray4[k][1][b] = q1; s.ray4[k][2][b] = q2;
-      s.gop[k][b] = q3.x;
-      if (k == 0) {
-        s.pix[b] = __float_as_uint(q3.w);
-        s.edge[b] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
-      }
-    }
+    float4 q3 = make_float4(0, 0, 0, 0);
+    if (active) q3 = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5)[3];
+    s.pix[lane] = __float_as_uint(q3.w);
+    s.edge[lane] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
   }
   __syncthreads();
-  const RayReg base = loadRayV(s, 0, lane);
+  const RayReg base = loadRayV(a, s, 0, lane);
   active = active && base.valid;
   // HomogeneousMedium::sampleDistance(Ray(o, d, Epsilon, beamDist), EDistanceAlwaysValid, rand),
   // homogeneous.cpp:293-430 (balance strategy, currentMediumSampling = 1)
