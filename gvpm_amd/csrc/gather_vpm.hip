@@ -25,6 +25,15 @@
 namespace gvpm {
 
 constexpr int VQ = 128;  // hit ring capacity
+// A/B probes (scripts/vpm_probe.py): GVPM_VPM_PROBE 1 = no evaluation, 2 = plain LDS adds instead of atomics
+#ifndef GVPM_VPM_PROBE
+#define GVPM_VPM_PROBE 0
+#endif
+#if GVPM_VPM_PROBE == 2
+#define VPM_ADD(p, v) (*(p) += (v))
+#else
+#define VPM_ADD(p, v) atomicAdd((p), (v))
+#endif
 
 // The rays are NOT staged in LDS: the 64 camera samples of a workgroup belong to one or two pixels (40 samples per
 // pixel at C1), i.e. to one or two beam sets, so the 5 x 64 bytes of a set are L1-resident broadcast reads -- and 17 KB
@@ -40,6 +49,9 @@ struct VpmLds {
   float radius[64];
   uint32_t pix[64];
   uint32_t edge[64];
+  float4 qr[64];       // query point and radius of the sample
+  uint32_t segOff[64], segStart[64];  // this row's photon ranges laid end to end: exclusive offsets, first photon
+  uint32_t found[64];  // photons inside the query sphere (M of the SPPM update)
 };
 
 __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s, int k, int b) {
@@ -70,6 +82,9 @@ __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s,
 template <bool FULLVIS>
 __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
                                             uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+#if GVPM_VPM_PROBE == 1
+  return;
+#endif
   const PhotonCold ph = loadCold(a, pidx);
   const uint32_t bits = ph.bits;
   const f3 pos = ph.pos;
@@ -88,9 +103,9 @@ __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint
 
   const f3 photonIn = sigS * ph.flux;
   const f3 baseContrib = base.eye * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * s.trBase[b];
-  atomicAdd(&s.acc[0][b], baseContrib.x * scale);
-  atomicAdd(&s.acc[1][b], baseContrib.y * scale);
-  atomicAdd(&s.acc[2][b], baseContrib.z * scale);
+  VPM_ADD(&s.acc[0][b], baseContrib.x * scale);
+  VPM_ADD(&s.acc[1][b], baseContrib.y * scale);
+  VPM_ADD(&s.acc[2][b], baseContrib.z * scale);
 
   const d3 pD = tod(pos);
   const d3 basePt = tod(base.o) + tod(base.d) * t;  // baseRay(maxt)
@@ -145,13 +160,13 @@ __device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint
     if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
     const float ws = w * scale;
     if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-      atomicAdd(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
-      atomicAdd(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
-      atomicAdd(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+      VPM_ADD(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
+      VPM_ADD(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
+      VPM_ADD(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
     }
-    atomicAdd(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
-    atomicAdd(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
-    atomicAdd(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
+    VPM_ADD(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
+    VPM_ADD(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
+    VPM_ADD(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
   }
 }
 
@@ -237,71 +252,107 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   }
   const int nyr = by1 - by0 + 1, nzr = bz1 - bz0 + 1;
   const int nrows = (bx1 >= bx0 && nyr > 0 && nzr > 0) ? nyr * nzr : 0;
-  int row = 0;
-  uint32_t cur = 0, end = 0;
-  const float r2f = radius * radius;
-  const double r2D = (double)radius * (double)radius;
-  const uint32_t edge = s.edge[lane];
-  uint32_t qHead = 0, qCount = 0;
-  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0, found = 0;
-  unsigned long long nCand = 0;
-
-  for (;;) {
-    // advance to the next non-empty row
-    while (cur >= end && row < nrows) {
-      const int y = by0 + row % nyr, z = bz0 + row / nyr;
+  // The wave walks the cells together.  A lane-per-sample walk runs as long as its busiest lane (the candidate counts
+  // of the samples of a ray differ by orders of magnitude) and reads 64 scattered lines per trip.  Instead, row by
+  // row, the lanes' photon ranges are laid end to end (wave prefix sum), and lane l of a batch takes candidate
+  // j0 + l of that list: it finds the owning sample by a search over the prefix offsets and tests the photon against
+  // that sample's sphere.  Consecutive lanes read consecutive photons and every trip is full.
+  int maxRows = nrows;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxRows = max(maxRows, __shfl_xor(maxRows, o, 64));
+  s.qr[lane] = make_float4(q.x, q.y, q.z, radius);
+  s.found[lane] = 0u;
+  auto rowRange = [&](int r, uint32_t &c, uint32_t &e) {
+    c = e = 0u;
+    if (r < nrows) {
+      const int y = by0 + r % nyr, z = bz0 + r / nyr;
       const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
-      cur = a.cellStart[rb + bx0];
-      end = a.cellStart[rb + bx1 + 1];
-      row++;
+      c = a.cellStart[rb + bx0];
+      e = a.cellStart[rb + bx1 + 1];
     }
-    const bool have = cur < end;
-    if (!__any(have)) break;
-    bool hit = false;
-    uint32_t gi = cur;
-    if (have) {
-      const float4 hp = a.hot[cur];
-      cur++;
-      nCand++;
-      const f3 p = mk3(hp.x, hp.y, hp.z);
-      const f3 dv = p - q;
-      const float d2 = dot(dv, dv);
-      // pointDistSquared < distSquared (kdtree.h:722) decided in fp32 unless within the error band
-      const float E = 3e-7f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
-      const float band = 4.f * radius * E + r2f * 2e-6f;
-      bool inside = d2 < r2f - band;
-      if (!inside && d2 < r2f + band) {
+  };
+  uint32_t qHead = 0, qCount = 0;
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+  unsigned long long nCand = 0;
+  uint32_t rc, re;
+  rowRange(0, rc, re);
+  for (int r = 0; r < maxRows; ++r) {
+    uint32_t nc, ne;
+    rowRange(r + 1, nc, ne);  // in flight while this row is consumed
+    const uint32_t cnt = re - rc;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, (unsigned)o, 64);
+      if (lane >= o) inc += v;
+    }
+    const uint32_t total = __shfl(inc, 63, 64);
+    if (total) {
+      __syncthreads();
+      s.segOff[lane] = inc - cnt;
+      s.segStart[lane] = rc;
+      __syncthreads();
+      for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool have = j < total;
+        bool hit = false;
+        uint32_t gi = 0, owner = 0;
+        if (have) {
+          // the last lane whose offset is <= j (empty ranges share the offset of the range after them)
+#pragma unroll
+          for (int st = 32; st > 0; st >>= 1)
+            if (s.segOff[owner + st] <= j) owner += st;
+          gi = s.segStart[owner] + (j - s.segOff[owner]);
+          const float4 hp = a.hot[gi];
+          const float4 qr = s.qr[owner];
+          nCand++;
+          const f3 p = mk3(hp.x, hp.y, hp.z);
+          const f3 qo = mk3(qr.x, qr.y, qr.z);
+          const float rad = qr.w, r2f = rad * rad;
+          const f3 dv = p - qo;
+          const float d2 = dot(dv, dv);
+          // pointDistSquared < distSquared (kdtree.h:722) decided in fp32 unless within the error band
+          const float E = 3e-7f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z));
+          const float band = 4.f * rad * E + r2f * 2e-6f;
+          bool inside = d2 < r2f - band;
+          if (!inside && d2 < r2f + band) {
 #pragma clang fp contract(off)
-        const double dx = (double)p.x - qD.x, dy = (double)p.y - qD.y, dz = (double)p.z - qD.z;
-        inside = dx * dx + dy * dy + dz * dz < r2D;
-      }
-      if (inside) {
-        found++;
-        const uint32_t bits = __float_as_uint(hp.w);
-        // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
-        const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
-        hit = true;
-        if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
-        if (!((bits >> 6) & 1u)) hit = false;
+            const RayReg bo = loadRayV(a, s, 0, (int)owner);
+            const d3 qd = tod(bo.o) + tod(bo.d) * s.t[owner];
+            const double dx = (double)p.x - qd.x, dy = (double)p.y - qd.y, dz = (double)p.z - qd.z;
+            inside = dx * dx + dy * dy + dz * dz < (double)rad * (double)rad;
+          }
+          if (inside) {
+            atomicAdd(&s.found[owner], 1u);
+            const uint32_t bits = __float_as_uint(hp.w);
+            // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
+            const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edge[owner];
+            hit = true;
+            if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
+            if (!((bits >> 6) & 1u)) hit = false;
+          }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+          if (hit) {
+            const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+            s.queue[(qHead + qCount + off) % VQ] = make_uint2(gi, owner);
+          }
+          qCount += __popcll(m);
+          if (qCount >= 64u) {
+            __syncthreads();
+            const uint2 e = s.queue[(qHead + lane) % VQ];
+            evaluateVpm<FULLVIS>(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
+            nEval++;
+            qHead = (qHead + 64u) % VQ;
+            qCount -= 64u;
+            __syncthreads();
+          }
+        }
       }
     }
-    const unsigned long long m = __ballot(hit);
-    if (m) {
-      if (hit) {
-        const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-        s.queue[(qHead + qCount + off) % VQ] = make_uint2(gi, (uint32_t)lane);
-      }
-      qCount += __popcll(m);
-      if (qCount >= 64u) {
-        __syncthreads();
-        const uint2 e = s.queue[(qHead + lane) % VQ];
-        evaluateVpm<FULLVIS>(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
-        nEval++;
-        qHead = (qHead + 64u) % VQ;
-        qCount -= 64u;
-        __syncthreads();
-      }
-    }
+    rc = nc;
+    re = ne;
   }
   __syncthreads();
   if ((uint32_t)lane < qCount) {
@@ -311,18 +362,36 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   }
   __syncthreads();
   // ---- write out ----
-  for (int idx = lane; idx < 27 * 64; idx += 64) {
-    const int k = idx / 64, bb = idx % 64;
-    if ((uint32_t)bb < ns) {
-      const float v = s.acc[k][bb];
-      if (v != 0.f) {
-        const uint32_t pv = s.pix[bb];
-        const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
-        atomicAdd(&a.iter[p * 27 + k], v);
-      }
+  // The samples of a pixel sit in consecutive lanes (40 per pixel at C1), so their sums are combined in the wave
+  // (segmented suffix sum keyed by the pixel) and the first lane of each run issues the global atomic: per-lane
+  // atomics put up to 64 operations on one address and those serialise in L2.
+  {
+    uint32_t same = 0;  // bit j: lane + 2^j belongs to the same pixel run
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const uint32_t other = __shfl_down(pixv, 1u << j, 64);
+      if (lane + (1 << j) < 64 && other == pixv) same |= 1u << j;
     }
+    const uint32_t prev = __shfl_up(pixv, 1u, 64);
+    const bool head = lane == 0 || prev != pixv;
+    const size_t p = (size_t)(pixv >> 16) * a.cfg.width + (pixv & 0xFFFFu);
+    for (int k = 0; k < 27; ++k) {
+      float v = s.acc[k][lane];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float w = __shfl_down(v, 1u << j, 64);
+        if ((same >> j) & 1u) v += w;
+      }
+      if (head && v != 0.f) atomicAdd(&a.iter[p * 27 + k], v);
+    }
+    float fv = (float)s.found[lane];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float w = __shfl_down(fv, 1u << j, 64);
+      if ((same >> j) & 1u) fv += w;
+    }
+    if (head && fv != 0.f) atomicAdd(&a.mvol[pixIdx], fv);
   }
-  if (found) atomicAdd(&a.mvol[pixIdx], (float)found);
   {
     unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail, ca = nCand;
 #pragma unroll
