@@ -997,11 +997,22 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
   const bool pathSet = a.cfg.path_set != 0;
   const int maxDepth = a.cfg.max_depth;
   unsigned long long nCand = 0;
+  // Blocks of the pair list are reserved RESERVE at a time: atomics on one address retire at ~11 ns each on this
+  // part whatever the number of waves (scripts/probes/atomics_bench.hip), so one atomic per block (~260 k per pass)
+  // bounded the kernel at 3 ms.  What a wave has left over at the end is written as empty blocks of its last tile.
+  constexpr uint32_t RESERVE = 8u;
+  uint32_t resSlot = 0, resLeft = 0, lastSet = 0;
 
+  // the first item of every wave is its own index; the shared counter (one address: ~11 ns per atomic whatever the
+  // number of waves) serves the rest
+  bool firstItem = true;
   for (;;) {
-    uint32_t it = 0;
-    if (lane == 0) it = atomicAdd(queueHead, 1u);
-    it = __shfl(it, 0, 64);
+    uint32_t it = blockIdx.x;
+    if (!firstItem) {
+      if (lane == 0) it = gridDim.x + atomicAdd(queueHead, 1u);
+      it = __shfl(it, 0, 64);
+    }
+    firstItem = false;
     if (it >= nItems) break;
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y;
@@ -1016,9 +1027,15 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
     const int edge = (int)bi.edge;
     uint32_t qHead = 0, qCount = 0;
     auto emit = [&](uint32_t n) {  // n <= 64 pairs of the ring -> one block of 64 in the global list
-      uint32_t slot = 0;
-      if (lane == 0) slot = atomicAdd(pairCount, 64u);
-      slot = __shfl(slot, 0, 64);
+      if (resLeft == 0u) {
+        if (lane == 0) resSlot = atomicAdd(pairCount, 64u * RESERVE);
+        resSlot = __shfl(resSlot, 0, 64);
+        resLeft = RESERVE;
+      }
+      const uint32_t slot = resSlot;
+      resSlot += 64u;
+      resLeft--;
+      lastSet = setBase;
       const uint2 e = (uint32_t)lane < n ? s.outq[(qHead + lane) % QCAP] : make_uint2(0xFFFFFFFFu, 0u);
       if (slot + 64u <= pairCap) {  // past the capacity: counted, not written (host regrows)
         pairs[slot + lane] = e;
@@ -1125,6 +1142,15 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
     if (qCount) emit(qCount);
     __syncthreads();
   }
+  for (; resLeft; --resLeft, resSlot += 64u) {
+    if (resSlot + 64u <= pairCap) {
+      pairs[resSlot + lane] = make_uint2(0xFFFFFFFFu, 0u);
+      if (lane == 0) {
+        blockKey[resSlot / 64u] = lastSet;
+        blockVal[resSlot / 64u] = resSlot / 64u;
+      }
+    }
+  }
   if (lane == 0 && nCand) atomicAdd(&a.stats[1], nCand);
 }
 
@@ -1169,10 +1195,16 @@ __global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams
     }
     __syncthreads();
   };
+  // the first item of every wave is its own index; the shared counter (one address: ~11 ns per atomic whatever the
+  // number of waves) serves the rest
+  bool firstItem = true;
   for (;;) {
-    uint32_t run = 0;
-    if (lane == 0) run = atomicAdd(queueHead, 1u);
-    run = __shfl(run, 0, 64);
+    uint32_t run = blockIdx.x;
+    if (!firstItem) {
+      if (lane == 0) run = gridDim.x + atomicAdd(queueHead, 1u);
+      run = __shfl(run, 0, 64);
+    }
+    firstItem = false;
     const uint32_t b0 = run * RUN;
     if (b0 >= nBlocks) break;
     const uint32_t b1 = min(nBlocks, b0 + RUN);

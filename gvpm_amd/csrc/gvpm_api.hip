@@ -1015,6 +1015,11 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
   lap("syncB");
   const uint32_t blocks = h->pinCtl[0];
+  if (getenv("GVPM_TRACE_PLAN")) {
+    uint32_t q[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[plan] items %u staged blocks %u tiles %u sets %u\n", q[0], blocks, h->bs->ntiles, h->nsets);
+  }
   if (rebuilt) {
     h->nearOverflow = h->cfg.visibility_as_written && h->pinCtl[1] != 0;
     // what the extension lists asked for (the cursor keeps counting past the capacity): sizes the next build's
