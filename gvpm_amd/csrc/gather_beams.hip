@@ -504,9 +504,9 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
   if (!kRec.valid) return false;
   const d3 eyeB = tod(base.eye);
   const d3 baseContrib = mkd(eyeB.x * kRec.contrib.x, eyeB.y * kRec.contrib.y, eyeB.z * kRec.contrib.z) * kRec.weightKernel;
-  atomicAdd(&s.acc[0][bIdx], (float)(baseContrib.x * rr));
-  atomicAdd(&s.acc[1][bIdx], (float)(baseContrib.y * rr));
-  atomicAdd(&s.acc[2][bIdx], (float)(baseContrib.z * rr));
+  atomicAdd(&s.acc[0][bIdx], (double)(float)(baseContrib.x * rr));
+  atomicAdd(&s.acc[1][bIdx], (double)(float)(baseContrib.y * rr));
+  atomicAdd(&s.acc[2][bIdx], (double)(float)(baseContrib.z * rr));
   const uint32_t st = GVPM_PF_SHIFT_TYPE(b.flags);
   if (a.cfg.debug_shift != GVPM_SHIFT_ALL && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
     const int cur = st == 1u ? GVPM_SHIFT_DIFFUSE : st == 2u ? GVPM_SHIFT_MEDIUM : st == 3u ? GVPM_SHIFT_MANIFOLD : GVPM_SHIFT_INVALID;
@@ -578,13 +578,13 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
     const double ws = w * rr;
     if (sflux.x != 0 || sflux.y != 0 || sflux.z != 0) {
       const double wk = ws * kRec.weightKernel;
-      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (float)(sflux.x * wk));
-      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (float)(sflux.y * wk));
-      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (float)(sflux.z * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (double)(float)(sflux.x * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (double)(float)(sflux.y * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (double)(float)(sflux.z * wk));
     }
-    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (float)(baseContrib.x * ws));
-    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (float)(baseContrib.y * ws));
-    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (float)(baseContrib.z * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (double)(float)(baseContrib.x * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (double)(float)(baseContrib.y * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (double)(float)(baseContrib.z * ws));
   }
   return true;
 }
@@ -839,9 +839,9 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
   if (!(k.contrib.x == k.contrib.x)) return false;
 
   const f3 baseContrib = base.eye * k.contrib * k.weightKernel;
-  atomicAdd(&s.acc[0][bIdx], baseContrib.x * rr);
-  atomicAdd(&s.acc[1][bIdx], baseContrib.y * rr);
-  atomicAdd(&s.acc[2][bIdx], baseContrib.z * rr);
+  atomicAdd(&s.acc[0][bIdx], (double)(baseContrib.x * rr));
+  atomicAdd(&s.acc[1][bIdx], (double)(baseContrib.y * rr));
+  atomicAdd(&s.acc[2][bIdx], (double)(baseContrib.z * rr));
   const uint32_t st = GVPM_PF_SHIFT_TYPE(b.flags);
   if (a.cfg.debug_shift != GVPM_SHIFT_ALL && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
     const int cur = st == 1u ? GVPM_SHIFT_DIFFUSE : st == 2u ? GVPM_SHIFT_MEDIUM : st == 3u ? GVPM_SHIFT_MANIFOLD : GVPM_SHIFT_INVALID;
@@ -949,13 +949,13 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
     const float ws = w * rr;
     if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
       const float wk = ws * k.weightKernel;
-      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], sflux.x * wk);
-      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], sflux.y * wk);
-      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], sflux.z * wk);
+      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (double)(sflux.x * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (double)(sflux.y * wk));
+      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (double)(sflux.z * wk));
     }
-    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], baseContrib.x * ws);
-    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], baseContrib.y * ws);
-    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], baseContrib.z * ws);
+    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (double)(baseContrib.x * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (double)(baseContrib.y * ws));
+    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (double)(baseContrib.z * ws));
   }
   return true;
 }
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams
       for (int idx = lane; idx < 27 * B; idx += 64) {
         const int k = idx / B, bb = idx % B;
         if ((uint32_t)bb < curNb) {
-          const float v = s.acc[k][bb];
+          const float v = (float)s.acc[k][bb];
           if (v != 0.f) {
             const uint32_t pv = s.pix[bb];
             const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams
         curBase = setBase;
         curNb = min((uint32_t)B, a.nsets - setBase);
         loadTileRays<B>(a, s, setBase, curNb, lane);
-        for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+        for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
         __syncthreads();
       }
       const uint2 e = pairs[(size_t)sortedBlock[bi] * 64u + lane];

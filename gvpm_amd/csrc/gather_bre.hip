@@ -146,7 +146,7 @@ constexpr int QD = GVPM_QD;  // per-lane reconnection queue depth (a step adds a
 constexpr uint32_t EVAL_LDS_TRIS = 64;  // occluders staged in the evaluation kernel's LDS when the scene has no more
 
 template <int B> struct EvalLds : RayTile<B> {
-  float acc[27][B];
+  double acc[27][B];  // double: ds_add_f64 runs ~25x the rate of ds_add_f32 on gfx950 (scripts/probes/lds_atomics_bench.hip)
   uint32_t boff[B + 1];      // prefix offsets of the item's per-beam lists
   // per-lane queues, [slot][lane]: photon and beam | shift << 8.  t' and pdfCam are recomputed by the reconnection
   // (a dozen fp64 operations) rather than queued: 12 bytes less per entry is 6 KB of LDS per wave, the difference
@@ -353,12 +353,12 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
       acc.v[15 + 3 * ii + 2] += m * wb.z;
     }
   } else {
-    atomicAdd(&s.acc[3 + 3 * i + 0][b], sf.x);
-    atomicAdd(&s.acc[3 + 3 * i + 1][b], sf.y);
-    atomicAdd(&s.acc[3 + 3 * i + 2][b], sf.z);
-    atomicAdd(&s.acc[15 + 3 * i + 0][b], wb.x);
-    atomicAdd(&s.acc[15 + 3 * i + 1][b], wb.y);
-    atomicAdd(&s.acc[15 + 3 * i + 2][b], wb.z);
+    atomicAdd(&s.acc[3 + 3 * i + 0][b], (double)(sf.x));
+    atomicAdd(&s.acc[3 + 3 * i + 1][b], (double)(sf.y));
+    atomicAdd(&s.acc[3 + 3 * i + 2][b], (double)(sf.z));
+    atomicAdd(&s.acc[15 + 3 * i + 0][b], (double)(wb.x));
+    atomicAdd(&s.acc[15 + 3 * i + 1][b], (double)(wb.y));
+    atomicAdd(&s.acc[15 + 3 * i + 2][b], (double)(wb.z));
   }
 }
 
@@ -366,7 +366,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
 template <int B> __device__ __forceinline__ void flushAcc(EvalLds<B> &s, Acc27 &acc, uint32_t beam) {
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    atomicAdd(&s.acc[k][beam], acc.v[k]);
+    atomicAdd(&s.acc[k][beam], (double)(acc.v[k]));
     acc.v[k] = 0.f;
   }
 }
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
     if (lane < B) s.boff[lane + 1] = incl;
     if (lane == 0) s.boff[0] = 0u;
     loadTileRays<B>(a, s, setBase, nb, lane);
-    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
     for (int idx = lane; idx < 4 * B; idx += 64) {
       const int i = idx / B, bb = idx % B;
       const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
     for (int idx = lane; idx < 27 * B; idx += 64) {
       const int k = idx / B, bb = idx % B;
       if ((uint32_t)bb < nb) {
-        const float v = s.acc[k][bb];
+        const float v = (float)s.acc[k][bb];
         if (v != 0.f) {
           const uint32_t pv = s.pix[bb];
           const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);

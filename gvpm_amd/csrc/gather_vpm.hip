@@ -30,9 +30,9 @@ constexpr int VQ = 128;  // hit ring capacity
 #define GVPM_VPM_PROBE 0
 #endif
 #if GVPM_VPM_PROBE == 2
-#define VPM_ADD(p, v) (*(p) += (v))
+#define VPM_ADD(p, v) (*(p) += (double)(v))
 #else
-#define VPM_ADD(p, v) atomicAdd((p), (v))
+#define VPM_ADD(p, v) atomicAdd((p), (double)(v))
 #endif
 
 // The rays are NOT staged in LDS: the 64 camera samples of a workgroup belong to one or two pixels (40 samples per
@@ -40,7 +40,7 @@ constexpr int VQ = 128;  // hit ring capacity
 // of LDS a wave held the kernel at 6 waves per CU.
 struct VpmLds {
   uint32_t set[64];    // beam set of the sample (0xFFFFFFFF: none)
-  float acc[27][64];
+  double acc[27][64];  // double: ds_add_f64 runs ~25x the rate of ds_add_f32 on gfx950 (scripts/probes/lds_atomics_bench.hip)
   uint2 queue[VQ];
   double t[64];        // sampled camera distance (mRec.t)
   float pdfBase[64];   // pdfBaseRay() = mRec.pdfSuccess * pdfSel
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   const float norm = 1.f / (float)a.cfg.nb_camera_samples;
   const float eps = a.cfg.epsilon;
 
-  for (int idx = lane; idx < 27 * 64; idx += 64) (&s.acc[0][0])[idx] = 0.f;
+  for (int idx = lane; idx < 27 * 64; idx += 64) (&s.acc[0][0])[idx] = 0.0;
 
   // ---- this lane's sample: rays -> LDS, distance sampling ----
   bool active = (uint32_t)lane < ns;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
     const bool head = lane == 0 || prev != pixv;
     const size_t p = (size_t)(pixv >> 16) * a.cfg.width + (pixv & 0xFFFFu);
     for (int k = 0; k < 27; ++k) {
-      float v = s.acc[k][lane];
+      float v = (float)s.acc[k][lane];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const float w = __shfl_down(v, 1u << j, 64);

@@ -24,7 +24,7 @@ template <int B> struct RayTile {
 };
 
 template <int B> struct TileLds : RayTile<B> {
-  float acc[27][B];
+  double acc[27][B];  // double: ds_add_f64 runs ~25x the rate of ds_add_f32 on gfx950 (scripts/probes/lds_atomics_bench.hip)
   float4 stage[STAGE];
   uint32_t stageIdx[STAGE];
   uint2 queue[QCAP];
