@@ -219,6 +219,7 @@ struct gvpm_context {
   int setIdx = 0;
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
   bool beamsExact = false;        // G-Beams: the literal fp64 evaluation instead of the local-frame fp32 one
+  size_t beamPairsInit = (size_t)16 << 20;  // G-Beams: first capacity of the pair list (GVPM_BEAM_PAIRS_INIT; tests shrink it)
   bool pipeline = true;           // GVPM_PIPELINE=0: everything on the gather stream (isolated kernel timings)
   gvpm_params cfg;
   gvpm_medium medium;
@@ -436,6 +437,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_STREAM")) h->travStream = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BEAM_PAIRS_INIT")) {
+    const long long v = atoll(e);
+    if (v >= 64 && v <= ((long long)1 << 31)) h->beamPairsInit = (size_t)v;
+  }
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -1210,7 +1215,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   // sub-beams x rays per slab box, ~100x the survivors): it starts at 16 M pairs and, when the traversal reports
   // more than fit, is regrown to what it counted and the traversal repeated (deterministic, first iterations only).
   // queueCtl: [0] items, [1] item queue head, [2] pairs (multiple of 64), [3] block queue head
-  if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure((size_t)16 << 20));
+  if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure(h->beamPairsInit));
   uint32_t npairs = 0;
   for (int attempt = 0;; ++attempt) {
     const uint32_t cap = (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u);

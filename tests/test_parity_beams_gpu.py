@@ -82,3 +82,13 @@ def test_beams_fine_image_null_shifts_and_empty():
     c2.end_n = c2.end_n[:0]
     acc, ref, st = device_beams(c2)
     assert st["evaluations"] == 0 and not acc.any()
+
+
+def test_beams_pair_list_regrows(monkeypatch):
+    # a pair list far too small for the first pass: the traversal only counts, the host regrows the list to the count
+    # and repeats the pass (gvpm_api.hip gatherBeams); blocks are reserved eight at a time, so the count includes the
+    # empty blocks waves had left over
+    monkeypatch.setenv("GVPM_BEAM_PAIRS_INIT", "1024")
+    c = make_beam_case("cbox", 32, 28, 12000, 2.5)
+    acc, ref, st = device_beams(c, iters=2)
+    assert st["evaluations"] > 20000
