@@ -11,11 +11,11 @@
 // BRE kernel (shift_device.h).
 //
 // One wave handles 64 consecutive camera samples (the host emits the nbCameraSamples samples of a
-// pixel consecutively, so a wave covers 1-2 pixels and its five-ray beam sets stay L1/LDS hot).
-// Every lane walks the <= 3x3x3 grid cells its query sphere touches, one candidate photon per
-// loop trip; hits are compacted (ballot + popcount) into an LDS ring and evaluated 64 at a time,
-// exactly like the BRE kernel.  The radius is per pixel (gp.scaleVol), the grid cell is the
-// largest radius of the iteration.
+// pixel consecutively, so a wave covers 1-2 pixels and its five-ray beam sets stay L1 hot).
+// The wave walks the <= 3x3x3 grid cells of its 64 query spheres together (the lanes' photon ranges
+// laid end to end, one candidate per lane and trip); hits are compacted (ballot + popcount) into an
+// LDS ring and evaluated 64 at a time, exactly like the BRE kernel.  The radius is per pixel
+// (gp.scaleVol), the grid cell is the largest radius of the iteration.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
