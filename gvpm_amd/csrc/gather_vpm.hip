@@ -25,6 +25,7 @@
 namespace gvpm {
 
 constexpr int VQ = 128;  // hit ring capacity
+constexpr int VRQ = 128; // reconnection ring: 63 left over + the 64 one shift of a batch can add
 // A/B probes (scripts/vpm_probe.py): GVPM_VPM_PROBE 1 = no evaluation, 2 = plain LDS adds instead of atomics
 #ifndef GVPM_VPM_PROBE
 #define GVPM_VPM_PROBE 0
@@ -52,6 +53,7 @@ struct VpmLds {
   float4 qr[64];       // query point and radius of the sample
   uint32_t segOff[64], segStart[64];  // this row's photon ranges laid end to end: exclusive offsets, first photon
   uint32_t found[64];  // photons inside the query sphere (M of the SPPM update)
+  uint2 rq[VRQ];       // queued reconnections {photon, sample | shift << 8}
 };
 
 __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s, int k, int b) {
@@ -78,96 +80,136 @@ __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s,
   return r;
 }
 
-// One evaluation: VolumeGradientPositionQuery::operator() after the filters.
-template <bool FULLVIS>
-__device__ __forceinline__ void evaluateVpm(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
-                                            uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
-#if GVPM_VPM_PROBE == 1
-  return;
-#endif
-  const PhotonCold ph = loadCold(a, pidx);
-  const uint32_t bits = ph.bits;
-  const f3 pos = ph.pos;
-  const RayReg base = loadRayV(a, s, 0, b);
-  const uint32_t edge = s.edge[b];
+// What both phases of an evaluation need of the (photon, sample) pair.
+struct VpmPair {
+  PhotonCold ph;
+  RayReg base;
+  f3 photonIn, baseContrib, rel;
+  d3 pD, basePt;
+  double t;
+  float tf, r2, pdfBase, pdfSel, scale, trS;
+  uint32_t edge;
+  int px, py;
+};
+
+__device__ __forceinline__ VpmPair vpmPair(const GatherArgs &a, const VpmLds &s, uint32_t pidx, uint32_t b, float norm) {
+  VpmPair v;
+  v.ph = loadCold(a, pidx);
+  v.base = loadRayV(a, s, 0, b);
+  v.edge = s.edge[b];
   const uint32_t pix = s.pix[b];
-  const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
-  const float r = s.radius[b], r2 = r * r;
-  const double t = s.t[b];
-  const float tf = (float)t;
-  const float pdfBase = s.pdfBase[b], pdfSel = s.pdfSel[b];
+  v.px = (int)(pix & 0xFFFFu);
+  v.py = (int)(pix >> 16);
+  const float r = s.radius[b];
+  v.r2 = r * r;
+  v.t = s.t[b];
+  v.tf = (float)v.t;
+  v.pdfBase = s.pdfBase[b];
+  v.pdfSel = s.pdfSel[b];
   const float sigT = a.med.sigmaT[0];
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
-  const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r2 * r;
-  const float scale = norm / (kernelVol * pdfBase);
-
-  const f3 photonIn = sigS * ph.flux;
-  const f3 baseContrib = base.eye * (photonIn * phaseEval(a.med.g, ph.wi, -base.d)) * s.trBase[b];
-  VPM_ADD(&s.acc[0][b], baseContrib.x * scale);
-  VPM_ADD(&s.acc[1][b], baseContrib.y * scale);
-  VPM_ADD(&s.acc[2][b], baseContrib.z * scale);
-
-  const d3 pD = tod(pos);
-  const d3 basePt = tod(base.o) + tod(base.d) * t;  // baseRay(maxt)
-  const f3 rel = tof(pD - basePt);
+  const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * v.r2 * r;
+  v.scale = norm / (kernelVol * v.pdfBase);
+  v.photonIn = sigS * v.ph.flux;
+  v.baseContrib = v.base.eye * (v.photonIn * phaseEval(a.med.g, v.ph.wi, -v.base.d)) * s.trBase[b];
+  v.pD = tod(v.ph.pos);
+  v.basePt = tod(v.base.o) + tod(v.base.d) * v.t;  // baseRay(maxt)
+  v.rel = tof(v.pD - v.basePt);
   // shiftMRec: Medium::eval(shiftRay, EDistanceAlwaysValid) with mRec.t = t: Tr = exp(-sigma_t t)
-  float trS = __expf(-sigT * tf);
-  if (trS < 1e-20f) trS = 0.f;
+  v.trS = __expf(-sigT * v.tf);
+  if (v.trS < 1e-20f) v.trS = 0.f;
+  return v;
+}
+
+__device__ __forceinline__ void vpmAddShift(VpmLds &s, uint32_t b, int i, const f3 &sflux, const f3 &baseContrib, float w,
+                                            float scale, int px, int py, const GatherArgs &a) {
+  if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
+  const float ws = w * scale;
+  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+    VPM_ADD(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
+    VPM_ADD(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
+    VPM_ADD(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+  }
+  VPM_ADD(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
+  VPM_ADD(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
+  VPM_ADD(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
+}
+
+// Phase 1 of one evaluation (VolumeGradientPositionQuery::operator() after the filters): the base contribution, and
+// of each of the four shifts everything but the reconnection -- the null shift, the failed ones.  Returns the mask of
+// the shifts that need shiftPhotonDiffuse; those are queued and run densely in phase 2 (87 % of the shifts at C1 are
+// null shifts, but a batch that evaluates in one pass pays for the reconnection code of the few lanes that take it).
+__device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
+                                              uint32_t &nNull, uint32_t &nFail) {
+#if GVPM_VPM_PROBE == 1
+  return 0u;
+#endif
+  const VpmPair v = vpmPair(a, s, pidx, b, norm);
+  VPM_ADD(&s.acc[0][b], v.baseContrib.x * v.scale);
+  VPM_ADD(&s.acc[1][b], v.baseContrib.y * v.scale);
+  VPM_ADD(&s.acc[2][b], v.baseContrib.z * v.scale);
+  const float sigT = a.med.sigmaT[0];
+  uint32_t qMask = 0u;
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
     const RayReg sh = loadRayV(a, s, 1 + i, b);
     float w = 1.f;
     f3 sflux = mk3(0.f);
     // validShiftDist: valid edge and shiftDistMax >= baseRay.maxt (shift_volume_photon.cpp:546-566)
-    if (sh.valid && sh.len >= tf) {
-      // pdfShiftRay = shiftMRec.pdfSuccess * pdfSel, normalised over [Epsilon, shiftDistMax]
-      const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
-      const float pdfShift = (sigT / normS) * __expf(-sigT * tf) * pdfSel;
-      const f3 trShift = mk3(trS);
-      const d3 zP = tod(sh.o) + tod(sh.d) * t;
-      const f3 y = tof(pD - zP);
-      bool alreadyShifted = false;
-      if (a.cfg.use_shift_null && dot(y, y) < r2) {
+    if (sh.valid && sh.len >= v.tf) {
+      const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
+      const f3 y = tof(v.pD - zP);
+      if (a.cfg.use_shift_null && dot(y, y) < v.r2) {
         // shiftNull, shift_volume_photon.cpp:119-158
-        alreadyShifted = true;
-        sflux = trShift * (photonIn * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
+        // pdfShiftRay = shiftMRec.pdfSuccess * pdfSel, normalised over [Epsilon, shiftDistMax]
+        const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
+        const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
+        sflux = mk3(v.trS) * (v.photonIn * phaseEval(a.med.g, v.ph.wi, -sh.d)) * sh.eye;
         w = 0.5f;
         if (a.cfg.use_mis) {
-          if (pdfShift == 0.f || pdfBase == 0.f) w = 1.f;
-          else w = 1.f / (1.f + sensorMIS(sh, base, edge) * pdfShift / pdfBase);
+          if (pdfShift == 0.f || v.pdfBase == 0.f) w = 1.f;
+          else w = 1.f / (1.f + sensorMIS(sh, v.base, v.edge) * pdfShift / v.pdfBase);
         }
         nNull++;
-      }
-      if (!alreadyShifted) {
-        // getShiftPos (coherent = false), shift_volume_photon.cpp:858-896
-        f3 offRel = rel;
-        if (a.cfg.use_shift_null) {
-          const f3 dS = tof(zP - basePt);
-          const f3 bo = dS + offRel;
-          if (dot(bo, bo) < r2) offRel = offRel + dS * (-2.f * dot(dS, offRel) / dot(dS, dS));
+      } else if (a.cfg.debug_shift != GVPM_SHIFT_NULL) {
+        const uint32_t st = GVPM_PF_SHIFT_TYPE(v.ph.bits);
+        if (st == 1u || st == 2u) {
+          qMask |= 1u << i;
+          continue;  // phase 2 adds this shift's terms
         }
-        if (a.cfg.debug_shift != GVPM_SHIFT_NULL) {
-          const uint32_t st = GVPM_PF_SHIFT_TYPE(bits);
-          bool ok = false;
-          if (st == 1u || st == 2u) {
-            const f3 dProjU = (tof(zP) - ph.parentPos) + offRel;
-            w = shiftDiffuse<FULLVIS>(a, ph, bits, dProjU, sh, base, edge, trShift, pdfBase, pdfShift, sflux, ok);
-          }
-          if (ok) nDiff++; else nFail++;
-        }
+        nFail++;
       }
     }
-    if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
-    const float ws = w * scale;
-    if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-      VPM_ADD(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
-      VPM_ADD(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
-      VPM_ADD(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
-    }
-    VPM_ADD(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
-    VPM_ADD(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
-    VPM_ADD(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
+    vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
   }
+  return qMask;
+}
+
+// Phase 2: the reconnection of shift i (getShiftPos with coherent = false, shift_volume_photon.cpp:858-896, then
+// shiftPhotonDiffuse) for one queued (photon, sample, shift).
+template <bool FULLVIS>
+__device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t meta, float norm,
+                                          uint32_t &nDiff, uint32_t &nFail) {
+  const uint32_t b = meta & 0xFFu;
+  const int i = (int)(meta >> 8);
+  const VpmPair v = vpmPair(a, s, pidx, b, norm);
+  const RayReg sh = loadRayV(a, s, 1 + i, b);
+  const float sigT = a.med.sigmaT[0];
+  const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
+  const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
+  const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
+  f3 offRel = v.rel;
+  if (a.cfg.use_shift_null) {
+    const f3 dS = tof(zP - v.basePt);
+    const f3 bo = dS + offRel;
+    if (dot(bo, bo) < v.r2) offRel = offRel + dS * (-2.f * dot(dS, offRel) / dot(dS, dS));
+  }
+  const f3 dProjU = (tof(zP) - v.ph.parentPos) + offRel;
+  bool ok = false;
+  f3 sflux = mk3(0.f);
+  const float w = shiftDiffuse<FULLVIS>(a, v.ph, v.ph.bits, dProjU, sh, v.base, v.edge, mk3(v.trS), v.pdfBase, pdfShift, sflux, ok);
+  if (ok) nDiff++; else nFail++;
+  vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
 }
 
 template <bool FULLVIS>
@@ -271,9 +313,39 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
       e = a.cellStart[rb + bx1 + 1];
     }
   };
-  uint32_t qHead = 0, qCount = 0;
+  uint32_t qHead = 0, qCount = 0, rqHead = 0, rqCount = 0;
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   unsigned long long nCand = 0;
+  auto drain = [&](uint32_t n) {  // phase 2 for the first n <= 64 queued reconnections
+    __syncthreads();
+    if ((uint32_t)lane < n) {
+      const uint2 e = s.rq[(rqHead + lane) % VRQ];
+      vpmPhase2<FULLVIS>(a, s, e.x, e.y, norm, nDiff, nFail);
+    }
+    rqHead = (rqHead + n) % VRQ;
+    rqCount -= n;
+    __syncthreads();
+  };
+  auto evalBatch = [&](bool valid, uint2 e) {  // phase 1 for one (photon, sample) pair per lane
+    uint32_t qMask = 0u;
+    if (valid) {
+      qMask = vpmPhase1(a, s, e.x, e.y, norm, nNull, nFail);
+      nEval++;
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < 4u; ++i) {
+      const bool want = (qMask >> i) & 1u;
+      const unsigned long long m = __ballot(want);
+      if (m) {
+        if (want) {
+          const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+          s.rq[(rqHead + rqCount + off) % VRQ] = make_uint2(e.x, e.y | (i << 8));
+        }
+        rqCount += __popcll(m);
+        if (rqCount >= 64u) drain(64u);
+      }
+    }
+  };
   uint32_t rc, re;
   rowRange(0, rc, re);
   for (int r = 0; r < maxRows; ++r) {
@@ -341,9 +413,7 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
           qCount += __popcll(m);
           if (qCount >= 64u) {
             __syncthreads();
-            const uint2 e = s.queue[(qHead + lane) % VQ];
-            evaluateVpm<FULLVIS>(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
-            nEval++;
+            evalBatch(true, s.queue[(qHead + lane) % VQ]);
             qHead = (qHead + 64u) % VQ;
             qCount -= 64u;
             __syncthreads();
@@ -355,11 +425,8 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
     re = ne;
   }
   __syncthreads();
-  if ((uint32_t)lane < qCount) {
-    const uint2 e = s.queue[(qHead + lane) % VQ];
-    evaluateVpm<FULLVIS>(a, s, e.x, e.y, norm, nNull, nDiff, nFail);
-    nEval++;
-  }
+  if (qCount) evalBatch((uint32_t)lane < qCount, s.queue[(qHead + lane) % VQ]);
+  if (rqCount) drain(rqCount);
   __syncthreads();
   // ---- write out ----
   // The samples of a pixel sit in consecutive lanes (40 per pixel at C1), so their sums are combined in the wave
