@@ -74,7 +74,14 @@ struct GatherArgs {
   // outputs
   float *iter;               // P * 27: this iteration's un-normalised sums (G-BRE: the running SUM over iterations)
   float iterScale;           // G-BRE: 1 / nb_paths of this iteration, applied when a partial sum is added
-  unsigned long long *stats; // 8 counters (gvpm_stats order)
+  unsigned long long *stats; // GVPM_STAT_ROWS rows of 8 counters (gvpm_stats order), summed on read
 };
+
+// Counter rows: a workgroup adds into row blockIdx % GVPM_STAT_ROWS.  One shared row would put every workgroup's
+// atomics on one cache line, and atomics on one address retire at ~11 ns each (41 k workgroups of G-VPM: ~1 ms).
+#define GVPM_STAT_ROWS 8192
+__device__ __forceinline__ unsigned long long *statRow(const GatherArgs &a) {
+  return a.stats + 8 * (size_t)(blockIdx.x % GVPM_STAT_ROWS);
+}
 
 }  // namespace gvpm

@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
       }
     }
   }
-  if (lane == 0 && nCand) atomicAdd(&a.stats[1], nCand);
+  if (lane == 0 && nCand) atomicAdd(&statRow(a)[1], nCand);
 }
 
 // ---- evaluation: one pair per lane, blocks of 64 pairs of one tile --------------------------------------------
@@ -1239,10 +1239,10 @@ __global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams
       fa += __shfl_xor(fa, o, 64);
     }
     if (lane == 0 && ev) {
-      atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[2], nu);
-      atomicAdd(&a.stats[3], di);
-      atomicAdd(&a.stats[4], fa);
+      atomicAdd(&statRow(a)[0], ev);
+      atomicAdd(&statRow(a)[2], nu);
+      atomicAdd(&statRow(a)[3], di);
+      atomicAdd(&statRow(a)[4], fa);
     }
   }
 }

@@ -378,10 +378,10 @@ __global__ __launch_bounds__(64, 2) void gather_planes_kernel(GatherArgs a, Plan
       fa += __shfl_xor(fa, off, 64);
     }
     if (lane == 0 && (ev | nCand)) {
-      atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[1], nCand);
-      atomicAdd(&a.stats[3], di);
-      atomicAdd(&a.stats[4], fa);
+      atomicAdd(&statRow(a)[0], ev);
+      atomicAdd(&statRow(a)[1], nCand);
+      atomicAdd(&statRow(a)[3], di);
+      atomicAdd(&statRow(a)[4], fa);
     }
   }
 }

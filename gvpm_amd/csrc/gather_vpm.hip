@@ -469,12 +469,12 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
       fa += __shfl_xor(fa, o, 64);
       ca += __shfl_xor(ca, o, 64);
     }
-    if (lane == 0 && (ev | ca)) {
-      atomicAdd(&a.stats[0], ev);
-      atomicAdd(&a.stats[1], ca);
-      atomicAdd(&a.stats[2], nu);
-      atomicAdd(&a.stats[3], di);
-      atomicAdd(&a.stats[4], fa);
+    if (GVPM_VPM_PROBE != 3 && lane == 0 && (ev | ca)) {
+      atomicAdd(&statRow(a)[0], ev);
+      atomicAdd(&statRow(a)[1], ca);
+      atomicAdd(&statRow(a)[2], nu);
+      atomicAdd(&statRow(a)[3], di);
+      atomicAdd(&statRow(a)[4], fa);
     }
   }
 }

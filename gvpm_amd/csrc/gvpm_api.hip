@@ -152,8 +152,7 @@ RcclApi g_rccl;
 }  // namespace
 
 #define GVPM_PHASES 3
-// counters: one row of 8 per persistent wave (plain adds, no same-address atomics at kernel end), summed on read
-#define GVPM_STAT_ROWS 8192
+// counters: GVPM_STAT_ROWS rows of 8 (device_types.h), one per persistent wave / a few workgroups each, summed on read
 
 // Everything a gather reads that is rebuilt per photon set / beam set.  Two of them: G-BRE builds
 // step N+1 (grid, sorts, planner) on a second stream while the evaluation kernel of step N runs.
@@ -1236,7 +1235,8 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, h->beamPairs.ensure((size_t)npairs + (npairs >> 2) + 64));
     HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 1, 0, 2 * sizeof(uint32_t), h->stream));
     // the candidate count of the discarded pass
-    HIP_TRY(h, hipMemsetAsync(a.stats + 1, 0, sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemset2DAsync(a.stats + 1, 8 * sizeof(unsigned long long), 0, sizeof(unsigned long long), GVPM_STAT_ROWS,
+                                h->stream));
   }
   // blocks of 64 pairs, sorted by tile: the evaluation loads a tile's rays once per run of its blocks
   const uint32_t nBlocks = npairs / 64u;
