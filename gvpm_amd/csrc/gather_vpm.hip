@@ -433,14 +433,17 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   // (segmented suffix sum keyed by the pixel) and the first lane of each run issues the global atomic: per-lane
   // atomics put up to 64 operations on one address and those serialise in L2.
   {
-    uint32_t same = 0;  // bit j: lane + 2^j belongs to the same pixel run
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const uint32_t other = __shfl_down(pixv, 1u << j, 64);
-      if (lane + (1 << j) < 64 && other == pixv) same |= 1u << j;
-    }
+    // A run = consecutive lanes of one pixel.  The C ABI does not promise that a pixel's samples are adjacent, so a
+    // pixel may come back later in the wave: that is another run with its own atomic, never joined across the gap.
     const uint32_t prev = __shfl_up(pixv, 1u, 64);
     const bool head = lane == 0 || prev != pixv;
+    const unsigned long long heads = __ballot(head);
+    uint32_t same = 0;  // bit j: no run starts in lanes lane+1 .. lane+2^j, i.e. lane + 2^j is in this lane's run
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int o = 1 << j;
+      if (lane + o < 64 && (((heads >> (lane + 1)) & ((1ull << o) - 1ull)) == 0ull)) same |= 1u << j;
+    }
     const size_t p = (size_t)(pixv >> 16) * a.cfg.width + (pixv & 0xFFFFu);
     for (int k = 0; k < 27; ++k) {
       float v = (float)s.acc[k][lane];

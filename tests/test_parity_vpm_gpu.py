@@ -84,3 +84,33 @@ def test_vpm_paper_radius_and_empty_inputs():
         ctx.gather(1, 10)   # samples not uploaded
     assert e.value.code == abi.GVPM_ERR_STATE
     ctx.close()
+
+
+def test_vpm_sample_orderings():
+    # The kernel combines the sums of the samples of one pixel inside a wave (runs of consecutive lanes) before the
+    # global atomics: one sample per pixel (runs of length 1), a shuffled order (a pixel's samples in many runs and
+    # waves) and samples naming a beam set that does not exist (skipped) must all give the per-sample sums.
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=1)
+    device_vpm(c)
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=6)
+    rng = np.random.default_rng(7)
+    c.samples = c.samples[rng.permutation(len(c.samples))]
+    device_vpm(c)
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=6)
+    smp = c.samples.copy()
+    bad = smp[::5].copy()
+    bad["set"] = len(c.rays) + 3
+    mixed = np.concatenate([smp[:100], bad, smp[100:]])
+    ctx_ref = device_vpm(c)                      # all valid samples
+    c.samples = mixed
+    p = c.p
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*c.tris); ctx.upload_medium(c.m); ctx.upload_photons(c.ph); ctx.upload_camera_beams(c.rays)
+    ctx.upload_vpm_samples(mixed)
+    ctx.gather(1, c.nb)
+    acc = ctx.download_accum()
+    st = ctx.stats()
+    ctx.close()
+    lum = max(ctx_ref[1][..., 0:3].mean(), 1e-30)
+    assert st["evaluations"] == ctx_ref[2]["evaluations"]
+    assert l2(acc, ctx_ref[1], lum) < TOL
