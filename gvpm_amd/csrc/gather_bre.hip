@@ -36,6 +36,9 @@
 //     kernel sat at 256 VGPRs with spills and 2 waves/SIMD).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "device_types.h"
 #include "shift_device.h"
 #include "tile_walk.h"
@@ -179,8 +182,8 @@ struct BaseTerms {
 };
 
 // hit geometry + base contribution of a (photon, beam) pair, shift_volume_photon.cpp:701-751
-template <int B>
-__device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const EvalLds<B> &s, f3 pos, f3 wi, f3 flux,
+template <int B, typename LDS>
+__device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const LDS &s, f3 pos, f3 wi, f3 flux,
                                                const RayReg &base, uint32_t b) {
   BaseTerms t;
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
@@ -214,8 +217,8 @@ __device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const EvalLd
 }
 
 // phase 1: base contribution + the four shift attempts of one pair; reconnections are returned in qMask
-template <int B>
-__device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t b, Acc27 &acc,
+template <int B, typename LDS>
+__device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t b, Acc27 &acc,
                                            uint32_t &nNull, uint32_t &nFail, uint32_t &qMask, double &tPrimeOut,
                                            float &pdfCamOut) {
   const PhotonFront ph = loadFront(a, pidx);
@@ -274,12 +277,9 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, EvalLds<B> &s, u
 
 // phase 2: one queued reconnection shift (shiftPhotonDiffuse through getShiftPos); the result goes to
 // the lane's registers when it belongs to the lane's current beam, else straight to the LDS accumulators
-template <int B, bool FULLVIS>
-__device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t meta,
-                                           uint32_t curBeam, Acc27 &acc, uint32_t &nDiff, uint32_t &nFail,
-                                           const float4 *ldsTri) {
-  const uint32_t b = meta & 0xFFu;
-  const int i = (int)(meta >> 8);
+template <int B, bool FULLVIS, typename LDS>
+__device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t b, int i, f3 &sf,
+                                               f3 &wb, uint32_t &nDiff, uint32_t &nFail, const float4 *ldsTri) {
   const PhotonCold ph = loadCold(a, pidx);
   const RayReg base = loadRay(s, 0, b);
   const RayReg sh = loadRay(s, 1 + i, b);
@@ -340,7 +340,18 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
   if (ok) nDiff++; else nFail++;
   borderRule(a, s.pix[b], i, w);
   const float ws = w * scale;
-  const f3 sf = sflux * ws, wb = bc * w;
+  sf = sflux * ws;
+  wb = bc * w;
+}
+
+template <int B, bool FULLVIS>
+__device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t meta,
+                                           uint32_t curBeam, Acc27 &acc, uint32_t &nDiff, uint32_t &nFail,
+                                           const float4 *ldsTri) {
+  const uint32_t b = meta & 0xFFu;
+  const int i = (int)(meta >> 8);
+  f3 sf, wb;
+  evalPhase2Core<B, FULLVIS>(a, s, pidx, b, i, sf, wb, nDiff, nFail, ldsTri);
   if (b == curBeam) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
@@ -363,7 +374,7 @@ __device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, u
 }
 
 // a lane's register sums -> the LDS accumulators of `beam`
-template <int B> __device__ __forceinline__ void flushAcc(EvalLds<B> &s, Acc27 &acc, uint32_t beam) {
+template <int B, typename LDS> __device__ __forceinline__ void flushAcc(LDS &s, Acc27 &acc, uint32_t beam) {
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     atomicAdd(&s.acc[k][beam], (double)(acc.v[k]));
@@ -729,6 +740,227 @@ __global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const ui
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// evaluation, segmented: the same work with the two phases in SEPARATE loops.
+//
+// The kernel above interleaves the reconnections with the phase-1 walk, so the 27 register sums of phase 1 stay
+// live across phase 2 and the register allocation is the union of both (187 VGPRs, two waves per SIMD); each
+// wave also holds per-lane reconnection queues of 4 KB.  Here a wave walks a SEGMENT of its item's pairs through
+// phase 1 only (<= SEG_STEPS steps, or until the queue could overflow), appending the reconnections it meets to ONE
+// compact queue (ballot + popcount, 2 bytes per entry: step, lane, shift, beam), folds its register sums into the
+// LDS accumulators, and then runs the queue through phase 2 in a dense loop of its own: every lane takes an equal,
+// contiguous share of the queue, whose entries come in runs of one (beam, shift), so a lane keeps 6 sums in
+// registers and touches the LDS accumulators once per run.  The allocation is the larger of the two loops, not
+// their union, the queue is a quarter of the size, and the waves of a workgroup share the staged occluders:
+// three waves per SIMD instead of two.
+// ------------------------------------------------------------------------------------------
+#ifndef GVPM_EVAL_MINW
+#define GVPM_EVAL_MINW 3
+#endif
+constexpr int SEG_STEPS = 16;   // steps per segment (4 bits of a queue entry)
+constexpr int SEG_QCAP = 1024;  // queue entries per wave; a step appends at most 4 * 64
+template <int B> struct SegCfg {
+  // waves per workgroup: they share nothing but the staged occluders
+  static constexpr int WPB = B == 16 ? 4 : (B == 32 ? 2 : 1);
+  using Entry = typename std::conditional<B == 16, uint16_t, uint32_t>::type;
+  static constexpr int BEAM_BITS = B == 16 ? 4 : 6;
+};
+template <int B> struct SegLds : RayTile<B> {
+  double acc[27][B];
+  uint32_t boff[B + 1];
+  typename SegCfg<B>::Entry q[SEG_QCAP];  // step | lane | shift | beam
+  float4 relO[4][B], relD[4][B];          // as in EvalLds
+};
+
+// LDS accesses of ONE wave are executed in order; what has to be stopped is the compiler moving them
+__device__ __forceinline__ void waveLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int B, bool FULLVIS>
+__global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 > 0 ? GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 : 1)
+void evaluate_bre_seg_kernel(GatherArgs a, const uint4 *__restrict__ items, const uint2 *__restrict__ itemOff,
+                             const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
+                             const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ pairCnt) {
+  constexpr int WPB = SegCfg<B>::WPB;
+  constexpr int BB = SegCfg<B>::BEAM_BITS;
+  using Entry = typename SegCfg<B>::Entry;
+  __shared__ SegLds<B> sAll[WPB];
+  extern __shared__ float4 sceneTri[];  // the occluders of a small scene (48 bytes each), shared by the waves
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  SegLds<B> &s = sAll[wv];
+  const float4 *ldsTri = nullptr;
+  if (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) {
+    for (uint32_t i = threadIdx.x; i < 3u * a.ntri; i += 64u * WPB) sceneTri[i] = a.tri4[i];
+    ldsTri = sceneTri;
+  }
+  __syncthreads();  // the only workgroup barrier: from here on the waves run independently
+  const uint32_t nItems = *itemCount;
+  const uint32_t waveId = blockIdx.x * WPB + wv, nWaves = gridDim.x * WPB;
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+
+  bool firstItem = true;
+  for (;;) {
+    uint32_t it = waveId;
+    if (!firstItem) {
+      if (lane == 0) it = nWaves + atomicAdd(queueHead, 1u);
+      it = __shfl(it, 0, 64);
+    }
+    firstItem = false;
+    if (it >= nItems) break;
+    const uint4 item = items[it];
+    const uint32_t setBase = item.x, nb = item.y;
+    if (nb == 0) continue;
+    const uint32_t cntb = (uint32_t)lane < nb ? pairCnt[(size_t)it * B + lane] : 0u;
+    const uint32_t incl = wave_scan_incl(cntb, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0) continue;
+    const uint2 reg = itemOff[it];
+    const uint32_t *lists = pairs + (size_t)reg.x * 64u;
+    const uint32_t cap = reg.y;
+    waveLdsSync();
+    if (lane < B) s.boff[lane + 1] = incl;
+    if (lane == 0) s.boff[0] = 0u;
+    loadTileRaysNoSync<B>(a, s, setBase, nb, lane);
+    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+    waveLdsSync();
+    for (int idx = lane; idx < 4 * B; idx += 64) {
+      const int i = idx / B, bb = idx % B;
+      const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
+      const f3 dO = tof(tod(sr.o) - tod(br.o)), dD = tof(tod(sr.d) - tod(br.d));
+      s.relO[i][bb] = make_float4(dO.x, dO.y, dO.z, sensorMIS(sr, br, s.edge[bb]));
+      s.relD[i][bb] = make_float4(dD.x, dD.y, dD.z, 0.f);
+    }
+    waveLdsSync();
+
+    // my chunk [g0, g1) of the concatenated per-beam lists (lane l of ANY wave position: g0 = min(total, l * chunk))
+    const uint32_t chunk = (total + 63u) / 64u;
+    const uint32_t g0 = min(total, (uint32_t)lane * chunk), g1 = min(total, g0 + chunk);
+    uint32_t cur = 0;  // current beam
+    if (g0 < g1)
+      while (s.boff[cur + 1] <= g0) cur++;
+
+    for (uint32_t tSeg = 0; tSeg < chunk;) {
+      // ---- phase 1 over a segment of steps ----
+      uint32_t qn = 0;  // wave-uniform
+      Acc27 acc;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc.v[k] = 0.f;
+      uint32_t t = tSeg;
+      for (; t < chunk && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP; ++t) {
+        const uint32_t g = g0 + t;
+        uint32_t qMask = 0;
+        if (g < g1) {
+          if (g >= s.boff[cur + 1]) {
+            flushAcc<B>(s, acc, cur);
+            do cur++; while (s.boff[cur + 1] <= g);
+          }
+          uint32_t pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
+          bool ok = true;
+          if (pidx & 0x80000000u) {
+            // the traversal could not decide this pair in fp32: the reference predicate, fp64, uncontracted
+            pidx &= 0x7FFFFFFFu;
+            const float4 c0 = a.cold[(size_t)pidx * GVPM_REC_QUADS];
+            const RayReg br = loadRay(s, 0, cur);
+            ok = exactHit(mk3(c0.x, c0.y, c0.z), br.o, br.d, br.len, a.radius, s.rnd[cur], a.cfg.epsilon,
+                          a.cfg.vol_technique == GVPM_VOL_BRE3D);
+          }
+          if (ok) {
+            double tP;
+            float pdfCam;
+            evalPhase1<B>(a, s, pidx, cur, acc, nNull, nFail, qMask, tP, pdfCam);
+            nEval++;
+          }
+        }
+        const uint32_t ent = ((t - tSeg) << (8 + BB)) | ((uint32_t)lane << (2 + BB)) | cur;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+          const bool qd = (qMask >> i) & 1u;
+          const unsigned long long m = __ballot(qd);
+          if (qd) s.q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (Entry)(ent | (i << BB));
+          qn += (uint32_t)__popcll(m);
+        }
+      }
+      if (g0 < g1) flushAcc<B>(s, acc, cur);
+      waveLdsSync();
+      // ---- phase 2 over the segment's queue: lane l takes entries [l * cq, (l + 1) * cq) ----
+      const uint32_t cq = (qn + 63u) / 64u;
+      const uint32_t e0 = min(qn, (uint32_t)lane * cq), e1 = min(qn, e0 + cq);
+      uint32_t key = 0xFFFFFFFFu;
+      f3 rs = mk3(0.f), rw = mk3(0.f);
+      for (uint32_t j = 0; j < cq; ++j) {
+        if (e0 + j < e1) {
+          const uint32_t e = s.q[e0 + j];
+          const uint32_t b = e & ((1u << BB) - 1u), i = (e >> BB) & 3u, ln = (e >> (2 + BB)) & 63u, ts = e >> (8 + BB);
+          const uint32_t g = min(total, ln * chunk) + tSeg + ts;
+          const uint32_t pidx = lists[(size_t)b * cap + (g - s.boff[b])] & 0x7FFFFFFFu;
+          const uint32_t k2 = (b << 2) | i;
+          if (k2 != key) {
+            if (key != 0xFFFFFFFFu) {
+              const uint32_t kb = key >> 2, ki = key & 3u;
+              atomicAdd(&s.acc[3 + 3 * ki + 0][kb], (double)rs.x);
+              atomicAdd(&s.acc[3 + 3 * ki + 1][kb], (double)rs.y);
+              atomicAdd(&s.acc[3 + 3 * ki + 2][kb], (double)rs.z);
+              atomicAdd(&s.acc[15 + 3 * ki + 0][kb], (double)rw.x);
+              atomicAdd(&s.acc[15 + 3 * ki + 1][kb], (double)rw.y);
+              atomicAdd(&s.acc[15 + 3 * ki + 2][kb], (double)rw.z);
+            }
+            key = k2;
+            rs = rw = mk3(0.f);
+          }
+          f3 sf, wb;
+          evalPhase2Core<B, FULLVIS>(a, s, pidx, b, (int)i, sf, wb, nDiff, nFail, ldsTri);
+          rs = rs + sf;
+          rw = rw + wb;
+        }
+      }
+      if (key != 0xFFFFFFFFu) {
+        const uint32_t kb = key >> 2, ki = key & 3u;
+        atomicAdd(&s.acc[3 + 3 * ki + 0][kb], (double)rs.x);
+        atomicAdd(&s.acc[3 + 3 * ki + 1][kb], (double)rs.y);
+        atomicAdd(&s.acc[3 + 3 * ki + 2][kb], (double)rs.z);
+        atomicAdd(&s.acc[15 + 3 * ki + 0][kb], (double)rw.x);
+        atomicAdd(&s.acc[15 + 3 * ki + 1][kb], (double)rw.y);
+        atomicAdd(&s.acc[15 + 3 * ki + 2][kb], (double)rw.z);
+      }
+      waveLdsSync();
+      tSeg = t;
+    }
+    // ---- write out: 27 partial sums per beam set into the running sum ----
+    for (int idx = lane; idx < 27 * B; idx += 64) {
+      const int k = idx / B, bb = idx % B;
+      if ((uint32_t)bb < nb) {
+        const float v = (float)s.acc[k][bb];
+        if (v != 0.f) {
+          const uint32_t pv = s.pix[bb];
+          const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+          atomicAdd(&a.iter[p * 27 + k], v * a.iterScale);
+        }
+      }
+    }
+  }
+  // ---- statistics ----
+  {
+    unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ev += __shfl_xor(ev, o, 64);
+      nu += __shfl_xor(nu, o, 64);
+      di += __shfl_xor(di, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+    }
+    if (lane == 0 && ev) {
+      unsigned long long *row = a.stats + 8 * (size_t)(waveId % GVPM_STAT_ROWS);  // this wave's own row
+      row[0] += ev;
+      row[2] += nu;
+      row[3] += di;
+      row[4] += fa;
+    }
+  }
+}
+
 // itemCount / blockTotal must be zero on entry (memset on the same stream)
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
                      uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream) {
@@ -760,6 +992,15 @@ static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *i
                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                            uint32_t nwaves, hipStream_t stream) {
   const size_t dyn = (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) ? (size_t)a.ntri * 48u : 0u;
+  static const bool seg = !(getenv("GVPM_EVAL_SEG") && atoi(getenv("GVPM_EVAL_SEG")) == 0);
+  if (seg) {
+    switch (beamsPerWave) {
+      case 64: hipLaunchKernelGGL((evaluate_bre_seg_kernel<64, FULLVIS>), dim3(nwaves / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+      case 32: hipLaunchKernelGGL((evaluate_bre_seg_kernel<32, FULLVIS>), dim3(nwaves / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+      default: hipLaunchKernelGGL((evaluate_bre_seg_kernel<16, FULLVIS>), dim3(nwaves / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    }
+    return;
+  }
   switch (beamsPerWave) {
     case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
     case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;

@@ -59,9 +59,10 @@ struct TileWalk {
   bool any;
 };
 
+// (no barrier at the end: for kernels whose waves own their LDS tile and order its accesses themselves)
 template <int B>
-__device__ __forceinline__ void loadTileRays(const GatherArgs &a, RayTile<B> &s, uint32_t setBase, uint32_t nb,
-                                             int lane) {
+__device__ __forceinline__ void loadTileRaysNoSync(const GatherArgs &a, RayTile<B> &s, uint32_t setBase, uint32_t nb,
+                                                   int lane) {
   for (int idx = lane; idx < B * 20; idx += 64) {
     const int b = idx / 20, k = (idx % 20) / 4, q = idx % 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -88,6 +89,11 @@ __device__ __forceinline__ void loadTileRays(const GatherArgs &a, RayTile<B> &s,
       }
     }
   }
+}
+template <int B>
+__device__ __forceinline__ void loadTileRays(const GatherArgs &a, RayTile<B> &s, uint32_t setBase, uint32_t nb,
+                                             int lane) {
+  loadTileRaysNoSync<B>(a, s, setBase, nb, lane);
   __syncthreads();
 }
 

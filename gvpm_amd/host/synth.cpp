@@ -127,9 +127,12 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     s.camPos = V3(0, 0, 0.95);
     s.tanHalfFovX = std::tan(0.5 * 60.0 * kPi / 180.0);
     s.cameraInside = true;
-  } else if (name == "laser") {
-    // S-laser: sigma_t = 0.5, small emitter behind an aperture plate
-    addBoxRoom(s, 0, 0, 0, 1, 2, 3);
+  } else if (name == "laser" || name == "laser_hg" || name == "laser_in" || name == "laser_in_hg") {
+    // S-laser: sigma_t = 0.5, small emitter behind an aperture plate; `_hg`: HG g = 0.7;
+    // `_in`: closed room with the sensor inside the fog, what the plane estimator requires (gvpm.cpp:784-788)
+    const bool inside = name == "laser_in" || name == "laser_in_hg";
+    const bool hg = name == "laser_hg" || name == "laser_in_hg";
+    addBoxRoom(s, 0, 0, 0, 1, 2, inside ? 0 : 3);
     setLight(s, V3(0, 0.998, 0), 0.02, 0.02, V3(15000, 15000, 15000), 0);
     // aperture plate at y = 0.9 with a 0.05 x 0.05 hole: four quads facing up and down
     double h = 0.025, y = 0.9;
@@ -140,7 +143,12 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
       s.addQuad(V3(lo[k].x, y, lo[k].z), V3(hi[k].x, y, lo[k].z), V3(hi[k].x, y, hi[k].z),
                 V3(lo[k].x, y, hi[k].z), 0);
     }
-    setMedium(s, 0.25, 0.25, 0.0);
+    setMedium(s, 0.25, 0.25, hg ? 0.7 : 0.0);
+    if (inside) {
+      s.camPos = V3(0, 0, 0.95);
+      s.tanHalfFovX = std::tan(0.5 * 60.0 * kPi / 180.0);
+      s.cameraInside = true;
+    }
   } else if (name == "fogroom") {
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
@@ -289,15 +297,31 @@ void cameraBeams(const SynthScene &scene, int iteration, int x0, int y0, int x1,
   out.clear();
   const SceneView sc = scene.view();
   const int tilesX = (sc.width + 3) / 4;
-  for (int py = y0; py < y1; ++py) {
-    for (int px = x0; px < x1; ++px) {
-      // image-sharded hosts: 4x4-pixel tiles dealt round-robin to the ranks (an even split of the work)
-      if (tileMod > 1 && ((py / 4) * tilesX + px / 4) % tileMod != tileRem) continue;
-      gvpm_camera_ray set[5];
-      if (!cameraBeamSet(sc, iteration, px, py, set)) continue;
-      out.insert(out.end(), set, set + 5);
+  // pixels are keyed by their index: rows are generated by worker threads and concatenated in row order,
+  // which is the sequential loop's output
+  const int nrows = y1 > y0 ? y1 - y0 : 0;
+  std::vector<std::vector<gvpm_camera_ray>> rows((size_t)nrows);
+  const unsigned nthreads = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), (unsigned)std::max(1, nrows)}));
+  auto worker = [&](unsigned tid) {
+    for (int r = (int)tid; r < nrows; r += (int)nthreads) {
+      const int py = y0 + r;
+      for (int px = x0; px < x1; ++px) {
+        // image-sharded hosts: 4x4-pixel tiles dealt round-robin to the ranks (an even split of the work)
+        if (tileMod > 1 && ((py / 4) * tilesX + px / 4) % tileMod != tileRem) continue;
+        gvpm_camera_ray set[5];
+        if (!cameraBeamSet(sc, iteration, px, py, set)) continue;
+        rows[(size_t)r].insert(rows[(size_t)r].end(), set, set + 5);
+      }
     }
-  }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
+  worker(0);
+  for (auto &t : th) t.join();
+  size_t total = 0;
+  for (const auto &r : rows) total += r.size();
+  out.reserve(total);
+  for (const auto &r : rows) out.insert(out.end(), r.begin(), r.end());
 }
 
 void cameraSamplesVPM(const SynthScene &sc, int iteration, const std::vector<gvpm_camera_ray> &rays,
