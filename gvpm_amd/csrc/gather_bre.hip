@@ -23,17 +23,17 @@
 //   * traverse_bre_kernel is persistent (waves pull items from an atomic queue) and holds no
 //     evaluation state, so it runs at high occupancy: for each slab step the 16-byte hot photon
 //     records of the ranges are copied coalesced into an LDS stage and every lane tests them
-//     against its own beam (LDS broadcast reads): fp32 test with a rigorous error band, the
-//     reference predicate in uncontracted fp64 only when the band could change the decision, so
-//     the hit set equals the fp64 oracle's bit for bit.  Hits are compacted with __ballot /
-//     popcount and appended as (photon, beam) pairs to the item's region of the pair buffer
-//     (the region is sized by the planner's upper bound; ~8 bytes written per hit);
-//   * evaluate_bre_kernel, also persistent, takes an item's pairs 64 at a time: every lane
-//     evaluates one (photon record = one 128-byte line): base contribution + 4 shifts (null
-//     shift, or offset-path reconnection with shadow ray, Jacobian and MIS weight), adds 27
-//     partial sums to the beam's LDS accumulators and flushes them with global atomics at the
-//     end of the item.  Splitting the two phases gives each its own register budget (the fused
-//     kernel sat at 256 VGPRs with spills and 2 waves/SIMD).
+//     against its own beam (LDS broadcast reads) with a CONSERVATIVE fp32 test (error band on the
+//     safe side) plus the exact integer filters (depth, interaction mode, checkerboard parity).
+//     Survivors are compacted with __ballot / popcount and appended to the list of their beam in
+//     the item's region of the pair buffer (sized by the planner's upper bound; 4 bytes per pair);
+//   * evaluate_bre_kernel, also persistent, cuts the concatenated per-beam lists of an item into 64
+//     equal chunks, one per lane.  Every pair is first DECIDED: the fp32 test with a rigorous error
+//     band, the reference predicate in uncontracted fp64 only when the band could change the
+//     decision (~1e-5 of the pairs), so the evaluated set equals the fp64 oracle's bit for bit.
+//     Then phase 1 (base contribution + null shifts, 27 sums in registers) and, in a loop of its
+//     own, phase 2 (offset-path reconnections with shadow ray, Jacobian, MIS weight); the sums go
+//     to per-beam LDS accumulators and are flushed with global atomics at the end of the item.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -126,9 +126,9 @@ __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
 // the expensive, divergent part runs on full waves:
 //   phase 1 (one lane per (photon, beam) pair): base contribution, then for each of the four
 //     shifted rays the null shift if it applies (cheap); a shift that needs the offset-path
-//     reconnection is only QUEUED (per lane, in LDS) as (photon, beam, shift, t', pdf);
+//     reconnection is only QUEUED (2 bytes: step, lane, shift, beam);
 //   phase 2 (one lane per queued shift): the diffuse reconnection with its shadow ray, Jacobian
-//     and MIS weight; it runs whenever most lanes have an entry pending.
+//     and MIS weight, in a dense loop of its own (see the kernel).
 // At C2 ~70 % of the shifts are null shifts: running both branches on every lane of a mixed
 // wave cost ~1.5x the VALU work of this arrangement.
 //
@@ -136,32 +136,51 @@ __device__ __forceinline__ void coherentFrame(f3 n, f3 &b1, f3 &b2) {
 // them per evaluation were half of this kernel's time.  The traversal therefore writes one photon
 // list PER BEAM, the evaluation wave cuts the concatenated lists of an item into 64 equal chunks
 // (perfect balance) and every lane sums its 27 outputs in REGISTERS; a lane touches the LDS
-// accumulators only when its chunk crosses into the next beam and at the end of the item.
+// accumulators (double: ds_add_f64 runs ~25x the rate of ds_add_f32, scripts/probes/lds_atomics_bench.hip)
+// only when its chunk crosses into the next beam and at the end of a segment.
 //
 // Numerics: every quantity that the reference obtains by subtracting O(1) positions to get an
 // O(radius) vector (photon - ray point, shifted ray point - base ray point) is formed in fp64 and
 // then carried as a small fp32 vector; everything downstream of those differences (kernel chord
 // lengths sqrt(r^2 - d^2), pdfs, BSDF / phase / transmittance products, MIS weights) is fp32.
-#ifndef GVPM_QD
-#define GVPM_QD 8
-#endif
-constexpr int QD = GVPM_QD;  // per-lane reconnection queue depth (a step adds at most 4)
 constexpr uint32_t EVAL_LDS_TRIS = 64;  // occluders staged in the evaluation kernel's LDS when the scene has no more
 
-template <int B> struct EvalLds : RayTile<B> {
-  double acc[27][B];  // double: ds_add_f64 runs ~25x the rate of ds_add_f32 on gfx950 (scripts/probes/lds_atomics_bench.hip)
-  uint32_t boff[B + 1];      // prefix offsets of the item's per-beam lists
-  // per-lane queues, [slot][lane]: photon and beam | shift << 8.  t' and pdfCam are recomputed by the reconnection
-  // (a dozen fp64 operations) rather than queued: 12 bytes less per entry is 6 KB of LDS per wave, the difference
-  // between 8 and 12 resident waves per CU
-  uint32_t qPh[QD][64];
-  uint32_t qMeta[QD][64];
-  // per (shift, beam), derived once per item: the shifted ray RELATIVE to the base ray {o_s - o_b, sensorMIS} and
-  // {d_s - d_b, -}.  shiftRay(t') - baseRay(t') = dO + dD t' then is a small fp32 vector (pixel spacing at depth t'),
-  // accurate to ~1e-10: the per-evaluation fp64 evaluation of shiftRay(t') (3 cvt + 3 fma + 3 add fp64 per shift)
-  // goes away, and so do the three divisions of sensorMIS
-  float4 relO[4][B], relD[4][B];
-};
+// the fp32 error band of the hit test: E bounds |disk - disk_exact|, band |d2 - d2_exact| for the
+// difference vector wv = photon - ray origin and disk = wv . d
+__device__ __forceinline__ void hitBand(f3 wv, float disk, float r, float r2f, float &E, float &band) {
+  E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
+  band = 4.f * r * E + r2f * 2e-6f;
+}
+
+// The hit decision of one (photon, beam) candidate: gvpm_accel.h:279-301 (disk, distSqr, own box) and, for the
+// 3D kernel, the validity of the resampled t' (shift_volume_photon.cpp:707-726).  Decided in fp32 when the error
+// band cannot change the reference's decision, otherwise by the reference predicate itself (fp64, uncontracted).
+// Returns 1 (hit), 0 (no hit) or 2: the band cannot decide -- about one candidate in 10^5 at C2, plus the photons
+// that project beyond the beam's end (the own-box test decides those) -- and exactHit() has to.
+__device__ __forceinline__ int decidePair(f3 pos, const RayReg &base, float rnd, float r, float eps, bool use3D) {
+  const float r2f = r * r, mint = eps, maxt = base.len - eps;
+  const f3 wv = pos - base.o;
+  const float disk = dot(wv, base.d);
+  const f3 v = wv - base.d * disk;
+  const float d2 = dot(v, v);
+  float E, band;
+  hitBand(wv, disk, r, r2f, E, band);
+  const bool in0 = d2 < r2f - band && disk > mint + E && disk < maxt - E;
+  // surely outside: beyond the band of the disk test (the own-box test can only remove more)
+  bool outside = d2 > r2f + band || disk < mint - E;
+  bool in = in0;
+  if (use3D) {
+    // t' = (disk - deltaT) + 2 deltaT rnd must lie in [mint, len]: bracket it with deltaT in [dTlo, dTup]
+    const float q = r2f - d2;
+    const float dTup = fsqrt(fmaxf(q + band, 0.f)) * 1.000001f, dTlo = fsqrt(fmaxf(q - band, 0.f)) * 0.999999f;
+    const float slop = 2.f * E + 4e-7f * (fabsf(disk) + dTup);
+    const float tLo = (disk - dTup) + 2.f * dTlo * rnd - slop;
+    const float tHi = (disk - dTlo) + 2.f * dTup * rnd + slop;
+    in = in0 && tLo > mint && tHi < base.len;
+    outside = outside || (in0 && (tHi < mint || tLo > base.len));
+  }
+  return in ? 1 : (outside ? 0 : 2);
+}
 
 // the 27 per-beam outputs of one lane, in registers
 struct Acc27 {
@@ -218,11 +237,8 @@ __device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const LDS &s
 
 // phase 1: base contribution + the four shift attempts of one pair; reconnections are returned in qMask
 template <int B, typename LDS>
-__device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t b, Acc27 &acc,
-                                           uint32_t &nNull, uint32_t &nFail, uint32_t &qMask, double &tPrimeOut,
-                                           float &pdfCamOut) {
-  const PhotonFront ph = loadFront(a, pidx);
-  const RayReg base = loadRay(s, 0, b);
+__device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const PhotonFront &ph, const RayReg &base,
+                                           uint32_t b, Acc27 &acc, uint32_t &nNull, uint32_t &nFail, uint32_t &qMask) {
   const uint32_t pix = s.pix[b];
   const float r2 = a.radius * a.radius;
   const BaseTerms bt = baseTerms<B>(a, s, ph.pos, ph.wi, ph.flux, base, b);
@@ -230,8 +246,6 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, uint32_t
   acc.v[0] += bc.x;
   acc.v[1] += bc.y;
   acc.v[2] += bc.z;
-  tPrimeOut = bt.tPrime;
-  pdfCamOut = bt.pdfCam;
   qMask = 0u;
 
   const f3 photonIn = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]) * ph.flux;
@@ -344,35 +358,6 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   wb = bc * w;
 }
 
-template <int B, bool FULLVIS>
-__device__ __forceinline__ void evalPhase2(const GatherArgs &a, EvalLds<B> &s, uint32_t pidx, uint32_t meta,
-                                           uint32_t curBeam, Acc27 &acc, uint32_t &nDiff, uint32_t &nFail,
-                                           const float4 *ldsTri) {
-  const uint32_t b = meta & 0xFFu;
-  const int i = (int)(meta >> 8);
-  f3 sf, wb;
-  evalPhase2Core<B, FULLVIS>(a, s, pidx, b, i, sf, wb, nDiff, nFail, ldsTri);
-  if (b == curBeam) {
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const float m = ii == i ? 1.f : 0.f;
-      acc.v[3 + 3 * ii + 0] += m * sf.x;
-      acc.v[3 + 3 * ii + 1] += m * sf.y;
-      acc.v[3 + 3 * ii + 2] += m * sf.z;
-      acc.v[15 + 3 * ii + 0] += m * wb.x;
-      acc.v[15 + 3 * ii + 1] += m * wb.y;
-      acc.v[15 + 3 * ii + 2] += m * wb.z;
-    }
-  } else {
-    atomicAdd(&s.acc[3 + 3 * i + 0][b], (double)(sf.x));
-    atomicAdd(&s.acc[3 + 3 * i + 1][b], (double)(sf.y));
-    atomicAdd(&s.acc[3 + 3 * i + 2][b], (double)(sf.z));
-    atomicAdd(&s.acc[15 + 3 * i + 0][b], (double)(wb.x));
-    atomicAdd(&s.acc[15 + 3 * i + 1][b], (double)(wb.y));
-    atomicAdd(&s.acc[15 + 3 * i + 2][b], (double)(wb.z));
-  }
-}
-
 // a lane's register sums -> the LDS accumulators of `beam`
 template <int B, typename LDS> __device__ __forceinline__ void flushAcc(LDS &s, Acc27 &acc, uint32_t beam) {
 #pragma unroll
@@ -394,7 +379,8 @@ template <int B>
 __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
                                                           const uint2 *__restrict__ itemOff,
                                                           const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
-                                                          uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairCnt) {
+                                                          uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairCnt,
+                                                          uint32_t persistent) {
   constexpr int LPB = 64 / B;
   __shared__ TravLds s;
   const int lane = threadIdx.x;
@@ -403,16 +389,19 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
   const float r = a.radius;
   const float r2f = r * r;
   const float eps = a.cfg.epsilon;
-  const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const uint32_t coalesceAt = a.cfg.reserved[3] ? (uint32_t)a.cfg.reserved[3] : 512u;  // photons in a box row set
   unsigned long long nCand = 0, nOver = 0;
 
-  // the first item of every wave is its own index; the shared counter (one address: ~11 ns per atomic whatever the
-  // number of waves) serves the rest
+  // One item per wave (the grid is the item count: the hardware dispatcher balances the load and, at every workgroup
+  // boundary, lets the other streams' kernels in by priority -- persistent waves hold their registers until the whole
+  // kernel ends, which stretched the next step's build, a chain of twenty small kernels, from 0.55 to 1.3 ms).
+  // `persistent` (GVPM_PERSISTENT=1): waves loop over items; the first is the wave's own index, a shared counter
+  // (one address: ~11 ns per atomic whatever the number of waves) serves the rest.
   bool firstItem = true;
   for (;;) {
     uint32_t it = blockIdx.x;
     if (!firstItem) {
+      if (!persistent) break;
       if (lane == 0) it = gridDim.x + atomicAdd(queueHead, 1u);
       it = __shfl(it, 0, 64);
     }
@@ -432,8 +421,12 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
     tileSetupFrom(a, base, base.valid, w);
     const bool beamValid = w.beamValid;
     const float mint = eps, maxt = base.len - eps;
-    const uint32_t edge = bi.edge;
+    // depth + edge within [minDepth, maxDepth] (shift_volume_photon.cpp:670-673) as a window on the photon's depth
+    const int dmax = a.cfg.max_depth > 0 ? a.cfg.max_depth - (int)bi.edge : 0x7FFFFFFF;
+    const int dmin = a.cfg.min_depth != 0 ? a.cfg.min_depth - (int)bi.edge : -0x7FFFFFFF;
     const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
+    const uint32_t fmask = 0x40u | (a.cfg.path_set ? (1u << GVPM_HOT_PARITY_BIT) : 0u);
+    const uint32_t fwant = 0x40u | (a.cfg.path_set ? (pixParity << GVPM_HOT_PARITY_BIT) : 0u);
     uint32_t staged = 0;  // wave-uniform
 
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
@@ -494,9 +487,8 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
           __syncthreads();
           staged += nst;
           const uint32_t iters = (nst + LPB - 1) / LPB;
-          // groups of G staged photons per lane: a branch-free coarse pass marks the candidates (the G LDS
-          // reads overlap), then the wave resolves candidates one per lane and round (~1.5 rounds per
-          // group instead of G passes through the divergent code)
+          // groups of G staged photons per lane: a branch-free pass marks the candidates (the G LDS reads
+          // overlap), then the wave appends them one per lane and round
           constexpr uint32_t G = 4;
           for (uint32_t jj = 0; jj < iters; jj += G) {
             uint32_t cm = 0;
@@ -509,61 +501,32 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
                 const float disk = dot(wv, base.d);
                 const f3 v = wv - base.d * disk;
                 const float d2 = dot(v, v);
-                const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
-                const float band = 4.f * r * E + r2f * 2e-6f;
-                if (j < nst && d2 < r2f + band && disk > mint - E && disk < maxt + 2.f * r) cm |= 1u << u;
+                float E, band;
+                hitBand(wv, disk, r, r2f, E, band);
+                // the exact filters, shift_volume_photon.cpp:670-697: depth window, computeVolumeContribution +
+                // debugShift (bit 6, folded by grid_build), checkerboard parity (bit 7)
+                const uint32_t bits = __float_as_uint(hp.w);
+                const int depth = (int)GVPM_PF_DEPTH(bits);
+                const bool keep = depth <= dmax && depth >= dmin && (bits & fmask) == fwant;
+                // conservative: every pair the reference accepts passes (its disk test within the band; beyond the
+                // beam end the own-box test admits diskDistance up to maxt + sqrt(3) r)
+                if (j < nst && keep && d2 < r2f + band && disk > mint - E && disk < maxt + 2.f * r) cm |= 1u << u;
               }
             }
             while (__ballot(cm != 0u)) {
-              // straight-line, predicated (a lane without a candidate computes on entry 0 and discards)
-              const bool active = cm != 0u;
-              const uint32_t j = min((jj + (active ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)STAGE - 1u);
+              const bool hit = cm != 0u;
+              const uint32_t j = min((jj + (hit ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)STAGE - 1u);
               cm &= cm - 1u;
-              const float4 hp = s.stage[j];
-              const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
-              const float disk = dot(wv, base.d);
-              const f3 v = wv - base.d * disk;
-              const float d2 = dot(v, v);
-              // fp32 with a rigorous error band: E bounds |disk - disk_exact|, band |d2 - d2_exact|
-              const float E = 6e-7f * (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(disk));
-              const float band = 4.f * r * E + r2f * 2e-6f;
-              const uint32_t bits = __float_as_uint(hp.w);
-              // filters, shift_volume_photon.cpp:670-697
-              const int depth = (int)GVPM_PF_DEPTH(bits) + (int)edge;
-              const bool keep = active && !(a.cfg.max_depth > 0 && depth > a.cfg.max_depth) &&
-                                !(a.cfg.min_depth != 0 && depth < a.cfg.min_depth) &&
-                                ((bits >> 6) & 1u) &&  // computeVolumeContribution + debugShift (grid_build)
-                                !(a.cfg.path_set && ((bits >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity);
-              // decided in fp32 when the error band cannot change the reference's decision ...
-              const bool in0 = d2 < r2f - band && disk > mint + E && disk < maxt - E;
-              bool in = in0, outside = false;
-              if (use3D) {
-                // t' = (disk - deltaT) + 2 deltaT rnd must lie in [mint, len] (shift_volume_photon.cpp:707-726):
-                // bracket it with deltaT in [dTlo, dTup]
-                const float q = r2f - d2;
-                const float dTup = fsqrt(fmaxf(q + band, 0.f)) * 1.000001f, dTlo = fsqrt(fmaxf(q - band, 0.f)) * 0.999999f;
-                const float slop = 2.f * E + 4e-7f * (fabsf(disk) + dTup);
-                const float tLo = (disk - dTup) + 2.f * dTlo * bi.rnd - slop;
-                const float tHi = (disk - dTlo) + 2.f * dTup * bi.rnd + slop;
-                in = in0 && tLo > mint && tHi < base.len;
-                outside = in0 && (tHi < mint || tLo > base.len);
-              }
-              // ... otherwise the pair is passed on flagged: the evaluation kernel runs the reference
-              // predicate itself (fp64, uncontracted) on it -- about one candidate in 10^5
-              const bool hit = keep && !outside;
-              const bool amb = keep && !in && !outside;
               const unsigned long long m = __ballot(hit);
-              if (m) {
-                // the hits of my beam in this round sit in lanes b, b + B, ...: append in lane order
-                constexpr unsigned long long GROUP = B == 16 ? 0x0001000100010001ull : (B == 32 ? 0x0000000100000001ull : 1ull);
-                const unsigned long long g = (m >> b) & GROUP;
-                if (hit) {
-                  const uint32_t off = mine + __popcll(g & ((1ull << (sub * B)) - 1ull));
-                  if (off < cap) out[off] = s.stageIdx[j] | (amb ? 0x80000000u : 0u);
-                  else nOver++;
-                }
-                mine += __popcll(g);
+              // the candidates of my beam in this round sit in lanes b, b + B, ...: append in lane order
+              constexpr unsigned long long GROUP = B == 16 ? 0x0001000100010001ull : (B == 32 ? 0x0000000100000001ull : 1ull);
+              const unsigned long long g = (m >> b) & GROUP;
+              if (hit) {
+                const uint32_t off = mine + __popcll(g & ((1ull << (sub * B)) - 1ull));
+                if (off < cap) out[off] = s.stageIdx[j];
+                else nOver++;
               }
+              mine += __popcll(g);
             }
           }
         }
@@ -576,189 +539,33 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nOver += __shfl_xor(nOver, o, 64);
     if (lane == 0 && (nCand | nOver)) {
-      unsigned long long *row = a.stats + 8 * (size_t)blockIdx.x;  // this wave's own row
-      row[1] += nCand;
-      if (nOver) row[7] += nOver;  // must stay 0: the planner's bound is exact
+      unsigned long long *row = statRow(a);
+      atomicAdd(&row[1], nCand);
+      if (nOver) atomicAdd(&row[7], nOver);  // must stay 0: the planner's bound is exact
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// evaluation: persistent waves, one item's pairs at a time, 64 evaluations per step
-// ------------------------------------------------------------------------------------------
-template <int B, bool FULLVIS>
-__global__ __launch_bounds__(64) void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
-                                                          const uint2 *__restrict__ itemOff,
-                                                          const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
-                                                          const uint32_t *__restrict__ pairs,
-                                                          const uint32_t *__restrict__ pairCnt) {
-  __shared__ EvalLds<B> s;
-  // the occluders of a small scene live in LDS: the near-occluder loop of the reconnection then reads LDS instead
-  // of (L1/L2-resident) global memory, whose latency two waves per SIMD cannot hide
-  // (dynamic shared memory, sized by the launcher: 48 bytes per occluder, nothing for larger scenes)
-  extern __shared__ float4 sceneTri[];
-  const int lane = threadIdx.x;
-  const float4 *ldsTri = nullptr;
-  if (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) {
-    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
-    ldsTri = sceneTri;
-    __syncthreads();
-  }
-  const uint32_t nItems = *itemCount;
-  const bool skip = (a.cfg.reserved[0] & 1) != 0;  // development switch: count, do not evaluate
-  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
-
-  // the first item of every wave is its own index; the shared counter (one address: ~11 ns per atomic whatever the
-  // number of waves) serves the rest
-  bool firstItem = true;
-  for (;;) {
-    uint32_t it = blockIdx.x;
-    if (!firstItem) {
-      if (lane == 0) it = gridDim.x + atomicAdd(queueHead, 1u);
-      it = __shfl(it, 0, 64);
-    }
-    firstItem = false;
-    if (it >= nItems) break;
-    const uint4 item = items[it];
-    const uint32_t setBase = item.x, nb = item.y;
-    if (nb == 0) continue;
-    // prefix offsets of the per-beam lists
-    const uint32_t cntb = (uint32_t)lane < nb ? pairCnt[(size_t)it * B + lane] : 0u;
-    const uint32_t incl = wave_scan_incl(cntb, lane);
-    const uint32_t total = __shfl(incl, 63, 64);
-    if (total == 0) continue;
-    const uint2 reg = itemOff[it];
-    const uint32_t *lists = pairs + (size_t)reg.x * 64u;
-    const uint32_t cap = reg.y;
-    __syncthreads();
-    if (lane < B) s.boff[lane + 1] = incl;
-    if (lane == 0) s.boff[0] = 0u;
-    loadTileRays<B>(a, s, setBase, nb, lane);
-    for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
-    for (int idx = lane; idx < 4 * B; idx += 64) {
-      const int i = idx / B, bb = idx % B;
-      const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
-      const f3 dO = tof(tod(sr.o) - tod(br.o)), dD = tof(tod(sr.d) - tod(br.d));
-      s.relO[i][bb] = make_float4(dO.x, dO.y, dO.z, sensorMIS(sr, br, s.edge[bb]));
-      s.relD[i][bb] = make_float4(dD.x, dD.y, dD.z, 0.f);
-    }
-    __syncthreads();
-
-    // my chunk [g0, g1) of the concatenated lists
-    const uint32_t chunk = (total + 63u) / 64u;
-    const uint32_t g0 = min(total, (uint32_t)lane * chunk), g1 = min(total, g0 + chunk);
-    uint32_t cur = 0;  // current beam
-    if (g0 < g1)
-      while (s.boff[cur + 1] <= g0) cur++;
-    Acc27 acc;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc.v[k] = 0.f;
-    uint32_t qHead = 0, qCount = 0;  // this lane's reconnection queue
-
-    for (uint32_t t = 0; t <= chunk; ++t) {
-      const bool last = t == chunk;
-      if (!last) {
-        const uint32_t g = g0 + t;
-        uint32_t qMask = 0;
-        double tP = 0.0;
-        float pdfCam = 0.f;
-        uint32_t pidx = 0;
-        if (g < g1) {
-          if (g >= s.boff[cur + 1]) {
-            flushAcc<B>(s, acc, cur);
-            do cur++; while (s.boff[cur + 1] <= g);
-          }
-          pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
-          bool ok = true;
-          if (pidx & 0x80000000u) {
-            // the traversal could not decide this pair in fp32: the reference predicate, fp64, uncontracted
-            pidx &= 0x7FFFFFFFu;
-            const float4 c0 = a.cold[(size_t)pidx * GVPM_REC_QUADS];
-            const RayReg br = loadRay(s, 0, cur);
-            ok = exactHit(mk3(c0.x, c0.y, c0.z), br.o, br.d, br.len, a.radius, s.rnd[cur], a.cfg.epsilon,
-                          a.cfg.vol_technique == GVPM_VOL_BRE3D);
-          }
-          if (ok) {
-            if (!skip) evalPhase1<B>(a, s, pidx, cur, acc, nNull, nFail, qMask, tP, pdfCam);
-            nEval++;
-          }
-        }
-        for (uint32_t m = qMask; m; m &= m - 1u) {
-          const uint32_t sh = (uint32_t)__ffs(m) - 1u;
-          const uint32_t q = (qHead + qCount) % QD;
-          s.qPh[q][lane] = pidx;
-          s.qMeta[q][lane] = cur | (sh << 8);
-          qCount++;
-        }
-      }
-      // reconnections: run while most lanes have one pending, or a queue could overflow next step;
-      // after the last step drain everything
-      for (;;) {
-        const unsigned long long pending = __ballot(qCount > 0u);
-        if (!pending) break;
-        if (!last && __popcll(pending) < 48 && !__ballot(qCount > (uint32_t)(QD - 4))) break;
-        if (qCount > 0u) {
-          const uint32_t q = qHead;
-          evalPhase2<B, FULLVIS>(a, s, s.qPh[q][lane], s.qMeta[q][lane], cur, acc, nDiff, nFail, ldsTri);
-          qHead = (qHead + 1u) % QD;
-          qCount--;
-        }
-      }
-    }
-    if (g0 < g1) flushAcc<B>(s, acc, cur);
-    __syncthreads();
-    // ---- write out: 27 partial sums per beam set into the iteration buffer ----
-    for (int idx = lane; idx < 27 * B; idx += 64) {
-      const int k = idx / B, bb = idx % B;
-      if ((uint32_t)bb < nb) {
-        const float v = (float)s.acc[k][bb];
-        if (v != 0.f) {
-          const uint32_t pv = s.pix[bb];
-          const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
-          atomicAdd(&a.iter[p * 27 + k], v * a.iterScale);
-        }
-      }
-    }
-  }
-  // ---- statistics ----
-  {
-    unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      ev += __shfl_xor(ev, o, 64);
-      nu += __shfl_xor(nu, o, 64);
-      di += __shfl_xor(di, o, 64);
-      fa += __shfl_xor(fa, o, 64);
-    }
-    if (lane == 0 && ev) {
-      unsigned long long *row = a.stats + 8 * (size_t)blockIdx.x;  // this wave's own row
-      row[0] += ev;
-      row[2] += nu;
-      row[3] += di;
-      row[4] += fa;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// evaluation, segmented: the same work with the two phases in SEPARATE loops.
+// evaluation: persistent waves, one item at a time, the two phases in SEPARATE loops.
 //
-// The kernel above interleaves the reconnections with the phase-1 walk, so the 27 register sums of phase 1 stay
-// live across phase 2 and the register allocation is the union of both (187 VGPRs, two waves per SIMD); each
-// wave also holds per-lane reconnection queues of 4 KB.  Here a wave walks a SEGMENT of its item's pairs through
-// phase 1 only (<= SEG_STEPS steps, or until the queue could overflow), appending the reconnections it meets to ONE
-// compact queue (ballot + popcount, 2 bytes per entry: step, lane, shift, beam), folds its register sums into the
-// LDS accumulators, and then runs the queue through phase 2 in a dense loop of its own: every lane takes an equal,
-// contiguous share of the queue, whose entries come in runs of one (beam, shift), so a lane keeps 6 sums in
-// registers and touches the LDS accumulators once per run.  The allocation is the larger of the two loops, not
-// their union, the queue is a quarter of the size, and the waves of a workgroup share the staged occluders:
-// three waves per SIMD instead of two.
+// A wave walks a SEGMENT of its item's pairs through the decision + phase 1 only (<= SEG_STEPS steps, or until
+// the queue could overflow), appending the reconnections it meets to ONE compact queue (ballot + popcount, 2 bytes
+// per entry: step, lane, shift, beam), folds its register sums into the LDS accumulators, and then runs the queue
+// through phase 2 in a dense loop of its own: every lane takes an equal, contiguous share of the queue, whose
+// entries come in runs of one (beam, shift), so a lane keeps 6 sums in registers and touches the LDS accumulators
+// once per run.  (Round 1 interleaved the reconnections with the phase-1 walk: the 27 register sums of phase 1
+// stayed live across phase 2, the allocation was the union of both -- 187 VGPRs, two waves per SIMD -- and each
+// wave held per-lane queues of 4 KB.)  Here the allocation is the larger of the two loops, the queue is a quarter
+// of the size, and the 4 waves of a workgroup share the staged occluders: 12 KB of LDS per wave, 3 waves per SIMD.
+// Measured at C2 (MI355X, isolated): 1.09 -> 0.78 ms.
 // ------------------------------------------------------------------------------------------
 #ifndef GVPM_EVAL_MINW
 #define GVPM_EVAL_MINW 3
 #endif
 constexpr int SEG_STEPS = 16;   // steps per segment (4 bits of a queue entry)
 constexpr int SEG_QCAP = 1024;  // queue entries per wave; a step appends at most 4 * 64
+constexpr int SEG_AMB = 128;    // undecided pairs per segment; a step appends at most 64
 template <int B> struct SegCfg {
   // waves per workgroup: they share nothing but the staged occluders
   static constexpr int WPB = B == 16 ? 4 : (B == 32 ? 2 : 1);
@@ -769,6 +576,7 @@ template <int B> struct SegLds : RayTile<B> {
   double acc[27][B];
   uint32_t boff[B + 1];
   typename SegCfg<B>::Entry q[SEG_QCAP];  // step | lane | shift | beam
+  uint16_t amb[SEG_AMB];                  // pairs the fp32 band could not decide: step << 6 | lane
   float4 relO[4][B], relD[4][B];          // as in EvalLds
 };
 
@@ -781,9 +589,10 @@ __device__ __forceinline__ void waveLdsSync() {
 
 template <int B, bool FULLVIS>
 __global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 > 0 ? GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 : 1)
-void evaluate_bre_seg_kernel(GatherArgs a, const uint4 *__restrict__ items, const uint2 *__restrict__ itemOff,
+void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const uint2 *__restrict__ itemOff,
                              const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
-                             const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ pairCnt) {
+                             const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ pairCnt,
+                             uint32_t persistent) {
   constexpr int WPB = SegCfg<B>::WPB;
   constexpr int BB = SegCfg<B>::BEAM_BITS;
   using Entry = typename SegCfg<B>::Entry;
@@ -805,6 +614,7 @@ void evaluate_bre_seg_kernel(GatherArgs a, const uint4 *__restrict__ items, cons
   for (;;) {
     uint32_t it = waveId;
     if (!firstItem) {
+      if (!persistent) break;  // one item per wave (see traverse_bre_kernel)
       if (lane == 0) it = nWaves + atomicAdd(queueHead, 1u);
       it = __shfl(it, 0, 64);
     }
@@ -835,6 +645,7 @@ void evaluate_bre_seg_kernel(GatherArgs a, const uint4 *__restrict__ items, cons
     }
     waveLdsSync();
 
+    const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
     // my chunk [g0, g1) of the concatenated per-beam lists (lane l of ANY wave position: g0 = min(total, l * chunk))
     const uint32_t chunk = (total + 63u) / 64u;
     const uint32_t g0 = min(total, (uint32_t)lane * chunk), g1 = min(total, g0 + chunk);
@@ -843,90 +654,141 @@ void evaluate_bre_seg_kernel(GatherArgs a, const uint4 *__restrict__ items, cons
       while (s.boff[cur + 1] <= g0) cur++;
 
     for (uint32_t tSeg = 0; tSeg < chunk;) {
-      // ---- phase 1 over a segment of steps ----
-      uint32_t qn = 0;  // wave-uniform
-      Acc27 acc;
+      uint32_t tEnd = tSeg;  // first step of the next segment
+      uint32_t nLate = 0;    // undecided pairs of the segment that the reference predicate accepted
+      uint32_t curKeep = cur;
+      // pass 0: the segment's pairs; pass 1 (rare): its undecided pairs that exactHit() accepted.  Both passes run
+      // the SAME two loops, so the kernel holds one copy of either phase.
+      for (int pass = 0; pass < 2; ++pass) {
+        const bool late = pass == 1;
+        // ---- decision + phase 1 ----
+        uint32_t qn = 0, an = 0;  // wave-uniform
+        Acc27 acc;
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc.v[k] = 0.f;
-      uint32_t t = tSeg;
-      for (; t < chunk && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP; ++t) {
-        const uint32_t g = g0 + t;
-        uint32_t qMask = 0;
-        if (g < g1) {
-          if (g >= s.boff[cur + 1]) {
-            flushAcc<B>(s, acc, cur);
-            do cur++; while (s.boff[cur + 1] <= g);
+        for (int k = 0; k < 27; ++k) acc.v[k] = 0.f;
+        bool dirty = false;  // acc holds sums of beam `cur`
+        const uint32_t tLim = late ? tSeg + (nLate + 63u) / 64u : chunk;
+        uint32_t t = tSeg;
+        for (; t < tLim && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP && an + 64u <= (uint32_t)SEG_AMB; ++t) {
+          // the pair of this lane and step: entry g of the concatenated lists, or a late pair
+          uint32_t g = g0 + t;
+          bool have = g < g1;
+          if (late) {
+            const uint32_t li = (t - tSeg) * 64u + (uint32_t)lane;
+            have = li < nLate;
+            const uint32_t e = s.amb[have ? li : 0u];
+            g = min(total, (e & 63u) * chunk) + tSeg + (e >> 6);
           }
-          uint32_t pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
-          bool ok = true;
-          if (pidx & 0x80000000u) {
-            // the traversal could not decide this pair in fp32: the reference predicate, fp64, uncontracted
-            pidx &= 0x7FFFFFFFu;
-            const float4 c0 = a.cold[(size_t)pidx * GVPM_REC_QUADS];
-            const RayReg br = loadRay(s, 0, cur);
-            ok = exactHit(mk3(c0.x, c0.y, c0.z), br.o, br.d, br.len, a.radius, s.rnd[cur], a.cfg.epsilon,
-                          a.cfg.vol_technique == GVPM_VOL_BRE3D);
-          }
-          if (ok) {
-            double tP;
-            float pdfCam;
-            evalPhase1<B>(a, s, pidx, cur, acc, nNull, nFail, qMask, tP, pdfCam);
-            nEval++;
-          }
-        }
-        const uint32_t ent = ((t - tSeg) << (8 + BB)) | ((uint32_t)lane << (2 + BB)) | cur;
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i) {
-          const bool qd = (qMask >> i) & 1u;
-          const unsigned long long m = __ballot(qd);
-          if (qd) s.q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (Entry)(ent | (i << BB));
-          qn += (uint32_t)__popcll(m);
-        }
-      }
-      if (g0 < g1) flushAcc<B>(s, acc, cur);
-      waveLdsSync();
-      // ---- phase 2 over the segment's queue: lane l takes entries [l * cq, (l + 1) * cq) ----
-      const uint32_t cq = (qn + 63u) / 64u;
-      const uint32_t e0 = min(qn, (uint32_t)lane * cq), e1 = min(qn, e0 + cq);
-      uint32_t key = 0xFFFFFFFFu;
-      f3 rs = mk3(0.f), rw = mk3(0.f);
-      for (uint32_t j = 0; j < cq; ++j) {
-        if (e0 + j < e1) {
-          const uint32_t e = s.q[e0 + j];
-          const uint32_t b = e & ((1u << BB) - 1u), i = (e >> BB) & 3u, ln = (e >> (2 + BB)) & 63u, ts = e >> (8 + BB);
-          const uint32_t g = min(total, ln * chunk) + tSeg + ts;
-          const uint32_t pidx = lists[(size_t)b * cap + (g - s.boff[b])] & 0x7FFFFFFFu;
-          const uint32_t k2 = (b << 2) | i;
-          if (k2 != key) {
-            if (key != 0xFFFFFFFFu) {
-              const uint32_t kb = key >> 2, ki = key & 3u;
-              atomicAdd(&s.acc[3 + 3 * ki + 0][kb], (double)rs.x);
-              atomicAdd(&s.acc[3 + 3 * ki + 1][kb], (double)rs.y);
-              atomicAdd(&s.acc[3 + 3 * ki + 2][kb], (double)rs.z);
-              atomicAdd(&s.acc[15 + 3 * ki + 0][kb], (double)rw.x);
-              atomicAdd(&s.acc[15 + 3 * ki + 1][kb], (double)rw.y);
-              atomicAdd(&s.acc[15 + 3 * ki + 2][kb], (double)rw.z);
+          uint32_t qMask = 0;
+          bool undecided = false;
+          if (have) {
+            uint32_t b = late ? 0u : cur;  // (a lane's own pairs come in ascending beam order)
+            while (s.boff[b + 1] <= g) b++;
+            if (b != cur) {
+              if (dirty) flushAcc<B>(s, acc, cur);
+              dirty = false;
+              cur = b;
             }
-            key = k2;
+            const uint32_t pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
+            const PhotonFront ph = loadFront(a, pidx);
+            const RayReg base = loadRay(s, 0, cur);
+            const int dec = late ? 1 : decidePair(ph.pos, base, s.rnd[cur], a.radius, a.cfg.epsilon, use3D);
+            undecided = dec == 2;
+            if (dec == 1) {
+              evalPhase1<B>(a, s, ph, base, cur, acc, nNull, nFail, qMask);
+              dirty = true;
+              nEval++;
+            }
+          }
+          {
+            const unsigned long long m = __ballot(undecided);
+            if (undecided) s.amb[an + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(((t - tSeg) << 6) | (uint32_t)lane);
+            an += (uint32_t)__popcll(m);
+          }
+          const uint32_t ent = ((t - tSeg) << (8 + BB)) | ((uint32_t)lane << (2 + BB)) | cur;
+#pragma unroll
+          for (uint32_t i = 0; i < 4u; ++i) {
+            const bool qd = (qMask >> i) & 1u;
+            const unsigned long long m = __ballot(qd);
+            if (qd) s.q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (Entry)(ent | (i << BB));
+            qn += (uint32_t)__popcll(m);
+          }
+        }
+        if (dirty) flushAcc<B>(s, acc, cur);
+        if (!late) {
+          tEnd = t;
+          curKeep = cur;  // the late pass visits beams in any order: the walk resumes from here
+        }
+        waveLdsSync();
+        // ---- phase 2 over the queue: lane l takes entries [l * cq, (l + 1) * cq) ----
+        const uint32_t cq = (qn + 63u) / 64u;
+        const uint32_t e0 = min(qn, (uint32_t)lane * cq), e1 = min(qn, e0 + cq);
+        uint32_t key = 0xFFFFFFFFu;
+        f3 rs = mk3(0.f), rw = mk3(0.f);
+        for (uint32_t j = 0; j <= cq; ++j) {
+          const bool have = j < cq && e0 + j < e1;
+          uint32_t k2 = 0xFFFFFFFFu, pidx = 0, b = 0, i = 0;
+          if (have) {
+            const uint32_t e = s.q[e0 + j];
+            b = e & ((1u << BB) - 1u);
+            i = (e >> BB) & 3u;
+            uint32_t ln = (e >> (2 + BB)) & 63u, ts = e >> (8 + BB);
+            if (late) {
+              const uint32_t e2 = s.amb[ts * 64u + ln];
+              ln = e2 & 63u;
+              ts = e2 >> 6;
+            }
+            const uint32_t g = min(total, ln * chunk) + tSeg + ts;
+            pidx = lists[(size_t)b * cap + (g - s.boff[b])];
+            k2 = (b << 2) | i;
+          }
+          if (k2 != key && key != 0xFFFFFFFFu) {
+            // the run of one (beam, shift) ended: its 6 sums go to the LDS accumulators
+            const uint32_t kb = key >> 2, ki = key & 3u;
+            atomicAdd(&s.acc[3 + 3 * ki + 0][kb], (double)rs.x);
+            atomicAdd(&s.acc[3 + 3 * ki + 1][kb], (double)rs.y);
+            atomicAdd(&s.acc[3 + 3 * ki + 2][kb], (double)rs.z);
+            atomicAdd(&s.acc[15 + 3 * ki + 0][kb], (double)rw.x);
+            atomicAdd(&s.acc[15 + 3 * ki + 1][kb], (double)rw.y);
+            atomicAdd(&s.acc[15 + 3 * ki + 2][kb], (double)rw.z);
             rs = rw = mk3(0.f);
           }
-          f3 sf, wb;
-          evalPhase2Core<B, FULLVIS>(a, s, pidx, b, (int)i, sf, wb, nDiff, nFail, ldsTri);
-          rs = rs + sf;
-          rw = rw + wb;
+          key = k2;
+          if (have) {
+            f3 sf, wb;
+            evalPhase2Core<B, FULLVIS>(a, s, pidx, b, (int)i, sf, wb, nDiff, nFail, ldsTri);
+            rs = rs + sf;
+            rw = rw + wb;
+          }
         }
+        waveLdsSync();
+        if (late || an == 0u) break;
+        // ---- the undecided pairs: the reference predicate (fp64, uncontracted); the accepted ones are compacted
+        // in place into the late list and go through the two loops above once more ----
+        for (uint32_t j0 = 0; j0 < an; j0 += 64u) {
+          const uint32_t j = j0 + (uint32_t)lane;
+          bool ok = false;
+          uint32_t e = 0;
+          if (j < an) {
+            e = s.amb[j];
+            const uint32_t g = min(total, (e & 63u) * chunk) + tSeg + (e >> 6);
+            uint32_t b = 0;
+            while (s.boff[b + 1] <= g) b++;
+            const uint32_t pidx = lists[(size_t)b * cap + (g - s.boff[b])];
+            const float4 c0 = a.cold[(size_t)pidx * GVPM_REC_QUADS];
+            const RayReg base = loadRay(s, 0, b);
+            ok = exactHit(mk3(c0.x, c0.y, c0.z), base.o, base.d, base.len, a.radius, s.rnd[b], a.cfg.epsilon, use3D);
+          }
+          const unsigned long long m = __ballot(ok);
+          waveLdsSync();  // every lane has read its entry before the compacted ones are written over the list
+          if (ok) s.amb[nLate + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
+          nLate += (uint32_t)__popcll(m);
+        }
+        waveLdsSync();
+        if (nLate == 0u) break;
       }
-      if (key != 0xFFFFFFFFu) {
-        const uint32_t kb = key >> 2, ki = key & 3u;
-        atomicAdd(&s.acc[3 + 3 * ki + 0][kb], (double)rs.x);
-        atomicAdd(&s.acc[3 + 3 * ki + 1][kb], (double)rs.y);
-        atomicAdd(&s.acc[3 + 3 * ki + 2][kb], (double)rs.z);
-        atomicAdd(&s.acc[15 + 3 * ki + 0][kb], (double)rw.x);
-        atomicAdd(&s.acc[15 + 3 * ki + 1][kb], (double)rw.y);
-        atomicAdd(&s.acc[15 + 3 * ki + 2][kb], (double)rw.z);
-      }
-      waveLdsSync();
-      tSeg = t;
+      tSeg = tEnd;
+      cur = curKeep;
     }
     // ---- write out: 27 partial sums per beam set into the running sum ----
     for (int idx = lane; idx < 27 * B; idx += 64) {
@@ -952,11 +814,11 @@ void evaluate_bre_seg_kernel(GatherArgs a, const uint4 *__restrict__ items, cons
       fa += __shfl_xor(fa, o, 64);
     }
     if (lane == 0 && ev) {
-      unsigned long long *row = a.stats + 8 * (size_t)(waveId % GVPM_STAT_ROWS);  // this wave's own row
-      row[0] += ev;
-      row[2] += nu;
-      row[3] += di;
-      row[4] += fa;
+      unsigned long long *row = a.stats + 8 * (size_t)(waveId % GVPM_STAT_ROWS);
+      atomicAdd(&row[0], ev);
+      atomicAdd(&row[2], nu);
+      atomicAdd(&row[3], di);
+      atomicAdd(&row[4], fa);
     }
   }
 }
@@ -978,43 +840,36 @@ void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uin
 // queueHead must be zero on entry
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
-                         uint32_t nwaves, hipStream_t stream) {
-  if (a.nsets == 0) return;
+                         uint32_t nwaves, bool persistent, hipStream_t stream) {
+  if (a.nsets == 0 || nwaves == 0) return;
+  const uint32_t persist = persistent ? 1u : 0u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
   }
 }
 
 template <bool FULLVIS>
 static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
-                           uint32_t nwaves, hipStream_t stream) {
+                           uint32_t nwaves, bool persistent, hipStream_t stream) {
+  const uint32_t persist = persistent ? 1u : 0u;
   const size_t dyn = (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) ? (size_t)a.ntri * 48u : 0u;
-  static const bool seg = !(getenv("GVPM_EVAL_SEG") && atoi(getenv("GVPM_EVAL_SEG")) == 0);
-  if (seg) {
-    switch (beamsPerWave) {
-      case 64: hipLaunchKernelGGL((evaluate_bre_seg_kernel<64, FULLVIS>), dim3(nwaves / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-      case 32: hipLaunchKernelGGL((evaluate_bre_seg_kernel<32, FULLVIS>), dim3(nwaves / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-      default: hipLaunchKernelGGL((evaluate_bre_seg_kernel<16, FULLVIS>), dim3(nwaves / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    }
-    return;
-  }
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
-    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS>), dim3(nwaves), dim3(64), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS>), dim3((nwaves + SegCfg<64>::WPB - 1) / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS>), dim3((nwaves + SegCfg<32>::WPB - 1) / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS>), dim3((nwaves + SegCfg<16>::WPB - 1) / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
   }
 }
 
 // fullVis: shadow rays walk the occluder BVH (intended visibility, > 254 occluders, near-list overflow)
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
-                         uint32_t nwaves, hipStream_t stream) {
-  if (a.nsets == 0) return;
-  if (fullVis) launchEvaluate<true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, stream);
-  else launchEvaluate<false>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, stream);
+                         uint32_t nwaves, bool persistent, hipStream_t stream) {
+  if (a.nsets == 0 || nwaves == 0) return;
+  if (fullVis) launchEvaluate<true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream);
+  else launchEvaluate<false>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream);
 }
 
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave) {

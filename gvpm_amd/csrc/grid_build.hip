@@ -75,11 +75,13 @@ __global__ void bounds_final_kernel(const float *partial, int nblocks, float *ou
 }
 
 // counters -> pinned host memory (same reason)
-__global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *hostOut) {
+__global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d,
+                                  uint32_t *hostOut) {
   if (threadIdx.x == 0) {
     hostOut[0] = a ? *a : 0u;
     hostOut[1] = b ? *b : 0u;
     hostOut[2] = c ? *c : 0u;
+    hostOut[3] = d ? *d : 0u;
     __threadfence_system();
   }
 }
@@ -443,8 +445,9 @@ void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, fl
   hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6, hostOut);
 }
 
-void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *hostOut, hipStream_t s) {
-  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, c, hostOut);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *hostOut,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, c, d, hostOut);
 }
 
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {

@@ -23,7 +23,8 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
                    hipStream_t s);
 hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
-void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *hostOut, hipStream_t s);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *hostOut,
+                       hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
@@ -44,10 +45,10 @@ void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uin
                      uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream);
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
-                         uint32_t nwaves, hipStream_t stream);
+                         uint32_t nwaves, bool persistent, hipStream_t stream);
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
-                         uint32_t nwaves, hipStream_t stream);
+                         uint32_t nwaves, bool persistent, hipStream_t stream);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
 struct PoissonGraphCache {
   hipGraph_t graph = nullptr;
@@ -303,6 +304,11 @@ struct gvpm_context {
   uint32_t nwaves = 2048;      // persistent gather waves
   uint32_t ncu = 256;
   uint32_t nwavesTrav = 4096;  // persistent traversal waves (G-BRE)
+  // G-BRE: persistent waves pulling items from a queue, or one item per wave (GVPM_PERSISTENT: bit 0 evaluation, bit 1
+  // traversal).  Measured at C2: the evaluation is faster persistent (0.97 against 1.11 ms: its 4-wave workgroups stage
+  // the occluders once), the traversal one item per wave (0.57 against 0.78 ms beside the evaluation: the dispatcher
+  // slots its workgroups, and the next build's kernels, in as others retire)
+  bool persistentEval = true, persistentTrav = false;
   // per item and beam: photon index lists + their lengths
 
   // reconstruction scratch
@@ -433,6 +439,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     if (h->nwaves > GVPM_STAT_ROWS) h->nwaves = GVPM_STAT_ROWS;
   }
   if (const char *e = getenv("GVPM_PIPELINE")) h->pipeline = atoi(e) != 0;
+  // alone on the GPU (single stream) the evaluation runs best at its full 3 waves per SIMD; beside the traversal and the
+  // build of the following steps 8 per CU leave them room (measured: 12 per CU costs the pipelined step 3-4 %)
+  if (!h->pipeline && !getenv("GVPM_WAVES_PER_CU") && h->ncu) h->nwaves = std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS);
+  if (const char *e = getenv("GVPM_PERSISTENT")) h->persistentEval = (atoi(e) & 1) != 0, h->persistentTrav = (atoi(e) & 2) != 0;
   if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_STREAM")) h->travStream = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
@@ -1013,12 +1023,13 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, rebuilt ? h->bs->nearExt.p : nullptr,
-                    h->pinCtl, h->bstream);
+                    h->bs->queueCtl.p, h->pinCtl, h->bstream);
   HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
   lap("plan");
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
   lap("syncB");
   const uint32_t blocks = h->pinCtl[0];
+  const uint32_t nItems = h->pinCtl[3];
   if (getenv("GVPM_TRACE_PLAN")) {
     uint32_t q[4] = {0, 0, 0, 0};
     (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
@@ -1056,14 +1067,15 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   hipStream_t ts = h->pipeline && h->travStream ? h->streamC : (h->travOnBuild ? h->bstream : h->stream);
   HIP_TRY(h, hipEventRecord(evTrav->first, ts));
   launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
-                      h->bs->pairs.p, h->bs->pairCnt.p, h->nwavesTrav, ts);
+                      h->bs->pairs.p, h->bs->pairCnt.p, h->persistentTrav ? h->nwavesTrav : nItems, h->persistentTrav, ts);
   HIP_TRY(h, hipEventRecord(evTrav->second, ts));
   HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
   h->bstream = h->stream;
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
   launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
-                      h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->nwaves, h->stream);
+                      h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? h->nwaves : nItems, h->persistentEval,
+                      h->stream);
   HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
   HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
   if (h->pipeline) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of G-BRE evaluation variants on the GPU box: bash scripts/ab_bre.sh OUTDIR
+# A/B of G-BRE variants on the GPU box: bash scripts/ab_bre.sh OUTDIR
 out=${1:-gpurun_out/ab}; mkdir -p $out
 run() { # name, env...
   name=$1; shift
@@ -8,9 +8,10 @@ import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%-28s %8.1f Mev/s  step %.3f ms  eval %.3f  iso %.3f  trav %.3f  build %.3f' % ('$name', d['value'], d['ms_per_step'], r['kernel_avg_ms'], r.get('kernel_isolated_ms',0), r['traverse_avg_ms'], r['build_avg_ms']))" | tee -a $out/summary.txt
 }
-run old_w8 GVPM_EVAL_SEG=0
-run seg3_w8 GVPM_EVAL_SEG=1
-run seg3_w12 GVPM_EVAL_SEG=1 GVPM_WAVES_PER_CU=12
-run seg2_w8 GVPM_HIP_LIB=build/variants/libgvpm_hip_minw2.so
-run old_w8_b GVPM_EVAL_SEG=0
-run seg3_w12_b GVPM_EVAL_SEG=1 GVPM_WAVES_PER_CU=12
+run mix_default A=1
+run both_pers GVPM_PERSISTENT=3
+run mix_w10 GVPM_WAVES_PER_CU=10
+run mix_w12 GVPM_WAVES_PER_CU=12
+run mix_prio000 GVPM_STREAM_PRIORITIES=0,0,0
+run mix_buildhigh GVPM_STREAM_PRIORITIES=0,-1,0
+run mix_default_b A=1
