@@ -101,7 +101,8 @@ class PhotonSoA(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("evaluations", C.c_uint64), ("candidates", C.c_uint64), ("null_shifts", C.c_uint64),
-        ("diffuse_shifts", C.c_uint64), ("failed_shifts", C.c_uint64), ("reserved", C.c_uint64 * 3),
+        ("diffuse_shifts", C.c_uint64), ("failed_shifts", C.c_uint64), ("dropped_pairs", C.c_uint64),
+        ("reserved", C.c_uint64 * 2),
     ]
 
 

@@ -26,30 +26,29 @@ struct BeamF {
   f3 flux, prefixW, parentScat, parentN, parentWi, endN;
   float parentPdf, parentRR, parentG;
   uint32_t flags;
+  uint32_t nl0, nl1, nl2;  // occluders near the beam (beam_near_kernel): 12 byte indices, 0xFF = none, top byte 0xFE: all
   bool endOnSurface;
 };
 
 __device__ __forceinline__ BeamF loadBeamF(const GatherArgs &a, uint32_t idx) {
-  const size_t N = a.nbeams;
-  const float4 c0 = a.cold[0 * N + idx], c1 = a.cold[1 * N + idx], c2 = a.cold[2 * N + idx], c3 = a.cold[3 * N + idx];
-  const float4 c4 = a.cold[4 * N + idx], c5 = a.cold[5 * N + idx], c6 = a.cold[6 * N + idx], c7 = a.cold[7 * N + idx];
-  const float4 c8 = a.cold[8 * N + idx];
+  // one 128-byte record (grid_build.hip, beam_cold_kernel)
+  const float4 *rec = a.cold + (size_t)idx * GVPM_REC_QUADS;
+  const float4 c1 = rec[0], c2 = rec[1], c3 = rec[2], c4 = rec[3], c5 = rec[4], c6 = rec[5], c7 = rec[6], c8 = rec[7];
   BeamF b;
-  b.parentPdf = c0.w;
+  b.parentPdf = c1.w;
   b.flux = mk3(c1.x, c1.y, c1.z);
   b.p1 = mk3(c2.x, c2.y, c2.z); b.parentRR = c2.w;
   b.parentN = mk3(c3.x, c3.y, c3.z); b.parentG = c3.w;
-  b.prefixW = mk3(c4.x, c4.y, c4.z);
-  b.parentScat = mk3(c5.x, c5.y, c5.z);
-  b.parentWi = mk3(c6.x, c6.y, c6.z);
+  b.prefixW = mk3(c4.x, c4.y, c4.z); b.nl0 = __float_as_uint(c4.w);
+  b.parentScat = mk3(c5.x, c5.y, c5.z); b.nl1 = __float_as_uint(c5.w);
+  b.parentWi = mk3(c6.x, c6.y, c6.z); b.nl2 = __float_as_uint(c6.w);
   b.p2 = mk3(c7.x, c7.y, c7.z); b.flags = __float_as_uint(c7.w);
   b.endN = mk3(c8.x, c8.y, c8.z);
   b.endOnSurface = !(c8.x == 0.f && c8.y == 0.f && c8.z == 0.f);
-  // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81: the length (hence the sub-beam count) is the fp64 path's
-  const d3 dD = tod(b.p2) - tod(b.p1);
-  const double lenD = sqrt(len2(dD));
-  b.len = (float)lenD;
-  b.bd = tof(dD * (1.0 / lenD));
+  // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81: the length (hence the sub-beam count) is the fp64 path's,
+  // rounded once at the build (beam_cold_kernel)
+  b.len = c8.w;
+  b.bd = tof(tod(b.p2) - tod(b.p1)) * frcp(b.len);
   return b;
 }
 
@@ -133,6 +132,7 @@ struct KRecF {
   float v, w;     // absolute parameters on the beam / on the camera ray
   float sigmaW;   // w - (camera foot parameter)
   float pdfKernel, pdfEdgeFailure, u, weightKernel;
+  float sc;       // contrib = flux * sigma_s * sc
   f3 contrib;
 };
 

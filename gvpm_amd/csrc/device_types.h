@@ -13,7 +13,8 @@ namespace gvpm {
 //     0 {pos, bits} 1 {wi, parentPdf} 2 {flux, edgePdf} 3 {parentPos, parentRR} 4 {parentN, parentG}
 //     5 {prefixW, nearOccluders} 6 {parentScat, -} 7 {parentWi, -}
 // bits = GVPM_PF_* flags of the ABI with bit 7 = pathID & 1.
-// (G-Beams keeps 9 planes of nbeams float4 in the same buffer, see gather_beams.hip.)
+// (G-Beams keeps one 128-byte record per BEAM in the same buffer -- grid_build.hip, beam_cold_kernel -- and the sorted
+// sub-beam centres in `hot`.)
 #define GVPM_HOT_PARITY_BIT 7
 // per-photon near-occluder lists (grid_build.hip, nearOccluders): 8-bit indices up to NARROW_MAX occluders, 16-bit up
 // to WIDE_MAX (the top byte of word 0 must stay below the 0xFD / 0xFE marks), extension lists beyond
@@ -62,7 +63,7 @@ struct GatherArgs {
   gvpm_params cfg;
   float radius;
   // G-Beams only: a.radius is the traversal radius (kernel radius + half a sub-beam),
-  // cold holds 9 planes of `nbeams`, hot holds the sub-beam centres {xyz, beam | sub << 24}
+  // cold holds one 128-byte record per beam, hot holds the sub-beam centres {xyz, beam | sub << 24}
   float kernelRadius;
   float subLen;              // target sub-beam length used by the build
   uint32_t nbeams;

@@ -384,12 +384,10 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
 }
 
 __device__ __forceinline__ BeamD loadBeam(const GatherArgs &a, uint32_t idx) {
-  const size_t N = a.nbeams;
-  const float4 c0 = a.cold[0 * N + idx], c1 = a.cold[1 * N + idx], c2 = a.cold[2 * N + idx], c3 = a.cold[3 * N + idx];
-  const float4 c4 = a.cold[4 * N + idx], c5 = a.cold[5 * N + idx], c6 = a.cold[6 * N + idx], c7 = a.cold[7 * N + idx];
-  const float4 c8 = a.cold[8 * N + idx];
+  const float4 *rec = a.cold + (size_t)idx * GVPM_REC_QUADS;
+  const float4 c1 = rec[0], c2 = rec[1], c3 = rec[2], c4 = rec[3], c5 = rec[4], c6 = rec[5], c7 = rec[6], c8 = rec[7];
   BeamD b;
-  b.parentPdf = c0.w;
+  b.parentPdf = c1.w;
   b.flux = mkd(c1.x, c1.y, c1.z);
   b.p1 = mkd(c2.x, c2.y, c2.z); b.parentRR = c2.w;
   b.parentN = mkd(c3.x, c3.y, c3.z); b.parentG = c3.w;
@@ -633,10 +631,20 @@ __device__ __forceinline__ bool anyHitLds(const float4 *tri, uint32_t ntri, f3 o
 
 // shiftBeamDiffuse + diffuseReconnectionPhotonBeam (shift_volume_beams.cpp:410-539, shift_diffuse.cpp:136-268) in
 // the local frame.  newPos: the offset position relative to the local origin; p1rel = p1 - origin.
+// visibility over the whole new beam [Epsilon, dist] (shift_volume_beams.cpp:420-426): the occluders listed near the
+// beam (beam_near_kernel, grid_build.hip), or all of them when the list overflowed / the scene is large
+__device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const BeamF &b, const float4 *ldsTri, f3 nd, float dist) {
+  if ((b.nl0 >> 24) == 0xFEu)
+    return ldsTri ? anyHitLds(ldsTri, a.ntri, b.p1, nd, a.cfg.epsilon, dist)
+                  : anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist);
+  return nearListHit(ldsTri ? ldsTri : a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist);
+}
+
+// kV = kRec.v, pdfKernelAndDist = kRec.pdfEdgeFailure * kRec.pdfKernel
 template <int B>
-__device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const BeamF &b, const RayReg &sh,
-                                                   const RayReg &base, uint32_t edge, const LocalRay &sr, float shiftW,
-                                                   const KRecF &k, f3 newPos, f3 p1rel, int technique,
+__device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const BeamF &b, f3 shEye, float sMIS,
+                                                   const LocalRay &sr, float shiftW,
+                                                   float kV, float pdfKernelAndDist, f3 newPos, f3 p1rel, int technique,
                                                    const float4 *ldsTri, f3 &shiftedFlux, bool &ok) {
   ok = false;
   shiftedFlux = mk3(0.f);
@@ -644,11 +652,7 @@ __device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const Be
   const float dist2 = dot(nd, nd);
   const float dist = fsqrt(dist2);
   nd = nd * frcp(dist);
-  // visibility over the whole new beam [Epsilon, dist], shift_volume_beams.cpp:420-426
-  if (ldsTri ? anyHitLds(ldsTri, a.ntri, b.p1, nd, a.cfg.epsilon, dist)
-             : anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist))
-    return 1.f;
-  const float pdfKernelAndDist = k.pdfEdgeFailure * k.pdfKernel;
+  if (beamShadowBlocked(a, b, ldsTri, nd, dist)) return 1.f;
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
   f3 thr;
   float pdfValueSA;
@@ -672,7 +676,7 @@ __device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const Be
   // pdf of the base position from the parent: parentPdf * |p1 - p2|^2 [/ |n_end . d|] / v^2
   float pdfBasePos = b.parentPdf * (b.len * b.len);
   if (b.endOnSurface) pdfBasePos = fdiv(pdfBasePos, fabsf(dot(b.endN, b.bd)));
-  pdfBasePos *= frcp(k.v * k.v);
+  pdfBasePos *= frcp(kV * kV);
   if (pdfBasePos == 0.f) return 1.f;
   thr = thr * fdiv(b.parentRR, pdfBasePos);
   if (GVPM_PF_EDGE_IN_MEDIUM(b.flags)) {
@@ -702,7 +706,7 @@ __device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const Be
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
   const MRecF mS = mediumEvalF(a.med, shiftW);
   const float ph = phaseEval(a.med.g, -nd, -sr.d) * mS.tr;
-  shiftedFlux = b.prefixW * thr * sigS * sh.eye * ph;
+  shiftedFlux = b.prefixW * thr * sigS * shEye * ph;
   ok = true;
   float w = 0.5f;
   if (a.cfg.use_mis) {
@@ -712,32 +716,103 @@ __device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const Be
       ok = false;
       return 1.f;
     }
-    const float x = sensorMIS(sh, base, edge) * fdiv(offsetPdf, basePdf);
+    const float x = sMIS * fdiv(offsetPdf, basePdf);
     w = a.cfg.power_heuristic ? frcp(1.f + x * x) : frcp(1.f + x);
   }
   return w;
 }
 
-// One (camera ray, sub-beam) candidate in fp32 (beams_eval_f32.h): BeamGradRadianceQuery::operator().
-template <int B>
-__device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s, const float4 *ldsTri, uint32_t id,
-                                              uint32_t bIdx, uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+// the shifted rays of a freshly loaded tile, in place: {o, len} -> {o_s - o_b, len}, {d, pdf} -> {d_s - d_b, sensorMIS},
+// {eye, jacobian} stays.  The differences are formed in fp64 and are exact to fp32; the base rays stay absolute.
+template <int B> __device__ __forceinline__ void relToBase(RayTile<B> &s, int lane) {
+  for (int idx = lane; idx < 4 * B; idx += 64) {
+    const int i = idx / B, bb = idx % B;
+    const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
+    const f3 dO = tof(tod(sr.o) - tod(br.o)), dD = tof(tod(sr.d) - tod(br.d));
+    const float lenSigned = s.ray4[1 + i][0][bb].w;  // the valid bit rides on its sign
+    const float sm = sensorMIS(sr, br, s.edge[bb]);
+    s.ray4[1 + i][0][bb] = make_float4(dO.x, dO.y, dO.z, lenSigned);
+    s.ray4[1 + i][1][bb] = make_float4(dD.x, dD.y, dD.z, sm);
+  }
+}
+struct ShiftRel {
+  f3 ro, rd, d, eye;  // o_s - o_b, d_s - d_b, d_s, eyeContrib
+  float len, sMIS;
+  bool valid;
+};
+template <int B> __device__ __forceinline__ ShiftRel loadShiftRel(const RayTile<B> &s, int i, int b, f3 baseD) {
+  ShiftRel r;
+  const float4 q0 = s.ray4[1 + i][0][b], q1 = s.ray4[1 + i][1][b], q2 = s.ray4[1 + i][2][b];
+  r.ro = mk3(q0.x, q0.y, q0.z);
+  r.len = fabsf(q0.w);
+  r.valid = q0.w >= 0.f;
+  r.rd = mk3(q1.x, q1.y, q1.z);
+  r.sMIS = q1.w;
+  r.d = baseD + r.rd;
+  r.eye = mk3(q2.x, q2.y, q2.z);
+  return r;
+}
+// The shifted ray seen from the local origin, from the base ray's local form (cam) and the relative ray:
+//   s0_s = s0_b + delta, delta = D0_b . relD + s0_b (d_b . relD) - relO . d_s
+//   D0_s = D0_b - relO - relD s0_b - d_s delta
+// every term is a product with a small factor, so fp32 holds them to ~1e-10; deriving them from the absolute
+// positions took a dozen fp64 operations per shift.
+__device__ __forceinline__ LocalRay shiftedLocal(const LocalRay &cam, const ShiftRel &sh, float eps, float &delta) {
+  LocalRay sr;
+  delta = dot(cam.D0, sh.rd) + cam.s0f * dot(cam.d, sh.rd) - dot(sh.ro, sh.d);
+  sr.D0 = cam.D0 - sh.ro - sh.rd * cam.s0f - sh.d * delta;
+  sr.s0 = cam.s0 + (double)delta;
+  sr.d = sh.d;
+  sr.s0f = (float)sr.s0;
+  sr.mint = eps;
+  sr.maxt = sh.len;
+  return sr;
+}
+
+// One (camera ray, sub-beam) candidate in fp32 (beams_eval_f32.h): BeamGradRadianceQuery::operator(), in two phases
+// like the G-BRE evaluation.  Phase 1 (a lane per pair): filters, kernel record, base contribution, then per offset
+// pixel the null shift (shiftNull3D) or -- only PREPARED here -- the reconnection: its offset position goes into a
+// wave-wide queue.  Phase 2 (a lane per queued reconnection, dense): shiftBeamDiffuse with its visibility test over
+// the whole new beam.  Fused, every lane of a wave walked the reconnection of every shift some lane needed: 55 % of
+// the shifts at C3, ~9100 lane-instructions per evaluation.
+struct BeamP1 {
+  BeamF b;
+  LocalRay cam;
+  KRecF k;
+  d3 O;             // local origin: the sub-beam's centre
+  f3 p1rel, kc, camW, baseContrib;
+  double wD;
+  float rr, tc;
+  uint32_t edge, pix, st, id;
+};
+// a prepared reconnection: 36 bytes
+struct BeamQ {
+  uint32_t id;  // beam | sub << 24
+  float4 p;     // offset position (local), kRec.v
+  float4 s;     // kRec.w, kRec.pdfEdgeFailure * kRec.pdfKernel, rr * weightKernel * sc, bits(ray | shift << 8)
+};
+
+// filters + kernel record + base contribution; false: the pair produces nothing
+template <int B, typename LDS>
+__device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t id, uint32_t bIdx, BeamP1 &o) {
   const uint32_t beamIdx = id & 0xFFFFFFu, sub = id >> 24;
-  const BeamF b = loadBeamF(a, beamIdx);
+  o.id = id;
+  o.b = loadBeamF(a, beamIdx);
+  const BeamF &b = o.b;
   const RayReg base = loadRay(s, 0, bIdx);
-  const uint32_t edge = s.edge[bIdx];
-  const uint32_t pix = s.pix[bIdx];
-  const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
+  o.edge = s.edge[bIdx];
+  o.pix = s.pix[bIdx];
+  const int px = (int)(o.pix & 0xFFFFu), py = (int)(o.pix >> 16);
   const int technique = a.cfg.vol_technique;
   const bool is1D = technique == GVPM_BEAM_BEAM_1D;
   // filters, shift_volume_beams.cpp:142-184
-  const int pathLength = (int)edge + (int)GVPM_PF_DEPTH(b.flags);
+  const int pathLength = (int)o.edge + (int)GVPM_PF_DEPTH(b.flags);
   if (a.cfg.max_depth > 0 && pathLength > a.cfg.max_depth) return false;
   if (!((b.flags >> 6) & 1u)) return false;
-  float rr = 1.f;
+  o.rr = 1.f;
   if (a.cfg.path_set) {
     if (((b.flags >> GVPM_HOT_PARITY_BIT) & 1u) != (uint32_t)((px + py) & 1)) return false;
-    rr = 2.f;
+    o.rr = 2.f;
   }
   const float r = a.kernelRadius, eps = a.cfg.epsilon;
   const uint32_t nSub = subBeamCount(b.len, a.subLen);
@@ -745,12 +820,13 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
   const float tmin = ls * (float)sub;
   const float tmax = (sub + 1u >= nSub) ? b.len : fminf(ls * (float)(sub + 1u), b.len);
   const float tc = ls * ((float)sub + 0.5f);
+  o.tc = tc;
   // local origin: the sub-beam's centre, kept in fp64 so that it lies on the beam's line
   const d3 p1D = tod(b.p1);
-  const d3 O = p1D + (tod(b.p2) - p1D) * ((double)tc / (double)b.len);
-  LocalRay cam;
+  o.O = p1D + (tod(b.p2) - p1D) * (double)(tc * frcp(b.len));
+  LocalRay &cam = o.cam;
   {
-    const d3 c = O - tod(base.o), dd = tod(base.d);
+    const d3 c = o.O - tod(base.o), dd = tod(base.d);
     cam.s0 = dot(c, dd);
     cam.D0 = tof(c - dd * cam.s0);
     cam.d = base.d;
@@ -758,7 +834,7 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
     cam.mint = eps;
     cam.maxt = base.len - eps;
   }
-  const f3 p1rel = b.bd * (-tc);
+  o.p1rel = b.bd * (-tc);
   const float bdd = dot(b.bd, base.d);
   const float sin2 = fmaxf(1.f - bdd * bdd, 0.f);
   uint32_t o0, o1;
@@ -767,7 +843,7 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
   const float uw = (float)(o1 >> 8) * (1.0f / 16777216.0f);
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
 
-  KRecF k;
+  KRecF &k = o.k;
   k.u = 0.f;
   const float band0 = 2e-6f * (r + ls) * frcp(fmaxf(sin2, 1e-12f));
   if (is1D) {
@@ -802,6 +878,7 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
     k.pdfEdgeFailure = mB.pdfFailure;
     if (mB.pdfFailure == 0.f && mB.tr != 0.f) return false;
     const float sc = fdiv(mB.tr * mCam.tr * phaseEval(a.med.g, -b.bd, -base.d), mB.pdfFailure * k.pdfKernel);
+    k.sc = sc;
     k.contrib = sigS * b.flux * sc;
   } else {
     // BeamKernelRecord::eval, shift_volume_beams.h:157-290
@@ -831,6 +908,7 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
     const MRecF mB = mediumEvalF(a.med, k.v), mCam = mediumEvalF(a.med, k.w);
     const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
     const float sc = fdiv(mB.tr * mCam.tr * phaseEval(a.med.g, -b.bd, -base.d), k.pdfKernel * mB.pdfFailure);
+    k.sc = sc;
     k.contrib = b.flux * sigS * sc;
     k.weightKernel = frcp(kernelVol);
     k.pdfEdgeFailure = mB.pdfFailure;
@@ -838,126 +916,190 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
   if (k.contrib.x == 0.f && k.contrib.y == 0.f && k.contrib.z == 0.f) return false;
   if (!(k.contrib.x == k.contrib.x)) return false;
 
-  const f3 baseContrib = base.eye * k.contrib * k.weightKernel;
-  atomicAdd(&s.acc[0][bIdx], (double)(baseContrib.x * rr));
-  atomicAdd(&s.acc[1][bIdx], (double)(baseContrib.y * rr));
-  atomicAdd(&s.acc[2][bIdx], (double)(baseContrib.z * rr));
-  const uint32_t st = GVPM_PF_SHIFT_TYPE(b.flags);
+  o.baseContrib = base.eye * k.contrib * k.weightKernel;
+  atomicAdd(&s.acc[0][bIdx], (double)(o.baseContrib.x * o.rr));
+  atomicAdd(&s.acc[1][bIdx], (double)(o.baseContrib.y * o.rr));
+  atomicAdd(&s.acc[2][bIdx], (double)(o.baseContrib.z * o.rr));
+  o.st = GVPM_PF_SHIFT_TYPE(b.flags);
   if (a.cfg.debug_shift != GVPM_SHIFT_ALL && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
+    const uint32_t st = o.st;
     const int cur = st == 1u ? GVPM_SHIFT_DIFFUSE : st == 2u ? GVPM_SHIFT_MEDIUM : st == 3u ? GVPM_SHIFT_MANIFOLD : GVPM_SHIFT_INVALID;
-    if (a.cfg.debug_shift != cur) return false;  // base contribution kept, no shifts (shift_volume_beams.cpp:210-216)
+    if (a.cfg.debug_shift != cur) o.st = 0xFFu;  // base contribution kept, no shifts (shift_volume_beams.cpp:210-216)
   }
-  const double wD = cam.s0 + (double)k.sigmaW;
-  const f3 kc = b.bd * k.tauV;                 // kernel centre on the beam, local
-  const f3 camW = atLocal(cam, k.sigmaW);      // camera ray at w, local
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    const RayReg sh = loadRay(s, 1 + i, bIdx);
-    float w = 1.f;
-    f3 sflux = mk3(0.f);
-    if (sh.valid) {
-      const float shiftDistMAX = sh.len;
-      LocalRay sr;
-      {
-        const d3 c = O - tod(sh.o), dd = tod(sh.d);
-        sr.s0 = dot(c, dd);
-        sr.D0 = tof(c - dd * sr.s0);
-        sr.d = sh.d;
-        sr.s0f = (float)sr.s0;
-        sr.mint = eps;
-        sr.maxt = shiftDistMAX;
-      }
-      const float sigS_w = (float)(wD - sr.s0);  // the same distance w on the shifted ray, from its foot point
-      const f3 shW = atLocal(sr, sigS_w);
-      bool alreadyShift = false;
-      if (a.cfg.use_shift_null && !is1D) {
-        const f3 dz = shW - kc;
-        if (dot(dz, dz) < r * r && k.w <= shiftDistMAX) {
-          // BeamKernelRecord copy-shift constructor (shift_volume_beams.h:40-144) + shiftNull3D (.cpp:748-786)
-          float tN, tF;
-          const float z0 = (float)((double)eps - sr.s0), z1 = (float)((double)shiftDistMAX - sr.s0);
-          if (cylLocal(sr.D0, b.bd, sr.d, z0, z1, r, -tc, b.len - tc, tN, tF)) {
-            float pdfK = frcp(fmaxf(tF - tN, 0.0001f));
-            const float bds = dot(b.bd, sr.d);
-            f3 perp = sr.D0 + (b.bd - sr.d * bds) * k.tauV;
-            perp = perp - sr.d * dot(perp, sr.d);
-            const float distSqr = dot(perp, perp), radSqr = r * r;
-            if (distSqr < radSqr && !(k.w < sr.mint || k.w > sr.maxt)) {
-              pdfK *= frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
-              nNull++;
-              sflux = k.contrib * sh.eye;  // kS.contrib * kpdf(kS) / kpdf(kRec): the pdf ratios cancel
-              w = 0.5f;
-              if (a.cfg.use_mis) {
-                const float x = sensorMIS(sh, base, edge) * fdiv(pdfK, k.pdfKernel);
-                w = a.cfg.power_heuristic ? frcp(1.f + x * x) : frcp(1.f + x);
-              }
-              alreadyShift = true;
+  o.wD = cam.s0 + (double)k.sigmaW;
+  o.kc = b.bd * k.tauV;                 // kernel centre on the beam, local
+  o.camW = atLocal(cam, k.sigmaW);      // camera ray at w, local
+  return true;
+}
+
+// the border rule: no reverse shift at the right and top borders, shift_volume_beams.cpp (as the photon functors)
+__device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, int i) {
+  const int px = (int)(pix & 0xFFFFu), py = (int)(pix >> 16);
+  return (i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1);
+}
+
+// shift i of a pair that passed beamBase: the null shift is evaluated here, a reconnection is returned in q (push)
+template <int B, typename LDS>
+__device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const BeamP1 &o, uint32_t bIdx, int i, bool &push,
+                                           BeamQ &q, uint32_t &nNull, uint32_t &nFail) {
+  push = false;
+  if (o.st == 0xFFu) return;
+  const BeamF &b = o.b;
+  const KRecF &k = o.k;
+  const LocalRay &cam = o.cam;
+  const int technique = a.cfg.vol_technique;
+  const bool is1D = technique == GVPM_BEAM_BEAM_1D;
+  const float r = a.kernelRadius, eps = a.cfg.epsilon;
+  const ShiftRel sh = loadShiftRel(s, i, bIdx, cam.d);
+  float w = 1.f;
+  f3 sflux = mk3(0.f);
+  if (sh.valid) {
+    const float shiftDistMAX = sh.len;
+    float delta;
+    const LocalRay sr = shiftedLocal(cam, sh, eps, delta);
+    const float sigS_w = k.sigmaW - delta;  // the same distance w on the shifted ray, from its foot point
+    const f3 shW = atLocal(sr, sigS_w);
+    bool alreadyShift = false;
+    if (a.cfg.use_shift_null && !is1D) {
+      const f3 dz = shW - o.kc;
+      if (dot(dz, dz) < r * r && k.w <= shiftDistMAX) {
+        // BeamKernelRecord copy-shift constructor (shift_volume_beams.h:40-144) + shiftNull3D (.cpp:748-786)
+        float tN, tF;
+        const float z0 = (float)((double)eps - sr.s0), z1 = (float)((double)shiftDistMAX - sr.s0);
+        if (cylLocal(sr.D0, b.bd, sr.d, z0, z1, r, -o.tc, b.len - o.tc, tN, tF)) {
+          float pdfK = frcp(fmaxf(tF - tN, 0.0001f));
+          const float bds = dot(b.bd, sr.d);
+          f3 perp = sr.D0 + (b.bd - sr.d * bds) * k.tauV;
+          perp = perp - sr.d * dot(perp, sr.d);
+          const float distSqr = dot(perp, perp), radSqr = r * r;
+          if (distSqr < radSqr && !(k.w < sr.mint || k.w > sr.maxt)) {
+            pdfK *= frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
+            nNull++;
+            sflux = k.contrib * sh.eye;  // kS.contrib * kpdf(kS) / kpdf(kRec): the pdf ratios cancel
+            w = 0.5f;
+            if (a.cfg.use_mis) {
+              const float x = sh.sMIS * fdiv(pdfK, k.pdfKernel);
+              w = a.cfg.power_heuristic ? frcp(1.f + x * x) : frcp(1.f + x);
             }
+            alreadyShift = true;
           }
         }
       }
-      if (!alreadyShift && k.w <= shiftDistMAX) {
-        bool doShift = true;
-        f3 offsetPos;
-        if (!is1D) {
-          // distance of the beam's origin to the shifted ray against kRec.u (= 0 for the 3D kernel)
-          f3 pv = p1rel + sr.D0;
-          pv = pv - sr.d * dot(pv, sr.d);
-          if (dot(pv, pv) > k.u * k.u) {
-            // getShiftPos (3D), shift_volume_beams.cpp:93-137: the kernel offset in the base ray's coherent frame,
-            // replayed in the shifted ray's
-            const f3 u = kc - camW;
-            f3 bs, bt, ns, nt;
-            coordSysCoherentF(base.d, bs, bt);
-            coordSysCoherentF(sr.d, ns, nt);
-            const float lx = dot(u, bs), ly = dot(u, bt), lz = dot(u, base.d);
-            offsetPos = shW + (ns * lx + nt * ly + sr.d * lz);
-            if (a.cfg.use_shift_null) {
-              const f3 dv = camW - offsetPos;
-              if (dot(dv, dv) < r * r) {
-                f3 dShift = shW - camW;
-                dShift = dShift * frsq(dot(dShift, dShift));
-                const float cosD = dot(dShift, shW - offsetPos);
-                offsetPos = offsetPos + dShift * (cosD * 2.0f);
-              }
+    }
+    if (!alreadyShift && k.w <= shiftDistMAX) {
+      bool doShift = true;
+      f3 offsetPos = mk3(0.f);
+      if (!is1D) {
+        // distance of the beam's origin to the shifted ray against kRec.u (= 0 for the 3D kernel)
+        f3 pv = o.p1rel + sr.D0;
+        pv = pv - sr.d * dot(pv, sr.d);
+        if (dot(pv, pv) > k.u * k.u) {
+          // getShiftPos (3D), shift_volume_beams.cpp:93-137: the kernel offset in the base ray's coherent frame,
+          // replayed in the shifted ray's
+          const f3 u = o.kc - o.camW;
+          f3 bs, bt, ns, nt;
+          coordSysCoherentF(cam.d, bs, bt);
+          coordSysCoherentF(sr.d, ns, nt);
+          const float lx = dot(u, bs), ly = dot(u, bt), lz = dot(u, cam.d);
+          offsetPos = shW + (ns * lx + nt * ly + sr.d * lz);
+          if (a.cfg.use_shift_null) {
+            const f3 dv = o.camW - offsetPos;
+            if (dot(dv, dv) < r * r) {
+              f3 dShift = shW - o.camW;
+              dShift = dShift * frsq(dot(dShift, dShift));
+              const float cosD = dot(dShift, shW - offsetPos);
+              offsetPos = offsetPos + dShift * (cosD * 2.0f);
             }
-          } else {
-            doShift = false;
           }
         } else {
-          // getShiftPos1D, shift_volume_beams.cpp:81-91
-          const f3 aCam = p1rel + cam.D0;  // p1 from the base ray's foot point
-          f3 back = shiftPointLocal(base.d, aCam, k.u, k.sigmaW, false) - aCam;
-          back = back * frsq(dot(back, back));
-          const f3 df = back - b.bd;
-          const bool flip = dot(df, df) > 0.001f;
-          offsetPos = shiftPointLocal(sr.d, p1rel + sr.D0, k.u, sigS_w, flip) - sr.D0;
+          doShift = false;
         }
-        if (doShift) {
-          if (a.cfg.debug_shift == GVPM_SHIFT_NULL || k.w > sr.maxt) {
-            w = 1.f;
-          } else {
-            bool ok = false;
-            if (st == 1u || st == 2u)
-              w = shiftBeamDiffuseF<B>(a, b, sh, base, edge, sr, k.w, k, offsetPos, p1rel, technique, ldsTri, sflux, ok);
-            if (ok) nDiff++; else nFail++;
-          }
+      } else {
+        // getShiftPos1D, shift_volume_beams.cpp:81-91
+        const f3 aCam = o.p1rel + cam.D0;  // p1 from the base ray's foot point
+        f3 back = shiftPointLocal(cam.d, aCam, k.u, k.sigmaW, false) - aCam;
+        back = back * frsq(dot(back, back));
+        const f3 df = back - b.bd;
+        const bool flip = dot(df, df) > 0.001f;
+        offsetPos = shiftPointLocal(sr.d, o.p1rel + sr.D0, k.u, sigS_w, flip) - sr.D0;
+      }
+      if (doShift) {
+        if (a.cfg.debug_shift == GVPM_SHIFT_NULL || k.w > sr.maxt) {
+          w = 1.f;
+        } else if (o.st == 1u || o.st == 2u) {
+          // shiftBeamDiffuse: phase 2.  The weighted base term of this shift is added there too.
+          push = true;
+          q.id = o.id;
+          q.p = make_float4(offsetPos.x, offsetPos.y, offsetPos.z, k.v);
+          // base.eye * k.contrib * weightKernel * rr = (base.eye * flux * sigS) * (sc * weightKernel * rr): the scalar is carried
+          q.s = make_float4(k.w, k.pdfEdgeFailure * k.pdfKernel, k.sc * k.weightKernel * o.rr,
+                            __uint_as_float(bIdx | ((uint32_t)i << 8)));
+          return;
+        } else {
+          nFail++;
         }
       }
     }
-    if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
-    const float ws = w * rr;
-    if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-      const float wk = ws * k.weightKernel;
-      atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (double)(sflux.x * wk));
-      atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (double)(sflux.y * wk));
-      atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (double)(sflux.z * wk));
-    }
-    atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (double)(baseContrib.x * ws));
-    atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (double)(baseContrib.y * ws));
-    atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (double)(baseContrib.z * ws));
   }
-  return true;
+  if (beamBorder(a, o.pix, i)) w = 1.f;
+  const float ws = w * o.rr;
+  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+    const float wk = ws * k.weightKernel;
+    atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (double)(sflux.x * wk));
+    atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (double)(sflux.y * wk));
+    atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (double)(sflux.z * wk));
+  }
+  atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (double)(o.baseContrib.x * ws));
+  atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (double)(o.baseContrib.y * ws));
+  atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (double)(o.baseContrib.z * ws));
+}
+
+// phase 2: one prepared reconnection (shiftBeamDiffuse) -> the shifted and the weighted sums of its (ray, shift)
+template <int B, typename LDS>
+__device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const BeamQ &q, const float4 *ldsTri,
+                                           uint32_t &nDiff, uint32_t &nFail) {
+  const uint32_t beamIdx = q.id & 0xFFFFFFu, sub = q.id >> 24;
+  const uint32_t meta = __float_as_uint(q.s.w);
+  const uint32_t bIdx = meta & 0xFFu;
+  const int i = (int)(meta >> 8);
+  const BeamF b = loadBeamF(a, beamIdx);
+  const RayReg base = loadRay(s, 0, bIdx);
+  const uint32_t nSub = subBeamCount(b.len, a.subLen);
+  const float ls = b.len / (float)nSub;
+  const float tc = ls * ((float)sub + 0.5f);
+  const d3 p1D = tod(b.p1);
+  const d3 O = p1D + (tod(b.p2) - p1D) * (double)(tc * frcp(b.len));  // (the expression of beamBase: same origin)
+  LocalRay cam;
+  {
+    const d3 c = O - tod(base.o), dd = tod(base.d);
+    cam.s0 = dot(c, dd);
+    cam.D0 = tof(c - dd * cam.s0);
+    cam.d = base.d;
+    cam.s0f = (float)cam.s0;
+  }
+  const ShiftRel sh = loadShiftRel(s, i, bIdx, base.d);
+  float delta;
+  const LocalRay sr = shiftedLocal(cam, sh, a.cfg.epsilon, delta);
+  bool ok = false;
+  f3 sflux;
+  float w = shiftBeamDiffuseF<B>(a, b, sh.eye, sh.sMIS, sr, q.s.x, q.p.w, q.s.y, mk3(q.p.x, q.p.y, q.p.z), b.bd * (-tc),
+                                 a.cfg.vol_technique, ldsTri, sflux, ok);
+  if (ok) nDiff++; else nFail++;
+  if (beamBorder(a, s.pix[bIdx], i)) w = 1.f;
+  const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  const f3 bcv = base.eye * b.flux * sigS * q.s.z;
+  // rr * weightKernel: the same for every pair of a launch (shift_volume_beams.h: 0.5 / r, or 1 / (4/3 pi r^3))
+  const float rK = a.kernelRadius;
+  const float wkrr = (a.cfg.path_set ? 2.f : 1.f) *
+                     (a.cfg.vol_technique == GVPM_BEAM_BEAM_1D ? 0.5f * frcp(rK) : frcp((4.0f / 3.0f) * 3.14159265358979323846f * rK * rK * rK));
+  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+    atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (double)(sflux.x * (w * wkrr)));
+    atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (double)(sflux.y * (w * wkrr)));
+    atomicAdd(&s.acc[3 + 3 * i + 2][bIdx], (double)(sflux.z * (w * wkrr)));
+  }
+  atomicAdd(&s.acc[15 + 3 * i + 0][bIdx], (double)(bcv.x * w));
+  atomicAdd(&s.acc[15 + 3 * i + 1][bIdx], (double)(bcv.y * w));
+  atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (double)(bcv.z * w));
 }
 
 
@@ -972,10 +1114,13 @@ __device__ __forceinline__ bool evaluateBeamF(const GatherArgs &a, TileLds<B> &s
 // (a stage of 128: the one-layer slab boxes hold ~100 sub-beams, and 6 KB of LDS per wave instead of 10 leaves room
 // for more resident waves, which is what hides the per-slab latency chain)
 constexpr int BSTAGE = GVPM_BSTAGE;
+constexpr int BCQ = 512;  // sphere-test survivors waiting for the prefilter (a group adds at most 4 x 64, 63 wait; power of 2)
 struct BeamTravLds {
   float4 st0[BSTAGE], st1[BSTAGE];
   uint32_t stF[BSTAGE];
   uint2 outq[QCAP];
+  float4 rayO[64], rayD[64];  // the tile's base rays {o, len} {d, -}: a candidate is resolved by ANY lane
+  uint16_t candq[BCQ];        // staged record | ray << 8
 };
 
 template <int B>
@@ -1015,8 +1160,10 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
     firstItem = false;
     if (it >= nItems) break;
     const uint4 item = items[it];
-    const uint32_t setBase = item.x, nb = item.y;
+    // a heavy item comes as `parts` items that take its staging windows round-robin (plan_kernel)
+    const uint32_t setBase = item.x, nb = item.y & 0xFFu, part = (item.y >> 8) & 0xFFFu, parts = max(item.y >> 20, 1u);
     if (nb == 0) continue;
+    uint32_t winIdx = 0;  // staging windows of the item so far (wave-uniform)
     BaseInfo bi;
     const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
     TileWalk w;
@@ -1048,6 +1195,44 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
       qHead = (qHead + n) % QCAP;
       qCount -= n;
     };
+    __syncthreads();
+    if (sub == 0) {
+      s.rayO[b] = make_float4(base.o.x, base.o.y, base.o.z, base.len);
+      s.rayD[b] = make_float4(base.d.x, base.d.y, base.d.z, 0.f);
+    }
+    __syncthreads();
+    uint32_t cHead = 0, cCount = 0;  // candidate ring, wave-uniform
+    auto resolve = [&](uint32_t n) {  // n <= 64 candidates: ownership prefilter, survivors -> the pair ring
+      __syncthreads();
+      bool keep = false;
+      uint32_t id = 0, rb = 0;
+      if ((uint32_t)lane < n) {
+        const uint32_t c = s.candq[(cHead + (uint32_t)lane) % BCQ];
+        const uint32_t j = c & 0xFFu;
+        rb = c >> 8;
+        const float4 h0 = s.st0[j], h1 = s.st1[j], ro = s.rayO[rb], rd = s.rayD[rb];
+        id = __float_as_uint(h0.w);
+        RayReg ray;
+        ray.o = mk3(ro.x, ro.y, ro.z);
+        ray.d = mk3(rd.x, rd.y, rd.z);
+        ray.len = ro.w;
+        keep = beamPrefilter(ray, mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z), h1.w, id >> 24, r, eps, technique);
+      }
+      nCand += n;
+      cHead = (cHead + n) % BCQ;
+      cCount -= n;
+      const unsigned long long km = __ballot(keep);
+      if (km) {
+        if (keep)
+          s.outq[(qHead + qCount + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) % QCAP] = make_uint2(id, setBase + rb);
+        qCount += (uint32_t)__popcll(km);
+        if (qCount >= 64u) {
+          __syncthreads();
+          emit(64u);
+          __syncthreads();
+        }
+      }
+    };
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
       const int cAe = min(cA + w.K - 1, cEnd);
@@ -1061,6 +1246,7 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
         const uint32_t excl = incl - count;
         const uint32_t total = __shfl(incl, 63, 64);
         for (uint32_t win = 0; win < total; win += BSTAGE) {
+          if (winIdx++ % parts != part) continue;
           __syncthreads();
           const uint32_t nst = min((uint32_t)BSTAGE, total - win);
           // Staging: entry k of the window is element win + k of the concatenated ranges.  Consecutive LANES take
@@ -1110,31 +1296,23 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
                   cm |= 1u << u;
               }
             }
-            unsigned long long any = __ballot(cm != 0u);
-            while (any) {
-              const bool active = cm != 0u;
-              const uint32_t j = min((jj + (active ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)BSTAGE - 1u);
-              cm &= cm - 1u;
-              nCand += __popcll(any);
-              const float4 h0 = s.st0[j], h1 = s.st1[j];
-              const uint32_t id = __float_as_uint(h0.w);
-              bool keep = active;
-              keep = keep && beamPrefilter(base, mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z), h1.w, id >> 24, r, eps, technique);
-              const unsigned long long km = __ballot(keep);
-              if (km) {
-                if (keep)
-                  s.outq[(qHead + qCount + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))) % QCAP] =
-                      make_uint2(id, setBase + (uint32_t)b);
-                qCount += (uint32_t)__popcll(km);
-                if (qCount >= 64u) {
-                  __syncthreads();
-                  emit(64u);
-                  __syncthreads();
-                }
-              }
-              any = __ballot(cm != 0u);
+            // the survivors (a few per cent of the tests, scattered over the lanes) are compacted into a candidate
+            // ring and go through the ownership prefilter 64 at a time, one per lane whatever ray they belong to:
+            // resolved in place -- every lane looping over its own marks -- a round ran the ~100 instructions of
+            // the prefilter for the one lane in ten that had a mark
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {
+              const bool bit = (cm >> u) & 1u;
+              const unsigned long long m = __ballot(bit);
+              if (bit)
+                s.candq[(cHead + cCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BCQ] =
+                    (uint16_t)(((jj + u) * LPB + sub) | ((uint32_t)b << 8));
+              cCount += (uint32_t)__popcll(m);
             }
+            while (cCount >= 64u) resolve(64u);
           }
+          // the stage is about to be overwritten: the candidates that refer to it go first
+          while (cCount) resolve(min(cCount, 64u));
         }
       }
     }
@@ -1154,28 +1332,21 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
   if (lane == 0 && nCand) atomicAdd(&statRow(a)[1], nCand);
 }
 
-// ---- evaluation: one pair per lane, blocks of 64 pairs of one tile --------------------------------------------
-// The block's camera-beam sets (at most B consecutive sorted sets) are loaded into LDS, the lanes evaluate their
-// pairs (fp32 local-frame evaluation, or the literal fp64 one when EXACT) into the block's LDS accumulators, and
-// the touched accumulators go to the film with one global atomic each.
+// ---- evaluation, literal fp64 path (GVPM_BEAMS_FP64=1: the on-device cross-check) ------------------------------
+// One pair per lane, blocks of 64 pairs of one tile.  The block's camera-beam sets (at most B consecutive sorted
+// sets) are loaded into LDS, the lanes evaluate their pairs (evaluateBeam: the reference transcribed in fp64) into
+// the block's LDS accumulators, and the touched accumulators go to the film with one global atomic each.
 // The blocks arrive sorted by tile (radix sort of the block keys on the host side of the launch), and a wave takes
 // RUN consecutive blocks at a time: the tile's rays are loaded, the accumulators zeroed and flushed once per tile
 // and run instead of once per block (that bookkeeping was 3.2 of the kernel's 5.9 ms at the probe).
-template <int B, bool EXACT>
-__global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
-                                                                           const uint32_t *__restrict__ sortedKey,
-                                                                           const uint32_t *__restrict__ sortedBlock,
-                                                                           uint32_t nBlocks, uint32_t *queueHead) {
+template <int B>
+__global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
+                                                                     const uint32_t *__restrict__ sortedKey,
+                                                                     const uint32_t *__restrict__ sortedBlock,
+                                                                     uint32_t nBlocks, uint32_t *queueHead) {
   constexpr uint32_t RUN = 8;
   __shared__ TileLds<B> s;
-  __shared__ float4 sceneTri[EXACT ? 1 : 3 * SCENE_LDS_TRIS];
   const int lane = threadIdx.x;
-  const float4 *ldsTri = nullptr;
-  if (!EXACT && a.ntri <= SCENE_LDS_TRIS) {
-    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
-    ldsTri = sceneTri;
-    __syncthreads();
-  }
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
   auto flushTile = [&]() {
@@ -1221,10 +1392,136 @@ __global__ __launch_bounds__(64, (EXACT || B == 64) ? 1 : 2) void evaluate_beams
       const uint2 e = pairs[(size_t)sortedBlock[bi] * 64u + lane];
       const bool live = e.x != 0xFFFFFFFFu && e.y >= setBase && e.y - setBase < curNb;
       if (live) {
-        if (EXACT ? evaluateBeam<B>(a, s, e.x, e.y - setBase, nNull, nDiff, nFail)
-                  : evaluateBeamF<B>(a, s, ldsTri, e.x, e.y - setBase, nNull, nDiff, nFail))
-          nEval++;
+        if (evaluateBeam<B>(a, s, e.x, e.y - setBase, nNull, nDiff, nFail)) nEval++;
       }
+    }
+    flushTile();
+    curBase = 0xFFFFFFFFu;
+  }
+  {
+    unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ev += __shfl_xor(ev, o, 64);
+      nu += __shfl_xor(nu, o, 64);
+      di += __shfl_xor(di, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+    }
+    if (lane == 0 && ev) {
+      atomicAdd(&statRow(a)[0], ev);
+      atomicAdd(&statRow(a)[2], nu);
+      atomicAdd(&statRow(a)[3], di);
+      atomicAdd(&statRow(a)[4], fa);
+    }
+  }
+}
+
+// ---- evaluation, fp32 path: two phases ----------------------------------------------------------------------------
+// As above (blocks of 64 pairs sorted by tile, RUN blocks per reservation), but a block goes through phase 1 only
+// (beamBase + beamShift1: kernel record, base contribution, null shifts); the reconnections it needs are appended to
+// a wave-wide LDS ring (ballot + popcount; 40 bytes each) and run 64 at a time through phase 2 (beamShift2) whenever
+// the ring holds a full wave of them, and completely before the tile's accumulators are flushed.
+constexpr int BQCAP = 320;  // a block appends at most 4 x 64, at most 63 wait from the block before
+// LDS is what bounds this kernel's residency (245 VGPRs allow 8 waves per CU): the shifted rays of the tile are kept
+// RELATIVE to their base ray in the ray tile's own slots (relToBase), the queue entries are 36 bytes.
+template <int B> struct BeamEvalLds : RayTile<B> {
+  double acc[27][B];
+  uint32_t qid[BQCAP];              // beam | sub << 24
+  float4 qp[BQCAP], qs[BQCAP];      // {offset position (local), kRec.v} {kRec.w, pdfEdgeFailure * pdfKernel, scale, ray | shift << 8}
+};
+
+template <int B>
+__global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
+                                                                             const uint32_t *__restrict__ sortedKey,
+                                                                             const uint32_t *__restrict__ sortedBlock,
+                                                                             uint32_t nBlocks, uint32_t *queueHead) {
+  constexpr uint32_t RUN = 8;
+  __shared__ BeamEvalLds<B> s;
+  extern __shared__ float4 sceneTri[];  // occluders of a small scene (dynamic: 48 bytes each, none for larger scenes)
+  const int lane = threadIdx.x;
+  const float4 *ldsTri = nullptr;
+  if (a.ntri <= SCENE_LDS_TRIS) {
+    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
+    ldsTri = sceneTri;
+    __syncthreads();
+  }
+  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+  uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
+  uint32_t qHead = 0, qCount = 0;  // wave-uniform
+  auto drain = [&](uint32_t n) {   // n <= 64 entries of the ring through phase 2
+    __syncthreads();
+    if ((uint32_t)lane < n) {
+      const uint32_t e = (qHead + (uint32_t)lane) % BQCAP;
+      BeamQ q;
+      q.id = s.qid[e];
+      q.p = s.qp[e];
+      q.s = s.qs[e];
+      beamShift2<B>(a, s, q, ldsTri, nDiff, nFail);
+    }
+    qHead = (qHead + n) % BQCAP;
+    qCount -= n;
+  };
+  auto flushTile = [&]() {
+    while (qCount) drain(min(qCount, 64u));
+    __syncthreads();
+    if (curBase != 0xFFFFFFFFu) {
+      for (int idx = lane; idx < 27 * B; idx += 64) {
+        const int k = idx / B, bb = idx % B;
+        if ((uint32_t)bb < curNb) {
+          const float v = (float)s.acc[k][bb];
+          if (v != 0.f) {
+            const uint32_t pv = s.pix[bb];
+            const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+            atomicAdd(&a.iter[p * 27 + k], v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  bool firstItem = true;
+  for (;;) {
+    uint32_t run = blockIdx.x;
+    if (!firstItem) {
+      if (lane == 0) run = gridDim.x + atomicAdd(queueHead, 1u);
+      run = __shfl(run, 0, 64);
+    }
+    firstItem = false;
+    const uint32_t b0 = run * RUN;
+    if (b0 >= nBlocks) break;
+    const uint32_t b1 = min(nBlocks, b0 + RUN);
+    for (uint32_t bi = b0; bi < b1; ++bi) {
+      const uint32_t setBase = sortedKey[bi];
+      if (setBase != curBase) {
+        flushTile();
+        curBase = setBase;
+        curNb = min((uint32_t)B, a.nsets - setBase);
+        loadTileRays<B>(a, s, setBase, curNb, lane);
+        for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+        relToBase<B>(s, lane);
+        __syncthreads();
+      }
+      const uint2 e = pairs[(size_t)sortedBlock[bi] * 64u + lane];
+      const bool live = e.x != 0xFFFFFFFFu && e.y >= setBase && e.y - setBase < curNb;
+      const uint32_t bIdx = e.y - setBase;
+      BeamP1 st;
+      const bool alive = live && beamBase<B>(a, s, e.x, bIdx, st);
+      if (alive && st.st != 0xFFu) nEval++;  // (debugShift mismatch: base contribution kept, not an evaluation -- as the reference returns)
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        bool push = false;
+        BeamQ q;
+        if (alive) beamShift1<B>(a, s, st, bIdx, i, push, q, nNull, nFail);
+        const unsigned long long m = __ballot(push);
+        if (push) {
+          const uint32_t slot = (qHead + qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BQCAP;
+          s.qid[slot] = q.id;
+          s.qp[slot] = q.p;
+          s.qs[slot] = q.s;
+        }
+        qCount += (uint32_t)__popcll(m);
+      }
+      while (qCount >= 64u) drain(64u);
     }
     flushTile();
     curBase = 0xFFFFFFFFu;
@@ -1262,20 +1559,21 @@ void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, co
                            const uint32_t *sortedBlock, uint32_t nBlocks, uint32_t *queueHead, uint32_t nwaves,
                            hipStream_t stream) {
   if (a.nsets == 0 || nBlocks == 0) return;
-#define GVPM_LAUNCH_BEAMS(BB, EX) \
-  hipLaunchKernelGGL((evaluate_beams_kernel<BB, EX>), dim3(nwaves), dim3(64), 0, stream, a, pairs, sortedKey, sortedBlock, \
+#define GVPM_LAUNCH_BEAMS(BB) \
+  hipLaunchKernelGGL((evaluate_beams_exact_kernel<BB>), dim3(nwaves), dim3(64), 0, stream, a, pairs, sortedKey, sortedBlock, \
                      nBlocks, queueHead)
   if (exact) {
     switch (beamsPerWave) {
-      case 64: GVPM_LAUNCH_BEAMS(64, true); break;
-      case 32: GVPM_LAUNCH_BEAMS(32, true); break;
-      default: GVPM_LAUNCH_BEAMS(16, true); break;
+      case 64: GVPM_LAUNCH_BEAMS(64); break;
+      case 32: GVPM_LAUNCH_BEAMS(32); break;
+      default: GVPM_LAUNCH_BEAMS(16); break;
     }
   } else {
+    const size_t dyn = a.ntri <= SCENE_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
     switch (beamsPerWave) {
-      case 64: GVPM_LAUNCH_BEAMS(64, false); break;
-      case 32: GVPM_LAUNCH_BEAMS(32, false); break;
-      default: GVPM_LAUNCH_BEAMS(16, false); break;
+      case 64: hipLaunchKernelGGL((evaluate_beams2_kernel<64>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
+      case 32: hipLaunchKernelGGL((evaluate_beams2_kernel<32>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
+      default: hipLaunchKernelGGL((evaluate_beams2_kernel<16>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
     }
   }
 #undef GVPM_LAUNCH_BEAMS
@@ -1331,7 +1629,7 @@ __global__ __launch_bounds__(256) void sub_hot_kernel(const float *__restrict__ 
   if (j >= n) return;
   const uint32_t src = order[j];
   const uint32_t id = ids[src], beam = id & 0xFFFFFFu;
-  const float4 c2 = cold[2 * (size_t)nbeams + beam], c7 = cold[7 * (size_t)nbeams + beam];
+  const float4 c2 = cold[(size_t)beam * GVPM_REC_QUADS + 1], c7 = cold[(size_t)beam * GVPM_REC_QUADS + 6];
   const double dx = (double)c7.x - (double)c2.x, dy = (double)c7.y - (double)c2.y, dz = (double)c7.z - (double)c2.z;
   const double lenD = sqrt(dx * dx + dy * dy + dz * dz);
   const double inv = 1.0 / lenD;

@@ -825,15 +825,15 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
 
 // itemCount / blockTotal must be zero on entry (memset on the same stream)
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
-                     uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream) {
+                     uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, uint32_t itemCap, hipStream_t stream) {
   if (a.nsets == 0 || ntiles == 0) return;
   // waves stride over the tiles; the stride is prime because image-sharded input owns every N-th tile, and a
   // stride that is a multiple of N would leave all the work to 1/N of the blocks
   const uint32_t nwg = ntiles < 4093u ? ntiles : 4093u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
-    case 32: hipLaunchKernelGGL(plan_kernel<32>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
-    default: hipLaunchKernelGGL(plan_kernel<16>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal); break;
+    case 64: hipLaunchKernelGGL(plan_kernel<64>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal, itemCap); break;
+    case 32: hipLaunchKernelGGL(plan_kernel<32>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal, itemCap); break;
+    default: hipLaunchKernelGGL(plan_kernel<16>, dim3(nwg), dim3(64), 0, stream, a, ntiles, target, items, itemCount, itemOff, blockTotal, itemCap); break;
   }
 }
 

@@ -407,7 +407,10 @@ hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uin
   return hipcub::DeviceScan::ExclusiveSum(tmp.d, need, in, out, (int)n, s);
 }
 
-// cold planes of photon beams (indexed by beam, not sorted): the 7 photon planes + {p2, bits} + {endN, -}
+// records of photon beams (indexed by beam, not sorted), 128 bytes = one cache line per evaluation (the nine
+// plane-major float4 arrays of round 1 cost nine):
+//   0 {flux, parentPdf} 1 {p1, parentRR} 2 {parentN, parentG} 3 {prefixW, near0} 4 {parentScat, near1}
+//   5 {parentWi, near2} 6 {p2, bits} 7 {endN, length}   (near0..2: beam_near_kernel)
 __global__ __launch_bounds__(256) void beam_cold_kernel(RawPhotons r, const float *__restrict__ endN, uint32_t n,
                                                         gvpm_params cfg, float4 *cold) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -419,16 +422,110 @@ __global__ __launch_bounds__(256) void beam_cold_kernel(RawPhotons r, const floa
   c2.debug_shift = GVPM_SHIFT_ALL;
   if (photonContributes(bits, c2)) bits |= 1u << 6;
   bits |= (r.path_id[i] & 1u) << GVPM_HOT_PARITY_BIT;
-  const size_t N = n;
-  cold[0 * N + i] = ld3(r.wi, i, r.parent_pdf[i]);
-  cold[1 * N + i] = ld3(r.flux, i, r.edge_pdf[i]);
-  cold[2 * N + i] = ld3(r.parent_pos, i, r.parent_rr[i]);
-  cold[3 * N + i] = ld3(r.parent_n, i, r.parent_g[i]);
-  cold[4 * N + i] = ld3(r.prefix_w, i, 0.f);
-  cold[5 * N + i] = ld3(r.parent_scat, i, 0.f);
-  cold[6 * N + i] = ld3(r.parent_wi, i, 0.f);
-  cold[7 * N + i] = ld3(r.pos, i, __uint_as_float(bits));
-  cold[8 * N + i] = ld3(endN, i, 0.f);
+  float4 *rec = cold + (size_t)i * GVPM_REC_QUADS;
+  rec[0] = ld3(r.flux, i, r.parent_pdf[i]);
+  rec[1] = ld3(r.parent_pos, i, r.parent_rr[i]);
+  rec[2] = ld3(r.parent_n, i, r.parent_g[i]);
+  rec[3] = ld3(r.prefix_w, i, 0.f);
+  rec[4] = ld3(r.parent_scat, i, 0.f);
+  rec[5] = ld3(r.parent_wi, i, 0.f);
+  rec[6] = ld3(r.pos, i, __uint_as_float(bits));
+  // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81: the length, once, in fp64 (an fp64 square root and division
+  // per evaluation otherwise)
+  const double dx = (double)r.pos[3 * (size_t)i] - (double)r.parent_pos[3 * (size_t)i];
+  const double dy = (double)r.pos[3 * (size_t)i + 1] - (double)r.parent_pos[3 * (size_t)i + 1];
+  const double dz = (double)r.pos[3 * (size_t)i + 2] - (double)r.parent_pos[3 * (size_t)i + 2];
+  rec[7] = ld3(endN, i, (float)sqrt(dx * dx + dy * dy + dz * dz));
+}
+
+// ---- occluders near a photon beam -----------------------------------------------------------------------------
+// The reconnection of a beam shift tests the whole NEW beam parent -> offset position for occluders
+// (shift_volume_beams.cpp:420-426).  The offset position lies within `delta` of the point X of the original beam the
+// kernel sits at, so every point of the new segment lies within delta of the original segment [p1, p2] (the two
+// segments share p1 and end delta apart): only triangles whose box, inflated by delta, the original segment crosses
+// can be hit.  delta = 4 r + S: |offsetPos - X| <= |shiftRay(w) - baseRay(w)| + (kernel offset, replayed in the
+// shifted frame: 2 r) + (mirror adjustment of getShiftPos, shift_volume_beams.cpp:120-135: 2 r), and S bounds the
+// first term over every uploaded beam set (shift_extent_kernel).  Up to 12 byte indices per beam go into the spare
+// words of quads 3-5 of its record; a beam with more (or a scene of more than 253 occluders) is marked 0xFE in the
+// top byte of word 0 and takes the full test.
+__global__ __launch_bounds__(256) void shift_extent_kernel(const gvpm_camera_ray *__restrict__ rays, uint32_t nsets,
+                                                           uint32_t *extentBits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  float S = 0.f;
+  if (i < nsets) {
+    const gvpm_camera_ray b = rays[(size_t)i * 5];
+    for (int k = 1; k < 5; ++k) {
+      const gvpm_camera_ray s = rays[(size_t)i * 5 + k];
+      if (!GVPM_RAY_VALID(s.info)) continue;
+      const float ox = s.o[0] - b.o[0], oy = s.o[1] - b.o[1], oz = s.o[2] - b.o[2];
+      const float dx = s.d[0] - b.d[0], dy = s.d[1] - b.d[1], dz = s.d[2] - b.d[2];
+      // w <= min(len_b, len_s) (shift_volume_beams.cpp: the shift is dropped when w exceeds the shifted edge)
+      const float e = sqrtf(ox * ox + oy * oy + oz * oz) + fminf(b.len, s.len) * sqrtf(dx * dx + dy * dy + dz * dz);
+      S = fmaxf(S, e);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) S = fmaxf(S, __shfl_xor(S, o, 64));
+  if ((threadIdx.x & 63) == 0 && S > 0.f) atomicMax(extentBits, __float_as_uint(S * 1.0001f));  // S >= 0: bit order = value order
+}
+
+__global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n, const float4 *__restrict__ tri4, uint32_t ntri,
+                                                        float r, const uint32_t *__restrict__ extentBits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t N = GVPM_REC_QUADS;
+  uint32_t w[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  if (ntri > GVPM_NEAR_NARROW_MAX) {
+    w[0] = 0xFE000000u | 0x00FFFFFFu;
+  } else {
+    const float delta = 4.f * r + __uint_as_float(*extentBits);
+    const float4 c2 = cold[N * i + 1], c7 = cold[N * i + 6];
+    const float p1[3] = {c2.x, c2.y, c2.z}, p2[3] = {c7.x, c7.y, c7.z};
+    uint32_t cnt = 0;
+    for (uint32_t t = 0; t < ntri; ++t) {
+      const float4 t0 = tri4[3 * t], t1 = tri4[3 * t + 1], t2 = tri4[3 * t + 2];
+      const float v0[3] = {t0.x, t0.y, t0.z}, e1[3] = {t1.x, t1.y, t1.z}, e2[3] = {t2.x, t2.y, t2.z};
+      // segment [p1, p2] against the triangle's box inflated by delta (slab test, conservative)
+      float t0s = 0.f, t1s = 1.f;
+      bool hit = true;
+      for (int c = 0; c < 3; ++c) {
+        const float lo = fminf(v0[c], fminf(v0[c] + e1[c], v0[c] + e2[c])) - delta;
+        const float hi = fmaxf(v0[c], fmaxf(v0[c] + e1[c], v0[c] + e2[c])) + delta;
+        const float d = p2[c] - p1[c];
+        if (fabsf(d) < 1e-20f) {
+          hit = hit && p1[c] >= lo && p1[c] <= hi;
+        } else {
+          const float inv = 1.f / d;
+          const float a = (lo - p1[c]) * inv, b = (hi - p1[c]) * inv;
+          t0s = fmaxf(t0s, fminf(a, b) - 1e-5f);
+          t1s = fminf(t1s, fmaxf(a, b) + 1e-5f);
+        }
+      }
+      hit = hit && t0s <= t1s;
+      if (hit) {
+        if (cnt < 12u) {
+          const uint32_t wi = cnt >> 2, sh = (cnt & 3u) * 8u;
+          w[wi] = (w[wi] & ~(0xFFu << sh)) | (t << sh);
+        }
+        cnt++;
+      }
+    }
+    // (index 0xFE / 0xFF cannot occur in the top byte of word 0: ntri <= 253)
+    if (cnt > 12u) w[0] = 0xFE000000u | 0x00FFFFFFu;
+  }
+  cold[N * i + 3].w = __uint_as_float(w[0]);
+  cold[N * i + 4].w = __uint_as_float(w[1]);
+  cold[N * i + 5].w = __uint_as_float(w[2]);
+}
+
+void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s) {
+  (void)hipMemsetAsync(extentBits, 0, sizeof(uint32_t), s);
+  if (nsets) hipLaunchKernelGGL(shift_extent_kernel, dim3((nsets + 255) / 256), dim3(256), 0, s, rays, nsets, extentBits);
+}
+
+void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
+                      hipStream_t s) {
+  if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, tri4, ntri, r, extentBits);
 }
 
 void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg, float4 *cold,

@@ -42,7 +42,7 @@ void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint3
 void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
                       uint32_t *vals, hipStream_t s);
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
-                     uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, hipStream_t stream);
+                     uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, uint32_t itemCap, hipStream_t stream);
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
                          uint32_t nwaves, bool persistent, hipStream_t stream);
@@ -71,6 +71,9 @@ void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n
                        hipStream_t stream);
 void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);
 hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s);
+void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s);
+void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
+                      hipStream_t s);
 void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg, float4 *cold,
                       hipStream_t s);
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
@@ -265,6 +268,8 @@ struct gvpm_context {
   const float *w1Dev = nullptr, *len1Dev = nullptr;
   DevBuf<float4> planeTest;
   DevBuf<uint32_t> subFlags;      // G-Beams: filter bits per sorted sub-beam
+  DevBuf<uint32_t> shiftExtent;   // G-Beams: max distance between a shifted camera ray and its base ray (float bits)
+  bool beamNearStale = true;      // G-Beams: the per-beam near-occluder lists must be rebuilt
   DevBuf<uint32_t> blockKeyA, blockKeyB, blockValA, blockValB;  // G-Beams: pair blocks and their tiles, unsorted / sorted
   DevBuf<uint2> beamPairs;        // G-Beams: (beam | sub << 24, sorted set) pairs between traversal and evaluation
   bool havePlanes = false;
@@ -489,7 +494,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->raysOwned.release();
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release();
-  h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release();
+  h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release(); h->shiftExtent.release();
   h->blockKeyA.release(); h->blockKeyB.release(); h->blockValA.release(); h->blockValB.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   poisson_graph_release(h->poissonGraph);
@@ -1015,7 +1020,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   HIP_TRY(h, h->bs->queueCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->bstream));
   launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,
-                  h->bs->queueCtl.p + 3, h->bstream);
+                  h->bs->queueCtl.p + 3, itemCap, h->bstream);
   // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only) ...
   // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
   if (!h->pinB6) {
@@ -1030,6 +1035,10 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   lap("syncB");
   const uint32_t blocks = h->pinCtl[0];
   const uint32_t nItems = h->pinCtl[3];
+  if (nItems > itemCap) {
+    h->bstream = h->stream;
+    return fail(h, GVPM_ERR_STATE, "G-BRE planner produced more work items than its bound");
+  }
   if (getenv("GVPM_TRACE_PLAN")) {
     uint32_t q[4] = {0, 0, 0, 0};
     (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
@@ -1103,7 +1112,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   const uint32_t n = h->nph;
   h->nsub = 0;
   h->maxSubLen = 0.f;
-  HIP_TRY(h, h->bs->cold.ensure((size_t)(n + 1) * 9));
+  HIP_TRY(h, h->bs->cold.ensure((size_t)(n + 1) * GVPM_REC_QUADS));
   if (n == 0) {
     h->bs->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
     HIP_TRY(h, h->bs->cellStart.ensure(2));
@@ -1196,11 +1205,22 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     if (rc != GVPM_OK) return rc;
     h->photonsDirty = false;
     h->bs->builtRadius = r;
+    h->beamNearStale = true;  // new records (or a new radius): the near-occluder lists are rebuilt below
   }
+  bool nearDirty = false;
   if (h->beamsDirty) {
     int rc = sortBeams(h);
     if (rc != GVPM_OK) return rc;
     h->beamsDirty = false;
+    // how far a shifted camera ray strays from its base ray, over all uploaded sets (beam_near_kernel's delta)
+    HIP_TRY(h, h->shiftExtent.ensure(1));
+    launch_shift_extent(h->raysDev, h->nsets, h->shiftExtent.p, h->stream);
+    nearDirty = true;
+  }
+  if (nearDirty || h->beamNearStale) {
+    HIP_TRY(h, h->shiftExtent.ensure(1));
+    launch_beam_near(h->bs->cold.p, h->nph, h->tri4.p, h->ntri, r, h->shiftExtent.p, h->stream);
+    h->beamNearStale = false;
   }
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   GatherArgs a;
@@ -1217,10 +1237,13 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
-  HIP_TRY(h, h->bs->items.ensure(plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave)));
+  // (heavy items are split into parts: room for them on top of the planner's own bound)
+  const uint32_t itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave) + h->nsub / 256u + 4096u;
+  HIP_TRY(h, h->bs->items.ensure(itemCap));
   HIP_TRY(h, h->bs->queueCtl.ensure(8));
   HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
-  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr, h->stream);
+  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr, itemCap,
+                  h->stream);
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   // traversal -> pair list (blocks of 64) -> evaluation.  The list has no useful a-priori bound (the planner's is
   // sub-beams x rays per slab box, ~100x the survivors): it starts at 16 M pairs and, when the traversal reports
@@ -1234,8 +1257,11 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nblkCap));
     launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
                           h->beamPairs.p, h->bs->queueCtl.p + 2, cap, h->blockKeyA.p, h->blockValA.p, h->nwavesTrav, h->stream);
-    HIP_TRY(h, hipMemcpyAsync(&npairs, h->bs->queueCtl.p + 2, 4, hipMemcpyDeviceToHost, h->stream));
+    uint32_t ctl[3] = {0, 0, 0};
+    HIP_TRY(h, hipMemcpyAsync(ctl, h->bs->queueCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    npairs = ctl[2];
+    if (ctl[0] > itemCap) return fail(h, GVPM_ERR_STATE, "G-Beams planner produced more work items than its bound");
     if (getenv("GVPM_BEAMS_TRACE")) {
       uint32_t q[4];
       (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
@@ -1413,6 +1439,9 @@ int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   out->null_shifts = v[2];
   out->diffuse_shifts = v[3];
   out->failed_shifts = v[4];
+  out->dropped_pairs = v[7];
+  // the planner's bound on an item's pair region is exact: a dropped pair means a biased image, not a slow one
+  if (v[7]) return fail(h, GVPM_ERR_STATE, "the G-BRE traversal dropped pairs: planner bound violated");
   return GVPM_OK;
 }
 

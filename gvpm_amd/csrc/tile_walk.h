@@ -300,10 +300,13 @@ __device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox 
 // ------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
-                                                  uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal) {
+                                                  uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal,
+                                                  uint32_t itemCap) {
   // The finished items are staged in LDS and flushed ~PLAN_STAGE at a time: one pair of global atomics
   // per flush (same-address returning atomics retire one per ~10 ns: one per tile cost 0.35 ms at C2).
-  constexpr uint32_t PLAN_STAGE = 128;
+  constexpr uint32_t PLAN_STAGE = 512;
+  // (no pair regions to size -- G-Beams -- means heavy items may be split into parts, see below)
+  const bool splitHeavy = itemOff == nullptr;
   __shared__ float pb[8][B];
   __shared__ uint32_t pvalid[B];
   __shared__ uint4 stItem[PLAN_STAGE];
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       }
       slot0 = __shfl(slot0, 0, 64);
       blk0 = __shfl(blk0, 0, 64);
-      if (live) {
+      if (live && slot0 + lane < itemCap) {  // (past the capacity: counted, not written -- the host checks the count)
         items[slot0 + lane] = itv;
         if (itemOff) itemOff[slot0 + lane] = make_uint2(blk0 + (bIncl - blocks), stg);
       }
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       const uint32_t staged = incl - exclFirst;
       const bool emit = closes && staged > 0u;
       const unsigned long long emitMask = __ballot(emit);
-      if (emitMask) {
+      if (emitMask && !splitHeavy) {
         if (nStaged + 64u > PLAN_STAGE) flush();
         if (emit) {
           const uint32_t k = nStaged + (uint32_t)__popcll(emitMask & ((1ull << lane) - 1ull));
@@ -408,6 +411,24 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
           stStaged[k] = staged;
         }
         nStaged += (uint32_t)__popcll(emitMask);
+      } else if (emitMask) {
+        // A single slab step cannot be cut by the greedy rule above, and a dense spot of the map (the shaft of
+        // S-laser: half a million sub-beams in one box) then is ONE item that a single wave walks long after every
+        // other wave has finished (measured at C3: the traversal's waves were resident 30 % of its duration).  Such an
+        // item is emitted as `parts` items that share its walk and take its staging windows round-robin:
+        // item.y = nb | part << 8 | parts << 20.
+        for (unsigned long long em = emitMask; em; em &= em - 1ull) {
+          const int src = __ffsll((long long)em) - 1;
+          const uint32_t stg = __shfl(staged, src, 64);
+          const uint32_t cF = (uint32_t)__shfl(cAFirst, src, 64), cE = (uint32_t)__shfl(cAe, src, 64);
+          const uint32_t parts = stg > 2u * target ? min(PLAN_STAGE, (stg + target - 1u) / target) : 1u;
+          if (nStaged + parts > PLAN_STAGE) flush();
+          for (uint32_t pp = (uint32_t)lane; pp < parts; pp += 64u) {
+            stItem[nStaged + pp] = make_uint4(setBase, nb | (parts > 1u ? (pp << 8) | (parts << 20) : 0u), cF, cE);
+            stStaged[nStaged + pp] = (stg + parts - 1u) / parts;
+          }
+          nStaged += parts;
+        }
       }
     }
   }

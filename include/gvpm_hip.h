@@ -239,7 +239,9 @@ typedef struct gvpm_stats {
                              contribution + 4 shift attempts       */
   uint64_t candidates;    /* (beam, photon) pairs tested geometrically         */
   uint64_t null_shifts, diffuse_shifts, failed_shifts;
-  uint64_t reserved[3];
+  uint64_t dropped_pairs; /* (photon, beam) pairs the traversal could not store: must be 0 -- gvpm_get_stats returns
+                             GVPM_ERR_STATE otherwise (the image would be biased)  */
+  uint64_t reserved[2];
 } gvpm_stats;
 
 typedef struct gvpm_context gvpm_context;
