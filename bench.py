@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: G-BRE 3D photon gather + gradient-domain shift (BASELINE.json configs[1]).
+"""Headline benchmark of the gvpm photon-gather + gradient-domain shift path on MI355X.
 
-One "step" = one SPPM iteration of the hot path (device acceleration-structure build + beam
-ordering + gather/shift kernel + normalisation/APA fold) over one batch of synthetic input
-already resident in HBM.  Metric: M photon-gather+shift evaluations / s.
+One "step" = one SPPM iteration of the hot path (device acceleration-structure build + beam ordering + traversal +
+gather/shift evaluation, which folds into the running film) over one batch of synthetic input already resident in
+HBM.  Metric: M photon-gather+shift evaluations / s.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: image sharding (the frame's 4x4-pixel tiles dealt round-robin to the ranks), photon map
-replicated, one all-reduce of the film's 3 planes {throughput, dx, dy} (RCCL through
-torch.distributed) at the end of the timed region.  Weak scaling: every rank owns
-512x512 pixels of a (tiles_x*512) x (tiles_y*512) frame of the same scene.
+Workloads (BASELINE.json `configs`):
+  N = 1  configs[1] "C2": S-cbox + homogeneous medium, G-BRE 3D, 512x512, 1 M photons / iteration.
+  N > 1  configs[3] "C4": S-fogroom, G-BRE 3D, 1024x1024, 4 M photons / iteration, STRONG scaling: the frame's 4x4-pixel
+         tiles are dealt round-robin to the ranks (scripts/shard_balance.py: mean/max 0.99), the photon map is replicated,
+         the film's three planes {throughput, dx, dy} are summed across ranks (RCCL through torch.distributed)
+         once, inside the timed region, before reconstruction (gvpm.cpp:535).
+  --workload c2|c4 forces one; --weak: every rank owns --tile^2 pixels of a larger frame of the same scene instead.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -25,9 +30,24 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+WORKLOADS = {
+    "c2": dict(scene="cbox", frame=512, photons=1000000, distinct=16, name="BASELINE configs[1]"),
+    "c4": dict(scene="fogroom", frame=1024, photons=4000000, distinct=3, name="BASELINE configs[3]"),
+}
+
 
 def tile_grid(n):
     return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(n, (n, 1))
+
+
+def csrc_sha():
+    """What the PMC traffic file must have been measured on: the sources of libgvpm_hip.so."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "gvpm_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")) or os.path.basename(f) == "Makefile":
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -35,19 +55,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tile", type=int, default=512, help="pixels per side of one rank's tile")
-    ap.add_argument("--photons", type=int, default=1000000)
-    ap.add_argument("--scene", default="cbox")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c4"],
+                    help="auto: c2 (BASELINE configs[1]) on one GPU, c4 (configs[3], strong-sharded) on several")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: every rank owns --tile^2 pixels of a (tiles_x*tile) x (tiles_y*tile) frame")
+    ap.add_argument("--frame", type=int, default=0, help="pixels per side of the whole frame (strong scaling; 0: the workload's)")
+    ap.add_argument("--tile", type=int, default=512, help="--weak / --emulate-gpus: pixels per side of one rank's share")
+    ap.add_argument("--photons", type=int, default=0, help="photons per iteration (0: the workload's)")
+    ap.add_argument("--scene", default="", help="synthetic scene (default: the workload's)")
     ap.add_argument("--technique", default="bre3d", choices=["bre3d", "bre2d"],
-                    help="bre3d = BASELINE configs[1] (the bench line); bre2d: the 2D-kernel BRE of the same path (probe)")
+                    help="bre3d = the bench line; bre2d: the 2D-kernel BRE of the same path (probe)")
     ap.add_argument("--scale", type=float, default=1.0, help="initialScaleVolume")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct pre-generated iterations (cycled)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct pre-generated iterations, cycled (0: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-window", type=int, default=512)
-    ap.add_argument("--cpu-iters", type=int, default=8, help="iterations of the workload the CPU baseline is timed on")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="iterations of the workload the all-core CPU baseline is timed on")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of step 1 (parity_l2 / relMSE)")
+    ap.add_argument("--no-upload-inclusive", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--emulate-gpus", type=int, default=0,
-                    help="single-GPU run of rank 0's shard of an N-GPU frame (sizing probe, e.g. BASELINE configs[3]: "
-                         "--emulate-gpus 8 --tile 362 --photons 4000000); not a bench line")
+                    help="single-GPU run of rank 0's shard of an N-GPU frame (sizing probe); not a bench line")
     ap.add_argument("--device-gen", action="store_true",
                     help="probe (SURVEY 8f3): every step shoots its photons and generates its camera beams on the GPU "
                          "(gvpm_devgen_*) inside the timed region instead of reading pre-generated inputs from HBM")
@@ -59,13 +84,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+
+    # every GVPM_* variable changes what is measured: they are reported, and the evaluation-skipping development
+    # switch of round 1 (compiled out since) is refused outright
+    gvpm_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("GVPM_")}
+    if "GVPM_DEBUG_FLAGS" in gvpm_env:
+        raise SystemExit("bench.py refuses to run with GVPM_DEBUG_FLAGS set (development switches change the measured work)")
 
     import torch
     import torch.distributed as dist
-    from gvpm_amd import abi, hip
+    from gvpm_amd import abi, hip, metrics
     from gvpm_amd.host import SynthScene
 
     if not torch.cuda.is_available():
@@ -77,9 +107,18 @@ def main():
         dist.init_process_group(args.backend)
 
     nshards = args.emulate_gpus if (args.emulate_gpus and world == 1) else world
-    tx, ty = tile_grid(nshards)
-    W, H = args.tile * tx, args.tile * ty  # weak scaling: tile^2 pixels per rank
-    sc = SynthScene(args.scene, W, H)
+    wl_key = args.workload if args.workload != "auto" else ("c2" if nshards == 1 else "c4")
+    wl = WORKLOADS[wl_key]
+    scene = args.scene or wl["scene"]
+    photons = args.photons or wl["photons"]
+    ndist_req = args.distinct or wl["distinct"]
+    strong = not args.weak and not args.emulate_gpus
+    if strong:
+        W = H = args.frame or wl["frame"]
+    else:
+        tx, ty = tile_grid(nshards)
+        W, H = args.tile * tx, args.tile * ty
+    sc = SynthScene(scene, W, H)
     p = sc.params()
     p.vol_technique = abi.GVPM_VOL_BRE3D if args.technique == "bre3d" else abi.GVPM_VOL_BRE2D
     if args.technique == "bre2d":
@@ -92,17 +131,15 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     K, Wu = args.steps, args.warmup
-    ndist = max(1, min(args.distinct, max(K, Wu)))
-    inputs = []
-    keep = []
-    host0 = []  # host copies of the first iterations' inputs: the CPU baseline's sample
+    ndist = max(1, min(ndist_req, max(K, Wu)))
+    inputs, keep = [], []
+    host0 = []  # host copies of the first iterations' inputs: the CPU baseline's and the parity check's sample
     gen = hip.DeviceGenerator(sc, device=local_rank) if args.device_gen else None
+    n_host = max(args.cpu_iters if not args.no_cpu_baseline else 0, 2 if not args.no_upload_inclusive else 0, 1)
     for i in range(0 if gen else ndist):
-        ph, nb = sc.shoot_photons(i + 1, args.photons)
-        # image sharding: the frame's 4x4-pixel tiles are dealt round-robin to the ranks -- contiguous blocks
-        # split S-cbox 2.5:1 unevenly (scripts/shard_balance.py: mean/max 0.41 vs 0.99 interleaved)
+        ph, nb = sc.shoot_photons(i + 1, photons)
         rays = sc.camera_beams_interleaved(i + 1, nshards, rank) if nshards > 1 else sc.camera_beams(i + 1)
-        if i < args.cpu_iters and rank == 0 and not args.no_cpu_baseline:
+        if i < n_host and rank == 0:
             host0.append((ph, nb, rays))
         soa = abi.PhotonSoA()
         for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
@@ -120,7 +157,7 @@ def main():
 
     def step(it):
         if gen:
-            soa, nb = gen.shoot_photons((it - 1) % ndist + 1, args.photons)
+            soa, nb = gen.shoot_photons((it - 1) % ndist + 1, photons)
             rptr, nsets = gen.camera_beams((it - 1) % ndist + 1, nshards, rank)
             gen_sets.append(nsets)
             gen_ph.append(int(soa.n))
@@ -141,6 +178,8 @@ def main():
     ctx.synchronize()
     ctx.reset()
     ctx.kernel_time()
+    ctx.phase_time(1)
+    ctx.phase_time(2)
     ev0 = ctx.stats()["evaluations"]
     film = torch.zeros(W * H * 9, dtype=torch.float32, device="cuda") if world > 1 else None
     if world > 1:
@@ -177,19 +216,26 @@ def main():
     if rank == 0:
         nsets_avg = float(np.mean(gen_sets if gen else [x[4] for x in inputs]))
         nph_avg = float(np.mean(gen_ph if gen else [x[1] for x in inputs]))
-        P = args.tile * args.tile
+        P = W * H / nshards  # pixels this rank owns
         # algorithmic bytes per gather-kernel launch (BASELINE.md / SURVEY 8d convention)
         bytes_alg = 128.0 * (evals / K) + 320.0 * nsets_avg + 108.0 * P + 128.0 * nph_avg
         achieved = bytes_alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the PMC passes of scripts/profile.sh on this same
-        # command (2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes), recorded under profiles/
+        sha = csrc_sha()
+        # HBM bytes per launch of the dominant kernel from the PMC passes of scripts/profile.sh (2 x FETCH_SIZE +
+        # WRITE_SIZE as MI355X_MICROARCH.md prescribes): reported only when that file was measured on THIS workload with
+        # THESE kernel sources
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and args.tile == 512 and args.photons == 1000000:
+        for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
             try:
-                traffic = json.load(open(tj))["evaluate_bre_kernel"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/profile.sh)"
-            except (KeyError, ValueError):
+                d = json.load(open(tj))
+                meta = d.get("_meta", {})
+                want = dict(technique=args.technique, scene=scene, scale=args.scale, frame=[W, H], photons=photons,
+                            n_gpus=world, csrc_sha=sha)
+                if all(meta.get(k) == v for k, v in want.items()):
+                    traffic = d["evaluate_bre_kernel"]["hbm_bytes_per_launch"]
+                    traffic_src = f"{os.path.relpath(tj, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/profile.sh)"
+                    break
+            except (KeyError, ValueError, OSError):
                 pass
         out = {
             "metric": "photon gather+shift evaluations per second (G-BRE %s)" % ("3D" if args.technique == "bre3d" else "2D"),
@@ -200,27 +246,30 @@ def main():
             "warmup": Wu,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (generated on the device inside every step)" if gen else "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: S-{args.scene} + homogeneous medium, G-BRE {args.technique[3:].upper()} kernel, "
-                            f"{args.tile}x{args.tile} px per GPU ({W}x{H} frame), {args.photons} photons/iter, "
-                            f"{K} SPPM iters, initialScaleVolume {args.scale}",
-                "technique": args.technique, "frame": [W, H], "tile_per_gpu": [args.tile, args.tile],
-                "photons_per_iter": args.photons, "iterations": K,
-                "sharding": f"4x4-pixel tiles round-robin over {nshards} ranks" if nshards > 1 else "none",
+                "workload": f"{wl['name'] if (scene == wl['scene'] and photons == wl['photons']) else 'custom'}: S-{scene} + homogeneous "
+                            f"medium, G-BRE {args.technique[3:].upper()} kernel, {W}x{H} frame"
+                            + (f" sharded over {nshards} GPUs (4x4-pixel tiles round-robin)" if nshards > 1 else "")
+                            + f", {photons} photons/iter, {K} SPPM iters, initialScaleVolume {args.scale}",
+                "technique": args.technique, "scene": scene, "frame": [W, H], "pixels_per_gpu": P,
+                "photons_per_iter": photons, "iterations": K,
+                "sharding": (f"4x4-pixel tiles round-robin over {nshards} ranks, photon map replicated, one film all-reduce "
+                             f"in the timed region") if nshards > 1 else "none",
                 "evaluations": evals_total, "evals_per_iter_per_gpu": evals / K,
                 "tests_per_iter_per_gpu": st["candidates"] / K,
+                "env": gvpm_env, "csrc_sha": sha,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "evaluate_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
                 "traverse_avg_ms": ctx.phase_time(1)[0], "build_avg_ms": ctx.phase_time(2)[0],
-                "note": "build + traversal of step N+1 run on a second stream while this kernel evaluates step N: "
-                        "the durations include that sharing (GVPM_PIPELINE=0 gives the isolated ones)",
+                "note": "build + traversal of the next steps run on other streams while this kernel evaluates step N: "
+                        "the durations include that sharing (kernel_isolated_ms: the same kernel alone, GVPM_PIPELINE=0)",
                 "bytes_alg_per_launch": bytes_alg,
             },
             "stats": st,
@@ -249,39 +298,140 @@ def main():
                     out["roofline"]["frac_isolated"] = bytes_alg / (ims * 1e-3) / 1e9 / 8000.0
             finally:
                 os.environ.pop("GVPM_PIPELINE", None)
+        if world == 1 and not gen and not args.no_upload_inclusive:
+            out["upload_inclusive"] = upload_inclusive(hip, p, m, tris, host0, K, local_rank)
+        if world == 1 and not gen and not args.no_parity:
+            out.update(parity(hip, metrics, sc, p, m, tris, host0[0], W, H))
         if world == 1 and not args.no_cpu_baseline and not gen:
-            out["cpu_baseline"] = cpu_baseline(sc, p, m, tris, host0, args)
+            out["cpu_baseline"] = cpu_baseline(p, m, tris, host0[:args.cpu_iters], W, H)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, p, m, tris, host0, args):
-    """The oracle (fp32, fast-math, kd-tree -> BVH walk as the reference) timed on this box's host cores on a bounded
-    sample of the same workload: the first --cpu-iters iterations (their own photon maps and camera beams), a centred
-    pixel window, every iteration including its kd-tree + BVH build as the reference pays it."""
+def upload_inclusive(hip, p, m, tris, host0, K, device):
+    """The same K steps fed from HOST memory through gvpm_upload_* / gvpm_prefetch_*: pinned buffers (one packed block per
+    photon set, gvpm_host_alloc_photons), copies on the handle's copy stream, the copy of step N+1 in flight while step N
+    runs.  Never `value`: the PCIe-inclusive rate SURVEY 8d asks to have beside it."""
+    sets = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays)) for ph, nb, rays in host0[:2]]
+    nbytes = host0[0][0].n * 120 + host0[0][2].nbytes
+    ctx = hip.Context(p, device=device)
+    ctx.upload_scene(*tris)
+    ctx.upload_medium(m)
+    res = {}
+    for mode in ("prefetch", "serial"):
+        ctx.reset()
+        for rep in range(2):  # first pass: allocations
+            ctx.synchronize()
+            ev0 = ctx.stats()["evaluations"]
+            t0 = time.perf_counter()
+            ph, nb, rays = sets[0]
+            ctx.upload_pinned(ph, rays)
+            for it in range(1, K + 1):
+                if mode == "prefetch":
+                    if it < K:
+                        nxt = sets[it % len(sets)]
+                        ctx.prefetch(nxt[0], nxt[2])
+                    ctx.gather(it, sets[(it - 1) % len(sets)][1])
+                else:
+                    if it > 1:
+                        cur = sets[(it - 1) % len(sets)]
+                        ctx.upload_pinned(cur[0], cur[2])
+                    ctx.gather(it, sets[(it - 1) % len(sets)][1])
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            ev = ctx.stats()["evaluations"] - ev0
+        res[mode] = dict(ms_per_step=dt / K * 1e3, value=ev / dt / 1e6)
+    ctx.close()
+    for s in sets:
+        s[0].close()
+        s[2].close()
+    return {
+        "value": res["prefetch"]["value"], "unit": "Mevals/s", "ms_per_step": res["prefetch"]["ms_per_step"],
+        "ms_per_step_without_prefetch": res["serial"]["ms_per_step"],
+        "host_bytes_per_step": nbytes,
+        "pcie_gb_per_s_at_this_rate": nbytes / (res["prefetch"]["ms_per_step"] * 1e-3) / 1e9,
+        "how": "pinned host buffers (gvpm_host_alloc_photons: one packed block per photon set), gvpm_prefetch_* of step N+1 "
+               "before gvpm_gather of step N: copies on the copy stream overlap the previous step's kernels",
+    }
+
+
+def parity(hip, metrics, sc, p, m, tris, first, W, H):
+    """Step 1 of the workload against the fp64 oracle on a centred 32x32-pixel window (the full photon map): per-pixel L2
+    of the 27 accumulators and of throughput / dx / dy over the mean luminance, and relMSE (imageerrors.h:117-121)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    w = min(args.cpu_window, args.tile)
-    lo = (args.tile - w) // 2
+    ph, nb, rays = first
+    w = 32
+    x0, y0 = (W - w) // 2, (H - w) // 2
+    px = rays["pixel"][:, 0] & 0xFFFF
+    py = rays["pixel"][:, 0] >> 16
+    sel = (px >= x0) & (px < x0 + w) & (py >= y0) & (py < y0 + w)
+    wr = np.ascontiguousarray(rays[sel])
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*tris)
+    ctx.upload_medium(m)
+    ctx.upload_photons(ph)
+    ctx.upload_camera_beams(wr)
+    r = ctx.radius()
+    ctx.gather(1, nb)
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    film = ctx.download_film(1, True)
+    ctx.close()
+    ref, cnt, _ = O.gather_bre(p, m, tris, ph, wr, r, 1, nb, precision=64, use_accel=True)
+    rfilm = O.assemble(ref, 1, True)
+    win = (slice(y0, y0 + w), slice(x0, x0 + w))
+    lum = ref[win][..., 0:3].mean()
+    return {
+        "parity_l2": max([metrics.l2_over_luminance(acc[win], ref[win], lum)] +
+                         [metrics.l2_over_luminance(a[win], b[win], lum) for a, b in zip(film, rfilm)]),
+        "parity": {
+            "what": f"step 1, centred {w}x{w}-pixel window, full photon map, fp64 oracle (oracle/, reference BVH walk)",
+            "evaluations_device": st["evaluations"], "evaluations_oracle": cnt["evaluations"],
+            "l2_accumulators": metrics.l2_over_luminance(acc[win], ref[win], lum),
+            "l2_throughput_dx_dy": [metrics.l2_over_luminance(a[win], b[win], lum) for a, b in zip(film, rfilm)],
+            "relMSE_throughput_dx_dy": [metrics.rel_mse(a[win], b[win]) for a, b in zip(film, rfilm)],
+            "bar": "L2 / mean luminance < 1e-3 (BASELINE.md), evaluation counts equal",
+        },
+    }
+
+
+def cpu_baseline(p, m, tris, host0, W, H):
+    """The oracle (fp32, fast-math, kd-tree -> BVH walk as the reference) timed on this box's host cores on a bounded
+    sample of the same workload.  All cores: the first --cpu-iters iterations (their own photon maps and camera beams),
+    the full frame, every iteration including its kd-tree + BVH build as the reference pays it.  One thread: a centred
+    pixel window of the first iteration.  Reported, not targeted."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
     r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
     cores = os.cpu_count() or 1
     evals, secs, nsets = 0, 0.0, 0
     for ph, nb, rays in host0:
-        px = rays["pixel"][:, 0] & 0xFFFF
-        py = rays["pixel"][:, 0] >> 16
-        sel = (px >= lo) & (px < lo + w) & (py >= lo) & (py < lo + w)
-        sample = np.ascontiguousarray(rays[sel])
-        _, cnt, s = O.gather_bre(p, m, tris, ph, sample, r, 1, nb, precision=32, use_accel=True, threads=cores, fast=True)
+        _, cnt, s = O.gather_bre(p, m, tris, ph, rays, r, 1, nb, precision=32, use_accel=True, threads=cores, fast=True)
         evals += cnt["evaluations"]
         secs += s
-        nsets += sample.shape[0]
+        nsets += rays.shape[0]
+    # one thread: iteration 1, a window sized for ~5-10 s (the whole 512x512 frame of C2)
+    ph, nb, rays = host0[0]
+    w1 = min(W, H, 512)
+    x0, y0 = (W - w1) // 2, (H - w1) // 2
+    px = rays["pixel"][:, 0] & 0xFFFF
+    py = rays["pixel"][:, 0] >> 16
+    sel = (px >= x0) & (px < x0 + w1) & (py >= y0) & (py < y0 + w1)
+    _, cnt1, s1 = O.gather_bre(p, m, tris, ph, np.ascontiguousarray(rays[sel]), r, 1, nb, precision=32, use_accel=True, threads=1,
+                               fast=True)
     return {
         "value": evals / secs / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
-        "sample": f"{len(host0)} iterations (each its own {host0[0][0].n}-photon map), centred {w}x{w} px window "
-                  f"({nsets} beam sets in all), kd-tree + BVH builds included ({secs:.2f} s, {evals} evaluations, "
-                  f"initial radius in every iteration)",
+        "sample": f"{len(host0)} iterations (each its own {host0[0][0].n}-photon map), the full {W}x{H} frame "
+                  f"({nsets} beam sets in all), kd-tree + BVH builds included ({secs:.2f} s, {evals} evaluations); every "
+                  f"iteration at the INITIAL radius (the GPU's radius shrinks with the iteration: its later steps find fewer "
+                  f"photons per beam)",
+        "one_thread": {"value": cnt1["evaluations"] / s1 / 1e6, "unit": "Mevals/s", "cores": 1,
+                       "sample": f"iteration 1, centred {w1}x{w1}-pixel window ({int(sel.sum())} beam sets), the 1-thread "
+                                 f"kd-tree + BVH build of the full {ph.n}-photon map included ({s1:.2f} s, "
+                                 f"{cnt1['evaluations']} evaluations)"},
     }
 
 

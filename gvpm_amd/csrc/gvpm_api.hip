@@ -234,9 +234,25 @@ struct gvpm_context {
   uint32_t ntri = 0;
   float triMin[3] = {0, 0, 0}, triMax[3] = {0, 0, 0};  // occluder bounds (host side, at upload)
 
+  // Host uploads land in a ring of three staging slots per kind, through a copy stream of their own: the copy of
+  // step N+1 (or, prefetched, N+2) then runs while the kernels of step N still read theirs.  A slot's `copied` event
+  // orders its consumers after the copy, `freed` (rays: read until the evaluation kernel ends) the next copy after them.
+  struct PhotonSlot {
+    DevBuf<uint32_t> raw;   // 30 words per photon: the 8 xyz arrays, the 4 scalars, flags, path_id (the ABI's order)
+    gvpm_photon_soa dev;    // device pointers into raw
+    hipEvent_t copied = nullptr;
+  } phSlot[3];
+  struct RaySlot {
+    DevBuf<gvpm_camera_ray> rays;
+    uint32_t nsets = 0;
+    hipEvent_t copied = nullptr, freed = nullptr;
+    bool read = false;      // a gather has launched kernels that read it since its last copy
+  } raySlot[3];
+  int phCur = 0, phPending = -1, rayCur = 0, rayPending = -1;   // pending: prefetched, current after the next gather
+  bool phWait = false, rayWait = false;   // the next gather's streams must wait for the current slot's copy
+  bool raysOwnedCur = false;              // the current camera rays live in raySlot[rayCur]
+  hipStream_t copyStream = nullptr;
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid
-  DevBuf<float> rawF;      // 28 floats per photon when owned
-  DevBuf<uint32_t> rawU;   // 2 per photon
   gvpm_photon_soa rawDev;  // device pointers
   uint32_t nph = 0;
   bool havePhotons = false, photonsDirty = false;
@@ -250,7 +266,6 @@ struct gvpm_context {
   uint32_t *pinCtl = nullptr;
 
   // camera beams
-  DevBuf<gvpm_camera_ray> raysOwned;
   const gvpm_camera_ray *raysDev = nullptr;
   uint32_t nsets = 0;
   bool haveBeams = false, beamsDirty = false;
@@ -407,6 +422,17 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     gvpm_destroy(h);
     return GVPM_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) != hipSuccess) {
+    gvpm_destroy(h);
+    return GVPM_ERR_HIP;
+  }
+  for (int k = 0; k < 3; ++k)
+    if (hipEventCreateWithFlags(&h->phSlot[k].copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->raySlot[k].copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->raySlot[k].freed, hipEventDisableTiming) != hipSuccess) {
+      gvpm_destroy(h);
+      return GVPM_ERR_HIP;
+    }
   h->bstream = h->stream;
   if (const char *e = getenv("GVPM_BEAMS_PER_WAVE")) {
     int v = atoi(e);
@@ -490,8 +516,16 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->streamC) (void)hipStreamSynchronize(h->streamC);
   for (BuildSet &b : h->sets) b.release();
   h->tri4.release(); h->bvh.release();
-  h->rawF.release(); h->rawU.release();
-  h->raysOwned.release();
+  for (auto &ps : h->phSlot) {
+    ps.raw.release();
+    if (ps.copied) (void)hipEventDestroy(ps.copied);
+  }
+  for (auto &rs : h->raySlot) {
+    rs.rays.release();
+    if (rs.copied) (void)hipEventDestroy(rs.copied);
+    if (rs.freed) (void)hipEventDestroy(rs.freed);
+  }
+  if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release(); h->shiftExtent.release();
@@ -587,7 +621,36 @@ int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *m) {
   return GVPM_OK;
 }
 
-static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool fromDevice) {
+static bool isPinnedHost(const void *ptr) {
+  hipPointerAttribute_t attr;
+  if (!ptr || hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory is reported as an error: not one of ours
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+int gvpm_host_alloc(uint64_t bytes, void **out) {
+  if (!out || bytes == 0) return GVPM_ERR_INVALID_ARG;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? GVPM_OK : GVPM_ERR_HIP;
+}
+int gvpm_host_free(void *p) { return hipHostFree(p) == hipSuccess ? GVPM_OK : GVPM_ERR_HIP; }
+int gvpm_host_alloc_photons(uint64_t n, gvpm_photon_soa *view, void **block) {
+  if (!view || !block || n == 0 || n > 0x7FFFFFF0ull) return GVPM_ERR_INVALID_ARG;
+  if (hipHostMalloc(block, (size_t)n * 30 * 4, hipHostMallocDefault) != hipSuccess) return GVPM_ERR_HIP;
+  float *f = (float *)*block;
+  const float **v3[8] = {&view->pos, &view->wi, &view->flux, &view->parent_pos, &view->parent_n, &view->prefix_w,
+                         &view->parent_scat, &view->parent_wi};
+  const float **v1[4] = {&view->parent_pdf, &view->edge_pdf, &view->parent_rr, &view->parent_g};
+  for (auto q : v3) { *q = f; f += (size_t)n * 3; }
+  for (auto q : v1) { *q = f; f += n; }
+  view->flags = (const uint32_t *)f;
+  view->path_id = (const uint32_t *)f + n;
+  view->n = n;
+  return GVPM_OK;
+}
+
+static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool fromDevice, bool prefetch = false) {
   if (!p) return fail(h, GVPM_ERR_INVALID_ARG, "null photon soa");
   if (p->n > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many photons");
   const uint32_t n = (uint32_t)p->n;
@@ -597,39 +660,54 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
     for (const void *q : ptrs)
       if (!q) return fail(h, GVPM_ERR_INVALID_ARG, "null photon array");
   }
-  // G-BRE reads the raw arrays only from its build stream (and is done with them when gvpm_gather
-  // returns), so the copy need not wait for the evaluation kernel still running on the gather stream
-  const bool bre = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
-  hipStream_t up = bre && h->pipeline ? h->streamB : h->stream;
   if (fromDevice) {
+    if (prefetch) return fail(h, GVPM_ERR_INVALID_ARG, "prefetch takes host buffers");
     h->rawDev = *p;
+    h->phWait = false;
   } else {
-    HIP_TRY(h, h->rawF.ensure((size_t)n * 28 + 4));
-    HIP_TRY(h, h->rawU.ensure((size_t)n * 2 + 4));
-    float *f = h->rawF.p;
-    const float *src3[8] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat, p->parent_wi};
-    const float *src1[4] = {p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g};
-    const float **dst3[8] = {&h->rawDev.pos, &h->rawDev.wi, &h->rawDev.flux, &h->rawDev.parent_pos, &h->rawDev.parent_n,
-                             &h->rawDev.prefix_w, &h->rawDev.parent_scat, &h->rawDev.parent_wi};
-    const float **dst1[4] = {&h->rawDev.parent_pdf, &h->rawDev.edge_pdf, &h->rawDev.parent_rr, &h->rawDev.parent_g};
-    for (int k = 0; k < 8; ++k) {
-      if (n) HIP_TRY(h, hipMemcpyAsync(f, src3[k], (size_t)n * 12, hipMemcpyHostToDevice, up));
-      *dst3[k] = f;
-      f += (size_t)n * 3;
+    const bool pinned = isPinnedHost(p->pos);
+    if (prefetch && !pinned) return fail(h, GVPM_ERR_INVALID_ARG, "gvpm_prefetch_photons needs pinned host memory (gvpm_host_alloc*)");
+    if (prefetch && h->phPending >= 0) return fail(h, GVPM_ERR_STATE, "a prefetched photon set is already pending");
+    // (no build is in flight between two gvpm_gather calls: every slot but a pending prefetch is free)
+    int slot = (h->phCur + 1) % 3;
+    if (slot == h->phPending) slot = (h->phCur + 2) % 3;
+    gvpm_context::PhotonSlot &ps = h->phSlot[slot];
+    HIP_TRY(h, ps.raw.ensure((size_t)n * 30 + 8));
+    const void *src[14] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat, p->parent_wi,
+                           p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g, p->flags, p->path_id};
+    const void **dst[14] = {(const void **)&ps.dev.pos, (const void **)&ps.dev.wi, (const void **)&ps.dev.flux,
+                            (const void **)&ps.dev.parent_pos, (const void **)&ps.dev.parent_n, (const void **)&ps.dev.prefix_w,
+                            (const void **)&ps.dev.parent_scat, (const void **)&ps.dev.parent_wi, (const void **)&ps.dev.parent_pdf,
+                            (const void **)&ps.dev.edge_pdf, (const void **)&ps.dev.parent_rr, (const void **)&ps.dev.parent_g,
+                            (const void **)&ps.dev.flags, (const void **)&ps.dev.path_id};
+    // one packed copy when the host arrays are one block in the ABI's order (gvpm_host_alloc_photons), else one each
+    bool packed = n > 0;
+    size_t off = 0;
+    for (int k = 0; k < 14 && packed; ++k) {
+      packed = (const char *)src[k] == (const char *)src[0] + off * 4;
+      off += (size_t)n * (k < 8 ? 3 : 1);
     }
-    for (int k = 0; k < 4; ++k) {
-      if (n) HIP_TRY(h, hipMemcpyAsync(f, src1[k], (size_t)n * 4, hipMemcpyHostToDevice, up));
-      *dst1[k] = f;
-      f += n;
+    off = 0;
+    for (int k = 0; k < 14; ++k) {
+      const size_t words = (size_t)n * (k < 8 ? 3 : 1);
+      *dst[k] = ps.raw.p + off;
+      if (n && !packed) HIP_TRY(h, hipMemcpyAsync(ps.raw.p + off, src[k], words * 4, hipMemcpyHostToDevice, h->copyStream));
+      off += words;
     }
-    if (n) {
-      HIP_TRY(h, hipMemcpyAsync(h->rawU.p, p->flags, (size_t)n * 4, hipMemcpyHostToDevice, up));
-      HIP_TRY(h, hipMemcpyAsync(h->rawU.p + n, p->path_id, (size_t)n * 4, hipMemcpyHostToDevice, up));
+    if (packed) HIP_TRY(h, hipMemcpyAsync(ps.raw.p, src[0], off * 4, hipMemcpyHostToDevice, h->copyStream));
+    ps.dev.n = n;
+    HIP_TRY(h, hipEventRecord(ps.copied, h->copyStream));
+    // pageable memory: the caller may reuse its buffers when this returns.  Pinned memory (gvpm_host_alloc*): the copy is
+    // left in flight; the buffer must stay untouched until the gather that consumes it has returned (G-BRE) or the
+    // handle was synchronised
+    if (!pinned) HIP_TRY(h, hipStreamSynchronize(h->copyStream));
+    if (prefetch) {
+      h->phPending = slot;
+      return GVPM_OK;
     }
-    h->rawDev.flags = h->rawU.p;
-    h->rawDev.path_id = h->rawU.p + n;
-    h->rawDev.n = n;
-    HIP_TRY(h, hipStreamSynchronize(up));  // the caller may reuse its buffers
+    h->phCur = slot;
+    h->rawDev = ps.dev;
+    h->phWait = true;
   }
   h->nph = n;
   h->havePhotons = true;
@@ -644,6 +722,10 @@ int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *p) {
 int gvpm_upload_photons_dev(gvpm_context *h, const gvpm_photon_soa *p) {
   CHECK_H(h);
   return uploadPhotonsCommon(h, p, true);
+}
+int gvpm_prefetch_photons(gvpm_context *h, const gvpm_photon_soa *p) {
+  CHECK_H(h);
+  return uploadPhotonsCommon(h, p, false, true);
 }
 
 static int uploadPhotonBeamsCommon(gvpm_context *h, const gvpm_photon_soa *b, const float *end_n, bool fromDevice) {
@@ -706,19 +788,43 @@ int gvpm_upload_beams_dev(gvpm_context *h, const gvpm_photon_soa *beams, const f
   return uploadPhotonBeamsCommon(h, beams, end_n, true);
 }
 
-static int uploadBeamsCommon(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t nsets, bool fromDevice) {
+static int uploadBeamsCommon(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t nsets, bool fromDevice,
+                             bool prefetch = false) {
   if (nsets && !rays) return fail(h, GVPM_ERR_INVALID_ARG, "null camera rays");
   if (nsets > 0x0FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "too many beam sets");
   if (fromDevice) {
+    if (prefetch) return fail(h, GVPM_ERR_INVALID_ARG, "prefetch takes host buffers");
     h->raysDev = rays;
+    h->rayWait = false;
+    h->raysOwnedCur = false;
   } else {
-    HIP_TRY(h, h->raysOwned.ensure((size_t)nsets * 5 + 1));
-    if (nsets) {
-      HIP_TRY(h, hipMemcpyAsync(h->raysOwned.p, rays, (size_t)nsets * 5 * sizeof(gvpm_camera_ray),
-                                hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const bool pinned = nsets && isPinnedHost(rays);
+    if (prefetch && !pinned) return fail(h, GVPM_ERR_INVALID_ARG, "gvpm_prefetch_camera_beams needs pinned host memory (gvpm_host_alloc)");
+    if (prefetch && h->rayPending >= 0) return fail(h, GVPM_ERR_STATE, "a prefetched camera-beam list is already pending");
+    int slot = (h->rayCur + 1) % 3;
+    if (slot == h->rayPending) slot = (h->rayCur + 2) % 3;
+    gvpm_context::RaySlot &rs = h->raySlot[slot];
+    // the evaluation kernel of the step that last used this slot may still be reading it
+    if (rs.read) HIP_TRY(h, hipStreamWaitEvent(h->copyStream, rs.freed, 0));
+    rs.read = false;
+    if (rs.rays.cap < (size_t)nsets * 5 + 1) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));  // regrowing frees the old buffer
+      HIP_TRY(h, rs.rays.ensure((size_t)nsets * 5 + 1));
     }
-    h->raysDev = h->raysOwned.p;
+    if (nsets)
+      HIP_TRY(h, hipMemcpyAsync(rs.rays.p, rays, (size_t)nsets * 5 * sizeof(gvpm_camera_ray), hipMemcpyHostToDevice,
+                                h->copyStream));
+    rs.nsets = (uint32_t)nsets;
+    HIP_TRY(h, hipEventRecord(rs.copied, h->copyStream));
+    if (!pinned) HIP_TRY(h, hipStreamSynchronize(h->copyStream));
+    if (prefetch) {
+      h->rayPending = slot;
+      return GVPM_OK;
+    }
+    h->rayCur = slot;
+    h->raysDev = rs.rays.p;
+    h->rayWait = true;
+    h->raysOwnedCur = true;
   }
   h->nsets = (uint32_t)nsets;
   h->haveBeams = true;
@@ -733,6 +839,10 @@ int gvpm_upload_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uint6
 int gvpm_upload_camera_beams_dev(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t n_sets) {
   CHECK_H(h);
   return uploadBeamsCommon(h, rays, n_sets, true);
+}
+int gvpm_prefetch_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t n_sets) {
+  CHECK_H(h);
+  return uploadBeamsCommon(h, rays, n_sets, false, true);
 }
 
 static int uploadSamplesCommon(gvpm_context *h, const gvpm_vpm_sample *smp, uint64_t n, bool fromDevice) {
@@ -951,11 +1061,18 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
 
 static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, int phase = 0) {
   // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved) and the other phases
+  // a ring of at most GVPM_EVENT_RING pairs per phase: a host that never polls gvpm_get_phase_time keeps the timings of
+  // its last launches instead of growing the pool by three pairs per step
+  constexpr size_t GVPM_EVENT_RING = 256;
   if (h->eventsUsed[phase] == h->events[phase].size()) {
-    hipEvent_t e0, e1;
-    HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
-    h->events[phase].emplace_back(e0, e1);
+    if (h->events[phase].size() >= GVPM_EVENT_RING) {
+      h->eventsUsed[phase] = 0;  // overwrite the oldest
+    } else {
+      hipEvent_t e0, e1;
+      HIP_TRY(h, hipEventCreate(&e0));
+      HIP_TRY(h, hipEventCreate(&e1));
+      h->events[phase].emplace_back(e0, e1);
+    }
   }
   *ev = &h->events[phase][h->eventsUsed[phase]++];
   return GVPM_OK;
@@ -1000,6 +1117,10 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->bs->builtRadius = r;
     rebuilt = h->nph > 0;
   } else {
+    // same inputs, same radius: the set is re-planned and re-traversed in place, once the evaluation kernel that still
+    // reads its items and pair lists is done
+    if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
+    if (h->bs->used && h->pipeline && h->travStream) HIP_TRY(h, hipStreamWaitEvent(h->streamC, h->bs->lastUse, 0));
     HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
   }
   GatherArgs a;
@@ -1391,15 +1512,52 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
   h->useAll = false;
   h->bstream = h->stream;
+  // the streams that read this step's host-uploaded inputs wait for their copies (copy stream)
+  if (h->phWait) {
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->phSlot[h->phCur].copied, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->streamB, h->phSlot[h->phCur].copied, 0));
+    h->phWait = false;
+  }
+  if (h->rayWait) {
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->raySlot[h->rayCur].copied, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->streamB, h->raySlot[h->rayCur].copied, 0));
+    h->rayWait = false;
+  }
+  int rc;
   switch (h->cfg.vol_technique) {
     case GVPM_VOL_BRE2D:
-    case GVPM_VOL_BRE3D: return gatherBRE(h, it, nb_paths);
-    case GVPM_DISTANCE: return gatherVPM(h, it, nb_paths);
+    case GVPM_VOL_BRE3D: rc = gatherBRE(h, it, nb_paths); break;
+    case GVPM_DISTANCE: rc = gatherVPM(h, it, nb_paths); break;
     case GVPM_BEAM_BEAM_1D:
-    case GVPM_BEAM_BEAM_3D_OPTIMIZED: return gatherBeams(h, it, nb_paths);
-    case GVPM_VOL_PLANE0D: return gatherPlanes(h, it, nb_paths);
+    case GVPM_BEAM_BEAM_3D_OPTIMIZED: rc = gatherBeams(h, it, nb_paths); break;
+    case GVPM_VOL_PLANE0D: rc = gatherPlanes(h, it, nb_paths); break;
     default: return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
   }
+  if (rc != GVPM_OK) return rc;
+  // the kernels just queued on the gather stream are the last readers of this step's camera rays
+  if (h->raysOwnedCur) {
+    HIP_TRY(h, hipEventRecord(h->raySlot[h->rayCur].freed, h->stream));
+    h->raySlot[h->rayCur].read = true;
+  }
+  // prefetched inputs (gvpm_prefetch_*) become the current ones: what an upload at this point would have done
+  if (h->phPending >= 0) {
+    h->phCur = h->phPending;
+    h->phPending = -1;
+    h->rawDev = h->phSlot[h->phCur].dev;
+    h->nph = (uint32_t)h->rawDev.n;
+    h->phWait = true;
+    h->photonsDirty = true;
+  }
+  if (h->rayPending >= 0) {
+    h->rayCur = h->rayPending;
+    h->rayPending = -1;
+    h->raysDev = h->raySlot[h->rayCur].rays.p;
+    h->nsets = h->raySlot[h->rayCur].nsets;
+    h->rayWait = true;
+    h->raysOwnedCur = true;
+    h->beamsDirty = true;
+  }
+  return GVPM_OK;
 }
 
 int gvpm_download_vpm_state(gvpm_context *h, float *scale_vol, float *n_vol) {
@@ -1532,6 +1690,7 @@ int gvpm_download_film_dev(gvpm_context *h, int it, int reuse_primal, const floa
 
 int gvpm_synchronize(gvpm_context *h) {
   CHECK_H(h);
+  HIP_TRY(h, hipStreamSynchronize(h->copyStream));  // uploads from pinned memory are left in flight
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GVPM_OK;
 }

@@ -177,10 +177,16 @@ struct gvpm_devgen {
   Buf<SynthTri> tris;
   Buf<SynthMat> mats;
   Buf<uint32_t> counts, counted, nonEmpty, offs, countedOffs, neOffs, ctl;
-  Buf<float> f3[8], f1[4], endN;
-  Buf<uint32_t> flags, pathId;
+  // Outputs are BORROWED by the gather context (gvpm_upload_*_dev), whose kernels of up to three consecutive steps are
+  // in flight: three output sets per kind, used in turn, so that a call never writes what the two steps before it read.
+  struct PhotonOut {
+    Buf<float> f3[8], f1[4], endN;
+    Buf<uint32_t> flags, pathId;
+  } pout[3];
+  int poutIdx = 0, raysIdx = 0;
+  PhotonOut &po() { return pout[poutIdx]; }
   Buf<uint32_t> pixFlag, pixOffs;
-  Buf<gvpm_camera_ray> rays;
+  Buf<gvpm_camera_ray> raysOut[3];
   SortTemp scanTmp;
   uint32_t *pinned = nullptr;  // 8 words, mapped host memory
   double pathsPerPhoton = 0.0;  // light paths walked per stored photon in the last shoot
@@ -262,9 +268,13 @@ int gvpm_devgen_destroy(gvpm_devgen *g) {
   g->tris.release(); g->mats.release();
   g->counts.release(); g->counted.release(); g->nonEmpty.release(); g->offs.release(); g->countedOffs.release();
   g->neOffs.release(); g->ctl.release();
-  for (auto &b : g->f3) b.release();
-  for (auto &b : g->f1) b.release();
-  g->endN.release(); g->flags.release(); g->pathId.release(); g->pixFlag.release(); g->pixOffs.release(); g->rays.release();
+  for (auto &o : g->pout) {
+    for (auto &b : o.f3) b.release();
+    for (auto &b : o.f1) b.release();
+    o.endN.release(); o.flags.release(); o.pathId.release();
+  }
+  g->pixFlag.release(); g->pixOffs.release();
+  for (auto &b : g->raysOut) b.release();
   if (g->scanTmp.d) (void)hipFree(g->scanTmp.d);
   if (g->pinned) (void)hipHostFree(g->pinned);
   if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -278,11 +288,12 @@ static int shootCommon(gvpm_devgen *g, int iteration, uint64_t capacity, int bea
   if (!g || !soa || !nbPaths || capacity == 0 || capacity > 0x7FFFFFF0ull) return GVPM_ERR_INVALID_ARG;
   (void)hipSetDevice(g->device);
   hipStream_t s = g->stream;
-  for (auto &b : g->f3) SY_TRY(b.ensure(capacity * 3 + 4));
-  for (auto &b : g->f1) SY_TRY(b.ensure(capacity + 4));
-  SY_TRY(g->flags.ensure(capacity + 4));
-  SY_TRY(g->pathId.ensure(capacity + 4));
-  if (beams) SY_TRY(g->endN.ensure(capacity * 3 + 4));
+  g->poutIdx = (g->poutIdx + 1) % 3;
+  for (auto &b : g->po().f3) SY_TRY(b.ensure(capacity * 3 + 4));
+  for (auto &b : g->po().f1) SY_TRY(b.ensure(capacity + 4));
+  SY_TRY(g->po().flags.ensure(capacity + 4));
+  SY_TRY(g->po().pathId.ensure(capacity + 4));
+  if (beams) SY_TRY(g->po().endN.ensure(capacity * 3 + 4));
   // paths per batch: what the previous shoot needed per stored photon plus a margin, so that one batch (one
   // count pass + one write pass) usually suffices; `capacity` paths the first time
   const double perPhoton = g->pathsPerPhoton > 0.0 ? g->pathsPerPhoton * 1.06 : 1.0;
@@ -292,11 +303,11 @@ static int shootCommon(gvpm_devgen *g, int iteration, uint64_t capacity, int bea
   SY_TRY(g->ctl.ensure(8));
   SY_TRY(hipMemsetAsync(g->ctl.p, 0, 8 * sizeof(uint32_t), s));
   PhotonOut o;
-  for (int a = 0; a < 8; ++a) o.v3[a] = g->f3[a].p;
-  for (int a = 0; a < 4; ++a) o.f1[a] = g->f1[a].p;
-  o.flags = g->flags.p;
-  o.pathId = g->pathId.p;
-  o.endN = beams ? g->endN.p : nullptr;
+  for (int a = 0; a < 8; ++a) o.v3[a] = g->po().f3[a].p;
+  for (int a = 0; a < 4; ++a) o.f1[a] = g->po().f1[a].p;
+  o.flags = g->po().flags.p;
+  o.pathId = g->po().pathId.p;
+  o.endN = beams ? g->po().endN.p : nullptr;
   uint64_t base = 0, stored = 0, paths = 0;
   for (int batch = 0; stored < capacity; ++batch) {
     if (batch > 4096) return GVPM_ERR_STATE;  // a scene that stores nothing
@@ -322,13 +333,13 @@ static int shootCommon(gvpm_devgen *g, int iteration, uint64_t capacity, int bea
     SY_TRY(hipMemcpyAsync(g->ctl.p, next, sizeof(next), hipMemcpyHostToDevice, s));
     SY_TRY(hipStreamSynchronize(s));
   }
-  soa->pos = g->f3[0].p; soa->wi = g->f3[1].p; soa->flux = g->f3[2].p; soa->parent_pos = g->f3[3].p;
-  soa->parent_n = g->f3[4].p; soa->prefix_w = g->f3[5].p; soa->parent_scat = g->f3[6].p; soa->parent_wi = g->f3[7].p;
-  soa->parent_pdf = g->f1[0].p; soa->edge_pdf = g->f1[1].p; soa->parent_rr = g->f1[2].p; soa->parent_g = g->f1[3].p;
-  soa->flags = g->flags.p;
-  soa->path_id = g->pathId.p;
+  soa->pos = g->po().f3[0].p; soa->wi = g->po().f3[1].p; soa->flux = g->po().f3[2].p; soa->parent_pos = g->po().f3[3].p;
+  soa->parent_n = g->po().f3[4].p; soa->prefix_w = g->po().f3[5].p; soa->parent_scat = g->po().f3[6].p; soa->parent_wi = g->po().f3[7].p;
+  soa->parent_pdf = g->po().f1[0].p; soa->edge_pdf = g->po().f1[1].p; soa->parent_rr = g->po().f1[2].p; soa->parent_g = g->po().f1[3].p;
+  soa->flags = g->po().flags.p;
+  soa->path_id = g->po().pathId.p;
   soa->n = stored;
-  if (endN) *endN = beams ? g->endN.p : nullptr;
+  if (endN) *endN = beams ? g->po().endN.p : nullptr;
   *nbPaths = paths;
   if (stored) g->pathsPerPhoton = (double)base / (double)stored;
   return GVPM_OK;
@@ -367,12 +378,13 @@ int gvpm_devgen_camera_beams(gvpm_devgen *g, int iteration, int tile_mod, int ti
   uint32_t total = 0;
   SY_TRY(hipMemcpyAsync(&total, g->pixOffs.p + npix, 4, hipMemcpyDeviceToHost, s));
   SY_TRY(hipStreamSynchronize(s));
-  SY_TRY(g->rays.ensure((size_t)total * 5 + 5));
+  g->raysIdx = (g->raysIdx + 1) % 3;
+  SY_TRY(g->raysOut[g->raysIdx].ensure((size_t)total * 5 + 5));
   hipLaunchKernelGGL(synth_beam_write_kernel, dim3(nb), dim3(64), 0, s, g->view, iteration, npix, g->pixFlag.p, g->pixOffs.p,
-                     g->rays.p);
+                     g->raysOut[g->raysIdx].p);
   SY_TRY(hipStreamSynchronize(s));
   SY_TRY(hipGetLastError());
-  *rays_dev = g->rays.p;
+  *rays_dev = g->raysOut[g->raysIdx].p;
   *n_sets = total;
   return GVPM_OK;
 }

@@ -26,6 +26,7 @@ SYMBOLS = [
     "gvpm_allreduce_accum", "gvpm_allreduce_film", "gvpm_download_film_dev", "gvpm_devgen_create",
     "gvpm_devgen_destroy", "gvpm_devgen_shoot_photons", "gvpm_devgen_shoot_beams", "gvpm_devgen_camera_beams", "gvpm_devgen_read",
     "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
+    "gvpm_host_alloc", "gvpm_host_alloc_photons", "gvpm_host_free", "gvpm_prefetch_photons", "gvpm_prefetch_camera_beams",
 ]
 
 
@@ -88,8 +89,64 @@ def lib():
         L.gvpm_poisson_preset.argtypes = [C.c_char_p, C.POINTER(abi.PoissonParams)]
         L.gvpm_poisson_solve.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.gvpm_poisson_solve_dev.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.gvpm_host_alloc.argtypes = [C.c_uint64, C.POINTER(vp)]
+        L.gvpm_host_alloc_photons.argtypes = [C.c_uint64, C.POINTER(abi.PhotonSoA), C.POINTER(vp)]
+        L.gvpm_host_free.argtypes = [vp]
+        L.gvpm_prefetch_photons.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
+        L.gvpm_prefetch_camera_beams.argtypes = [vp, vp, C.c_uint64]
         _LIB = L
     return _LIB
+
+
+class PinnedPhotons:
+    """A photon SoA in ONE block of pinned host memory (gvpm_host_alloc_photons): uploads from it are a single packed,
+    asynchronous copy.  fill() copies an abi.Photons into it."""
+
+    def __init__(self, n):
+        self.soa = abi.PhotonSoA()
+        self._block = C.c_void_p()
+        rc = lib().gvpm_host_alloc_photons(n, C.byref(self.soa), C.byref(self._block))
+        if rc != 0:
+            raise GvpmError(rc, "gvpm_host_alloc_photons failed")
+        self.n = n
+
+    def fill(self, ph):
+        assert ph.n == self.n
+        for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
+            a = np.ascontiguousarray(getattr(ph, k))
+            C.memmove(getattr(self.soa, k), a.ctypes.data, a.nbytes)
+        return self
+
+    def close(self):
+        if self._block:
+            lib().gvpm_host_free(self._block)
+            self._block = C.c_void_p()
+
+    __del__ = close
+
+
+class PinnedRays:
+    """Camera-beam sets in pinned host memory (gvpm_host_alloc)."""
+
+    def __init__(self, rays):
+        rays = np.ascontiguousarray(rays)
+        self.nsets = rays.shape[0]
+        self._p = C.c_void_p()
+        rc = lib().gvpm_host_alloc(max(rays.nbytes, 64), C.byref(self._p))
+        if rc != 0:
+            raise GvpmError(rc, "gvpm_host_alloc failed")
+        C.memmove(self._p, rays.ctypes.data, rays.nbytes)
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def close(self):
+        if self._p:
+            lib().gvpm_host_free(self._p)
+            self._p = C.c_void_p()
+
+    __del__ = close
 
 
 class Context:
@@ -145,6 +202,20 @@ class Context:
 
     def upload_camera_beams_dev(self, dev_ptr, n_sets):
         self._check(lib().gvpm_upload_camera_beams_dev(self._h, dev_ptr, n_sets))
+
+    # host buffers in pinned memory (PinnedPhotons / PinnedRays): asynchronous copies on the handle's copy stream
+    def upload_pinned(self, photons=None, rays=None):
+        if photons is not None:
+            self._check(lib().gvpm_upload_photons(self._h, C.byref(photons.soa)))
+        if rays is not None:
+            self._check(lib().gvpm_upload_camera_beams(self._h, rays.ptr, rays.nsets))
+
+    def prefetch(self, photons=None, rays=None):
+        """The inputs of the step after the coming gather (gvpm_prefetch_*)."""
+        if photons is not None:
+            self._check(lib().gvpm_prefetch_photons(self._h, C.byref(photons.soa)))
+        if rays is not None:
+            self._check(lib().gvpm_prefetch_camera_beams(self._h, rays.ptr, rays.nsets))
 
     def upload_beams(self, beams, end_n):
         """beams: abi.Photons re-read as photon beams; end_n: (n,3) float32"""
@@ -254,7 +325,8 @@ class Context:
 
 class DeviceGenerator:
     """Device-side photon shooting and camera-beam generation for a closed-form scene (gvpm_devgen_*).
-    Outputs are device pointers owned by the generator, valid until its next call of the same kind."""
+    Outputs are device pointers owned by the generator; it rotates three output buffers per kind, so an output stays
+    untouched for the two following calls of the same kind (the kernels of up to three steps are in flight)."""
 
     def __init__(self, synth_scene, device=0):
         self._scene = synth_scene  # keeps the host arrays alive during create
@@ -263,7 +335,7 @@ class DeviceGenerator:
         rc = lib().gvpm_devgen_create(C.byref(d), device, C.byref(self._h))
         if rc != 0:
             self._h = None
-            raise GvpmError(f"gvpm_devgen_create failed: {rc}")
+            raise GvpmError(rc, "gvpm_devgen_create failed")  # (status kept: GVPM_ERR_NO_DEVICE / _HIP / _INVALID_ARG)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -278,7 +350,7 @@ class DeviceGenerator:
         soa, nb = abi.PhotonSoA(), C.c_uint64(0)
         rc = lib().gvpm_devgen_shoot_photons(self._h, iteration, capacity, C.byref(soa), C.byref(nb))
         if rc != 0:
-            raise GvpmError(f"gvpm_devgen_shoot_photons failed: {rc}")
+            raise GvpmError(rc, "gvpm_devgen_shoot_photons failed")
         return soa, int(nb.value)
 
     def shoot_beams(self, iteration, capacity):
@@ -286,7 +358,7 @@ class DeviceGenerator:
         soa, nb, en = abi.PhotonSoA(), C.c_uint64(0), C.c_void_p()
         rc = lib().gvpm_devgen_shoot_beams(self._h, iteration, capacity, C.byref(soa), C.byref(en), C.byref(nb))
         if rc != 0:
-            raise GvpmError(f"gvpm_devgen_shoot_beams failed: {rc}")
+            raise GvpmError(rc, "gvpm_devgen_shoot_beams failed")
         return soa, en.value, int(nb.value)
 
     def read(self, dev_ptr, count, dtype):
@@ -294,7 +366,7 @@ class DeviceGenerator:
         out = np.empty(count, dtype)
         rc = lib().gvpm_devgen_read(self._h, dev_ptr, out.ctypes.data, out.nbytes)
         if rc != 0:
-            raise GvpmError(f"gvpm_devgen_read failed: {rc}")
+            raise GvpmError(rc, "gvpm_devgen_read failed")
         return out
 
     def camera_beams(self, iteration, tile_mod=1, tile_rem=0):
@@ -302,7 +374,7 @@ class DeviceGenerator:
         ptr, n = C.c_void_p(), C.c_uint64(0)
         rc = lib().gvpm_devgen_camera_beams(self._h, iteration, tile_mod, tile_rem, C.byref(ptr), C.byref(n))
         if rc != 0:
-            raise GvpmError(f"gvpm_devgen_camera_beams failed: {rc}")
+            raise GvpmError(rc, "gvpm_devgen_camera_beams failed")
         return ptr.value, int(n.value)
 
 

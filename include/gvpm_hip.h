@@ -16,11 +16,19 @@
  *    the last failure of a handle is available through gvpm_last_error();
  *    nothing throws or aborts (Mitsuba's SLog(EError) throws; a shim converts);
  *  - the caller owns every host buffer passed in; the library copies during
- *    the call (uploads are synchronous with respect to the host buffer);
+ *    the call (uploads are synchronous with respect to the host buffer), with
+ *    one exception: a buffer in PINNED host memory (gvpm_host_alloc*) is copied
+ *    asynchronously on the handle's copy stream and must stay untouched until
+ *    the gvpm_gather that consumes it has returned (G-BRE) or, for the other
+ *    techniques, until gvpm_synchronize / a download has returned;
  *  - a handle is single-owner (call it from the RenderJob thread only);
  *    kernels are stream-ordered; gvpm_download_* block until results are ready;
  *  - the `_dev` variants take DEVICE pointers (already resident in HBM, e.g.
- *    a torch tensor's data_ptr()) and do no PCIe traffic.
+ *    a torch tensor's data_ptr()) and do no PCIe traffic.  They are BORROWED:
+ *    kernels of up to three consecutive steps are in flight at a time (build of
+ *    N+2, traversal of N+1, evaluation of N), so a borrowed buffer must stay
+ *    untouched until gvpm_synchronize has returned or the SECOND gvpm_gather
+ *    after the one that consumed it has returned.
  *
  * All floating-point payload is fp32 (the reference's SCons default
  * SINGLE_PRECISION build, build/config-linux-gcc.py:7); the device computes in
@@ -297,6 +305,19 @@ int gvpm_upload_camera_beams_dev(gvpm_context *h,
                                  uint64_t n_sets);
 int gvpm_upload_vpm_samples_dev(gvpm_context *h, const gvpm_vpm_sample *samples_dev, uint64_t n);
 
+/* ---- pipelined uploads -----------------------------------------------------*/
+/* Pinned host memory for producers (hipHostMalloc).  gvpm_host_alloc_photons lays ONE block out as the 14 arrays
+ * of a photon SoA in the struct's order and returns the view: an upload from it is a single packed copy.           */
+int gvpm_host_alloc(uint64_t bytes, void **out);
+int gvpm_host_alloc_photons(uint64_t n, gvpm_photon_soa *view, void **block);
+int gvpm_host_free(void *p);
+/* Start copying the inputs of the step AFTER the coming gvpm_gather (pinned memory only): the copy runs on the copy
+ * stream while that gather's kernels run, and the set becomes the current input when that gather returns -- as if
+ * gvpm_upload_* had been called at that point.  One pending set per kind.  Loop of a pipelined host:
+ *   upload(1); for N: prefetch(N+1); gather(N).                                                                     */
+int gvpm_prefetch_photons(gvpm_context *h, const gvpm_photon_soa *photons);
+int gvpm_prefetch_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t n_sets);
+
 /* ---- the hot path ---------------------------------------------------------*/
 /* One SPPM iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079;
  * vol_technique BRE2D/BRE3D): builds the acceleration structure over the
@@ -404,14 +425,16 @@ typedef struct gvpm_devgen gvpm_devgen;
 int gvpm_devgen_create(const gvpm_devgen_scene *scene, int device, gvpm_devgen **out);
 int gvpm_devgen_destroy(gvpm_devgen *g);
 /* shoots light paths 0, 1, 2, ... of `iteration` until `capacity` photons are stored; *dev_soa receives device
- * pointers owned by the generator (valid until its next shoot), *nb_paths the number of paths shot             */
+ * pointers owned by the generator, *nb_paths the number of paths shot.  The generator rotates THREE output sets per
+ * kind (photons / beams, camera rays): an output stays untouched during the two following calls of its kind, which
+ * is what the borrowing rule of the `_dev` uploads needs (kernels of three steps in flight)                       */
 int gvpm_devgen_shoot_photons(gvpm_devgen *g, int iteration, uint64_t capacity, gvpm_photon_soa *dev_soa,
                               uint64_t *nb_paths);
 /* photon beams (one record per medium edge, see gvpm_upload_beams) + the end normals                           */
 int gvpm_devgen_shoot_beams(gvpm_devgen *g, int iteration, uint64_t capacity, gvpm_photon_soa *dev_soa,
                             const float **end_n_dev, uint64_t *nb_paths);
 /* beam sets (5 rays each) of the pixels whose 4x4 tile t has t % tile_mod == tile_rem (1, 0: the whole frame),
- * row-major pixel order; *rays_dev is owned by the generator (valid until its next call)                        */
+ * row-major pixel order; *rays_dev is owned by the generator (one of three buffers used in turn, see above)        */
 int gvpm_devgen_camera_beams(gvpm_devgen *g, int iteration, int tile_mod, int tile_rem,
                              const gvpm_camera_ray **rays_dev, uint64_t *n_sets);
 /* copies `bytes` of a generator output back to the host (inspection, tests)                                     */

@@ -52,7 +52,16 @@ for k in fetch:
     short = k.split("(")[0].split("::")[-1].split("<")[0]
     traffic[short] = {"fetch_kb_raw": fetch[k], "write_kb_raw": write.get(k, 0.0),
                       "hbm_bytes_per_launch": (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0}
+# what the measurement was taken on (bench.py reports `traffic` only for the same workload and kernel sources)
+try:
+    line = json.loads(open(os.path.join(out, "bench_trace.log")).read().strip().splitlines()[-1])
+    cfg = line["config"]
+    traffic["_meta"] = {"technique": cfg["technique"], "scene": cfg["scene"], "frame": cfg["frame"],
+                        "photons": cfg["photons_per_iter"], "scale": float(cfg["workload"].rsplit(" ", 1)[-1]),
+                        "n_gpus": line["n_gpus"], "csrc_sha": cfg["csrc_sha"]}
+except (OSError, ValueError, KeyError, IndexError) as e:
+    print("no bench line to take the workload from:", e)
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
 print("== HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, bytes) ==")
-for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:10]:
+for k, v in sorted(((k, v) for k, v in traffic.items() if k != "_meta"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:10]:
     print(f"   {k:40s} {v['hbm_bytes_per_launch'] / 1e6:12.2f} MB")

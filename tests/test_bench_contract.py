@@ -26,6 +26,34 @@ def test_json_line_has_the_contract_keys():
     for key in ("cores", "kind", "sample"):
         assert '"%s"' % key in src, key
     assert '"workload"' in src and '"vs_baseline": None' in src
+    # round 2: the PCIe-inclusive leg, the parity figures and the 1-thread CPU baseline ride on the same line
+    for key in ("upload_inclusive", "parity_l2", "relMSE_throughput_dx_dy", "one_thread", "env", "csrc_sha"):
+        assert '"%s"' % key in src, key
+
+
+def test_development_switches_are_refused():
+    env = dict(os.environ, GVPM_DEBUG_FLAGS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "GVPM_DEBUG_FLAGS" in (out.stderr + out.stdout)
+
+
+def test_rel_mse_is_the_reference_formula():
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from gvpm_amd import metrics
+    rng = np.random.default_rng(3)
+    ref = rng.random((5, 7, 3)) * 2
+    img = ref + rng.normal(0, 0.1, ref.shape)
+    # metricPix + errorNorm of scripts/rgbe/sources/imageerrors.h, pixel by pixel
+    tot = 0.0
+    for a, b in zip(img.reshape(-1, 3), ref.reshape(-1, 3)):
+        diff = ((a[0] - b[0]) + (a[1] - b[1]) + (a[2] - b[2])) / 3
+        gray = (b[0] + b[1] + b[2]) / 3
+        tot += diff * diff / (gray * gray + 0.001)
+    assert abs(metrics.rel_mse(img, ref) - tot / 35) < 1e-12
+    assert metrics.rel_mse(ref, ref) == 0.0
+    assert abs(metrics.l2_over_luminance(img, ref, 1.0) - np.sqrt(((img - ref) ** 2).mean())) < 1e-15
 
 
 def test_without_a_gpu_it_refuses_instead_of_falling_back():

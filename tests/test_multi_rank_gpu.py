@@ -1,0 +1,69 @@
+"""The N > 1 path on the device: image tiles dealt round-robin to the ranks, photon map replicated, the
+partial films summed.  A one-GPU box runs the two ranks on GPU 0 over gloo (`--single-device`); the ranks are child
+processes of their own (started before they touch the GPU), as bench.py's are under the driver."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "multi_rank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(nproc, script, *args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script, *args]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-1000:]
+    return out
+
+
+def test_two_ranks_sum_to_the_single_rank_film(tmp_path):
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    out = subprocess.run([sys.executable, WORKER, "--out", one], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    _launch(2, WORKER, "--out", two, "--backend", "gloo", "--single-device")
+    f1, f2 = np.load(one), np.load(two)
+    assert f1.shape == f2.shape and np.abs(f1[0]).max() > 0 and np.abs(f1[1]).max() > 0
+    # computeGradient adds one term from a pixel and one from its +x / +y neighbour, each non-zero on exactly one rank:
+    # dx, dy and the throughput of the sharded run are the single-rank film's, up to the order in which the float
+    # atomics of a pixel's work items land (two runs of ONE rank differ by as much: test_full_size_properties)
+    scale = np.abs(f1[0]).max()
+    assert np.allclose(f1, f2, rtol=2e-5, atol=2e-6 * scale)
+    assert np.array_equal(f1[0] == 0, f2[0] == 0)  # the throughput's support: no pixel lost or doubled at a tile border
+
+
+def test_library_rccl_collective_single_rank(tmp_path):
+    """gvpm_comm_unique_id / gvpm_comm_init / gvpm_allreduce_film with a world of one: RCCL loaded, communicator
+    created, the all-reduce of the film is the identity."""
+    a, b = str(tmp_path / "a.npy"), str(tmp_path / "b.npy")
+    for path, coll in ((a, "torch"), (b, "gvpm")):
+        out = subprocess.run([sys.executable, WORKER, "--out", path, "--collective", coll, "--frame", "64", "--steps", "2"],
+                             capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+    fa, fb = np.load(a), np.load(b)
+    assert np.abs(fa).max() > 0 and np.allclose(fa, fb, rtol=2e-5, atol=2e-6 * np.abs(fa[0]).max())
+
+
+def test_bench_two_ranks_is_the_strong_sharded_c4_shape():
+    out = _launch(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                  "--single-device", "--frame", "128", "--photons", "60000", "--distinct", "2")
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["scene"] == "fogroom" and line["config"]["frame"] == [128, 128]
+    assert "round-robin over 2 ranks" in line["config"]["sharding"] and "all-reduce" in line["config"]["sharding"]
+    assert line["roofline"]["kernel_avg_ms"] > 0 and line["config"]["pixels_per_gpu"] == 128 * 128 / 2

@@ -441,3 +441,50 @@ def test_non_consecutive_iteration_numbers_fold_like_the_reference():
     assert l2(acc, ref, lum) < TOL
     for a, b in zip(film, O.assemble(ref, 9, True)):
         assert l2(a, b, lum) < TOL
+
+
+def test_prefetched_pinned_uploads_equal_plain_uploads():
+    """gvpm_host_alloc* + gvpm_prefetch_*: the copy of step N+1 is started before the gather of step N and becomes the
+    current input when that gather returns -- four iterations that way must give the plain-upload accumulators, bit for
+    bit (same kernels on the same inputs), and so must asynchronous uploads from pinned memory without prefetch."""
+    c = cases.make_case("cbox", 40, 36, 20000, 2.5)
+    data = []
+    for it in range(1, 5):
+        ph, nb = c.sc.shoot_photons(it, 20000 + 1000 * it)   # sizes differ: the staging slots regrow
+        data.append((ph, nb, c.sc.camera_beams(it)))
+
+    def run(mode):
+        ctx = hip.Context(c.p, device=0)
+        ctx.upload_scene(*c.tris)
+        ctx.upload_medium(c.m)
+        pinned = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays)) for ph, nb, rays in data] if mode != "plain" else None
+        if mode == "prefetch":
+            ctx.upload_pinned(pinned[0][0], pinned[0][2])
+        for it, (ph, nb, rays) in enumerate(data, 1):
+            if mode == "plain":
+                ctx.upload_photons(ph)
+                ctx.upload_camera_beams(rays)
+            elif mode == "pinned":
+                ctx.upload_pinned(pinned[it - 1][0], pinned[it - 1][2])
+            elif it < len(data):
+                ctx.prefetch(pinned[it][0], pinned[it][2])
+            ctx.gather(it, nb)
+        acc, st = ctx.download_accum(), ctx.stats()
+        ctx.close()
+        return acc, st
+
+    ref, rst = run("plain")
+    for mode in ("pinned", "prefetch"):
+        acc, st = run(mode)
+        assert st["evaluations"] == rst["evaluations"] > 10000
+        assert np.allclose(acc, ref, rtol=2e-6, atol=0)   # (float atomics: the order of the partial sums is not fixed)
+    # a second prefetch before the gather that consumes the first is a call-order error, pageable memory an argument error
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    pp, pr = hip.PinnedPhotons(data[0][0].n).fill(data[0][0]), hip.PinnedRays(data[0][2])
+    ctx.prefetch(pp, pr)
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.prefetch(pp, pr)
+    assert e.value.code == abi.GVPM_ERR_STATE
+    ctx.close()
