@@ -144,12 +144,10 @@ __global__ __launch_bounds__(64) void synth_beam_flag_kernel(SceneView sc, int i
   int px, py;
   uint32_t f = 0;
   if (ownedPixel(sc, p, tileMod, tileRem, px, py)) {
-    // only the base ray decides whether the pixel has a set
-    Philox rng(sc.seed, 0xca3eu, (uint32_t)iteration, (uint32_t)(py * sc.width + px));
-    const double jx = rng.next1D(), jy = rng.next1D();
-    CamPath base;
-    traceCamera(sc, px + jx, py + jy, base);
-    f = base.hasBeam ? 1u : 0u;
+    // the number of sets (medium edges of the base path: 0, 1, or 2 behind a mirror)
+    gvpm_camera_ray sets[2][5];
+    float w[2];
+    f = (uint32_t)cameraBeamSets(sc, iteration, px, py, sets, w);
   }
   flag[p] = f;
 }
@@ -159,10 +157,12 @@ __global__ __launch_bounds__(64) void synth_beam_write_kernel(SceneView sc, int 
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix || !flag[p]) return;
   const int px = (int)(p % (uint32_t)sc.width), py = (int)(p / (uint32_t)sc.width);
-  gvpm_camera_ray set[5];
-  if (!cameraBeamSet(sc, iteration, px, py, set)) return;
+  gvpm_camera_ray sets[2][5];
+  float w[2];
+  const int n = cameraBeamSets(sc, iteration, px, py, sets, w);
   gvpm_camera_ray *dst = out + (size_t)offs[p] * 5;
-  for (int k = 0; k < 5; ++k) dst[k] = set[k];
+  for (int q = 0; q < n; ++q)
+    for (int k = 0; k < 5; ++k) dst[5 * q + k] = sets[q][k];
 }
 
 }  // namespace

@@ -10,6 +10,7 @@ struct gvpm_synth {
   std::vector<gvpm_camera_ray> rays;
   std::vector<float> v0, e1, e2;
   std::vector<gvpm_vpm_sample> samples;
+  std::vector<float> selW;  // per beam set of `rays`: its weight in the G-VPM edge selection
   std::vector<float> endN, w1, len1;
   std::vector<double> dgTris, dgAlbedo;  // gvpm_devgen_scene arrays
   std::vector<int32_t> dgTriMat, dgMatKind;
@@ -121,21 +122,21 @@ uint64_t gvpm_synth_planes(gvpm_synth *s, int it, const float **w1, const float 
 uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
                           const gvpm_camera_ray **out) {
   if (!s || !out) return 0;
-  gvpm::cameraBeams(s->scene, it, x0, y0, x1, y1, s->rays);
+  gvpm::cameraBeams(s->scene, it, x0, y0, x1, y1, s->rays, 1, 0, &s->selW);
   *out = s->rays.data();
   return s->rays.size() / 5;
 }
 
 uint64_t gvpm_synth_beams_interleaved(gvpm_synth *s, int it, int tile_mod, int tile_rem, const gvpm_camera_ray **out) {
   if (!s || !out || tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) return 0;
-  gvpm::cameraBeams(s->scene, it, 0, 0, s->scene.width, s->scene.height, s->rays, tile_mod, tile_rem);
+  gvpm::cameraBeams(s->scene, it, 0, 0, s->scene.width, s->scene.height, s->rays, tile_mod, tile_rem, &s->selW);
   *out = s->rays.data();
   return s->rays.size() / 5;
 }
 
 uint64_t gvpm_synth_vpm_samples(gvpm_synth *s, int it, int nb_camera_samples, const gvpm_vpm_sample **out) {
   if (!s || !out || nb_camera_samples <= 0) return 0;
-  gvpm::cameraSamplesVPM(s->scene, it, s->rays, nb_camera_samples, s->samples);
+  gvpm::cameraSamplesVPM(s->scene, it, s->rays, s->selW, nb_camera_samples, s->samples);
   *out = s->samples.data();
   return s->samples.size();
 }

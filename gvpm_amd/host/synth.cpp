@@ -149,6 +149,19 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
       s.tanHalfFovX = std::tan(0.5 * 60.0 * kPi / 180.0);
       s.cameraInside = true;
     }
+  } else if (name == "cbox_mirror" || name == "cbox_mirror_side") {
+    // closed room, sensor inside the fog, one wall a perfect mirror: the camera paths that meet it have TWO medium
+    // edges (sensor -> mirror -> a diffuse wall), light paths get Dirac vertices (manifold-type shifts).  Back wall:
+    // perpendicular to the optical axis (the sensor's area pdf is constant over it); `_side`: the left wall, met at
+    // grazing angles (pdf, Jacobian and GOp of the shifted paths all differ from the base path's)
+    s.mats.push_back({MAT_MIRROR, V3(0.9, 0.85, 0.8)});  // 4
+    if (name == "cbox_mirror") addBoxRoom(s, 0, 0, 4, 1, 2, 0);
+    else addBoxRoom(s, 0, 0, 0, 4, 2, 0);
+    setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
+    setMedium(s, 0.5, 0.5, 0.0);
+    s.camPos = V3(0.1, 0.05, 0.95);
+    s.tanHalfFovX = std::tan(0.5 * 75.0 * kPi / 180.0);
+    s.cameraInside = true;
   } else if (name == "fogroom") {
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
@@ -293,14 +306,16 @@ static uint64_t shootCommon(const SynthScene &scene, int iteration, uint64_t cap
 
 // ----------------------------------------------------------- camera beams --
 void cameraBeams(const SynthScene &scene, int iteration, int x0, int y0, int x1, int y1,
-                 std::vector<gvpm_camera_ray> &out, int tileMod, int tileRem) {
+                 std::vector<gvpm_camera_ray> &out, int tileMod, int tileRem, std::vector<float> *selW) {
   out.clear();
+  if (selW) selW->clear();
   const SceneView sc = scene.view();
   const int tilesX = (sc.width + 3) / 4;
   // pixels are keyed by their index: rows are generated by worker threads and concatenated in row order,
   // which is the sequential loop's output
   const int nrows = y1 > y0 ? y1 - y0 : 0;
   std::vector<std::vector<gvpm_camera_ray>> rows((size_t)nrows);
+  std::vector<std::vector<float>> rowW((size_t)nrows);
   const unsigned nthreads = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), (unsigned)std::max(1, nrows)}));
   auto worker = [&](unsigned tid) {
     for (int r = (int)tid; r < nrows; r += (int)nthreads) {
@@ -308,9 +323,13 @@ void cameraBeams(const SynthScene &scene, int iteration, int x0, int y0, int x1,
       for (int px = x0; px < x1; ++px) {
         // image-sharded hosts: 4x4-pixel tiles dealt round-robin to the ranks (an even split of the work)
         if (tileMod > 1 && ((py / 4) * tilesX + px / 4) % tileMod != tileRem) continue;
-        gvpm_camera_ray set[5];
-        if (!cameraBeamSet(sc, iteration, px, py, set)) continue;
-        rows[(size_t)r].insert(rows[(size_t)r].end(), set, set + 5);
+        gvpm_camera_ray sets[2][5];
+        float w[2];
+        const int n = cameraBeamSets(sc, iteration, px, py, sets, w);  // one set per medium edge of the pixel's path
+        for (int k = 0; k < n; ++k) {
+          rows[(size_t)r].insert(rows[(size_t)r].end(), sets[k], sets[k] + 5);
+          rowW[(size_t)r].push_back(w[k]);
+        }
       }
     }
   };
@@ -322,24 +341,46 @@ void cameraBeams(const SynthScene &scene, int iteration, int x0, int y0, int x1,
   for (const auto &r : rows) total += r.size();
   out.reserve(total);
   for (const auto &r : rows) out.insert(out.end(), r.begin(), r.end());
+  if (selW)
+    for (const auto &r : rowW) selW->insert(selW->end(), r.begin(), r.end());
 }
 
+// computeVolumeGradientPhoton's per-pixel part, gvpm.cpp:1117-1172: the CDF over the medium edges of the pixel's camera
+// path (weights weightBeam.max()), one sampler->next1D() per camera sample, sampleReuse (the selected edge and the
+// re-stretched sample), and the selection probability the functor divides by.  The sets of a pixel are consecutive.
 void cameraSamplesVPM(const SynthScene &sc, int iteration, const std::vector<gvpm_camera_ray> &rays,
-                      int nbCameraSamples, std::vector<gvpm_vpm_sample> &out) {
+                      const std::vector<float> &selW, int nbCameraSamples, std::vector<gvpm_vpm_sample> &out) {
   out.clear();
   const size_t nsets = rays.size() / 5;
-  for (size_t s = 0; s < nsets; ++s) {
+  for (size_t s = 0; s < nsets;) {
     const uint32_t pix = rays[5 * s].pixel;
+    size_t e = s + 1;
+    while (e < nsets && rays[5 * e].pixel == pix) ++e;
+    const size_t ne = e - s;  // medium edges of this pixel
+    // DiscreteDistribution::normalize (include/mitsuba/core/pmf.h): cdf[i + 1] = cdf[i] + w[i], divided by the sum
+    float cdf[3] = {0.f, 0.f, 0.f}, w[2] = {1.f, 0.f};
+    for (size_t k = 0; k < ne && k < 2; ++k) {
+      w[k] = selW.size() == nsets ? selW[s + k] : 1.f;
+      cdf[k + 1] = cdf[k] + w[k];
+    }
+    const float sum = cdf[ne < 2 ? ne : 2];
+    for (size_t k = 1; k <= ne && k <= 2; ++k) cdf[k] = sum > 0.f ? cdf[k] / sum : 0.f;
+    cdf[ne < 2 ? ne : 2] = 1.f;
     const uint32_t idx = (pix >> 16) * (uint32_t)sc.width + (pix & 0xFFFFu);
     Philox rng(sc.seed, 0x5a3fu, (uint32_t)iteration, idx);
     for (int k = 0; k < nbCameraSamples; ++k) {
+      float u = rng.next1D();
+      // sampleReuse: index = the entry whose cdf interval holds u; u re-stretched to [0, 1) inside it
+      size_t sel = (ne >= 2 && u >= cdf[1]) ? 1 : 0;
+      u = (u - cdf[sel]) / (cdf[sel + 1] - cdf[sel]);
       gvpm_vpm_sample sm;
-      sm.set = (uint32_t)s;
-      sm.rand = rng.next1D();  // sampleReuse over a single-entry CDF leaves the sample unchanged
-      sm.pdf_sel = 1.f;
+      sm.set = (uint32_t)(s + sel);
+      sm.rand = u;
+      sm.pdf_sel = cdf[sel + 1] - cdf[sel];
       sm.reserved = 0;
       out.push_back(sm);
     }
+    s = e;
   }
 }
 

@@ -74,13 +74,14 @@ void planesFromBeams(const SynthScene &sc, int iteration, const PhotonBuffers &b
 
 // Camera beam sets (5 rays each) for the pixels [x0,x1) x [y0,y1) of iteration
 // `iteration`; pixels whose camera path has no medium edge produce no set.
+// selW (optional): per set, the weight of its edge in the G-VPM edge selection (gvpm.cpp:1117-1129).
 void cameraBeams(const SynthScene &sc, int iteration, int x0, int y0, int x1, int y1,
-                 std::vector<gvpm_camera_ray> &out, int tileMod = 1, int tileRem = 0);
+                 std::vector<gvpm_camera_ray> &out, int tileMod = 1, int tileRem = 0, std::vector<float> *selW = nullptr);
 
-// G-VPM camera samples for beam sets produced by cameraBeams(): nbCameraSamples records per set,
-// consecutive per pixel (gvpm.cpp:1143-1172 with a one-edge camera path: selBeam = {1}).
+// G-VPM camera samples for beam sets produced by cameraBeams() (with their selection weights): nbCameraSamples records
+// per PIXEL, consecutive (gvpm.cpp:1117-1172: edge selection by sampleReuse over the pixel's medium edges).
 void cameraSamplesVPM(const SynthScene &sc, int iteration, const std::vector<gvpm_camera_ray> &rays,
-                      int nbCameraSamples, std::vector<gvpm_vpm_sample> &out);
+                      const std::vector<float> &selW, int nbCameraSamples, std::vector<gvpm_vpm_sample> &out);
 
 void defaultParams(const SynthScene &sc, gvpm_params &p);
 

@@ -15,7 +15,9 @@
 
 namespace gvpm {
 
-enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1 };
+// MAT_MIRROR: perfect specular reflector (a Dirac BSDF, reflectance = albedo): what puts a SECOND medium edge on a
+// camera path (randomWalkFromPixelToFirstDiffuse walks on past smooth vertices) and a non-diffuse vertex on light paths
+enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2 };
 
 struct SynthTri {
   V3 v0, e1, e2, n;  // n: geometric normal (front side)
@@ -188,12 +190,21 @@ GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
         // index-matched medium boundary: passes straight through and leaves the fog
         break;
       }
-      if (dot(cur.n, wi) <= 0) break;  // one-sided diffuse BSDF
-      V3 local = cosineHemisphere(a, b);
-      wo = toWorld(cur.n, local);
-      cur.weight = cur.albedo;
-      cur.pdf = local.z * kInvPi;
-      if (local.z <= 0 || maxc(cur.weight) <= 0) break;
+      if (dot(cur.n, wi) <= 0) break;  // one-sided BSDFs
+      if (cur.matKind == MAT_MIRROR) {
+        // Dirac reflection: weight = reflectance, pdf = 1 in the discrete measure (not converted to area below)
+        wo = cur.n * (2.0 * dot(cur.n, wi)) - wi;
+        cur.weight = cur.albedo;
+        cur.pdf = 1.0;
+        solidAngle = false;
+        if (maxc(cur.weight) <= 0) break;
+      } else {
+        V3 local = cosineHemisphere(a, b);
+        wo = toWorld(cur.n, local);
+        cur.weight = cur.albedo;
+        cur.pdf = local.z * kInvPi;
+        if (local.z <= 0 || maxc(cur.weight) <= 0) break;
+      }
     } else {  // medium
       V3 wi = normalize(path[i - 1].pos - cur.pos);
       double a = rng.next1D(), b = rng.next1D();
@@ -400,6 +411,7 @@ GVPM_HD inline void flattenPath(const SceneView &sc, const LPath &path, RecList 
     r.parentWi = V3(1.0, 0.0, 0.0);
     uint32_t ptype = GVPM_PARENT_EMITTER, comp = GVPM_BSDF_DIFFUSE_REFLECTION;
     if (par.type == VT_SURFACE) {
+      if (par.matKind == MAT_MIRROR) comp = 0x00008u;  // BSDF::EDeltaReflection
       ptype = GVPM_PARENT_SURFACE;
       r.parentScat = par.albedo;
       r.parentWi = normalize(path[i - 2].pos - par.pos);
@@ -418,11 +430,26 @@ GVPM_HD inline void flattenPath(const SceneView &sc, const LPath &path, RecList 
 }
 
 
+// A camera path of the long-beam walk to the first diffuse vertex (randomWalkFromPixelToFirstDiffuse,
+// gvpm_gatherpoint.h:22-170) reduced to what the gather reads: its medium edges (at most two here: a second one behind
+// a mirror) with the geometry of their end points.
+struct CamEdge {
+  V3 o, d, nEnd;   // start point, unit direction (away from the camera), geometric normal at the end point
+  double len;
+  int matEnd;      // material kind at the end point
+  V3 albedoEnd;    // its reflectance
+};
 struct CamPath {
   bool hasBeam;
-  V3 v2, v3, d, n2, n3;
-  double len1, len2;
-  double pdfDir;  // solid-angle pdf of the primary direction (0 outside the film)
+  int nEdges;        // medium edges
+  int firstEdge;     // path index of the first medium edge: 1 (sensor inside the medium) or 2 (behind the index-matched boundary)
+  CamEdge e[2];
+  V3 n2;             // normal at vertex 2 (the primary hit), len1 = |v2 - v1|: the sensor's area-measure conversion
+  double len1;
+  V3 d;              // primary direction
+  double pdfDir;     // solid-angle pdf of the primary direction (0 outside the film)
+  double rr2;        // rrWeight of the mirror vertex (1 when there is none)
+  V3 rho;            // its reflectance
 };
 
 GVPM_HD inline double importance(const SceneView &sc, double sx, double sy, V3 d) {
@@ -435,90 +462,164 @@ GVPM_HD inline double importance(const SceneView &sc, double sx, double sy, V3 d
   return 1.0 / (area * cosTheta * cosTheta * cosTheta);
 }
 
-GVPM_HD inline void traceCamera(const SceneView &sc, double sx, double sy, CamPath &cp) {
+// Traces the path through film position (sx, sy).  A base path (`base` == nullptr) walks on behind a mirror (its
+// Russian roulette is the caller's: cameraBeamSets); a shifted path copies the base path's decisions and half-vectors
+// (ShiftGatherPoint::trace, shift_cameraPath.h:146-413) and stops where the base path stops.
+GVPM_HD inline void traceCamera(const SceneView &sc, double sx, double sy, CamPath &cp, const CamPath *base = nullptr) {
   double tx = sc.tanHalfFovX, ty = tx * sc.height / sc.width;
   V3 d = normalize(V3((2 * sx / sc.width - 1) * tx, (2 * sy / sc.height - 1) * ty, -1.0));
   cp.d = d;
   cp.pdfDir = importance(sc, sx, sy, d);
   cp.hasBeam = false;
+  cp.nEdges = 0;
+  cp.firstEdge = sc.cameraInside ? 1 : 2;
+  cp.rr2 = base ? base->rr2 : 1.0;  // currInfo->weight *= baseVertex->rrWeight (shift_cameraPath.h:353)
+  cp.rho = V3(1.0);
   Hit h;
   if (!closestHit(sc, sc.camPos, d, kEpsilon, h)) return;
   const SynthTri &t2 = sc.tris[h.tri];
-  if (sc.cameraInside) {
-    // sensor inside the medium: edge 1 (sensor sample -> first surface) is the medium edge
-    if (sc.mats[t2.mat].kind == MAT_NULL) return;
-    cp.v2 = sc.camPos;
-    cp.v3 = sc.camPos + d * h.t;
-    cp.n2 = cp.n3 = t2.n;
-    cp.len1 = cp.len2 = h.t;
-    cp.hasBeam = true;
-    return;
-  }
-  if (sc.mats[t2.mat].kind != MAT_NULL) return;  // did not enter through the medium boundary
-  cp.v2 = sc.camPos + d * h.t;
   cp.n2 = t2.n;
   cp.len1 = h.t;
-  Hit h3;
-  if (!closestHit(sc, cp.v2, d, kEpsilon, h3)) return;
-  const SynthTri &t3 = sc.tris[h3.tri];
-  if (sc.mats[t3.mat].kind == MAT_NULL) return;
-  cp.v3 = cp.v2 + d * h3.t;
-  cp.n3 = t3.n;
-  cp.len2 = h3.t;
+  if (sc.cameraInside) {
+    // sensor inside the medium: edge 1 (sensor sample -> first surface) is the first medium edge
+    if (sc.mats[t2.mat].kind == MAT_NULL) return;
+    cp.e[0].o = sc.camPos;
+    cp.e[0].d = d;
+    cp.e[0].len = h.t;
+    cp.e[0].nEnd = t2.n;
+    cp.e[0].matEnd = sc.mats[t2.mat].kind;
+    cp.e[0].albedoEnd = sc.mats[t2.mat].albedo;
+  } else {
+    if (sc.mats[t2.mat].kind != MAT_NULL) return;  // did not enter through the medium boundary
+    // vertex 2 is a null interaction (an index-matched boundary): the direction is kept (shift_cameraPath.h:292-296)
+    const V3 v2 = sc.camPos + d * h.t;
+    Hit h3;
+    if (!closestHit(sc, v2, d, kEpsilon, h3)) return;
+    const SynthTri &t3 = sc.tris[h3.tri];
+    if (sc.mats[t3.mat].kind == MAT_NULL) return;
+    cp.e[0].o = v2;
+    cp.e[0].d = d;
+    cp.e[0].len = h3.t;
+    cp.e[0].nEnd = t3.n;
+    cp.e[0].matEnd = sc.mats[t3.mat].kind;
+    cp.e[0].albedoEnd = sc.mats[t3.mat].albedo;
+  }
+  cp.nEdges = 1;
   cp.hasBeam = true;
+  // a mirror at the end of the first medium edge: the walk goes on (one bounce: the scenes hold one mirror wall)
+  if (cp.e[0].matEnd != MAT_MIRROR || (base && base->nEdges < 2)) return;
+  const CamEdge &e0 = cp.e[0];
+  if (dot(e0.nEnd, e0.d) >= 0) return;  // one-sided: seen from behind
+  cp.rho = e0.albedoEnd;
+  // half-vector copy at a Dirac vertex = the mirror direction (halfVectorShift, shift_utilities.h:94-107: the base
+  // half-vector of a mirror is its normal; the Jacobian is forced to 1, shift_cameraPath.h:317-318)
+  const V3 wi = -e0.d;
+  const V3 wo = e0.nEnd * (2.0 * dot(e0.nEnd, wi)) - wi;
+  const V3 v3o = e0.o + e0.d * e0.len;
+  Hit h2;
+  if (!closestHit(sc, v3o, wo, kEpsilon, h2)) return;
+  const SynthTri &tn = sc.tris[h2.tri];
+  cp.e[1].o = v3o;
+  cp.e[1].d = wo;
+  cp.e[1].len = h2.t;
+  cp.e[1].nEnd = tn.n;
+  cp.e[1].matEnd = sc.mats[tn.mat].kind;
+  cp.e[1].albedoEnd = sc.mats[tn.mat].albedo;
+  cp.nEdges = 2;
 }
 
-GVPM_HD inline void fillRay(gvpm_camera_ray &r, const CamPath &cp, double pdf, double jac, bool valid, int edge) {
+// The SVertexPDF cache entries of medium edge k (0 or 1) of a path, as the functors read them (gvpm_struct.h:361-370,
+// 523-631): base path = generateVertexInfo, shifted path = ShiftGatherPoint::trace + generate.
+GVPM_HD inline void fillRay(const SceneView &sc, gvpm_camera_ray &r, const CamPath &cp, int k, double pdfSensorArea, double jac,
+                            bool valid) {
   std::memset(&r, 0, sizeof(r));
+  const int edge = cp.firstEdge + k;
   if (!valid) {
     r.info = GVPM_RAY_INFO(0, edge);
     return;
   }
-  r.o[0] = (float)cp.v2.x; r.o[1] = (float)cp.v2.y; r.o[2] = (float)cp.v2.z;
-  r.d[0] = (float)cp.d.x; r.d[1] = (float)cp.d.y; r.d[2] = (float)cp.d.z;
-  r.len = (float)cp.len2;
-  r.eye[0] = r.eye[1] = r.eye[2] = 1.f;
-  r.pdf = (float)pdf;
+  const CamEdge &e = cp.e[k];
+  r.o[0] = (float)e.o.x; r.o[1] = (float)e.o.y; r.o[2] = (float)e.o.z;
+  r.d[0] = (float)e.d.x; r.d[1] = (float)e.d.y; r.d[2] = (float)e.d.z;
+  r.len = (float)e.len;
+  // eyeContrib = getWeightBeam(edge - 1) * getWeightVertex(edge): 1 on the first medium edge (perspective sensor with
+  // importance sampling; a null boundary has weight 1); behind the mirror the transmittance of the edge before it
+  // (long beams: the edge weight) times the mirror's vertex weight rho * rrWeight
+  V3 eye(1.0);
+  if (k == 1) eye = cp.rho * (std::exp(-(double)sc.medium.sigma_t[1] * cp.e[0].len) * cp.rr2);
+  r.eye[0] = (float)eye.x; r.eye[1] = (float)eye.y; r.eye[2] = (float)eye.z;
+  // info.pdf: the sensor's pdf in area measure at vertex 2; a Dirac vertex multiplies it by 1 (discrete measure)
+  r.pdf = (float)pdfSensorArea;
   r.jacobian = (float)jac;
-  // GOp(e) = geometryOpposingTerm(path, 2, 3), gvpm/gvpm_geoOps.h:17-26
-  r.gop = (float)(std::fabs(dot(cp.n3, cp.d)) / (cp.len2 * cp.len2));
+  // GOp(edge) = geometryOpposingTerm(path, edge, edge + 1), gvpm/gvpm_geoOps.h:17-26
+  r.gop = (float)(std::fabs(dot(e.nEnd, e.d)) / (e.len * e.len));
   r.info = GVPM_RAY_INFO(1, edge);
 }
 
-
-// The beam set (base + L R T B, EPixel order) of pixel (px, py) at `iteration`; false when the pixel's camera path
-// has no medium edge.
-GVPM_HD inline bool cameraBeamSet(const SceneView &sc, int iteration, int px, int py, gvpm_camera_ray out[5]) {
+// The beam sets (base + L R T B, EPixel order) of pixel (px, py) at `iteration`: one per medium edge of its camera
+// path, in path order; 0 when the path has no medium edge or is invalid.  selW[k]: the weight of edge k in the G-VPM
+// edge selection (weightBeam.max(), gvpm.cpp:1117-1129).
+GVPM_HD inline int cameraBeamSets(const SceneView &sc, int iteration, int px, int py, gvpm_camera_ray out[2][5], float selW[2]) {
   const int offX[4] = {-1, 1, 0, 0}, offY[4] = {0, 0, 1, -1};  // L R T B
   Philox rng(sc.seed, 0xca3eu, (uint32_t)iteration, (uint32_t)(py * sc.width + px));
   double jx = rng.next1D(), jy = rng.next1D();
-  float randValue = rng.next1D();
+  float randValue[2];
+  randValue[0] = rng.next1D();
+  randValue[1] = 0.f;
   CamPath base;
   traceCamera(sc, px + jx, py + jy, base);
-  if (!base.hasBeam) return false;
-  // base SVertexPDF (generateVertexInfo): pdf = pdfDir converted to area at
-  // vertex 2 (vertex.cpp:403-408); jacobian = 1
-  double gopBase12 = std::fabs(dot(base.n2, base.d)) / (base.len1 * base.len1);
-  const int edge = sc.cameraInside ? 1 : 2;
-  fillRay(out[0], base, base.pdfDir * gopBase12, 1.0, true, edge);
-  out[0].rand = randValue;
-  out[0].pixel = (uint32_t)px | ((uint32_t)py << 16);
-  for (int k = 0; k < 4; ++k) {
-    gvpm_camera_ray &r = out[1 + k];
+  if (!base.hasBeam) return 0;
+  if (base.e[0].matEnd == MAT_MIRROR) {
+    // (two more draws, only on paths that meet the mirror: the others keep the streams of the mirror-less scenes)
+    randValue[1] = rng.next1D();
+    const double rr = rng.next1D();
+    if (base.nEdges < 2) return 0;  // the walk could not go on: invalid gather point (gvpm_gatherpoint.h:121-124)
+    // sampleNext(..., russianRoulette = true, &throughput): the throughput at the mirror is v1's weight (1) * the
+    // edge weight (long beam: the transmittance) * the mirror's weight; q = min(max, 0.95)
+    const double thr = std::exp(-(double)sc.medium.sigma_t[1] * base.e[0].len) * maxc(base.rho);
+    const double q = std::fmin(thr, 0.95);
+    if (rr > q) return 0;
+    base.rr2 = 1.0 / q;
+  }
+  // base SVertexPDF (generateVertexInfo): pdf = pdfDir converted to area at vertex 2 (vertex.cpp:403-408); jacobian = 1
+  const double gopBase12 = std::fabs(dot(base.n2, base.d)) / (base.len1 * base.len1);
+  for (int k = 0; k < base.nEdges; ++k) {
+    fillRay(sc, out[k][0], base, k, base.pdfDir * gopBase12, 1.0, true);
+    out[k][0].rand = randValue[k];
+    out[k][0].pixel = (uint32_t)px | ((uint32_t)py << 16);
+  }
+  selW[0] = 1.f;
+  // weightBeam *= vertex(2).weight[EImportance] * edge(1).weight[EImportance]: no rrWeight (the FIXME at gvpm.cpp:1127)
+  selW[1] = base.nEdges == 2 ? (float)(maxc(base.rho) * std::exp(-(double)sc.medium.sigma_t[1] * base.e[0].len)) : 0.f;
+  for (int i = 0; i < 4; ++i) {
     CamPath sh;
-    traceCamera(sc, px + offX[k] + jx, py + offY[k] + jy, sh);
-    if (!sh.hasBeam) {
-      fillRay(r, sh, 0, 0, false, edge);
-    } else {
+    traceCamera(sc, px + offX[i] + jx, py + offY[i] + jy, sh, &base);
+    double pdf = 0, jac = 0;
+    if (sh.hasBeam) {
       // ShiftGatherPoint::trace/generate, shift_cameraPath.h:76-116,191-242
       double pdf1 = base.pdfDir, pdf2 = sh.pdfDir;
       double gopNew12 = std::fabs(dot(sh.n2, sh.d)) / (sh.len1 * sh.len1);
-      double pdf = (pdf2 == 0.0 ? pdf1 : pdf2) * gopNew12;
-      double jac = (pdf2 == 0.0 ? 1.0 : pdf1 / pdf2) * (gopBase12 / gopNew12);
-      fillRay(r, sh, pdf, jac, true, edge);
+      pdf = (pdf2 == 0.0 ? pdf1 : pdf2) * gopNew12;
+      jac = (pdf2 == 0.0 ? 1.0 : pdf1 / pdf2) * (gopBase12 / gopNew12);
     }
-    r.pixel = 0;  // base ray only (fillRay zeroes rand too)
+    for (int k = 0; k < base.nEdges; ++k) {
+      gvpm_camera_ray &r = out[k][1 + i];
+      // validVolumeEdge(edge): the shifted path reached this edge (k = 1: its vertex 2 is a mirror too and the
+      // reflected ray hit something; a Dirac vertex leaves pdf and Jacobian as they are, shift_cameraPath.h:60-116)
+      fillRay(sc, r, sh, k, pdf, jac, sh.hasBeam && k < sh.nEdges);
+      r.pixel = 0;  // base ray only (fillRay zeroes rand too)
+    }
   }
+  return base.nEdges;
+}
+
+// single-edge form (scenes without a mirror)
+GVPM_HD inline bool cameraBeamSet(const SceneView &sc, int iteration, int px, int py, gvpm_camera_ray out[5]) {
+  gvpm_camera_ray sets[2][5];
+  float selW[2];
+  const int n = cameraBeamSets(sc, iteration, px, py, sets, selW);
+  if (n < 1) return false;
+  for (int k = 0; k < 5; ++k) out[k] = sets[0][k];
   return true;
 }
 

@@ -12,6 +12,7 @@
 #include "gvpm_oracle_beams.hpp"
 #include "gvpm_oracle_planes.hpp"
 #include "poisson_oracle.hpp"
+#include "camera_path_oracle.hpp"
 
 using namespace oracle;
 
@@ -369,4 +370,74 @@ int oracle_poisson_solve(const char *preset, float alpha, int width, int height,
   oracle::poissonSolve(p, width, height, dx, dy, throughput, direct, out);
   return 0;
 }
+}
+
+// ---- pins ported from the reference's own adjacent tests ------------------------------------------------
+// The oracle's kd-tree (PointKDTree, ESlidingMidpoint -- the only heuristic gvpm builds, gvpm_accel.h:96 -- and
+// executeQuery, kdtree.h:675-731) queried like src/tests/test_kd.cpp:133-200 queries Mitsuba's: tests compare with a
+// brute-force search.  out_idx receives the ORIGINAL indices (path_id carries them) of the points within `radius`.
+extern "C" int64_t oracle_kd_radius_query(const float *pos, uint64_t n, const double *query, double radius, int precision,
+                                          uint32_t *out_idx, uint64_t cap, uint64_t *visited) {
+  if (!pos || !query || !out_idx) return -1;
+  std::vector<float> zero3(3 * n, 0.f), zero1(n, 0.f);
+  std::vector<uint32_t> zeroU(n, 0u), ids(n);
+  for (uint64_t i = 0; i < n; ++i) ids[i] = (uint32_t)i;
+  gvpm_photon_soa soa;
+  soa.pos = pos; soa.wi = zero3.data(); soa.flux = zero3.data(); soa.parent_pos = zero3.data(); soa.parent_n = zero3.data();
+  soa.prefix_w = zero3.data(); soa.parent_scat = zero3.data(); soa.parent_wi = zero3.data();
+  soa.parent_pdf = zero1.data(); soa.edge_pdf = zero1.data(); soa.parent_rr = zero1.data(); soa.parent_g = zero1.data();
+  soa.flags = zeroU.data(); soa.path_id = ids.data(); soa.n = n;
+  auto run = [&](auto tag) -> int64_t {
+    using F = decltype(tag);
+    PhotonMap<F> map;
+    map.load(soa);
+    map.buildKD();
+    struct Collect {
+      Counters cnt;
+      std::vector<uint32_t> found;
+      void vpmFunctor(const Photon<F> &p) { found.push_back(p.pathID); }
+    } c;
+    map.executeQuery(Vec3<F>((F)query[0], (F)query[1], (F)query[2]), (F)radius, c);
+    if (visited) *visited = c.cnt.candidates;
+    for (size_t i = 0; i < c.found.size() && i < cap; ++i) out_idx[i] = c.found[i];
+    return (int64_t)c.found.size();
+  };
+  return precision == 32 ? run(float()) : run(double());
+}
+
+// HGPhaseFunction::sample (src/phase/hg.cpp:74-97; Epsilon = 1e-4) and the oracle's phase eval (the pdf): what
+// src/tests/test_chisquare.cpp:508-573 checks against each other for data/tests/test_phase.xml's g = 0.9 and -0.3.
+extern "C" double oracle_phase_eval(double g, const double *wi, const double *wo) {
+  return Medium<double>::phaseEval(g, Vec3<double>(wi[0], wi[1], wi[2]), Vec3<double>(wo[0], wo[1], wo[2]));
+}
+extern "C" void oracle_hg_sample(double g, const double *wi, double u1, double u2, double *wo) {
+  double cosTheta;
+  if (std::abs(g) < 1e-4) {
+    cosTheta = 1 - 2 * u1;
+  } else {
+    const double sqrTerm = (1 - g * g) / (1 - g + 2 * g * u1);
+    cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+  }
+  const double sinTheta = safe_sqrt(1.0 - cosTheta * cosTheta);
+  const double sinPhi = std::sin(2 * M_PI * u2), cosPhi = std::cos(2 * M_PI * u2);
+  // FrameCoherent(-wi).toWorld
+  Vec3<double> n(-wi[0], -wi[1], -wi[2]), s, t;
+  coordinateSystemCoherent(n, s, t);
+  const Vec3<double> w = s * (sinTheta * cosPhi) + t * (sinTheta * sinPhi) + n * cosTheta;
+  wo[0] = w.x; wo[1] = w.y; wo[2] = w.z;
+}
+
+// halfVectorShift, gvpm/shift/shift_utilities.h:42-110 (tangent-space vectors; out: wo[3], jacobian)
+extern "C" int oracle_half_vector_shift(const double *mainWi, const double *mainWo, const double *shiftedWi, double mainEta,
+                                        double shiftedEta, double *out4) {
+  using namespace gvpm_oracle;
+  const HalfVectorShiftResult r = halfVectorShift(hv(mainWi[0], mainWi[1], mainWi[2]), hv(mainWo[0], mainWo[1], mainWo[2]),
+                                                  hv(shiftedWi[0], shiftedWi[1], shiftedWi[2]), mainEta, shiftedEta);
+  out4[0] = r.wo.x; out4[1] = r.wo.y; out4[2] = r.wo.z; out4[3] = r.jacobian;
+  return r.success ? 1 : 0;
+}
+// GatherPoint::sensorMIS as written, gvpm_struct.h:608-631
+extern "C" double oracle_sensor_mis(unsigned idVertex, double sPdf, double sJac, double sG, double bPdf, double bG, double sDist,
+                                    double bDist) {
+  return gvpm_oracle::sensorMISRef(idVertex, sPdf, sJac, sG, bPdf, bG, sDist, bDist);
 }

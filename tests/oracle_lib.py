@@ -200,3 +200,55 @@ def ref_poisson_solve(dx, dy, throughput, direct=None, preset="L1D", alpha=0.2, 
     if rc != 0:
         raise RuntimeError(f"ref_poisson_solve failed: {rc}")
     return out
+
+
+# ---- pins ported from the reference's adjacent tests + camera-path pieces (oracle_api.cpp) -------------------------
+def kd_radius_query(pos, query, radius, precision=64):
+    """Indices (into pos) of the points within `radius` of `query` by the oracle's kd-tree, and the nodes visited."""
+    L = lib()
+    L.oracle_kd_radius_query.restype = C.c_int64
+    L.oracle_kd_radius_query.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_uint64,
+                                         C.POINTER(C.c_uint64)]
+    pos = np.ascontiguousarray(pos, np.float32)
+    q = np.ascontiguousarray(query, np.float64)
+    out = np.zeros(pos.shape[0], np.uint32)
+    vis = C.c_uint64(0)
+    n = L.oracle_kd_radius_query(pos.ctypes.data, pos.shape[0], q.ctypes.data, float(radius), precision, out.ctypes.data,
+                                 out.size, C.byref(vis))
+    assert n >= 0
+    return np.sort(out[:n]), int(vis.value)
+
+
+def phase_eval(g, wi, wo):
+    L = lib()
+    L.oracle_phase_eval.restype = C.c_double
+    L.oracle_phase_eval.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+    a, b = np.ascontiguousarray(wi, np.float64), np.ascontiguousarray(wo, np.float64)
+    return L.oracle_phase_eval(float(g), a.ctypes.data, b.ctypes.data)
+
+
+def hg_sample(g, wi, u1, u2):
+    L = lib()
+    L.oracle_hg_sample.argtypes = [C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    a = np.ascontiguousarray(wi, np.float64)
+    out = np.zeros(3, np.float64)
+    L.oracle_hg_sample(float(g), a.ctypes.data, float(u1), float(u2), out.ctypes.data)
+    return out
+
+
+def half_vector_shift(main_wi, main_wo, shifted_wi, main_eta=1.0, shifted_eta=1.0):
+    """halfVectorShift of shift_utilities.h:42-110 -> (success, wo[3], jacobian)"""
+    L = lib()
+    L.oracle_half_vector_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    a, b, c = (np.ascontiguousarray(v, np.float64) for v in (main_wi, main_wo, shifted_wi))
+    out = np.zeros(4, np.float64)
+    ok = L.oracle_half_vector_shift(a.ctypes.data, b.ctypes.data, c.ctypes.data, float(main_eta), float(shifted_eta),
+                                    out.ctypes.data)
+    return bool(ok), out[:3].copy(), float(out[3])
+
+
+def sensor_mis(id_vertex, s_pdf, s_jac, s_g, b_pdf, b_g, s_dist=1.0, b_dist=1.0):
+    L = lib()
+    L.oracle_sensor_mis.restype = C.c_double
+    L.oracle_sensor_mis.argtypes = [C.c_uint] + [C.c_double] * 7
+    return L.oracle_sensor_mis(int(id_vertex), s_pdf, s_jac, s_g, b_pdf, b_g, s_dist, b_dist)

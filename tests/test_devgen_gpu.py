@@ -31,7 +31,7 @@ def close(a, b):
     return np.allclose(a, b, rtol=2e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("scene,cap", [("cbox", 30000), ("cbox_hg", 9000), ("fogroom", 5000)])
+@pytest.mark.parametrize("scene,cap", [("cbox", 30000), ("cbox_hg", 9000), ("fogroom", 5000), ("cbox_mirror", 9000)])
 def test_photons_match_the_host_generator(scene, cap):
     sc = SynthScene(scene, 32, 24)
     g = hip.DeviceGenerator(sc)
@@ -67,7 +67,8 @@ def test_beams_and_batches():
     g.close()
 
 
-@pytest.mark.parametrize("scene,mod,rem", [("cbox", 1, 0), ("cbox", 3, 1), ("cbox_in", 1, 0)])
+@pytest.mark.parametrize("scene,mod,rem", [("cbox", 1, 0), ("cbox", 3, 1), ("cbox_in", 1, 0), ("cbox_mirror", 1, 0),
+                                           ("cbox_mirror_side", 2, 1)])
 def test_camera_beams_match_the_host_generator(scene, mod, rem):
     sc = SynthScene(scene, 44, 36)
     g = hip.DeviceGenerator(sc)

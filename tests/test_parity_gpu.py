@@ -488,3 +488,33 @@ def test_prefetched_pinned_uploads_equal_plain_uploads():
         ctx.prefetch(pp, pr)
     assert e.value.code == abi.GVPM_ERR_STATE
     ctx.close()
+
+
+@pytest.mark.parametrize("scene,W,H", [("cbox_mirror", 48, 40), ("cbox_mirror_side", 112, 84)])
+@pytest.mark.parametrize("tech", [abi.GVPM_VOL_BRE3D, abi.GVPM_VOL_BRE2D])
+def test_camera_paths_with_two_medium_edges(scene, W, H, tech):
+    """pixels behind a mirror upload TWO beam sets (edge 1 and edge 2: eyeContrib != 1, its own GOp,
+    the shifted path's half-vector-copied second edge, invalid where the offset path misses the mirror); light paths
+    through the mirror carry manifold-type shifts (failed on the device as with useManifold=false)."""
+    kw = dict(use_shift_null=0) if tech == abi.GVPM_VOL_BRE2D else {}
+    c = cases.make_case(scene, W, H, 30000, 2.5, vol_technique=tech, **kw)
+    e = (c.rays["info"][:, 0] >> 8) & 0xFF
+    assert (e == 2).sum() > 40 and (e == 1).sum() > 1000
+    sh2 = c.rays[e == 2][:, 1:]
+    assert ((sh2["info"] & 1) == 0).any() and ((sh2["info"] & 1) == 1).any()
+    acc, ref, st = check(c)
+    assert st["failed_shifts"] > 100
+    # the second edges alone: their share of the estimate
+    only2 = np.ascontiguousarray(c.rays[e == 2])
+    acc2, ref2, st2 = check(c, rays=only2)
+    assert st2["evaluations"] > 150
+
+
+def test_vpm_two_edge_camera_paths():
+    from test_oracle_vpm import make_vpm_case
+    from test_parity_vpm_gpu import device_vpm
+    c = make_vpm_case("cbox_mirror", 48, 40, 40000, 5.0, nb=24)
+    e = (c.rays["info"][:, 0] >> 8) & 0xFF
+    on2 = np.isin(c.samples["set"], np.nonzero(e == 2)[0])
+    assert on2.sum() > 100 and (c.samples["pdf_sel"][on2] < 0.5).all()   # the per-pixel edge CDF has two entries
+    device_vpm(c, iters=2)
