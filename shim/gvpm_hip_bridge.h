@@ -1,0 +1,455 @@
+/*
+ * gvpm_hip_bridge.h -- the Mitsuba-side half of the drop-in: everything the reference's `gvpm`
+ * plugin needs to hand the volume gather of one SPPM iteration to libgvpm_hip.so and to take the result back.
+ *
+ * How it goes into the reference build.  GPMIntegrator lives in src/integrators/photonmapper/gvpm/gvpm.cpp (a
+ * translation unit, not a header), so the drop-in is this header next to it plus the 40-line patch
+ * shim/gvpm.cpp.patch: the `switch (m_config.volTechnique)` of photonMapPass (gvpm.cpp:456-474) calls
+ * GvpmHipBridge::gather() instead of computeVolumeGradient{Photon,PhotonBRE,Beams,Planes}, and the bridge writes the
+ * 27 accumulators back into the GatherPoints, so normalisation, reusePrimal, computeGradient, the Poisson
+ * reconstruction and every dump of photonMapPass (gvpm.cpp:476-727) run unchanged.  The plugin stays `gvpm`
+ * (MTS_EXPORT_PLUGIN at gvpm.cpp:1530, add_recons(gvpm ...) at src/integrators/CMakeLists.txt:105-146, see
+ * shim/CMakeLists.patch); XML scenes do not change; `useHip=false` in the integrator's properties keeps the CPU path.
+ *
+ * This file cannot be compiled in the build container (Mitsuba needs Boost / Eigen / Xerces / OpenEXR, none present):
+ * it is written against the reference headers as they are, every assignment citing the reference expression it
+ * copies the VALUE of (not the code: the functors' arithmetic lives in the HIP kernels).
+ *
+ * Citations are relative to src/integrators/photonmapper/ unless they start with src/ or include/.
+ */
+#pragma once
+#if !defined(__MITSUBA_RENDER_SCENE_H_)
+#error "include after the gvpm headers (it is included from gvpm.cpp, below gvpm_struct.h / gvpm_accel.h / gvpm_beams.h / gvpm_plane.h)"
+#endif
+
+#include <array>
+#include <vector>
+
+#include <mitsuba/render/trimesh.h>
+
+#include "gvpm_hip.h"  /* include/gvpm_hip.h of the gvpm-hip repository */
+
+MTS_NAMESPACE_BEGIN
+
+class GvpmHipBridge {
+public:
+  GvpmHipBridge() : m_h(nullptr) {}
+  ~GvpmHipBridge() {
+    if (m_h) gvpm_destroy(m_h);
+  }
+
+  /* ---- once per render(): after GPMIntegrator::preprocess and the allocation of the gather points
+   *      (gvpm.cpp:126-179,272-291) ------------------------------------------------------------------------------ */
+  void create(const Scene *scene, const GPMConfig &config, const AABB &smokeAABB, int device = 0) {
+    const Vector2i crop = scene->getFilm()->getCropSize();
+    gvpm_params p;
+    memset(&p, 0, sizeof(p));
+    p.abi_version = GVPM_ABI_VERSION;
+    p.width = crop.x;                                               /* film->getCropSize(), gvpm.cpp:396          */
+    p.height = crop.y;
+    p.vol_technique = (int32_t) config.volTechnique;                /* EVolumeTechnique, same order (volume_utils.h:12-21) */
+    p.max_depth = config.maxDepth;                                  /* gvpm_struct.h:107-333, same names          */
+    p.min_depth = config.minDepth;
+    p.use_mis = config.useMIS ? 1 : 0;                              /* GPMConfig::load: "area" -> true, "none" -> false (:243-256) */
+    p.use_shift_null = config.useShiftNull ? 1 : 0;
+    p.path_set = config.pathSet ? 1 : 0;
+    p.power_heuristic = config.powerHeuristic ? 1 : 0;
+    p.no_medium_shift = config.noMediumShift ? 1 : 0;
+    p.use_manifold = config.useManifold ? 1 : 0;                    /* manifold shifts stay on the host: the device
+                                                                       treats them as useManifold=false does
+                                                                       (shift_volume_photon.cpp:101-104)          */
+    p.debug_shift = (int32_t) config.debugShift;                    /* ELightShiftType values kept                */
+    p.lighting_interaction_mode = (int32_t) config.lightingInteractionMode;
+    p.bsdf_interaction_mode = (int32_t) config.bsdfInteractionMode;
+    p.nb_camera_samples = config.nbCameraSamples;
+    p.visibility_as_written = 1;                                    /* shift_volume_photon.cpp:396                */
+    p.alpha = (float) config.alpha;
+    p.initial_scale_volume = (float) config.initialScaleVolume;
+    p.bsphere_radius = (float) smokeAABB.getBSphere().radius;       /* gvpm.cpp:391,881,989,1082                  */
+    p.epsilon = (float) Epsilon;                                    /* include/mitsuba/core/constants.h:24-31     */
+    p.shadow_epsilon = (float) ShadowEpsilon;
+    check(gvpm_create(&p, device, &m_h), "gvpm_create");
+    m_params = p;
+    m_config = config;
+    uploadScene(scene);
+    uploadMedium(scene);
+  }
+
+  /* ---- once per SPPM iteration: replaces the switch at gvpm.cpp:456-474 ------------------------------------------
+   * gatherBlocks: m_gatherBlocks; threadData: m_threadData[0] (its MemoryPool serves the eager shifted paths);
+   * sampler: m_gpManager->getSamplerBlock(0) (the draws of gvpm.cpp:1042 / :1145 / gvpm_plane.h:60-68, made here
+   * in block order instead of inside the worker threads: a deterministic stream).
+   * Returns after the results are back in the GatherPoints; globalScaleVolume is advanced like scaleVolumeAPA(it). */
+  void gather(int it, Scene *scene, std::vector<std::vector<GatherPoint>> &gatherBlocks, GPMThreadData &threadData,
+              Sampler *sampler, const GPhotonMap *photonMap, const LTBeamMap *beamMap, size_t nbPaths,
+              Float &globalScaleVolume) {
+    /* the radius of this pass: R * 0.01 * globalScaleVolume (gvpm.cpp:391,881,989); the handle applies
+     * scaleVolumeAPA itself (gvpm.cpp:181-215), set explicitly here so that host and device never drift */
+    check(gvpm_set_global_scale(m_h, (float) globalScaleVolume), "gvpm_set_global_scale");
+    const EVolumeTechnique tech = (EVolumeTechnique) m_params.vol_technique;
+    m_soa.clear();
+    switch (tech) {
+      case EDistance:
+      case EVolBRE2D:
+      case EVolBRE3D:
+        flattenPhotons(photonMap);
+        check(gvpm_upload_photons(m_h, &m_soa.view()), "gvpm_upload_photons");
+        break;
+      case EBeamBeam1D:
+      case EBeamBeam3D_Optimized:
+        flattenBeams(beamMap);
+        check(gvpm_upload_beams(m_h, &m_soa.view(), m_endN.data()), "gvpm_upload_beams");
+        break;
+      case EVolPlane0D:
+        if (scene->getSensor()->getMedium() == nullptr)             /* gvpm.cpp:784-788                            */
+          SLog(EError, "Planes does not support camera outside the medium");
+        flattenPlanes(beamMap, sampler);
+        check(gvpm_upload_planes(m_h, &m_soa.view(), m_w1.data(), m_len1.data()), "gvpm_upload_planes");
+        break;
+      default: /* EBeamBeam3D_Naive / _EGSR: SAssert(false) in BeamKernelRecord::eval (shift_volume_beams.h) */
+        SLog(EError, "gvpm_hip: volume technique not available (the reference asserts on it too)");
+    }
+    flattenCameraBeams(scene, gatherBlocks, threadData, sampler, tech == EDistance);
+    check(gvpm_upload_camera_beams(m_h, m_rays.data(), m_rays.size() / 5), "gvpm_upload_camera_beams");
+    if (tech == EDistance) {
+      uploadVpmState(gatherBlocks);   /* nothing to send: scaleVol / NVol live on the device (see writeBack) */
+      check(gvpm_upload_vpm_samples(m_h, m_samples.data(), m_samples.size()), "gvpm_upload_vpm_samples");
+    }
+    check(gvpm_gather(m_h, it, (uint64_t) nbPaths), "gvpm_gather");
+    writeBack(gatherBlocks, tech == EDistance);
+    float r = 0.f;
+    check(gvpm_get_radius(m_h, &r), "gvpm_get_radius");
+    /* scaleVolumeAPA(it) ran inside gvpm_gather (not for EDistance, gvpm.cpp:456 vs :1081-1203) */
+    if (tech != EDistance) globalScaleVolume = (Float) (r / (m_params.bsphere_radius * 0.01f));
+  }
+
+  /* GPMIntegrator::render re-initialises the gather points (gvpm.cpp:272-291) */
+  void reset() { check(gvpm_reset(m_h), "gvpm_reset"); }
+
+private:
+  /* ---------------------------------------------------------------------------------------------- SoA storage -- */
+  struct Soa {
+    std::vector<float> pos, wi, flux, parent_pos, parent_n, prefix_w, parent_scat, parent_wi;
+    std::vector<float> parent_pdf, edge_pdf, parent_rr, parent_g;
+    std::vector<uint32_t> flags, path_id;
+    gvpm_photon_soa v;
+    void clear() {
+      pos.clear(); wi.clear(); flux.clear(); parent_pos.clear(); parent_n.clear(); prefix_w.clear();
+      parent_scat.clear(); parent_wi.clear(); parent_pdf.clear(); edge_pdf.clear(); parent_rr.clear();
+      parent_g.clear(); flags.clear(); path_id.clear();
+    }
+    const gvpm_photon_soa &view() {
+      v.pos = pos.data(); v.wi = wi.data(); v.flux = flux.data(); v.parent_pos = parent_pos.data();
+      v.parent_n = parent_n.data(); v.prefix_w = prefix_w.data(); v.parent_scat = parent_scat.data();
+      v.parent_wi = parent_wi.data(); v.parent_pdf = parent_pdf.data(); v.edge_pdf = edge_pdf.data();
+      v.parent_rr = parent_rr.data(); v.parent_g = parent_g.data(); v.flags = flags.data(); v.path_id = path_id.data();
+      v.n = flags.size();
+      return v;
+    }
+  };
+  static void push3(std::vector<float> &v, const Point &p) { v.push_back((float) p.x); v.push_back((float) p.y); v.push_back((float) p.z); }
+  static void push3(std::vector<float> &v, const Vector &p) { v.push_back((float) p.x); v.push_back((float) p.y); v.push_back((float) p.z); }
+  static void push3(std::vector<float> &v, const Spectrum &s) {
+    Float r, g, b;
+    s.toLinearRGB(r, g, b);                                          /* RGB build (SPECTRUM_SAMPLES = 3): identity */
+    v.push_back((float) r); v.push_back((float) g); v.push_back((float) b);
+  }
+
+  /* The part of a record that describes vertex(c-1), the vertex a photon (c = vertexId) or a beam (c = edgeID + 1)
+   * is re-connected from -- what shiftPhotonDiffuse / shiftBeamDiffuse and diffuseReconnection read of it
+   * (shift/shift_volume_photon.cpp:382-486, shift/shift_volume_beams.cpp:410-539, shift/operation/shift_diffuse.cpp:11-268). */
+  void pushParent(const Path *lt, size_t c) {
+    const PathVertex *par = lt->vertex(c - 1);
+    const PathEdge *e = lt->edge(c - 1);
+    push3(m_soa.parent_pos, par->getPosition());                     /* parentVertex->getPosition(), :389-395      */
+    /* geometric normal of a surface / emitter parent (:404-412; area.cpp:132-150 for the emitter's cosine);
+     * the closed set is Lambertian: shading frame = geometric frame                                                 */
+    push3(m_soa.parent_n, par->isMediumInteraction() ? Vector(0.f) : Vector(par->getGeometricNormal()));
+    /* prod_{i < c-1} v_i.weight * v_i.rrWeight * e_i.weight, shift_volume_photon.cpp:415-422                        */
+    Spectrum prefix(1.f);
+    for (size_t i = 0; i + 1 < c; ++i)
+      prefix *= lt->vertex(i)->weight[EImportance] * lt->vertex(i)->rrWeight * lt->edge(i)->weight[EImportance];
+    push3(m_soa.prefix_w, prefix);
+    /* BSDF::eval of the parent = diffuse reflectance * INV_PI * cos (src/bsdfs/diffuse.cpp:110-127);
+     * medium parent: sigma_s * phase (shift_diffuse.cpp:54-70)                                                      */
+    Spectrum scat(0.f);
+    if (par->isSurfaceInteraction()) {
+      const Intersection &its = par->getIntersection();
+      scat = its.getBSDF()->getDiffuseReflectance(its);
+    } else if (par->isMediumInteraction()) {
+      scat = par->getMediumSamplingRecord().sigmaS;
+    }
+    push3(m_soa.parent_scat, scat);
+    /* direction parent -> vertex(c-2): bRec.wi / pRec.wi of the re-evaluated parent (shift_diffuse.cpp:30-70)       */
+    push3(m_soa.parent_wi, c >= 3 ? normalize(lt->vertex(c - 2)->getPosition() - par->getPosition()) : Vector(1, 0, 0));
+    m_soa.parent_pdf.push_back((float) par->pdf[EImportance]);       /* shift_volume_photon.cpp:463-470, area measure */
+    m_soa.edge_pdf.push_back((float) e->pdf[EImportance]);           /* parentEdge->pdf[EImportance]                */
+    m_soa.parent_rr.push_back((float) par->rrWeight);                /* shift_diffuse.cpp:111-112                   */
+    m_soa.parent_g.push_back(par->isMediumInteraction()
+                                 ? (float) par->getMediumSamplingRecord().getPhaseFunction()->getMeanCosine()
+                                 : 0.f);                             /* hg.cpp:112-114                              */
+  }
+
+  /* flags: parent type, the result of getTypeShift (a pure function of the light path, shift/shift_utilities.h:112-136),
+   * whether edge(c-1) lies in the medium, depth = c - 1, getVertexComponentType(parent) (shift_utilities.h:222-231).
+   * A parent outside the device's closed set (non-Lambertian surface, heterogeneous medium) is flagged `invalid`:
+   * the shift then fails with w = 1, as the reference's non-invertible shifts do.                                    */
+  uint32_t makeFlags(const Path *lt, size_t c, size_t depth) const {
+    const PathVertex *par = lt->vertex(c - 1);
+    int b = -1;
+    const ELightShiftType t = getTypeShift(lt, c, b);
+    uint32_t st = t == EDiffuseShift ? 1u : t == EMediumShift ? 2u : t == EManifoldShift ? 3u : 0u;
+    if (st == 1u || st == 2u) {
+      if (par->isSurfaceInteraction()) {
+        const BSDF *bsdf = par->getIntersection().getBSDF();
+        if (!(bsdf->getType() & BSDF::EDiffuseReflection) || (bsdf->getType() & ~(BSDF::EDiffuseReflection | BSDF::EFrontSide)) != 0)
+          st = 0u;
+      } else if (par->isMediumInteraction() && !par->getMediumSamplingRecord().medium->isHomogeneous()) {
+        st = 0u;
+      }
+    }
+    const uint32_t ptype = par->isEmitterSample() ? GVPM_PARENT_EMITTER
+                         : par->isSurfaceInteraction() ? GVPM_PARENT_SURFACE : GVPM_PARENT_MEDIUM;
+    return GVPM_PF_MAKE(ptype, st, lt->edge(c - 1)->medium != nullptr, depth, getVertexComponentType(par));
+  }
+
+  /* ------------------------------------------------------------------------------------------- photon map ---- */
+  /* One record per node of the volume photon map, in kd-tree storage order (the device builds its own grid):
+   * GPhotonNodeData {vertexId, lightPath, weight, pathID}, gvpm_accel.h:17-65, filled by GPhotonMap::tryAppend (:119-199). */
+  void flattenPhotons(const GPhotonMap *map) {
+    for (size_t k = 0; k < map->size(); ++k) {
+      const GPhotonNodeData &d = (*map)[k].getData();
+      const Path *lt = d.lightPath;
+      const size_t c = d.vertexId;
+      push3(m_soa.pos, lt->vertex(c)->getPosition());                /* GPhotonNodeKD position = photon.its.p, :77-84 */
+      push3(m_soa.wi, -lt->edge(c - 1)->d);                          /* its.wi = -edge->d, :49-51                  */
+      push3(m_soa.flux, d.weight);                                   /* importanceWeights at the append, :134-148  */
+      pushParent(lt, c);
+      m_soa.flags.push_back(makeFlags(lt, c, c - 1));                /* depth = vID - 1, :43                       */
+      m_soa.path_id.push_back((uint32_t) d.pathID);                  /* m_nbLightPathAdded, :165,189-191           */
+    }
+  }
+
+  /* ----------------------------------------------------------------------------------------- photon beams ---- */
+  /* One record per LTPhotonBeam (gvpm_beams.h:18-43): edge i of a light path, origin vertex(i), end vertex(i+1). */
+  void pushBeam(const LTPhotonBeam &bm) {
+    const Path *lt = bm.path;
+    const size_t i = bm.edgeID;
+    push3(m_soa.pos, lt->vertex(i + 1)->getPosition());              /* setEndPoint(lastVertex->getPosition()), :35-36 */
+    push3(m_soa.wi, -lt->edge(i)->d);
+    push3(m_soa.flux, bm.flux);                                      /* without the transmittance of edge i, :26-33 */
+    pushParent(lt, i + 1);                                           /* parent = vertex(i): the beam's origin       */
+    m_soa.flags.push_back(makeFlags(lt, i + 1, i));                  /* depth = edgeID (PhotonBeam ctor's last argument) */
+    m_soa.path_id.push_back((uint32_t) bm.pathID);
+    const PathVertex *end = lt->vertex(i + 1);                       /* geometric normal of a surface end point:
+                                                                        pdfBasePos conversion, shift_volume_beams.cpp:502-513 */
+    push3(m_endN, end->isSurfaceInteraction() ? Vector(end->getGeometricNormal()) : Vector(0.f));
+  }
+  void flattenBeams(const LTBeamMap *map) {
+    m_endN.clear();
+    for (const auto &pb : map->getBeams()) pushBeam(pb.second);     /* std::vector<std::pair<int, T>>, beams.h:332-334 */
+  }
+
+  /* ---------------------------------------------------------------------------------------- photon planes ---- */
+  /* gvpm.cpp:790-797: every beam becomes a plane by LTPhotonPlane::transformBeam (gvpm_plane.h:53-73) -- kept on the
+   * host, serial, with the reference's sampler, so the second edges are the reference's.                           */
+  void flattenPlanes(const LTBeamMap *map, Sampler *sampler) {
+    m_endN.clear(); m_w1.clear(); m_len1.clear();
+    for (const auto &pb : map->getBeams()) {
+      const LTPhotonPlane pl = LTPhotonPlane::transformBeam(pb.second, sampler);
+      pushBeam(pb.second);                                           /* ori, w0 * length0, flux, edgeID: the beam's  */
+      push3(m_w1, pl.w1());                                          /* PhotonPlane::w1(), plane_struct.h:205          */
+      m_len1.push_back((float) pl.length1());                        /* PhotonPlane::length1(), plane_struct.h:217     */
+    }
+  }
+
+  /* ------------------------------------------------------------------------------------------ camera beams --- */
+  /* The SVertexPDF cache entries of edge e of a (base or shifted) gather point, gvpm_struct.h:361-370,585-631.      */
+  static void fillRay(gvpm_camera_ray &r, const GatherPoint &gp, size_t e, bool valid) {
+    memset(&r, 0, sizeof(r));
+    r.info = GVPM_RAY_INFO(valid ? 1 : 0, e);
+    if (!valid) return;
+    const PathEdge *ed = gp.path.edge(e);
+    const Point o = gp.path.vertex(e)->getPosition();                /* gvpm.cpp:1032-1038, shift_volume_photon.cpp:765-770 */
+    const Vector d = -ed->d;                                         /* ERadiance edges point at the camera, edge.cpp:78-81 */
+    r.o[0] = (float) o.x; r.o[1] = (float) o.y; r.o[2] = (float) o.z;
+    r.d[0] = (float) d.x; r.d[1] = (float) d.y; r.d[2] = (float) d.z;
+    r.len = (float) ed->length;
+    Float cr, cg, cb;
+    (gp.getWeightBeam(e - 1) * gp.getWeightVertex(e)).toLinearRGB(cr, cg, cb);  /* eyeContrib, shift_volume_photon.cpp:741-745 */
+    r.eye[0] = (float) cr; r.eye[1] = (float) cg; r.eye[2] = (float) cb;
+    r.pdf = (float) gp.getVertexInfo(e).pdf;                         /* sensorMIS operands, gvpm_struct.h:608-631     */
+    r.jacobian = (float) gp.getVertexInfo(e).jacobian;
+    r.gop = (float) gp.GOp(e);
+  }
+
+  /* One beam set per medium edge of every gather point, base + the four offset pixels in EPixel order
+   * (gvpm_struct.h:354-359; generateOffsetPos, shift_utilities.h:255-261).  The shifted gather points are generated
+   * EAGERLY here (the functors generate them lazily on their first hit, shift_volume_photon.cpp:543,761).
+   * vpm: also the camera samples of computeVolumeGradientPhoton (gvpm.cpp:1117-1172).                              */
+  void flattenCameraBeams(Scene *scene, std::vector<std::vector<GatherPoint>> &blocks, GPMThreadData &td, Sampler *sampler,
+                          bool vpm) {
+    m_rays.clear();
+    m_samples.clear();
+    const GPMConfig &cfg = m_config;
+    for (auto &block : blocks) {
+      for (GatherPoint &gp : block) {
+        std::vector<size_t> mediumEdges;
+        std::vector<Float> selWeight;
+        Spectrum weightBeam(1.f);
+        for (size_t e = 1; e < gp.path.edgeCount(); ++e) {
+          if (!vpm) {
+            if (cfg.minCameraDepth > e) continue;                     /* gvpm.cpp:1020-1025 (BRE), :921-926 (beams)  */
+            if (cfg.maxCameraDepth != -1 && (int) e > cfg.maxCameraDepth + 1) break;
+          }
+          if (gp.path.edge(e)->medium != nullptr) {
+            mediumEdges.push_back(e);
+            selWeight.push_back(weightBeam.max());                    /* selBeam.append(weightBeam.max()), gvpm.cpp:1119-1122 */
+          }
+          weightBeam *= gp.path.vertex(e + 1)->weight[EImportance];   /* :1127-1128                                   */
+          weightBeam *= gp.path.edge(e)->weight[EImportance];
+        }
+        if (mediumEdges.empty()) continue;
+        gp.haveSmoke = true;                                          /* gvpm.cpp:1030                                */
+        std::vector<ShiftGatherPoint> shiftGPs(4);
+        const Point2 basePixel = gp.path.vertex(1)->getSamplePosition();
+        const std::array<Point2, 4> pixels = generateOffsetPos(basePixel);
+        for (int i = 0; i < 4; ++i) shiftGPs[i].generate(scene, td.pool, gp, pixels[i], false);
+        const size_t firstSet = m_rays.size() / 5;
+        for (size_t e : mediumEdges) {
+          gvpm_camera_ray set[5];
+          fillRay(set[0], gp, e, true);
+          set[0].rand = vpm ? 0.f : (float) sampler->next1D();        /* bre->query(..., sampler->next1D()), gvpm.cpp:1042;
+                                                                         G-Beams: the key of the per-hit Philox stream */
+          set[0].pixel = (uint32_t) gp.pixel.x | ((uint32_t) gp.pixel.y << 16);
+          for (int i = 0; i < 4; ++i)
+            fillRay(set[1 + i], shiftGPs[i], e, shiftGPs[i].validVolumeEdge(e, gp.path.edge(e)->medium));
+          m_rays.insert(m_rays.end(), set, set + 5);
+        }
+        if (vpm) {
+          /* DiscreteDistribution selBeam; normalize(); per sample sampleReuse(randSample) (gvpm.cpp:1130,1143-1150) */
+          DiscreteDistribution selBeam(selWeight.size());
+          for (Float w : selWeight) selBeam.append(w);
+          selBeam.normalize();
+          const Float normalization = 1.f / cfg.nbCameraSamples;
+          for (int s = 0; s < cfg.nbCameraSamples; ++s) {
+            Float randSample = sampler->next1D();
+            if (cfg.stratified) randSample = s * normalization + randSample * normalization;
+            const size_t sampleIndex = selBeam.sampleReuse(randSample);
+            const size_t e = mediumEdges[sampleIndex];
+            if (cfg.maxCameraDepth != -1 && (int) e > cfg.maxCameraDepth + 1) continue;   /* :1153-1158 */
+            if (cfg.minCameraDepth != 0 && e < cfg.minCameraDepth + 1) continue;
+            gvpm_vpm_sample sm;
+            sm.set = (uint32_t) (firstSet + sampleIndex);
+            sm.rand = (float) randSample;                              /* drives sampleDistance(EDistanceAlwaysValid), :1168 */
+            sm.pdf_sel = (float) selBeam[sampleIndex];                 /* gRec.changeEdge(idEdge, selBeam[sampleIndex]), :1160 */
+            sm.reserved = 0;
+            m_samples.push_back(sm);
+          }
+        }
+        for (auto &sgp : shiftGPs) sgp.path.release(td.pool);         /* gvpm.cpp:1071-1074                           */
+      }
+    }
+  }
+
+  /* G-VPM keeps GatherPoint::scaleVol / NVol on the device from gvpm_reset on (initialScaleVolume, 0: what
+   * GVPMRadiusInitializer::init writes, gvpm_gatherpoint.h:176-260); they are mirrored back after every pass. */
+  void uploadVpmState(std::vector<std::vector<GatherPoint>> &) {}
+
+  /* ---------------------------------------------------------------------------------------------- results ---- */
+  /* gp.mediumFlux / shiftedMediumFlux[4] / weightedMediumFlux[4] (gvpm_struct.h:429-441) <- the 27 accumulators;
+   * G-VPM also scaleVol / NVol (gvpm.cpp:1191-1195).                                                              */
+  void writeBack(std::vector<std::vector<GatherPoint>> &blocks, bool vpm) {
+    const size_t P = (size_t) m_params.width * m_params.height;
+    m_accum.resize(P * GVPM_ACCUM_FLOATS);
+    check(gvpm_download_accum(m_h, m_accum.data()), "gvpm_download_accum");
+    if (vpm) {
+      m_scaleVol.resize(P);
+      m_nVol.resize(P);
+      check(gvpm_download_vpm_state(m_h, m_scaleVol.data(), m_nVol.data()), "gvpm_download_vpm_state");
+    }
+    for (auto &block : blocks)
+      for (GatherPoint &gp : block) {
+        const size_t px = (size_t) gp.pixel.y * m_params.width + gp.pixel.x;
+        const float *a = &m_accum[px * GVPM_ACCUM_FLOATS];
+        gp.mediumFlux.fromLinearRGB(a[0], a[1], a[2]);
+        for (int k = 0; k < 4; ++k) {
+          gp.shiftedMediumFlux[k].fromLinearRGB(a[3 + 3 * k], a[4 + 3 * k], a[5 + 3 * k]);
+          gp.weightedMediumFlux[k].fromLinearRGB(a[15 + 3 * k], a[16 + 3 * k], a[17 + 3 * k]);
+        }
+        if (vpm) {
+          gp.scaleVol = m_scaleVol[px];
+          gp.NVol = m_nVol[px];
+        }
+      }
+  }
+
+  /* ------------------------------------------------------------------------------------- scene and medium ---- */
+  /* scene->rayIntersect(Ray) of the shifts' visibility tests (shift_volume_photon.cpp:398, shift_volume_beams.cpp:421):
+   * every triangle of every TriMesh of the scene, world space.                                                    */
+  void uploadScene(const Scene *scene) {
+    std::vector<float> v0, e1, e2;
+    for (const auto &shape : scene->getShapes()) {
+      const TriMesh *mesh = dynamic_cast<const TriMesh *>(shape.get());
+      if (!mesh) {
+        ref<TriMesh> tess = const_cast<Shape *>(shape.get())->createTriMesh();   /* analytic shapes: their tessellation */
+        mesh = tess.get();
+        if (!mesh) SLog(EError, "gvpm_hip: shape '%s' has no triangle representation", shape->getName().c_str());
+        appendMesh(mesh, v0, e1, e2);
+        continue;
+      }
+      appendMesh(mesh, v0, e1, e2);
+    }
+    gvpm_triangles t;
+    t.v0 = v0.data(); t.e1 = e1.data(); t.e2 = e2.data();
+    t.n = (uint32_t) (v0.size() / 3);
+    check(gvpm_upload_scene(m_h, &t), "gvpm_upload_scene");
+  }
+  static void appendMesh(const TriMesh *mesh, std::vector<float> &v0, std::vector<float> &e1, std::vector<float> &e2) {
+    const Point *pos = mesh->getVertexPositions();
+    const Triangle *tri = mesh->getTriangles();
+    for (size_t k = 0; k < mesh->getTriangleCount(); ++k) {
+      const Point &a = pos[tri[k].idx[0]], &b = pos[tri[k].idx[1]], &c = pos[tri[k].idx[2]];
+      push3(v0, a);
+      push3(e1, b - a);
+      push3(e2, c - a);
+    }
+  }
+
+  /* The one homogeneous medium of the scene (the reference's own restriction: `Medium *m_smoke`, computeOnlyVolume-
+   * Interaction sets its sampling weight to 1, gvpm.cpp:135-142): sigma_a, sigma_s, sigma_t = sigma_a + sigma_s
+   * (src/medium/homogeneous.cpp:170-200), the phase function's mean cosine (isotropic: 0).                         */
+  void uploadMedium(const Scene *scene) {
+    const Medium *med = nullptr;
+    for (const auto &m : scene->getMedia()) med = m.get();
+    if (!med) SLog(EError, "gvpm_hip: the scene has no participating medium");
+    if (!med->isHomogeneous()) SLog(EError, "gvpm_hip: heterogeneous media stay on the CPU path (useHip=false)");
+    gvpm_medium gm;
+    memset(&gm, 0, sizeof(gm));
+    Float r, g, b;
+    med->getSigmaA().toLinearRGB(r, g, b);
+    gm.sigma_a[0] = (float) r; gm.sigma_a[1] = (float) g; gm.sigma_a[2] = (float) b;
+    med->getSigmaS().toLinearRGB(r, g, b);
+    gm.sigma_s[0] = (float) r; gm.sigma_s[1] = (float) g; gm.sigma_s[2] = (float) b;
+    med->getSigmaT().toLinearRGB(r, g, b);
+    gm.sigma_t[0] = (float) r; gm.sigma_t[1] = (float) g; gm.sigma_t[2] = (float) b;
+    gm.g = (float) med->getPhaseFunction()->getMeanCosine();
+    gm.medium_sampling_weight = 1.f;                                  /* computeOnlyVolumeInteraction(), gvpm.cpp:135-142 */
+    check(gvpm_upload_medium(m_h, &gm), "gvpm_upload_medium");
+  }
+
+  /* Mitsuba's SLog(EError, ...) throws: a negative status is raised exactly where the reference would have raised   */
+  void check(int rc, const char *what) const {
+    if (rc < 0) SLog(EError, "gvpm_hip: %s failed (%d): %s", what, rc, m_h ? gvpm_last_error(m_h) : "no handle");
+  }
+
+  gvpm_context *m_h;
+  gvpm_params m_params;
+  GPMConfig m_config;
+  Soa m_soa;
+  std::vector<float> m_endN, m_w1, m_len1, m_accum, m_scaleVol, m_nVol;
+  std::vector<gvpm_camera_ray> m_rays;
+  std::vector<gvpm_vpm_sample> m_samples;
+};
+
+MTS_NAMESPACE_END
