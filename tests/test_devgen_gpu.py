@@ -46,6 +46,25 @@ def test_photons_match_the_host_generator(scene, cap):
     g.close()
 
 
+@pytest.mark.parametrize("scene,cap", [("cbox", 2500), ("cbox_hg", 1500), ("cbox_mirror", 1500), ("fogroom", 1200)])
+def test_device_photons_match_an_independent_implementation(scene, cap):
+    """Not a self-comparison: tests/indep_lightpaths.py shares no code with host/synth_core.h, the header both the host
+    and the device generator compile (a compiler-dependent evaluation order in that header -- the g++ / clang argument
+    order of DESIGN 5c -- would show here, not in a device-vs-host test)."""
+    import indep_lightpaths as IL
+    sc = SynthScene(scene, 16, 16)
+    g = hip.DeviceGenerator(sc)
+    for it in (1, 2):
+        ref, nb_ref = IL.shoot_photons(IL.Scene(sc.devgen_scene()), it, cap)
+        soa, nb = g.shoot_photons(it, cap)
+        assert int(soa.n) == cap and nb == nb_ref
+        got = photons_from_dev(g, soa)
+        assert np.array_equal(got.flags, ref["flags"]) and np.array_equal(got.path_id, ref["path_id"])
+        for k in abi.PHOTON_VEC3 + abi.PHOTON_F1:
+            assert close(getattr(got, k), ref[k]), k
+    g.close()
+
+
 def test_beams_and_batches():
     """Photon beams + end normals; a capacity that takes several batches of paths."""
     sc = SynthScene("cbox", 16, 16)
