@@ -255,10 +255,11 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
   for (int i = 0; i < 4; ++i) {
     // branch-free: the null-shift arithmetic is cheap and some lane of the wave needs it anyway; a wave
     // spends more on exec-mask bookkeeping and taken branches than on the arithmetic they would skip
-    const RayReg sh = loadRay(s, 1 + i, b);
-    const float4 ro = s.relO[i][b], rd = s.relD[i][b];
+    // the shifted ray RELATIVE to the base ray (relToBase, tile_walk.h): shiftRay(t') - baseRay(t') = relO + relD t' is a
+    // small fp32 vector (pixel spacing at depth t'), accurate to ~1e-10; the sensorMIS factor rides along
+    const ShiftRel sh = loadShiftRel(s, i, b, base.d);
     // photon relative to shiftRay(t') = (photon - baseRay(t')) - (shiftRay(t') - baseRay(t'))
-    const f3 y = bt.rel - (mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * tPf);
+    const f3 y = bt.rel - (sh.ro + sh.rd * tPf);
     // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
     const bool isNull = sh.valid && a.cfg.use_shift_null && dot(y, y) < r2 && tPf < sh.len;
     const f3 yp = y - sh.d * dot(y, sh.d);
@@ -268,7 +269,7 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
     if (a.cfg.use_mis)
       wNull = (pdfShiftPos == 0.f || bt.pdfCam == 0.f)
                   ? 1.f
-                  : frcp(1.f + ro.w * pdfShiftPos * frcp(bt.pdfCam));
+                  : frcp(1.f + sh.sMIS * pdfShiftPos * frcp(bt.pdfCam));
     const f3 nullFlux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
     // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
     const bool wantsShift = sh.valid && !isNull && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL;
@@ -296,7 +297,12 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
                                                f3 &wb, uint32_t &nDiff, uint32_t &nFail, const float4 *ldsTri) {
   const PhotonCold ph = loadCold(a, pidx);
   const RayReg base = loadRay(s, 0, b);
-  const RayReg sh = loadRay(s, 1 + i, b);
+  const ShiftRel sr = loadShiftRel(s, i, b, base.d);
+  RayReg sh;  // what the reconnection reads of the shifted ray: direction, eye contribution
+  sh.d = sr.d;
+  sh.eye = sr.eye;
+  sh.len = sr.len;
+  sh.valid = sr.valid;
   const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
   const float r = a.radius, r2 = r * r;
   // t', pdfCameraPos and the photon relative to baseRay(t') exactly as phase 1 derived them (baseTerms)
@@ -325,8 +331,7 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   const f3 bc = (sigS * ph.flux) * (trT.x * phaseEval(a.med.g, ph.wi, -base.d) * scale) * base.eye;
 
   const f3 basePt = base.o + base.d * (float)tPrime;  // baseRay(t'), absolute (for the segment to the parent)
-  const float4 ro = s.relO[i][b], rd = s.relD[i][b];
-  const f3 dS = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * (float)tPrime;  // shiftRay(t') - baseRay(t')
+  const f3 dS = sr.ro + sr.rd * (float)tPrime;  // shiftRay(t') - baseRay(t')
   // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
   f3 offRel = rel;
   if (!use3D) {
@@ -350,7 +355,7 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   f3 sflux;
   const f3 dProjU = ((basePt + dS) - ph.parentPos) + offRel;  // offsetPos - parent
   float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok, ldsTri,
-                                 ro.w);
+                                 sr.sMIS);
   if (ok) nDiff++; else nFail++;
   borderRule(a, s.pix[b], i, w);
   const float ws = w * scale;
@@ -577,7 +582,7 @@ template <int B> struct SegLds : RayTile<B> {
   uint32_t boff[B + 1];
   typename SegCfg<B>::Entry q[SEG_QCAP];  // step | lane | shift | beam
   uint16_t amb[SEG_AMB];                  // pairs the fp32 band could not decide: step << 6 | lane
-  float4 relO[4][B], relD[4][B];          // as in EvalLds
+  // (the shifted rays are kept RELATIVE to their base ray in the ray tile's own slots, with sensorMIS: relToBase)
 };
 
 // LDS accesses of ONE wave are executed in order; what has to be stopped is the compiler moving them
@@ -636,13 +641,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
     loadTileRaysNoSync<B>(a, s, setBase, nb, lane);
     for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
     waveLdsSync();
-    for (int idx = lane; idx < 4 * B; idx += 64) {
-      const int i = idx / B, bb = idx % B;
-      const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
-      const f3 dO = tof(tod(sr.o) - tod(br.o)), dD = tof(tod(sr.d) - tod(br.d));
-      s.relO[i][bb] = make_float4(dO.x, dO.y, dO.z, sensorMIS(sr, br, s.edge[bb]));
-      s.relD[i][bb] = make_float4(dD.x, dD.y, dD.z, 0.f);
-    }
+    relToBase<B>(s, lane);
     waveLdsSync();
 
     const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
@@ -669,27 +668,39 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
         bool dirty = false;  // acc holds sums of beam `cur`
         const uint32_t tLim = late ? tSeg + (nLate + 63u) / 64u : chunk;
         uint32_t t = tSeg;
-        for (; t < tLim && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP && an + 64u <= (uint32_t)SEG_AMB; ++t) {
-          // the pair of this lane and step: entry g of the concatenated lists, or a late pair
-          uint32_t g = g0 + t;
-          bool have = g < g1;
+        // the pair of a lane at step tt: entry g of the concatenated lists (or a late pair), its beam, its photon index.
+        // The index of step t + 1 is fetched while step t computes: one dependent global load less per step.
+        auto locate = [&](uint32_t tt, uint32_t from, bool &hv, uint32_t &gg, uint32_t &bb, uint32_t &pi) {
+          gg = g0 + tt;
+          hv = gg < g1 && tt < tLim;
           if (late) {
-            const uint32_t li = (t - tSeg) * 64u + (uint32_t)lane;
-            have = li < nLate;
-            const uint32_t e = s.amb[have ? li : 0u];
-            g = min(total, (e & 63u) * chunk) + tSeg + (e >> 6);
+            const uint32_t li = (tt - tSeg) * 64u + (uint32_t)lane;
+            hv = li < nLate && tt < tLim;
+            const uint32_t e = s.amb[hv ? li : 0u];
+            gg = min(total, (e & 63u) * chunk) + tSeg + (e >> 6);
           }
+          bb = late ? 0u : from;  // (a lane's own pairs come in ascending beam order)
+          pi = 0u;
+          if (hv) {
+            while (s.boff[bb + 1] <= gg) bb++;
+            pi = lists[(size_t)bb * cap + (gg - s.boff[bb])];
+          }
+        };
+        bool haveN;
+        uint32_t gN, bN, pidxN;
+        locate(t, cur, haveN, gN, bN, pidxN);
+        for (; t < tLim && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP && an + 64u <= (uint32_t)SEG_AMB; ++t) {
+          const bool have = haveN;
+          const uint32_t b = bN, pidx = pidxN;
+          locate(t + 1u, b, haveN, gN, bN, pidxN);
           uint32_t qMask = 0;
           bool undecided = false;
           if (have) {
-            uint32_t b = late ? 0u : cur;  // (a lane's own pairs come in ascending beam order)
-            while (s.boff[b + 1] <= g) b++;
             if (b != cur) {
               if (dirty) flushAcc<B>(s, acc, cur);
               dirty = false;
               cur = b;
             }
-            const uint32_t pidx = lists[(size_t)cur * cap + (g - s.boff[cur])];
             const PhotonFront ph = loadFront(a, pidx);
             const RayReg base = loadRay(s, 0, cur);
             const int dec = late ? 1 : decidePair(ph.pos, base, s.rnd[cur], a.radius, a.cfg.epsilon, use3D);
@@ -725,13 +736,15 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
         const uint32_t e0 = min(qn, (uint32_t)lane * cq), e1 = min(qn, e0 + cq);
         uint32_t key = 0xFFFFFFFFu;
         f3 rs = mk3(0.f), rw = mk3(0.f);
-        for (uint32_t j = 0; j <= cq; ++j) {
-          const bool have = j < cq && e0 + j < e1;
-          uint32_t k2 = 0xFFFFFFFFu, pidx = 0, b = 0, i = 0;
-          if (have) {
+        // (the photon index of entry j + 1 is fetched while entry j computes)
+        auto entry = [&](uint32_t j, bool &hv, uint32_t &k2o, uint32_t &pi, uint32_t &bo, uint32_t &io) {
+          hv = j < cq && e0 + j < e1;
+          k2o = 0xFFFFFFFFu;
+          pi = bo = io = 0u;
+          if (hv) {
             const uint32_t e = s.q[e0 + j];
-            b = e & ((1u << BB) - 1u);
-            i = (e >> BB) & 3u;
+            bo = e & ((1u << BB) - 1u);
+            io = (e >> BB) & 3u;
             uint32_t ln = (e >> (2 + BB)) & 63u, ts = e >> (8 + BB);
             if (late) {
               const uint32_t e2 = s.amb[ts * 64u + ln];
@@ -739,9 +752,17 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
               ts = e2 >> 6;
             }
             const uint32_t g = min(total, ln * chunk) + tSeg + ts;
-            pidx = lists[(size_t)b * cap + (g - s.boff[b])];
-            k2 = (b << 2) | i;
+            pi = lists[(size_t)bo * cap + (g - s.boff[bo])];
+            k2o = (bo << 2) | io;
           }
+        };
+        bool haveE;
+        uint32_t k2E, pidxE, bE, iE;
+        entry(0u, haveE, k2E, pidxE, bE, iE);
+        for (uint32_t j = 0; j <= cq; ++j) {
+          const bool have = haveE;
+          const uint32_t k2 = k2E, pidx = pidxE, b = bE, i = iE;
+          entry(j + 1u, haveE, k2E, pidxE, bE, iE);
           if (k2 != key && key != 0xFFFFFFFFu) {
             // the run of one (beam, shift) ended: its 6 sums go to the LDS accumulators
             const uint32_t kb = key >> 2, ki = key & 3u;

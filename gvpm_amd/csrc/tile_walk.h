@@ -44,6 +44,36 @@ template <int B> __device__ __forceinline__ RayReg loadRay(const RayTile<B> &s, 
   return r;
 }
 
+// the shifted rays of a freshly loaded tile, in place: {o, len} -> {o_s - o_b, len}, {d, pdf} -> {d_s - d_b, sensorMIS},
+// {eye, jacobian} stays.  The differences are formed in fp64 and are exact to fp32; the base rays stay absolute.
+template <int B> __device__ __forceinline__ void relToBase(RayTile<B> &s, int lane) {
+  for (int idx = lane; idx < 4 * B; idx += 64) {
+    const int i = idx / B, bb = idx % B;
+    const RayReg br = loadRay(s, 0, bb), sr = loadRay(s, 1 + i, bb);
+    const f3 dO = tof(tod(sr.o) - tod(br.o)), dD = tof(tod(sr.d) - tod(br.d));
+    const float lenSigned = s.ray4[1 + i][0][bb].w;  // the valid bit rides on its sign
+    const float sm = sensorMIS(sr, br, s.edge[bb]);
+    s.ray4[1 + i][0][bb] = make_float4(dO.x, dO.y, dO.z, lenSigned);
+    s.ray4[1 + i][1][bb] = make_float4(dD.x, dD.y, dD.z, sm);
+  }
+}
+struct ShiftRel {
+  f3 ro, rd, d, eye;  // o_s - o_b, d_s - d_b, d_s, eyeContrib
+  float len, sMIS;
+  bool valid;
+};
+template <int B> __device__ __forceinline__ ShiftRel loadShiftRel(const RayTile<B> &s, int i, int b, f3 baseD) {
+  ShiftRel r;
+  const float4 q0 = s.ray4[1 + i][0][b], q1 = s.ray4[1 + i][1][b], q2 = s.ray4[1 + i][2][b];
+  r.ro = mk3(q0.x, q0.y, q0.z);
+  r.len = fabsf(q0.w);
+  r.valid = q0.w >= 0.f;
+  r.rd = mk3(q1.x, q1.y, q1.z);
+  r.sMIS = q1.w;
+  r.d = baseD + r.rd;
+  r.eye = mk3(q2.x, q2.y, q2.z);
+  return r;
+}
 // ------------------------------------------------------------------------------------------
 // Tile traversal state shared by the planner and the gather kernel
 // ------------------------------------------------------------------------------------------
