@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=8, help="iterations of the workload the all-core CPU baseline is timed on")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of step 1 (parity_l2 / relMSE)")
     ap.add_argument("--no-upload-inclusive", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the single-stream leg (kernel_isolated_ms)")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="profiling runs: nothing but warm-up + the timed steps touches the GPU (implies the four --no-* flags)")
     ap.add_argument("--emulate-gpus", type=int, default=0,
                     help="single-GPU run of rank 0's shard of an N-GPU frame (sizing probe); not a bench line")
     ap.add_argument("--device-gen", action="store_true",
@@ -80,6 +83,8 @@ def main():
                                                       "the N > 1 code path on a one-GPU box together with --single-device")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (smoke test, not a bench line)")
     args = ap.parse_args()
+    if args.only_timed:
+        args.no_cpu_baseline = args.no_parity = args.no_upload_inclusive = args.no_isolated = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -274,7 +279,7 @@ def main():
             },
             "stats": st,
         }
-        if world == 1 and not gen:
+        if world == 1 and not gen and not args.no_isolated:
             # the same kernel without the other streams' kernels beside it (a second handle with GVPM_PIPELINE=0,
             # a few untimed steps after the timed region): reported next to the live figure, which is the one `frac` uses
             os.environ["GVPM_PIPELINE"] = "0"

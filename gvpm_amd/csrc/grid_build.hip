@@ -390,21 +390,79 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
   return hipcub::DeviceRadixSort::SortPairs(tmp.d, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
 }
 
-// make the temporary large enough for scans of up to n elements
+// make the temporary large enough for scans of up to n elements (so that no scan of a step allocates)
 hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n) {
-  size_t need = 0;
-  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0);
-  if (e != hipSuccess) return e;
-  return ensureTemp(tmp, need);
+  return ensureTemp(tmp, ((size_t)n / 2048 + 2) * sizeof(uint32_t) + 256);
 }
 
+// Exclusive prefix sum in three plain kernels: block sums, their scan by one block, down-sweep.  (hipCUB's single-pass
+// scan makes every block look back at its predecessors' flags: beside the persistent evaluation waves of the previous
+// step, which hold most of the chip until they finish, those predecessors are often not resident yet -- the two scans of
+// a G-BRE build, 50 us each alone, took 260 us each in the pipelined run.  Nothing here waits for another block.)
+constexpr uint32_t SCAN_BLOCK = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *lds, uint32_t &total) {
+  // 256 threads = 4 waves: wave scan, then the 4 wave totals
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t incl = wave_scan_incl(v, lane);
+  if (lane == 63) lds[wv] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int k = 0; k < wv; ++k) base += lds[k];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + incl - v;
+}
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t n, uint32_t *blockSum) {
+  __shared__ uint32_t lds[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t v = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; ++k)
+    if (base + k < n) v += in[base + k];
+  uint32_t total;
+  (void)block_scan_excl(v, lds, total);
+  if (threadIdx.x == 0) blockSum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void scan_spine_kernel(uint32_t *blockSum, uint32_t nblocks) {
+  __shared__ uint32_t lds[4];
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += SCAN_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < nblocks ? blockSum[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_scan_excl(v, lds, total);
+    if (i < nblocks) blockSum[i] = carry + ex;
+    carry += total;
+  }
+}
+__global__ __launch_bounds__(256) void scan_down_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
+                                                        const uint32_t *__restrict__ blockSum) {
+  __shared__ uint32_t lds[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t x[SCAN_PER_THREAD], v = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; ++k) {
+    x[k] = base + k < n ? in[base + k] : 0u;
+    v += x[k];
+  }
+  uint32_t total;
+  uint32_t run = blockSum[blockIdx.x] + block_scan_excl(v, lds, total);
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; ++k) {
+    if (base + k < n) out[base + k] = run;  // (in == out is fine: every thread has read its own eight before it writes)
+    run += x[k];
+  }
+}
 hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s) {
-  size_t need = 0;
-  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, s);
+  if (n == 0) return hipSuccess;
+  const uint32_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipError_t e = ensureTemp(tmp, (size_t)nblocks * sizeof(uint32_t) + 256);
   if (e != hipSuccess) return e;
-  e = ensureTemp(tmp, need);
-  if (e != hipSuccess) return e;
-  return hipcub::DeviceScan::ExclusiveSum(tmp.d, need, in, out, (int)n, s);
+  uint32_t *blockSum = reinterpret_cast<uint32_t *>(tmp.d);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, in, n, blockSum);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, blockSum, nblocks);
+  hipLaunchKernelGGL(scan_down_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, in, out, n, blockSum);
+  return hipGetLastError();
 }
 
 // records of photon beams (indexed by beam, not sorted), 128 bytes = one cache line per evaluation (the nine

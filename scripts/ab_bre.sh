@@ -9,9 +9,5 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%-28s %8.1f Mev/s  step %.3f ms  eval %.3f  iso %.3f  trav %.3f  build %.3f' % ('$name', d['value'], d['ms_per_step'], r['kernel_avg_ms'], r.get('kernel_isolated_ms',0), r['traverse_avg_ms'], r['build_avg_ms']))" | tee -a $out/summary.txt
 }
 run default A=1
-run two_stage GVPM_TRAV_STREAM=0
-run two_stage_w12 GVPM_TRAV_STREAM=0 GVPM_WAVES_PER_CU=12
-run serial GVPM_PIPELINE=0
-run plan1536 GVPM_PLAN_TARGET=1536
-run plan1280 GVPM_PLAN_TARGET=1280
 run default_b A=1
+run cell15 GVPM_CELL_SCALE=1.5

@@ -54,7 +54,7 @@ for k in fetch:
                       "hbm_bytes_per_launch": (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0}
 # what the measurement was taken on (bench.py reports `traffic` only for the same workload and kernel sources)
 try:
-    line = json.loads(open(os.path.join(out, "bench_trace.log")).read().strip().splitlines()[-1])
+    line = json.loads([l for l in open(os.path.join(out, "bench_trace.log")).read().splitlines() if l.startswith("{")][-1])
     cfg = line["config"]
     traffic["_meta"] = {"technique": cfg["technique"], "scene": cfg["scene"], "frame": cfg["frame"],
                         "photons": cfg["photons_per_iter"], "scale": float(cfg["workload"].rsplit(" ", 1)[-1]),
