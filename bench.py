@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: every rank owns --tile^2 pixels of a (tiles_x*tile) x (tiles_y*tile) frame")
     ap.add_argument("--frame", type=int, default=0, help="pixels per side of the whole frame (strong scaling; 0: the workload's)")
-    ap.add_argument("--tile", type=int, default=512, help="--weak / --emulate-gpus: pixels per side of one rank's share")
+    ap.add_argument("--tile", type=int, default=512, help="--weak: pixels per side of one rank's share")
     ap.add_argument("--photons", type=int, default=0, help="photons per iteration (0: the workload's)")
     ap.add_argument("--scene", default="", help="synthetic scene (default: the workload's)")
     ap.add_argument("--technique", default="bre3d", choices=["bre3d", "bre2d"],
@@ -117,7 +117,7 @@ def main():
     scene = args.scene or wl["scene"]
     photons = args.photons or wl["photons"]
     ndist_req = args.distinct or wl["distinct"]
-    strong = not args.weak and not args.emulate_gpus
+    strong = not args.weak
     if strong:
         W = H = args.frame or wl["frame"]
     else:

@@ -19,9 +19,10 @@
 // owns the intersection -- the reference's own rule (1D: v in (t1,t2], beams_struct.h:297-299;
 // 3D: tNear in (t1,t2), shift_volume_beams.h:213-220) -- so the result does not depend on how
 // beams are cut.  Traversal, LDS staging, ballot compaction and the work queue are those of the
-// BRE kernel (tile_walk.h).  The evaluation itself runs in fp64 (half rate on CDNA4): it is a
-// literal transcription of the reference with its float intermediates; an fp32 fast path is
-// future work.
+// BRE kernel (tile_walk.h).  The evaluation runs in fp32 in a local frame (beams_eval_f32.h), in two
+// phases (base + null shifts, then the queued reconnections); the literal fp64 transcription of the
+// reference with its float intermediates is kept as the on-device cross-check (GVPM_BEAMS_FP64=1) and
+// settles the ownership decisions that fall inside the fp32 error band.
 #include <hip/hip_runtime.h>
 
 #include "beams_eval_f32.h"

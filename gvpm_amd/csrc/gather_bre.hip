@@ -10,7 +10,7 @@
 //   GatherPoint::sensorMIS                          gvpm/gvpm_struct.h:608-631
 //   HomogeneousMedium::eval, phase eval             src/medium/homogeneous.cpp:432-513, src/phase/*.cpp
 //
-// Execution model (one 64-lane wave per workgroup, no MFMA: gather / divergent math):
+// Execution model (64-lane waves that share nothing but staged occluders, no MFMA: gather / divergent math):
 //   * a TILE is a bundle of B camera-beam sets (B = 16/32/64, 64/B lanes per beam) that the
 //     tile sort made spatially coherent (8x8 / 8x4 / 4x4 pixel tiles);
 //   * the photon map is a uniform grid (all photons share one radius, gvpm.cpp:989) sorted by
@@ -20,15 +20,15 @@
 //   * plan_kernel walks every tile once WITHOUT touching photons (cellStart differences only) and
 //     cuts it into work items of roughly equal candidate count -- the load balancer that replaces
 //     BlockScheduler's dynamic image blocks (photonmapper/utilities/block_sched.h:87-113);
-//   * traverse_bre_kernel is persistent (waves pull items from an atomic queue) and holds no
-//     evaluation state, so it runs at high occupancy: for each slab step the 16-byte hot photon
+//   * traverse_bre_kernel (one workgroup per item, or persistent waves pulling items from an atomic
+//     queue: GVPM_PERSISTENT) holds no evaluation state, so it runs at high occupancy: for each slab step the 16-byte hot photon
 //     records of the ranges are copied coalesced into an LDS stage and every lane tests them
 //     against its own beam (LDS broadcast reads) with a CONSERVATIVE fp32 test (error band on the
 //     safe side) plus the exact integer filters (depth, interaction mode, checkerboard parity).
 //     Survivors are compacted with __ballot / popcount and appended to the list of their beam in
 //     the item's region of the pair buffer (sized by the planner's upper bound; 4 bytes per pair);
-//   * evaluate_bre_kernel, also persistent, cuts the concatenated per-beam lists of an item into 64
-//     equal chunks, one per lane.  Every pair is first DECIDED: the fp32 test with a rigorous error
+//   * evaluate_bre_kernel (persistent, four waves per workgroup) cuts the concatenated per-beam lists
+//     of an item into 64 equal chunks, one per lane, walked in segments of 16 steps.  Every pair is first DECIDED: the fp32 test with a rigorous error
 //     band, the reference predicate in uncontracted fp64 only when the band could change the
 //     decision (~1e-5 of the pairs), so the evaluated set equals the fp64 oracle's bit for bit.
 //     Then phase 1 (base contribution + null shifts, 27 sums in registers) and, in a loop of its

@@ -1,6 +1,15 @@
-f() { python bench.py "$@" --steps 16 --warmup 2 --no-cpu-baseline | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value']), round(d['ms_per_step'],3), round(d['config']['evals_per_iter_per_gpu']), 'eval',round(r['kernel_avg_ms'],3), 'trav',round(r['traverse_avg_ms'],3), 'build',round(r['build_avg_ms'],3))"; }
-echo "C2 x8 pipelined"; f --emulate-gpus 8
-echo "C2 x8 single stream"; GVPM_PIPELINE=0 f --emulate-gpus 8
-echo "C4 x8 pipelined"; f --emulate-gpus 8 --tile 362 --photons 4000000
-echo "C4 x8 single"; GVPM_PIPELINE=0 f --emulate-gpus 8 --tile 362 --photons 4000000
-echo "C2 x2"; f --emulate-gpus 2
+#!/bin/bash
+# bash scripts/shard_probe.sh OUTDIR: the single-GPU probes of DESIGN.md section 6 (C2, C4 whole, rank 0's share of the 8-GPU runs)
+out=${1:-gpurun_out/shard}; mkdir -p $out
+run() { name=$1; shift
+  python bench.py --no-cpu-baseline --no-parity --no-upload-inclusive --no-isolated --steps 8 --warmup 2 "$@" 2> $out/$name.err | grep '^{' > $out/$name.json
+  python - $out/$name.json $name <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); r=d['roofline']; c=d['config']
+print('%-22s %7.2f ms/step  %7.1f M evals/step/GPU  %7.0f M evals/s  eval %.2f trav %.2f build %.2f  | %s' % (sys.argv[2], d['ms_per_step'], c['evals_per_iter_per_gpu']/1e6, d['value'], r['kernel_avg_ms'], r['traverse_avg_ms'], r['build_avg_ms'], c['workload'][:60]))
+PY
+}
+run c2
+run c2_weak8_rank0 --workload c2 --weak --emulate-gpus 8
+run c4_one_gpu --workload c4
+run c4_strong8_rank0 --workload c4 --emulate-gpus 8
