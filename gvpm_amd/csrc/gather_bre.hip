@@ -375,20 +375,43 @@ template <int B, typename LDS> __device__ __forceinline__ void flushAcc(LDS &s, 
 // ------------------------------------------------------------------------------------------
 // traversal: persistent waves pulling work items, (photon, beam) pairs out
 // ------------------------------------------------------------------------------------------
-struct TravLds {
-  float4 stage[STAGE];
+// LDS accesses of ONE wave are executed in order; what has to be stopped is the compiler moving them
+__device__ __forceinline__ void waveLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef GVPM_TRAV_WPB
+#define GVPM_TRAV_WPB 1
+#endif
+// waves per traversal workgroup: they share nothing (a slice of LDS each, wave-local synchronisation); one
+// workgroup of 4 waves costs the dispatcher what a workgroup of one wave does, and 22 000 single-wave workgroups per
+// launch were dispatch-bound (2.4 resident waves per SIMD on average where registers and LDS allow 5)
+constexpr int TRAV_WPB = GVPM_TRAV_WPB;
+#ifndef GVPM_TRAV_MINW
+#define GVPM_TRAV_MINW 3
+#endif
+// the staged photons, one array per component: a lane tests FOUR consecutive photons against its beam, read with four
+// ds_read_b128 issued together, two photons per packed-fp32 instruction
+struct alignas(16) TravLds {
+  float x[STAGE], y[STAGE], z[STAGE];
+  uint32_t bits[STAGE];
   uint32_t stageIdx[STAGE];
 };
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int B>
-__global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
+__global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(GVPM_TRAV_MINW))) void traverse_bre_kernel(GatherArgs a, const uint4 *__restrict__ items,
                                                           const uint2 *__restrict__ itemOff,
                                                           const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
                                                           uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairCnt,
                                                           uint32_t persistent) {
   constexpr int LPB = 64 / B;
-  __shared__ TravLds s;
-  const int lane = threadIdx.x;
+  __shared__ TravLds sAll[TRAV_WPB];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (the compiler must see it is wave-uniform)
+  TravLds &s = sAll[wv];
+  const int lane = threadIdx.x & 63;
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
   const float r = a.radius;
@@ -404,10 +427,10 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
   // (one address: ~11 ns per atomic whatever the number of waves) serves the rest.
   bool firstItem = true;
   for (;;) {
-    uint32_t it = blockIdx.x;
+    uint32_t it = blockIdx.x * TRAV_WPB + (uint32_t)wv;
     if (!firstItem) {
       if (!persistent) break;
-      if (lane == 0) it = gridDim.x + atomicAdd(queueHead, 1u);
+      if (lane == 0) it = gridDim.x * TRAV_WPB + atomicAdd(queueHead, 1u);
       it = __shfl(it, 0, 64);
     }
     firstItem = false;
@@ -432,7 +455,30 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
     const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
     const uint32_t fmask = 0x40u | (a.cfg.path_set ? (1u << GVPM_HOT_PARITY_BIT) : 0u);
     const uint32_t fwant = 0x40u | (a.cfg.path_set ? (pixParity << GVPM_HOT_PARITY_BIT) : 0u);
+    const bool depthWindow = a.cfg.max_depth > 0 || a.cfg.min_depth != 0;  // wave-uniform
+    int dlo = max(dmin, 0), dhi = min(dmax, 255);
+    if (dhi < dlo) dlo = dhi = 256;  // nothing passes
+    const uint32_t dspan = (uint32_t)(dhi - dlo);
+    // thresholds of the conservative test.  The fp32 error of disk is below 6e-7 (|wv|_1 + |disk|) (hitBand) with
+    // wv = photon - origin and |disk| <= |wv|_1; every photon lies in the grid's box, whose farther faces bound |wv|_1
+    float wv1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float ok_ = k == 0 ? base.o.x : (k == 1 ? base.o.y : base.o.z);
+      const float glo = a.grid.org[k] - a.grid.cell, ghi = a.grid.org[k] + (float)(a.grid.dim[k] + 1) * a.grid.cell;
+      wv1 += fmaxf(fabsf(ok_ - glo), fabsf(ok_ - ghi));
+    }
+    const float Emax = 1.25e-6f * wv1;
+    const float thrD2 = beamValid ? r2f + (4.f * r * Emax + r2f * 2e-6f) : -1.f;
+    const float thrLo = mint - Emax, thrHi = maxt + 2.f * r;
     uint32_t staged = 0;  // wave-uniform
+    auto putStage = [&](uint32_t k, float4 v, uint32_t gi) {
+      s.x[k] = v.x;
+      s.y[k] = v.y;
+      s.z[k] = v.z;
+      s.bits[k] = __float_as_uint(v.w);
+      s.stageIdx[k] = gi;
+    };
 
     const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
@@ -448,7 +494,7 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
         const uint32_t total = __shfl(incl, 63, 64);
         for (uint32_t win = 0; win < total; win += STAGE) {
           // stage [win, win + STAGE) of the concatenated ranges
-          __syncthreads();
+          waveLdsSync();
           const uint32_t nst = min((uint32_t)STAGE, total - win);
           if (total >= coalesceAt) {
             // dense boxes (C4: 4 M photons): consecutive LANES take consecutive entries of the window (the range an
@@ -467,8 +513,7 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
               const uint32_t rStart = (uint32_t)__shfl((int)start, (int)rr, 64), rExcl = (uint32_t)__shfl((int)excl, (int)rr, 64);
               if (k < nst) {
                 const uint32_t gi = rStart + (e - rExcl);
-                s.stage[k] = a.hot[gi];
-                s.stageIdx[k] = gi;
+                putStage(k, a.hot[gi], gi);
               }
             }
           } else
@@ -479,59 +524,84 @@ __global__ __launch_bounds__(64) void traverse_bre_kernel(GatherArgs a, const ui
             for (; i + 4 <= hi_i; i += 4) {
               const uint32_t gi = start + (i - excl);
               const float4 v0 = a.hot[gi], v1 = a.hot[gi + 1], v2 = a.hot[gi + 2], v3 = a.hot[gi + 3];
-              s.stage[i - win] = v0; s.stage[i - win + 1] = v1; s.stage[i - win + 2] = v2; s.stage[i - win + 3] = v3;
-              s.stageIdx[i - win] = gi; s.stageIdx[i - win + 1] = gi + 1;
-              s.stageIdx[i - win + 2] = gi + 2; s.stageIdx[i - win + 3] = gi + 3;
+              putStage(i - win, v0, gi); putStage(i - win + 1, v1, gi + 1);
+              putStage(i - win + 2, v2, gi + 2); putStage(i - win + 3, v3, gi + 3);
             }
             for (; i < hi_i; ++i) {
               const uint32_t gi = start + (i - excl);
-              s.stage[i - win] = a.hot[gi];
-              s.stageIdx[i - win] = gi;
+              putStage(i - win, a.hot[gi], gi);
             }
           }
-          __syncthreads();
+          // the slots between nst and the next multiple of 16 hold photons no beam can meet
+          if (lane < 16 && nst + (uint32_t)lane < ((nst + 15u) & ~15u)) s.x[nst + lane] = 3.0e38f;
+          waveLdsSync();
           staged += nst;
-          const uint32_t iters = (nst + LPB - 1) / LPB;
-          // groups of G staged photons per lane: a branch-free pass marks the candidates (the G LDS reads
-          // overlap), then the wave appends them one per lane and round
+          // groups of G * LPB staged photons: sub-lane `sub` of a beam takes G consecutive ones.  A branch-free pass
+          // marks the candidates, then the wave appends them one per lane and round.
           constexpr uint32_t G = 4;
-          for (uint32_t jj = 0; jj < iters; jj += G) {
+          static_assert(STAGE % (G * LPB) == 0 && G == 4, "a lane reads four consecutive photons with one b128 per component");
+          for (uint32_t jb = 0; jb < nst; jb += G * LPB) {  // wave-uniform trip count: the append below is collective
+            const uint32_t j0 = jb + (uint32_t)sub * G;
+            const float4 X = *reinterpret_cast<const float4 *>(&s.x[j0]);
+            const float4 Y = *reinterpret_cast<const float4 *>(&s.y[j0]);
+            const float4 Z = *reinterpret_cast<const float4 *>(&s.z[j0]);
+            const uint4 Bt = *reinterpret_cast<const uint4 *>(&s.bits[j0]);
             uint32_t cm = 0;
-            if (beamValid) {
+            {
+              const v2f ox = {base.o.x, base.o.x}, oy = {base.o.y, base.o.y}, oz = {base.o.z, base.o.z};
+              const v2f dx = {base.d.x, base.d.x}, dy = {base.d.y, base.d.y}, dz = {base.d.z, base.d.z};
+              const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+              const uint32_t bs[4] = {Bt.x, Bt.y, Bt.z, Bt.w};
 #pragma unroll
-              for (uint32_t u = 0; u < G; ++u) {
-                const uint32_t j = (jj + u) * LPB + sub;
-                const float4 hp = s.stage[min(j, (uint32_t)STAGE - 1u)];
-                const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
-                const float disk = dot(wv, base.d);
-                const f3 v = wv - base.d * disk;
-                const float d2 = dot(v, v);
-                float E, band;
-                hitBand(wv, disk, r, r2f, E, band);
-                // the exact filters, shift_volume_photon.cpp:670-697: depth window, computeVolumeContribution +
-                // debugShift (bit 6, folded by grid_build), checkerboard parity (bit 7)
-                const uint32_t bits = __float_as_uint(hp.w);
-                const int depth = (int)GVPM_PF_DEPTH(bits);
-                const bool keep = depth <= dmax && depth >= dmin && (bits & fmask) == fwant;
-                // conservative: every pair the reference accepts passes (its disk test within the band; beyond the
-                // beam end the own-box test admits diskDistance up to maxt + sqrt(3) r)
-                if (j < nst && keep && d2 < r2f + band && disk > mint - E && disk < maxt + 2.f * r) cm |= 1u << u;
+              for (int h = 0; h < 2; ++h) {
+                const v2f wx = (v2f){xs[2 * h], xs[2 * h + 1]} - ox, wy = (v2f){ys[2 * h], ys[2 * h + 1]} - oy,
+                          wz = (v2f){zs[2 * h], zs[2 * h + 1]} - oz;
+                const v2f disk = wx * dx + (wy * dy + wz * dz);
+                const v2f vx = wx - dx * disk, vy = wy - dy * disk, vz = wz - dz * disk;
+                const v2f d2 = vx * vx + (vy * vy + vz * vz);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const int u = 2 * h + e;
+                  // conservative: every pair the reference accepts passes (its disk test within the band -- folded into
+                  // the thresholds, from the largest |photon - origin| the grid allows; beyond the beam end the
+                  // own-box test admits diskDistance up to maxt + sqrt(3) r)
+                  uint32_t ok = (uint32_t)(d2[e] < thrD2) & (uint32_t)(disk[e] > thrLo) & (uint32_t)(disk[e] < thrHi);
+                  // the exact filters, shift_volume_photon.cpp:670-697: computeVolumeContribution + debugShift (bit 6,
+                  // folded by grid_build), checkerboard parity (bit 7), depth window
+                  ok &= (uint32_t)((bs[u] & fmask) == fwant);
+                  if (depthWindow) ok &= (uint32_t)((uint32_t)((int)GVPM_PF_DEPTH(bs[u]) - dlo) <= dspan);
+                  cm |= ok << u;
+                }
               }
             }
-            while (__ballot(cm != 0u)) {
-              const bool hit = cm != 0u;
-              const uint32_t j = min((jj + (hit ? (uint32_t)__ffs(cm) - 1u : 0u)) * LPB + sub, (uint32_t)STAGE - 1u);
-              cm &= cm - 1u;
-              const unsigned long long m = __ballot(hit);
-              // the candidates of my beam in this round sit in lanes b, b + B, ...: append in lane order
-              constexpr unsigned long long GROUP = B == 16 ? 0x0001000100010001ull : (B == 32 ? 0x0000000100000001ull : 1ull);
-              const unsigned long long g = (m >> b) & GROUP;
-              if (hit) {
-                const uint32_t off = mine + __popcll(g & ((1ull << (sub * B)) - 1ull));
-                if (off < cap) out[off] = s.stageIdx[j];
-                else nOver++;
+            if (__ballot(cm != 0u)) {
+              // append: the LPB sub-lanes of a beam (lanes b, b + B, ...) write their candidates behind one another.
+              // (consecutive photons are neighbours in space, so one lane often holds several of a beam's hits: a
+              // collective round per hit would cost the whole wave a round for each)
+              const uint32_t c = (uint32_t)__popc(cm);
+              uint32_t before = 0, total = c;
+              if (B <= 32) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)total, 32, 64);
+                before += (lane & 32) ? t : 0u;
+                total += t;
               }
-              mine += __popcll(g);
+              if (B == 16) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)c, 16, 64);
+                // lanes with bit 4 set come after their partner; the pair with bit 5 set after the pair without
+                const uint32_t pairSum = c + t;
+                const uint32_t t2 = (uint32_t)__shfl_xor((int)pairSum, 32, 64);
+                before = ((lane & 16) ? t : 0u) + ((lane & 32) ? t2 : 0u);
+                total = pairSum + t2;
+              }
+              uint32_t off = mine + before;
+              while (cm) {
+                const uint32_t u = (uint32_t)__ffs(cm) - 1u;
+                cm &= cm - 1u;
+                if (off < cap) out[off] = s.stageIdx[j0 + u];
+                else nOver++;
+                ++off;
+              }
+              mine += total;
             }
           }
         }
@@ -585,12 +655,38 @@ template <int B> struct SegLds : RayTile<B> {
   // (the shifted rays are kept RELATIVE to their base ray in the ray tile's own slots, with sensorMIS: relToBase)
 };
 
-// LDS accesses of ONE wave are executed in order; what has to be stopped is the compiler moving them
-__device__ __forceinline__ void waveLdsSync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+#ifdef GVPM_EVAL_TIMING
+// probe builds only: shader-clock ticks per part of the evaluation kernel, summed over waves
+// [0] wave lifetime [1] item header + LDS setup [2] decision + phase 1 [3] phase 2 [4] late pass bookkeeping [5] write-out [6] items
+__device__ unsigned long long gvpmEvalTiming[16];  // [12] longest wave [13] longest item [14] waves
+// wall clock (100 MHz, the same on every XCD) at the start and the end of every wave of the LAST launch, and its units
+__device__ unsigned long long gvpmEvalWaveLog[16 * 16384];
+extern "C" int gvpm_debug_eval_timing(unsigned long long *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(gvpmEvalTiming), sizeof(gvpmEvalTiming)) != hipSuccess) return -1;
+  if (out && hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(gvpmEvalWaveLog), sizeof(gvpmEvalWaveLog)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gvpmEvalTiming), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
 }
+__device__ __forceinline__ unsigned long long tickNow() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define TICK() tickNow()
+__device__ __forceinline__ unsigned long long tickLight() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define LTICK() tickLight()
+#else
+#define TICK() 0ull
+#define LTICK() 0ull
+#endif
 
 template <int B, bool FULLVIS>
 __global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 > 0 ? GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 : 1)
@@ -614,9 +710,17 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
   const uint32_t nItems = *itemCount;
   const uint32_t waveId = blockIdx.x * WPB + wv, nWaves = gridDim.x * WPB;
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
+  [[maybe_unused]] unsigned long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] const unsigned long long tStart = TICK();
+  [[maybe_unused]] unsigned long long tItemMax = 0;
+#ifdef GVPM_EVAL_TIMING
+  const unsigned long long wStart = wall_clock64();
+  unsigned long long wLastStart = 0, lastN = 0, lastUk = 0, wLastEnd = 0, tkLast[6] = {0, 0, 0, 0, 0, 0}, suLast[4] = {0, 0, 0, 0};
+#endif
 
   bool firstItem = true;
   for (;;) {
+    [[maybe_unused]] const unsigned long long tItem = TICK();
     uint32_t it = waveId;
     if (!firstItem) {
       if (!persistent) break;  // one item per wave (see traverse_bre_kernel)
@@ -632,22 +736,42 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
     const uint32_t incl = wave_scan_incl(cntb, lane);
     const uint32_t total = __shfl(incl, 63, 64);
     if (total == 0) continue;
+    const uint32_t r0 = 0u, n = total;  // (the wave's share of the item's concatenated lists: all of it)
+#ifdef GVPM_EVAL_TIMING
+    wLastStart = wall_clock64();
+    lastN = n;
+    lastUk = it;
+    for (int k = 1; k <= 5; ++k) tkLast[k] = tk[k];  // ([1]: this unit's setup is added after this point)
+    const unsigned long long su0 = TICK();
+#endif
     const uint2 reg = itemOff[it];
     const uint32_t *lists = pairs + (size_t)reg.x * 64u;
     const uint32_t cap = reg.y;
     waveLdsSync();
     if (lane < B) s.boff[lane + 1] = incl;
     if (lane == 0) s.boff[0] = 0u;
+#ifdef GVPM_EVAL_TIMING
+    const unsigned long long su1 = TICK();
+#endif
     loadTileRaysNoSync<B>(a, s, setBase, nb, lane);
+#ifdef GVPM_EVAL_TIMING
+    const unsigned long long su2 = TICK();
+#endif
     for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
     waveLdsSync();
     relToBase<B>(s, lane);
     waveLdsSync();
+#ifdef GVPM_EVAL_TIMING
+    suLast[0] = su0 - tItem; suLast[1] = su1 - su0; suLast[2] = su2 - su1; suLast[3] = TICK() - su2;
+#endif
+    [[maybe_unused]] unsigned long long tMark = TICK();
+    tk[1] += tMark - tItem;
+    tk[6] += 1;
 
     const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
     // my chunk [g0, g1) of the concatenated per-beam lists (lane l of ANY wave position: g0 = min(total, l * chunk))
-    const uint32_t chunk = (total + 63u) / 64u;
-    const uint32_t g0 = min(total, (uint32_t)lane * chunk), g1 = min(total, g0 + chunk);
+    const uint32_t chunk = (n + 63u) / 64u;
+    const uint32_t g0 = r0 + min(n, (uint32_t)lane * chunk), g1 = min(r0 + n, g0 + chunk);
     uint32_t cur = 0;  // current beam
     if (g0 < g1)
       while (s.boff[cur + 1] <= g0) cur++;
@@ -677,7 +801,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             const uint32_t li = (tt - tSeg) * 64u + (uint32_t)lane;
             hv = li < nLate && tt < tLim;
             const uint32_t e = s.amb[hv ? li : 0u];
-            gg = min(total, (e & 63u) * chunk) + tSeg + (e >> 6);
+            gg = r0 + min(n, (e & 63u) * chunk) + tSeg + (e >> 6);
           }
           bb = late ? 0u : from;  // (a lane's own pairs come in ascending beam order)
           pi = 0u;
@@ -690,21 +814,30 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
         uint32_t gN, bN, pidxN;
         locate(t, cur, haveN, gN, bN, pidxN);
         for (; t < tLim && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP && an + 64u <= (uint32_t)SEG_AMB; ++t) {
+          [[maybe_unused]] const unsigned long long l0 = LTICK();
           const bool have = haveN;
           const uint32_t b = bN, pidx = pidxN;
           locate(t + 1u, b, haveN, gN, bN, pidxN);
+          [[maybe_unused]] const unsigned long long l1 = LTICK();
+          tk[7] += l1 - l0;
           uint32_t qMask = 0;
           bool undecided = false;
+          [[maybe_unused]] unsigned long long l2 = l1, l3 = l1;
           if (have) {
             if (b != cur) {
               if (dirty) flushAcc<B>(s, acc, cur);
               dirty = false;
               cur = b;
             }
+            l2 = LTICK();
             const PhotonFront ph = loadFront(a, pidx);
             const RayReg base = loadRay(s, 0, cur);
             const int dec = late ? 1 : decidePair(ph.pos, base, s.rnd[cur], a.radius, a.cfg.epsilon, use3D);
             undecided = dec == 2;
+#ifdef GVPM_EVAL_TIMING
+            asm volatile("" :: "v"(dec));
+            l3 = LTICK();
+#endif
             if (dec == 1) {
               evalPhase1<B>(a, s, ph, base, cur, acc, nNull, nFail, qMask);
               dirty = true;
@@ -724,6 +857,9 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             if (qd) s.q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (Entry)(ent | (i << BB));
             qn += (uint32_t)__popcll(m);
           }
+#ifdef GVPM_EVAL_TIMING
+          { const unsigned long long l5 = LTICK(); tk[8] += l2 - l1; tk[9] += l3 - l2; tk[10] += l5 - l3; tk[11] += 1; }
+#endif
         }
         if (dirty) flushAcc<B>(s, acc, cur);
         if (!late) {
@@ -731,6 +867,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           curKeep = cur;  // the late pass visits beams in any order: the walk resumes from here
         }
         waveLdsSync();
+        { [[maybe_unused]] const unsigned long long tn = TICK(); tk[2] += tn - tMark; tMark = tn; }
         // ---- phase 2 over the queue: lane l takes entries [l * cq, (l + 1) * cq) ----
         const uint32_t cq = (qn + 63u) / 64u;
         const uint32_t e0 = min(qn, (uint32_t)lane * cq), e1 = min(qn, e0 + cq);
@@ -751,7 +888,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
               ln = e2 & 63u;
               ts = e2 >> 6;
             }
-            const uint32_t g = min(total, ln * chunk) + tSeg + ts;
+            const uint32_t g = r0 + min(n, ln * chunk) + tSeg + ts;
             pi = lists[(size_t)bo * cap + (g - s.boff[bo])];
             k2o = (bo << 2) | io;
           }
@@ -783,6 +920,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           }
         }
         waveLdsSync();
+        { [[maybe_unused]] const unsigned long long tn = TICK(); tk[3] += tn - tMark; tMark = tn; }
         if (late || an == 0u) break;
         // ---- the undecided pairs: the reference predicate (fp64, uncontracted); the accepted ones are compacted
         // in place into the late list and go through the two loops above once more ----
@@ -792,7 +930,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           uint32_t e = 0;
           if (j < an) {
             e = s.amb[j];
-            const uint32_t g = min(total, (e & 63u) * chunk) + tSeg + (e >> 6);
+            const uint32_t g = r0 + min(n, (e & 63u) * chunk) + tSeg + (e >> 6);
             uint32_t b = 0;
             while (s.boff[b + 1] <= g) b++;
             const uint32_t pidx = lists[(size_t)b * cap + (g - s.boff[b])];
@@ -806,6 +944,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           nLate += (uint32_t)__popcll(m);
         }
         waveLdsSync();
+        { [[maybe_unused]] const unsigned long long tn = TICK(); tk[4] += tn - tMark; tMark = tn; }
         if (nLate == 0u) break;
       }
       tSeg = tEnd;
@@ -823,7 +962,35 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
         }
       }
     }
+    { [[maybe_unused]] const unsigned long long tn = TICK(); tk[5] += tn - tMark; if (tn - tItem > tItemMax) tItemMax = tn - tItem; }
+#ifdef GVPM_EVAL_TIMING
+    wLastEnd = wall_clock64();
+#endif
   }
+#ifdef GVPM_EVAL_TIMING
+  tk[0] = TICK() - tStart;
+  if (lane == 0)
+  {
+#if GVPM_EVAL_TIMING > 1  // (same-address atomics of thousands of ending waves stall the loads of the waves still running)
+    for (int k = 0; k < 12; ++k) atomicAdd(&gvpmEvalTiming[k], tk[k]);
+    atomicMax(&gvpmEvalTiming[12], tk[0]);
+    atomicMax(&gvpmEvalTiming[13], tItemMax);
+    atomicAdd(&gvpmEvalTiming[14], 1ull);
+#endif
+    if (waveId < 16384u) {
+      unsigned long long *lg = gvpmEvalWaveLog + 16 * waveId;
+      for (int k = 0; k < 4; ++k) lg[12 + k] = suLast[k];
+      lg[0] = wStart;
+      lg[1] = wall_clock64();
+      lg[2] = tk[6];
+      lg[3] = wLastStart;
+      lg[4] = lastN;
+      lg[5] = lastUk;
+      for (int k = 1; k <= 5; ++k) lg[5 + k] = tk[k] - tkLast[k];
+      lg[11] = wLastEnd;
+    }
+  }
+#endif
   // ---- statistics ----
   {
     unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
@@ -865,9 +1032,9 @@ void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *ite
   if (a.nsets == 0 || nwaves == 0) return;
   const uint32_t persist = persistent ? 1u : 0u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
   }
 }
 

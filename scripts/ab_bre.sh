@@ -9,5 +9,12 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%-28s %8.1f Mev/s  step %.3f ms  eval %.3f  iso %.3f  trav %.3f  build %.3f' % ('$name', d['value'], d['ms_per_step'], r['kernel_avg_ms'], r.get('kernel_isolated_ms',0), r['traverse_avg_ms'], r['build_avg_ms']))" | tee -a $out/summary.txt
 }
 run default A=1
-run default_b A=1
-run cell15 GVPM_CELL_SCALE=1.5
+run default_single GVPM_PIPELINE=0
+for e in $ENVS; do
+  run single_$e GVPM_PIPELINE=0 $e
+  run pipe_$e $e
+done
+for v in $VARIANTS; do
+  run $v GVPM_HIP_LIB=$PWD/build/variants/libgvpm_hip_$v.so
+  run ${v}_single GVPM_HIP_LIB=$PWD/build/variants/libgvpm_hip_$v.so GVPM_PIPELINE=0
+done

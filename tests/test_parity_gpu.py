@@ -198,7 +198,8 @@ def test_dev_upload_equals_host_upload(case):
     ctx.gather(1, c.nb)
     acc = ctx.download_accum()
     assert ctx.stats()["evaluations"] == st_host["evaluations"]
-    assert np.allclose(acc, acc_host, rtol=1e-5, atol=1e-9)
+    # (float atomics: the order of a pixel's sums differs from run to run, ~sqrt(terms) ulp)
+    np.testing.assert_allclose(acc, acc_host, rtol=5e-5, atol=1e-6 * float(np.abs(acc_host).max()))
     out = torch.zeros(acc.size, dtype=torch.float32, device="cuda")
     ctx.download_accum_dev(out.data_ptr())
     assert np.array_equal(out.cpu().numpy().reshape(acc.shape), acc)
