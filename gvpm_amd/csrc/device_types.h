@@ -30,6 +30,15 @@ struct Grid {
   uint32_t ncells;
 };
 
+// Occluders by cell of a coarse uniform grid over the scene (grid_build.hip: near_grid_*): tris[start[c] .. start[c + 1])
+// are the triangles a point of cell c can have within `reach`.  start == nullptr: no grid (small scenes scan linearly).
+struct NearGrid {
+  const uint32_t *start = nullptr;
+  const uint32_t *tris = nullptr;
+  float org[3] = {0, 0, 0}, inv[3] = {0, 0, 0};  // cell index = floor((p - org) * inv)
+  int dim[3] = {0, 0, 0};
+};
+
 struct SortTemp {
   void *d = nullptr;
   size_t bytes = 0;

@@ -1401,6 +1401,23 @@ template <int B> struct BeamEvalLds : RayTile<B> {
   float4 qp[BQCAP], qs[BQCAP];      // {offset position (local), kRec.v} {kRec.w, pdfEdgeFailure * pdfKernel, scale, ray | shift << 8}
 };
 
+#ifdef GVPM_EVAL_TIMING
+// probe builds only: per wave of the last launch, shader-clock ticks in [0] beamBase [1] beamShift1 + push [2] phase 2
+// [3] tile change (flush, rays) [7] lifetime; [4] blocks [5] pairs alive after beamBase [6] reconnections
+__device__ unsigned long long gvpmBeamsLog[8 * 16384];
+extern "C" int gvpm_debug_beams_timing(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gvpmBeamsLog), sizeof(gvpmBeamsLog)) == hipSuccess ? 0 : -1;
+}
+__device__ __forceinline__ unsigned long long beamsTick() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define BTICK() beamsTick()
+#else
+#define BTICK() 0ull
+#endif
+
 template <int B>
 __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
                                                                              const uint32_t *__restrict__ sortedKey,
@@ -1419,7 +1436,11 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
   uint32_t qHead = 0, qCount = 0;  // wave-uniform
+  [[maybe_unused]] unsigned long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] const unsigned long long btStart = BTICK();
   auto drain = [&](uint32_t n) {   // n <= 64 entries of the ring through phase 2
+    [[maybe_unused]] const unsigned long long d0 = BTICK();
+    bt[6] += n;
     __syncthreads();
     if ((uint32_t)lane < n) {
       const uint32_t e = (qHead + (uint32_t)lane) % BQCAP;
@@ -1431,6 +1452,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
     }
     qHead = (qHead + n) % BQCAP;
     qCount -= n;
+    bt[2] += BTICK() - d0;
   };
   auto flushTile = [&]() {
     while (qCount) drain(min(qCount, 64u));
@@ -1463,6 +1485,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
     const uint32_t b1 = min(nBlocks, b0 + RUN);
     for (uint32_t bi = b0; bi < b1; ++bi) {
       const uint32_t setBase = sortedKey[bi];
+      [[maybe_unused]] const unsigned long long c0 = BTICK(), dr0 = bt[2];
       if (setBase != curBase) {
         flushTile();
         curBase = setBase;
@@ -1472,12 +1495,21 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
         relToBase<B>(s, lane);
         __syncthreads();
       }
+      [[maybe_unused]] const unsigned long long c1 = BTICK();
+      bt[3] += (c1 - c0) - (bt[2] - dr0);
       const uint2 e = pairs[(size_t)sortedBlock[bi] * 64u + lane];
       const bool live = e.x != 0xFFFFFFFFu && e.y >= setBase && e.y - setBase < curNb;
       const uint32_t bIdx = e.y - setBase;
       BeamP1 st;
       const bool alive = live && beamBase<B>(a, s, e.x, bIdx, st);
       if (alive && st.st != 0xFFu) nEval++;  // (debugShift mismatch: base contribution kept, not an evaluation -- as the reference returns)
+#ifdef GVPM_EVAL_TIMING
+      asm volatile("" :: "v"((int)alive));
+      const unsigned long long c2 = BTICK();
+      bt[0] += c2 - c1;
+      bt[4] += 1;
+      bt[5] += (unsigned long long)__popcll(__ballot(alive));
+#endif
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         bool push = false;
@@ -1492,11 +1524,23 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
         }
         qCount += (uint32_t)__popcll(m);
       }
+#ifdef GVPM_EVAL_TIMING
+      bt[1] += BTICK() - c2;
+#endif
       while (qCount >= 64u) drain(64u);
     }
-    flushTile();
+    {
+      [[maybe_unused]] const unsigned long long f0 = BTICK(), dr0 = bt[2];
+      flushTile();
+      bt[3] += (BTICK() - f0) - (bt[2] - dr0);
+    }
     curBase = 0xFFFFFFFFu;
   }
+#ifdef GVPM_EVAL_TIMING
+  bt[7] = BTICK() - btStart;
+  if (lane == 0 && blockIdx.x < 16384u)
+    for (int k = 0; k < 8; ++k) gvpmBeamsLog[8 * blockIdx.x + k] = bt[k];
+#endif
   {
     unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail;
 #pragma unroll

@@ -31,7 +31,10 @@ void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *ke
                        hipStream_t s);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
                     uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
-                    uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow, hipStream_t s);
+                    const NearGrid &ng, uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
+                    hipStream_t s);
+void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
+                      hipStream_t s);
 void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
                        uint32_t *rank, uint32_t *count, hipStream_t s);
 void launch_beam_scatter(const uint32_t *keys, const uint32_t *rank, const uint32_t *start, uint32_t n,
@@ -233,6 +236,11 @@ struct gvpm_context {
   DevBuf<float4> tri4, bvh;   // packed triangles in BVH leaf order + nodes (scene_bvh.h)
   uint32_t ntri = 0;
   float triMin[3] = {0, 0, 0}, triMax[3] = {0, 0, 0};  // occluder bounds (host side, at upload)
+  // occluders by cell of a coarse grid, for the near-occluder lists of scenes with more than 64 of them (built on the
+  // first gather of a scene, for 1.5 x the reach it asks for; rebuilt if a later gather asks for more)
+  DevBuf<uint32_t> nearGridStart, nearGridTris, nearGridCount;
+  NearGrid nearGrid;
+  float nearGridReach = -1.f;
 
   // Host uploads land in a ring of three staging slots per kind, through a copy stream of their own: the copy of
   // step N+1 (or, prefetched, N+2) then runs while the kernels of step N still read theirs.  A slot's `copied` event
@@ -606,6 +614,8 @@ int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *t) {
       h->triMax[c] = fmaxf(h->triMax[c], fmaxf(a, fmaxf(b, d)));
     }
   h->photonsDirty = h->havePhotons;  // the near-occluder lists depend on the scene
+  h->nearGridReach = -1.f;
+  h->nearGrid = NearGrid();
   return GVPM_OK;
 }
 
@@ -885,6 +895,44 @@ static int ilog2ceil(uint32_t v) {
 
 // uniform grid over the photons for kernel radius r.  deferred: use the bounds of the previous
 // photon set when there is one and leave this set's bounds in flight (pinB6) for the caller's sync.
+// The occluder grid of the near-occluder lists (grid_build.hip: near_grid_kernel, nearVisit): count, scan, fill.  Once per
+// scene: the one host read-back (the number of entries) stalls nothing that matters.
+static int buildNearGrid(gvpm_context *h, float reach) {
+  NearGrid g;
+  float ext[3], vol = 1.f;
+  for (int c = 0; c < 3; ++c) {
+    ext[c] = std::max(h->triMax[c] - h->triMin[c] + 2.02f * reach, 1e-6f);
+    vol *= ext[c];
+  }
+  // about 64^3 cells, cubic ones: per axis extent / cell, cell = (volume / 64^3)^(1/3), at least 1, at most 256
+  const float cell = std::cbrt(vol / 262144.f);
+  size_t ncells = 1;
+  for (int c = 0; c < 3; ++c) {
+    g.dim[c] = std::max(1, std::min(256, (int)std::ceil(ext[c] / std::max(cell, 1e-9f))));
+    g.org[c] = h->triMin[c] - 1.01f * reach;
+    g.inv[c] = (float)g.dim[c] / ext[c];
+    ncells *= (size_t)g.dim[c];
+  }
+  hipStream_t st = h->bstream;
+  HIP_TRY(h, h->nearGridStart.ensure(ncells + 1));
+  HIP_TRY(h, h->nearGridCount.ensure(ncells + 1));
+  HIP_TRY(h, hipMemsetAsync(h->nearGridCount.p, 0, (ncells + 1) * sizeof(uint32_t), st));
+  launch_near_grid(h->tri4.p, h->ntri, g, reach, h->nearGridCount.p, nullptr, 0, st);
+  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->nearGridCount.p, h->nearGridStart.p, (uint32_t)ncells + 1, st));
+  uint32_t total = 0;
+  HIP_TRY(h, hipMemcpyAsync(&total, h->nearGridStart.p + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  HIP_TRY(h, h->nearGridTris.ensure((size_t)total + 1));
+  HIP_TRY(h, hipMemsetAsync(h->nearGridCount.p, 0, (ncells + 1) * sizeof(uint32_t), st));
+  g.start = h->nearGridStart.p;
+  g.tris = h->nearGridTris.p;
+  launch_near_grid(h->tri4.p, h->ntri, g, reach, h->nearGridCount.p, h->nearGridTris.p, 1, st);
+  HIP_TRY(h, hipGetLastError());
+  h->nearGrid = g;
+  h->nearGridReach = reach;
+  return GVPM_OK;
+}
+
 static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   const uint32_t n = h->nph;
   h->boundsPending = false;
@@ -965,6 +1013,10 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   }
   const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
+  if (h->ntri > 64u && !(dmax <= h->nearGridReach)) {
+    const int rcg = buildNearGrid(h, dmax * 1.5f);
+    if (rcg != GVPM_OK) return rcg;
+  }
   HIP_TRY(h, h->bs->overflowCtr.ensure(2));
   HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
   // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only);
@@ -973,7 +1025,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   HIP_TRY(h, h->bs->nearExt.ensure(extWant));
   HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->bs->nearExt.p, 1, 1, h->bstream));
   launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
-                 h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
+                 h->nearGrid, h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
                  h->bs->cold.p, h->bs->overflowCtr.p, h->bstream);
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
