@@ -1086,8 +1086,12 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
 // for more resident waves, which is what hides the per-slab latency chain)
 constexpr int BSTAGE = GVPM_BSTAGE;
 constexpr int BCQ = 512;  // sphere-test survivors waiting for the prefilter (a group adds at most 4 x 64, 63 wait; power of 2)
-struct BeamTravLds {
+typedef float v2fb __attribute__((ext_vector_type(2)));
+struct alignas(16) BeamTravLds {
   float4 st0[BSTAGE], st1[BSTAGE];
+  // the centres and the filter bits once more, one array per component: the sphere test reads FOUR consecutive staged
+  // sub-beams with four ds_read_b128 issued together and tests two at a time in packed fp32 (as the G-BRE traversal)
+  float sx[BSTAGE], sy[BSTAGE], sz[BSTAGE];
   uint32_t stF[BSTAGE];
   uint2 outq[QCAP];
   float4 rayO[64], rayD[64];  // the tile's base rays {o, len} {d, -}: a candidate is resolved by ANY lane
@@ -1095,7 +1099,7 @@ struct BeamTravLds {
 };
 
 template <int B>
-__global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const uint32_t *__restrict__ hotFlags,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void traverse_beams_kernel(GatherArgs a, const uint32_t *__restrict__ hotFlags,
                                                             const uint4 *__restrict__ items,
                                                             const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
                                                             uint2 *__restrict__ pairs, uint32_t *pairCount,
@@ -1143,6 +1147,11 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
     const float mint = eps, maxt = base.len - eps;
     const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
     const int edge = (int)bi.edge;
+    // the sphere test's thresholds (an invalid beam set passes nothing) and filter words
+    const float thrD2 = beamValid ? rT * rT * 1.001f : -1.f, thrLo = mint - rT * 1.001f, thrHi = maxt + rT * 1.001f;
+    const uint32_t fmask = 0x40u | (pathSet ? (1u << GVPM_HOT_PARITY_BIT) : 0u);
+    const uint32_t fwant = 0x40u | (pathSet ? (pixParity << GVPM_HOT_PARITY_BIT) : 0u);
+    const int dmaxB = maxDepth - edge;
     uint32_t qHead = 0, qCount = 0;
     auto emit = [&](uint32_t n) {  // n <= 64 pairs of the ring -> one block of 64 in the global list
       if (resLeft == 0u) {
@@ -1238,33 +1247,50 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
             const uint32_t rStart = (uint32_t)__shfl((int)start, (int)rr, 64), rExcl = (uint32_t)__shfl((int)excl, (int)rr, 64);
             if (k < nst) {
               const uint32_t gi = rStart + (e - rExcl);
-              s.st0[k] = a.hot[2 * (size_t)gi];
+              const float4 c0 = a.hot[2 * (size_t)gi];
+              s.st0[k] = c0;
               s.st1[k] = a.hot[2 * (size_t)gi + 1];
+              s.sx[k] = c0.x;
+              s.sy[k] = c0.y;
+              s.sz[k] = c0.z;
               s.stF[k] = hotFlags[gi];
             }
           }
+          // the slots between nst and the next multiple of 16 hold centres no ray can meet
+          if (lane < 16 && nst + (uint32_t)lane < ((nst + 15u) & ~15u)) s.sx[nst + lane] = 3.0e38f;
           __syncthreads();
-          const uint32_t iters = (nst + LPB - 1) / LPB;
           constexpr uint32_t G = 4;
-          for (uint32_t jj = 0; jj < iters; jj += G) {
+          static_assert(BSTAGE % (G * LPB) == 0, "a lane reads four consecutive staged sub-beams with one b128 per component");
+          for (uint32_t jb = 0; jb < nst; jb += G * LPB) {
+            const uint32_t j0 = jb + (uint32_t)sub * G;
             uint32_t cm = 0;
-            if (beamValid) {
+            {
+              const float4 X = *reinterpret_cast<const float4 *>(&s.sx[j0]);
+              const float4 Y = *reinterpret_cast<const float4 *>(&s.sy[j0]);
+              const float4 Z = *reinterpret_cast<const float4 *>(&s.sz[j0]);
+              const uint4 Ft = *reinterpret_cast<const uint4 *>(&s.stF[j0]);
+              const v2fb ox = {base.o.x, base.o.x}, oy = {base.o.y, base.o.y}, oz = {base.o.z, base.o.z};
+              const v2fb dx = {base.d.x, base.d.x}, dy = {base.d.y, base.d.y}, dz = {base.d.z, base.d.z};
+              const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+              const uint32_t fs[4] = {Ft.x, Ft.y, Ft.z, Ft.w};
 #pragma unroll
-              for (uint32_t u = 0; u < G; ++u) {
-                const uint32_t j = (jj + u) * LPB + sub;
-                const float4 hp = s.st0[min(j, (uint32_t)BSTAGE - 1u)];
-                const f3 wv = mk3(hp.x, hp.y, hp.z) - base.o;
-                const float disk = dot(wv, base.d);
-                const f3 v = wv - base.d * disk;
-                // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment; the
-                // beam's filter bits (contribution, checkerboard parity, depth) are tested here too: they halve
-                // the pairs that reach the ownership prefilter
-                const uint32_t fl = s.stF[min(j, (uint32_t)BSTAGE - 1u)];
-                const bool flagsOk = ((fl >> 6) & 1u) != 0u && !(pathSet && ((fl >> GVPM_HOT_PARITY_BIT) & 1u) != pixParity) &&
-                                     !(maxDepth > 0 && edge + (int)GVPM_PF_DEPTH(fl) > maxDepth);
-                if (j < nst && flagsOk && dot(v, v) < rT * rT * 1.001f && disk > mint - rT * 1.001f &&
-                    disk < maxt + rT * 1.001f)
-                  cm |= 1u << u;
+              for (int h = 0; h < 2; ++h) {
+                const v2fb wx = (v2fb){xs[2 * h], xs[2 * h + 1]} - ox, wy = (v2fb){ys[2 * h], ys[2 * h + 1]} - oy,
+                           wz = (v2fb){zs[2 * h], zs[2 * h + 1]} - oz;
+                const v2fb disk = wx * dx + (wy * dy + wz * dz);
+                const v2fb vx = wx - dx * disk, vy = wy - dy * disk, vz = wz - dz * disk;
+                const v2fb d2 = vx * vx + (vy * vy + vz * vz);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const int u = 2 * h + e;
+                  // conservative: sub-beam centre within (kernel radius + half sub-beam) of the ray segment; the
+                  // beam's filter bits (contribution, checkerboard parity, depth) are tested here too: they halve
+                  // the pairs that reach the ownership prefilter
+                  uint32_t ok = (uint32_t)(d2[e] < thrD2) & (uint32_t)(disk[e] > thrLo) & (uint32_t)(disk[e] < thrHi);
+                  ok &= (uint32_t)((fs[u] & fmask) == fwant);
+                  if (maxDepth > 0) ok &= (uint32_t)((int)GVPM_PF_DEPTH(fs[u]) <= dmaxB);
+                  cm |= ok << u;
+                }
               }
             }
             // the survivors (a few per cent of the tests, scattered over the lanes) are compacted into a candidate
@@ -1277,7 +1303,7 @@ __global__ __launch_bounds__(64) void traverse_beams_kernel(GatherArgs a, const 
               const unsigned long long m = __ballot(bit);
               if (bit)
                 s.candq[(cHead + cCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BCQ] =
-                    (uint16_t)(((jj + u) * LPB + sub) | ((uint32_t)b << 8));
+                    (uint16_t)((j0 + u) | ((uint32_t)b << 8));
               cCount += (uint32_t)__popcll(m);
             }
             while (cCount >= 64u) resolve(64u);

@@ -319,11 +319,11 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
 }
 
 // ---- the occluder grid of nearVisit: triangle i is listed in every cell its bounding box, grown by `reach`, overlaps and
-// whose centre is within reach + the cell's half extent (projected on the normal) of its plane.  One thread per triangle
-// (built once per scene: a wall-sized triangle walks a few thousand cells).  mode 0 counts, mode 1 fills.
+// whose centre is within reach + the cell's half extent (projected on the normal) of its plane.  One wave per triangle,
+// the lanes striding over the cells of its box (built once per scene).  mode 0 counts, mode 1 fills.
 __global__ __launch_bounds__(64) void near_grid_kernel(const float4 *__restrict__ tri4, uint32_t ntri, NearGrid g, float reach,
                                                        uint32_t *counts, uint32_t *tris, int mode) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = blockIdx.x;
   if (i >= ntri) return;
   const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
   const f3 a = mk3(t0.x, t0.y, t0.z), e1 = mk3(t1.x, t1.y, t1.z), e2 = mk3(t2.x, t2.y, t2.z), n = mk3(t0.w, t1.w, t2.w);
@@ -339,19 +339,21 @@ __global__ __launch_bounds__(64) void near_grid_kernel(const float4 *__restrict_
   }
   const float slab = reach * 1.001f + 0.5f * 1.001f * (fabsf(n.x) * cs[0] + fabsf(n.y) * cs[1] + fabsf(n.z) * cs[2]) + 1e-6f * (cs[0] + cs[1] + cs[2]);
   const bool flat = n.x == 0.f && n.y == 0.f && n.z == 0.f;  // degenerate: no plane to cull with
-  for (int z = lo[2]; z <= hi[2]; ++z)
-    for (int y = lo[1]; y <= hi[1]; ++y)
-      for (int x = lo[0]; x <= hi[0]; ++x) {
+  const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+  if (nx <= 0 || ny <= 0 || nz <= 0) return;
+  const long long ncell = (long long)nx * ny * nz;
+  for (long long q = threadIdx.x; q < ncell; q += blockDim.x) {
+        const int x = lo[0] + (int)(q % nx), y = lo[1] + (int)((q / nx) % ny), z = lo[2] + (int)(q / ((long long)nx * ny));
         const f3 c = mk3(g.org[0] + ((float)x + 0.5f) * cs[0], g.org[1] + ((float)y + 0.5f) * cs[1], g.org[2] + ((float)z + 0.5f) * cs[2]);
         if (!flat && fabsf(dot(n, c - a)) > slab + cs[0] + cs[1] + cs[2]) continue;  // (a whole cell of slack again)
         const uint32_t cell = ((uint32_t)z * (uint32_t)g.dim[1] + (uint32_t)y) * (uint32_t)g.dim[0] + (uint32_t)x;
         if (mode == 0) atomicAdd(&counts[cell], 1u);
         else tris[g.start[cell] + atomicAdd(&counts[cell], 1u)] = i;
-      }
+  }
 }
 void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
                       hipStream_t s) {
-  if (ntri) hipLaunchKernelGGL(near_grid_kernel, dim3((ntri + 63) / 64), dim3(64), 0, s, tri4, ntri, g, reach, counts, tris, mode);
+  if (ntri) hipLaunchKernelGGL(near_grid_kernel, dim3(ntri), dim3(64), 0, s, tri4, ntri, g, reach, counts, tris, mode);
 }
 
 // ---- segment starts of a sorted key array: start[c] = first i with (key[i] >> shift) >= c ----
