@@ -189,15 +189,17 @@ __device__ __forceinline__ bool nearTriangle(f3 P, const float4 *tri4, uint32_t 
   }
   return !out;
 }
-template <class F>
+// MODE (one per instantiation of reorder_kernel, chosen at launch: the three walks inlined together cost the small
+// scenes' kernel a quarter of its speed): 0 linear scan (<= 64 occluders), 1 BVH point query, 2 occluder grid
+template <int MODE, class F>
 __device__ __forceinline__ void nearVisit(f3 P, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                                           const NearGrid &ng, F f) {
-  if (ntri <= 64u) {
+  if (MODE == 0) {
     for (uint32_t i = 0; i < ntri; ++i)
       if (nearTriangle(P, tri4, i, dmax)) f(i);
     return;
   }
-  if (ng.start) {
+  if (MODE == 2) {
     // the cell's occluder list (built for a reach >= dmax): one dependent load instead of a stack walk of the BVH,
     // which was latency-bound per lane -- 2.1 ms of a 4.4 ms step for 4 M photons among 780 occluders (C4)
     const float cx = (P.x - ng.org[0]) * ng.inv[0], cy = (P.y - ng.org[1]) * ng.inv[1], cz = (P.z - ng.org[2]) * ng.inv[2];
@@ -235,6 +237,7 @@ __device__ __forceinline__ void nearVisit(f3 P, const float4 *bvh, const float4 
     }
   }
 }
+template <int MODE>
 __device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                                               const NearGrid &ng, uint32_t *ext, uint32_t extCap, uint32_t &w0, uint32_t &w1,
                                               uint32_t &w2) {
@@ -243,7 +246,7 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const flo
   const bool narrow = ntri <= GVPM_NEAR_NARROW_MAX, wide = !narrow && ntri <= GVPM_NEAR_WIDE_MAX;
   const uint32_t cap = narrow ? 12u : (wide ? 6u : 0u);
   uint32_t cnt = 0, a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
-  nearVisit(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) {
+  nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) {
     if (cnt < cap) {
       uint32_t word, sh, m;
       if (narrow) { word = cnt >> 2; sh = 8u * (cnt & 3u); m = ~(0xFFu << sh); }
@@ -268,13 +271,14 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const flo
   }
   ext[off] = cnt;
   uint32_t k = 0;
-  nearVisit(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) { ext[off + 1u + (k++)] = i; });
+  nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) { ext[off + 1u + (k++)] = i; });
   w0 = 0xFDFFFFFFu;
   w1 = off;
 }
 
 // counting sort, pass 3: photon `src` (reads in upload order: coalesced) goes to slot cellStart[key] + rank
 // (whole 128-byte records: full-line writes)
+template <int MODE>
 __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ rank,
                                                       const uint32_t *__restrict__ cellStart, uint32_t n,
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
     stg[t][4] = ld3(r.parent_n, src, r.parent_g[src]);
     const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
     uint32_t w0, w1, w2;
-    nearOccluders(P, bvh, tri4, ntri, dmax, ng, nearExt, extCap, w0, w1, w2);
+    nearOccluders<MODE>(P, bvh, tri4, ntri, dmax, ng, nearExt, extCap, w0, w1, w2);
     if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
     stg[t][5] = ld3(r.prefix_w, src, __uint_as_float(w0));
     stg[t][6] = ld3(r.parent_scat, src, __uint_as_float(w1));
@@ -679,8 +683,13 @@ void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(reorder_kernel, dim3((n + 63) / 64), dim3(64), 0, s, r, keys, rank, cellStart, n, cfg, bvh, tri4,
-                     ntri, dmax, ng, nearExt, extCap, hot, cold, overflow);
+#define GVPM_REORDER(M) \
+  hipLaunchKernelGGL(reorder_kernel<M>, dim3((n + 63) / 64), dim3(64), 0, s, r, keys, rank, cellStart, n, cfg, bvh, tri4, ntri, \
+                     dmax, ng, nearExt, extCap, hot, cold, overflow)
+  if (ntri <= 64u) GVPM_REORDER(0);
+  else if (ng.start) GVPM_REORDER(2);
+  else GVPM_REORDER(1);
+#undef GVPM_REORDER
 }
 
 void launch_segment_start(const uint32_t *keys, uint32_t n, uint32_t nseg, uint32_t shift, uint32_t *start,
