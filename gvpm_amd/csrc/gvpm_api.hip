@@ -241,6 +241,7 @@ struct gvpm_context {
   DevBuf<uint32_t> nearGridStart, nearGridTris, nearGridCount;
   NearGrid nearGrid;
   float nearGridReach = -1.f;
+  bool useNearGrid = true;  // GVPM_NEAR_GRID=0: the BVH point query instead (kept as the cross-check of the grid)
 
   // Host uploads land in a ring of three staging slots per kind, through a copy stream of their own: the copy of
   // step N+1 (or, prefetched, N+2) then runs while the kernels of step N still read theirs.  A slot's `copied` event
@@ -483,6 +484,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (!h->pipeline && !getenv("GVPM_WAVES_PER_CU") && h->ncu) h->nwaves = std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS);
   if (const char *e = getenv("GVPM_PERSISTENT")) h->persistentEval = (atoi(e) & 1) != 0, h->persistentTrav = (atoi(e) & 2) != 0;
   if (const char *e = getenv("GVPM_TRAV_ON_BUILD")) h->travOnBuild = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_NEAR_GRID")) h->useNearGrid = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_STREAM")) h->travStream = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAM_PAIRS_INIT")) {
@@ -1013,7 +1015,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   }
   const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
-  if (h->ntri > 64u && !(dmax <= h->nearGridReach)) {
+  if (h->ntri > 64u && h->useNearGrid && !(dmax <= h->nearGridReach)) {
     const int rcg = buildNearGrid(h, dmax * 1.5f);
     if (rcg != GVPM_OK) return rcg;
   }

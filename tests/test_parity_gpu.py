@@ -344,6 +344,30 @@ def test_near_occluder_list_formats(levels, seps):
     assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
 
 
+def test_near_occluder_grid_finds_what_the_bvh_query_finds(monkeypatch):
+    """Above 64 occluders the near-occluder lists come from the occluder grid (grid_build.hip: near_grid_kernel);
+    GVPM_NEAR_GRID=0 keeps the BVH point query they came from before.  Same lists => the same shadow-ray outcomes: every
+    counter equal and the accumulators equal up to the order of the float atomics."""
+    c = cases.make_case("cbox", 32, 28, 20000, 3.0, shadow_epsilon=0.01)
+    fine = cases.tessellate(c.tris, 3)  # 896 occluders: 16-bit lists
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GVPM_NEAR_GRID", flag)
+        ctx = hip.Context(c.p, device=0)
+        ctx.upload_scene(*fine)
+        ctx.upload_medium(c.m)
+        ctx.upload_photons(c.ph)
+        ctx.upload_camera_beams(c.rays)
+        ctx.gather(1, c.nb)
+        out.append((ctx.download_accum(), ctx.stats()))
+        ctx.close()
+    (a1, s1), (a0, s0) = out
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert s1[k] == s0[k], (k, s1, s0)
+    assert s1["failed_shifts"] > 0
+    np.testing.assert_allclose(a1, a0, rtol=5e-5, atol=1e-6 * float(np.abs(a0).max()))
+
+
 def test_row_sharded_film_and_moving_shards():
     """A handle only clears / folds the film rows it has touched since the last reset (image-sharded ranks own
     a fraction of the frame): two shard handles must add up to the full-frame result, and a handle whose beam
