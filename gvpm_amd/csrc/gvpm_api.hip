@@ -1217,7 +1217,9 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   if (getenv("GVPM_TRACE_PLAN")) {
     uint32_t q[4] = {0, 0, 0, 0};
     (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[plan] items %u staged blocks %u tiles %u sets %u\n", q[0], blocks, h->bs->ntiles, h->nsets);
+    fprintf(stderr, "[plan] items %u staged blocks %u tiles %u sets %u; photons %u, grid %d x %d x %d cells of %g (radius %g)\n", q[0],
+            blocks, h->bs->ntiles, h->nsets, h->nph, h->bs->grid.dim[0], h->bs->grid.dim[1], h->bs->grid.dim[2],
+            (double)h->bs->grid.cell, (double)r);
   }
   if (rebuilt) {
     h->nearOverflow = h->cfg.visibility_as_written && h->pinCtl[1] != 0;

@@ -14,6 +14,13 @@ for e in $ENVS; do
   run single_$e GVPM_PIPELINE=0 $e
   run pipe_$e $e
 done
+IFS=';' read -ra CB <<< "$COMBOS"
+for c in "${CB[@]}"; do
+  [ -z "$c" ] && continue
+  n=$(echo $c | tr ' =' '__')
+  run pipe_$n $c
+  run single_$n GVPM_PIPELINE=0 $c
+done
 for v in $VARIANTS; do
   run $v GVPM_HIP_LIB=$PWD/build/variants/libgvpm_hip_$v.so
   run ${v}_single GVPM_HIP_LIB=$PWD/build/variants/libgvpm_hip_$v.so GVPM_PIPELINE=0
