@@ -17,7 +17,7 @@ done
 IFS=';' read -ra CB <<< "$COMBOS"
 for c in "${CB[@]}"; do
   [ -z "$c" ] && continue
-  n=$(echo $c | tr ' =' '__')
+  n=$(echo $c | sed 's#[^ ]*libgvpm_hip_##g' | tr ' =/' '___')
   run pipe_$n $c
   run single_$n GVPM_PIPELINE=0 $c
 done
