@@ -1662,23 +1662,19 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(const float *__restric
 // sorted sub-beam records for the traversal: {centre, beam | sub << 24} {beam direction, sub-beam length} and the
 // beam's filter bits (cold word 7.w: contribution, parity, depth).  The length is the evaluation's (fp64 norm
 // rounded to float), so that sub-beam ranges agree.
-__global__ __launch_bounds__(256) void sub_hot_kernel(const float *__restrict__ centres, const uint32_t *__restrict__ ids,
-                                                      const uint32_t *__restrict__ order, uint32_t n,
-                                                      const float4 *__restrict__ cold, uint32_t nbeams,
-                                                      const uint32_t *__restrict__ counts, float4 *hot, uint32_t *hotFlags) {
+__global__ __launch_bounds__(256) void sub_hot_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ order,
+                                                      uint32_t n, const float4 *__restrict__ aux, float4 *hot,
+                                                      uint32_t *hotFlags) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const uint32_t src = order[j];
-  const uint32_t id = ids[src], beam = id & 0xFFFFFFu;
-  const float4 c2 = cold[(size_t)beam * GVPM_REC_QUADS + 1], c7 = cold[(size_t)beam * GVPM_REC_QUADS + 6];
-  const double dx = (double)c7.x - (double)c2.x, dy = (double)c7.y - (double)c2.y, dz = (double)c7.z - (double)c2.z;
-  const double lenD = sqrt(dx * dx + dy * dy + dz * dz);
-  const double inv = 1.0 / lenD;
-  const float ls = (float)lenD / (float)counts[beam];
-  hot[2 * (size_t)j] = make_float4(centres[3 * (size_t)src], centres[3 * (size_t)src + 1], centres[3 * (size_t)src + 2],
-                                   __uint_as_float(id));
-  hot[2 * (size_t)j + 1] = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), ls);
-  hotFlags[j] = __float_as_uint(c7.w);
+  const uint32_t id = ids[order[j]], beam = id & 0xFFFFFFu, sub = id >> 24;
+  // {p1, bits} {direction, sub-beam length} of the beam (beam_cold_kernel): one 32-byte gather; the centre is computed,
+  // not gathered (to a few ulp the one beam_expand_kernel binned: every test downstream carries a margin)
+  const float4 a0 = aux[2 * (size_t)beam], a1 = aux[2 * (size_t)beam + 1];
+  const float t = a1.w * ((float)sub + 0.5f);
+  hot[2 * (size_t)j] = make_float4(a0.x + a1.x * t, a0.y + a1.y * t, a0.z + a1.z * t, __uint_as_float(id));
+  hot[2 * (size_t)j + 1] = a1;
+  hotFlags[j] = __float_as_uint(a0.w);
 }
 
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
@@ -1689,10 +1685,9 @@ void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint
                         float *centres, uint32_t *ids, hipStream_t s) {
   hipLaunchKernelGGL(beam_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, counts, offsets, centres, ids);
 }
-void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *cold,
-                    uint32_t nbeams, const uint32_t *counts, float4 *hot, uint32_t *hotFlags, hipStream_t s) {
-  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, centres, ids, order, n, cold, nbeams, counts,
-                     hot, hotFlags);
+void launch_sub_hot(const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *aux, float4 *hot,
+                    uint32_t *hotFlags, hipStream_t s) {
+  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, order, n, aux, hot, hotFlags);
 }
 
 }  // namespace gvpm

@@ -526,7 +526,8 @@ hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uin
 //   0 {flux, parentPdf} 1 {p1, parentRR} 2 {parentN, parentG} 3 {prefixW, near0} 4 {parentScat, near1}
 //   5 {parentWi, near2} 6 {p2, bits} 7 {endN, length}   (near0..2: beam_near_kernel)
 __global__ __launch_bounds__(256) void beam_cold_kernel(RawPhotons r, const float *__restrict__ endN, uint32_t n,
-                                                        gvpm_params cfg, float4 *cold) {
+                                                        gvpm_params cfg, const uint32_t *__restrict__ subCounts, float4 *cold,
+                                                        float4 *aux) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t bits = r.flags[i] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
@@ -549,7 +550,15 @@ __global__ __launch_bounds__(256) void beam_cold_kernel(RawPhotons r, const floa
   const double dx = (double)r.pos[3 * (size_t)i] - (double)r.parent_pos[3 * (size_t)i];
   const double dy = (double)r.pos[3 * (size_t)i + 1] - (double)r.parent_pos[3 * (size_t)i + 1];
   const double dz = (double)r.pos[3 * (size_t)i + 2] - (double)r.parent_pos[3 * (size_t)i + 2];
-  rec[7] = ld3(endN, i, (float)sqrt(dx * dx + dy * dy + dz * dz));
+  const double lenD = sqrt(dx * dx + dy * dy + dz * dz);
+  rec[7] = ld3(endN, i, (float)lenD);
+  // what the sorted sub-beam records are made of (sub_hot_kernel), 32 bytes per beam: {p1, bits} {direction, sub-beam
+  // length} -- the fp64 norm and division once per beam instead of once per sub-beam (47 M of them at C3)
+  if (aux) {
+    const double inv = 1.0 / lenD;
+    aux[2 * (size_t)i] = ld3(r.parent_pos, i, __uint_as_float(bits));
+    aux[2 * (size_t)i + 1] = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), (float)lenD / (float)subCounts[i]);
+  }
 }
 
 // ---- occluders near a photon beam -----------------------------------------------------------------------------
@@ -642,12 +651,12 @@ void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntr
   if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, tri4, ntri, r, extentBits);
 }
 
-void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg, float4 *cold,
-                      hipStream_t s) {
+void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg,
+                      const uint32_t *subCounts, float4 *cold, float4 *aux, hipStream_t s) {
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(beam_cold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, endN, n, cfg, cold);
+  hipLaunchKernelGGL(beam_cold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, endN, n, cfg, subCounts, cold, aux);
 }
 
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,

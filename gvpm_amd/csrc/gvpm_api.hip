@@ -77,14 +77,14 @@ hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uin
 void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s);
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
                       hipStream_t s);
-void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg, float4 *cold,
-                      hipStream_t s);
+void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg,
+                      const uint32_t *subCounts, float4 *cold, float4 *aux, hipStream_t s);
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
                           hipStream_t s);
 void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint32_t *counts, const uint32_t *offsets,
                         float *centres, uint32_t *ids, hipStream_t s);
-void launch_sub_hot(const float *centres, const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *cold,
-                    uint32_t nbeams, const uint32_t *counts, float4 *hot, uint32_t *hotFlags, hipStream_t s);
+void launch_sub_hot(const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *aux, float4 *hot,
+                    uint32_t *hotFlags, hipStream_t s);
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
                            const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
                            uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream);
@@ -284,6 +284,7 @@ struct gvpm_context {
   const float *endNDev = nullptr;
   bool haveBeamsMap = false;
   DevBuf<uint32_t> subCounts, subOffsets, subIds, beamCtl;
+  DevBuf<float4> beamAux;  // G-Beams: {p1, bits} {direction, sub-beam length} per beam, what sub_hot_kernel gathers
   uint32_t nsub = 0;
   float subLen = 0.f, maxSubLen = 0.f;
 
@@ -537,7 +538,8 @@ int gvpm_destroy(gvpm_context *h) {
   }
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
-  h->subIds.release(); h->beamCtl.release();
+  h->subIds.release(); h->beamCtl.release(); h->beamAux.release();
+  h->nearGridStart.release(); h->nearGridTris.release(); h->nearGridCount.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release(); h->shiftExtent.release();
   h->blockKeyA.release(); h->blockKeyB.release(); h->blockValA.release(); h->blockValB.release();
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
@@ -1360,9 +1362,9 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   launch_cell_keys(h->subCentres.p, h->nsub, g, h->bs->keysA.p, h->bs->valsA.p, h->stream);
   HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, h->nsub,
                           ilog2ceil(g.ncells + 1), h->stream));
-  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->bs->cold.p, h->stream);
-  launch_sub_hot(h->subCentres.p, h->subIds.p, h->bs->valsB.p, h->nsub, h->bs->cold.p, n, h->subCounts.p, h->bs->hot.p,
-                 h->subFlags.p, h->stream);
+  HIP_TRY(h, h->beamAux.ensure(2 * (size_t)n + 2));
+  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->subCounts.p, h->bs->cold.p, h->beamAux.p, h->stream);
+  launch_sub_hot(h->subIds.p, h->bs->valsB.p, h->nsub, h->beamAux.p, h->bs->hot.p, h->subFlags.p, h->stream);
   launch_segment_start(h->bs->keysB.p, h->nsub, g.ncells, 0, h->bs->cellStart.p, h->stream);
   {
     const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
