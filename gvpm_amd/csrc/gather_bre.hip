@@ -460,14 +460,9 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
     if (dhi < dlo) dlo = dhi = 256;  // nothing passes
     const uint32_t dspan = (uint32_t)(dhi - dlo);
     // thresholds of the conservative test.  The fp32 error of disk is below 6e-7 (|wv|_1 + |disk|) (hitBand) with
-    // wv = photon - origin and |disk| <= |wv|_1; every photon lies in the grid's box, whose farther faces bound |wv|_1
-    float wv1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float ok_ = k == 0 ? base.o.x : (k == 1 ? base.o.y : base.o.z);
-      const float glo = a.grid.org[k] - a.grid.cell, ghi = a.grid.org[k] + (float)(a.grid.dim[k] + 1) * a.grid.cell;
-      wv1 += fmaxf(fabsf(ok_ - glo), fabsf(ok_ - ghi));
-    }
+    // wv = photon - origin and |disk| <= |wv|_1.  Only pairs the reference accepts must pass, and for those the photon
+    // lies within 3 r of the beam's segment: |wv|_1 <= sqrt(3) (len + 3 r), whatever the grid or the other photons are
+    const float wv1 = 1.7321f * (fmaxf(base.len, 0.f) + 3.f * r);
     const float Emax = 1.25e-6f * wv1;
     const float thrD2 = beamValid ? r2f + (4.f * r * Emax + r2f * 2e-6f) : -1.f;
     const float thrLo = mint - Emax, thrHi = maxt + 2.f * r;
