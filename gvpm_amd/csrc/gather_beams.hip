@@ -1148,7 +1148,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
     const uint32_t pixParity = ((bi.pix & 0xFFFFu) + (bi.pix >> 16)) & 1u;
     const int edge = (int)bi.edge;
     // the sphere test's thresholds (an invalid beam set passes nothing) and filter words
-    const float thrD2 = beamValid ? rT * rT * 1.001f : -1.f, thrLo = mint - rT * 1.001f, thrHi = maxt + rT * 1.001f;
+    // (plus the fp32 error of the test itself, bounded as in the G-BRE traversal by the beam's own length: a centre that
+    // passes the exact test lies within rT of the segment)
+    const float eT = 1.25e-6f * 1.7321f * (fmaxf(base.len, 0.f) + 3.f * rT);
+    const float thrD2 = beamValid ? rT * rT * 1.001f + 4.f * rT * eT : -1.f, thrLo = mint - rT * 1.001f - eT,
+                thrHi = maxt + rT * 1.001f + eT;
     const uint32_t fmask = 0x40u | (pathSet ? (1u << GVPM_HOT_PARITY_BIT) : 0u);
     const uint32_t fwant = 0x40u | (pathSet ? (pixParity << GVPM_HOT_PARITY_BIT) : 0u);
     const int dmaxB = maxDepth - edge;
