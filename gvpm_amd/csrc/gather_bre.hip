@@ -902,13 +902,23 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             k2o = (bo << 2) | io;
           }
         };
-        bool haveE;
-        uint32_t k2E, pidxE, bE, iE;
+        bool haveE = false, haveF = false;
+        uint32_t k2E = 0, pidxE = 0, bE = 0, iE = 0, k2F = 0, pidxF = 0, bF = 0, iF = 0;
         entry(0u, haveE, k2E, pidxE, bE, iE);
+        if (PF) entry(1u, haveF, k2F, pidxF, bF, iF);
         for (uint32_t j = 0; j <= cq; ++j) {
           const bool have = haveE;
           const uint32_t k2 = k2E, pidx = pidxE, b = bE, i = iE;
-          entry(j + 1u, haveE, k2E, pidxE, bE, iE);
+          [[maybe_unused]] float warm = 0.f;
+          if (PF) {
+            // the index of entry j + 2 in flight, and one word of the record of entry j + 1 touched: the line (the whole
+            // 128-byte record) is on its way from HBM while entry j computes
+            haveE = haveF; k2E = k2F; pidxE = pidxF; bE = bF; iE = iF;
+            warm = reinterpret_cast<const float *>(a.cold + (size_t)pidxE * GVPM_REC_QUADS)[0];
+            entry(j + 2u, haveF, k2F, pidxF, bF, iF);
+          } else {
+            entry(j + 1u, haveE, k2E, pidxE, bE, iE);
+          }
           if (k2 != key && key != 0xFFFFFFFFu) {
             // the run of one (beam, shift) ended: its 6 sums go to the LDS accumulators
             const uint32_t kb = key >> 2, ki = key & 3u;
@@ -927,6 +937,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             rs = rs + sf;
             rw = rw + wb;
           }
+          if (PF) asm volatile("" ::"v"(warm));
         }
         waveLdsSync();
         { [[maybe_unused]] const unsigned long long tn = TICK(); tk[3] += tn - tMark; tMark = tn; }
