@@ -329,7 +329,7 @@ struct gvpm_context {
   size_t eventsUsed[GVPM_PHASES] = {0, 0, 0};
 
   int beamsPerWave = 16;
-  float cellScale = 1.0f;
+  float cellScale = 0.f;  // GVPM_CELL_SCALE; 0: the technique's default (buildGrid)
   uint32_t planTarget = 1024;  // staged photons per work item
   uint32_t nwaves = 2048;      // persistent gather waves
   uint32_t ncu = 256;
@@ -973,7 +973,12 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
     ext = fmaxf(ext, b6[3 + c] - b6[c]);
   }
   Grid g;
-  float cell = fmaxf(h->cellScale * r, ext / 384.f);
+  // cell edge in radii.  G-BRE with maps up to 2 M photons: 1.5 -- the cell arrays (memset, scan, summed-volume table:
+  // ~135 of the build's 575 us at C2 with cells of one radius) shrink 3.4x, and there the build is the stage the
+  // pipelined step waits for; the traversal tests 1.3x the photons per hit.  Measured at C2: 1.51 -> 1.43-1.445 ms per
+  // step.  At C4 (4 M photons) the evaluation is the long stage and the larger cells cost the traversal 1 % of the step.
+  const float cellScale = h->cellScale > 0.f ? h->cellScale : (deferred && n <= 2000000u ? 1.5f : 1.0f);
+  float cell = fmaxf(cellScale * r, ext / 384.f);
   if (!(cell > 0.f)) cell = 1.f;
   g.cell = cell;
   g.invCell = 1.f / cell;
@@ -1319,7 +1324,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   Grid g;
   // sub-beams (and cells) of 3/4 of the kernel radius: the traversal cost follows the number of sphere tests, which
   // shrinks with the cell until the ext/256 floor (measured: 34 ms at 1.5 r, 23.5 ms at 0.75 r and below)
-  float cell = fmaxf(0.75f * h->cellScale * r, ext / 256.f);
+  float cell = fmaxf(0.75f * (h->cellScale > 0.f ? h->cellScale : 1.0f) * r, ext / 256.f);
   if (!(cell > 0.f)) cell = 1.f;
   g.cell = cell;
   g.invCell = 1.f / cell;
