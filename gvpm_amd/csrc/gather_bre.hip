@@ -515,13 +515,8 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
           {
             const uint32_t lo_i = max(excl, win), hi_i = min(excl + count, win + STAGE);
             uint32_t i = lo_i;
-            // four independent 16-byte loads in flight per lane before the LDS writes
-            for (; i + 4 <= hi_i; i += 4) {
-              const uint32_t gi = start + (i - excl);
-              const float4 v0 = a.hot[gi], v1 = a.hot[gi + 1], v2 = a.hot[gi + 2], v3 = a.hot[gi + 3];
-              putStage(i - win, v0, gi); putStage(i - win + 1, v1, gi + 1);
-              putStage(i - win + 2, v2, gi + 2); putStage(i - win + 3, v3, gi + 3);
-            }
+            // (one record per lane and trip: four loads in flight per lane, as this loop had them, cost 44 VGPRs -- a
+            // wave per SIMD -- and the kernel a fifth of its speed)
             for (; i < hi_i; ++i) {
               const uint32_t gi = start + (i - excl);
               putStage(i - win, a.hot[gi], gi);

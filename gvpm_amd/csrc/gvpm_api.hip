@@ -947,7 +947,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
     HIP_TRY(h, hipMemsetAsync(h->bs->cellStart.p, 0, 2 * sizeof(uint32_t), h->bstream));
     return GVPM_OK;
   }
-  const int nblocks = 256;
+  const int nblocks = 1024;
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
   HIP_TRY(h, h->bs->bounds6.ensure(8));
   float b6[6];
