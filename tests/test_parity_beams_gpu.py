@@ -92,3 +92,29 @@ def test_beams_pair_list_regrows(monkeypatch):
     c = make_beam_case("cbox", 32, 28, 12000, 2.5)
     acc, ref, st = device_beams(c, iters=2)
     assert st["evaluations"] > 20000
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg"])
+def test_literal_fp64_path_has_the_oracles_hit_set_exactly(tech, scene, monkeypatch):
+    """What separates "float intermediates" from "an ownership bug" in the looser bar of the tests above: the device's
+    literal transcription (GVPM_BEAMS_FP64=1: the reference's statements with its float intermediates, the same
+    traversal, sub-beam ownership, pair lists and tile order as the fast path) must reproduce the oracle's counters
+    EXACTLY -- evaluations, null shifts, reconnections, failures -- and its sums to fp32 accumulation noise.  The fast
+    path differs from it only by its fp32 local-frame arithmetic (ownership decided in fp64 inside the error band)."""
+    c = make_beam_case(scene, 32, 28, 12000, 2.5, technique=tech)
+    monkeypatch.setenv("GVPM_BEAMS_FP64", "1")
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    rad = ctx.radius()
+    ctx.upload_beams(c.beams, c.end_n)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(1, c.nb)
+    st, acc = ctx.stats(), ctx.download_accum()
+    ctx.close()
+    ref, cnt, _ = O.gather_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, rad, 1, c.nb, 64)
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert st[k] == cnt[k], (k, st, cnt)
+    assert cnt["evaluations"] > 20000
+    assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 2e-5
