@@ -646,6 +646,23 @@ void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *
   if (nsets) hipLaunchKernelGGL(shift_extent_kernel, dim3((nsets + 255) / 256), dim3(256), 0, s, rays, nsets, extentBits);
 }
 
+// GVPM_BEAMS_TRACE: how long the beams' near-occluder lists are -- hist[k] = lists of k entries (k <= 12), hist[13] = overflowed
+__global__ __launch_bounds__(256) void beam_near_hist_kernel(const float4 *__restrict__ cold, uint32_t n, uint32_t *hist) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t N = GVPM_REC_QUADS;
+  const uint32_t w[3] = {__float_as_uint(cold[N * i + 3].w), __float_as_uint(cold[N * i + 4].w), __float_as_uint(cold[N * i + 5].w)};
+  uint32_t k = 13;
+  if ((w[0] >> 24) != 0xFEu) {
+    k = 0;
+    for (int q = 0; q < 12; ++q)
+      if (((w[q >> 2] >> (8 * (q & 3))) & 0xFFu) != 0xFFu) k++;
+  }
+  atomicAdd(&hist[k], 1u);
+}
+void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t *hist, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(beam_near_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, hist);
+}
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
                       hipStream_t s) {
   if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, tri4, ntri, r, extentBits);
