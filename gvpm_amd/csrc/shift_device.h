@@ -104,7 +104,13 @@ __device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uin
     if (i == 0xFFu) break;
     l = k == 3 ? nl1 : (k == 7 ? nl2 : (l >> 8) | 0xFF000000u);
     const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
-    if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+    // both ends of the segment strictly on one side of the triangle's plane (the stored unit normal; zero for a
+    // degenerate triangle, which then goes to the full test): nothing to intersect -- a quarter of the work of the test
+    // it spares, and at C3 a third of a beam's listed occluders (ceiling and floor under and above a vertical beam)
+    const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
+    const float s0 = dot(nrm, o - v0), sd = dot(nrm, d);
+    if ((s0 + sd * mint) * (s0 + sd * maxt) > 1e-12f) continue;
+    if (triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
   }
   return hit;
 }
