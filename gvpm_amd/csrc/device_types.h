@@ -39,6 +39,35 @@ struct NearGrid {
   int dim[3] = {0, 0, 0};
 };
 
+// A beam's near-occluder list in the three spare words of its record (beam_near_kernel / beamShadowBlocked): a string of
+// 96 bits cut into entries of `bits`, all ones = empty.  Small scenes get narrow indices and hence longer lists -- at C3
+// (22 occluders) one beam in forty listed more than twelve and, tested against everything, kept its whole wave in a
+// 22-trip loop in four drains of five.
+//   occluders <= 31:  19 entries of 5 bits, overflow = bit 95
+//   occluders <= 63:  15 entries of 6 bits, overflow = bit 95
+//   otherwise:        12 entries of 8 bits, overflow = top byte of word 0 is 0xFE  (<= 253 occluders; beyond: all overflow)
+#ifdef __HIPCC__
+#define GVPM_DT_HD __host__ __device__
+#else
+#define GVPM_DT_HD
+#endif
+struct BeamNearFmt {
+  uint32_t bits, cap, mask;
+};
+GVPM_DT_HD inline BeamNearFmt beamNearFmt(uint32_t ntri) {
+  return ntri <= 31u ? BeamNearFmt{5u, 19u, 31u} : (ntri <= 63u ? BeamNearFmt{6u, 15u, 63u} : BeamNearFmt{8u, 12u, 255u});
+}
+GVPM_DT_HD inline bool beamNearOverflow(const BeamNearFmt &f, uint32_t w0, uint32_t w2) {
+  return f.bits == 8u ? (w0 >> 24) == 0xFEu : (w2 >> 31) != 0u;
+}
+// entry k of the list (k < cap)
+GVPM_DT_HD inline uint32_t beamNearEntry(const BeamNearFmt &f, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t k) {
+  const uint32_t off = k * f.bits, word = off >> 5, sh = off & 31u;
+  const uint32_t lo = word == 0u ? w0 : (word == 1u ? w1 : w2), hi = word == 0u ? w1 : (word == 1u ? w2 : 0u);
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  return (uint32_t)(v >> sh) & f.mask;
+}
+
 struct SortTemp {
   void *d = nullptr;
   size_t bytes = 0;

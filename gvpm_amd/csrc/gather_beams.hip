@@ -640,18 +640,18 @@ __device__ __forceinline__ bool anyHitLds(const float4 *tri, uint32_t ntri, f3 o
 // visibility over the whole new beam [Epsilon, dist] (shift_volume_beams.cpp:420-426): the occluders listed near the
 // beam (beam_near_kernel, grid_build.hip), or all of them when the list overflowed / the scene is large
 __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const BeamF &b, const float4 *ldsTri, f3 nd, float dist) {
-  const bool ovf = (b.nl0 >> 24) == 0xFEu;
+  const BeamNearFmt fmt = beamNearFmt(a.ntri);  // (wave-uniform)
+  const bool ovf = beamNearOverflow(fmt, b.nl0, b.nl2);
   if (!ldsTri) {
+    // (more than SCENE_LDS_TRIS occluders: the 8-bit format, read from global memory, or every list overflowed)
     if (ovf) return anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist);
     return nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist);
   }
   // occluders in LDS: ONE loop for the lanes that walk their beam's list and the lanes whose list overflowed (every
-  // occluder: 2.5 % of the beams at C3, but four drains in five hold one).  A loop for each, one after the other, cost
-  // the wave 12 + ntri trips; this one costs max(12, ntri).
+  // occluder).  A loop for each, one after the other, cost the wave cap + ntri trips; this one costs max(cap, ntri).
   const f3 o = b.p1;
   const float mint = a.cfg.epsilon, maxt = dist;
   bool hit = false;
-  uint32_t l = b.nl0, w1 = b.nl1, w2 = b.nl2;
   bool more = true;
 #pragma unroll 1
   for (uint32_t k = 0;; ++k) {
@@ -660,9 +660,8 @@ __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const Bea
       i = k;
       more = k < a.ntri;
     } else {
-      i = l & 0xFFu;
-      more = more && i != 0xFFu && k < 12u;
-      l = k == 3u ? w1 : (k == 7u ? w2 : (l >> 8) | 0xFF000000u);
+      i = k < fmt.cap ? beamNearEntry(fmt, b.nl0, b.nl1, b.nl2, k) : fmt.mask;
+      more = more && i != fmt.mask;
     }
     if (__ballot(more) == 0ull) break;
     if (more) {

@@ -598,6 +598,8 @@ __global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n
   if (i >= n) return;
   const size_t N = GVPM_REC_QUADS;
   uint32_t w[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  const BeamNearFmt fmt = beamNearFmt(ntri);
+  if (fmt.bits != 8u) w[2] &= 0x7FFFFFFFu;  // (bit 95: the narrow formats' overflow flag)
   if (ntri > GVPM_NEAR_NARROW_MAX) {
     w[0] = 0xFE000000u | 0x00FFFFFFu;
   } else {
@@ -626,15 +628,20 @@ __global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n
       }
       hit = hit && t0s <= t1s;
       if (hit) {
-        if (cnt < 12u) {
-          const uint32_t wi = cnt >> 2, sh = (cnt & 3u) * 8u;
-          w[wi] = (w[wi] & ~(0xFFu << sh)) | (t << sh);
+        if (cnt < fmt.cap) {
+          // entry cnt: fmt.bits bits at bit cnt * fmt.bits of the 96-bit string (it may straddle two words)
+          const uint32_t off = cnt * fmt.bits, wi = off >> 5, sh = off & 31u;
+          w[wi] = (w[wi] & ~(fmt.mask << sh)) | (t << sh);
+          if (sh + fmt.bits > 32u) w[wi + 1] = (w[wi + 1] & ~(fmt.mask >> (32u - sh))) | (t >> (32u - sh));
         }
         cnt++;
       }
     }
     // (index 0xFE / 0xFF cannot occur in the top byte of word 0: ntri <= 253)
-    if (cnt > 12u) w[0] = 0xFE000000u | 0x00FFFFFFu;
+    if (cnt > fmt.cap) {
+      if (fmt.bits == 8u) w[0] = 0xFE000000u | 0x00FFFFFFu;
+      else w[2] |= 0x80000000u;
+    }
   }
   cold[N * i + 3].w = __uint_as_float(w[0]);
   cold[N * i + 4].w = __uint_as_float(w[1]);
@@ -646,22 +653,23 @@ void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *
   if (nsets) hipLaunchKernelGGL(shift_extent_kernel, dim3((nsets + 255) / 256), dim3(256), 0, s, rays, nsets, extentBits);
 }
 
-// GVPM_BEAMS_TRACE: how long the beams' near-occluder lists are -- hist[k] = lists of k entries (k <= 12), hist[13] = overflowed
-__global__ __launch_bounds__(256) void beam_near_hist_kernel(const float4 *__restrict__ cold, uint32_t n, uint32_t *hist) {
+// GVPM_BEAMS_TRACE: how long the beams' near-occluder lists are -- hist[k] = lists of k entries (k <= 19), hist[20] = overflowed
+__global__ __launch_bounds__(256) void beam_near_hist_kernel(const float4 *__restrict__ cold, uint32_t n, uint32_t ntri, uint32_t *hist) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t N = GVPM_REC_QUADS;
   const uint32_t w[3] = {__float_as_uint(cold[N * i + 3].w), __float_as_uint(cold[N * i + 4].w), __float_as_uint(cold[N * i + 5].w)};
-  uint32_t k = 13;
-  if ((w[0] >> 24) != 0xFEu) {
+  const BeamNearFmt fmt = beamNearFmt(ntri);
+  uint32_t k = 20;
+  if (!beamNearOverflow(fmt, w[0], w[2])) {
     k = 0;
-    for (int q = 0; q < 12; ++q)
-      if (((w[q >> 2] >> (8 * (q & 3))) & 0xFFu) != 0xFFu) k++;
+    for (uint32_t q = 0; q < fmt.cap; ++q)
+      if (beamNearEntry(fmt, w[0], w[1], w[2], q) != fmt.mask) k++;
   }
   atomicAdd(&hist[k], 1u);
 }
-void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t *hist, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(beam_near_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, hist);
+void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t ntri, uint32_t *hist, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(beam_near_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, ntri, hist);
 }
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
                       hipStream_t s) {

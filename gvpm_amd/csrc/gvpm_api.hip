@@ -77,7 +77,7 @@ hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uin
 void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s);
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
                       hipStream_t s);
-void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t *hist, hipStream_t s);
+void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t ntri, uint32_t *hist, hipStream_t s);
 void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg,
                       const uint32_t *subCounts, float4 *cold, float4 *aux, hipStream_t s);
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
@@ -1414,17 +1414,17 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     launch_beam_near(h->bs->cold.p, h->nph, h->tri4.p, h->ntri, r, h->shiftExtent.p, h->stream);
     if (getenv("GVPM_BEAMS_TRACE")) {
       DevBuf<uint32_t> hist;
-      uint32_t hh[14] = {0}, ext = 0;
-      if (hist.ensure(16) == hipSuccess && hipMemsetAsync(hist.p, 0, 64, h->stream) == hipSuccess) {
-        launch_beam_near_hist(h->bs->cold.p, h->nph, hist.p, h->stream);
+      uint32_t hh[21] = {0}, ext = 0;
+      if (hist.ensure(24) == hipSuccess && hipMemsetAsync(hist.p, 0, 96, h->stream) == hipSuccess) {
+        launch_beam_near_hist(h->bs->cold.p, h->nph, h->ntri, hist.p, h->stream);
         (void)hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream);
         (void)hipMemcpyAsync(&ext, h->shiftExtent.p, 4, hipMemcpyDeviceToHost, h->stream);
         (void)hipStreamSynchronize(h->stream);
         float extf;
         memcpy(&extf, &ext, 4);
-        fprintf(stderr, "[beams] near lists (delta = 4 x %g + %g, %u occluders): lengths 0..12:", (double)r, (double)extf, h->ntri);
-        for (int k = 0; k <= 12; ++k) fprintf(stderr, " %u", hh[k]);
-        fprintf(stderr, "; overflowed %u\n", hh[13]);
+        fprintf(stderr, "[beams] near lists (delta = 4 x %g + %g, %u occluders): lengths 0..19:", (double)r, (double)extf, h->ntri);
+        for (int k = 0; k <= 19; ++k) fprintf(stderr, " %u", hh[k]);
+        fprintf(stderr, "; overflowed %u\n", hh[20]);
       }
       hist.release();
     }
