@@ -14,4 +14,5 @@ trap restore EXIT
 cp $T/liboracle.so oracle/liboracle.so; cp $T/libgvpm_host.so gvpm_amd/host/libgvpm_host.so
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
   python -m pytest tests/test_oracle.py tests/test_oracle_beams.py tests/test_oracle_planes.py tests/test_oracle_vpm.py \
-  tests/test_host.py -x -q -m "not gpu"
+  tests/test_host.py tests/test_camera_paths.py tests/test_oracle_pins.py tests/test_indep_statements.py \
+  tests/test_indep_lightpaths.py -x -q -m "not gpu"
