@@ -118,3 +118,28 @@ def test_literal_fp64_path_has_the_oracles_hit_set_exactly(tech, scene, monkeypa
         assert st[k] == cnt[k], (k, st, cnt)
     assert cnt["evaluations"] > 20000
     assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 2e-5
+
+
+@pytest.mark.parametrize("levels", [0, 1, 2, 3])
+def test_beam_near_list_formats(levels):
+    """The per-beam near-occluder lists by scene size (device_types.h: BeamNearFmt): 14 occluders -> 19 x 5 bits, 56 ->
+    15 x 6 bits, 224 -> 12 x 8 bits read from global memory (more than the 128 LDS holds), 896 -> every list overflowed,
+    visibility through the occluder BVH.  The same surface in every case: the oracle, which tests every triangle of the
+    untessellated scene, must be met at the usual bar, and the shift counters must not move with the tessellation."""
+    c = make_beam_case("cbox", 24, 20, 6000, 3.0)
+    fine = cases.tessellate(c.tris, levels) if levels else c.tris
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*fine)
+    ctx.upload_medium(c.m)
+    rad = ctx.radius()
+    ctx.upload_beams(c.beams, c.end_n)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(1, c.nb)
+    st, acc = ctx.stats(), ctx.download_accum()
+    ctx.close()
+    ref, cnt, _ = O.gather_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, rad, 1, c.nb, 64)
+    assert abs(st["evaluations"] - cnt["evaluations"]) <= max(2, 2e-4 * cnt["evaluations"])
+    for k in ("diffuse_shifts", "failed_shifts"):
+        assert abs(st[k] - cnt[k]) <= max(4, 1e-3 * cnt["diffuse_shifts"]), (k, st, cnt)
+    assert cnt["failed_shifts"] > 0
+    assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
