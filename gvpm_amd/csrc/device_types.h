@@ -96,6 +96,7 @@ struct GatherArgs {
   const float4 *bvh;         // 2 float4 per node (scene_bvh.h)
   const uint32_t *nearExt;   // extension lists of the per-photon near-occluder lists {count, index...}
   uint32_t ntri;
+  float triAbs1;             // sum over the axes of the largest |coordinate| of an occluder vertex (planeSideMargin)
   MediumDev med;
   // config
   gvpm_params cfg;

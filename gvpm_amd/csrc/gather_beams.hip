@@ -588,11 +588,34 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
   return true;
 }
 
-// The reference's decision whether sub-beam `sub` evaluates this (camera ray, beam) pair, in the fp64 transcription
-// (3D: cylinderIntersection + the ownership rule of BeamKernelRecord::eval; 1D: all of rayIntersectInternal1D).
-// Called for the few pairs whose fp32 ownership parameter falls inside its own error band.
-static __device__ __noinline__ bool beamOwnerExact(f3 p1f, f3 p2f, f3 of, f3 df, float camLen, float eps, float radius,
-                                                   uint32_t sub, float subLen, int technique) {
+#ifdef GVPM_BEAMS_AUDIT
+// probe builds only (bash scripts/build_variant.sh baudit gather_beams.hip -DGVPM_BEAMS_AUDIT; scripts/beams_audit.py):
+// the fp32 kernel record runs the fp64 transcription for EVERY pair and logs (i) the pairs whose banded fp32 decision
+// was taken as sure and differs from the transcription's, (ii) the largest observed |fp32 - fp64| / band per quantity
+// over the pairs both accept: the safety factor of each band.
+__device__ unsigned int gvpmAuditCount;
+__device__ float gvpmAuditLog[256][16];
+__device__ unsigned int gvpmAuditRatio[8];  // float bits (positive): [0] tN [1] v [2] w [3] pdfKernel (relative, no band)
+extern "C" int gvpm_debug_beams_audit(unsigned int *count, float *log, float *ratio) {
+  if (hipMemcpyFromSymbol(count, HIP_SYMBOL(gvpmAuditCount), 4) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(log, HIP_SYMBOL(gvpmAuditLog), sizeof(float) * 256 * 16) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(ratio, HIP_SYMBOL(gvpmAuditRatio), 32) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
+// The geometric part of BeamKernelRecord::eval for sub-beam `sub` of a (camera ray, beam) pair in the fp64
+// transcription -- every validity decision of the reference up to the radiometry (3D: cylinderIntersection, the
+// ownership rule, v in [0, len], the kernel centre inside the ray's cylinder, w in [mint, maxt]; 1D: all of
+// rayIntersectInternal1D with its float intermediates) -- and the numbers the rest of the evaluation is built on:
+// v, w, pdfKernel (1D: sin theta) and u.  The fp32 evaluation calls it for the pairs one of whose decisions falls
+// inside its fp32 error band (3D), and for every pair of the 1D kernel, whose reference derives v from float dot
+// products of absolute positions (beams_struct.h:275-290): its result follows the reference's rounding, not the
+// geometry, and only the transcription reproduces it.  The evaluated set is therefore the fp64 oracle's.
+static __device__ __noinline__ bool beamKernelExact(f3 p1f, f3 p2f, f3 of, f3 df, float camLen, float eps, float radius,
+                                                    uint32_t sub, float subLen, int technique, float uvf, float uwf,
+                                                    double &vOut, double &wOut, double &pdfOut, double &uOut,
+                                                    double *dbg = nullptr) {
   BeamD b;
   b.p1 = tod(p1f);
   b.p2 = tod(p2f);
@@ -605,15 +628,39 @@ static __device__ __noinline__ bool beamOwnerExact(f3 p1f, f3 p2f, f3 of, f3 df,
   double tmax = (sub + 1u >= nSub) ? INFINITY : (double)(ls * (float)(sub + 1u));
   if (tmax > b.len) tmax = b.len;
   const RayD cam{tod(of), tod(df), (double)eps, (double)camLen - (double)eps};
+  vOut = wOut = pdfOut = uOut = 0.0;
   if (technique == GVPM_BEAM_BEAM_1D) {
     double u, v, w, st;
-    return rayIntersect1D(b, (double)radius, cam, tmin, tmax, u, v, w, st);
+    if (!rayIntersect1D(b, (double)radius, cam, tmin, tmax, u, v, w, st)) return false;
+    vOut = v; wOut = w; pdfOut = st; uOut = u;
+    return true;
   }
+  // BeamKernelRecord::eval (3D), shift_volume_beams.h:157-290, as krecEval above
   const RayD _cam{at(cam, cam.mint), cam.d, 0.0, cam.maxt - cam.mint};
   const RayD _beam{b.p1, b.dir, 0.0, b.len};
   double tN, tF;
+  if (dbg) dbg[0] = 1.0;
   if (!cylinderIntersection(_cam, _beam, (double)radius, tN, tF)) return false;
-  return (tN < 0 && tmin <= (double)eps) || (tN > tmin && tN < tmax);
+  if (dbg) { dbg[0] = 2.0; dbg[1] = tN; dbg[2] = tF; }
+  if (!((tN < 0 && tmin <= (double)eps) || (tN > tmin && tN < tmax))) return false;
+  const double v = tN + (tF - tN) * (double)uvf;
+  double pdfK = 1.0 / fmax(tF - tN, 0.0001);
+  if (dbg) { dbg[0] = 3.0; dbg[3] = v; }
+  if (v < 0 || v > b.len) return false;
+  const d3 kc = b.p1 + b.dir * v;
+  const double distToProj = dot(kc - cam.o, cam.d);
+  const double distSqr = len2(at(cam, distToProj) - kc);
+  const double radSqr = (double)radius * (double)radius;
+  if (dbg) { dbg[0] = 4.0; dbg[4] = distSqr; }
+  if (distSqr >= radSqr) return false;
+  const double deltaT = sqrt(fmax(0.0, radSqr - distSqr));
+  const double w = distToProj - deltaT + 2 * deltaT * (double)uwf;
+  pdfK *= 1.0 / fmax(2.0 * deltaT, 0.0001);
+  if (dbg) { dbg[0] = 5.0; dbg[5] = w; }
+  if (w < cam.mint || w > cam.maxt) return false;
+  vOut = v; wOut = w; pdfOut = pdfK;
+  if (dbg) dbg[0] = 6.0;
+  return true;
 }
 
 // Occluders of a small scene staged in LDS once per (persistent) workgroup: the visibility test of the beam
@@ -621,19 +668,6 @@ static __device__ __noinline__ bool beamOwnerExact(f3 p1f, f3 p2f, f3 of, f3 df,
 // latency) instead of a per-lane stack walk of the BVH in global memory, which at one or two waves per SIMD was
 // latency-bound and cost more than the rest of the evaluation together.
 constexpr uint32_t SCENE_LDS_TRIS = 128;
-__device__ __forceinline__ bool anyHitLds(const float4 *tri, uint32_t ntri, f3 o, f3 d, float mint, float maxt) {
-  bool hit = false;
-  for (uint32_t i = 0; i < ntri; ++i) {
-    const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
-    // (both ends of the segment strictly on one side of the triangle's plane: nothing to intersect, see nearListHit.
-    // One lane whose beam's list overflowed sends its whole wave through this loop: 80 % of the drains at C3)
-    const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
-    const float s0 = dot(nrm, o - v0), sd = dot(nrm, d);
-    if (__ballot((s0 + sd * mint) * (s0 + sd * maxt) <= 1e-12f) == 0ull) continue;
-    hit |= triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt);
-  }
-  return hit;
-}
 
 // shiftBeamDiffuse + diffuseReconnectionPhotonBeam (shift_volume_beams.cpp:410-539, shift_diffuse.cpp:136-268) in
 // the local frame.  newPos: the offset position relative to the local origin; p1rel = p1 - origin.
@@ -645,12 +679,13 @@ __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const Bea
   if (!ldsTri) {
     // (more than SCENE_LDS_TRIS occluders: the 8-bit format, read from global memory, or every list overflowed)
     if (ovf) return anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist);
-    return nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist);
+    return nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist));
   }
   // occluders in LDS: ONE loop for the lanes that walk their beam's list and the lanes whose list overflowed (every
   // occluder).  A loop for each, one after the other, cost the wave cap + ntri trips; this one costs max(cap, ntri).
   const f3 o = b.p1;
   const float mint = a.cfg.epsilon, maxt = dist;
+  const float margin = planeSideMargin(a.triAbs1, o, maxt);
   bool hit = false;
   bool more = true;
 #pragma unroll 1
@@ -669,7 +704,7 @@ __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const Bea
       const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
       const float s0 = dot(nrm, o - v0), sd = dot(nrm, nd);
       // (both ends of the segment strictly on one side of the triangle's plane: nothing to intersect, see nearListHit)
-      if ((s0 + sd * mint) * (s0 + sd * maxt) <= 1e-12f && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
+      if (!planeSideMiss(s0, sd, mint, maxt, margin) && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
         hit = true;
     }
   }
@@ -853,27 +888,22 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
   k.u = 0.f;
   const float band0 = 2e-6f * (r + ls) * frcp(fmaxf(sin2, 1e-12f));
   if (is1D) {
-    // PhotonBeam::rayIntersectInternal1D (pm/beams_struct.h:250-311): closest approach of the two lines
+    // PhotonBeam::rayIntersectInternal1D (pm/beams_struct.h:250-311): closest approach of the two lines.  The
+    // reference derives v and w from FLOAT dot products of absolute positions divided by d1.d2 and d1.d2^2 - 1: what
+    // it accepts follows that rounding (~1e-6 / (sin^2 |d1.d2|) on v against sub-beams of ~1e-2), so the decision and
+    // the four numbers come from the transcription; the cheap fp32 line-distance test in front of it only removes
+    // pairs that miss by more than its own error.
     const f3 cr = cross(base.d, b.bd);
     const float ad = dot(cam.D0, cr);
-    if (ad * ad >= r * r * sin2) return false;
-    if (sin2 < 1e-5f) return false;  // |d1.d2^2 - 1| < 1e-5
-    const float d0d = dot(cam.D0, base.d);
-    const float tau0 = -(dot(cam.D0, b.bd) - d0d * bdd) * frcp(sin2);
-    const float sig0 = d0d + tau0 * bdd;
-    const float v = tc + tau0;
-    const float w = (float)(cam.s0 + (double)sig0);
-    const float band = band0 + 1e-5f * (fabsf(v) + ls);
-    const bool amb = fabsf(v - tmin) < band || fabsf(v - tmax) < band || fabsf(bdd) < 0.05f;
-    if (amb) {
-      if (!beamOwnerExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique)) return false;
-    } else {
-      if (w <= cam.mint || w >= cam.maxt) return false;
-      if (v <= 0.f || v >= b.len) return false;
-      if (tmin >= v || tmax < v) return false;
-    }
-    const float sinT = fsqrt(sin2);
-    k.u = fdiv(fabsf(ad), sinT);
+    if (ad * ad >= r * r * sin2 * 1.001f + 1e-12f) return false;
+    double vD, wD, pdfD, uD;
+    if (!beamKernelExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique, uv, uw, vD, wD, pdfD, uD))
+      return false;
+    const float v = (float)vD, w = (float)wD;
+    const float tau0 = (float)(vD - (double)tc);
+    const float sig0 = (float)(wD - cam.s0);
+    const float sinT = (float)pdfD;
+    k.u = (float)uD;
     k.tauV = tau0;
     k.v = v;
     k.w = w;
@@ -887,30 +917,106 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
     k.sc = sc;
     k.contrib = sigS * b.flux * sc;
   } else {
-    // BeamKernelRecord::eval, shift_volume_beams.h:157-290
-    float tN, tF;
+    // BeamKernelRecord::eval, shift_volume_beams.h:157-290, with cylinderIntersection (beams_3d_intersections.h:77-140)
+    // in the local frame.  Every comparison that decides whether the pair is evaluated carries an error band (the
+    // fp32 rounding of its operands, with a margin): `rej` collects the rejections that are sure, `amb` the comparisons
+    // that fell inside their band -- those pairs (~1e-4) are decided, and their v / w / pdfKernel computed, by the
+    // fp64 transcription (beamKernelExact), so the evaluated set is the reference's.
     const float z0 = (float)((double)cam.mint - cam.s0), z1 = (float)((double)cam.maxt - cam.s0);
-    if (!cylLocal(cam.D0, b.bd, base.d, z0, z1, r, -tc, b.len - tc, tN, tF)) return false;
-    const float tNa = tc + tN;
-    const float band = band0 + 1e-5f * (fabsf(tNa) + ls);
-    const bool amb = fabsf(tNa - tmin) < band || fabsf(tNa - tmax) < band || (sub == 0u && fabsf(tNa) < band);
-    const bool own = amb ? beamOwnerExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique)
-                         : ((tNa < 0.f && tmin <= eps) || (tNa > tmin && tNa < tmax));
-    if (!own) return false;
+    const float radSqr = r * r;
+    const float bandT = 2.f * band0 + 2e-6f * (tc + ls + r);              // beam parameters (absolute: tc + tau)
+    const float bandZ = 2.f * band0 + 2e-6f * r + 4e-7f * (fabsf(z0) + fabsf(z1));  // camera parameters from the foot point
+    const float bandW = 2.f * band0 + 2e-6f * r + 4e-7f * base.len;
+    bool amb = !(sin2 > 1e-6f), rej = false;
+    // the view line is the beam (origin O, direction bd), the cylinder the camera ray: rel = O - foot = D0
+    const float rzc = dot(cam.D0, base.d);
+    const float Bh = dot(cam.D0, b.bd) - rzc * bdd;
+    const float rel2 = dot(cam.D0, cam.D0);
+    const float Cq = rel2 - rzc * rzc - radSqr;
+    const float disc = Bh * Bh - sin2 * Cq;
+    amb |= fabsf(disc) <= 2e-5f * (Bh * Bh + sin2 * (rel2 + radSqr));
+    rej |= !(disc > 0.f);
+    const float sq = fsqrt(fmaxf(disc, 0.f));
+    const float qq = Bh < 0.f ? (sq - Bh) : -(Bh + sq);
+    float tN = fdiv(qq, fmaxf(sin2, 1e-12f)), tF = fdiv(Cq, qq);
+    if (tN > tF) { const float t = tN; tN = tF; tF = t; }
+    // tNear > view.maxt || tFar < 0 (the beam's own extent, absolute parameters tc + t)
+    {
+      const float tHi = b.len - tc, tLo = -tc;
+      amb |= fabsf(tN - tHi) <= bandT || fabsf(tF - tLo) <= bandT;
+      rej |= tN > tHi || tF < tLo;
+    }
+    // the caps of the camera ray's cylinder
+    {
+      const float zN = rzc + bdd * tN, zF = rzc + bdd * tF;
+      amb |= fabsf(zN - z0) <= bandZ || fabsf(zN - z1) <= bandZ;
+      const bool below = zN < z0, above = zN > z1;
+      const float zc = below ? z0 : z1;
+      if (below || above) {
+        amb |= fabsf(zF - zc) <= bandZ;
+        rej |= below ? zF < z0 : zF > z1;
+        tN = tN + (tF - tN) * fdiv(zN - zc, zN - zF);
+      }
+    }
+    // ownership: tmin < tNear < tmax, or the first sub-beam when the ray's cylinder contains the beam's origin
+    {
+      const float tNa = tc + tN;
+      amb |= fabsf(tNa - tmin) <= bandT || fabsf(tNa - tmax) <= bandT || (sub == 0u && fabsf(tNa) <= bandT);
+      rej |= !((tNa < 0.f && tmin <= eps) || (tNa > tmin && tNa < tmax));
+    }
     k.tauV = tN + (tF - tN) * uv;
     k.v = tc + k.tauV;
     k.pdfKernel = frcp(fmaxf(tF - tN, 0.0001f));
-    if (k.v < 0.f || k.v > b.len) return false;
+    amb |= fabsf(k.v) <= bandT || fabsf(k.v - b.len) <= bandT;
+    rej |= k.v < 0.f || k.v > b.len;
     f3 perp = cam.D0 + (b.bd - base.d * bdd) * k.tauV;
     perp = perp - base.d * dot(perp, base.d);
-    const float distSqr = dot(perp, perp), radSqr = r * r;
-    if (distSqr >= radSqr) return false;
+    const float distSqr = dot(perp, perp);
+    amb |= fabsf(distSqr - radSqr) <= 2e-5f * radSqr;
+    rej |= distSqr >= radSqr;
     const float deltaT = fsqrt(fmaxf(0.f, radSqr - distSqr));
     // distToProj = s0 + dot(D0, d) + tauV * (b.d): the kernel centre's parameter on the camera ray
-    k.sigmaW = (dot(cam.D0, base.d) + k.tauV * bdd) - deltaT + 2.f * deltaT * uw;
+    k.sigmaW = (rzc + k.tauV * bdd) - deltaT + 2.f * deltaT * uw;
     k.w = (float)(cam.s0 + (double)k.sigmaW);
     k.pdfKernel *= frcp(fmaxf(2.f * deltaT, 0.0001f));
-    if (k.w < cam.mint || k.w > cam.maxt) return false;
+    amb |= fabsf(k.w - cam.mint) <= bandW || fabsf(k.w - cam.maxt) <= bandW;
+    rej |= k.w < cam.mint || k.w > cam.maxt;
+#ifdef GVPM_BEAMS_AUDIT
+    {
+      double vD, wD, pdfD, uD, dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const bool ex = beamKernelExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique, uv, uw, vD, wD,
+                                      pdfD, uD, dbg);
+      if (!amb && ex == rej) {
+        const unsigned int slot = atomicAdd(&gvpmAuditCount, 1u);
+        if (slot < 256u) {
+          float *L = gvpmAuditLog[slot];
+          L[0] = __uint_as_float(id); L[1] = __uint_as_float(o.pix); L[2] = ex ? 1.f : 0.f; L[3] = (float)dbg[0];
+          L[4] = tc + tN; L[5] = (float)dbg[1]; L[6] = tc + tF; L[7] = (float)dbg[2]; L[8] = k.v; L[9] = (float)dbg[3];
+          L[10] = distSqr / radSqr; L[11] = (float)(dbg[4] / ((double)r * r)); L[12] = k.w; L[13] = (float)dbg[5];
+          L[14] = sin2; L[15] = bandT;
+        }
+      }
+      if (!amb && !rej && ex) {
+        atomicMax(&gvpmAuditRatio[0], __float_as_uint(fabsf((float)((double)tc + (double)tN - dbg[1])) / bandT));
+        atomicMax(&gvpmAuditRatio[1], __float_as_uint(fabsf((float)((double)k.v - vD)) / bandT));
+        atomicMax(&gvpmAuditRatio[2], __float_as_uint(fabsf((float)((double)k.w - wD)) / bandW));
+        atomicMax(&gvpmAuditRatio[3], __float_as_uint(fabsf((float)(((double)k.pdfKernel - pdfD) / pdfD))));
+        atomicMax(&gvpmAuditRatio[4], __float_as_uint(fabsf((float)(((double)distSqr - dbg[4]) / ((double)radSqr * 2e-5)))));
+      }
+    }
+#endif
+    if (amb) {
+      double vD, wD, pdfD, uD;
+      if (!beamKernelExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique, uv, uw, vD, wD, pdfD, uD))
+        return false;
+      k.v = (float)vD;
+      k.tauV = (float)(vD - (double)tc);
+      k.w = (float)wD;
+      k.sigmaW = (float)(wD - cam.s0);
+      k.pdfKernel = (float)pdfD;
+    } else if (rej) {
+      return false;
+    }
     const MRecF mB = mediumEvalF(a.med, k.v), mCam = mediumEvalF(a.med, k.w);
     const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
     const float sc = fdiv(mB.tr * mCam.tr * phaseEval(a.med.g, -b.bd, -base.d), k.pdfKernel * mB.pdfFailure);
@@ -1136,7 +1242,7 @@ struct alignas(16) BeamTravLds {
 template <int B>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void traverse_beams_kernel(GatherArgs a, const uint32_t *__restrict__ hotFlags,
                                                             const uint4 *__restrict__ items,
-                                                            const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
+                                                            const uint32_t *__restrict__ itemCount, uint32_t itemCap, uint32_t *queueHead,
                                                             uint2 *__restrict__ pairs, uint32_t *pairCount,
                                                             uint32_t pairCap, uint32_t *__restrict__ blockKey,
                                                             uint32_t *__restrict__ blockVal) {
@@ -1144,7 +1250,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
   __shared__ BeamTravLds s;
   const int lane = threadIdx.x;
   const int technique = a.cfg.vol_technique;
-  const uint32_t nItems = *itemCount;
+  // (the planner counts the items it had no room to write: never read past the list; the host regrows it and repeats)
+  const uint32_t nItems = min(*itemCount, itemCap);
   const int b = lane % B, sub = lane / B;
   const float rT = a.radius;  // test radius = kernel radius + half a sub-beam
   const float r = a.kernelRadius;
@@ -1625,13 +1732,13 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
 }
 
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
-                           const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
+                           const uint32_t *itemCount, uint32_t itemCap, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
                            uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream) {
   if (a.nsets == 0) return;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(traverse_beams_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, queueHead, pairs, pairCount, pairCap, blockKey, blockVal); break;
-    case 32: hipLaunchKernelGGL(traverse_beams_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, queueHead, pairs, pairCount, pairCap, blockKey, blockVal); break;
-    default: hipLaunchKernelGGL(traverse_beams_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, queueHead, pairs, pairCount, pairCap, blockKey, blockVal); break;
+    case 64: hipLaunchKernelGGL(traverse_beams_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, itemCap, queueHead, pairs, pairCount, pairCap, blockKey, blockVal); break;
+    case 32: hipLaunchKernelGGL(traverse_beams_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, itemCap, queueHead, pairs, pairCount, pairCap, blockKey, blockVal); break;
+    default: hipLaunchKernelGGL(traverse_beams_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, hotFlags, items, itemCount, itemCap, queueHead, pairs, pairCount, pairCap, blockKey, blockVal); break;
   }
 }
 

@@ -87,7 +87,7 @@ void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint
 void launch_sub_hot(const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *aux, float4 *hot,
                     uint32_t *hotFlags, hipStream_t s);
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
-                           const uint32_t *itemCount, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
+                           const uint32_t *itemCount, uint32_t itemCap, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
                            uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream);
 void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint2 *pairs, const uint32_t *sortedKey,
                            const uint32_t *sortedBlock, uint32_t nBlocks, uint32_t *queueHead, uint32_t nwaves,
@@ -227,6 +227,8 @@ struct gvpm_context {
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
   bool beamsExact = false;        // G-Beams: the literal fp64 evaluation instead of the local-frame fp32 one
   size_t beamPairsInit = (size_t)16 << 20;  // G-Beams: first capacity of the pair list (GVPM_BEAM_PAIRS_INIT; tests shrink it)
+  uint32_t beamItemsInit = 0;     // G-Beams: first capacity of the item list (GVPM_BEAM_ITEMS_INIT; tests shrink it; 0: the planner's bound)
+  uint32_t beamItemCap = 0;       // G-Beams: capacity the item list was regrown to after an overflow
   bool pipeline = true;           // GVPM_PIPELINE=0: everything on the gather stream (isolated kernel timings)
   gvpm_params cfg;
   gvpm_medium medium;
@@ -251,6 +253,10 @@ struct gvpm_context {
     DevBuf<uint32_t> raw;   // 30 words per photon: the 8 xyz arrays, the 4 scalars, flags, path_id (the ABI's order)
     gvpm_photon_soa dev;    // device pointers into raw
     hipEvent_t copied = nullptr;
+    // recorded, on the gather stream and on the build stream, behind the kernels of every gather that read the slot
+    // (builds; the G-Planes gather itself): the next copy into the slot waits for both
+    hipEvent_t consumed = nullptr, consumedB = nullptr;
+    bool read = false;      // a gather has launched kernels that read it since its last copy
   } phSlot[3];
   struct RaySlot {
     DevBuf<gvpm_camera_ray> rays;
@@ -261,6 +267,7 @@ struct gvpm_context {
   int phCur = 0, phPending = -1, rayCur = 0, rayPending = -1;   // pending: prefetched, current after the next gather
   bool phWait = false, rayWait = false;   // the next gather's streams must wait for the current slot's copy
   bool raysOwnedCur = false;              // the current camera rays live in raySlot[rayCur]
+  bool photonsOwnedCur = false;           // the current photon map lives in phSlot[phCur]
   hipStream_t copyStream = nullptr;
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid
   gvpm_photon_soa rawDev;  // device pointers
@@ -327,7 +334,8 @@ struct gvpm_context {
   DevBuf<unsigned long long> stats;
   // HIP event brackets per phase: 0 = dominant kernel, 1 = BRE traversal, 2 = build (grid + sorts + plan)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events[GVPM_PHASES];
-  size_t eventsUsed[GVPM_PHASES] = {0, 0, 0};
+  size_t eventsHead[GVPM_PHASES] = {0, 0, 0};   // next slot of the ring
+  size_t eventsCount[GVPM_PHASES] = {0, 0, 0};  // launches recorded since the last poll, saturating at the ring size
 
   int beamsPerWave = 16;
   float cellScale = 0.f;  // GVPM_CELL_SCALE; 0: the technique's default (buildGrid)
@@ -440,6 +448,8 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   }
   for (int k = 0; k < 3; ++k)
     if (hipEventCreateWithFlags(&h->phSlot[k].copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->phSlot[k].consumed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->phSlot[k].consumedB, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->raySlot[k].copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->raySlot[k].freed, hipEventDisableTiming) != hipSuccess) {
       gvpm_destroy(h);
@@ -495,6 +505,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     const long long v = atoll(e);
     if (v >= 64 && v <= ((long long)1 << 31)) h->beamPairsInit = (size_t)v;
   }
+  if (const char *e = getenv("GVPM_BEAM_ITEMS_INIT")) {
+    const long long v = atoll(e);
+    if (v >= 1 && v <= ((long long)1 << 30)) h->beamItemsInit = (uint32_t)v;
+  }
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -533,6 +547,8 @@ int gvpm_destroy(gvpm_context *h) {
   for (auto &ps : h->phSlot) {
     ps.raw.release();
     if (ps.copied) (void)hipEventDestroy(ps.copied);
+    if (ps.consumed) (void)hipEventDestroy(ps.consumed);
+    if (ps.consumedB) (void)hipEventDestroy(ps.consumedB);
   }
   for (auto &rs : h->raySlot) {
     rs.rays.release();
@@ -565,7 +581,8 @@ int gvpm_reset(gvpm_context *h) {
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
   h->sumIt = 0;
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
-  for (size_t &u : h->eventsUsed) u = 0;
+  for (size_t &u : h->eventsHead) u = 0;
+  for (size_t &u : h->eventsCount) u = 0;
   h->useAll = false;
   h->totalEmitted = 0;
   {
@@ -681,15 +698,33 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
     if (prefetch) return fail(h, GVPM_ERR_INVALID_ARG, "prefetch takes host buffers");
     h->rawDev = *p;
     h->phWait = false;
+    h->photonsOwnedCur = false;
   } else {
-    const bool pinned = isPinnedHost(p->pos);
+    // pinned only if EVERY array is: one pageable array makes the runtime stage that copy itself, and the call must then
+    // not return before the copy stream has drained (the header's contract: the library copies during the call)
+    bool pinned = n > 0;
+    {
+      const void *all[14] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat, p->parent_wi,
+                             p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g, p->flags, p->path_id};
+      for (int k = 0; k < 14 && pinned; ++k) pinned = isPinnedHost(all[k]);
+    }
     if (prefetch && !pinned) return fail(h, GVPM_ERR_INVALID_ARG, "gvpm_prefetch_photons needs pinned host memory (gvpm_host_alloc*)");
     if (prefetch && h->phPending >= 0) return fail(h, GVPM_ERR_STATE, "a prefetched photon set is already pending");
-    // (no build is in flight between two gvpm_gather calls: every slot but a pending prefetch is free)
     int slot = (h->phCur + 1) % 3;
     if (slot == h->phPending) slot = (h->phCur + 2) % 3;
     gvpm_context::PhotonSlot &ps = h->phSlot[slot];
-    HIP_TRY(h, ps.raw.ensure((size_t)n * 30 + 8));
+    // the kernels of the gathers that last read this slot (its build; the G-Planes gather) may still be running
+    if (ps.read) {
+      HIP_TRY(h, hipStreamWaitEvent(h->copyStream, ps.consumed, 0));
+      HIP_TRY(h, hipStreamWaitEvent(h->copyStream, ps.consumedB, 0));
+    }
+    ps.read = false;
+    if (ps.raw.cap < (size_t)n * 30 + 8) {
+      // regrowing frees the old buffer
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->streamB));
+      HIP_TRY(h, ps.raw.ensure((size_t)n * 30 + 8));
+    }
     const void *src[14] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat, p->parent_wi,
                            p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g, p->flags, p->path_id};
     const void **dst[14] = {(const void **)&ps.dev.pos, (const void **)&ps.dev.wi, (const void **)&ps.dev.flux,
@@ -725,6 +760,7 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
     h->phCur = slot;
     h->rawDev = ps.dev;
     h->phWait = true;
+    h->photonsOwnedCur = true;
   }
   h->nph = n;
   h->havePhotons = true;
@@ -1104,6 +1140,9 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.tri4 = h->tri4.p;
   a.bvh = h->bvh.p;
   a.ntri = h->ntri;
+  a.triAbs1 = 0.f;
+  if (h->ntri)
+    for (int c = 0; c < 3; ++c) a.triAbs1 += fmaxf(fabsf(h->triMin[c]), fabsf(h->triMax[c]));
   for (int c = 0; c < 3; ++c) {
     a.med.sigmaS[c] = h->medium.sigma_s[c];
     a.med.sigmaT[c] = h->medium.sigma_t[c];
@@ -1128,9 +1167,9 @@ static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, i
   // a ring of at most GVPM_EVENT_RING pairs per phase: a host that never polls gvpm_get_phase_time keeps the timings of
   // its last launches instead of growing the pool by three pairs per step
   constexpr size_t GVPM_EVENT_RING = 256;
-  if (h->eventsUsed[phase] == h->events[phase].size()) {
+  if (h->eventsHead[phase] == h->events[phase].size()) {
     if (h->events[phase].size() >= GVPM_EVENT_RING) {
-      h->eventsUsed[phase] = 0;  // overwrite the oldest
+      h->eventsHead[phase] = 0;  // overwrite the oldest
     } else {
       hipEvent_t e0, e1;
       HIP_TRY(h, hipEventCreate(&e0));
@@ -1138,7 +1177,8 @@ static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, i
       h->events[phase].emplace_back(e0, e1);
     }
   }
-  *ev = &h->events[phase][h->eventsUsed[phase]++];
+  *ev = &h->events[phase][h->eventsHead[phase]++];
+  h->eventsCount[phase] = std::min(h->eventsCount[phase] + 1, GVPM_EVENT_RING);
   return GVPM_OK;
 }
 
@@ -1445,41 +1485,58 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
-  // (heavy items are split into parts: room for them on top of the planner's own bound)
-  const uint32_t itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave) + h->nsub / 256u + 4096u;
-  HIP_TRY(h, h->bs->items.ensure(itemCap));
+  // The planner splits heavy items into as many as 512 parts (tile_walk.h), so its own bound (items per tile chunk) is
+  // not a bound on the list: the list starts at that bound plus room for the parts and, when the planner reports more
+  // (it counts what it could not write, and the traversal never reads past the capacity), is regrown to the count and
+  // the plan repeated -- as the pair list below.
+  uint32_t itemCap = h->beamItemsInit ? h->beamItemsInit
+                                      : plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave) + h->nsub / 256u + 4096u;
+  itemCap = std::max(itemCap, h->beamItemCap);
   HIP_TRY(h, h->bs->queueCtl.ensure(8));
-  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
-  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr, itemCap,
-                  h->stream);
-  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   // traversal -> pair list (blocks of 64) -> evaluation.  The list has no useful a-priori bound (the planner's is
   // sub-beams x rays per slab box, ~100x the survivors): it starts at 16 M pairs and, when the traversal reports
   // more than fit, is regrown to what it counted and the traversal repeated (deterministic, first iterations only).
   // queueCtl: [0] items, [1] item queue head, [2] pairs (multiple of 64), [3] block queue head
   if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure(h->beamPairsInit));
   uint32_t npairs = 0;
+  bool planned = false;
   for (int attempt = 0;; ++attempt) {
+    if (!planned) {
+      HIP_TRY(h, h->bs->items.ensure(itemCap));
+      HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
+      launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr,
+                      itemCap, h->stream);
+      if (attempt == 0) HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+      planned = true;
+    }
     const uint32_t cap = (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u);
     const size_t nblkCap = cap / 64u + 1u;
     for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nblkCap));
-    launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
+    launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, itemCap, h->bs->queueCtl.p + 1,
                           h->beamPairs.p, h->bs->queueCtl.p + 2, cap, h->blockKeyA.p, h->blockValA.p, h->nwavesTrav, h->stream);
     uint32_t ctl[3] = {0, 0, 0};
     HIP_TRY(h, hipMemcpyAsync(ctl, h->bs->queueCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     npairs = ctl[2];
-    if (ctl[0] > itemCap) return fail(h, GVPM_ERR_STATE, "G-Beams planner produced more work items than its bound");
     if (getenv("GVPM_BEAMS_TRACE")) {
       uint32_t q[4];
       (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
-      fprintf(stderr, "[beams] items %u pairs %u (cap %u) nsub %u nsets %u tiles %u cell %.3f r %.3f dims %d %d %d\n", q[0], npairs, cap,
-              h->nsub, h->nsets, h->bs->ntiles, h->bs->grid.cell, r, h->bs->grid.dim[0], h->bs->grid.dim[1], h->bs->grid.dim[2]);
+      fprintf(stderr, "[beams] items %u (cap %u) pairs %u (cap %u) nsub %u nsets %u tiles %u cell %.3f r %.3f dims %d %d %d\n", q[0],
+              itemCap, npairs, cap, h->nsub, h->nsets, h->bs->ntiles, h->bs->grid.cell, r, h->bs->grid.dim[0], h->bs->grid.dim[1],
+              h->bs->grid.dim[2]);
     }
-    if (npairs <= cap) break;
-    if (attempt > 0) return fail(h, GVPM_ERR_HIP, "beam pair list overflowed twice");
-    HIP_TRY(h, h->beamPairs.ensure((size_t)npairs + (npairs >> 2) + 64));
-    HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 1, 0, 2 * sizeof(uint32_t), h->stream));
+    const bool itemsOver = ctl[0] > itemCap, pairsOver = npairs > cap;
+    if (!itemsOver && !pairsOver) break;
+    if (attempt >= 3) return fail(h, GVPM_ERR_HIP, "G-Beams item / pair lists overflowed after being regrown");
+    if (itemsOver) {
+      // (the pass over the truncated list is discarded whole)
+      itemCap = ctl[0] + (ctl[0] >> 2) + 64u;
+      h->beamItemCap = itemCap;
+      planned = false;
+    } else {
+      HIP_TRY(h, h->beamPairs.ensure((size_t)npairs + (npairs >> 2) + 64));
+      HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 1, 0, 2 * sizeof(uint32_t), h->stream));
+    }
     // the candidate count of the discarded pass
     HIP_TRY(h, hipMemset2DAsync(a.stats + 1, 8 * sizeof(unsigned long long), 0, sizeof(unsigned long long), GVPM_STAT_ROWS,
                                 h->stream));
@@ -1626,6 +1683,13 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, hipEventRecord(h->raySlot[h->rayCur].freed, h->stream));
     h->raySlot[h->rayCur].read = true;
   }
+  // ... and of the staged photon arrays (the build on either stream; G-Planes reads them in the gather itself)
+  if (h->photonsOwnedCur) {
+    gvpm_context::PhotonSlot &ps = h->phSlot[h->phCur];
+    HIP_TRY(h, hipEventRecord(ps.consumed, h->stream));
+    HIP_TRY(h, hipEventRecord(ps.consumedB, h->streamB));
+    ps.read = true;
+  }
   // prefetched inputs (gvpm_prefetch_*) become the current ones: what an upload at this point would have done
   if (h->phPending >= 0) {
     h->phCur = h->phPending;
@@ -1633,6 +1697,7 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     h->rawDev = h->phSlot[h->phCur].dev;
     h->nph = (uint32_t)h->rawDev.n;
     h->phWait = true;
+    h->photonsOwnedCur = true;
     h->photonsDirty = true;
   }
   if (h->rayPending >= 0) {
@@ -1694,15 +1759,19 @@ int gvpm_get_phase_time(gvpm_context *h, int phase, float *avg_ms, uint32_t *lau
   CHECK_H(h);
   if (phase < 0 || phase >= GVPM_PHASES) return fail(h, GVPM_ERR_INVALID_ARG, "unknown phase");
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // the last `count` launches: the slots behind the head, wrapping (once the ring is full every slot holds one)
   double total = 0;
-  for (size_t i = 0; i < h->eventsUsed[phase]; ++i) {
+  const size_t count = h->eventsCount[phase], size = h->events[phase].size();
+  for (size_t k = 0; k < count; ++k) {
+    const size_t i = (h->eventsHead[phase] + size - 1 - k) % size;
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->events[phase][i].first, h->events[phase][i].second));
     total += ms;
   }
-  if (avg_ms) *avg_ms = h->eventsUsed[phase] ? (float)(total / h->eventsUsed[phase]) : 0.f;
-  if (launches) *launches = (uint32_t)h->eventsUsed[phase];
-  h->eventsUsed[phase] = 0;
+  if (avg_ms) *avg_ms = count ? (float)(total / count) : 0.f;
+  if (launches) *launches = (uint32_t)count;
+  h->eventsHead[phase] = 0;
+  h->eventsCount[phase] = 0;
   return GVPM_OK;
 }
 

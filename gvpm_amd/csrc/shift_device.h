@@ -94,8 +94,20 @@ static __device__ __noinline__ bool anyHitScene(const float4 *bvh, const float4 
 // words of the record), so the loop touches 0-12 triangles.  FULLVIS kernels (intended visibility,
 // more than 254 occluders, or a photon whose list overflowed) walk the BVH instead; the fast
 // kernels carry no call, which is worth ~30 VGPRs.
+// Margin of the plane-side early-out in front of a triangle test: the signed distances s0 + sd * t of the segment's
+// two ends to the triangle's plane are fp32 sums of products of O(|o|_1 + |v0|_1) and O(maxt) operands, so their
+// rounding error is a few ulps of that magnitude.  A triangle is skipped only when BOTH ends lie on one side by MORE
+// than this margin; anything closer goes to triHit, which decides as the reference's rayIntersect does.
+__device__ __forceinline__ float planeSideMargin(float triAbs1, f3 o, float maxt) {
+  return 2e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + triAbs1 + maxt);
+}
+__device__ __forceinline__ bool planeSideMiss(float s0, float sd, float mint, float maxt, float margin) {
+  const float e0 = s0 + sd * mint, e1 = s0 + sd * maxt;
+  return fminf(e0, e1) > margin || fmaxf(e0, e1) < -margin;
+}
+
 __device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
-                                            float mint, float maxt) {
+                                            float mint, float maxt, float margin) {
   bool hit = false;
   uint32_t l = nl0;
 #pragma unroll 1
@@ -109,7 +121,7 @@ __device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uin
     // it spares, and at C3 a third of a beam's listed occluders (ceiling and floor under and above a vertical beam)
     const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
     const float s0 = dot(nrm, o - v0), sd = dot(nrm, d);
-    if ((s0 + sd * mint) * (s0 + sd * maxt) > 1e-12f) continue;
+    if (planeSideMiss(s0, sd, mint, maxt, margin)) continue;
     if (triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
   }
   return hit;
@@ -152,7 +164,9 @@ __device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const float4 
     return nearListHitWide(a.tri4, nl0, nl1, nl2, o, d, mint, maxt);
   }
   if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
-  return ldsTri ? nearListHit(ldsTri, nl0, nl1, nl2, o, d, mint, maxt) : nearListHit(a.tri4, nl0, nl1, nl2, o, d, mint, maxt);
+  const float margin = planeSideMargin(a.triAbs1, o, maxt);
+  return ldsTri ? nearListHit(ldsTri, nl0, nl1, nl2, o, d, mint, maxt, margin)
+                : nearListHit(a.tri4, nl0, nl1, nl2, o, d, mint, maxt, margin);
 }
 
 // GatherPoint::sensorMIS, gvpm_struct.h:608-631 (sDist == bDist for BRE: same t')

@@ -20,6 +20,7 @@
 #pragma once
 
 #include "gvpm_oracle.hpp"
+#include "gvpm_oracle_accel.hpp"
 
 namespace oracle {
 
@@ -633,19 +634,22 @@ template <typename F> struct BeamMapO {
   }
 };
 
-// One beam set of computeVolumeGradientBeams' inner loop, gvpm.cpp:918-946, with BeamMap::query's
-// ENoAccel loop (pm/beams.h:289-294).  subBeamSize > 0 additionally cuts every beam into sub-beams
+// One beam set of computeVolumeGradientBeams' inner loop, gvpm.cpp:918-946.  accel != null: BeamMap::query through the
+// reference's SubBeamBVH (EBVHAccel, what gvpm.cpp:880-986 builds; gvpm_oracle_accel.hpp).  Otherwise BeamMap::query's
+// ENoAccel loop (pm/beams.h:289-294); subBeamSize > 0 additionally cuts every beam into sub-beams
 // of that length and calls the functor per sub-beam (the ownership rule of the reference's SubBeamBVH).
 template <typename F>
 inline void gatherSetBeams(const GatherContext<F> &ctx, const BeamMapO<F> &map, F radius, const gvpm_camera_ray *set,
-                           F subBeamSize, F *iter, Counters &cnt) {
+                           F subBeamSize, F *iter, Counters &cnt, const SubBeamBVHO<F, Beam<F>> *accel = nullptr) {
   CamRay<F> base(set[0]);
   CamRay<F> shifts[4] = {CamRay<F>(set[1]), CamRay<F>(set[2]), CamRay<F>(set[3]), CamRay<F>(set[4])};
   // Ray ray(vertex(idEdge), d, Epsilon, distTotal - Epsilon), gvpm.cpp:932
   Ray<F> ray(base.o, base.d, ctx.Epsilon, base.len - ctx.Epsilon);
   BeamGradRadianceQuery<F> q(ctx, &base, shifts, ray);
   q.ctx_radius = radius;
-  for (const Beam<F> &b : map.beams) {
+  if (accel) {
+    accel->query(map.beams, ray, q);
+  } else for (const Beam<F> &b : map.beams) {
     if (subBeamSize > 0) {
       int nb = (int)std::ceil(b.length / subBeamSize);
       F ls = b.length / nb;

@@ -6,13 +6,15 @@
 //   PhotonPlane::intersectPlane0D / getContrib0D    pm/plane_struct.h:104-192, invJacobian :199
 //   PlaneGradRadianceQuery::operator()              gvpm/shift/shift_volume_planes.h:57-101
 //   specularShift / intersection                    shift_volume_planes.h:263-416, 426-453
-// The plane BVH (pm/plane_accel.h:85-207) only prunes: the functor performs the complete
-// intersection test itself, so a loop over all planes visits the same hits.
+// The plane BVH (pm/plane_accel.h:85-207) is restated in gvpm_oracle_accel.hpp (PhotonPlaneBVHO); it only prunes: the
+// functor performs the complete intersection test itself, so a loop over all planes visits the same hits
+// (tests/test_oracle_accel.py).
 // LTPhotonPlane::transformBeam (gvpm_plane.h:53-73; second distance + phase direction drawn from
 // block 0's sampler, gvpm.cpp:793-797) is host-side: the planes arrive with w1 / length1.
 #pragma once
 
 #include "gvpm_oracle.hpp"
+#include "gvpm_oracle_accel.hpp"
 
 namespace oracle {
 
@@ -196,12 +198,13 @@ template <typename F> struct PlaneGradRadianceQuery {
 // one beam set of computeVolumeGradientPlanes' inner loop, gvpm.cpp:821-846
 template <typename F>
 inline void gatherSetPlanes(const GatherContext<F> &ctx, const PlaneMapO<F> &map, const gvpm_camera_ray *set, F *iter,
-                            Counters &cnt) {
+                            Counters &cnt, const PhotonPlaneBVHO<F, Plane<F>> *accel = nullptr) {
   CamRay<F> base(set[0]);
   CamRay<F> shifts[4] = {CamRay<F>(set[1]), CamRay<F>(set[2]), CamRay<F>(set[3]), CamRay<F>(set[4])};
   Ray<F> ray(base.o, base.d, ctx.Epsilon, base.len - ctx.Epsilon);
   PlaneGradRadianceQuery<F> q(ctx, &base, shifts, ray);
-  for (const Plane<F> &p : map.planes) q(p);
+  if (accel) accel->query(map.planes, ray, q);  // m_planesAccel->query(query), gvpm.cpp:836
+  else for (const Plane<F> &p : map.planes) q(p);
   for (int c = 0; c < 3; ++c) {
     iter[c] += q.mediumFlux[c];
     for (int k = 0; k < 4; ++k) {

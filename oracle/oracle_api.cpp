@@ -140,13 +140,17 @@ int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
 template <typename F>
 int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *beams,
                 const float *endN, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
-                uint64_t nbPaths, double subBeamSize, int threads, double *accum, uint64_t *counters,
-                double *seconds) {
+                uint64_t nbPaths, double subBeamSize, int useAccel, int threads, double *accum, uint64_t *counters,
+                double *seconds, double *buildSeconds) {
   Gatherer<F> g;
   g.setup(*p, *m, *t);
   BeamMapO<F> map;
   map.load(*beams, endN);
   auto t0 = std::chrono::steady_clock::now();
+  // new BeamMap<LTPhotonBeam>(...)->build(EBVHAccel): serial, as the reference (gvpm.cpp:450-454)
+  SubBeamBVHO<F, Beam<F>> bvh;
+  if (useAccel) bvh.build(map.beams, (F)radius);
+  if (buildSeconds) *buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const size_t P = (size_t)p->width * p->height;
   std::vector<F> perSet((size_t)nsets * 27, (F)0);
   Counters total;
@@ -158,7 +162,8 @@ int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles
     Counters local;
 #pragma omp for schedule(dynamic, 16)
     for (int64_t s = 0; s < (int64_t)nsets; ++s)
-      gatherSetBeams<F>(g.ctx, map, (F)radius, rays + 5 * s, (F)subBeamSize, &perSet[(size_t)s * 27], local);
+      gatherSetBeams<F>(g.ctx, map, (F)radius, rays + 5 * s, (F)subBeamSize, &perSet[(size_t)s * 27], local,
+                        useAccel ? &bvh : nullptr);
 #pragma omp critical
     total.add(local);
   }
@@ -190,12 +195,17 @@ int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles
 template <typename F>
 int gatherPlanes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *beams,
                  const float *w1, const float *len1, const gvpm_camera_ray *rays, uint64_t nsets, int it,
-                 uint64_t nbPaths, int threads, double *accum, uint64_t *counters, double *seconds) {
+                 uint64_t nbPaths, int useAccel, int threads, double *accum, uint64_t *counters, double *seconds,
+                 double *buildSeconds) {
   Gatherer<F> g;
   g.setup(*p, *m, *t);
   PlaneMapO<F> map;
   map.load(*beams, w1, len1);
   auto t0 = std::chrono::steady_clock::now();
+  // m_planesAccel = new PhotonPlaneBVH<LTPhotonPlane>(m_planes), gvpm.cpp:799
+  PhotonPlaneBVHO<F, Plane<F>> bvh;
+  if (useAccel) bvh.build(map.planes);
+  if (buildSeconds) *buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const size_t P = (size_t)p->width * p->height;
   std::vector<F> perSet((size_t)nsets * 27, (F)0);
   Counters total;
@@ -207,7 +217,7 @@ int gatherPlanes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangle
     Counters local;
 #pragma omp for schedule(dynamic, 16)
     for (int64_t s = 0; s < (int64_t)nsets; ++s)
-      gatherSetPlanes<F>(g.ctx, map, rays + 5 * s, &perSet[(size_t)s * 27], local);
+      gatherSetPlanes<F>(g.ctx, map, rays + 5 * s, &perSet[(size_t)s * 27], local, useAccel ? &bvh : nullptr);
 #pragma omp critical
     total.add(local);
   }
@@ -238,33 +248,41 @@ int gatherPlanes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangle
 
 extern "C" {
 
-// One iteration of computeVolumeGradientPlanes (gvpm.cpp:782-878) on the CPU (loop over all planes).
+// One iteration of computeVolumeGradientPlanes (gvpm.cpp:782-878) on the CPU.  use_accel: 1 = through the
+// reference's PhotonPlaneBVH (pm/plane_accel.h:85-207), 0 = a loop over all planes.  seconds: build + gather;
+// build_seconds (optional): the serial build alone.
 int oracle_gather_planes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
                          const gvpm_photon_soa *beams, const float *w1, const float *len1,
                          const gvpm_camera_ray *rays, uint64_t nsets, int it, uint64_t nb_paths, int precision,
-                         int threads, double *accum, uint64_t *counters, double *seconds) {
+                         int use_accel, int threads, double *accum, uint64_t *counters, double *seconds,
+                         double *build_seconds) {
   if (!p || !m || !t || !beams || (beams->n && (!w1 || !len1)) || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
   if (p->vol_technique != GVPM_VOL_PLANE0D) return GVPM_ERR_INVALID_ARG;
   if (precision == 32)
-    return gatherPlanes<float>(p, m, t, beams, w1, len1, rays, nsets, it, nb_paths, threads, accum, counters, seconds);
-  return gatherPlanes<double>(p, m, t, beams, w1, len1, rays, nsets, it, nb_paths, threads, accum, counters, seconds);
+    return gatherPlanes<float>(p, m, t, beams, w1, len1, rays, nsets, it, nb_paths, use_accel, threads, accum, counters,
+                               seconds, build_seconds);
+  return gatherPlanes<double>(p, m, t, beams, w1, len1, rays, nsets, it, nb_paths, use_accel, threads, accum, counters,
+                              seconds, build_seconds);
 }
 
-// One iteration of computeVolumeGradientBeams (gvpm.cpp:880-986) on the CPU with the reference's
-// ENoAccel loop over all beams (pm/beams.h:289-294).  sub_beam_size > 0: every beam is also cut
+// One iteration of computeVolumeGradientBeams (gvpm.cpp:880-986) on the CPU.  use_accel: 1 = through the
+// reference's SubBeamBVH (pm/beams_accel.h:82-267: what the integrator builds, EBVHAccel), 0 = the reference's
+// ENoAccel loop over all beams (pm/beams.h:289-294).  sub_beam_size > 0 (ENoAccel only): every beam is also cut
 // into sub-beams of that length, exercising the ownership rule of SubBeamBVH (pm/beams_accel.h:98-131).
+// seconds: build + gather; build_seconds (optional): the serial build alone.
 int oracle_gather_beams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
                         const gvpm_photon_soa *beams, const float *end_n, const gvpm_camera_ray *rays,
                         uint64_t nsets, double radius, int it, uint64_t nb_paths, int precision,
-                        double sub_beam_size, int threads, double *accum, uint64_t *counters, double *seconds) {
+                        double sub_beam_size, int use_accel, int threads, double *accum, uint64_t *counters,
+                        double *seconds, double *build_seconds) {
   if (!p || !m || !t || !beams || (beams->n && !end_n) || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
   if (p->vol_technique != GVPM_BEAM_BEAM_1D && p->vol_technique != GVPM_BEAM_BEAM_3D_OPTIMIZED)
     return GVPM_ERR_UNSUPPORTED;  // BeamKernelRecord::eval: SAssert(false) for the other variants
   if (precision == 32)
-    return gatherBeams<float>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, threads, accum,
-                              counters, seconds);
-  return gatherBeams<double>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, threads, accum,
-                             counters, seconds);
+    return gatherBeams<float>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, use_accel, threads,
+                              accum, counters, seconds, build_seconds);
+  return gatherBeams<double>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, use_accel, threads,
+                             accum, counters, seconds, build_seconds);
 }
 
 // One iteration of computeVolumeGradientPhoton (gvpm.cpp:1081-1203) on the CPU.  accum: P*27

@@ -42,12 +42,12 @@ def lib(fast=False):
                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_gather_beams.argtypes = [
             C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
-            C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int,
-            C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+            C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.oracle_gather_planes.argtypes = [
             C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
-            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
-            C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.oracle_poisson_solve.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
         _LIBS[name] = L
@@ -109,8 +109,9 @@ def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_a
 
 
 def gather_beams(params, medium, tris, beams, end_n, rays, radius, it=1, nb_paths=1, precision=64, sub_beam_size=0.0,
-                 threads=0, accum=None, fast=False):
-    """One iteration of computeVolumeGradientBeams on the CPU -> (accum[H,W,27], counters, seconds)."""
+                 threads=0, accum=None, fast=False, use_accel=False, timing=None):
+    """One iteration of computeVolumeGradientBeams on the CPU -> (accum[H,W,27], counters, seconds).
+    use_accel: through the reference's SubBeamBVH instead of the ENoAccel loop; timing (dict): receives build_s."""
     tstruct, keep = abi.triangles_struct(*tris)
     soa = beams.soa()
     end_n = np.ascontiguousarray(end_n, np.float32)
@@ -119,19 +120,23 @@ def gather_beams(params, medium, tris, beams, end_n, rays, radius, it=1, nb_path
     accum = np.zeros(P * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
     counters = np.zeros(5, np.uint64)
     secs = C.c_double(0)
+    bsecs = C.c_double(0)
     rc = lib(fast).oracle_gather_beams(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
                                        end_n.ctypes.data, rays.ctypes.data, rays.shape[0], float(radius), it,
-                                       nb_paths, precision, float(sub_beam_size), threads, accum.ctypes.data,
-                                       counters.ctypes.data, C.byref(secs))
+                                       nb_paths, precision, float(sub_beam_size), int(bool(use_accel)), threads,
+                                       accum.ctypes.data, counters.ctypes.data, C.byref(secs), C.byref(bsecs))
     if rc != 0:
         raise RuntimeError(f"oracle_gather_beams failed: {rc}")
+    if timing is not None:
+        timing["build_s"] = bsecs.value
     return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
             secs.value)
 
 
 def gather_planes(params, medium, tris, beams, w1, len1, rays, it=1, nb_paths=1, precision=64, threads=0, accum=None,
-                  fast=False):
-    """One iteration of computeVolumeGradientPlanes on the CPU -> (accum[H,W,27], counters, seconds)."""
+                  fast=False, use_accel=False, timing=None):
+    """One iteration of computeVolumeGradientPlanes on the CPU -> (accum[H,W,27], counters, seconds).
+    use_accel: through the reference's PhotonPlaneBVH instead of the loop over all planes; timing (dict): build_s."""
     tstruct, keep = abi.triangles_struct(*tris)
     soa = beams.soa()
     w1 = np.ascontiguousarray(w1, np.float32)
@@ -141,12 +146,15 @@ def gather_planes(params, medium, tris, beams, w1, len1, rays, it=1, nb_paths=1,
     accum = np.zeros(P * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
     counters = np.zeros(5, np.uint64)
     secs = C.c_double(0)
+    bsecs = C.c_double(0)
     rc = lib(fast).oracle_gather_planes(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
                                         w1.ctypes.data, len1.ctypes.data, rays.ctypes.data, rays.shape[0], it,
-                                        nb_paths, precision, threads, accum.ctypes.data, counters.ctypes.data,
-                                        C.byref(secs))
+                                        nb_paths, precision, int(bool(use_accel)), threads, accum.ctypes.data,
+                                        counters.ctypes.data, C.byref(secs), C.byref(bsecs))
     if rc != 0:
         raise RuntimeError(f"oracle_gather_planes failed: {rc}")
+    if timing is not None:
+        timing["build_s"] = bsecs.value
     return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
             secs.value)
 

@@ -9,6 +9,7 @@ from test_oracle_beams import make_beam_case, TECHS
 from test_parity_gpu import l2, TOL
 
 pytestmark = pytest.mark.gpu
+SHIFT_COUNTERS = ("null_shifts", "diffuse_shifts", "failed_shifts")
 
 
 def device_beams(c, p=None, rays=None, iters=1):
@@ -17,7 +18,7 @@ def device_beams(c, p=None, rays=None, iters=1):
     ctx.upload_scene(*c.tris)
     ctx.upload_medium(c.m)
     ref = None
-    total = 0
+    total = {k: 0 for k in SHIFT_COUNTERS + ("evaluations",)}
     for it in range(1, iters + 1):
         if it == 1:
             beams, en, nb, r = c.beams, c.end_n, c.nb, (c.rays if rays is None else rays)
@@ -29,15 +30,20 @@ def device_beams(c, p=None, rays=None, iters=1):
         ctx.upload_camera_beams(r)
         ctx.gather(it, nb)
         ref, cnt, _ = O.gather_beams(p, c.m, c.tris, beams, en, r, rad, it, nb, 64, accum=ref)
-        total += cnt["evaluations"]
+        for k in total:
+            total[k] += cnt[k]
     acc = ctx.download_accum()
     st = ctx.stats()
     film = ctx.download_film(iters, True)
     ctx.close()
     lum = max(ref[..., 0:3].mean(), 1e-30)
-    # ownership boundaries (measure zero) and the float intermediates of the reference may move a
-    # handful of intersections across a validity test
-    assert abs(st["evaluations"] - total) <= max(2, 2e-4 * total), (st, total)
+    # "count = device atomic, must equal the oracle's count exactly" -- on the default (fp32 local-frame)
+    # path too: every validity decision of the kernel record is banded and settled in fp64 inside the band
+    # (gather_beams.hip beamBase / beamKernelExact).  The shifts' own decisions (null shift or reconnection, the
+    # visibility of a reconnection) are fp32: a pair within rounding of one of them may move between counters.
+    assert st["evaluations"] == total["evaluations"], (st, total)
+    for k in SHIFT_COUNTERS:
+        assert abs(st[k] - total[k]) <= 2, (k, st, total)
     assert l2(acc, ref, lum) < 1e-3
     rfilm = O.assemble(ref, iters, True)
     for a, b in zip(film, rfilm):
@@ -82,6 +88,16 @@ def test_beams_fine_image_null_shifts_and_empty():
     c2.end_n = c2.end_n[:0]
     acc, ref, st = device_beams(c2)
     assert st["evaluations"] == 0 and not acc.any()
+
+
+def test_beams_item_list_regrows(monkeypatch):
+    # an item list far too small for the planner's output (heavy items are split into parts, so its size has no
+    # a-priori bound): the planner counts what it could not write, the traversal never reads past the capacity, the host
+    # regrows the list to the count and repeats plan + traversal
+    monkeypatch.setenv("GVPM_BEAM_ITEMS_INIT", "7")
+    c = make_beam_case("cbox", 32, 28, 12000, 2.5)
+    acc, ref, st = device_beams(c, iters=2)
+    assert st["evaluations"] > 20000
 
 
 def test_beams_pair_list_regrows(monkeypatch):
@@ -138,8 +154,8 @@ def test_beam_near_list_formats(levels):
     st, acc = ctx.stats(), ctx.download_accum()
     ctx.close()
     ref, cnt, _ = O.gather_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, rad, 1, c.nb, 64)
-    assert abs(st["evaluations"] - cnt["evaluations"]) <= max(2, 2e-4 * cnt["evaluations"])
+    assert st["evaluations"] == cnt["evaluations"], (st, cnt)
     for k in ("diffuse_shifts", "failed_shifts"):
-        assert abs(st[k] - cnt[k]) <= max(4, 1e-3 * cnt["diffuse_shifts"]), (k, st, cnt)
+        assert abs(st[k] - cnt[k]) <= 2, (k, st, cnt)
     assert cnt["failed_shifts"] > 0
     assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
