@@ -33,6 +33,20 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     "c2": dict(scene="cbox", frame=512, photons=1000000, distinct=16, name="BASELINE configs[1]"),
     "c4": dict(scene="fogroom", frame=1024, photons=4000000, distinct=3, name="BASELINE configs[3]"),
+    # the other configs of BASELINE.json at their stated sizes (parity cases: tests/test_configs_gpu.py), as bench lines
+    # of the same shape (one GPU): `python bench.py --workload c1|c3|c5`
+    "c1": dict(scene="cbox", frame=256, photons=100000, distinct=4, name="BASELINE configs[0]", technique="vpm", samples=40,
+               scale=2.0),
+    "c3": dict(scene="laser", frame=512, photons=2000000, distinct=3, name="BASELINE configs[2]", technique="beams3d", scale=1.0),
+    "c5": dict(scene="laser_in", frame=256, photons=50000, distinct=4, name="BASELINE configs[4]", technique="planes0d",
+               scale=1.0),
+}
+# per technique: kernel the roofline is quoted on, algorithmic bytes per evaluation / per map record
+TECH = {
+    "vpm": dict(label="G-VPM (3D point kernel)", kernel="gather_vpm_kernel", rec=128, what="photons"),
+    "beams3d": dict(label="G-Beams (beam x beam, 3D kernel)", kernel="evaluate_beams2_kernel", rec=160, what="beam segments"),
+    "beams1d": dict(label="G-Beams (beam x beam, 1D kernel)", kernel="evaluate_beams2_kernel", rec=160, what="beam segments"),
+    "planes0d": dict(label="G-Planes (0D kernel)", kernel="gather_planes_kernel", rec=176, what="planes"),
 }
 
 
@@ -55,17 +69,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c4"],
-                    help="auto: c2 (BASELINE configs[1]) on one GPU, c4 (configs[3], strong-sharded) on several")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"],
+                    help="auto: c2 (BASELINE configs[1]) on one GPU, c4 (configs[3], strong-sharded) on several; "
+                         "c1 / c3 / c5: the G-VPM / G-Beams / G-Planes configs at their stated sizes (one GPU)")
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: every rank owns --tile^2 pixels of a (tiles_x*tile) x (tiles_y*tile) frame")
     ap.add_argument("--frame", type=int, default=0, help="pixels per side of the whole frame (strong scaling; 0: the workload's)")
     ap.add_argument("--tile", type=int, default=512, help="--weak: pixels per side of one rank's share")
     ap.add_argument("--photons", type=int, default=0, help="photons per iteration (0: the workload's)")
     ap.add_argument("--scene", default="", help="synthetic scene (default: the workload's)")
-    ap.add_argument("--technique", default="bre3d", choices=["bre3d", "bre2d"],
-                    help="bre3d = the bench line; bre2d: the 2D-kernel BRE of the same path (probe)")
-    ap.add_argument("--scale", type=float, default=1.0, help="initialScaleVolume")
+    ap.add_argument("--technique", default="bre3d", choices=["bre3d", "bre2d", "beams1d"],
+                    help="bre3d = the bench line; bre2d: the 2D-kernel BRE of the same path (probe); beams1d: with "
+                         "--workload c3, the 1D beam kernel instead of the 3D one (probe)")
+    ap.add_argument("--scale", type=float, default=0.0, help="initialScaleVolume (0: the workload's, 1.0 for c2 / c4)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="c1 / c3 / c5: CPU time the all-core oracle sample is sized for (a pilot window sets the size)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct pre-generated iterations, cycled (0: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8, help="iterations of the workload the all-core CPU baseline is timed on")
@@ -85,6 +103,10 @@ def main():
     args = ap.parse_args()
     if args.only_timed:
         args.no_cpu_baseline = args.no_parity = args.no_upload_inclusive = args.no_isolated = True
+    if args.workload in ("c1", "c3", "c5"):
+        return main_technique(args)
+    if args.scale == 0.0:
+        args.scale = 1.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -315,6 +337,284 @@ def main():
         dist.destroy_process_group()
 
 
+def main_technique(args):
+    """--workload c1 | c3 | c5: G-VPM / G-Beams / G-Planes at the size BASELINE.json states, one GPU, the same JSON shape
+    as the G-BRE line: a step = one SPPM iteration of the hot path (device build + camera-beam ordering + gather/shift
+    kernels + the fold into the film) on inputs already in HBM."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != 1 or args.gpus != 1:
+        raise SystemExit("--workload c1 / c3 / c5 are one-GPU lines (the sharded workload is c4)")
+    gvpm_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("GVPM_")}
+    if "GVPM_DEBUG_FLAGS" in gvpm_env:
+        raise SystemExit("bench.py refuses to run with GVPM_DEBUG_FLAGS set (development switches change the measured work)")
+    import torch
+    from gvpm_amd import abi, hip, metrics
+    from gvpm_amd.host import SynthScene
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the gather path)")
+    torch.cuda.set_device(0)
+    wl = WORKLOADS[args.workload]
+    tech = "beams1d" if (args.technique == "beams1d" and args.workload == "c3") else wl["technique"]
+    T = TECH[tech]
+    scene = args.scene or wl["scene"]
+    nrec = args.photons or wl["photons"]
+    W = H = args.frame or wl["frame"]
+    scale = args.scale or wl["scale"]
+    sc = SynthScene(scene, W, H)
+    p = sc.params()
+    p.initial_scale_volume = scale
+    nsamp = wl.get("samples", 0)
+    if tech == "vpm":
+        p.vol_technique = abi.GVPM_DISTANCE
+        p.nb_camera_samples = nsamp
+    elif tech == "beams3d":
+        p.vol_technique = abi.GVPM_BEAM_BEAM_3D_OPTIMIZED
+    elif tech == "beams1d":
+        p.vol_technique = abi.GVPM_BEAM_BEAM_1D
+        p.use_shift_null = 0
+    else:
+        p.vol_technique = abi.GVPM_VOL_PLANE0D
+        p.use_shift_null = 0  # GPMConfig::load rejects useShiftNull for planes (gvpm_struct.h:310-313)
+        p.min_depth = 2       # gvpm.cpp:164-175
+    m, tris = sc.medium(), sc.triangles()
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*tris)
+    ctx.upload_medium(m)
+
+    K, Wu = args.steps, args.warmup
+    ndist = max(1, min(args.distinct or wl["distinct"], max(K, Wu)))
+    keep, inputs, host0 = [], [], []
+
+    def dev(a):
+        t = torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else np.ascontiguousarray(a)).cuda()
+        keep.append(t)
+        return t.data_ptr()
+
+    def dev_soa(ph):
+        soa = abi.PhotonSoA()
+        for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
+            setattr(soa, k, dev(getattr(ph, k)))
+        soa.n = ph.n
+        return soa
+
+    for i in range(ndist):
+        it = i + 1
+        rec = {}
+        if tech == "vpm":
+            ph, nb = sc.shoot_photons(it, nrec)
+            rays, smp = sc.camera_beams_and_vpm_samples(it, nsamp)
+            rec.update(host=(ph, nb, rays, smp), soa=dev_soa(ph), n=ph.n, nb=nb, smp=dev(smp.view(np.uint8).reshape(-1)),
+                       nsmp=smp.shape[0])
+        elif tech in ("beams3d", "beams1d"):
+            ph, en, nb = sc.shoot_beams(it, nrec)
+            rays = sc.camera_beams(it)
+            rec.update(host=(ph, en, nb, rays), soa=dev_soa(ph), n=ph.n, nb=nb, en=dev(np.ascontiguousarray(en, np.float32)))
+        else:
+            ph, en, w1, l1, nb = sc.shoot_planes(it, nrec)
+            rays = sc.camera_beams(it)
+            rec.update(host=(ph, w1, l1, nb, rays), soa=dev_soa(ph), n=ph.n, nb=nb, w1=dev(np.ascontiguousarray(w1, np.float32)),
+                       l1=dev(np.ascontiguousarray(l1, np.float32)))
+        rec["rays"] = dev(rays.view(np.uint8).reshape(-1))
+        rec["nsets"] = rays.shape[0]
+        if i == 0:
+            host0.append(rec["host"])
+        rec.pop("host")
+        inputs.append(rec)
+    torch.cuda.synchronize()
+
+    def step(it):
+        r = inputs[(it - 1) % ndist]
+        if tech == "vpm":
+            ctx.upload_photons_dev(r["soa"])
+        elif tech in ("beams3d", "beams1d"):
+            ctx.upload_beams_dev(r["soa"], r["en"])
+        else:
+            ctx.upload_planes_dev(r["soa"], r["w1"], r["l1"])
+        ctx.upload_camera_beams_dev(r["rays"], r["nsets"])
+        if tech == "vpm":
+            ctx.upload_vpm_samples_dev(r["smp"], r["nsmp"])
+        ctx.gather(it, r["nb"])
+
+    for it in range(1, Wu + 1):
+        step(it)
+    ctx.synchronize()
+    ctx.reset()
+    for ph_ in (0, 1, 2):
+        ctx.phase_time(ph_)
+    ev0 = ctx.stats()["evaluations"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, K + 1):
+        step(it)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    evals = st["evaluations"] - ev0
+    kms, klaunches = ctx.kernel_time()
+    trav_ms, build_ms = ctx.phase_time(1)[0], ctx.phase_time(2)[0]
+    nsets_avg = float(np.mean([x["nsets"] for x in inputs]))
+    nrec_avg = float(np.mean([x["n"] for x in inputs]))
+    P = W * H
+    # algorithmic bytes per launch of the dominant kernel (SURVEY 8d / BASELINE.md convention: record bytes per
+    # evaluation + 320 B per camera-beam set + 108 B per pixel + one mandatory read of every map record; G-VPM: + 16 B per
+    # camera sample)
+    bytes_alg = T["rec"] * (evals / K) + 320.0 * nsets_avg + 108.0 * P + T["rec"] * nrec_avg
+    if tech == "vpm":
+        bytes_alg += 16.0 * float(np.mean([x["nsmp"] for x in inputs]))
+    achieved = bytes_alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    sha = csrc_sha()
+    traffic, traffic_src = None, None
+    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)), reverse=True):
+        try:
+            d = json.load(open(tj))
+            meta = d.get("_meta", {})
+            want = dict(technique=tech, scene=scene, scale=scale, frame=[W, H], photons=nrec, n_gpus=1, csrc_sha=sha)
+            if all(meta.get(k) == v for k, v in want.items()):
+                traffic = d[T["kernel"]]["hbm_bytes_per_launch"]
+                traffic_src = f"{os.path.relpath(tj, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/profile.sh)"
+                break
+        except (KeyError, ValueError, OSError):
+            pass
+    is_wl = scene == wl["scene"] and nrec == wl["photons"] and W == wl["frame"]
+    out = {
+        "metric": "photon gather+shift evaluations per second (%s)" % T["label"],
+        "value": evals / elapsed / 1e6, "unit": "Mevals/s", "n_gpus": 1, "steps": K, "warmup": Wu,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{wl['name'] if is_wl else 'custom'}: S-{scene} + homogeneous medium, {T['label']}, {W}x{H} frame, "
+                        f"{nrec} {T['what']}/iter" + (f", {nsamp} camera samples/pixel" if nsamp else "")
+                        + f", {K} SPPM iters, initialScaleVolume {scale}",
+            "technique": tech, "scene": scene, "frame": [W, H], "pixels_per_gpu": P, "records_per_iter": nrec,
+            "iterations": K, "sharding": "none", "evaluations": float(evals), "evals_per_iter_per_gpu": evals / K,
+            "tests_per_iter_per_gpu": st["candidates"] / K, "env": gvpm_env, "csrc_sha": sha,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": T["kernel"], "kernel_avg_ms": kms,
+            "launches": klaunches, "traverse_avg_ms": trav_ms, "build_avg_ms": build_ms,
+            "bytes_alg_per_launch": bytes_alg,
+            "bytes_alg_formula": "%d*H + 320*B + 108*P + %d*N%s" % (T["rec"], T["rec"], " + 16*S" if tech == "vpm" else ""),
+            "note": "one stream: the step's kernels run one after the other (build, traversal / plan, evaluation); "
+                    "kernel_avg_ms brackets the dominant kernel alone (HIP events on its stream)",
+        },
+        "stats": st,
+    }
+    if not args.no_parity:
+        out.update(parity_technique(hip, metrics, tech, p, m, tris, host0[0], W, H))
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_technique(tech, p, m, tris, host0[0], W, H, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def _window(rays, x0, y0, w, h):
+    px = rays["pixel"][:, 0] & 0xFFFF
+    py = rays["pixel"][:, 0] >> 16
+    return (px >= x0) & (px < x0 + w) & (py >= y0) & (py < y0 + h)
+
+
+def _sub_vpm(rays, smp, sel):
+    remap = np.full(len(rays), -1, np.int64)
+    remap[np.nonzero(sel)[0]] = np.arange(int(sel.sum()))
+    keepm = remap[smp["set"]] >= 0
+    s2 = smp[keepm].copy()
+    s2["set"] = remap[s2["set"]]
+    return np.ascontiguousarray(rays[sel]), s2
+
+
+def parity_technique(hip, metrics, tech, p, m, tris, first, W, H):
+    """Step 1 of the workload on a centred 24x24-pixel window (the full map) against the fp64 oracle: evaluation counts
+    and the per-pixel L2 of the 27 accumulators over the mean luminance."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    w = 24
+    x0, y0 = (W - w) // 2 // 4 * 4, (H - w) // 2 // 4 * 4
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*tris)
+    ctx.upload_medium(m)
+    if tech == "vpm":
+        ph, nb, rays, smp = first
+        wr, ws = _sub_vpm(rays, smp, _window(rays, x0, y0, w, w))
+        ctx.upload_photons(ph); ctx.upload_camera_beams(wr); ctx.upload_vpm_samples(ws)
+        ctx.gather(1, nb)
+        ref, _, _, cnt, _ = O.gather_vpm(p, m, tris, ph, wr, ws, 64, use_accel=True)
+    elif tech in ("beams3d", "beams1d"):
+        ph, en, nb, rays = first
+        wr = np.ascontiguousarray(rays[_window(rays, x0, y0, w, w)])
+        ctx.upload_beams(ph, en); ctx.upload_camera_beams(wr)
+        rad = ctx.radius()
+        ctx.gather(1, nb)
+        ref, cnt, _ = O.gather_beams(p, m, tris, ph, en, wr, rad, 1, nb, 64, use_accel=True)
+    else:
+        ph, w1, l1, nb, rays = first
+        wr = np.ascontiguousarray(rays[_window(rays, x0, y0, w, w)])
+        ctx.upload_planes(ph, w1, l1); ctx.upload_camera_beams(wr)
+        ctx.gather(1, nb)
+        ref, cnt, _ = O.gather_planes(p, m, tris, ph, w1, l1, wr, 1, nb, 64, use_accel=True)
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    if tech == "vpm":
+        ref = ref / 1.0  # plain sums on both sides (the film divides by the emitted count)
+    win = (slice(y0, y0 + w), slice(x0, x0 + w))
+    lum = max(ref[win][..., 0:3].mean(), 1e-30)
+    l2 = metrics.l2_over_luminance(acc[win], ref[win], lum)
+    return {"parity_l2": l2,
+            "parity": {"what": f"step 1, centred {w}x{w}-pixel window, full map, fp64 oracle through the reference's accelerator",
+                       "evaluations_device": st["evaluations"], "evaluations_oracle": cnt["evaluations"],
+                       "l2_accumulators": l2, "bar": "L2 / mean luminance < 1e-3 (BASELINE.md), evaluation counts equal"}}
+
+
+def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
+    """The oracle (fp32, fast-math) through the REFERENCE's accelerator (kd-tree for G-VPM, SubBeamBVH for G-Beams,
+    PhotonPlaneBVH for G-Planes; the serial build included, as the reference pays it) on this box's host cores: a pilot
+    window sets the size of the timed sample (about `budget_s` of CPU work), iteration 1 of the same workload, the full
+    map.  Reported, not targeted."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
+
+    def run(rows, threads):
+        tm = {}
+        y0 = max(0, (H - rows) // 2)
+        if tech == "vpm":
+            ph, nb, rays, smp = first
+            wr, ws = _sub_vpm(rays, smp, _window(rays, 0, y0, W, rows))
+            _, _, _, cnt, s = O.gather_vpm(p, m, tris, ph, wr, ws, 32, use_accel=True, threads=threads, fast=True, timing=tm)
+        elif tech in ("beams3d", "beams1d"):
+            ph, en, nb, rays = first
+            wr = np.ascontiguousarray(rays[_window(rays, 0, y0, W, rows)])
+            _, cnt, s = O.gather_beams(p, m, tris, ph, en, wr, r, 1, nb, 32, use_accel=True, threads=threads, fast=True, timing=tm)
+        else:
+            ph, w1, l1, nb, rays = first
+            wr = np.ascontiguousarray(rays[_window(rays, 0, y0, W, rows)])
+            _, cnt, s = O.gather_planes(p, m, tris, ph, w1, l1, wr, 1, nb, 32, use_accel=True, threads=threads, fast=True, timing=tm)
+        return cnt["evaluations"], s, tm.get("build_s", 0.0), wr.shape[0]
+
+    # pilot: a band of 8 pixel rows through the middle of the frame
+    ev, s, b, _ = run(min(8, H), cores)
+    gather_rate = ev / max(s - b, 1e-6)
+    rows = H
+    if gather_rate > 0:
+        # evaluations per row vary over the frame: size by the pilot's rows, cap at the frame
+        per_row = max(ev / min(8, H), 1.0)
+        rows = int(min(H, max(8, (budget_s * gather_rate) / per_row)))
+    ev, s, b, nsets = run(rows, cores)
+    out = {"value": ev / s / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
+           "build_s": b, "gather_s": s - b, "gather_only_value": ev / max(s - b, 1e-9) / 1e6,
+           "sample": f"iteration 1, the middle {rows} of {H} pixel rows ({nsets} beam sets), the full map through the "
+                     f"reference's accelerator; its serial build ({b:.2f} s) + the gather on {cores} threads ({s - b:.2f} s), "
+                     f"{ev} evaluations"}
+    ev1, s1, b1, n1 = run(min(2, H), 1)
+    out["one_thread"] = {"value": ev1 / s1 / 1e6, "unit": "Mevals/s", "cores": 1, "build_s": b1, "gather_s": s1 - b1,
+                         "sample": f"iteration 1, the middle {min(2, H)} pixel rows ({n1} beam sets), build included "
+                                   f"({s1:.2f} s, {ev1} evaluations)"}
+    return out
+
+
 def upload_inclusive(hip, p, m, tris, host0, K, device):
     """The same K steps fed from HOST memory through gvpm_upload_* / gvpm_prefetch_*: pinned buffers (one packed block per
     photon set, gvpm_host_alloc_photons), copies on the handle's copy stream, the copy of step N+1 in flight while step N
@@ -412,11 +712,14 @@ def cpu_baseline(p, m, tris, host0, W, H):
     import oracle_lib as O
     r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
     cores = os.cpu_count() or 1
-    evals, secs, nsets = 0, 0.0, 0
+    evals, secs, nsets, build = 0, 0.0, 0, 0.0
     for ph, nb, rays in host0:
-        _, cnt, s = O.gather_bre(p, m, tris, ph, rays, r, 1, nb, precision=32, use_accel=True, threads=cores, fast=True)
+        tm = {}
+        _, cnt, s = O.gather_bre(p, m, tris, ph, rays, r, 1, nb, precision=32, use_accel=True, threads=cores, fast=True,
+                                 timing=tm)
         evals += cnt["evaluations"]
         secs += s
+        build += tm["build_s"]
         nsets += rays.shape[0]
     # one thread: iteration 1, a window sized for ~5-10 s (the whole 512x512 frame of C2)
     ph, nb, rays = host0[0]
@@ -425,15 +728,20 @@ def cpu_baseline(p, m, tris, host0, W, H):
     px = rays["pixel"][:, 0] & 0xFFFF
     py = rays["pixel"][:, 0] >> 16
     sel = (px >= x0) & (px < x0 + w1) & (py >= y0) & (py < y0 + w1)
+    tm1 = {}
     _, cnt1, s1 = O.gather_bre(p, m, tris, ph, np.ascontiguousarray(rays[sel]), r, 1, nb, precision=32, use_accel=True, threads=1,
-                               fast=True)
+                               fast=True, timing=tm1)
     return {
         "value": evals / secs / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
+        # the kd-tree + BVH build is serial in the reference (gvpm.cpp:450-454) and in the port: the split says how much of
+        # the all-core figure is that one thread
+        "build_s": build, "gather_s": secs - build, "gather_only_value": evals / max(secs - build, 1e-9) / 1e6,
         "sample": f"{len(host0)} iterations (each its own {host0[0][0].n}-photon map), the full {W}x{H} frame "
                   f"({nsets} beam sets in all), kd-tree + BVH builds included ({secs:.2f} s, {evals} evaluations); every "
                   f"iteration at the INITIAL radius (the GPU's radius shrinks with the iteration: its later steps find fewer "
                   f"photons per beam)",
         "one_thread": {"value": cnt1["evaluations"] / s1 / 1e6, "unit": "Mevals/s", "cores": 1,
+                       "build_s": tm1["build_s"], "gather_s": s1 - tm1["build_s"],
                        "sample": f"iteration 1, centred {w1}x{w1}-pixel window ({int(sel.sum())} beam sets), the 1-thread "
                                  f"kd-tree + BVH build of the full {ph.n}-photon map included ({s1:.2f} s, "
                                  f"{cnt1['evaluations']} evaluations)"},

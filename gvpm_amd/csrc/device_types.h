@@ -106,6 +106,7 @@ struct GatherArgs {
   float kernelRadius;
   float subLen;              // target sub-beam length used by the build
   uint32_t nbeams;
+  const float2 *beamClear;   // per beam {cosA0, M1}: the free cone of its reconnections (grid_build.hip, beam_near_kernel)
   // G-VPM only
   const gvpm_vpm_sample *samples;
   uint32_t nsamples;

@@ -165,6 +165,23 @@ __device__ __forceinline__ bool rayIntersect1D(const BeamD &b, double radius, co
   return true;
 }
 
+// 1D kernel: WHICH sub-beam evaluates a (camera ray, beam) pair the reference's test accepts.  The reference asks
+// every sub-beam whose box the ray meets for `tmin < v <= tmax` with ITS v -- float dot products of absolute positions
+// divided by d1.d2 (beams_struct.h:275-290): for near-perpendicular lines (|d1.d2| < 1e-4: 3e-4 of C3's pairs, whose
+// camera rays are horizontal and beams vertical) that v is off by whole sub-beams, up to anything, and lands in a
+// sub-beam far from where the lines meet -- which the reference evaluates or not depending on whether its BVH happens to
+// visit that box.  The accel-independent statement (the reference's own ENoAccel loop, pm/beams.h:289-294, and the
+// oracle's): the pair is evaluated iff the test over the WHOLE beam accepts it, with the reference's v and w.  Here the
+// sub-beam that contains the GEOMETRIC closest approach (well conditioned, fp64, the same for every sub-beam that asks)
+// speaks for the beam; it is always among the traversal's candidates when the lines pass within the radius.
+__device__ __forceinline__ bool beamOwner1D(const BeamD &b, const RayD &cam, uint32_t sub, uint32_t nSub, double tmin,
+                                            double tmax) {
+  const d3 op = cam.o - b.p1;
+  const double c12 = dot(cam.d, b.dir);
+  const double vg = (dot(op, b.dir) - c12 * dot(op, cam.d)) / (1.0 - c12 * c12);
+  return (sub == 0u || vg > tmin) && (sub + 1u >= nSub || vg <= tmax);
+}
+
 // BeamKernelRecord::eval, shift_volume_beams.h:157-290 (short beams)
 __device__ __forceinline__ void krecEval(const GatherArgs &a, const BeamD &b, const RayD &cam, double tmin, double tmax,
                                          double uv, double uw, int technique, KRecD &k) {
@@ -437,11 +454,11 @@ __device__ __forceinline__ bool beamPrefilter(const RayReg &base, f3 C, f3 bd, f
   const float half = 0.5f * ls;
   float tau;
   if (technique == GVPM_BEAM_BEAM_1D) {
-    // tmin < v <= tmax; the reference derives v from float dot products of absolute positions divided by d1.d2
-    // (beams_struct.h:275-290): its own rounding error grows as 1/|d1.d2|, so near-perpendicular pairs go through
-    if (fabsf(bdd) < 0.05f) return true;
+    // the sub-beam that contains the geometric closest approach speaks for the beam (beamOwner1D; the first one also
+    // for an approach before the beam's origin -- one beyond either end can only be accepted through the reference's
+    // rounding, and then by no candidate of this traversal: the bounded difference DESIGN.md states)
     tau = tau0;
-    return tau > -half - delta && tau < half + delta;
+    return tau < half + delta && (sub == 0u || tau > -half - delta);
   }
   const float hw = fsqrt(fmaxf(r * r - dmin2, 0.f) * inv);
   float tN = tau0 - hw, tF = tau0 + hw;
@@ -499,7 +516,12 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
   kRec.radius = (double)a.kernelRadius;
   kRec.v = kRec.w = kRec.pdfKernel = kRec.pdfEdgeFailure = kRec.u = kRec.weightKernel = kRec.beamTrans = 0;
   kRec.contrib = mkd(0, 0, 0);
-  krecEval(a, b, cam, tmin, tmax, uv, uw, technique, kRec);
+  if (technique == GVPM_BEAM_BEAM_1D) {
+    if (!beamOwner1D(b, cam, sub, nSub, tmin, tmax)) return false;
+    krecEval(a, b, cam, 0.0, INFINITY, uv, uw, technique, kRec);
+  } else {
+    krecEval(a, b, cam, tmin, tmax, uv, uw, technique, kRec);
+  }
   if (!kRec.valid) return false;
   const d3 eyeB = tod(base.eye);
   const d3 baseContrib = mkd(eyeB.x * kRec.contrib.x, eyeB.y * kRec.contrib.y, eyeB.z * kRec.contrib.z) * kRec.weightKernel;
@@ -631,7 +653,8 @@ static __device__ __noinline__ bool beamKernelExact(f3 p1f, f3 p2f, f3 of, f3 df
   vOut = wOut = pdfOut = uOut = 0.0;
   if (technique == GVPM_BEAM_BEAM_1D) {
     double u, v, w, st;
-    if (!rayIntersect1D(b, (double)radius, cam, tmin, tmax, u, v, w, st)) return false;
+    if (!beamOwner1D(b, cam, sub, nSub, tmin, tmax)) return false;
+    if (!rayIntersect1D(b, (double)radius, cam, 0.0, b.len, u, v, w, st)) return false;
     vOut = v; wOut = w; pdfOut = st; uOut = u;
     return true;
   }
@@ -670,9 +693,15 @@ static __device__ __noinline__ bool beamKernelExact(f3 p1f, f3 p2f, f3 of, f3 df
 constexpr uint32_t SCENE_LDS_TRIS = 128;
 
 // shiftBeamDiffuse + diffuseReconnectionPhotonBeam (shift_volume_beams.cpp:410-539, shift_diffuse.cpp:136-268) in
-// the local frame.  newPos: the offset position relative to the local origin; p1rel = p1 - origin.
-// visibility over the whole new beam [Epsilon, dist] (shift_volume_beams.cpp:420-426): the occluders listed near the
-// beam (beam_near_kernel, grid_build.hip), or all of them when the list overflowed / the scene is large
+// the local frame.
+//
+// Visibility over the whole new beam [Epsilon, dist] (shift_volume_beams.cpp:420-426): the occluders listed near the
+// beam (beam_near_kernel, grid_build.hip), or all of them when the list overflowed / the scene is large.
+// One loop for the lanes that walk their beam's list and the lanes whose list overflowed (every occluder).  In a wave of 64
+// unrelated segments some lane's triangle always passes the plane-side early-out, so every trip (the longest list:
+// 16-19) runs the full Moeller-Trumbore test; marking the crossed planes first and testing only those in a second loop
+// was measured at C3: 30.0 ms against 22.6 (two decodes and two rounds of LDS reads per entry).  What pays is not
+// entering the loop: beamShift2 sends only the reconnections outside their beam's free cone through it.
 __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const BeamF &b, const float4 *ldsTri, f3 nd, float dist) {
   const BeamNearFmt fmt = beamNearFmt(a.ntri);  // (wave-uniform)
   const bool ovf = beamNearOverflow(fmt, b.nl0, b.nl2);
@@ -681,49 +710,48 @@ __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const Bea
     if (ovf) return anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist);
     return nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist));
   }
-  // occluders in LDS: ONE loop for the lanes that walk their beam's list and the lanes whose list overflowed (every
-  // occluder).  A loop for each, one after the other, cost the wave cap + ntri trips; this one costs max(cap, ntri).
   const f3 o = b.p1;
   const float mint = a.cfg.epsilon, maxt = dist;
   const float margin = planeSideMargin(a.triAbs1, o, maxt);
-  bool hit = false;
-  bool more = true;
+  {
+    bool hit1 = false;
+    bool more1 = true;
 #pragma unroll 1
-  for (uint32_t k = 0;; ++k) {
-    uint32_t i;
-    if (ovf) {
-      i = k;
-      more = k < a.ntri;
-    } else {
-      i = k < fmt.cap ? beamNearEntry(fmt, b.nl0, b.nl1, b.nl2, k) : fmt.mask;
-      more = more && i != fmt.mask;
+    for (uint32_t k = 0;; ++k) {
+      uint32_t i;
+      if (ovf) {
+        i = k;
+        more1 = k < a.ntri;
+      } else {
+        i = k < fmt.cap ? beamNearEntry(fmt, b.nl0, b.nl1, b.nl2, k) : fmt.mask;
+        more1 = more1 && i != fmt.mask;
+      }
+      if (__ballot(more1) == 0ull) break;
+      if (more1) {
+        const float4 t0 = ldsTri[3 * i], t1 = ldsTri[3 * i + 1], t2 = ldsTri[3 * i + 2];
+        const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
+        const float s0 = dot(nrm, o - v0), sd = dot(nrm, nd);
+        if (!planeSideMiss(s0, sd, mint, maxt, margin) && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
+          hit1 = true;
+      }
     }
-    if (__ballot(more) == 0ull) break;
-    if (more) {
-      const float4 t0 = ldsTri[3 * i], t1 = ldsTri[3 * i + 1], t2 = ldsTri[3 * i + 2];
-      const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
-      const float s0 = dot(nrm, o - v0), sd = dot(nrm, nd);
-      // (both ends of the segment strictly on one side of the triangle's plane: nothing to intersect, see nearListHit)
-      if (!planeSideMiss(s0, sd, mint, maxt, margin) && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
-        hit = true;
-    }
+    return hit1;
   }
-  return hit;
 }
 
-// kV = kRec.v, pdfKernelAndDist = kRec.pdfEdgeFailure * kRec.pdfKernel
-template <int B>
-__device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const BeamF &b, f3 shEye, float sMIS,
-                                                   const LocalRay &sr, float shiftW,
-                                                   float kV, float pdfKernelAndDist, f3 newPos, f3 p1rel, int technique,
-                                                   const float4 *ldsTri, f3 &shiftedFlux, bool &ok) {
+// what the reconnections of one pair share (diffuseReconnectionPhotonBeam's base side, the medium up to w)
+struct BeamRecPair {
+  float pdfBasePos;   // parentPdf * |p1 - p2|^2 [/ |n_end . d|] / v^2
+  float trW;          // transmittance of the camera ray up to w (the shifted rays keep w)
+  float pdfKernelAndDist;
+};
+
+// one reconnection once its new beam p1 -> newPos is known to be unoccluded: nd / dist its direction and length
+__device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF &b, const BeamRecPair &pr, f3 shEye, float sMIS,
+                                                const LocalRay &sr, f3 newPos, f3 nd, float dist, int technique,
+                                                f3 &shiftedFlux, bool &ok) {
   ok = false;
   shiftedFlux = mk3(0.f);
-  f3 nd = newPos - p1rel;
-  const float dist2 = dot(nd, nd);
-  const float dist = fsqrt(dist2);
-  nd = nd * frcp(dist);
-  if (beamShadowBlocked(a, b, ldsTri, nd, dist)) return 1.f;
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
   f3 thr;
   float pdfValueSA;
@@ -741,19 +769,15 @@ __device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const Be
     thr = mk3(INV_PI_F * dp);
     pdfValueSA = INV_PI_F * dp;
   }
-  const float GOpNew = frcp(dist2);
+  const float GOpNew = frcp(dist * dist);
   float sPdf = pdfValueSA * GOpNew;
   thr = thr * GOpNew;
-  // pdf of the base position from the parent: parentPdf * |p1 - p2|^2 [/ |n_end . d|] / v^2
-  float pdfBasePos = b.parentPdf * (b.len * b.len);
-  if (b.endOnSurface) pdfBasePos = fdiv(pdfBasePos, fabsf(dot(b.endN, b.bd)));
-  pdfBasePos *= frcp(kV * kV);
-  if (pdfBasePos == 0.f) return 1.f;
-  thr = thr * fdiv(b.parentRR, pdfBasePos);
+  if (pr.pdfBasePos == 0.f) return 1.f;
+  thr = thr * fdiv(b.parentRR, pr.pdfBasePos);
   if (GVPM_PF_EDGE_IN_MEDIUM(b.flags)) {
     const MRecF m = mediumEvalF(a.med, dist);
     sPdf *= m.pdfFailure;
-    thr = thr * fdiv(m.tr, pdfKernelAndDist);
+    thr = thr * fdiv(m.tr, pr.pdfKernelAndDist);
   }
   if (sPdf == 0.f) return 1.f;
   // BeamKernelRecord::kernelPDF of the new beam p1 -> newPos against the shifted ray (shift_volume_beams.h:300-336)
@@ -775,13 +799,12 @@ __device__ __forceinline__ float shiftBeamDiffuseF(const GatherArgs &a, const Be
   }
   if (shiftKernelPDF == 0.f) return 1.f;
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
-  const MRecF mS = mediumEvalF(a.med, shiftW);
-  const float ph = phaseEval(a.med.g, -nd, -sr.d) * mS.tr;
+  const float ph = phaseEval(a.med.g, -nd, -sr.d) * pr.trW;
   shiftedFlux = b.prefixW * thr * sigS * shEye * ph;
   ok = true;
   float w = 0.5f;
   if (a.cfg.use_mis) {
-    const float basePdf = pdfBasePos * pdfKernelAndDist;
+    const float basePdf = pr.pdfBasePos * pr.pdfKernelAndDist;
     const float offsetPdf = shiftKernelPDF * sPdf;
     if (offsetPdf == 0.f || basePdf == 0.f) {
       ok = false;
@@ -826,11 +849,15 @@ struct BeamP1 {
   float rr, tc;
   uint32_t edge, pix, st, id;
 };
-// a prepared reconnection: 36 bytes
-struct BeamQ {
-  uint32_t id;  // beam | sub << 24
-  float4 p;     // offset position (local), kRec.v
-  float4 s;     // kRec.w, kRec.pdfEdgeFailure * kRec.pdfKernel, rr * weightKernel * sc, bits(ray | shift << 8)
+// a reconnection to do (phase 2): 28 bytes -- what phase 2 cannot rebuild from the beam's record and the ray tile.
+// (Round 3 tried one entry per PAIR with a mask of its shifts, the pair's record and frame rebuilt once and the new beams of
+// its shifts tested together against each listed triangle: 30.5 ms against 23.0 at C3 -- a pair has 1.8 reconnections on
+// average, not 0 or 4, so the per-shift work ran at 46 % of the wave's width.)
+struct BeamPQ {
+  uint32_t id;    // beam | sub << 24
+  uint32_t meta;  // ray | shift << 8
+  float4 k;       // kRec.v - tc, kRec.w - (camera foot parameter), kRec.pdfEdgeFailure * kRec.pdfKernel, rr * weightKernel * sc
+  float u;        // kRec.u (the 1D kernel's distance between the lines)
 };
 
 // filters + kernel record + base contribution; false: the pair produces nothing
@@ -924,9 +951,6 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
     // fp64 transcription (beamKernelExact), so the evaluated set is the reference's.
     const float z0 = (float)((double)cam.mint - cam.s0), z1 = (float)((double)cam.maxt - cam.s0);
     const float radSqr = r * r;
-    const float bandT = 2.f * band0 + 2e-6f * (tc + ls + r);              // beam parameters (absolute: tc + tau)
-    const float bandZ = 2.f * band0 + 2e-6f * r + 4e-7f * (fabsf(z0) + fabsf(z1));  // camera parameters from the foot point
-    const float bandW = 2.f * band0 + 2e-6f * r + 4e-7f * base.len;
     bool amb = !(sin2 > 1e-6f), rej = false;
     // the view line is the beam (origin O, direction bd), the cylinder the camera ray: rel = O - foot = D0
     const float rzc = dot(cam.D0, base.d);
@@ -934,9 +958,16 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
     const float rel2 = dot(cam.D0, cam.D0);
     const float Cq = rel2 - rzc * rzc - radSqr;
     const float disc = Bh * Bh - sin2 * Cq;
-    amb |= fabsf(disc) <= 2e-5f * (Bh * Bh + sin2 * (rel2 + radSqr));
+    // rounding of the discriminant (a bound: ~8 ulps of its largest term); a pair within 32 of them of tangency goes to
+    // the transcription, and for the others the root carries errDisc / (2 sqrt(disc)): near tangency the chord ends move
+    // by much more than the operands' own rounding (measured with the audit build: 100 x the band that ignored it)
+    const float errDisc = 6e-7f * (Bh * Bh + sin2 * (rel2 + radSqr));
+    amb |= fabsf(disc) <= 32.f * errDisc;
     rej |= !(disc > 0.f);
     const float sq = fsqrt(fmaxf(disc, 0.f));
+    const float tErr = fdiv(16.f * errDisc, fmaxf(sq * sin2, 1e-30f));
+    const float bandT = 6.f * band0 + 3e-6f * (tc + ls + r) + tErr;       // beam parameters (absolute: tc + tau)
+    const float bandZ = bandT + 2e-6f * r + 4e-7f * (fabsf(z0) + fabsf(z1));  // camera parameters from the foot point
     const float qq = Bh < 0.f ? (sq - Bh) : -(Bh + sq);
     float tN = fdiv(qq, fmaxf(sin2, 1e-12f)), tF = fdiv(Cq, qq);
     if (tN > tF) { const float t = tN; tN = tF; tF = t; }
@@ -947,6 +978,7 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
       rej |= tN > tHi || tF < tLo;
     }
     // the caps of the camera ray's cylinder
+    float bandTc = bandT;  // the band of tNear once it has been moved to a cap
     {
       const float zN = rzc + bdd * tN, zF = rzc + bdd * tF;
       amb |= fabsf(zN - z0) <= bandZ || fabsf(zN - z1) <= bandZ;
@@ -955,30 +987,37 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
       if (below || above) {
         amb |= fabsf(zF - zc) <= bandZ;
         rej |= below ? zF < z0 : zF > z1;
+        // the entry point through a cap divides by the beam's slope along the ray, zN - zF = (d_beam . d_ray)(tN - tF): the
+        // error of the z's (the large ray parameters behind z0 / z1) comes back multiplied by chord / |zN - zF|
+        const float dz = fabsf(zN - zF);
+        bandTc += (tF - tN) * fdiv(2.f * bandZ, fmaxf(dz, 1e-30f));
         tN = tN + (tF - tN) * fdiv(zN - zc, zN - zF);
       }
     }
     // ownership: tmin < tNear < tmax, or the first sub-beam when the ray's cylinder contains the beam's origin
     {
       const float tNa = tc + tN;
-      amb |= fabsf(tNa - tmin) <= bandT || fabsf(tNa - tmax) <= bandT || (sub == 0u && fabsf(tNa) <= bandT);
+      amb |= fabsf(tNa - tmin) <= bandTc || fabsf(tNa - tmax) <= bandTc || (sub == 0u && fabsf(tNa) <= bandTc);
       rej |= !((tNa < 0.f && tmin <= eps) || (tNa > tmin && tNa < tmax));
     }
     k.tauV = tN + (tF - tN) * uv;
     k.v = tc + k.tauV;
     k.pdfKernel = frcp(fmaxf(tF - tN, 0.0001f));
-    amb |= fabsf(k.v) <= bandT || fabsf(k.v - b.len) <= bandT;
+    amb |= fabsf(k.v) <= bandTc || fabsf(k.v - b.len) <= bandTc;
     rej |= k.v < 0.f || k.v > b.len;
     f3 perp = cam.D0 + (b.bd - base.d * bdd) * k.tauV;
     perp = perp - base.d * dot(perp, base.d);
     const float distSqr = dot(perp, perp);
-    amb |= fabsf(distSqr - radSqr) <= 2e-5f * radSqr;
+    // the kernel centre moves with tauV's error at the beam's slope across the ray
+    const float errD2 = 4e-6f * radSqr + 2.f * r * fsqrt(sin2) * bandTc;
+    amb |= fabsf(distSqr - radSqr) <= 8.f * errD2;
     rej |= distSqr >= radSqr;
     const float deltaT = fsqrt(fmaxf(0.f, radSqr - distSqr));
     // distToProj = s0 + dot(D0, d) + tauV * (b.d): the kernel centre's parameter on the camera ray
     k.sigmaW = (rzc + k.tauV * bdd) - deltaT + 2.f * deltaT * uw;
     k.w = (float)(cam.s0 + (double)k.sigmaW);
     k.pdfKernel *= frcp(fmaxf(2.f * deltaT, 0.0001f));
+    const float bandW = bandTc + fdiv(errD2, fmaxf(deltaT, 1e-30f)) + 2e-6f * r + 4e-7f * base.len;
     amb |= fabsf(k.w - cam.mint) <= bandW || fabsf(k.w - cam.maxt) <= bandW;
     rej |= k.w < cam.mint || k.w > cam.maxt;
 #ifdef GVPM_BEAMS_AUDIT
@@ -997,15 +1036,22 @@ __device__ __forceinline__ bool beamBase(const GatherArgs &a, LDS &s, uint32_t i
         }
       }
       if (!amb && !rej && ex) {
-        atomicMax(&gvpmAuditRatio[0], __float_as_uint(fabsf((float)((double)tc + (double)tN - dbg[1])) / bandT));
-        atomicMax(&gvpmAuditRatio[1], __float_as_uint(fabsf((float)((double)k.v - vD)) / bandT));
+        atomicMax(&gvpmAuditRatio[0], __float_as_uint(fabsf((float)((double)tc + (double)tN - dbg[1])) / bandTc));
+        atomicMax(&gvpmAuditRatio[1], __float_as_uint(fabsf((float)((double)k.v - vD)) / bandTc));
+        atomicMax(&gvpmAuditRatio[5], __float_as_uint(fabsf((float)((double)tc + (double)tF - dbg[2])) / bandT));
         atomicMax(&gvpmAuditRatio[2], __float_as_uint(fabsf((float)((double)k.w - wD)) / bandW));
         atomicMax(&gvpmAuditRatio[3], __float_as_uint(fabsf((float)(((double)k.pdfKernel - pdfD) / pdfD))));
-        atomicMax(&gvpmAuditRatio[4], __float_as_uint(fabsf((float)(((double)distSqr - dbg[4]) / ((double)radSqr * 2e-5)))));
+        atomicMax(&gvpmAuditRatio[4], __float_as_uint(fabsf((float)(((double)distSqr - dbg[4]) / ((double)errD2 * 8.0)))));
       }
     }
 #endif
+#ifdef GVPM_BEAMS_NOBAND
+    amb = false;
+#endif
     if (amb) {
+      // (Measured at C3: this call, taken by 3 % of the blocks, costs the kernel ~1 ms of 20 whether it is taken or not; a
+      // late pass over the undecided pairs -- the call outside this function, the block's code run a second time for
+      // them as in the G-BRE evaluation -- cost 2.8 ms more than it saved.)
       double vD, wD, pdfD, uD;
       if (!beamKernelExact(b.p1, b.p2, base.o, base.d, base.len, eps, r, sub, a.subLen, technique, uv, uw, vD, wD, pdfD, uD))
         return false;
@@ -1050,17 +1096,17 @@ __device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, in
   return (i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1);
 }
 
-// shift i of a pair that passed beamBase: the null shift is evaluated here, a reconnection is returned in q (push)
+// shift i of a pair that passed beamBase: the null shift is evaluated here; `rec`: the shift needs the offset-path
+// reconnection, which phase 2 does (beamShift2)
 template <int B, typename LDS>
-__device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const BeamP1 &o, uint32_t bIdx, int i, bool &push,
-                                           BeamQ &q, uint32_t &nNull, uint32_t &nFail) {
-  push = false;
+__device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const BeamP1 &o, uint32_t bIdx, int i, bool &rec,
+                                           uint32_t &nNull, uint32_t &nFail) {
+  rec = false;
   if (o.st == 0xFFu) return;
   const BeamF &b = o.b;
   const KRecF &k = o.k;
   const LocalRay &cam = o.cam;
-  const int technique = a.cfg.vol_technique;
-  const bool is1D = technique == GVPM_BEAM_BEAM_1D;
+  const bool is1D = a.cfg.vol_technique == GVPM_BEAM_BEAM_1D;
   const float r = a.kernelRadius, eps = a.cfg.epsilon;
   const ShiftRel sh = loadShiftRel(s, i, bIdx, cam.d);
   float w = 1.f;
@@ -1069,11 +1115,10 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
     const float shiftDistMAX = sh.len;
     float delta;
     const LocalRay sr = shiftedLocal(cam, sh, eps, delta);
-    const float sigS_w = k.sigmaW - delta;  // the same distance w on the shifted ray, from its foot point
-    const f3 shW = atLocal(sr, sigS_w);
     bool alreadyShift = false;
     if (a.cfg.use_shift_null && !is1D) {
-      const f3 dz = shW - o.kc;
+      const float sigS_w = k.sigmaW - delta;  // the same distance w on the shifted ray, from its foot point
+      const f3 dz = atLocal(sr, sigS_w) - o.kc;
       if (dot(dz, dz) < r * r && k.w <= shiftDistMAX) {
         // BeamKernelRecord copy-shift constructor (shift_volume_beams.h:40-144) + shiftNull3D (.cpp:748-786)
         float tN, tF;
@@ -1099,57 +1144,22 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
       }
     }
     if (!alreadyShift && k.w <= shiftDistMAX) {
-      bool doShift = true;
-      f3 offsetPos = mk3(0.f);
-      if (!is1D) {
-        // distance of the beam's origin to the shifted ray against kRec.u (= 0 for the 3D kernel)
-        f3 pv = o.p1rel + sr.D0;
-        pv = pv - sr.d * dot(pv, sr.d);
-        if (dot(pv, pv) > k.u * k.u) {
-          // getShiftPos (3D), shift_volume_beams.cpp:93-137: the kernel offset in the base ray's coherent frame,
-          // replayed in the shifted ray's
-          const f3 u = o.kc - o.camW;
-          f3 bs, bt, ns, nt;
-          coordSysCoherentF(cam.d, bs, bt);
-          coordSysCoherentF(sr.d, ns, nt);
-          const float lx = dot(u, bs), ly = dot(u, bt), lz = dot(u, cam.d);
-          offsetPos = shW + (ns * lx + nt * ly + sr.d * lz);
-          if (a.cfg.use_shift_null) {
-            const f3 dv = o.camW - offsetPos;
-            if (dot(dv, dv) < r * r) {
-              f3 dShift = shW - o.camW;
-              dShift = dShift * frsq(dot(dShift, dShift));
-              const float cosD = dot(dShift, shW - offsetPos);
-              offsetPos = offsetPos + dShift * (cosD * 2.0f);
-            }
-          }
-        } else {
-          doShift = false;
-        }
+      // shiftBeam dispatch, shift_volume_beams.cpp:355-408.  (The reference first asks whether the beam's origin lies ON
+      // the shifted ray, `minDistSqr > kRec.u^2` -- no shift then, weight 1: phase 2 asks for the shifts it is given;
+      // for a light path that cannot be reconnected the question is asked here)
+      if (a.cfg.debug_shift == GVPM_SHIFT_NULL || k.w > sr.maxt) {
+        w = 1.f;
+      } else if (o.st == 1u || o.st == 2u) {
+        rec = true;  // shiftBeamDiffuse: phase 2, which also adds the weighted base term of this shift
+        return;
       } else {
-        // getShiftPos1D, shift_volume_beams.cpp:81-91
-        const f3 aCam = o.p1rel + cam.D0;  // p1 from the base ray's foot point
-        f3 back = shiftPointLocal(cam.d, aCam, k.u, k.sigmaW, false) - aCam;
-        back = back * frsq(dot(back, back));
-        const f3 df = back - b.bd;
-        const bool flip = dot(df, df) > 0.001f;
-        offsetPos = shiftPointLocal(sr.d, o.p1rel + sr.D0, k.u, sigS_w, flip) - sr.D0;
-      }
-      if (doShift) {
-        if (a.cfg.debug_shift == GVPM_SHIFT_NULL || k.w > sr.maxt) {
-          w = 1.f;
-        } else if (o.st == 1u || o.st == 2u) {
-          // shiftBeamDiffuse: phase 2.  The weighted base term of this shift is added there too.
-          push = true;
-          q.id = o.id;
-          q.p = make_float4(offsetPos.x, offsetPos.y, offsetPos.z, k.v);
-          // base.eye * k.contrib * weightKernel * rr = (base.eye * flux * sigS) * (sc * weightKernel * rr): the scalar is carried
-          q.s = make_float4(k.w, k.pdfEdgeFailure * k.pdfKernel, k.sc * k.weightKernel * o.rr,
-                            __uint_as_float(bIdx | ((uint32_t)i << 8)));
-          return;
-        } else {
-          nFail++;
+        bool doShift = true;
+        if (!is1D) {
+          f3 pv = o.p1rel + sr.D0;
+          pv = pv - sr.d * dot(pv, sr.d);
+          doShift = dot(pv, pv) > k.u * k.u;
         }
+        if (doShift) nFail++;
       }
     }
   }
@@ -1166,14 +1176,22 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
   atomicAdd(&s.acc[15 + 3 * i + 2][bIdx], (double)(o.baseContrib.z * ws));
 }
 
-// phase 2: one prepared reconnection (shiftBeamDiffuse) -> the shifted and the weighted sums of its (ray, shift)
+// phase 2: one reconnection (shiftBeamDiffuse) -> the shifted and the weighted sums of its (ray, shift).  The offset
+// position (getShiftPos / getShiftPos1D) is computed HERE, where every lane has one to compute: in phase 1 the lanes
+// with a null shift waited for the lanes that prepared a reconnection.
+// withVis (wave-uniform) = false: the first round -- a reconnection whose new beam is not inside its beam's free cone
+// (beamClear: inside, nothing can occlude it) is DEFERRED, untouched; true: the second round over the deferred ones,
+// through the any-hit loop.
 template <int B, typename LDS>
-__device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const BeamQ &q, const float4 *ldsTri,
-                                           uint32_t &nDiff, uint32_t &nFail) {
+__device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const BeamPQ &q, const float4 *ldsTri, bool withVis,
+                                           bool &defer, uint32_t &nDiff, uint32_t &nFail) {
+  defer = false;
   const uint32_t beamIdx = q.id & 0xFFFFFFu, sub = q.id >> 24;
-  const uint32_t meta = __float_as_uint(q.s.w);
-  const uint32_t bIdx = meta & 0xFFu;
-  const int i = (int)(meta >> 8);
+  const uint32_t bIdx = q.meta & 0xFFu;
+  const int i = (int)((q.meta >> 8) & 3u);
+  const int technique = a.cfg.vol_technique;
+  const bool is1D = technique == GVPM_BEAM_BEAM_1D;
+  const float r = a.kernelRadius, eps = a.cfg.epsilon;
   const BeamF b = loadBeamF(a, beamIdx);
   const RayReg base = loadRay(s, 0, bIdx);
   const uint32_t nSub = subBeamCount(b.len, a.subLen);
@@ -1188,22 +1206,83 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
     cam.D0 = tof(c - dd * cam.s0);
     cam.d = base.d;
     cam.s0f = (float)cam.s0;
+    cam.mint = eps;
+    cam.maxt = base.len - eps;
   }
-  const ShiftRel sh = loadShiftRel(s, i, bIdx, base.d);
+  const float tauV = q.k.x, sigmaW = q.k.y;
+  const float kV = tc + tauV, kW = (float)(cam.s0 + (double)sigmaW);
+  const f3 p1rel = b.bd * (-tc);
+  const ShiftRel sh = loadShiftRel(s, i, bIdx, cam.d);
   float delta;
-  const LocalRay sr = shiftedLocal(cam, sh, a.cfg.epsilon, delta);
-  bool ok = false;
-  f3 sflux;
-  float w = shiftBeamDiffuseF<B>(a, b, sh.eye, sh.sMIS, sr, q.s.x, q.p.w, q.s.y, mk3(q.p.x, q.p.y, q.p.z), b.bd * (-tc),
-                                 a.cfg.vol_technique, ldsTri, sflux, ok);
-  if (ok) nDiff++; else nFail++;
+  const LocalRay sr = shiftedLocal(cam, sh, eps, delta);
+  const float sigS_w = sigmaW - delta;  // the same distance w on the shifted ray, from its foot point
+  const f3 shW = atLocal(sr, sigS_w);
+  bool doShift = true;
+  f3 offsetPos;
+  if (!is1D) {
+    // distance of the beam's origin to the shifted ray against kRec.u (= 0 for the 3D kernel)
+    f3 pv = p1rel + sr.D0;
+    pv = pv - sr.d * dot(pv, sr.d);
+    doShift = dot(pv, pv) > q.u * q.u;  // else result.weight = 1
+    // getShiftPos (3D), shift_volume_beams.cpp:93-137: the kernel offset in the base ray's coherent frame, replayed in
+    // the shifted ray's
+    const f3 kc = b.bd * tauV;             // kernel centre on the beam, local
+    const f3 camW = atLocal(cam, sigmaW);  // camera ray at w, local
+    const f3 u = kc - camW;
+    f3 bs, bt, ns, nt;
+    coordSysCoherentF(cam.d, bs, bt);
+    coordSysCoherentF(sr.d, ns, nt);
+    const float lx = dot(u, bs), ly = dot(u, bt), lz = dot(u, cam.d);
+    offsetPos = shW + (ns * lx + nt * ly + sr.d * lz);
+    if (a.cfg.use_shift_null) {
+      const f3 dv = camW - offsetPos;
+      if (dot(dv, dv) < r * r) {
+        f3 dShift = shW - camW;
+        dShift = dShift * frsq(dot(dShift, dShift));
+        const float cosD = dot(dShift, shW - offsetPos);
+        offsetPos = offsetPos + dShift * (cosD * 2.0f);
+      }
+    }
+  } else {
+    // getShiftPos1D, shift_volume_beams.cpp:81-91
+    const f3 aCam = p1rel + cam.D0;  // p1 from the base ray's foot point
+    f3 back = shiftPointLocal(cam.d, aCam, q.u, sigmaW, false) - aCam;
+    back = back * frsq(dot(back, back));
+    const f3 df = back - b.bd;
+    const bool flip = dot(df, df) > 0.001f;
+    offsetPos = shiftPointLocal(sr.d, p1rel + sr.D0, q.u, sigS_w, flip) - sr.D0;
+  }
+  float w = 1.f;
+  f3 sflux = mk3(0.f);
+  if (doShift) {
+    f3 nd = offsetPos - p1rel;
+    const float dist = fsqrt(dot(nd, nd));
+    nd = nd * frcp(dist);
+    bool ok = false;
+    if (!withVis) {
+      const float2 cl = a.beamClear[beamIdx];
+      if (!(dot(nd, b.bd) > cl.x && dist < cl.y)) {
+        defer = true;
+        return;
+      }
+    }
+    if (!withVis || !beamShadowBlocked(a, b, ldsTri, nd, dist)) {
+      BeamRecPair pr;
+      pr.pdfBasePos = b.parentPdf * (b.len * b.len);
+      if (b.endOnSurface) pr.pdfBasePos = fdiv(pr.pdfBasePos, fabsf(dot(b.endN, b.bd)));
+      pr.pdfBasePos *= frcp(kV * kV);
+      pr.trW = mediumEvalF(a.med, kW).tr;
+      pr.pdfKernelAndDist = q.k.z;
+      w = reconnectBeamF(a, b, pr, sh.eye, sh.sMIS, sr, offsetPos, nd, dist, technique, sflux, ok);
+    }
+    if (ok) nDiff++; else nFail++;
+  }
   if (beamBorder(a, s.pix[bIdx], i)) w = 1.f;
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
-  const f3 bcv = base.eye * b.flux * sigS * q.s.z;
+  const f3 bcv = base.eye * b.flux * sigS * q.k.w;
   // rr * weightKernel: the same for every pair of a launch (shift_volume_beams.h: 0.5 / r, or 1 / (4/3 pi r^3))
-  const float rK = a.kernelRadius;
   const float wkrr = (a.cfg.path_set ? 2.f : 1.f) *
-                     (a.cfg.vol_technique == GVPM_BEAM_BEAM_1D ? 0.5f * frcp(rK) : frcp((4.0f / 3.0f) * 3.14159265358979323846f * rK * rK * rK));
+                     (is1D ? 0.5f * frcp(r) : frcp((4.0f / 3.0f) * 3.14159265358979323846f * r * r * r));
   if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
     atomicAdd(&s.acc[3 + 3 * i + 0][bIdx], (double)(sflux.x * (w * wkrr)));
     atomicAdd(&s.acc[3 + 3 * i + 1][bIdx], (double)(sflux.y * (w * wkrr)));
@@ -1565,12 +1644,19 @@ __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs 
 // a wave-wide LDS ring (ballot + popcount; 40 bytes each) and run 64 at a time through phase 2 (beamShift2) whenever
 // the ring holds a full wave of them, and completely before the tile's accumulators are flushed.
 constexpr int BQCAP = 320;  // a block appends at most 4 x 64, at most 63 wait from the block before
-// LDS is what bounds this kernel's residency (245 VGPRs allow 8 waves per CU): the shifted rays of the tile are kept
-// RELATIVE to their base ray in the ray tile's own slots (relToBase), the queue entries are 36 bytes.
+constexpr int BVCAP = 128;  // a first-round drain defers at most 64, at most 63 wait
+// LDS is what bounds this kernel's residency (253 VGPRs allow 8 waves per CU): the shifted rays of the tile are kept
+// RELATIVE to their base ray in the ray tile's own slots (relToBase), the queue entries are 28 bytes (36 until round 3,
+// when they carried the offset position phase 2 now computes itself).
 template <int B> struct BeamEvalLds : RayTile<B> {
   double acc[27][B];
-  uint32_t qid[BQCAP];              // beam | sub << 24
-  float4 qp[BQCAP], qs[BQCAP];      // {offset position (local), kRec.v} {kRec.w, pdfEdgeFailure * pdfKernel, scale, ray | shift << 8}
+  uint32_t qid[BQCAP], qmeta[BQCAP];  // beam | sub << 24; ray | shift << 8
+  float4 qk[BQCAP];                   // BeamPQ::k
+  float qu[BQCAP];                    // BeamPQ::u
+  // the reconnections the first round deferred (outside their beam's free cone): they wait for a full wave of them
+  uint32_t vid[BVCAP], vmeta[BVCAP];
+  float4 vk[BVCAP];
+  float vu[BVCAP];
 };
 
 #ifdef GVPM_EVAL_TIMING
@@ -1610,24 +1696,55 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
   uint32_t qHead = 0, qCount = 0;  // wave-uniform
   [[maybe_unused]] unsigned long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] const unsigned long long btStart = BTICK();
-  auto drain = [&](uint32_t n) {   // n <= 64 entries of the ring through phase 2
+  uint32_t vHead = 0, vCount = 0;  // the deferred ring, wave-uniform
+  auto drainVis = [&](uint32_t n) {  // n <= 64 deferred reconnections through the any-hit loop
+    __syncthreads();
+    if ((uint32_t)lane < n) {
+      const uint32_t e = (vHead + (uint32_t)lane) % BVCAP;
+      BeamPQ q;
+      q.id = s.vid[e];
+      q.meta = s.vmeta[e];
+      q.k = s.vk[e];
+      q.u = s.vu[e];
+      bool defer;
+      beamShift2<B>(a, s, q, ldsTri, true, defer, nDiff, nFail);
+    }
+    vHead = (vHead + n) % BVCAP;
+    vCount -= n;
+  };
+  auto drain = [&](uint32_t n) {   // n <= 64 entries of the ring through phase 2 (first round)
     [[maybe_unused]] const unsigned long long d0 = BTICK();
     bt[6] += n;
     __syncthreads();
+    bool defer = false;
+    BeamPQ q = {};
     if ((uint32_t)lane < n) {
       const uint32_t e = (qHead + (uint32_t)lane) % BQCAP;
-      BeamQ q;
       q.id = s.qid[e];
-      q.p = s.qp[e];
-      q.s = s.qs[e];
-      beamShift2<B>(a, s, q, ldsTri, nDiff, nFail);
+      q.meta = s.qmeta[e];
+      q.k = s.qk[e];
+      q.u = s.qu[e];
+      beamShift2<B>(a, s, q, ldsTri, false, defer, nDiff, nFail);
     }
     qHead = (qHead + n) % BQCAP;
     qCount -= n;
+    const unsigned long long dm = __ballot(defer);
+    if (dm) {
+      if (defer) {
+        const uint32_t slot = (vHead + vCount + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))) % BVCAP;
+        s.vid[slot] = q.id;
+        s.vmeta[slot] = q.meta;
+        s.vk[slot] = q.k;
+        s.vu[slot] = q.u;
+      }
+      vCount += (uint32_t)__popcll(dm);
+      if (vCount >= 64u) drainVis(64u);
+    }
     bt[2] += BTICK() - d0;
   };
   auto flushTile = [&]() {
     while (qCount) drain(min(qCount, 64u));
+    while (vCount) drainVis(min(vCount, 64u));
     __syncthreads();
     if (curBase != 0xFFFFFFFFu) {
       for (int idx = lane; idx < 27 * B; idx += 64) {
@@ -1684,15 +1801,16 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
 #endif
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
-        bool push = false;
-        BeamQ q;
-        if (alive) beamShift1<B>(a, s, st, bIdx, i, push, q, nNull, nFail);
-        const unsigned long long m = __ballot(push);
-        if (push) {
+        bool rec = false;
+        if (alive) beamShift1<B>(a, s, st, bIdx, i, rec, nNull, nFail);
+        const unsigned long long m = __ballot(rec);
+        if (rec) {
           const uint32_t slot = (qHead + qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BQCAP;
-          s.qid[slot] = q.id;
-          s.qp[slot] = q.p;
-          s.qs[slot] = q.s;
+          s.qid[slot] = st.id;
+          s.qmeta[slot] = bIdx | ((uint32_t)i << 8);
+          // base.eye * k.contrib * weightKernel * rr = (base.eye * flux * sigS) * (sc * weightKernel * rr): the scalar is carried
+          s.qk[slot] = make_float4(st.k.tauV, st.k.sigmaW, st.k.pdfEdgeFailure * st.k.pdfKernel, st.k.sc * st.k.weightKernel * st.rr);
+          s.qu[slot] = st.k.u;
         }
         qCount += (uint32_t)__popcll(m);
       }

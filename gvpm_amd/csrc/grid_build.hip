@@ -592,8 +592,72 @@ __global__ __launch_bounds__(256) void shift_extent_kernel(const gvpm_camera_ray
   if ((threadIdx.x & 63) == 0 && S > 0.f) atomicMax(extentBits, __float_as_uint(S * 1.0001f));  // S >= 0: bit order = value order
 }
 
+// The FREE CONE of a beam (round 3).  A new beam of a reconnection is a straight segment from the beam's origin p1: every
+// point of it is seen from p1 under ONE angle to the beam's direction, alpha = angle(nd, bd), and lies no farther than
+// its length.  For a listed triangle T let cosT = the largest cosine of that angle over the points of T (0 angle: the
+// beam's line pierces it) and, when the line pierces T's PLANE at t_p > 0, alongMin = t_p - delta tan(incidence): every
+// point of the plane within delta of the line -- all a new beam can reach, it stays within delta of the beam -- lies at
+// least that far along the beam.  With M1 = the smallest alongMin of the triangles the beam points at (cosT ~ 1: the
+// surface it ends on) and cosA0 = the largest cosT of the others,
+//     dot(nd, bd) > cosA0  and  |new beam| < M1   =>   the new beam meets no occluder,
+// because it is inside the cone no other triangle enters and too short for the ones in front.  The evaluation skips the
+// any-hit loop for such reconnections (85-95 % of them at C3: a beam through the aperture is certified unless the new
+// beam grazes the aperture's edge or reaches the floor), and takes the others through it as before.
+// Returned in clear[i] = {cosA0 + margin, M1 - margin}; {2, 0} = never certified (list overflowed, degenerate).
+struct BeamClearTri {
+  float cosT, alongMin;
+};
+__device__ __forceinline__ BeamClearTri beamClearTri(const float p1[3], const float bd[3], float delta, const float4 t0, const float4 t1,
+                                                     const float4 t2) {
+  const float a[3] = {t0.x - p1[0], t0.y - p1[1], t0.z - p1[2]};
+  const float e1[3] = {t1.x, t1.y, t1.z}, e2[3] = {t2.x, t2.y, t2.z};
+  const float b[3] = {a[0] + e1[0], a[1] + e1[1], a[2] + e1[2]}, c[3] = {a[0] + e2[0], a[1] + e2[1], a[2] + e2[2]};
+  auto dot3 = [](const float *x, const float *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+  // the largest cosine over an edge P + s E, s in [0, 1]: g(s) = (al + be s) / |P + s E|, stationary at
+  // s* = (al d - be c0) / (be d - al e)
+  auto edgeMax = [&](const float *P, const float *Q) {
+    const float E[3] = {Q[0] - P[0], Q[1] - P[1], Q[2] - P[2]};
+    const float al = dot3(P, bd), be = dot3(E, bd), c0 = dot3(P, P), d = dot3(P, E), e = dot3(E, E);
+    float m = -1.f;
+    auto at = [&](float sp) {
+      const float l2 = c0 + 2.f * d * sp + e * sp * sp;
+      if (l2 > 1e-30f) m = fmaxf(m, (al + be * sp) * rsqrtf(l2));
+      else m = 1.f;  // the beam's origin ON the edge: every direction of the plane is met
+    };
+    at(0.f);
+    at(1.f);
+    const float den = be * d - al * e;
+    if (fabsf(den) > 1e-30f) {
+      const float sp = (al * d - be * c0) / den;
+      if (sp > 0.f && sp < 1.f) at(sp);
+    }
+    return m;
+  };
+  BeamClearTri o;
+  o.cosT = fmaxf(edgeMax(a, b), fmaxf(edgeMax(b, c), edgeMax(c, a)));
+  // the beam's line through the triangle (Moeller-Trumbore from p1 along bd, with slack: a near miss is a hit here)
+  const float nrm[3] = {t0.w, t1.w, t2.w};
+  const float cn = dot3(bd, nrm), dn = dot3(a, nrm);  // plane: nrm . (x - v0) = 0, a = v0 - p1
+  o.alongMin = -INFINITY;
+  if (fabsf(cn) > 0.05f) {
+    const float tp = dn / cn;  // p1 + tp bd on the plane
+    if (tp > 0.f) {
+      o.alongMin = tp - delta * sqrtf(fmaxf(1.f - cn * cn, 0.f)) / fabsf(cn);
+      // inside (or within slack of) the triangle?  barycentrics of the piercing point
+      const float q[3] = {tp * bd[0] - a[0], tp * bd[1] - a[1], tp * bd[2] - a[2]};  // from v0
+      const float d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), q1 = dot3(q, e1), q2 = dot3(q, e2);
+      const float det = d11 * d22 - d12 * d12;
+      if (det > 1e-30f) {
+        const float u = (q1 * d22 - q2 * d12) / det, v = (q2 * d11 - q1 * d12) / det;
+        if (u > -1e-3f && v > -1e-3f && u + v < 1.001f) o.cosT = 1.f;
+      }
+    }
+  }
+  return o;
+}
+
 __global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n, const float4 *__restrict__ tri4, uint32_t ntri,
-                                                        float r, const uint32_t *__restrict__ extentBits) {
+                                                        float r, const uint32_t *__restrict__ extentBits, float2 *clear, bool freeCone) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t N = GVPM_REC_QUADS;
@@ -646,6 +710,36 @@ __global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n
   cold[N * i + 3].w = __uint_as_float(w[0]);
   cold[N * i + 4].w = __uint_as_float(w[1]);
   cold[N * i + 5].w = __uint_as_float(w[2]);
+  // the beam's free cone over its list (see above): two passes over the listed triangles
+  float2 cl = make_float2(2.f, 0.f);
+  if (freeCone && ntri <= GVPM_NEAR_NARROW_MAX && !beamNearOverflow(fmt, w[0], w[2])) {
+    const float delta = 4.f * r + __uint_as_float(*extentBits);
+    const float4 c2 = cold[N * i + 1], c7 = cold[N * i + 6];
+    const float p1[3] = {c2.x, c2.y, c2.z};
+    float bd[3] = {c7.x - c2.x, c7.y - c2.y, c7.z - c2.z};
+    const float l2 = bd[0] * bd[0] + bd[1] * bd[1] + bd[2] * bd[2];
+    if (l2 > 1e-30f) {
+      const float il = rsqrtf(l2);
+      bd[0] *= il; bd[1] *= il; bd[2] *= il;
+      const float cosSmall = 0.99955f;  // ~0.03 rad: "the beam points at this triangle"
+      float M1 = INFINITY;
+      for (uint32_t q = 0; q < fmt.cap; ++q) {
+        const uint32_t t = beamNearEntry(fmt, w[0], w[1], w[2], q);
+        if (t == fmt.mask) break;
+        const BeamClearTri ct = beamClearTri(p1, bd, delta, tri4[3 * t], tri4[3 * t + 1], tri4[3 * t + 2]);
+        if (ct.cosT > cosSmall) M1 = fminf(M1, ct.alongMin);
+      }
+      float cosA0 = -1.f;
+      for (uint32_t q = 0; q < fmt.cap; ++q) {
+        const uint32_t t = beamNearEntry(fmt, w[0], w[1], w[2], q);
+        if (t == fmt.mask) break;
+        const BeamClearTri ct = beamClearTri(p1, bd, delta, tri4[3 * t], tri4[3 * t + 1], tri4[3 * t + 2]);
+        if (!(ct.alongMin >= M1)) cosA0 = fmaxf(cosA0, ct.cosT);
+      }
+      if (M1 > 0.f) cl = make_float2(cosA0 + 1e-5f, M1 * (1.f - 1e-5f) - 1e-6f);
+    }
+  }
+  if (clear) clear[i] = cl;
 }
 
 void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s) {
@@ -672,8 +766,8 @@ void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t ntri, uint32
   if (n) hipLaunchKernelGGL(beam_near_hist_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, ntri, hist);
 }
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
-                      hipStream_t s) {
-  if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, tri4, ntri, r, extentBits);
+                      float2 *clear, bool freeCone, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, tri4, ntri, r, extentBits, clear, freeCone);
 }
 
 void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg,

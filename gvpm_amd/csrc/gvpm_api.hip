@@ -75,7 +75,7 @@ void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n
 void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);
 hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s);
 void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s);
-void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
+void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits, float2 *clear, bool freeCone,
                       hipStream_t s);
 void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t ntri, uint32_t *hist, hipStream_t s);
 void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg,
@@ -226,6 +226,7 @@ struct gvpm_context {
   int setIdx = 0;
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
   bool beamsExact = false;        // G-Beams: the literal fp64 evaluation instead of the local-frame fp32 one
+  bool beamsFreeCone = true;      // G-Beams: reconnections inside their beam's free cone skip the any-hit loop (GVPM_BEAMS_FREE_CONE=0: none do)
   size_t beamPairsInit = (size_t)16 << 20;  // G-Beams: first capacity of the pair list (GVPM_BEAM_PAIRS_INIT; tests shrink it)
   uint32_t beamItemsInit = 0;     // G-Beams: first capacity of the item list (GVPM_BEAM_ITEMS_INIT; tests shrink it; 0: the planner's bound)
   uint32_t beamItemCap = 0;       // G-Beams: capacity the item list was regrown to after an overflow
@@ -293,6 +294,7 @@ struct gvpm_context {
   bool haveBeamsMap = false;
   DevBuf<uint32_t> subCounts, subOffsets, subIds, beamCtl;
   DevBuf<float4> beamAux;  // G-Beams: {p1, bits} {direction, sub-beam length} per beam, what sub_hot_kernel gathers
+  DevBuf<float2> beamClear;  // G-Beams: {cosA0, M1} per beam, the free cone of its reconnections (beam_near_kernel)
   uint32_t nsub = 0;
   float subLen = 0.f, maxSubLen = 0.f;
 
@@ -501,6 +503,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_NEAR_GRID")) h->useNearGrid = atoi(e) != 0;
   if (const char *e = getenv("GVPM_TRAV_STREAM")) h->travStream = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAM_PAIRS_INIT")) {
     const long long v = atoll(e);
     if (v >= 64 && v <= ((long long)1 << 31)) h->beamPairsInit = (size_t)v;
@@ -557,7 +560,7 @@ int gvpm_destroy(gvpm_context *h) {
   }
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
-  h->subIds.release(); h->beamCtl.release(); h->beamAux.release();
+  h->subIds.release(); h->beamCtl.release(); h->beamAux.release(); h->beamClear.release();
   h->nearGridStart.release(); h->nearGridTris.release(); h->nearGridCount.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release(); h->shiftExtent.release();
   h->blockKeyA.release(); h->blockKeyB.release(); h->blockValA.release(); h->blockValB.release();
@@ -1432,6 +1435,16 @@ static int buildBeamGrid(gvpm_context *h, float r) {
 static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
   const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
+  // phases as for G-BRE (gvpm_get_phase_time): 2 = build (sub-beam grid, beam records, camera-beam sort, near lists),
+  // 1 = plan + traversal, 0 = the evaluation (block sort + evaluate_beams2_kernel)
+  std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav;
+  {
+    int rcE = nextEvents(h, &evBuild, 2);
+    if (rcE != GVPM_OK) return rcE;
+    rcE = nextEvents(h, &evTrav, 1);
+    if (rcE != GVPM_OK) return rcE;
+  }
+  HIP_TRY(h, hipEventRecord(evBuild->first, h->stream));
   if (h->photonsDirty || r != h->bs->builtRadius) {
     int rc = buildBeamGrid(h, r);
     if (rc != GVPM_OK) return rc;
@@ -1451,7 +1464,8 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   }
   if (nearDirty || h->beamNearStale) {
     HIP_TRY(h, h->shiftExtent.ensure(1));
-    launch_beam_near(h->bs->cold.p, h->nph, h->tri4.p, h->ntri, r, h->shiftExtent.p, h->stream);
+    HIP_TRY(h, h->beamClear.ensure((size_t)h->nph + 1));
+    launch_beam_near(h->bs->cold.p, h->nph, h->tri4.p, h->ntri, r, h->shiftExtent.p, h->beamClear.p, h->beamsFreeCone, h->stream);
     if (getenv("GVPM_BEAMS_TRACE")) {
       DevBuf<uint32_t> hist;
       uint32_t hh[21] = {0}, ext = 0;
@@ -1471,6 +1485,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     h->beamNearStale = false;
   }
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipEventRecord(evBuild->second, h->stream));
   GatherArgs a;
   fillArgs(h, a, r);
   a.kernelRadius = r;
@@ -1482,6 +1497,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   a.subLen = h->subLen;
   a.nbeams = h->nph;
   a.nph = h->nsub;
+  a.beamClear = h->beamClear.p;
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
@@ -1500,13 +1516,13 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure(h->beamPairsInit));
   uint32_t npairs = 0;
   bool planned = false;
+  HIP_TRY(h, hipEventRecord(evTrav->first, h->stream));
   for (int attempt = 0;; ++attempt) {
     if (!planned) {
       HIP_TRY(h, h->bs->items.ensure(itemCap));
       HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
       launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr,
                       itemCap, h->stream);
-      if (attempt == 0) HIP_TRY(h, hipEventRecord(ev->first, h->stream));
       planned = true;
     }
     const uint32_t cap = (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u);
@@ -1541,6 +1557,8 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, hipMemset2DAsync(a.stats + 1, 8 * sizeof(unsigned long long), 0, sizeof(unsigned long long), GVPM_STAT_ROWS,
                                 h->stream));
   }
+  HIP_TRY(h, hipEventRecord(evTrav->second, h->stream));
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   // blocks of 64 pairs, sorted by tile: the evaluation loads a tile's rays once per run of its blocks
   const uint32_t nBlocks = npairs / 64u;
   if (nBlocks)

@@ -232,6 +232,13 @@ class Context:
         self._check(lib().gvpm_upload_planes(self._h, C.byref(soa), w1.ctypes.data if beams.n else None,
                                              len1.ctypes.data if beams.n else None))
 
+    def upload_beams_dev(self, soa, end_n_dev_ptr):
+        """soa: abi.PhotonSoA of device addresses (photon beams); end_n_dev_ptr: 3 floats per beam, device."""
+        self._check(lib().gvpm_upload_beams_dev(self._h, C.byref(soa), end_n_dev_ptr))
+
+    def upload_planes_dev(self, soa, w1_dev_ptr, len1_dev_ptr):
+        self._check(lib().gvpm_upload_planes_dev(self._h, C.byref(soa), w1_dev_ptr, len1_dev_ptr))
+
     def upload_vpm_samples(self, samples):
         samples = np.ascontiguousarray(samples)
         assert samples.dtype == abi.VPM_SAMPLE_DTYPE

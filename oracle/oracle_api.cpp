@@ -21,13 +21,14 @@ namespace {
 template <typename F>
 int gatherBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
               const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it, uint64_t nbPaths, int useAccel,
-              int threads, double *accum, uint64_t *counters, double *seconds) {
+              int threads, double *accum, uint64_t *counters, double *seconds, double *buildSeconds) {
   Gatherer<F> g;
   g.setup(*p, *m, *t);
   g.map.load(*ph);
   auto t0 = std::chrono::steady_clock::now();
-  if (useAccel) g.map.buildBRE((F)radius);
+  if (useAccel) g.map.buildBRE((F)radius);  // kd-tree + BRE hierarchy: serial, as the reference (gvpm.cpp:450-454)
   else g.map.radius = (F)radius;
+  if (buildSeconds) *buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const size_t P = (size_t)p->width * p->height;
   std::vector<F> perSet((size_t)nsets * 27, (F)0);
   Counters total;
@@ -73,12 +74,13 @@ template <typename F>
 int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
               const gvpm_camera_ray *rays, uint64_t nsets, const gvpm_vpm_sample *samples, uint64_t nsamples,
               int useAccel, int threads, double *accum, double *scaleVol, double *nVol, uint64_t *counters,
-              double *seconds) {
+              double *seconds, double *buildSeconds) {
   Gatherer<F> g;
   g.setup(*p, *m, *t);
   g.map.load(*ph);
   auto t0 = std::chrono::steady_clock::now();
   if (useAccel) g.map.buildKD();
+  if (buildSeconds) *buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const size_t P = (size_t)p->width * p->height;
   // BBPourcentageCONST = bsphere radius * POURCENTAGE_BS (gvpm.cpp:1082), Float arithmetic
   const F BBPourcentageCONST = (F)p->bsphere_radius * (F)0.01;
@@ -287,18 +289,32 @@ int oracle_gather_beams(const gvpm_params *p, const gvpm_medium *m, const gvpm_t
 
 // One iteration of computeVolumeGradientPhoton (gvpm.cpp:1081-1203) on the CPU.  accum: P*27
 // doubles (in/out, plain sums); scale_vol / n_vol: P doubles each (in/out GatherPoint state).
+int oracle_gather_vpm_timed(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                            const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets,
+                            const gvpm_vpm_sample *samples, uint64_t nsamples, int precision, int use_accel, int threads,
+                            double *accum, double *scale_vol, double *n_vol, uint64_t *counters, double *seconds,
+                            double *build_seconds);
 int oracle_gather_vpm(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
                       const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets,
                       const gvpm_vpm_sample *samples, uint64_t nsamples, int precision, int use_accel, int threads,
                       double *accum, double *scale_vol, double *n_vol, uint64_t *counters, double *seconds) {
+  return oracle_gather_vpm_timed(p, m, t, ph, rays, nsets, samples, nsamples, precision, use_accel, threads, accum,
+                                 scale_vol, n_vol, counters, seconds, nullptr);
+}
+// (seconds: kd-tree build + gather; build_seconds: the serial build alone)
+int oracle_gather_vpm_timed(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                            const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets,
+                            const gvpm_vpm_sample *samples, uint64_t nsamples, int precision, int use_accel, int threads,
+                            double *accum, double *scale_vol, double *n_vol, uint64_t *counters, double *seconds,
+                            double *build_seconds) {
   if (!p || !m || !t || !ph || (!rays && nsets) || (!samples && nsamples) || !accum || !scale_vol || !n_vol)
     return GVPM_ERR_INVALID_ARG;
   if (p->vol_technique != GVPM_DISTANCE) return GVPM_ERR_INVALID_ARG;
   if (precision == 32)
     return gatherVPM<float>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol,
-                            counters, seconds);
+                            counters, seconds, build_seconds);
   return gatherVPM<double>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol,
-                           counters, seconds);
+                           counters, seconds, build_seconds);
 }
 
 // One iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079) on the CPU.
@@ -306,16 +322,30 @@ int oracle_gather_vpm(const gvpm_params *p, const gvpm_medium *m, const gvpm_tri
 // 0 = brute-force O(B*N) over the same hit predicate.  accum: width*height*27 doubles
 // (in/out, the APA running mean).  counters: 5 x uint64 {evaluations, candidates,
 // null, diffuse, failed}.
+int oracle_gather_bre_timed(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                            const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
+                            uint64_t nb_paths, int precision, int use_accel, int threads, double *accum,
+                            uint64_t *counters, double *seconds, double *build_seconds);
 int oracle_gather_bre(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
                       const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
                       uint64_t nb_paths, int precision, int use_accel, int threads, double *accum,
                       uint64_t *counters, double *seconds) {
+  return oracle_gather_bre_timed(p, m, t, ph, rays, nsets, radius, it, nb_paths, precision, use_accel, threads, accum, counters,
+                                 seconds, nullptr);
+}
+// (seconds: kd-tree + BVH build + gather; build_seconds: the serial build alone)
+int oracle_gather_bre_timed(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
+                            const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
+                            uint64_t nb_paths, int precision, int use_accel, int threads, double *accum,
+                            uint64_t *counters, double *seconds, double *build_seconds) {
   if (!p || !m || !t || !ph || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
   if (p->vol_technique != GVPM_VOL_BRE2D && p->vol_technique != GVPM_VOL_BRE3D) return GVPM_ERR_INVALID_ARG;
   if (p->use_shift_null && p->vol_technique == GVPM_VOL_BRE2D) return GVPM_ERR_UNSUPPORTED;  // gvpm_struct.h:310-313
   if (precision == 32)
-    return gatherBRE<float>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds);
-  return gatherBRE<double>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds);
+    return gatherBRE<float>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds,
+                            build_seconds);
+  return gatherBRE<double>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds,
+                           build_seconds);
 }
 
 double oracle_scale_volume_apa(double global_scale, int it, double alpha, int technique) {

@@ -25,5 +25,5 @@ for row in L[:min(cnt.value, 40)]:
     ids = row[:2].view(np.uint32)
     print("  beam %d sub %d pix (%d,%d) exact=%d stage=%d | " % (ids[0] & 0xFFFFFF, ids[0] >> 24, ids[1] & 0xFFFF, ids[1] >> 16, row[2], row[3]) +
           " ".join("%s=%.9g" % (n, v) for n, v in zip(names[4:], row[4:])))
-print("largest |fp32 - fp64| / band over the accepted pairs: tN %.3g  v %.3g  w %.3g  distSqr %.3g;  pdfKernel relative %.3g" % (
-    ratio[0], ratio[1], ratio[2], ratio[4], ratio[3]))
+print("largest |fp32 - fp64| / band over the accepted pairs: tN %.3g  tF %.3g  v %.3g  w %.3g  distSqr %.3g;  pdfKernel relative %.3g" % (
+    ratio[0], ratio[5], ratio[1], ratio[2], ratio[4], ratio[3]))

@@ -57,7 +57,7 @@ try:
     line = json.loads([l for l in open(os.path.join(out, "bench_trace.log")).read().splitlines() if l.startswith("{")][-1])
     cfg = line["config"]
     traffic["_meta"] = {"technique": cfg["technique"], "scene": cfg["scene"], "frame": cfg["frame"],
-                        "photons": cfg["photons_per_iter"], "scale": float(cfg["workload"].rsplit(" ", 1)[-1]),
+                        "photons": cfg.get("photons_per_iter", cfg.get("records_per_iter")), "scale": float(cfg["workload"].rsplit(" ", 1)[-1]),
                         "n_gpus": line["n_gpus"], "csrc_sha": cfg["csrc_sha"]}
 except (OSError, ValueError, KeyError, IndexError) as e:
     print("no bench line to take the workload from:", e)

@@ -29,6 +29,7 @@ def lib(fast=False):
             C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
             C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_gather_bre_timed.argtypes = L.oracle_gather_bre.argtypes + [C.POINTER(C.c_double)]
         L.oracle_scale_volume_apa.restype = C.c_double
         L.oracle_scale_volume_apa.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int]
         L.oracle_assemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -38,6 +39,7 @@ def lib(fast=False):
             C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
             C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.oracle_gather_vpm_timed.argtypes = L.oracle_gather_vpm.argtypes + [C.POINTER(C.c_double)]
         L.oracle_assemble_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_gather_beams.argtypes = [
@@ -58,7 +60,7 @@ COUNTER_NAMES = ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "
 
 
 def gather_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, precision=64, use_accel=True,
-               threads=0, accum=None, fast=False):
+               threads=0, accum=None, fast=False, timing=None):
     """One iteration of computeVolumeGradientPhotonBRE on the CPU.
 
     tris: (v0,e1,e2) arrays; photons: abi.Photons; rays: (n_sets,5) CAMERA_RAY_DTYPE.
@@ -72,19 +74,21 @@ def gather_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, pr
     else:
         accum = np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
     counters = np.zeros(5, np.uint64)
-    secs = C.c_double(0)
-    rc = lib(fast).oracle_gather_bre(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
-                                     rays.ctypes.data, rays.shape[0], float(radius), it, nb_paths, precision,
-                                     1 if use_accel else 0, threads, accum.ctypes.data, counters.ctypes.data,
-                                     C.byref(secs))
+    secs, bsecs = C.c_double(0), C.c_double(0)
+    rc = lib(fast).oracle_gather_bre_timed(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
+                                           rays.ctypes.data, rays.shape[0], float(radius), it, nb_paths, precision,
+                                           1 if use_accel else 0, threads, accum.ctypes.data, counters.ctypes.data,
+                                           C.byref(secs), C.byref(bsecs))
     if rc != 0:
         raise RuntimeError(f"oracle_gather_bre failed: {rc}")
+    if timing is not None:
+        timing["build_s"] = bsecs.value  # the serial kd-tree + BVH build, part of `seconds`
     return (accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters))),
             secs.value)
 
 
 def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_accel=True, threads=0, accum=None,
-               scale_vol=None, n_vol=None, fast=False):
+               scale_vol=None, n_vol=None, fast=False, timing=None):
     """One iteration of computeVolumeGradientPhoton (G-VPM) on the CPU.
     Returns (accum[H,W,27] sums, scale_vol[H,W], n_vol[H,W], counters, seconds)."""
     tstruct, keep = abi.triangles_struct(*tris)
@@ -97,13 +101,16 @@ def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_a
                  else np.ascontiguousarray(scale_vol, np.float64).reshape(-1).copy())
     n_vol = np.zeros(H * W, np.float64) if n_vol is None else np.ascontiguousarray(n_vol, np.float64).reshape(-1).copy()
     counters = np.zeros(5, np.uint64)
-    secs = C.c_double(0)
-    rc = lib(fast).oracle_gather_vpm(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
-                                     rays.ctypes.data, rays.shape[0], samples.ctypes.data, samples.shape[0],
-                                     precision, 1 if use_accel else 0, threads, accum.ctypes.data,
-                                     scale_vol.ctypes.data, n_vol.ctypes.data, counters.ctypes.data, C.byref(secs))
+    secs, bsecs = C.c_double(0), C.c_double(0)
+    rc = lib(fast).oracle_gather_vpm_timed(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa),
+                                           rays.ctypes.data, rays.shape[0], samples.ctypes.data, samples.shape[0],
+                                           precision, 1 if use_accel else 0, threads, accum.ctypes.data,
+                                           scale_vol.ctypes.data, n_vol.ctypes.data, counters.ctypes.data, C.byref(secs),
+                                           C.byref(bsecs))
     if rc != 0:
         raise RuntimeError(f"oracle_gather_vpm failed: {rc}")
+    if timing is not None:
+        timing["build_s"] = bsecs.value
     return (accum.reshape(H, W, 27), scale_vol.reshape(H, W), n_vol.reshape(H, W),
             dict(zip(COUNTER_NAMES, map(int, counters))), secs.value)
 

@@ -63,3 +63,41 @@ def test_without_a_gpu_it_refuses_instead_of_falling_back():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
+
+
+def test_cpu_baseline_leg_of_the_other_workloads_runs_on_small_frames():
+    """`bench.py --workload c1|c3|c5`: the CPU leg (oracle through the reference's accelerator, build / gather split, a
+    pilot window that sizes the sample) on tiny frames -- the GPU side of those lines is -m gpu (tests/test_bench_gpu.py)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from gvpm_amd import abi
+    from gvpm_amd.host import SynthScene
+    for wl in ("c1", "c3", "c5"):
+        assert wl in bench.WORKLOADS and bench.WORKLOADS[wl]["technique"] in bench.TECH
+    for tech, scene in (("vpm", "cbox"), ("beams3d", "laser"), ("beams1d", "laser"), ("planes0d", "laser_in")):
+        W = H = 16
+        sc = SynthScene(scene, W, H)
+        p = sc.params()
+        p.initial_scale_volume = 3.0
+        if tech == "vpm":
+            p.vol_technique = abi.GVPM_DISTANCE
+            p.nb_camera_samples = 4
+            ph, nb = sc.shoot_photons(1, 3000)
+            rays, smp = sc.camera_beams_and_vpm_samples(1, 4)
+            first = (ph, nb, rays, smp)
+        elif tech.startswith("beams"):
+            p.vol_technique = abi.GVPM_BEAM_BEAM_3D_OPTIMIZED if tech == "beams3d" else abi.GVPM_BEAM_BEAM_1D
+            if tech == "beams1d":
+                p.use_shift_null = 0
+            ph, en, nb = sc.shoot_beams(1, 3000)
+            first = (ph, en, nb, sc.camera_beams(1))
+        else:
+            p.vol_technique = abi.GVPM_VOL_PLANE0D
+            p.use_shift_null = 0
+            p.min_depth = 2
+            ph, en, w1, l1, nb = sc.shoot_planes(1, 2000)
+            first = (ph, w1, l1, nb, sc.camera_beams(1))
+        r = bench.cpu_baseline_technique(tech, p, sc.medium(), sc.triangles(), first, W, H, 0.2)
+        assert r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0
+        assert r["build_s"] >= 0 and r["gather_s"] > 0 and r["one_thread"]["value"] > 0
+        assert "accelerator" in r["sample"]

@@ -160,9 +160,14 @@ def test_c3_laser_beams_512x512_2m_segments(tech):
         ref, cnt, _ = O.gather_beams(p, m, tris, beams, en, wr, rad, 1, nb, 64)
         win = (slice(y0, y0 + h), slice(x0, x0 + w))
         lum = max(ref[win][..., 0:3].mean(), 1e-30)
+        # the evaluated set is the oracle's exactly (every decision of the kernel record is banded and settled in fp64
+        # inside the band).  The shifts' own decisions -- null shift or reconnection, visibility of the new beam, the
+        # hemisphere tests -- are fp32: at this size (6 M reconnections per window) about one in a million lands on
+        # the other side (5 of 6.05 M measured); the small parity cases (test_parity_beams_gpu.py) hold +-2
         assert wst["evaluations"] == cnt["evaluations"], (wst, cnt)
+        nshift = 4 * cnt["evaluations"]
         for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
-            assert abs(wst[k] - cnt[k]) <= 2, (k, wst, cnt)
+            assert abs(wst[k] - cnt[k]) <= max(2, 2e-6 * nshift), (k, wst, cnt)
         assert cnt["evaluations"] > 10000
         assert l2(wacc[win], ref[win], lum) < 1e-3
         assert np.allclose(acc[win], wacc[win], rtol=1e-4, atol=1e-7 * lum)

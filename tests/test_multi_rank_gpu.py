@@ -67,3 +67,24 @@ def test_bench_two_ranks_is_the_strong_sharded_c4_shape():
     assert line["config"]["scene"] == "fogroom" and line["config"]["frame"] == [128, 128]
     assert "round-robin over 2 ranks" in line["config"]["sharding"] and "all-reduce" in line["config"]["sharding"]
     assert line["roofline"]["kernel_avg_ms"] > 0 and line["config"]["pixels_per_gpu"] == 128 * 128 / 2
+
+
+def test_bench_eight_ranks_run_to_completion_on_one_gpu():
+    """The driver's 8-GPU launch is `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...`: the same
+    command here with the eight ranks on GPU 0 over gloo and a small frame, so that the driver's run is not the first
+    8-rank run of this code (sharding by 8, the film all-reduce, the max-over-ranks timing, rank 0's line)."""
+    out = _launch(8, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                  "--single-device", "--frame", "128", "--photons", "40000", "--distinct", "2", timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints, nobody else
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["value"] > 0 and line["steps"] == 2
+    assert line["config"]["frame"] == [128, 128] and line["config"]["pixels_per_gpu"] == 128 * 128 / 8
+    assert "round-robin over 8 ranks" in line["config"]["sharding"]
+    # every evaluation of the frame is counted once: the eight shards' counts add up to a one-rank run's
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--steps", "2", "--warmup", "1",
+                          "--frame", "128", "--photons", "40000", "--distinct", "2", "--only-timed"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert l1["config"]["evaluations"] == line["config"]["evaluations"]

@@ -159,3 +159,25 @@ def test_beam_near_list_formats(levels):
         assert abs(st[k] - cnt[k]) <= 2, (k, st, cnt)
     assert cnt["failed_shifts"] > 0
     assert l2(acc, ref, max(ref[..., 0:3].mean(), 1e-30)) < 1e-3
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene,scale", [("fogroom", 2.5), ("laser", 2.0), ("laser_hg", 2.0)])
+def test_reconnections_among_occluders(tech, scene, scale):
+    """Scenes whose new beams ARE blocked (64 boxes standing in the fog; the aperture plate of S-laser): the evaluation
+    skips the any-hit loop for a reconnection inside its beam's free cone (grid_build.hip, beam_near_kernel) and takes
+    the others through it -- a cone that certified a blocked beam would turn failed shifts into reconnections."""
+    c = make_beam_case(scene, 32, 28, 12000, scale, technique=tech)
+    acc, ref, st = device_beams(c)
+    assert st["evaluations"] > 2000 and st["failed_shifts"] > (200 if scene == "fogroom" else 20)
+
+
+def test_free_cone_off_equals_free_cone_on(monkeypatch):
+    # the same gather with every reconnection sent through the any-hit loop (GVPM_BEAMS_FREE_CONE=0): same counters,
+    # same sums to float-atomic ordering
+    c = make_beam_case("fogroom", 32, 28, 12000, 2.5)
+    acc1, ref, st1 = device_beams(c)
+    monkeypatch.setenv("GVPM_BEAMS_FREE_CONE", "0")
+    acc0, _, st0 = device_beams(c)
+    assert st0 == st1
+    assert np.allclose(acc0, acc1, rtol=1e-5, atol=1e-7 * max(ref[..., 0:3].mean(), 1e-30))
