@@ -342,6 +342,7 @@ struct gvpm_context {
   int beamsPerWave = 16;
   float cellScale = 0.f;  // GVPM_CELL_SCALE; 0: the technique's default (buildGrid)
   uint32_t planTarget = 1024;  // staged photons per work item
+  bool planTargetSet = false;  // GVPM_PLAN_TARGET given (else G-Beams takes its own default)
   uint32_t nwaves = 2048;      // persistent gather waves
   bool nwavesFromEnv = false;
   uint32_t ncu = 256;
@@ -474,7 +475,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_COALESCE_AT")) h->cfg.reserved[3] = atoi(e);
   if (const char *e = getenv("GVPM_PLAN_TARGET")) {
     int v = atoi(e);
-    if (v >= 64 && v <= (1 << 24)) h->planTarget = (uint32_t)v;
+    if (v >= 64 && v <= (1 << 24)) h->planTarget = (uint32_t)v, h->planTargetSet = true;
   }
   {
     hipDeviceProp_t prop;
@@ -1374,7 +1375,11 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   Grid g;
   // sub-beams (and cells) of 3/4 of the kernel radius: the traversal cost follows the number of sphere tests, which
   // shrinks with the cell until the ext/256 floor (measured: 34 ms at 1.5 r, 23.5 ms at 0.75 r and below)
-  float cell = fmaxf(0.75f * (h->cellScale > 0.f ? h->cellScale : 1.0f) * r, ext / 256.f);
+  // (round 3, measured at C3 with the round's evaluation: sub-beams and cells of 1.5 r -- 24 M sub-beams instead of 47 M,
+  // build 6.4 -> 4.2 ms, traversal 10.2 -> 9.9 -- and, with them, work items of 4096 staged sub-beams: traversal -> 7.9 ms.
+  // Round 2 had measured the opposite (23.5 ms at 0.75 r against 34 at 1.5 r) on a traversal that resolved its candidates
+  // one per lane and round: the cost followed the sphere tests then, the walk and the staging now.)
+  float cell = fmaxf(0.75f * (h->cellScale > 0.f ? h->cellScale : 2.0f) * r, ext / 256.f);
   if (!(cell > 0.f)) cell = 1.f;
   g.cell = cell;
   g.invCell = 1.f / cell;
@@ -1521,7 +1526,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
     if (!planned) {
       HIP_TRY(h, h->bs->items.ensure(itemCap));
       HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
-      launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr,
+      launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTargetSet ? h->planTarget : 4096u, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr,
                       itemCap, h->stream);
       planned = true;
     }

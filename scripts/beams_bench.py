@@ -15,6 +15,7 @@ ap.add_argument("--beams", type=int, default=200000)
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--scene", default="cbox")
+ap.add_argument("--phases", action="store_true", help="also report the traversal and build phases (gvpm_get_phase_time)")
 args = ap.parse_args()
 sc = SynthScene(args.scene, args.size, args.size)
 p = sc.params()
@@ -25,7 +26,7 @@ data = {it: (sc.shoot_beams(it, args.beams), sc.camera_beams(it)) for it in rang
 ctx = hip.Context(p, 0); ctx.upload_scene(*tris); ctx.upload_medium(m)
 for it in range(1, args.iters + 2):
     if it == 2:
-        ctx.synchronize(); ctx.kernel_time(); s0 = ctx.stats(); t0 = time.perf_counter()
+        ctx.synchronize(); ctx.kernel_time(); ctx.phase_time(1); ctx.phase_time(2); s0 = ctx.stats(); t0 = time.perf_counter()
     (beams, en, nb), rays = data[it]
     ctx.upload_beams(beams, en); ctx.upload_camera_beams(rays)
     ctx.gather(it, nb)
@@ -34,6 +35,10 @@ dt = time.perf_counter() - t0
 s1 = ctx.stats()
 d = {k: (s1[k] - s0[k]) // args.iters for k in s1 if isinstance(s1[k], int)}
 ms, n = ctx.kernel_time()
-print(json.dumps(dict(tech=args.tech, nbeams=int(data[1][0][0].n), mevals_per_s=round(d["evaluations"] * args.iters / dt / 1e6, 1),
-                      ms_per_iter=round(dt / args.iters * 1e3, 3), kernel_ms=round(ms, 3), per_iter=d)))
+out = dict(tech=args.tech, nbeams=int(data[1][0][0].n), mevals_per_s=round(d["evaluations"] * args.iters / dt / 1e6, 1),
+           ms_per_iter=round(dt / args.iters * 1e3, 3), kernel_ms=round(ms, 3), per_iter=d)
+if args.phases:
+    out["trav_ms"] = round(ctx.phase_time(1)[0], 3)
+    out["build_ms"] = round(ctx.phase_time(2)[0], 3)
+print(json.dumps(out))
 ctx.close()
