@@ -710,7 +710,14 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
     {
       const void *all[14] = {p->pos, p->wi, p->flux, p->parent_pos, p->parent_n, p->prefix_w, p->parent_scat, p->parent_wi,
                              p->parent_pdf, p->edge_pdf, p->parent_rr, p->parent_g, p->flags, p->path_id};
-      for (int k = 0; k < 14 && pinned; ++k) pinned = isPinnedHost(all[k]);
+      // (one block in the ABI's order -- gvpm_host_alloc_photons -- is one allocation: its first array speaks for all)
+      bool oneBlock = n > 0;
+      size_t off = 0;
+      for (int k = 0; k < 14 && oneBlock; ++k) {
+        oneBlock = (const char *)all[k] == (const char *)all[0] + off * 4;
+        off += (size_t)n * (k < 8 ? 3 : 1);
+      }
+      for (int k = 0; k < (oneBlock ? 1 : 14) && pinned; ++k) pinned = isPinnedHost(all[k]);
     }
     if (prefetch && !pinned) return fail(h, GVPM_ERR_INVALID_ARG, "gvpm_prefetch_photons needs pinned host memory (gvpm_host_alloc*)");
     if (prefetch && h->phPending >= 0) return fail(h, GVPM_ERR_STATE, "a prefetched photon set is already pending");
@@ -1708,10 +1715,17 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   }
   // ... and of the staged photon arrays (the build on either stream; G-Planes reads them in the gather itself)
   if (h->photonsOwnedCur) {
+    // G-BRE reads them in its build only (reorder_kernel), and gatherBRE has waited for that build on the host (the
+    // planner's counters): nothing of it is in flight here.  An event behind the whole gather made the prefetched copy
+    // of step N+2 wait for the EVALUATION of step N: the PCIe-inclusive step went from 3.6 to 5.8 ms.  The other
+    // techniques read them on the gather stream (their builds; G-Planes in the gather kernel itself).
     gvpm_context::PhotonSlot &ps = h->phSlot[h->phCur];
-    HIP_TRY(h, hipEventRecord(ps.consumed, h->stream));
-    HIP_TRY(h, hipEventRecord(ps.consumedB, h->streamB));
-    ps.read = true;
+    const bool bre = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
+    if (!bre) {
+      HIP_TRY(h, hipEventRecord(ps.consumed, h->stream));
+      HIP_TRY(h, hipEventRecord(ps.consumedB, h->streamB));
+      ps.read = true;
+    }
   }
   // prefetched inputs (gvpm_prefetch_*) become the current ones: what an upload at this point would have done
   if (h->phPending >= 0) {

@@ -226,3 +226,499 @@ def phase_vec(g, wi, wo):
     """phase() with a per-element g (the parent's medium)"""
     temp = 1 + g * g + 2 * g * (wi * wo).sum(-1)
     return np.where(g == 0, INV_4PI, INV_4PI * (1 - g * g) / (temp * np.sqrt(temp)))
+
+
+# ======================================================================================================================
+# G-Beams (beam x beam): 3D "optimized" kernel and 1D kernel, written from
+#     BeamGradRadianceQuery::operator()        gvpm/shift/shift_volume_beams.cpp:139-353
+#     BeamKernelRecord (eval, copy-shift, kernelPDF)   gvpm/shift/shift_volume_beams.h:24-338
+#     getShiftPos / getShiftPos1D / shift / localMatrix   shift_volume_beams.cpp:37-137
+#     shiftBeam / shiftBeamDiffuse / shiftNull3D          shift_volume_beams.cpp:355-539, 748-786
+#     diffuseReconnectionPhotonBeam            gvpm/shift/operation/shift_diffuse.cpp:136-268
+#     PhotonBeam::rayIntersectInternal1D, getContrib     pm/beams_struct.h:250-311, 136-185 (float intermediates kept)
+#     cylinderIntersection                     pm/beams_3d_intersections.h:77-140 (float sinThetaSqr / ad / clipped tNear)
+#     coordinateSystem(Coherent)               src/libcore/util.cpp:592-609
+# Per (camera ray, beam) the two random numbers of the 3D kernel come from Philox4x32-10, key (bits(ray.rand), 0x6265616d),
+# counter (beam index, 0, 0, 0) -- the stand-in's specification (oracle/gvpm_oracle_beams.hpp header), not the reference's.
+# One (ray, beam) pair at a time, plain Python: small cases only.
+# ======================================================================================================================
+def _philox2(key0, beam):
+    c0, c1, c2, c3 = beam & 0xFFFFFFFF, 0, 0, 0
+    k0, k1 = key0 & 0xFFFFFFFF, 0x6265616D
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    f32 = np.float32
+    return float(f32(c0 >> 8) * f32(1.0 / 16777216.0)), float(f32(c1 >> 8) * f32(1.0 / 16777216.0))
+
+
+def _coord_system(a):
+    if abs(a[0]) > abs(a[1]):
+        inv = 1.0 / np.sqrt(a[0] * a[0] + a[2] * a[2])
+        c = np.array([a[2] * inv, 0.0, -a[0] * inv])
+    else:
+        inv = 1.0 / np.sqrt(a[1] * a[1] + a[2] * a[2])
+        c = np.array([0.0, a[2] * inv, -a[1] * inv])
+    return np.cross(c, a), c  # Frame(a): s, t
+
+
+def _coherent(n):
+    f = np.float32
+    sign = f(np.copysign(1.0, f(n[2])))
+    a = f(-1.0 / (float(sign) + n[2]))
+    b = f(n[0] * n[1] * float(a))
+    sg, a, b = float(sign), float(a), float(b)
+    return np.array([1.0 + sg * n[0] * n[0] * a, sg * b, -sg * n[0]]), np.array([b, sg + n[1] * n[1] * a, -n[1]])
+
+
+def _solve_quadratic(a, b, c):
+    if a == 0:
+        return (-c / b, -c / b) if b != 0 else None
+    disc = b * b - 4.0 * a * c
+    if disc < 0:
+        return None
+    sq = np.sqrt(disc)
+    temp = -0.5 * (b - sq) if b < 0 else -0.5 * (b + sq)
+    x0, x1 = temp / a, c / temp
+    return (x1, x0) if x0 > x1 else (x0, x1)
+
+
+def _cylinder(cyl_o, cyl_d, cyl_maxt, view_o, view_d, view_maxt, radius):
+    """cylinderIntersection(rCylinder, view, radius) -> (tNear, tFar) along `view`, or None"""
+    f = np.float32
+    cr = np.cross(view_d, cyl_d)
+    sin2 = f(cr @ cr)
+    ad = f((cyl_o - view_o) @ cr)
+    if float(ad * ad) >= (radius * radius) * float(sin2):
+        return None
+    s, t = _coord_system(cyl_d)
+    rel = view_o - cyl_o
+    ox, oy, oz = s @ rel, t @ rel, cyl_d @ rel
+    dx, dy, dz = s @ view_d, t @ view_d, cyl_d @ view_d
+    q = _solve_quadratic(dx * dx + dy * dy, 2 * (dx * ox + dy * oy), ox * ox + oy * oy - radius * radius)
+    if q is None:
+        return None
+    tn, tf = q
+    if tn > view_maxt or tf < 0:
+        return None
+    zn, zf = oz + dz * tn, oz + dz * tf
+    if zn < 0:
+        if zf < 0:
+            return None
+        return float(f(tn + (tf - tn) * zn / (zn - zf))), tf
+    if zn < cyl_maxt:
+        return tn, tf
+    if zn > cyl_maxt:
+        if zf > cyl_maxt:
+            return None
+        return float(f(tn + (tf - tn) * (zn - cyl_maxt) / (zn - zf))), tf
+    return None
+
+
+def _medium(sig_t, msw, dist):
+    """HomogeneousMedium::eval over `dist` (equal channels): (transmittance, pdfFailure)"""
+    e = np.exp(-sig_t * dist)
+    return (0.0 if e < 1e-20 else e), e * msw + (1 - msw)
+
+
+def _phase1(g, wi, wo):
+    if g == 0:
+        return INV_4PI
+    temp = 1 + g * g + 2 * g * float(wi @ wo)
+    return INV_4PI * (1 - g * g) / (temp * np.sqrt(temp))
+
+
+def _shift_point(ro, rd, a, u, w, flip):
+    d = (a - ro) @ rd
+    s = a - (ro + rd * d)
+    s = s / np.linalg.norm(s)
+    t = np.cross(rd, s)
+    la_y = (a - (ro + rd * d)) @ s
+    x = min(1.0, max(-1.0, u / abs(la_y)))
+    phi = np.pi / 2 - np.arcsin(x)
+    if flip:
+        phi = -phi
+    return ro + rd * w + s * (u * np.cos(phi)) + t * (u * np.sin(phi))
+
+
+def beams_full(c):
+    """One iteration (it = 1) of G-Beams (c.p.vol_technique: 3D optimized or 1D) over every beam set of the case."""
+    p, bm, rays, m = c.p, c.beams, c.rays, c.m
+    H, W = p.height, p.width
+    f8 = np.float64
+    acc = np.zeros((H, W, 27))
+    is1d = p.vol_technique == abi.GVPM_BEAM_BEAM_1D
+    P1, P2, FLUX = bm.parent_pos.astype(f8), bm.pos.astype(f8), bm.flux.astype(f8)
+    PN, PREF, PSCAT, PWI = bm.parent_n.astype(f8), bm.prefix_w.astype(f8), bm.parent_scat.astype(f8), bm.parent_wi.astype(f8)
+    PPDF, PRR, PG = bm.parent_pdf.astype(f8), bm.parent_rr.astype(f8), bm.parent_g.astype(f8)
+    ENDN = np.asarray(c.end_n, f8)
+    fl = bm.flags
+    ptype, stype, emed, depth, comp = fl & 3, (fl >> 2) & 7, (fl >> 5) & 1, (fl >> 8) & 0xFF, (fl >> 16) & 0xFFFF
+    parity = bm.path_id & 1
+    r = f8(c.r)
+    eps = f8(p.epsilon)
+    sig_t, sig_s, g, msw = f8(m.sigma_t[0]), np.array(list(m.sigma_s), f8), f8(m.g), f8(m.medium_sampling_weight)
+    cnt = dict(evaluations=0, null_shifts=0, diffuse_shifts=0, failed_shifts=0)
+    mode = p.lighting_interaction_mode
+    contributes = np.ones(bm.n, bool)
+    if not ((mode & abi.GVPM_SURF2MEDIA) and (mode & abi.GVPM_MEDIA2MEDIA)):
+        contributes &= np.where(ptype == abi.GVPM_PARENT_MEDIUM, bool(mode & abi.GVPM_MEDIA2MEDIA), bool(mode & abi.GVPM_SURF2MEDIA))
+    if p.bsdf_interaction_mode != abi.GVPM_BSDF_ALL:
+        contributes &= ~((comp > 0) & ((comp & p.bsdf_interaction_mode) == 0))
+    shift_code = {1: abi.GVPM_SHIFT_DIFFUSE, 2: abi.GVPM_SHIFT_MEDIUM, 3: abi.GVPM_SHIFT_MANIFOLD}
+    BD = P2 - P1
+    LEN = np.linalg.norm(BD, axis=1)
+    BD = BD / LEN[:, None]
+    wk = 0.5 / r if is1d else 1.0 / (4.0 / 3.0 * np.pi * r ** 3)
+    tris = c.tris
+
+    for s in range(rays.shape[0]):
+        b = rays[s, 0]
+        if not (int(b["info"]) & 1):
+            continue
+        o, d, ln = b["o"].astype(f8), b["d"].astype(f8), f8(b["len"])
+        edge = (int(b["info"]) >> 8) & 0xFF
+        px, py = int(b["pixel"]) & 0xFFFF, int(b["pixel"]) >> 16
+        key0 = int(np.float32(b["rand"]).view(np.uint32))
+        mint, maxt = eps, ln - eps
+        eye = b["eye"].astype(f8)
+        # a cheap necessary condition (the two LINES within the radius, the reference's own first test up to rounding)
+        # keeps the Python loop short
+        cr = np.cross(d, BD)
+        sin2 = (cr * cr).sum(1)
+        ad = ((P1 - o) * cr).sum(1)
+        cand = np.nonzero((ad * ad < r * r * sin2 * 1.001 + 1e-30) & contributes)[0]
+        for k in cand:
+            if p.max_depth > 0 and edge + int(depth[k]) > p.max_depth:
+                continue
+            rr = 1.0
+            if p.path_set:
+                if int(parity[k]) != (px + py) % 2:
+                    continue
+                rr = 2.0
+            p1, bd, L, flux = P1[k], BD[k], LEN[k], FLUX[k]
+            # ---- BeamKernelRecord::eval over the whole beam (tmin = 0, tmax = length) ----
+            u = 0.0
+            if is1d:
+                f = np.float32
+                crk = np.cross(d, bd)
+                s2 = f(crk @ crk)
+                adk = f((p1 - o) @ crk)
+                if float(adk * adk) >= (r * r) * float(s2):
+                    continue
+                d1d2 = f(d @ bd)
+                m1 = f(d1d2 * d1d2) - f(1.0)
+                if m1 < f(1e-5) and m1 > f(-1e-5):
+                    continue
+                d1o1, d1o2 = f(d @ o), f(d @ p1)
+                w = (float(f(d1o1 - d1o2)) - float(d1d2) * (bd @ o - bd @ p1)) / float(m1)
+                if w <= mint or w >= maxt:
+                    continue
+                v = (w + float(d1o1) - float(d1o2)) / float(d1d2)
+                if v <= 0.0 or v >= L or np.isnan(v):
+                    continue
+                sin_t = float(np.sqrt(s2))
+                u = float(abs(adk) / f(sin_t))
+                pdf_kernel = sin_t
+                tr_cam, _ = _medium(sig_t, msw, w)
+                tr_b, pf_b = _medium(sig_t, msw, v)
+                if pf_b == 0 and tr_b != 0:
+                    continue
+                contrib = flux * sig_s * (tr_b * tr_cam * _phase1(g, -bd, -d) / pf_b / pdf_kernel)
+            else:
+                q = _cylinder(o + d * mint, d, maxt - mint, p1, bd, L, r)
+                if q is None:
+                    continue
+                tn, tf = q
+                # (the whole beam is one sub-beam: tmin = 0 <= Epsilon, tmax = length)
+                if not (tn < 0 or (0 < tn < L)):
+                    continue
+                uv, uw = _philox2(key0, int(k))
+                v = tn + (tf - tn) * uv
+                pdf_kernel = 1.0 / max(tf - tn, 0.0001)
+                if v < 0 or v > L:
+                    continue
+                kc = p1 + bd * v
+                dtp = (kc - o) @ d
+                d2 = ((o + d * dtp - kc) ** 2).sum()
+                if d2 >= r * r:
+                    continue
+                dT = np.sqrt(max(0.0, r * r - d2))
+                w = dtp - dT + 2 * dT * uw
+                pdf_kernel *= 1.0 / max(2.0 * dT, 0.0001)
+                if w < mint or w > maxt:
+                    continue
+                tr_b, pf_b = _medium(sig_t, msw, v)
+                tr_cam, _ = _medium(sig_t, msw, w)
+                contrib = flux * sig_s * (tr_b * tr_cam * _phase1(g, -bd, -d) / pdf_kernel / pf_b)
+            if not contrib.any():
+                continue
+            kpdf = pf_b * pdf_kernel
+            base_c = eye * contrib * wk
+            acc[py, px, 0:3] += base_c * rr
+            st = int(stype[k])
+            if p.debug_shift not in (abi.GVPM_SHIFT_ALL, abi.GVPM_SHIFT_NULL) and shift_code.get(st, abi.GVPM_SHIFT_INVALID) != p.debug_shift:
+                continue
+            cnt["evaluations"] += 1
+            kc = p1 + bd * v
+            for i in range(4):
+                sh = rays[s, 1 + i]
+                wgt, sflux = 1.0, np.zeros(3)
+                if int(sh["info"]) & 1:
+                    so, sd, sl = sh["o"].astype(f8), sh["d"].astype(f8), f8(sh["len"])
+                    seye = sh["eye"].astype(f8)
+                    ratio, jac = f8(sh["pdf"]) / f8(b["pdf"]), f8(sh["jacobian"])
+                    if edge != 1:
+                        jac *= f8(sh["gop"]) / f8(b["gop"])
+                        ratio *= f8(b["gop"]) / f8(sh["gop"])
+                    sensor = ratio * jac
+                    done = False
+                    if p.use_shift_null and not is1d:
+                        zp = ((so + sd * w - kc) ** 2).sum()
+                        if zp < r * r and w <= sl:
+                            # the copy-shift constructor (3D): same v and w on the shifted ray
+                            q = _cylinder(so + sd * eps, sd, sl - eps, p1, bd, L, r)
+                            if q is not None and not (v < 0 or v > L):
+                                pk = 1.0 / max(q[1] - q[0], 0.0001)
+                                dtp = (kc - so) @ sd
+                                d2 = ((so + sd * dtp - kc) ** 2).sum()
+                                if d2 < r * r and not (w < eps or w > sl):
+                                    pk *= 1.0 / max(2.0 * np.sqrt(max(0.0, r * r - d2)), 0.0001)
+                                    c_s = contrib * (pdf_kernel / pk)
+                                    if c_s.any():
+                                        # shiftNull3D
+                                        c_s = c_s * ((pf_b * pk) / kpdf)
+                                        sflux = c_s * seye
+                                        wgt = 0.5
+                                        if p.use_mis:
+                                            x = sensor * ((pf_b * pk) / kpdf)
+                                            wgt = 1.0 / (1.0 + (x * x if p.power_heuristic else x))
+                                        cnt["null_shifts"] += 1
+                                        done = True
+                    if not done and w <= sl:
+                        do_shift = True
+                        if not is1d:
+                            t0 = (p1 - so) @ sd
+                            do_shift = ((p1 - (so + sd * t0)) ** 2).sum() > u * u
+                            if do_shift:
+                                uvec = kc - (o + d * w)
+                                bs, bt = _coherent(d)
+                                ns, nt = _coherent(sd)
+                                off = so + sd * w + ns * (uvec @ bs) + nt * (uvec @ bt) + sd * (uvec @ d)
+                                if p.use_shift_null:
+                                    bcw = o + d * w
+                                    if ((bcw - off) ** 2).sum() < r * r:
+                                        dsh = (so + sd * w) - bcw
+                                        dsh = dsh / np.linalg.norm(dsh)
+                                        off = off + dsh * (dsh @ -(off - (so + sd * w))) * 2
+                        else:
+                            back = _shift_point(o, d, p1, u, w, False) - p1
+                            back = back / np.linalg.norm(back)
+                            off = _shift_point(so, sd, p1, u, w, ((back - bd) ** 2).sum() > 0.001)
+                        if do_shift and not (p.debug_shift == abi.GVPM_SHIFT_NULL or w > sl):
+                            ok = False
+                            if st in (1, 2):
+                                ok, wgt, sflux = _beam_reconnect(p, tris, k, off, p1, P2[k], bd, v, kpdf, r, is1d, so, sd, sl, w, sensor,
+                                                                 seye, ptype, PN, PREF, PSCAT, PWI, PPDF, PRR, PG, ENDN, emed, sig_t,
+                                                                 sig_s, g, msw, eps)
+                            cnt["diffuse_shifts" if ok else "failed_shifts"] += 1
+                sflux = sflux * wk
+                if (i == abi.GVPM_RIGHT and px == W - 1) or (i == abi.GVPM_TOP and py == H - 1):
+                    wgt = 1.0
+                acc[py, px, 3 + 3 * i:6 + 3 * i] += sflux * (wgt * rr)
+                acc[py, px, 15 + 3 * i:18 + 3 * i] += base_c * (wgt * rr)
+    return acc / c.nb, cnt
+
+
+def _beam_reconnect(p, tris, k, off, p1, p2, bd, v, kpdf, r, is1d, so, sd, sl, w, sensor, seye, ptype, PN, PREF, PSCAT, PWI, PPDF,
+                    PRR, PG, ENDN, emed, sig_t, sig_s, g, msw, eps):
+    """shiftBeamDiffuse + diffuseReconnectionPhotonBeam for beam k -> (ok, weight, shiftedFlux before the kernel weight)"""
+    nd = off - p1
+    dist = np.linalg.norm(nd)
+    nd = nd / dist
+    zero = np.zeros(3)
+    if any_hit(tris, p1[None, :], nd[None, :], eps, np.array([dist]))[0]:
+        return False, 1.0, zero
+    n = PN[k]
+    if ptype[k] == abi.GVPM_PARENT_SURFACE:
+        cos_wo, cos_wi = n @ nd, n @ PWI[k]
+        if cos_wi <= 0 or cos_wo <= 0:
+            return False, 1.0, zero
+        thr, pdf_sa = PSCAT[k] * (INV_PI * cos_wo), INV_PI * cos_wo
+    elif ptype[k] == abi.GVPM_PARENT_MEDIUM:
+        ph = _phase1(PG[k], PWI[k], nd)
+        thr, pdf_sa = PSCAT[k] * ph, ph
+    else:
+        dp = max(nd @ n, 0.0)
+        thr, pdf_sa = np.full(3, INV_PI * dp), INV_PI * dp
+    gop = 1.0 / (dist * dist)
+    spdf = pdf_sa * gop
+    thr = thr * gop
+    base_pos = p1 + bd * v
+    pdf_base = PPDF[k] * ((p1 - p2) ** 2).sum()
+    if ENDN[k].any():
+        pdf_base /= abs(ENDN[k] @ bd)
+    pdf_base *= 1.0 / ((p1 - base_pos) ** 2).sum()
+    if pdf_base == 0:
+        return False, 1.0, zero
+    thr = thr / pdf_base * PRR[k]
+    if emed[k]:
+        tr, pf = _medium(sig_t, msw, dist)
+        spdf *= pf
+        thr = thr * (tr / kpdf)
+    if spdf == 0:
+        return False, 1.0, zero
+    # BeamKernelRecord::kernelPDF of the new beam against the shifted ray
+    if is1d:
+        kp = float(np.linalg.norm(np.cross(sd, nd)))
+    else:
+        kp = 0.0
+        q = _cylinder(so, sd, sl, p1, nd, np.inf, r)
+        if q is not None:
+            kc = p1 + nd * dist
+            dtp = (kc - so) @ sd
+            d2 = ((so + sd * dtp - kc) ** 2).sum()
+            if d2 < r * r:
+                kp = 1.0 / max(q[1] - q[0], 0.0001) / max(2.0 * np.sqrt(max(0.0, r * r - d2)), 0.0001)
+    if kp == 0:
+        return False, 1.0, zero
+    tr_s, _ = _medium(sig_t, msw, w)
+    sflux = PREF[k] * thr * sig_s * (_phase1(g, -nd, -sd) * tr_s) * seye
+    wgt = 0.5
+    if p.use_mis:
+        base_pdf = PPDF[k] * ((p1 - p2) ** 2).sum()
+        if ENDN[k].any():
+            base_pdf /= abs(ENDN[k] @ bd)
+        base_pdf /= ((p1 - base_pos) ** 2).sum()
+        base_pdf *= kpdf
+        off_pdf = kp * spdf
+        if off_pdf == 0 or base_pdf == 0:
+            return False, 1.0, sflux  # (the flux is set before the MIS test: it stays, with weight 1)
+        x = sensor * off_pdf / base_pdf
+        wgt = 1.0 / (1.0 + (x * x if p.power_heuristic else x))
+    return True, wgt, sflux
+
+
+# ======================================================================================================================
+# G-Planes (0D kernel), written from
+#     PlaneGradRadianceQuery::operator() / specularShift / intersection   gvpm/shift/shift_volume_planes.h:57-101,263-453
+#     PhotonPlane::intersectPlane0D, getContrib0D, invJacobian            pm/plane_struct.h:104-199 (float det kept)
+#     HomogeneousMedium::eval (transmittance, pdfSuccess, pdfFailure)     src/medium/homogeneous.cpp:432-513
+# No visibility, no depth / path-set filters, no border rule and no eye contribution in the plane functor (as written).
+# ======================================================================================================================
+def planes_full(c):
+    """One iteration (it = 1) of G-Planes 0D over every beam set of the case: (accum[H, W, 27], counters)."""
+    p, bm, rays, m = c.p, c.beams, c.rays, c.m
+    H, W = p.height, p.width
+    f8 = np.float64
+    acc = np.zeros((H, W, 27))
+    ori = bm.parent_pos.astype(f8)
+    e0v = bm.pos.astype(f8) - ori
+    l0 = np.linalg.norm(e0v, axis=1)
+    w0 = e0v / l0[:, None]
+    w1 = np.asarray(c.w1, f8)
+    l1 = np.asarray(c.len1, f8)
+    flux = bm.flux.astype(f8)
+    edge_id = ((bm.flags >> 8) & 0xFF).astype(np.int64)
+    eps = f8(p.epsilon)
+    sig_t, sig_s, g, msw = f8(m.sigma_t[0]), np.array(list(m.sigma_s), f8), f8(m.g), f8(m.medium_sampling_weight)
+    cnt = dict(evaluations=0, null_shifts=0, diffuse_shifts=0, failed_shifts=0)
+
+    def med(dist):
+        e = np.exp(-sig_t * dist)
+        return np.where(e < 1e-20, 0.0, e), sig_t * e * msw, e * msw + (1 - msw)  # transmittance, pdfSuccess, pdfFailure
+
+    def ph(wi, wo):
+        if g == 0:
+            return np.full(wi.shape[:-1] if wi.ndim > 1 else wo.shape[:-1], INV_4PI)
+        temp = 1 + g * g + 2 * g * (wi * wo).sum(-1)
+        return INV_4PI * (1 - g * g) / (temp * np.sqrt(temp))
+
+    for s in range(rays.shape[0]):
+        b = rays[s, 0]
+        if not (int(b["info"]) & 1):
+            continue
+        o, d, ln = b["o"].astype(f8), b["d"].astype(f8), f8(b["len"])
+        edge = (int(b["info"]) >> 8) & 0xFF
+        px, py = int(b["pixel"]) & 0xFFFF, int(b["pixel"]) >> 16
+        mint, maxt = eps, ln - eps
+        # intersectPlane0D (float det)
+        E0, E1 = w0 * l0[:, None], w1 * l1[:, None]
+        P = np.cross(d, E1)
+        det = (E0 * P).sum(1).astype(np.float32)
+        ok = np.abs(det) >= np.float32(1e-5)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = (np.float32(1.0) / det).astype(f8)
+            T = o - ori
+            t0 = (T * P).sum(1) * inv
+            Q = np.cross(T, E0)
+            t1 = (Q @ d) * inv
+            tc = (E1 * Q).sum(1) * inv
+        ok &= ~((t0 < 0) | (t0 > 1)) & ~((t1 < 0) | (t1 > 1)) & ~((tc <= mint) | (tc >= maxt))
+        idx = np.nonzero(ok)[0]
+        if idx.size == 0:
+            continue
+        cnt["evaluations"] += idx.size
+        t0, t1, tc = t0[idx] * l0[idx], t1[idx] * l1[idx], tc[idx]
+        W0, W1, O, FL = w0[idx], w1[idx], ori[idx], flux[idx]
+        tr_cam = med(tc)[0]
+        tr0, ps0, pf0 = med(t0)
+        tr1, ps1, pf1 = med(t1)
+        inv_j = 1.0 / np.abs((W0 * np.cross(W1, d)).sum(1))
+        pbase = ph(-W1, -d[None, :])
+        base = (tr_cam * pbase * tr1 * tr0 / pf0 / pf1 * inv_j)[:, None] * FL * sig_s * sig_s
+        acc[py, px, 0:3] += base.sum(0)
+        for i in range(4):
+            sh = rays[s, 1 + i]
+            w = np.ones(idx.size)
+            sflux = np.zeros((idx.size, 3))
+            if int(sh["info"]) & 1:
+                so, sd, sl = sh["o"].astype(f8), sh["d"].astype(f8), f8(sh["len"])
+                ratio, jac = f8(sh["pdf"]) / f8(b["pdf"]), f8(sh["jacobian"])
+                if edge != 1:
+                    jac *= f8(sh["gop"]) / f8(b["gop"])
+                    ratio *= f8(b["gop"]) / f8(sh["gop"])
+                sensor = ratio * jac
+                new_i = so + np.outer(tc, sd)
+                rel = new_i - O
+                orth = new_i - (O + W0 * (rel * W0).sum(1)[:, None])
+                orth = orth / np.linalg.norm(orth, axis=1)[:, None]
+                w0dot = (W0 * W1).sum(1)
+                nw1 = np.sqrt(1 - w0dot * w0dot)[:, None] * orth + W0 * w0dot[:, None]
+                # intersection(shiftRay, ori, w0, newW1): unit vectors, no upper bounds on t0 / t1
+                Pn = np.cross(sd, nw1)
+                detn = (W0 * Pn).sum(1)
+                good = np.abs(detn) >= np.float32(1e-8)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    invn = 1.0 / detn
+                    Tn = so - O
+                    t0n = (Tn * Pn).sum(1) * invn
+                    Qn = np.cross(Tn, W0)
+                    t1n = (Qn @ sd) * invn
+                    tcn = (nw1 * Qn).sum(1) * invn
+                good &= ~(t0n < 0) & ~(t1n < 0) & ~((tcn <= eps) | (tcn >= sl))
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tr0s, ps0s, _ = med(t0n)
+                    tr1s, ps1s, _ = med(t1n)
+                    jn = np.abs((W0 * np.cross(nw1, sd)).sum(1))
+                    thr = base * (tr0s / tr0 * (tr1s / tr1) / inv_j * (1.0 / jn))[:, None]
+                    jcb = inv_j * jn / (t1n / t1)
+                    jcb = np.where(edge_id[idx] != 1, jcb / (t0n / t0), jcb)
+                    pnew = ph(-nw1, -sd[None, :])
+                    thr = thr * (pnew / pbase)[:, None]
+                    wk = np.full(idx.size, 0.5)
+                    mis_ok = np.ones(idx.size, bool)
+                    if p.use_mis:
+                        base_pdf = ps0 * ps1 * pbase
+                        off_pdf = ps0s * ps1s * pnew
+                        mis_ok = ~((off_pdf == 0) | (base_pdf == 0))
+                        wk = 1.0 / (1.0 + sensor * jcb * off_pdf / base_pdf)
+                ok2 = good & mis_ok
+                sflux = np.where(good[:, None], np.nan_to_num(thr * jcb[:, None]), 0.0)  # a failed MIS keeps its flux, weight 1
+                w = np.where(ok2, wk, 1.0)
+                cnt["diffuse_shifts"] += int(ok2.sum())
+                cnt["failed_shifts"] += int((~ok2).sum())
+            acc[py, px, 3 + 3 * i:6 + 3 * i] += (sflux * w[:, None]).sum(0)
+            acc[py, px, 15 + 3 * i:18 + 3 * i] += (base * w[:, None]).sum(0)
+    return acc / c.nb, cnt
