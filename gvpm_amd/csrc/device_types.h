@@ -106,6 +106,12 @@ struct GatherArgs {
   float kernelRadius;
   float subLen;              // target sub-beam length used by the build
   uint32_t nbeams;
+  // G-BRE: the cell box of every slab step of every tile chunk, written by the planner (which needs them to count the
+  // staged photons) and read by the traversal instead of being reduced over the tile's beams a second time:
+  // planBoxes[chunk * planBoxStride + step], chunk = setBase / B + tile, {x0 | x1 << 10 | y0 << 20, y1 | z0 << 10 | z1 << 20},
+  // x = 0xFFFFFFFF: no beam of the chunk reaches the slab.  Null: the traversal computes its boxes (G-Beams).
+  uint2 *planBoxes;
+  uint32_t planBoxStride;
   const float2 *beamClear;   // per beam {cosA0, M1}: the free cone of its reconnections (grid_build.hip, beam_near_kernel)
   // G-VPM only
   const gvpm_vpm_sample *samples;

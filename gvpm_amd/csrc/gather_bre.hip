@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
     firstItem = false;
     if (it >= nItems) break;
     const uint4 item = items[it];
-    const uint32_t setBase = item.x, nb = item.y;
+    const uint32_t setBase = item.x, nb = item.y & 0xFFu, chunk = item.y >> 8;
     if (nb == 0) continue;
     // the item's region: one list of up to `cap` photon indices per beam of the tile
     const uint2 reg = itemOff[it];
@@ -479,7 +479,14 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
       const int cAe = min(cA + w.K - 1, cEnd);
       CellBox bx;
-      if (!slabBox(a, w, cA, cAe, bx)) continue;
+      // the slab's cell box: the planner's (it reduced the tile's footprints to count the box's photons), one load
+      // instead of a footprint per lane, four wave reductions and the cell arithmetic per slab step
+      const uint32_t stepIdx = (uint32_t)(cA - w.cA0) / (uint32_t)w.K;
+      if (a.planBoxes && stepIdx < a.planBoxStride) {
+        if (!unpackCellBox(a.planBoxes[(size_t)chunk * a.planBoxStride + stepIdx], bx)) continue;
+      } else if (!slabBox(a, w, cA, cAe, bx)) {
+        continue;
+      }
       const int nranges = (bx.by1 - bx.by0 + 1) * (bx.bz1 - bx.bz0 + 1);
       for (int rbase = 0; rbase < nranges; rbase += 64) {
         uint32_t start, count;
@@ -720,7 +727,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
     firstItem = false;
     if (it >= nItems) break;
     const uint4 item = items[it];
-    const uint32_t setBase = item.x, nb = item.y;
+    const uint32_t setBase = item.x, nb = item.y & 0xFFu;
     if (nb == 0) continue;
     const uint32_t cntb = (uint32_t)lane < nb ? pairCnt[(size_t)it * B + lane] : 0u;
     const uint32_t incl = wave_scan_incl(cntb, lane);

@@ -30,18 +30,29 @@ constexpr int VRQ = 128; // reconnection ring: 63 left over + the 64 one shift o
 #ifndef GVPM_VPM_PROBE
 #define GVPM_VPM_PROBE 0
 #endif
-#if GVPM_VPM_PROBE == 2
-#define VPM_ADD(p, v) (*(p) += (double)(v))
-#else
-#define VPM_ADD(p, v) atomicAdd((p), (double)(v))
+// The 27 sums of a PIXEL RUN (the consecutive samples of one pixel: 40 at C1, so a wave holds two or three runs), not of
+// a sample: 27 x 64 doubles were 13.8 KB of the kernel's 21 KB of LDS and held it at 7 waves per CU.  A wave with more
+// than VPM_RUNS runs (a host that does not group a pixel's samples) adds the surplus straight to the film.
+#ifndef GVPM_VPM_RUNS
+#define GVPM_VPM_RUNS 4
 #endif
+#ifndef GVPM_VPM_SUB
+#define GVPM_VPM_SUB 8
+#endif
+constexpr int VPM_RUNS = GVPM_VPM_RUNS;
+// ... and VPM_SUB copies of a run's sums, picked by the adding lane: all 64 lanes on the two or three addresses of one
+// copy serialise in the LDS atomic unit (measured at 4 x the C1 radius, 16 M evaluations: 3.2 -> 3.9 ms with one copy)
+constexpr int VPM_SUB = GVPM_VPM_SUB;
+#define VPM_ADD(k, b, v) vpmAdd(a, s, (k), (b), (v))
 
 // The rays are NOT staged in LDS: the 64 camera samples of a workgroup belong to one or two pixels (40 samples per
 // pixel at C1), i.e. to one or two beam sets, so the 5 x 64 bytes of a set are L1-resident broadcast reads -- and 17 KB
 // of LDS a wave held the kernel at 6 waves per CU.
 struct VpmLds {
   uint32_t set[64];    // beam set of the sample (0xFFFFFFFF: none)
-  double acc[27][64];  // double: ds_add_f64 runs ~25x the rate of ds_add_f32 on gfx950 (scripts/probes/lds_atomics_bench.hip)
+  double acc[27][VPM_RUNS * VPM_SUB];  // double: ds_add_f64 runs ~25x the rate of ds_add_f32 on gfx950 (scripts/probes/lds_atomics_bench.hip)
+  uint32_t run[64];    // pixel run of the sample
+  uint32_t runPix[VPM_RUNS];  // pixel index of the run
   uint2 queue[VQ];
   double t[64];        // sampled camera distance (mRec.t)
   float pdfBase[64];   // pdfBaseRay() = mRec.pdfSuccess * pdfSel
@@ -78,6 +89,16 @@ __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s,
   r.jac = q2.w;
   r.gop = q3.x;
   return r;
+}
+
+__device__ __forceinline__ void vpmAdd(const GatherArgs &a, VpmLds &s, int k, uint32_t b, float v) {
+  const uint32_t r = s.run[b];
+  if (r < (uint32_t)VPM_RUNS) {
+    atomicAdd(&s.acc[k][r * VPM_SUB + (threadIdx.x & (VPM_SUB - 1))], (double)v);
+  } else {
+    const uint32_t pv = s.pix[b];
+    atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v);
+  }
 }
 
 // What both phases of an evaluation need of the (photon, sample) pair.
@@ -126,13 +147,13 @@ __device__ __forceinline__ void vpmAddShift(VpmLds &s, uint32_t b, int i, const 
   if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
   const float ws = w * scale;
   if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-    VPM_ADD(&s.acc[3 + 3 * i + 0][b], sflux.x * ws);
-    VPM_ADD(&s.acc[3 + 3 * i + 1][b], sflux.y * ws);
-    VPM_ADD(&s.acc[3 + 3 * i + 2][b], sflux.z * ws);
+    VPM_ADD(3 + 3 * i + 0, b, sflux.x * ws);
+    VPM_ADD(3 + 3 * i + 1, b, sflux.y * ws);
+    VPM_ADD(3 + 3 * i + 2, b, sflux.z * ws);
   }
-  VPM_ADD(&s.acc[15 + 3 * i + 0][b], baseContrib.x * ws);
-  VPM_ADD(&s.acc[15 + 3 * i + 1][b], baseContrib.y * ws);
-  VPM_ADD(&s.acc[15 + 3 * i + 2][b], baseContrib.z * ws);
+  VPM_ADD(15 + 3 * i + 0, b, baseContrib.x * ws);
+  VPM_ADD(15 + 3 * i + 1, b, baseContrib.y * ws);
+  VPM_ADD(15 + 3 * i + 2, b, baseContrib.z * ws);
 }
 
 // Phase 1 of one evaluation (VolumeGradientPositionQuery::operator() after the filters): the base contribution, and
@@ -145,9 +166,9 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
   return 0u;
 #endif
   const VpmPair v = vpmPair(a, s, pidx, b, norm);
-  VPM_ADD(&s.acc[0][b], v.baseContrib.x * v.scale);
-  VPM_ADD(&s.acc[1][b], v.baseContrib.y * v.scale);
-  VPM_ADD(&s.acc[2][b], v.baseContrib.z * v.scale);
+  VPM_ADD(0, b, v.baseContrib.x * v.scale);
+  VPM_ADD(1, b, v.baseContrib.y * v.scale);
+  VPM_ADD(2, b, v.baseContrib.z * v.scale);
   const float sigT = a.med.sigmaT[0];
   uint32_t qMask = 0u;
 #pragma unroll 1
@@ -221,7 +242,8 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   const float norm = 1.f / (float)a.cfg.nb_camera_samples;
   const float eps = a.cfg.epsilon;
 
-  for (int idx = lane; idx < 27 * 64; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+  for (int idx = lane; idx < 27 * VPM_RUNS * VPM_SUB; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+  uint32_t nRuns = 0;  // wave-uniform: runs that have LDS accumulators
 
   // ---- this lane's sample: rays -> LDS, distance sampling ----
   bool active = (uint32_t)lane < ns;
@@ -240,7 +262,18 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
     if (active) q3 = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5)[3];
     s.pix[lane] = __float_as_uint(q3.w);
     s.edge[lane] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
+    // pixel runs: consecutive lanes of one pixel (the C ABI does not promise that a pixel's samples are adjacent: a
+    // pixel that comes back later in the wave is another run)
+    const uint32_t pv = __float_as_uint(q3.w);
+    const uint32_t prev = __shfl_up(pv, 1u, 64);
+    const bool head = lane == 0 || prev != pv;
+    const unsigned long long heads = __ballot(head);
+    const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull)) - 1u;
+    s.run[lane] = run;
+    if (head && run < (uint32_t)VPM_RUNS) s.runPix[run] = pv;
+    if (lane == 0) nRuns = min((uint32_t)__popcll(heads), (uint32_t)VPM_RUNS);
   }
+  nRuns = __shfl(nRuns, 0, 64);
   __syncthreads();
   const RayReg base = loadRayV(a, s, 0, lane);
   active = active && base.valid;
@@ -429,12 +462,21 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   if (rqCount) drain(rqCount);
   __syncthreads();
   // ---- write out ----
-  // The samples of a pixel sit in consecutive lanes (40 per pixel at C1), so their sums are combined in the wave
-  // (segmented suffix sum keyed by the pixel) and the first lane of each run issues the global atomic: per-lane
-  // atomics put up to 64 operations on one address and those serialise in L2.
+  // one global atomic per (run, value): per-sample atomics would put up to 64 operations on one address, and those
+  // serialise in L2 (a run that overflowed VPM_RUNS has added to the film directly)
+  for (uint32_t idx = (uint32_t)lane; idx < 27u * nRuns; idx += 64u) {
+    const uint32_t k = idx / nRuns, rr = idx % nRuns;
+    double vd = 0.0;
+#pragma unroll
+    for (int c = 0; c < VPM_SUB; ++c) vd += s.acc[k][rr * VPM_SUB + c];
+    const float v = (float)vd;
+    if (v != 0.f) {
+      const uint32_t pv = s.runPix[rr];
+      atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v);
+    }
+  }
   {
-    // A run = consecutive lanes of one pixel.  The C ABI does not promise that a pixel's samples are adjacent, so a
-    // pixel may come back later in the wave: that is another run with its own atomic, never joined across the gap.
+    // the photon counts M of the samples of a run, combined in the wave (segmented suffix sum keyed by the pixel)
     const uint32_t prev = __shfl_up(pixv, 1u, 64);
     const bool head = lane == 0 || prev != pixv;
     const unsigned long long heads = __ballot(head);
@@ -443,16 +485,6 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
     for (int j = 0; j < 6; ++j) {
       const int o = 1 << j;
       if (lane + o < 64 && (((heads >> (lane + 1)) & ((1ull << o) - 1ull)) == 0ull)) same |= 1u << j;
-    }
-    const size_t p = (size_t)(pixv >> 16) * a.cfg.width + (pixv & 0xFFFFu);
-    for (int k = 0; k < 27; ++k) {
-      float v = (float)s.acc[k][lane];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float w = __shfl_down(v, 1u << j, 64);
-        if ((same >> j) & 1u) v += w;
-      }
-      if (head && v != 0.f) atomicAdd(&a.iter[p * 27 + k], v);
     }
     float fv = (float)s.found[lane];
 #pragma unroll

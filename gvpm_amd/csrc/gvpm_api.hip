@@ -179,6 +179,7 @@ struct BuildSet {
   bool scanSized = false;
   DevBuf<uint4> items;
   DevBuf<uint2> itemOff;
+  DevBuf<uint2> planBoxes;  // the planner's slab boxes, read by the traversal (GatherArgs::planBoxes)
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
   // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
   DevBuf<uint32_t> pairs, pairCnt, nearExt;
@@ -194,7 +195,7 @@ struct BuildSet {
     GVPM_MIRROR(sat); GVPM_MIRROR(keysA); GVPM_MIRROR(keysB); GVPM_MIRROR(valsA); GVPM_MIRROR(valsB);
     GVPM_MIRROR(beamCount); GVPM_MIRROR(beamStart); GVPM_MIRROR(boundsPartial); GVPM_MIRROR(bounds6);
     GVPM_MIRROR(bKeysA); GVPM_MIRROR(bKeysB); GVPM_MIRROR(bValsA); GVPM_MIRROR(setPerm); GVPM_MIRROR(tileStart);
-    GVPM_MIRROR(items); GVPM_MIRROR(itemOff); GVPM_MIRROR(queueCtl); GVPM_MIRROR(pairs); GVPM_MIRROR(pairCnt);
+    GVPM_MIRROR(items); GVPM_MIRROR(itemOff); GVPM_MIRROR(planBoxes); GVPM_MIRROR(queueCtl); GVPM_MIRROR(pairs); GVPM_MIRROR(pairCnt);
     GVPM_MIRROR(nearExt);
 #undef GVPM_MIRROR
     return e;
@@ -203,7 +204,7 @@ struct BuildSet {
     hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); cellCount.release(); sat.release();
     beamCount.release(); beamStart.release(); keysA.release(); keysB.release();
     valsA.release(); valsB.release(); boundsPartial.release(); bounds6.release(); bKeysA.release(); bKeysB.release();
-    bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); queueCtl.release();
+    bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); planBoxes.release(); queueCtl.release();
     if (sortTmp.d) (void)hipFree(sortTmp.d);
     sortTmp.d = nullptr;
     sortTmp.bytes = 0;
@@ -226,6 +227,7 @@ struct gvpm_context {
   int setIdx = 0;
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
   bool beamsExact = false;        // G-Beams: the literal fp64 evaluation instead of the local-frame fp32 one
+  bool planBoxHandOff = true;     // G-BRE: the traversal reads the planner's slab boxes (GVPM_PLAN_BOXES=0: computes its own)
   bool beamsFreeCone = true;      // G-Beams: reconnections inside their beam's free cone skip the any-hit loop (GVPM_BEAMS_FREE_CONE=0: none do)
   size_t beamPairsInit = (size_t)16 << 20;  // G-Beams: first capacity of the pair list (GVPM_BEAM_PAIRS_INIT; tests shrink it)
   uint32_t beamItemsInit = 0;     // G-Beams: first capacity of the item list (GVPM_BEAM_ITEMS_INIT; tests shrink it; 0: the planner's bound)
@@ -505,6 +507,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_TRAV_STREAM")) h->travStream = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_PLAN_BOXES")) h->planBoxHandOff = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAM_PAIRS_INIT")) {
     const long long v = atoll(e);
     if (v >= 64 && v <= ((long long)1 << 31)) h->beamPairsInit = (size_t)v;
@@ -1253,6 +1256,19 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   const uint32_t itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
   HIP_TRY(h, h->bs->items.ensure(itemCap));
   HIP_TRY(h, h->bs->itemOff.ensure(itemCap));
+  if (h->planBoxHandOff) {
+    // one box per slab step and tile chunk: steps <= dim / (thinnest slab) + 1, chunks < nsets / B + ntiles + 1 (< 2^24)
+    const Grid &g = h->bs->grid;
+    const int kmin = std::max(1, std::min(a.cfg.reserved[2] ? a.cfg.reserved[2] : 8, a.cfg.reserved[1] ? a.cfg.reserved[1] : 6));
+    // (sized for the finest grid the cell rule allows, as the cell arrays: a regrowth is a device-wide sync)
+    const uint32_t stride = (uint32_t)(std::max(386, std::max(g.dim[0], std::max(g.dim[1], g.dim[2]))) / kmin + 2);
+    const size_t chunks = (size_t)h->nsets / (size_t)h->beamsPerWave + h->bs->ntiles + 2;
+    if (chunks < (1u << 24) && std::max(g.dim[0], std::max(g.dim[1], g.dim[2])) < 1024) {
+      HIP_TRY(h, h->bs->planBoxes.ensure(chunks * stride));
+      a.planBoxes = h->bs->planBoxes.p;
+      a.planBoxStride = stride;
+    }
+  }
   HIP_TRY(h, h->bs->queueCtl.ensure(4));
   HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->bstream));
   launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,

@@ -291,6 +291,16 @@ __device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, 
   return boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx);
 }
 
+__device__ __forceinline__ uint2 packCellBox(const CellBox &bx) {
+  return make_uint2((uint32_t)bx.bx0 | ((uint32_t)bx.bx1 << 10) | ((uint32_t)bx.by0 << 20),
+                    (uint32_t)bx.by1 | ((uint32_t)bx.bz0 << 10) | ((uint32_t)bx.bz1 << 20));
+}
+__device__ __forceinline__ bool unpackCellBox(uint2 p, CellBox &bx) {
+  bx.bx0 = (int)(p.x & 1023u); bx.bx1 = (int)((p.x >> 10) & 1023u); bx.by0 = (int)((p.x >> 20) & 1023u);
+  bx.by1 = (int)(p.y & 1023u); bx.bz0 = (int)((p.y >> 10) & 1023u); bx.bz1 = (int)((p.y >> 20) & 1023u);
+  return p.x != 0xFFFFFFFFu;
+}
+
 // x-contiguous photon range of this lane for range index ri of the box
 __device__ __forceinline__ void boxRange(const GatherArgs &a, const CellBox &bx, int ri, int nranges, uint32_t &start,
                                          uint32_t &count) {
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       const bool live = k < nStaged;
       const uint4 itv = live ? stItem[k] : make_uint4(0u, 0u, 0u, 0u);
       const uint32_t stg = live ? stStaged[k] : 0u;
-      const uint32_t blocks = live ? (uint32_t)(((unsigned long long)stg * itv.y + 63ull) / 64ull) : 0u;
+      const uint32_t blocks = live ? (uint32_t)(((unsigned long long)stg * (itv.y & 0xFFu) + 63ull) / 64ull) : 0u;
       const uint32_t bIncl = wave_scan_incl(blocks, lane);
       const uint32_t bTotal = __shfl(bIncl, 63, 64);
       const uint32_t n = min(64u, nStaged - base);
@@ -405,7 +415,10 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
           }
         }
         CellBox bx;
-        if (boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx)) {
+        const bool haveBox = boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx);
+        if (a.planBoxes && (uint32_t)step < a.planBoxStride)
+          a.planBoxes[(size_t)(setBase / B + tile) * a.planBoxStride + step] = haveBox ? packCellBox(bx) : make_uint2(0xFFFFFFFFu, 0u);
+        if (haveBox) {
           // photons in the box from the summed-volume table: 8 reads
           const uint32_t nx1 = a.grid.dim[0] + 1, ny1 = a.grid.dim[1] + 1;
           const uint32_t *T = a.sat;
@@ -437,7 +450,8 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
         if (nStaged + 64u > PLAN_STAGE) flush();
         if (emit) {
           const uint32_t k = nStaged + (uint32_t)__popcll(emitMask & ((1ull << lane) - 1ull));
-          stItem[k] = make_uint4(setBase, nb, (uint32_t)cAFirst, (uint32_t)cAe);
+          // (G-BRE: the chunk's ordinal rides on nb, for the traversal to find the chunk's boxes)
+          stItem[k] = make_uint4(setBase, nb | ((setBase / B + tile) << 8), (uint32_t)cAFirst, (uint32_t)cAe);
           stStaged[k] = staged;
         }
         nStaged += (uint32_t)__popcll(emitMask);
