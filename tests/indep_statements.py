@@ -73,6 +73,7 @@ def bre3d_full(c):
         code = {1: abi.GVPM_SHIFT_DIFFUSE, 2: abi.GVPM_SHIFT_MEDIUM, 3: abi.GVPM_SHIFT_MANIFOLD, 0: abi.GVPM_SHIFT_INVALID}
         contributes &= np.array([code.get(int(s), abi.GVPM_SHIFT_INVALID) for s in stype]) == p.debug_shift
 
+    ph_arrays = (ppos, pn, prefix, pscat, pwi, ppdf, epdf, prr, pg, ptype, stype, emed)
     for s in range(rays.shape[0]):
         b = rays[s, 0]
         o, d, ln, rnd = b["o"].astype(f8), b["d"].astype(f8), f8(b["len"]), f8(b["rand"])
@@ -164,55 +165,10 @@ def bre3d_full(c):
                     dk = (off - so) @ sd
                     ds = (((so + np.outer(dk, sd)) - off) ** 2).sum(1)
                     pdf_s = 1.0 / np.maximum(2.0 * np.sqrt(np.maximum(0, r * r - ds)), 1e-4)
-                    gi = idx[k]
-                    st = stype[gi]
-                    can = (st == 1) | (st == 2)   # EDiffuseShift, EMediumShift with noMediumShift; manifold: host-only -> fails
-                    dproj = off - ppos[gi]
-                    lproj = np.linalg.norm(dproj, axis=1)
-                    dproj = dproj / lproj[:, None]
-                    vmax = lproj * seps if p.visibility_as_written else lproj * (1 - seps)
-                    ok = can & ~any_hit(c.tris, ppos[gi], dproj, eps, vmax)
-                    is_med, is_surf = ptype[gi] == abi.GVPM_PARENT_MEDIUM, ptype[gi] == abi.GVPM_PARENT_SURFACE
-                    n = pn[gi]
-                    cos_wo = (n * dproj).sum(1)
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        sign = cos_wo / (n * -WI[k]).sum(1)          # edge(c-1).d points parent -> photon = -wi
-                    ok &= is_med | ~(sign < 0)
-                    cos_wi = (n * pwi[gi]).sum(1)
-                    lam = INV_PI * cos_wo
-                    surf_ok = (cos_wi > 0) & (cos_wo > 0)
-                    pmed = phase_vec(pg[gi], pwi[gi], dproj)
-                    emit = INV_PI * np.maximum(cos_wo, 0)
-                    pdf_val = np.where(is_med, pmed, np.where(is_surf, np.where(surf_ok, lam, 0.0), emit))
-                    thr = np.where(is_med[:, None], pscat[gi] * pmed[:, None],
-                                   np.where(is_surf[:, None], pscat[gi] * np.where(surf_ok, lam, 0.0)[:, None], emit[:, None] * np.ones(3)))
-                    ok &= ~(is_surf & ~surf_ok)                      # the shading-normal test returns before the pdf is set
-                    gop = 1.0 / (lproj * lproj)
-                    spdf = pdf_val * gop
-                    thr = thr * gop[:, None]
-                    ok &= ppdf[gi] != 0
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        thr = thr / ppdf[gi][:, None] * prr[gi][:, None]
-                        in_med = emed[gi] == 1
-                        trl = np.exp(-sig_t * lproj)
-                        trl = np.where(trl < 1e-20, 0.0, trl)
-                        spdf = np.where(in_med, spdf * (sig_t * np.exp(-sig_t * lproj) * msw), spdf)
-                        thr = np.where(in_med[:, None], thr * (trl / epdf[gi])[:, None], thr)
-                    ok &= spdf != 0
-                    contrib = sig_s * (prefix[gi] * thr) * phase(g, -dproj, -sd)[:, None]
-                    sf = tr[k][:, None] * contrib * seye
-                    wk = np.full(k.size, 0.5)
-                    mis_ok = np.ones(k.size, bool)
-                    if p.use_mis:
-                        base_pdf = pdf_cam[k] * ppdf[gi] * epdf[gi]
-                        off_pdf = spdf * pdf_s
-                        mis_ok = ~((off_pdf == 0) | (base_pdf == 0))
-                        with np.errstate(divide="ignore", invalid="ignore"):
-                            x = sensor * (off_pdf / base_pdf)
-                        wk = 1.0 / (1.0 + (x * x if p.power_heuristic else x))
-                    good = ok & mis_ok
-                    sflux[k] = np.where(ok[:, None], sf, 0.0)         # a failed MIS keeps its flux and takes weight 1
-                    w[k] = np.where(good, wk, 1.0)
+                    sf_k, w_k, good = _photon_reconnect(p, c.tris, ph_arrays, idx[k], off, sd, WI[k], tr[k], pdf_cam[k], pdf_s, sensor,
+                                                        seye, eps, seps, sig_t, sig_s, g, msw)
+                    sflux[k] = sf_k
+                    w[k] = w_k
                     cnt["diffuse_shifts"] += int(good.sum())
                     cnt["failed_shifts"] += int((~good).sum())
             if (i == abi.GVPM_RIGHT and px == W - 1) or (i == abi.GVPM_TOP and py == H - 1):
@@ -220,6 +176,67 @@ def bre3d_full(c):
             acc[py, px, 15 + 3 * i:18 + 3 * i] += (base_c * (w[:, None] * norm)).sum(0)
             acc[py, px, 3 + 3 * i:6 + 3 * i] += (np.nan_to_num(sflux) * (w[:, None] * norm)).sum(0)
     return acc / c.nb, cnt
+
+
+def _photon_reconnect(p, tris, ph_arrays, gi, off, sd, WIk, trk, pdf_base_ray, pdf_s, sensor, seye, eps, seps, sig_t, sig_s, g, msw):
+    """shiftPhoton -> shiftPhotonDiffuse + diffuseReconnection (shift_volume_photon.cpp:49-117,382-486, shift_diffuse.cpp:11-134)
+    for the photons gi with offset positions `off`: (shiftedFlux, weight, success).  trk: transmittance of the shifted
+    camera ray up to the gather distance; pdf_base_ray / pdf_s: pdfBaseRay / pdfShiftRay of the estimator."""
+    ppos, pn, prefix, pscat, pwi, ppdf, epdf, prr, pg, ptype, stype, emed = ph_arrays
+    k = np.arange(len(gi))
+    tr = np.broadcast_to(trk, (len(gi),)) if np.ndim(trk) == 0 else trk
+    pdf_cam = np.broadcast_to(pdf_base_ray, (len(gi),)) if np.ndim(pdf_base_ray) == 0 else pdf_base_ray
+    WI = WIk
+    c = type("C", (), {"tris": tris})
+    st = stype[gi]
+    can = (st == 1) | (st == 2)   # EDiffuseShift, EMediumShift with noMediumShift; manifold: host-only -> fails
+    dproj = off - ppos[gi]
+    lproj = np.linalg.norm(dproj, axis=1)
+    dproj = dproj / lproj[:, None]
+    vmax = lproj * seps if p.visibility_as_written else lproj * (1 - seps)
+    ok = can & ~any_hit(c.tris, ppos[gi], dproj, eps, vmax)
+    is_med, is_surf = ptype[gi] == abi.GVPM_PARENT_MEDIUM, ptype[gi] == abi.GVPM_PARENT_SURFACE
+    n = pn[gi]
+    cos_wo = (n * dproj).sum(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sign = cos_wo / (n * -WI).sum(1)          # edge(c-1).d points parent -> photon = -wi
+    ok &= is_med | ~(sign < 0)
+    cos_wi = (n * pwi[gi]).sum(1)
+    lam = INV_PI * cos_wo
+    surf_ok = (cos_wi > 0) & (cos_wo > 0)
+    pmed = phase_vec(pg[gi], pwi[gi], dproj)
+    emit = INV_PI * np.maximum(cos_wo, 0)
+    pdf_val = np.where(is_med, pmed, np.where(is_surf, np.where(surf_ok, lam, 0.0), emit))
+    thr = np.where(is_med[:, None], pscat[gi] * pmed[:, None],
+                   np.where(is_surf[:, None], pscat[gi] * np.where(surf_ok, lam, 0.0)[:, None], emit[:, None] * np.ones(3)))
+    ok &= ~(is_surf & ~surf_ok)                      # the shading-normal test returns before the pdf is set
+    gop = 1.0 / (lproj * lproj)
+    spdf = pdf_val * gop
+    thr = thr * gop[:, None]
+    ok &= ppdf[gi] != 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        thr = thr / ppdf[gi][:, None] * prr[gi][:, None]
+        in_med = emed[gi] == 1
+        trl = np.exp(-sig_t * lproj)
+        trl = np.where(trl < 1e-20, 0.0, trl)
+        spdf = np.where(in_med, spdf * (sig_t * np.exp(-sig_t * lproj) * msw), spdf)
+        thr = np.where(in_med[:, None], thr * (trl / epdf[gi])[:, None], thr)
+    ok &= spdf != 0
+    contrib = sig_s * (prefix[gi] * thr) * phase(g, -dproj, -sd)[:, None]
+    sf = tr[:, None] * contrib * seye
+    wk = np.full(k.size, 0.5)
+    mis_ok = np.ones(k.size, bool)
+    if p.use_mis:
+        base_pdf = pdf_cam * ppdf[gi] * epdf[gi]
+        off_pdf = spdf * pdf_s
+        mis_ok = ~((off_pdf == 0) | (base_pdf == 0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = sensor * (off_pdf / base_pdf)
+        wk = 1.0 / (1.0 + (x * x if p.power_heuristic else x))
+    good = ok & mis_ok
+    sf_out = np.where(ok[:, None], sf, 0.0)         # a failed MIS keeps its flux and takes weight 1
+    w_out = np.where(good, wk, 1.0)
+    return sf_out, w_out, good
 
 
 def phase_vec(g, wi, wo):
@@ -722,3 +739,132 @@ def planes_full(c):
             acc[py, px, 3 + 3 * i:6 + 3 * i] += (sflux * w[:, None]).sum(0)
             acc[py, px, 15 + 3 * i:18 + 3 * i] += (base * w[:, None]).sum(0)
     return acc / c.nb, cnt
+
+
+# ======================================================================================================================
+# G-VPM (3D point kernel at sampled camera distances), written from
+#     GPMIntegrator::computeVolumeGradientPhoton     gvpm/gvpm.cpp:1081-1203 (the CDF over medium edges is host work:
+#                                                    the samples arrive with their edge's beam set, rand and pdfSel)
+#     HomogeneousMedium::sampleDistance / eval (EDistanceAlwaysValid)   src/medium/homogeneous.cpp:293-513
+#     VolumeGradientPositionQuery::operator()        gvpm/shift/shift_volume_photon.cpp:489-655
+#     VolumeGradientDistanceQuery pdfs               gvpm/shift/shift_volume_photon.h:162-197
+#     shiftNull / getShiftPos / shiftPhotonDiffuse   shift_volume_photon.cpp:119-158, 858-896, 382-486
+# ======================================================================================================================
+def vpm_full(c, scale_vol=None):
+    """One iteration of G-VPM over the case's samples: (sums[H, W, 27], counters, MVol[H, W]).  scale_vol: per-pixel
+    GatherPoint::scaleVol (default: the initial one everywhere)."""
+    p, ph, rays, smp, m = c.p, c.ph, c.rays, c.samples, c.m
+    H, W = p.height, p.width
+    f8 = np.float64
+    acc = np.zeros((H, W, 27))
+    mvol = np.zeros((H, W))
+    pos, wi, flux = ph.pos.astype(f8), ph.wi.astype(f8), ph.flux.astype(f8)
+    ppos, pn, prefix = ph.parent_pos.astype(f8), ph.parent_n.astype(f8), ph.prefix_w.astype(f8)
+    pscat, pwi = ph.parent_scat.astype(f8), ph.parent_wi.astype(f8)
+    ppdf, epdf, prr, pg = (a.astype(f8) for a in (ph.parent_pdf, ph.edge_pdf, ph.parent_rr, ph.parent_g))
+    fl = ph.flags
+    ptype, stype, emed, depth, comp = fl & 3, (fl >> 2) & 7, (fl >> 5) & 1, (fl >> 8) & 0xFF, (fl >> 16) & 0xFFFF
+    ph_arrays = (ppos, pn, prefix, pscat, pwi, ppdf, epdf, prr, pg, ptype, stype, emed)
+    eps, seps = f8(p.epsilon), f8(p.shadow_epsilon)
+    sig_t, sig_s, g, msw = f8(m.sigma_t[0]), np.array(list(m.sigma_s), f8), f8(m.g), f8(m.medium_sampling_weight)
+    norm = f8(np.float32(1.0) / np.float32(p.nb_camera_samples))  # `Float normalization = 1.f / nbCameraSamples`: a float quotient
+    bb = f8(np.float32(p.bsphere_radius)) * 0.01
+    cnt = dict(evaluations=0, null_shifts=0, diffuse_shifts=0, failed_shifts=0)
+    mode = p.lighting_interaction_mode
+    contributes = np.ones(ph.n, bool)
+    if not ((mode & abi.GVPM_SURF2MEDIA) and (mode & abi.GVPM_MEDIA2MEDIA)):
+        contributes &= np.where(ptype == abi.GVPM_PARENT_MEDIUM, bool(mode & abi.GVPM_MEDIA2MEDIA), bool(mode & abi.GVPM_SURF2MEDIA))
+    if p.bsdf_interaction_mode != abi.GVPM_BSDF_ALL:
+        contributes &= ~((comp > 0) & ((comp & p.bsdf_interaction_mode) == 0))
+    if p.debug_shift not in (abi.GVPM_SHIFT_ALL, abi.GVPM_SHIFT_NULL):
+        code = {1: abi.GVPM_SHIFT_DIFFUSE, 2: abi.GVPM_SHIFT_MEDIUM, 3: abi.GVPM_SHIFT_MANIFOLD, 0: abi.GVPM_SHIFT_INVALID}
+        contributes &= np.array([code.get(int(s), abi.GVPM_SHIFT_INVALID) for s in stype]) == p.debug_shift
+
+    for sm in smp:
+        set_i, rnd, pdf_sel = int(sm["set"]), f8(sm["rand"]), f8(sm["pdf_sel"])
+        b = rays[set_i, 0]
+        if not (int(b["info"]) & 1):
+            continue
+        o, d, ln = b["o"].astype(f8), b["d"].astype(f8), f8(b["len"])
+        edge = (int(b["info"]) >> 8) & 0xFF
+        px, py = int(b["pixel"]) & 0xFFFF, int(b["pixel"]) >> 16
+        sv = f8(p.initial_scale_volume) if scale_vol is None else f8(scale_vol[py, px])
+        r = bb * sv
+        # sampleDistance(Ray(o, d, Epsilon, beamDist), EDistanceAlwaysValid, rand), mediumSamplingWeight -> 1
+        mint, maxt = eps, ln
+        max_dist = max((maxt - mint) - eps, 0.0)
+        sampled = -np.log(1 - rnd * (1 - np.exp(-sig_t * max_dist))) / sig_t
+        if not (sampled < maxt - mint):
+            continue
+        t = sampled + mint
+        pdf_dist = sig_t / (1 - np.exp(-sig_t * (maxt - mint))) * np.exp(-sig_t * sampled)
+        tr_b = np.exp(-sig_t * sampled)
+        tr_b = 0.0 if tr_b < 1e-20 else tr_b
+        pdf_base = pdf_dist * pdf_sel
+        q = o + d * t
+        # PointKDTree::executeQuery: every photon with |p - q|^2 < r^2 is handed to the functor and counted (MVol)
+        d2 = ((pos - q) ** 2).sum(1)
+        inside = d2 < r * r
+        mvol[py, px] += int(inside.sum())
+        hit = inside & contributes
+        if p.max_depth > 0:
+            hit &= (depth.astype(np.int64) + edge) <= p.max_depth
+        idx = np.nonzero(hit)[0]
+        if idx.size == 0:
+            continue
+        cnt["evaluations"] += idx.size
+        P, WI, FL = pos[idx], wi[idx], flux[idx]
+        kv = 4.0 / 3.0 * np.pi * r ** 3
+        base_c = (tr_b * phase(g, WI, -d))[:, None] * FL * sig_s * b["eye"].astype(f8)
+        scale = norm / (kv * pdf_base)
+        acc[py, px, 0:3] += (base_c * scale).sum(0)
+        for i in range(4):
+            sh = rays[set_i, 1 + i]
+            w = np.ones(idx.size)
+            sflux = np.zeros((idx.size, 3))
+            if int(sh["info"]) & 1 and f8(sh["len"]) >= t:
+                so, sd, sl = sh["o"].astype(f8), sh["d"].astype(f8), f8(sh["len"])
+                seye = sh["eye"].astype(f8)
+                ratio, jac = f8(sh["pdf"]) / f8(b["pdf"]), f8(sh["jacobian"])
+                if edge != 1:
+                    jac *= f8(sh["gop"]) / f8(b["gop"])
+                    ratio *= f8(b["gop"]) / f8(sh["gop"])
+                sensor = ratio * jac
+                # shiftMRec: eval(Ray(so, sd, Epsilon, shiftDistMax), EDistanceAlwaysValid) with mRec.t = t
+                tr_s = np.exp(-sig_t * t)
+                tr_s = 0.0 if tr_s < 1e-20 else tr_s
+                pdf_shift = sig_t / (1 - np.exp(-sig_t * (sl - eps))) * np.exp(-sig_t * t) * pdf_sel
+                sh_pt = so + sd * t
+                is_null = np.zeros(idx.size, bool)
+                if p.use_shift_null:
+                    is_null = ((P - sh_pt) ** 2).sum(1) < r * r
+                if is_null.any():
+                    k = np.nonzero(is_null)[0]
+                    sflux[k] = (tr_s * phase(g, WI[k], -sd))[:, None] * FL[k] * sig_s * seye
+                    w[k] = 0.5
+                    if p.use_mis:
+                        w[k] = 1.0 if (pdf_shift == 0 or pdf_base == 0) else 1.0 / (1.0 + sensor * pdf_shift / pdf_base)
+                    cnt["null_shifts"] += k.size
+                rec = ~is_null
+                if p.debug_shift == abi.GVPM_SHIFT_NULL:
+                    rec[:] = False
+                k = np.nonzero(rec)[0]
+                if k.size:
+                    off = sh_pt + (P[k] - q)
+                    if p.use_shift_null:
+                        inside_k = ((q - off) ** 2).sum(1) < r * r
+                        dsh = sh_pt - q
+                        dsh = dsh / np.linalg.norm(dsh)
+                        cosd = (-(off - sh_pt)) @ dsh
+                        off = np.where(inside_k[:, None], off + dsh * (cosd * 2)[:, None], off)
+                    sf_k, w_k, good = _photon_reconnect(p, c.tris, ph_arrays, idx[k], off, sd, WI[k], tr_s, pdf_base, pdf_shift, sensor,
+                                                        seye, eps, seps, sig_t, sig_s, g, msw)
+                    sflux[k] = sf_k
+                    w[k] = w_k
+                    cnt["diffuse_shifts"] += int(good.sum())
+                    cnt["failed_shifts"] += int((~good).sum())
+            if (i == abi.GVPM_RIGHT and px == W - 1) or (i == abi.GVPM_TOP and py == H - 1):
+                w[:] = 1.0
+            acc[py, px, 15 + 3 * i:18 + 3 * i] += (base_c * (w * scale)[:, None]).sum(0)
+            acc[py, px, 3 + 3 * i:6 + 3 * i] += (np.nan_to_num(sflux) * (w * scale)[:, None]).sum(0)
+    return acc, cnt, mvol

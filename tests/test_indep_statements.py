@@ -110,3 +110,27 @@ def test_planes_all_27_accumulators(scene, g, kw):
     lum = ref[..., 0:3].mean()
     for j in range(9):
         assert np.abs(acc[..., 3 * j:3 * j + 3] - ref[..., 3 * j:3 * j + 3]).max() / lum < 1e-9, j
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G-VPM: distance sampling, radius query, null shift / reconnection at the sampled distance, pdfs of the distance estimator
+from test_oracle_vpm import make_vpm_case  # noqa: E402
+
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_mirror"])
+@pytest.mark.parametrize("kw", [dict(), dict(use_mis=0), dict(use_shift_null=0), dict(max_depth=3)])
+def test_vpm_all_27_accumulators(scene, kw):
+    c = make_vpm_case(scene, 12, 10, 6000, 8.0, 6, **kw)
+    ref, rsv, rnv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=True)
+    acc, icnt, mvol = I.vpm_full(c)
+    assert cnt["evaluations"] > 300
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert icnt[k] == cnt[k], (k, icnt, cnt)
+    lum = ref[..., 0:3].mean()
+    for j in range(9):
+        assert np.abs(acc[..., 3 * j:3 * j + 3] - ref[..., 3 * j:3 * j + 3]).max() / lum < 1e-9, j
+    # the SPPM update of gvpm.cpp:1191-1195 from the photon counts
+    N = mvol * c.p.alpha
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sv = np.where(mvol > 0, c.p.initial_scale_volume * np.cbrt((c.p.alpha * mvol) / mvol), c.p.initial_scale_volume)
+    assert np.allclose(rnv, N, rtol=1e-12) and np.allclose(rsv, sv, rtol=1e-12)
