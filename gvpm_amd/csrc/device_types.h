@@ -28,6 +28,20 @@ struct Grid {
   float invCell;
   int dim[3];
   uint32_t ncells;
+  // mode 1 (G-BRE, round 3): the camera beams' lines pass through ONE point (a pinhole sensor's first medium edges), so a
+  // photon can only be met by rays inside a small rectangle of the ray bundle's (u, v) = (d.U, d.V) / d.A plane.  The
+  // cells are then (u cell, v cell, level): level l has cells of s0 * 2^l and holds the photons whose rectangle's half
+  // extent is at most that; a tile reads, per level, the cells its rays' bounding rectangle reaches when dilated by one
+  // cell size.  dim = {G, G, 2}, G a power of two, level l has (G >> l)^2 cells, the last level is one cell; the levels
+  // are packed into the two layers as bundle_grid.h lays out.  Everything downstream of the cell key (counting sort, summed-volume table, planner items,
+  // staging, tests) is the 3D grid's: a "slab step" of a tile is a level instead of a run of layers, and there are a
+  // handful of them instead of dozens (bundle_grid.h).
+  int mode, levels;
+  float bo[3], ba[3], bu[3], bv[3];  // the point the rays' lines share; A (the bundle's mean direction), U, V orthonormal
+  float lineTol;                     // how far from that point a ray's line may pass (fp32 rounding of the host's rays)
+  float uMin, uMax, vMin, vMax;      // the rays' (u, v) range, padded
+  float s0, invS0;                   // level-0 cell size
+  float radius;                      // kernel radius the photons were binned for
 };
 
 // Occluders by cell of a coarse uniform grid over the scene (grid_build.hip: near_grid_*): tris[start[c] .. start[c + 1])
@@ -112,6 +126,7 @@ struct GatherArgs {
   // x = 0xFFFFFFFF: no beam of the chunk reaches the slab.  Null: the traversal computes its boxes (G-Beams).
   uint2 *planBoxes;
   uint32_t planBoxStride;
+  uint32_t *bundleFlag;  // set by the planner when a valid ray is outside the bundle the grid (mode 1) was built for
   const float2 *beamClear;   // per beam {cosA0, M1}: the free cone of its reconnections (grid_build.hip, beam_near_kernel)
   // G-VPM only
   const gvpm_vpm_sample *samples;

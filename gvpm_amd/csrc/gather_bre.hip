@@ -475,7 +475,11 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
       s.stageIdx[k] = gi;
     };
 
-    const int cBeg = max((int)item.z, w.cA0), cEnd = min((int)item.w, w.cA1);
+    // (bundle cells: a heavy item is split into parts that take its staging windows round-robin, tile_walk.h)
+    const bool bundle = a.grid.mode == 1;
+    const uint32_t part = bundle ? (item.z >> 8) & 0xFFFu : 0u, parts = bundle ? max(item.z >> 20, 1u) : 1u;
+    uint32_t winNo = 0;
+    const int cBeg = max((int)(bundle ? item.z & 0xFFu : item.z), w.cA0), cEnd = min((int)item.w, w.cA1);
     for (int cA = cBeg; cA <= cEnd; cA += w.K) {
       const int cAe = min(cA + w.K - 1, cEnd);
       CellBox bx;
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
         const uint32_t excl = incl - count;
         const uint32_t total = __shfl(incl, 63, 64);
         for (uint32_t win = 0; win < total; win += STAGE) {
+          if (parts > 1u && (winNo++ % parts) != part) continue;
           // stage [win, win + STAGE) of the concatenated ranges
           waveLdsSync();
           const uint32_t nst = min((uint32_t)STAGE, total - win);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include "bundle_grid.h"
 #include "device_types.h"
 #include "shift_device.h"
 #include "vec.h"
@@ -76,12 +77,13 @@ __global__ void bounds_final_kernel(const float *partial, int nblocks, float *ou
 
 // counters -> pinned host memory (same reason)
 __global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d,
-                                  uint32_t *hostOut) {
+                                  const uint32_t *e, uint32_t *hostOut) {
   if (threadIdx.x == 0) {
     hostOut[0] = a ? *a : 0u;
     hostOut[1] = b ? *b : 0u;
     hostOut[2] = c ? *c : 0u;
     hostOut[3] = d ? *d : 0u;
+    hostOut[4] = e ? *e : 0u;
     __threadfence_system();
   }
 }
@@ -108,10 +110,15 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict
                                                          uint32_t *keys, uint32_t *rank, uint32_t *count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int cx = cellCoord(pos[3 * (size_t)i + 0], g.org[0], g.invCell, g.dim[0]);
-  const int cy = cellCoord(pos[3 * (size_t)i + 1], g.org[1], g.invCell, g.dim[1]);
-  const int cz = cellCoord(pos[3 * (size_t)i + 2], g.org[2], g.invCell, g.dim[2]);
-  const uint32_t k = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+  uint32_t k;
+  if (g.mode == 1) {
+    k = bundlePhotonKey(g, pos[3 * (size_t)i + 0], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]);
+  } else {
+    const int cx = cellCoord(pos[3 * (size_t)i + 0], g.org[0], g.invCell, g.dim[0]);
+    const int cy = cellCoord(pos[3 * (size_t)i + 1], g.org[1], g.invCell, g.dim[1]);
+    const int cz = cellCoord(pos[3 * (size_t)i + 2], g.org[2], g.invCell, g.dim[2]);
+    k = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+  }
   keys[i] = k;
   rank[i] = atomicAdd(&count[k], 1u);
 }
@@ -786,9 +793,72 @@ void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, fl
   hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6, hostOut);
 }
 
-void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *hostOut,
-                       hipStream_t s) {
-  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, c, d, hostOut);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, const uint32_t *e,
+                       uint32_t *hostOut, hipStream_t s) {
+  hipLaunchKernelGGL(export_u32_kernel, dim3(1), dim3(64), 0, s, a, b, c, d, e, hostOut);
+}
+
+// ---- the ray bundle of an upload of camera beams (Grid::mode 1, bundle_grid.h) ------------
+// One workgroup, run once per fit (the host keeps the frame until a planner reports a ray outside it).  The base rays
+// start where their camera path enters the medium, so what they share is a point C on their LINES, the sensor's
+// pinhole: the least-squares point of sum |(I - d d^T)(C - o)|^2.
+// pass 0 (sums, fp64): out = {M = sum (I - d d^T): xx xy xz yy yz zz; b = sum (I - d d^T) o (3); sum d (3); valid base rays}
+// pass 1 (frame in g): out = {uMin, uMax, vMin, vMax, min d.A, max |(I - d d^T)(o - C)|^2, min (o - C).d, max (o - C).d}
+__global__ __launch_bounds__(1024) void bundle_fit_kernel(const gvpm_camera_ray *__restrict__ rays, uint32_t nsets, int pass, Grid g,
+                                                          double *out) {
+  constexpr int NV = 13;
+  __shared__ double red[NV][16];
+  double v[NV];
+  // kind of reduction per slot: 0 sum, 1 min, 2 max
+  auto kind = [&](int k) { return pass == 0 ? 0 : ((k == 0 || k == 2 || k == 4 || k == 6) ? 1 : (k < 8 ? 2 : 0)); };
+  for (int k = 0; k < NV; ++k) v[k] = kind(k) == 0 ? 0.0 : (kind(k) == 1 ? (double)INFINITY : -(double)INFINITY);
+  for (uint32_t i = threadIdx.x; i < nsets; i += blockDim.x) {
+    const gvpm_camera_ray &r = rays[(size_t)i * 5];
+    if (!GVPM_RAY_VALID(r.info)) continue;
+    const double dx = r.d[0], dy = r.d[1], dz = r.d[2];
+    if (pass == 0) {
+      const double ox = r.o[0], oy = r.o[1], oz = r.o[2];
+      const double od = ox * dx + oy * dy + oz * dz;
+      v[0] += 1.0 - dx * dx; v[1] -= dx * dy; v[2] -= dx * dz;
+      v[3] += 1.0 - dy * dy; v[4] -= dy * dz; v[5] += 1.0 - dz * dz;
+      v[6] += ox - dx * od; v[7] += oy - dy * od; v[8] += oz - dz * od;
+      v[9] += dx; v[10] += dy; v[11] += dz;
+      v[12] += 1.0;
+    } else {
+      const double dA = dx * g.ba[0] + dy * g.ba[1] + dz * g.ba[2];
+      const double inv = 1.0 / fmax(dA, 1e-30);
+      const double u = (dx * g.bu[0] + dy * g.bu[1] + dz * g.bu[2]) * inv;
+      const double w = (dx * g.bv[0] + dy * g.bv[1] + dz * g.bv[2]) * inv;
+      const double wx = (double)r.o[0] - g.bo[0], wy = (double)r.o[1] - g.bo[1], wz = (double)r.o[2] - g.bo[2];
+      const double sd = wx * dx + wy * dy + wz * dz;
+      const double px = wx - sd * dx, py = wy - sd * dy, pz = wz - sd * dz;
+      v[0] = fmin(v[0], u); v[1] = fmax(v[1], u);
+      v[2] = fmin(v[2], w); v[3] = fmax(v[3], w);
+      v[4] = fmin(v[4], dA);
+      v[5] = fmax(v[5], px * px + py * py + pz * pz);
+      v[6] = fmin(v[6], sd);
+      v[7] = fmax(v[7], sd);
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+    for (int o = 32; o > 0; o >>= 1) {
+      const double y = __shfl_xor(x, o, 64);
+      x = kind(k) == 0 ? x + y : (kind(k) == 1 ? fmin(x, y) : fmax(x, y));
+    }
+    if (lane == 0) red[k][wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    double x = red[k][0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) x = kind(k) == 0 ? x + red[k][w] : (kind(k) == 1 ? fmin(x, red[k][w]) : fmax(x, red[k][w]));
+    out[k] = x;
+  }
+}
+void launch_bundle_fit(const gvpm_camera_ray *rays, uint32_t nsets, int pass, const Grid &g, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(bundle_fit_kernel, dim3(1), dim3(1024), 0, s, rays, nsets, pass, g, out);
 }
 
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {

@@ -23,7 +23,8 @@ hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, cons
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
                    hipStream_t s);
 hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
-void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, uint32_t *hostOut,
+void launch_bundle_fit(const gvpm_camera_ray *rays, uint32_t nsets, int pass, const Grid &g, double *out, hipStream_t s);
+void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, const uint32_t *e, uint32_t *hostOut,
                        hipStream_t s);
 void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
@@ -227,6 +228,17 @@ struct gvpm_context {
   int setIdx = 0;
   bool travOnBuild = true;        // traversal on the build stream (else on the gather stream)
   bool beamsExact = false;        // G-Beams: the literal fp64 evaluation instead of the local-frame fp32 one
+  // G-BRE bundle cells (Grid::mode 1, bundle_grid.h), GVPM_BUNDLE=1.  Off by default: measured on MI355X (round 3,
+  // scripts/r03_bundle_ab.sh, r03_bundle_c4.sh) the traversal gains 16 % alone (0.45 -> 0.38 ms at C2) and a rank's step
+  // of the 8-GPU C4 run 8 % (3.09 -> 2.85 ms), but the pipelined C2 step is unchanged (1.29 ms: the evaluation kernel
+  // paces it) and the whole-frame C4 step loses 4 %.  bundleState: 0 not fitted, 1 frame fitted (bundleGrid holds it;
+  // the cell fields are filled per build), -1 the rays are not a bundle (until gvpm_reset).
+  bool bundleEnabled = false;
+  int bundleState = 0, bundleViolations = 0;
+  int lastGridMode = 0;  // of the last G-BRE build (gvpm_stats::reserved[0])
+  uint32_t lastGridCells = 0;
+  float bundleDiv = 2.f;  // level-0 cells per tile width (GVPM_BUNDLE_DIV)
+  Grid bundleGrid{};
   bool planBoxHandOff = true;     // G-BRE: the traversal reads the planner's slab boxes (GVPM_PLAN_BOXES=0: computes its own)
   bool beamsFreeCone = true;      // G-Beams: reconnections inside their beam's free cone skip the any-hit loop (GVPM_BEAMS_FREE_CONE=0: none do)
   size_t beamPairsInit = (size_t)16 << 20;  // G-Beams: first capacity of the pair list (GVPM_BEAM_PAIRS_INIT; tests shrink it)
@@ -508,6 +520,11 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
   if (const char *e = getenv("GVPM_PLAN_BOXES")) h->planBoxHandOff = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BUNDLE")) h->bundleEnabled = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BUNDLE_DIV")) {
+    const float v = (float)atof(e);
+    if (v >= 0.25f && v <= 16.f) h->bundleDiv = v;
+  }
   if (const char *e = getenv("GVPM_BEAM_PAIRS_INIT")) {
     const long long v = atoll(e);
     if (v >= 64 && v <= ((long long)1 << 31)) h->beamPairsInit = (size_t)v;
@@ -587,6 +604,8 @@ int gvpm_reset(gvpm_context *h) {
   HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * GVPM_STAT_ROWS * sizeof(unsigned long long), h->stream));
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
   h->sumIt = 0;
+  h->bundleState = 0;
+  h->bundleViolations = 0;
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   for (size_t &u : h->eventsHead) u = 0;
   for (size_t &u : h->eventsCount) u = 0;
@@ -955,7 +974,7 @@ static int ilog2ceil(uint32_t v) {
 // The occluder grid of the near-occluder lists (grid_build.hip: near_grid_kernel, nearVisit): count, scan, fill.  Once per
 // scene: the one host read-back (the number of entries) stalls nothing that matters.
 static int buildNearGrid(gvpm_context *h, float reach) {
-  NearGrid g;
+  NearGrid g{};
   float ext[3], vol = 1.f;
   for (int c = 0; c < 3; ++c) {
     ext[c] = std::max(h->triMax[c] - h->triMin[c] + 2.02f * reach, 1e-6f);
@@ -990,7 +1009,97 @@ static int buildNearGrid(gvpm_context *h, float reach) {
   return GVPM_OK;
 }
 
-static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
+// The frame of the camera beams' bundle: common origin, mean direction, (u, v) range.  Two small reductions and a host
+// wait, once; afterwards every planner run checks its rays against the frame (GatherArgs::bundleFlag).
+static int fitBundle(gvpm_context *h) {
+  h->bundleState = -1;
+  if (!h->nsets || !h->raysDev) return GVPM_OK;
+  HIP_TRY(h, h->bs->bounds6.ensure(32));
+  double *dev = reinterpret_cast<double *>(h->bs->bounds6.p);
+  double o[13];
+  Grid g{};
+  launch_bundle_fit(h->raysDev, h->nsets, 0, g, dev, h->bstream);
+  HIP_TRY(h, hipMemcpyAsync(o, dev, sizeof(o), hipMemcpyDeviceToHost, h->bstream));
+  HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  for (int k = 0; k < 13; ++k)
+    if (!std::isfinite(o[k])) return GVPM_OK;
+  const double cnt = o[12];
+  if (!(cnt >= 1.0)) return GVPM_OK;
+  // C = M^-1 b, M symmetric (adjugate); rays of one direction only (an orthographic sensor) leave M singular
+  const double xx = o[0], xy = o[1], xz = o[2], yy = o[3], yz = o[4], zz = o[5];
+  const double c00 = yy * zz - yz * yz, c01 = xz * yz - xy * zz, c02 = xy * yz - xz * yy;
+  const double c11 = xx * zz - xz * xz, c12 = xy * xz - xx * yz, c22 = xx * yy - xy * xy;
+  const double det = xx * c00 + xy * c01 + xz * c02;
+  if (!(det > 1e-9 * cnt * cnt * cnt)) return GVPM_OK;
+  const double C[3] = {(c00 * o[6] + c01 * o[7] + c02 * o[8]) / det, (c01 * o[6] + c11 * o[7] + c12 * o[8]) / det,
+                       (c02 * o[6] + c12 * o[7] + c22 * o[8]) / det};
+  double A[3] = {o[9], o[10], o[11]};
+  const double len = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
+  if (!(len > 0.2 * cnt)) return GVPM_OK;  // directions all over the sphere
+  int sm = 0;
+  for (int c = 0; c < 3; ++c) {
+    A[c] /= len;
+    if (fabs(A[c]) < fabs(A[sm])) sm = c;
+  }
+  double E[3] = {0, 0, 0}, U[3], V[3];
+  E[sm] = 1.0;
+  U[0] = A[1] * E[2] - A[2] * E[1]; U[1] = A[2] * E[0] - A[0] * E[2]; U[2] = A[0] * E[1] - A[1] * E[0];
+  const double ul = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+  for (int c = 0; c < 3; ++c) U[c] /= ul;
+  V[0] = A[1] * U[2] - A[2] * U[1]; V[1] = A[2] * U[0] - A[0] * U[2]; V[2] = A[0] * U[1] - A[1] * U[0];
+  double c1 = 0;
+  for (int c = 0; c < 3; ++c) {
+    g.bo[c] = (float)C[c];
+    g.ba[c] = (float)A[c];
+    g.bu[c] = (float)U[c];
+    g.bv[c] = (float)V[c];
+    c1 += fabs(C[c]);
+  }
+  launch_bundle_fit(h->raysDev, h->nsets, 1, g, dev, h->bstream);
+  HIP_TRY(h, hipMemcpyAsync(o, dev, sizeof(o), hipMemcpyDeviceToHost, h->bstream));
+  HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  for (int k = 0; k < 8; ++k)
+    if (!std::isfinite(o[k])) return GVPM_OK;
+  if (!(o[4] > 0.15)) return GVPM_OK;  // a field of view near 180 degrees: (u, v) is no parametrisation for it
+  // the lines must pass the point to fp32 rounding of positions of this size, and the point must not lie ahead of a start
+  const double scale = 1.0 + c1 + fabs(o[6]) + fabs(o[7]);
+  const double res = std::sqrt(std::max(o[5], 0.0));
+  if (res > 4e-6 * scale || o[6] < -4e-6 * scale) return GVPM_OK;
+  g.lineTol = (float)(2.0 * res + 4e-6 * scale);
+  // the next uploads are the same sensor with other sub-pixel offsets: two pixels of margin
+  const double px = std::max(o[1] - o[0], o[3] - o[2]) / (double)std::max(1, std::min(h->cfg.width, h->cfg.height));
+  const double pad = 2.0 * px + 1e-5 * (1.0 + fabs(o[0]) + fabs(o[1]) + fabs(o[2]) + fabs(o[3]));
+  g.uMin = (float)(o[0] - pad); g.uMax = (float)(o[1] + pad);
+  g.vMin = (float)(o[2] - pad); g.vMax = (float)(o[3] + pad);
+  g.mode = 1;
+  h->bundleGrid = g;
+  h->bundleState = 1;
+  return GVPM_OK;
+}
+
+// cells of the bundle grid for this build: level-0 cells of 1 / bundleDiv of a tile's width
+static Grid bundleCells(const gvpm_context *h, float r, int tileW) {
+  Grid g = h->bundleGrid;
+  const float range = fmaxf(g.uMax - g.uMin, g.vMax - g.vMin);
+  const float tile = range * (float)tileW / (float)std::max(1, std::max(h->cfg.width, h->cfg.height));
+  int G = 8;
+  while (G < 512 && range / (float)G > tile / h->bundleDiv) G *= 2;
+  int levels = 1;
+  while ((1 << (levels - 1)) < G) ++levels;  // log2(G) + 1: the last level is one cell
+  g.dim[0] = g.dim[1] = G;
+  g.dim[2] = 2;
+  g.levels = levels;
+  g.ncells = (uint32_t)G * (uint32_t)G * 2u;
+  g.s0 = range / (float)G;
+  g.invS0 = 1.f / g.s0;
+  g.radius = r;
+  g.org[0] = g.org[1] = g.org[2] = 0.f;
+  g.cell = g.s0;
+  g.invCell = g.invS0;
+  return g;
+}
+
+static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force3D = false) {
   const uint32_t n = h->nph;
   h->boundsPending = false;
   if (n == 0) {
@@ -1001,7 +1110,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   }
   const int nblocks = 1024;
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
-  HIP_TRY(h, h->bs->bounds6.ensure(8));
+  HIP_TRY(h, h->bs->bounds6.ensure(32));
   float b6[6];
   if (!h->pinB6) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
@@ -1024,7 +1133,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
     if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
     ext = fmaxf(ext, b6[3 + c] - b6[c]);
   }
-  Grid g;
+  Grid g{};
   // cell edge in radii.  G-BRE with maps up to 2 M photons: 1.5 -- the cell arrays (memset, scan, summed-volume table:
   // ~135 of the build's 575 us at C2 with cells of one radius) shrink 3.4x, and there the build is the stage the
   // pipelined step waits for; the traversal tests 1.3x the photons per hit.  Measured at C2: 1.51 -> 1.43-1.445 ms per
@@ -1042,6 +1151,14 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false) {
   }
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
+  if (deferred && h->bundleEnabled && h->bundleState >= 0 && !force3D) {
+    // G-BRE: the camera beams of a pinhole sensor leave one point -- cells over the bundle's (u, v) plane instead
+    if (h->bundleState == 0) {
+      const int rcf = fitBundle(h);
+      if (rcf != GVPM_OK) return rcf;
+    }
+    if (h->bundleState == 1) g = bundleCells(h, r, h->beamsPerWave == 16 ? 4 : 8);
+  }
   h->bs->grid = g;
   // counting sort by cell (x fastest): count + rank, exclusive scan, scatter
   HIP_TRY(h, h->bs->keysA.ensure(n));
@@ -1214,7 +1331,21 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   int rc = nextEvents(h, &evBuild, 2);
   if (rc != GVPM_OK) return rc;
   h->bstream = h->pipeline ? h->streamB : h->stream;
+  // the evaluation adds this iteration's estimate (1 / nb_paths per partial sum) straight into the running sum
+  h->sumMode = true;
+  if (h->sumIt != 0 && it - 1 != h->sumIt) {
+    // not the successor of the last iteration: the reference's fold (mean * (it - 1) + v) / it then weighs the old
+    // mean by (it - 1) / it, i.e. the sum by (it - 1) / last
+    launch_scale(h->accum.p, h->accum.p, h->npix * 27, (float)((double)(it - 1) / (double)h->sumIt), h->stream);
+  }
+  h->sumIt = it;
   bool rebuilt = false;
+  GatherArgs a;
+  uint32_t itemCap = 0, blocks = 0, nItems = 0;
+  bool force3D = false;
+  // (a second pass only when the planner met a ray outside the bundle the grid was keyed for: rebuilt in 3D)
+  for (int attempt = 0;; ++attempt) {
+  rebuilt = false;
   if (h->photonsDirty || h->beamsDirty || r != h->bs->builtRadius) {
     // the other set; wait until the kernels that last read it are done
     h->setIdx = (h->setIdx + 1) % (h->pipeline && h->travStream ? 3 : 2);
@@ -1222,7 +1353,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
     HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
     lap("waitevent");
-    rc = buildGrid(h, r, true);
+    rc = buildGrid(h, r, true, force3D);
     lap("buildGrid");
     if (rc == GVPM_OK) rc = sortBeams(h);
     lap("sortBeams");
@@ -1241,19 +1372,10 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     if (h->bs->used && h->pipeline && h->travStream) HIP_TRY(h, hipStreamWaitEvent(h->streamC, h->bs->lastUse, 0));
     HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
   }
-  GatherArgs a;
   fillArgs(h, a, r);
-  // the evaluation adds this iteration's estimate (1 / nb_paths per partial sum) straight into the running sum
-  h->sumMode = true;
   a.iter = h->accum.p;
   a.iterScale = 1.0f / (float)nb_paths;
-  if (h->sumIt != 0 && it - 1 != h->sumIt) {
-    // not the successor of the last iteration: the reference's fold (mean * (it - 1) + v) / it then weighs the old
-    // mean by (it - 1) / it, i.e. the sum by (it - 1) / last
-    launch_scale(h->accum.p, h->accum.p, h->npix * 27, (float)((double)(it - 1) / (double)h->sumIt), h->stream);
-  }
-  h->sumIt = it;
-  const uint32_t itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
+  itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
   HIP_TRY(h, h->bs->items.ensure(itemCap));
   HIP_TRY(h, h->bs->itemOff.ensure(itemCap));
   if (h->planBoxHandOff) {
@@ -1269,8 +1391,9 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
       a.planBoxStride = stride;
     }
   }
-  HIP_TRY(h, h->bs->queueCtl.ensure(4));
-  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 4 * sizeof(uint32_t), h->bstream));
+  HIP_TRY(h, h->bs->queueCtl.ensure(8));
+  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->bstream));
+  a.bundleFlag = h->bs->queueCtl.p + 4;
   launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,
                   h->bs->queueCtl.p + 3, itemCap, h->bstream);
   // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only) ...
@@ -1280,13 +1403,26 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, rebuilt ? h->bs->nearExt.p : nullptr,
-                    h->bs->queueCtl.p, h->pinCtl, h->bstream);
+                    h->bs->queueCtl.p, h->bs->queueCtl.p + 4, h->pinCtl, h->bstream);
   HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
   lap("plan");
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
   lap("syncB");
-  const uint32_t blocks = h->pinCtl[0];
-  const uint32_t nItems = h->pinCtl[3];
+  blocks = h->pinCtl[0];
+  nItems = h->pinCtl[3];
+  if (a.grid.mode == 1 && h->pinCtl[4] != 0u && attempt == 0) {
+    // not the bundle the cells were keyed for (another sensor, or later edges of the camera paths among the beams):
+    // this step again on the 3D grid; the frame is fitted anew at the next build, a few times
+    h->bundleState = ++h->bundleViolations > 3 ? -1 : 0;
+    h->photonsDirty = true;
+    h->boundsPending = false;
+    force3D = true;
+    continue;
+  }
+  break;
+  }
+  h->lastGridMode = a.grid.mode;
+  h->lastGridCells = a.grid.ncells;
   if (nItems > itemCap) {
     h->bstream = h->stream;
     return fail(h, GVPM_ERR_STATE, "G-BRE planner produced more work items than its bound");
@@ -1294,9 +1430,9 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   if (getenv("GVPM_TRACE_PLAN")) {
     uint32_t q[4] = {0, 0, 0, 0};
     (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[plan] items %u staged blocks %u tiles %u sets %u; photons %u, grid %d x %d x %d cells of %g (radius %g)\n", q[0],
-            blocks, h->bs->ntiles, h->nsets, h->nph, h->bs->grid.dim[0], h->bs->grid.dim[1], h->bs->grid.dim[2],
-            (double)h->bs->grid.cell, (double)r);
+    fprintf(stderr, "[plan] items %u staged blocks %u tiles %u sets %u; photons %u, %s %d x %d x %d cells of %g (radius %g)\n", q[0],
+            blocks, h->bs->ntiles, h->nsets, h->nph, h->bs->grid.mode == 1 ? "bundle cells" : "grid", h->bs->grid.dim[0],
+            h->bs->grid.dim[1], h->bs->grid.dim[2], (double)h->bs->grid.cell, (double)r);
   }
   if (rebuilt) {
     h->nearOverflow = h->cfg.visibility_as_written && h->pinCtl[1] != 0;
@@ -1382,7 +1518,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   // bounds of the beam end points and origins
   const int nblocks = 256;
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
-  HIP_TRY(h, h->bs->bounds6.ensure(16));
+  HIP_TRY(h, h->bs->bounds6.ensure(32));
   launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, nullptr, h->stream);
   launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, nullptr, h->stream);
   float b12[12];
@@ -1395,7 +1531,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
     if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite beam position");
     ext = fmaxf(ext, b6[3 + c] - b6[c]);
   }
-  Grid g;
+  Grid g{};
   // sub-beams (and cells) of 3/4 of the kernel radius: the traversal cost follows the number of sphere tests, which
   // shrinks with the cell until the ext/256 floor (measured: 34 ms at 1.5 r, 23.5 ms at 0.75 r and below)
   // (round 3, measured at C3 with the round's evaluation: sub-beams and cells of 1.5 r -- 24 M sub-beams instead of 47 M,
@@ -1803,6 +1939,7 @@ int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   out->diffuse_shifts = v[3];
   out->failed_shifts = v[4];
   out->dropped_pairs = v[7];
+  out->reserved[0] = ((uint64_t)h->lastGridMode << 56) | (uint64_t)h->lastGridCells;
   // the planner's bound on an item's pair region is exact: a dropped pair means a biased image, not a slow one
   if (v[7]) return fail(h, GVPM_ERR_STATE, "the G-BRE traversal dropped pairs: planner bound violated");
   return GVPM_OK;

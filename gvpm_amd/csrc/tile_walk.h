@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "bundle_grid.h"
 #include "device_types.h"
 #include "shift_device.h"
 #include "vec.h"
@@ -87,6 +88,9 @@ struct TileWalk {
   float orgA, orgU, orgV, pad;
   int dimA, dimU, dimV;
   bool any;
+  // bundle grid (Grid::mode == 1): the (u, v) rectangle of the tile's rays; a "slab step" is a level
+  float bu0, bu1, bv0, bv1;
+  bool bundleBad;  // a valid ray of the tile is not of the bundle the grid was built for: the host rebuilds in 3D
 };
 
 // (no barrier at the end: for kernels whose waves own their LDS tile and order its accesses themselves)
@@ -175,6 +179,22 @@ __device__ __forceinline__ void tileSetup(const GatherArgs &a, const RayTile<B> 
 __device__ __forceinline__ void tileSetupFrom(const GatherArgs &a, const RayReg &base, bool valid, TileWalk &w) {
   w.base = base;
   w.beamValid = valid;
+  w.bundleBad = false;
+  if (a.grid.mode == 1) {
+    float u = 0.f, v = 0.f;
+    const bool ok = bundleRayUV(a.grid, base.o.x, base.o.y, base.o.z, base.d.x, base.d.y, base.d.z, u, v);
+    w.bundleBad = __ballot(valid && !ok) != 0ull;
+    w.bu0 = wave_min(valid ? u : INFINITY); w.bu1 = wave_max(valid ? u : -INFINITY);
+    w.bv0 = wave_min(valid ? v : INFINITY); w.bv1 = wave_max(valid ? v : -INFINITY);
+    w.any = w.bu0 <= w.bu1 && a.nph > 0 && !w.bundleBad;
+    w.A = 0;
+    w.cA0 = 0;
+    w.cA1 = w.any ? a.grid.levels - 1 : -1;
+    w.K = 1;
+    w.dimA = a.grid.levels;
+    w.pad = 0.f;
+    return;
+  }
   const float r = a.radius, eps = a.cfg.epsilon;
   const float mint = eps, maxt = w.base.len - eps;
   int A;
@@ -276,6 +296,11 @@ __device__ __forceinline__ bool boxFromFootprint(const GatherArgs &a, const Tile
 // cell box of the slab layers [cA, cAe] (every lane holds one beam; wave-uniform result);
 // false when no beam of the tile reaches the slab
 __device__ __forceinline__ bool slabBox(const GatherArgs &a, const TileWalk &w, int cA, int cAe, CellBox &bx) {
+  if (a.grid.mode == 1) {
+    const BundleBox b = bundleTileBox(a.grid, cA, w.bu0, w.bu1, w.bv0, w.bv1);
+    bx.bx0 = b.x0; bx.bx1 = b.x1; bx.by0 = b.y0; bx.by1 = b.y1; bx.bz0 = bx.bz1 = b.z;
+    return true;
+  }
   float lo, hi;
   slabRange(a, w, cA, cAe, lo, hi);
   float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
@@ -387,9 +412,10 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
     const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
     TileWalk w;
     tileSetupFrom(a, base, base.valid, w);
+    if (w.bundleBad && lane == 0 && a.bundleFlag) atomicOr(a.bundleFlag, 1u);
     if (!w.any) continue;
     __syncthreads();
-    if (lane < B) {
+    if (lane < B && a.grid.mode != 1) {
       pb[0][lane] = w.oA; pb[1][lane] = w.dA; pb[2][lane] = w.oU; pb[3][lane] = w.dU;
       pb[4][lane] = w.oV; pb[5][lane] = w.dV; pb[6][lane] = w.t0; pb[7][lane] = w.t1;
       pvalid[lane] = w.beamValid ? 1u : 0u;
@@ -402,20 +428,25 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       const int cA = w.cA0 + step * w.K, cAe = min(cA + w.K - 1, w.cA1);
       uint32_t cnt = 0;
       if (live) {
-        float lo, hi;
-        slabRange(a, w, cA, cAe, lo, hi);
-        float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
-        for (uint32_t j = 0; j < nb; ++j) {
-          if (!pvalid[j]) continue;
-          const BeamSlab q{pb[0][j], pb[1][j], pb[2][j], pb[3][j], pb[4][j], pb[5][j], pb[6][j], pb[7][j]};
-          float a0, a1, b0, b1;
-          if (beamFootprint(q, lo, hi, w.pad, a0, a1, b0, b1)) {
-            uLo = fminf(uLo, a0); uHi = fmaxf(uHi, a1);
-            vLo = fminf(vLo, b0); vHi = fmaxf(vHi, b1);
-          }
-        }
         CellBox bx;
-        const bool haveBox = boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx);
+        bool haveBox;
+        if (a.grid.mode == 1) {
+          haveBox = slabBox(a, w, cA, cAe, bx);  // (no wave operation inside in this mode)
+        } else {
+          float lo, hi;
+          slabRange(a, w, cA, cAe, lo, hi);
+          float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
+          for (uint32_t j = 0; j < nb; ++j) {
+            if (!pvalid[j]) continue;
+            const BeamSlab q{pb[0][j], pb[1][j], pb[2][j], pb[3][j], pb[4][j], pb[5][j], pb[6][j], pb[7][j]};
+            float a0, a1, b0, b1;
+            if (beamFootprint(q, lo, hi, w.pad, a0, a1, b0, b1)) {
+              uLo = fminf(uLo, a0); uHi = fmaxf(uHi, a1);
+              vLo = fminf(vLo, b0); vHi = fmaxf(vHi, b1);
+            }
+          }
+          haveBox = boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx);
+        }
         if (a.planBoxes && (uint32_t)step < a.planBoxStride)
           a.planBoxes[(size_t)(setBase / B + tile) * a.planBoxStride + step] = haveBox ? packCellBox(bx) : make_uint2(0xFFFFFFFFu, 0u);
         if (haveBox) {
@@ -446,7 +477,28 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
       const uint32_t staged = incl - exclFirst;
       const bool emit = closes && staged > 0u;
       const unsigned long long emitMask = __ballot(emit);
-      if (emitMask && !splitHeavy) {
+      if (emitMask && !splitHeavy && a.grid.mode == 1) {
+        // Bundle cells: a tile has a handful of steps (levels), and one of them usually holds most of its photons -- the
+        // greedy rule cannot cut there, and the evaluation then meets items twenty times the average (measured at C2:
+        // its kernel took twice as long).  A heavy item becomes `parts` items that share its walk and take its staging
+        // windows round-robin (as G-Beams' do): item.z = first level | part << 8 | parts << 20; the pair region of a
+        // part is sized for its share of the windows.
+        for (unsigned long long em = emitMask; em; em &= em - 1ull) {
+          const int src = __ffsll((long long)em) - 1;
+          const uint32_t stg = __shfl(staged, src, 64);
+          const uint32_t cF = (uint32_t)__shfl(cAFirst, src, 64), cE = (uint32_t)__shfl(cAe, src, 64);
+          const uint32_t wmax = stg / (uint32_t)STAGE + (cE - cF + 1u);  // windows of the walk, at most
+          uint32_t parts = stg > 2u * target ? min(PLAN_STAGE, (stg + target - 1u) / target) : 1u;
+          parts = max(1u, min(parts, wmax));
+          const uint32_t capP = parts > 1u ? min(stg, ((wmax + parts - 1u) / parts) * (uint32_t)STAGE) : stg;
+          if (nStaged + parts > PLAN_STAGE) flush();
+          for (uint32_t pp = (uint32_t)lane; pp < parts; pp += 64u) {
+            stItem[nStaged + pp] = make_uint4(setBase, nb | ((setBase / B + tile) << 8), cF | (parts > 1u ? (pp << 8) | (parts << 20) : 0u), cE);
+            stStaged[nStaged + pp] = capP;
+          }
+          nStaged += parts;
+        }
+      } else if (emitMask && !splitHeavy) {
         if (nStaged + 64u > PLAN_STAGE) flush();
         if (emit) {
           const uint32_t k = nStaged + (uint32_t)__popcll(emitMask & ((1ull << lane) - 1ull));

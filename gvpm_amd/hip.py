@@ -270,6 +270,12 @@ class Context:
         return {k: int(getattr(s, k)) for k in
                 ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts")}
 
+    def grid_info(self):
+        """G-BRE: (kind, cells) of the last build's photon cells -- kind 1: the ray-bundle cells (gvpm_stats.reserved[0])"""
+        s = abi.Stats()
+        self._check(lib().gvpm_get_stats(self._h, C.byref(s)))
+        return int(s.reserved[0]) >> 56, int(s.reserved[0]) & ((1 << 56) - 1)
+
     def kernel_time(self):
         ms, n = C.c_float(), C.c_uint32()
         self._check(lib().gvpm_get_kernel_time(self._h, C.byref(ms), C.byref(n)))

@@ -249,7 +249,8 @@ typedef struct gvpm_stats {
   uint64_t null_shifts, diffuse_shifts, failed_shifts;
   uint64_t dropped_pairs; /* (photon, beam) pairs the traversal could not store: must be 0 -- gvpm_get_stats returns
                              GVPM_ERR_STATE otherwise (the image would be biased)  */
-  uint64_t reserved[2];
+  uint64_t reserved[2];   /* [0]: G-BRE, the last build's photon cells: kind << 56 | count; kind 0 = uniform 3D grid,
+                             1 = cells over the (u, v) plane of a single-origin ray bundle   */
 } gvpm_stats;
 
 typedef struct gvpm_context gvpm_context;
