@@ -1,0 +1,950 @@
+// The per-technique drivers behind gvpm_gather (C ABI, include/gvpm_hip.h): device builds (photon grid, beam sort, planner)
+// and the kernel sequences of G-BRE, G-Beams, G-Planes and G-VPM.  Mirrors GPMIntegrator::photonMapPass and the
+// computeVolumeGradient* drivers (gvpm/gvpm.cpp:383-500, 880-1180).
+#include "context.h"
+
+float currentRadius(const gvpm_context *h) {
+  // breInitSize = bsphere.radius * globalScaleVolume * POURCENTAGE_BS, gvpm.cpp:989 (Float = float)
+  return h->cfg.bsphere_radius * h->globalScaleVolume * 0.01f;
+}
+
+static int ilog2ceil(uint32_t v) {
+  int b = 0;
+  while ((1ull << b) < v) ++b;
+  return b;
+}
+
+// uniform grid over the photons for kernel radius r.  deferred: use the bounds of the previous
+// photon set when there is one and leave this set's bounds in flight (pinB6) for the caller's sync.
+// The occluder grid of the near-occluder lists (grid_build.hip: near_grid_kernel, nearVisit): count, scan, fill.  Once per
+// scene: the one host read-back (the number of entries) stalls nothing that matters.
+static int buildNearGrid(gvpm_context *h, float reach) {
+  NearGrid g{};
+  float ext[3], vol = 1.f;
+  for (int c = 0; c < 3; ++c) {
+    ext[c] = std::max(h->triMax[c] - h->triMin[c] + 2.02f * reach, 1e-6f);
+    vol *= ext[c];
+  }
+  // about 64^3 cells, cubic ones: per axis extent / cell, cell = (volume / 64^3)^(1/3), at least 1, at most 256
+  const float cell = std::cbrt(vol / 262144.f);
+  size_t ncells = 1;
+  for (int c = 0; c < 3; ++c) {
+    g.dim[c] = std::max(1, std::min(256, (int)std::ceil(ext[c] / std::max(cell, 1e-9f))));
+    g.org[c] = h->triMin[c] - 1.01f * reach;
+    g.inv[c] = (float)g.dim[c] / ext[c];
+    ncells *= (size_t)g.dim[c];
+  }
+  hipStream_t st = h->bstream;
+  HIP_TRY(h, h->nearGridStart.ensure(ncells + 1));
+  HIP_TRY(h, h->nearGridCount.ensure(ncells + 1));
+  HIP_TRY(h, hipMemsetAsync(h->nearGridCount.p, 0, (ncells + 1) * sizeof(uint32_t), st));
+  launch_near_grid(h->tri4.p, h->ntri, g, reach, h->nearGridCount.p, nullptr, 0, st);
+  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->nearGridCount.p, h->nearGridStart.p, (uint32_t)ncells + 1, st));
+  uint32_t total = 0;
+  HIP_TRY(h, hipMemcpyAsync(&total, h->nearGridStart.p + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  HIP_TRY(h, h->nearGridTris.ensure((size_t)total + 1));
+  HIP_TRY(h, hipMemsetAsync(h->nearGridCount.p, 0, (ncells + 1) * sizeof(uint32_t), st));
+  g.start = h->nearGridStart.p;
+  g.tris = h->nearGridTris.p;
+  launch_near_grid(h->tri4.p, h->ntri, g, reach, h->nearGridCount.p, h->nearGridTris.p, 1, st);
+  HIP_TRY(h, hipGetLastError());
+  h->nearGrid = g;
+  h->nearGridReach = reach;
+  return GVPM_OK;
+}
+
+// The frame of the camera beams' bundle: common origin, mean direction, (u, v) range.  Two small reductions and a host
+// wait, once; afterwards every planner run checks its rays against the frame (GatherArgs::bundleFlag).
+static int fitBundle(gvpm_context *h) {
+  h->bundleState = -1;
+  if (!h->nsets || !h->raysDev) return GVPM_OK;
+  HIP_TRY(h, h->bs->bounds6.ensure(32));
+  double *dev = reinterpret_cast<double *>(h->bs->bounds6.p);
+  double o[13];
+  Grid g{};
+  launch_bundle_fit(h->raysDev, h->nsets, 0, g, dev, h->bstream);
+  HIP_TRY(h, hipMemcpyAsync(o, dev, sizeof(o), hipMemcpyDeviceToHost, h->bstream));
+  HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  for (int k = 0; k < 13; ++k)
+    if (!std::isfinite(o[k])) return GVPM_OK;
+  const double cnt = o[12];
+  if (!(cnt >= 1.0)) return GVPM_OK;
+  // C = M^-1 b, M symmetric (adjugate); rays of one direction only (an orthographic sensor) leave M singular
+  const double xx = o[0], xy = o[1], xz = o[2], yy = o[3], yz = o[4], zz = o[5];
+  const double c00 = yy * zz - yz * yz, c01 = xz * yz - xy * zz, c02 = xy * yz - xz * yy;
+  const double c11 = xx * zz - xz * xz, c12 = xy * xz - xx * yz, c22 = xx * yy - xy * xy;
+  const double det = xx * c00 + xy * c01 + xz * c02;
+  if (!(det > 1e-9 * cnt * cnt * cnt)) return GVPM_OK;
+  const double C[3] = {(c00 * o[6] + c01 * o[7] + c02 * o[8]) / det, (c01 * o[6] + c11 * o[7] + c12 * o[8]) / det,
+                       (c02 * o[6] + c12 * o[7] + c22 * o[8]) / det};
+  double A[3] = {o[9], o[10], o[11]};
+  const double len = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
+  if (!(len > 0.2 * cnt)) return GVPM_OK;  // directions all over the sphere
+  int sm = 0;
+  for (int c = 0; c < 3; ++c) {
+    A[c] /= len;
+    if (fabs(A[c]) < fabs(A[sm])) sm = c;
+  }
+  double E[3] = {0, 0, 0}, U[3], V[3];
+  E[sm] = 1.0;
+  U[0] = A[1] * E[2] - A[2] * E[1]; U[1] = A[2] * E[0] - A[0] * E[2]; U[2] = A[0] * E[1] - A[1] * E[0];
+  const double ul = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+  for (int c = 0; c < 3; ++c) U[c] /= ul;
+  V[0] = A[1] * U[2] - A[2] * U[1]; V[1] = A[2] * U[0] - A[0] * U[2]; V[2] = A[0] * U[1] - A[1] * U[0];
+  double c1 = 0;
+  for (int c = 0; c < 3; ++c) {
+    g.bo[c] = (float)C[c];
+    g.ba[c] = (float)A[c];
+    g.bu[c] = (float)U[c];
+    g.bv[c] = (float)V[c];
+    c1 += fabs(C[c]);
+  }
+  launch_bundle_fit(h->raysDev, h->nsets, 1, g, dev, h->bstream);
+  HIP_TRY(h, hipMemcpyAsync(o, dev, sizeof(o), hipMemcpyDeviceToHost, h->bstream));
+  HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  for (int k = 0; k < 8; ++k)
+    if (!std::isfinite(o[k])) return GVPM_OK;
+  if (!(o[4] > 0.15)) return GVPM_OK;  // a field of view near 180 degrees: (u, v) is no parametrisation for it
+  // the lines must pass the point to fp32 rounding of positions of this size, and the point must not lie ahead of a start
+  const double scale = 1.0 + c1 + fabs(o[6]) + fabs(o[7]);
+  const double res = std::sqrt(std::max(o[5], 0.0));
+  if (res > 4e-6 * scale || o[6] < -4e-6 * scale) return GVPM_OK;
+  g.lineTol = (float)(2.0 * res + 4e-6 * scale);
+  // the next uploads are the same sensor with other sub-pixel offsets: two pixels of margin
+  const double px = std::max(o[1] - o[0], o[3] - o[2]) / (double)std::max(1, std::min(h->cfg.width, h->cfg.height));
+  const double pad = 2.0 * px + 1e-5 * (1.0 + fabs(o[0]) + fabs(o[1]) + fabs(o[2]) + fabs(o[3]));
+  g.uMin = (float)(o[0] - pad); g.uMax = (float)(o[1] + pad);
+  g.vMin = (float)(o[2] - pad); g.vMax = (float)(o[3] + pad);
+  g.mode = 1;
+  h->bundleGrid = g;
+  h->bundleState = 1;
+  return GVPM_OK;
+}
+
+// cells of the bundle grid for this build: level-0 cells of 1 / bundleDiv of a tile's width
+static Grid bundleCells(const gvpm_context *h, float r, int tileW) {
+  Grid g = h->bundleGrid;
+  const float range = fmaxf(g.uMax - g.uMin, g.vMax - g.vMin);
+  const float tile = range * (float)tileW / (float)std::max(1, std::max(h->cfg.width, h->cfg.height));
+  int G = 8;
+  while (G < 512 && range / (float)G > tile / h->bundleDiv) G *= 2;
+  int levels = 1;
+  while ((1 << (levels - 1)) < G) ++levels;  // log2(G) + 1: the last level is one cell
+  g.dim[0] = g.dim[1] = G;
+  g.dim[2] = 2;
+  g.levels = levels;
+  g.ncells = (uint32_t)G * (uint32_t)G * 2u;
+  g.s0 = range / (float)G;
+  g.invS0 = 1.f / g.s0;
+  g.radius = r;
+  g.org[0] = g.org[1] = g.org[2] = 0.f;
+  g.cell = g.s0;
+  g.invCell = g.invS0;
+  return g;
+}
+
+static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force3D = false) {
+  const uint32_t n = h->nph;
+  h->boundsPending = false;
+  if (n == 0) {
+    h->bs->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
+    HIP_TRY(h, h->bs->cellStart.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->bs->cellStart.p, 0, 2 * sizeof(uint32_t), h->bstream));
+    return GVPM_OK;
+  }
+  const int nblocks = 1024;
+  HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
+  HIP_TRY(h, h->bs->bounds6.ensure(32));
+  float b6[6];
+  if (!h->pinB6) {
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+    h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
+  }
+  const bool defer = deferred && h->haveCachedBounds;
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, defer ? h->pinB6 : nullptr,
+                h->bstream);
+  if (defer) {
+    h->boundsPending = true;
+    memcpy(b6, h->cachedB6, sizeof(b6));
+  } else {
+    HIP_TRY(h, hipMemcpyAsync(b6, h->bs->bounds6.p, sizeof(b6), hipMemcpyDeviceToHost, h->bstream));
+    HIP_TRY(h, hipStreamSynchronize(h->bstream));
+    memcpy(h->cachedB6, b6, sizeof(b6));
+    h->haveCachedBounds = true;
+  }
+  float ext = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
+    ext = fmaxf(ext, b6[3 + c] - b6[c]);
+  }
+  Grid g{};
+  // cell edge in radii.  G-BRE with maps up to 2 M photons: 1.5 -- the cell arrays (memset, scan, summed-volume table:
+  // ~135 of the build's 575 us at C2 with cells of one radius) shrink 3.4x, and there the build is the stage the
+  // pipelined step waits for; the traversal tests 1.3x the photons per hit.  Measured at C2: 1.51 -> 1.43-1.445 ms per
+  // step.  At C4 (4 M photons) the evaluation is the long stage and the larger cells cost the traversal 1 % of the step.
+  const float cellScale = h->cellScale > 0.f ? h->cellScale : (deferred && n <= 2000000u ? 1.5f : 1.0f);
+  float cell = fmaxf(cellScale * r, ext / 384.f);
+  if (!(cell > 0.f)) cell = 1.f;
+  g.cell = cell;
+  g.invCell = 1.f / cell;
+  uint64_t nc = 1;
+  for (int c = 0; c < 3; ++c) {
+    g.org[c] = b6[c] - 0.5f * cell;
+    g.dim[c] = (int)floorf((b6[3 + c] - g.org[c]) * g.invCell) + 2;
+    nc *= (uint64_t)g.dim[c];
+  }
+  if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
+  g.ncells = (uint32_t)nc;
+  if (deferred && h->bundleEnabled && h->bundleState >= 0 && !force3D) {
+    // G-BRE: the camera beams of a pinhole sensor leave one point -- cells over the bundle's (u, v) plane instead
+    if (h->bundleState == 0) {
+      const int rcf = fitBundle(h);
+      if (rcf != GVPM_OK) return rcf;
+    }
+    if (h->bundleState == 1) g = bundleCells(h, r, h->beamsPerWave == 16 ? 4 : 8);
+  }
+  h->bs->grid = g;
+  // counting sort by cell (x fastest): count + rank, exclusive scan, scatter
+  HIP_TRY(h, h->bs->keysA.ensure(n));
+  HIP_TRY(h, h->bs->valsA.ensure(n));
+  HIP_TRY(h, h->bs->hot.ensure(n));
+  HIP_TRY(h, h->bs->cold.ensure((size_t)n * GVPM_REC_QUADS));
+  // the radius shrinks every iteration, so the grid grows: size the cell arrays (and the scan's temporary)
+  // for the finest grid the cell rule allows (386^3 cells, 230 MB each) once -- a regrowth is a hipFree,
+  // i.e. a device-wide sync in the middle of the pipeline
+  const size_t worstCells = (size_t)386 * 386 * 386 + 2;
+  HIP_TRY(h, h->bs->cellCount.ensure(std::max((size_t)g.ncells + 2, worstCells)));
+  HIP_TRY(h, h->bs->cellStart.ensure(std::max((size_t)g.ncells + 2, worstCells)));
+  if (!h->bs->scanSized) {
+    HIP_TRY(h, reserveScanTemp(h->bs->sortTmp, (uint32_t)worstCells));
+    h->bs->scanSized = true;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
+  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, h->bstream);
+  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
+  if (deferred) {
+    // G-BRE: summed-volume table for the planner (sized once for the finest grid, like the cell arrays)
+    const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
+    HIP_TRY(h, h->bs->sat.ensure(std::max(satCells, (size_t)387 * 387 * 387)));
+    launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->bstream);
+  }
+  // longest possible reconnection segment: diagonal of (occluders U photons), generously padded
+  float diag2 = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float lo = fminf(b6[c], h->ntri ? h->triMin[c] : b6[c]), hi = fmaxf(b6[3 + c], h->ntri ? h->triMax[c] : b6[3 + c]);
+    diag2 += (hi - lo) * (hi - lo);
+  }
+  const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
+  const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
+  if (h->ntri > 64u && h->useNearGrid && !(dmax <= h->nearGridReach)) {
+    const int rcg = buildNearGrid(h, dmax * 1.5f);
+    if (rcg != GVPM_OK) return rcg;
+  }
+  HIP_TRY(h, h->bs->overflowCtr.ensure(2));
+  HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
+  // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only);
+  // word 0 is the allocation cursor
+  const size_t extWant = std::min<size_t>(std::max<size_t>((size_t)n * 8u + 4096u, h->nearExtWant), 0xFFFFFF00u);
+  HIP_TRY(h, h->bs->nearExt.ensure(extWant));
+  HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->bs->nearExt.p, 1, 1, h->bstream));
+  launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
+                 h->nearGrid, h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
+                 h->bs->cold.p, h->bs->overflowCtr.p, h->bstream);
+  HIP_TRY(h, hipGetLastError());
+  h->nearOverflow = false;
+  if (!deferred && h->cfg.visibility_as_written) {
+    uint32_t over = 0;
+    HIP_TRY(h, hipMemcpyAsync(&over, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
+    HIP_TRY(h, hipStreamSynchronize(h->bstream));
+    h->nearOverflow = over != 0;
+  }
+  return GVPM_OK;
+}
+
+static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
+  const uint32_t n = h->nsets;
+  if (!beamsPerWave) beamsPerWave = h->beamsPerWave;
+  int tw = 8, th = 4;
+  if (beamsPerWave == 64) th = 8;
+  if (beamsPerWave == 16) tw = 4;
+  const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
+  h->bs->ntiles = tilesX * tilesY;
+  h->bs->tileW = tw;
+  h->bs->tileH = th;
+  HIP_TRY(h, h->bs->tileStart.ensure((size_t)h->bs->ntiles + 2));
+  HIP_TRY(h, h->bs->bKeysA.ensure(n + 1));
+  HIP_TRY(h, h->bs->bValsA.ensure(n + 1));
+  HIP_TRY(h, h->bs->setPerm.ensure(n + 1));
+  if (n) {
+    // counting sort by (tile, pixel in tile, edge): count + rank, exclusive scan, scatter
+    const int tileShift = ilog2ceil(tw * th) + 3;
+    const uint64_t nkeys = (uint64_t)h->bs->ntiles << tileShift;
+    if (nkeys > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "film too large for the beam sort");
+    HIP_TRY(h, h->bs->beamCount.ensure(nkeys + 2));
+    HIP_TRY(h, h->bs->beamStart.ensure(nkeys + 2));
+    HIP_TRY(h, hipMemsetAsync(h->bs->beamCount.p, 0, (nkeys + 1) * sizeof(uint32_t), h->bstream));
+    launch_beam_count(h->raysDev, n, h->cfg.width, tw, th, h->bs->bKeysA.p, h->bs->bValsA.p, h->bs->beamCount.p, h->bstream);
+    HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->beamCount.p, h->bs->beamStart.p, (uint32_t)nkeys + 1, h->bstream));
+    launch_beam_scatter(h->bs->bKeysA.p, h->bs->bValsA.p, h->bs->beamStart.p, n, h->bs->setPerm.p, h->bstream);
+    launch_tile_start(h->bs->beamStart.p, h->bs->ntiles, (uint32_t)tileShift, h->bs->tileStart.p, h->bstream);
+  } else {
+    HIP_TRY(h, hipMemsetAsync(h->bs->tileStart.p, 0, ((size_t)h->bs->ntiles + 1) * sizeof(uint32_t), h->bstream));
+  }
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
+// shadow rays through the occluder BVH instead of the per-photon near-occluder lists
+static bool needFullVis(const gvpm_context *h) {
+  return !h->cfg.visibility_as_written || h->nearOverflow;
+}
+
+static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
+  memset(&a, 0, sizeof(a));
+  a.hot = h->bs->hot.p;
+  a.cold = h->bs->cold.p;
+  a.cellStart = h->bs->cellStart.p;
+  a.nearExt = h->bs->nearExt.p;
+  a.sat = h->bs->sat.p;
+  a.nph = h->nph;
+  a.grid = h->bs->grid;
+  a.rays = h->raysDev;
+  a.setPerm = h->bs->setPerm.p;
+  a.tileStart = h->bs->tileStart.p;
+  a.nsets = h->nsets;
+  a.tri4 = h->tri4.p;
+  a.bvh = h->bvh.p;
+  a.ntri = h->ntri;
+  a.triAbs1 = 0.f;
+  if (h->ntri)
+    for (int c = 0; c < 3; ++c) a.triAbs1 += fmaxf(fabsf(h->triMin[c]), fabsf(h->triMax[c]));
+  for (int c = 0; c < 3; ++c) {
+    a.med.sigmaS[c] = h->medium.sigma_s[c];
+    a.med.sigmaT[c] = h->medium.sigma_t[c];
+  }
+  a.med.g = h->medium.g;
+  a.med.msw = h->medium.medium_sampling_weight;
+  a.cfg = h->cfg;
+  a.radius = r;
+  a.iter = h->iter.p;
+  a.stats = h->stats.p;
+  a.samples = h->samplesDev;
+  a.nsamples = h->nsamples;
+  a.scaleVol = h->scaleVol.p;
+  a.mvol = h->mvol.p;
+  a.kernelRadius = r;
+  a.subLen = 0.f;
+  a.nbeams = 0;
+}
+
+static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, int phase = 0) {
+  // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved) and the other phases
+  // a ring of at most GVPM_EVENT_RING pairs per phase: a host that never polls gvpm_get_phase_time keeps the timings of
+  // its last launches instead of growing the pool by three pairs per step
+  constexpr size_t GVPM_EVENT_RING = 256;
+  if (h->eventsHead[phase] == h->events[phase].size()) {
+    if (h->events[phase].size() >= GVPM_EVENT_RING) {
+      h->eventsHead[phase] = 0;  // overwrite the oldest
+    } else {
+      hipEvent_t e0, e1;
+      HIP_TRY(h, hipEventCreate(&e0));
+      HIP_TRY(h, hipEventCreate(&e1));
+      h->events[phase].emplace_back(e0, e1);
+    }
+  }
+  *ev = &h->events[phase][h->eventsHead[phase]++];
+  h->eventsCount[phase] = std::min(h->eventsCount[phase] + 1, GVPM_EVENT_RING);
+  return GVPM_OK;
+}
+
+// computeVolumeGradientPhotonBRE, gvpm.cpp:988-1079.
+// Pipeline: the build of this step (grid, beam sort, planner) runs on streamB into the build set
+// the previous step is NOT reading, so it overlaps the previous step's evaluation kernel; the
+// host waits once (planner counters) and then queues traversal + evaluation on the gather stream.
+static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
+  const float r = currentRadius(h);
+  static const bool traceHost = getenv("GVPM_TRACE_HOST") != nullptr;
+  auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!traceHost) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host] it=%d %-10s %8.1f us\n", it, what, std::chrono::duration<double, std::micro>(t - T0).count());
+    T0 = t;
+  };
+  std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav, *evEval;
+  int rc = nextEvents(h, &evBuild, 2);
+  if (rc != GVPM_OK) return rc;
+  h->bstream = h->pipeline ? h->streamB : h->stream;
+  // the evaluation adds this iteration's estimate (1 / nb_paths per partial sum) straight into the running sum
+  h->sumMode = true;
+  if (h->sumIt != 0 && it - 1 != h->sumIt) {
+    // not the successor of the last iteration: the reference's fold (mean * (it - 1) + v) / it then weighs the old
+    // mean by (it - 1) / it, i.e. the sum by (it - 1) / last
+    launch_scale(h->accum.p, h->accum.p, h->npix * 27, (float)((double)(it - 1) / (double)h->sumIt), h->stream);
+  }
+  h->sumIt = it;
+  bool rebuilt = false;
+  GatherArgs a;
+  uint32_t itemCap = 0, blocks = 0, nItems = 0;
+  bool force3D = false;
+  // (a second pass only when the planner met a ray outside the bundle the grid was keyed for: rebuilt in 3D)
+  for (int attempt = 0;; ++attempt) {
+  rebuilt = false;
+  if (h->photonsDirty || h->beamsDirty || r != h->bs->builtRadius) {
+    // the other set; wait until the kernels that last read it are done
+    h->setIdx = (h->setIdx + 1) % (h->pipeline && h->travStream ? 3 : 2);
+    h->bs = &h->sets[h->setIdx];
+    if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
+    HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
+    lap("waitevent");
+    rc = buildGrid(h, r, true, force3D);
+    lap("buildGrid");
+    if (rc == GVPM_OK) rc = sortBeams(h);
+    lap("sortBeams");
+    if (rc != GVPM_OK) {
+      h->bstream = h->stream;
+      return rc;
+    }
+    h->photonsDirty = false;
+    h->beamsDirty = false;
+    h->bs->builtRadius = r;
+    rebuilt = h->nph > 0;
+  } else {
+    // same inputs, same radius: the set is re-planned and re-traversed in place, once the evaluation kernel that still
+    // reads its items and pair lists is done
+    if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
+    if (h->bs->used && h->pipeline && h->travStream) HIP_TRY(h, hipStreamWaitEvent(h->streamC, h->bs->lastUse, 0));
+    HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
+  }
+  fillArgs(h, a, r);
+  a.iter = h->accum.p;
+  a.iterScale = 1.0f / (float)nb_paths;
+  itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
+  HIP_TRY(h, h->bs->items.ensure(itemCap));
+  HIP_TRY(h, h->bs->itemOff.ensure(itemCap));
+  if (h->planBoxHandOff) {
+    // one box per slab step and tile chunk: steps <= dim / (thinnest slab) + 1, chunks < nsets / B + ntiles + 1 (< 2^24)
+    const Grid &g = h->bs->grid;
+    const int kmin = std::max(1, std::min(a.cfg.reserved[2] ? a.cfg.reserved[2] : 8, a.cfg.reserved[1] ? a.cfg.reserved[1] : 6));
+    // (sized for the finest grid the cell rule allows, as the cell arrays: a regrowth is a device-wide sync)
+    const uint32_t stride = (uint32_t)(std::max(386, std::max(g.dim[0], std::max(g.dim[1], g.dim[2]))) / kmin + 2);
+    const size_t chunks = (size_t)h->nsets / (size_t)h->beamsPerWave + h->bs->ntiles + 2;
+    if (chunks < (1u << 24) && std::max(g.dim[0], std::max(g.dim[1], g.dim[2])) < 1024) {
+      HIP_TRY(h, h->bs->planBoxes.ensure(chunks * stride));
+      a.planBoxes = h->bs->planBoxes.p;
+      a.planBoxStride = stride;
+    }
+  }
+  HIP_TRY(h, h->bs->queueCtl.ensure(8));
+  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->bstream));
+  a.bundleFlag = h->bs->queueCtl.p + 4;
+  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,
+                  h->bs->queueCtl.p + 3, itemCap, h->bstream);
+  // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only) ...
+  // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
+  if (!h->pinB6) {
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+    h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
+  }
+  launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, rebuilt ? h->bs->nearExt.p : nullptr,
+                    h->bs->queueCtl.p, h->bs->queueCtl.p + 4, h->pinCtl, h->bstream);
+  HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
+  lap("plan");
+  HIP_TRY(h, hipStreamSynchronize(h->bstream));
+  lap("syncB");
+  blocks = h->pinCtl[0];
+  nItems = h->pinCtl[3];
+  if (a.grid.mode == 1 && h->pinCtl[4] != 0u && attempt == 0) {
+    // not the bundle the cells were keyed for (another sensor, or later edges of the camera paths among the beams):
+    // this step again on the 3D grid; the frame is fitted anew at the next build, a few times
+    h->bundleState = ++h->bundleViolations > 3 ? -1 : 0;
+    h->photonsDirty = true;
+    h->boundsPending = false;
+    force3D = true;
+    continue;
+  }
+  break;
+  }
+  h->lastGridMode = a.grid.mode;
+  h->lastGridCells = a.grid.ncells;
+  if (nItems > itemCap) {
+    h->bstream = h->stream;
+    return fail(h, GVPM_ERR_STATE, "G-BRE planner produced more work items than its bound");
+  }
+  if (getenv("GVPM_TRACE_PLAN")) {
+    uint32_t q[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[plan] items %u staged blocks %u tiles %u sets %u; photons %u, %s %d x %d x %d cells of %g (radius %g)\n", q[0],
+            blocks, h->bs->ntiles, h->nsets, h->nph, h->bs->grid.mode == 1 ? "bundle cells" : "grid", h->bs->grid.dim[0],
+            h->bs->grid.dim[1], h->bs->grid.dim[2], (double)h->bs->grid.cell, (double)r);
+  }
+  if (rebuilt) {
+    h->nearOverflow = h->cfg.visibility_as_written && h->pinCtl[1] != 0;
+    // what the extension lists asked for (the cursor keeps counting past the capacity): sizes the next build's
+    h->nearExtWant = std::max<size_t>(h->nearExtWant, (size_t)h->pinCtl[2] + h->pinCtl[2] / 4);
+    if (getenv("GVPM_TRACE_VIS"))
+      fprintf(stderr, "[vis] ntri %u photons %u: %u lists overflowed, extension cursor %u of %zu, fullvis %d\n", h->ntri, h->nph,
+              h->pinCtl[1], h->pinCtl[2], h->bs->nearExt.cap, (int)needFullVis(h));
+  }
+  if (h->boundsPending) {
+    h->boundsPending = false;
+    for (int c = 0; c < 6; ++c)
+      if (!std::isfinite(h->pinB6[c])) {
+        h->bstream = h->stream;
+        return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
+      }
+    memcpy(h->cachedB6, h->pinB6, sizeof(h->cachedB6));
+  }
+  // the traversal also runs on the build stream (this set's own pair buffer): only the evaluation
+  // kernels of consecutive steps are serialised on the gather stream
+  HIP_TRY(h, h->bs->pairs.ensure((size_t)blocks * 64u + 64u));
+  HIP_TRY(h, h->bs->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
+  rc = nextEvents(h, &evTrav, 1);
+  if (rc == GVPM_OK) rc = nextEvents(h, &evEval, 0);
+  if (rc != GVPM_OK) {
+    h->bstream = h->stream;
+    return rc;
+  }
+  // three stages: the traversal has its own stream, so that the build of the NEXT step (which starts on the build
+  // stream as soon as this call returns) overlaps it; the build stream is idle here, the host has just synchronised it
+  hipStream_t ts = h->pipeline && h->travStream ? h->streamC : (h->travOnBuild ? h->bstream : h->stream);
+  HIP_TRY(h, hipEventRecord(evTrav->first, ts));
+  launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
+                      h->bs->pairs.p, h->bs->pairCnt.p, h->persistentTrav ? h->nwavesTrav : nItems, h->persistentTrav, ts);
+  HIP_TRY(h, hipEventRecord(evTrav->second, ts));
+  HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
+  h->bstream = h->stream;
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
+  // maps beyond 2 M photons: the evaluation is the stage the pipelined step waits for (its records no longer fit the
+  // Infinity Cache), so it gets its third wave per SIMD; below, the other stages need the room more (measured: +6 % on a
+  // rank's step at C4 with 12 waves per CU, -3 % at C2)
+  const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u)
+                              ? std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS) : h->nwaves;
+  HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
+  launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
+                      h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItems, h->persistentEval,
+                      h->stream);
+  HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
+  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
+  if (h->pipeline) {
+    for (int k = 0; k < (h->travStream ? 3 : 2); ++k) {
+      BuildSet &other = h->sets[k];
+      if (&other != h->bs && !other.used && !h->bs->used) HIP_TRY(h, other.mirrorFrom(*h->bs));
+    }
+  }
+  h->bs->used = true;
+  HIP_TRY(h, hipGetLastError());
+  lap("launchK");
+  // scaleVolumeAPA(it), gvpm.cpp:181-215 (m_independentScale = false, forceAPA empty)
+  {
+    const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
+    double f = ratio;
+    if (h->cfg.vol_technique == GVPM_VOL_BRE3D) f = std::cbrt(ratio);
+    else if (h->cfg.vol_technique == GVPM_VOL_BRE2D) f = std::sqrt(ratio);
+    h->globalScaleVolume = (float)(h->globalScaleVolume * f);
+  }
+  return GVPM_OK;
+}
+
+// sub-beam grid for photon beams of kernel radius r
+static int buildBeamGrid(gvpm_context *h, float r) {
+  const uint32_t n = h->nph;
+  h->nsub = 0;
+  h->maxSubLen = 0.f;
+  HIP_TRY(h, h->bs->cold.ensure((size_t)(n + 1) * GVPM_REC_QUADS));
+  if (n == 0) {
+    h->bs->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
+    HIP_TRY(h, h->bs->cellStart.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->bs->cellStart.p, 0, 2 * sizeof(uint32_t), h->stream));
+    h->subLen = r;
+    return GVPM_OK;
+  }
+  // bounds of the beam end points and origins
+  const int nblocks = 256;
+  HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
+  HIP_TRY(h, h->bs->bounds6.ensure(32));
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, nullptr, h->stream);
+  launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, nullptr, h->stream);
+  float b12[12];
+  HIP_TRY(h, hipMemcpyAsync(b12, h->bs->bounds6.p, sizeof(b12), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float b6[6], ext = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    b6[c] = fminf(b12[c], b12[6 + c]);
+    b6[3 + c] = fmaxf(b12[3 + c], b12[9 + c]);
+    if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite beam position");
+    ext = fmaxf(ext, b6[3 + c] - b6[c]);
+  }
+  Grid g{};
+  // sub-beams (and cells) of 3/4 of the kernel radius: the traversal cost follows the number of sphere tests, which
+  // shrinks with the cell until the ext/256 floor (measured: 34 ms at 1.5 r, 23.5 ms at 0.75 r and below)
+  // (round 3, measured at C3 with the round's evaluation: sub-beams and cells of 1.5 r -- 24 M sub-beams instead of 47 M,
+  // build 6.4 -> 4.2 ms, traversal 10.2 -> 9.9 -- and, with them, work items of 4096 staged sub-beams: traversal -> 7.9 ms.
+  // Round 2 had measured the opposite (23.5 ms at 0.75 r against 34 at 1.5 r) on a traversal that resolved its candidates
+  // one per lane and round: the cost followed the sphere tests then, the walk and the staging now.)
+  float cell = fmaxf(0.75f * (h->cellScale > 0.f ? h->cellScale : 2.0f) * r, ext / 256.f);
+  if (!(cell > 0.f)) cell = 1.f;
+  g.cell = cell;
+  g.invCell = 1.f / cell;
+  uint64_t nc = 1;
+  for (int c = 0; c < 3; ++c) {
+    g.org[c] = b6[c] - 0.5f * cell;
+    g.dim[c] = (int)floorf((b6[3 + c] - g.org[c]) * g.invCell) + 2;
+    nc *= (uint64_t)g.dim[c];
+  }
+  if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
+  g.ncells = (uint32_t)nc;
+  h->bs->grid = g;
+  h->subLen = cell;
+  // cut the beams into sub-beams of about one cell
+  HIP_TRY(h, h->subCounts.ensure(n + 1));
+  HIP_TRY(h, h->subOffsets.ensure(n + 1));
+  HIP_TRY(h, h->beamCtl.ensure(4));
+  HIP_TRY(h, hipMemsetAsync(h->beamCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
+  launch_beam_subcount(h->rawDev.pos, h->rawDev.parent_pos, n, h->subLen, h->subCounts.p, h->beamCtl.p, h->stream);
+  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->subCounts.p, h->subOffsets.p, n, h->stream));
+  uint32_t lastOff = 0, lastCnt = 0, maxBits = 0;
+  HIP_TRY(h, hipMemcpyAsync(&lastOff, h->subOffsets.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&lastCnt, h->subCounts.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&maxBits, h->beamCtl.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const uint64_t S = (uint64_t)lastOff + lastCnt;
+  if (S > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many sub-beams");
+  h->nsub = (uint32_t)S;
+  memcpy(&h->maxSubLen, &maxBits, 4);
+  HIP_TRY(h, h->subCentres.ensure(S * 3 + 4));
+  HIP_TRY(h, h->subIds.ensure(S + 1));
+  HIP_TRY(h, h->bs->keysA.ensure(S));
+  HIP_TRY(h, h->bs->keysB.ensure(S));
+  HIP_TRY(h, h->bs->valsA.ensure(S));
+  HIP_TRY(h, h->bs->valsB.ensure(S));
+  HIP_TRY(h, h->bs->hot.ensure(2 * S));
+  HIP_TRY(h, h->subFlags.ensure(S + 1));
+  HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
+  launch_beam_expand(h->rawDev.pos, h->rawDev.parent_pos, n, h->subCounts.p, h->subOffsets.p, h->subCentres.p,
+                     h->subIds.p, h->stream);
+  launch_cell_keys(h->subCentres.p, h->nsub, g, h->bs->keysA.p, h->bs->valsA.p, h->stream);
+  HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, h->nsub,
+                          ilog2ceil(g.ncells + 1), h->stream));
+  HIP_TRY(h, h->beamAux.ensure(2 * (size_t)n + 2));
+  launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->subCounts.p, h->bs->cold.p, h->beamAux.p, h->stream);
+  launch_sub_hot(h->subIds.p, h->bs->valsB.p, h->nsub, h->beamAux.p, h->bs->hot.p, h->subFlags.p, h->stream);
+  launch_segment_start(h->bs->keysB.p, h->nsub, g.ncells, 0, h->bs->cellStart.p, h->stream);
+  {
+    const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
+    HIP_TRY(h, h->bs->sat.ensure(satCells));
+    launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->stream);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
+// computeVolumeGradientBeams, gvpm.cpp:880-986
+static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
+  if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
+  const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
+  // phases as for G-BRE (gvpm_get_phase_time): 2 = build (sub-beam grid, beam records, camera-beam sort, near lists),
+  // 1 = plan + traversal, 0 = the evaluation (block sort + evaluate_beams2_kernel)
+  std::pair<hipEvent_t, hipEvent_t> *evBuild, *evTrav;
+  {
+    int rcE = nextEvents(h, &evBuild, 2);
+    if (rcE != GVPM_OK) return rcE;
+    rcE = nextEvents(h, &evTrav, 1);
+    if (rcE != GVPM_OK) return rcE;
+  }
+  HIP_TRY(h, hipEventRecord(evBuild->first, h->stream));
+  if (h->photonsDirty || r != h->bs->builtRadius) {
+    int rc = buildBeamGrid(h, r);
+    if (rc != GVPM_OK) return rc;
+    h->photonsDirty = false;
+    h->bs->builtRadius = r;
+    h->beamNearStale = true;  // new records (or a new radius): the near-occluder lists are rebuilt below
+  }
+  bool nearDirty = false;
+  if (h->beamsDirty) {
+    int rc = sortBeams(h);
+    if (rc != GVPM_OK) return rc;
+    h->beamsDirty = false;
+    // how far a shifted camera ray strays from its base ray, over all uploaded sets (beam_near_kernel's delta)
+    HIP_TRY(h, h->shiftExtent.ensure(1));
+    launch_shift_extent(h->raysDev, h->nsets, h->shiftExtent.p, h->stream);
+    nearDirty = true;
+  }
+  if (nearDirty || h->beamNearStale) {
+    HIP_TRY(h, h->shiftExtent.ensure(1));
+    HIP_TRY(h, h->beamClear.ensure((size_t)h->nph + 1));
+    launch_beam_near(h->bs->cold.p, h->nph, h->tri4.p, h->ntri, r, h->shiftExtent.p, h->beamClear.p, h->beamsFreeCone, h->stream);
+    if (getenv("GVPM_BEAMS_TRACE")) {
+      DevBuf<uint32_t> hist;
+      uint32_t hh[21] = {0}, ext = 0;
+      if (hist.ensure(24) == hipSuccess && hipMemsetAsync(hist.p, 0, 96, h->stream) == hipSuccess) {
+        launch_beam_near_hist(h->bs->cold.p, h->nph, h->ntri, hist.p, h->stream);
+        (void)hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(&ext, h->shiftExtent.p, 4, hipMemcpyDeviceToHost, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+        float extf;
+        memcpy(&extf, &ext, 4);
+        fprintf(stderr, "[beams] near lists (delta = 4 x %g + %g, %u occluders): lengths 0..19:", (double)r, (double)extf, h->ntri);
+        for (int k = 0; k <= 19; ++k) fprintf(stderr, " %u", hh[k]);
+        fprintf(stderr, "; overflowed %u\n", hh[20]);
+      }
+      hist.release();
+    }
+    h->beamNearStale = false;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipEventRecord(evBuild->second, h->stream));
+  GatherArgs a;
+  fillArgs(h, a, r);
+  a.kernelRadius = r;
+  // one cell layer per slab step (the box of a thicker slab grows with the tile's perspective spread, and the
+  // traversal cost follows the number of sphere tests: 5.1 ms at 1 layer, 6.2 at 2, 8.9 at 4/6)
+  if (!a.cfg.reserved[1]) a.cfg.reserved[1] = 1;
+  if (!a.cfg.reserved[2]) a.cfg.reserved[2] = 1;
+  a.radius = r + 0.5f * h->maxSubLen * 1.001f + 1e-6f;  // traversal radius: sub-beams are binned by their centre
+  a.subLen = h->subLen;
+  a.nbeams = h->nph;
+  a.nph = h->nsub;
+  a.beamClear = h->beamClear.p;
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
+  // The planner splits heavy items into as many as 512 parts (tile_walk.h), so its own bound (items per tile chunk) is
+  // not a bound on the list: the list starts at that bound plus room for the parts and, when the planner reports more
+  // (it counts what it could not write, and the traversal never reads past the capacity), is regrown to the count and
+  // the plan repeated -- as the pair list below.
+  uint32_t itemCap = h->beamItemsInit ? h->beamItemsInit
+                                      : plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave) + h->nsub / 256u + 4096u;
+  itemCap = std::max(itemCap, h->beamItemCap);
+  HIP_TRY(h, h->bs->queueCtl.ensure(8));
+  // traversal -> pair list (blocks of 64) -> evaluation.  The list has no useful a-priori bound (the planner's is
+  // sub-beams x rays per slab box, ~100x the survivors): it starts at 16 M pairs and, when the traversal reports
+  // more than fit, is regrown to what it counted and the traversal repeated (deterministic, first iterations only).
+  // queueCtl: [0] items, [1] item queue head, [2] pairs (multiple of 64), [3] block queue head
+  if (h->beamPairs.cap == 0) HIP_TRY(h, h->beamPairs.ensure(h->beamPairsInit));
+  uint32_t npairs = 0;
+  bool planned = false;
+  HIP_TRY(h, hipEventRecord(evTrav->first, h->stream));
+  for (int attempt = 0;; ++attempt) {
+    if (!planned) {
+      HIP_TRY(h, h->bs->items.ensure(itemCap));
+      HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->stream));
+      launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTargetSet ? h->planTarget : 4096u, h->bs->items.p, h->bs->queueCtl.p, nullptr, nullptr,
+                      itemCap, h->stream);
+      planned = true;
+    }
+    const uint32_t cap = (uint32_t)std::min<size_t>(h->beamPairs.cap, 0xFFFFFFC0u);
+    const size_t nblkCap = cap / 64u + 1u;
+    for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nblkCap));
+    launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, itemCap, h->bs->queueCtl.p + 1,
+                          h->beamPairs.p, h->bs->queueCtl.p + 2, cap, h->blockKeyA.p, h->blockValA.p, h->nwavesTrav, h->stream);
+    uint32_t ctl[3] = {0, 0, 0};
+    HIP_TRY(h, hipMemcpyAsync(ctl, h->bs->queueCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    npairs = ctl[2];
+    if (getenv("GVPM_BEAMS_TRACE")) {
+      uint32_t q[4];
+      (void)hipMemcpy(q, h->bs->queueCtl.p, sizeof(q), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[beams] items %u (cap %u) pairs %u (cap %u) nsub %u nsets %u tiles %u cell %.3f r %.3f dims %d %d %d\n", q[0],
+              itemCap, npairs, cap, h->nsub, h->nsets, h->bs->ntiles, h->bs->grid.cell, r, h->bs->grid.dim[0], h->bs->grid.dim[1],
+              h->bs->grid.dim[2]);
+    }
+    const bool itemsOver = ctl[0] > itemCap, pairsOver = npairs > cap;
+    if (!itemsOver && !pairsOver) break;
+    if (attempt >= 3) return fail(h, GVPM_ERR_HIP, "G-Beams item / pair lists overflowed after being regrown");
+    if (itemsOver) {
+      // (the pass over the truncated list is discarded whole)
+      itemCap = ctl[0] + (ctl[0] >> 2) + 64u;
+      h->beamItemCap = itemCap;
+      planned = false;
+    } else {
+      HIP_TRY(h, h->beamPairs.ensure((size_t)npairs + (npairs >> 2) + 64));
+      HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 1, 0, 2 * sizeof(uint32_t), h->stream));
+    }
+    // the candidate count of the discarded pass
+    HIP_TRY(h, hipMemset2DAsync(a.stats + 1, 8 * sizeof(unsigned long long), 0, sizeof(unsigned long long), GVPM_STAT_ROWS,
+                                h->stream));
+  }
+  HIP_TRY(h, hipEventRecord(evTrav->second, h->stream));
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+  // blocks of 64 pairs, sorted by tile: the evaluation loads a tile's rays once per run of its blocks
+  const uint32_t nBlocks = npairs / 64u;
+  if (nBlocks)
+    HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBlocks,
+                            ilog2ceil(h->nsets + 1), h->stream));
+  launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
+                        h->bs->queueCtl.p + 3, h->nwaves, h->stream);
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  {
+    // scaleVolumeAPA(it): cube root for the 3D kernels, linear for the 1D kernel (gvpm.cpp:195-201)
+    const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
+    const double f = h->cfg.vol_technique == GVPM_BEAM_BEAM_1D ? ratio : std::cbrt(ratio);
+    h->globalScaleVolume = (float)(h->globalScaleVolume * f);
+  }
+  return GVPM_OK;
+}
+
+// computeVolumeGradientPlanes, gvpm.cpp:782-878
+static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
+  if (!h->havePlanes) return fail(h, GVPM_ERR_STATE, "G-Planes gather needs gvpm_upload_planes");
+  PlaneArgs pa;
+  pa.ori = h->rawDev.parent_pos;
+  pa.end = h->rawDev.pos;
+  pa.flux = h->rawDev.flux;
+  pa.flags = h->rawDev.flags;
+  pa.w1 = h->w1Dev;
+  pa.len1 = h->len1Dev;
+  pa.nplanes = h->nph;
+  pa.planesPerItem = h->nph;
+  if (h->photonsDirty) {
+    HIP_TRY(h, h->planeTest.ensure((size_t)h->nph * 3 + 1));
+    pa.test = h->planeTest.p;
+    launch_plane_records(pa, h->planeTest.p, h->stream);
+    h->photonsDirty = false;
+    h->bs->builtRadius = -1.f;
+  }
+  pa.test = h->planeTest.p;
+  if (h->beamsDirty) {
+    int rc = sortBeams(h, 64);  // one camera ray per lane: 8x8 pixel tiles
+    if (rc != GVPM_OK) return rc;
+    h->beamsDirty = false;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  GatherArgs a;
+  fillArgs(h, a, 0.f);
+  // enough (tile, plane chunk) items to fill the chip; chunks of at least 256 planes
+  uint32_t nchunks = 1;
+  if (h->bs->ntiles && h->nph) {
+    nchunks = (4u * h->nwaves + h->bs->ntiles - 1) / h->bs->ntiles;
+    nchunks = std::max(1u, std::min(nchunks, (h->nph + 255u) / 256u));
+    nchunks = std::min(nchunks, 65535u);
+    pa.planesPerItem = (h->nph + nchunks - 1) / nchunks;
+    nchunks = (h->nph + pa.planesPerItem - 1) / pa.planesPerItem;
+  }
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+  launch_gather_planes(a, pa, h->bs->ntiles, nchunks, h->stream);
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  {
+    // scaleVolumeAPA(it): the plane estimator takes the linear ratio (gvpm.cpp:195-201)
+    const double ratio = ((it - 1) + (double)h->cfg.alpha) / ((it - 1) + 1);
+    h->globalScaleVolume = (float)(h->globalScaleVolume * ratio);
+  }
+  return GVPM_OK;
+}
+
+// computeVolumeGradientPhoton (G-VPM), gvpm.cpp:1081-1203
+static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
+  (void)it;
+  if (!h->haveSamples) return fail(h, GVPM_ERR_STATE, "G-VPM gather needs gvpm_upload_vpm_samples");
+  if (h->cfg.nb_camera_samples <= 0) return fail(h, GVPM_ERR_INVALID_ARG, "nb_camera_samples must be positive");
+  // grid cell = the largest per-pixel radius R * 0.01 * max(scaleVol)
+  uint32_t bits = 0;
+  HIP_TRY(h, hipMemcpyAsync(&bits, h->maxScaleBits.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float maxScale;
+  memcpy(&maxScale, &bits, 4);
+  const float rmax = (h->cfg.bsphere_radius * 0.01f) * maxScale;
+  if (h->photonsDirty || rmax != h->bs->builtRadius) {
+    int rc = buildGrid(h, rmax);
+    if (rc != GVPM_OK) return rc;
+    h->photonsDirty = false;
+    h->bs->builtRadius = rmax;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->maxScaleBits.p, 0, 4, h->stream));
+  GatherArgs a;
+  fillArgs(h, a, rmax);
+  std::pair<hipEvent_t, hipEvent_t> *ev;
+  int rc = nextEvents(h, &ev);
+  if (rc != GVPM_OK) return rc;
+  HIP_TRY(h, hipEventRecord(ev->first, h->stream));
+  launch_gather_vpm(a, needFullVis(h), h->stream);
+  HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->stream);
+  launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  h->totalEmitted += (double)nb_paths;  // m_totalEmittedVolume, gvpm.cpp:434
+  return GVPM_OK;
+}
+
+extern "C" {
+
+int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
+  CHECK_H(h);
+  if (it < 1 || nb_paths == 0) return fail(h, GVPM_ERR_INVALID_ARG, "it must be >= 1 and nb_paths > 0");
+  if (!h->haveMedium || !h->havePhotons || !h->haveBeams)
+    return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
+  h->useAll = false;
+  h->bstream = h->stream;
+  // the streams that read this step's host-uploaded inputs wait for their copies (copy stream)
+  if (h->phWait) {
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->phSlot[h->phCur].copied, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->streamB, h->phSlot[h->phCur].copied, 0));
+    h->phWait = false;
+  }
+  if (h->rayWait) {
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->raySlot[h->rayCur].copied, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->streamB, h->raySlot[h->rayCur].copied, 0));
+    h->rayWait = false;
+  }
+  int rc;
+  switch (h->cfg.vol_technique) {
+    case GVPM_VOL_BRE2D:
+    case GVPM_VOL_BRE3D: rc = gatherBRE(h, it, nb_paths); break;
+    case GVPM_DISTANCE: rc = gatherVPM(h, it, nb_paths); break;
+    case GVPM_BEAM_BEAM_1D:
+    case GVPM_BEAM_BEAM_3D_OPTIMIZED: rc = gatherBeams(h, it, nb_paths); break;
+    case GVPM_VOL_PLANE0D: rc = gatherPlanes(h, it, nb_paths); break;
+    default: return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
+  }
+  if (rc != GVPM_OK) return rc;
+  // the kernels just queued on the gather stream are the last readers of this step's camera rays
+  if (h->raysOwnedCur) {
+    HIP_TRY(h, hipEventRecord(h->raySlot[h->rayCur].freed, h->stream));
+    h->raySlot[h->rayCur].read = true;
+  }
+  // ... and of the staged photon arrays (the build on either stream; G-Planes reads them in the gather itself)
+  if (h->photonsOwnedCur) {
+    // G-BRE reads them in its build only (reorder_kernel), and gatherBRE has waited for that build on the host (the
+    // planner's counters): nothing of it is in flight here.  An event behind the whole gather made the prefetched copy
+    // of step N+2 wait for the EVALUATION of step N: the PCIe-inclusive step went from 3.6 to 5.8 ms.  The other
+    // techniques read them on the gather stream (their builds; G-Planes in the gather kernel itself).
+    gvpm_context::PhotonSlot &ps = h->phSlot[h->phCur];
+    const bool bre = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
+    if (!bre) {
+      HIP_TRY(h, hipEventRecord(ps.consumed, h->stream));
+      HIP_TRY(h, hipEventRecord(ps.consumedB, h->streamB));
+      ps.read = true;
+    }
+  }
+  // prefetched inputs (gvpm_prefetch_*) become the current ones: what an upload at this point would have done
+  if (h->phPending >= 0) {
+    h->phCur = h->phPending;
+    h->phPending = -1;
+    h->rawDev = h->phSlot[h->phCur].dev;
+    h->nph = (uint32_t)h->rawDev.n;
+    h->phWait = true;
+    h->photonsOwnedCur = true;
+    h->photonsDirty = true;
+  }
+  if (h->rayPending >= 0) {
+    h->rayCur = h->rayPending;
+    h->rayPending = -1;
+    h->raysDev = h->raySlot[h->rayCur].rays.p;
+    h->nsets = h->raySlot[h->rayCur].nsets;
+    h->rayWait = true;
+    h->raysOwnedCur = true;
+    h->beamsDirty = true;
+  }
+  return GVPM_OK;
+}
+}  // extern "C"

@@ -102,7 +102,7 @@ def test_beams_item_list_regrows(monkeypatch):
 
 def test_beams_pair_list_regrows(monkeypatch):
     # a pair list far too small for the first pass: the traversal only counts, the host regrows the list to the count
-    # and repeats the pass (gvpm_api.hip gatherBeams); blocks are reserved eight at a time, so the count includes the
+    # and repeats the pass (gather_drivers.hip gatherBeams); blocks are reserved eight at a time, so the count includes the
     # empty blocks waves had left over
     monkeypatch.setenv("GVPM_BEAM_PAIRS_INIT", "1024")
     c = make_beam_case("cbox", 32, 28, 12000, 2.5)
