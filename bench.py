@@ -616,34 +616,43 @@ def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
 
 
 def upload_inclusive(hip, p, m, tris, host0, K, device):
-    """The same K steps fed from HOST memory through gvpm_upload_* / gvpm_prefetch_*: pinned buffers (one packed block per
-    photon set, gvpm_host_alloc_photons), copies on the handle's copy stream, the copy of step N+1 in flight while step N
-    runs.  Never `value`: the PCIe-inclusive rate SURVEY 8d asks to have beside it."""
-    sets = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays)) for ph, nb, rays in host0[:2]]
-    nbytes = host0[0][0].n * 120 + host0[0][2].nbytes
+    """The same K steps fed from HOST memory: pinned buffers, copies on the handle's copy stream, the copy of step N+1 in
+    flight while step N runs.  Never `value`: the PCIe-inclusive rate SURVEY 8d asks to have beside it.  The headline of
+    this leg is the packed records (gvpm_upload_*_packed: 76 bytes a photon, 272 a beam set); the fp32 SoA entry points
+    (120 / 320 bytes) are timed beside them."""
+    table = hip.MaterialTable()
+    sets = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays), hip.PinnedPacked(ph, rays, table))
+            for ph, nb, rays in host0[:2]]
+    nbytes_soa = host0[0][0].n * 120 + host0[0][2].nbytes
+    nbytes = sets[0][3].nbytes
     ctx = hip.Context(p, device=device)
     ctx.upload_scene(*tris)
     ctx.upload_medium(m)
+    ctx.upload_materials(table)
     res = {}
-    for mode in ("prefetch", "serial"):
+    for mode in ("packed", "prefetch", "serial"):
         ctx.reset()
         for rep in range(2):  # first pass: allocations
             ctx.synchronize()
             ev0 = ctx.stats()["evaluations"]
             t0 = time.perf_counter()
-            ph, nb, rays = sets[0]
-            ctx.upload_pinned(ph, rays)
+            ph, nb, rays, pk = sets[0]
+            if mode == "packed":
+                ctx.upload_pinned_packed(pk)
+            else:
+                ctx.upload_pinned(ph, rays)
             for it in range(1, K + 1):
-                if mode == "prefetch":
+                if mode == "packed":
+                    if it < K:
+                        ctx.prefetch_packed(sets[it % len(sets)][3])
+                elif mode == "prefetch":
                     if it < K:
                         nxt = sets[it % len(sets)]
                         ctx.prefetch(nxt[0], nxt[2])
-                    ctx.gather(it, sets[(it - 1) % len(sets)][1])
-                else:
-                    if it > 1:
-                        cur = sets[(it - 1) % len(sets)]
-                        ctx.upload_pinned(cur[0], cur[2])
-                    ctx.gather(it, sets[(it - 1) % len(sets)][1])
+                elif it > 1:
+                    cur = sets[(it - 1) % len(sets)]
+                    ctx.upload_pinned(cur[0], cur[2])
+                ctx.gather(it, sets[(it - 1) % len(sets)][1])
             ctx.synchronize()
             dt = time.perf_counter() - t0
             ev = ctx.stats()["evaluations"] - ev0
@@ -652,13 +661,17 @@ def upload_inclusive(hip, p, m, tris, host0, K, device):
     for s in sets:
         s[0].close()
         s[2].close()
+        s[3].close()
     return {
-        "value": res["prefetch"]["value"], "unit": "Mevals/s", "ms_per_step": res["prefetch"]["ms_per_step"],
-        "ms_per_step_without_prefetch": res["serial"]["ms_per_step"],
+        "value": res["packed"]["value"], "unit": "Mevals/s", "ms_per_step": res["packed"]["ms_per_step"],
         "host_bytes_per_step": nbytes,
-        "pcie_gb_per_s_at_this_rate": nbytes / (res["prefetch"]["ms_per_step"] * 1e-3) / 1e9,
-        "how": "pinned host buffers (gvpm_host_alloc_photons: one packed block per photon set), gvpm_prefetch_* of step N+1 "
-               "before gvpm_gather of step N: copies on the copy stream overlap the previous step's kernels",
+        "pcie_gb_per_s_at_this_rate": nbytes / (res["packed"]["ms_per_step"] * 1e-3) / 1e9,
+        "soa": {"ms_per_step": res["prefetch"]["ms_per_step"], "value": res["prefetch"]["value"],
+                "ms_per_step_without_prefetch": res["serial"]["ms_per_step"], "host_bytes_per_step": nbytes_soa,
+                "pcie_gb_per_s_at_this_rate": nbytes_soa / (res["prefetch"]["ms_per_step"] * 1e-3) / 1e9},
+        "how": "pinned host buffers of packed records (gvpm_pack_photons / gvpm_pack_camera_beams: 76 bytes a photon, 272 a "
+               "beam set; decoded at the head of the consuming gather's build), gvpm_prefetch_*_packed of step N+1 before gvpm_gather of step N; "
+               "`soa`: the same through the fp32 SoA entry points (gvpm_host_alloc_photons, 120 / 320 bytes)",
     }
 
 

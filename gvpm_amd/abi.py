@@ -121,6 +121,18 @@ VPM_SAMPLE_DTYPE = np.dtype([("set", np.uint32), ("rand", np.float32), ("pdf_sel
 assert VPM_SAMPLE_DTYPE.itemsize == 16
 
 
+# packed upload records (include/gvpm_hip.h, "packed uploads")
+MATERIAL_DTYPE = np.dtype([("scat", np.float32, 3), ("g", np.float32)])
+PHOTON_PACKED_DTYPE = np.dtype([
+    ("pos", np.float32, 3), ("parent_pdf", np.float32), ("parent_pos", np.float32, 3), ("edge_pdf", np.float32),
+    ("flux", np.float32, 3), ("parent_rr", np.float32), ("prefix_w", np.float32, 3), ("parent_n_oct", np.uint32),
+    ("parent_wi_oct", np.uint32), ("flags", np.uint32), ("material", np.uint32)])
+RAY_PACKED_DTYPE = np.dtype([
+    ("o", np.float32, 3), ("len", np.float32), ("d", np.float32, 3), ("pdf", np.float32), ("eye", np.float32, 3),
+    ("jacobian", np.float32), ("gop", np.float32)])
+assert PHOTON_PACKED_DTYPE.itemsize == 76 and RAY_PACKED_DTYPE.itemsize == 52
+
+
 class Photons:
     """Host-side photon SoA as numpy arrays (owning), convertible to gvpm_photon_soa."""
 

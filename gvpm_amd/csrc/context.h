@@ -264,6 +264,9 @@ struct gvpm_context {
   struct PhotonSlot {
     DevBuf<uint32_t> raw;   // 30 words per photon: the 8 xyz arrays, the 4 scalars, flags, path_id (the ABI's order)
     gvpm_photon_soa dev;    // device pointers into raw
+    DevBuf<uint32_t> packed;  // a packed upload lands here and is decoded into raw (uploads.hip) by the consuming gather
+    bool needUnpack = false;
+    hipEvent_t unpacked = nullptr;
     hipEvent_t copied = nullptr;
     // recorded, on the gather stream and on the build stream, behind the kernels of every gather that read the slot
     // (builds; the G-Planes gather itself): the next copy into the slot waits for both
@@ -272,6 +275,9 @@ struct gvpm_context {
   } phSlot[3];
   struct RaySlot {
     DevBuf<gvpm_camera_ray> rays;
+    DevBuf<uint32_t> packed;  // a packed upload lands here and is decoded into rays by the consuming gather
+    bool needUnpack = false;
+    hipEvent_t unpacked = nullptr;
     uint32_t nsets = 0;
     hipEvent_t copied = nullptr, freed = nullptr;
     bool read = false;      // a gather has launched kernels that read it since its last copy
@@ -281,6 +287,8 @@ struct gvpm_context {
   bool raysOwnedCur = false;              // the current camera rays live in raySlot[rayCur]
   bool photonsOwnedCur = false;           // the current photon map lives in phSlot[phCur]
   hipStream_t copyStream = nullptr;
+  DevBuf<gvpm_material> materials;  // gvpm_upload_materials: the table the packed photon records index
+  uint32_t nmaterials = 0;
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid
   gvpm_photon_soa rawDev;  // device pointers
   uint32_t nph = 0;
@@ -394,6 +402,12 @@ static inline int fail(gvpm_context *h, int code, const char *msg) {
   return code;
 }
 
+
+namespace gvpm {
+void launch_unpack_photons(const uint32_t *packed, uint32_t n, const gvpm_material *table, uint32_t table_n,
+                           const gvpm_photon_soa &dst, hipStream_t s);
+void launch_unpack_rays(const uint32_t *packed, uint32_t nsets, gvpm_camera_ray *dst, hipStream_t s);
+}  // namespace gvpm
 
 // shared between the files above
 float currentRadius(const gvpm_context *h);

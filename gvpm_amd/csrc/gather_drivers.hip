@@ -886,14 +886,35 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   h->useAll = false;
   h->bstream = h->stream;
   // the streams that read this step's host-uploaded inputs wait for their copies (copy stream)
+  // (packed records are decoded here, at the head of the chain that reads them: G-BRE builds on the build stream)
+  const bool breTech = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
+  hipStream_t us = breTech && h->pipeline ? h->streamB : h->stream, other = us == h->stream ? h->streamB : h->stream;
   if (h->phWait) {
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->phSlot[h->phCur].copied, 0));
-    HIP_TRY(h, hipStreamWaitEvent(h->streamB, h->phSlot[h->phCur].copied, 0));
+    gvpm_context::PhotonSlot &ps = h->phSlot[h->phCur];
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, ps.copied, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->streamB, ps.copied, 0));
+    if (ps.needUnpack) {
+      launch_unpack_photons(ps.packed.p, (uint32_t)ps.dev.n, h->materials.p, h->nmaterials, ps.dev, us);
+      HIP_TRY(h, hipGetLastError());
+      if (!ps.unpacked) HIP_TRY(h, hipEventCreateWithFlags(&ps.unpacked, hipEventDisableTiming));
+      HIP_TRY(h, hipEventRecord(ps.unpacked, us));
+      HIP_TRY(h, hipStreamWaitEvent(other, ps.unpacked, 0));
+      ps.needUnpack = false;
+    }
     h->phWait = false;
   }
   if (h->rayWait) {
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->raySlot[h->rayCur].copied, 0));
-    HIP_TRY(h, hipStreamWaitEvent(h->streamB, h->raySlot[h->rayCur].copied, 0));
+    gvpm_context::RaySlot &rs = h->raySlot[h->rayCur];
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, rs.copied, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->streamB, rs.copied, 0));
+    if (rs.needUnpack) {
+      launch_unpack_rays(rs.packed.p, rs.nsets, rs.rays.p, us);
+      HIP_TRY(h, hipGetLastError());
+      if (!rs.unpacked) HIP_TRY(h, hipEventCreateWithFlags(&rs.unpacked, hipEventDisableTiming));
+      HIP_TRY(h, hipEventRecord(rs.unpacked, us));
+      HIP_TRY(h, hipStreamWaitEvent(other, rs.unpacked, 0));
+      rs.needUnpack = false;
+    }
     h->rayWait = false;
   }
   int rc;

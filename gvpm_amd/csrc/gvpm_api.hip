@@ -178,16 +178,21 @@ int gvpm_destroy(gvpm_context *h) {
   h->tri4.release(); h->bvh.release();
   for (auto &ps : h->phSlot) {
     ps.raw.release();
+    ps.packed.release();
+    if (ps.unpacked) (void)hipEventDestroy(ps.unpacked);
     if (ps.copied) (void)hipEventDestroy(ps.copied);
     if (ps.consumed) (void)hipEventDestroy(ps.consumed);
     if (ps.consumedB) (void)hipEventDestroy(ps.consumedB);
   }
   for (auto &rs : h->raySlot) {
     rs.rays.release();
+    rs.packed.release();
+    if (rs.unpacked) (void)hipEventDestroy(rs.unpacked);
     if (rs.copied) (void)hipEventDestroy(rs.copied);
     if (rs.freed) (void)hipEventDestroy(rs.freed);
   }
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
+  h->materials.release();
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release(); h->beamAux.release(); h->beamClear.release();
   h->nearGridStart.release(); h->nearGridTris.release(); h->nearGridCount.release();

@@ -27,6 +27,9 @@ SYMBOLS = [
     "gvpm_devgen_destroy", "gvpm_devgen_shoot_photons", "gvpm_devgen_shoot_beams", "gvpm_devgen_camera_beams", "gvpm_devgen_read",
     "gvpm_poisson_preset", "gvpm_poisson_solve", "gvpm_poisson_solve_dev",
     "gvpm_host_alloc", "gvpm_host_alloc_photons", "gvpm_host_free", "gvpm_prefetch_photons", "gvpm_prefetch_camera_beams",
+    "gvpm_pack_photons", "gvpm_unpack_photons", "gvpm_pack_camera_beams", "gvpm_unpack_camera_beams", "gvpm_upload_materials",
+    "gvpm_upload_photons_packed", "gvpm_prefetch_photons_packed", "gvpm_upload_camera_beams_packed",
+    "gvpm_prefetch_camera_beams_packed",
 ]
 
 
@@ -90,6 +93,15 @@ def lib():
         L.gvpm_poisson_solve.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.gvpm_poisson_solve_dev.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.gvpm_host_alloc.argtypes = [C.c_uint64, C.POINTER(vp)]
+        L.gvpm_pack_photons.argtypes = [C.POINTER(abi.PhotonSoA), vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gvpm_unpack_photons.argtypes = [vp, C.c_uint64, vp, C.c_uint32, C.POINTER(abi.PhotonSoA)]
+        L.gvpm_pack_camera_beams.argtypes = [vp, C.c_uint64, vp]
+        L.gvpm_unpack_camera_beams.argtypes = [vp, C.c_uint64, vp]
+        L.gvpm_upload_materials.argtypes = [vp, vp, C.c_uint32]
+        L.gvpm_upload_photons_packed.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_prefetch_photons_packed.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_camera_beams_packed.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_prefetch_camera_beams_packed.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_host_alloc_photons.argtypes = [C.c_uint64, C.POINTER(abi.PhotonSoA), C.POINTER(vp)]
         L.gvpm_host_free.argtypes = [vp]
         L.gvpm_prefetch_photons.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
@@ -145,6 +157,90 @@ class PinnedRays:
         if self._p:
             lib().gvpm_host_free(self._p)
             self._p = C.c_void_p()
+
+    __del__ = close
+
+
+class MaterialTable:
+    """The table the packed photon records index (gvpm_material): grows as gvpm_pack_photons meets new materials."""
+
+    def __init__(self, cap=256):
+        self.table = np.zeros(cap, abi.MATERIAL_DTYPE)
+        self.n = 0
+
+
+def pack_photons(ph, table, out=None):
+    """gvpm_pack_photons: abi.Photons -> packed records (numpy, PHOTON_PACKED_DTYPE), in `out` (e.g. a view of pinned
+    memory) when given.  Plain host code: works without a GPU."""
+    if out is None:
+        out = np.zeros(ph.n, abi.PHOTON_PACKED_DTYPE)
+    assert out.dtype == abi.PHOTON_PACKED_DTYPE and out.size == ph.n and out.flags["C_CONTIGUOUS"]
+    soa = ph.soa()
+    cnt = C.c_uint32(table.n)
+    rc = lib().gvpm_pack_photons(C.byref(soa), out.ctypes.data, table.table.ctypes.data, table.table.size, C.byref(cnt))
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_pack_photons failed (more materials than the table holds?)")
+    table.n = cnt.value
+    return out
+
+
+def unpack_photons(packed, table):
+    """gvpm_unpack_photons: what the device makes of the records, as abi.Photons"""
+    ph = abi.Photons(packed.size)
+    soa = ph.soa()
+    packed = np.ascontiguousarray(packed)
+    rc = lib().gvpm_unpack_photons(packed.ctypes.data, packed.size, table.table.ctypes.data, table.n, C.byref(soa))
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_unpack_photons failed")
+    return ph
+
+
+def pack_camera_beams(rays, out=None):
+    """gvpm_pack_camera_beams: (nsets, 5) camera rays -> nsets records of 272 bytes (uint8 array (nsets, 272))"""
+    rays = np.ascontiguousarray(rays)
+    n = rays.size // 5
+    if out is None:
+        out = np.zeros((n, 272), np.uint8)
+    assert out.nbytes == n * 272 and out.flags["C_CONTIGUOUS"]
+    rc = lib().gvpm_pack_camera_beams(rays.ctypes.data, n, out.ctypes.data)
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_pack_camera_beams failed (a shifted ray on another edge than its base?)")
+    return out
+
+
+def unpack_camera_beams(packed):
+    packed = np.ascontiguousarray(packed)
+    n = packed.nbytes // 272
+    rays = np.zeros((n, 5), abi.CAMERA_RAY_DTYPE)
+    rc = lib().gvpm_unpack_camera_beams(packed.ctypes.data, n, rays.ctypes.data)
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_unpack_camera_beams failed")
+    return rays
+
+
+class PinnedPacked:
+    """One iteration's inputs as packed records in pinned host memory: what a pipelined producer hands to
+    gvpm_upload_*_packed / gvpm_prefetch_*_packed."""
+
+    def __init__(self, ph, rays, table):
+        self.n = ph.n
+        self.nsets = np.asarray(rays).size // 5
+        self._pp, self._pr = C.c_void_p(), C.c_void_p()
+        for ptr, nbytes in ((self._pp, self.n * 76), (self._pr, self.nsets * 272)):
+            rc = lib().gvpm_host_alloc(max(nbytes, 64), C.byref(ptr))
+            if rc != 0:
+                raise GvpmError(rc, "gvpm_host_alloc failed")
+        pv = np.frombuffer((C.c_char * (self.n * 76)).from_address(self._pp.value), abi.PHOTON_PACKED_DTYPE) if self.n else np.zeros(0, abi.PHOTON_PACKED_DTYPE)
+        rv = np.frombuffer((C.c_char * (self.nsets * 272)).from_address(self._pr.value), np.uint8).reshape(self.nsets, 272) if self.nsets else np.zeros((0, 272), np.uint8)
+        pack_photons(ph, table, out=pv)
+        pack_camera_beams(rays, out=rv)
+        self.nbytes = self.n * 76 + self.nsets * 272
+
+    def close(self):
+        for ptr in (self._pp, self._pr):
+            if ptr:
+                lib().gvpm_host_free(ptr)
+        self._pp, self._pr = C.c_void_p(), C.c_void_p()
 
     __del__ = close
 
@@ -209,6 +305,28 @@ class Context:
             self._check(lib().gvpm_upload_photons(self._h, C.byref(photons.soa)))
         if rays is not None:
             self._check(lib().gvpm_upload_camera_beams(self._h, rays.ptr, rays.nsets))
+
+    # packed records (gvpm_upload_*_packed): 76 bytes a photon, 272 a beam set
+    def upload_materials(self, table):
+        self._check(lib().gvpm_upload_materials(self._h, table.table.ctypes.data, table.n))
+
+    def upload_photons_packed(self, packed):
+        packed = np.ascontiguousarray(packed)
+        assert packed.dtype == abi.PHOTON_PACKED_DTYPE
+        self._check(lib().gvpm_upload_photons_packed(self._h, packed.ctypes.data if packed.size else None, packed.size))
+
+    def upload_camera_beams_packed(self, packed):
+        packed = np.ascontiguousarray(packed)
+        n = packed.nbytes // 272
+        self._check(lib().gvpm_upload_camera_beams_packed(self._h, packed.ctypes.data if n else None, n))
+
+    def upload_pinned_packed(self, pk):
+        self._check(lib().gvpm_upload_photons_packed(self._h, pk._pp, pk.n))
+        self._check(lib().gvpm_upload_camera_beams_packed(self._h, pk._pr, pk.nsets))
+
+    def prefetch_packed(self, pk):
+        self._check(lib().gvpm_prefetch_photons_packed(self._h, pk._pp, pk.n))
+        self._check(lib().gvpm_prefetch_camera_beams_packed(self._h, pk._pr, pk.nsets))
 
     def prefetch(self, photons=None, rays=None):
         """The inputs of the step after the coming gather (gvpm_prefetch_*)."""

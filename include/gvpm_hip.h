@@ -319,6 +319,67 @@ int gvpm_host_free(void *p);
 int gvpm_prefetch_photons(gvpm_context *h, const gvpm_photon_soa *photons);
 int gvpm_prefetch_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uint64_t n_sets);
 
+/* ---- packed uploads (round 3) ----------------------------------------------*/
+/* The SoA entry points above move 120 bytes a photon and 320 a beam set over PCIe -- at C2 2.9 times the duration of the
+ * step they feed.  These records carry the same inputs in 76 and 272 bytes:
+ *   photons  -- wi is not sent: the device forms normalize(parent_pos - pos) (in fp64, rounded once), which is what
+ *               -edge(c-1)->d is; parent_n and parent_wi travel as octahedral 2 x snorm16 (axis-aligned vectors are exact,
+ *               others are off by < 4e-5 rad; a zero vector stays zero); parent_scat and parent_g become an index into a
+ *               table of the scene's materials (gvpm_upload_materials); path_id travels as the one bit the gather reads
+ *               of it (checkerboard parity, gvpm.cpp:1020-1030) in bit 7 of flags.  Positions, flux, prefix_w and the three
+ *               pdfs / weights stay fp32: evaluation counts are those of the SoA upload, bit for bit.
+ *   beam set -- the base ray as it is, the four shifted rays without the fields only the base carries (rand, pixel) and
+ *               with `info` folded away: valid = !signbit(len), edge = the base ray's.  Lossless.
+ * gvpm_pack_* / gvpm_unpack_* are plain host functions (no GPU): a producer packs straight into pinned memory
+ * (gvpm_host_alloc), and what a packed upload means is DEFINED by gvpm_unpack_photons -- the device decodes with the same
+ * arithmetic, operation for operation.  Reference seam: gvpm/gvpm_accel.h:31-59,119-199 (the fields read back there).     */
+typedef struct gvpm_material {
+  float scat[3];            /* parent_scat: diffuse reflectance of a surface, sigma_s of a medium */
+  float g;                  /* parent_g                                                            */
+} gvpm_material;
+typedef struct gvpm_photon_packed { /* 76 bytes */
+  float pos[3];
+  float parent_pdf;
+  float parent_pos[3];
+  float edge_pdf;
+  float flux[3];
+  float parent_rr;
+  float prefix_w[3];
+  uint32_t parent_n_oct;    /* x | y << 16, snorm16 each; 0x80008000: the zero vector            */
+  uint32_t parent_wi_oct;
+  uint32_t flags;           /* GVPM_PF_* with bit 7 = path_id & 1                                 */
+  uint32_t material;        /* index into the table of gvpm_upload_materials                      */
+} gvpm_photon_packed;
+typedef struct gvpm_ray_packed {    /* 52 bytes: a shifted ray of a beam set */
+  float o[3];
+  float len;                /* sign bit set: !validVolumeEdge (the magnitude is still the length) */
+  float d[3];
+  float pdf;
+  float eye[3];
+  float jacobian;
+  float gop;
+} gvpm_ray_packed;
+typedef struct gvpm_beam_set_packed { /* 272 bytes */
+  gvpm_camera_ray base;
+  gvpm_ray_packed shifted[4];
+} gvpm_beam_set_packed;
+/* table / table_n: the materials met so far (in/out, appended to; at most table_cap <= 65536 entries --
+ * GVPM_ERR_INVALID_ARG beyond, e.g. a textured scene: such a host keeps the SoA upload).                                  */
+int gvpm_pack_photons(const gvpm_photon_soa *src, gvpm_photon_packed *dst, gvpm_material *table, uint32_t table_cap,
+                      uint32_t *table_n);
+/* dst: 14 writable arrays of src_n elements (the pointers of a gvpm_photon_soa, cast)                                    */
+int gvpm_unpack_photons(const gvpm_photon_packed *src, uint64_t n, const gvpm_material *table, uint32_t table_n,
+                        const gvpm_photon_soa *dst);
+/* GVPM_ERR_INVALID_ARG when a shifted ray's edge index differs from its base ray's                                       */
+int gvpm_pack_camera_beams(const gvpm_camera_ray *rays, uint64_t n_sets, gvpm_beam_set_packed *dst);
+int gvpm_unpack_camera_beams(const gvpm_beam_set_packed *src, uint64_t n_sets, gvpm_camera_ray *dst);
+int gvpm_upload_materials(gvpm_context *h, const gvpm_material *table, uint32_t n);
+/* as gvpm_upload_photons / gvpm_prefetch_photons (pageable or pinned memory; prefetch: pinned only)                       */
+int gvpm_upload_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n);
+int gvpm_prefetch_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n);
+int gvpm_upload_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
+int gvpm_prefetch_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
+
 /* ---- the hot path ---------------------------------------------------------*/
 /* One SPPM iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079;
  * vol_technique BRE2D/BRE3D): builds the acceleration structure over the

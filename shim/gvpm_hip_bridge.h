@@ -93,7 +93,7 @@ public:
       case EVolBRE2D:
       case EVolBRE3D:
         flattenPhotons(photonMap);
-        check(gvpm_upload_photons(m_h, &m_soa.view()), "gvpm_upload_photons");
+        uploadPhotons();
         break;
       case EBeamBeam1D:
       case EBeamBeam3D_Optimized:
@@ -110,7 +110,7 @@ public:
         SLog(EError, "gvpm_hip: volume technique not available (the reference asserts on it too)");
     }
     flattenCameraBeams(scene, gatherBlocks, threadData, sampler, tech == EDistance);
-    check(gvpm_upload_camera_beams(m_h, m_rays.data(), m_rays.size() / 5), "gvpm_upload_camera_beams");
+    uploadCameraBeams();
     if (tech == EDistance) {
       uploadVpmState(gatherBlocks);   /* nothing to send: scaleVol / NVol live on the device (see writeBack) */
       check(gvpm_upload_vpm_samples(m_h, m_samples.data(), m_samples.size()), "gvpm_upload_vpm_samples");
@@ -127,6 +127,53 @@ public:
   void reset() { check(gvpm_reset(m_h), "gvpm_reset"); }
 
 private:
+  /* ------------------------------------------------------------------------------------------- packed uploads -- */
+  /* The per-iteration inputs cross PCIe as packed records from pinned memory (include/gvpm_hip.h "packed uploads":
+   * 76 bytes a photon instead of 120, 272 a beam set instead of 320; an asynchronous copy instead of a staged one).  The
+   * buffers are reused by the next iteration, which starts after writeBack() has waited for this one's results. */
+  struct Pinned {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes) {
+      if (bytes > cap) {
+        if (p) gvpm_host_free(p);
+        p = nullptr;
+        cap = 0;
+        if (gvpm_host_alloc(bytes + bytes / 4 + 64, &p) != GVPM_OK) SLog(EError, "gvpm_hip: gvpm_host_alloc failed");
+        cap = bytes + bytes / 4 + 64;
+      }
+      return p;
+    }
+    ~Pinned() { if (p) gvpm_host_free(p); }
+  };
+  void uploadPhotons() {
+    const gvpm_photon_soa &v = m_soa.view();
+    if (m_materials.empty()) m_materials.resize(4096);
+    gvpm_photon_packed *dst = (gvpm_photon_packed *) m_pinPhotons.get((size_t) v.n * sizeof(gvpm_photon_packed));
+    uint32_t nmat = m_nMaterials;
+    if (gvpm_pack_photons(&v, dst, m_materials.data(), (uint32_t) m_materials.size(), &nmat) == GVPM_OK) {
+      if (nmat != m_nMaterials) {
+        check(gvpm_upload_materials(m_h, m_materials.data(), nmat), "gvpm_upload_materials");
+        m_nMaterials = nmat;
+      }
+      check(gvpm_upload_photons_packed(m_h, dst, v.n), "gvpm_upload_photons_packed");
+    } else {
+      /* more distinct (reflectance, g) pairs than the table holds -- a textured scene: the fp32 SoA upload */
+      check(gvpm_upload_photons(m_h, &v), "gvpm_upload_photons");
+    }
+  }
+  void uploadCameraBeams() {
+    const size_t nsets = m_rays.size() / 5;
+    gvpm_beam_set_packed *dst = (gvpm_beam_set_packed *) m_pinRays.get(nsets * sizeof(gvpm_beam_set_packed));
+    if (gvpm_pack_camera_beams(m_rays.data(), nsets, dst) == GVPM_OK)
+      check(gvpm_upload_camera_beams_packed(m_h, dst, nsets), "gvpm_upload_camera_beams_packed");
+    else
+      check(gvpm_upload_camera_beams(m_h, m_rays.data(), nsets), "gvpm_upload_camera_beams");
+  }
+  Pinned m_pinPhotons, m_pinRays;
+  std::vector<gvpm_material> m_materials;
+  uint32_t m_nMaterials = 0;
+
   /* ---------------------------------------------------------------------------------------------- SoA storage -- */
   struct Soa {
     std::vector<float> pos, wi, flux, parent_pos, parent_n, prefix_w, parent_scat, parent_wi;
