@@ -127,6 +127,14 @@ PHOTON_PACKED_DTYPE = np.dtype([
     ("pos", np.float32, 3), ("parent_pdf", np.float32), ("parent_pos", np.float32, 3), ("edge_pdf", np.float32),
     ("flux", np.float32, 3), ("parent_rr", np.float32), ("prefix_w", np.float32, 3), ("parent_n_oct", np.uint32),
     ("parent_wi_oct", np.uint32), ("flags", np.uint32), ("material", np.uint32)])
+SHIFT_REQUEST_DTYPE = np.dtype([
+    ("photon", np.uint32), ("set", np.uint32), ("shift", np.uint32), ("reserved", np.uint32), ("offset_pos", np.float32, 3),
+    ("radius", np.float32), ("base_point", np.float32, 3), ("t", np.float32), ("shift_point", np.float32, 3),
+    ("reserved2", np.float32)])
+HOST_SHIFT_DTYPE = np.dtype([
+    ("ok", np.uint32), ("throughput", np.float32, 3), ("wi", np.float32, 3), ("pdf", np.float32), ("det_ratio", np.float32),
+    ("base_pdf", np.float32)])
+assert SHIFT_REQUEST_DTYPE.itemsize == 64 and HOST_SHIFT_DTYPE.itemsize == 40
 RAY_PACKED_DTYPE = np.dtype([
     ("o", np.float32, 3), ("len", np.float32), ("d", np.float32, 3), ("pdf", np.float32), ("eye", np.float32, 3),
     ("jacobian", np.float32), ("gop", np.float32)])

@@ -34,7 +34,8 @@ void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *ke
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
                     uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                     const NearGrid &ng, uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
-                    hipStream_t s);
+                    uint32_t *origIdx, hipStream_t s);
+void launch_apply_host_shifts(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s);
 void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
                       hipStream_t s);
 void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
@@ -166,6 +167,7 @@ struct BuildSet {
   float builtRadius = -1.f;
   DevBuf<float4> hot, cold;
   DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
+  DevBuf<uint32_t> origIdx;      // sorted photon -> index in the upload (host-shift requests; filled only when enabled)
   DevBuf<uint32_t> cellStart, cellCount, sat, keysA, keysB, valsA, valsB;
   DevBuf<uint32_t> beamCount, beamStart;  // counting sort of the beam sets
   DevBuf<float> boundsPartial, bounds6;
@@ -189,7 +191,7 @@ struct BuildSet {
   hipError_t mirrorFrom(const BuildSet &o) {
     hipError_t e = hipSuccess;
 #define GVPM_MIRROR(X) if (e == hipSuccess) e = X.reserveExact(o.X.cap)
-    GVPM_MIRROR(hot); GVPM_MIRROR(cold); GVPM_MIRROR(overflowCtr); GVPM_MIRROR(cellStart); GVPM_MIRROR(cellCount);
+    GVPM_MIRROR(hot); GVPM_MIRROR(cold); GVPM_MIRROR(overflowCtr); GVPM_MIRROR(origIdx); GVPM_MIRROR(cellStart); GVPM_MIRROR(cellCount);
     GVPM_MIRROR(sat); GVPM_MIRROR(keysA); GVPM_MIRROR(keysB); GVPM_MIRROR(valsA); GVPM_MIRROR(valsB);
     GVPM_MIRROR(beamCount); GVPM_MIRROR(beamStart); GVPM_MIRROR(boundsPartial); GVPM_MIRROR(bounds6);
     GVPM_MIRROR(bKeysA); GVPM_MIRROR(bKeysB); GVPM_MIRROR(bValsA); GVPM_MIRROR(setPerm); GVPM_MIRROR(tileStart);
@@ -199,7 +201,7 @@ struct BuildSet {
     return e;
   }
   void release() {
-    hot.release(); cold.release(); overflowCtr.release(); cellStart.release(); cellCount.release(); sat.release();
+    hot.release(); cold.release(); overflowCtr.release(); origIdx.release(); cellStart.release(); cellCount.release(); sat.release();
     beamCount.release(); beamStart.release(); keysA.release(); keysB.release();
     valsA.release(); valsB.release(); boundsPartial.release(); bounds6.release(); bKeysA.release(); bKeysB.release();
     bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); planBoxes.release(); queueCtl.release();
@@ -287,6 +289,14 @@ struct gvpm_context {
   bool raysOwnedCur = false;              // the current camera rays live in raySlot[rayCur]
   bool photonsOwnedCur = false;           // the current photon map lives in phSlot[phCur]
   hipStream_t copyStream = nullptr;
+  // manifold shifts through the host (gvpm_enable_host_shifts): the requests of the last G-BRE gather
+  uint64_t reqCap = 0;
+  DevBuf<gvpm_shift_request> reqHost;
+  DevBuf<float4> reqCtx;
+  DevBuf<uint32_t> reqCount;
+  DevBuf<gvpm_host_shift> reqResults;
+  bool reqOutstanding = false;   // a gather recorded requests that were neither answered nor written off yet
+  GatherArgs reqArgs;            // of that gather (medium, film, iteration scale)
   DevBuf<gvpm_material> materials;  // gvpm_upload_materials: the table the packed photon records index
   uint32_t nmaterials = 0;
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid
@@ -410,5 +420,6 @@ void launch_unpack_rays(const uint32_t *packed, uint32_t nsets, gvpm_camera_ray 
 }  // namespace gvpm
 
 // shared between the files above
+int flushHostShifts(gvpm_context *h);  // unanswered shift requests become failed shifts (before anything reads the film)
 float currentRadius(const gvpm_context *h);
 

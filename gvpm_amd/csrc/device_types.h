@@ -126,6 +126,12 @@ struct GatherArgs {
   // x = 0xFFFFFFFF: no beam of the chunk reaches the slab.  Null: the traversal computes its boxes (G-Beams).
   uint2 *planBoxes;
   uint32_t planBoxStride;
+  // manifold shifts through the host (gvpm_enable_host_shifts): requests, the device's own part of each, their number
+  gvpm_shift_request *reqHost;
+  float4 *reqCtx;       // 4 per request: {tr, pdfCam, pdfShiftPos, sensorMIS} {scale, bc} {shifted ray d, pixel} {eye, shift}
+  uint32_t *reqCount;
+  uint32_t reqCap;
+  const uint32_t *origIdx;  // sorted photon -> index in the upload
   uint32_t *bundleFlag;  // set by the planner when a valid ray is outside the bundle the grid (mode 1) was built for
   const float2 *beamClear;   // per beam {cosA0, M1}: the free cone of its reconnections (grid_build.hip, beam_near_kernel)
   // G-VPM only

@@ -236,7 +236,8 @@ __device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const LDS &s
 }
 
 // phase 1: base contribution + the four shift attempts of one pair; reconnections are returned in qMask
-template <int B, typename LDS>
+// (HS: manifold-typed shifts are recorded for the host, gvpm_enable_host_shifts -- its own instantiation of the kernel)
+template <int B, bool HS, typename LDS>
 __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const PhotonFront &ph, const RayReg &base,
                                            uint32_t b, Acc27 &acc, uint32_t &nNull, uint32_t &nFail, uint32_t &qMask) {
   const uint32_t pix = s.pix[b];
@@ -273,7 +274,8 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
     const f3 nullFlux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
     // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
     const bool wantsShift = sh.valid && !isNull && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL;
-    const bool queued = wantsShift && (st == 1u || st == 2u);
+    // (a manifold-typed photon goes to phase 2 as well when the host answers such shifts: it records the request there)
+    const bool queued = wantsShift && (st == 1u || st == 2u || (HS && st == 3u));
     nNull += isNull ? 1u : 0u;
     nFail += (wantsShift && !queued) ? 1u : 0u;
     qMask |= queued ? (1u << i) : 0u;
@@ -290,9 +292,109 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
   }
 }
 
+// A shift that needs the manifold walk (shiftPhotonManifold, shift_volume_photon.cpp:160-295): what the walk reads goes
+// to the host's request list, what the device needs to finish the shift once the host has answered (:217-279) stays beside
+// it.  Rare and register hungry: not inlined.  False: the list is full -- a failed shift.
+static __device__ __noinline__ bool recordShiftRequest(const GatherArgs &a, uint32_t pidx, uint32_t set, int i, f3 offsetPos, f3 basePt,
+                                                       f3 shiftPt, float tPrime, float tr, float pdfCam, float pdfShiftPos, float sMIS,
+                                                       float scale, f3 bc, f3 shD, f3 eye, uint32_t pix) {
+  const uint32_t slot = atomicAdd(a.reqCount, 1u);
+  if (slot >= a.reqCap) return false;
+  gvpm_shift_request rq;
+  rq.photon = a.origIdx[pidx];
+  rq.set = set;
+  rq.shift = (uint32_t)i;
+  rq.reserved = 0u;
+  rq.offset_pos[0] = offsetPos.x; rq.offset_pos[1] = offsetPos.y; rq.offset_pos[2] = offsetPos.z;
+  rq.radius = a.radius;
+  rq.base_point[0] = basePt.x; rq.base_point[1] = basePt.y; rq.base_point[2] = basePt.z;
+  rq.t = tPrime;
+  rq.shift_point[0] = shiftPt.x; rq.shift_point[1] = shiftPt.y; rq.shift_point[2] = shiftPt.z;
+  rq.reserved2 = 0.f;
+  a.reqHost[slot] = rq;
+  float4 *c = a.reqCtx + 4 * (size_t)slot;
+  c[0] = make_float4(tr, pdfCam, pdfShiftPos, sMIS);
+  c[1] = make_float4(scale, bc.x, bc.y, bc.z);
+  c[2] = make_float4(shD.x, shD.y, shD.z, __uint_as_float(pix));
+  c[3] = make_float4(eye.x, eye.y, eye.z, __uint_as_float((uint32_t)i));
+  return true;
+}
+
+// The rest of shiftPhotonManifold for the recorded requests, once the host has run the walks (results == nullptr: it has
+// not -- every request is a failed shift): shift_volume_photon.cpp:205-279, then the accumulation of :843-853.
+__global__ __launch_bounds__(256) void apply_host_shifts_kernel(GatherArgs a, const gvpm_host_shift *__restrict__ results, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t ok = 0, bad = 0;
+  if (k < n) {
+    const float4 c0 = a.reqCtx[4 * (size_t)k], c1 = a.reqCtx[4 * (size_t)k + 1], c2 = a.reqCtx[4 * (size_t)k + 2],
+                 c3 = a.reqCtx[4 * (size_t)k + 3];
+    const float tr = c0.x, pdfCam = c0.y, pdfShiftPos = c0.z, sMIS = c0.w, scale = c1.x;
+    const f3 bc = mk3(c1.y, c1.z, c1.w), shD = mk3(c2.x, c2.y, c2.z), eye = mk3(c3.x, c3.y, c3.z);
+    const uint32_t pix = __float_as_uint(c2.w);
+    const int i = (int)__float_as_uint(c3.w);
+    float w = 1.f;
+    f3 sflux = mk3(0.f);
+    bool good = false;
+    if (results && results[k].ok) {
+      const gvpm_host_shift r = results[k];
+      // result.jacobian *= sRecME.jacobian (1) * additionalJacobian (1); *= detProposed / detSource
+      const float jac = r.det_ratio;
+      if (jac > 0.f && isfinite(jac)) {
+        good = true;
+        const f3 photonWeight = mk3(r.throughput[0], r.throughput[1], r.throughput[2]);
+        const f3 wi = mk3(r.wi[0], r.wi[1], r.wi[2]);
+        const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+        const f3 contrib = (sigS * photonWeight) * phaseEval(a.med.g, wi, -shD);
+        sflux = contrib * eye * (tr * jac);
+        w = 0.5f;
+        const float offsetPdf = r.pdf * pdfShiftPos;
+        if (offsetPdf == 0.f) {
+          w = 1.f;
+          sflux = mk3(0.f);
+        }
+        if (a.cfg.use_mis) {
+          const float basePdf = pdfCam * r.base_pdf;
+          if (basePdf == 0.f) {
+            w = 0.f;
+          } else if (a.cfg.power_heuristic) {
+            const float v = sMIS * jac * (offsetPdf / basePdf);
+            w = 1.f / (1.f + v * v);
+          } else {
+            w = 1.f / (1.f + sMIS * offsetPdf * jac / basePdf);
+          }
+        }
+      }
+    }
+    borderRule(a, pix, i, w);
+    const size_t p = (size_t)(pix >> 16) * a.cfg.width + (pix & 0xFFFFu);
+    const float ws = w * scale * a.iterScale, wbS = w * a.iterScale;
+    float *dst = a.iter + p * 27;
+    if (ws != 0.f) {
+      atomicAdd(&dst[3 + 3 * i + 0], sflux.x * ws);
+      atomicAdd(&dst[3 + 3 * i + 1], sflux.y * ws);
+      atomicAdd(&dst[3 + 3 * i + 2], sflux.z * ws);
+    }
+    atomicAdd(&dst[15 + 3 * i + 0], bc.x * wbS);
+    atomicAdd(&dst[15 + 3 * i + 1], bc.y * wbS);
+    atomicAdd(&dst[15 + 3 * i + 2], bc.z * wbS);
+    ok = good ? 1u : 0u;
+    bad = good ? 0u : 1u;
+  }
+  // statistics: a manifold shift that succeeded counts with the reconnections, the others are failed shifts
+  const uint32_t nOk = (uint32_t)__popcll(__ballot(ok != 0u)), nBad = (uint32_t)__popcll(__ballot(bad != 0u));
+  if ((threadIdx.x & 63) == 0 && (nOk | nBad)) {
+    unsigned long long *row = a.stats + 8 * (size_t)(blockIdx.x % GVPM_STAT_ROWS);
+    atomicAdd(&row[3], (unsigned long long)nOk);
+    atomicAdd(&row[4], (unsigned long long)nBad);
+  }
+}
+void launch_apply_host_shifts(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(apply_host_shifts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, results, n);
+}
+
 // phase 2: one queued reconnection shift (shiftPhotonDiffuse through getShiftPos); the result goes to
 // the lane's registers when it belongs to the lane's current beam, else straight to the LDS accumulators
-template <int B, bool FULLVIS, typename LDS>
+template <int B, bool FULLVIS, bool HS, typename LDS>
 __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t b, int i, f3 &sf,
                                                f3 &wb, uint32_t &nDiff, uint32_t &nFail, const float4 *ldsTri) {
   const PhotonCold ph = loadCold(a, pidx);
@@ -350,6 +452,19 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
     const f3 op = offRel - sh.d * dot(offRel, sh.d);
     const float deltaO = fsqrt(fmaxf(0.f, r2 - dot(op, op)));
     pdfShiftPos = frcp(fmaxf(2.f * deltaO, 0.0001f));
+  }
+  if (HS && GVPM_PF_SHIFT_TYPE(ph.bits) == 3u) {
+    // EManifoldShift: the walk is the host's (recordShiftRequest); nothing is added now
+    const f3 shiftPt = basePt + dS;
+    if (recordShiftRequest(a, pidx, a.setPerm[s.setBase + b], i, shiftPt + offRel, basePt, shiftPt, (float)tPrime, trT.x, pdfCam,
+                           pdfShiftPos, sr.sMIS, scale, bc, sh.d, sh.eye, s.pix[b])) {
+      sf = wb = mk3(0.f);
+    } else {
+      nFail++;
+      sf = mk3(0.f);
+      wb = bc;  // weight 1
+    }
+    return;
   }
   bool ok = false;
   f3 sflux;
@@ -654,6 +769,7 @@ template <int B> struct SegLds : RayTile<B> {
   uint32_t boff[B + 1];
   typename SegCfg<B>::Entry q[SEG_QCAP];  // step | lane | shift | beam
   uint16_t amb[SEG_AMB];                  // pairs the fp32 band could not decide: step << 6 | lane
+  uint32_t setBase;                       // of the item (host-shift requests name the beam set)
   // (the shifted rays are kept RELATIVE to their base ray in the ray tile's own slots, with sensorMIS: relToBase)
 };
 
@@ -690,7 +806,7 @@ __device__ __forceinline__ unsigned long long tickLight() {
 #define LTICK() 0ull
 #endif
 
-template <int B, bool FULLVIS, bool PF>
+template <int B, bool FULLVIS, bool PF, bool HS = false>
 __global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 > 0 ? GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 : 1)
 void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const uint2 *__restrict__ itemOff,
                              const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
@@ -752,6 +868,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
     waveLdsSync();
     if (lane < B) s.boff[lane + 1] = incl;
     if (lane == 0) s.boff[0] = 0u;
+    if (lane == 0) s.setBase = setBase;
 #ifdef GVPM_EVAL_TIMING
     const unsigned long long su1 = TICK();
 #endif
@@ -855,7 +972,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             l3 = LTICK();
 #endif
             if (dec == 1) {
-              evalPhase1<B>(a, s, ph, base, cur, acc, nNull, nFail, qMask);
+              evalPhase1<B, HS>(a, s, ph, base, cur, acc, nNull, nFail, qMask);
               dirty = true;
               nEval++;
             }
@@ -940,7 +1057,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           key = k2;
           if (have) {
             f3 sf, wb;
-            evalPhase2Core<B, FULLVIS>(a, s, pidx, b, (int)i, sf, wb, nDiff, nFail, ldsTri);
+            evalPhase2Core<B, FULLVIS, HS>(a, s, pidx, b, (int)i, sf, wb, nDiff, nFail, ldsTri);
             rs = rs + sf;
             rw = rw + wb;
           }
@@ -1065,16 +1182,16 @@ void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *ite
   }
 }
 
-template <bool FULLVIS, bool PF>
+template <bool FULLVIS, bool PF, bool HS = false>
 static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                            uint32_t nwaves, bool persistent, hipStream_t stream) {
   const uint32_t persist = persistent ? 1u : 0u;
   const size_t dyn = (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) ? (size_t)a.ntri * 48u : 0u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS, PF>), dim3((nwaves + SegCfg<64>::WPB - 1) / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS, PF>), dim3((nwaves + SegCfg<32>::WPB - 1) / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS, PF>), dim3((nwaves + SegCfg<16>::WPB - 1) / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<64>::WPB - 1) / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<32>::WPB - 1) / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<16>::WPB - 1) / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
   }
 }
 
@@ -1088,7 +1205,11 @@ void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, co
   const bool pf = (a.cfg.reserved[0] & 32) ? false : ((a.cfg.reserved[0] & 64) ? true : (size_t)a.nph * 128u > ((size_t)256 << 20));
 #define GVPM_LAUNCH_EVAL(FV, P) \
   launchEvaluate<FV, P>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream)
-  if (fullVis) {
+  if (a.reqHost) {
+    // manifold-typed shifts go to the host's request list (no record prefetch variant of these)
+    if (fullVis) launchEvaluate<true, false, true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream);
+    else launchEvaluate<false, false, true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream);
+  } else if (fullVis) {
     if (pf) GVPM_LAUNCH_EVAL(true, true);
     else GVPM_LAUNCH_EVAL(true, false);
   } else {

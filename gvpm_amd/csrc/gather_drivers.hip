@@ -243,6 +243,8 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   }
   HIP_TRY(h, h->bs->overflowCtr.ensure(2));
   HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
+  const bool wantOrig = deferred && h->reqCap > 0 && h->cfg.use_manifold;
+  if (wantOrig) HIP_TRY(h, h->bs->origIdx.ensure((size_t)n + 1));
   // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only);
   // word 0 is the allocation cursor
   const size_t extWant = std::min<size_t>(std::max<size_t>((size_t)n * 8u + 4096u, h->nearExtWant), 0xFFFFFF00u);
@@ -250,7 +252,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->bs->nearExt.p, 1, 1, h->bstream));
   launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
                  h->nearGrid, h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
-                 h->bs->cold.p, h->bs->overflowCtr.p, h->bstream);
+                 h->bs->cold.p, h->bs->overflowCtr.p, wantOrig ? h->bs->origIdx.p : nullptr, h->bstream);
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
   if (!deferred && h->cfg.visibility_as_written) {
@@ -521,6 +523,20 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   // rank's step at C4 with 12 waves per CU, -3 % at C2)
   const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u)
                               ? std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS) : h->nwaves;
+  if (h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
+    // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing
+    HIP_TRY(h, h->reqHost.ensure(h->reqCap));
+    HIP_TRY(h, h->reqCtx.ensure(4 * h->reqCap));
+    HIP_TRY(h, h->reqCount.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
+    a.reqHost = h->reqHost.p;
+    a.reqCtx = h->reqCtx.p;
+    a.reqCount = h->reqCount.p;
+    a.reqCap = (uint32_t)h->reqCap;
+    a.origIdx = h->bs->origIdx.p;
+    h->reqArgs = a;
+    h->reqOutstanding = true;
+  }
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
   launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
                       h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItems, h->persistentEval,
@@ -876,7 +892,68 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   return GVPM_OK;
 }
 
+// ---- manifold shifts through the host (include/gvpm_hip.h) --------------------------------------------------------------
+static int requestCount(gvpm_context *h, uint32_t *n) {
+  uint32_t c = 0;
+  HIP_TRY(h, hipMemcpyAsync(&c, h->reqCount.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  *n = (uint32_t)std::min<uint64_t>(c, h->reqCap);
+  return GVPM_OK;
+}
+int flushHostShifts(gvpm_context *h) {
+  if (!h->reqOutstanding) return GVPM_OK;
+  h->reqOutstanding = false;
+  uint32_t n = 0;
+  const int rc = requestCount(h, &n);
+  if (rc != GVPM_OK) return rc;
+  launch_apply_host_shifts(h->reqArgs, nullptr, n, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  return GVPM_OK;
+}
+
 extern "C" {
+
+int gvpm_enable_host_shifts(gvpm_context *h, uint64_t capacity) {
+  CHECK_H(h);
+  if (capacity > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "host-shift capacity too large");
+  const int rc = flushHostShifts(h);
+  if (rc != GVPM_OK) return rc;
+  h->reqCap = capacity;
+  h->photonsDirty = true;  // (the next build writes the upload index of every photon)
+  return GVPM_OK;
+}
+
+int gvpm_download_shift_requests(gvpm_context *h, gvpm_shift_request *out, uint64_t cap, uint64_t *n) {
+  CHECK_H(h);
+  if (!n || (cap && !out)) return GVPM_ERR_INVALID_ARG;
+  *n = 0;
+  if (!h->reqOutstanding) return GVPM_OK;
+  uint32_t c = 0;
+  const int rc = requestCount(h, &c);
+  if (rc != GVPM_OK) return rc;
+  *n = c;
+  const size_t m = (size_t)std::min<uint64_t>(c, cap);
+  if (m) HIP_TRY(h, hipMemcpy(out, h->reqHost.p, m * sizeof(gvpm_shift_request), hipMemcpyDeviceToHost));
+  return GVPM_OK;
+}
+
+int gvpm_upload_host_shifts(gvpm_context *h, const gvpm_host_shift *results, uint64_t n) {
+  CHECK_H(h);
+  if (!h->reqOutstanding) return n == 0 ? GVPM_OK : fail(h, GVPM_ERR_STATE, "no shift requests are waiting for results");
+  if (n && !results) return fail(h, GVPM_ERR_INVALID_ARG, "null host shifts");
+  uint32_t c = 0;
+  const int rc = requestCount(h, &c);
+  if (rc != GVPM_OK) return rc;
+  if (n != c) return fail(h, GVPM_ERR_INVALID_ARG, "gvpm_upload_host_shifts: one result per recorded request");
+  h->reqOutstanding = false;
+  if (!c) return GVPM_OK;
+  HIP_TRY(h, h->reqResults.ensure(c));
+  HIP_TRY(h, hipMemcpyAsync(h->reqResults.p, results, (size_t)c * sizeof(gvpm_host_shift), hipMemcpyHostToDevice, h->stream));
+  launch_apply_host_shifts(h->reqArgs, h->reqResults.p, c, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // (the caller may reuse `results`)
+  return GVPM_OK;
+}
 
 int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   CHECK_H(h);
@@ -885,6 +962,10 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
   h->useAll = false;
   h->bstream = h->stream;
+  {
+    const int rcf = flushHostShifts(h);
+    if (rcf != GVPM_OK) return rcf;
+  }
   // the streams that read this step's host-uploaded inputs wait for their copies (copy stream)
   // (packed records are decoded here, at the head of the chain that reads them: G-BRE builds on the build stream)
   const bool breTech = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
                                                       const uint32_t *__restrict__ cellStart, uint32_t n,
                                                       gvpm_params cfg, const float4 *bvh, const float4 *tri4,
                                                       uint32_t ntri, float dmax, NearGrid ng, uint32_t *nearExt,
-                                                      uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow) {
+                                                      uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
+                                                      uint32_t *origIdx) {
   // The record is assembled in LDS and written by EIGHT lanes (one 16-byte quad each): a store instruction then
   // covers eight whole 128-byte lines instead of sixty-four 16-byte pieces of sixty-four lines.
   __shared__ float4 stg[64][GVPM_REC_QUADS + 1];  // +1: odd stride against bank conflicts (9 KB: one wave a block)
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
     bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
     const float4 h0 = ld3(r.pos, src, __uint_as_float(bits));
     hot[i] = h0;
+    if (origIdx) origIdx[i] = src;  // (host-shift requests name photons by their place in the upload)
     // one 128-byte record per photon: an evaluation touches exactly one cache line
     stg[t][0] = h0;
     stg[t][1] = ld3(r.wi, src, r.parent_pdf[src]);
@@ -879,13 +881,13 @@ void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *ke
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
                     uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                     const NearGrid &ng, uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
-                    hipStream_t s) {
+                    uint32_t *origIdx, hipStream_t s) {
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
 #define GVPM_REORDER(M) \
   hipLaunchKernelGGL(reorder_kernel<M>, dim3((n + 63) / 64), dim3(64), 0, s, r, keys, rank, cellStart, n, cfg, bvh, tri4, ntri, \
-                     dmax, ng, nearExt, extCap, hot, cold, overflow)
+                     dmax, ng, nearExt, extCap, hot, cold, overflow, origIdx)
   if (ntri <= 64u) GVPM_REORDER(0);
   else if (ng.start) GVPM_REORDER(2);
   else GVPM_REORDER(1);

@@ -193,6 +193,7 @@ int gvpm_destroy(gvpm_context *h) {
   }
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   h->materials.release();
+  h->reqHost.release(); h->reqCtx.release(); h->reqCount.release(); h->reqResults.release();
   h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
   h->subIds.release(); h->beamCtl.release(); h->beamAux.release(); h->beamClear.release();
   h->nearGridStart.release(); h->nearGridTris.release(); h->nearGridCount.release();
@@ -367,6 +368,10 @@ static float accumScale(const gvpm_context *h) { return h->sumMode && h->sumIt >
 
 int gvpm_download_accum(gvpm_context *h, float *accum) {
   CHECK_H(h);
+  {
+    const int rcf = flushHostShifts(h);
+    if (rcf != GVPM_OK) return rcf;
+  }
   if (!accum) return GVPM_ERR_INVALID_ARG;
   const float *src = h->useAll ? h->accumAll.p : h->accum.p;
   if (accumScale(h) != 1.f) {
@@ -382,6 +387,10 @@ int gvpm_download_accum(gvpm_context *h, float *accum) {
 
 int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
   CHECK_H(h);
+  {
+    const int rcf = flushHostShifts(h);
+    if (rcf != GVPM_OK) return rcf;
+  }
   if (!accum_dev) return GVPM_ERR_INVALID_ARG;
   launch_scale(h->useAll ? h->accumAll.p : h->accum.p, accum_dev, h->npix * 27, accumScale(h), h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -390,6 +399,10 @@ int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
 
 // throughput | dx | dy planes into filmOut (device); emission already on the device or null
 static int filmToDevice(gvpm_context *h, int it, int reuse_primal, const float *emissionDev, float *out) {
+  {
+    const int rcf = flushHostShifts(h);
+    if (rcf != GVPM_OK) return rcf;
+  }
   const size_t n = h->npix * 3;
   // non-APA estimators are normalised by the emitted path count (gvpm.cpp:489-492)
   float invDiv = 1.f;

@@ -30,6 +30,7 @@ SYMBOLS = [
     "gvpm_pack_photons", "gvpm_unpack_photons", "gvpm_pack_camera_beams", "gvpm_unpack_camera_beams", "gvpm_upload_materials",
     "gvpm_upload_photons_packed", "gvpm_prefetch_photons_packed", "gvpm_upload_camera_beams_packed",
     "gvpm_prefetch_camera_beams_packed",
+    "gvpm_enable_host_shifts", "gvpm_download_shift_requests", "gvpm_upload_host_shifts",
 ]
 
 
@@ -93,6 +94,9 @@ def lib():
         L.gvpm_poisson_solve.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.gvpm_poisson_solve_dev.argtypes = [vp, C.POINTER(abi.PoissonParams), C.c_int, C.c_int, vp, vp, vp, vp, vp]
         L.gvpm_host_alloc.argtypes = [C.c_uint64, C.POINTER(vp)]
+        L.gvpm_enable_host_shifts.argtypes = [vp, C.c_uint64]
+        L.gvpm_download_shift_requests.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gvpm_upload_host_shifts.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_pack_photons.argtypes = [C.POINTER(abi.PhotonSoA), vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gvpm_unpack_photons.argtypes = [vp, C.c_uint64, vp, C.c_uint32, C.POINTER(abi.PhotonSoA)]
         L.gvpm_pack_camera_beams.argtypes = [vp, C.c_uint64, vp]
@@ -305,6 +309,22 @@ class Context:
             self._check(lib().gvpm_upload_photons(self._h, C.byref(photons.soa)))
         if rays is not None:
             self._check(lib().gvpm_upload_camera_beams(self._h, rays.ptr, rays.nsets))
+
+    # manifold shifts through the host (gvpm_enable_host_shifts)
+    def enable_host_shifts(self, capacity):
+        self._check(lib().gvpm_enable_host_shifts(self._h, capacity))
+
+    def download_shift_requests(self, cap):
+        """(requests recorded by the last gather [numpy SHIFT_REQUEST_DTYPE, at most cap], their total number)"""
+        out = np.zeros(cap, abi.SHIFT_REQUEST_DTYPE)
+        n = C.c_uint64(0)
+        self._check(lib().gvpm_download_shift_requests(self._h, out.ctypes.data if cap else None, cap, C.byref(n)))
+        return out[:min(cap, n.value)], n.value
+
+    def upload_host_shifts(self, results):
+        results = np.ascontiguousarray(results)
+        assert results.dtype == abi.HOST_SHIFT_DTYPE
+        self._check(lib().gvpm_upload_host_shifts(self._h, results.ctypes.data if results.size else None, results.size))
 
     # packed records (gvpm_upload_*_packed): 76 bytes a photon, 272 a beam set
     def upload_materials(self, table):

@@ -380,6 +380,44 @@ int gvpm_prefetch_photons_packed(gvpm_context *h, const gvpm_photon_packed *phot
 int gvpm_upload_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
 int gvpm_prefetch_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
 
+/* ---- manifold shifts through the host (first slice) ----------------------------------------*/
+/* A photon whose shift type is 3 (EManifoldShift: a specular chain between the photon and the vertex it can be re-connected
+ * from) needs the manifold walk of shiftPhotonManifold (shift_volume_photon.cpp:160-295: generateShiftPathME + ShiftME,
+ * shift/operation/shift_ME.cpp:13-142, SpecularManifold::det, src/libbidir/mut_manifold.cpp:1310-1410) -- Newton iterations
+ * over Mitsuba's Path / BSDF objects that stay on the host.  With use_manifold = 0 such a shift is a failed shift (weight 1),
+ * as in the reference.  With use_manifold = 1 and gvpm_enable_host_shifts(h, capacity > 0), a G-BRE gather instead RECORDS
+ * one request per (photon, beam, shifted pixel) that reaches shiftPhotonManifold -- everything the walk takes as input -- and
+ * adds nothing for it; the host runs the walk for each request and hands the results back; the device then applies
+ * shift_volume_photon.cpp:217-279 (contribution, Jacobian, MIS weight) and adds the terms to the iteration:
+ *     gvpm_gather(it) -> gvpm_download_shift_requests -> [host: manifold walks] -> gvpm_upload_host_shifts
+ * Requests the host never answers (the next gvpm_gather or download comes first), and requests beyond `capacity`, count as
+ * failed shifts.                                                                                                          */
+typedef struct gvpm_shift_request { /* 64 bytes */
+  uint32_t photon;          /* index into this iteration's photon upload: lightPath / vertexId = c of the walk           */
+  uint32_t set;             /* beam set (upload order) and ...                                                            */
+  uint32_t shift;           /* ... which of its shifted rays: 0..3 = L R T B                                              */
+  uint32_t reserved;
+  float offset_pos[3];      /* offsetPos (getShiftPos, :858-896): where vertex c of the proposal lies                     */
+  float radius;             /* photonRadius (the host multiplies by its config.relaxME)                                   */
+  float base_point[3];      /* baseRay(baseRay.maxt)                                                                      */
+  float t;                  /* baseRay.maxt = shiftRay.maxt = t'                                                          */
+  float shift_point[3];     /* shiftRay(shiftRay.maxt)                                                                    */
+  float reserved2;
+} gvpm_shift_request;
+typedef struct gvpm_host_shift {    /* 40 bytes */
+  uint32_t ok;              /* generateShiftPathME && ShiftME succeeded                                                    */
+  float throughput[3];      /* sRecME.throughtput                                                                          */
+  float wi[3];              /* normalize(proposal.vertex(c-1)->getPosition() - offsetPos)                                  */
+  float pdf;                /* sRecME.pdf                                                                                  */
+  float det_ratio;          /* manifold->det(proposal, b, c) / manifold->det(source, b, c)                                 */
+  float base_pdf;           /* prod_{i=b}^{c-1} source.vertex(i)->pdf[EImportance] * source.edge(i)->pdf[EImportance]      */
+} gvpm_host_shift;
+int gvpm_enable_host_shifts(gvpm_context *h, uint64_t capacity);   /* 0: off (the default)                                 */
+/* waits for the gather; *n = requests recorded (at most capacity), the first min(*n, cap) of them copied to `out`        */
+int gvpm_download_shift_requests(gvpm_context *h, gvpm_shift_request *out, uint64_t cap, uint64_t *n);
+/* results[k] answers request k; n must be the number of recorded requests                                                */
+int gvpm_upload_host_shifts(gvpm_context *h, const gvpm_host_shift *results, uint64_t n);
+
 /* ---- the hot path ---------------------------------------------------------*/
 /* One SPPM iteration of computeVolumeGradientPhotonBRE (gvpm.cpp:988-1079;
  * vol_technique BRE2D/BRE3D): builds the acceleration structure over the

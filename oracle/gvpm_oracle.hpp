@@ -486,6 +486,73 @@ template <typename F> struct VolumeGradientRecord {
     return true;
   }
 
+  // The manifold walk itself (generateShiftPathME + ShiftME + SpecularManifold::det; shift_ME.cpp:13-142,
+  // mut_manifold.cpp:1310-1410) runs over Mitsuba's Path / BSDF objects and is NOT restated: this oracle, like the device,
+  // takes its results as given.  STAND-IN used by the tests of the host-shift round trip (include/gvpm_hip.h
+  // gvpm_upload_host_shifts): a smooth closed-form function of the request and of the photon's parent vertex, shaped like
+  // a reconnection to the parent -- NOT Mitsuba's walk.  What the tests verify with it is the content of the requests and
+  // the application of shift_volume_photon.cpp:205-279 below.
+  struct HostShift {
+    bool ok;
+    V throughput, wi;
+    F pdf, detRatio, basePdf;
+  };
+  static HostShift standinManifoldWalk(const V &offsetPos, const V &photonPos, const V &parentPos, const V &prefixW,
+                                       F parentPdf, F edgePdf) {
+    HostShift r;
+    V d = parentPos - offsetPos;
+    const F len = d.length(), lenB = (parentPos - photonPos).length();
+    r.ok = len > (F)0 && len < (F)3 * lenB;
+    r.wi = len > (F)0 ? d / len : V((F)0);
+    const F q = len > (F)0 ? (lenB * lenB) / (len * len) : (F)0;
+    r.throughput = prefixW * (len > (F)0 ? lenB / len : (F)0);
+    r.pdf = parentPdf * q;
+    r.detRatio = q;
+    r.basePdf = parentPdf * edgePdf;
+    return r;
+  }
+
+  // shiftPhotonManifold, shift_volume_photon.cpp:160-295, from the walk's results on
+  bool shiftPhotonManifold(const V &offsetPos, const Photon<F> &ph, const CamRay<F> &shiftGP, const Ray<F> &shiftRay,
+                           const MRec<F> &shiftMRec, GradientSamplingResult<F> &result, F pdfBaseRay, F pdfShiftRay,
+                           F additionalJacobian) {
+    const HostShift hs = standinManifoldWalk(offsetPos, ph.pos, ph.parentPos, ph.prefixW, ph.parentPdf, ph.edgePdf);
+    if (!hs.ok) {  // generateShiftPathME / ShiftME failed (:186-203)
+      result.weight = 1.0f;
+      return false;
+    }
+    result.jacobian *= (F)1 * additionalJacobian;  // sRecME.jacobian stays 1 (shift_utilities.h:30)
+    result.jacobian *= hs.detRatio;                // detProposed / detSource (:212-214)
+    if (result.jacobian <= 0.0 || !std::isfinite(result.jacobian)) {
+      result.weight = 1.0f;
+      return false;
+    }
+    V contrib = getVolumePhotonContrib(hs.throughput, shiftMRec, hs.wi, -shiftRay.d);
+    V eyeShiftContrib = shiftGP.eye;
+    result.weight = 0.5f;
+    result.shiftedFlux = shiftMRec.transmittance * contrib * eyeShiftContrib * result.jacobian;
+    F offsetPdf = hs.pdf * pdfShiftRay;
+    if (offsetPdf == (F)0) {
+      result.weight = 1.0f;
+      result.shiftedFlux = V((F)0);
+    }
+    if (ctx.cfg.use_mis) {
+      F basePdf = pdfBaseRay * hs.basePdf;
+      if (basePdf == (F)0) {
+        result.weight = 0.0f;
+      } else {
+        const F sensorPart = sensorMIS(shiftGP, *baseGather, currEdge, shiftRay.maxt, baseRay.maxt);
+        if (ctx.cfg.power_heuristic) {
+          F v = sensorPart * result.jacobian * (offsetPdf / basePdf);
+          result.weight = 1.0f / (1.0f + v * v);
+        } else {
+          result.weight = 1.0f / (1.0f + sensorPart * offsetPdf * result.jacobian / basePdf);
+        }
+      }
+    }
+    return true;
+  }
+
   // shiftPhoton dispatch, shift_volume_photon.cpp:49-117 (shiftedEnoughRough == true)
   bool shiftPhoton(const V &offsetPos, const Photon<F> &ph, const CamRay<F> &shiftGP, const Ray<F> &shiftRay,
                    const MRec<F> &shiftMRec, GradientSamplingResult<F> &result, F pdfBaseRay, F pdfShiftRay,
@@ -500,8 +567,10 @@ template <typename F> struct VolumeGradientRecord {
       // noMediumShift (default true): diffuse reconnection; shiftPhotonMedium is SAssert(false)
       ok = shiftPhotonDiffuse(offsetPos, ph, shiftGP, shiftRay, shiftMRec, result, pdfBaseRay, pdfShiftRay, additionalJacobian);
     } else {
-      // EManifoldShift: host-only; without useManifold the reference returns false (:101-104)
-      ok = false;
+      // EManifoldShift: without useManifold the reference returns false (:101-104)
+      ok = ctx.cfg.use_manifold ? shiftPhotonManifold(offsetPos, ph, shiftGP, shiftRay, shiftMRec, result, pdfBaseRay, pdfShiftRay,
+                                                      additionalJacobian)
+                                : false;
     }
     if (ok) cnt.diffuseShifts++; else cnt.failedShifts++;
     return ok;

@@ -322,6 +322,29 @@ int oracle_gather_vpm_timed(const gvpm_params *p, const gvpm_medium *m, const gv
 // 0 = brute-force O(B*N) over the same hit predicate.  accum: width*height*27 doubles
 // (in/out, the APA running mean).  counters: 5 x uint64 {evaluations, candidates,
 // null, diffuse, failed}.
+// the stand-in of the host's manifold walk (gvpm_oracle.hpp standinManifoldWalk) applied to downloaded requests: what the
+// tests of gvpm_upload_host_shifts hand back to the device
+int oracle_standin_host_shifts(const gvpm_photon_soa *ph, const gvpm_shift_request *req, uint64_t n, gvpm_host_shift *out) {
+  using R = oracle::VolumeGradientRecord<double>;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t i = req[k].photon;
+    if (i >= ph->n) return 1;
+    auto v3 = [&](const float *a) { return oracle::Vec3<double>(a[3 * i], a[3 * i + 1], a[3 * i + 2]); };
+    const oracle::Vec3<double> off(req[k].offset_pos[0], req[k].offset_pos[1], req[k].offset_pos[2]);
+    const R::HostShift hs = R::standinManifoldWalk(off, v3(ph->pos), v3(ph->parent_pos), v3(ph->prefix_w),
+                                                   (double)ph->parent_pdf[i], (double)ph->edge_pdf[i]);
+    out[k].ok = hs.ok ? 1u : 0u;
+    for (int c = 0; c < 3; ++c) {
+      out[k].throughput[c] = (float)hs.throughput[c];
+      out[k].wi[c] = (float)hs.wi[c];
+    }
+    out[k].pdf = (float)hs.pdf;
+    out[k].det_ratio = (float)hs.detRatio;
+    out[k].base_pdf = (float)hs.basePdf;
+  }
+  return 0;
+}
+
 int oracle_gather_bre_timed(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
                             const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
                             uint64_t nb_paths, int precision, int use_accel, int threads, double *accum,

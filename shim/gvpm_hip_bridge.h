@@ -55,9 +55,11 @@ public:
     p.path_set = config.pathSet ? 1 : 0;
     p.power_heuristic = config.powerHeuristic ? 1 : 0;
     p.no_medium_shift = config.noMediumShift ? 1 : 0;
-    p.use_manifold = config.useManifold ? 1 : 0;                    /* manifold shifts stay on the host: the device
-                                                                       treats them as useManifold=false does
-                                                                       (shift_volume_photon.cpp:101-104)          */
+    p.use_manifold = config.useManifold ? 1 : 0;                    /* the manifold WALK stays on the host: the G-BRE
+                                                                       gather records a request per such shift and
+                                                                       answerShiftRequests() below answers them; the
+                                                                       other techniques treat these shifts as
+                                                                       useManifold=false does (:101-104)          */
     p.debug_shift = (int32_t) config.debugShift;                    /* ELightShiftType values kept                */
     p.lighting_interaction_mode = (int32_t) config.lightingInteractionMode;
     p.bsdf_interaction_mode = (int32_t) config.bsdfInteractionMode;
@@ -69,6 +71,7 @@ public:
     p.epsilon = (float) Epsilon;                                    /* include/mitsuba/core/constants.h:24-31     */
     p.shadow_epsilon = (float) ShadowEpsilon;
     check(gvpm_create(&p, device, &m_h), "gvpm_create");
+    if (config.useManifold) check(gvpm_enable_host_shifts(m_h, kShiftRequestCapacity), "gvpm_enable_host_shifts");
     m_params = p;
     m_config = config;
     uploadScene(scene);
@@ -116,6 +119,7 @@ public:
       check(gvpm_upload_vpm_samples(m_h, m_samples.data(), m_samples.size()), "gvpm_upload_vpm_samples");
     }
     check(gvpm_gather(m_h, it, (uint64_t) nbPaths), "gvpm_gather");
+    if (m_config.useManifold && (tech == EVolBRE2D || tech == EVolBRE3D)) answerShiftRequests(photonMap, threadData, scene);
     writeBack(gatherBlocks, tech == EDistance);
     float r = 0.f;
     check(gvpm_get_radius(m_h, &r), "gvpm_get_radius");
@@ -127,6 +131,71 @@ public:
   void reset() { check(gvpm_reset(m_h), "gvpm_reset"); }
 
 private:
+  /* ------------------------------------------------------------------------------------------ manifold shifts -- */
+  /* shiftPhotonManifold, shift_volume_photon.cpp:160-295, split where the data lives: the device gathered, found the
+   * shifts that need the walk and recorded their inputs (gvpm_shift_request); the walk (generateShiftPathME + ShiftME,
+   * shift/operation/shift_ME.cpp:13-142) and the determinants of the specular manifold (:205-214) run here on Mitsuba's
+   * Path objects, exactly as the reference runs them; the device then applies :217-279 to what comes back.          */
+  static const uint64_t kShiftRequestCapacity = 1u << 22;
+  void answerShiftRequests(const GPhotonMap *photonMap, GPMThreadData &thdata, const Scene *scene) {
+    m_requests.resize(kShiftRequestCapacity);
+    uint64_t n = 0;
+    check(gvpm_download_shift_requests(m_h, m_requests.data(), m_requests.size(), &n), "gvpm_download_shift_requests");
+    if (n > m_requests.size()) n = m_requests.size();   /* the surplus was written off as failed shifts by the device */
+    gvpm_host_shift none;
+    memset(&none, 0, sizeof(none));
+    m_hostShifts.assign((size_t) n, none);
+    const Medium *medium = nullptr;
+    for (const auto &m : scene->getMedia()) medium = m.get();
+    for (uint64_t k = 0; k < n; ++k) {
+      const gvpm_shift_request &rq = m_requests[k];
+      gvpm_host_shift &out = m_hostShifts[k];
+      const GPhotonNodeData &d = (*photonMap)[rq.photon].getData();
+      const Path &source = *d.lightPath;
+      const int c = (int) d.vertexId;
+      int b = 0;
+      getTypeShift(&source, (size_t) c, b);                          /* shift_utilities.h:112-136: where the chain starts */
+      const Point offsetPos(rq.offset_pos[0], rq.offset_pos[1], rq.offset_pos[2]);
+      Path proposal;
+      PathVertex shiftVertex;                                        /* :171-181 */
+      memset(&shiftVertex, 0, sizeof(PathVertex));
+      MediumSamplingRecord &cacheMRec = shiftVertex.getMediumSamplingRecord();
+      cacheMRec.t = 0.f;
+      cacheMRec.p = offsetPos;
+      cacheMRec.medium = medium;
+      shiftVertex.type = PathVertex::EMediumInteraction;
+      shiftVertex.measure = EArea;
+      shiftVertex.sampledComponentIndex = -1;
+      ShiftRecord sRecME;
+      bool ok = generateShiftPathME(source, proposal, (size_t) b, (size_t) c, thdata.pool, thdata.offsetGenerator.get(),
+                                    shiftVertex, (Float) rq.radius * m_config.relaxME,
+                                    Point(rq.base_point[0], rq.base_point[1], rq.base_point[2]),
+                                    Point(rq.shift_point[0], rq.shift_point[1], rq.shift_point[2]));
+      ok = ok && ShiftME(sRecME, source, proposal, (size_t) b, (size_t) c, false);
+      if (ok) {
+        SpecularManifold *manifold = thdata.offsetGenerator->getSpecularManifold();
+        out.det_ratio = (float) (manifold->det(proposal, b, c) / manifold->det(source, b, c));   /* :212-214 */
+        Float r, g, bl;
+        sRecME.throughtput.toLinearRGB(r, g, bl);
+        out.throughput[0] = (float) r; out.throughput[1] = (float) g; out.throughput[2] = (float) bl;
+        const Vector wi = normalize(proposal.vertex(c - 1)->getPosition() - offsetPos);          /* :227 */
+        out.wi[0] = (float) wi.x; out.wi[1] = (float) wi.y; out.wi[2] = (float) wi.z;
+        out.pdf = (float) sRecME.pdf;
+        Float basePdf = 1.f;                                         /* :256-260, without pdfBaseRay (the device's)  */
+        for (int i = b; i < c; ++i) basePdf *= source.vertex(i)->pdf[EImportance] * source.edge(i)->pdf[EImportance];
+        out.base_pdf = (float) basePdf;
+        out.ok = 1;
+      }
+      for (int i = b; i <= c; ++i) {                                 /* :187-190, :199-202, :287-290 */
+        thdata.pool.release(proposal.edge(i - 1));
+        thdata.pool.release(proposal.vertex(i));
+      }
+    }
+    check(gvpm_upload_host_shifts(m_h, m_hostShifts.data(), n), "gvpm_upload_host_shifts");
+  }
+  std::vector<gvpm_shift_request> m_requests;
+  std::vector<gvpm_host_shift> m_hostShifts;
+
   /* ------------------------------------------------------------------------------------------- packed uploads -- */
   /* The per-iteration inputs cross PCIe as packed records from pinned memory (include/gvpm_hip.h "packed uploads":
    * 76 bytes a photon instead of 120, 272 a beam set instead of 320; an asynchronous copy instead of a staged one).  The

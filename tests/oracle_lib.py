@@ -87,6 +87,19 @@ def gather_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, pr
             secs.value)
 
 
+def standin_host_shifts(photons, requests):
+    """The stand-in of the host's manifold walk (oracle/gvpm_oracle.hpp standinManifoldWalk) on downloaded requests."""
+    requests = np.ascontiguousarray(requests)
+    out = np.zeros(requests.size, abi.HOST_SHIFT_DTYPE)
+    soa = photons.soa()
+    L = lib()
+    L.oracle_standin_host_shifts.argtypes = [C.POINTER(abi.PhotonSoA), C.c_void_p, C.c_uint64, C.c_void_p]
+    rc = L.oracle_standin_host_shifts(C.byref(soa), requests.ctypes.data, requests.size, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("oracle_standin_host_shifts: a request names a photon outside the map")
+    return out
+
+
 def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_accel=True, threads=0, accum=None,
                scale_vol=None, n_vol=None, fast=False, timing=None):
     """One iteration of computeVolumeGradientPhoton (G-VPM) on the CPU.

@@ -92,7 +92,12 @@ def test_every_citation_names_a_file_of_the_reference():
      ["volTechnique", "maxDepth", "minDepth", "useMIS", "useShiftNull", "pathSet", "powerHeuristic", "noMediumShift", "useManifold",
       "debugShift", "lightingInteractionMode", "bsdfInteractionMode", "nbCameraSamples", "alpha", "initialScaleVolume",
       "minCameraDepth", "maxCameraDepth", "stratified", "getWeightBeam", "getWeightVertex", "getVertexInfo", "GOp", "mediumFlux",
-      "shiftedMediumFlux", "weightedMediumFlux", "scaleVol", "NVol", "haveSmoke", "struct GPMThreadData", "MemoryPool pool"]),
+      "shiftedMediumFlux", "weightedMediumFlux", "scaleVol", "NVol", "haveSmoke", "struct GPMThreadData", "MemoryPool pool",
+      "relaxME", "offsetGenerator"]),
+    ("src/integrators/photonmapper/gvpm/shift/operation/shift_ME.h", ["generateShiftPathME", "ShiftME"]),
+    ("src/integrators/photonmapper/gvpm/shift/shift_utilities.h", ["struct ShiftRecord", "throughtput"]),
+    ("include/mitsuba/bidir/mut_manifold.h", ["getSpecularManifold"]),
+    ("include/mitsuba/bidir/manifold.h", ["Float det(const Path &path, int b, int c)"]),
     ("src/integrators/photonmapper/gvpm/gvpm_accel.h", ["struct GPhotonNodeData", "vertexId", "lightPath", "pathID", "operator[]", "size()"]),
     ("src/integrators/photonmapper/gvpm/gvpm_beams.h", ["struct LTPhotonBeam", "edgeID", "pathID", "const Path *path"]),
     ("src/integrators/photonmapper/gvpm/gvpm_plane.h", ["transformBeam"]),
@@ -115,4 +120,5 @@ def test_members_the_bridge_touches_exist_in_the_reference(header, members):
         assert m in text, (header, m)
         token = m.split("(")[0].split()[-1]
         assert token in SHIM or m in ("size()", "operator[]", "MemoryPool pool", "struct GPMThreadData", "const Path *path",
-                                      "struct GPhotonNodeData", "struct LTPhotonBeam", "normalize()", "append("), (header, m)
+                                      "struct GPhotonNodeData", "struct LTPhotonBeam", "normalize()", "append(", "struct ShiftRecord",
+                                      "Float det(const Path &path, int b, int c)"), (header, m)
