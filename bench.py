@@ -621,8 +621,10 @@ def upload_inclusive(hip, p, m, tris, host0, K, device):
     this leg is the packed records (gvpm_upload_*_packed: 76 bytes a photon, 272 a beam set); the fp32 SoA entry points
     (120 / 320 bytes) are timed beside them."""
     table = hip.MaterialTable()
-    sets = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays), hip.PinnedPacked(ph, rays, table))
-            for ph, nb, rays in host0[:2]]
+    # (the packed records first: on a box whose GPU-side NUMA node is short of free memory the later pinned blocks land on
+    # the far node and are read at ~33 GB/s instead of 55 -- seen on one box of the pool, after many processes had run)
+    packed = [hip.PinnedPacked(ph, rays, table) for ph, nb, rays in host0[:2]]
+    sets = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays), pk) for (ph, nb, rays), pk in zip(host0[:2], packed)]
     nbytes_soa = host0[0][0].n * 120 + host0[0][2].nbytes
     nbytes = sets[0][3].nbytes
     ctx = hip.Context(p, device=device)
@@ -630,7 +632,7 @@ def upload_inclusive(hip, p, m, tris, host0, K, device):
     ctx.upload_medium(m)
     ctx.upload_materials(table)
     res = {}
-    for mode in ("packed", "prefetch", "serial"):
+    for mode in os.environ.get("GVPM_BENCH_UPLOAD_MODES", "packed,prefetch,serial").split(","):
         ctx.reset()
         for rep in range(2):  # first pass: allocations
             ctx.synchronize()
@@ -657,6 +659,8 @@ def upload_inclusive(hip, p, m, tris, host0, K, device):
             dt = time.perf_counter() - t0
             ev = ctx.stats()["evaluations"] - ev0
         res[mode] = dict(ms_per_step=dt / K * 1e3, value=ev / dt / 1e6)
+        if os.environ.get("GVPM_BENCH_UPLOAD_TRACE"):
+            print("[upload] %s %.3f ms/step" % (mode, dt / K * 1e3), file=sys.stderr)
     ctx.close()
     for s in sets:
         s[0].close()
