@@ -210,6 +210,19 @@ def poisson_solve(dx, dy, throughput, direct=None, preset="L1D", alpha=0.2):
 
 
 REF_POISSON = os.path.join(ROOT, "oracle", "_ref", "libref_poisson.so")
+REF_IMAGEERRORS = os.path.join(ROOT, "oracle", "_ref", "libref_imageerrors.so")
+REF_METRICS = {"mse": 0, "rmse": 1, "mse_log": 2, "rmse_log": 3, "tvi": 4, "relative": 5, "relmse": 6}
+
+
+def ref_image_metric(img, ref, which="relmse"):
+    """The REFERENCE's metric() (scripts/rgbe/sources/imageerrors.h, built into oracle/_ref by oracle/Makefile.ref)."""
+    L = C.CDLL(REF_IMAGEERRORS)
+    L.ref_image_metric.restype = C.c_float
+    L.ref_image_metric.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    a = np.ascontiguousarray(img, np.float64)
+    b = np.ascontiguousarray(ref, np.float64)
+    assert a.shape == b.shape and a.shape[-1] == 3
+    return float(L.ref_image_metric(a.ctypes.data, b.ctypes.data, a.shape[1], a.shape[0], REF_METRICS[which]))
 _REF = None
 
 

@@ -101,3 +101,26 @@ def test_cpu_baseline_leg_of_the_other_workloads_runs_on_small_frames():
         assert r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0
         assert r["build_s"] >= 0 and r["gather_s"] > 0 and r["one_thread"]["value"] > 0
         assert "accelerator" in r["sample"]
+
+
+def test_rel_mse_equals_the_references_own_metric_code():
+    """gvpm_amd/metrics.rel_mse against the REFERENCE's metric() itself (scripts/rgbe/sources/imageerrors.h compiled into
+    oracle/_ref by oracle/Makefile.ref): the reference sums floats, per pixel and over the image -- equal to that rounding."""
+    import numpy as np
+    import pytest
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from gvpm_amd import metrics
+    if not os.path.exists(O.REF_IMAGEERRORS):
+        pytest.skip("oracle/_ref not built (needs the reference tree)")
+    rng = np.random.default_rng(11)
+    for (H, W, noise) in ((1, 1, 0.1), (7, 5, 0.05), (64, 48, 0.01), (32, 32, 0.0)):
+        ref = rng.random((H, W, 3)) * 3
+        img = ref + rng.normal(0, noise, ref.shape)
+        a, b = metrics.rel_mse(img, ref), O.ref_image_metric(img, ref, "relmse")
+        assert abs(a - b) <= 2e-5 * max(a, 1e-30) + 1e-12, (H, W, a, b)
+    # and the plain MSE of the same header against the L2 figure of the parity bar: mse = 3 * mean((img - ref)^2)
+    ref = rng.random((16, 12, 3))
+    img = ref + rng.normal(0, 0.02, ref.shape)
+    assert abs(O.ref_image_metric(img, ref, "mse") - 3 * ((img - ref) ** 2).mean()) < 1e-6
