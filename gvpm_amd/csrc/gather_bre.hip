@@ -505,7 +505,7 @@ __device__ __forceinline__ void waveLdsSync() {
 // launch were dispatch-bound (2.4 resident waves per SIMD on average where registers and LDS allow 5)
 constexpr int TRAV_WPB = GVPM_TRAV_WPB;
 #ifndef GVPM_TRAV_MINW
-#define GVPM_TRAV_MINW 3
+#define GVPM_TRAV_MINW 4  // (128 VGPRs; 3 -- 147 -- is 2 % slower on the pipelined C2 step, 5 -- 96, 60 spilled -- equal)
 #endif
 // the staged photons, one array per component: a lane tests FOUR consecutive photons against its beam, read with four
 // ds_read_b128 issued together, two photons per packed-fp32 instruction
@@ -513,6 +513,7 @@ struct alignas(16) TravLds {
   float x[STAGE], y[STAGE], z[STAGE];
   uint32_t bits[STAGE];
   uint32_t stageIdx[STAGE];
+  float4 cyl[3];  // the tile's cylinder: {axis point, R^2} {axis direction, s0} {s1}
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -581,7 +582,64 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
     const float Emax = 1.25e-6f * wv1;
     const float thrD2 = beamValid ? r2f + (4.f * r * Emax + r2f * 2e-6f) : -1.f;
     const float thrLo = mint - Emax, thrHi = maxt + 2.f * r;
-    uint32_t staged = 0;  // wave-uniform
+    // The tile's rays in one cylinder (round 3): axis = the mean ray, radius = how far the (fattened) segment of any ray
+    // strays from it -- the distance from the points of a segment to a line is convex along the segment, so its end
+    // points bound it.  A photon one of the rays accepts lies within the band's radius of a point of that ray's segment,
+    // hence within rho + that radius of the axis and within the segments' axial range, padded alike.  The box of a slab
+    // step holds ~3 x the photons of that cylinder (the box is the cells the footprints touch); a staged window is
+    // compacted to the cylinder's photons before the 16-beam pass tests it (GVPM_TRAV_PREFILTER=0: as staged).
+    const bool prefilter = !(a.cfg.reserved[0] & 128);
+    f3 axO = mk3(0.f), axD = mk3(0.f, 0.f, 1.f);
+    float cylR2 = INFINITY, cylS0 = -INFINITY, cylS1 = INFINITY;
+    if (prefilter) {
+      const float nv = (float)__popcll(__ballot(beamValid));
+      f3 so = beamValid ? base.o : mk3(0.f), sd = beamValid ? base.d : mk3(0.f);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        so.x += __shfl_xor(so.x, o, 64); so.y += __shfl_xor(so.y, o, 64); so.z += __shfl_xor(so.z, o, 64);
+        sd.x += __shfl_xor(sd.x, o, 64); sd.y += __shfl_xor(sd.y, o, 64); sd.z += __shfl_xor(sd.z, o, 64);
+      }
+      const float dl = fsqrt(dot(sd, sd));
+      if (nv > 0.f && dl > 0.5f * nv) {  // (rays of one tile look one way; otherwise no cylinder: everything passes)
+        axO = so * frcp(nv);
+        axD = sd * frcp(dl);
+        float rho2 = 0.f, s0 = INFINITY, s1 = -INFINITY;
+        if (beamValid) {
+          // the range of ray parameters a photon's foot point can have: [thrLo, thrHi], fattened
+          const float ta = fminf(thrLo, 0.f) - r, tb = thrHi + r;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const f3 q = (base.o - axO) + base.d * (e ? tb : ta);
+            const float sq = dot(q, axD);
+            const f3 pq = q - axD * sq;
+            rho2 = fmaxf(rho2, dot(pq, pq));
+            s0 = fminf(s0, sq);
+            s1 = fmaxf(s1, sq);
+          }
+        }
+        const float rho = fsqrt(wave_max(rho2));
+        s0 = wave_min(s0);
+        s1 = wave_max(s1);
+        // radius a photon may have from its ray's foot point: sqrt(thrD2) <= r (1 + 1e-6) + 2 Emax; fp32 slack of this
+        // test itself: a few ulps of the coordinates involved
+        const float slack = 4e-6f * (fabsf(axO.x) + fabsf(axO.y) + fabsf(axO.z) + fabsf(s0) + fabsf(s1) + rho + r) + 2.f * Emax;
+        const float R = (r + rho) * 1.0001f + slack;
+        cylR2 = R * R;
+        cylS0 = s0 - r * 1.0001f - slack;
+        cylS1 = s1 + r * 1.0001f + slack;
+      }
+      // (nine wave-uniform numbers used once per staged window: parked in LDS rather than held in registers beside the
+      // test loop -- the kernel's register budget is what lets the build's kernels run beside it)
+      waveLdsSync();
+      if (lane == 0) {
+        s.cyl[0] = make_float4(axO.x, axO.y, axO.z, cylR2);
+        s.cyl[1] = make_float4(axD.x, axD.y, axD.z, cylS0);
+        s.cyl[2] = make_float4(cylS1, 0.f, 0.f, 0.f);
+      }
+      waveLdsSync();
+    }
+    const bool haveCyl = prefilter && __builtin_amdgcn_readfirstlane((int)(cylR2 < INFINITY));
+    unsigned long long tested = 0;  // wave-uniform
     auto putStage = [&](uint32_t k, float4 v, uint32_t gi) {
       s.x[k] = v.x;
       s.y[k] = v.y;
@@ -649,15 +707,44 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
               putStage(i - win, a.hot[gi], gi);
             }
           }
-          // the slots between nst and the next multiple of 16 hold photons no beam can meet
-          if (lane < 16 && nst + (uint32_t)lane < ((nst + 15u) & ~15u)) s.x[nst + lane] = 3.0e38f;
           waveLdsSync();
-          staged += nst;
+          uint32_t nkeep = nst;
+          if (haveCyl) {
+            // compaction in place, 64 entries a round: a round's survivors go to slots at or below the round's own (every
+            // lane holds its entry in registers before anything is written; later rounds' slots are not touched)
+            nkeep = 0;
+            const float4 c0 = s.cyl[0], c1 = s.cyl[1];
+            const float cS1 = s.cyl[2].x;
+            const f3 axO = mk3(c0.x, c0.y, c0.z), axD = mk3(c1.x, c1.y, c1.z);
+            const float cylR2 = c0.w, cylS0 = c1.w, cylS1 = cS1;
+            for (uint32_t k0 = 0; k0 < nst; k0 += 64u) {
+              const uint32_t k = k0 + (uint32_t)lane;
+              const bool live = k < nst;
+              const float px = live ? s.x[k] : 0.f, py = live ? s.y[k] : 0.f, pz = live ? s.z[k] : 0.f;
+              const uint32_t pb = live ? s.bits[k] : 0u, pi = live ? s.stageIdx[k] : 0u;
+              const f3 wv = mk3(px, py, pz) - axO;
+              const float sq = dot(wv, axD);
+              const float d2 = dot(wv, wv) - sq * sq;
+              const bool keep = live && d2 < cylR2 && sq > cylS0 && sq < cylS1 && (pb & 0x40u);
+              const unsigned long long m = __ballot(keep);
+              waveLdsSync();
+              if (keep) {
+                const uint32_t dst = nkeep + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                s.x[dst] = px; s.y[dst] = py; s.z[dst] = pz; s.bits[dst] = pb; s.stageIdx[dst] = pi;
+              }
+              nkeep += (uint32_t)__popcll(m);
+            }
+            waveLdsSync();
+          }
+          // the slots between the last photon and the next multiple of 16 hold photons no beam can meet
+          if (lane < 16 && nkeep + (uint32_t)lane < ((nkeep + 15u) & ~15u)) s.x[nkeep + lane] = 3.0e38f;
+          waveLdsSync();
+          tested += nkeep;
           // groups of G * LPB staged photons: sub-lane `sub` of a beam takes G consecutive ones.  A branch-free pass
           // marks the candidates, then the wave appends them one per lane and round.
           constexpr uint32_t G = 4;
           static_assert(STAGE % (G * LPB) == 0 && G == 4, "a lane reads four consecutive photons with one b128 per component");
-          for (uint32_t jb = 0; jb < nst; jb += G * LPB) {  // wave-uniform trip count: the append below is collective
+          for (uint32_t jb = 0; jb < nkeep; jb += G * LPB) {  // wave-uniform trip count: the append below is collective
             const uint32_t j0 = jb + (uint32_t)sub * G;
             const float4 X = *reinterpret_cast<const float4 *>(&s.x[j0]);
             const float4 Y = *reinterpret_cast<const float4 *>(&s.y[j0]);
@@ -725,7 +812,7 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
       }
     }
     if (sub == 0) pairCnt[(size_t)it * B + b] = (uint32_t)b < nb ? min(mine, cap) : 0u;
-    nCand += (unsigned long long)staged * nb;
+    nCand += tested * nb;  // (pairs the 16-beam pass tested)
   }
   {
 #pragma unroll

@@ -88,6 +88,8 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   // development switch (perf attribution only): bit 0 = skip the evaluations, keep the traversal
   h->cfg.reserved[0] = 0;
   if (const char *e = getenv("GVPM_DEBUG_FLAGS")) h->cfg.reserved[0] = atoi(e);
+  if (const char *e = getenv("GVPM_TRAV_PREFILTER"))
+    if (!atoi(e)) h->cfg.reserved[0] |= 128;  // (gather_bre.hip: traverse_bre_kernel's tile cylinder)
   if (const char *e = getenv("GVPM_RECORD_PREFETCH")) h->cfg.reserved[0] |= atoi(e) ? 64 : 32;  // (gather_bre.hip: launch_evaluate_bre)
   h->cfg.reserved[1] = 0;  // slab layers per step (0 = default)
   if (const char *e = getenv("GVPM_SLAB_LAYERS")) h->cfg.reserved[1] = atoi(e);
