@@ -1377,6 +1377,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
     const uint32_t fmask = 0x40u | (pathSet ? (1u << GVPM_HOT_PARITY_BIT) : 0u);
     const uint32_t fwant = 0x40u | (pathSet ? (pixParity << GVPM_HOT_PARITY_BIT) : 0u);
     const int dmaxB = maxDepth - edge;
+    // the tile's bounding cylinder (tile_walk.h tileCylinder; round 3): sub-beams whose centre lies outside it are not
+    // staged at all -- the box of a slab step holds about three times the centres any of the tile's rays can accept
+    const bool prefilter = !(a.cfg.reserved[0] & 128);
+    TileCyl cyl;
+    cyl.ok = false;
+    if (prefilter) cyl = tileCylinder(base, beamValid, fminf(thrLo, 0.f) - rT, thrHi + rT, rT * 1.0005f, 2.f * eT);
+    const bool haveCyl = prefilter && __builtin_amdgcn_readfirstlane((int)cyl.ok);
     uint32_t qHead = 0, qCount = 0;
     auto emit = [&](uint32_t n) {  // n <= 64 pairs of the ring -> one block of 64 in the global list
       if (resLeft == 0u) {
@@ -1453,7 +1460,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
         for (uint32_t win = 0; win < total; win += BSTAGE) {
           if (winIdx++ % parts != part) continue;
           __syncthreads();
-          const uint32_t nst = min((uint32_t)BSTAGE, total - win);
+          const uint32_t nwin = min((uint32_t)BSTAGE, total - win);
+          uint32_t nst = 0;  // staged so far (wave-uniform): the window's entries inside the tile's cylinder, compacted
           // Staging: entry k of the window is element win + k of the concatenated ranges.  Consecutive LANES take
           // consecutive entries (the range an entry falls in is found by a 6-step search over the exclusive scan,
           // through ds_bpermute), so a load instruction reads a few contiguous runs of records instead of 64
@@ -1470,16 +1478,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
               if (v <= e) rr = cand;
             }
             const uint32_t rStart = (uint32_t)__shfl((int)start, (int)rr, 64), rExcl = (uint32_t)__shfl((int)excl, (int)rr, 64);
-            if (k < nst) {
-              const uint32_t gi = rStart + (e - rExcl);
-              const float4 c0 = a.hot[2 * (size_t)gi];
-              s.st0[k] = c0;
-              s.st1[k] = a.hot[2 * (size_t)gi + 1];
-              s.sx[k] = c0.x;
-              s.sy[k] = c0.y;
-              s.sz[k] = c0.z;
-              s.stF[k] = hotFlags[gi];
+            const uint32_t gi = rStart + (e - rExcl);
+            float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool keep = k < nwin;
+            if (keep) {
+              c0 = a.hot[2 * (size_t)gi];
+              keep = !haveCyl || insideCylinder(cyl, mk3(c0.x, c0.y, c0.z));
             }
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+              const uint32_t dst = nst + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+              s.st0[dst] = c0;
+              s.st1[dst] = a.hot[2 * (size_t)gi + 1];
+              s.sx[dst] = c0.x;
+              s.sy[dst] = c0.y;
+              s.sz[dst] = c0.z;
+              s.stF[dst] = hotFlags[gi];
+            }
+            nst += (uint32_t)__popcll(km);
           }
           // the slots between nst and the next multiple of 16 hold centres no ray can meet
           if (lane < 16 && nst + (uint32_t)lane < ((nst + 15u) & ~15u)) s.sx[nst + lane] = 3.0e38f;

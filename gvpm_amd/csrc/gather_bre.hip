@@ -582,63 +582,26 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
     const float Emax = 1.25e-6f * wv1;
     const float thrD2 = beamValid ? r2f + (4.f * r * Emax + r2f * 2e-6f) : -1.f;
     const float thrLo = mint - Emax, thrHi = maxt + 2.f * r;
-    // The tile's rays in one cylinder (round 3): axis = the mean ray, radius = how far the (fattened) segment of any ray
-    // strays from it -- the distance from the points of a segment to a line is convex along the segment, so its end
-    // points bound it.  A photon one of the rays accepts lies within the band's radius of a point of that ray's segment,
-    // hence within rho + that radius of the axis and within the segments' axial range, padded alike.  The box of a slab
-    // step holds ~3 x the photons of that cylinder (the box is the cells the footprints touch); a staged window is
-    // compacted to the cylinder's photons before the 16-beam pass tests it (GVPM_TRAV_PREFILTER=0: as staged).
+    // The box of a slab step holds ~3 x the photons of the tile's bounding cylinder (tile_walk.h tileCylinder): a staged
+    // window is compacted to the cylinder's photons before the 16-beam pass tests it (GVPM_TRAV_PREFILTER=0: as staged).
     const bool prefilter = !(a.cfg.reserved[0] & 128);
-    f3 axO = mk3(0.f), axD = mk3(0.f, 0.f, 1.f);
-    float cylR2 = INFINITY, cylS0 = -INFINITY, cylS1 = INFINITY;
+    bool cylOk = false;
     if (prefilter) {
-      const float nv = (float)__popcll(__ballot(beamValid));
-      f3 so = beamValid ? base.o : mk3(0.f), sd = beamValid ? base.d : mk3(0.f);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        so.x += __shfl_xor(so.x, o, 64); so.y += __shfl_xor(so.y, o, 64); so.z += __shfl_xor(so.z, o, 64);
-        sd.x += __shfl_xor(sd.x, o, 64); sd.y += __shfl_xor(sd.y, o, 64); sd.z += __shfl_xor(sd.z, o, 64);
-      }
-      const float dl = fsqrt(dot(sd, sd));
-      if (nv > 0.f && dl > 0.5f * nv) {  // (rays of one tile look one way; otherwise no cylinder: everything passes)
-        axO = so * frcp(nv);
-        axD = sd * frcp(dl);
-        float rho2 = 0.f, s0 = INFINITY, s1 = -INFINITY;
-        if (beamValid) {
-          // the range of ray parameters a photon's foot point can have: [thrLo, thrHi], fattened
-          const float ta = fminf(thrLo, 0.f) - r, tb = thrHi + r;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const f3 q = (base.o - axO) + base.d * (e ? tb : ta);
-            const float sq = dot(q, axD);
-            const f3 pq = q - axD * sq;
-            rho2 = fmaxf(rho2, dot(pq, pq));
-            s0 = fminf(s0, sq);
-            s1 = fmaxf(s1, sq);
-          }
-        }
-        const float rho = fsqrt(wave_max(rho2));
-        s0 = wave_min(s0);
-        s1 = wave_max(s1);
-        // radius a photon may have from its ray's foot point: sqrt(thrD2) <= r (1 + 1e-6) + 2 Emax; fp32 slack of this
-        // test itself: a few ulps of the coordinates involved
-        const float slack = 4e-6f * (fabsf(axO.x) + fabsf(axO.y) + fabsf(axO.z) + fabsf(s0) + fabsf(s1) + rho + r) + 2.f * Emax;
-        const float R = (r + rho) * 1.0001f + slack;
-        cylR2 = R * R;
-        cylS0 = s0 - r * 1.0001f - slack;
-        cylS1 = s1 + r * 1.0001f + slack;
-      }
+      // foot points of accepted photons have ray parameters in [thrLo, thrHi]; an accepted photon is within
+      // sqrt(thrD2) <= r (1 + 1e-6) + 2 Emax of its foot point
+      const TileCyl c = tileCylinder(base, beamValid, fminf(thrLo, 0.f) - r, thrHi + r, r, 2.f * Emax);
+      cylOk = c.ok;
       // (nine wave-uniform numbers used once per staged window: parked in LDS rather than held in registers beside the
       // test loop -- the kernel's register budget is what lets the build's kernels run beside it)
       waveLdsSync();
       if (lane == 0) {
-        s.cyl[0] = make_float4(axO.x, axO.y, axO.z, cylR2);
-        s.cyl[1] = make_float4(axD.x, axD.y, axD.z, cylS0);
-        s.cyl[2] = make_float4(cylS1, 0.f, 0.f, 0.f);
+        s.cyl[0] = make_float4(c.o.x, c.o.y, c.o.z, c.R2);
+        s.cyl[1] = make_float4(c.d.x, c.d.y, c.d.z, c.s0);
+        s.cyl[2] = make_float4(c.s1, 0.f, 0.f, 0.f);
       }
       waveLdsSync();
     }
-    const bool haveCyl = prefilter && __builtin_amdgcn_readfirstlane((int)(cylR2 < INFINITY));
+    const bool haveCyl = prefilter && __builtin_amdgcn_readfirstlane((int)cylOk);
     unsigned long long tested = 0;  // wave-uniform
     auto putStage = [&](uint32_t k, float4 v, uint32_t gi) {
       s.x[k] = v.x;

@@ -422,6 +422,10 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   fillArgs(h, a, r);
   a.iter = h->accum.p;
   a.iterScale = 1.0f / (float)nb_paths;
+  // slab thickness along y / z: 8 layers with the 1.5-radius cells of maps up to 2 M photons (round 3, with the traversal's
+  // cylinder filter: -4 % on the C2 step, three alternating runs on one box), 6 with the one-radius cells above (a rank's
+  // share of C4: 2.9 ms against 3.1)
+  if (!a.cfg.reserved[1] && h->cellScale <= 0.f && h->nph <= 2000000u) a.cfg.reserved[1] = 8;
   itemCap = plan_items_capacity(h->nsets, h->bs->ntiles, h->beamsPerWave);
   HIP_TRY(h, h->bs->items.ensure(itemCap));
   HIP_TRY(h, h->bs->itemOff.ensure(itemCap));

@@ -242,6 +242,64 @@ __device__ __forceinline__ void tileSetupFrom(const GatherArgs &a, const RayReg 
   w.K = (A == 0) ? (a.cfg.reserved[2] ? a.cfg.reserved[2] : 8) : (a.cfg.reserved[1] ? a.cfg.reserved[1] : 6);
 }
 
+// The tile's rays in one cylinder: axis = the mean ray, radius = how far the segment [tLo, tHi] of any ray strays from it
+// -- the distance from the points of a segment to a line is convex along the segment, so its end points bound it.  A
+// point within `rad` of some ray's segment then lies within rho + rad of the axis and inside the segments' axial range
+// padded by rad.  `slack`: the caller's bound on the fp32 error of ITS test of that point; the error of the cylinder test
+// itself is added here.  ok == false (no valid ray, or rays that look every way): no cylinder, everything passes.
+struct TileCyl {
+  f3 o, d;
+  float R2, s0, s1;
+  bool ok;
+};
+__device__ __forceinline__ TileCyl tileCylinder(const RayReg &base, bool valid, float tLo, float tHi, float rad, float slack) {
+  TileCyl c;
+  c.o = mk3(0.f);
+  c.d = mk3(0.f, 0.f, 1.f);
+  c.R2 = INFINITY;
+  c.s0 = -INFINITY;
+  c.s1 = INFINITY;
+  c.ok = false;
+  const float nv = (float)__popcll(__ballot(valid));
+  f3 so = valid ? base.o : mk3(0.f), sd = valid ? base.d : mk3(0.f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    so.x += __shfl_xor(so.x, o, 64); so.y += __shfl_xor(so.y, o, 64); so.z += __shfl_xor(so.z, o, 64);
+    sd.x += __shfl_xor(sd.x, o, 64); sd.y += __shfl_xor(sd.y, o, 64); sd.z += __shfl_xor(sd.z, o, 64);
+  }
+  const float dl = fsqrt(dot(sd, sd));
+  if (!(nv > 0.f && dl > 0.5f * nv)) return c;
+  c.o = so * frcp(nv);
+  c.d = sd * frcp(dl);
+  float rho2 = 0.f, s0 = INFINITY, s1 = -INFINITY;
+  if (valid) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const f3 q = (base.o - c.o) + base.d * (e ? tHi : tLo);
+      const float sq = dot(q, c.d);
+      const f3 pq = q - c.d * sq;
+      rho2 = fmaxf(rho2, dot(pq, pq));
+      s0 = fminf(s0, sq);
+      s1 = fmaxf(s1, sq);
+    }
+  }
+  const float rho = fsqrt(wave_max(rho2));
+  s0 = wave_min(s0);
+  s1 = wave_max(s1);
+  const float own = 4e-6f * (fabsf(c.o.x) + fabsf(c.o.y) + fabsf(c.o.z) + fabsf(s0) + fabsf(s1) + rho + rad) + slack;
+  const float R = (rad + rho) * 1.0001f + own;
+  c.R2 = R * R;
+  c.s0 = s0 - rad * 1.0001f - own;
+  c.s1 = s1 + rad * 1.0001f + own;
+  c.ok = true;
+  return c;
+}
+__device__ __forceinline__ bool insideCylinder(const TileCyl &c, f3 p) {
+  const f3 wv = p - c.o;
+  const float sq = dot(wv, c.d);
+  return dot(wv, wv) - sq * sq < c.R2 && sq > c.s0 && sq < c.s1;
+}
+
 struct CellBox {
   int bx0, bx1, by0, by1, bz0, bz1;
 };
