@@ -102,3 +102,28 @@ def test_empty_and_unknown_material():
         lib = hip.lib()
         ctx._check(lib.gvpm_upload_photons_packed(ctx._h, None, 5))
     ctx.close()
+
+
+def test_packed_records_feed_g_vpm_too():
+    """the packed photon / beam-set uploads fill the same staging slots as the SoA ones: G-VPM on packed records evaluates
+    what the oracle evaluates on the unpacked arrays"""
+    from test_oracle_vpm import make_vpm_case
+    c = make_vpm_case("cbox_hg", 32, 28, 40000, 5.0, nb=10)
+    t = hip.MaterialTable()
+    pk = hip.pack_photons(c.ph, t)
+    unp = hip.unpack_photons(pk, t)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_materials(t)
+    ctx.upload_photons_packed(pk)
+    ctx.upload_camera_beams_packed(hip.pack_camera_beams(c.rays))
+    ctx.upload_vpm_samples(c.samples)
+    ctx.gather(1, c.nb)
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    ref, sv, nv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, unp, c.rays, c.samples, 64, use_accel=False)
+    assert st["evaluations"] == cnt["evaluations"] > 5000
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert np.sqrt(((acc - ref) ** 2).mean()) / lum < 1e-4
