@@ -117,3 +117,34 @@ def test_beams_that_are_no_bundle_keep_the_3d_grid():
     for k in COUNTERS:
         assert sb[k] == s3[k]
     assert np.abs(ab.astype(np.float64) - a3).max() <= 2e-4 * np.abs(a3).max()
+
+
+def test_c2_size_bundle_cells_and_packed_records_give_the_plain_runs_counters():
+    """BASELINE configs[1] at its size (512x512, 1 M photons): the ray-bundle cells and the packed upload records only
+    change HOW candidates are found and how the inputs travel -- all four counters equal the plain run's, the sums to
+    the order of their atomics / the records' stated losses."""
+    c = cases.make_case("cbox", 512, 512, 1000000, 1.0)
+    a0, s0, k0 = run(c, False)
+    a1, s1, k1 = run(c, True)
+    assert k0 == [0] and k1 == [1] and s0["evaluations"] > 10_000_000
+    for k in COUNTERS:
+        assert s1[k] == s0[k], (k, s1, s0)
+    assert s1["candidates"] != s0["candidates"]
+    lum = max(a0[..., 0:3].mean(), 1e-30)
+    assert np.sqrt(((a1.astype(np.float64) - a0) ** 2).mean()) / lum < 1e-6
+    t = hip.MaterialTable()
+    pk = hip.pack_photons(c.ph, t)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_materials(t)
+    ctx.upload_photons_packed(pk)
+    ctx.upload_camera_beams_packed(hip.pack_camera_beams(c.rays))
+    ctx.gather(1, c.nb)
+    a2 = ctx.download_accum().astype(np.float64)
+    s2 = ctx.stats()
+    ctx.close()
+    assert s2["evaluations"] == s0["evaluations"]
+    for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert abs(s2[k] - s0[k]) <= max(2, 1e-5 * s0[k]), (k, s2[k], s0[k])
+    assert np.sqrt(((a2 - a0) ** 2).mean()) / lum < 2e-5
