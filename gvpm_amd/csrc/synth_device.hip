@@ -50,7 +50,8 @@ struct PhotonOut {
   float *endN;
 };
 
-__device__ __forceinline__ void walkAndFlatten(const SceneView &sc, int iteration, uint64_t idx, bool beams, RecList &recs,
+template <class RL>
+__device__ __forceinline__ void walkAndFlatten(const SceneView &sc, int iteration, uint64_t idx, bool beams, RL &recs,
                                                bool &counted) {
   Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32));
   LPath path;
@@ -60,11 +61,55 @@ __device__ __forceinline__ void walkAndFlatten(const SceneView &sc, int iteratio
   else flattenPath(sc, path, recs);
 }
 
-__global__ __launch_bounds__(64) void synth_count_kernel(SceneView sc, int iteration, uint64_t base, uint32_t m, int beams,
-                                                         uint32_t *counts, uint32_t *counted, uint32_t *nonEmpty) {
+// the sinks of flattenPath / flattenBeams (synth_core.h): the count pass keeps a number, the write pass stores each record
+// where it belongs -- neither holds the path's records in (scratch) memory
+struct CountSink {
+  int n;
+  __device__ CountSink() : n(0) {}
+  __device__ void clear() { n = 0; }
+  __device__ bool empty() const { return n == 0; }
+  __device__ void push_back(const PhotonRec &) {
+    if (n < GVPM_SYNTH_MAXV) ++n;
+  }
+};
+// The walk runs ONCE (round 3; it ran twice: count, then write): its records are parked at a slot that depends on the path
+// alone -- path k, record n at (k * stride + n) -- and a copy kernel moves them to their place in the output once the
+// scans have said where that is.  32 words a record; with 288 GB of HBM the 1-2 GB of parking space are affordable, a
+// second walk of 0.85 M light paths in fp64 (1.5 ms) was not.
+constexpr int PARK_WORDS = 32;
+struct ParkSink {
+  float *park;  // this path's slots
+  int n, stride;
+  __device__ void clear() { n = 0; }
+  __device__ bool empty() const { return n == 0; }
+  __device__ void push_back(const PhotonRec &r) {
+    if (n >= stride) return;
+    float *d = park + (size_t)n * PARK_WORDS;
+    ++n;
+    const V3 v[9] = {r.pos, r.wi, r.flux, r.parentPos, r.parentN, r.prefixW, r.parentScat, r.parentWi, r.endN};
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      d[3 * a] = (float)v[a].x;
+      d[3 * a + 1] = (float)v[a].y;
+      d[3 * a + 2] = (float)v[a].z;
+    }
+    d[27] = r.parentPdf;
+    d[28] = r.edgePdf;
+    d[29] = r.parentRR;
+    d[30] = r.parentG;
+    d[31] = __uint_as_float(r.flags);
+  }
+};
+
+__global__ __launch_bounds__(64) void synth_walk_kernel(SceneView sc, int iteration, uint64_t base, uint32_t m, int beams,
+                                                        float *park, int stride, uint32_t *counts, uint32_t *counted,
+                                                        uint32_t *nonEmpty) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
-  RecList recs;
+  ParkSink recs;
+  recs.park = park + (size_t)k * stride * PARK_WORDS;
+  recs.stride = stride;
+  recs.n = 0;
   bool c;
   walkAndFlatten(sc, iteration, base + k, beams != 0, recs, c);
   counts[k] = (uint32_t)recs.n;
@@ -95,39 +140,33 @@ __global__ void synth_stop_kernel(const uint32_t *counts, const uint32_t *offs, 
   ctl[6] = ctl[2] + neOffs[last] + nonEmpty[last];
 }
 
-__global__ __launch_bounds__(64) void synth_write_kernel(SceneView sc, int iteration, uint64_t base, int beams,
-                                                         const uint32_t *offs, const uint32_t *neOffs, const uint32_t *ctl,
-                                                         uint64_t capacity, PhotonOut o) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ctl[3]) return;
-  RecList recs;
-  bool c;
-  walkAndFlatten(sc, iteration, base + k, beams != 0, recs, c);
-  const uint64_t at = (uint64_t)ctl[0] + offs[k];
-  const uint32_t pathId = ctl[2] + neOffs[k];
-  for (int q = 0; q < recs.n; ++q) {
-    const uint64_t i = at + (uint64_t)q;
-    if (i >= capacity) break;
-    const PhotonRec &r = recs.r[q];
-    const V3 v[8] = {r.pos, r.wi, r.flux, r.parentPos, r.parentN, r.prefixW, r.parentScat, r.parentWi};
+// one lane per (path, record slot): the parked records of the paths the host loop would have processed -> the output
+__global__ __launch_bounds__(256) void synth_place_kernel(const float *__restrict__ park, int stride, const uint32_t *__restrict__ counts,
+                                                          const uint32_t *__restrict__ offs, const uint32_t *__restrict__ neOffs,
+                                                          const uint32_t *__restrict__ ctl, uint32_t m, uint64_t capacity, PhotonOut o) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = t / (uint32_t)stride, q = t % (uint32_t)stride;
+  if (k >= m || k >= ctl[3] || q >= counts[k]) return;
+  const uint64_t i = (uint64_t)ctl[0] + offs[k] + q;
+  if (i >= capacity) return;
+  const float *d = park + ((size_t)k * stride + q) * PARK_WORDS;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      o.v3[a][3 * i] = (float)v[a].x;
-      o.v3[a][3 * i + 1] = (float)v[a].y;
-      o.v3[a][3 * i + 2] = (float)v[a].z;
-    }
-    o.f1[0][i] = r.parentPdf;
-    o.f1[1][i] = r.edgePdf;
-    o.f1[2][i] = r.parentRR;
-    o.f1[3][i] = r.parentG;
-    o.flags[i] = r.flags;
-    o.pathId[i] = pathId;
-    if (o.endN) {
-      o.endN[3 * i] = (float)r.endN.x;
-      o.endN[3 * i + 1] = (float)r.endN.y;
-      o.endN[3 * i + 2] = (float)r.endN.z;
-    }
+  for (int a = 0; a < 8; ++a) {
+    o.v3[a][3 * i] = d[3 * a];
+    o.v3[a][3 * i + 1] = d[3 * a + 1];
+    o.v3[a][3 * i + 2] = d[3 * a + 2];
   }
+  if (o.endN) {
+    o.endN[3 * i] = d[24];
+    o.endN[3 * i + 1] = d[25];
+    o.endN[3 * i + 2] = d[26];
+  }
+  o.f1[0][i] = d[27];
+  o.f1[1][i] = d[28];
+  o.f1[2][i] = d[29];
+  o.f1[3][i] = d[30];
+  o.flags[i] = __float_as_uint(d[31]);
+  o.pathId[i] = ctl[2] + neOffs[k];
 }
 
 // ---- camera beams ----
@@ -177,6 +216,7 @@ struct gvpm_devgen {
   Buf<SynthTri> tris;
   Buf<SynthMat> mats;
   Buf<uint32_t> counts, counted, nonEmpty, offs, countedOffs, neOffs, ctl;
+  Buf<float> park;  // parked records of a batch's paths (synth_walk_kernel)
   // Outputs are BORROWED by the gather context (gvpm_upload_*_dev), whose kernels of up to three consecutive steps are
   // in flight: three output sets per kind, used in turn, so that a call never writes what the two steps before it read.
   struct PhotonOut {
@@ -267,7 +307,7 @@ int gvpm_devgen_destroy(gvpm_devgen *g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   g->tris.release(); g->mats.release();
   g->counts.release(); g->counted.release(); g->nonEmpty.release(); g->offs.release(); g->countedOffs.release();
-  g->neOffs.release(); g->ctl.release();
+  g->neOffs.release(); g->ctl.release(); g->park.release();
   for (auto &o : g->pout) {
     for (auto &b : o.f3) b.release();
     for (auto &b : o.f1) b.release();
@@ -302,6 +342,9 @@ static int shootCommon(gvpm_devgen *g, int iteration, uint64_t capacity, int bea
   for (auto *b : scratch) SY_TRY(b->ensure((size_t)m + 1));
   SY_TRY(g->ctl.ensure(8));
   SY_TRY(hipMemsetAsync(g->ctl.p, 0, 8 * sizeof(uint32_t), s));
+  // a path stores at most one record per vertex beyond the emitter sample
+  const int stride = std::max(1, std::min(GVPM_SYNTH_MAXV, g->view.maxDepth));
+  SY_TRY(g->park.ensure((size_t)m * stride * PARK_WORDS + 64));
   PhotonOut o;
   for (int a = 0; a < 8; ++a) o.v3[a] = g->po().f3[a].p;
   for (int a = 0; a < 4; ++a) o.f1[a] = g->po().f1[a].p;
@@ -312,15 +355,18 @@ static int shootCommon(gvpm_devgen *g, int iteration, uint64_t capacity, int bea
   for (int batch = 0; stored < capacity; ++batch) {
     if (batch > 4096) return GVPM_ERR_STATE;  // a scene that stores nothing
     const unsigned nb = (m + 63) / 64;
-    hipLaunchKernelGGL(synth_count_kernel, dim3(nb), dim3(64), 0, s, g->view, iteration, base, m, beams, g->counts.p,
-                       g->counted.p, g->nonEmpty.p);
+    hipLaunchKernelGGL(synth_walk_kernel, dim3(nb), dim3(64), 0, s, g->view, iteration, base, m, beams, g->park.p, stride,
+                       g->counts.p, g->counted.p, g->nonEmpty.p);
     SY_TRY(exclusiveSumU32(g->scanTmp, g->counts.p, g->offs.p, m, s));
     SY_TRY(exclusiveSumU32(g->scanTmp, g->counted.p, g->countedOffs.p, m, s));
     SY_TRY(exclusiveSumU32(g->scanTmp, g->nonEmpty.p, g->neOffs.p, m, s));
     hipLaunchKernelGGL(synth_stop_kernel, dim3(1), dim3(1), 0, s, g->counts.p, g->offs.p, g->countedOffs.p, g->counted.p,
                        g->neOffs.p, g->nonEmpty.p, m, capacity, g->ctl.p);
-    hipLaunchKernelGGL(synth_write_kernel, dim3(nb), dim3(64), 0, s, g->view, iteration, base, beams, g->offs.p,
-                       g->neOffs.p, g->ctl.p, capacity, o);
+    {
+      const uint64_t slots = (uint64_t)m * (uint64_t)stride;
+      hipLaunchKernelGGL(synth_place_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, g->park.p, stride, g->counts.p,
+                         g->offs.p, g->neOffs.p, g->ctl.p, m, capacity, o);
+    }
     uint32_t c[8];
     SY_TRY(hipMemcpyAsync(c, g->ctl.p, sizeof(c), hipMemcpyDeviceToHost, s));
     SY_TRY(hipStreamSynchronize(s));

@@ -356,7 +356,9 @@ GVPM_HD inline void fillParent(const SceneView &sc, const LPath &path, size_t ip
 // LTBeamMap::tryAppendLT + LTPhotonBeam (gvpm/gvpm_beams.h:18-84) without capacity / pathID bookkeeping.
 // Returns false when the path had medium edges but all of them were culled by the camera sphere
 // (tryAppendLT returns -1: the path is then not counted as shot, gvpm_proc.cpp:330-336).
-GVPM_HD inline bool flattenBeams(const SceneView &sc, const LPath &path, RecList &recs) {
+// (RL: RecList, or any sink with clear() / push_back(const PhotonRec &) / empty() -- the device generator counts or writes
+// straight to its output arrays instead of parking up to 16 records of 236 bytes per lane, synth_device.hip)
+template <class RL> GVPM_HD inline bool flattenBeams(const SceneView &sc, const LPath &path, RL &recs) {
   recs.clear();
   for (size_t i = 1; i + 1 < path.size(); ++i)
     if (path[i].pdf == 0.0) return true;
@@ -385,7 +387,7 @@ GVPM_HD inline bool flattenBeams(const SceneView &sc, const LPath &path, RecList
 }
 
 // GPhotonMap::tryAppend (gvpm/gvpm_accel.h:119-199) without the capacity / pathID bookkeeping
-GVPM_HD inline void flattenPath(const SceneView &sc, const LPath &path, RecList &recs) {
+template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const LPath &path, RL &recs) {
   recs.clear();
   const size_t startIndex = (size_t)(sc.minDepth + 1 > 2 ? sc.minDepth + 1 : 2);
   // generatePath(): reject paths with a zero interior pdf (gvpm_proc.cpp:138-143)
