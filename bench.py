@@ -162,7 +162,8 @@ def main():
     inputs, keep = [], []
     host0 = []  # host copies of the first iterations' inputs: the CPU baseline's and the parity check's sample
     gen = hip.DeviceGenerator(sc, device=local_rank) if args.device_gen else None
-    n_host = max(args.cpu_iters if not args.no_cpu_baseline else 0, 2 if not args.no_upload_inclusive else 0, 1)
+    # (the PCIe-inclusive leg replays the timed region from host memory: it needs every distinct input set on the host)
+    n_host = max(args.cpu_iters if not args.no_cpu_baseline else 0, ndist if not args.no_upload_inclusive else 0, 1)
     for i in range(0 if gen else ndist):
         ph, nb = sc.shoot_photons(i + 1, photons)
         rays = sc.camera_beams_interleaved(i + 1, nshards, rank) if nshards > 1 else sc.camera_beams(i + 1)
@@ -302,7 +303,7 @@ def main():
             "stats": st,
         }
         if world == 1 and not gen and not args.no_upload_inclusive:
-            out["upload_inclusive"] = upload_inclusive(hip, p, m, tris, host0, K, local_rank)
+            out["upload_inclusive"] = upload_inclusive(hip, sc, p, m, tris, host0[:ndist], K, local_rank, evals / K)
         if world == 1 and not gen and not args.no_isolated:
             # the same kernel without the other streams' kernels beside it (a second handle with GVPM_PIPELINE=0,
             # a few untimed steps after the timed region): reported next to the live figure, which is the one `frac` uses
@@ -615,47 +616,53 @@ def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
     return out
 
 
-def upload_inclusive(hip, p, m, tris, host0, K, device):
+def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed):
     """The same K steps fed from HOST memory: pinned buffers, copies on the handle's copy stream, the copy of step N+1 in
     flight while step N runs.  Never `value`: the PCIe-inclusive rate SURVEY 8d asks to have beside it.  The headline of
-    this leg is the packed records (gvpm_upload_*_packed: 76 bytes a photon, 272 a beam set); the fp32 SoA entry points
-    (120 / 320 bytes) are timed beside them."""
+    this leg (`compact`) is what the shim uploads: packed photon records (76 bytes) + compact beam sets (60 bytes, rebuilt
+    from the sensor on the device; deeper edges as 272-byte records); beside it the round-3 records (`packed`: 76 / 272) and
+    the fp32 SoA entry points (120 / 320).  EVERY pass starts from gvpm_reset, so that its K gathers run at the radii of
+    the timed region (gatherBRE shrinks the radius on every call: without the reset a later pass measures a lighter
+    gather), and the headline cycles the same input sets as the timed region: its evaluation count must equal it."""
     table = hip.MaterialTable()
+    sensor = sc.sensor()
     # (the packed records first: on a box whose GPU-side NUMA node is short of free memory the later pinned blocks land on
     # the far node and are read at ~33 GB/s instead of 55 -- seen on one box of the pool, after many processes had run)
+    compact = [hip.PinnedPacked(ph, rays, table, sensor=sensor, jitter=sc.jitter(i + 1, rays)) for i, (ph, nb, rays) in enumerate(host0)]
     packed = [hip.PinnedPacked(ph, rays, table) for ph, nb, rays in host0[:2]]
-    sets = [(hip.PinnedPhotons(ph.n).fill(ph), nb, hip.PinnedRays(rays), pk) for (ph, nb, rays), pk in zip(host0[:2], packed)]
-    nbytes_soa = host0[0][0].n * 120 + host0[0][2].nbytes
-    nbytes = sets[0][3].nbytes
+    soa = [(hip.PinnedPhotons(ph.n).fill(ph), hip.PinnedRays(rays)) for ph, nb, rays in host0[:2]]
+    nbs = [nb for ph, nb, rays in host0]
+    nbytes = {"compact": float(np.mean([c.nbytes for c in compact])), "packed": float(packed[0].nbytes),
+              "soa": float(host0[0][0].n * 120 + host0[0][2].nbytes)}
     ctx = hip.Context(p, device=device)
     ctx.upload_scene(*tris)
     ctx.upload_medium(m)
     ctx.upload_materials(table)
+    ctx.upload_sensor(sensor)
     res = {}
-    for mode in os.environ.get("GVPM_BENCH_UPLOAD_MODES", "packed,prefetch,serial").split(","):
-        ctx.reset()
+    for mode in os.environ.get("GVPM_BENCH_UPLOAD_MODES", "compact,packed,prefetch,serial").split(","):
+        sets = compact if mode == "compact" else (packed if mode == "packed" else soa)
+        ns = len(sets)
         best = None
         for rep in range(4):  # first pass: allocations; then the fastest of three (see "how")
+            ctx.reset()
             ctx.synchronize()
             ev0 = ctx.stats()["evaluations"]
             t0 = time.perf_counter()
-            ph, nb, rays, pk = sets[0]
-            if mode == "packed":
-                ctx.upload_pinned_packed(pk)
+            if mode in ("compact", "packed"):
+                ctx.upload_pinned_packed(sets[0])
             else:
-                ctx.upload_pinned(ph, rays)
+                ctx.upload_pinned(*sets[0])
             for it in range(1, K + 1):
-                if mode == "packed":
+                if mode in ("compact", "packed"):
                     if it < K:
-                        ctx.prefetch_packed(sets[it % len(sets)][3])
+                        ctx.prefetch_packed(sets[it % ns])
                 elif mode == "prefetch":
                     if it < K:
-                        nxt = sets[it % len(sets)]
-                        ctx.prefetch(nxt[0], nxt[2])
+                        ctx.prefetch(*sets[it % ns])
                 elif it > 1:
-                    cur = sets[(it - 1) % len(sets)]
-                    ctx.upload_pinned(cur[0], cur[2])
-                ctx.gather(it, sets[(it - 1) % len(sets)][1])
+                    ctx.upload_pinned(*sets[(it - 1) % ns])
+                ctx.gather(it, nbs[(it - 1) % ns])
                 if os.environ.get("GVPM_BENCH_UPLOAD_TRACE") == "2":
                     print("[upload]   %s rep %d it %d returned at %.3f ms" % (mode, rep, it, (time.perf_counter() - t0) * 1e3), file=sys.stderr)
             ctx.synchronize()
@@ -664,27 +671,40 @@ def upload_inclusive(hip, p, m, tris, host0, K, device):
             if rep > 0 and (best is None or dt < best[0]):
                 best = (dt, ev)
         dt, ev = best
-        res[mode] = dict(ms_per_step=dt / K * 1e3, value=ev / dt / 1e6)
+        res[mode] = dict(ms_per_step=dt / K * 1e3, value=ev / dt / 1e6, evals_per_step=ev / K)
         if os.environ.get("GVPM_BENCH_UPLOAD_TRACE"):
-            print("[upload] %s %.3f ms/step" % (mode, dt / K * 1e3), file=sys.stderr)
+            print("[upload] %s %.3f ms/step, %.0f evaluations/step" % (mode, dt / K * 1e3, ev / K), file=sys.stderr)
     ctx.close()
-    for s in sets:
-        s[0].close()
-        s[2].close()
-        s[3].close()
+    for c in compact + packed:
+        c.close()
+    for a, b in soa:
+        a.close()
+        b.close()
+    head = res.get("compact") or next(iter(res.values()))
+    # the leg exists to say what an iteration costs WITH its upload: it must be the timed region's iteration
+    if "compact" in res and abs(head["evals_per_step"] - evals_per_step_timed) > 0.01 * evals_per_step_timed:
+        raise SystemExit("upload_inclusive ran %.0f evaluations per step, the timed region %.0f: not the same workload"
+                         % (head["evals_per_step"], evals_per_step_timed))
+
+    def leg(mode, nb):
+        r = res.get(mode)
+        return None if r is None else dict(r, host_bytes_per_step=nb, pcie_gb_per_s_at_this_rate=nb / (r["ms_per_step"] * 1e-3) / 1e9)
     return {
-        "value": res["packed"]["value"], "unit": "Mevals/s", "ms_per_step": res["packed"]["ms_per_step"],
-        "host_bytes_per_step": nbytes,
-        "pcie_gb_per_s_at_this_rate": nbytes / (res["packed"]["ms_per_step"] * 1e-3) / 1e9,
-        "soa": {"ms_per_step": res["prefetch"]["ms_per_step"], "value": res["prefetch"]["value"],
-                "ms_per_step_without_prefetch": res["serial"]["ms_per_step"], "host_bytes_per_step": nbytes_soa,
-                "pcie_gb_per_s_at_this_rate": nbytes_soa / (res["prefetch"]["ms_per_step"] * 1e-3) / 1e9},
-        "how": "pinned host buffers of packed records (gvpm_pack_photons / gvpm_pack_camera_beams: 76 bytes a photon, 272 a "
-               "beam set; decoded at the head of the consuming gather's build), gvpm_prefetch_*_packed of step N+1 before gvpm_gather of step N; "
-               "`soa`: the same through the fp32 SoA entry points (gvpm_host_alloc_photons, 120 / 320 bytes).  Each figure is "
-               "the fastest of three passes of K steps after an allocation pass: on some boxes of the pool the host-to-device "
-               "copies run at ~33 instead of 55 GB/s for stretches of 50-100 ms (seen from the sixth step of a pass on, in "
-               "either mode), which a single pass of 16 steps can fall into",
+        "value": head["value"], "unit": "Mevals/s", "ms_per_step": head["ms_per_step"],
+        "evals_per_step": head["evals_per_step"], "evals_per_step_timed_region": evals_per_step_timed,
+        "host_bytes_per_step": nbytes["compact"],
+        "pcie_gb_per_s_at_this_rate": nbytes["compact"] / (head["ms_per_step"] * 1e-3) / 1e9,
+        "sets": {"compact": compact[0].ncompact, "full": compact[0].nfull},
+        "packed": leg("packed", nbytes["packed"]),
+        "soa": dict(leg("prefetch", nbytes["soa"]) or {}, ms_per_step_without_prefetch=(res.get("serial") or {}).get("ms_per_step")),
+        "how": "pinned host buffers: gvpm_pack_photons records (76 bytes a photon) + gvpm_pack_camera_beams_compact sets (60 bytes "
+               "for a sensor-adjacent edge, rebuilt from gvpm_upload_sensor on the device; 272 for deeper edges), decoded at the "
+               "head of the consuming gather's build; gvpm_prefetch_* of step N+1 before gvpm_gather of step N; the input sets "
+               "of the timed region, in its order, gvpm_reset before every pass.  `packed`: round 3's records (76 / 272 bytes), "
+               "`soa`: the fp32 SoA entry points (gvpm_host_alloc_photons, 120 / 320 bytes), both over the first two input sets.  "
+               "Each figure is the fastest of three passes of K steps after an allocation pass: on some boxes of the pool the "
+               "host-to-device copies run at ~33 instead of 55 GB/s for stretches of 50-100 ms, which a single pass of 16 "
+               "steps can fall into",
     }
 
 

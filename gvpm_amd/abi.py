@@ -141,6 +141,19 @@ RAY_PACKED_DTYPE = np.dtype([
 assert PHOTON_PACKED_DTYPE.itemsize == 76 and RAY_PACKED_DTYPE.itemsize == 52
 
 
+# compact camera-beam sets (include/gvpm_hip.h, "compact camera-beam sets")
+BEAM_SET_COMPACT_DTYPE = np.dtype([
+    ("pixel", np.uint32), ("jitter", np.float32, 2), ("rand", np.float32), ("info", np.uint32), ("t0", np.float32, 5),
+    ("len", np.float32, 5)])
+assert BEAM_SET_COMPACT_DTYPE.itemsize == 60
+
+
+class Sensor(C.Structure):
+    """gvpm_sensor: the perspective sensor the compact beam sets are decoded with"""
+    _fields_ = [("pos", C.c_double * 3), ("to_world", C.c_double * 9), ("tan_half_fov_x", C.c_double),
+                ("tan_half_fov_y", C.c_double), ("width", C.c_int32), ("height", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 class Photons:
     """Host-side photon SoA as numpy arrays (owning), convertible to gvpm_photon_soa."""
 

@@ -278,6 +278,8 @@ struct gvpm_context {
   struct RaySlot {
     DevBuf<gvpm_camera_ray> rays;
     DevBuf<uint32_t> packed;  // a packed upload lands here and is decoded into rays by the consuming gather
+    DevBuf<uint32_t> compact; // compact sets (60 bytes each) of a compact upload; its full sets land in `packed`
+    uint32_t ncompact = 0;    // the first ncompact sets of the slot are decoded from `compact`, the others from `packed`
     bool needUnpack = false;
     hipEvent_t unpacked = nullptr;
     uint32_t nsets = 0;
@@ -299,6 +301,9 @@ struct gvpm_context {
   GatherArgs reqArgs;            // of that gather (medium, film, iteration scale)
   DevBuf<gvpm_material> materials;  // gvpm_upload_materials: the table the packed photon records index
   uint32_t nmaterials = 0;
+  std::vector<gvpm_material> materialsHost;  // what the device table holds (append-only growth needs no stream sync)
+  gvpm_sensor sensor{};             // gvpm_upload_sensor: what the compact beam sets are decoded with
+  bool haveSensor = false;
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid
   gvpm_photon_soa rawDev;  // device pointers
   uint32_t nph = 0;
@@ -415,8 +420,10 @@ static inline int fail(gvpm_context *h, int code, const char *msg) {
 
 namespace gvpm {
 void launch_unpack_photons(const uint32_t *packed, uint32_t n, const gvpm_material *table, uint32_t table_n,
-                           const gvpm_photon_soa &dst, hipStream_t s);
+                           const gvpm_photon_soa &dst, unsigned long long *bad, hipStream_t s);
 void launch_unpack_rays(const uint32_t *packed, uint32_t nsets, gvpm_camera_ray *dst, hipStream_t s);
+void launch_unpack_compact_rays(const gvpm_sensor &sensor, const uint32_t *compact, uint32_t ncompact, gvpm_camera_ray *dst,
+                                hipStream_t s);
 }  // namespace gvpm
 
 // shared between the files above

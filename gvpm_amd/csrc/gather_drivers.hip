@@ -979,7 +979,10 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, hipStreamWaitEvent(h->stream, ps.copied, 0));
     HIP_TRY(h, hipStreamWaitEvent(h->streamB, ps.copied, 0));
     if (ps.needUnpack) {
-      launch_unpack_photons(ps.packed.p, (uint32_t)ps.dev.n, h->materials.p, h->nmaterials, ps.dev, us);
+      // (a packed record names its parent's material by index: without a table every parent would decode as black)
+      if (h->nmaterials == 0)
+        return fail(h, GVPM_ERR_STATE, "packed photons were uploaded but no material table (gvpm_upload_materials)");
+      launch_unpack_photons(ps.packed.p, (uint32_t)ps.dev.n, h->materials.p, h->nmaterials, ps.dev, h->stats.p + 6, us);
       HIP_TRY(h, hipGetLastError());
       if (!ps.unpacked) HIP_TRY(h, hipEventCreateWithFlags(&ps.unpacked, hipEventDisableTiming));
       HIP_TRY(h, hipEventRecord(ps.unpacked, us));
@@ -993,7 +996,12 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
     HIP_TRY(h, hipStreamWaitEvent(h->stream, rs.copied, 0));
     HIP_TRY(h, hipStreamWaitEvent(h->streamB, rs.copied, 0));
     if (rs.needUnpack) {
-      launch_unpack_rays(rs.packed.p, rs.nsets, rs.rays.p, us);
+      if (rs.ncompact) {
+        if (!h->haveSensor)
+          return fail(h, GVPM_ERR_STATE, "compact beam sets were uploaded but no sensor (gvpm_upload_sensor)");
+        launch_unpack_compact_rays(h->sensor, rs.compact.p, rs.ncompact, rs.rays.p, us);
+      }
+      launch_unpack_rays(rs.packed.p, rs.nsets - rs.ncompact, rs.rays.p + (size_t)rs.ncompact * 5, us);
       HIP_TRY(h, hipGetLastError());
       if (!rs.unpacked) HIP_TRY(h, hipEventCreateWithFlags(&rs.unpacked, hipEventDisableTiming));
       HIP_TRY(h, hipEventRecord(rs.unpacked, us));

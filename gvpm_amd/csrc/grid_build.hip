@@ -648,10 +648,15 @@ __device__ __forceinline__ BeamClearTri beamClearTri(const float p1[3], const fl
   const float nrm[3] = {t0.w, t1.w, t2.w};
   const float cn = dot3(bd, nrm), dn = dot3(a, nrm);  // plane: nrm . (x - v0) = 0, a = v0 - p1
   o.alongMin = -INFINITY;
-  if (fabsf(cn) > 0.05f) {
+  // The pierce test runs at ANY incidence: a line that crosses a large triangle at a grazing angle (|cn| <= 0.05) sees it
+  // under angle 0 although every edge is far off axis -- filed under "others" with the edges' cosine, such a triangle let
+  // reconnections inside that cone skip the any-hit test (a thin plate with medium on both sides).  alongMin is only
+  // trusted away from grazing (delta tan(incidence) explodes there): a grazed triangle the beam points at leaves
+  // M1 = -inf, i.e. the beam is never certified.
+  if (fabsf(cn) > 1e-12f) {
     const float tp = dn / cn;  // p1 + tp bd on the plane
     if (tp > 0.f) {
-      o.alongMin = tp - delta * sqrtf(fmaxf(1.f - cn * cn, 0.f)) / fabsf(cn);
+      if (fabsf(cn) > 0.05f) o.alongMin = tp - delta * sqrtf(fmaxf(1.f - cn * cn, 0.f)) / fabsf(cn);
       // inside (or within slack of) the triangle?  barycentrics of the piercing point
       const float q[3] = {tp * bd[0] - a[0], tp * bd[1] - a[1], tp * bd[2] - a[2]};  // from v0
       const float d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), q1 = dot3(q, e1), q2 = dot3(q, e2);

@@ -336,6 +336,8 @@ int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   out->failed_shifts = v[4];
   out->dropped_pairs = v[7];
   out->reserved[0] = ((uint64_t)h->lastGridMode << 56) | (uint64_t)h->lastGridCells;
+  out->reserved[1] = v[6];
+  if (v[6]) return fail(h, GVPM_ERR_STATE, "packed photon records named materials beyond the uploaded table (decoded as black)");
   // the planner's bound on an item's pair region is exact: a dropped pair means a biased image, not a slow one
   if (v[7]) return fail(h, GVPM_ERR_STATE, "the G-BRE traversal dropped pairs: planner bound violated");
   return GVPM_OK;

@@ -100,4 +100,46 @@ GVPM_HD gvpm_camera_ray unpackRay(const gvpm_beam_set_packed &s, int k) {
   return r;
 }
 
+// ray k (0: base, 1..4: L R T B) of a compact beam set: the first medium edge of the camera path through film position
+// (px, py) + offset_k + jitter of a perspective sensor (shift_cameraPath.h:29-133 re-traces the base path through the
+// offset pixel with the base sample's fractional position, vertex.cpp:345-346).  pdf = jacobian = gop = 1: see the header
+// (sensorMIS, gvpm_struct.h:608-631, is their only reader and its value for such an edge is 1 by construction).
+GVPM_HD gvpm_camera_ray unpackCompactRay(const gvpm_sensor &s, const gvpm_beam_set_compact &c, int k) {
+#pragma clang fp contract(off)
+  gvpm_camera_ray r;
+  memset(&r, 0, sizeof(r));
+  const uint32_t edge = (c.info >> 8) & 0xFFu;
+  if (!((c.info >> k) & 1u)) {
+    r.info = GVPM_RAY_INFO(0u, edge);
+    return r;
+  }
+  const double offX = k == 1 ? -1.0 : (k == 2 ? 1.0 : 0.0), offY = k == 3 ? 1.0 : (k == 4 ? -1.0 : 0.0);
+  const double sx = (double)(c.pixel & 0xFFFFu) + offX + (double)c.jitter[0];
+  const double sy = (double)(c.pixel >> 16) + offY + (double)c.jitter[1];
+  const double cx = (2.0 * sx / (double)s.width - 1.0) * s.tan_half_fov_x;
+  const double cy = (2.0 * sy / (double)s.height - 1.0) * s.tan_half_fov_y;
+  const double cz = -1.0;
+  const double len = sqrt(cx * cx + cy * cy + cz * cz);
+  const double ux = cx / len, uy = cy / len, uz = cz / len;
+  const double dx = s.to_world[0] * ux + s.to_world[1] * uy + s.to_world[2] * uz;
+  const double dy = s.to_world[3] * ux + s.to_world[4] * uy + s.to_world[5] * uz;
+  const double dz = s.to_world[6] * ux + s.to_world[7] * uy + s.to_world[8] * uz;
+  const double t0 = (double)c.t0[k];
+  r.o[0] = (float)(s.pos[0] + dx * t0);
+  r.o[1] = (float)(s.pos[1] + dy * t0);
+  r.o[2] = (float)(s.pos[2] + dz * t0);
+  r.d[0] = (float)dx;
+  r.d[1] = (float)dy;
+  r.d[2] = (float)dz;
+  r.len = c.len[k];
+  r.eye[0] = r.eye[1] = r.eye[2] = 1.f;
+  r.pdf = r.jacobian = r.gop = 1.f;
+  r.info = GVPM_RAY_INFO(1u, edge);
+  if (k == 0) {
+    r.rand = c.rand;
+    r.pixel = c.pixel;
+  }
+  return r;
+}
+
 }  // namespace gvpm

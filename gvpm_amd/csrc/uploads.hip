@@ -9,9 +9,13 @@ namespace {
 // ---- packed records -> what the SoA uploads put in the slots (pack_codec.h) ----------------
 __global__ __launch_bounds__(256) void unpack_photons_kernel(const gvpm_photon_packed *__restrict__ src, uint32_t n,
                                                              const gvpm_material *__restrict__ table, uint32_t table_n,
-                                                             gvpm_photon_soa dst) {
+                                                             gvpm_photon_soa dst, unsigned long long *bad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) unpackPhoton(src[i], table, table_n, dst, i);
+  if (i < n) {
+    // gvpm_unpack_photons refuses such a record; here it decodes as a black parent and is REPORTED (gvpm_get_stats fails)
+    if (src[i].material >= table_n) atomicAdd(bad, 1ull);
+    unpackPhoton(src[i], table, table_n, dst, i);
+  }
 }
 __global__ __launch_bounds__(256) void unpack_rays_kernel(const gvpm_beam_set_packed *__restrict__ src, uint32_t nsets,
                                                           gvpm_camera_ray *__restrict__ dst) {
@@ -19,14 +23,26 @@ __global__ __launch_bounds__(256) void unpack_rays_kernel(const gvpm_beam_set_pa
   if (i < nsets * 5u) dst[i] = unpackRay(src[i / 5u], (int)(i % 5u));
 }
 
+__global__ __launch_bounds__(256) void unpack_compact_rays_kernel(gvpm_sensor sensor, const gvpm_beam_set_compact *__restrict__ src,
+                                                                  uint32_t nsets, gvpm_camera_ray *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nsets * 5u) dst[i] = unpackCompactRay(sensor, src[i / 5u], (int)(i % 5u));
+}
+
 }  // namespace
 
 namespace gvpm {
+void launch_unpack_compact_rays(const gvpm_sensor &sensor, const uint32_t *compact, uint32_t ncompact, gvpm_camera_ray *dst,
+                                hipStream_t s) {
+  if (ncompact)
+    hipLaunchKernelGGL(unpack_compact_rays_kernel, dim3((ncompact * 5u + 255) / 256), dim3(256), 0, s, sensor,
+                       reinterpret_cast<const gvpm_beam_set_compact *>(compact), ncompact, dst);
+}
 void launch_unpack_photons(const uint32_t *packed, uint32_t n, const gvpm_material *table, uint32_t table_n,
-                           const gvpm_photon_soa &dst, hipStream_t s) {
+                           const gvpm_photon_soa &dst, unsigned long long *bad, hipStream_t s) {
   if (n)
     hipLaunchKernelGGL(unpack_photons_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
-                       reinterpret_cast<const gvpm_photon_packed *>(packed), n, table, table_n, dst);
+                       reinterpret_cast<const gvpm_photon_packed *>(packed), n, table, table_n, dst, bad);
 }
 void launch_unpack_rays(const uint32_t *packed, uint32_t nsets, gvpm_camera_ray *dst, hipStream_t s) {
   if (nsets)
@@ -141,16 +157,97 @@ int gvpm_unpack_camera_beams(const gvpm_beam_set_packed *src, uint64_t n_sets, g
   return GVPM_OK;
 }
 
+int gvpm_unpack_camera_beams_compact(const gvpm_sensor *sensor, const gvpm_beam_set_compact *src, uint64_t n_compact,
+                                     gvpm_camera_ray *dst) {
+  if (!sensor || (n_compact && (!src || !dst))) return GVPM_ERR_INVALID_ARG;
+  for (uint64_t i = 0; i < n_compact; ++i)
+    for (int k = 0; k < 5; ++k) dst[5 * i + k] = unpackCompactRay(*sensor, src[i], k);
+  return GVPM_OK;
+}
+
+int gvpm_pack_camera_beams_compact(const gvpm_sensor *sensor, const gvpm_camera_ray *rays, const float *jitter,
+                                   uint64_t n_sets, gvpm_beam_set_compact *compact, uint64_t *n_compact,
+                                   gvpm_beam_set_packed *full, uint64_t *n_full, uint32_t *new_index) {
+  if (!sensor || !n_compact || !n_full || (n_sets && (!rays || !jitter || !compact || !full))) return GVPM_ERR_INVALID_ARG;
+  uint64_t nc = 0, nf = 0;
+  std::vector<uint8_t> isFull(new_index ? n_sets : 0);
+  for (uint64_t i = 0; i < n_sets; ++i) {
+    const gvpm_camera_ray *s = rays + 5 * i;
+    gvpm_beam_set_compact c;
+    memset(&c, 0, sizeof(c));
+    c.pixel = s[0].pixel;
+    c.jitter[0] = jitter[2 * i];
+    c.jitter[1] = jitter[2 * i + 1];
+    c.rand = s[0].rand;
+    const uint32_t edge = GVPM_RAY_EDGE(s[0].info);
+    c.info = edge << 8;
+    bool ok = c.jitter[0] >= 0.f && c.jitter[0] < 1.f && c.jitter[1] >= 0.f && c.jitter[1] < 1.f;
+    for (int k = 0; k < 5; ++k) {
+      if (GVPM_RAY_EDGE(s[k].info) != edge) return GVPM_ERR_INVALID_ARG;
+      if (!GVPM_RAY_VALID(s[k].info)) continue;
+      c.info |= 1u << k;
+      const double ox = (double)s[k].o[0] - sensor->pos[0], oy = (double)s[k].o[1] - sensor->pos[1], oz = (double)s[k].o[2] - sensor->pos[2];
+      // (a ray that starts AT the sensor -- the sensor sits in the medium -- has t0 = 0 whatever the rounding of pos)
+      const bool atSensor = (float)sensor->pos[0] == s[k].o[0] && (float)sensor->pos[1] == s[k].o[1] && (float)sensor->pos[2] == s[k].o[2];
+      c.t0[k] = atSensor ? 0.f : (float)std::sqrt(ox * ox + oy * oy + oz * oz);
+      c.len[k] = s[k].len;
+    }
+    // eligible iff the decode gives the rays back (to rounding) and the fields the format drops hold what it assumes
+    for (int k = 0; k < 5 && ok; ++k) {
+      const gvpm_camera_ray u = unpackCompactRay(*sensor, c, k);
+      if (u.info != s[k].info) ok = false;
+      if (!GVPM_RAY_VALID(s[k].info)) continue;
+      for (int a = 0; a < 3 && ok; ++a) {
+        const double tolD = 4.0 * 1.1920929e-7, tolO = 4.0 * 1.1920929e-7 * std::fmax(1.0, std::fabs((double)s[k].o[a]));
+        if (std::fabs((double)u.d[a] - (double)s[k].d[a]) > tolD || std::fabs((double)u.o[a] - (double)s[k].o[a]) > tolO) ok = false;
+        if (s[k].eye[a] != 1.f) ok = false;
+      }
+      if (u.len != s[k].len) ok = false;
+      if (k > 0 && ok) {
+        const double prod = (double)s[k].pdf / (double)s[0].pdf * (double)s[k].jacobian;
+        if (!(std::fabs(prod - 1.0) <= 1e-4)) ok = false;
+      }
+    }
+    if (ok && (!GVPM_RAY_VALID(s[0].info))) ok = false;  // (a set without a base ray is not a set)
+    if (ok) {
+      compact[nc++] = c;
+    } else {
+      const int rc = gvpm_pack_camera_beams(s, 1, full + nf);
+      if (rc != GVPM_OK) return rc;
+      ++nf;
+    }
+    if (new_index) isFull[i] = !ok;
+  }
+  if (new_index) {
+    uint64_t a = 0, b = nc;
+    for (uint64_t i = 0; i < n_sets; ++i) new_index[i] = (uint32_t)(isFull[i] ? b++ : a++);
+  }
+  *n_compact = nc;
+  *n_full = nf;
+  return GVPM_OK;
+}
+
 int gvpm_upload_materials(gvpm_context *h, const gvpm_material *table, uint32_t n) {
   CHECK_H(h);
   if (n && !table) return fail(h, GVPM_ERR_INVALID_ARG, "null material table");
   if (n > 65536u) return fail(h, GVPM_ERR_INVALID_ARG, "more than 65536 materials");
-  if (h->materials.cap < (size_t)n + 1) {
-    // (an unpack kernel of a pending prefetch may still read the old table)
+  // The unpack kernels that read the table run at the head of a gather's build chain (gather stream or build stream) and
+  // may be in flight.  A table that only GROWS (the usual case: gvpm_pack_photons appends) is safe to extend under them --
+  // no record in flight names an entry beyond the old count; an edit of existing entries, or a regrowth (which frees the
+  // old buffer), first waits for every stream of the handle.
+  const bool prefixSame = n >= h->nmaterials && h->nmaterials == (uint32_t)h->materialsHost.size() &&
+                          (h->nmaterials == 0 || memcmp(h->materialsHost.data(), table, (size_t)h->nmaterials * sizeof(gvpm_material)) == 0);
+  const bool regrow = h->materials.cap < (size_t)n + 1;
+  if (regrow || !prefixSame) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->streamB));
     HIP_TRY(h, hipStreamSynchronize(h->copyStream));
-    HIP_TRY(h, h->materials.ensure((size_t)n + 1));
   }
-  if (n) HIP_TRY(h, hipMemcpy(h->materials.p, table, (size_t)n * sizeof(gvpm_material), hipMemcpyHostToDevice));
+  if (regrow) HIP_TRY(h, h->materials.ensure(std::max<size_t>((size_t)n + 1, 64)));
+  const uint32_t first = (regrow || !prefixSame) ? 0u : h->nmaterials;
+  if (n > first)
+    HIP_TRY(h, hipMemcpy(h->materials.p + first, table + first, (size_t)(n - first) * sizeof(gvpm_material), hipMemcpyHostToDevice));
+  h->materialsHost.assign(table, table + n);
   h->nmaterials = n;
   return GVPM_OK;
 }
@@ -481,6 +578,7 @@ static int uploadBeamsPacked(gvpm_context *h, const gvpm_beam_set_packed *src, u
     HIP_TRY(h, hipMemcpyAsync(rs.packed.p, src, (size_t)nsets * sizeof(gvpm_beam_set_packed), hipMemcpyHostToDevice, h->copyStream));
   rs.needUnpack = nsets > 0;
   rs.nsets = (uint32_t)nsets;
+  rs.ncompact = 0;
   HIP_TRY(h, hipEventRecord(rs.copied, h->copyStream));
   if (!pinned) HIP_TRY(h, hipStreamSynchronize(h->copyStream));
   if (prefetch) {
@@ -494,6 +592,82 @@ static int uploadBeamsPacked(gvpm_context *h, const gvpm_beam_set_packed *src, u
   h->nsets = (uint32_t)nsets;
   h->haveBeams = true;
   h->beamsDirty = true;
+  return GVPM_OK;
+}
+
+// compact sets (60 bytes, rebuilt from the sensor) + the full packed sets of deeper edges: two copies into the slot,
+// decoded by the consuming gather like the packed records
+static int uploadBeamsCompact(gvpm_context *h, const gvpm_beam_set_compact *compact, uint64_t ncompact,
+                              const gvpm_beam_set_packed *full, uint64_t nfull, bool prefetch) {
+  if ((ncompact && !compact) || (nfull && !full)) return fail(h, GVPM_ERR_INVALID_ARG, "null compact / full beam sets");
+  const uint64_t nsets = ncompact + nfull;
+  if (nsets > 0x0FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "too many beam sets");
+  if (ncompact && !h->haveSensor) return fail(h, GVPM_ERR_STATE, "compact beam sets need gvpm_upload_sensor first");
+  const bool pinned = nsets && (!ncompact || isPinnedHost(compact)) && (!nfull || isPinnedHost(full));
+  if (prefetch && !pinned) return fail(h, GVPM_ERR_INVALID_ARG, "gvpm_prefetch_camera_beams_compact needs pinned host memory (gvpm_host_alloc)");
+  if (prefetch && h->rayPending >= 0) return fail(h, GVPM_ERR_STATE, "a prefetched camera-beam list is already pending");
+  int slot = (h->rayCur + 1) % 3;
+  if (slot == h->rayPending) slot = (h->rayCur + 2) % 3;
+  gvpm_context::RaySlot &rs = h->raySlot[slot];
+  if (rs.read) HIP_TRY(h, hipStreamWaitEvent(h->copyStream, rs.freed, 0));
+  rs.read = false;
+  constexpr size_t SW = sizeof(gvpm_beam_set_packed) / 4, CW = sizeof(gvpm_beam_set_compact) / 4;
+  if (rs.rays.cap < (size_t)nsets * 5 + 1 || rs.packed.cap < (size_t)nfull * SW + 8 || rs.compact.cap < (size_t)ncompact * CW + 8) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // regrowing frees the old buffers
+    HIP_TRY(h, hipStreamSynchronize(h->copyStream));
+    HIP_TRY(h, rs.rays.ensure((size_t)nsets * 5 + 1));
+    HIP_TRY(h, rs.packed.ensure((size_t)nfull * SW + 8));
+    HIP_TRY(h, rs.compact.ensure((size_t)ncompact * CW + 8));
+  }
+  if (ncompact)
+    HIP_TRY(h, hipMemcpyAsync(rs.compact.p, compact, (size_t)ncompact * sizeof(gvpm_beam_set_compact), hipMemcpyHostToDevice, h->copyStream));
+  if (nfull)
+    HIP_TRY(h, hipMemcpyAsync(rs.packed.p, full, (size_t)nfull * sizeof(gvpm_beam_set_packed), hipMemcpyHostToDevice, h->copyStream));
+  rs.needUnpack = nsets > 0;
+  rs.nsets = (uint32_t)nsets;
+  rs.ncompact = (uint32_t)ncompact;
+  HIP_TRY(h, hipEventRecord(rs.copied, h->copyStream));
+  if (!pinned) HIP_TRY(h, hipStreamSynchronize(h->copyStream));
+  if (prefetch) {
+    h->rayPending = slot;
+    return GVPM_OK;
+  }
+  h->rayCur = slot;
+  h->raysDev = rs.rays.p;
+  h->rayWait = true;
+  h->raysOwnedCur = true;
+  h->nsets = (uint32_t)nsets;
+  h->haveBeams = true;
+  h->beamsDirty = true;
+  return GVPM_OK;
+}
+
+int gvpm_upload_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_compact *compact, uint64_t n_compact,
+                                     const gvpm_beam_set_packed *full, uint64_t n_full) {
+  CHECK_H(h);
+  return uploadBeamsCompact(h, compact, n_compact, full, n_full, false);
+}
+int gvpm_prefetch_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_compact *compact, uint64_t n_compact,
+                                       const gvpm_beam_set_packed *full, uint64_t n_full) {
+  CHECK_H(h);
+  return uploadBeamsCompact(h, compact, n_compact, full, n_full, true);
+}
+
+int gvpm_upload_sensor(gvpm_context *h, const gvpm_sensor *sensor) {
+  CHECK_H(h);
+  if (!sensor) return fail(h, GVPM_ERR_INVALID_ARG, "null sensor");
+  if (sensor->width < 1 || sensor->height < 1 || sensor->width > 65535 || sensor->height > 65535 ||
+      !(sensor->tan_half_fov_x > 0.0) || !(sensor->tan_half_fov_y > 0.0))
+    return fail(h, GVPM_ERR_INVALID_ARG, "sensor: film size in 1..65535 and positive field of view");
+  for (int k = 0; k < 3; ++k) {
+    // rows of a rotation: unit length, mutually orthogonal (a sheared or scaled transform is not a pinhole this format covers)
+    const double *r = sensor->to_world + 3 * k, *q = sensor->to_world + 3 * ((k + 1) % 3);
+    if (std::fabs(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] - 1.0) > 1e-9 || std::fabs(r[0] * q[0] + r[1] * q[1] + r[2] * q[2]) > 1e-9)
+      return fail(h, GVPM_ERR_INVALID_ARG, "sensor: to_world must be a rotation");
+  }
+  // (the decode kernel takes the sensor by value at launch: nothing on the device to order against)
+  h->sensor = *sensor;
+  h->haveSensor = true;
   return GVPM_OK;
 }
 

@@ -31,6 +31,8 @@ SYMBOLS = [
     "gvpm_upload_photons_packed", "gvpm_prefetch_photons_packed", "gvpm_upload_camera_beams_packed",
     "gvpm_prefetch_camera_beams_packed",
     "gvpm_enable_host_shifts", "gvpm_download_shift_requests", "gvpm_upload_host_shifts",
+    "gvpm_upload_sensor", "gvpm_pack_camera_beams_compact", "gvpm_unpack_camera_beams_compact",
+    "gvpm_upload_camera_beams_compact", "gvpm_prefetch_camera_beams_compact",
 ]
 
 
@@ -106,6 +108,12 @@ def lib():
         L.gvpm_prefetch_photons_packed.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_camera_beams_packed.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_prefetch_camera_beams_packed.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_sensor.argtypes = [vp, C.POINTER(abi.Sensor)]
+        L.gvpm_pack_camera_beams_compact.argtypes = [C.POINTER(abi.Sensor), vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64), vp,
+                                                     C.POINTER(C.c_uint64), vp]
+        L.gvpm_unpack_camera_beams_compact.argtypes = [C.POINTER(abi.Sensor), vp, C.c_uint64, vp]
+        L.gvpm_upload_camera_beams_compact.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+        L.gvpm_prefetch_camera_beams_compact.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
         L.gvpm_host_alloc_photons.argtypes = [C.c_uint64, C.POINTER(abi.PhotonSoA), C.POINTER(vp)]
         L.gvpm_host_free.argtypes = [vp]
         L.gvpm_prefetch_photons.argtypes = [vp, C.POINTER(abi.PhotonSoA)]
@@ -222,29 +230,70 @@ def unpack_camera_beams(packed):
     return rays
 
 
+def pack_camera_beams_compact(sensor, rays, jitter, out_compact=None, out_full=None):
+    """gvpm_pack_camera_beams_compact: (nsets, 5) camera rays + (nsets, 2) film offsets -> (compact records
+    [BEAM_SET_COMPACT_DTYPE], full records [uint8 (nfull, 272)], new_index [uint32 per input set]).  out_*: buffers with
+    room for nsets records each (e.g. views of pinned memory); the returned arrays are their filled prefixes."""
+    rays = np.ascontiguousarray(rays)
+    n = rays.size // 5
+    jitter = np.ascontiguousarray(jitter, np.float32)
+    assert jitter.size == 2 * n
+    if out_compact is None:
+        out_compact = np.zeros(n, abi.BEAM_SET_COMPACT_DTYPE)
+    if out_full is None:
+        out_full = np.zeros((n, 272), np.uint8)
+    assert out_compact.nbytes >= n * 60 and out_full.nbytes >= n * 272
+    nc, nf = C.c_uint64(0), C.c_uint64(0)
+    idx = np.zeros(n, np.uint32)
+    rc = lib().gvpm_pack_camera_beams_compact(C.byref(sensor), rays.ctypes.data, jitter.ctypes.data, n, out_compact.ctypes.data,
+                                              C.byref(nc), out_full.ctypes.data, C.byref(nf), idx.ctypes.data)
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_pack_camera_beams_compact failed")
+    return out_compact[:nc.value], out_full[:nf.value], idx
+
+
+def unpack_camera_beams_compact(sensor, compact):
+    compact = np.ascontiguousarray(compact)
+    n = compact.size
+    rays = np.zeros((n, 5), abi.CAMERA_RAY_DTYPE)
+    rc = lib().gvpm_unpack_camera_beams_compact(C.byref(sensor), compact.ctypes.data, n, rays.ctypes.data)
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_unpack_camera_beams_compact failed")
+    return rays
+
+
 class PinnedPacked:
     """One iteration's inputs as packed records in pinned host memory: what a pipelined producer hands to
-    gvpm_upload_*_packed / gvpm_prefetch_*_packed."""
+    gvpm_upload_*_packed / gvpm_prefetch_*_packed.  With sensor + jitter the beam sets are split into compact records
+    (60 bytes) and full ones (272) as gvpm_pack_camera_beams_compact does; otherwise every set is a full record."""
 
-    def __init__(self, ph, rays, table):
+    def __init__(self, ph, rays, table, sensor=None, jitter=None):
         self.n = ph.n
         self.nsets = np.asarray(rays).size // 5
-        self._pp, self._pr = C.c_void_p(), C.c_void_p()
-        for ptr, nbytes in ((self._pp, self.n * 76), (self._pr, self.nsets * 272)):
+        self.compact = sensor is not None
+        self._pp, self._pr, self._pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        for ptr, nbytes in ((self._pp, self.n * 76), (self._pr, self.nsets * 272)) + (((self._pc, self.nsets * 60),) if self.compact else ()):
             rc = lib().gvpm_host_alloc(max(nbytes, 64), C.byref(ptr))
             if rc != 0:
                 raise GvpmError(rc, "gvpm_host_alloc failed")
         pv = np.frombuffer((C.c_char * (self.n * 76)).from_address(self._pp.value), abi.PHOTON_PACKED_DTYPE) if self.n else np.zeros(0, abi.PHOTON_PACKED_DTYPE)
         rv = np.frombuffer((C.c_char * (self.nsets * 272)).from_address(self._pr.value), np.uint8).reshape(self.nsets, 272) if self.nsets else np.zeros((0, 272), np.uint8)
         pack_photons(ph, table, out=pv)
-        pack_camera_beams(rays, out=rv)
-        self.nbytes = self.n * 76 + self.nsets * 272
+        if self.compact:
+            cv = np.frombuffer((C.c_char * (self.nsets * 60)).from_address(self._pc.value), abi.BEAM_SET_COMPACT_DTYPE) if self.nsets else np.zeros(0, abi.BEAM_SET_COMPACT_DTYPE)
+            c, f, self.new_index = pack_camera_beams_compact(sensor, rays, jitter, out_compact=cv, out_full=rv)
+            self.ncompact, self.nfull = int(c.size), int(f.shape[0])
+            self.nbytes = self.n * 76 + self.ncompact * 60 + self.nfull * 272
+        else:
+            pack_camera_beams(rays, out=rv)
+            self.ncompact, self.nfull = 0, self.nsets
+            self.nbytes = self.n * 76 + self.nsets * 272
 
     def close(self):
-        for ptr in (self._pp, self._pr):
+        for ptr in (self._pp, self._pr, self._pc):
             if ptr:
                 lib().gvpm_host_free(ptr)
-        self._pp, self._pr = C.c_void_p(), C.c_void_p()
+        self._pp, self._pr, self._pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
 
     __del__ = close
 
@@ -340,13 +389,32 @@ class Context:
         n = packed.nbytes // 272
         self._check(lib().gvpm_upload_camera_beams_packed(self._h, packed.ctypes.data if n else None, n))
 
+    def upload_sensor(self, sensor):
+        self._check(lib().gvpm_upload_sensor(self._h, C.byref(sensor)))
+
+    def upload_camera_beams_compact(self, compact, full):
+        """compact: BEAM_SET_COMPACT_DTYPE records; full: uint8 (nfull, 272) packed records (gvpm_pack_camera_beams_compact)"""
+        compact = np.ascontiguousarray(compact)
+        full = np.ascontiguousarray(full)
+        nc, nf = compact.size, full.nbytes // 272
+        self._check(lib().gvpm_upload_camera_beams_compact(self._h, compact.ctypes.data if nc else None, nc,
+                                                           full.ctypes.data if nf else None, nf))
+
     def upload_pinned_packed(self, pk):
         self._check(lib().gvpm_upload_photons_packed(self._h, pk._pp, pk.n))
-        self._check(lib().gvpm_upload_camera_beams_packed(self._h, pk._pr, pk.nsets))
+        if pk.compact:
+            self._check(lib().gvpm_upload_camera_beams_compact(self._h, pk._pc if pk.ncompact else None, pk.ncompact,
+                                                               pk._pr if pk.nfull else None, pk.nfull))
+        else:
+            self._check(lib().gvpm_upload_camera_beams_packed(self._h, pk._pr, pk.nsets))
 
     def prefetch_packed(self, pk):
         self._check(lib().gvpm_prefetch_photons_packed(self._h, pk._pp, pk.n))
-        self._check(lib().gvpm_prefetch_camera_beams_packed(self._h, pk._pr, pk.nsets))
+        if pk.compact:
+            self._check(lib().gvpm_prefetch_camera_beams_compact(self._h, pk._pc if pk.ncompact else None, pk.ncompact,
+                                                                 pk._pr if pk.nfull else None, pk.nfull))
+        else:
+            self._check(lib().gvpm_prefetch_camera_beams_packed(self._h, pk._pr, pk.nsets))
 
     def prefetch(self, photons=None, rays=None):
         """The inputs of the step after the coming gather (gvpm_prefetch_*)."""

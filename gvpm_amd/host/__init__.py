@@ -41,6 +41,8 @@ def lib():
         L.gvpm_synth_beams_interleaved.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gvpm_synth_planes.restype = C.c_uint64
         L.gvpm_synth_planes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.gvpm_synth_sensor.argtypes = [C.c_void_p, C.POINTER(abi.Sensor)]
+        L.gvpm_synth_jitter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -79,6 +81,20 @@ class SynthScene:
             buf = (C.c_float * (3 * n)).from_address(ptr)
             out.append(np.array(buf, np.float32).reshape(n, 3).copy())
         return tuple(out)
+
+    def sensor(self):
+        """the scene's pinhole sensor (gvpm_sensor) the compact beam sets are decoded with"""
+        s = abi.Sensor()
+        assert lib().gvpm_synth_sensor(self._h, C.byref(s)) == 0
+        return s
+
+    def jitter(self, iteration, rays):
+        """(nsets, 2) float32: the fractional film offsets the base paths of `rays` were sampled at"""
+        rays = np.ascontiguousarray(rays)
+        n = rays.size // 5
+        out = np.zeros((n, 2), np.float32)
+        assert lib().gvpm_synth_jitter(self._h, iteration, rays.ctypes.data, n, out.ctypes.data) == 0
+        return out
 
     def devgen_scene(self):
         """The scene as gvpm_devgen_create takes it (arrays owned by this object: keep it alive)."""

@@ -134,6 +134,33 @@ uint64_t gvpm_synth_beams_interleaved(gvpm_synth *s, int it, int tile_mod, int t
   return s->rays.size() / 5;
 }
 
+int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out) {
+  if (!s || !out) return GVPM_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  const gvpm::SynthScene &sc = s->scene;
+  out->pos[0] = sc.camPos.x;
+  out->pos[1] = sc.camPos.y;
+  out->pos[2] = sc.camPos.z;
+  out->to_world[0] = out->to_world[4] = out->to_world[8] = 1.0;  // the synthetic sensors look along -z, unrotated
+  out->tan_half_fov_x = sc.tanHalfFovX;
+  out->tan_half_fov_y = sc.tanHalfFovX * sc.height / sc.width;   // traceCamera's `ty`, same operations
+  out->width = sc.width;
+  out->height = sc.height;
+  return GVPM_OK;
+}
+
+int gvpm_synth_jitter(const gvpm_synth *s, int it, const gvpm_camera_ray *rays, uint64_t n_sets, float *out) {
+  if (!s || (n_sets && (!rays || !out))) return GVPM_ERR_INVALID_ARG;
+  const gvpm::SynthScene &sc = s->scene;
+  for (uint64_t i = 0; i < n_sets; ++i) {
+    const uint32_t px = rays[5 * i].pixel & 0xFFFFu, py = rays[5 * i].pixel >> 16;
+    gvpm::Philox rng(sc.seed, 0xca3eu, (uint32_t)it, (uint32_t)(py * sc.width + px));
+    out[2 * i] = rng.next1D();
+    out[2 * i + 1] = rng.next1D();
+  }
+  return GVPM_OK;
+}
+
 uint64_t gvpm_synth_vpm_samples(gvpm_synth *s, int it, int nb_camera_samples, const gvpm_vpm_sample **out) {
   if (!s || !out || nb_camera_samples <= 0) return 0;
   gvpm::cameraSamplesVPM(s->scene, it, s->rays, s->selW, nb_camera_samples, s->samples);

@@ -29,6 +29,12 @@ uint64_t gvpm_synth_planes(gvpm_synth *s, int it, const float **w1, const float 
 /* camera beam sets of the pixel rectangle; returns the number of sets */
 uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
                           const gvpm_camera_ray **out);
+/* the scene's pinhole sensor as the compact beam sets take it (gvpm_upload_sensor, include/gvpm_hip.h) */
+int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out);
+/* the fractional film offsets (2 floats per set) the base paths of `rays` (5 per set) of iteration `it` were sampled at:
+ * the first two draws of the pixel's stream (cameraBeamSets, synth_core.h) -- what a Mitsuba host reads off its sample
+ * position; the second argument of gvpm_pack_camera_beams_compact */
+int gvpm_synth_jitter(const gvpm_synth *s, int it, const gvpm_camera_ray *rays, uint64_t n_sets, float *out);
 /* G-VPM camera samples for the beam sets of the LAST gvpm_synth_beams call */
 uint64_t gvpm_synth_vpm_samples(gvpm_synth *s, int it, int nb_camera_samples, const gvpm_vpm_sample **out);
 #ifdef __cplusplus

@@ -250,7 +250,9 @@ typedef struct gvpm_stats {
   uint64_t dropped_pairs; /* (photon, beam) pairs the traversal could not store: must be 0 -- gvpm_get_stats returns
                              GVPM_ERR_STATE otherwise (the image would be biased)  */
   uint64_t reserved[2];   /* [0]: G-BRE, the last build's photon cells: kind << 56 | count; kind 0 = uniform 3D grid,
-                             1 = cells over the (u, v) plane of a single-origin ray bundle   */
+                             1 = cells over the (u, v) plane of a single-origin ray bundle;
+                             [1]: packed photon records whose material index lay beyond the uploaded table (decoded with a
+                             black parent): must be 0 -- gvpm_get_stats returns GVPM_ERR_STATE otherwise           */
 } gvpm_stats;
 
 typedef struct gvpm_context gvpm_context;
@@ -323,7 +325,10 @@ int gvpm_prefetch_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uin
 /* The SoA entry points above move 120 bytes a photon and 320 a beam set over PCIe -- at C2 2.9 times the duration of the
  * step they feed.  These records carry the same inputs in 76 and 272 bytes:
  *   photons  -- wi is not sent: the device forms normalize(parent_pos - pos) (in fp64, rounded once), which is what
- *               -edge(c-1)->d is; parent_n and parent_wi travel as octahedral 2 x snorm16 (axis-aligned vectors are exact,
+ *               -edge(c-1)->d is -- to the rounding of the two fp32 positions: for a photon at distance L from its parent
+ *               the derived direction is off by up to ~1e-7 / L rad (L ~ 1e-4, one photon in a thousand at C2: 1e-3 to
+ *               1e-2 rad; tests/test_packed_upload.py bounds it).  A host that cannot accept that keeps the SoA upload
+ *               (the shim: GVPM_HIP_UPLOAD=soa); parent_n and parent_wi travel as octahedral 2 x snorm16 (axis-aligned vectors are exact,
  *               others are off by < 4e-5 rad; a zero vector stays zero); parent_scat and parent_g become an index into a
  *               table of the scene's materials (gvpm_upload_materials); path_id travels as the one bit the gather reads
  *               of it (checkerboard parity, gvpm.cpp:1020-1030) in bit 7 of flags.  Positions, flux, prefix_w and the three
@@ -373,12 +378,71 @@ int gvpm_unpack_photons(const gvpm_photon_packed *src, uint64_t n, const gvpm_ma
 /* GVPM_ERR_INVALID_ARG when a shifted ray's edge index differs from its base ray's                                       */
 int gvpm_pack_camera_beams(const gvpm_camera_ray *rays, uint64_t n_sets, gvpm_beam_set_packed *dst);
 int gvpm_unpack_camera_beams(const gvpm_beam_set_packed *src, uint64_t n_sets, gvpm_camera_ray *dst);
+/* The table may be re-uploaded at any time with MORE entries behind an unchanged prefix (what gvpm_pack_photons' appending
+ * produces): that never waits.  Changing existing entries, or growing beyond the allocated capacity, first waits for all
+ * work of the handle.  A gather that consumes packed photons without a table fails with GVPM_ERR_STATE.                   */
 int gvpm_upload_materials(gvpm_context *h, const gvpm_material *table, uint32_t n);
 /* as gvpm_upload_photons / gvpm_prefetch_photons (pageable or pinned memory; prefetch: pinned only)                       */
 int gvpm_upload_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n);
 int gvpm_prefetch_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n);
 int gvpm_upload_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
 int gvpm_prefetch_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
+
+/* ---- compact camera-beam sets (round 4) ------------------------------------*/
+/* The beam sets of a frame are most of a step's upload (272 of every 348 bytes at one set per photon-free pixel; 71 of
+ * C2's 143.6 MB).  For the FIRST medium edge of a camera path of a perspective sensor nearly all of a set is a function
+ * of the sensor: every ray starts on the line through the sensor's origin and its film position, the five film positions
+ * share their fractional offset (src/libbidir/vertex.cpp:345-346), eyeContrib = getWeightBeam(e-1) * getWeightVertex(e)
+ * is 1 (importance-sampled pinhole, null boundary), and the SVertexPDF entries enter the gather only through
+ * GatherPoint::sensorMIS (gvpm/gvpm_struct.h:608-631) = (pdf_s / pdf_b) * jacobian_s, where ShiftGatherPoint::trace /
+ * generate DEFINE jacobian_s as the reciprocal of that pdf ratio (shift_cameraPath.h:76-116,191-242: jacobian = pdf1/pdf2 *
+ * GOpBase/GOpNew against pdf = pdf2 * GOpNew; pdf2 == 0 replaces pdf2 by pdf1 in BOTH) -- the product is 1.  Such a set
+ * travels as 60 bytes: pixel, the sample's fractional film offset, the base ray's random number, a validity mask, and per
+ * ray the distance from the sensor's origin to the start of the edge (0 when the sensor sits in the medium) and the edge's
+ * length.  The device rebuilds the five rays from the sensor (gvpm_upload_sensor); deeper edges (behind a mirror or a
+ * rough vertex: their eye weight, origin and Jacobians are the path's) keep the full 272-byte records and ride along in the
+ * same upload.  What a compact set MEANS is defined by gvpm_unpack_camera_beams_compact, with which the device agrees bit
+ * for bit (fp64, no contraction).  Against the producer's own fp32 rays the decoded ones differ by rounding only: d is the
+ * sensor direction rounded once; o = fp32(origin + t0 * d) moves along the ray by the rounding of t0 (<= 6e-8 relative)
+ * and off it by half an ulp, as the producer's own fp32 o does against the exact ray; pdf = jacobian = gop = 1 carry the
+ * product above exactly where the producer's fp32 factors carry it to a few ulp.                                           */
+typedef struct gvpm_sensor {
+  double pos[3];            /* sensor origin, world space                                                                 */
+  double to_world[9];       /* row-major rotation camera -> world; camera space looks along -z, +x to the right of the
+                               film, +y towards larger pixel rows (a shim folds Mitsuba's flips into it)                  */
+  double tan_half_fov_x, tan_half_fov_y;
+  int32_t width, height;    /* film size in pixels                                                                        */
+  int32_t reserved[4];
+} gvpm_sensor;
+/* direction through film position (sx, sy), in pixels:
+ *   c = ((2 sx / width - 1) tan_half_fov_x, (2 sy / height - 1) tan_half_fov_y, -1);  d = to_world * (c / |c|)          */
+typedef struct gvpm_beam_set_compact { /* 60 bytes */
+  uint32_t pixel;           /* px | py << 16 of the base path                                                             */
+  float jitter[2];          /* film position of the base sample minus (px, py), in [0, 1); shifted path k samples
+                               (px, py) + offset_k + jitter, offsets L R T B = (-1,0) (+1,0) (0,+1) (0,-1)                */
+  float rand;               /* the base ray's `rand`                                                                      */
+  uint32_t info;            /* bit k (0 base, 1..4 L R T B): validVolumeEdge of ray k; bits 8..15: edge index e           */
+  float t0[5];              /* |vertex(e) - sensor origin| per ray                                                        */
+  float len[5];             /* edge(e)->length per ray                                                                    */
+} gvpm_beam_set_compact;
+int gvpm_upload_sensor(gvpm_context *h, const gvpm_sensor *sensor);
+/* Splits n_sets beam sets (5 rays each) into compact records and full packed records.  jitter: 2 floats per set.  A set
+ * goes to `compact` iff its decode reproduces the five rays (o, d within 4 ulp of their magnitude, len, validity and edge
+ * exactly), every eye weight is 1 and every valid shifted ray has |pdf_s / pdf_b * jacobian_s - 1| <= 1e-4; otherwise to
+ * `full`.  Both outputs need room for n_sets records.  new_index (n_sets entries, may be NULL): the index a set has in the
+ * upload made of the two lists -- compact sets first, in input order, then the full ones (G-VPM samples and shift
+ * requests name sets by that index).                                                                                     */
+int gvpm_pack_camera_beams_compact(const gvpm_sensor *sensor, const gvpm_camera_ray *rays, const float *jitter,
+                                   uint64_t n_sets, gvpm_beam_set_compact *compact, uint64_t *n_compact,
+                                   gvpm_beam_set_packed *full, uint64_t *n_full, uint32_t *new_index);
+/* dst: 5 * n_compact rays                                                                                                */
+int gvpm_unpack_camera_beams_compact(const gvpm_sensor *sensor, const gvpm_beam_set_compact *src, uint64_t n_compact,
+                                     gvpm_camera_ray *dst);
+/* as gvpm_upload_camera_beams_packed / gvpm_prefetch_camera_beams_packed: the upload holds n_compact + n_full sets       */
+int gvpm_upload_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_compact *compact, uint64_t n_compact,
+                                     const gvpm_beam_set_packed *full, uint64_t n_full);
+int gvpm_prefetch_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_compact *compact, uint64_t n_compact,
+                                       const gvpm_beam_set_packed *full, uint64_t n_full);
 
 /* ---- manifold shifts through the host (first slice) ----------------------------------------*/
 /* A photon whose shift type is 3 (EManifoldShift: a specular chain between the photon and the vertex it can be re-connected

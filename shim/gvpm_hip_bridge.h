@@ -76,6 +76,7 @@ public:
     m_config = config;
     uploadScene(scene);
     uploadMedium(scene);
+    uploadSensor(scene);
   }
 
   /* ---- once per SPPM iteration: replaces the switch at gvpm.cpp:456-474 ------------------------------------------
@@ -113,7 +114,7 @@ public:
         SLog(EError, "gvpm_hip: volume technique not available (the reference asserts on it too)");
     }
     flattenCameraBeams(scene, gatherBlocks, threadData, sampler, tech == EDistance);
-    uploadCameraBeams();
+    uploadCameraBeams();   /* (compact sets reorder the upload: m_samples' set indices are remapped there) */
     if (tech == EDistance) {
       uploadVpmState(gatherBlocks);   /* nothing to send: scaleVol / NVol live on the device (see writeBack) */
       check(gvpm_upload_vpm_samples(m_h, m_samples.data(), m_samples.size()), "gvpm_upload_vpm_samples");
@@ -197,9 +198,13 @@ private:
   std::vector<gvpm_host_shift> m_hostShifts;
 
   /* ------------------------------------------------------------------------------------------- packed uploads -- */
-  /* The per-iteration inputs cross PCIe as packed records from pinned memory (include/gvpm_hip.h "packed uploads":
-   * 76 bytes a photon instead of 120, 272 a beam set instead of 320; an asynchronous copy instead of a staged one).  The
-   * buffers are reused by the next iteration, which starts after writeBack() has waited for this one's results. */
+  /* The per-iteration inputs cross PCIe as packed records from pinned memory (include/gvpm_hip.h "packed uploads" and
+   * "compact camera-beam sets": 76 bytes a photon instead of 120; 60 bytes for the beam set of a sensor-adjacent edge of a
+   * perspective sensor, 272 for any other set, instead of 320; an asynchronous copy instead of a staged one).  The
+   * buffers are reused by the next iteration, which starts after writeBack() has waited for this one's results.
+   * Both formats are lossy in the last bits of what they re-derive (the header quantifies it); a host that wants the
+   * fp32 records moved as they are sets GVPM_HIP_UPLOAD=soa (every record as flattened) or =packed (photons packed,
+   * beam sets as the lossless 272-byte records); the default is `compact`.                                          */
   struct Pinned {
     void *p = nullptr;
     size_t cap = 0;
@@ -215,8 +220,47 @@ private:
     }
     ~Pinned() { if (p) gvpm_host_free(p); }
   };
+  enum EUploadMode { EUploadSoA = 0, EUploadPacked = 1, EUploadCompact = 2 };
+  static EUploadMode uploadMode() {
+    const char *e = getenv("GVPM_HIP_UPLOAD");
+    if (e && strcmp(e, "soa") == 0) return EUploadSoA;
+    if (e && strcmp(e, "packed") == 0) return EUploadPacked;
+    return EUploadCompact;
+  }
+  /* The sensor the compact beam sets are rebuilt from (gvpm_sensor): PerspectiveCamera::sampleRay,
+   * src/sensors/perspective.cpp:247-269 with m_cameraToSample of :150-157 -- camera space looks along +z and both film
+   * axes are flipped, d_cam ~ ((1 - 2u) tan(xfov/2), (1 - 2v) tan(xfov/2) / aspect, 1): the negated rotation of the
+   * camera-to-world transform maps the header's (cx, cy, -1) convention onto it.  Any other sensor, or a cropped
+   * film, keeps the full records.                                                                                    */
+  void uploadSensor(const Scene *scene) {
+    m_haveSensor = false;
+    const Sensor *sensor = scene->getSensor();
+    if (sensor->getClass()->getName() != "PerspectiveCamera") return;
+    const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
+    const Film *film = sensor->getFilm();
+    if (film->getCropSize() != film->getSize() || film->getCropOffset() != Point2i(0)) return;
+    const Transform trafo = cam->getWorldTransform()->eval(0.f);
+    const Matrix4x4 &mtx = trafo.getMatrix();
+    gvpm_sensor gs;
+    memset(&gs, 0, sizeof(gs));
+    const Point o = trafo.transformAffine(Point(0.0f));
+    gs.pos[0] = o.x; gs.pos[1] = o.y; gs.pos[2] = o.z;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) gs.to_world[3 * r + c] = -(double) mtx(r, c);
+    gs.tan_half_fov_x = std::tan(0.5 * degToRad((double) cam->getXFov()));
+    gs.tan_half_fov_y = gs.tan_half_fov_x / (double) cam->getAspect();
+    gs.width = film->getSize().x;
+    gs.height = film->getSize().y;
+    /* (a scaled or sheared world transform is refused by the library: the sets then stay full records) */
+    m_haveSensor = gvpm_upload_sensor(m_h, &gs) == GVPM_OK;
+    m_sensor = gs;
+  }
   void uploadPhotons() {
     const gvpm_photon_soa &v = m_soa.view();
+    if (uploadMode() == EUploadSoA) {
+      check(gvpm_upload_photons(m_h, &v), "gvpm_upload_photons");
+      return;
+    }
     if (m_materials.empty()) m_materials.resize(4096);
     gvpm_photon_packed *dst = (gvpm_photon_packed *) m_pinPhotons.get((size_t) v.n * sizeof(gvpm_photon_packed));
     uint32_t nmat = m_nMaterials;
@@ -233,12 +277,34 @@ private:
   }
   void uploadCameraBeams() {
     const size_t nsets = m_rays.size() / 5;
-    gvpm_beam_set_packed *dst = (gvpm_beam_set_packed *) m_pinRays.get(nsets * sizeof(gvpm_beam_set_packed));
-    if (gvpm_pack_camera_beams(m_rays.data(), nsets, dst) == GVPM_OK)
-      check(gvpm_upload_camera_beams_packed(m_h, dst, nsets), "gvpm_upload_camera_beams_packed");
+    const EUploadMode mode = uploadMode();
+    if (mode == EUploadSoA) {
+      check(gvpm_upload_camera_beams(m_h, m_rays.data(), nsets), "gvpm_upload_camera_beams");
+      return;
+    }
+    gvpm_beam_set_packed *full = (gvpm_beam_set_packed *) m_pinRays.get(nsets * sizeof(gvpm_beam_set_packed));
+    if (mode == EUploadCompact && m_haveSensor) {
+      gvpm_beam_set_compact *compact = (gvpm_beam_set_compact *) m_pinCompact.get(nsets * sizeof(gvpm_beam_set_compact));
+      uint64_t nc = 0, nf = 0;
+      m_newIndex.resize(nsets);
+      if (gvpm_pack_camera_beams_compact(&m_sensor, m_rays.data(), m_jitter.data(), nsets, compact, &nc, full, &nf,
+                                         m_newIndex.data()) == GVPM_OK) {
+        check(gvpm_upload_camera_beams_compact(m_h, compact, nc, full, nf), "gvpm_upload_camera_beams_compact");
+        /* compact sets first, then the full ones: the G-VPM samples name sets by their index in the upload */
+        for (gvpm_vpm_sample &sm : m_samples) sm.set = m_newIndex[sm.set];
+        return;
+      }
+    }
+    if (gvpm_pack_camera_beams(m_rays.data(), nsets, full) == GVPM_OK)
+      check(gvpm_upload_camera_beams_packed(m_h, full, nsets), "gvpm_upload_camera_beams_packed");
     else
       check(gvpm_upload_camera_beams(m_h, m_rays.data(), nsets), "gvpm_upload_camera_beams");
   }
+  Pinned m_pinCompact;
+  gvpm_sensor m_sensor;
+  bool m_haveSensor = false;
+  std::vector<float> m_jitter;          /* 2 per beam set: the base sample's film position minus its pixel */
+  std::vector<uint32_t> m_newIndex;
   Pinned m_pinPhotons, m_pinRays;
   std::vector<gvpm_material> m_materials;
   uint32_t m_nMaterials = 0;
@@ -407,6 +473,7 @@ private:
                           bool vpm) {
     m_rays.clear();
     m_samples.clear();
+    m_jitter.clear();
     const GPMConfig &cfg = m_config;
     for (auto &block : blocks) {
       for (GatherPoint &gp : block) {
@@ -441,6 +508,10 @@ private:
           for (int i = 0; i < 4; ++i)
             fillRay(set[1 + i], shiftGPs[i], e, shiftGPs[i].validVolumeEdge(e, gp.path.edge(e)->medium));
           m_rays.insert(m_rays.end(), set, set + 5);
+          /* the film position the base path was sampled at, relative to its pixel: the offset paths keep the fractional
+           * part (src/libbidir/vertex.cpp:345-346), which is all a compact set carries of the five directions            */
+          m_jitter.push_back((float) (basePixel.x - (Float) gp.pixel.x));
+          m_jitter.push_back((float) (basePixel.y - (Float) gp.pixel.y));
         }
         if (vpm) {
           /* DiscreteDistribution selBeam; normalize(); per sample sampleReuse(randSample) (gvpm.cpp:1130,1143-1150) */

@@ -56,3 +56,11 @@ def test_default_workload_reduced():
     d = run_bench("--steps", "3", "--warmup", "1", "--frame", "96", "--photons", "50000", "--cpu-iters", "1")
     check_line(d, 3)
     assert d["roofline"]["kernel"] == "evaluate_bre_kernel" and "upload_inclusive" in d
+    # the PCIe-inclusive leg replays the timed region's iterations (same input sets, same radii): same evaluation count
+    u = d["upload_inclusive"]
+    assert abs(u["evals_per_step"] - d["config"]["evals_per_iter_per_gpu"]) <= 0.01 * d["config"]["evals_per_iter_per_gpu"]
+    assert u["evals_per_step_timed_region"] == d["config"]["evals_per_iter_per_gpu"]
+    for leg in (u["packed"], u["soa"]):  # (two input sets instead of three: within the spread of the sets)
+        assert abs(leg["evals_per_step"] - u["evals_per_step"]) <= 0.1 * u["evals_per_step"]
+    assert u["sets"]["compact"] > 0 and u["sets"]["full"] == 0
+    assert u["host_bytes_per_step"] < 0.75 * u["packed"]["host_bytes_per_step"] < u["soa"]["host_bytes_per_step"]

@@ -44,10 +44,10 @@ def device_beams(c, p=None, rays=None, iters=1):
     assert st["evaluations"] == total["evaluations"], (st, total)
     for k in SHIFT_COUNTERS:
         assert abs(st[k] - total[k]) <= 2, (k, st, total)
-    assert l2(acc, ref, lum) < 1e-3
+    assert l2(acc, ref, lum) < 2e-4   # (measured 6e-6 .. 6e-5; SURVEY's bar is 1e-3)
     rfilm = O.assemble(ref, iters, True)
     for a, b in zip(film, rfilm):
-        assert l2(a, b, lum) < 1e-3
+        assert l2(a, b, lum) < 2e-4
     return acc, ref, st
 
 
@@ -170,6 +170,29 @@ def test_reconnections_among_occluders(tech, scene, scale):
     c = make_beam_case(scene, 32, 28, 12000, scale, technique=tech)
     acc, ref, st = device_beams(c)
     assert st["evaluations"] > 2000 and st["failed_shifts"] > (200 if scene == "fogroom" else 20)
+
+
+@pytest.mark.parametrize("tilt_deg", [1.5, 0.4])
+def test_a_thin_plate_grazed_by_the_beams_blocks_their_reconnections(tilt_deg, monkeypatch):
+    """S-laser's shaft runs down the y axis.  A large thin plate is stood IN the shaft, a degree or so off the beams'
+    direction: the beams' lines pierce it at grazing incidence (|cos| <= 0.05), far from all of its edges.  The free cone
+    of such a beam must not certify reconnections (beamClearTri: the pierce test runs at any incidence) -- every counter
+    equals the oracle's, which tests every new beam against every triangle, and the gather with the cone switched off."""
+    c = make_beam_case("laser", 32, 28, 12000, 2.0)
+    v0, e1, e2 = (np.array(a, np.float32) for a in c.tris)
+    t = np.tan(np.radians(tilt_deg))
+    # the plane x = 0.004 - t * y, for y in [-0.95, 0.85], z in [-0.6, 0.6]: one quad, two triangles
+    a = np.array([0.004 + t * 0.95, -0.95, -0.6]); b = np.array([0.004 - t * 0.85, 0.85, -0.6])
+    cc = np.array([0.004 - t * 0.85, 0.85, 0.6]); d = np.array([0.004 + t * 0.95, -0.95, 0.6])
+    v0 = np.vstack([v0, a, a]).astype(np.float32)
+    e1 = np.vstack([e1, b - a, cc - a]).astype(np.float32)
+    e2 = np.vstack([e2, cc - a, d - a]).astype(np.float32)
+    c.tris = (v0, e1, e2)
+    acc1, ref, st1 = device_beams(c)
+    assert st1["failed_shifts"] > 200 and st1["diffuse_shifts"] > 200
+    monkeypatch.setenv("GVPM_BEAMS_FREE_CONE", "0")
+    acc0, _, st0 = device_beams(c)
+    assert st0 == st1
 
 
 def test_free_cone_off_equals_free_cone_on(monkeypatch):

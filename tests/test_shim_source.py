@@ -111,6 +111,9 @@ def test_every_citation_names_a_file_of_the_reference():
     ("include/mitsuba/render/shape.h", ["createTriMesh"]),
     ("include/mitsuba/render/trimesh.h", ["getVertexPositions", "getTriangles", "getTriangleCount"]),
     ("include/mitsuba/render/scene.h", ["getShapes()", "getMedia()", "getSensor"]),
+    ("include/mitsuba/render/sensor.h", ["class MTS_EXPORT_RENDER PerspectiveCamera", "getXFov", "getAspect", "getWorldTransform", "getFilm"]),
+    ("include/mitsuba/render/film.h", ["getCropOffset", "getCropSize", "getSize()"]),
+    ("include/mitsuba/core/transform.h", ["getMatrix", "transformAffine"]),
 ])
 def test_members_the_bridge_touches_exist_in_the_reference(header, members):
     if not os.path.isdir(REF):
@@ -121,4 +124,4 @@ def test_members_the_bridge_touches_exist_in_the_reference(header, members):
         token = m.split("(")[0].split()[-1]
         assert token in SHIM or m in ("size()", "operator[]", "MemoryPool pool", "struct GPMThreadData", "const Path *path",
                                       "struct GPhotonNodeData", "struct LTPhotonBeam", "normalize()", "append(", "struct ShiftRecord",
-                                      "Float det(const Path &path, int b, int c)"), (header, m)
+                                      "Float det(const Path &path, int b, int c)", "class MTS_EXPORT_RENDER PerspectiveCamera"), (header, m)
