@@ -45,7 +45,8 @@ GVPM_MEDIA2MEDIA = 1 << 4
 GVPM_BSDF_DIFFUSE_REFLECTION = 0x00002
 GVPM_BSDF_ALL = 0x1FFFF
 
-GVPM_PARENT_EMITTER, GVPM_PARENT_SURFACE, GVPM_PARENT_MEDIUM = 0, 1, 2
+GVPM_PARENT_EMITTER, GVPM_PARENT_SURFACE, GVPM_PARENT_MEDIUM, GVPM_PARENT_SURFACE_BSDF = 0, 1, 2, 3
+GVPM_BSDF_PHONG = 1
 GVPM_ACCUM_FLOATS = 27
 
 
@@ -140,6 +141,11 @@ RAY_PACKED_DTYPE = np.dtype([
     ("jacobian", np.float32), ("gop", np.float32)])
 assert PHOTON_PACKED_DTYPE.itemsize == 76 and RAY_PACKED_DTYPE.itemsize == 52
 
+
+# gvpm_bsdf: a glossy surface parent's BSDF (gvpm_upload_bsdfs)
+BSDF_DTYPE = np.dtype([("kind", np.int32), ("specular", np.float32, 3), ("exponent", np.float32),
+                       ("specular_sampling_weight", np.float32), ("reserved", np.float32, 2)])
+assert BSDF_DTYPE.itemsize == 32
 
 # compact camera-beam sets (include/gvpm_hip.h, "compact camera-beam sets")
 BEAM_SET_COMPACT_DTYPE = np.dtype([

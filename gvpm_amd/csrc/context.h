@@ -302,6 +302,8 @@ struct gvpm_context {
   DevBuf<gvpm_material> materials;  // gvpm_upload_materials: the table the packed photon records index
   uint32_t nmaterials = 0;
   std::vector<gvpm_material> materialsHost;  // what the device table holds (append-only growth needs no stream sync)
+  DevBuf<float4> bsdfs;             // gvpm_upload_bsdfs: 2 float4 per glossy surface BSDF
+  uint32_t nbsdfs = 0;
   gvpm_sensor sensor{};             // gvpm_upload_sensor: what the compact beam sets are decoded with
   bool haveSensor = false;
   // photons: raw upload (owned copies or borrowed device pointers) and the built grid

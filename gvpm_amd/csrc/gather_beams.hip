@@ -345,11 +345,25 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
   d3 thr;
   double pdfValueSA;
-  if (ptype == GVPM_PARENT_SURFACE) {
+  if (ptype == GVPM_PARENT_SURFACE || ptype == GVPM_PARENT_SURFACE_BSDF) {
     const double cosWo = dot(b.parentN, newPBDir), cosWi = dot(b.parentN, b.parentWi);
     if (cosWi <= 0 || cosWo <= 0) return 1.0;  // eval = pdf = 0 (or the shading-normal reject): sRec.pdf == 0
     thr = b.parentScat * (INV_PI * cosWo);
     pdfValueSA = INV_PI * cosWo;
+    if (ptype == GVPM_PARENT_SURFACE_BSDF) {
+      // a glossy parent (gvpm_upload_bsdfs): Phong with both components, src/bsdfs/phong.cpp:121-186
+      const uint32_t bi = (uint32_t)b.parentG;
+      if (!(b.parentG >= 0.0) || bi >= a.nbsdfs) return 1.0;
+      const float4 b0 = a.bsdfs[2 * bi], b1 = a.bsdfs[2 * bi + 1];
+      if (__float_as_int(b0.x) != GVPM_BSDF_PHONG) return 1.0;
+      const double e = b1.x, w = b1.y;
+      const d3 refl = b.parentN * (2.0 * cosWi) - b.parentWi;
+      const double alpha = dot(newPBDir, refl);
+      const double lobe = alpha > 0 ? pow(alpha, e) : 0.0;
+      const double INV_TWOPI = 0.15915494309189533577;
+      thr = (mkd(b0.y, b0.z, b0.w) * ((e + 2.0) * INV_TWOPI * lobe) + b.parentScat * INV_PI) * cosWo;
+      pdfValueSA = w * (lobe * (e + 1.0) * INV_TWOPI) + (1.0 - w) * (INV_PI * cosWo);
+    }
   } else if (ptype == GVPM_PARENT_MEDIUM) {
     const double p = phaseD(b.parentG, b.parentWi, newPBDir);
     thr = b.parentScat * p;
@@ -755,11 +769,14 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
   f3 thr;
   float pdfValueSA;
-  if (ptype == GVPM_PARENT_SURFACE) {
+  if (ptype == GVPM_PARENT_SURFACE || ptype == GVPM_PARENT_SURFACE_BSDF) {
     const float cosWo = dot(b.parentN, nd), cosWi = dot(b.parentN, b.parentWi);
     if (cosWi <= 0.f || cosWo <= 0.f) return 1.f;
     thr = b.parentScat * (INV_PI_F * cosWo);
     pdfValueSA = INV_PI_F * cosWo;
+    if (ptype == GVPM_PARENT_SURFACE_BSDF &&
+        !glossyParentEval(a, b.parentG, b.parentScat, b.parentN, b.parentWi, nd, cosWi, cosWo, thr, pdfValueSA))
+      return 1.f;
   } else if (ptype == GVPM_PARENT_MEDIUM) {
     const float ph = phaseEval(b.parentG, b.parentWi, nd);
     thr = b.parentScat * ph;

@@ -338,6 +338,8 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.kernelRadius = r;
   a.subLen = 0.f;
   a.nbeams = 0;
+  a.bsdfs = h->bsdfs.p;
+  a.nbsdfs = h->nbsdfs;
 }
 
 static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, int phase = 0) {

@@ -297,6 +297,30 @@ int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *m) {
   return GVPM_OK;
 }
 
+int gvpm_upload_bsdfs(gvpm_context *h, const gvpm_bsdf *table, uint32_t n) {
+  CHECK_H(h);
+  if (n && !table) return fail(h, GVPM_ERR_INVALID_ARG, "null bsdf table");
+  if (n > (1u << 24)) return fail(h, GVPM_ERR_INVALID_ARG, "more than 2^24 bsdfs (the index travels as a float)");
+  std::vector<float4> rows(2 * (size_t)n + 2);
+  for (uint32_t i = 0; i < n; ++i) {
+    const gvpm_bsdf &b = table[i];
+    if (b.kind != GVPM_BSDF_PHONG) return fail(h, GVPM_ERR_UNSUPPORTED, "bsdf kind outside the device's closed set (Phong)");
+    if (!(b.exponent >= 0.f) || !(b.specular_sampling_weight >= 0.f && b.specular_sampling_weight <= 1.f))
+      return fail(h, GVPM_ERR_INVALID_ARG, "Phong: exponent >= 0 and a sampling weight in [0, 1]");
+    float kindBits;
+    memcpy(&kindBits, &b.kind, 4);
+    rows[2 * i] = make_float4(kindBits, b.specular[0], b.specular[1], b.specular[2]);
+    rows[2 * i + 1] = make_float4(b.exponent, b.specular_sampling_weight, 0.f, 0.f);
+  }
+  // once per scene: waits for whatever still reads the old table
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->streamB));
+  HIP_TRY(h, h->bsdfs.ensure(rows.size()));
+  HIP_TRY(h, hipMemcpy(h->bsdfs.p, rows.data(), rows.size() * sizeof(float4), hipMemcpyHostToDevice));
+  h->nbsdfs = n;
+  return GVPM_OK;
+}
+
 int gvpm_download_vpm_state(gvpm_context *h, float *scale_vol, float *n_vol) {
   CHECK_H(h);
   if (!scale_vol || !n_vol) return GVPM_ERR_INVALID_ARG;

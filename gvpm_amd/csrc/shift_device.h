@@ -221,6 +221,28 @@ __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx
   return c;
 }
 
+// A glossy surface parent (GVPM_PARENT_SURFACE_BSDF): BSDF::eval and BSDF::pdf * pdfComponent of the table entry the
+// record names, towards the new direction `wo` (shift_diffuse.cpp:25-41 with bRec.component = -1).  Phong, src/bsdfs/
+// phong.cpp:121-186: eval = (ks (e + 2) / 2pi alpha^e + kd / pi) cos_o, pdf = w alpha^e (e + 1) / 2pi + (1 - w) cos_o / pi,
+// alpha = wo . reflect(wi).  cosWi, cosWo > 0 is the caller's test.  False: no such entry (a failed shift).
+__device__ __forceinline__ bool glossyParentEval(const GatherArgs &a, float index, f3 kd, f3 n, f3 wi, f3 wo, float cosWi,
+                                                 float cosWo, f3 &f, float &pdf) {
+  const uint32_t bi = (uint32_t)index;
+  f = mk3(0.f);
+  pdf = 0.f;
+  if (!(index >= 0.f) || bi >= a.nbsdfs) return false;
+  const float4 b0 = a.bsdfs[2 * bi], b1 = a.bsdfs[2 * bi + 1];
+  if (__float_as_int(b0.x) != GVPM_BSDF_PHONG) return false;
+  const float e = b1.x, w = b1.y;
+  const f3 refl = n * (2.f * cosWi) - wi;
+  const float alpha = dot(wo, refl);
+  const float lobe = alpha > 0.f ? __builtin_exp2f(e * __builtin_log2f(alpha)) : 0.f;  // std::pow(alpha, exponent)
+  const float INV_TWOPI_F = 0.15915494309189533577f;
+  f = (mk3(b0.y, b0.z, b0.w) * ((e + 2.f) * INV_TWOPI_F * lobe) + kd * INV_PI_F) * cosWo;
+  pdf = w * (lobe * (e + 1.f) * INV_TWOPI_F) + (1.f - w) * (INV_PI_F * cosWo);
+  return true;
+}
+
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.
 // Written branch-free apart from the shadow-ray loop: every early `return false` of the reference
 // (shift_volume_photon.cpp:398-412, shift_diffuse.cpp:43-47, 100-104, :463-470) clears `good`, the
@@ -241,15 +263,20 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const float cosWo = dot(ph.parentN, dProj);
   // surface / emitter parents: the offset direction must leave on the side the photon left (sign of
   // dot(n, dProj) / dot(n, -wi))
-  const bool isMedium = ptype == GVPM_PARENT_MEDIUM, isSurface = ptype == GVPM_PARENT_SURFACE;
+  const bool isMedium = ptype == GVPM_PARENT_MEDIUM, isGlossy = ptype == GVPM_PARENT_SURFACE_BSDF;
+  const bool isSurface = ptype == GVPM_PARENT_SURFACE || isGlossy;
   good = good && (isMedium || cosWo * dot(ph.parentN, -ph.wi) >= 0.f);
   // eval / pdf of the parent towards the offset position (diffuse.cpp:110-127, phase eval, area.cpp:132-150)
   const float cosWi = dot(ph.parentN, ph.parentWi);
   good = good && (!isSurface || (cosWi > 0.f && cosWo > 0.f));  // eval/pdf = 0 or the shading-normal reject
   const float lam = INV_PI_F * fmaxf(cosWo, 0.f);
   const float pMed = phaseEval(ph.parentG, ph.parentWi, dProj);
-  const float pdfValue = isMedium ? pMed : lam;
+  float pdfValue = isMedium ? pMed : lam;
   f3 thr = isSurface ? ph.parentScat * lam : (isMedium ? ph.parentScat * pMed : mk3(lam));
+  if (isGlossy) {
+    // (a branch of its own: scenes without glossy walls pay one wave-uniform test)
+    if (!glossyParentEval(a, ph.parentG, ph.parentScat, ph.parentN, ph.parentWi, dProj, cosWi, cosWo, thr, pdfValue)) good = false;
+  }
   const float gop = frcp(l2Proj);
   float sPdf = pdfValue * gop;
   good = good && ph.parentPdf != 0.f;

@@ -268,6 +268,12 @@ int gvpm_devgen_create(const gvpm_devgen_scene *sc, int device, gvpm_devgen **ou
   for (uint32_t i = 0; i < sc->n_mats; ++i) {
     mats[i].kind = sc->mat_kind[i];
     mats[i].albedo = V3(sc->mat_albedo[3 * i], sc->mat_albedo[3 * i + 1], sc->mat_albedo[3 * i + 2]);
+    mats[i].spec = V3(0.0);
+    mats[i].exponent = mats[i].specWeight = 0.0;
+    mats[i].bsdf = -1;
+    // (the device generators' closed set: Lambertian, index-matched boundary, mirror -- a Phong wall's parameters do not
+    // travel in gvpm_devgen_scene: such scenes are shot on the host)
+    if (mats[i].kind < 0 || mats[i].kind > MAT_MIRROR) return bail(GVPM_ERR_UNSUPPORTED);
   }
   if (g->tris.ensure(tris.size() + 1) != hipSuccess || g->mats.ensure(mats.size() + 1) != hipSuccess) return bail(GVPM_ERR_HIP);
   if (!tris.empty() && hipMemcpy(g->tris.p, tris.data(), tris.size() * sizeof(SynthTri), hipMemcpyHostToDevice) != hipSuccess)

@@ -32,7 +32,7 @@ SYMBOLS = [
     "gvpm_prefetch_camera_beams_packed",
     "gvpm_enable_host_shifts", "gvpm_download_shift_requests", "gvpm_upload_host_shifts",
     "gvpm_upload_sensor", "gvpm_pack_camera_beams_compact", "gvpm_unpack_camera_beams_compact",
-    "gvpm_upload_camera_beams_compact", "gvpm_prefetch_camera_beams_compact",
+    "gvpm_upload_camera_beams_compact", "gvpm_prefetch_camera_beams_compact", "gvpm_upload_bsdfs",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         L.gvpm_prefetch_photons_packed.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_upload_camera_beams_packed.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_prefetch_camera_beams_packed.argtypes = [vp, vp, C.c_uint64]
+        L.gvpm_upload_bsdfs.argtypes = [vp, vp, C.c_uint32]
         L.gvpm_upload_sensor.argtypes = [vp, C.POINTER(abi.Sensor)]
         L.gvpm_pack_camera_beams_compact.argtypes = [C.POINTER(abi.Sensor), vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64), vp,
                                                      C.POINTER(C.c_uint64), vp]
@@ -388,6 +389,11 @@ class Context:
         packed = np.ascontiguousarray(packed)
         n = packed.nbytes // 272
         self._check(lib().gvpm_upload_camera_beams_packed(self._h, packed.ctypes.data if n else None, n))
+
+    def upload_bsdfs(self, table):
+        """table: numpy array of abi.BSDF_DTYPE (the scene's glossy surfaces)"""
+        table = np.ascontiguousarray(table, abi.BSDF_DTYPE)
+        self._check(lib().gvpm_upload_bsdfs(self._h, table.ctypes.data if table.size else None, table.size))
 
     def upload_sensor(self, sensor):
         self._check(lib().gvpm_upload_sensor(self._h, C.byref(sensor)))

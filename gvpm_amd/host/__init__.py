@@ -41,6 +41,8 @@ def lib():
         L.gvpm_synth_beams_interleaved.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.gvpm_synth_planes.restype = C.c_uint64
         L.gvpm_synth_planes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.gvpm_synth_bsdfs.restype = C.c_uint32
+        L.gvpm_synth_bsdfs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.gvpm_synth_sensor.argtypes = [C.c_void_p, C.POINTER(abi.Sensor)]
         L.gvpm_synth_jitter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _LIB = L
@@ -81,6 +83,14 @@ class SynthScene:
             buf = (C.c_float * (3 * n)).from_address(ptr)
             out.append(np.array(buf, np.float32).reshape(n, 3).copy())
         return tuple(out)
+
+    def bsdfs(self):
+        """the BSDF table of the scene's glossy walls (numpy, abi.BSDF_DTYPE; empty for the Lambertian scenes)"""
+        n = lib().gvpm_synth_bsdfs(self._h, None, 0)
+        out = np.zeros(n, abi.BSDF_DTYPE)
+        if n:
+            lib().gvpm_synth_bsdfs(self._h, out.ctypes.data, n)
+        return out
 
     def sensor(self):
         """the scene's pinhole sensor (gvpm_sensor) the compact beam sets are decoded with"""

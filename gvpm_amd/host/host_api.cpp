@@ -134,6 +134,24 @@ uint64_t gvpm_synth_beams_interleaved(gvpm_synth *s, int it, int tile_mod, int t
   return s->rays.size() / 5;
 }
 
+uint32_t gvpm_synth_bsdfs(const gvpm_synth *s, gvpm_bsdf *out, uint32_t cap) {
+  if (!s) return 0;
+  uint32_t n = 0;
+  for (const auto &m : s->scene.mats) {
+    if (m.kind != gvpm::MAT_PHONG) continue;
+    if (out && (uint32_t)m.bsdf < cap) {
+      gvpm_bsdf &b = out[m.bsdf];
+      memset(&b, 0, sizeof(b));
+      b.kind = GVPM_BSDF_PHONG;
+      b.specular[0] = (float)m.spec.x; b.specular[1] = (float)m.spec.y; b.specular[2] = (float)m.spec.z;
+      b.exponent = (float)m.exponent;
+      b.specular_sampling_weight = (float)m.specWeight;
+    }
+    ++n;
+  }
+  return n;
+}
+
 int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out) {
   if (!s || !out) return GVPM_ERR_INVALID_ARG;
   memset(out, 0, sizeof(*out));

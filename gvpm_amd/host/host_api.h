@@ -29,6 +29,9 @@ uint64_t gvpm_synth_planes(gvpm_synth *s, int it, const float **w1, const float 
 /* camera beam sets of the pixel rectangle; returns the number of sets */
 uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
                           const gvpm_camera_ray **out);
+/* the BSDF table of the scene's glossy (Phong) walls, in the order the photons' parent_g name them (gvpm_upload_bsdfs);
+ * returns the number of entries (at most cap are written) */
+uint32_t gvpm_synth_bsdfs(const gvpm_synth *s, gvpm_bsdf *out, uint32_t cap);
 /* the scene's pinhole sensor as the compact beam sets take it (gvpm_upload_sensor, include/gvpm_hip.h) */
 int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out);
 /* the fractional film offsets (2 floats per set) the base paths of `rays` (5 per set) of iteration `it` were sampled at:

@@ -104,11 +104,27 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
   s.maxDepth = 12;  // scripts/scene/generatorGVPM.py:39-85 paper settings
   s.rrDepth = 1;
   s.minDepth = 0;
-  s.mats.push_back({MAT_LAMBERT, V3(0.5, 0.5, 0.5)});       // 0 white
-  s.mats.push_back({MAT_LAMBERT, V3(0.63, 0.065, 0.05)});    // 1 red (left)
-  s.mats.push_back({MAT_LAMBERT, V3(0.14, 0.45, 0.091)});    // 2 green (right)
-  s.mats.push_back({MAT_NULL, V3(0, 0, 0)});                 // 3 medium boundary (front)
-  if (name == "cbox") {
+  s.mats.push_back({MAT_LAMBERT, V3(0.5, 0.5, 0.5), V3(0.0), 0.0, 0.0, -1});       // 0 white
+  s.mats.push_back({MAT_LAMBERT, V3(0.63, 0.065, 0.05), V3(0.0), 0.0, 0.0, -1});    // 1 red (left)
+  s.mats.push_back({MAT_LAMBERT, V3(0.14, 0.45, 0.091), V3(0.0), 0.0, 0.0, -1});    // 2 green (right)
+  s.mats.push_back({MAT_NULL, V3(0, 0, 0), V3(0.0), 0.0, 0.0, -1});                 // 3 medium boundary (front)
+  if (name == "cbox_phong" || name == "cbox_phong_hg") {
+    // S-cbox with GLOSSY walls: floor and back wall are Phong surfaces (a polished floor, exponent 40;
+    // a satin wall, exponent 12), so that a large part of the photons are re-connected through a non-Lambertian parent
+    auto phong = [&](V3 kd, V3 ks, double e) {
+      auto lum = [](V3 c) { return 0.212671 * c.x + 0.715160 * c.y + 0.072169 * c.z; };  // Spectrum::getLuminance, RGB
+      SynthMat m{MAT_PHONG, kd, ks, e, lum(ks) / (lum(kd) + lum(ks)), 0};
+      m.bsdf = 0;
+      for (const auto &q : s.mats) m.bsdf += q.kind == MAT_PHONG ? 1 : 0;
+      s.mats.push_back(m);
+      return (int)s.mats.size() - 1;
+    };
+    const int mFloor = phong(V3(0.3, 0.3, 0.3), V3(0.5, 0.5, 0.45), 40.0);
+    const int mBack = phong(V3(0.2, 0.25, 0.4), V3(0.3, 0.3, 0.3), 12.0);
+    addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
+    setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
+    setMedium(s, 0.5, 0.5, name == "cbox_phong_hg" ? 0.7 : 0.0);
+  } else if (name == "cbox") {
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, 0.0);
@@ -154,7 +170,7 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     // edges (sensor -> mirror -> a diffuse wall), light paths get Dirac vertices (manifold-type shifts).  Back wall:
     // perpendicular to the optical axis (the sensor's area pdf is constant over it); `_side`: the left wall, met at
     // grazing angles (pdf, Jacobian and GOp of the shifted paths all differ from the base path's)
-    s.mats.push_back({MAT_MIRROR, V3(0.9, 0.85, 0.8)});  // 4
+    s.mats.push_back({MAT_MIRROR, V3(0.9, 0.85, 0.8), V3(0.0), 0.0, 0.0, -1});  // 4
     if (name == "cbox_mirror") addBoxRoom(s, 0, 0, 4, 1, 2, 0);
     else addBoxRoom(s, 0, 0, 0, 4, 2, 0);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);

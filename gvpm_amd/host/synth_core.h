@@ -17,7 +17,10 @@ namespace gvpm {
 
 // MAT_MIRROR: perfect specular reflector (a Dirac BSDF, reflectance = albedo): what puts a SECOND medium edge on a
 // camera path (randomWalkFromPixelToFirstDiffuse walks on past smooth vertices) and a non-diffuse vertex on light paths
-enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2 };
+// MAT_PHONG: the modified Phong BSDF of src/bsdfs/phong.cpp, both components sampled together (roughness >= 0.05, so
+// that PathVertex::sampleNext keeps sampledComponentIndex = -1, vertex.cpp:160-180): a GLOSSY wall that still classifies
+// as diffuse for the reconnection (gvpm_struct.h:66-100) -- the parent type GVPM_PARENT_SURFACE_BSDF of the ABI
+enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3 };
 
 struct SynthTri {
   V3 v0, e1, e2, n;  // n: geometric normal (front side)
@@ -25,7 +28,11 @@ struct SynthTri {
 };
 struct SynthMat {
   int kind;
-  V3 albedo;
+  V3 albedo;          // Lambertian / mirror reflectance; Phong: the diffuse reflectance
+  V3 spec;            // Phong: specular reflectance
+  double exponent;    // Phong exponent
+  double specWeight;  // m_specularSamplingWeight = lum(spec) / (lum(diffuse) + lum(spec)), phong.cpp:93-97
+  int bsdf;           // index in the table of gvpm_upload_bsdfs (-1: none)
 };
 
 // what the generators read of a scene (SynthScene::view(); the device gets the arrays in HBM)
@@ -98,6 +105,8 @@ struct LVertex {
   bool eMedium;
   V3 albedo;
   int matKind;
+  int mat;          // material index of a surface vertex (-1 otherwise)
+  uint32_t comp;    // componentType of a sampled surface vertex (BSDF::EBSDFType of the sampled lobe)
 };
 
 // a light path: at most maxDepth + 1 vertices
@@ -159,12 +168,16 @@ GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
   v0.ePdf = 1.0;
   v0.eMedium = true;
   v0.matKind = -1;
+  v0.mat = -1;
+  v0.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
   double u1 = rng.next1D(), u2 = rng.next1D();
   LVertex v1;
   v1.type = VT_EMITTER;
   v1.pos = sc.lightC + sc.lightU * (u1 - 0.5) + sc.lightV * (u2 - 0.5);
   v1.n = sc.lightN;
   v1.matKind = -1;
+  v1.mat = -1;
+  v1.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
   path.push_back(v0);
   path.push_back(v1);
 
@@ -197,6 +210,40 @@ GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
         cur.weight = cur.albedo;
         cur.pdf = 1.0;
         solidAngle = false;
+        if (maxc(cur.weight) <= 0) break;
+      } else if (cur.matKind == MAT_PHONG) {
+        // Phong::sample with bRec.component = -1 (phong.cpp:188-247): the sample picks the lobe, weight = eval / pdf of the
+        // WHOLE BSDF, pdf = the mixture's (:157-186)
+        const SynthMat &pm = sc.mats[cur.mat];
+        const double sw = pm.specWeight, e = pm.exponent, cosWi = dot(cur.n, wi);
+        const V3 refl = cur.n * (2.0 * cosWi) - wi;  // reflect(wi) in world space
+        double sx = a;
+        bool choseSpecular = true;
+        if (sx <= sw) {
+          sx /= sw;
+        } else {
+          sx = (sx - sw) / (1 - sw);
+          choseSpecular = false;
+        }
+        if (choseSpecular) {
+          const double sinAlpha = std::sqrt(std::fmax(0.0, 1 - std::pow(b, 2 / (e + 1))));
+          const double cosAlpha = std::pow(b, 1 / (e + 1));
+          const double phi = 2.0 * kPi * sx;
+          wo = toWorld(refl, V3(sinAlpha * std::cos(phi), sinAlpha * std::sin(phi), cosAlpha));
+          cur.comp = 0x00008u;  // EGlossyReflection
+        } else {
+          wo = toWorld(cur.n, cosineHemisphere(sx, b));
+          cur.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+        }
+        const double cosWo = dot(cur.n, wo);
+        if (cosWo <= 0) break;
+        const double alpha = dot(wo, refl);
+        const double lobe = alpha > 0 ? std::pow(alpha, e) : 0.0;
+        const double pdfW = sw * lobe * (e + 1) / (2.0 * kPi) + (1 - sw) * cosWo * kInvPi;
+        if (pdfW == 0) break;
+        const V3 f = (pm.spec * ((e + 2) / (2.0 * kPi) * lobe) + pm.albedo * kInvPi) * cosWo;
+        cur.weight = f * (1.0 / pdfW);
+        cur.pdf = pdfW;
         if (maxc(cur.weight) <= 0) break;
       } else {
         V3 local = cosineHemisphere(a, b);
@@ -245,6 +292,7 @@ GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
       succ.pos = cur.pos + wo * len;
       succ.n = V3(0, 0, 0);
       succ.matKind = -1;
+      succ.mat = -1;
       succ.albedo = V3(0.0);
     } else if (surface) {
       succ.type = VT_SURFACE;
@@ -253,10 +301,12 @@ GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
       const SynthTri &tri = sc.tris[hit.tri];
       succ.n = tri.n;
       succ.matKind = sc.mats[tri.mat].kind;
+      succ.mat = tri.mat;
       succ.albedo = sc.mats[tri.mat].albedo;
     } else {
       break;
     }
+    succ.comp = succ.matKind == MAT_MIRROR ? 0x00008u : GVPM_BSDF_DIFFUSE_REFLECTION;
     if (len == 0) break;
     tr = std::exp(-sigT * len);
     pdfSuccess = sigT * tr * msw;
@@ -296,7 +346,9 @@ GVPM_HD inline bool cameraHit(const SceneView &sc, V3 org, V3 dest) {
 GVPM_HD inline bool vertexIsDiffuse(const SceneView &sc, const LVertex &v) {
   switch (v.type) {
     case VT_EMITTER: return true;
-    case VT_SURFACE: return v.matKind == MAT_LAMBERT;
+    // (Phong: the Beckmann-equivalent roughness sqrt(2 / (2 + exponent)) of its glossy lobe, phong.cpp:293-300, is far
+    // above bounceRoughness = 0.001 for every exponent the both-components branch admits)
+    case VT_SURFACE: return v.matKind == MAT_LAMBERT || v.matKind == MAT_PHONG;
     case VT_MEDIUM: return !(sc.medium.g > 0.5);
     default: return false;
   }
@@ -338,10 +390,15 @@ GVPM_HD inline void fillParent(const SceneView &sc, const LPath &path, size_t ip
   r.parentScat = V3(0.0);
   r.parentWi = V3(1.0, 0.0, 0.0);
   ptype = GVPM_PARENT_EMITTER;
+  r.parentG = sc.medium.g;
   if (par.type == VT_SURFACE) {
     ptype = GVPM_PARENT_SURFACE;
     r.parentScat = par.albedo;
     r.parentWi = normalize(path[ip - 1].pos - par.pos);
+    if (par.matKind == MAT_PHONG) {
+      ptype = GVPM_PARENT_SURFACE_BSDF;
+      r.parentG = (float)sc.mats[par.mat].bsdf;
+    }
   } else if (par.type == VT_MEDIUM) {
     ptype = GVPM_PARENT_MEDIUM;
     r.parentScat = V3(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
@@ -350,7 +407,6 @@ GVPM_HD inline void fillParent(const SceneView &sc, const LPath &path, size_t ip
   r.parentPdf = (float)par.pdf;
   r.edgePdf = (float)par.ePdf;
   r.parentRR = (float)par.rr;
-  r.parentG = sc.medium.g;
 }
 
 // LTBeamMap::tryAppendLT + LTPhotonBeam (gvpm/gvpm_beams.h:18-84) without capacity / pathID bookkeeping.
@@ -412,11 +468,17 @@ template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const L
     r.parentScat = V3(0.0);
     r.parentWi = V3(1.0, 0.0, 0.0);
     uint32_t ptype = GVPM_PARENT_EMITTER, comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+    r.parentG = sc.medium.g;
     if (par.type == VT_SURFACE) {
       if (par.matKind == MAT_MIRROR) comp = 0x00008u;  // BSDF::EDeltaReflection
       ptype = GVPM_PARENT_SURFACE;
       r.parentScat = par.albedo;
       r.parentWi = normalize(path[i - 2].pos - par.pos);
+      if (par.matKind == MAT_PHONG) {
+        ptype = GVPM_PARENT_SURFACE_BSDF;
+        r.parentG = (float)sc.mats[par.mat].bsdf;
+        comp = par.comp;  // the sampled lobe's type: EGlossyReflection or EDiffuseReflection (vertex.cpp:178-179)
+      }
     } else if (par.type == VT_MEDIUM) {
       ptype = GVPM_PARENT_MEDIUM;
       r.parentScat = V3(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
@@ -425,7 +487,6 @@ template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const L
     r.parentPdf = (float)par.pdf;
     r.edgePdf = (float)par.ePdf;
     r.parentRR = (float)par.rr;
-    r.parentG = sc.medium.g;
     r.flags = GVPM_PF_MAKE(ptype, typeShift(sc, path, i), par.eMedium ? 1 : 0, i - 1, comp);
     recs.push_back(r);
   }

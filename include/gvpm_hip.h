@@ -108,6 +108,10 @@ enum {
 #define GVPM_PARENT_EMITTER 0u  /* PathVertex::EEmitterSample (area light)    */
 #define GVPM_PARENT_SURFACE 1u  /* ESurfaceInteraction, Lambertian closed set */
 #define GVPM_PARENT_MEDIUM 2u   /* EMediumInteraction                         */
+#define GVPM_PARENT_SURFACE_BSDF 3u /* ESurfaceInteraction whose BSDF is entry
+                                   (uint32_t) parent_g of the table of
+                                   gvpm_upload_bsdfs (a glossy parent, round 4);
+                                   parent_scat = its diffuse reflectance       */
 #define GVPM_PF_PARENT_TYPE(f) ((f) & 3u)
 /* result of getTypeShift() (gvpm/shift/shift_utilities.h:112-136) -- a pure
  * function of the light path, evaluated by the host at flattening time:
@@ -166,6 +170,30 @@ typedef struct gvpm_medium {
   float medium_sampling_weight; /* 1 after computeOnlyVolumeInteraction()      */
   float reserved[5];
 } gvpm_medium;
+
+/* ---- glossy surface parents ------------------------------*/
+/* diffuseReconnection re-evaluates the BSDF of the vertex a photon is re-connected from towards the offset position
+ * (gvpm/shift/operation/shift_diffuse.cpp:25-47: BSDF::eval, BSDF::pdf * pdfComponent with
+ * bRec.component = parent->sampledComponentIndex).  The device's closed set: the Lambertian of GVPM_PARENT_SURFACE
+ * (src/bsdfs/diffuse.cpp:110-127) and the BSDFs of this table, named by photons of parent type
+ * GVPM_PARENT_SURFACE_BSDF through parent_g (an index, stored as a float).
+ *   GVPM_BSDF_PHONG  the modified Phong model of src/bsdfs/phong.cpp with BOTH components, i.e. a vertex whose
+ *     sampledComponentIndex is -1 -- what PathVertex::sampleNext records for every Phong surface of roughness
+ *     sqrt(2 / (2 + exponent)) >= 0.05 (exponent <= 798; vertex.cpp:160-165 with Phong::sampleComponent, phong.cpp:311-330):
+ *       eval(wi, wo) = (specular (exponent + 2) / (2 pi) alpha^exponent [alpha > 0] + diffuse / pi) cos(theta_o)   :121-150
+ *       pdf(wi, wo)  = w alpha^exponent (exponent + 1) / (2 pi) [alpha > 0] + (1 - w) cos(theta_o) / pi          :157-186
+ *     with alpha = wo . reflect(wi), w = specular_sampling_weight, both zero unless cos(theta_i), cos(theta_o) > 0;
+ *     pdfComponent = 1.  Such a vertex classifies as DIFFUSE for every roughness above bounceRoughness (default 0.001,
+ *     gvpm_struct.h:66-100,232-236): its photons are re-connected through it like through a Lambertian wall.
+ * A surface parent outside the closed set stays what it was: the host flags the photon's shift type 0 (failed shift).   */
+enum { GVPM_BSDF_PHONG = 1 };
+typedef struct gvpm_bsdf {    /* 32 bytes */
+  int32_t kind;               /* GVPM_BSDF_PHONG                                                        */
+  float specular[3];          /* m_specularReflectance (after ensureEnergyConservation, phong.cpp:86-91) */
+  float exponent;             /* m_exponent                                                             */
+  float specular_sampling_weight; /* m_specularSamplingWeight, phong.cpp:93-97                          */
+  float reserved[2];
+} gvpm_bsdf;
 
 /* ---- scene occluders for scene->rayIntersect(Ray) ------------------------*/
 /* call sites shift_volume_photon.cpp:398, shift_volume_beams.cpp:421.
@@ -271,6 +299,9 @@ int gvpm_reset(gvpm_context *h);
 /* ---- uploads --------------------------------------------------------------*/
 int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *tris);
 int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *medium);
+/* the BSDF table of the scene's glossy surfaces (once per scene, before the first gather that meets a photon of parent
+ * type GVPM_PARENT_SURFACE_BSDF; such a photon with an index beyond the table is a failed shift)                       */
+int gvpm_upload_bsdfs(gvpm_context *h, const gvpm_bsdf *table, uint32_t n);
 /* per iteration: replaces the proc->getPhotonVolumeMap() of gvpm.cpp:450-454  */
 int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *photons);
 /* G-Beams, per iteration: replaces proc->getBeamMap() (gvpm.cpp:449).  One record per LTPhotonBeam

@@ -327,6 +327,43 @@ template <typename F> inline void coordinateSystemCoherent(const Vec3<F> &n, Vec
 // The per-photon functors.  AbstractVolumeGradientRecord + VolumeGradientBREQuery
 // (gvpm/shift/shift_volume_photon.{h,cpp}).
 // ---------------------------------------------------------------------------
+// The BSDF table of the scene's glossy surfaces (include/gvpm_hip.h, gvpm_upload_bsdfs), set by oracle_set_bsdfs before a
+// gather (test infrastructure: one table per process).
+inline std::vector<gvpm_bsdf> &bsdfTable() {
+  static std::vector<gvpm_bsdf> t;
+  return t;
+}
+
+// Phong::eval / Phong::pdf, src/bsdfs/phong.cpp:121-186, with bRec.component = -1 (hasSpecular && hasDiffuse) and
+// pdfComponent = 1 (:332-334), in the LOCAL frame of the intersection as the reference evaluates them: Frame(n) with
+// coordinateSystem(n) (frame.h:37-80; the value does not depend on the tangents).  wi, wo: world-space unit vectors.
+template <typename F>
+inline bool phongEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n, const Vec3<F> &wiW, const Vec3<F> &woW,
+                         Vec3<F> &f, F &pdf) {
+  typedef Vec3<F> V;
+  const F INV_PI = (F)0.31830988618379067154, INV_TWOPI = (F)0.15915494309189533577, M_PI_F = (F)3.14159265358979323846;
+  V s, t;
+  coordinateSystem(n, s, t);
+  const V wi(dot(wiW, s), dot(wiW, t), dot(wiW, n)), wo(dot(woW, s), dot(woW, t), dot(woW, n));  // its.toLocal
+  f = V((F)0);
+  pdf = 0;
+  if (wi.z <= 0 || wo.z <= 0) return false;   // Frame::cosTheta(bRec.wi) <= 0 || Frame::cosTheta(bRec.wo) <= 0
+  const V refl(-wi.x, -wi.y, wi.z);            // reflect(wi), :117-119
+  const F alpha = dot(wo, refl), exponent = (F)b.exponent;
+  V result((F)0);
+  F specProb = 0;
+  if (alpha > 0) {
+    result += V((F)b.specular[0], (F)b.specular[1], (F)b.specular[2]) * ((exponent + 2) * INV_TWOPI * std::pow(alpha, exponent));
+    specProb = std::pow(alpha, exponent) * (exponent + (F)1) / ((F)2 * M_PI_F);
+  }
+  result += kd * INV_PI;
+  f = result * wo.z;
+  const F diffuseProb = INV_PI * wo.z;         // warp::squareToCosineHemispherePdf
+  const F w = (F)b.specular_sampling_weight;
+  pdf = w * specProb + (1 - w) * diffuseProb;
+  return true;
+}
+
 template <typename F> struct GatherContext {
   gvpm_params cfg;
   Medium<F> medium;
@@ -401,6 +438,21 @@ template <typename F> struct VolumeGradientRecord {
       pdfValue *= (F)1;  // pdfComponent
       F wiDotGeoN = cosWi, woDotGeoN = cosWo;
       if (wiDotGeoN * cosWi <= 0 || woDotGeoN * cosWo <= 0) return false;
+    } else if (ptype == GVPM_PARENT_SURFACE_BSDF) {
+      // a glossy parent: BSDF::eval, BSDF::pdf * pdfComponent of the table's entry (shift_diffuse.cpp:25-41)
+      const std::vector<gvpm_bsdf> &tab = bsdfTable();
+      const size_t bi = (size_t)ph.parentG;
+      if (!(ph.parentG >= 0) || bi >= tab.size() || tab[bi].kind != GVPM_BSDF_PHONG) {
+        sRec.throughtput *= V((F)0);  // outside the closed set: a failed shift, as the device makes of it
+        sRec.pdf = 0;
+        return false;
+      }
+      V f;
+      phongEvalPdf<F>(tab[bi], ph.parentScat, ph.parentN, ph.parentWi, newD, f, pdfValue);
+      sRec.throughtput *= f;
+      pdfValue *= (F)1;  // pdfComponent, bRec.component == -1
+      F cosWo = dot(ph.parentN, newD), cosWi = dot(ph.parentN, ph.parentWi);
+      if (cosWi * cosWi <= 0 || cosWo * cosWo <= 0) return false;  // shading frame == geometric frame
     } else if (ptype == GVPM_PARENT_MEDIUM) {
       V pWo = newD;
       V pWi = ph.parentWi;  // normalize(predPos - pMRec.p)

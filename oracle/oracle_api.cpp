@@ -249,6 +249,12 @@ int gatherPlanes(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangle
 }  // namespace
 
 extern "C" {
+// the BSDF table of the scene's glossy surfaces for the gathers that follow (gvpm_upload_bsdfs on the device side)
+int oracle_set_bsdfs(const gvpm_bsdf *table, uint32_t n) {
+  if (n && !table) return GVPM_ERR_INVALID_ARG;
+  oracle::bsdfTable().assign(table, table + n);
+  return GVPM_OK;
+}
 
 // One iteration of computeVolumeGradientPlanes (gvpm.cpp:782-878) on the CPU.  use_accel: 1 = through the
 // reference's PhotonPlaneBVH (pm/plane_accel.h:85-207), 0 = a loop over all planes.  seconds: build + gather;
@@ -478,6 +484,66 @@ extern "C" int64_t oracle_kd_radius_query(const float *pos, uint64_t n, const do
 
 // HGPhaseFunction::sample (src/phase/hg.cpp:74-97; Epsilon = 1e-4) and the oracle's phase eval (the pdf): what
 // src/tests/test_chisquare.cpp:508-573 checks against each other for data/tests/test_phase.xml's g = 0.9 and -0.3.
+// Phong::eval / pdf (phong.cpp:121-186, both components) and Phong::sample (:188-247, bRec.component = -1): what
+// src/tests/test_chisquare.cpp (test01_BSDF) checks against each other for the "phong" instance of data/tests/test_bsdf.xml.
+extern "C" int oracle_phong_eval_pdf(const gvpm_bsdf *b, const double *kd, const double *n, const double *wi, const double *wo,
+                                     double *f, double *pdf) {
+  Vec3<double> fv;
+  double p = 0;
+  const bool ok = phongEvalPdf<double>(*b, Vec3<double>(kd[0], kd[1], kd[2]), Vec3<double>(n[0], n[1], n[2]),
+                                       Vec3<double>(wi[0], wi[1], wi[2]), Vec3<double>(wo[0], wo[1], wo[2]), fv, p);
+  f[0] = fv.x; f[1] = fv.y; f[2] = fv.z;
+  *pdf = p;
+  return ok ? 1 : 0;
+}
+extern "C" int oracle_phong_sample(const gvpm_bsdf *b, const double *n, const double *wiW, double u1, double u2, double *woW) {
+  typedef Vec3<double> V;
+  const V nn(n[0], n[1], n[2]);
+  V s, t;
+  coordinateSystem(nn, s, t);
+  const V wiV(wiW[0], wiW[1], wiW[2]);
+  const V wi(dot(wiV, s), dot(wiV, t), dot(wiV, nn));
+  double sx = u1, sy = u2;
+  const double w = b->specular_sampling_weight, exponent = b->exponent;
+  bool choseSpecular = true;
+  if (sx <= w) {
+    sx /= w;
+  } else {
+    sx = (sx - w) / (1 - w);
+    choseSpecular = false;
+  }
+  V wo;
+  if (choseSpecular) {
+    const V R(-wi.x, -wi.y, wi.z);
+    const double sinAlpha = std::sqrt(1 - std::pow(sy, 2 / (exponent + 1)));
+    const double cosAlpha = std::pow(sy, 1 / (exponent + 1));
+    const double phi = (2.0 * M_PI) * sx;
+    const V localDir(sinAlpha * std::cos(phi), sinAlpha * std::sin(phi), cosAlpha);
+    V rs, rt;
+    coordinateSystem(R, rs, rt);  // Frame(R).toWorld
+    wo = rs * localDir.x + rt * localDir.y + R * localDir.z;
+    if (wo.z <= 0) return 0;
+  } else {
+    // warp::squareToCosineHemisphere: squareToUniformDiskConcentric (src/libcore/warp.cpp:81-104) lifted to the hemisphere
+    const double r1 = 2.0 * sx - 1.0, r2 = 2.0 * sy - 1.0;
+    double phi, r;
+    if (r1 == 0 && r2 == 0) {
+      r = phi = 0;
+    } else if (r1 * r1 > r2 * r2) {
+      r = r1;
+      phi = (M_PI / 4.0) * (r2 / r1);
+    } else {
+      r = r2;
+      phi = (M_PI / 2.0) - (r1 / r2) * (M_PI / 4.0);
+    }
+    const double px = r * std::cos(phi), py = r * std::sin(phi);
+    wo = V(px, py, std::sqrt(std::max(0.0, 1.0 - px * px - py * py)));
+  }
+  const V out = s * wo.x + t * wo.y + nn * wo.z;
+  woW[0] = out.x; woW[1] = out.y; woW[2] = out.z;
+  return 1;
+}
+
 extern "C" double oracle_phase_eval(double g, const double *wi, const double *wo) {
   return Medium<double>::phaseEval(g, Vec3<double>(wi[0], wi[1], wi[2]), Vec3<double>(wo[0], wo[1], wo[2]));
 }

@@ -23,6 +23,7 @@
 #endif
 
 #include <array>
+#include <map>
 #include <vector>
 
 #include <mitsuba/render/trimesh.h>
@@ -118,6 +119,10 @@ public:
     if (tech == EDistance) {
       uploadVpmState(gatherBlocks);   /* nothing to send: scaleVol / NVol live on the device (see writeBack) */
       check(gvpm_upload_vpm_samples(m_h, m_samples.data(), m_samples.size()), "gvpm_upload_vpm_samples");
+    }
+    if (m_bsdfsDirty) {   /* a glossy BSDF met for the first time while flattening this iteration's light paths */
+      check(gvpm_upload_bsdfs(m_h, m_bsdfs.data(), (uint32_t) m_bsdfs.size()), "gvpm_upload_bsdfs");
+      m_bsdfsDirty = false;
     }
     check(gvpm_gather(m_h, it, (uint64_t) nbPaths), "gvpm_gather");
     if (m_config.useManifold && (tech == EVolBRE2D || tech == EVolBRE3D)) answerShiftRequests(photonMap, threadData, scene);
@@ -367,22 +372,61 @@ private:
     m_soa.parent_pdf.push_back((float) par->pdf[EImportance]);       /* shift_volume_photon.cpp:463-470, area measure */
     m_soa.edge_pdf.push_back((float) e->pdf[EImportance]);           /* parentEdge->pdf[EImportance]                */
     m_soa.parent_rr.push_back((float) par->rrWeight);                /* shift_diffuse.cpp:111-112                   */
+    const int glossy = glossyIndex(par);
     m_soa.parent_g.push_back(par->isMediumInteraction()
                                  ? (float) par->getMediumSamplingRecord().getPhaseFunction()->getMeanCosine()
-                                 : 0.f);                             /* hg.cpp:112-114                              */
+                                 : (glossy >= 0 ? (float) glossy : 0.f));   /* hg.cpp:112-114; a glossy surface parent:
+                                                                               its entry in the table of gvpm_upload_bsdfs */
   }
+
+  /* A surface parent whose BSDF is in the device's table of glossy BSDFs (include/gvpm_hip.h, gvpm_bsdf): the modified Phong
+   * model (src/bsdfs/phong.cpp), not textured, sampled with BOTH components (sampledComponentIndex == -1: what
+   * PathVertex::sampleNext records when Phong::sampleComponent finds the lobe's roughness >= 0.05, vertex.cpp:160-165,
+   * phong.cpp:311-330).  Returns its index (appending the entry on first sight), -1 for every other vertex.  The exponent
+   * and the sampling weight have no getters: they are read back through getRoughness = sqrt(2 / (2 + exponent))
+   * (phong.cpp:293-300) and pdfComponent(component 0) = m_specularSamplingWeight (:332-343).                            */
+  int glossyIndex(const PathVertex *par) {
+    if (!par->isSurfaceInteraction() || par->sampledComponentIndex != -1) return -1;
+    const Intersection &its = par->getIntersection();
+    const BSDF *bsdf = its.getBSDF();
+    if (bsdf->getClass()->getName() != "Phong" || (bsdf->getType() & BSDF::ESpatiallyVarying)) return -1;
+    auto found = m_bsdfIndex.find(bsdf);
+    if (found != m_bsdfIndex.end()) return (int) found->second;
+    gvpm_bsdf b;
+    memset(&b, 0, sizeof(b));
+    b.kind = GVPM_BSDF_PHONG;
+    Float cr, cg, cb;
+    bsdf->getSpecularReflectance(its).toLinearRGB(cr, cg, cb);
+    b.specular[0] = (float) cr; b.specular[1] = (float) cg; b.specular[2] = (float) cb;
+    const Float rough = bsdf->getRoughness(its, 0);
+    b.exponent = (float) (2.0 / ((double) rough * (double) rough) - 2.0);
+    BSDFSamplingRecord bRec(its, its.wi, its.wi, EImportance);
+    bRec.component = 0;
+    b.specular_sampling_weight = (float) bsdf->pdfComponent(bRec);
+    const uint32_t idx = (uint32_t) m_bsdfs.size();
+    m_bsdfs.push_back(b);
+    m_bsdfIndex[bsdf] = idx;
+    m_bsdfsDirty = true;
+    return (int) idx;
+  }
+  std::map<const BSDF *, uint32_t> m_bsdfIndex;
+  std::vector<gvpm_bsdf> m_bsdfs;
+  bool m_bsdfsDirty = false;
 
   /* flags: parent type, the result of getTypeShift (a pure function of the light path, shift/shift_utilities.h:112-136),
    * whether edge(c-1) lies in the medium, depth = c - 1, getVertexComponentType(parent) (shift_utilities.h:222-231).
-   * A parent outside the device's closed set (non-Lambertian surface, heterogeneous medium) is flagged `invalid`:
+   * A parent outside the device's closed set (a surface that is neither Lambertian nor an untextured Phong sampled with both
+   * components -- glossyIndex() --, a heterogeneous medium) is flagged `invalid`:
    * the shift then fails with w = 1, as the reference's non-invertible shifts do.                                    */
   uint32_t makeFlags(const Path *lt, size_t c, size_t depth) const {
     const PathVertex *par = lt->vertex(c - 1);
     int b = -1;
     const ELightShiftType t = getTypeShift(lt, c, b);
     uint32_t st = t == EDiffuseShift ? 1u : t == EMediumShift ? 2u : t == EManifoldShift ? 3u : 0u;
+    const bool glossy = m_bsdfIndex.count(par->isSurfaceInteraction() ? par->getIntersection().getBSDF() : nullptr) != 0 &&
+                        par->sampledComponentIndex == -1;   /* (pushParent ran first: the entry exists) */
     if (st == 1u || st == 2u) {
-      if (par->isSurfaceInteraction()) {
+      if (par->isSurfaceInteraction() && !glossy) {
         const BSDF *bsdf = par->getIntersection().getBSDF();
         if (!(bsdf->getType() & BSDF::EDiffuseReflection) || (bsdf->getType() & ~(BSDF::EDiffuseReflection | BSDF::EFrontSide)) != 0)
           st = 0u;
@@ -391,7 +435,8 @@ private:
       }
     }
     const uint32_t ptype = par->isEmitterSample() ? GVPM_PARENT_EMITTER
-                         : par->isSurfaceInteraction() ? GVPM_PARENT_SURFACE : GVPM_PARENT_MEDIUM;
+                         : par->isSurfaceInteraction() ? (glossy ? GVPM_PARENT_SURFACE_BSDF : GVPM_PARENT_SURFACE)
+                                                       : GVPM_PARENT_MEDIUM;
     return GVPM_PF_MAKE(ptype, st, lt->edge(c - 1)->medium != nullptr, depth, getVertexComponentType(par));
   }
 

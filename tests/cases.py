@@ -30,7 +30,19 @@ def make_case(scene="cbox", W=24, H=20, nph=6000, scale=4.0, it=1, **overrides):
     c.rays = c.sc.camera_beams(it)
     c.r = radius_of(c.p)
     c.it = it
+    use_bsdfs(c)
     return c
+
+
+def use_bsdfs(c):
+    """The BSDF table of the case's scene (its glossy walls; empty for the Lambertian scenes) for everything that evaluates
+    a parent's BSDF on the CPU: the oracle (both builds) and the independent numpy statements.  The device gets it through
+    Context.upload_bsdfs(c.bsdfs)."""
+    import indep_statements
+    import oracle_lib
+    c.bsdfs = c.sc.bsdfs()
+    oracle_lib.set_bsdfs(c.bsdfs)
+    indep_statements.set_bsdfs(c.bsdfs)
 
 
 def rays_shift_equals_base(rays):
@@ -130,3 +142,9 @@ def tessellate(tris, levels):
         a, b, c = (np.concatenate(x) for x in ((a, ab, ca, ab), (ab, b, bc, bc), (ca, bc, c, ca)))
     f = np.float32
     return np.ascontiguousarray(a, f), np.ascontiguousarray(b - a, f), np.ascontiguousarray(c - a, f)
+
+
+def upload_bsdfs(ctx, c):
+    """the device's copy of the case's BSDF table (gvpm_upload_bsdfs); nothing for the Lambertian scenes"""
+    if getattr(c, "bsdfs", None) is not None and c.bsdfs.size:
+        ctx.upload_bsdfs(c.bsdfs)

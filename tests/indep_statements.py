@@ -178,6 +178,35 @@ def bre3d_full(c):
     return acc / c.nb, cnt
 
 
+# The BSDF table of the scene's glossy walls (gvpm_upload_bsdfs), for the statements below: set_bsdfs(sc.bsdfs()).
+BSDFS = np.zeros(0, abi.BSDF_DTYPE)
+
+
+def set_bsdfs(table):
+    global BSDFS
+    BSDFS = np.ascontiguousarray(table, abi.BSDF_DTYPE)
+
+
+def phong_world(kd, index, n, wi, wo):
+    """The modified Phong BRDF with both lobes, and the pdf of sampling it (Lafortune & Willems 1994, as src/bsdfs/phong.cpp
+    implements it), stated in WORLD space: f cos = (ks (e + 2) / 2pi max(r . wo, 0)^e + kd / pi) (n . wo),
+    pdf = w (e + 1) / 2pi max(r . wo, 0)^e + (1 - w) (n . wo) / pi, r = 2 (n . wi) n - wi; zero below the horizon.
+    Vectorised over rows; index: the rows' table entries.  Returns (f cos [k, 3], pdf [k], known [k])."""
+    index = np.asarray(index)
+    known = (index >= 0) & (index < BSDFS.size)
+    b = BSDFS[np.where(known, index, 0).astype(np.int64)] if BSDFS.size else np.zeros(index.shape, abi.BSDF_DTYPE)
+    ks, e, w = b["specular"].astype(np.float64), b["exponent"].astype(np.float64), b["specular_sampling_weight"].astype(np.float64)
+    ci, co = (n * wi).sum(-1), (n * wo).sum(-1)
+    r = 2.0 * ci[..., None] * n - wi
+    a = np.maximum((r * wo).sum(-1), 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        lobe = np.where(a > 0, a ** e, 0.0)
+    up = (ci > 0) & (co > 0)
+    f = (ks * ((e + 2.0) / (2.0 * np.pi) * lobe)[..., None] + kd / np.pi) * co[..., None]
+    pdf = w * (e + 1.0) / (2.0 * np.pi) * lobe + (1.0 - w) * co / np.pi
+    return np.where(up[..., None], f, 0.0), np.where(up, pdf, 0.0), known
+
+
 def _photon_reconnect(p, tris, ph_arrays, gi, off, sd, WIk, trk, pdf_base_ray, pdf_s, sensor, seye, eps, seps, sig_t, sig_s, g, msw):
     """shiftPhoton -> shiftPhotonDiffuse + diffuseReconnection (shift_volume_photon.cpp:49-117,382-486, shift_diffuse.cpp:11-134)
     for the photons gi with offset positions `off`: (shiftedFlux, weight, success).  trk: transmittance of the shifted
@@ -195,7 +224,8 @@ def _photon_reconnect(p, tris, ph_arrays, gi, off, sd, WIk, trk, pdf_base_ray, p
     dproj = dproj / lproj[:, None]
     vmax = lproj * seps if p.visibility_as_written else lproj * (1 - seps)
     ok = can & ~any_hit(c.tris, ppos[gi], dproj, eps, vmax)
-    is_med, is_surf = ptype[gi] == abi.GVPM_PARENT_MEDIUM, ptype[gi] == abi.GVPM_PARENT_SURFACE
+    is_gl = ptype[gi] == abi.GVPM_PARENT_SURFACE_BSDF
+    is_med, is_surf = ptype[gi] == abi.GVPM_PARENT_MEDIUM, (ptype[gi] == abi.GVPM_PARENT_SURFACE) | is_gl
     n = pn[gi]
     cos_wo = (n * dproj).sum(1)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -210,6 +240,12 @@ def _photon_reconnect(p, tris, ph_arrays, gi, off, sd, WIk, trk, pdf_base_ray, p
     thr = np.where(is_med[:, None], pscat[gi] * pmed[:, None],
                    np.where(is_surf[:, None], pscat[gi] * np.where(surf_ok, lam, 0.0)[:, None], emit[:, None] * np.ones(3)))
     ok &= ~(is_surf & ~surf_ok)                      # the shading-normal test returns before the pdf is set
+    if is_gl.any():
+        # a glossy parent: the whole Phong BRDF towards the offset position instead of the Lambertian lobe
+        fg, pg_, known = phong_world(pscat[gi], np.where(is_gl, pg[gi], -1).astype(np.int64), n, pwi[gi], dproj)
+        pdf_val = np.where(is_gl, pg_, pdf_val)
+        thr = np.where(is_gl[:, None], fg, thr)
+        ok &= ~(is_gl & ~known)
     gop = 1.0 / (lproj * lproj)
     spdf = pdf_val * gop
     thr = thr * gop[:, None]
@@ -558,11 +594,16 @@ def _beam_reconnect(p, tris, k, off, p1, p2, bd, v, kpdf, r, is1d, so, sd, sl, w
     if any_hit(tris, p1[None, :], nd[None, :], eps, np.array([dist]))[0]:
         return False, 1.0, zero
     n = PN[k]
-    if ptype[k] == abi.GVPM_PARENT_SURFACE:
+    if ptype[k] in (abi.GVPM_PARENT_SURFACE, abi.GVPM_PARENT_SURFACE_BSDF):
         cos_wo, cos_wi = n @ nd, n @ PWI[k]
         if cos_wi <= 0 or cos_wo <= 0:
             return False, 1.0, zero
         thr, pdf_sa = PSCAT[k] * (INV_PI * cos_wo), INV_PI * cos_wo
+        if ptype[k] == abi.GVPM_PARENT_SURFACE_BSDF:
+            fg, pg_, known = phong_world(PSCAT[k][None, :], np.array([int(PG[k])]), n[None, :], PWI[k][None, :], nd[None, :])
+            if not known[0]:
+                return False, 1.0, zero
+            thr, pdf_sa = fg[0], float(pg_[0])
     elif ptype[k] == abi.GVPM_PARENT_MEDIUM:
         ph = _phase1(PG[k], PWI[k], nd)
         thr, pdf_sa = PSCAT[k] * ph, ph

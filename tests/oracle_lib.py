@@ -52,8 +52,23 @@ def lib(fast=False):
             C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.oracle_poisson_solve.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.oracle_set_bsdfs.argtypes = [C.c_void_p, C.c_uint32]
         _LIBS[name] = L
+        if _BSDFS is not None:
+            L.oracle_set_bsdfs(_BSDFS.ctypes.data if _BSDFS.size else None, _BSDFS.size)
     return _LIBS[name]
+
+
+_BSDFS = None
+
+
+def set_bsdfs(table):
+    """The BSDF table of the scene's glossy surfaces (abi.BSDF_DTYPE) for every gather that follows, in both builds of
+    the oracle: the counterpart of gvpm_upload_bsdfs.  An empty table restores the Lambertian-only closed set."""
+    global _BSDFS
+    _BSDFS = np.ascontiguousarray(table, abi.BSDF_DTYPE)
+    for L in _LIBS.values():
+        L.oracle_set_bsdfs(_BSDFS.ctypes.data if _BSDFS.size else None, _BSDFS.size)
 
 
 COUNTER_NAMES = ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts")
@@ -293,3 +308,25 @@ def sensor_mis(id_vertex, s_pdf, s_jac, s_g, b_pdf, b_g, s_dist=1.0, b_dist=1.0)
     L.oracle_sensor_mis.restype = C.c_double
     L.oracle_sensor_mis.argtypes = [C.c_uint] + [C.c_double] * 7
     return L.oracle_sensor_mis(int(id_vertex), s_pdf, s_jac, s_g, b_pdf, b_g, s_dist, b_dist)
+
+
+def phong_eval_pdf(bsdf, kd, n, wi, wo):
+    """Phong::eval (x cos) and Phong::pdf of one table entry (numpy record of abi.BSDF_DTYPE), world-space unit vectors"""
+    L = lib()
+    L.oracle_phong_eval_pdf.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    b = np.ascontiguousarray(np.atleast_1d(bsdf), abi.BSDF_DTYPE)
+    a = [np.ascontiguousarray(x, np.float64) for x in (kd, n, wi, wo)]
+    f, pdf = np.zeros(3), np.zeros(1)
+    L.oracle_phong_eval_pdf(b.ctypes.data, *[x.ctypes.data for x in a], f.ctypes.data, pdf.ctypes.data)
+    return f, float(pdf[0])
+
+
+def phong_sample(bsdf, n, wi, u1, u2):
+    """Phong::sample with both components (phong.cpp:188-247): the sampled world direction, or None (below the horizon)"""
+    L = lib()
+    L.oracle_phong_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    b = np.ascontiguousarray(np.atleast_1d(bsdf), abi.BSDF_DTYPE)
+    n, wi = np.ascontiguousarray(n, np.float64), np.ascontiguousarray(wi, np.float64)
+    wo = np.zeros(3)
+    ok = L.oracle_phong_sample(b.ctypes.data, n.ctypes.data, wi.ctypes.data, float(u1), float(u2), wo.ctypes.data)
+    return wo if ok else None

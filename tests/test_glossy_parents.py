@@ -1,0 +1,148 @@
+"""Glossy surface parents (include/gvpm_hip.h GVPM_PARENT_SURFACE_BSDF, gvpm_upload_bsdfs): photons and
+beams whose parent vertex lies on a Phong wall are re-connected through the wall's whole BSDF (diffuseReconnection,
+shift_diffuse.cpp:25-47 with src/bsdfs/phong.cpp:121-186) instead of failing their shift.  CPU side: the oracle's
+restatement against the independent numpy statement for the three techniques that reconnect, the synthetic host's Phong
+walls against both, and the sampling routine against its pdf."""
+import numpy as np
+import pytest
+
+import cases
+import indep_statements as I
+import oracle_lib as O
+from gvpm_amd import abi
+from test_indep_statements import compare, compare_beams
+from test_oracle_beams import make_beam_case, TECHS
+from test_oracle_vpm import make_vpm_case
+
+
+def test_the_scene_has_photons_behind_glossy_walls_and_a_table_for_them():
+    c = cases.make_case("cbox_phong", 20, 16, 20000, 4.0)
+    assert c.bsdfs.size == 2 and (c.bsdfs["kind"] == abi.GVPM_BSDF_PHONG).all()
+    pt = c.ph.flags & 3
+    gl = pt == abi.GVPM_PARENT_SURFACE_BSDF
+    assert gl.sum() > 500 and (pt == abi.GVPM_PARENT_SURFACE).sum() > 500
+    # the table index rides in parent_g; such photons classify as diffuse reconnections (gvpm_struct.h:66-100)
+    idx = c.ph.parent_g[gl]
+    assert set(np.unique(idx)) == {0.0, 1.0}
+    assert (((c.ph.flags[gl] >> 2) & 7) == 1).all()
+    # componentType of the parent = the lobe that was sampled: EGlossyReflection or EDiffuseReflection
+    assert set(np.unique(c.ph.flags[gl] >> 16)) == {0x2, 0x8}
+    # energy conservation of the two materials (ensureEnergyConservation, phong.cpp:86-91): kd + ks <= 1
+    kd = np.array([c.ph.parent_scat[gl][idx == k][0] for k in (0, 1)])
+    assert (kd + c.bsdfs["specular"] <= 1.0).all()
+    # m_specularSamplingWeight = lum(ks) / (lum(kd) + lum(ks)), phong.cpp:93-97 (Spectrum::getLuminance, RGB)
+    lum = lambda v: v @ np.array([0.212671, 0.715160, 0.072169])
+    assert np.allclose(c.bsdfs["specular_sampling_weight"], lum(c.bsdfs["specular"]) / (lum(kd) + lum(c.bsdfs["specular"])), rtol=1e-6)
+
+
+def test_the_hosts_phong_bounce_is_weight_times_pdf_equals_eval():
+    """A photon stored right behind a Phong bounce: flux = prefix * (f cos / pdf) * rr * (Tr / edgePdf)  (gvpm_accel.h:134-148
+    with vertex.cpp:165-171: weight = bsdf->sample() = eval / pdf), where pdf in solid angle = the stored area pdf * len^2
+    (vertex.cpp:315-329; a medium successor has no cosine).  Checked with the INDEPENDENT statement of the BRDF."""
+    c = cases.make_case("cbox_phong", 20, 16, 20000, 4.0)
+    gl = np.flatnonzero((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF)[:400]
+    d = c.ph.pos[gl].astype(np.float64) - c.ph.parent_pos[gl]
+    ln = np.linalg.norm(d, axis=1)
+    wo = d / ln[:, None]
+    f, pdf, known = I.phong_world(c.ph.parent_scat[gl].astype(np.float64), c.ph.parent_g[gl].astype(np.int64),
+                                  c.ph.parent_n[gl].astype(np.float64), c.ph.parent_wi[gl].astype(np.float64), wo)
+    assert known.all()
+    assert np.allclose(pdf, c.ph.parent_pdf[gl] * ln * ln, rtol=2e-4)  # (len from fp32 positions)
+    tr = np.exp(-float(c.m.sigma_t[0]) * ln)
+    want = c.ph.prefix_w[gl] * (f / pdf[:, None]) * c.ph.parent_rr[gl][:, None] * (tr / c.ph.edge_pdf[gl])[:, None]
+    assert np.allclose(c.ph.flux[gl], want, rtol=4e-4)
+    # and the oracle's local-frame restatement says the same as the world-space one
+    for k in range(0, 400, 40):
+        fo, po = O.phong_eval_pdf(c.bsdfs[int(c.ph.parent_g[gl][k])], c.ph.parent_scat[gl][k], c.ph.parent_n[gl][k],
+                                  c.ph.parent_wi[gl][k], wo[k])
+        assert np.allclose(fo, f[k], rtol=1e-12) and abs(po - pdf[k]) < 1e-12 * pdf[k]
+
+
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+def test_bre3d_all_27_accumulators(scene):
+    c = cases.make_case(scene, 20, 16, 6000, 4.0)
+    cnt = compare(c)
+    assert cnt["diffuse_shifts"] > 300
+    # without the table the same photons fail their shifts -- the state of affairs before round 4
+    O.set_bsdfs(c.bsdfs[:0])
+    _, cnt0, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, 1, c.nb, 64, use_accel=False)
+    cases.use_bsdfs(c)
+    assert cnt0["failed_shifts"] - cnt["failed_shifts"] == cnt["diffuse_shifts"] - cnt0["diffuse_shifts"] > 100
+
+
+@pytest.mark.parametrize("kw", [dict(use_mis=0), dict(power_heuristic=1), dict(use_shift_null=0), dict(bsdf_interaction_mode=0x8),
+                                dict(bsdf_interaction_mode=0x2)])
+def test_bre3d_flags(kw):
+    # (bsdfInteractionMode = glossy keeps only the photons whose parent sampled its glossy lobe: a larger map for that one)
+    c = cases.make_case("cbox_phong", 16, 12, 60000 if kw.get("bsdf_interaction_mode") == 0x8 else 5000, 4.0, **kw)
+    compare(c)
+
+
+@pytest.mark.parametrize("tech", TECHS)
+def test_beams_all_27_accumulators(tech):
+    c = make_beam_case("cbox_phong", 12, 10, 600, 5.0, technique=tech)
+    assert ((c.beams.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 30
+    compare_beams(c)
+
+
+def test_vpm_all_27_accumulators():
+    c = make_vpm_case("cbox_phong", 12, 10, 6000, 8.0, 6)
+    ref, rsv, rnv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=True)
+    acc, icnt, mvol = I.vpm_full(c)
+    assert cnt["evaluations"] > 300
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert icnt[k] == cnt[k], (k, icnt, cnt)
+    lum = ref[..., 0:3].mean()
+    for j in range(9):
+        assert np.abs(acc[..., 3 * j:3 * j + 3] - ref[..., 3 * j:3 * j + 3]).max() / lum < 1e-9, j
+
+
+def test_phong_sampling_matches_its_pdf_chi_square():
+    """src/tests/test_chisquare.cpp (test01_BSDF) for the "phong" instance of data/tests/test_bsdf.xml (diffuse 0.2, specular
+    0.4, the default exponent 30): for 10 incident directions the histogram of Phong::sample over 10 x 20 (theta, phi)
+    bins against the integral of Phong::pdf over the bins; bins with an expected frequency below 5 are pooled
+    (libcore/chisquare.cpp), significance 0.01 with the Sidak correction."""
+    from scipy import stats
+    b = np.zeros(1, abi.BSDF_DTYPE)
+    b["kind"], b["specular"], b["exponent"] = abi.GVPM_BSDF_PHONG, 0.4, 30.0
+    b["specular_sampling_weight"] = 0.4 / 0.6
+    kd = np.full(3, 0.2)
+    n = np.array([0.0, 0.0, 1.0])
+    rng = np.random.default_rng(11)
+    theta_bins, phi_bins, n_wi, n_samples = 10, 20, 10, 40000
+    alpha = 1.0 - (1.0 - 0.01) ** (1.0 / n_wi)
+    for _ in range(n_wi):
+        z = 0.05 + 0.95 * rng.random()
+        ph = 2 * np.pi * rng.random()
+        wi = np.array([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z])
+        wos = [O.phong_sample(b[0], n, wi, *rng.random(2)) for _ in range(n_samples)]
+        below = sum(w is None for w in wos)  # a lobe sample under the horizon: Phong::sample returns 0 (weight lost)
+        wo = np.array([w for w in wos if w is not None])
+        theta = np.arccos(np.clip(wo[:, 2], -1, 1))
+        phi = np.arctan2(wo[:, 1], wo[:, 0]) % (2 * np.pi)
+        obs, _, _ = np.histogram2d(theta, phi, bins=[theta_bins, phi_bins], range=[[0, np.pi], [0, 2 * np.pi]])
+        sub = 16
+        th = (np.arange(theta_bins * sub) + 0.5) * (np.pi / (theta_bins * sub))
+        phs = (np.arange(phi_bins * sub) + 0.5) * (2 * np.pi / (phi_bins * sub))
+        T, Pm = np.meshgrid(th, phs, indexing="ij")
+        dirs = np.stack([np.sin(T) * np.cos(Pm), np.sin(T) * np.sin(Pm), np.cos(T)], -1).reshape(-1, 3)
+        I.set_bsdfs(b)  # (the independent statement reads its module table; the oracle's pdf is spot-checked against it)
+        _, pdf, _ = I.phong_world(kd[None, :], np.zeros(len(dirs), np.int64), np.broadcast_to(n, dirs.shape),
+                                  np.broadcast_to(wi, dirs.shape), dirs)
+        for k in (37, 5000, 20011):
+            assert abs(pdf[k] - O.phong_eval_pdf(b[0], kd, n, wi, dirs[k])[1]) < 1e-12 + 1e-12 * pdf[k]
+        pdf = pdf.reshape(theta_bins * sub, phi_bins * sub)
+        cell = np.sin(T) * (np.pi / (theta_bins * sub)) * (2 * np.pi / (phi_bins * sub))
+        exp_ = (pdf * cell).reshape(theta_bins, sub, phi_bins, sub).sum((1, 3)) * n_samples
+        # the pdf integrates to 1 minus the part of the lobe under the horizon, which the sampler loses
+        assert abs(exp_.sum() - (n_samples - below)) < 5 * np.sqrt(n_samples) + 0.01 * n_samples
+        o, e = obs.ravel(), exp_.ravel()
+        order = np.argsort(e)
+        o, e = o[order], e[order]
+        cum = np.cumsum(e)
+        k = int(np.searchsorted(cum, 5.0)) + 1
+        o = np.concatenate([[o[:k].sum()], o[k:]])
+        e = np.concatenate([[e[:k].sum()], e[k:]])
+        chi2 = ((o - e) ** 2 / e).sum()
+        pval = 1 - stats.chi2.cdf(chi2, df=e.size - 1)
+        assert pval > alpha, (wi, chi2, pval)

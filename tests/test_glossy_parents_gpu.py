@@ -1,0 +1,114 @@
+"""Glossy surface parents on the device (GVPM_PARENT_SURFACE_BSDF + gvpm_upload_bsdfs; shift_device.h glossyParentEval):
+photons and beams behind S-cbox-phong's Phong floor and back wall are re-connected through the wall's whole BSDF
+(diffuseReconnection, shift_diffuse.cpp:25-47 with phong.cpp:121-186) -- for every technique that reconnects, against the
+fp64 oracle; without the table (or with an index beyond it) the same shifts fail, as they did before round 4."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+from gvpm_amd import abi, hip
+from test_oracle_beams import make_beam_case, TECHS
+from test_oracle_vpm import make_vpm_case
+from test_parity_beams_gpu import device_beams
+from test_parity_gpu import check, device_gather, l2, TOL
+from test_parity_vpm_gpu import device_vpm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+@pytest.mark.parametrize("kw", [dict(), dict(vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0), dict(use_mis=0), dict(power_heuristic=1)])
+def test_bre_matches_fp64_oracle(scene, kw):
+    c = cases.make_case(scene, 40, 36, 30000, 2.5, **kw)
+    gl = ((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum()
+    assert gl > 1000
+    acc, ref, st = check(c)
+    assert st["evaluations"] > 10000 and st["diffuse_shifts"] > 10000
+
+
+def test_the_glossy_lobe_matters_and_a_missing_table_fails_the_shifts():
+    c = cases.make_case("cbox_phong", 40, 36, 30000, 2.5)
+    acc, ref, st = check(c)
+    lum = ref[..., 0:3].mean()
+    # the oracle without the table: the round-3 state (those photons' shifts fail with weight 1)
+    O.set_bsdfs(c.bsdfs[:0])
+    ref0, cnt0, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, c.it, c.nb, 64, use_accel=False)
+    cases.use_bsdfs(c)
+    assert cnt0["failed_shifts"] - st["failed_shifts"] > 2000
+    assert l2(ref0, ref, lum) > 1e-2
+    # ... which is what the device does when no table was uploaded
+    saved, c.bsdfs = c.bsdfs, c.bsdfs[:0]
+    acc0, st0, _ = device_gather(c)
+    c.bsdfs = saved
+    assert st0["evaluations"] == cnt0["evaluations"]
+    for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert abs(st0[k] - cnt0[k]) <= max(2, 2e-6 * 4 * cnt0["evaluations"])
+    assert l2(acc0, ref0, lum) < TOL
+    # a Lambertian statement of the same walls (the diffuse lobe alone) is NOT what the reference computes
+    lam = cases.make_case("cbox_phong", 40, 36, 30000, 2.5)
+    lam.ph.flags[:] = np.where((lam.ph.flags & 3) == 3, (lam.ph.flags & ~np.uint32(3)) | 1, lam.ph.flags)
+    ref_l, _, _ = O.gather_bre(lam.p, lam.m, lam.tris, lam.ph, lam.rays, lam.r, lam.it, lam.nb, 64, use_accel=False)
+    assert l2(ref_l, ref, lum) > 1e-3
+
+
+def test_unsupported_table_entries_are_refused():
+    c = cases.make_case("cbox_phong", 16, 12, 500, 3.0)
+    ctx = hip.Context(c.p, device=0)
+    bad = c.bsdfs.copy()
+    bad["kind"][0] = 7
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.upload_bsdfs(bad)
+    assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
+    bad = c.bsdfs.copy()
+    bad["specular_sampling_weight"][1] = 1.5
+    with pytest.raises(hip.GvpmError):
+        ctx.upload_bsdfs(bad)
+    ctx.upload_bsdfs(c.bsdfs)
+    ctx.upload_bsdfs(c.bsdfs[:0])
+    ctx.close()
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+def test_beams_match_fp64_oracle(tech, scene):
+    c = make_beam_case(scene, 32, 28, 12000, 2.5, technique=tech)
+    assert ((c.beams.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 500
+    acc, ref, st = device_beams(c)
+    assert st["evaluations"] > 20000 and st["diffuse_shifts"] > 5000
+
+
+def test_beams_fp64_transcription_agrees(monkeypatch):
+    c = make_beam_case("cbox_phong", 24, 20, 6000, 3.0)
+    monkeypatch.setenv("GVPM_BEAMS_FP64", "1")
+    device_beams(c)
+
+
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+def test_vpm_matches_fp64_oracle(scene):
+    c = make_vpm_case(scene, 32, 28, 40000, 5.0, nb=10)
+    assert ((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 1000
+    acc, ref, st = device_vpm(c)
+    assert st["evaluations"] > 5000 and st["diffuse_shifts"] > 2000
+
+
+def test_packed_photons_carry_the_table_index():
+    """the packed photon record names (parent_scat, parent_g) through the material table: the BSDF index rides along"""
+    c = cases.make_case("cbox_phong", 40, 32, 20000, 3.0)
+    t = hip.MaterialTable()
+    pk = hip.pack_photons(c.ph, t)
+    unp = hip.unpack_photons(pk, t)
+    assert np.array_equal(unp.parent_g, c.ph.parent_g) and np.array_equal(unp.flags, c.ph.flags)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_bsdfs(c.bsdfs)
+    ctx.upload_materials(t)
+    ctx.upload_photons_packed(pk)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(1, c.nb)
+    acc, st = ctx.download_accum().astype(np.float64), ctx.stats()
+    ctx.close()
+    ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, unp, c.rays, c.r, 1, c.nb, 64)
+    assert st["evaluations"] == cnt["evaluations"] and abs(st["diffuse_shifts"] - cnt["diffuse_shifts"]) <= 2
+    assert np.sqrt(((acc - ref) ** 2).mean()) / ref[..., 0:3].mean() < 1e-4

@@ -17,6 +17,7 @@ def device_beams(c, p=None, rays=None, iters=1):
     ctx = hip.Context(p, device=0)
     ctx.upload_scene(*c.tris)
     ctx.upload_medium(c.m)
+    cases.upload_bsdfs(ctx, c)
     ref = None
     total = {k: 0 for k in SHIFT_COUNTERS + ("evaluations",)}
     for it in range(1, iters + 1):

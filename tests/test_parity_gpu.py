@@ -41,6 +41,7 @@ def device_gather(c, rays=None, ph=None, p=None, iters=None, beams_per_wave=None
                 os.environ["GVPM_BEAMS_PER_WAVE"] = old
     ctx.upload_scene(*c.tris)
     ctx.upload_medium(c.m)
+    cases.upload_bsdfs(ctx, c)
     ctx.upload_photons(c.ph if ph is None else ph)
     ctx.upload_camera_beams(c.rays if rays is None else rays)
     assert abs(ctx.radius() - c.r) == 0.0
@@ -59,9 +60,10 @@ def check(c, p=None, rays=None, ph=None, use_accel=False, **kw):
                                c.it, c.nb, 64, use_accel=use_accel)
     lum = max(ref[..., 0:3].mean(), 1e-30)
     assert st["evaluations"] == cnt["evaluations"]
-    # which shift a borderline evaluation takes may flip with the fp32 re-derivation of t'
+    # which shift a borderline evaluation takes may flip with the fp32 re-derivation of t': at most 2e-6 of the shifts
+    # (4 per evaluation), the bar the C3-size windows hold (test_configs_gpu.py)
     for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
-        assert abs(st[k] - cnt[k]) <= max(2, 1e-4 * cnt[k]), (k, st, cnt)
+        assert abs(st[k] - cnt[k]) <= max(2, 2e-6 * 4 * cnt["evaluations"]), (k, st, cnt)
     err = l2(acc, ref, lum)
     assert err < TOL, err
     rthr, rdx, rdy = O.assemble(ref, c.it, True)

@@ -16,6 +16,7 @@ def device_vpm(c, iters=1, p=None, rays=None):
     ctx = hip.Context(p, device=0)
     ctx.upload_scene(*c.tris)
     ctx.upload_medium(c.m)
+    cases.upload_bsdfs(ctx, c)
     ref = sv = nv = None
     total = 0
     emitted = 0

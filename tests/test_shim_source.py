@@ -114,6 +114,8 @@ def test_every_citation_names_a_file_of_the_reference():
     ("include/mitsuba/render/sensor.h", ["class MTS_EXPORT_RENDER PerspectiveCamera", "getXFov", "getAspect", "getWorldTransform", "getFilm"]),
     ("include/mitsuba/render/film.h", ["getCropOffset", "getCropSize", "getSize()"]),
     ("include/mitsuba/core/transform.h", ["getMatrix", "transformAffine"]),
+    ("include/mitsuba/render/bsdf.h", ["getSpecularReflectance", "getRoughness", "pdfComponent", "ESpatiallyVarying"]),
+    ("include/mitsuba/bidir/vertex.h", ["sampledComponentIndex"]),
 ])
 def test_members_the_bridge_touches_exist_in_the_reference(header, members):
     if not os.path.isdir(REF):
