@@ -37,9 +37,14 @@ constexpr int VRQ = 128; // reconnection ring: 63 left over + the 64 one shift o
 #define GVPM_VPM_RUNS 4
 #endif
 #ifndef GVPM_VPM_SUB
-#define GVPM_VPM_SUB 8
+#define GVPM_VPM_SUB 4  // (round 4: 8 -> 4 copies, 13 KB of LDS a wave: 12 waves per CU at 168 VGPRs instead of 9; C1 0.587 -> 0.562 ms)
+#endif
+// waves per SIMD the register allocation aims at (3: 168 VGPRs)
+#ifndef GVPM_VPM_MINW
+#define GVPM_VPM_MINW 3
 #endif
 constexpr int VPM_RUNS = GVPM_VPM_RUNS;
+constexpr int VPM_ROWS = 9;  // rows of a sample's cell box walked per pass (a box is 3 x 3 x 3 cells but for rounding)
 // ... and VPM_SUB copies of a run's sums, picked by the adding lane: all 64 lanes on the two or three addresses of one
 // copy serialise in the LDS atomic unit (measured at 4 x the C1 radius, 16 M evaluations: 3.2 -> 3.9 ms with one copy)
 constexpr int VPM_SUB = GVPM_VPM_SUB;
@@ -62,7 +67,10 @@ struct VpmLds {
   uint32_t pix[64];
   uint32_t edge[64];
   float4 qr[64];       // query point and radius of the sample
-  uint32_t segOff[64], segStart[64];  // this row's photon ranges laid end to end: exclusive offsets, first photon
+  // the candidate lists of the 64 samples laid end to end: a sample's first entry, and per row of its cell box (VPM_ROWS
+  // rows a pass: the 3 x 3 rows of a box are one pass) the row's first photon and its first entry within the sample's list
+  uint32_t segOff[64 + 1];
+  uint32_t rowStart[VPM_ROWS][64], rowOff[VPM_ROWS][64];
   uint32_t found[64];  // photons inside the query sphere (M of the SPPM update)
   uint2 rq[VRQ];       // queued reconnections {photon, sample | shift << 8}
 };
@@ -234,7 +242,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
 }
 
 template <bool FULLVIS>
-__global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
   __shared__ VpmLds s;
   const int lane = threadIdx.x;
   const uint32_t sBase = blockIdx.x * 64u;
@@ -293,9 +301,12 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
     const double distSurf = maxt - mint;
     if (sampled < distSurf) {
       t = sampled + mint;
-      const double nrm2 = 1.0 - exp(-sigT * distSurf);
-      const double e = exp(-sigT * sampled);
-      pdfBase = (float)((sigT / nrm2) * e) * pdfSel;  // mRec.pdfSuccess * pdfSel
+      // exp(-sigma_t * sampled) IS the argument of the logarithm above (to a rounding of the double, far below the float
+      // the two results are stored as); the normalisation over the whole edge feeds a float too: one fp64 exponential and
+      // one logarithm per sample instead of three and one
+      const double e = 1.0 - (double)rnd * normalization;
+      const float nrm2 = 1.f - __expf(-(float)sigT * (float)distSurf);
+      pdfBase = ((float)sigT / nrm2) * (float)e * pdfSel;  // mRec.pdfSuccess * pdfSel
       trBase = (float)e;
       if (trBase < 1e-20f) trBase = 0.f;
       // querySize = R * POURCENTAGE_BS * gp.scaleVol, gvpm.cpp:1082,1132
@@ -328,22 +339,40 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
   const int nyr = by1 - by0 + 1, nzr = bz1 - bz0 + 1;
   const int nrows = (bx1 >= bx0 && nyr > 0 && nzr > 0) ? nyr * nzr : 0;
   // The wave walks the cells together.  A lane-per-sample walk runs as long as its busiest lane (the candidate counts
-  // of the samples of a ray differ by orders of magnitude) and reads 64 scattered lines per trip.  Instead, row by
-  // row, the lanes' photon ranges are laid end to end (wave prefix sum), and lane l of a batch takes candidate
-  // j0 + l of that list: it finds the owning sample by a search over the prefix offsets and tests the photon against
-  // that sample's sphere.  Consecutive lanes read consecutive photons and every trip is full.
+  // of the samples of a ray differ by orders of magnitude) and reads 64 scattered lines per trip.  Instead the photon
+  // ranges of ALL rows of ALL 64 boxes are laid end to end (round 4: one wave prefix sum over the samples' totals and a
+  // per-sample prefix over its <= 9 rows, where round 3 made one list -- scan, two barriers, a mostly empty last trip --
+  // per row: 9 of each per wave for ~14 candidates a sample at C1), and lane l of a trip takes candidate j0 + l of the
+  // list: it finds the owning sample by a search over the samples' offsets, the row by a search over that sample's row
+  // offsets, and tests the photon against that sample's sphere.  Consecutive lanes read consecutive photons within a
+  // row and every trip but the last is full.
   int maxRows = nrows;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxRows = max(maxRows, __shfl_xor(maxRows, o, 64));
   s.qr[lane] = make_float4(q.x, q.y, q.z, radius);
   s.found[lane] = 0u;
+  // A row of the box is a run of cells along x at one (y, z): only the part of it the sphere can reach is listed -- the
+  // cells of a 3 x 3 x 3 box hold ~6 times the sphere's volume, the trimmed rows ~3 times (C1: 14.6 -> ~8 candidates a
+  // sample).  Conservative: the reach carries 1e-4 r + 1e-6 + 2e-4 cells of slack -- a cell's bounds are rebuilt here as
+  // org + index * cell, off the build's floor((p - org) * invCell) by up to ~1e-7 * index cells.
+  const float padW = radius * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
   auto rowRange = [&](int r, uint32_t &c, uint32_t &e) {
     c = e = 0u;
     if (r < nrows) {
       const int y = by0 + r % nyr, z = bz0 + r / nyr;
-      const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
-      c = a.cellStart[rb + bx0];
-      e = a.cellStart[rb + bx1 + 1];
+      const float ylo = gr.org[1] + (float)y * gr.cell, zlo = gr.org[2] + (float)z * gr.cell;
+      const float dy = fmaxf(0.f, fmaxf(ylo - q.y, q.y - (ylo + gr.cell))), dz = fmaxf(0.f, fmaxf(zlo - q.z, q.z - (zlo + gr.cell)));
+      const float h2 = pad2 - (dy * dy + dz * dz);
+      if (h2 > 0.f) {
+        const float hx = sqrtf(h2) + 1e-6f;
+        const int x0 = max(bx0, (int)floorf((q.x - hx - gr.org[0]) * gr.invCell));
+        const int x1 = min(bx1, (int)floorf((q.x + hx - gr.org[0]) * gr.invCell));
+        if (x1 >= x0) {
+          const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
+          c = a.cellStart[rb + x0];
+          e = a.cellStart[rb + x1 + 1];
+        }
+      }
     }
   };
   uint32_t qHead = 0, qCount = 0, rqHead = 0, rqCount = 0;
@@ -379,12 +408,19 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
       }
     }
   };
-  uint32_t rc, re;
-  rowRange(0, rc, re);
-  for (int r = 0; r < maxRows; ++r) {
-    uint32_t nc, ne;
-    rowRange(r + 1, nc, ne);  // in flight while this row is consumed
-    const uint32_t cnt = re - rc;
+  for (int r0 = 0; r0 < maxRows; r0 += VPM_ROWS) {
+    // this lane's rows of the pass: all ranges in flight together, then the lane's own prefix over them
+    uint32_t rcs[VPM_ROWS], res[VPM_ROWS];
+#pragma unroll
+    for (int k = 0; k < VPM_ROWS; ++k) rowRange(r0 + k, rcs[k], res[k]);
+    __syncthreads();  // (the previous pass has read its offsets)
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < VPM_ROWS; ++k) {
+      s.rowStart[k][lane] = rcs[k];
+      s.rowOff[k][lane] = cnt;
+      cnt += res[k] - rcs[k];
+    }
     uint32_t inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -392,70 +428,75 @@ __global__ __launch_bounds__(64, 2) void gather_vpm_kernel(GatherArgs a) {
       if (lane >= o) inc += v;
     }
     const uint32_t total = __shfl(inc, 63, 64);
-    if (total) {
-      __syncthreads();
-      s.segOff[lane] = inc - cnt;
-      s.segStart[lane] = rc;
-      __syncthreads();
-      for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
-        const uint32_t j = j0 + (uint32_t)lane;
-        const bool have = j < total;
-        bool hit = false;
-        uint32_t gi = 0, owner = 0;
-        if (have) {
-          // the last lane whose offset is <= j (empty ranges share the offset of the range after them)
+    s.segOff[lane] = inc - cnt;
+    if (lane == 63) s.segOff[64] = total;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool have = j < total;
+      bool hit = false;
+      uint32_t gi = 0, owner = 0;
+      if (have) {
+        // the last sample whose offset is <= j (empty lists share the offset of the list after them) ...
 #pragma unroll
-          for (int st = 32; st > 0; st >>= 1)
-            if (s.segOff[owner + st] <= j) owner += st;
-          gi = s.segStart[owner] + (j - s.segOff[owner]);
-          const float4 hp = a.hot[gi];
-          const float4 qr = s.qr[owner];
-          nCand++;
-          const f3 p = mk3(hp.x, hp.y, hp.z);
-          const f3 qo = mk3(qr.x, qr.y, qr.z);
-          const float rad = qr.w, r2f = rad * rad;
-          const f3 dv = p - qo;
-          const float d2 = dot(dv, dv);
-          // pointDistSquared < distSquared (kdtree.h:722) decided in fp32 unless within the error band
-          const float E = 3e-7f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z));
-          const float band = 4.f * rad * E + r2f * 2e-6f;
-          bool inside = d2 < r2f - band;
-          if (!inside && d2 < r2f + band) {
-#pragma clang fp contract(off)
-            const RayReg bo = loadRayV(a, s, 0, (int)owner);
-            const d3 qd = tod(bo.o) + tod(bo.d) * s.t[owner];
-            const double dx = (double)p.x - qd.x, dy = (double)p.y - qd.y, dz = (double)p.z - qd.z;
-            inside = dx * dx + dy * dy + dz * dz < (double)rad * (double)rad;
-          }
-          if (inside) {
-            atomicAdd(&s.found[owner], 1u);
-            const uint32_t bits = __float_as_uint(hp.w);
-            // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
-            const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edge[owner];
-            hit = true;
-            if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
-            if (!((bits >> 6) & 1u)) hit = false;
-          }
+        for (int st = 32; st > 0; st >>= 1)
+          if (s.segOff[owner + st] <= j) owner += st;
+        // ... and the last of its rows whose offset is <= the entry's place in the sample's list
+        const uint32_t kk = j - s.segOff[owner];
+        uint32_t row = 0;
+        if (s.rowOff[8][owner] <= kk) {
+          row = 8;
+        } else {
+#pragma unroll
+          for (int st = 4; st > 0; st >>= 1)
+            if (s.rowOff[row + st][owner] <= kk) row += st;
         }
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-          if (hit) {
-            const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-            s.queue[(qHead + qCount + off) % VQ] = make_uint2(gi, owner);
-          }
-          qCount += __popcll(m);
-          if (qCount >= 64u) {
-            __syncthreads();
-            evalBatch(true, s.queue[(qHead + lane) % VQ]);
-            qHead = (qHead + 64u) % VQ;
-            qCount -= 64u;
-            __syncthreads();
-          }
+        gi = s.rowStart[row][owner] + (kk - s.rowOff[row][owner]);
+        const float4 hp = a.hot[gi];
+        const float4 qr = s.qr[owner];
+        nCand++;
+        const f3 p = mk3(hp.x, hp.y, hp.z);
+        const f3 qo = mk3(qr.x, qr.y, qr.z);
+        const float rad = qr.w, r2f = rad * rad;
+        const f3 dv = p - qo;
+        const float d2 = dot(dv, dv);
+        // pointDistSquared < distSquared (kdtree.h:722) decided in fp32 unless within the error band
+        const float E = 3e-7f * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z) + fabsf(qo.x) + fabsf(qo.y) + fabsf(qo.z));
+        const float band = 4.f * rad * E + r2f * 2e-6f;
+        bool inside = d2 < r2f - band;
+        if (!inside && d2 < r2f + band) {
+#pragma clang fp contract(off)
+          const RayReg bo = loadRayV(a, s, 0, (int)owner);
+          const d3 qd = tod(bo.o) + tod(bo.d) * s.t[owner];
+          const double dx = (double)p.x - qd.x, dy = (double)p.y - qd.y, dz = (double)p.z - qd.z;
+          inside = dx * dx + dy * dy + dz * dz < (double)rad * (double)rad;
+        }
+        if (inside) {
+          atomicAdd(&s.found[owner], 1u);
+          const uint32_t bits = __float_as_uint(hp.w);
+          // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
+          const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edge[owner];
+          hit = true;
+          if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
+          if (!((bits >> 6) & 1u)) hit = false;
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (m) {
+        if (hit) {
+          const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+          s.queue[(qHead + qCount + off) % VQ] = make_uint2(gi, owner);
+        }
+        qCount += __popcll(m);
+        if (qCount >= 64u) {
+          __syncthreads();
+          evalBatch(true, s.queue[(qHead + lane) % VQ]);
+          qHead = (qHead + 64u) % VQ;
+          qCount -= 64u;
+          __syncthreads();
         }
       }
     }
-    rc = nc;
-    re = ne;
   }
   __syncthreads();
   if (qCount) evalBatch((uint32_t)lane < qCount, s.queue[(qHead + lane) % VQ]);
