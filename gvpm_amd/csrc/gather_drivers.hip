@@ -196,6 +196,13 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   }
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
+  if (deferred && !h->bundleFromEnv) {
+    const bool sharded = h->nsets > 0 && (size_t)h->nsets * 2u <= h->npix;
+    if (sharded != h->bundleEnabled) {
+      h->bundleEnabled = sharded;
+      if (sharded && h->bundleState < 0) h->bundleState = 0;  // (a frame that failed earlier is tried again, a few times)
+    }
+  }
   if (deferred && h->bundleEnabled && h->bundleState >= 0 && !force3D) {
     // G-BRE: the camera beams of a pinhole sensor leave one point -- cells over the bundle's (u, v) plane instead
     if (h->bundleState == 0) {

@@ -130,7 +130,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
   if (const char *e = getenv("GVPM_PLAN_BOXES")) h->planBoxHandOff = atoi(e) != 0;
-  if (const char *e = getenv("GVPM_BUNDLE")) h->bundleEnabled = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BUNDLE")) {
+    h->bundleEnabled = atoi(e) != 0;
+    h->bundleFromEnv = true;
+  }
   if (const char *e = getenv("GVPM_BUNDLE_DIV")) {
     const float v = (float)atof(e);
     if (v >= 0.25f && v <= 16.f) h->bundleDiv = v;
