@@ -292,34 +292,6 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
   }
 }
 
-// A shift that needs the manifold walk (shiftPhotonManifold, shift_volume_photon.cpp:160-295): what the walk reads goes
-// to the host's request list, what the device needs to finish the shift once the host has answered (:217-279) stays beside
-// it.  Rare and register hungry: not inlined.  False: the list is full -- a failed shift.
-static __device__ __noinline__ bool recordShiftRequest(const GatherArgs &a, uint32_t pidx, uint32_t set, int i, f3 offsetPos, f3 basePt,
-                                                       f3 shiftPt, float tPrime, float tr, float pdfCam, float pdfShiftPos, float sMIS,
-                                                       float scale, f3 bc, f3 shD, f3 eye, uint32_t pix) {
-  const uint32_t slot = atomicAdd(a.reqCount, 1u);
-  if (slot >= a.reqCap) return false;
-  gvpm_shift_request rq;
-  rq.photon = a.origIdx[pidx];
-  rq.set = set;
-  rq.shift = (uint32_t)i;
-  rq.reserved = 0u;
-  rq.offset_pos[0] = offsetPos.x; rq.offset_pos[1] = offsetPos.y; rq.offset_pos[2] = offsetPos.z;
-  rq.radius = a.radius;
-  rq.base_point[0] = basePt.x; rq.base_point[1] = basePt.y; rq.base_point[2] = basePt.z;
-  rq.t = tPrime;
-  rq.shift_point[0] = shiftPt.x; rq.shift_point[1] = shiftPt.y; rq.shift_point[2] = shiftPt.z;
-  rq.reserved2 = 0.f;
-  a.reqHost[slot] = rq;
-  float4 *c = a.reqCtx + 4 * (size_t)slot;
-  c[0] = make_float4(tr, pdfCam, pdfShiftPos, sMIS);
-  c[1] = make_float4(scale, bc.x, bc.y, bc.z);
-  c[2] = make_float4(shD.x, shD.y, shD.z, __uint_as_float(pix));
-  c[3] = make_float4(eye.x, eye.y, eye.z, __uint_as_float((uint32_t)i));
-  return true;
-}
-
 // The rest of shiftPhotonManifold for the recorded requests, once the host has run the walks (results == nullptr: it has
 // not -- every request is a failed shift): shift_volume_photon.cpp:205-279, then the accumulation of :843-853.
 __global__ __launch_bounds__(256) void apply_host_shifts_kernel(GatherArgs a, const gvpm_host_shift *__restrict__ results, uint32_t n) {
@@ -456,7 +428,7 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   if (HS && GVPM_PF_SHIFT_TYPE(ph.bits) == 3u) {
     // EManifoldShift: the walk is the host's (recordShiftRequest); nothing is added now
     const f3 shiftPt = basePt + dS;
-    if (recordShiftRequest(a, pidx, a.setPerm[s.setBase + b], i, shiftPt + offRel, basePt, shiftPt, (float)tPrime, trT.x, pdfCam,
+    if (recordShiftRequest(a, a.radius, pidx, a.setPerm[s.setBase + b], i, shiftPt + offRel, basePt, shiftPt, (float)tPrime, trT.x, pdfCam,
                            pdfShiftPos, sr.sMIS, scale, bc, sh.d, sh.eye, s.pix[b])) {
       sf = wb = mk3(0.f);
     } else {

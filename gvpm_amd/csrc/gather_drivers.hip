@@ -250,7 +250,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   }
   HIP_TRY(h, h->bs->overflowCtr.ensure(2));
   HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
-  const bool wantOrig = deferred && h->reqCap > 0 && h->cfg.use_manifold;
+  const bool wantOrig = h->reqCap > 0 && h->cfg.use_manifold;  // (host-shift requests name photons by their place in the upload)
   if (wantOrig) HIP_TRY(h, h->bs->origIdx.ensure((size_t)n + 1));
   // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only);
   // word 0 is the allocation cursor
@@ -895,6 +895,23 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
+  if (h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
+    // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing; the answered
+    // terms are added straight to the accumulators (plain sums: this iteration's buffer is folded right below)
+    HIP_TRY(h, h->reqHost.ensure(h->reqCap));
+    HIP_TRY(h, h->reqCtx.ensure(4 * h->reqCap));
+    HIP_TRY(h, h->reqCount.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
+    a.reqHost = h->reqHost.p;
+    a.reqCtx = h->reqCtx.p;
+    a.reqCount = h->reqCount.p;
+    a.reqCap = (uint32_t)h->reqCap;
+    a.origIdx = h->bs->origIdx.p;
+    h->reqArgs = a;
+    h->reqArgs.iter = h->accum.p;
+    h->reqArgs.iterScale = 1.f;
+    h->reqOutstanding = true;
+  }
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   launch_gather_vpm(a, needFullVis(h), h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));

@@ -168,6 +168,7 @@ __device__ __forceinline__ void vpmAddShift(VpmLds &s, uint32_t b, int i, const 
 // of each of the four shifts everything but the reconnection -- the null shift, the failed ones.  Returns the mask of
 // the shifts that need shiftPhotonDiffuse; those are queued and run densely in phase 2 (87 % of the shifts at C1 are
 // null shifts, but a batch that evaluates in one pass pays for the reconnection code of the few lanes that take it).
+template <bool HS>
 __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
                                               uint32_t &nNull, uint32_t &nFail) {
 #if GVPM_VPM_PROBE == 1
@@ -202,7 +203,8 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
         nNull++;
       } else if (a.cfg.debug_shift != GVPM_SHIFT_NULL) {
         const uint32_t st = GVPM_PF_SHIFT_TYPE(v.ph.bits);
-        if (st == 1u || st == 2u) {
+        // (HS: a manifold-typed photon goes to phase 2 too -- it records the host's request there, gvpm_enable_host_shifts)
+        if (st == 1u || st == 2u || (HS && st == 3u)) {
           qMask |= 1u << i;
           continue;  // phase 2 adds this shift's terms
         }
@@ -216,7 +218,7 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
 
 // Phase 2: the reconnection of shift i (getShiftPos with coherent = false, shift_volume_photon.cpp:858-896, then
 // shiftPhotonDiffuse) for one queued (photon, sample, shift).
-template <bool FULLVIS>
+template <bool FULLVIS, bool HS>
 __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t meta, float norm,
                                           uint32_t &nDiff, uint32_t &nFail) {
   const uint32_t b = meta & 0xFFu;
@@ -233,6 +235,18 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
     const f3 bo = dS + offRel;
     if (dot(bo, bo) < v.r2) offRel = offRel + dS * (-2.f * dot(dS, offRel) / dot(dS, dS));
   }
+  if (HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) {
+    // EManifoldShift (shiftPhoton -> shiftPhotonManifold, shift_volume_photon.cpp:49-117,160-295): the walk is the host's.
+    // Recorded with what the device needs to finish the shift (apply_host_shifts_kernel): nothing is added now.  The base
+    // contribution rides along already scaled, as G-BRE's does.
+    const f3 zPf = tof(zP), basePtF = tof(v.basePt);
+    if (!recordShiftRequest(a, s.radius[b], pidx, s.set[b], i, zPf + offRel, basePtF, zPf, v.tf, v.trS, v.pdfBase, pdfShift,
+                            sensorMIS(sh, v.base, v.edge), v.scale, v.baseContrib * v.scale, sh.d, sh.eye, s.pix[b])) {
+      nFail++;  // the list is full: a failed shift (weight 1)
+      vpmAddShift(s, b, i, mk3(0.f), v.baseContrib, 1.f, v.scale, v.px, v.py, a);
+    }
+    return;
+  }
   const f3 dProjU = (tof(zP) - v.ph.parentPos) + offRel;
   bool ok = false;
   f3 sflux = mk3(0.f);
@@ -241,7 +255,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
 }
 
-template <bool FULLVIS>
+template <bool FULLVIS, bool HS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
   __shared__ VpmLds s;
   const int lane = threadIdx.x;
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
     __syncthreads();
     if ((uint32_t)lane < n) {
       const uint2 e = s.rq[(rqHead + lane) % VRQ];
-      vpmPhase2<FULLVIS>(a, s, e.x, e.y, norm, nDiff, nFail);
+      vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail);
     }
     rqHead = (rqHead + n) % VRQ;
     rqCount -= n;
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   auto evalBatch = [&](bool valid, uint2 e) {  // phase 1 for one (photon, sample) pair per lane
     uint32_t qMask = 0u;
     if (valid) {
-      qMask = vpmPhase1(a, s, e.x, e.y, norm, nNull, nFail);
+      qMask = vpmPhase1<HS>(a, s, e.x, e.y, norm, nNull, nFail);
       nEval++;
     }
 #pragma unroll 1
@@ -582,8 +596,16 @@ __global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ acc
 
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream) {
   if (a.nsamples == 0) return;
-  if (fullVis) hipLaunchKernelGGL(gather_vpm_kernel<true>, dim3((a.nsamples + 63u) / 64u), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL(gather_vpm_kernel<false>, dim3((a.nsamples + 63u) / 64u), dim3(64), 0, stream, a);
+  const dim3 grid((a.nsamples + 63u) / 64u);
+  if (a.reqHost) {
+    // manifold-typed shifts go to the host's request list (an instantiation of its own: the default one keeps its registers)
+    if (fullVis) hipLaunchKernelGGL((gather_vpm_kernel<true, true>), grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((gather_vpm_kernel<false, true>), grid, dim3(64), 0, stream, a);
+  } else if (fullVis) {
+    hipLaunchKernelGGL((gather_vpm_kernel<true, false>), grid, dim3(64), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((gather_vpm_kernel<false, false>), grid, dim3(64), 0, stream, a);
+  }
 }
 
 void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,

@@ -308,6 +308,34 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   return ok ? w : 1.f;
 }
 
+// A shift that needs the manifold walk (shiftPhotonManifold, shift_volume_photon.cpp:160-295): what the walk reads goes
+// to the host's request list, what the device needs to finish the shift once the host has answered (:217-279) stays beside
+// it.  Rare and register hungry: not inlined.  False: the list is full -- a failed shift.
+static __device__ __noinline__ bool recordShiftRequest(const GatherArgs &a, float radius, uint32_t pidx, uint32_t set, int i, f3 offsetPos, f3 basePt,
+                                                       f3 shiftPt, float tPrime, float tr, float pdfCam, float pdfShiftPos, float sMIS,
+                                                       float scale, f3 bc, f3 shD, f3 eye, uint32_t pix) {
+  const uint32_t slot = atomicAdd(a.reqCount, 1u);
+  if (slot >= a.reqCap) return false;
+  gvpm_shift_request rq;
+  rq.photon = a.origIdx[pidx];
+  rq.set = set;
+  rq.shift = (uint32_t)i;
+  rq.reserved = 0u;
+  rq.offset_pos[0] = offsetPos.x; rq.offset_pos[1] = offsetPos.y; rq.offset_pos[2] = offsetPos.z;
+  rq.radius = radius;  // (G-VPM: the pixel's own radius)
+  rq.base_point[0] = basePt.x; rq.base_point[1] = basePt.y; rq.base_point[2] = basePt.z;
+  rq.t = tPrime;
+  rq.shift_point[0] = shiftPt.x; rq.shift_point[1] = shiftPt.y; rq.shift_point[2] = shiftPt.z;
+  rq.reserved2 = 0.f;
+  a.reqHost[slot] = rq;
+  float4 *c = a.reqCtx + 4 * (size_t)slot;
+  c[0] = make_float4(tr, pdfCam, pdfShiftPos, sMIS);
+  c[1] = make_float4(scale, bc.x, bc.y, bc.z);
+  c[2] = make_float4(shD.x, shD.y, shD.z, __uint_as_float(pix));
+  c[3] = make_float4(eye.x, eye.y, eye.z, __uint_as_float((uint32_t)i));
+  return true;
+}
+
 // computeVolumeContribution (gvpm/shift/shift_utilities.h:231-253) and the debugShift filter
 // (shift_volume_photon.cpp:680-687) depend only on the photon and the configuration: fold
 // them into bit 6 of the hot record.

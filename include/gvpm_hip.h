@@ -480,7 +480,8 @@ int gvpm_prefetch_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_comp
  * from) needs the manifold walk of shiftPhotonManifold (shift_volume_photon.cpp:160-295: generateShiftPathME + ShiftME,
  * shift/operation/shift_ME.cpp:13-142, SpecularManifold::det, src/libbidir/mut_manifold.cpp:1310-1410) -- Newton iterations
  * over Mitsuba's Path / BSDF objects that stay on the host.  With use_manifold = 0 such a shift is a failed shift (weight 1),
- * as in the reference.  With use_manifold = 1 and gvpm_enable_host_shifts(h, capacity > 0), a G-BRE gather instead RECORDS
+ * as in the reference.  With use_manifold = 1 and gvpm_enable_host_shifts(h, capacity > 0), a G-BRE or (round 4) G-VPM gather
+ * (VolumeGradientPositionQuery reaches the same dispatch, shift_volume_photon.cpp:489-655 -> :49-117) instead RECORDS
  * one request per (photon, beam, shifted pixel) that reaches shiftPhotonManifold -- everything the walk takes as input -- and
  * adds nothing for it; the host runs the walk for each request and hands the results back; the device then applies
  * shift_volume_photon.cpp:217-279 (contribution, Jacobian, MIS weight) and adds the terms to the iteration:
@@ -493,7 +494,7 @@ typedef struct gvpm_shift_request { /* 64 bytes */
   uint32_t shift;           /* ... which of its shifted rays: 0..3 = L R T B                                              */
   uint32_t reserved;
   float offset_pos[3];      /* offsetPos (getShiftPos, :858-896): where vertex c of the proposal lies                     */
-  float radius;             /* photonRadius (the host multiplies by its config.relaxME)                                   */
+  float radius;             /* photonRadius (the host multiplies by its config.relaxME); G-VPM: the pixel's own radius   */
   float base_point[3];      /* baseRay(baseRay.maxt)                                                                      */
   float t;                  /* baseRay.maxt = shiftRay.maxt = t'                                                          */
   float shift_point[3];     /* shiftRay(shiftRay.maxt)                                                                    */

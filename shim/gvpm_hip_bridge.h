@@ -57,9 +57,9 @@ public:
     p.power_heuristic = config.powerHeuristic ? 1 : 0;
     p.no_medium_shift = config.noMediumShift ? 1 : 0;
     p.use_manifold = config.useManifold ? 1 : 0;                    /* the manifold WALK stays on the host: the G-BRE
-                                                                       gather records a request per such shift and
-                                                                       answerShiftRequests() below answers them; the
-                                                                       other techniques treat these shifts as
+                                                                       and G-VPM gathers record a request per such shift
+                                                                       and answerShiftRequests() below answers them; the
+                                                                       beam / plane techniques treat these shifts as
                                                                        useManifold=false does (:101-104)          */
     p.debug_shift = (int32_t) config.debugShift;                    /* ELightShiftType values kept                */
     p.lighting_interaction_mode = (int32_t) config.lightingInteractionMode;
@@ -125,7 +125,9 @@ public:
       m_bsdfsDirty = false;
     }
     check(gvpm_gather(m_h, it, (uint64_t) nbPaths), "gvpm_gather");
-    if (m_config.useManifold && (tech == EVolBRE2D || tech == EVolBRE3D)) answerShiftRequests(photonMap, threadData, scene);
+    /* manifold shifts: the point-kernel gathers (G-BRE, G-VPM) record their requests; G-Beams / G-Planes treat them as failed */
+    if (m_config.useManifold && (tech == EVolBRE2D || tech == EVolBRE3D || tech == EDistance))
+      answerShiftRequests(photonMap, threadData, scene);
     writeBack(gatherBlocks, tech == EDistance);
     float r = 0.f;
     check(gvpm_get_radius(m_h, &r), "gvpm_get_radius");

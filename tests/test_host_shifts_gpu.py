@@ -1,8 +1,10 @@
 """Manifold shifts through the host (include/gvpm_hip.h gvpm_enable_host_shifts ... gvpm_upload_host_shifts; SURVEY 8 row
-f4, first slice): the G-BRE gather records a request for every shift that reaches shiftPhotonManifold, the host answers,
-the device finishes the shift (shift_volume_photon.cpp:205-279).  The host's walk is Mitsuba's; here it is replaced, on
-both sides, by the oracle's stand-in (a smooth function of the request and the photon's parent) -- what is verified is the
-content of the requests and the arithmetic the device applies to the answers."""
+f4): the G-BRE and (round 4) G-VPM gathers record a request for every shift that reaches shiftPhotonManifold, the host
+answers, the device finishes the shift (shift_volume_photon.cpp:205-279).  The host's walk is Mitsuba's; here it is
+replaced by a STAND-IN (a smooth function of the request and the photon's parent).  The oracle has its own statement of the
+stand-in (gvpm_oracle.hpp standinManifoldWalk); the device is answered by a SECOND, independent numpy statement of it
+(standin_numpy below; round 3 fed the device the oracle's own routine) -- what is verified is the content of the requests
+and the arithmetic the device applies to the answers."""
 import numpy as np
 import pytest
 
@@ -21,6 +23,37 @@ def mirror_case(**over):
     return c
 
 
+def standin_numpy(ph, req):
+    """The stand-in of the host's manifold walk, stated independently of oracle/gvpm_oracle.hpp: a "reconnection" of the
+    proposal's vertex c to the photon's parent -- succeeds when the new segment is shorter than three times the old one;
+    throughput = prefix * |old| / |new|, new wi towards the parent, pdf = parent pdf * (|old| / |new|)^2 = the determinant
+    ratio, base pdf = parent pdf * edge pdf.  float64 on the uploaded fp32 records, rounded once into the answers."""
+    out = np.zeros(req.size, abi.HOST_SHIFT_DTYPE)
+    k = req["photon"].astype(np.int64)
+    par, pos = ph.parent_pos[k].astype(np.float64), ph.pos[k].astype(np.float64)
+    d = par - req["offset_pos"].astype(np.float64)
+    ln, lb = np.linalg.norm(d, axis=1), np.linalg.norm(par - pos, axis=1)
+    ok = (ln > 0) & (ln < 3.0 * lb)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(ln > 0, (lb * lb) / (ln * ln), 0.0)
+        out["wi"] = np.where(ln[:, None] > 0, d / ln[:, None], 0.0)
+        out["throughput"] = ph.prefix_w[k].astype(np.float64) * np.where(ln > 0, lb / ln, 0.0)[:, None]
+    out["ok"] = ok
+    out["pdf"] = ph.parent_pdf[k].astype(np.float64) * q
+    out["det_ratio"] = q
+    out["base_pdf"] = ph.parent_pdf[k].astype(np.float64) * ph.edge_pdf[k]
+    return out
+
+
+def test_the_two_statements_of_the_stand_in_agree():
+    c = mirror_case()
+    acc, st, req, n = device(c, False)
+    a, b = standin_numpy(c.ph, req), O.standin_host_shifts(c.ph, req)
+    assert np.array_equal(a["ok"], b["ok"]) and a["ok"].sum() > 100 and (~a["ok"].astype(bool)).sum() >= 0
+    for k in ("throughput", "wi", "pdf", "det_ratio", "base_pdf"):
+        assert np.allclose(a[k], b[k], rtol=2e-6, atol=1e-30), k
+
+
 def device(c, answer, cap=1 << 20):
     ctx = hip.Context(c.p, device=0)
     ctx.upload_scene(*c.tris)
@@ -31,7 +64,7 @@ def device(c, answer, cap=1 << 20):
     ctx.gather(c.it, c.nb)
     req, n = ctx.download_shift_requests(cap)
     if answer:
-        ctx.upload_host_shifts(O.standin_host_shifts(c.ph, req))
+        ctx.upload_host_shifts(standin_numpy(c.ph, req))
     acc = ctx.download_accum().astype(np.float64)
     st = ctx.stats()
     ctx.close()
@@ -103,3 +136,63 @@ def test_off_by_default_and_wrong_result_count():
     with pytest.raises(hip.GvpmError):
         ctx.upload_host_shifts(np.zeros(3, abi.HOST_SHIFT_DTYPE))
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- G-VPM
+def vpm_mirror_case(**over):
+    from test_oracle_vpm import make_vpm_case
+    c = make_vpm_case("cbox_mirror", 32, 28, 40000, 6.0, nb=10, use_manifold=1, **over)
+    assert (((c.ph.flags >> 2) & 7) == 3).sum() > 500
+    return c
+
+
+def device_vpm(c, answer, cap=1 << 20):
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.enable_host_shifts(cap)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    ctx.upload_vpm_samples(c.samples)
+    ctx.gather(1, c.nb)
+    req, n = ctx.download_shift_requests(cap)
+    if answer:
+        ctx.upload_host_shifts(standin_numpy(c.ph, req))
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    return acc, st, req, n
+
+
+@pytest.mark.parametrize("over", [dict(), dict(use_mis=0), dict(power_heuristic=1)])
+def test_vpm_answered_requests_give_the_oracles_manifold_shifts(over):
+    """computeVolumeGradientPhoton reaches the same dispatch (VolumeGradientPositionQuery -> shiftPhoton,
+    shift_volume_photon.cpp:489-655 -> :49-117): the G-VPM kernel records the same requests, with the pixel's own radius"""
+    c = vpm_mirror_case(**over)
+    acc, st, req, n = device_vpm(c, True)
+    assert n == req.size and n > 300
+    ref, sv, nv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=False)
+    assert st["evaluations"] == cnt["evaluations"] and st["null_shifts"] == cnt["null_shifts"]
+    assert abs(st["diffuse_shifts"] - cnt["diffuse_shifts"]) <= 2 and abs(st["failed_shifts"] - cnt["failed_shifts"]) <= 2
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert np.sqrt(((acc - ref) ** 2).mean()) / lum < 1e-4
+    assert (((c.ph.flags[req["photon"]] >> 2) & 7) == 3).all()
+    assert (req["set"] < c.rays.shape[0]).all() and (req["shift"] < 4).all()
+    base = c.rays[req["set"], 0]
+    sh = c.rays[req["set"], 1 + req["shift"].astype(np.int64)]
+    bp = base["o"].astype(np.float64) + base["d"] * req["t"][:, None].astype(np.float64)
+    sp = sh["o"].astype(np.float64) + sh["d"] * req["t"][:, None].astype(np.float64)
+    assert np.abs(bp - req["base_point"]).max() < 1e-5 and np.abs(sp - req["shift_point"]).max() < 1e-5
+    # the radius of a request is its pixel's: R * 0.01 * scaleVol (gvpm.cpp:1132), here the initial one everywhere
+    assert np.allclose(req["radius"], np.float32(c.p.bsphere_radius) * np.float32(0.01) * np.float32(c.p.initial_scale_volume), rtol=1e-6)
+    assert (np.linalg.norm(req["offset_pos"] - req["shift_point"], axis=1) <= 3.01 * req["radius"]).all()
+    # the answered terms matter
+    p0 = c.p.copy()
+    p0.use_manifold = 0
+    ref0, _, _, cnt0, _ = O.gather_vpm(p0, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=False)
+    assert np.sqrt(((ref0 - ref) ** 2).mean()) / lum > 1e-3
+    # ... and unanswered requests are failed shifts: the gather without the feature
+    acc0, st0, _, _ = device_vpm(c, False)
+    for k in COUNTERS:
+        assert st0[k] == cnt0[k], (k, st0, cnt0)
+    assert np.sqrt(((acc0 - ref0) ** 2).mean()) / lum < 1e-4
