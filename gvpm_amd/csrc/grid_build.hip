@@ -244,8 +244,21 @@ __device__ __forceinline__ void nearVisit(f3 P, const float4 *bvh, const float4 
     }
   }
 }
+// The wall the parent SITS ON cannot block its reconnections (round 4): the segment starts Epsilon along a direction that
+// leaves the wall's plane on the photon's side -- a direction into the wall fails the shift before visibility matters
+// (shift_volume_photon.cpp:404-412: the sign test on dot(n_g, dProj) / dot(n_g, edge.d)) -- and moves away from it.  Such
+// triangles (coplanar with the parent to position rounding, normal parallel to the parent's) were 95 % of S-cbox's list
+// entries: every evaluation wave walked the any-hit loop for tests that cannot succeed.  A medium parent has no normal
+// (zero): nothing is skipped for it.
+__device__ __forceinline__ bool ownWall(f3 P, f3 pn, const float4 *tri4, uint32_t i) {
+  const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
+  const f3 a = mk3(t0.x, t0.y, t0.z), n = mk3(t0.w, t1.w, t2.w);
+  const float tol = 1e-6f * (1.f + fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + fabsf(a.x) + fabsf(a.y) + fabsf(a.z));
+  return fabsf(dot(n, pn)) > 0.99999f && fabsf(dot(n, P - a)) <= tol;
+}
+
 template <int MODE>
-__device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
+__device__ __forceinline__ void nearOccluders(f3 P, f3 pn, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                                               const NearGrid &ng, uint32_t *ext, uint32_t extCap, uint32_t &w0, uint32_t &w1,
                                               uint32_t &w2) {
   w0 = w1 = w2 = 0xFFFFFFFFu;
@@ -254,6 +267,7 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const flo
   const uint32_t cap = narrow ? 12u : (wide ? 6u : 0u);
   uint32_t cnt = 0, a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
   nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) {
+    if (ownWall(P, pn, tri4, i)) return;
     if (cnt < cap) {
       uint32_t word, sh, m;
       if (narrow) { word = cnt >> 2; sh = 8u * (cnt & 3u); m = ~(0xFFu << sh); }
@@ -278,7 +292,9 @@ __device__ __forceinline__ void nearOccluders(f3 P, const float4 *bvh, const flo
   }
   ext[off] = cnt;
   uint32_t k = 0;
-  nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) { ext[off + 1u + (k++)] = i; });
+  nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) {
+    if (!ownWall(P, pn, tri4, i)) ext[off + 1u + (k++)] = i;
+  });
   w0 = 0xFDFFFFFFu;
   w1 = off;
 }
@@ -316,7 +332,8 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
     stg[t][4] = ld3(r.parent_n, src, r.parent_g[src]);
     const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
     uint32_t w0, w1, w2;
-    nearOccluders<MODE>(P, bvh, tri4, ntri, dmax, ng, nearExt, extCap, w0, w1, w2);
+    const f3 PN = mk3(r.parent_n[3 * (size_t)src], r.parent_n[3 * (size_t)src + 1], r.parent_n[3 * (size_t)src + 2]);
+    nearOccluders<MODE>(P, PN, bvh, tri4, ntri, dmax, ng, nearExt, extCap, w0, w1, w2);
     if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
     stg[t][5] = ld3(r.prefix_w, src, __uint_as_float(w0));
     stg[t][6] = ld3(r.parent_scat, src, __uint_as_float(w1));
