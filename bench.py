@@ -97,12 +97,17 @@ def main():
     ap.add_argument("--device-gen", action="store_true",
                     help="probe (SURVEY 8f3): every step shoots its photons and generates its camera beams on the GPU "
                          "(gvpm_devgen_*) inside the timed region instead of reading pre-generated inputs from HBM")
+    ap.add_argument("--primal", action="store_true",
+                    help="probe (SURVEY 8f3): the PRIMAL beam radiance estimate of the reference's sppm integrator "
+                         "(gvpm_gather_primal) on the same inputs instead of the gradient gather; not the bench line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to smoke-test "
                                                       "the N > 1 code path on a one-GPU box together with --single-device")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (smoke test, not a bench line)")
     args = ap.parse_args()
     if args.only_timed:
         args.no_cpu_baseline = args.no_parity = args.no_upload_inclusive = args.no_isolated = True
+    if args.primal:
+        args.no_cpu_baseline = args.no_upload_inclusive = args.no_isolated = True
     if args.workload in ("c1", "c3", "c5"):
         return main_technique(args)
     if args.scale == 0.0:
@@ -151,6 +156,8 @@ def main():
     if args.technique == "bre2d":
         p.use_shift_null = 0  # GPMConfig::load rejects useShiftNull for the 2D kernel (gvpm_struct.h:310-313)
     p.initial_scale_volume = args.scale
+    if args.primal:
+        p.path_set = 0  # (the primal pass has no checkerboard, sppm.cpp:882-1000)
     m, tris = sc.medium(), sc.triangles()
     ctx = hip.Context(p, device=local_rank)
     ctx.upload_scene(*tris)
@@ -193,7 +200,10 @@ def main():
             soa, nph, nb, rptr, nsets = inputs[(it - 1) % ndist]
         ctx.upload_photons_dev(soa)
         ctx.upload_camera_beams_dev(rptr, nsets)
-        ctx.gather(it, nb)
+        if args.primal:
+            ctx.gather_primal(it, nb)
+        else:
+            ctx.gather(it, nb)
 
     def barrier():
         torch.cuda.synchronize()
@@ -266,7 +276,8 @@ def main():
             except (KeyError, ValueError, OSError):
                 pass
         out = {
-            "metric": "photon gather+shift evaluations per second (G-BRE %s)" % ("3D" if args.technique == "bre3d" else "2D"),
+            "metric": ("PROBE: primal beam-radiance-estimate evaluations per second (sppm volumePhotonPassBRE, %s kernel)"
+                       if args.primal else "photon gather+shift evaluations per second (G-BRE %s)") % ("3D" if args.technique == "bre3d" else "2D"),
             "value": evals_total / elapsed / 1e6,
             "unit": "Mevals/s",
             "n_gpus": world,
@@ -294,7 +305,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "evaluate_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
+                "kernel": "evaluate_primal_kernel" if args.primal else "evaluate_bre_kernel", "kernel_avg_ms": kms, "launches": klaunches,
                 "traverse_avg_ms": ctx.phase_time(1)[0], "build_avg_ms": ctx.phase_time(2)[0],
                 "note": "build + traversal of the next steps run on other streams while this kernel evaluates step N: "
                         "the durations include that sharing (kernel_isolated_ms: the same kernel alone, GVPM_PIPELINE=0)",
@@ -328,7 +339,9 @@ def main():
                     out["roofline"]["frac_isolated"] = bytes_alg / (ims * 1e-3) / 1e9 / 8000.0
             finally:
                 os.environ.pop("GVPM_PIPELINE", None)
-        if world == 1 and not gen and not args.no_parity:
+        if world == 1 and not gen and not args.no_parity and args.primal:
+            out.update(parity_primal(hip, metrics, p, m, tris, host0[0], W, H))
+        elif world == 1 and not gen and not args.no_parity:
             out.update(parity(hip, metrics, sc, p, m, tris, host0[0], W, H))
         if world == 1 and not args.no_cpu_baseline and not gen:
             out["cpu_baseline"] = cpu_baseline(p, m, tris, host0[:args.cpu_iters], W, H)
@@ -706,6 +719,34 @@ def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed
                "host-to-device copies run at ~33 instead of 55 GB/s for stretches of 50-100 ms, which a single pass of 16 "
                "steps can fall into",
     }
+
+
+def parity_primal(hip, metrics, p, m, tris, first, W, H):
+    """--primal: step 1 on a centred 32x32-pixel window (the full photon map) against the fp64 oracle's literal restatement of
+    the reference's sppm pass (oracle/gvpm_oracle_primal.hpp)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    ph, nb, rays = first
+    w = 32
+    x0, y0 = (W - w) // 2, (H - w) // 2
+    wr = np.ascontiguousarray(rays[_window(rays, x0, y0, w, w)])
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*tris)
+    ctx.upload_medium(m)
+    ctx.upload_photons(ph)
+    ctx.upload_camera_beams(wr)
+    r = ctx.radius()
+    ctx.gather_primal(1, nb)
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    ref, cnt = O.gather_primal_bre(p, m, tris, ph, wr, r, 1, nb, precision=64, use_accel=True)
+    win = (slice(y0, y0 + w), slice(x0, x0 + w))
+    lum = ref[win][..., 0:3].mean()
+    l2 = metrics.l2_over_luminance(acc[win], ref[win], lum)
+    return {"parity_l2": l2,
+            "parity": {"what": f"step 1, centred {w}x{w}-pixel window, full photon map, fp64 oracle of the primal pass (walk over the hierarchy)",
+                       "evaluations_device": st["evaluations"], "evaluations_oracle": cnt["evaluations"], "l2_accumulators": l2}}
 
 
 def parity(hip, metrics, sc, p, m, tris, first, W, H):

@@ -52,6 +52,9 @@ void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uin
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
                          uint32_t nwaves, bool persistent, hipStream_t stream);
+void launch_evaluate_primal(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
+                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
+                            uint32_t nwaves, hipStream_t stream);
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                          uint32_t nwaves, bool persistent, hipStream_t stream);

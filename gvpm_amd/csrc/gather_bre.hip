@@ -1177,6 +1177,173 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The PRIMAL beam radiance estimate (second half): BeamRadianceEstimator::query,
+// src/integrators/photonmapper/bre.cpp:166-254, as SPPMIntegrator::volumePhotonPassBRE drives it (sppm.cpp:882-1000,
+// cameraHeuristic = true: the gradient pass's uniform radius).  A strict subset of the gradient gather: same grid, planner,
+// traversal and pair lists; this kernel walks an item's lists like evaluate_bre_kernel but evaluates the primal query's
+// term only -- re-based ray (:168), stored power without sigma_s, one random number PER HIT for the 3D kernel (Philox keyed
+// by the beam's `rand` and the photon's position bits: the reference's comes from a stateful sampler in traversal order),
+// a far check for the 2D kernel (:240-242), no checkerboard, no shifts.  The hit decision is the reference's own, in
+// uncontracted fp64 in its operation order (this is not the headline kernel: no banded fp32 fast path), so the evaluated
+// set equals the fp64 oracle's (oracle/gvpm_oracle_primal.hpp); radiometry fp32.
+// ------------------------------------------------------------------------------------------
+template <int B> struct PrimalLds : RayTile<B> {
+  double acc[3][B];
+  uint32_t boff[B + 1];
+};
+
+__device__ __forceinline__ float primalHitRandom(float setRand, f3 pos) {
+  uint32_t k0 = __float_as_uint(setRand), k1 = 0x70726d6cu;
+  uint32_t c0 = __float_as_uint(pos.x), c1 = __float_as_uint(pos.y), c2 = __float_as_uint(pos.z), c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+// bre.cpp:168-223 / :240-242 for one (photon, beam) pair: accepted?  tR: the distance the transmittance is taken over
+// (on the re-based ray), deltaT: half the kernel's chord.
+__device__ __forceinline__ bool primalDecide(f3 pf, f3 of, f3 df, float len, float r, float eps, float setRand, bool use3D,
+                                             double &tR, double &deltaT) {
+#pragma clang fp contract(off)
+  const double mint = (double)eps, maxtRay = (double)len - (double)eps;
+  const double dx = df.x, dy = df.y, dz = df.z;
+  // ray = Ray(r(r.mint), r.d, 0, r.maxt - r.mint)
+  const double ox = (double)of.x + dx * mint, oy = (double)of.y + dy * mint, oz = (double)of.z + dz * mint;
+  const double maxt = maxtRay - mint;
+  const double px = pf.x, py = pf.y, pz = pf.z;
+  const double cx = px - ox, cy = py - oy, cz = pz - oz;
+  const double disk = cx * dx + cy * dy + cz * dz;
+  const double qx = ox + dx * disk, qy = oy + dy * disk, qz = oz + dz * disk;
+  const double vx = qx - px, vy = qy - py, vz = qz - pz;
+  const double distSqr = vx * vx + vy * vy + vz * vz;
+  const double radius = (double)r, radSqr = radius * radius;
+  tR = disk;
+  deltaT = 0.0;
+  if (!(disk > 0 && distSqr < radSqr)) return false;
+  if (use3D) {
+    if (disk - (radius * 2) > maxt) return false;
+    deltaT = sqrt(radSqr - distSqr);
+    const double tminKernel = disk - deltaT;
+    tR = tminKernel + 2 * deltaT * (double)primalHitRandom(setRand, pf);
+    return !(tR < 0 || tR > maxt);
+  }
+  return !(disk > maxt);
+}
+
+template <int B>
+__global__ __launch_bounds__(64) void evaluate_primal_kernel(GatherArgs a, const uint4 *__restrict__ items,
+                                                             const uint2 *__restrict__ itemOff,
+                                                             const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
+                                                             const uint32_t *__restrict__ pairs,
+                                                             const uint32_t *__restrict__ pairCnt) {
+  __shared__ PrimalLds<B> s;
+  const int lane = threadIdx.x;
+  const uint32_t nItems = *itemCount;
+  const bool use3D = a.cfg.vol_technique == GVPM_VOL_BRE3D;
+  const float r = a.radius;
+  const float kernelVol = use3D ? (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r : 3.14159265358979323846f * r * r;
+  const float weight = 1.f / kernelVol;
+  unsigned long long nEval = 0;
+  bool firstItem = true;
+  for (;;) {
+    uint32_t it = blockIdx.x;
+    if (!firstItem) {
+      if (lane == 0) it = gridDim.x + atomicAdd(queueHead, 1u);
+      it = __shfl(it, 0, 64);
+    }
+    firstItem = false;
+    if (it >= nItems) break;
+    const uint4 item = items[it];
+    const uint32_t setBase = item.x, nb = item.y & 0xFFu;
+    if (nb == 0) continue;
+    const uint32_t cntb = (uint32_t)lane < nb ? pairCnt[(size_t)it * B + lane] : 0u;
+    const uint32_t incl = wave_scan_incl(cntb, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0) continue;
+    const uint2 reg = itemOff[it];
+    const uint32_t *lists = pairs + (size_t)reg.x * 64u;
+    const uint32_t cap = reg.y;
+    __syncthreads();
+    if (lane < B) s.boff[lane + 1] = incl;
+    if (lane == 0) s.boff[0] = 0u;
+    loadTileRaysNoSync<B>(a, s, setBase, nb, lane);
+    for (int idx = lane; idx < 3 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+    __syncthreads();
+    const uint32_t chunk = (total + 63u) / 64u;
+    const uint32_t g0 = min(total, (uint32_t)lane * chunk), g1 = min(total, g0 + chunk);
+    uint32_t cur = 0;
+    if (g0 < g1)
+      while (s.boff[cur + 1] <= g0) cur++;
+    f3 sum = mk3(0.f);
+    bool dirty = false;
+    for (uint32_t g = g0; g < g1; ++g) {
+      uint32_t b = cur;
+      while (s.boff[b + 1] <= g) b++;
+      if (b != cur) {
+        if (dirty) {
+          atomicAdd(&s.acc[0][cur], (double)sum.x);
+          atomicAdd(&s.acc[1][cur], (double)sum.y);
+          atomicAdd(&s.acc[2][cur], (double)sum.z);
+        }
+        sum = mk3(0.f);
+        dirty = false;
+        cur = b;
+      }
+      const uint32_t pidx = lists[(size_t)b * cap + (g - s.boff[b])];
+      const PhotonFront ph = loadFront(a, pidx);
+      const RayReg base = loadRay(s, 0, cur);
+      double tR, deltaT;
+      if (!primalDecide(ph.pos, base.o, base.d, base.len, r, a.cfg.epsilon, s.rnd[cur], use3D, tR, deltaT)) continue;
+      // result += Tr * power * phase(wi, -d) * (weight * scaleFactor) [* max(2 deltaT, 1e-4)]; * beam.weight (sppm.cpp:976-981)
+      f3 trT;
+      float dummy;
+      mediumEval(a.med, (float)tR, trT, dummy);
+      const float inv = use3D ? fmaxf(2.f * (float)deltaT, 0.0001f) : 1.f;
+      sum = sum + ph.flux * base.eye * (trT.x * phaseEval(a.med.g, ph.wi, -base.d) * weight * inv);
+      dirty = true;
+      nEval++;
+    }
+    if (dirty) {
+      atomicAdd(&s.acc[0][cur], (double)sum.x);
+      atomicAdd(&s.acc[1][cur], (double)sum.y);
+      atomicAdd(&s.acc[2][cur], (double)sum.z);
+    }
+    __syncthreads();
+    for (int idx = lane; idx < 3 * B; idx += 64) {
+      const int k = idx / B, bb = idx % B;
+      if ((uint32_t)bb < nb) {
+        const float v = (float)s.acc[k][bb];
+        if (v != 0.f) {
+          const uint32_t pv = s.pix[bb];
+          atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v * a.iterScale);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nEval += __shfl_xor(nEval, o, 64);
+  if (lane == 0 && nEval) atomicAdd(&statRow(a)[0], nEval);
+}
+
+void launch_evaluate_primal(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
+                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
+                            uint32_t nwaves, hipStream_t stream) {
+  if (a.nsets == 0 || nwaves == 0) return;
+  switch (beamsPerWave) {
+    case 64: hipLaunchKernelGGL(evaluate_primal_kernel<64>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    case 32: hipLaunchKernelGGL(evaluate_primal_kernel<32>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+    default: hipLaunchKernelGGL(evaluate_primal_kernel<16>, dim3(nwaves), dim3(64), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt); break;
+  }
+}
+
 // itemCount / blockTotal must be zero on entry (memset on the same stream)
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
                      uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, uint32_t itemCap, hipStream_t stream) {

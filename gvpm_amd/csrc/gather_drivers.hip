@@ -373,7 +373,7 @@ static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, i
 // Pipeline: the build of this step (grid, beam sort, planner) runs on streamB into the build set
 // the previous step is NOT reading, so it overlaps the previous step's evaluation kernel; the
 // host waits once (planner counters) and then queues traversal + evaluation on the gather stream.
-static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
+static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = false) {
   const float r = currentRadius(h);
   static const bool traceHost = getenv("GVPM_TRACE_HOST") != nullptr;
   auto T0 = std::chrono::steady_clock::now();
@@ -536,7 +536,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
   // rank's step at C4 with 12 waves per CU, -3 % at C2)
   const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u)
                               ? std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS) : h->nwaves;
-  if (h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
+  if (!primal && h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
     // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing
     HIP_TRY(h, h->reqHost.ensure(h->reqCap));
     HIP_TRY(h, h->reqCtx.ensure(4 * h->reqCap));
@@ -551,6 +551,11 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths) {
     h->reqOutstanding = true;
   }
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
+  if (primal)
+    // the primal beam radiance estimate over the same items and pair lists (gather_bre.hip, evaluate_primal_kernel)
+    launch_evaluate_primal(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 2,
+                           h->bs->pairs.p, h->bs->pairCnt.p, std::max<uint32_t>(1u, std::min<uint32_t>(nItems, h->ncu * 16u)), h->stream);
+  else
   launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
                       h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItems, h->persistentEval,
                       h->stream);
@@ -985,8 +990,23 @@ int gvpm_upload_host_shifts(gvpm_context *h, const gvpm_host_shift *results, uin
   return GVPM_OK;
 }
 
+static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal);
 int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   CHECK_H(h);
+  return gatherEntry(h, it, nb_paths, false);
+}
+int gvpm_gather_primal(gvpm_context *h, int it, uint64_t nb_paths) {
+  CHECK_H(h);
+  const gvpm_params &c = h->cfg;
+  if (c.vol_technique != GVPM_VOL_BRE2D && c.vol_technique != GVPM_VOL_BRE3D)
+    return fail(h, GVPM_ERR_UNSUPPORTED, "gvpm_gather_primal: the primal estimator built is the beam radiance estimate (BRE 2D / 3D)");
+  // the primal pass has none of the gradient pass's filters (sppm.cpp:882-1000): the handle must not carry them
+  if (c.path_set || c.debug_shift != GVPM_SHIFT_ALL || c.min_depth != 0 || c.bsdf_interaction_mode != GVPM_BSDF_ALL ||
+      !((c.lighting_interaction_mode & GVPM_SURF2MEDIA) && (c.lighting_interaction_mode & GVPM_MEDIA2MEDIA)))
+    return fail(h, GVPM_ERR_UNSUPPORTED, "gvpm_gather_primal: path_set, debug_shift, min_depth and the interaction modes must be neutral");
+  return gatherEntry(h, it, nb_paths, true);
+}
+static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) {
   if (it < 1 || nb_paths == 0) return fail(h, GVPM_ERR_INVALID_ARG, "it must be >= 1 and nb_paths > 0");
   if (!h->haveMedium || !h->havePhotons || !h->haveBeams)
     return fail(h, GVPM_ERR_STATE, "gather needs medium, photons and camera beams uploaded");
@@ -1039,7 +1059,7 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
   int rc;
   switch (h->cfg.vol_technique) {
     case GVPM_VOL_BRE2D:
-    case GVPM_VOL_BRE3D: rc = gatherBRE(h, it, nb_paths); break;
+    case GVPM_VOL_BRE3D: rc = gatherBRE(h, it, nb_paths, primal); break;
     case GVPM_DISTANCE: rc = gatherVPM(h, it, nb_paths); break;
     case GVPM_BEAM_BEAM_1D:
     case GVPM_BEAM_BEAM_3D_OPTIMIZED: rc = gatherBeams(h, it, nb_paths); break;

@@ -32,7 +32,7 @@ SYMBOLS = [
     "gvpm_prefetch_camera_beams_packed",
     "gvpm_enable_host_shifts", "gvpm_download_shift_requests", "gvpm_upload_host_shifts",
     "gvpm_upload_sensor", "gvpm_pack_camera_beams_compact", "gvpm_unpack_camera_beams_compact",
-    "gvpm_upload_camera_beams_compact", "gvpm_prefetch_camera_beams_compact", "gvpm_upload_bsdfs",
+    "gvpm_upload_camera_beams_compact", "gvpm_prefetch_camera_beams_compact", "gvpm_upload_bsdfs", "gvpm_gather_primal",
 ]
 
 
@@ -71,6 +71,7 @@ def lib():
         L.gvpm_upload_vpm_samples_dev.argtypes = [vp, vp, C.c_uint64]
         L.gvpm_download_vpm_state.argtypes = [vp, vp, vp]
         L.gvpm_gather.argtypes = [vp, C.c_int, C.c_uint64]
+        L.gvpm_gather_primal.argtypes = [vp, C.c_int, C.c_uint64]
         L.gvpm_get_radius.argtypes = [vp, C.POINTER(C.c_float)]
         L.gvpm_set_global_scale.argtypes = [vp, C.c_float]
         L.gvpm_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
@@ -467,6 +468,10 @@ class Context:
 
     def gather(self, it, nb_paths):
         self._check(lib().gvpm_gather(self._h, it, nb_paths))
+
+    def gather_primal(self, it, nb_paths):
+        """the primal beam radiance estimate (sppm's volumePhotonPassBRE): fluxVol in the first three accumulators"""
+        self._check(lib().gvpm_gather_primal(self._h, it, nb_paths))
 
     def radius(self):
         r = C.c_float()

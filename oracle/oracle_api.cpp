@@ -11,6 +11,7 @@
 #include "gvpm_oracle.hpp"
 #include "gvpm_oracle_beams.hpp"
 #include "gvpm_oracle_planes.hpp"
+#include "gvpm_oracle_primal.hpp"
 #include "poisson_oracle.hpp"
 #include "camera_path_oracle.hpp"
 
@@ -65,6 +66,50 @@ int gatherBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
   if (counters) {
     counters[0] = total.evaluations; counters[1] = total.candidates; counters[2] = total.nullShifts;
     counters[3] = total.diffuseShifts; counters[4] = total.failedShifts;
+  }
+  return GVPM_OK;
+}
+
+// One iteration of the PRIMAL sppm integrator's volumePhotonPassBRE, sppm.cpp:882-1000 (gvpm_oracle_primal.hpp)
+template <typename F>
+int gatherPrimalBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
+                    const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it, uint64_t nbPaths, int useAccel,
+                    int threads, double *accum, uint64_t *counters) {
+  Gatherer<F> g;
+  g.setup(*p, *m, *t);
+  g.map.load(*ph);
+  if (useAccel) g.map.buildBRE((F)radius);
+  else g.map.radius = (F)radius;
+  const size_t P = (size_t)p->width * p->height;
+  std::vector<F> perSet((size_t)nsets * 3, (F)0);
+  Counters total;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+  {
+    Counters local;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t s = 0; s < (int64_t)nsets; ++s) gatherBeamPrimalBRE<F>(g, rays[5 * s], useAccel != 0, &perSet[(size_t)s * 3], local);
+#pragma omp critical
+    total.add(local);
+  }
+  std::vector<F> iter(P * 3, (F)0);
+  for (uint64_t s = 0; s < nsets; ++s) {
+    const gvpm_camera_ray &b = rays[5 * s];
+    size_t px = b.pixel & 0xFFFFu, py = b.pixel >> 16;
+    if (px >= (size_t)p->width || py >= (size_t)p->height) return GVPM_ERR_INVALID_ARG;
+    for (int k = 0; k < 3; ++k) iter[(py * p->width + px) * 3 + k] += perSet[(size_t)s * 3 + k];
+  }
+  for (size_t i = 0; i < P; ++i)
+    for (int k = 0; k < 3; ++k) {
+      // photonMap->setScaleFactor(1 / shotParticles) (sppm.cpp:921) multiplies every term of the query: here once per sum
+      F v = iter[i * 3 + k] * ((F)1 / (F)nbPaths);
+      F prev = (F)accum[i * 27 + k];
+      accum[i * 27 + k] = (double)((prev * (F)(it - 1) + v) / (F)it);  // gp.fluxVol APA fold, sppm.cpp:986
+    }
+  if (counters) {
+    counters[0] = total.evaluations; counters[1] = total.candidates; counters[2] = counters[3] = counters[4] = 0;
   }
   return GVPM_OK;
 }
@@ -375,6 +420,16 @@ int oracle_gather_bre_timed(const gvpm_params *p, const gvpm_medium *m, const gv
                             build_seconds);
   return gatherBRE<double>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds,
                            build_seconds);
+}
+
+// accum: P*27 doubles, only the first three of a pixel (fluxVol) are read and written
+int oracle_gather_primal_bre(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
+                             const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it, uint64_t nb_paths,
+                             int precision, int use_accel, int threads, double *accum, uint64_t *counters) {
+  if (!p || !m || !t || !ph || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_VOL_BRE2D && p->vol_technique != GVPM_VOL_BRE3D) return GVPM_ERR_INVALID_ARG;
+  if (precision == 32) return gatherPrimalBRE<float>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters);
+  return gatherPrimalBRE<double>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters);
 }
 
 double oracle_scale_volume_apa(double global_scale, int it, double alpha, int technique) {

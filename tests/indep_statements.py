@@ -909,3 +909,69 @@ def vpm_full(c, scale_vol=None):
             acc[py, px, 15 + 3 * i:18 + 3 * i] += (base_c * (w * scale)[:, None]).sum(0)
             acc[py, px, 3 + 3 * i:6 + 3 * i] += (np.nan_to_num(sflux) * (w * scale)[:, None]).sum(0)
     return acc, cnt, mvol
+
+
+# ======================================================================================================================
+# The PRIMAL beam radiance estimate (Jarosz et al. 2008, as the reference's `sppm` integrator runs it with a uniform
+# radius: src/integrators/photonmapper/sppm.cpp:882-1000, bre.cpp:166-254), stated from the estimator's definition:
+# for a camera beam x(t) = o + t d, t in [eps, len - eps], and photons (p_k, power_k, wi_k) of radius r,
+#   2D kernel:  L += sum_k [ |p_k - x(t_k)| < r, eps < t_k <= len - eps ]  Tr(t_k - eps) phase(wi_k, -d) power_k / (pi r^2)
+#   3D kernel:  one point t' drawn uniformly on the chord of the kernel sphere around p_k along the beam,
+#               L += Tr(t' - eps) phase power_k / (4/3 pi r^3) * chord, kept iff eps <= t' <= len - eps
+# with t_k the parameter of p_k's projection; everything times 1 / emitted paths and the beam's weight.  (Transmittance is
+# counted from the start of the usable segment, as the re-based ray of bre.cpp:168 has it.)
+def philox4x32_10(k0, k1, c):
+    c0, c1, c2, c3 = [int(x) for x in c]
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def primal_bre_full(c):
+    """-> (fluxVol[H, W, 3] of one iteration, accepted pairs)"""
+    p, ph, rays = c.p, c.ph, c.rays
+    use3d = p.vol_technique == abi.GVPM_VOL_BRE3D
+    r = float(c.r)
+    eps = float(np.float32(p.epsilon))
+    sig_t = float(c.m.sigma_t[0])
+    g = float(c.m.g)
+    pos, power, wi = ph.pos.astype(np.float64), ph.flux.astype(np.float64), ph.wi.astype(np.float64)
+    depth = ((ph.flags >> 8) & 0xFF).astype(np.int64)
+    posbits = ph.pos.view(np.uint32)
+    out = np.zeros((p.height, p.width, 3))
+    n = 0
+    for sset in rays:
+        b = sset[0]
+        o, d, ln = b["o"].astype(np.float64), b["d"].astype(np.float64), float(b["len"])
+        px, py, edge = int(b["pixel"]) & 0xFFFF, int(b["pixel"]) >> 16, (int(b["info"]) >> 8) & 0xFF
+        a0 = o + d * eps                      # start of the usable segment
+        L = (ln - eps) - eps                  # its length
+        t = (pos - a0) @ d
+        perp2 = ((a0 + t[:, None] * d - pos) ** 2).sum(1)
+        ok = (t > 0) & (perp2 < r * r)
+        if p.max_depth > 0:
+            ok &= ~(depth > p.max_depth - edge)
+        idx = np.flatnonzero(ok)
+        if use3d:
+            half = np.sqrt(r * r - perp2[idx])
+            key = int(np.array([b["rand"]], np.float32).view(np.uint32)[0])
+            u = np.array([(philox4x32_10(key, 0x70726d6c, (posbits[k, 0], posbits[k, 1], posbits[k, 2], 0))[0] >> 8) / 16777216.0
+                          for k in idx])
+            keep = ~(t[idx] - 2 * r > L)
+            tp = (t[idx] - half) + 2 * half * u
+            keep &= (tp >= 0) & (tp <= L)
+            idx, tp, half = idx[keep], tp[keep], half[keep]
+            w = np.maximum(2.0 * half, 1e-4) / (4.0 / 3.0 * np.pi * r ** 3)
+        else:
+            keep = t[idx] <= L
+            idx = idx[keep]
+            tp = t[idx]
+            w = np.full(idx.size, 1.0 / (np.pi * r * r))
+        tr = np.exp(-sig_t * tp)
+        tr = np.where(tr < 1e-20, 0.0, tr)
+        phs = phase(g, wi[idx], -d)
+        out[py, px] += ((power[idx] * (tr * phs * w)[:, None]).sum(0)) * b["eye"].astype(np.float64)
+        n += idx.size
+    return out / c.nb, n

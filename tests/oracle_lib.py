@@ -330,3 +330,25 @@ def phong_sample(bsdf, n, wi, u1, u2):
     wo = np.zeros(3)
     ok = L.oracle_phong_sample(b.ctypes.data, n.ctypes.data, wi.ctypes.data, float(u1), float(u2), wo.ctypes.data)
     return wo if ok else None
+
+
+def gather_primal_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, precision=64, use_accel=True, threads=0,
+                      accum=None):
+    """One iteration of the primal sppm integrator's volumePhotonPassBRE (oracle/gvpm_oracle_primal.hpp).
+    Returns (accum[H,W,27] with fluxVol in [..., 0:3], counters dict)."""
+    L = lib()
+    L.oracle_gather_primal_bre.argtypes = [
+        C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+        C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = photons.soa()
+    rays = np.ascontiguousarray(rays)
+    P = params.width * params.height
+    accum = np.zeros(P * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    rc = L.oracle_gather_primal_bre(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa), rays.ctypes.data,
+                                    rays.shape[0], float(radius), it, nb_paths, precision, 1 if use_accel else 0, threads,
+                                    accum.ctypes.data, counters.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_primal_bre failed: {rc}")
+    return accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters)))

@@ -1,0 +1,116 @@
+"""The primal beam radiance estimate on the device (gvpm_gather_primal; gather_bre.hip evaluate_primal_kernel) against the
+fp64 oracle's literal restatement of the reference's sppm pass (oracle/gvpm_oracle_primal.hpp): accepted pairs equal,
+fluxVol to the parity bar, over the APA schedule, at C2's size on windows, and the refusals of the entry point."""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+from gvpm_amd import abi, hip
+from test_configs_gpu import pick_windows, window_of
+from test_primal_bre import primal_case
+
+pytestmark = pytest.mark.gpu
+
+
+def device(c, iters=1, rays=None):
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ref = None
+    total = 0
+    for it in range(1, iters + 1):
+        ph, nb = (c.ph, c.nb) if it == 1 else c.sc.shoot_photons(it, c.ph.n)
+        r = (c.rays if rays is None else rays) if it == 1 else c.sc.camera_beams(it)
+        rad = ctx.radius()
+        ctx.upload_photons(ph)
+        ctx.upload_camera_beams(r)
+        ctx.gather_primal(it, nb)
+        ref, cnt = O.gather_primal_bre(c.p, c.m, c.tris, ph, r, rad, it, nb, 64, accum=ref)
+        total += cnt["evaluations"]
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    return acc, st, ref, total
+
+
+@pytest.mark.parametrize("tech", [abi.GVPM_VOL_BRE3D, abi.GVPM_VOL_BRE2D])
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_mirror"])
+def test_primal_matches_fp64_oracle(tech, scene):
+    c = primal_case(scene, 40, 36, 30000, 2.5, vol_technique=tech, use_shift_null=0)
+    acc, st, ref, total = device(c)
+    assert st["evaluations"] == total > 10000
+    assert st["null_shifts"] == st["diffuse_shifts"] == st["failed_shifts"] == 0
+    lum = ref[..., 0:3].mean()
+    assert np.sqrt(((acc - ref) ** 2).mean()) / lum < 1e-4
+    assert not acc[..., 3:].any()
+
+
+def test_three_iterations_radius_schedule_and_max_depth():
+    c = primal_case("cbox", 32, 32, 20000, 3.0, max_depth=4)
+    acc, st, ref, total = device(c, iters=3)
+    assert st["evaluations"] == total
+    assert np.sqrt(((acc - ref) ** 2).mean()) / ref[..., 0:3].mean() < 1e-4
+
+
+def test_c2_size_windows():
+    """BASELINE configs[1]'s inputs (512 x 512, 1 M photons) through the primal pass: two 32 x 32 windows against the oracle"""
+    W = H = 512
+    sc = cases.SynthScene("cbox", W, H)
+    p = sc.params()
+    p.initial_scale_volume = 1.0
+    p.path_set = 0
+    m, tris = sc.medium(), sc.triangles()
+    ph, nb = sc.shoot_photons(1, 1_000_000)
+    rays = sc.camera_beams(1)
+    c = cases.Case()
+    c.p, c.m, c.tris, c.ph, c.nb, c.rays, c.sc = p, m, tris, ph, nb, rays, sc
+    acc, st, _, _ = device_noref(c)
+    assert st["evaluations"] > 15_000_000
+    for (x0, y0) in pick_windows(acc, 32):
+        sel = window_of(rays, x0, y0, 32, 32)
+        wr = np.ascontiguousarray(rays[sel])
+        c.rays = wr
+        wacc, wst, ref, total = device(c)
+        win = (slice(y0, y0 + 32), slice(x0, x0 + 32))
+        lum = ref[win][..., 0:3].mean()
+        assert wst["evaluations"] == total > 20000
+        assert np.sqrt(((wacc[win] - ref[win]) ** 2).mean()) / lum < 1e-4
+        assert np.allclose(acc[win], wacc[win], rtol=2e-5, atol=1e-9 * lum)
+
+
+def device_noref(c):
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather_primal(1, c.nb)
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    return acc, st, None, None
+
+
+def test_refusals():
+    c = cases.make_case("cbox", 16, 12, 500, 3.0)  # path_set = 1: a filter the primal pass does not have
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.gather_primal(1, c.nb)
+    assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
+    ctx.close()
+    from test_oracle_vpm import make_vpm_case
+    v = make_vpm_case("cbox", 16, 12, 500, 3.0, path_set=0)
+    ctx = hip.Context(v.p, device=0)
+    ctx.upload_scene(*v.tris)
+    ctx.upload_medium(v.m)
+    ctx.upload_photons(v.ph)
+    ctx.upload_camera_beams(v.rays)
+    with pytest.raises(hip.GvpmError) as e:
+        ctx.gather_primal(1, v.nb)  # only the beam radiance estimate is built
+    assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
+    ctx.close()
