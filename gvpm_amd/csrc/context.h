@@ -75,7 +75,7 @@ void launch_finalize(float *accum, const float *iter, size_t n, int it, uint64_t
 void launch_scale(const float *in, float *out, size_t n, float scale, hipStream_t s);
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
-void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream);
+void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream_t stream);
 void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
                        hipStream_t stream);
 void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);

@@ -875,7 +875,7 @@ static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
 }
 
 // computeVolumeGradientPhoton (G-VPM), gvpm.cpp:1081-1203
-static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
+static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = false) {
   (void)it;
   if (!h->haveSamples) return fail(h, GVPM_ERR_STATE, "G-VPM gather needs gvpm_upload_vpm_samples");
   if (h->cfg.nb_camera_samples <= 0) return fail(h, GVPM_ERR_INVALID_ARG, "nb_camera_samples must be positive");
@@ -900,7 +900,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
-  if (h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
+  if (!primal && h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
     // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing; the answered
     // terms are added straight to the accumulators (plain sums: this iteration's buffer is folded right below)
     HIP_TRY(h, h->reqHost.ensure(h->reqCap));
@@ -918,7 +918,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths) {
     h->reqOutstanding = true;
   }
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_vpm(a, needFullVis(h), h->stream);
+  launch_gather_vpm(a, needFullVis(h), primal, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->stream);
   launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
@@ -998,8 +998,8 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
 int gvpm_gather_primal(gvpm_context *h, int it, uint64_t nb_paths) {
   CHECK_H(h);
   const gvpm_params &c = h->cfg;
-  if (c.vol_technique != GVPM_VOL_BRE2D && c.vol_technique != GVPM_VOL_BRE3D)
-    return fail(h, GVPM_ERR_UNSUPPORTED, "gvpm_gather_primal: the primal estimator built is the beam radiance estimate (BRE 2D / 3D)");
+  if (c.vol_technique != GVPM_VOL_BRE2D && c.vol_technique != GVPM_VOL_BRE3D && c.vol_technique != GVPM_DISTANCE)
+    return fail(h, GVPM_ERR_UNSUPPORTED, "gvpm_gather_primal: built for the beam radiance estimate (BRE 2D / 3D) and the point estimate (DISTANCE)");
   // the primal pass has none of the gradient pass's filters (sppm.cpp:882-1000): the handle must not carry them
   if (c.path_set || c.debug_shift != GVPM_SHIFT_ALL || c.min_depth != 0 || c.bsdf_interaction_mode != GVPM_BSDF_ALL ||
       !((c.lighting_interaction_mode & GVPM_SURF2MEDIA) && (c.lighting_interaction_mode & GVPM_MEDIA2MEDIA)))
@@ -1060,7 +1060,7 @@ static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) 
   switch (h->cfg.vol_technique) {
     case GVPM_VOL_BRE2D:
     case GVPM_VOL_BRE3D: rc = gatherBRE(h, it, nb_paths, primal); break;
-    case GVPM_DISTANCE: rc = gatherVPM(h, it, nb_paths); break;
+    case GVPM_DISTANCE: rc = gatherVPM(h, it, nb_paths, primal); break;
     case GVPM_BEAM_BEAM_1D:
     case GVPM_BEAM_BEAM_3D_OPTIMIZED: rc = gatherBeams(h, it, nb_paths); break;
     case GVPM_VOL_PLANE0D: rc = gatherPlanes(h, it, nb_paths); break;

@@ -168,6 +168,20 @@ __device__ __forceinline__ void vpmAddShift(VpmLds &s, uint32_t b, int i, const 
 // of each of the four shifts everything but the reconnection -- the null shift, the failed ones.  Returns the mask of
 // the shifts that need shiftPhotonDiffuse; those are queued and run densely in phase 2 (87 % of the shifts at C1 are
 // null shifts, but a batch that evaluates in one pass pays for the reconnection code of the few lanes that take it).
+// The PRIMAL point estimate (sppm.cpp:1087-1112 + RadianceQueryVolume, src/librender/photonmap.cpp:277-308): the term of one
+// (photon, sample) pair -- power * phase (no sigma_s) * beam.weight * Tr / (pdfSuccess * sel) * MCNorm / kernelVol
+__device__ __forceinline__ void vpmPrimalTerm(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm) {
+  const PhotonFront ph = loadFront(a, pidx);
+  const RayReg base = loadRayV(a, s, 0, b);
+  const float r = s.radius[b];
+  const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
+  const float scale = norm / (kernelVol * s.pdfBase[b]);
+  const f3 c = base.eye * ph.flux * (phaseEval(a.med.g, ph.wi, -base.d) * s.trBase[b] * scale);
+  VPM_ADD(0, b, c.x);
+  VPM_ADD(1, b, c.y);
+  VPM_ADD(2, b, c.z);
+}
+
 template <bool HS>
 __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
                                               uint32_t &nNull, uint32_t &nFail) {
@@ -255,7 +269,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
 }
 
-template <bool FULLVIS, bool HS>
+template <bool FULLVIS, bool HS, bool PRIMAL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
   __shared__ VpmLds s;
   const int lane = threadIdx.x;
@@ -405,7 +419,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   auto evalBatch = [&](bool valid, uint2 e) {  // phase 1 for one (photon, sample) pair per lane
     uint32_t qMask = 0u;
     if (valid) {
-      qMask = vpmPhase1<HS>(a, s, e.x, e.y, norm, nNull, nFail);
+      if (PRIMAL) vpmPrimalTerm(a, s, e.x, e.y, norm);
+      else qMask = vpmPhase1<HS>(a, s, e.x, e.y, norm, nNull, nFail);
       nEval++;
     }
 #pragma unroll 1
@@ -486,13 +501,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
           inside = dx * dx + dy * dy + dz * dz < (double)rad * (double)rad;
         }
         if (inside) {
-          atomicAdd(&s.found[owner], 1u);
           const uint32_t bits = __float_as_uint(hp.w);
-          // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
-          const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edge[owner];
           hit = true;
-          if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
-          if (!((bits >> 6) & 1u)) hit = false;
+          if (PRIMAL) {
+            // RadianceQueryVolume (photonmap.cpp:287-297): radius, then depth against maxDepth = m_maxDepth - beam.depth --
+            // `maxDepth > 0 &&` as written: a bound of zero or less filters nothing -- and M counts what passes both
+            const int md = a.cfg.max_depth > 0 ? a.cfg.max_depth - (int)s.edge[owner] : 0x7FFFFFFF;
+            if (md > 0 && (int)GVPM_PF_DEPTH(bits) > md) hit = false;
+            if (hit) atomicAdd(&s.found[owner], 1u);
+          } else {
+            atomicAdd(&s.found[owner], 1u);
+            // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
+            const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edge[owner];
+            if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
+            if (!((bits >> 6) & 1u)) hit = false;
+          }
         }
       }
       const unsigned long long m = __ballot(hit);
@@ -594,10 +617,13 @@ __global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ acc
   if (i < n) accum[i] += iter[i];
 }
 
-void launch_gather_vpm(const GatherArgs &a, bool fullVis, hipStream_t stream) {
+void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream_t stream) {
   if (a.nsamples == 0) return;
   const dim3 grid((a.nsamples + 63u) / 64u);
-  if (a.reqHost) {
+  if (primal) {
+    // the sppm integrator's point estimate: the walk and the rings of the gradient kernel, the primal term only
+    hipLaunchKernelGGL((gather_vpm_kernel<false, false, true>), grid, dim3(64), 0, stream, a);
+  } else if (a.reqHost) {
     // manifold-typed shifts go to the host's request list (an instantiation of its own: the default one keeps its registers)
     if (fullVis) hipLaunchKernelGGL((gather_vpm_kernel<true, true>), grid, dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((gather_vpm_kernel<false, true>), grid, dim3(64), 0, stream, a);

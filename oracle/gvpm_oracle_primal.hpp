@@ -125,4 +125,60 @@ inline void gatherBeamPrimalBRE(const Gatherer<F> &g, const gvpm_camera_ray &b, 
   iter[0] += q.x; iter[1] += q.y; iter[2] += q.z;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The PRIMAL point estimate of the sppm integrator's volume pass (SPPMIntegrator::volumePhotonPass with EDistance,
+// sppm.cpp:1040-1126) with PhotonMap::estimateVolumeRadiance (src/librender/photonmap.cpp:277-330).  Per camera sample:
+// the beam is chosen by the host's CDF (selBeam.sampleReuse, :1088-1089: the flattened sample carries the beam set, the
+// re-used random number and selBeam[beamIndex]), the distance is sampled with EDistanceAlwaysValid (:1101-1102), and the
+// photons within querySize = BBPourcentageCONST * gp.scaleVol of the sampled point are summed:
+//     gp.fluxVol += MCNorm * sum(power * phase) * beam.weight * Tr / (pdfSuccess * selBeam[k])          (:1109-1110)
+// between `gp.fluxVol *= kernelVol` and `/= kernelVol` (:1085,1113), i.e. the density accumulates sum / kernelVol.
+// M counts the photons that pass BOTH tests of RadianceQueryVolume (radius, then depth -- `maxDepth > 0 &&`: a maxDepth
+// of zero or less filters nothing, as written, photonmap.cpp:293).
+template <typename F> struct RadianceQueryVolumeO {
+  typedef Vec3<F> V;
+  const GatherContext<F> &ctx;
+  V pos, viewDir, result;
+  int maxDepth;
+  F searchRadius;
+  size_t M;
+  Counters cnt;
+  RadianceQueryVolumeO(const GatherContext<F> &c, const V &p, const V &vd, int md, F r)
+      : ctx(c), pos(p), viewDir(vd), result((F)0), maxDepth(md), searchRadius(r), M(0) {}
+  void vpmFunctor(const Photon<F> &photon) {  // operator()(const Photon &), photonmap.cpp:283-308
+    V wi = photon.wi;  // -photon.getDirection()
+    F lengthSqr = (pos - photon.pos).lengthSquared();
+    if ((searchRadius * searchRadius - lengthSqr) < 0) return;
+    if (maxDepth > 0 && (int)GVPM_PF_DEPTH(photon.flags) > maxDepth) return;
+    M += 1;
+    cnt.evaluations++;
+    V value = photon.flux * ctx.medium.phase(wi, -viewDir);
+    if (value.x == 0 && value.y == 0 && value.z == 0) return;
+    result += value;
+  }
+};
+
+// one camera sample of the loop at sppm.cpp:1087-1112; iter: the pixel's fluxVol increment (3 values); returns M
+template <typename F>
+inline size_t gatherSamplePrimalVPM(const Gatherer<F> &g, const gvpm_camera_ray *set, F rand, F pdfSel, F querySize, F MCNorm,
+                                    bool useAccel, F *iter, Counters &cnt) {
+  CamRay<F> base(set[0]);
+  Ray<F> ray(base.o, base.d, g.ctx.Epsilon, base.len);  // Ray ray(beam.p1, d, Epsilon, distTotal, 0.f)
+  MRec<F> mRec;
+  mRec.t = 0;
+  if (!g.ctx.medium.sampleDistanceAlwaysValid(ray, mRec, rand, g.ctx.Epsilon)) return 0;
+  const int maxDepth = g.ctx.cfg.max_depth <= 0 ? 0x7FFFFFFF : g.ctx.cfg.max_depth - base.edge;  // m_maxDepth == -1 ? INT_MAX : m_maxDepth - beam.depth
+  const Vec3<F> p = ray(mRec.t);  // mRec.p
+  RadianceQueryVolumeO<F> query(g.ctx, p, ray.d, maxDepth, querySize);
+  if (useAccel) g.map.executeQuery(p, querySize, query);
+  else g.map.executeQueryBrute(p, querySize, query);
+  const F kernelVol = (F)((4.0 / 3.0) * 3.14159265358979323846 * std::pow((double)querySize, 3));
+  const Vec3<F> add = query.result * base.eye * (MCNorm * mRec.transmittance.x / (mRec.pdfSuccess * pdfSel));
+  iter[0] += add.x / kernelVol;
+  iter[1] += add.y / kernelVol;
+  iter[2] += add.z / kernelVol;
+  cnt.add(query.cnt);
+  return query.M;
+}
+
 }  // namespace oracle

@@ -119,7 +119,7 @@ template <typename F>
 int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
               const gvpm_camera_ray *rays, uint64_t nsets, const gvpm_vpm_sample *samples, uint64_t nsamples,
               int useAccel, int threads, double *accum, double *scaleVol, double *nVol, uint64_t *counters,
-              double *seconds, double *buildSeconds) {
+              double *seconds, double *buildSeconds, int primal = 0) {
   Gatherer<F> g;
   g.setup(*p, *m, *t);
   g.map.load(*ph);
@@ -148,8 +148,11 @@ int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
       const size_t px = set[0].pixel & 0xFFFFu, py = set[0].pixel >> 16;
       if (px >= (size_t)p->width || py >= (size_t)p->height) { bad = 1; continue; }
       const F querySize = BBPourcentageCONST * (F)scaleVol[py * p->width + px];  // gvpm.cpp:1132
-      found[s] = (uint32_t)gatherSampleVPM<F>(g, set, (F)sm.rand, (F)sm.pdf_sel, querySize, normalization,
-                                              useAccel != 0, &perSample[(size_t)s * 27], local);
+      // (primal: the sppm integrator's point estimate, sppm.cpp:1087-1112 -- gvpm_oracle_primal.hpp)
+      found[s] = primal ? (uint32_t)gatherSamplePrimalVPM<F>(g, set, (F)sm.rand, (F)sm.pdf_sel, querySize, normalization,
+                                                             useAccel != 0, &perSample[(size_t)s * 27], local)
+                        : (uint32_t)gatherSampleVPM<F>(g, set, (F)sm.rand, (F)sm.pdf_sel, querySize, normalization,
+                                                       useAccel != 0, &perSample[(size_t)s * 27], local);
     }
 #pragma omp critical
     total.add(local);
@@ -420,6 +423,21 @@ int oracle_gather_bre_timed(const gvpm_params *p, const gvpm_medium *m, const gv
                             build_seconds);
   return gatherBRE<double>(p, m, t, ph, rays, nsets, radius, it, nb_paths, use_accel, threads, accum, counters, seconds,
                            build_seconds);
+}
+
+// the sppm integrator's point estimate (EDistance): accum / scale_vol / n_vol as oracle_gather_vpm; only fluxVol (the first
+// three accumulators of a pixel) is written
+int oracle_gather_primal_vpm(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *ph,
+                             const gvpm_camera_ray *rays, uint64_t nsets, const gvpm_vpm_sample *samples, uint64_t nsamples,
+                             int precision, int use_accel, int threads, double *accum, double *scale_vol, double *n_vol,
+                             uint64_t *counters) {
+  if (!p || !m || !t || !ph || !accum || !scale_vol || !n_vol || (nsamples && (!samples || !rays))) return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_DISTANCE || p->nb_camera_samples <= 0) return GVPM_ERR_INVALID_ARG;
+  if (precision == 32)
+    return gatherVPM<float>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol, counters,
+                            nullptr, nullptr, 1);
+  return gatherVPM<double>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol, counters,
+                           nullptr, nullptr, 1);
 }
 
 // accum: P*27 doubles, only the first three of a pixel (fluxVol) are read and written

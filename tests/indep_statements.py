@@ -975,3 +975,44 @@ def primal_bre_full(c):
         out[py, px] += ((power[idx] * (tr * phs * w)[:, None]).sum(0)) * b["eye"].astype(np.float64)
         n += idx.size
     return out / c.nb, n
+
+
+# ======================================================================================================================
+# The PRIMAL point estimate of the sppm integrator (sppm.cpp:1040-1126, photonmap.cpp:277-330), stated from the estimator:
+# per camera sample a distance t is drawn with pdf p(t) on the chosen beam, and the radiance density at x(t) is estimated
+# from the photons within r of it:  L += (1 / n) * w_beam * Tr(t) / (p(t) sel) * sum_k power_k phase(wi_k, -d) / (4/3 pi r^3)
+def primal_vpm_full(c):
+    """-> (fluxVol sums [H, W, 3] of one iteration, M per pixel [H, W], accepted pairs)"""
+    p = c.p
+    out = np.zeros((p.height, p.width, 3))
+    mvol = np.zeros((p.height, p.width))
+    pos, power, wi = c.ph.pos.astype(np.float64), c.ph.flux.astype(np.float64), c.ph.wi.astype(np.float64)
+    depth = ((c.ph.flags >> 8) & 0xFF).astype(np.int64)
+    st = float(c.m.sigma_t[1])
+    g = float(c.m.g)
+    eps = float(np.float32(p.epsilon))
+    r = float(np.float32(p.bsphere_radius)) * 0.01 * float(p.initial_scale_volume)
+    kv = 4.0 / 3.0 * np.pi * r ** 3
+    n = 0
+    for sm in c.samples:
+        b = c.rays[sm["set"], 0]
+        o, d, ln = b["o"].astype(np.float64), b["d"].astype(np.float64), float(b["len"])
+        px, py, edge = int(b["pixel"]) & 0xFFFF, int(b["pixel"]) >> 16, (int(b["info"]) >> 8) & 0xFF
+        usable = max((ln - eps) - eps, 0.0)
+        s = -np.log(1 - float(sm["rand"]) * (1 - np.exp(-st * usable))) / st
+        x = o + d * (s + eps)
+        pdf = st * np.exp(-st * s) / (1 - np.exp(-st * (ln - eps))) * float(sm["pdf_sel"])
+        tr = np.exp(-st * s)
+        near = ((pos - x) ** 2).sum(1) < r * r
+        bound = p.max_depth - edge if p.max_depth > 0 else None
+        if bound is not None and bound > 0:   # (a bound of zero or less filters nothing, as the reference is written)
+            near &= depth <= bound
+        k = np.flatnonzero(near)
+        mvol[py, px] += k.size
+        n += k.size
+        temp = 1 + g * g + 2 * g * (wi[k] @ -d)
+        ph = np.where(g == 0, 1 / (4 * np.pi), (1 / (4 * np.pi)) * (1 - g * g) / (temp * np.sqrt(temp)))
+        # (`const Float MCNorm = 1.f / m_nbCameraSamples`, sppm.cpp:1086: a FLOAT quotient whatever Float is)
+        mc = float(np.float32(1.0) / np.float32(p.nb_camera_samples))
+        out[py, px] += (power[k] * ph[:, None]).sum(0) * b["eye"].astype(np.float64) * (tr / pdf / kv * mc)
+    return out, mvol, n

@@ -352,3 +352,29 @@ def gather_primal_bre(params, medium, tris, photons, rays, radius, it=1, nb_path
     if rc != 0:
         raise RuntimeError(f"oracle_gather_primal_bre failed: {rc}")
     return accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters)))
+
+
+def gather_primal_vpm(params, medium, tris, photons, rays, samples, precision=64, use_accel=True, threads=0, accum=None,
+                      scale_vol=None, n_vol=None):
+    """One iteration of the sppm integrator's point estimate (EDistance; oracle/gvpm_oracle_primal.hpp).
+    Returns (accum[H,W,27] with the fluxVol sums in [..., 0:3], scale_vol[H,W], n_vol[H,W], counters)."""
+    L = lib()
+    L.oracle_gather_primal_vpm.argtypes = [
+        C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+        C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = photons.soa()
+    rays = np.ascontiguousarray(rays)
+    samples = np.ascontiguousarray(samples)
+    H, W = params.height, params.width
+    accum = np.zeros(H * W * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    scale_vol = (np.full(H * W, params.initial_scale_volume, np.float64) if scale_vol is None
+                 else np.ascontiguousarray(scale_vol, np.float64).reshape(-1).copy())
+    n_vol = np.zeros(H * W, np.float64) if n_vol is None else np.ascontiguousarray(n_vol, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    rc = L.oracle_gather_primal_vpm(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa), rays.ctypes.data,
+                                    rays.shape[0], samples.ctypes.data, samples.shape[0], precision, 1 if use_accel else 0,
+                                    threads, accum.ctypes.data, scale_vol.ctypes.data, n_vol.ctypes.data, counters.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_primal_vpm failed: {rc}")
+    return (accum.reshape(H, W, 27), scale_vol.reshape(H, W), n_vol.reshape(H, W), dict(zip(COUNTER_NAMES, map(int, counters))))

@@ -99,3 +99,35 @@ def test_3d_primal_averages_to_the_chord_integral():
         want += (power * (chord / (4 * np.pi) / (4.0 / 3.0 * np.pi * r ** 3))[:, None]).sum(0) * b["eye"]
     want /= c.nb
     assert np.allclose(mean, want, rtol=0.03)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the primal POINT estimate (sppm.cpp:1040-1126, photonmap.cpp:277-330)
+from test_oracle_vpm import make_vpm_case  # noqa: E402
+
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_mirror"])
+@pytest.mark.parametrize("kw", [dict(), dict(max_depth=3), dict(max_depth=2)])
+def test_primal_point_estimate_oracle_equals_the_independent_statement(scene, kw):
+    c = make_vpm_case(scene, 12, 10, 6000, 8.0, 6, **kw)
+    ref, sv, nv, cnt = O.gather_primal_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=True)
+    acc, mvol, n = I.primal_vpm_full(c)
+    assert cnt["evaluations"] == n > 200
+    lum = ref[..., 0:3].mean()
+    assert np.abs(acc - ref[..., 0:3]).max() / lum < 1e-9 and not ref[..., 3:].any()
+    # the kd-tree query evaluates what the loop over all photons does
+    brute = O.gather_primal_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=False)
+    assert brute[3]["evaluations"] == n and np.abs(brute[0] - ref).max() / lum < 1e-12
+    # the SPPM update from M (sppm.cpp:1116-1120)
+    al = float(c.p.alpha)
+    has = mvol > 0
+    assert np.allclose(nv[has], al * mvol[has]) and np.allclose(sv[has], c.p.initial_scale_volume * np.cbrt(al))
+    assert np.allclose(sv[~has], c.p.initial_scale_volume) and not nv[~has].any()
+
+
+def test_primal_point_estimate_is_the_gradient_base_term_without_sigma_s():
+    c = make_vpm_case("cbox", 12, 10, 6000, 8.0, 6)
+    prim = O.gather_primal_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64)[0]
+    grad = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64)[0]
+    sig_s = np.array(list(c.m.sigma_s))
+    assert np.allclose(prim[..., 0:3] * sig_s, grad[..., 0:3], rtol=1e-9, atol=1e-14)

@@ -103,14 +103,50 @@ def test_refusals():
         ctx.gather_primal(1, c.nb)
     assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
     ctx.close()
-    from test_oracle_vpm import make_vpm_case
-    v = make_vpm_case("cbox", 16, 12, 500, 3.0, path_set=0)
-    ctx = hip.Context(v.p, device=0)
-    ctx.upload_scene(*v.tris)
-    ctx.upload_medium(v.m)
-    ctx.upload_photons(v.ph)
-    ctx.upload_camera_beams(v.rays)
-    with pytest.raises(hip.GvpmError) as e:
-        ctx.gather_primal(1, v.nb)  # only the beam radiance estimate is built
-    assert e.value.code == abi.GVPM_ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------ the primal point estimate
+from test_oracle_vpm import make_vpm_case  # noqa: E402
+
+
+def device_vpm_primal(c, iters=1):
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ref = sv = nv = None
+    total = 0
+    for it in range(1, iters + 1):
+        if it == 1:
+            ph, nb, r, smp = c.ph, c.nb, c.rays, c.samples
+        else:
+            ph, nb = c.sc.shoot_photons(it, c.ph.n)
+            r, smp = c.sc.camera_beams_and_vpm_samples(it, c.p.nb_camera_samples)
+        ctx.upload_photons(ph)
+        ctx.upload_camera_beams(r)
+        ctx.upload_vpm_samples(smp)
+        ctx.gather_primal(it, nb)
+        ref, sv, nv, cnt = O.gather_primal_vpm(c.p, c.m, c.tris, ph, r, smp, 64, use_accel=False, accum=ref, scale_vol=sv, n_vol=nv)
+        total += cnt["evaluations"]
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    dsv, dnv = ctx.download_vpm_state()
     ctx.close()
+    return acc, st, ref, total, (dsv, dnv, sv, nv)
+
+
+@pytest.mark.parametrize("scene,kw", [("cbox", dict()), ("cbox_hg", dict()), ("cbox_mirror", dict(max_depth=3)), ("cbox", dict(max_depth=2))])
+def test_primal_point_estimate_matches_fp64_oracle(scene, kw):
+    c = make_vpm_case(scene, 32, 28, 40000, 5.0, nb=10, path_set=0, **kw)
+    acc, st, ref, total, (dsv, dnv, sv, nv) = device_vpm_primal(c)
+    assert st["evaluations"] == total > 5000
+    assert st["null_shifts"] == st["diffuse_shifts"] == st["failed_shifts"] == 0
+    assert np.sqrt(((acc - ref) ** 2).mean()) / ref[..., 0:3].mean() < 1e-4 and not acc[..., 3:].any()
+    assert np.allclose(dsv, sv, rtol=1e-6) and np.allclose(dnv, nv, rtol=1e-6)  # M counts what passed radius AND depth
+
+
+def test_primal_point_estimate_three_iterations_sppm_state():
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=8, path_set=0)
+    acc, st, ref, total, (dsv, dnv, sv, nv) = device_vpm_primal(c, iters=3)
+    assert st["evaluations"] == total
+    assert np.sqrt(((acc - ref) ** 2).mean()) / ref[..., 0:3].mean() < 1e-4
+    assert np.allclose(dsv, sv, rtol=1e-6) and np.allclose(dnv, nv, rtol=1e-6)
