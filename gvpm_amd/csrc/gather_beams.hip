@@ -1832,10 +1832,13 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
       bt[4] += 1;
       bt[5] += (unsigned long long)__popcll(__ballot(alive));
 #endif
+      // (primal: the sppm integrator's beam pass -- BeamRadianceQuery, pm/beams.h:29-223 -- is the kernel record's base term
+      // alone: no shifts.  cfg.reserved[5], set by gvpm_gather_primal's driver)
+      const bool primal = a.cfg.reserved[5] != 0;
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         bool rec = false;
-        if (alive) beamShift1<B>(a, s, st, bIdx, i, rec, nNull, nFail);
+        if (alive && !primal) beamShift1<B>(a, s, st, bIdx, i, rec, nNull, nFail);
         const unsigned long long m = __ballot(rec);
         if (rec) {
           const uint32_t slot = (qHead + qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BQCAP;

@@ -675,7 +675,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
 }
 
 // computeVolumeGradientBeams, gvpm.cpp:880-986
-static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
+static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal = false) {
   if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
   const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
   // phases as for G-BRE (gvpm_get_phase_time): 2 = build (sub-beam grid, beam records, camera-beam sort, near lists),
@@ -741,6 +741,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   a.nbeams = h->nph;
   a.nph = h->nsub;
   a.beamClear = h->beamClear.p;
+  if (primal) a.cfg.reserved[5] = 1;  // the evaluation stops after the kernel record's base term
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
@@ -807,9 +808,16 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths) {
   if (nBlocks)
     HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBlocks,
                             ilog2ceil(h->nsets + 1), h->stream));
-  launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
+  launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact && !primal, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
                         h->bs->queueCtl.p + 3, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  if (primal) {
+    // BeamRadianceQuery takes the camera ray's transmittance over [Epsilon, w] (pm/beams.h:57-61,189-193) where the gradient
+    // pass's kernel record takes it over [0, w] (shift_volume_beams.h:167,262): one factor exp(sigma_t Epsilon) on every term
+    // (sigma_t is equal across the channels, gvpm_upload_medium)
+    const float f = (float)std::exp((double)h->medium.sigma_t[0] * (double)h->cfg.epsilon);
+    launch_scale(h->iter.p, h->iter.p, h->npix * 27, f, h->stream);
+  }
   launch_finalize(h->accum.p, h->iter.p, h->npix * 27, it, nb_paths, h->stream);
   HIP_TRY(h, hipGetLastError());
   {
@@ -998,8 +1006,8 @@ int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths) {
 int gvpm_gather_primal(gvpm_context *h, int it, uint64_t nb_paths) {
   CHECK_H(h);
   const gvpm_params &c = h->cfg;
-  if (c.vol_technique != GVPM_VOL_BRE2D && c.vol_technique != GVPM_VOL_BRE3D && c.vol_technique != GVPM_DISTANCE)
-    return fail(h, GVPM_ERR_UNSUPPORTED, "gvpm_gather_primal: built for the beam radiance estimate (BRE 2D / 3D) and the point estimate (DISTANCE)");
+  if (c.vol_technique == GVPM_VOL_PLANE0D || c.vol_technique == GVPM_BEAM_BEAM_3D_NAIVE || c.vol_technique == GVPM_BEAM_BEAM_3D_EGSR)
+    return fail(h, GVPM_ERR_UNSUPPORTED, "gvpm_gather_primal: built for BRE 2D / 3D, DISTANCE, BEAM_BEAM_1D and BEAM_BEAM_3D_OPTIMIZED");
   // the primal pass has none of the gradient pass's filters (sppm.cpp:882-1000): the handle must not carry them
   if (c.path_set || c.debug_shift != GVPM_SHIFT_ALL || c.min_depth != 0 || c.bsdf_interaction_mode != GVPM_BSDF_ALL ||
       !((c.lighting_interaction_mode & GVPM_SURF2MEDIA) && (c.lighting_interaction_mode & GVPM_MEDIA2MEDIA)))
@@ -1062,7 +1070,7 @@ static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) 
     case GVPM_VOL_BRE3D: rc = gatherBRE(h, it, nb_paths, primal); break;
     case GVPM_DISTANCE: rc = gatherVPM(h, it, nb_paths, primal); break;
     case GVPM_BEAM_BEAM_1D:
-    case GVPM_BEAM_BEAM_3D_OPTIMIZED: rc = gatherBeams(h, it, nb_paths); break;
+    case GVPM_BEAM_BEAM_3D_OPTIMIZED: rc = gatherBeams(h, it, nb_paths, primal); break;
     case GVPM_VOL_PLANE0D: rc = gatherPlanes(h, it, nb_paths); break;
     default: return fail(h, GVPM_ERR_UNSUPPORTED, "vol_technique not built in this library yet");
   }

@@ -531,27 +531,34 @@ int gvpm_upload_host_shifts(gvpm_context *h, const gvpm_host_shift *results, uin
  * Asynchronous on the handle's stream.                                        */
 int gvpm_gather(gvpm_context *h, int it, uint64_t nb_paths);
 
-/* ---- primal estimator (second half) ------------------------*/
-/* One iteration of the PRIMAL beam radiance estimate of the reference's `sppm` integrator:
- * SPPMIntegrator::volumePhotonPassBRE (src/integrators/photonmapper/sppm.cpp:882-1000) with BeamRadianceEstimator::query
- * (src/integrators/photonmapper/bre.cpp:166-254) on the estimator built with cameraHeuristic = true (sppm.cpp:927: the
- * uniform radius R*0.01*globalScaleVolume of the gradient pass), vol_technique BRE2D / BRE3D.  A strict subset of
- * gvpm_gather's machinery (same grid, planner, traversal); per hit the primal term only:
- *   Tr(t') * power * phase(wi, -d) / kernelVolume * (1 / nb_paths) [* max(2 deltaT, 1e-4), 3D] * beam.weight
- * on the ray re-based at r(mint), WITHOUT the sigma_s factor of the gradient functor, with one random number PER HIT for
- * the 3D kernel -- Philox4x32-10, key = {bits(base ray rand), 0x70726d6c}, counter = {bits(pos.x), bits(pos.y),
- * bits(pos.z), 0} of the photon (the reference draws from a stateful per-thread sampler in traversal order) -- and a far
- * check for the 2D kernel (:240-242).  Inputs through the same uploads, re-read as:
- *   photons  pos, wi = -Photon::getDirection(), flux = Photon::getPower() (what the compressed record DEcodes to,
+/* ---- primal estimators (second half) -----------------------*/
+/* One iteration of the PRIMAL volume pass of the reference's `sppm` integrator (src/integrators/photonmapper/sppm.cpp) for
+ * the handle's vol_technique, over the SAME uploads, grids, planners and traversals as gvpm_gather -- the primal estimators
+ * are the gradient functors' base terms with the conventions below -- with GatherPoint::fluxVol as the result: the first
+ * three of a pixel's 27 accumulators (gvpm_download_accum; the other 24 stay zero).  Inputs re-read as:
+ *   photons  pos, wi = -Photon::getDirection(), flux = Photon::getPower() (what Mitsuba's compressed record DEcodes to,
  *            include/mitsuba/render/photon.h:86-135), flags depth = Photon::getDepth(); the parent fields are not read;
- *   beams    the BASE ray of each set: o = beam.p1, d, len = |p2 - p1|, eye = beam.weight, edge = beam.depth, rand, pixel
- *            (sppm.cpp:949-981); the four shifted rays are ignored.
- * The result is GatherPoint::fluxVol, folded as sppm.cpp:986 does, in the first three of a pixel's 27 accumulators
- * (gvpm_download_accum; the other 24 stay zero); scaleVolumeAPA(it) is applied (sppm.cpp:255-285 = gvpm.cpp:181-215).
- * max_depth filters as query's maxDepth = m_maxDepth - beam.depth does.  GVPM_ERR_UNSUPPORTED when the handle carries a
- * filter the primal pass does not have (path_set, debug_shift, min_depth, interaction modes).  gvpm_stats.evaluations
- * counts the accepted (photon, beam) pairs.  Not built: the primal point (sppm.cpp:1000-1130) and beam (pm/beams.h)
- * estimators.                                                                                                         */
+ *   beams    (gvpm_upload_beams) as for gvpm_gather: PhotonBeam origin / end / flux / depth;
+ *   camera   the BASE ray of each set = one Beam{p1, p2, weight, depth} of a gather point: o = p1, d, len = |p2 - p1|,
+ *            eye = beam.weight, edge = beam.depth, rand, pixel (sppm.cpp:949-981); the four shifted rays are ignored.
+ * BRE2D / BRE3D  volumePhotonPassBRE (sppm.cpp:882-1000) with BeamRadianceEstimator::query (bre.cpp:166-254) on the
+ *   estimator built with cameraHeuristic = true (sppm.cpp:927: the gradient pass's uniform radius): per hit
+ *     Tr(t') * power * phase(wi, -d) / kernelVolume * (1 / nb_paths) [* max(2 deltaT, 1e-4), 3D] * beam.weight
+ *   on the ray re-based at r(mint), WITHOUT the sigma_s factor of the gradient functor, one random number PER HIT for the
+ *   3D kernel -- Philox4x32-10, key = {bits(base ray rand), 0x70726d6c}, counter = {bits(pos.x), bits(pos.y), bits(pos.z),
+ *   0} of the photon (the reference draws from a stateful per-thread sampler in traversal order) -- and a far check for the
+ *   2D kernel (:240-242).  APA fold of sppm.cpp:986 and scaleVolumeAPA(it) (sppm.cpp:255-285 = gvpm.cpp:181-215).
+ * DISTANCE  the point estimate (sppm.cpp:1040-1126) with PhotonMap::estimateVolumeRadiance (librender/photonmap.cpp:277-330)
+ *   per camera sample of gvpm_upload_vpm_samples: sum(power * phase) * beam.weight * Tr / (pdfSuccess * sel) * MCNorm /
+ *   kernelVolume added to fluxVol (plain sums, as gvpm_gather does for this technique), M = the photons that pass the
+ *   radius AND the depth test (`maxDepth > 0 &&`: a bound of zero or less filters nothing, as written), then the SPPM
+ *   update of scaleVol / NVol (:1116-1120).
+ * BEAM_BEAM_1D / BEAM_BEAM_3D_OPTIMIZED  volumePhotonPassBeams (sppm.cpp:762-880) with BeamRadianceQuery (pm/beams.h:29-223):
+ *   the gradient pass's kernel record (shift_volume_beams.h:157-290) with the camera transmittance over [Epsilon, w]
+ *   instead of [0, w]; the per-hit random numbers are gvpm_upload_beams' Philox stand-in; APA fold as for BRE.
+ * max_depth filters as the queries' maxDepth = m_maxDepth - beam.depth does.  GVPM_ERR_UNSUPPORTED when the handle carries a
+ * filter the primal passes do not have (path_set, debug_shift, min_depth, interaction modes) and for PLANE0D / the _NAIVE /
+ * _EGSR beam kernels.  gvpm_stats.evaluations counts the accepted pairs.                                              */
 int gvpm_gather_primal(gvpm_context *h, int it, uint64_t nb_paths);
 
 /* current kernel radius R*0.01*globalScaleVolume (gvpm.cpp:989)              */

@@ -181,4 +181,111 @@ inline size_t gatherSamplePrimalVPM(const Gatherer<F> &g, const gvpm_camera_ray 
   return query.M;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The PRIMAL beam x beam estimate of the sppm integrator (volumePhotonPassBeams, sppm.cpp:762-880) with
+// BeamRadianceQuery<PhotonBeam>::operator() (src/integrators/photonmapper/beams.h:29-223), kernels EBeamBeam1D and
+// EBeamBeam3D_Optimized (the two the gradient pass has; _Naive / _EGSR are not restated).  The gradient pass's
+// BeamKernelRecord::eval (shift_volume_beams.h:157-290) is this functor with the random numbers made explicit; what
+// differs: the camera transmittance runs over [Epsilon, w] here (rayBeam.mint = Epsilon, :57-61; cameraRay.mint = Epsilon,
+// :189-193) against [0, w] there; no checkerboard, no interaction filters; depth filters against maxDepth = m_maxDepth -
+// beam.depth and minDepth = max(0, m_minDepth - beam.depth) of the CAMERA beam (sppm.cpp:852-857).  Per-hit random numbers:
+// the same Philox stand-in as the gradient oracle (key {bits(ray rand), 0x6265616d}, counter {beam index, 0, 0, 0}).
+template <typename F> struct PrimalBeamRadianceQuery {
+  typedef Vec3<F> V;
+  const GatherContext<F> &ctx;
+  Ray<F> baseCameraRay;
+  int maxDepth, minDepth, volTechnique;
+  F radius;
+  float setRand;
+  V Li;
+  Counters cnt;
+  PrimalBeamRadianceQuery(const GatherContext<F> &c, const Ray<F> &ray, int maxD, int minD, int tech, F r, float rnd)
+      : ctx(c), baseCameraRay(ray), maxDepth(maxD), minDepth(minD), volTechnique(tech), radius(r), setRand(rnd), Li((F)0) {}
+
+  bool operator()(const Beam<F> &beam, F tmin, F tmax) {
+    cnt.candidates++;
+    if (tmax > beam.length) tmax = beam.length;
+    const int depth = (int)GVPM_PF_DEPTH(beam.ph.flags);
+    if (maxDepth != -1 && depth > maxDepth) return false;
+    if (minDepth != 0 && depth < minDepth) return false;
+    if (volTechnique == GVPM_BEAM_BEAM_1D) {
+      F u, v, w, sinTheta;
+      if (!BeamKernelRecord<F>::rayIntersect1D(beam, radius, baseCameraRay, tmin, tmax, u, v, w, sinTheta)) return false;
+      if (radius <= u) return false;
+      Ray<F> rayBeam(baseCameraRay.o, baseCameraRay.d, ctx.Epsilon, w);
+      MRec<F> mRec;
+      ctx.medium.eval(rayBeam, mRec);
+      F weightKernel = 0.5f / radius;
+      V bt;
+      F pf;
+      Li += BeamKernelRecord<F>::getContrib(ctx.medium, beam, v, mRec, rayBeam.d, bt, pf) * weightKernel / sinTheta;
+      cnt.evaluations++;
+      return true;
+    }
+    if (volTechnique != GVPM_BEAM_BEAM_3D_OPTIMIZED) return false;
+    F uv, uw;
+    beamRandoms<F>(setRand, beam.index, uv, uw);
+    Ray<F> _cam(baseCameraRay(baseCameraRay.mint), baseCameraRay.d, (F)0, baseCameraRay.maxt - baseCameraRay.mint);
+    Ray<F> _beam(beam.ph.parentPos, beam.dir, (F)0, beam.length);
+    double tNearBeam, tFarBeam;
+    if (!cylinderIntersection(_cam, _beam, radius, tNearBeam, tFarBeam)) return false;
+    if (tNearBeam < 0 && tmin <= ctx.Epsilon) {
+    } else if (tNearBeam > tmin && tNearBeam < tmax) {
+    } else {
+      return false;
+    }
+    F beamSegmentRand = (F)(tNearBeam + (tFarBeam - tNearBeam) * uv);
+    F invPDF = (F)std::max(tFarBeam - tNearBeam, 0.0001);
+    if (beamSegmentRand < 0 || beamSegmentRand > beam.length) return false;
+    V kernelCentroid = beam.getPos(beamSegmentRand);
+    F distToProj = dot(kernelCentroid - baseCameraRay.o, baseCameraRay.d);
+    F distSqr = (baseCameraRay(distToProj) - kernelCentroid).lengthSquared();
+    F radSqr = radius * radius;
+    if (distSqr >= radSqr) return false;
+    F deltaT = safe_sqrt(radSqr - distSqr);
+    F cameraSegmentRand = distToProj - deltaT + 2 * deltaT * uw;
+    invPDF *= (F)std::max(2.0 * (double)deltaT, 0.0001);
+    if (cameraSegmentRand < baseCameraRay.mint || cameraSegmentRand > baseCameraRay.maxt) return false;
+    Ray<F> rayTrans(beam.ph.parentPos, beam.dir, (F)0, beamSegmentRand);
+    MRec<F> mRecBeam;
+    ctx.medium.eval(rayTrans, mRecBeam);
+    V segmentFlux = beam.ph.flux * mRecBeam.transmittance;
+    Ray<F> cameraRay(baseCameraRay.o, baseCameraRay.d, ctx.Epsilon, cameraSegmentRand);
+    MRec<F> mRecCamera;
+    ctx.medium.eval(cameraRay, mRecCamera);
+    F phaseTerm = ctx.medium.phase(-beam.dir, -cameraRay.d);
+    F kernelVol = (F)((4.0 / 3.0) * 3.14159265358979323846 * std::pow((double)radius, 3));
+    V beamContrib = segmentFlux * mRecCamera.sigmaS * mRecCamera.transmittance * phaseTerm * (invPDF / kernelVol);
+    beamContrib /= mRecBeam.pdfFailure;  // (!beam->longBeams: the flattened beams are short beams)
+    Li += beamContrib;
+    cnt.evaluations++;
+    return true;
+  }
+};
+
+// one camera beam of volumePhotonPassBeams' loop, sppm.cpp:838-859: fluxVolIter += bRadQuery.Li * beam.weight
+template <typename F>
+inline void gatherBeamPrimalBeams(const GatherContext<F> &ctx, const BeamMapO<F> &map, F radius, const gvpm_camera_ray &b,
+                                  F subBeamSize, F *iter, Counters &cnt, const SubBeamBVHO<F, Beam<F>> *accel = nullptr) {
+  CamRay<F> base(b);
+  Ray<F> ray(base.o, base.d, ctx.Epsilon, base.len - ctx.Epsilon);
+  const int maxD = ctx.cfg.max_depth <= 0 ? -1 : ctx.cfg.max_depth - base.edge;
+  const int minD = std::max(0, ctx.cfg.min_depth - base.edge);
+  PrimalBeamRadianceQuery<F> q(ctx, ray, maxD, minD, ctx.cfg.vol_technique, radius, b.rand);
+  if (accel) {
+    accel->query(map.beams, ray, q);
+  } else for (const Beam<F> &bm : map.beams) {
+    if (subBeamSize > 0) {
+      int nb = (int)std::ceil(bm.length / subBeamSize);
+      F ls = bm.length / nb;
+      for (int i = 0; i < nb; ++i) q(bm, ls * i, ls * (i + 1));
+    } else {
+      q(bm, (F)0, std::numeric_limits<F>::infinity());
+    }
+  }
+  const Vec3<F> r = q.Li * base.eye;
+  iter[0] += r.x; iter[1] += r.y; iter[2] += r.z;
+  cnt.add(q.cnt);
+}
+
 }  // namespace oracle

@@ -191,7 +191,7 @@ template <typename F>
 int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *beams,
                 const float *endN, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
                 uint64_t nbPaths, double subBeamSize, int useAccel, int threads, double *accum, uint64_t *counters,
-                double *seconds, double *buildSeconds) {
+                double *seconds, double *buildSeconds, int primal = 0) {
   Gatherer<F> g;
   g.setup(*p, *m, *t);
   BeamMapO<F> map;
@@ -212,6 +212,10 @@ int gatherBeams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles
     Counters local;
 #pragma omp for schedule(dynamic, 16)
     for (int64_t s = 0; s < (int64_t)nsets; ++s)
+      if (primal)  // the sppm integrator's beam pass (gvpm_oracle_primal.hpp): fluxVol only
+        gatherBeamPrimalBeams<F>(g.ctx, map, (F)radius, rays[5 * s], (F)subBeamSize, &perSet[(size_t)s * 27], local,
+                                 useAccel ? &bvh : nullptr);
+      else
       gatherSetBeams<F>(g.ctx, map, (F)radius, rays + 5 * s, (F)subBeamSize, &perSet[(size_t)s * 27], local,
                         useAccel ? &bvh : nullptr);
 #pragma omp critical
@@ -438,6 +442,20 @@ int oracle_gather_primal_vpm(const gvpm_params *p, const gvpm_medium *m, const g
                             nullptr, nullptr, 1);
   return gatherVPM<double>(p, m, t, ph, rays, nsets, samples, nsamples, use_accel, threads, accum, scale_vol, n_vol, counters,
                            nullptr, nullptr, 1);
+}
+
+// the sppm integrator's beam x beam pass: as oracle_gather_beams, fluxVol in the first three accumulators of a pixel
+int oracle_gather_primal_beams(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t, const gvpm_photon_soa *beams,
+                               const float *end_n, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
+                               uint64_t nb_paths, int precision, double sub_beam_size, int use_accel, int threads, double *accum,
+                               uint64_t *counters) {
+  if (!p || !m || !t || !beams || !end_n || (!rays && nsets) || !accum) return GVPM_ERR_INVALID_ARG;
+  if (p->vol_technique != GVPM_BEAM_BEAM_1D && p->vol_technique != GVPM_BEAM_BEAM_3D_OPTIMIZED) return GVPM_ERR_INVALID_ARG;
+  if (precision == 32)
+    return gatherBeams<float>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, use_accel, threads, accum,
+                              counters, nullptr, nullptr, 1);
+  return gatherBeams<double>(p, m, t, beams, end_n, rays, nsets, radius, it, nb_paths, sub_beam_size, use_accel, threads, accum,
+                             counters, nullptr, nullptr, 1);
 }
 
 // accum: P*27 doubles, only the first three of a pixel (fluxVol) are read and written

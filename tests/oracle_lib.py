@@ -378,3 +378,27 @@ def gather_primal_vpm(params, medium, tris, photons, rays, samples, precision=64
     if rc != 0:
         raise RuntimeError(f"oracle_gather_primal_vpm failed: {rc}")
     return (accum.reshape(H, W, 27), scale_vol.reshape(H, W), n_vol.reshape(H, W), dict(zip(COUNTER_NAMES, map(int, counters))))
+
+
+def gather_primal_beams(params, medium, tris, beams, end_n, rays, radius, it=1, nb_paths=1, precision=64, sub_beam_size=0.0,
+                        threads=0, accum=None, use_accel=False):
+    """One iteration of the sppm integrator's beam x beam pass (oracle/gvpm_oracle_primal.hpp) -> (accum[H,W,27] with
+    fluxVol in [..., 0:3], counters)."""
+    L = lib()
+    L.oracle_gather_primal_beams.argtypes = [
+        C.POINTER(abi.Params), C.POINTER(abi.Medium), C.POINTER(abi.Triangles), C.POINTER(abi.PhotonSoA),
+        C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int,
+        C.c_void_p, C.c_void_p]
+    tstruct, keep = abi.triangles_struct(*tris)
+    soa = beams.soa()
+    end_n = np.ascontiguousarray(end_n, np.float32)
+    rays = np.ascontiguousarray(rays)
+    P = params.width * params.height
+    accum = np.zeros(P * 27, np.float64) if accum is None else np.ascontiguousarray(accum, np.float64).reshape(-1).copy()
+    counters = np.zeros(5, np.uint64)
+    rc = L.oracle_gather_primal_beams(C.byref(params), C.byref(medium), C.byref(tstruct), C.byref(soa), end_n.ctypes.data,
+                                      rays.ctypes.data, rays.shape[0], float(radius), it, nb_paths, precision,
+                                      float(sub_beam_size), int(bool(use_accel)), threads, accum.ctypes.data, counters.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_gather_primal_beams failed: {rc}")
+    return accum.reshape(params.height, params.width, 27), dict(zip(COUNTER_NAMES, map(int, counters)))

@@ -131,3 +131,33 @@ def test_primal_point_estimate_is_the_gradient_base_term_without_sigma_s():
     grad = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64)[0]
     sig_s = np.array(list(c.m.sigma_s))
     assert np.allclose(prim[..., 0:3] * sig_s, grad[..., 0:3], rtol=1e-9, atol=1e-14)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the primal BEAM x BEAM estimate (sppm.cpp:762-880, pm/beams.h:29-223)
+from test_oracle_beams import make_beam_case, TECHS  # noqa: E402
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "laser"])
+def test_primal_beams_are_the_kernel_records_base_term_over_eps_to_w(tech, scene):
+    """BeamRadianceQuery (the literal restatement) against the INDEPENDENT numpy statement of the gradient pass's kernel
+    record: the same term but for the camera transmittance, taken over [Epsilon, w] instead of [0, w] -- one factor
+    exp(sigma_t Epsilon) -- through the reference's SubBeamBVH and through the loop over all beams."""
+    c = make_beam_case(scene, 12, 10, 600, 5.0, technique=tech, path_set=0)
+    prim, cnt = O.gather_primal_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, c.r, 1, c.nb, 64, use_accel=True)
+    loop, cntl = O.gather_primal_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, c.r, 1, c.nb, 64, use_accel=False)
+    acc, icnt = I.beams_full(c)
+    assert cnt["evaluations"] == cntl["evaluations"] == icnt["evaluations"] > 100
+    f = np.exp(float(c.m.sigma_t[0]) * float(np.float32(c.p.epsilon)))
+    lum = prim[..., 0:3].mean()
+    assert np.abs(prim[..., 0:3] - acc[..., 0:3] * f).max() / lum < 1e-9 and not prim[..., 3:].any()
+    assert np.abs(loop - prim).max() / lum < 1e-12
+
+
+def test_primal_beams_depth_filters():
+    c = make_beam_case("cbox", 12, 10, 600, 5.0, path_set=0, max_depth=3)
+    prim, cnt = O.gather_primal_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, c.r, 1, c.nb, 64)
+    acc, icnt = I.beams_full(c)
+    call = make_beam_case("cbox", 12, 10, 600, 5.0, path_set=0)
+    assert 0 < cnt["evaluations"] == icnt["evaluations"] < O.gather_primal_beams(call.p, call.m, call.tris, call.beams, call.end_n, call.rays, call.r, 1, call.nb, 64)[1]["evaluations"]

@@ -150,3 +150,33 @@ def test_primal_point_estimate_three_iterations_sppm_state():
     assert st["evaluations"] == total
     assert np.sqrt(((acc - ref) ** 2).mean()) / ref[..., 0:3].mean() < 1e-4
     assert np.allclose(dsv, sv, rtol=1e-6) and np.allclose(dnv, nv, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ the primal beam x beam estimate
+from test_oracle_beams import make_beam_case, TECHS  # noqa: E402
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "laser"])
+def test_primal_beams_match_fp64_oracle(tech, scene):
+    c = make_beam_case(scene, 32, 28, 12000, 2.5, technique=tech, path_set=0)
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ref = None
+    total = 0
+    for it in (1, 2):
+        beams, en, nb = (c.beams, c.end_n, c.nb) if it == 1 else c.sc.shoot_beams(it, c.beams.n)
+        r = c.rays if it == 1 else c.sc.camera_beams(it)
+        rad = ctx.radius()
+        ctx.upload_beams(beams, en)
+        ctx.upload_camera_beams(r)
+        ctx.gather_primal(it, nb)
+        ref, cnt = O.gather_primal_beams(c.p, c.m, c.tris, beams, en, r, rad, it, nb, 64, accum=ref)
+        total += cnt["evaluations"]
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    assert st["evaluations"] == total > 20000
+    assert st["null_shifts"] == st["diffuse_shifts"] == st["failed_shifts"] == 0
+    assert np.sqrt(((acc - ref) ** 2).mean()) / ref[..., 0:3].mean() < 2e-4 and not acc[..., 3:].any()
