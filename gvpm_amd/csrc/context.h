@@ -52,6 +52,7 @@ void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uin
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
                          uint32_t nwaves, bool persistent, hipStream_t stream);
+void launch_apply_host_shifts_beams(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s);
 void launch_evaluate_primal(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                             const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                             uint32_t nwaves, hipStream_t stream);
@@ -305,6 +306,7 @@ struct gvpm_context {
   DevBuf<uint32_t> reqCount;
   DevBuf<gvpm_host_shift> reqResults;
   bool reqOutstanding = false;   // a gather recorded requests that were neither answered nor written off yet
+  bool reqBeams = false;         // ... of a G-Beams gather (five float4 of context a request, its own apply kernel)
   GatherArgs reqArgs;            // of that gather (medium, film, iteration scale)
   DevBuf<gvpm_material> materials;  // gvpm_upload_materials: the table the packed photon records index
   uint32_t nmaterials = 0;

@@ -753,6 +753,118 @@ __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const Bea
   }
 }
 
+__device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, int i);
+
+// ---- manifold shifts through the host for G-Beams (gvpm_enable_host_shifts; shiftBeamME, shift_volume_beams.cpp:601-746) ----
+// A manifold-typed beam's shift needs Mitsuba's walk (generateShiftPathME + ShiftME over the functor's cached source path,
+// :541-599,612-646): the request carries what the walk takes -- beam, set, shifted ray, the offset position newPos, the radius,
+// baseCameraRay(w - mint) / shiftRay(w - mint) (:627-628), w, and the kernel's place v on the beam (cacheSourcePath moves
+// vertex c there) -- and FIVE float4 of device context: {shifted ray o, maxt} {d, w} {base term * weights, weightKernel * rr}
+// {eye, sensorMIS} {radius, pixel, shift, -}.  Rare and register hungry: not inlined.  False: the list is full.
+static __device__ __noinline__ bool recordBeamShiftRequest(const GatherArgs &a, uint32_t beamIdx, uint32_t set, int i, f3 offsetAbs,
+                                                           f3 basePt, f3 shiftPt, float w, float v, float kpdfBase, float radius, f3 shO, float shMaxt,
+                                                           f3 shD, f3 bcv, float wkrr, f3 eye, float sMIS, uint32_t pix) {
+  const uint32_t slot = atomicAdd(a.reqCount, 1u);
+  if (slot >= a.reqCap) return false;
+  gvpm_shift_request rq;
+  rq.photon = beamIdx;
+  rq.set = set;
+  rq.shift = (uint32_t)i;
+  rq.reserved = __float_as_uint(kpdfBase);  // kRec.pdf(): the pdf cacheSourcePath gives the re-cut last edge (:574)
+  rq.offset_pos[0] = offsetAbs.x; rq.offset_pos[1] = offsetAbs.y; rq.offset_pos[2] = offsetAbs.z;
+  rq.radius = radius;
+  rq.base_point[0] = basePt.x; rq.base_point[1] = basePt.y; rq.base_point[2] = basePt.z;
+  rq.t = w;
+  rq.shift_point[0] = shiftPt.x; rq.shift_point[1] = shiftPt.y; rq.shift_point[2] = shiftPt.z;
+  rq.reserved2 = v;
+  a.reqHost[slot] = rq;
+  float4 *c = a.reqCtx + 5 * (size_t)slot;
+  c[0] = make_float4(shO.x, shO.y, shO.z, shMaxt);
+  c[1] = make_float4(shD.x, shD.y, shD.z, w);
+  c[2] = make_float4(bcv.x, bcv.y, bcv.z, wkrr);
+  c[3] = make_float4(eye.x, eye.y, eye.z, sMIS);
+  c[4] = make_float4(radius, __uint_as_float(pix), __uint_as_float((uint32_t)i), 0.f);
+  return true;
+}
+
+// The rest of shiftBeamME once the host has run the walks (results == nullptr: it has not -- every request is a failed shift):
+// kernelPDF of the proposal's last edge against the shifted ray (:653-663), Jacobian (:665-686), the shifted camera terms
+// (:688-703), MIS (:705-733), then the accumulation of BeamGradRadianceQuery::operator() (:330-350).  For G-Beams the answer's
+// `wi` is the proposal's last edge as a VECTOR from the new vertex to its predecessor (direction and length).
+__global__ __launch_bounds__(256) void apply_host_shifts_beams_kernel(GatherArgs a, const gvpm_host_shift *__restrict__ results, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t ok = 0, bad = 0;
+  if (k < n) {
+    const float4 c0 = a.reqCtx[5 * (size_t)k], c1 = a.reqCtx[5 * (size_t)k + 1], c2 = a.reqCtx[5 * (size_t)k + 2],
+                 c3 = a.reqCtx[5 * (size_t)k + 3], c4 = a.reqCtx[5 * (size_t)k + 4];
+    const f3 bcv = mk3(c2.x, c2.y, c2.z), eye = mk3(c3.x, c3.y, c3.z);
+    const float shiftW = c1.w, wkrr = c2.w, sMIS = c3.w, radius = c4.x;
+    const uint32_t pix = __float_as_uint(c4.y);
+    const int i = (int)__float_as_uint(c4.z);
+    float w = 1.f;
+    f3 sflux = mk3(0.f);
+    bool good = false;
+    if (results && results[k].ok) {
+      const gvpm_host_shift r = results[k];
+      const gvpm_shift_request rq = a.reqHost[k];
+      const d3 wiV = mkd(r.wi[0], r.wi[1], r.wi[2]);
+      const double newLen = sqrt(len2(wiV));
+      const double jac = (double)r.det_ratio;
+      if (newLen > 0.0) {
+        const d3 edgeD = wiV * (-1.0 / newLen);  // proposal.edge(c - 1)->d
+        const d3 newPos = mkd(rq.offset_pos[0], rq.offset_pos[1], rq.offset_pos[2]);
+        const d3 orgBeam = newPos + wiV;         // proposal.vertex(c - 1)
+        KRecD kr;
+        kr.radius = (double)radius;
+        const RayD shRay{mkd(c0.x, c0.y, c0.z), mkd(c1.x, c1.y, c1.z), (double)a.cfg.epsilon, (double)c0.w};
+        const double shiftKernelPDF = kernelPDF(kr, a.cfg.vol_technique, shRay, orgBeam, edgeD, newLen);
+        if (shiftKernelPDF != 0.0 && jac > 0.0 && isfinite(jac)) {
+          good = true;
+          const float tr = mediumEvalF(a.med, shiftW).tr;
+          const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+          const f3 shD = mk3(c1.x, c1.y, c1.z);
+          const float phaseTerm = phaseEval(a.med.g, tof(edgeD) * -1.f, -shD);
+          sflux = mk3(r.throughput[0], r.throughput[1], r.throughput[2]) * sigS * (tr * phaseTerm) * eye * (float)jac;
+          w = 0.5f;
+          if (a.cfg.use_mis) {
+            const double offsetPdf = (double)r.pdf * shiftKernelPDF, basePdf = (double)r.base_pdf;
+            if (basePdf == 0.0) {
+              w = 0.f;
+            } else if (offsetPdf == 0.0) {
+              w = 1.f;
+            } else {
+              const double x = (double)sMIS * jac * (offsetPdf / basePdf);
+              w = (float)(a.cfg.power_heuristic ? 1.0 / (1.0 + x * x) : 1.0 / (1.0 + x));
+            }
+          }
+        }
+      }
+    }
+    if (beamBorder(a, pix, i)) w = 1.f;
+    const size_t p = (size_t)(pix >> 16) * a.cfg.width + (pix & 0xFFFFu);
+    float *dst = a.iter + p * 27;
+    const float ws = w * wkrr * a.iterScale, wb = w * a.iterScale;
+    if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
+      atomicAdd(&dst[3 + 3 * i + 0], sflux.x * ws);
+      atomicAdd(&dst[3 + 3 * i + 1], sflux.y * ws);
+      atomicAdd(&dst[3 + 3 * i + 2], sflux.z * ws);
+    }
+    atomicAdd(&dst[15 + 3 * i + 0], bcv.x * wb);
+    atomicAdd(&dst[15 + 3 * i + 1], bcv.y * wb);
+    atomicAdd(&dst[15 + 3 * i + 2], bcv.z * wb);
+    ok = good ? 1u : 0u;
+    bad = good ? 0u : 1u;
+  }
+  const uint32_t nOk = (uint32_t)__popcll(__ballot(ok != 0u)), nBad = (uint32_t)__popcll(__ballot(bad != 0u));
+  if ((threadIdx.x & 63) == 0 && (nOk | nBad)) {
+    atomicAdd(&statRow(a)[3], (unsigned long long)nOk);
+    atomicAdd(&statRow(a)[4], (unsigned long long)nBad);
+  }
+}
+void launch_apply_host_shifts_beams(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(apply_host_shifts_beams_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, results, n);
+}
+
 // what the reconnections of one pair share (diffuseReconnectionPhotonBeam's base side, the medium up to w)
 struct BeamRecPair {
   float pdfBasePos;   // parentPdf * |p1 - p2|^2 [/ |n_end . d|] / v^2
@@ -1115,7 +1227,7 @@ __device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, in
 
 // shift i of a pair that passed beamBase: the null shift is evaluated here; `rec`: the shift needs the offset-path
 // reconnection, which phase 2 does (beamShift2)
-template <int B, typename LDS>
+template <int B, bool HS, typename LDS>
 __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const BeamP1 &o, uint32_t bIdx, int i, bool &rec,
                                            uint32_t &nNull, uint32_t &nFail) {
   rec = false;
@@ -1166,8 +1278,10 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
       // for a light path that cannot be reconnected the question is asked here)
       if (a.cfg.debug_shift == GVPM_SHIFT_NULL || k.w > sr.maxt) {
         w = 1.f;
-      } else if (o.st == 1u || o.st == 2u) {
-        rec = true;  // shiftBeamDiffuse: phase 2, which also adds the weighted base term of this shift
+      } else if (o.st == 1u || o.st == 2u || (HS && o.st == 3u)) {
+        // shiftBeamDiffuse: phase 2, which also adds the weighted base term of this shift (HS: a manifold-typed beam goes
+        // there too -- it records the host's request, gvpm_enable_host_shifts)
+        rec = true;
         return;
       } else {
         bool doShift = true;
@@ -1199,9 +1313,9 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
 // withVis (wave-uniform) = false: the first round -- a reconnection whose new beam is not inside its beam's free cone
 // (beamClear: inside, nothing can occlude it) is DEFERRED, untouched; true: the second round over the deferred ones,
 // through the any-hit loop.
-template <int B, typename LDS>
+template <int B, bool HS, typename LDS>
 __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const BeamPQ &q, const float4 *ldsTri, bool withVis,
-                                           bool &defer, uint32_t &nDiff, uint32_t &nFail) {
+                                           bool &defer, uint32_t &nDiff, uint32_t &nFail, uint32_t setBase) {
   defer = false;
   const uint32_t beamIdx = q.id & 0xFFFFFFu, sub = q.id >> 24;
   const uint32_t bIdx = q.meta & 0xFFu;
@@ -1271,6 +1385,21 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
   }
   float w = 1.f;
   f3 sflux = mk3(0.f);
+  if (HS && doShift && GVPM_PF_SHIFT_TYPE(b.flags) == 3u) {
+    // EManifoldShift -> shiftBeamME (shift_volume_beams.cpp:398-404,601-746): the walk is the host's.  Absolute positions:
+    // the local frame's origin O plus the local vectors; the rays at (w - mint), as generateShiftPathME is handed them.
+    const f3 Of = tof(O);
+    const f3 sigSv = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+    const f3 bcvR = base.eye * b.flux * sigSv * q.k.w;
+    const float wkrrR = (a.cfg.path_set ? 2.f : 1.f) *
+                        (is1D ? 0.5f * frcp(r) : frcp((4.0f / 3.0f) * 3.14159265358979323846f * r * r * r));
+    const f3 shO = base.o + sh.ro;
+    if (recordBeamShiftRequest(a, beamIdx, a.setPerm[setBase + bIdx], i, Of + offsetPos, base.o + base.d * (kW - eps),
+                               shO + sh.d * (kW - eps), kW, kV, q.k.z, r, shO, sh.len, sh.d, bcvR, wkrrR, sh.eye, sh.sMIS, s.pix[bIdx]))
+      return;  // (nothing is added now: the answer's terms and the weighted base term come with gvpm_upload_host_shifts)
+    nFail++;   // the list is full: a failed shift, weight 1
+    doShift = false;
+  }
   if (doShift) {
     f3 nd = offsetPos - p1rel;
     const float dist = fsqrt(dot(nd, nd));
@@ -1709,7 +1838,7 @@ __device__ __forceinline__ unsigned long long beamsTick() {
 #define BTICK() 0ull
 #endif
 
-template <int B>
+template <int B, bool HS = false>
 __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
                                                                              const uint32_t *__restrict__ sortedKey,
                                                                              const uint32_t *__restrict__ sortedBlock,
@@ -1740,7 +1869,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
       q.k = s.vk[e];
       q.u = s.vu[e];
       bool defer;
-      beamShift2<B>(a, s, q, ldsTri, true, defer, nDiff, nFail);
+      beamShift2<B, HS>(a, s, q, ldsTri, true, defer, nDiff, nFail, curBase);
     }
     vHead = (vHead + n) % BVCAP;
     vCount -= n;
@@ -1757,7 +1886,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
       q.meta = s.qmeta[e];
       q.k = s.qk[e];
       q.u = s.qu[e];
-      beamShift2<B>(a, s, q, ldsTri, false, defer, nDiff, nFail);
+      beamShift2<B, HS>(a, s, q, ldsTri, false, defer, nDiff, nFail, curBase);
     }
     qHead = (qHead + n) % BQCAP;
     qCount -= n;
@@ -1838,7 +1967,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         bool rec = false;
-        if (alive && !primal) beamShift1<B>(a, s, st, bIdx, i, rec, nNull, nFail);
+        if (alive && !primal) beamShift1<B, HS>(a, s, st, bIdx, i, rec, nNull, nFail);
         const unsigned long long m = __ballot(rec);
         if (rec) {
           const uint32_t slot = (qHead + qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BQCAP;
@@ -1908,6 +2037,14 @@ void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, co
       case 64: GVPM_LAUNCH_BEAMS(64); break;
       case 32: GVPM_LAUNCH_BEAMS(32); break;
       default: GVPM_LAUNCH_BEAMS(16); break;
+    }
+  } else if (a.reqHost) {
+    // manifold-typed shifts go to the host's request list (an instantiation of its own: the default keeps its registers)
+    const size_t dyn = a.ntri <= SCENE_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
+    switch (beamsPerWave) {
+      case 64: hipLaunchKernelGGL((evaluate_beams2_kernel<64, true>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
+      case 32: hipLaunchKernelGGL((evaluate_beams2_kernel<32, true>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
+      default: hipLaunchKernelGGL((evaluate_beams2_kernel<16, true>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
     }
   } else {
     const size_t dyn = a.ntri <= SCENE_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;

@@ -549,6 +549,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     a.origIdx = h->bs->origIdx.p;
     h->reqArgs = a;
     h->reqOutstanding = true;
+    h->reqBeams = false;
   }
   HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
   if (primal)
@@ -808,6 +809,23 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
   if (nBlocks)
     HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBlocks,
                             ilog2ceil(h->nsets + 1), h->stream));
+  if (!primal && !h->beamsExact && h->reqCap > 0 && h->cfg.use_manifold) {
+    // manifold-typed shifts (shiftBeamME) are recorded for the host instead of failing; the answered terms go straight into
+    // the running mean: this iteration's buffer is folded right below, with weight 1 / (nb_paths * it)
+    HIP_TRY(h, h->reqHost.ensure(h->reqCap));
+    HIP_TRY(h, h->reqCtx.ensure(5 * h->reqCap));
+    HIP_TRY(h, h->reqCount.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
+    a.reqHost = h->reqHost.p;
+    a.reqCtx = h->reqCtx.p;
+    a.reqCount = h->reqCount.p;
+    a.reqCap = (uint32_t)h->reqCap;
+    h->reqArgs = a;
+    h->reqArgs.iter = h->accum.p;
+    h->reqArgs.iterScale = (float)(1.0 / ((double)nb_paths * (double)it));
+    h->reqOutstanding = true;
+    h->reqBeams = true;
+  }
   launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact && !primal, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
                         h->bs->queueCtl.p + 3, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
@@ -924,6 +942,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     h->reqArgs.iter = h->accum.p;
     h->reqArgs.iterScale = 1.f;
     h->reqOutstanding = true;
+    h->reqBeams = false;
   }
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   launch_gather_vpm(a, needFullVis(h), primal, h->stream);
@@ -949,7 +968,8 @@ int flushHostShifts(gvpm_context *h) {
   uint32_t n = 0;
   const int rc = requestCount(h, &n);
   if (rc != GVPM_OK) return rc;
-  launch_apply_host_shifts(h->reqArgs, nullptr, n, h->stream);
+  if (h->reqBeams) launch_apply_host_shifts_beams(h->reqArgs, nullptr, n, h->stream);
+  else launch_apply_host_shifts(h->reqArgs, nullptr, n, h->stream);
   HIP_TRY(h, hipGetLastError());
   return GVPM_OK;
 }
@@ -992,7 +1012,8 @@ int gvpm_upload_host_shifts(gvpm_context *h, const gvpm_host_shift *results, uin
   if (!c) return GVPM_OK;
   HIP_TRY(h, h->reqResults.ensure(c));
   HIP_TRY(h, hipMemcpyAsync(h->reqResults.p, results, (size_t)c * sizeof(gvpm_host_shift), hipMemcpyHostToDevice, h->stream));
-  launch_apply_host_shifts(h->reqArgs, h->reqResults.p, c, h->stream);
+  if (h->reqBeams) launch_apply_host_shifts_beams(h->reqArgs, h->reqResults.p, c, h->stream);
+  else launch_apply_host_shifts(h->reqArgs, h->reqResults.p, c, h->stream);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // (the caller may reuse `results`)
   return GVPM_OK;

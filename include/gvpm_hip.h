@@ -480,8 +480,9 @@ int gvpm_prefetch_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_comp
  * from) needs the manifold walk of shiftPhotonManifold (shift_volume_photon.cpp:160-295: generateShiftPathME + ShiftME,
  * shift/operation/shift_ME.cpp:13-142, SpecularManifold::det, src/libbidir/mut_manifold.cpp:1310-1410) -- Newton iterations
  * over Mitsuba's Path / BSDF objects that stay on the host.  With use_manifold = 0 such a shift is a failed shift (weight 1),
- * as in the reference.  With use_manifold = 1 and gvpm_enable_host_shifts(h, capacity > 0), a G-BRE or (round 4) G-VPM gather
- * (VolumeGradientPositionQuery reaches the same dispatch, shift_volume_photon.cpp:489-655 -> :49-117) instead RECORDS
+ * as in the reference.  With use_manifold = 1 and gvpm_enable_host_shifts(h, capacity > 0), a G-BRE, (round 4) G-VPM
+ * (VolumeGradientPositionQuery reaches the same dispatch, shift_volume_photon.cpp:489-655 -> :49-117) or G-Beams gather
+ * (shiftBeamME, shift_volume_beams.cpp:601-746; see the request's and the answer's G-Beams notes) instead RECORDS
  * one request per (photon, beam, shifted pixel) that reaches shiftPhotonManifold -- everything the walk takes as input -- and
  * adds nothing for it; the host runs the walk for each request and hands the results back; the device then applies
  * shift_volume_photon.cpp:217-279 (contribution, Jacobian, MIS weight) and adds the terms to the iteration:
@@ -489,23 +490,28 @@ int gvpm_prefetch_camera_beams_compact(gvpm_context *h, const gvpm_beam_set_comp
  * Requests the host never answers (the next gvpm_gather or download comes first), and requests beyond `capacity`, count as
  * failed shifts.                                                                                                          */
 typedef struct gvpm_shift_request { /* 64 bytes */
-  uint32_t photon;          /* index into this iteration's photon upload: lightPath / vertexId = c of the walk           */
+  uint32_t photon;          /* index into this iteration's photon (G-Beams: beam) upload: lightPath / vertexId = c of the
+                               walk (G-Beams: beam->path, c = edgeID + 1)                                                 */
   uint32_t set;             /* beam set (upload order) and ...                                                            */
   uint32_t shift;           /* ... which of its shifted rays: 0..3 = L R T B                                              */
-  uint32_t reserved;
-  float offset_pos[3];      /* offsetPos (getShiftPos, :858-896): where vertex c of the proposal lies                     */
+  uint32_t reserved;        /* G-Beams: the bits of the float kRec.pdf() (pdfEdgeFailure * pdfKernel), the pdf
+                               cacheSourcePath gives the re-cut last edge of the source path (shift_volume_beams.cpp:574)  */
+  float offset_pos[3];      /* offsetPos (getShiftPos, :858-896; G-Beams: newPos): where vertex c of the proposal lies    */
   float radius;             /* photonRadius (the host multiplies by its config.relaxME); G-VPM: the pixel's own radius   */
-  float base_point[3];      /* baseRay(baseRay.maxt)                                                                      */
-  float t;                  /* baseRay.maxt = shiftRay.maxt = t'                                                          */
-  float shift_point[3];     /* shiftRay(shiftRay.maxt)                                                                    */
-  float reserved2;
+  float base_point[3];      /* baseRay(baseRay.maxt); G-Beams: baseCameraRay(shiftW - mint), as generateShiftPathME is
+                               handed it (shift_volume_beams.cpp:627)                                                     */
+  float t;                  /* baseRay.maxt = shiftRay.maxt = t'; G-Beams: shiftW = kRec.w                                */
+  float shift_point[3];     /* shiftRay(shiftRay.maxt); G-Beams: shiftRay(shiftW - mint) (:628)                           */
+  float reserved2;          /* G-Beams: kRec.v, the kernel's place on the beam (cacheSourcePath moves vertex c there)      */
 } gvpm_shift_request;
 typedef struct gvpm_host_shift {    /* 40 bytes */
   uint32_t ok;              /* generateShiftPathME && ShiftME succeeded                                                    */
   float throughput[3];      /* sRecME.throughtput                                                                          */
-  float wi[3];              /* normalize(proposal.vertex(c-1)->getPosition() - offsetPos)                                  */
+  float wi[3];              /* normalize(proposal.vertex(c-1)->getPosition() - offsetPos); G-Beams: NOT normalised --
+                               proposal.vertex(c-1)->getPosition() - newPos, i.e. -edge(c-1)->d * edge(c-1)->length: kernelPDF
+                               (shift_volume_beams.cpp:653-656) needs the proposal's last edge whole                       */
   float pdf;                /* sRecME.pdf                                                                                  */
-  float det_ratio;          /* manifold->det(proposal, b, c) / manifold->det(source, b, c)                                 */
+  float det_ratio;          /* manifold->det(proposal, b, c) / manifold->det(source, b, c) (G-Beams: of the cached source) */
   float base_pdf;           /* prod_{i=b}^{c-1} source.vertex(i)->pdf[EImportance] * source.edge(i)->pdf[EImportance]      */
 } gvpm_host_shift;
 int gvpm_enable_host_shifts(gvpm_context *h, uint64_t capacity);   /* 0: off (the default)                                 */

@@ -503,9 +503,89 @@ template <typename F> struct BeamGradRadianceQuery {
     const unsigned st = GVPM_PF_SHIFT_TYPE(beam.ph.flags);
     bool ok = false;
     if (st == 1 || st == 2) ok = shiftBeamDiffuse(beam, shiftGP, shiftRay, shiftW, result, kRec, newPos);
-    // invalid / manifold (host-only): return false, result untouched
+    // EManifoldShift: without useManifold the reference returns false (shift_volume_beams.cpp:398-404); with it, shiftBeamME
+    else if (st == 3 && ctx.cfg.use_manifold) ok = shiftBeamME(beam, shiftGP, shiftRay, shiftW, result, kRec, newPos);
+    // invalid: return false, result untouched
     if (ok) cnt.diffuseShifts++; else cnt.failedShifts++;
     return ok;
+  }
+
+  // The manifold walk (generateShiftPathME + ShiftME + SpecularManifold::det on the functor's cached source path,
+  // shift_volume_beams.cpp:541-599,601-640) is Mitsuba's and NOT restated: as for the photons (gvpm_oracle.hpp
+  // standinManifoldWalk) a STAND-IN answers in the tests of the host-shift round trip -- a smooth closed-form function of the
+  // request (the offset position) and the beam's origin, shaped like a reconnection to it.  `wi` is the proposal's last edge
+  // as a vector FROM the new vertex TO its predecessor: direction and length (kernelPDF needs both).
+  struct HostShiftBeam {
+    bool ok;
+    V throughput, wi;
+    F pdf, detRatio, basePdf;
+  };
+  static HostShiftBeam standinBeamWalk(const V &newPos, const Beam<F> &beam) {
+    HostShiftBeam r;
+    const Photon<F> &ph = beam.ph;
+    r.wi = ph.parentPos - newPos;
+    const F len = r.wi.length(), lenB = beam.length;
+    r.ok = len > (F)0 && len < (F)3 * lenB;
+    // (softened by a tenth of the beam's length: an offset position next to the beam's origin would otherwise make the
+    // answer a steep function of the request's last bits, and the test would measure that instead of the device)
+    const F lenE = std::sqrt(len * len + (F)0.01 * lenB * lenB);
+    const F q = (lenB * lenB) / (lenE * lenE);
+    r.throughput = ph.prefixW * (lenB / lenE);
+    r.pdf = ph.parentPdf * q;
+    r.detRatio = q;
+    r.basePdf = ph.parentPdf * ph.edgePdf;
+    return r;
+  }
+
+  // shiftBeamME, shift_volume_beams.cpp:601-746, from the walk's results on
+  bool shiftBeamME(const Beam<F> &beam, const CamRay<F> &shiftGP, const Ray<F> &shiftRay, F shiftW,
+                   GradientSamplingResult<F> &result, const BeamKernelRecord<F> &kRec, const V &newPos) {
+    const HostShiftBeam hs = standinBeamWalk(newPos, beam);
+    if (!hs.ok) {  // generateShiftPathME / ShiftME failed (:624-646)
+      result.weight = 1.0f;
+      return false;
+    }
+    const F newLen = hs.wi.length();
+    const V edgeD = -hs.wi / newLen;  // proposal.edge(c - 1)->d: from vertex c - 1 to the new vertex
+    const V orgBeam = newPos + hs.wi;  // proposal.vertex(c - 1)->getPosition()
+    F shiftKernelPDF = kRec.kernelPDF(shiftRay, orgBeam, edgeD, newLen);  // (:653-656)
+    if (shiftKernelPDF == 0) {
+      result.weight = 1.0f;
+      return false;
+    }
+    result.jacobian *= (F)1;          // sRecME.jacobian (shift_utilities.h:30)
+    result.jacobian *= hs.detRatio;   // detProposed / cacheDetSource (:674-679)
+    if (result.jacobian <= 0.0 || !std::isfinite(result.jacobian)) {
+      result.weight = 1.0f;
+      return false;
+    }
+    V shiftPhotonWeight = hs.throughput;
+    MRec<F> mRecShift;
+    Ray<F> shiftRayEval(shiftRay.o, shiftRay.d, (F)0, shiftW);
+    ctx.medium.eval(shiftRayEval, mRecShift);
+    F phaseTerm = ctx.medium.phase(-edgeD, -shiftRay.d);
+    shiftPhotonWeight *= mRecShift.transmittance * mRecShift.sigmaS * phaseTerm;
+    V eyeShiftContrib = shiftGP.eye;
+    result.shiftedFlux = shiftPhotonWeight * eyeShiftContrib * result.jacobian;
+    result.weight = 0.5f;
+    if (ctx.cfg.use_mis) {
+      F offsetPdf = hs.pdf * shiftKernelPDF;
+      F basePdf = hs.basePdf;
+      if (basePdf == (F)0) {
+        result.weight = 0.0f;
+      } else if (offsetPdf == (F)0) {
+        result.weight = 1.0f;
+      } else {
+        const F sensorPart = sensorMIS(shiftGP, *baseGather, currCameraEdge, shiftW, kRec.w);
+        if (ctx.cfg.power_heuristic) {
+          F x = sensorPart * result.jacobian * (offsetPdf / basePdf);
+          result.weight = 1.0f / (1.0f + x * x);
+        } else {
+          result.weight = 1.0f / (1.0f + sensorPart * result.jacobian * (offsetPdf / basePdf));
+        }
+      }
+    }
+    return true;
   }
 
   // shiftNull3D, shift_volume_beams.cpp:748-786

@@ -125,9 +125,11 @@ public:
       m_bsdfsDirty = false;
     }
     check(gvpm_gather(m_h, it, (uint64_t) nbPaths), "gvpm_gather");
-    /* manifold shifts: the point-kernel gathers (G-BRE, G-VPM) record their requests; G-Beams / G-Planes treat them as failed */
+    /* manifold shifts: the gathers record their requests (G-Planes has no such shift) and the walks run here */
     if (m_config.useManifold && (tech == EVolBRE2D || tech == EVolBRE3D || tech == EDistance))
       answerShiftRequests(photonMap, threadData, scene);
+    if (m_config.useManifold && (tech == EBeamBeam1D || tech == EBeamBeam3D_Optimized))
+      answerBeamShiftRequests(beamMap, threadData);
     writeBack(gatherBlocks, tech == EDistance);
     float r = 0.f;
     check(gvpm_get_radius(m_h, &r), "gvpm_get_radius");
@@ -198,6 +200,98 @@ private:
         thdata.pool.release(proposal.edge(i - 1));
         thdata.pool.release(proposal.vertex(i));
       }
+    }
+    check(gvpm_upload_host_shifts(m_h, m_hostShifts.data(), n), "gvpm_upload_host_shifts");
+  }
+  /* shiftBeamME, shift_volume_beams.cpp:601-746, host half: BeamGradRadianceQuery::cacheSourcePath (:551-599) rebuilds the
+   * source path with vertex c moved to the kernel's place on the beam (request: reserved2 = kRec.v, reserved = the bits of
+   * kRec.pdf()), then generateShiftPathME + ShiftME + the determinants (:612-679) as for the photons.  The answer's `wi` is
+   * the proposal's last edge WHOLE (not normalised): the device's kernelPDF needs its origin and length (:653-656).     */
+  void answerBeamShiftRequests(const LTBeamMap *beamMap, GPMThreadData &thdata) {
+    m_requests.resize(kShiftRequestCapacity);
+    uint64_t n = 0;
+    check(gvpm_download_shift_requests(m_h, m_requests.data(), m_requests.size(), &n), "gvpm_download_shift_requests");
+    if (n > m_requests.size()) n = m_requests.size();
+    gvpm_host_shift none;
+    memset(&none, 0, sizeof(none));
+    m_hostShifts.assign((size_t) n, none);
+    const auto &beams = beamMap->getBeams();
+    for (uint64_t k = 0; k < n; ++k) {
+      const gvpm_shift_request &rq = m_requests[k];
+      gvpm_host_shift &out = m_hostShifts[k];
+      const LTPhotonBeam &beam = beams[rq.photon].second;
+      const Path &oriSource = *beam.path;
+      const int c = (int) beam.edgeID + 1;
+      int b = 0;
+      getTypeShift(&oriSource, (size_t) c, b);
+      Float kpdf;
+      memcpy(&kpdf, &rq.reserved, sizeof(float));
+      const Float v = (Float) rq.reserved2;
+      /* --- cacheSourcePath, :551-599 */
+      Path cachePath;
+      cachePath.append(oriSource, 0, c - 1);
+      cachePath.append(oriSource.edge(c - 2));
+      PathVertex *cacheVertexParent = oriSource.vertex(c - 1)->clone(thdata.pool);
+      cachePath.append(cacheVertexParent);
+      PathEdge *cacheNewEdge = oriSource.edge(c - 1)->clone(thdata.pool);
+      MediumSamplingRecord mRecBeam;
+      beam.medium->eval(Ray(beam.getOri(), beam.getDir(), 0.f, v, 0.f), mRecBeam);   /* kRec.beamTrans, beams_struct.h:146-152 */
+      cacheNewEdge->length = v;
+      cacheNewEdge->pdf[EImportance] = kpdf;
+      cacheNewEdge->weight[EImportance] = mRecBeam.transmittance / cacheNewEdge->pdf[EImportance];
+      cachePath.append(cacheNewEdge);
+      PathVertex *cacheVertexVolume = thdata.pool.allocVertex();
+      memset(cacheVertexVolume, 0, sizeof(PathVertex));
+      MediumSamplingRecord &cacheMRec = cacheVertexVolume->getMediumSamplingRecord();
+      cacheMRec.t = v;
+      cacheMRec.time = 0.f;
+      cacheMRec.p = beam.getPos(v);
+      cacheMRec.medium = beam.medium;
+      cacheVertexVolume->type = PathVertex::EMediumInteraction;
+      cacheVertexVolume->measure = EArea;
+      cacheVertexVolume->sampledComponentIndex = -1;
+      cachePath.append(cacheVertexVolume);
+      if (oriSource.vertex(c - 1)->measure != EDiscrete)
+        cacheVertexParent->pdf[EImportance] *= fastGOp(cachePath, c - 1, c) / fastGOp(oriSource, c - 1, c);
+      /* --- the proposal, :612-646 */
+      const Point newPos(rq.offset_pos[0], rq.offset_pos[1], rq.offset_pos[2]);
+      Path proposal;
+      PathVertex shiftVertex;
+      memset(&shiftVertex, 0, sizeof(PathVertex));
+      MediumSamplingRecord &sMRec = shiftVertex.getMediumSamplingRecord();
+      sMRec.t = 0.f;
+      sMRec.p = newPos;
+      sMRec.medium = beam.medium;
+      shiftVertex.type = PathVertex::EMediumInteraction;
+      shiftVertex.measure = EArea;
+      shiftVertex.sampledComponentIndex = -1;
+      ShiftRecord sRecME;
+      bool ok = generateShiftPathME(cachePath, proposal, (size_t) b, (size_t) c, thdata.pool, thdata.offsetGenerator.get(),
+                                    shiftVertex, (Float) rq.radius * m_config.relaxME,
+                                    Point(rq.base_point[0], rq.base_point[1], rq.base_point[2]),
+                                    Point(rq.shift_point[0], rq.shift_point[1], rq.shift_point[2]));
+      ok = ok && ShiftME(sRecME, cachePath, proposal, (size_t) b, (size_t) c, true);
+      if (ok) {
+        SpecularManifold *manifold = thdata.offsetGenerator->getSpecularManifold();
+        out.det_ratio = (float) (manifold->det(proposal, b, c) / manifold->det(cachePath, b, c));   /* :674-679 */
+        Float r, g, bl;
+        sRecME.throughtput.toLinearRGB(r, g, bl);
+        out.throughput[0] = (float) r; out.throughput[1] = (float) g; out.throughput[2] = (float) bl;
+        const Vector wi = proposal.vertex(c - 1)->getPosition() - newPos;   /* = -edge(c-1)->d * edge(c-1)->length */
+        out.wi[0] = (float) wi.x; out.wi[1] = (float) wi.y; out.wi[2] = (float) wi.z;
+        out.pdf = (float) sRecME.pdf;
+        Float basePdf = 1.f;                                         /* :712-716 */
+        for (int i = b; i < c; ++i) basePdf *= cachePath.vertex(i)->pdf[EImportance] * cachePath.edge(i)->pdf[EImportance];
+        out.base_pdf = (float) basePdf;
+        out.ok = 1;
+      }
+      for (int i = b; i <= c; ++i) {
+        thdata.pool.release(proposal.edge(i - 1));
+        thdata.pool.release(proposal.vertex(i));
+      }
+      thdata.pool.release(cacheNewEdge);
+      thdata.pool.release(cacheVertexVolume);
+      thdata.pool.release(cacheVertexParent);
     }
     check(gvpm_upload_host_shifts(m_h, m_hostShifts.data(), n), "gvpm_upload_host_shifts");
   }

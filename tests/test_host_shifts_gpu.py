@@ -196,3 +196,90 @@ def test_vpm_answered_requests_give_the_oracles_manifold_shifts(over):
     for k in COUNTERS:
         assert st0[k] == cnt0[k], (k, st0, cnt0)
     assert np.sqrt(((acc0 - ref0) ** 2).mean()) / lum < 1e-4
+
+
+# -------------------------------------------------------------------------------------------------------------- G-Beams
+def standin_numpy_beams(beams, req):
+    """The stand-in of the host's walk for G-Beams, stated independently of oracle/gvpm_oracle_beams.hpp (standinBeamWalk):
+    the proposal's last edge runs from the beam's origin to the offset position; it succeeds when shorter than three times
+    the beam; throughput = prefix * |beam| / e; pdf = origin pdf * (|beam| / e)^2 = the determinant ratio, e^2 = |edge|^2 +
+    (|beam| / 10)^2; base pdf = origin pdf * edge pdf.  `wi` is the edge as a VECTOR from the new vertex to the origin (direction and length)."""
+    out = np.zeros(req.size, abi.HOST_SHIFT_DTYPE)
+    k = req["photon"].astype(np.int64)
+    org, end = beams.parent_pos[k].astype(np.float64), beams.pos[k].astype(np.float64)
+    wi = org - req["offset_pos"].astype(np.float64)
+    ln, lb = np.linalg.norm(wi, axis=1), np.linalg.norm(end - org, axis=1)
+    le = np.sqrt(ln * ln + 0.01 * lb * lb)   # (softened by a tenth of the beam's length, as the oracle's)
+    q = (lb * lb) / (le * le)
+    out["throughput"] = beams.prefix_w[k].astype(np.float64) * (lb / le)[:, None]
+    out["wi"] = wi
+    out["ok"] = (ln > 0) & (ln < 3.0 * lb)
+    out["pdf"] = beams.parent_pdf[k].astype(np.float64) * q
+    out["det_ratio"] = q
+    out["base_pdf"] = beams.parent_pdf[k].astype(np.float64) * beams.edge_pdf[k]
+    return out
+
+
+def beam_mirror_case(tech, **over):
+    from test_oracle_beams import make_beam_case
+    c = make_beam_case("cbox_mirror", 32, 28, 12000, 3.0, technique=tech, use_manifold=1, **over)
+    assert (((c.beams.flags >> 2) & 7) == 3).sum() > 300
+    return c
+
+
+def device_beams_hs(c, answer, cap=1 << 20):
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.enable_host_shifts(cap)
+    rad = ctx.radius()
+    ctx.upload_beams(c.beams, c.end_n)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(1, c.nb)
+    req, n = ctx.download_shift_requests(cap)
+    if answer:
+        ctx.upload_host_shifts(standin_numpy_beams(c.beams, req))
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    return acc, st, req, n, rad
+
+
+@pytest.mark.parametrize("tech,over", [(abi.GVPM_BEAM_BEAM_3D_OPTIMIZED, dict()), (abi.GVPM_BEAM_BEAM_3D_OPTIMIZED, dict(use_mis=0)),
+                                       (abi.GVPM_BEAM_BEAM_3D_OPTIMIZED, dict(power_heuristic=1)), (abi.GVPM_BEAM_BEAM_1D, dict())])
+def test_beams_answered_requests_give_the_oracles_manifold_shifts(tech, over):
+    """shiftBeamME (shift_volume_beams.cpp:601-746) split where the data lives: the device records a request per manifold-typed
+    beam and shifted ray, a stand-in answers (numpy; the oracle has its own statement), the device applies kernelPDF,
+    Jacobian and MIS to the answers"""
+    c = beam_mirror_case(tech, **over)
+    acc, st, req, n, rad = device_beams_hs(c, True)
+    assert n == req.size and n > 300
+    ref, cnt, _ = O.gather_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, rad, 1, c.nb, 64)
+    assert st["evaluations"] == cnt["evaluations"] and abs(st["null_shifts"] - cnt["null_shifts"]) <= 2
+    # (a stand-in walk "fails" where its reach test or kernelPDF flips in fp32)
+    assert abs(st["diffuse_shifts"] - cnt["diffuse_shifts"]) <= 4 and abs(st["failed_shifts"] - cnt["failed_shifts"]) <= 4
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert np.sqrt(((acc - ref) ** 2).mean()) / lum < 2e-4
+    # the requests: manifold-typed beams, sets and shifted rays of the upload, both rays at (w - Epsilon), the kernel's place
+    # v on the beam, the offset position within reach of the shifted point
+    assert (((c.beams.flags[req["photon"]] >> 2) & 7) == 3).all()
+    assert (req["set"] < c.rays.shape[0]).all() and (req["shift"] < 4).all()
+    eps = np.float64(np.float32(c.p.epsilon))
+    base = c.rays[req["set"], 0]
+    sh = c.rays[req["set"], 1 + req["shift"].astype(np.int64)]
+    tw = (req["t"].astype(np.float64) - eps)[:, None]
+    assert np.abs(base["o"].astype(np.float64) + base["d"] * tw - req["base_point"]).max() < 2e-5
+    assert np.abs(sh["o"].astype(np.float64) + sh["d"] * tw - req["shift_point"]).max() < 2e-5
+    blen = np.linalg.norm(c.beams.pos[req["photon"]].astype(np.float64) - c.beams.parent_pos[req["photon"]], axis=1)
+    assert (req["reserved2"] >= -1e-6).all() and (req["reserved2"] <= blen * (1 + 1e-5)).all()
+    assert np.array_equal(req["radius"], np.full(n, np.float32(rad)))
+    # the answered terms matter, and unanswered requests are failed shifts (the gather without the feature)
+    p0 = c.p.copy()
+    p0.use_manifold = 0
+    ref0, cnt0, _ = O.gather_beams(p0, c.m, c.tris, c.beams, c.end_n, c.rays, rad, 1, c.nb, 64)
+    assert np.sqrt(((ref0 - ref) ** 2).mean()) / lum > 1e-3
+    acc0, st0, _, _, _ = device_beams_hs(c, False)
+    assert st0["evaluations"] == cnt0["evaluations"]
+    for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert abs(st0[k] - cnt0[k]) <= 2, (k, st0, cnt0)
+    assert np.sqrt(((acc0 - ref0) ** 2).mean()) / lum < 2e-4

@@ -115,7 +115,11 @@ def test_every_citation_names_a_file_of_the_reference():
     ("include/mitsuba/render/film.h", ["getCropOffset", "getCropSize", "getSize()"]),
     ("include/mitsuba/core/transform.h", ["getMatrix", "transformAffine"]),
     ("include/mitsuba/render/bsdf.h", ["getSpecularReflectance", "getRoughness", "pdfComponent", "ESpatiallyVarying"]),
-    ("include/mitsuba/bidir/vertex.h", ["sampledComponentIndex"]),
+    ("include/mitsuba/bidir/vertex.h", ["sampledComponentIndex", "PathVertex *clone(MemoryPool &pool) const"]),
+    ("include/mitsuba/bidir/edge.h", ["PathEdge *clone(MemoryPool &pool) const"]),
+    ("include/mitsuba/bidir/mempool.h", ["allocVertex"]),
+    ("src/integrators/photonmapper/gvpm/gvpm_geoOps.h", ["fastGOp"]),
+    ("src/integrators/photonmapper/beams_struct.h", ["getOri()", "getDir()", "getPos("]),
 ])
 def test_members_the_bridge_touches_exist_in_the_reference(header, members):
     if not os.path.isdir(REF):
@@ -126,4 +130,5 @@ def test_members_the_bridge_touches_exist_in_the_reference(header, members):
         token = m.split("(")[0].split()[-1]
         assert token in SHIM or m in ("size()", "operator[]", "MemoryPool pool", "struct GPMThreadData", "const Path *path",
                                       "struct GPhotonNodeData", "struct LTPhotonBeam", "normalize()", "append(", "struct ShiftRecord",
-                                      "Float det(const Path &path, int b, int c)", "class MTS_EXPORT_RENDER PerspectiveCamera"), (header, m)
+                                      "Float det(const Path &path, int b, int c)", "class MTS_EXPORT_RENDER PerspectiveCamera",
+                                      "PathVertex *clone(MemoryPool &pool) const", "PathEdge *clone(MemoryPool &pool) const"), (header, m)
