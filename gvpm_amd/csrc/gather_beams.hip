@@ -761,11 +761,11 @@ __device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, in
 // baseCameraRay(w - mint) / shiftRay(w - mint) (:627-628), w, and the kernel's place v on the beam (cacheSourcePath moves
 // vertex c there) -- and FIVE float4 of device context: {shifted ray o, maxt} {d, w} {base term * weights, weightKernel * rr}
 // {eye, sensorMIS} {radius, pixel, shift, -}.  Rare and register hungry: not inlined.  False: the list is full.
-static __device__ __noinline__ bool recordBeamShiftRequest(const GatherArgs &a, uint32_t beamIdx, uint32_t set, int i, f3 offsetAbs,
+static __device__ __noinline__ bool recordBeamShiftRequest(ReqSink a, uint32_t beamIdx, uint32_t set, int i, f3 offsetAbs,
                                                            f3 basePt, f3 shiftPt, float w, float v, float kpdfBase, float radius, f3 shO, float shMaxt,
                                                            f3 shD, f3 bcv, float wkrr, f3 eye, float sMIS, uint32_t pix) {
-  const uint32_t slot = atomicAdd(a.reqCount, 1u);
-  if (slot >= a.reqCap) return false;
+  const uint32_t slot = atomicAdd(a.count, 1u);
+  if (slot >= a.cap) return false;
   gvpm_shift_request rq;
   rq.photon = beamIdx;
   rq.set = set;
@@ -777,8 +777,8 @@ static __device__ __noinline__ bool recordBeamShiftRequest(const GatherArgs &a, 
   rq.t = w;
   rq.shift_point[0] = shiftPt.x; rq.shift_point[1] = shiftPt.y; rq.shift_point[2] = shiftPt.z;
   rq.reserved2 = v;
-  a.reqHost[slot] = rq;
-  float4 *c = a.reqCtx + 5 * (size_t)slot;
+  a.host[slot] = rq;
+  float4 *c = a.ctx + 5 * (size_t)slot;
   c[0] = make_float4(shO.x, shO.y, shO.z, shMaxt);
   c[1] = make_float4(shD.x, shD.y, shD.z, w);
   c[2] = make_float4(bcv.x, bcv.y, bcv.z, wkrr);
@@ -1394,7 +1394,7 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
     const float wkrrR = (a.cfg.path_set ? 2.f : 1.f) *
                         (is1D ? 0.5f * frcp(r) : frcp((4.0f / 3.0f) * 3.14159265358979323846f * r * r * r));
     const f3 shO = base.o + sh.ro;
-    if (recordBeamShiftRequest(a, beamIdx, a.setPerm[setBase + bIdx], i, Of + offsetPos, base.o + base.d * (kW - eps),
+    if (recordBeamShiftRequest(reqSink(a), beamIdx, a.setPerm[setBase + bIdx], i, Of + offsetPos, base.o + base.d * (kW - eps),
                                shO + sh.d * (kW - eps), kW, kV, q.k.z, r, shO, sh.len, sh.d, bcvR, wkrrR, sh.eye, sh.sMIS, s.pix[bIdx]))
       return;  // (nothing is added now: the answer's terms and the weighted base term come with gvpm_upload_host_shifts)
     nFail++;   // the list is full: a failed shift, weight 1
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
     if (prefilter) cyl = tileCylinder(base, beamValid, fminf(thrLo, 0.f) - rT, thrHi + rT, rT * 1.0005f, 2.f * eT);
     const bool haveCyl = prefilter && __builtin_amdgcn_readfirstlane((int)cyl.ok);
     uint32_t qHead = 0, qCount = 0;
-    auto emit = [&](uint32_t n) {  // n <= 64 pairs of the ring -> one block of 64 in the global list
+    auto emit = [&](uint32_t n) __attribute__((always_inline)) {  // n <= 64 pairs of the ring -> one block of 64 in the global list
       if (resLeft == 0u) {
         if (lane == 0) resSlot = atomicAdd(pairCount, 64u * RESERVE);
         resSlot = __shfl(resSlot, 0, 64);
@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
     }
     __syncthreads();
     uint32_t cHead = 0, cCount = 0;  // candidate ring, wave-uniform
-    auto resolve = [&](uint32_t n) {  // n <= 64 candidates: ownership prefilter, survivors -> the pair ring
+    auto resolve = [&](uint32_t n) __attribute__((always_inline)) {  // n <= 64 candidates: ownership prefilter, survivors -> the pair ring
       __syncthreads();
       bool keep = false;
       uint32_t id = 0, rb = 0;
@@ -1733,7 +1733,7 @@ __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs 
   const int lane = threadIdx.x;
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
-  auto flushTile = [&]() {
+  auto flushTile = [&]() __attribute__((always_inline)) {
     __syncthreads();
     if (curBase != 0xFFFFFFFFu) {
       for (int idx = lane; idx < 27 * B; idx += 64) {
@@ -1805,7 +1805,10 @@ __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs 
 // (beamBase + beamShift1: kernel record, base contribution, null shifts); the reconnections it needs are appended to
 // a wave-wide LDS ring (ballot + popcount; 40 bytes each) and run 64 at a time through phase 2 (beamShift2) whenever
 // the ring holds a full wave of them, and completely before the tile's accumulators are flushed.
-constexpr int BQCAP = 320;  // a block appends at most 4 x 64, at most 63 wait from the block before
+#ifndef GVPM_BQCAP
+#define GVPM_BQCAP 320
+#endif
+constexpr int BQCAP = GVPM_BQCAP;  // a block appends at most 4 x 64, at most 63 wait from the block before
 constexpr int BVCAP = 128;  // a first-round drain defers at most 64, at most 63 wait
 // LDS is what bounds this kernel's residency (253 VGPRs allow 8 waves per CU): the shifted rays of the tile are kept
 // RELATIVE to their base ray in the ray tile's own slots (relToBase), the queue entries are 28 bytes (36 until round 3,
@@ -1859,7 +1862,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
   [[maybe_unused]] unsigned long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] const unsigned long long btStart = BTICK();
   uint32_t vHead = 0, vCount = 0;  // the deferred ring, wave-uniform
-  auto drainVis = [&](uint32_t n) {  // n <= 64 deferred reconnections through the any-hit loop
+  auto drainVis = [&](uint32_t n) __attribute__((always_inline)) {  // n <= 64 deferred reconnections through the any-hit loop
     __syncthreads();
     if ((uint32_t)lane < n) {
       const uint32_t e = (vHead + (uint32_t)lane) % BVCAP;
@@ -1874,7 +1877,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
     vHead = (vHead + n) % BVCAP;
     vCount -= n;
   };
-  auto drain = [&](uint32_t n) {   // n <= 64 entries of the ring through phase 2 (first round)
+  auto drain = [&](uint32_t n) __attribute__((always_inline)) {   // n <= 64 entries of the ring through phase 2 (first round)
     [[maybe_unused]] const unsigned long long d0 = BTICK();
     bt[6] += n;
     __syncthreads();
@@ -1904,7 +1907,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
     }
     bt[2] += BTICK() - d0;
   };
-  auto flushTile = [&]() {
+  auto flushTile = [&]() __attribute__((always_inline)) {
     while (qCount) drain(min(qCount, 64u));
     while (vCount) drainVis(min(vCount, 64u));
     __syncthreads();

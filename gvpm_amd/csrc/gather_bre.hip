@@ -428,7 +428,7 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   if (HS && GVPM_PF_SHIFT_TYPE(ph.bits) == 3u) {
     // EManifoldShift: the walk is the host's (recordShiftRequest); nothing is added now
     const f3 shiftPt = basePt + dS;
-    if (recordShiftRequest(a, a.radius, pidx, a.setPerm[s.setBase + b], i, shiftPt + offRel, basePt, shiftPt, (float)tPrime, trT.x, pdfCam,
+    if (recordShiftRequest(reqSink(a), a.radius, pidx, a.setPerm[s.setBase + b], i, shiftPt + offRel, basePt, shiftPt, (float)tPrime, trT.x, pdfCam,
                            pdfShiftPos, sr.sMIS, scale, bc, sh.d, sh.eye, s.pix[b])) {
       sf = wb = mk3(0.f);
     } else {

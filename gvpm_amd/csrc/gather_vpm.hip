@@ -254,7 +254,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
     // Recorded with what the device needs to finish the shift (apply_host_shifts_kernel): nothing is added now.  The base
     // contribution rides along already scaled, as G-BRE's does.
     const f3 zPf = tof(zP), basePtF = tof(v.basePt);
-    if (!recordShiftRequest(a, s.radius[b], pidx, s.set[b], i, zPf + offRel, basePtF, zPf, v.tf, v.trS, v.pdfBase, pdfShift,
+    if (!recordShiftRequest(reqSink(a), s.radius[b], pidx, s.set[b], i, zPf + offRel, basePtF, zPf, v.tf, v.trS, v.pdfBase, pdfShift,
                             sensorMIS(sh, v.base, v.edge), v.scale, v.baseContrib * v.scale, sh.d, sh.eye, s.pix[b])) {
       nFail++;  // the list is full: a failed shift (weight 1)
       vpmAddShift(s, b, i, mk3(0.f), v.baseContrib, 1.f, v.scale, v.px, v.py, a);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   // sample).  Conservative: the reach carries 1e-4 r + 1e-6 + 2e-4 cells of slack -- a cell's bounds are rebuilt here as
   // org + index * cell, off the build's floor((p - org) * invCell) by up to ~1e-7 * index cells.
   const float padW = radius * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
-  auto rowRange = [&](int r, uint32_t &c, uint32_t &e) {
+  auto rowRange = [&](int r, uint32_t &c, uint32_t &e) __attribute__((always_inline)) {
     c = e = 0u;
     if (r < nrows) {
       const int y = by0 + r % nyr, z = bz0 + r / nyr;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   uint32_t qHead = 0, qCount = 0, rqHead = 0, rqCount = 0;
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   unsigned long long nCand = 0;
-  auto drain = [&](uint32_t n) {  // phase 2 for the first n <= 64 queued reconnections
+  auto drain = [&](uint32_t n) __attribute__((always_inline)) {  // phase 2 for the first n <= 64 queued reconnections
     __syncthreads();
     if ((uint32_t)lane < n) {
       const uint2 e = s.rq[(rqHead + lane) % VRQ];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
     rqCount -= n;
     __syncthreads();
   };
-  auto evalBatch = [&](bool valid, uint2 e) {  // phase 1 for one (photon, sample) pair per lane
+  auto evalBatch = [&](bool valid, uint2 e) __attribute__((always_inline)) {  // phase 1 for one (photon, sample) pair per lane
     uint32_t qMask = 0u;
     if (valid) {
       if (PRIMAL) vpmPrimalTerm(a, s, e.x, e.y, norm);

@@ -310,12 +310,23 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
 
 // A shift that needs the manifold walk (shiftPhotonManifold, shift_volume_photon.cpp:160-295): what the walk reads goes
 // to the host's request list, what the device needs to finish the shift once the host has answered (:217-279) stays beside
-// it.  Rare and register hungry: not inlined.  False: the list is full -- a failed shift.
-static __device__ __noinline__ bool recordShiftRequest(const GatherArgs &a, float radius, uint32_t pidx, uint32_t set, int i, f3 offsetPos, f3 basePt,
+// it.  Rare and register hungry: not inlined -- and handed the list BY VALUE: a `const GatherArgs &` here makes the kernel
+// keep its whole argument block in scratch (a 600-byte frame, every a.field a scratch load).  False: the list is full --
+// a failed shift.
+struct ReqSink {
+  gvpm_shift_request *host;
+  float4 *ctx;
+  uint32_t *count;
+  uint32_t cap;
+  const uint32_t *origIdx;
+};
+__device__ __forceinline__ ReqSink reqSink(const GatherArgs &a) { return ReqSink{a.reqHost, a.reqCtx, a.reqCount, a.reqCap, a.origIdx}; }
+
+static __device__ __noinline__ bool recordShiftRequest(ReqSink a, float radius, uint32_t pidx, uint32_t set, int i, f3 offsetPos, f3 basePt,
                                                        f3 shiftPt, float tPrime, float tr, float pdfCam, float pdfShiftPos, float sMIS,
                                                        float scale, f3 bc, f3 shD, f3 eye, uint32_t pix) {
-  const uint32_t slot = atomicAdd(a.reqCount, 1u);
-  if (slot >= a.reqCap) return false;
+  const uint32_t slot = atomicAdd(a.count, 1u);
+  if (slot >= a.cap) return false;
   gvpm_shift_request rq;
   rq.photon = a.origIdx[pidx];
   rq.set = set;
@@ -327,8 +338,8 @@ static __device__ __noinline__ bool recordShiftRequest(const GatherArgs &a, floa
   rq.t = tPrime;
   rq.shift_point[0] = shiftPt.x; rq.shift_point[1] = shiftPt.y; rq.shift_point[2] = shiftPt.z;
   rq.reserved2 = 0.f;
-  a.reqHost[slot] = rq;
-  float4 *c = a.reqCtx + 4 * (size_t)slot;
+  a.host[slot] = rq;
+  float4 *c = a.ctx + 4 * (size_t)slot;
   c[0] = make_float4(tr, pdfCam, pdfShiftPos, sMIS);
   c[1] = make_float4(scale, bc.x, bc.y, bc.z);
   c[2] = make_float4(shD.x, shD.y, shD.z, __uint_as_float(pix));
