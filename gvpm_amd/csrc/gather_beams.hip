@@ -716,41 +716,48 @@ constexpr uint32_t SCENE_LDS_TRIS = 128;
 // 16-19) runs the full Moeller-Trumbore test; marking the crossed planes first and testing only those in a second loop
 // was measured at C3: 30.0 ms against 22.6 (two decodes and two rounds of LDS reads per entry).  What pays is not
 // entering the loop: beamShift2 sends only the reconnections outside their beam's free cone through it.
+// (TRI: the occluders in LDS or in global memory -- one loop for the lanes that walk their beam's list and, in LDS, the lanes
+// whose list overflowed: every occluder)
+__device__ __forceinline__ bool beamNearLoop(const GatherArgs &a, const BeamNearFmt fmt, bool ovf, const BeamF &b, const float4 *tri, f3 nd,
+                                             float dist) {
+  const f3 o = b.p1;
+  const float mint = a.cfg.epsilon, maxt = dist;
+  const float margin = planeSideMargin(a.triAbs1, o, maxt);
+  bool hit1 = false;
+  bool more1 = true;
+#pragma unroll 1
+  for (uint32_t k = 0;; ++k) {
+    uint32_t i;
+    if (ovf) {
+      i = k;
+      more1 = k < a.ntri;
+    } else {
+      i = k < fmt.cap ? beamNearEntry(fmt, b.nl0, b.nl1, b.nl2, k) : fmt.mask;
+      more1 = more1 && i != fmt.mask;
+    }
+    if (__ballot(more1) == 0ull) break;
+    if (more1) {
+      const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
+      const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
+      const float s0 = dot(nrm, o - v0), sd = dot(nrm, nd);
+      if (!planeSideMiss(s0, sd, mint, maxt, margin) && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
+        hit1 = true;
+    }
+  }
+  return hit1;
+}
+
 __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const BeamF &b, const float4 *ldsTri, f3 nd, float dist) {
   const BeamNearFmt fmt = beamNearFmt(a.ntri);  // (wave-uniform)
   const bool ovf = beamNearOverflow(fmt, b.nl0, b.nl2);
   if (!ldsTri) {
-    // (more than SCENE_LDS_TRIS occluders: the 8-bit format, read from global memory, or every list overflowed)
+    // (more occluders than the kernel's LDS holds: the lists' triangles from global memory; a list that overflowed walks the BVH)
     if (ovf) return anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist);
-    return nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist));
+    if (fmt.bits == 8u)
+      return nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist));
+    return beamNearLoop(a, fmt, false, b, a.tri4, nd, dist);
   }
-  const f3 o = b.p1;
-  const float mint = a.cfg.epsilon, maxt = dist;
-  const float margin = planeSideMargin(a.triAbs1, o, maxt);
-  {
-    bool hit1 = false;
-    bool more1 = true;
-#pragma unroll 1
-    for (uint32_t k = 0;; ++k) {
-      uint32_t i;
-      if (ovf) {
-        i = k;
-        more1 = k < a.ntri;
-      } else {
-        i = k < fmt.cap ? beamNearEntry(fmt, b.nl0, b.nl1, b.nl2, k) : fmt.mask;
-        more1 = more1 && i != fmt.mask;
-      }
-      if (__ballot(more1) == 0ull) break;
-      if (more1) {
-        const float4 t0 = ldsTri[3 * i], t1 = ldsTri[3 * i + 1], t2 = ldsTri[3 * i + 2];
-        const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
-        const float s0 = dot(nrm, o - v0), sd = dot(nrm, nd);
-        if (!planeSideMiss(s0, sd, mint, maxt, margin) && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
-          hit1 = true;
-      }
-    }
-    return hit1;
-  }
+  return beamNearLoop(a, fmt, ovf, b, ldsTri, nd, dist);
 }
 
 __device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, int i);
@@ -1805,24 +1812,29 @@ __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs 
 // (beamBase + beamShift1: kernel record, base contribution, null shifts); the reconnections it needs are appended to
 // a wave-wide LDS ring (ballot + popcount; 40 bytes each) and run 64 at a time through phase 2 (beamShift2) whenever
 // the ring holds a full wave of them, and completely before the tile's accumulators are flushed.
-#ifndef GVPM_BQCAP
-#define GVPM_BQCAP 320
-#endif
-constexpr int BQCAP = GVPM_BQCAP;  // a block appends at most 4 x 64, at most 63 wait from the block before
-constexpr int BVCAP = 128;  // a first-round drain defers at most 64, at most 63 wait
-// LDS is what bounds this kernel's residency (253 VGPRs allow 8 waves per CU): the shifted rays of the tile are kept
-// RELATIVE to their base ray in the ray tile's own slots (relToBase), the queue entries are 28 bytes (36 until round 3,
-// when they carried the offset position phase 2 now computes itself).
+// The reconnections waiting for phase 2 and the ones the first round deferred share ONE pool of entries, as two stacks
+// growing towards each other (the order of the reconnections is free: they only add to the accumulators): a block appends at
+// most 4 x 64 to at most 63 that wait from the block before, and at most 63 deferred ones wait beside them -- 382; a drain moves
+// entries from the lower stack to the upper one, never more.  (Until round 4 two rings of 320 + 128 entries: the 1.8 KB this
+// saves are what takes the kernel from 7 to 8 resident waves per CU at B = 16.)
+constexpr int BPOOL = 384;
+// LDS is what bounds this kernel's residency (253 VGPRs allow 8 waves per CU, 20480 bytes each): the shifted rays of the tile
+// are kept RELATIVE to their base ray in the ray tile's own slots (relToBase), the queue entries are 28 bytes (36 until round
+// 3, when they carried the offset position phase 2 now computes itself).
 template <int B> struct BeamEvalLds : RayTile<B> {
   double acc[27][B];
-  uint32_t qid[BQCAP], qmeta[BQCAP];  // beam | sub << 24; ray | shift << 8
-  float4 qk[BQCAP];                   // BeamPQ::k
-  float qu[BQCAP];                    // BeamPQ::u
-  // the reconnections the first round deferred (outside their beam's free cone): they wait for a full wave of them
-  uint32_t vid[BVCAP], vmeta[BVCAP];
-  float4 vk[BVCAP];
-  float vu[BVCAP];
+  uint32_t qid[BPOOL], qmeta[BPOOL];  // beam | sub << 24; ray | shift << 8
+  float4 qk[BPOOL];                   // BeamPQ::k
+  float qu[BPOOL];                    // BeamPQ::u
 };
+// occluders in LDS only while they leave the eighth wave its room: measured at C3 (22 occluders) with the two rings, 7 waves
+// with the triangles in LDS 20.4 ms, 8 waves reading the near lists' triangles from global memory 18.3 ms
+#ifdef GVPM_BEAM_LDS_TRIS  // (probe builds)
+constexpr uint32_t BEAM_LDS_TRIS = GVPM_BEAM_LDS_TRIS;
+#else
+constexpr uint32_t BEAM_LDS_TRIS = (20480u - (uint32_t)sizeof(BeamEvalLds<16>)) / 48u;
+#endif
+static_assert(BEAM_LDS_TRIS <= SCENE_LDS_TRIS && sizeof(BeamEvalLds<16>) + 32u * 48u <= 20480u, "the beam evaluation's LDS budget");
 
 #ifdef GVPM_EVAL_TIMING
 // probe builds only: per wave of the last launch, shader-clock ticks in [0] beamBase [1] beamShift1 + push [2] phase 2
@@ -1851,30 +1863,29 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
   extern __shared__ float4 sceneTri[];  // occluders of a small scene (dynamic: 48 bytes each, none for larger scenes)
   const int lane = threadIdx.x;
   const float4 *ldsTri = nullptr;
-  if (a.ntri <= SCENE_LDS_TRIS) {
+  if (a.ntri <= BEAM_LDS_TRIS) {
     for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
     ldsTri = sceneTri;
     __syncthreads();
   }
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
-  uint32_t qHead = 0, qCount = 0;  // wave-uniform
+  uint32_t qCount = 0;  // the lower stack of the pool, wave-uniform
   [[maybe_unused]] unsigned long long bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] const unsigned long long btStart = BTICK();
-  uint32_t vHead = 0, vCount = 0;  // the deferred ring, wave-uniform
+  uint32_t vCount = 0;  // the deferred ones: the upper stack, wave-uniform
   auto drainVis = [&](uint32_t n) __attribute__((always_inline)) {  // n <= 64 deferred reconnections through the any-hit loop
     __syncthreads();
     if ((uint32_t)lane < n) {
-      const uint32_t e = (vHead + (uint32_t)lane) % BVCAP;
+      const uint32_t e = (uint32_t)BPOOL - vCount + (uint32_t)lane;  // the last n pushed
       BeamPQ q;
-      q.id = s.vid[e];
-      q.meta = s.vmeta[e];
-      q.k = s.vk[e];
-      q.u = s.vu[e];
+      q.id = s.qid[e];
+      q.meta = s.qmeta[e];
+      q.k = s.qk[e];
+      q.u = s.qu[e];
       bool defer;
       beamShift2<B, HS>(a, s, q, ldsTri, true, defer, nDiff, nFail, curBase);
     }
-    vHead = (vHead + n) % BVCAP;
     vCount -= n;
   };
   auto drain = [&](uint32_t n) __attribute__((always_inline)) {   // n <= 64 entries of the ring through phase 2 (first round)
@@ -1884,23 +1895,24 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
     bool defer = false;
     BeamPQ q = {};
     if ((uint32_t)lane < n) {
-      const uint32_t e = (qHead + (uint32_t)lane) % BQCAP;
+      const uint32_t e = qCount - n + (uint32_t)lane;  // the last n pushed
       q.id = s.qid[e];
       q.meta = s.qmeta[e];
       q.k = s.qk[e];
       q.u = s.qu[e];
       beamShift2<B, HS>(a, s, q, ldsTri, false, defer, nDiff, nFail, curBase);
     }
-    qHead = (qHead + n) % BQCAP;
     qCount -= n;
     const unsigned long long dm = __ballot(defer);
     if (dm) {
+      // (one wave per workgroup: every lane has read its entry before any lane pushes -- the upper stack may grow into the
+      // slots just popped)
       if (defer) {
-        const uint32_t slot = (vHead + vCount + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))) % BVCAP;
-        s.vid[slot] = q.id;
-        s.vmeta[slot] = q.meta;
-        s.vk[slot] = q.k;
-        s.vu[slot] = q.u;
+        const uint32_t slot = (uint32_t)BPOOL - 1u - vCount - (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+        s.qid[slot] = q.id;
+        s.qmeta[slot] = q.meta;
+        s.qk[slot] = q.k;
+        s.qu[slot] = q.u;
       }
       vCount += (uint32_t)__popcll(dm);
       if (vCount >= 64u) drainVis(64u);
@@ -1973,7 +1985,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
         if (alive && !primal) beamShift1<B, HS>(a, s, st, bIdx, i, rec, nNull, nFail);
         const unsigned long long m = __ballot(rec);
         if (rec) {
-          const uint32_t slot = (qHead + qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % BQCAP;
+          const uint32_t slot = qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
           s.qid[slot] = st.id;
           s.qmeta[slot] = bIdx | ((uint32_t)i << 8);
           // base.eye * k.contrib * weightKernel * rr = (base.eye * flux * sigS) * (sc * weightKernel * rr): the scalar is carried
@@ -2043,14 +2055,14 @@ void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, co
     }
   } else if (a.reqHost) {
     // manifold-typed shifts go to the host's request list (an instantiation of its own: the default keeps its registers)
-    const size_t dyn = a.ntri <= SCENE_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
+    const size_t dyn = a.ntri <= BEAM_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
     switch (beamsPerWave) {
       case 64: hipLaunchKernelGGL((evaluate_beams2_kernel<64, true>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
       case 32: hipLaunchKernelGGL((evaluate_beams2_kernel<32, true>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
       default: hipLaunchKernelGGL((evaluate_beams2_kernel<16, true>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
     }
   } else {
-    const size_t dyn = a.ntri <= SCENE_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
+    const size_t dyn = a.ntri <= BEAM_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
     switch (beamsPerWave) {
       case 64: hipLaunchKernelGGL((evaluate_beams2_kernel<64>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
       case 32: hipLaunchKernelGGL((evaluate_beams2_kernel<32>), dim3(nwaves), dim3(64), dyn, stream, a, pairs, sortedKey, sortedBlock, nBlocks, queueHead); break;
