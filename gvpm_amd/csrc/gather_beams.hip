@@ -1730,12 +1730,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
 // The blocks arrive sorted by tile (radix sort of the block keys on the host side of the launch), and a wave takes
 // RUN consecutive blocks at a time: the tile's rays are loaded, the accumulators zeroed and flushed once per tile
 // and run instead of once per block (that bookkeeping was 3.2 of the kernel's 5.9 ms at the probe).
+#ifndef GVPM_BEAMS_RUN  // (probe builds)
+#define GVPM_BEAMS_RUN 256
+#endif
+#ifndef GVPM_BEAMS_RUN_MIN
+#define GVPM_BEAMS_RUN_MIN 16
+#endif
 template <int B>
 __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs a, const uint2 *__restrict__ pairs,
                                                                      const uint32_t *__restrict__ sortedKey,
                                                                      const uint32_t *__restrict__ sortedBlock,
                                                                      uint32_t nBlocks, uint32_t *queueHead) {
-  constexpr uint32_t RUN = 8;
+  constexpr uint32_t RUN = GVPM_BEAMS_RUN, RUN_MIN = GVPM_BEAMS_RUN_MIN;
   __shared__ TileLds<B> s;
   const int lane = threadIdx.x;
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
@@ -1759,17 +1765,25 @@ __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs 
   };
   // the first item of every wave is its own index; the shared counter (one address: ~11 ns per atomic whatever the
   // number of waves) serves the rest
+  // (guided runs of blocks, as in evaluate_beams2_kernel below)
   bool firstItem = true;
+  const uint32_t run0 = min(RUN, max(RUN_MIN, nBlocks / (4u * gridDim.x)));  // the first run of every wave is its own
+  const uint32_t firstDyn = gridDim.x * run0;
   for (;;) {
-    uint32_t run = blockIdx.x;
+    uint32_t b0 = blockIdx.x * run0, cnt = run0;
     if (!firstItem) {
-      if (lane == 0) run = gridDim.x + atomicAdd(queueHead, 1u);
-      run = __shfl(run, 0, 64);
+      if (lane == 0) {
+        const uint32_t seen = firstDyn + __hip_atomic_load(queueHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t rem = seen < nBlocks ? nBlocks - seen : 0u;
+        cnt = min(RUN, max(RUN_MIN, rem / (2u * gridDim.x)));
+        b0 = firstDyn + atomicAdd(queueHead, cnt);
+      }
+      b0 = __shfl(b0, 0, 64);
+      cnt = __shfl(cnt, 0, 64);
     }
     firstItem = false;
-    const uint32_t b0 = run * RUN;
     if (b0 >= nBlocks) break;
-    const uint32_t b1 = min(nBlocks, b0 + RUN);
+    const uint32_t b1 = min(nBlocks, b0 + cnt);
     for (uint32_t bi = b0; bi < b1; ++bi) {
       const uint32_t setBase = sortedKey[bi];
       if (setBase != curBase) {
@@ -1858,7 +1872,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
                                                                              const uint32_t *__restrict__ sortedKey,
                                                                              const uint32_t *__restrict__ sortedBlock,
                                                                              uint32_t nBlocks, uint32_t *queueHead) {
-  constexpr uint32_t RUN = 8;
+  constexpr uint32_t RUN = GVPM_BEAMS_RUN, RUN_MIN = GVPM_BEAMS_RUN_MIN;
   __shared__ BeamEvalLds<B> s;
   extern __shared__ float4 sceneTri[];  // occluders of a small scene (dynamic: 48 bytes each, none for larger scenes)
   const int lane = threadIdx.x;
@@ -1938,17 +1952,27 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
     }
     __syncthreads();
   };
+  // Runs of blocks, guided: a run ends with the tile's flush (27 x B film atomics, the next tile's rays), so runs are long (at
+  // C3 a tile has ~134 blocks: runs of 8 spent 11 % of the kernel in tile changes, 18.1 ms; runs of 32: 16.7; guided from 256
+  // down to 16: 16.2) and shrink towards the end of the list, so that the waves still finish together.
   bool firstItem = true;
+  const uint32_t run0 = min(RUN, max(RUN_MIN, nBlocks / (4u * gridDim.x)));  // the first run of every wave is its own
+  const uint32_t firstDyn = gridDim.x * run0;
   for (;;) {
-    uint32_t run = blockIdx.x;
+    uint32_t b0 = blockIdx.x * run0, cnt = run0;
     if (!firstItem) {
-      if (lane == 0) run = gridDim.x + atomicAdd(queueHead, 1u);
-      run = __shfl(run, 0, 64);
+      if (lane == 0) {
+        const uint32_t seen = firstDyn + __hip_atomic_load(queueHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t rem = seen < nBlocks ? nBlocks - seen : 0u;
+        cnt = min(RUN, max(RUN_MIN, rem / (2u * gridDim.x)));
+        b0 = firstDyn + atomicAdd(queueHead, cnt);
+      }
+      b0 = __shfl(b0, 0, 64);
+      cnt = __shfl(cnt, 0, 64);
     }
     firstItem = false;
-    const uint32_t b0 = run * RUN;
     if (b0 >= nBlocks) break;
-    const uint32_t b1 = min(nBlocks, b0 + RUN);
+    const uint32_t b1 = min(nBlocks, b0 + cnt);
     for (uint32_t bi = b0; bi < b1; ++bi) {
       const uint32_t setBase = sortedKey[bi];
       [[maybe_unused]] const unsigned long long c0 = BTICK(), dr0 = bt[2];
