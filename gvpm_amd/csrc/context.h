@@ -27,7 +27,6 @@ hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
 void launch_bundle_fit(const gvpm_camera_ray *rays, uint32_t nsets, int pass, const Grid &g, double *out, hipStream_t s);
 void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, const uint32_t *e, uint32_t *hostOut,
                        hipStream_t s);
-void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
                        hipStream_t s);
@@ -90,9 +89,8 @@ void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n,
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
                           hipStream_t s);
 void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint32_t *counts, const uint32_t *offsets,
-                        float *centres, uint32_t *ids, hipStream_t s);
-void launch_sub_hot(const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *aux, float4 *hot,
-                    uint32_t *hotFlags, hipStream_t s);
+                        const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s);
+void launch_sub_hot(const uint32_t *sortedIds, uint32_t n, const float4 *aux, float4 *hot, uint32_t *hotFlags, hipStream_t s);
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
                            const uint32_t *itemCount, uint32_t itemCap, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
                            uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream);
@@ -334,10 +332,10 @@ struct gvpm_context {
   bool haveBeams = false, beamsDirty = false;
 
   // G-Beams: raw upload shares rawF/rawU/rawDev with the photons; end normals + sub-beam build
-  DevBuf<float> endNOwned, subCentres;
+  DevBuf<float> endNOwned;
   const float *endNDev = nullptr;
   bool haveBeamsMap = false;
-  DevBuf<uint32_t> subCounts, subOffsets, subIds, beamCtl;
+  DevBuf<uint32_t> subCounts, subOffsets, beamCtl;
   DevBuf<float4> beamAux;  // G-Beams: {p1, bits} {direction, sub-beam length} per beam, what sub_hot_kernel gathers
   DevBuf<float2> beamClear;  // G-Beams: {cosA0, M1} per beam, the free cone of its reconnections (beam_near_kernel)
   uint32_t nsub = 0;

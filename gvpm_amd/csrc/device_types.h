@@ -82,6 +82,14 @@ GVPM_DT_HD inline uint32_t beamNearEntry(const BeamNearFmt &f, uint32_t w0, uint
   return (uint32_t)(v >> sh) & f.mask;
 }
 
+#ifdef __HIPCC__
+// the grid cell of a coordinate (clamped: positions on the bounds' upper faces, rounding)
+__device__ __forceinline__ int cellCoord(float p, float org, float inv, int dim) {
+  int c = (int)floorf((p - org) * inv);
+  return min(max(c, 0), dim - 1);
+}
+#endif
+
 struct SortTemp {
   void *d = nullptr;
   size_t bytes = 0;

@@ -2112,14 +2112,19 @@ __global__ __launch_bounds__(256) void beam_subcount_kernel(const float *__restr
     sub = len / (float)c;
   }
   sub = wave_max(sub);
-  if ((threadIdx.x & 63) == 0) atomicMax(maxLs, __float_as_uint(sub));
+  // (one address: atomics on it retire ~11 ns apart -- 31 k waves of them were 0.34 of this kernel's 0.36 ms -- so a wave
+  // first looks whether it would raise the maximum at all)
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(sub) > __hip_atomic_load(maxLs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(maxLs, __float_as_uint(sub));
 }
 
-// centres[j] (xyz) and ids[j] = beam | sub << 24 for every sub-beam j = offsets[beam] + sub
+// for every sub-beam j = offsets[beam] + sub: keys[j] = the grid cell of its centre, vals[j] = beam | sub << 24 -- the pair
+// the sort takes (until round 4: centres and ids written here, a key kernel over the centres, the sort carrying indices and
+// sub_hot_kernel gathering ids[order[j]]: 16 bytes a sub-beam more traffic and one dependent gather more)
 __global__ __launch_bounds__(256) void beam_expand_kernel(const float *__restrict__ p2, const float *__restrict__ p1,
                                                           uint32_t n, const uint32_t *__restrict__ counts,
-                                                          const uint32_t *__restrict__ offsets, float *centres,
-                                                          uint32_t *ids) {
+                                                          const uint32_t *__restrict__ offsets, Grid g, uint32_t *keys,
+                                                          uint32_t *vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t c = counts[i], o = offsets[i];
@@ -2128,22 +2133,22 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(const float *__restric
   for (uint32_t k = 0; k < c; ++k) {
     const float t = ((float)k + 0.5f) / (float)c;
     const f3 m = a + (b - a) * t;
-    centres[3 * (size_t)(o + k)] = m.x;
-    centres[3 * (size_t)(o + k) + 1] = m.y;
-    centres[3 * (size_t)(o + k) + 2] = m.z;
-    ids[o + k] = i | (k << 24);
+    const int cx = cellCoord(m.x, g.org[0], g.invCell, g.dim[0]);
+    const int cy = cellCoord(m.y, g.org[1], g.invCell, g.dim[1]);
+    const int cz = cellCoord(m.z, g.org[2], g.invCell, g.dim[2]);
+    keys[o + k] = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+    vals[o + k] = i | (k << 24);
   }
 }
 
 // sorted sub-beam records for the traversal: {centre, beam | sub << 24} {beam direction, sub-beam length} and the
 // beam's filter bits (cold word 7.w: contribution, parity, depth).  The length is the evaluation's (fp64 norm
 // rounded to float), so that sub-beam ranges agree.
-__global__ __launch_bounds__(256) void sub_hot_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ order,
-                                                      uint32_t n, const float4 *__restrict__ aux, float4 *hot,
-                                                      uint32_t *hotFlags) {
+__global__ __launch_bounds__(256) void sub_hot_kernel(const uint32_t *__restrict__ sortedIds, uint32_t n,
+                                                      const float4 *__restrict__ aux, float4 *hot, uint32_t *hotFlags) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const uint32_t id = ids[order[j]], beam = id & 0xFFFFFFu, sub = id >> 24;
+  const uint32_t id = sortedIds[j], beam = id & 0xFFFFFFu, sub = id >> 24;
   // {p1, bits} {direction, sub-beam length} of the beam (beam_cold_kernel): one 32-byte gather; the centre is computed,
   // not gathered (to a few ulp the one beam_expand_kernel binned: every test downstream carries a margin)
   const float4 a0 = aux[2 * (size_t)beam], a1 = aux[2 * (size_t)beam + 1];
@@ -2158,12 +2163,11 @@ void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls
   hipLaunchKernelGGL(beam_subcount_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, ls, counts, maxLs);
 }
 void launch_beam_expand(const float *p2, const float *p1, uint32_t n, const uint32_t *counts, const uint32_t *offsets,
-                        float *centres, uint32_t *ids, hipStream_t s) {
-  hipLaunchKernelGGL(beam_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, counts, offsets, centres, ids);
+                        const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {
+  hipLaunchKernelGGL(beam_expand_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p2, p1, n, counts, offsets, g, keys, vals);
 }
-void launch_sub_hot(const uint32_t *ids, const uint32_t *order, uint32_t n, const float4 *aux, float4 *hot,
-                    uint32_t *hotFlags, hipStream_t s) {
-  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, order, n, aux, hot, hotFlags);
+void launch_sub_hot(const uint32_t *sortedIds, uint32_t n, const float4 *aux, float4 *hot, uint32_t *hotFlags, hipStream_t s) {
+  hipLaunchKernelGGL(sub_hot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sortedIds, n, aux, hot, hotFlags);
 }
 
 }  // namespace gvpm

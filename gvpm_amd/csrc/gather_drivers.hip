@@ -596,7 +596,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
     return GVPM_OK;
   }
   // bounds of the beam end points and origins
-  const int nblocks = 256;
+  const int nblocks = 1024;  // (four workgroups per CU: 256 left this bandwidth-bound pass latency-bound, 58 us for 24 MB)
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
   HIP_TRY(h, h->bs->bounds6.ensure(32));
   launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, nullptr, h->stream);
@@ -648,8 +648,6 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   if (S > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many sub-beams");
   h->nsub = (uint32_t)S;
   memcpy(&h->maxSubLen, &maxBits, 4);
-  HIP_TRY(h, h->subCentres.ensure(S * 3 + 4));
-  HIP_TRY(h, h->subIds.ensure(S + 1));
   HIP_TRY(h, h->bs->keysA.ensure(S));
   HIP_TRY(h, h->bs->keysB.ensure(S));
   HIP_TRY(h, h->bs->valsA.ensure(S));
@@ -657,14 +655,13 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   HIP_TRY(h, h->bs->hot.ensure(2 * S));
   HIP_TRY(h, h->subFlags.ensure(S + 1));
   HIP_TRY(h, h->bs->cellStart.ensure((size_t)g.ncells + 2));
-  launch_beam_expand(h->rawDev.pos, h->rawDev.parent_pos, n, h->subCounts.p, h->subOffsets.p, h->subCentres.p,
-                     h->subIds.p, h->stream);
-  launch_cell_keys(h->subCentres.p, h->nsub, g, h->bs->keysA.p, h->bs->valsA.p, h->stream);
+  launch_beam_expand(h->rawDev.pos, h->rawDev.parent_pos, n, h->subCounts.p, h->subOffsets.p, g, h->bs->keysA.p,
+                     h->bs->valsA.p, h->stream);
   HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->bs->keysA.p, h->bs->keysB.p, h->bs->valsA.p, h->bs->valsB.p, h->nsub,
                           ilog2ceil(g.ncells + 1), h->stream));
   HIP_TRY(h, h->beamAux.ensure(2 * (size_t)n + 2));
   launch_beam_cold(h->rawDev, h->endNDev, n, h->cfg, h->subCounts.p, h->bs->cold.p, h->beamAux.p, h->stream);
-  launch_sub_hot(h->subIds.p, h->bs->valsB.p, h->nsub, h->beamAux.p, h->bs->hot.p, h->subFlags.p, h->stream);
+  launch_sub_hot(h->bs->valsB.p, h->nsub, h->beamAux.p, h->bs->hot.p, h->subFlags.p, h->stream);
   launch_segment_start(h->bs->keysB.p, h->nsub, g.ncells, 0, h->bs->cellStart.p, h->stream);
   {
     const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);

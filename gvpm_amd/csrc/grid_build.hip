@@ -89,21 +89,6 @@ __global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, const ui
 }
 
 // ---- cell keys ---------------------------------------------------------------------------
-__device__ __forceinline__ int cellCoord(float p, float org, float inv, int dim) {
-  int c = (int)floorf((p - org) * inv);
-  return min(max(c, 0), dim - 1);
-}
-
-__global__ __launch_bounds__(256) void cell_key_kernel(const float *__restrict__ pos, uint32_t n, Grid g,
-                                                       uint32_t *keys, uint32_t *vals) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int cx = cellCoord(pos[3 * (size_t)i + 0], g.org[0], g.invCell, g.dim[0]);
-  const int cy = cellCoord(pos[3 * (size_t)i + 1], g.org[1], g.invCell, g.dim[1]);
-  const int cz = cellCoord(pos[3 * (size_t)i + 2], g.org[2], g.invCell, g.dim[2]);
-  keys[i] = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
-  vals[i] = i;
-}
 
 // counting sort, pass 1: key of every photon, its arrival rank within the cell, photons per cell
 __global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict__ pos, uint32_t n, Grid g,
@@ -615,7 +600,10 @@ __global__ __launch_bounds__(256) void shift_extent_kernel(const gvpm_camera_ray
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) S = fmaxf(S, __shfl_xor(S, o, 64));
-  if ((threadIdx.x & 63) == 0 && S > 0.f) atomicMax(extentBits, __float_as_uint(S * 1.0001f));  // S >= 0: bit order = value order
+  // S >= 0: bit order = value order; a wave first looks whether it would raise the maximum (same-address atomics retire ~11 ns apart)
+  if ((threadIdx.x & 63) == 0 && S > 0.f &&
+      __float_as_uint(S * 1.0001f) > __hip_atomic_load(extentBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(extentBits, __float_as_uint(S * 1.0001f));
 }
 
 // The FREE CONE of a beam (round 3).  A new beam of a reconnection is a straight segment from the beam's origin p1: every
@@ -885,9 +873,6 @@ void launch_bundle_fit(const gvpm_camera_ray *rays, uint32_t nsets, int pass, co
   hipLaunchKernelGGL(bundle_fit_kernel, dim3(1), dim3(1024), 0, s, rays, nsets, pass, g, out);
 }
 
-void launch_cell_keys(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *vals, hipStream_t s) {
-  hipLaunchKernelGGL(cell_key_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, vals);
-}
 
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s) {
   const uint32_t nx1 = g.dim[0] + 1, ny1 = g.dim[1] + 1;

@@ -199,8 +199,8 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   h->materials.release();
   h->reqHost.release(); h->reqCtx.release(); h->reqCount.release(); h->reqResults.release();
-  h->endNOwned.release(); h->subCentres.release(); h->subCounts.release(); h->subOffsets.release();
-  h->subIds.release(); h->beamCtl.release(); h->beamAux.release(); h->beamClear.release();
+  h->endNOwned.release(); h->subCounts.release(); h->subOffsets.release();
+  h->beamCtl.release(); h->beamAux.release(); h->beamClear.release();
   h->nearGridStart.release(); h->nearGridTris.release(); h->nearGridCount.release();
   h->w1Owned.release(); h->len1Owned.release(); h->planeTest.release(); h->beamPairs.release(); h->subFlags.release(); h->shiftExtent.release();
   h->blockKeyA.release(); h->blockKeyB.release(); h->blockValA.release(); h->blockValB.release();
