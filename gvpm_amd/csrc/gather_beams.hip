@@ -1614,7 +1614,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
           if (winIdx++ % parts != part) continue;
           __syncthreads();
           const uint32_t nwin = min((uint32_t)BSTAGE, total - win);
-          uint32_t nst = 0;  // staged so far (wave-uniform): the window's entries inside the tile's cylinder, compacted
+          // staged so far (wave-uniform): the window's entries inside the tile's cylinder whose beam contributes at all,
+          // compacted -- and, with the checkerboard (pathSet), PARTITIONED by the beam's parity: parity 0 from slot 0 upwards,
+          // parity 1 from the last slot downwards.  A ray only meets beams of its pixel's parity (shift_volume_beams.cpp:
+          // 142-184), so its lanes walk their own half: half the sphere tests (round 4; the filter bits are still tested --
+          // where the halves' last groups of 16 overlap, a lane reads entries of the other parity)
+          uint32_t n0 = 0, n1 = 0;
           // Staging: entry k of the window is element win + k of the concatenated ranges.  Consecutive LANES take
           // consecutive entries (the range an entry falls in is found by a 6-step search over the exclusive scan,
           // through ds_bpermute), so a load instruction reads a few contiguous runs of records instead of 64
@@ -1633,31 +1638,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
             const uint32_t rStart = (uint32_t)__shfl((int)start, (int)rr, 64), rExcl = (uint32_t)__shfl((int)excl, (int)rr, 64);
             const uint32_t gi = rStart + (e - rExcl);
             float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t fl = 0;
             bool keep = k < nwin;
             if (keep) {
               c0 = a.hot[2 * (size_t)gi];
-              keep = !haveCyl || insideCylinder(cyl, mk3(c0.x, c0.y, c0.z));
+              fl = hotFlags[gi];
+              keep = (fl & 0x40u) && (!haveCyl || insideCylinder(cyl, mk3(c0.x, c0.y, c0.z)));
             }
-            const unsigned long long km = __ballot(keep);
+            const bool up = keep && pathSet && ((fl >> GVPM_HOT_PARITY_BIT) & 1u);
+            const unsigned long long km = __ballot(keep), um = __ballot(up), lm = km & ~um;
             if (keep) {
-              const uint32_t dst = nst + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+              const unsigned long long below = (1ull << lane) - 1ull;
+              const uint32_t dst = up ? (uint32_t)BSTAGE - 1u - n1 - (uint32_t)__popcll(um & below) : n0 + (uint32_t)__popcll(lm & below);
               s.st0[dst] = c0;
               s.st1[dst] = a.hot[2 * (size_t)gi + 1];
               s.sx[dst] = c0.x;
               s.sy[dst] = c0.y;
               s.sz[dst] = c0.z;
-              s.stF[dst] = hotFlags[gi];
+              s.stF[dst] = fl;
             }
-            nst += (uint32_t)__popcll(km);
+            n0 += (uint32_t)__popcll(lm);
+            n1 += (uint32_t)__popcll(um);
           }
-          // the slots between nst and the next multiple of 16 hold centres no ray can meet
-          if (lane < 16 && nst + (uint32_t)lane < ((nst + 15u) & ~15u)) s.sx[nst + lane] = 3.0e38f;
+          // the FREE slots up to each half's next multiple of 16 hold centres no ray can meet
+          {
+            const uint32_t free0 = n0, free1 = (uint32_t)BSTAGE - n1;  // the free slots: [free0, free1)
+            const uint32_t lo = n0 + (uint32_t)lane, hi = free1 - 1u - (uint32_t)lane;
+            if (lane < 16 && lo < ((n0 + 15u) & ~15u) && lo < free1) s.sx[lo] = 3.0e38f;
+            if (lane < 16 && (uint32_t)lane < (((n1 + 15u) & ~15u) - n1) && free1 >= free0 + 1u + (uint32_t)lane) s.sx[hi] = 3.0e38f;
+          }
           __syncthreads();
           constexpr uint32_t G = 4;
           static_assert(BSTAGE % (G * LPB) == 0, "a lane reads four consecutive staged sub-beams with one b128 per component");
-          for (uint32_t jb = 0; jb < nst; jb += G * LPB) {
-            const uint32_t j0 = jb + (uint32_t)sub * G;
+          // (wave-uniform trip count: the longer half; a lane whose own half is exhausted marks nothing -- the slots it
+          // reads then hold the other half or an earlier window)
+          const uint32_t nmax = max(n0, n1);
+          const bool upper = pathSet && pixParity != 0u;
+          const uint32_t nMine = upper ? n1 : n0;
+          for (uint32_t jb = 0; jb < nmax; jb += G * LPB) {
+            const uint32_t j0 = (upper ? (uint32_t)BSTAGE - (uint32_t)(G * LPB) - jb : jb) + (uint32_t)sub * G;
             uint32_t cm = 0;
+            if (jb < nMine)
             {
               const float4 X = *reinterpret_cast<const float4 *>(&s.sx[j0]);
               const float4 Y = *reinterpret_cast<const float4 *>(&s.sy[j0]);
