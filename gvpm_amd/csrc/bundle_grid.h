@@ -26,7 +26,7 @@ __host__ __device__ __forceinline__ uint32_t bundleCell(int G, int l, int cu, in
 // quotients of the interval ends (q_A >= max(c_A - r, tiny): an origin inside or beside the sphere gives an unbounded,
 // i.e. clamped, rectangle).  The rectangle, clipped to the bundle's range, is filed under its midpoint at the level whose
 // cell size covers its half extent.
-__device__ __forceinline__ uint32_t bundlePhotonKey(const Grid &g, float px, float py, float pz) {
+__device__ __forceinline__ uint32_t bundlePhotonKey(const Grid &g, float px, float py, float pz, int *level = nullptr) {
   const float cx = px - g.bo[0], cy = py - g.bo[1], cz = pz - g.bo[2];
   const float cA = cx * g.ba[0] + cy * g.ba[1] + cz * g.ba[2];
   const float cU = cx * g.bu[0] + cy * g.bu[1] + cz * g.bu[2];
@@ -54,6 +54,7 @@ __device__ __forceinline__ uint32_t bundlePhotonKey(const Grid &g, float px, flo
   int l = 0;
   const float q = half * g.invS0;
   if (q > 1.f) l = min(ilogbf(q) + 1, L - 1);
+  if (level) *level = l;
   const int Gl = G >> l;
   const float inv = g.invS0 / (float)(1 << l);
   const int cu = min(max((int)floorf((mu - g.uMin) * inv), 0), Gl - 1);

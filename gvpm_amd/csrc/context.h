@@ -28,12 +28,13 @@ void launch_bundle_fit(const gvpm_camera_ray *rays, uint32_t nsets, int pass, co
 void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, const uint32_t *e, uint32_t *hostOut,
                        hipStream_t s);
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
-void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count,
+uint32_t cell_stripes();
+void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count, uint32_t *sub,
                        hipStream_t s);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
                     uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                     const NearGrid &ng, uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
-                    uint32_t *origIdx, hipStream_t s);
+                    uint32_t *origIdx, const uint32_t *sub, uint32_t ncells, hipStream_t s);
 void launch_apply_host_shifts(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s);
 void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
                       hipStream_t s);
@@ -170,7 +171,7 @@ struct BuildSet {
   DevBuf<float4> hot, cold;
   DevBuf<uint32_t> overflowCtr;  // photons whose near-occluder list overflowed (they need the BVH kernels)
   DevBuf<uint32_t> origIdx;      // sorted photon -> index in the upload (host-shift requests; filled only when enabled)
-  DevBuf<uint32_t> cellStart, cellCount, sat, keysA, keysB, valsA, valsB;
+  DevBuf<uint32_t> cellStart, cellCount, cellSub, sat, keysA, keysB, valsA, valsB;
   DevBuf<uint32_t> beamCount, beamStart;  // counting sort of the beam sets
   DevBuf<float> boundsPartial, bounds6;
   Grid grid;
@@ -193,7 +194,7 @@ struct BuildSet {
   hipError_t mirrorFrom(const BuildSet &o) {
     hipError_t e = hipSuccess;
 #define GVPM_MIRROR(X) if (e == hipSuccess) e = X.reserveExact(o.X.cap)
-    GVPM_MIRROR(hot); GVPM_MIRROR(cold); GVPM_MIRROR(overflowCtr); GVPM_MIRROR(origIdx); GVPM_MIRROR(cellStart); GVPM_MIRROR(cellCount);
+    GVPM_MIRROR(hot); GVPM_MIRROR(cold); GVPM_MIRROR(overflowCtr); GVPM_MIRROR(origIdx); GVPM_MIRROR(cellStart); GVPM_MIRROR(cellCount); GVPM_MIRROR(cellSub);
     GVPM_MIRROR(sat); GVPM_MIRROR(keysA); GVPM_MIRROR(keysB); GVPM_MIRROR(valsA); GVPM_MIRROR(valsB);
     GVPM_MIRROR(beamCount); GVPM_MIRROR(beamStart); GVPM_MIRROR(boundsPartial); GVPM_MIRROR(bounds6);
     GVPM_MIRROR(bKeysA); GVPM_MIRROR(bKeysB); GVPM_MIRROR(bValsA); GVPM_MIRROR(setPerm); GVPM_MIRROR(tileStart);
@@ -203,7 +204,7 @@ struct BuildSet {
     return e;
   }
   void release() {
-    hot.release(); cold.release(); overflowCtr.release(); origIdx.release(); cellStart.release(); cellCount.release(); sat.release();
+    hot.release(); cold.release(); overflowCtr.release(); origIdx.release(); cellStart.release(); cellCount.release(); cellSub.release(); sat.release();
     beamCount.release(); beamStart.release(); keysA.release(); keysB.release();
     valsA.release(); valsB.release(); boundsPartial.release(); bounds6.release(); bKeysA.release(); bKeysB.release();
     bValsA.release(); setPerm.release(); tileStart.release(); items.release(); itemOff.release(); planBoxes.release(); queueCtl.release();

@@ -228,7 +228,14 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
     h->bs->scanSized = true;
   }
   HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
-  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, h->bstream);
+  // (bundle cells: striped counters, grid_build.hip cell_count_kernel)
+  uint32_t *sub = nullptr;
+  if (g.mode == 1) {
+    HIP_TRY(h, h->bs->cellSub.ensure((size_t)cell_stripes() * g.ncells));
+    HIP_TRY(h, hipMemsetAsync(h->bs->cellSub.p, 0, (size_t)cell_stripes() * g.ncells * sizeof(uint32_t), h->bstream));
+    sub = h->bs->cellSub.p;
+  }
+  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, sub, h->bstream);
   HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
   if (deferred) {
     // G-BRE: summed-volume table for the planner (sized once for the finest grid, like the cell arrays)
@@ -259,7 +266,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->bs->nearExt.p, 1, 1, h->bstream));
   launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
                  h->nearGrid, h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
-                 h->bs->cold.p, h->bs->overflowCtr.p, wantOrig ? h->bs->origIdx.p : nullptr, h->bstream);
+                 h->bs->cold.p, h->bs->overflowCtr.p, wantOrig ? h->bs->origIdx.p : nullptr, sub, g.ncells, h->bstream);
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
   if (!deferred && h->cfg.visibility_as_written) {
