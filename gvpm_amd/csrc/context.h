@@ -326,6 +326,7 @@ struct gvpm_context {
   bool haveCachedBounds = false, boundsPending = false;
   float *pinB6 = nullptr;      // pinned host staging: 6 floats + 2 uint32
   uint32_t *pinCtl = nullptr;
+  float *pinBeams = nullptr;   // the G-Beams driver's: 2 x 6 bounds (floats 0-5, 8-13), counters (uint32 from float 16 on)
 
   // camera beams
   const gvpm_camera_ray *raysDev = nullptr;

@@ -93,6 +93,8 @@ __device__ __forceinline__ int cellCoord(float p, float org, float inv, int dim)
 struct SortTemp {
   void *d = nullptr;
   size_t bytes = 0;
+  uint32_t sortN = 0;   // the largest pair count whose temporary size has been asked for (sortPairsU32) ...
+  size_t sortNeed = 0;  // ... and the answer
 };
 
 struct MediumDev {

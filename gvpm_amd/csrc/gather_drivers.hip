@@ -606,11 +606,16 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   const int nblocks = 1024;  // (four workgroups per CU: 256 left this bandwidth-bound pass latency-bound, 58 us for 24 MB)
   HIP_TRY(h, h->bs->boundsPartial.ensure(nblocks * 6));
   HIP_TRY(h, h->bs->bounds6.ensure(32));
-  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, nullptr, h->stream);
-  launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, nullptr, h->stream);
-  float b12[12];
-  HIP_TRY(h, hipMemcpyAsync(b12, h->bs->bounds6.p, sizeof(b12), hipMemcpyDeviceToHost, h->stream));
+  // (what the host reads back in this build -- bounds, sub-beam count -- and after the traversal is written by the kernels
+  // into pinned memory, as in the G-BRE build: a D2H copy is a runtime kernel of its own with ~20 us of latency around it)
+  if (!h->pinBeams) HIP_TRY(h, hipHostMalloc((void **)&h->pinBeams, 256, hipHostMallocMapped));
+  uint32_t *pinU = reinterpret_cast<uint32_t *>(h->pinBeams + 16);
+  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, h->pinBeams, h->stream);
+  launch_bounds(h->rawDev.parent_pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p + 6, h->pinBeams + 8, h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  float b12[12];
+  memcpy(b12, h->pinBeams, 6 * sizeof(float));
+  memcpy(b12 + 6, h->pinBeams + 8, 6 * sizeof(float));
   float b6[6], ext = 0.f;
   for (int c = 0; c < 3; ++c) {
     b6[c] = fminf(b12[c], b12[6 + c]);
@@ -646,11 +651,9 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   HIP_TRY(h, hipMemsetAsync(h->beamCtl.p, 0, 4 * sizeof(uint32_t), h->stream));
   launch_beam_subcount(h->rawDev.pos, h->rawDev.parent_pos, n, h->subLen, h->subCounts.p, h->beamCtl.p, h->stream);
   HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->subCounts.p, h->subOffsets.p, n, h->stream));
-  uint32_t lastOff = 0, lastCnt = 0, maxBits = 0;
-  HIP_TRY(h, hipMemcpyAsync(&lastOff, h->subOffsets.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(&lastCnt, h->subCounts.p + (n - 1), 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(&maxBits, h->beamCtl.p, 4, hipMemcpyDeviceToHost, h->stream));
+  launch_export_u32(h->subOffsets.p + (n - 1), h->subCounts.p + (n - 1), h->beamCtl.p, nullptr, nullptr, pinU, h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const uint32_t lastOff = pinU[0], lastCnt = pinU[1], maxBits = pinU[2];
   const uint64_t S = (uint64_t)lastOff + lastCnt;
   if (S > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many sub-beams");
   h->nsub = (uint32_t)S;
@@ -779,9 +782,11 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
     for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nblkCap));
     launch_traverse_beams(a, h->subFlags.p, h->beamsPerWave, h->bs->items.p, h->bs->queueCtl.p, itemCap, h->bs->queueCtl.p + 1,
                           h->beamPairs.p, h->bs->queueCtl.p + 2, cap, h->blockKeyA.p, h->blockValA.p, h->nwavesTrav, h->stream);
-    uint32_t ctl[3] = {0, 0, 0};
-    HIP_TRY(h, hipMemcpyAsync(ctl, h->bs->queueCtl.p, sizeof(ctl), hipMemcpyDeviceToHost, h->stream));
+    if (!h->pinBeams) HIP_TRY(h, hipHostMalloc((void **)&h->pinBeams, 256, hipHostMallocMapped));
+    uint32_t *pinU = reinterpret_cast<uint32_t *>(h->pinBeams + 16) + 8;
+    launch_export_u32(h->bs->queueCtl.p, h->bs->queueCtl.p + 1, h->bs->queueCtl.p + 2, nullptr, nullptr, pinU, h->stream);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const uint32_t ctl[3] = {pinU[0], pinU[1], pinU[2]};
     npairs = ctl[2];
     if (getenv("GVPM_BEAMS_TRACE")) {
       uint32_t q[4];

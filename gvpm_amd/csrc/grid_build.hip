@@ -474,14 +474,22 @@ static hipError_t ensureTemp(SortTemp &t, size_t need) {
   return e;
 }
 
+// (The size query is a full host-side pass of the library's dispatch -- ~240 us, device properties included -- and the G-Beams
+// step paid it twice per sort with the GPU idle behind it: asked once per high-water mark, for 1.25 x the count.)
 hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut,
                         uint32_t n, int endBit, hipStream_t s) {
-  size_t need = 0;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
+  if (n > tmp.sortN || tmp.sortNeed == 0) {
+    const uint32_t nq = (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4u + 1024u, 0x7FFFFFF0u);
+    size_t need = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, kIn, kOut, vIn, vOut, (int)nq, 0, 32, s);
+    if (e != hipSuccess) return e;
+    tmp.sortN = nq;
+    tmp.sortNeed = std::max(need, tmp.sortNeed);
+  }
+  hipError_t e = ensureTemp(tmp, tmp.sortNeed);
   if (e != hipSuccess) return e;
-  e = ensureTemp(tmp, need);
-  if (e != hipSuccess) return e;
-  return hipcub::DeviceRadixSort::SortPairs(tmp.d, need, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
+  size_t have = tmp.bytes;
+  return hipcub::DeviceRadixSort::SortPairs(tmp.d, have, kIn, kOut, vIn, vOut, (int)n, 0, endBit, s);
 }
 
 // make the temporary large enough for scans of up to n elements (so that no scan of a step allocates)

@@ -210,6 +210,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
+  if (h->pinBeams) (void)hipHostFree(h->pinBeams);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->streamB) (void)hipStreamDestroy(h->streamB);
   if (h->streamC) (void)hipStreamDestroy(h->streamC);
