@@ -144,8 +144,11 @@ assert PHOTON_PACKED_DTYPE.itemsize == 76 and RAY_PACKED_DTYPE.itemsize == 52
 
 # gvpm_bsdf: a glossy surface parent's BSDF (gvpm_upload_bsdfs)
 BSDF_DTYPE = np.dtype([("kind", np.int32), ("specular", np.float32, 3), ("exponent", np.float32),
-                       ("specular_sampling_weight", np.float32), ("reserved", np.float32, 2)])
-assert BSDF_DTYPE.itemsize == 32
+                       ("specular_sampling_weight", np.float32), ("distribution", np.int32), ("sample_visible", np.int32),
+                       ("eta", np.float32, 3), ("k", np.float32, 3), ("reserved", np.float32, 2)])
+assert BSDF_DTYPE.itemsize == 64
+GVPM_BSDF_PHONG, GVPM_BSDF_ROUGHCONDUCTOR = 1, 2
+GVPM_MICROFACET_BECKMANN, GVPM_MICROFACET_GGX = 0, 1
 
 # compact camera-beam sets (include/gvpm_hip.h, "compact camera-beam sets")
 BEAM_SET_COMPACT_DTYPE = np.dtype([

@@ -354,15 +354,25 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
       // a glossy parent (gvpm_upload_bsdfs): Phong with both components, src/bsdfs/phong.cpp:121-186
       const uint32_t bi = (uint32_t)b.parentG;
       if (!(b.parentG >= 0.0) || bi >= a.nbsdfs) return 1.0;
-      const float4 b0 = a.bsdfs[2 * bi], b1 = a.bsdfs[2 * bi + 1];
-      if (__float_as_int(b0.x) != GVPM_BSDF_PHONG) return 1.0;
-      const double e = b1.x, w = b1.y;
-      const d3 refl = b.parentN * (2.0 * cosWi) - b.parentWi;
-      const double alpha = dot(newPBDir, refl);
-      const double lobe = alpha > 0 ? pow(alpha, e) : 0.0;
-      const double INV_TWOPI = 0.15915494309189533577;
-      thr = (mkd(b0.y, b0.z, b0.w) * ((e + 2.0) * INV_TWOPI * lobe) + b.parentScat * INV_PI) * cosWo;
-      pdfValueSA = w * (lobe * (e + 1.0) * INV_TWOPI) + (1.0 - w) * (INV_PI * cosWo);
+      const float4 b0 = a.bsdfs[4 * bi], b1 = a.bsdfs[4 * bi + 1];
+      if (__float_as_int(b0.x) == GVPM_BSDF_PHONG) {
+        const double e = b1.x, w = b1.y;
+        const d3 refl = b.parentN * (2.0 * cosWi) - b.parentWi;
+        const double alpha = dot(newPBDir, refl);
+        const double lobe = alpha > 0 ? pow(alpha, e) : 0.0;
+        const double INV_TWOPI = 0.15915494309189533577;
+        thr = (mkd(b0.y, b0.z, b0.w) * ((e + 2.0) * INV_TWOPI * lobe) + b.parentScat * INV_PI) * cosWo;
+        pdfValueSA = w * (lobe * (e + 1.0) * INV_TWOPI) + (1.0 - w) * (INV_PI * cosWo);
+      } else {
+        // (the other table entries -- the rough conductor -- through the fp32 statement the default path uses)
+        f3 ff;
+        float pp;
+        if (!glossyParentEval(a, (float)b.parentG, tof(b.parentScat), tof(b.parentN), tof(b.parentWi), tof(newPBDir), (float)cosWi,
+                              (float)cosWo, ff, pp))
+          return 1.0;
+        thr = tod(ff);
+        pdfValueSA = (double)pp;
+      }
     }
   } else if (ptype == GVPM_PARENT_MEDIUM) {
     const double p = phaseD(b.parentG, b.parentWi, newPBDir);

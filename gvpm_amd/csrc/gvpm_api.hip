@@ -305,16 +305,28 @@ int gvpm_upload_bsdfs(gvpm_context *h, const gvpm_bsdf *table, uint32_t n) {
   CHECK_H(h);
   if (n && !table) return fail(h, GVPM_ERR_INVALID_ARG, "null bsdf table");
   if (n > (1u << 24)) return fail(h, GVPM_ERR_INVALID_ARG, "more than 2^24 bsdfs (the index travels as a float)");
-  std::vector<float4> rows(2 * (size_t)n + 2);
+  // four quads per entry: {kind, specular} {exponent | alpha, sampling weight, distribution, sample_visible} {eta, k.x} {k.yz}
+  std::vector<float4> rows(4 * (size_t)n + 4);
   for (uint32_t i = 0; i < n; ++i) {
     const gvpm_bsdf &b = table[i];
-    if (b.kind != GVPM_BSDF_PHONG) return fail(h, GVPM_ERR_UNSUPPORTED, "bsdf kind outside the device's closed set (Phong)");
-    if (!(b.exponent >= 0.f) || !(b.specular_sampling_weight >= 0.f && b.specular_sampling_weight <= 1.f))
-      return fail(h, GVPM_ERR_INVALID_ARG, "Phong: exponent >= 0 and a sampling weight in [0, 1]");
-    float kindBits;
+    float kindBits, distBits, visBits;
     memcpy(&kindBits, &b.kind, 4);
-    rows[2 * i] = make_float4(kindBits, b.specular[0], b.specular[1], b.specular[2]);
-    rows[2 * i + 1] = make_float4(b.exponent, b.specular_sampling_weight, 0.f, 0.f);
+    memcpy(&distBits, &b.distribution, 4);
+    memcpy(&visBits, &b.sample_visible, 4);
+    if (b.kind == GVPM_BSDF_PHONG) {
+      if (!(b.exponent >= 0.f) || !(b.specular_sampling_weight >= 0.f && b.specular_sampling_weight <= 1.f))
+        return fail(h, GVPM_ERR_INVALID_ARG, "Phong: exponent >= 0 and a sampling weight in [0, 1]");
+    } else if (b.kind == GVPM_BSDF_ROUGHCONDUCTOR) {
+      if (!(b.exponent >= 1e-4f)) return fail(h, GVPM_ERR_INVALID_ARG, "rough conductor: alpha >= 1e-4 (the reference clamps it)");
+      if (b.distribution != GVPM_MICROFACET_BECKMANN && b.distribution != GVPM_MICROFACET_GGX)
+        return fail(h, GVPM_ERR_UNSUPPORTED, "rough conductor: Beckmann or GGX");
+    } else {
+      return fail(h, GVPM_ERR_UNSUPPORTED, "bsdf kind outside the device's closed set (Phong, rough conductor)");
+    }
+    rows[4 * i] = make_float4(kindBits, b.specular[0], b.specular[1], b.specular[2]);
+    rows[4 * i + 1] = make_float4(b.exponent, b.specular_sampling_weight, distBits, visBits);
+    rows[4 * i + 2] = make_float4(b.eta[0], b.eta[1], b.eta[2], b.k[0]);
+    rows[4 * i + 3] = make_float4(b.k[1], b.k[2], 0.f, 0.f);
   }
   // once per scene: waits for whatever still reads the old table
   HIP_TRY(h, hipStreamSynchronize(h->stream));

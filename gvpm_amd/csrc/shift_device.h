@@ -221,26 +221,89 @@ __device__ __forceinline__ PhotonCold loadCold(const GatherArgs &a, uint32_t idx
   return c;
 }
 
+// MicrofacetDistribution, isotropic (src/bsdfs/microfacet.h): D of a half vector with cosine cH to the normal (:191-232) and
+// Smith's G1 of a direction with cosine cV to the normal and vDotH to the half vector (:477-518).
+__device__ __forceinline__ float microfacetD(int ggx, float alpha, float cH) {
+  if (cH <= 0.f) return 0.f;
+  const float c2 = cH * cH;
+  const float e = fdiv(fmaxf(1.f - c2, 0.f), alpha * alpha * c2);  // tan^2 / alpha^2
+  float r;
+  if (ggx) {
+    const float root = (1.f + e) * c2;
+    r = frcp(3.14159265358979323846f * alpha * alpha * root * root);
+  } else {
+    r = fdiv(__expf(-e), 3.14159265358979323846f * alpha * alpha * c2 * c2);
+  }
+  return r * cH < 1e-20f ? 0.f : r;
+}
+__device__ __forceinline__ float microfacetG1(int ggx, float alpha, float cV, float vDotH) {
+  if (vDotH * cV <= 0.f) return 0.f;
+  const float t2 = 1.f - cV * cV;
+  if (t2 <= 0.f) return 1.f;  // perpendicular incidence
+  const float tanT = fabsf(fdiv(fsqrt(t2), cV));
+  if (ggx) {
+    const float root = alpha * tanT;
+    return fdiv(2.f, 1.f + fsqrt(1.f + root * root));
+  }
+  const float a = frcp(alpha * tanT);
+  if (a >= 1.6f) return 1.f;
+  const float a2 = a * a;
+  return fdiv(3.535f * a + 2.181f * a2, 1.f + 2.276f * a + 2.577f * a2);
+}
+// fresnelConductorExact, one channel (src/libcore/util.cpp:747-769)
+__device__ __forceinline__ float fresnelConductor(float cI, float eta, float k) {
+  const float c2 = cI * cI, s2 = 1.f - c2, s4 = s2 * s2;
+  const float t1 = eta * eta - k * k - s2;
+  const float a2pb2 = fsqrt(fmaxf(t1 * t1 + k * k * eta * eta * 4.f, 0.f));
+  const float aa = fsqrt(fmaxf((a2pb2 + t1) * 0.5f, 0.f));
+  const float term1 = a2pb2 + c2, term2 = aa * (2.f * cI);
+  const float Rs2 = fdiv(term1 - term2, term1 + term2);
+  const float term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+  const float Rp2 = Rs2 * fdiv(term3 - term4, term3 + term4);
+  return 0.5f * (Rp2 + Rs2);
+}
+
 // A glossy surface parent (GVPM_PARENT_SURFACE_BSDF): BSDF::eval and BSDF::pdf * pdfComponent of the table entry the
 // record names, towards the new direction `wo` (shift_diffuse.cpp:25-41 with bRec.component = -1).  Phong, src/bsdfs/
 // phong.cpp:121-186: eval = (ks (e + 2) / 2pi alpha^e + kd / pi) cos_o, pdf = w alpha^e (e + 1) / 2pi + (1 - w) cos_o / pi,
-// alpha = wo . reflect(wi).  cosWi, cosWo > 0 is the caller's test.  False: no such entry (a failed shift).
+// alpha = wo . reflect(wi).  Rough conductor, src/bsdfs/roughconductor.cpp:257-319: eval = F D G / (4 cos_i), pdf = D G1(wi)
+// / (4 cos_i) or D cos_H / (4 |wo . H|) (include/gvpm_hip.h).  cosWi, cosWo > 0 is the caller's test.  False: no such
+// entry (a failed shift).
 __device__ __forceinline__ bool glossyParentEval(const GatherArgs &a, float index, f3 kd, f3 n, f3 wi, f3 wo, float cosWi,
                                                  float cosWo, f3 &f, float &pdf) {
   const uint32_t bi = (uint32_t)index;
   f = mk3(0.f);
   pdf = 0.f;
   if (!(index >= 0.f) || bi >= a.nbsdfs) return false;
-  const float4 b0 = a.bsdfs[2 * bi], b1 = a.bsdfs[2 * bi + 1];
-  if (__float_as_int(b0.x) != GVPM_BSDF_PHONG) return false;
-  const float e = b1.x, w = b1.y;
-  const f3 refl = n * (2.f * cosWi) - wi;
-  const float alpha = dot(wo, refl);
-  const float lobe = alpha > 0.f ? __builtin_exp2f(e * __builtin_log2f(alpha)) : 0.f;  // std::pow(alpha, exponent)
-  const float INV_TWOPI_F = 0.15915494309189533577f;
-  f = (mk3(b0.y, b0.z, b0.w) * ((e + 2.f) * INV_TWOPI_F * lobe) + kd * INV_PI_F) * cosWo;
-  pdf = w * (lobe * (e + 1.f) * INV_TWOPI_F) + (1.f - w) * (INV_PI_F * cosWo);
-  return true;
+  const float4 b0 = a.bsdfs[4 * bi], b1 = a.bsdfs[4 * bi + 1];
+  const int kind = __float_as_int(b0.x);
+  if (kind == GVPM_BSDF_PHONG) {
+    const float e = b1.x, w = b1.y;
+    const f3 refl = n * (2.f * cosWi) - wi;
+    const float alpha = dot(wo, refl);
+    const float lobe = alpha > 0.f ? __builtin_exp2f(e * __builtin_log2f(alpha)) : 0.f;  // std::pow(alpha, exponent)
+    const float INV_TWOPI_F = 0.15915494309189533577f;
+    f = (mk3(b0.y, b0.z, b0.w) * ((e + 2.f) * INV_TWOPI_F * lobe) + kd * INV_PI_F) * cosWo;
+    pdf = w * (lobe * (e + 1.f) * INV_TWOPI_F) + (1.f - w) * (INV_PI_F * cosWo);
+    return true;
+  }
+  if (kind == GVPM_BSDF_ROUGHCONDUCTOR) {
+    const float4 b2 = a.bsdfs[4 * bi + 2], b3 = a.bsdfs[4 * bi + 3];
+    const float alpha = b1.x;
+    const int ggx = __float_as_int(b1.z) == GVPM_MICROFACET_GGX, vis = __float_as_int(b1.w) != 0;
+    f3 H = wi + wo;
+    H = H * frsq(dot(H, H));
+    const float cH = dot(H, n), wiH = dot(wi, H), woH = dot(wo, H);
+    const float D = microfacetD(ggx, alpha, cH);
+    if (D == 0.f) return true;  // eval and pdf both zero (pdfAll = D cos_H, pdfVisible = D G1 ...)
+    const float G1i = microfacetG1(ggx, alpha, cosWi, wiH), G1o = microfacetG1(ggx, alpha, cosWo, woH);
+    const float model = fdiv(D * G1i * G1o, 4.f * cosWi);
+    f = mk3(fresnelConductor(wiH, b2.x, b2.w) * b0.y, fresnelConductor(wiH, b2.y, b3.x) * b0.z,
+            fresnelConductor(wiH, b2.z, b3.y) * b0.w) * model;
+    pdf = vis ? fdiv(D * G1i, 4.f * cosWi) : fdiv(D * cH, 4.f * fabsf(woH));
+    return true;
+  }
+  return false;
 }
 
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.

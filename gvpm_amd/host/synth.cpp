@@ -115,7 +115,7 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
       auto lum = [](V3 c) { return 0.212671 * c.x + 0.715160 * c.y + 0.072169 * c.z; };  // Spectrum::getLuminance, RGB
       SynthMat m{MAT_PHONG, kd, ks, e, lum(ks) / (lum(kd) + lum(ks)), 0};
       m.bsdf = 0;
-      for (const auto &q : s.mats) m.bsdf += q.kind == MAT_PHONG ? 1 : 0;
+      for (const auto &q : s.mats) m.bsdf += (q.kind == MAT_PHONG || q.kind == MAT_ROUGHCONDUCTOR) ? 1 : 0;
       s.mats.push_back(m);
       return (int)s.mats.size() - 1;
     };
@@ -124,6 +124,24 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, name == "cbox_phong_hg" ? 0.7 : 0.0);
+  } else if (name == "cbox_conductor") {
+    // S-cbox with METAL walls (row f4): the floor a rough copper plate (Beckmann, alpha 0.3), the back wall brushed aluminium
+    // (GGX, alpha 0.2) -- src/bsdfs/roughconductor.cpp, the table's second kind; eta / k: Mitsuba's Cu and Al at RGB
+    auto conductor = [&](V3 eta, V3 k, double alpha, int distribution) {
+      SynthMat m{MAT_ROUGHCONDUCTOR, V3(0.0), V3(1.0), alpha, 0.0, 0};
+      m.eta = eta;
+      m.k = k;
+      m.distribution = distribution;
+      m.bsdf = 0;
+      for (const auto &q : s.mats) m.bsdf += (q.kind == MAT_PHONG || q.kind == MAT_ROUGHCONDUCTOR) ? 1 : 0;
+      s.mats.push_back(m);
+      return (int)s.mats.size() - 1;
+    };
+    const int mFloor = conductor(V3(0.2004, 0.9240, 1.1022), V3(3.9129, 2.4528, 2.1421), 0.3, GVPM_MICROFACET_BECKMANN);
+    const int mBack = conductor(V3(1.6574, 0.8803, 0.5212), V3(9.2238, 6.2695, 4.8370), 0.2, GVPM_MICROFACET_GGX);
+    addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
+    setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
+    setMedium(s, 0.5, 0.5, 0.0);
   } else if (name == "cbox") {
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);

@@ -20,7 +20,9 @@ namespace gvpm {
 // MAT_PHONG: the modified Phong BSDF of src/bsdfs/phong.cpp, both components sampled together (roughness >= 0.05, so
 // that PathVertex::sampleNext keeps sampledComponentIndex = -1, vertex.cpp:160-180): a GLOSSY wall that still classifies
 // as diffuse for the reconnection (gvpm_struct.h:66-100) -- the parent type GVPM_PARENT_SURFACE_BSDF of the ABI
-enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3 };
+// MAT_ROUGHCONDUCTOR: src/bsdfs/roughconductor.cpp, isotropic Beckmann / GGX, sampled WITHOUT visible normals
+// (sampleVisible = false: MicrofacetDistribution::sampleAll) -- the table's second kind
+enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3, MAT_ROUGHCONDUCTOR = 4 };
 
 struct SynthTri {
   V3 v0, e1, e2, n;  // n: geometric normal (front side)
@@ -33,6 +35,9 @@ struct SynthMat {
   double exponent;    // Phong exponent
   double specWeight;  // m_specularSamplingWeight = lum(spec) / (lum(diffuse) + lum(spec)), phong.cpp:93-97
   int bsdf;           // index in the table of gvpm_upload_bsdfs (-1: none)
+  // rough conductor: spec = specular reflectance, exponent = alpha
+  V3 eta = V3(0.0), k = V3(0.0);
+  int distribution = 0;  // GVPM_MICROFACET_*
 };
 
 // what the generators read of a scene (SynthScene::view(); the device gets the arrays in HBM)
@@ -57,6 +62,43 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 1.0 / kPi;
 constexpr double kInvFourPi = 1.0 / (4.0 * kPi);
 constexpr double kEpsilon = 1e-4;  // Epsilon, single-precision build (constants.h:24-31)
+
+// isotropic microfacet terms of the rough conductor (microfacet.h:191-232, 477-518; util.cpp:747-769), by cosines
+GVPM_HD inline double conductorD(int ggx, double alpha, double cH) {
+  if (cH <= 0) return 0;
+  const double c2 = cH * cH, e = (1 - c2) / (alpha * alpha * c2);
+  double r;
+  if (ggx) {
+    const double root = (1 + e) * c2;
+    r = 1.0 / (kPi * alpha * alpha * root * root);
+  } else {
+    r = std::exp(-e) / (kPi * alpha * alpha * c2 * c2);
+  }
+  return r * cH < 1e-20 ? 0.0 : r;
+}
+GVPM_HD inline double conductorG1(int ggx, double alpha, double cV, double vDotH) {
+  if (vDotH * cV <= 0) return 0;
+  const double t2 = 1 - cV * cV;
+  if (t2 <= 0) return 1;
+  const double tanT = std::fabs(std::sqrt(t2) / cV);
+  if (ggx) {
+    const double root = alpha * tanT;
+    return 2.0 / (1.0 + std::sqrt(1.0 + root * root));
+  }
+  const double a = 1.0 / (alpha * tanT);
+  if (a >= 1.6) return 1;
+  return (3.535 * a + 2.181 * a * a) / (1.0 + 2.276 * a + 2.577 * a * a);
+}
+GVPM_HD inline double conductorFresnel(double cI, double eta, double k) {
+  const double c2 = cI * cI, s2 = 1 - c2, s4 = s2 * s2;
+  const double t1 = eta * eta - k * k - s2;
+  const double a2pb2 = std::sqrt(std::fmax(0.0, t1 * t1 + k * k * eta * eta * 4));
+  const double aa = std::sqrt(std::fmax(0.0, (a2pb2 + t1) * 0.5));
+  const double term1 = a2pb2 + c2, term2 = aa * (2 * cI);
+  const double Rs2 = (term1 - term2) / (term1 + term2);
+  const double term3 = a2pb2 * c2 + s4, term4 = term2 * s2;
+  return 0.5 * (Rs2 * (term3 - term4) / (term3 + term4) + Rs2);
+}
 
 // ------------------------------------------------------------------ scenes --
 struct Hit {
@@ -245,6 +287,39 @@ GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
         cur.weight = f * (1.0 / pdfW);
         cur.pdf = pdfW;
         if (maxc(cur.weight) <= 0) break;
+      } else if (cur.matKind == MAT_ROUGHCONDUCTOR) {
+        // RoughConductor::sample, sampleVisible = false (roughconductor.cpp:321-389 with MicrofacetDistribution::sampleAll,
+        // microfacet.h:287-347): half vector m ~ D cos, wo = reflect(wi, m), weight = F D G (wi . m) / (pdf_m cos_i),
+        // pdf = pdf_m / (4 |wo . m|)
+        const SynthMat &pm = sc.mats[cur.mat];
+        const double alpha = pm.exponent, alphaSqr = alpha * alpha, cosWi = dot(cur.n, wi);
+        double tanThetaMSqr, pdfM, cosThetaM;
+        if (pm.distribution == GVPM_MICROFACET_GGX) {
+          tanThetaMSqr = alphaSqr * a / (1.0 - a);
+          cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
+          const double temp = 1 + tanThetaMSqr / alphaSqr;
+          pdfM = kInvPi / (alphaSqr * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        } else {
+          tanThetaMSqr = alphaSqr * -std::log(1.0 - a);
+          cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
+          pdfM = (1.0 - a) / (kPi * alphaSqr * cosThetaM * cosThetaM * cosThetaM);
+        }
+        if (!(pdfM >= 1e-20)) break;
+        const double sinThetaM = std::sqrt(std::fmax(0.0, 1 - cosThetaM * cosThetaM)), phi = 2.0 * kPi * b;
+        const V3 m = toWorld(cur.n, V3(sinThetaM * std::cos(phi), sinThetaM * std::sin(phi), cosThetaM));
+        const double wiM = dot(wi, m);
+        wo = m * (2.0 * wiM) - wi;
+        const double cosWo = dot(cur.n, wo);
+        if (cosWo <= 0) break;
+        const double woM = dot(wo, m);
+        const double D = conductorD(pm.distribution, alpha, cosThetaM);
+        const double G = conductorG1(pm.distribution, alpha, cosWi, wiM) * conductorG1(pm.distribution, alpha, cosWo, woM);
+        const double wgt = D * G * wiM / (pdfM * cosWi);
+        cur.weight = V3(conductorFresnel(wiM, pm.eta.x, pm.k.x) * pm.spec.x, conductorFresnel(wiM, pm.eta.y, pm.k.y) * pm.spec.y,
+                        conductorFresnel(wiM, pm.eta.z, pm.k.z) * pm.spec.z) * wgt;
+        cur.pdf = pdfM / (4.0 * std::fabs(woM));
+        cur.comp = 0x00008u;  // EGlossyReflection
+        if (maxc(cur.weight) <= 0 || !(cur.pdf > 0)) break;
       } else {
         V3 local = cosineHemisphere(a, b);
         wo = toWorld(cur.n, local);
@@ -348,7 +423,7 @@ GVPM_HD inline bool vertexIsDiffuse(const SceneView &sc, const LVertex &v) {
     case VT_EMITTER: return true;
     // (Phong: the Beckmann-equivalent roughness sqrt(2 / (2 + exponent)) of its glossy lobe, phong.cpp:293-300, is far
     // above bounceRoughness = 0.001 for every exponent the both-components branch admits)
-    case VT_SURFACE: return v.matKind == MAT_LAMBERT || v.matKind == MAT_PHONG;
+    case VT_SURFACE: return v.matKind == MAT_LAMBERT || v.matKind == MAT_PHONG || v.matKind == MAT_ROUGHCONDUCTOR;
     case VT_MEDIUM: return !(sc.medium.g > 0.5);
     default: return false;
   }
@@ -395,7 +470,7 @@ GVPM_HD inline void fillParent(const SceneView &sc, const LPath &path, size_t ip
     ptype = GVPM_PARENT_SURFACE;
     r.parentScat = par.albedo;
     r.parentWi = normalize(path[ip - 1].pos - par.pos);
-    if (par.matKind == MAT_PHONG) {
+    if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
       ptype = GVPM_PARENT_SURFACE_BSDF;
       r.parentG = (float)sc.mats[par.mat].bsdf;
     }
@@ -474,7 +549,7 @@ template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const L
       ptype = GVPM_PARENT_SURFACE;
       r.parentScat = par.albedo;
       r.parentWi = normalize(path[i - 2].pos - par.pos);
-      if (par.matKind == MAT_PHONG) {
+      if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
         ptype = GVPM_PARENT_SURFACE_BSDF;
         r.parentG = (float)sc.mats[par.mat].bsdf;
         comp = par.comp;  // the sampled lobe's type: EGlossyReflection or EDiffuseReflection (vertex.cpp:178-179)

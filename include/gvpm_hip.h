@@ -185,13 +185,25 @@ typedef struct gvpm_medium {
  *     with alpha = wo . reflect(wi), w = specular_sampling_weight, both zero unless cos(theta_i), cos(theta_o) > 0;
  *     pdfComponent = 1.  Such a vertex classifies as DIFFUSE for every roughness above bounceRoughness (default 0.001,
  *     gvpm_struct.h:66-100,232-236): its photons are re-connected through it like through a Lambertian wall.
+ *   GVPM_BSDF_ROUGHCONDUCTOR  src/bsdfs/roughconductor.cpp with an ISOTROPIC Beckmann or GGX distribution (alphaU == alphaV:
+ *     the photon record carries the parent's normal, not its tangent frame) -- one component, EGlossyReflection:
+ *       H = normalize(wi + wo), D = MicrofacetDistribution::eval (microfacet.h:191-232), G = smithG1(wi, H) smithG1(wo, H)
+ *       (:477-522), F = fresnelConductorExact(wi . H, eta, k) * specular (libcore/util.cpp:747-769)
+ *       eval(wi, wo) = F D G / (4 cos(theta_i))                                                                 :257-293
+ *       pdf(wi, wo)  = D smithG1(wi, H) / (4 cos(theta_i))  [sample_visible]   or   D cos(theta_H) / (4 |wo . H|)  :295-319
+ *     both zero unless cos(theta_i), cos(theta_o) > 0; pdfComponent = 1.  `exponent` carries alpha (after the constructor's
+ *     clamp to >= 1e-4, microfacet.h:135-136).  Classified like any vertex by its roughness alpha against bounceRoughness.
  * A surface parent outside the closed set stays what it was: the host flags the photon's shift type 0 (failed shift).   */
-enum { GVPM_BSDF_PHONG = 1 };
-typedef struct gvpm_bsdf {    /* 32 bytes */
-  int32_t kind;               /* GVPM_BSDF_PHONG                                                        */
-  float specular[3];          /* m_specularReflectance (after ensureEnergyConservation, phong.cpp:86-91) */
-  float exponent;             /* m_exponent                                                             */
-  float specular_sampling_weight; /* m_specularSamplingWeight, phong.cpp:93-97                          */
+enum { GVPM_BSDF_PHONG = 1, GVPM_BSDF_ROUGHCONDUCTOR = 2 };
+enum { GVPM_MICROFACET_BECKMANN = 0, GVPM_MICROFACET_GGX = 1 };
+typedef struct gvpm_bsdf {    /* 64 bytes */
+  int32_t kind;               /* GVPM_BSDF_*                                                            */
+  float specular[3];          /* m_specularReflectance (Phong: after ensureEnergyConservation, phong.cpp:86-91) */
+  float exponent;             /* Phong: m_exponent; rough conductor: alpha                              */
+  float specular_sampling_weight; /* Phong: m_specularSamplingWeight, phong.cpp:93-97                   */
+  int32_t distribution;       /* rough conductor: GVPM_MICROFACET_*                                     */
+  int32_t sample_visible;     /* rough conductor: m_sampleVisible (the pdf's form)                      */
+  float eta[3], k[3];         /* rough conductor: m_eta, m_k (relative to the exterior, roughconductor.cpp:181-191) */
   float reserved[2];
 } gvpm_bsdf;
 

@@ -364,6 +364,89 @@ inline bool phongEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n
   return true;
 }
 
+// RoughConductor::eval / pdf, src/bsdfs/roughconductor.cpp:257-319 (one component: bRec.component -1 or 0), with
+// MicrofacetDistribution (src/bsdfs/microfacet.h: eval :191-232, pdf :270-275 -> pdfAll = eval * cosTheta / pdfVisible,
+// smithG1 :477-518, G :520-522, projectRoughness = alphaU for an isotropic distribution :541-546) and fresnelConductorExact
+// (src/libcore/util.cpp:747-769), in the local frame of the intersection.  Beckmann or GGX, alphaU == alphaV = b.exponent.
+template <typename F> inline F microfacetEval(const gvpm_bsdf &b, const Vec3<F> &m) {
+  const F M_PI_F = (F)3.14159265358979323846, alpha = (F)b.exponent;
+  if (m.z <= 0) return 0;
+  const F cosTheta2 = m.z * m.z;
+  const F beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
+  F result;
+  if (b.distribution == GVPM_MICROFACET_GGX) {
+    const F root = ((F)1 + beckmannExponent) * cosTheta2;
+    result = (F)1 / (M_PI_F * alpha * alpha * root * root);
+  } else {
+    result = std::exp(-beckmannExponent) / (M_PI_F * alpha * alpha * cosTheta2 * cosTheta2);  // math::fastexp
+  }
+  if (result * m.z < (F)1e-20) result = 0;
+  return result;
+}
+template <typename F> inline F microfacetSmithG1(const gvpm_bsdf &b, const Vec3<F> &v, const Vec3<F> &m) {
+  if (dot(v, m) * v.z <= 0) return 0;
+  const F temp = 1 - v.z * v.z;                       // Frame::tanTheta(v), frame.h
+  const F tanTheta = temp <= 0 ? (F)0 : std::abs(std::sqrt(temp) / v.z);
+  if (tanTheta == 0) return 1;
+  const F alpha = (F)b.exponent;                      // projectRoughness, isotropic
+  if (b.distribution == GVPM_MICROFACET_GGX) {
+    const F root = alpha * tanTheta;
+    return (F)2 / ((F)1 + std::sqrt((F)1 + root * root));  // math::hypot2(1, root)
+  }
+  const F a = (F)1 / (alpha * tanTheta);
+  if (a >= (F)1.6) return 1;
+  const F aSqr = a * a;
+  return ((F)3.535 * a + (F)2.181 * aSqr) / ((F)1 + (F)2.276 * a + (F)2.577 * aSqr);
+}
+template <typename F> inline F fresnelConductorExact1(F cosThetaI, F eta, F k) {
+  const F cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+  const F temp1 = eta * eta - k * k - sinThetaI2;
+  const F a2pb2 = std::sqrt(std::max((F)0, temp1 * temp1 + k * k * eta * eta * 4));  // safe_sqrt
+  const F a = std::sqrt(std::max((F)0, (a2pb2 + temp1) * (F)0.5));
+  const F term1 = a2pb2 + cosThetaI2, term2 = a * (2 * cosThetaI);
+  const F Rs2 = (term1 - term2) / (term1 + term2);
+  const F term3 = a2pb2 * cosThetaI2 + sinThetaI4, term4 = term2 * sinThetaI2;
+  const F Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+  return (F)0.5 * (Rp2 + Rs2);
+}
+template <typename F>
+inline bool roughConductorEvalPdf(const gvpm_bsdf &b, const Vec3<F> &n, const Vec3<F> &wiW, const Vec3<F> &woW, Vec3<F> &f, F &pdf) {
+  typedef Vec3<F> V;
+  V s, t;
+  coordinateSystem(n, s, t);
+  const V wi(dot(wiW, s), dot(wiW, t), dot(wiW, n)), wo(dot(woW, s), dot(woW, t), dot(woW, n));
+  f = V((F)0);
+  pdf = 0;
+  if (wi.z <= 0 || wo.z <= 0) return false;
+  const V H = normalize(wo + wi);
+  const F D = microfacetEval<F>(b, H);
+  if (D != 0) {
+    const F wiH = dot(wi, H);
+    const V Fr(fresnelConductorExact1<F>(wiH, (F)b.eta[0], (F)b.k[0]) * (F)b.specular[0],
+               fresnelConductorExact1<F>(wiH, (F)b.eta[1], (F)b.k[1]) * (F)b.specular[1],
+               fresnelConductorExact1<F>(wiH, (F)b.eta[2], (F)b.k[2]) * (F)b.specular[2]);
+    const F G = microfacetSmithG1<F>(b, wi, H) * microfacetSmithG1<F>(b, wo, H);
+    f = Fr * (D * G / ((F)4 * wi.z));
+  }
+  if (b.sample_visible) pdf = D * microfacetSmithG1<F>(b, wi, H) / ((F)4 * wi.z);
+  else pdf = D * H.z / ((F)4 * std::abs(dot(wo, H)));  // pdfAll(H) / (4 absDot(wo, H))
+  return true;
+}
+// the table entry's eval and pdf (false: a kind outside the closed set)
+template <typename F>
+inline bool glossyEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n, const Vec3<F> &wiW, const Vec3<F> &woW, Vec3<F> &f,
+                          F &pdf) {
+  if (b.kind == GVPM_BSDF_PHONG) {
+    phongEvalPdf<F>(b, kd, n, wiW, woW, f, pdf);
+    return true;
+  }
+  if (b.kind == GVPM_BSDF_ROUGHCONDUCTOR) {
+    roughConductorEvalPdf<F>(b, n, wiW, woW, f, pdf);
+    return true;
+  }
+  return false;
+}
+
 template <typename F> struct GatherContext {
   gvpm_params cfg;
   Medium<F> medium;
@@ -442,13 +525,12 @@ template <typename F> struct VolumeGradientRecord {
       // a glossy parent: BSDF::eval, BSDF::pdf * pdfComponent of the table's entry (shift_diffuse.cpp:25-41)
       const std::vector<gvpm_bsdf> &tab = bsdfTable();
       const size_t bi = (size_t)ph.parentG;
-      if (!(ph.parentG >= 0) || bi >= tab.size() || tab[bi].kind != GVPM_BSDF_PHONG) {
+      V f;
+      if (!(ph.parentG >= 0) || bi >= tab.size() || !glossyEvalPdf<F>(tab[bi], ph.parentScat, ph.parentN, ph.parentWi, newD, f, pdfValue)) {
         sRec.throughtput *= V((F)0);  // outside the closed set: a failed shift, as the device makes of it
         sRec.pdf = 0;
         return false;
       }
-      V f;
-      phongEvalPdf<F>(tab[bi], ph.parentScat, ph.parentN, ph.parentWi, newD, f, pdfValue);
       sRec.throughtput *= f;
       pdfValue *= (F)1;  // pdfComponent, bRec.component == -1
       F cosWo = dot(ph.parentN, newD), cosWi = dot(ph.parentN, ph.parentWi);

@@ -383,13 +383,12 @@ template <typename F> struct BeamGradRadianceQuery {
       // a glossy parent (gvpm_upload_bsdfs): shift_diffuse.cpp:150-176 evaluates the parent's BSDF as :25-41 does
       const std::vector<gvpm_bsdf> &tab = bsdfTable();
       const size_t bi = (size_t)ph.parentG;
-      if (!(ph.parentG >= 0) || bi >= tab.size() || tab[bi].kind != GVPM_BSDF_PHONG) {
+      V f;
+      if (!(ph.parentG >= 0) || bi >= tab.size() || !glossyEvalPdf<F>(tab[bi], ph.parentScat, ph.parentN, ph.parentWi, newD, f, pdfValueSA)) {
         sRec.throughtput *= V((F)0);
         sRec.pdf = 0;
         return false;
       }
-      V f;
-      phongEvalPdf<F>(tab[bi], ph.parentScat, ph.parentN, ph.parentWi, newD, f, pdfValueSA);
       sRec.throughtput *= f;
       F cosWo = dot(ph.parentN, newD), cosWi = dot(ph.parentN, ph.parentWi);
       if (cosWi * cosWi <= 0 || cosWo * cosWo <= 0) return false;

@@ -635,6 +635,57 @@ extern "C" int oracle_phong_sample(const gvpm_bsdf *b, const double *n, const do
   return 1;
 }
 
+// the table entry's eval / pdf whatever its kind (glossyEvalPdf), and MicrofacetDistribution::sampleAll + RoughConductor::sample
+// without visible-normal sampling (microfacet.h:287-345, roughconductor.cpp:321-389, isotropic): the half vector, the
+// reflected direction, `weight` = F * D G (wi . m) / (pdf_m cos_i), pdf = pdf_m / (4 |wo . m|).
+extern "C" int oracle_bsdf_eval_pdf(const gvpm_bsdf *b, const double *kd, const double *n, const double *wi, const double *wo,
+                                    double *f, double *pdf) {
+  Vec3<double> fv;
+  double p = 0;
+  const bool ok = glossyEvalPdf<double>(*b, Vec3<double>(kd[0], kd[1], kd[2]), Vec3<double>(n[0], n[1], n[2]),
+                                        Vec3<double>(wi[0], wi[1], wi[2]), Vec3<double>(wo[0], wo[1], wo[2]), fv, p);
+  f[0] = fv.x; f[1] = fv.y; f[2] = fv.z;
+  *pdf = p;
+  return ok ? 1 : 0;
+}
+extern "C" int oracle_roughconductor_sample(const gvpm_bsdf *b, const double *n, const double *wiW, double u1, double u2, double *woW,
+                                            double *weight, double *pdf) {
+  typedef Vec3<double> V;
+  const V nn(n[0], n[1], n[2]);
+  V s, t;
+  coordinateSystem(nn, s, t);
+  const V wiV(wiW[0], wiW[1], wiW[2]);
+  const V wi(dot(wiV, s), dot(wiV, t), dot(wiV, nn));
+  if (wi.z < 0) return 0;
+  const double alpha = b->exponent, alphaSqr = alpha * alpha;
+  const double phi = 2.0 * M_PI * u2;
+  double tanThetaMSqr, pdfM, cosThetaM;
+  if (b->distribution == GVPM_MICROFACET_GGX) {
+    tanThetaMSqr = alphaSqr * u1 / (1.0 - u1);
+    cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
+    const double temp = 1 + tanThetaMSqr / alphaSqr;
+    pdfM = (1.0 / M_PI) / (alpha * alpha * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+  } else {
+    tanThetaMSqr = alphaSqr * -std::log(1.0 - u1);
+    cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
+    pdfM = (1.0 - u1) / (M_PI * alpha * alpha * cosThetaM * cosThetaM * cosThetaM);
+  }
+  if (pdfM < 1e-20) pdfM = 0;
+  if (pdfM == 0) return 0;
+  const double sinThetaM = std::sqrt(std::max(0.0, 1 - cosThetaM * cosThetaM));
+  const V m(sinThetaM * std::cos(phi), sinThetaM * std::sin(phi), cosThetaM);
+  const V wo = m * (2 * dot(wi, m)) - wi;  // reflect(wi, m)
+  if (wo.z <= 0) return 0;
+  const double D = microfacetEval<double>(*b, m), G = microfacetSmithG1<double>(*b, wi, m) * microfacetSmithG1<double>(*b, wo, m);
+  const double wgt = D * G * dot(wi, m) / (pdfM * wi.z);
+  const double wiM = dot(wi, m);
+  for (int c = 0; c < 3; ++c) weight[c] = fresnelConductorExact1<double>(wiM, (double)b->eta[c], (double)b->k[c]) * b->specular[c] * wgt;
+  *pdf = pdfM / (4.0 * std::abs(dot(wo, m)));
+  const V out = s * wo.x + t * wo.y + nn * wo.z;
+  woW[0] = out.x; woW[1] = out.y; woW[2] = out.z;
+  return 1;
+}
+
 extern "C" double oracle_phase_eval(double g, const double *wi, const double *wo) {
   return Medium<double>::phaseEval(g, Vec3<double>(wi[0], wi[1], wi[2]), Vec3<double>(wo[0], wo[1], wo[2]));
 }

@@ -28,6 +28,9 @@
 
 #include <mitsuba/render/trimesh.h>
 
+#include "../../../bsdfs/ior.h"         /* src/bsdfs/ior.h: lookupIOR, as roughconductor.cpp:22-23 includes them   */
+#include "../../../bsdfs/microfacet.h"  /* src/bsdfs/microfacet.h: MicrofacetDistribution(const Properties &)      */
+
 #include "gvpm_hip.h"  /* include/gvpm_hip.h of the gvpm-hip repository */
 
 MTS_NAMESPACE_BEGIN
@@ -475,30 +478,54 @@ private:
                                                                                its entry in the table of gvpm_upload_bsdfs */
   }
 
-  /* A surface parent whose BSDF is in the device's table of glossy BSDFs (include/gvpm_hip.h, gvpm_bsdf): the modified Phong
-   * model (src/bsdfs/phong.cpp), not textured, sampled with BOTH components (sampledComponentIndex == -1: what
+  /* A surface parent whose BSDF is in the device's table of glossy BSDFs (include/gvpm_hip.h, gvpm_bsdf).  Returns its index
+   * (appending the entry on first sight), -1 for every other vertex.
+   * Phong (src/bsdfs/phong.cpp), not textured, sampled with BOTH components (sampledComponentIndex == -1: what
    * PathVertex::sampleNext records when Phong::sampleComponent finds the lobe's roughness >= 0.05, vertex.cpp:160-165,
-   * phong.cpp:311-330).  Returns its index (appending the entry on first sight), -1 for every other vertex.  The exponent
-   * and the sampling weight have no getters: they are read back through getRoughness = sqrt(2 / (2 + exponent))
-   * (phong.cpp:293-300) and pdfComponent(component 0) = m_specularSamplingWeight (:332-343).                            */
+   * phong.cpp:311-330).  The exponent and the sampling weight have no getters: they are read back through getRoughness =
+   * sqrt(2 / (2 + exponent)) (phong.cpp:293-300) and pdfComponent(component 0) = m_specularSamplingWeight (:332-343).
+   * RoughConductor (src/bsdfs/roughconductor.cpp), not textured, isotropic Beckmann or GGX, whose Properties name `eta` and `k`
+   * themselves (a `material` preset keeps its spectra in protected members: such a surface stays outside the closed set):
+   * m_eta = eta / extEta, m_k = k / extEta (:181-191), alpha and the distribution through MicrofacetDistribution(props) as the
+   * constructor reads them (:193-201).                                                                                    */
   int glossyIndex(const PathVertex *par) {
-    if (!par->isSurfaceInteraction() || par->sampledComponentIndex != -1) return -1;
+    if (!par->isSurfaceInteraction()) return -1;
     const Intersection &its = par->getIntersection();
     const BSDF *bsdf = its.getBSDF();
-    if (bsdf->getClass()->getName() != "Phong" || (bsdf->getType() & BSDF::ESpatiallyVarying)) return -1;
+    const std::string cls = bsdf->getClass()->getName();
+    if (bsdf->getType() & BSDF::ESpatiallyVarying) return -1;
+    if (cls == "Phong" ? par->sampledComponentIndex != -1 : cls != "RoughConductor") return -1;
     auto found = m_bsdfIndex.find(bsdf);
     if (found != m_bsdfIndex.end()) return (int) found->second;
     gvpm_bsdf b;
     memset(&b, 0, sizeof(b));
-    b.kind = GVPM_BSDF_PHONG;
     Float cr, cg, cb;
     bsdf->getSpecularReflectance(its).toLinearRGB(cr, cg, cb);
     b.specular[0] = (float) cr; b.specular[1] = (float) cg; b.specular[2] = (float) cb;
-    const Float rough = bsdf->getRoughness(its, 0);
-    b.exponent = (float) (2.0 / ((double) rough * (double) rough) - 2.0);
-    BSDFSamplingRecord bRec(its, its.wi, its.wi, EImportance);
-    bRec.component = 0;
-    b.specular_sampling_weight = (float) bsdf->pdfComponent(bRec);
+    if (cls == "Phong") {
+      b.kind = GVPM_BSDF_PHONG;
+      const Float rough = bsdf->getRoughness(its, 0);
+      b.exponent = (float) (2.0 / ((double) rough * (double) rough) - 2.0);
+      BSDFSamplingRecord bRec(its, its.wi, its.wi, EImportance);
+      bRec.component = 0;
+      b.specular_sampling_weight = (float) bsdf->pdfComponent(bRec);
+    } else {
+      const Properties &props = bsdf->getProperties();
+      if (!props.hasProperty("eta") || !props.hasProperty("k")) return -1;
+      MicrofacetDistribution distr(props);
+      if (!distr.isIsotropic() || (distr.getType() != MicrofacetDistribution::EBeckmann && distr.getType() != MicrofacetDistribution::EGGX))
+        return -1;
+      b.kind = GVPM_BSDF_ROUGHCONDUCTOR;
+      b.exponent = (float) distr.getAlphaU();
+      b.distribution = distr.getType() == MicrofacetDistribution::EGGX ? GVPM_MICROFACET_GGX : GVPM_MICROFACET_BECKMANN;
+      b.sample_visible = distr.getSampleVisible() ? 1 : 0;
+      const Float extEta = lookupIOR(props, "extEta", "air");
+      const Spectrum eta = props.getSpectrum("eta") / extEta, k = props.getSpectrum("k") / extEta;
+      eta.toLinearRGB(cr, cg, cb);
+      b.eta[0] = (float) cr; b.eta[1] = (float) cg; b.eta[2] = (float) cb;
+      k.toLinearRGB(cr, cg, cb);
+      b.k[0] = (float) cr; b.k[1] = (float) cg; b.k[2] = (float) cb;
+    }
     const uint32_t idx = (uint32_t) m_bsdfs.size();
     m_bsdfs.push_back(b);
     m_bsdfIndex[bsdf] = idx;
@@ -519,8 +546,10 @@ private:
     int b = -1;
     const ELightShiftType t = getTypeShift(lt, c, b);
     uint32_t st = t == EDiffuseShift ? 1u : t == EMediumShift ? 2u : t == EManifoldShift ? 3u : 0u;
-    const bool glossy = m_bsdfIndex.count(par->isSurfaceInteraction() ? par->getIntersection().getBSDF() : nullptr) != 0 &&
-                        par->sampledComponentIndex == -1;   /* (pushParent ran first: the entry exists) */
+    const BSDF *parBsdf = par->isSurfaceInteraction() ? par->getIntersection().getBSDF() : nullptr;
+    /* (pushParent ran first: the entry exists; a Phong vertex that sampled ONE lobe is not the table's BSDF) */
+    const bool glossy = m_bsdfIndex.count(parBsdf) != 0 &&
+                        (par->sampledComponentIndex == -1 || m_bsdfs[m_bsdfIndex.at(parBsdf)].kind == GVPM_BSDF_ROUGHCONDUCTOR);
     if (st == 1u || st == 2u) {
       if (par->isSurfaceInteraction() && !glossy) {
         const BSDF *bsdf = par->getIntersection().getBSDF();

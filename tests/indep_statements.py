@@ -188,22 +188,60 @@ def set_bsdfs(table):
 
 
 def phong_world(kd, index, n, wi, wo):
-    """The modified Phong BRDF with both lobes, and the pdf of sampling it (Lafortune & Willems 1994, as src/bsdfs/phong.cpp
-    implements it), stated in WORLD space: f cos = (ks (e + 2) / 2pi max(r . wo, 0)^e + kd / pi) (n . wo),
-    pdf = w (e + 1) / 2pi max(r . wo, 0)^e + (1 - w) (n . wo) / pi, r = 2 (n . wi) n - wi; zero below the horizon.
-    Vectorised over rows; index: the rows' table entries.  Returns (f cos [k, 3], pdf [k], known [k])."""
+    """The table entries' BRDF (times the cosine) and the pdf of sampling it, stated in WORLD space, vectorised over rows;
+    index: the rows' table entries.  Returns (f cos [k, 3], pdf [k], known [k]).
+    Phong -- the modified Phong BRDF with both lobes (Lafortune & Willems 1994, as src/bsdfs/phong.cpp implements it):
+    f cos = (ks (e + 2) / 2pi max(r . wo, 0)^e + kd / pi) (n . wo), pdf = w (e + 1) / 2pi max(r . wo, 0)^e + (1 - w) (n . wo) / pi,
+    r = 2 (n . wi) n - wi.  Rough conductor -- the Torrance-Sparrow microfacet BRDF (Walter et al. 2007, as
+    src/bsdfs/roughconductor.cpp + microfacet.h implement it, isotropic): f cos = F D G / (4 n . wi) with the half vector
+    h = (wi + wo) / |wi + wo|, D Beckmann or GGX in their textbook forms, G = G1(wi) G1(wo) (Beckmann: Walter's rational fit),
+    F the unpolarised Fresnel reflectance of a complex index eta + i k computed with COMPLEX arithmetic; pdf = D (n . h) / (4 |wo . h|)
+    (all normals) or D G1(wi) / (4 n . wi) (visible normals).  Zero below the horizon."""
     index = np.asarray(index)
     known = (index >= 0) & (index < BSDFS.size)
     b = BSDFS[np.where(known, index, 0).astype(np.int64)] if BSDFS.size else np.zeros(index.shape, abi.BSDF_DTYPE)
     ks, e, w = b["specular"].astype(np.float64), b["exponent"].astype(np.float64), b["specular_sampling_weight"].astype(np.float64)
     ci, co = (n * wi).sum(-1), (n * wo).sum(-1)
+    up = (ci > 0) & (co > 0)
+    # Phong rows
     r = 2.0 * ci[..., None] * n - wi
     a = np.maximum((r * wo).sum(-1), 0.0)
-    with np.errstate(invalid="ignore", divide="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
         lobe = np.where(a > 0, a ** e, 0.0)
-    up = (ci > 0) & (co > 0)
-    f = (ks * ((e + 2.0) / (2.0 * np.pi) * lobe)[..., None] + kd / np.pi) * co[..., None]
-    pdf = w * (e + 1.0) / (2.0 * np.pi) * lobe + (1.0 - w) * co / np.pi
+        f = (ks * ((e + 2.0) / (2.0 * np.pi) * lobe)[..., None] + kd / np.pi) * co[..., None]
+        pdf = w * (e + 1.0) / (2.0 * np.pi) * lobe + (1.0 - w) * co / np.pi
+        # rough conductor rows
+        cond = b["kind"] == abi.GVPM_BSDF_ROUGHCONDUCTOR
+        if np.any(cond):
+            al = e  # (the field carries alpha)
+            h = wi + wo
+            h = h / np.linalg.norm(h, axis=-1, keepdims=True)
+            ch, wih, woh = (n * h).sum(-1), (wi * h).sum(-1), (wo * h).sum(-1)
+            ggx = b["distribution"] == abi.GVPM_MICROFACET_GGX
+            c2 = ch * ch
+            t2 = (1.0 - c2) / c2
+            D = np.where(ggx, al * al / (np.pi * (c2 * (al * al - 1.0) + 1.0) ** 2), np.exp(-t2 / (al * al)) / (np.pi * al * al * c2 * c2))
+            D = np.where((ch > 0) & (D * ch >= 1e-20), D, 0.0)
+
+            def g1(cv, vh):
+                tan = np.sqrt(np.maximum(1.0 - cv * cv, 0.0)) / np.abs(cv)
+                aa = 1.0 / (al * tan)
+                beck = np.where(aa >= 1.6, 1.0, (3.535 * aa + 2.181 * aa * aa) / (1.0 + 2.276 * aa + 2.577 * aa * aa))
+                g = np.where(ggx, 2.0 / (1.0 + np.sqrt(1.0 + (al * tan) ** 2)), beck)
+                g = np.where(tan == 0, 1.0, g)
+                return np.where(vh * cv > 0, g, 0.0)
+
+            g1i, g1o = g1(ci, wih), g1(co, woh)
+            nn = b["eta"].astype(np.float64) + 1j * b["k"].astype(np.float64)          # complex index, per channel
+            cth = wih[..., None].astype(np.complex128)
+            root = np.sqrt(nn * nn - (1.0 - cth * cth))
+            rs = (cth - root) / (cth + root)
+            rp = (nn * nn * cth - root) / (nn * nn * cth + root)
+            F = 0.5 * (np.abs(rs) ** 2 + np.abs(rp) ** 2)
+            fc = ks * F * (D * g1i * g1o / (4.0 * ci))[..., None]
+            pc = np.where(b["sample_visible"] != 0, D * g1i / (4.0 * ci), D * ch / (4.0 * np.abs(woh)))
+            f = np.where(cond[..., None], fc, f)
+            pdf = np.where(cond, pc, pdf)
     return np.where(up[..., None], f, 0.0), np.where(up, pdf, 0.0), known
 
 

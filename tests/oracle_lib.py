@@ -332,6 +332,30 @@ def phong_sample(bsdf, n, wi, u1, u2):
     return wo if ok else None
 
 
+def bsdf_eval_pdf(bsdf, kd, n, wi, wo):
+    """eval (x cos) and pdf of one table entry whatever its kind (glossyEvalPdf), world-space unit vectors"""
+    L = lib()
+    L.oracle_bsdf_eval_pdf.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    b = np.ascontiguousarray(np.atleast_1d(bsdf), abi.BSDF_DTYPE)
+    a = [np.ascontiguousarray(x, np.float64) for x in (kd, n, wi, wo)]
+    f, pdf = np.zeros(3), np.zeros(1)
+    L.oracle_bsdf_eval_pdf(b.ctypes.data, *[x.ctypes.data for x in a], f.ctypes.data, pdf.ctypes.data)
+    return f, float(pdf[0])
+
+
+def roughconductor_sample(bsdf, n, wi, u1, u2):
+    """RoughConductor::sample without visible-normal sampling: (wo, weight[3], pdf), or None"""
+    L = lib()
+    L.oracle_roughconductor_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+    b = np.ascontiguousarray(np.atleast_1d(bsdf), abi.BSDF_DTYPE)
+    n, wi = np.ascontiguousarray(n, np.float64), np.ascontiguousarray(wi, np.float64)
+    wo, wgt, pdf = np.zeros(3), np.zeros(3), np.zeros(1)
+    ok = L.oracle_roughconductor_sample(b.ctypes.data, n.ctypes.data, wi.ctypes.data, float(u1), float(u2), wo.ctypes.data,
+                                        wgt.ctypes.data, pdf.ctypes.data)
+    return (wo, wgt, float(pdf[0])) if ok else None
+
+
 def gather_primal_bre(params, medium, tris, photons, rays, radius, it=1, nb_paths=1, precision=64, use_accel=True, threads=0,
                       accum=None):
     """One iteration of the primal sppm integrator's volumePhotonPassBRE (oracle/gvpm_oracle_primal.hpp).

@@ -58,9 +58,9 @@ def test_the_hosts_phong_bounce_is_weight_times_pdf_equals_eval():
         assert np.allclose(fo, f[k], rtol=1e-12) and abs(po - pdf[k]) < 1e-12 * pdf[k]
 
 
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor"])
 def test_bre3d_all_27_accumulators(scene):
-    c = cases.make_case(scene, 20, 16, 6000, 4.0)
+    c = cases.make_case(scene, 20, 16, 6000 if scene != "cbox_conductor" else 20000, 4.0)
     cnt = compare(c)
     assert cnt["diffuse_shifts"] > 300
     # without the table the same photons fail their shifts -- the state of affairs before round 4
@@ -79,14 +79,16 @@ def test_bre3d_flags(kw):
 
 
 @pytest.mark.parametrize("tech", TECHS)
-def test_beams_all_27_accumulators(tech):
-    c = make_beam_case("cbox_phong", 12, 10, 600, 5.0, technique=tech)
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_conductor"])
+def test_beams_all_27_accumulators(tech, scene):
+    c = make_beam_case(scene, 12, 10, 600 if scene == "cbox_phong" else 1500, 5.0, technique=tech)
     assert ((c.beams.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 30
     compare_beams(c)
 
 
-def test_vpm_all_27_accumulators():
-    c = make_vpm_case("cbox_phong", 12, 10, 6000, 8.0, 6)
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_conductor"])
+def test_vpm_all_27_accumulators(scene):
+    c = make_vpm_case(scene, 12, 10, 6000 if scene == "cbox_phong" else 20000, 8.0, 6)
     ref, rsv, rnv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=True)
     acc, icnt, mvol = I.vpm_full(c)
     assert cnt["evaluations"] > 300
@@ -141,6 +143,111 @@ def test_phong_sampling_matches_its_pdf_chi_square():
         o, e = o[order], e[order]
         cum = np.cumsum(e)
         k = int(np.searchsorted(cum, 5.0)) + 1
+        o = np.concatenate([[o[:k].sum()], o[k:]])
+        e = np.concatenate([[e[:k].sum()], e[k:]])
+        chi2 = ((o - e) ** 2 / e).sum()
+        pval = 1 - stats.chi2.cdf(chi2, df=e.size - 1)
+        assert pval > alpha, (wi, chi2, pval)
+
+
+# ---- the table's second kind: the rough conductor (src/bsdfs/roughconductor.cpp + microfacet.h, isotropic Beckmann / GGX) ----
+def test_the_conductor_scene_and_its_table():
+    c = cases.make_case("cbox_conductor", 20, 16, 20000, 4.0)
+    assert c.bsdfs.size == 2 and (c.bsdfs["kind"] == abi.GVPM_BSDF_ROUGHCONDUCTOR).all()
+    assert list(c.bsdfs["distribution"]) == [abi.GVPM_MICROFACET_BECKMANN, abi.GVPM_MICROFACET_GGX] and not c.bsdfs["sample_visible"].any()
+    gl = (c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF
+    assert gl.sum() > 800 and set(np.unique(c.ph.parent_g[gl])) == {0.0, 1.0}
+    assert (((c.ph.flags[gl] >> 2) & 7) == 1).all()          # roughness alpha = 0.3 / 0.2 > bounceRoughness: diffuse shifts
+    assert set(np.unique(c.ph.flags[gl] >> 16)) == {0x8}     # one component: EGlossyReflection
+
+
+def test_the_hosts_conductor_bounce_is_weight_times_pdf_equals_eval():
+    """as for Phong above: flux = prefix * (f cos / pdf) * rr * (Tr / edgePdf) with RoughConductor::sample's weight = eval / pdf
+    (roughconductor.cpp:321-365, sampleVisible = false) -- against the INDEPENDENT statement (textbook D and G, complex Fresnel)"""
+    c = cases.make_case("cbox_conductor", 20, 16, 20000, 4.0)
+    gl = np.flatnonzero((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF)[:600]
+    d = c.ph.pos[gl].astype(np.float64) - c.ph.parent_pos[gl]
+    ln = np.linalg.norm(d, axis=1)
+    wo = d / ln[:, None]
+    f, pdf, known = I.phong_world(c.ph.parent_scat[gl].astype(np.float64), c.ph.parent_g[gl].astype(np.int64),
+                                  c.ph.parent_n[gl].astype(np.float64), c.ph.parent_wi[gl].astype(np.float64), wo)
+    assert known.all() and (pdf > 0).all()
+    assert np.allclose(pdf, c.ph.parent_pdf[gl] * ln * ln, rtol=4e-4)
+    tr = np.exp(-float(c.m.sigma_t[0]) * ln)
+    want = c.ph.prefix_w[gl] * (f / pdf[:, None]) * c.ph.parent_rr[gl][:, None] * (tr / c.ph.edge_pdf[gl])[:, None]
+    assert np.allclose(c.ph.flux[gl], want, rtol=6e-4)
+    for k in range(0, 600, 30):
+        fo, po = O.bsdf_eval_pdf(c.bsdfs[int(c.ph.parent_g[gl][k])], c.ph.parent_scat[gl][k], c.ph.parent_n[gl][k],
+                                 c.ph.parent_wi[gl][k], wo[k])
+        assert np.allclose(fo, f[k], rtol=1e-11) and abs(po - pdf[k]) < 1e-11 * pdf[k]
+
+
+@pytest.mark.parametrize("distribution", [abi.GVPM_MICROFACET_BECKMANN, abi.GVPM_MICROFACET_GGX])
+@pytest.mark.parametrize("visible", [0, 1])
+def test_conductor_statements_agree_over_the_hemisphere(distribution, visible):
+    """oracle restatement (local frame, the reference's operations) == independent statement (world space, textbook forms,
+    complex Fresnel) for random directions, both pdf forms, grazing angles included"""
+    b = np.zeros(1, abi.BSDF_DTYPE)
+    b["kind"], b["specular"], b["exponent"] = abi.GVPM_BSDF_ROUGHCONDUCTOR, (0.9, 0.8, 1.0), 0.15
+    b["distribution"], b["sample_visible"], b["eta"], b["k"] = distribution, visible, (0.2, 0.92, 1.1), (3.9, 2.45, 2.14)
+    I.set_bsdfs(b)
+    rng = np.random.default_rng(3)
+    nrm = rng.normal(size=3)
+    nrm /= np.linalg.norm(nrm)
+    worst = 0.0
+    for _ in range(400):
+        v = rng.normal(size=(2, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        v = np.where((v @ nrm)[:, None] < 0, -v, v) if rng.random() < 0.9 else v   # (some pairs below the horizon)
+        f, pdf, _ = I.phong_world(np.zeros((1, 3)), np.zeros(1, np.int64), nrm[None, :], v[0][None, :], v[1][None, :])
+        fo, po = O.bsdf_eval_pdf(b[0], np.zeros(3), nrm, v[0], v[1])
+        assert np.allclose(fo, f[0], rtol=1e-10, atol=1e-300) and abs(po - pdf[0]) <= 1e-10 * abs(pdf[0])
+        worst = max(worst, float(pdf[0]))
+    assert worst > 1.0  # (the lobe was met)
+
+
+@pytest.mark.parametrize("distribution", [abi.GVPM_MICROFACET_BECKMANN, abi.GVPM_MICROFACET_GGX])
+def test_conductor_sampling_matches_its_pdf_chi_square(distribution):
+    """src/tests/test_chisquare.cpp (test01_BSDF) as it runs for the roughconductor instances of data/tests/test_bsdf.xml, here
+    with sampleVisible = false: the histogram of RoughConductor::sample over 10 x 20 (theta, phi) bins against the integral of
+    RoughConductor::pdf; and the returned weight IS eval / pdf."""
+    from scipy import stats
+    b = np.zeros(1, abi.BSDF_DTYPE)
+    b["kind"], b["specular"], b["exponent"] = abi.GVPM_BSDF_ROUGHCONDUCTOR, 1.0, 0.25
+    b["distribution"], b["eta"], b["k"] = distribution, (0.2, 0.92, 1.1), (3.9, 2.45, 2.14)
+    I.set_bsdfs(b)
+    n = np.array([0.0, 0.0, 1.0])
+    rng = np.random.default_rng(17)
+    theta_bins, phi_bins, n_wi, n_samples = 10, 20, 6, 30000
+    alpha = 1.0 - (1.0 - 0.01) ** (1.0 / n_wi)
+    for _ in range(n_wi):
+        z = 0.1 + 0.9 * rng.random()
+        ph = 2 * np.pi * rng.random()
+        wi = np.array([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z])
+        res = [O.roughconductor_sample(b[0], n, wi, *rng.random(2)) for _ in range(n_samples)]
+        lost = sum(r is None for r in res)
+        wo = np.array([r[0] for r in res if r is not None])
+        for r in [r for r in res if r is not None][:50]:
+            fo, po = O.bsdf_eval_pdf(b[0], np.zeros(3), n, wi, r[0])
+            assert abs(po - r[2]) < 1e-9 * po and np.allclose(fo / po, r[1], rtol=1e-9)
+        theta = np.arccos(np.clip(wo[:, 2], -1, 1))
+        phi = np.arctan2(wo[:, 1], wo[:, 0]) % (2 * np.pi)
+        obs, _, _ = np.histogram2d(theta, phi, bins=[theta_bins, phi_bins], range=[[0, np.pi], [0, 2 * np.pi]])
+        sub = 16
+        th = (np.arange(theta_bins * sub) + 0.5) * (np.pi / (theta_bins * sub))
+        phs = (np.arange(phi_bins * sub) + 0.5) * (2 * np.pi / (phi_bins * sub))
+        T, Pm = np.meshgrid(th, phs, indexing="ij")
+        dirs = np.stack([np.sin(T) * np.cos(Pm), np.sin(T) * np.sin(Pm), np.cos(T)], -1).reshape(-1, 3)
+        _, pdf, _ = I.phong_world(np.zeros((1, 3)), np.zeros(len(dirs), np.int64), np.broadcast_to(n, dirs.shape),
+                                  np.broadcast_to(wi, dirs.shape), dirs)
+        pdf = pdf.reshape(theta_bins * sub, phi_bins * sub)
+        cell = np.sin(T) * (np.pi / (theta_bins * sub)) * (2 * np.pi / (phi_bins * sub))
+        exp_ = (pdf * cell).reshape(theta_bins, sub, phi_bins, sub).sum((1, 3)) * n_samples
+        assert abs(exp_.sum() - (n_samples - lost)) < 5 * np.sqrt(n_samples) + 0.01 * n_samples
+        o, e = obs.ravel(), exp_.ravel()
+        order = np.argsort(e)
+        o, e = o[order], e[order]
+        k = int(np.searchsorted(np.cumsum(e), 5.0)) + 1
         o = np.concatenate([[o[:k].sum()], o[k:]])
         e = np.concatenate([[e[:k].sum()], e[k:]])
         chi2 = ((o - e) ** 2 / e).sum()

@@ -17,7 +17,7 @@ from test_parity_vpm_gpu import device_vpm
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor"])
 @pytest.mark.parametrize("kw", [dict(), dict(vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0), dict(use_mis=0), dict(power_heuristic=1)])
 def test_bre_matches_fp64_oracle(scene, kw):
     c = cases.make_case(scene, 40, 36, 30000, 2.5, **kw)
@@ -25,6 +25,18 @@ def test_bre_matches_fp64_oracle(scene, kw):
     assert gl > 1000
     acc, ref, st = check(c)
     assert st["evaluations"] > 10000 and st["diffuse_shifts"] > 10000
+
+
+def test_conductor_with_visible_normal_pdf():
+    """the pdf's other form (m_sampleVisible = true, Mitsuba's default): D G1(wi) / (4 cos_i)"""
+    c = cases.make_case("cbox_conductor", 40, 36, 30000, 2.5)
+    c.bsdfs = c.bsdfs.copy()
+    c.bsdfs["sample_visible"] = 1
+    O.set_bsdfs(c.bsdfs)
+    acc, ref, st = check(c)
+    c2 = cases.make_case("cbox_conductor", 40, 36, 30000, 2.5)  # (sets the scene's own table again)
+    ref2, _, _ = O.gather_bre(c2.p, c2.m, c2.tris, c2.ph, c2.rays, c2.r, c2.it, c2.nb, 64, use_accel=False)
+    assert l2(ref2, ref, ref[..., 0:3].mean()) > 1e-5  # (the MIS weights see the other pdf)
 
 
 def test_the_glossy_lobe_matters_and_a_missing_table_fails_the_shifts():
@@ -70,7 +82,7 @@ def test_unsupported_table_entries_are_refused():
 
 
 @pytest.mark.parametrize("tech", TECHS)
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor"])
 def test_beams_match_fp64_oracle(tech, scene):
     c = make_beam_case(scene, 32, 28, 12000, 2.5, technique=tech)
     assert ((c.beams.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 500
@@ -78,13 +90,14 @@ def test_beams_match_fp64_oracle(tech, scene):
     assert st["evaluations"] > 20000 and st["diffuse_shifts"] > 5000
 
 
-def test_beams_fp64_transcription_agrees(monkeypatch):
-    c = make_beam_case("cbox_phong", 24, 20, 6000, 3.0)
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_conductor"])
+def test_beams_fp64_transcription_agrees(monkeypatch, scene):
+    c = make_beam_case(scene, 24, 20, 6000, 3.0)
     monkeypatch.setenv("GVPM_BEAMS_FP64", "1")
     device_beams(c)
 
 
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor"])
 def test_vpm_matches_fp64_oracle(scene):
     c = make_vpm_case(scene, 32, 28, 40000, 5.0, nb=10)
     assert ((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 1000

@@ -120,6 +120,12 @@ def test_every_citation_names_a_file_of_the_reference():
     ("include/mitsuba/bidir/mempool.h", ["allocVertex"]),
     ("src/integrators/photonmapper/gvpm/gvpm_geoOps.h", ["fastGOp"]),
     ("src/integrators/photonmapper/beams_struct.h", ["getOri()", "getDir()", "getPos("]),
+    ("src/bsdfs/microfacet.h", ["MicrofacetDistribution(const Properties &props", "isIsotropic", "getAlphaU", "getSampleVisible",
+                                "getType()", "EBeckmann", "EGGX"]),
+    ("src/bsdfs/ior.h", ["inline Float lookupIOR(const Properties &props"]),
+    ("include/mitsuba/core/cobject.h", ["getProperties"]),
+    ("include/mitsuba/core/properties.h", ["hasProperty", "getSpectrum"]),
+    ("src/bsdfs/roughconductor.cpp", ["class RoughConductor", "props.getSpectrum(\"eta\", intEta) / extEta"]),
 ])
 def test_members_the_bridge_touches_exist_in_the_reference(header, members):
     if not os.path.isdir(REF):
@@ -131,4 +137,6 @@ def test_members_the_bridge_touches_exist_in_the_reference(header, members):
         assert token in SHIM or m in ("size()", "operator[]", "MemoryPool pool", "struct GPMThreadData", "const Path *path",
                                       "struct GPhotonNodeData", "struct LTPhotonBeam", "normalize()", "append(", "struct ShiftRecord",
                                       "Float det(const Path &path, int b, int c)", "class MTS_EXPORT_RENDER PerspectiveCamera",
-                                      "PathVertex *clone(MemoryPool &pool) const", "PathEdge *clone(MemoryPool &pool) const"), (header, m)
+                                      "PathVertex *clone(MemoryPool &pool) const", "PathEdge *clone(MemoryPool &pool) const",
+                                      "MicrofacetDistribution(const Properties &props", "inline Float lookupIOR(const Properties &props",
+                                      "class RoughConductor", "props.getSpectrum(\"eta\", intEta) / extEta"), (header, m)
