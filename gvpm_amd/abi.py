@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-GVPM_ABI_VERSION = 1
+GVPM_ABI_VERSION = 2
 
 # gvpm_status
 GVPM_OK = 0

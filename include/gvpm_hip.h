@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GVPM_ABI_VERSION 1
+#define GVPM_ABI_VERSION 2  /* 2: gvpm_bsdf grew to 64 bytes (rough conductor), round 4 */
 
 /* ---- status codes --------------------------------------------------------*/
 typedef enum gvpm_status {
