@@ -326,6 +326,9 @@ struct gvpm_context {
   bool haveCachedBounds = false, boundsPending = false;
   float *pinB6 = nullptr;      // pinned host staging: 6 floats + 2 uint32
   uint32_t *pinCtl = nullptr;
+  uint32_t vpmOrderN = 0;      // batches the G-VPM order in blockValB was sorted for (0: none)
+  uint32_t vpmLaunches = 0;
+  bool vpmNoOrder = false;     // GVPM_VPM_ORDER=0
   float *pinBeams = nullptr;   // the G-Beams driver's: 2 x 6 bounds (floats 0-5, 8-13), counters (uint32 from float 16 on)
 
   // camera beams

@@ -152,6 +152,11 @@ struct GatherArgs {
   uint32_t nsamples;
   const float *scaleVol;     // per pixel GatherPoint::scaleVol (read)
   float *mvol;               // per pixel photons found this iteration (MVol, atomically added)
+  // the order the waves take the 64-sample batches in: heaviest first, by the candidate counts of the LAST launch (the batches
+  // hold the same pixels every iteration); null: in order.  vpmCostKey / vpmCostVal: this launch's {0xFFFFF - candidates, batch}
+  const uint32_t *vpmOrder;
+  uint32_t vpmOrderN;        // entries of vpmOrder (a permutation of the last launch's batches; the counts may differ a little)
+  uint32_t *vpmCostKey, *vpmCostVal;
   // outputs
   float *iter;               // P * 27: this iteration's un-normalised sums (G-BRE: the running SUM over iterations)
   float iterScale;           // G-BRE: 1 / nb_paths of this iteration, applied when a partial sum is added

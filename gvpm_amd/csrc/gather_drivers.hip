@@ -354,6 +354,9 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.nbeams = 0;
   a.bsdfs = h->bsdfs.p;
   a.nbsdfs = h->nbsdfs;
+  a.vpmOrder = nullptr;
+  a.vpmOrderN = 0;
+  a.vpmCostKey = a.vpmCostVal = nullptr;
 }
 
 static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, int phase = 0) {
@@ -953,9 +956,27 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     h->reqOutstanding = true;
     h->reqBeams = false;
   }
+  // Heaviest batches first.  A wave's time follows its candidate count (correlation 0.99, scripts/vpm_timing.py) and the
+  // counts are heavy-tailed (C1: median 159, maximum 6 500 -- the pixels that look at the light): in sample order the last
+  // heavy wave started when the others were done, and the kernel ran 160 of its 560 us on a handful of waves.  The batches
+  // hold the same pixels every iteration, so the last launch's counts order this one.
+  const uint32_t nBatches = (h->nsamples + 63u) / 64u;
+  for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nBatches + 1));
+  a.vpmCostKey = h->blockKeyA.p;
+  a.vpmCostVal = h->blockValA.p;
+  // (a launch of another size: the permutation's slots, then the batches it does not know, in order; see the kernel)
+  const bool haveOrder = h->vpmOrderN != 0 && !h->vpmNoOrder && h->vpmOrderN <= 2u * nBatches && nBatches <= 2u * h->vpmOrderN;
+  a.vpmOrder = haveOrder ? h->blockValB.p : nullptr;
+  a.vpmOrderN = haveOrder ? h->vpmOrderN : 0u;
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   launch_gather_vpm(a, needFullVis(h), primal, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  // (re-sorted every fourth launch: the heavy pixels stay where they are while the radii shrink)
+  if (!h->vpmNoOrder && nBatches > 1024u && (!haveOrder || (h->vpmLaunches & 3u) == 0u)) {
+    HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBatches, 20, h->stream));
+    h->vpmOrderN = nBatches;
+  }
+  h->vpmLaunches++;
   launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->stream);
   launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
   HIP_TRY(h, hipGetLastError());

@@ -102,7 +102,7 @@ __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s,
 __device__ __forceinline__ void vpmAdd(const GatherArgs &a, VpmLds &s, int k, uint32_t b, float v) {
   const uint32_t r = s.run[b];
   if (r < (uint32_t)VPM_RUNS) {
-    atomicAdd(&s.acc[k][r * VPM_SUB + (threadIdx.x & (VPM_SUB - 1))], (double)v);
+    atomicAdd(&s.acc[k][r * VPM_SUB + (threadIdx.x & (VPM_SUB - 1))], (double)v);  // (VPM_SUB divides 64)
   } else {
     const uint32_t pv = s.pix[b];
     atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v);
@@ -269,12 +269,45 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
 }
 
+// Waves per workgroup: they share nothing (an LDS slice each, wave-local synchronisation).  One wave per workgroup made the
+// C1 launch -- 39 k workgroups that live ~6 us each -- DISPATCH-bound: 0.44 resident waves per SIMD on average where registers
+// and LDS allow 3 (rocprofv3: SQ_WAVE_CYCLES / (SIMDs x kernel cycles)).
+#ifndef GVPM_VPM_WPB
+#define GVPM_VPM_WPB 1
+#endif
+constexpr int VPM_WPB = GVPM_VPM_WPB;
+#ifndef GVPM_VPM_SPW
+#define GVPM_VPM_SPW 64
+#endif
+constexpr uint32_t VPM_SPW = GVPM_VPM_SPW;  // camera samples per wave (<= 64: one per lane in the set-up phase)
+// LDS accesses of ONE wave are executed in order; what has to be stopped is the compiler moving them
+__device__ __forceinline__ void vpmWaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifdef GVPM_VPM_TIMING
+// probe builds only: per wave of the last launch {start, end (wall clock, 100 MHz), candidates, evaluations}
+__device__ unsigned long long gvpmVpmLog[4 * 65536];
+extern "C" int gvpm_debug_vpm_timing(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gvpmVpmLog), sizeof(gvpmVpmLog)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <bool FULLVIS, bool HS, bool PRIMAL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
-  __shared__ VpmLds s;
-  const int lane = threadIdx.x;
-  const uint32_t sBase = blockIdx.x * 64u;
-  const uint32_t ns = min(64u, a.nsamples - sBase);
+__global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
+  __shared__ VpmLds sAll[VPM_WPB];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  VpmLds &s = sAll[wv];
+  const uint32_t slot = blockIdx.x * (uint32_t)VPM_WPB + (uint32_t)wv;
+  // heaviest first (gatherVPM): slots below vpmOrderN take the permutation's batch, the others their own
+  const uint32_t batch = slot < a.vpmOrderN ? a.vpmOrder[slot] : slot;
+  const uint32_t sBase = batch * VPM_SPW;
+  if (sBase >= a.nsamples) return;  // (no workgroup barrier anywhere: the waves run independently)
+#ifdef GVPM_VPM_TIMING
+  const unsigned long long tw0 = wall_clock64();
+#endif
+  const uint32_t ns = min(VPM_SPW, a.nsamples - sBase);
   const float norm = 1.f / (float)a.cfg.nb_camera_samples;
   const float eps = a.cfg.epsilon;
 
@@ -310,7 +343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
     if (lane == 0) nRuns = min((uint32_t)__popcll(heads), (uint32_t)VPM_RUNS);
   }
   nRuns = __shfl(nRuns, 0, 64);
-  __syncthreads();
+  vpmWaveSync();
   const RayReg base = loadRayV(a, s, 0, lane);
   active = active && base.valid;
   // HomogeneousMedium::sampleDistance(Ray(o, d, Epsilon, beamDist), EDistanceAlwaysValid, rand),
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   s.pdfSel[lane] = pdfSel;
   s.trBase[lane] = trBase;
   s.radius[lane] = radius;
-  __syncthreads();
+  vpmWaveSync();
 
   // ---- cell box of the query sphere ----
   const d3 qD = tod(base.o) + tod(base.d) * t;
@@ -407,14 +440,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
   unsigned long long nCand = 0;
   auto drain = [&](uint32_t n) __attribute__((always_inline)) {  // phase 2 for the first n <= 64 queued reconnections
-    __syncthreads();
+    vpmWaveSync();
     if ((uint32_t)lane < n) {
       const uint2 e = s.rq[(rqHead + lane) % VRQ];
       vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail);
     }
     rqHead = (rqHead + n) % VRQ;
     rqCount -= n;
-    __syncthreads();
+    vpmWaveSync();
   };
   auto evalBatch = [&](bool valid, uint2 e) __attribute__((always_inline)) {  // phase 1 for one (photon, sample) pair per lane
     uint32_t qMask = 0u;
@@ -442,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
     uint32_t rcs[VPM_ROWS], res[VPM_ROWS];
 #pragma unroll
     for (int k = 0; k < VPM_ROWS; ++k) rowRange(r0 + k, rcs[k], res[k]);
-    __syncthreads();  // (the previous pass has read its offsets)
+    vpmWaveSync();  // (the previous pass has read its offsets)
     uint32_t cnt = 0;
 #pragma unroll
     for (int k = 0; k < VPM_ROWS; ++k) {
@@ -459,7 +492,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
     const uint32_t total = __shfl(inc, 63, 64);
     s.segOff[lane] = inc - cnt;
     if (lane == 63) s.segOff[64] = total;
-    __syncthreads();
+    vpmWaveSync();
     for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
       const uint32_t j = j0 + (uint32_t)lane;
       const bool have = j < total;
@@ -526,19 +559,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
         }
         qCount += __popcll(m);
         if (qCount >= 64u) {
-          __syncthreads();
+          vpmWaveSync();
           evalBatch(true, s.queue[(qHead + lane) % VQ]);
           qHead = (qHead + 64u) % VQ;
           qCount -= 64u;
-          __syncthreads();
+          vpmWaveSync();
         }
       }
     }
   }
-  __syncthreads();
+  vpmWaveSync();
   if (qCount) evalBatch((uint32_t)lane < qCount, s.queue[(qHead + lane) % VQ]);
   if (rqCount) drain(rqCount);
-  __syncthreads();
+  vpmWaveSync();
   // ---- write out ----
   // one global atomic per (run, value): per-sample atomics would put up to 64 operations on one address, and those
   // serialise in L2 (a run that overflowed VPM_RUNS has added to the film directly)
@@ -582,6 +615,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
       fa += __shfl_xor(fa, o, 64);
       ca += __shfl_xor(ca, o, 64);
     }
+#ifdef GVPM_VPM_TIMING
+    {
+      const uint32_t wid = batch;
+      if (lane == 0 && wid < 65536u) {
+        gvpmVpmLog[4 * wid] = tw0;
+        gvpmVpmLog[4 * wid + 1] = wall_clock64();
+        gvpmVpmLog[4 * wid + 2] = ca;
+        gvpmVpmLog[4 * wid + 3] = ev;
+      }
+    }
+#endif
+    if (lane == 0 && a.vpmCostKey) {
+      a.vpmCostKey[batch] = 0xFFFFFu - (uint32_t)min(ca, 0xFFFFFull);
+      a.vpmCostVal[batch] = batch;
+    }
     if (GVPM_VPM_PROBE != 3 && lane == 0 && (ev | ca)) {
       atomicAdd(&statRow(a)[0], ev);
       atomicAdd(&statRow(a)[1], ca);
@@ -621,18 +669,19 @@ __global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ acc
 
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream_t stream) {
   if (a.nsamples == 0) return;
-  const dim3 grid((a.nsamples + 63u) / 64u);
+  const uint32_t nwaves = max((a.nsamples + VPM_SPW - 1u) / VPM_SPW, a.vpmOrderN);
+  const dim3 grid((nwaves + (uint32_t)VPM_WPB - 1u) / (uint32_t)VPM_WPB);
   if (primal) {
     // the sppm integrator's point estimate: the walk and the rings of the gradient kernel, the primal term only
-    hipLaunchKernelGGL((gather_vpm_kernel<false, false, true>), grid, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((gather_vpm_kernel<false, false, true>), grid, dim3(64 * VPM_WPB), 0, stream, a);
   } else if (a.reqHost) {
     // manifold-typed shifts go to the host's request list (an instantiation of its own: the default one keeps its registers)
-    if (fullVis) hipLaunchKernelGGL((gather_vpm_kernel<true, true>), grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((gather_vpm_kernel<false, true>), grid, dim3(64), 0, stream, a);
+    if (fullVis) hipLaunchKernelGGL((gather_vpm_kernel<true, true>), grid, dim3(64 * VPM_WPB), 0, stream, a);
+    else hipLaunchKernelGGL((gather_vpm_kernel<false, true>), grid, dim3(64 * VPM_WPB), 0, stream, a);
   } else if (fullVis) {
-    hipLaunchKernelGGL((gather_vpm_kernel<true, false>), grid, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((gather_vpm_kernel<true, false>), grid, dim3(64 * VPM_WPB), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((gather_vpm_kernel<false, false>), grid, dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((gather_vpm_kernel<false, false>), grid, dim3(64 * VPM_WPB), 0, stream, a);
   }
 }
 

@@ -130,6 +130,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
   if (const char *e = getenv("GVPM_PLAN_BOXES")) h->planBoxHandOff = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
   if (const char *e = getenv("GVPM_BUNDLE")) {
     h->bundleEnabled = atoi(e) != 0;
     h->bundleFromEnv = true;

@@ -10,7 +10,7 @@ from gvpm_amd.host import SynthScene
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 sc = SynthScene("cbox", 256, 256)
-p = sc.params(); p.vol_technique = abi.GVPM_DISTANCE; p.nb_camera_samples = 40; p.initial_scale_volume = 4.0
+p = sc.params(); p.vol_technique = abi.GVPM_DISTANCE; p.nb_camera_samples = 40; p.initial_scale_volume = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
 m, tris = sc.medium(), sc.triangles()
 data = {it: (sc.shoot_photons(it, 100000), sc.camera_beams_and_vpm_samples(it, 40)) for it in range(1, iters + 2)}
 ctx = hip.Context(p, 0); ctx.upload_scene(*tris); ctx.upload_medium(m)
