@@ -1481,6 +1481,13 @@ struct alignas(16) BeamTravLds {
   uint16_t candq[BCQ];        // staged record | ray << 8
 };
 
+#ifdef GVPM_TRAV_TIMING
+// probe builds only: per wave of the last launch {start, end (wall clock, 100 MHz), items, candidates}
+__device__ unsigned long long gvpmBeamTravLog[4 * 8192];
+extern "C" int gvpm_debug_beamtrav_timing(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gvpmBeamTravLog), sizeof(gvpmBeamTravLog)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int B>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void traverse_beams_kernel(GatherArgs a, const uint32_t *__restrict__ hotFlags,
                                                             const uint4 *__restrict__ items,
@@ -1501,6 +1508,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
   const bool pathSet = a.cfg.path_set != 0;
   const int maxDepth = a.cfg.max_depth;
   unsigned long long nCand = 0;
+#ifdef GVPM_TRAV_TIMING
+  const unsigned long long tw0 = wall_clock64();
+  unsigned long long nIt = 0;
+#endif
   // Blocks of the pair list are reserved RESERVE at a time: atomics on one address retire at ~11 ns each on this
   // part whatever the number of waves (scripts/probes/atomics_bench.hip), so one atomic per block (~260 k per pass)
   // bounded the kernel at 3 ms.  What a wave has left over at the end is written as empty blocks of its last tile.
@@ -1518,6 +1529,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
     }
     firstItem = false;
     if (it >= nItems) break;
+#ifdef GVPM_TRAV_TIMING
+    nIt++;
+#endif
     const uint4 item = items[it];
     // a heavy item comes as `parts` items that take its staging windows round-robin (plan_kernel)
     const uint32_t setBase = item.x, nb = item.y & 0xFFu, part = (item.y >> 8) & 0xFFFu, parts = max(item.y >> 20, 1u);
@@ -1752,6 +1766,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
     }
   }
   if (lane == 0 && nCand) atomicAdd(&statRow(a)[1], nCand);
+#ifdef GVPM_TRAV_TIMING
+  if (lane == 0 && blockIdx.x < 8192u) {
+    gvpmBeamTravLog[4 * blockIdx.x] = tw0;
+    gvpmBeamTravLog[4 * blockIdx.x + 1] = wall_clock64();
+    gvpmBeamTravLog[4 * blockIdx.x + 2] = nIt;
+    gvpmBeamTravLog[4 * blockIdx.x + 3] = nCand;
+  }
+#endif
 }
 
 // ---- evaluation, literal fp64 path (GVPM_BEAMS_FP64=1: the on-device cross-check) ------------------------------
