@@ -144,7 +144,8 @@ static Grid bundleCells(const gvpm_context *h, float r, int tileW) {
   return g;
 }
 
-static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force3D = false) {
+// knownB6 (optional): the photons' bounds, already on the host (the caller read them back with something else)
+static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force3D = false, const float *knownB6 = nullptr) {
   const uint32_t n = h->nph;
   h->boundsPending = false;
   if (n == 0) {
@@ -162,9 +163,14 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   const bool defer = deferred && h->haveCachedBounds;
-  launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, defer ? h->pinB6 : nullptr,
-                h->bstream);
-  if (defer) {
+  if (!knownB6)
+    launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, defer ? h->pinB6 : nullptr,
+                  h->bstream);
+  if (knownB6) {
+    memcpy(b6, knownB6, sizeof(b6));
+    memcpy(h->cachedB6, b6, sizeof(b6));
+    h->haveCachedBounds = true;
+  } else if (defer) {
     h->boundsPending = true;
     memcpy(b6, h->cachedB6, sizeof(b6));
   } else {
@@ -270,10 +276,13 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   HIP_TRY(h, hipGetLastError());
   h->nearOverflow = false;
   if (!deferred && h->cfg.visibility_as_written) {
-    uint32_t over = 0;
-    HIP_TRY(h, hipMemcpyAsync(&over, h->bs->overflowCtr.p, 4, hipMemcpyDeviceToHost, h->bstream));
+    if (!h->pinB6) {
+      HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+      h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
+    }
+    launch_export_u32(h->bs->overflowCtr.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->bstream);
     HIP_TRY(h, hipStreamSynchronize(h->bstream));
-    h->nearOverflow = over != 0;
+    h->nearOverflow = h->pinCtl[0] != 0;
   }
   return GVPM_OK;
 }
@@ -918,14 +927,26 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   if (!h->haveSamples) return fail(h, GVPM_ERR_STATE, "G-VPM gather needs gvpm_upload_vpm_samples");
   if (h->cfg.nb_camera_samples <= 0) return fail(h, GVPM_ERR_INVALID_ARG, "nb_camera_samples must be positive");
   // grid cell = the largest per-pixel radius R * 0.01 * max(scaleVol)
-  uint32_t bits = 0;
-  HIP_TRY(h, hipMemcpyAsync(&bits, h->maxScaleBits.p, 4, hipMemcpyDeviceToHost, h->stream));
+  // ONE host round trip for the largest radius and the photons' bounds (each was a D2H copy + a wait of its own: ~30 us of
+  // an idle GPU, and C1's step is 0.6 ms): the kernels write them into pinned memory
+  if (!h->pinB6) {
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+    h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
+  }
+  const bool wantBounds = h->photonsDirty && h->nph > 0;
+  if (wantBounds) {
+    HIP_TRY(h, h->bs->boundsPartial.ensure(1024 * 6));
+    HIP_TRY(h, h->bs->bounds6.ensure(32));
+    launch_bounds(h->rawDev.pos, h->nph, h->bs->boundsPartial.p, 1024, h->bs->bounds6.p, h->pinB6, h->stream);
+  }
+  launch_export_u32(h->maxScaleBits.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const uint32_t bits = h->pinCtl[0];
   float maxScale;
   memcpy(&maxScale, &bits, 4);
   const float rmax = (h->cfg.bsphere_radius * 0.01f) * maxScale;
   if (h->photonsDirty || rmax != h->bs->builtRadius) {
-    int rc = buildGrid(h, rmax);
+    int rc = buildGrid(h, rmax, false, false, wantBounds ? h->pinB6 : nullptr);
     if (rc != GVPM_OK) return rc;
     h->photonsDirty = false;
     h->bs->builtRadius = rmax;
