@@ -697,6 +697,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
 // computeVolumeGradientBeams, gvpm.cpp:880-986
 static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal = false) {
   if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
+  h->vpmOrderN = 0;  // (the block-sort buffers below also hold G-VPM's batch order)
   const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
   // phases as for G-BRE (gvpm_get_phase_time): 2 = build (sub-beam grid, beam records, camera-beam sort, near lists),
   // 1 = plan + traversal, 0 = the evaluation (block sort + evaluate_beams2_kernel)
@@ -982,6 +983,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   // heavy wave started when the others were done, and the kernel ran 160 of its 560 us on a handful of waves.  The batches
   // hold the same pixels every iteration, so the last launch's counts order this one.
   const uint32_t nBatches = (h->nsamples + 63u) / 64u;
+  if (h->blockValB.cap < (size_t)nBatches + 1) h->vpmOrderN = 0;  // (a regrown buffer has lost the order)
   for (DevBuf<uint32_t> *b : {&h->blockKeyA, &h->blockKeyB, &h->blockValA, &h->blockValB}) HIP_TRY(h, b->ensure(nBatches + 1));
   a.vpmCostKey = h->blockKeyA.p;
   a.vpmCostVal = h->blockValA.p;

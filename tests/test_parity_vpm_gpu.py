@@ -115,3 +115,36 @@ def test_vpm_sample_orderings():
     lum = max(ctx_ref[1][..., 0:3].mean(), 1e-30)
     assert st["evaluations"] == ctx_ref[2]["evaluations"]
     assert l2(acc, ctx_ref[1], lum) < TOL
+
+
+def test_heaviest_first_batch_order_changes_nothing(monkeypatch):
+    """Round 4: the waves take their 64-sample batches in the order of the LAST launch's candidate counts (gatherVPM,
+    re-sorted every fourth launch; above 1024 batches).  Sample sets of different sizes from one iteration to the next --
+    more, fewer, and a regrown buffer -- must give what sample order gives: the oracle's evaluations, the same sums."""
+    c = make_vpm_case("cbox", 64, 48, 30000, 4.0, nb=36)
+    assert c.samples.shape[0] > 1024 * 64
+    n = c.samples.shape[0]
+
+    def run():
+        ctx = hip.Context(c.p, device=0)
+        ctx.upload_scene(*c.tris)
+        ctx.upload_medium(c.m)
+        ctx.upload_photons(c.ph)
+        ctx.upload_camera_beams(c.rays)
+        out = []
+        for k, m in enumerate([n * 2 // 3, n * 2 // 3 + 64 * 7 + 5, n // 2, n, n - 1000, n, n, n, n]):
+            ctx.upload_vpm_samples(c.samples[:m])
+            ctx.gather(k + 1, c.nb)
+            out.append(ctx.stats()["evaluations"])
+        acc = ctx.download_accum().astype(np.float64)
+        st = ctx.stats()
+        ctx.close()
+        return acc, st, out
+
+    a1, s1, e1 = run()
+    monkeypatch.setenv("GVPM_VPM_ORDER", "0")
+    a0, s0, e0 = run()
+    assert e1 == e0 and s1["evaluations"] > 50000
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert s1[k] == s0[k], (k, s1, s0)
+    assert np.abs(a1 - a0).max() <= 2e-5 * np.abs(a0).max()  # (the order of the atomics)
