@@ -144,7 +144,8 @@ struct GatherArgs {
   const uint32_t *origIdx;  // sorted photon -> index in the upload
   uint32_t *bundleFlag;  // set by the planner when a valid ray is outside the bundle the grid (mode 1) was built for
   const float2 *beamClear;   // per beam {cosA0, M1}: the free cone of its reconnections (grid_build.hip, beam_near_kernel)
-  // glossy surface parents (gvpm_upload_bsdfs): 2 float4 per entry {kind, specular} {exponent, sampling weight, -, -}
+  // glossy surface parents (gvpm_upload_bsdfs): 4 float4 per entry {kind, specular} {exponent | alpha, sampling weight,
+  // distribution, sample_visible} {eta, k.x} {k.y, k.z, -, -}
   const float4 *bsdfs;
   uint32_t nbsdfs;
   // G-VPM only
