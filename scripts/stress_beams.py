@@ -1,0 +1,19 @@
+import os, sys
+sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+import numpy as np
+from test_oracle_beams import make_beam_case
+from test_parity_beams_gpu import device_beams
+from gvpm_amd import abi
+n = 0
+for scene in ("laser", "cbox", "fogroom"):
+    for tech in (abi.GVPM_BEAM_BEAM_3D_OPTIMIZED, abi.GVPM_BEAM_BEAM_1D):
+        for kw in (dict(use_shift_null=0), dict(use_shift_null=0, path_set=0), dict(path_set=0, max_depth=4), dict()):
+            for fc in ("1", "0"):
+                os.environ["GVPM_BEAMS_FREE_CONE"] = fc
+                if tech == abi.GVPM_BEAM_BEAM_1D and "use_shift_null" in kw:
+                    kw = {k: v for k, v in kw.items() if k != "use_shift_null"}
+                c = make_beam_case(scene, 40, 32, 9000, 3.0, technique=tech, **kw)
+                acc, ref, st = device_beams(c)
+                n += 1
+                print(scene, tech, kw, fc, st["evaluations"], st["diffuse_shifts"], st["failed_shifts"], flush=True)
+print("cases", n)
