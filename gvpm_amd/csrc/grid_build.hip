@@ -571,39 +571,49 @@ hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uin
 // plane-major float4 arrays of round 1 cost nine):
 //   0 {flux, parentPdf} 1 {p1, parentRR} 2 {parentN, parentG} 3 {prefixW, near0} 4 {parentScat, near1}
 //   5 {parentWi, near2} 6 {p2, bits} 7 {endN, length}   (near0..2: beam_near_kernel)
-__global__ __launch_bounds__(256) void beam_cold_kernel(RawPhotons r, const float *__restrict__ endN, uint32_t n,
-                                                        gvpm_params cfg, const uint32_t *__restrict__ subCounts, float4 *cold,
-                                                        float4 *aux) {
+__global__ __launch_bounds__(64) void beam_cold_kernel(RawPhotons r, const float *__restrict__ endN, uint32_t n,
+                                                       gvpm_params cfg, const uint32_t *__restrict__ subCounts, float4 *cold,
+                                                       float4 *aux) {
+  // The record is assembled in LDS and written by EIGHT lanes (one 16-byte quad each), as reorder_kernel does: a store
+  // instruction then covers eight whole 128-byte lines instead of sixty-four 16-byte pieces of sixty-four lines.
+  __shared__ float4 stg[64][GVPM_REC_QUADS + 1];  // +1: odd stride against bank conflicts
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t bits = r.flags[i] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
-  // for beams the debugShift filter only suppresses the shifts (shift_volume_beams.cpp:210-216),
-  // so only computeVolumeContribution is folded into bit 6
-  gvpm_params c2 = cfg;
-  c2.debug_shift = GVPM_SHIFT_ALL;
-  if (photonContributes(bits, c2)) bits |= 1u << 6;
-  bits |= (r.path_id[i] & 1u) << GVPM_HOT_PARITY_BIT;
-  float4 *rec = cold + (size_t)i * GVPM_REC_QUADS;
-  rec[0] = ld3(r.flux, i, r.parent_pdf[i]);
-  rec[1] = ld3(r.parent_pos, i, r.parent_rr[i]);
-  rec[2] = ld3(r.parent_n, i, r.parent_g[i]);
-  rec[3] = ld3(r.prefix_w, i, 0.f);
-  rec[4] = ld3(r.parent_scat, i, 0.f);
-  rec[5] = ld3(r.parent_wi, i, 0.f);
-  rec[6] = ld3(r.pos, i, __uint_as_float(bits));
-  // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81: the length, once, in fp64 (an fp64 square root and division
-  // per evaluation otherwise)
-  const double dx = (double)r.pos[3 * (size_t)i] - (double)r.parent_pos[3 * (size_t)i];
-  const double dy = (double)r.pos[3 * (size_t)i + 1] - (double)r.parent_pos[3 * (size_t)i + 1];
-  const double dz = (double)r.pos[3 * (size_t)i + 2] - (double)r.parent_pos[3 * (size_t)i + 2];
-  const double lenD = sqrt(dx * dx + dy * dy + dz * dz);
-  rec[7] = ld3(endN, i, (float)lenD);
-  // what the sorted sub-beam records are made of (sub_hot_kernel), 32 bytes per beam: {p1, bits} {direction, sub-beam
-  // length} -- the fp64 norm and division once per beam instead of once per sub-beam (47 M of them at C3)
-  if (aux) {
-    const double inv = 1.0 / lenD;
-    aux[2 * (size_t)i] = ld3(r.parent_pos, i, __uint_as_float(bits));
-    aux[2 * (size_t)i + 1] = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), (float)lenD / (float)subCounts[i]);
+  const int t = threadIdx.x;
+  if (i < n) {
+    uint32_t bits = r.flags[i] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
+    // for beams the debugShift filter only suppresses the shifts (shift_volume_beams.cpp:210-216),
+    // so only computeVolumeContribution is folded into bit 6
+    gvpm_params c2 = cfg;
+    c2.debug_shift = GVPM_SHIFT_ALL;
+    if (photonContributes(bits, c2)) bits |= 1u << 6;
+    bits |= (r.path_id[i] & 1u) << GVPM_HOT_PARITY_BIT;
+    stg[t][0] = ld3(r.flux, i, r.parent_pdf[i]);
+    stg[t][1] = ld3(r.parent_pos, i, r.parent_rr[i]);
+    stg[t][2] = ld3(r.parent_n, i, r.parent_g[i]);
+    stg[t][3] = ld3(r.prefix_w, i, 0.f);
+    stg[t][4] = ld3(r.parent_scat, i, 0.f);
+    stg[t][5] = ld3(r.parent_wi, i, 0.f);
+    stg[t][6] = ld3(r.pos, i, __uint_as_float(bits));
+    // PhotonBeam::setEndPoint, pm/beams_struct.h:73-81: the length, once, in fp64 (an fp64 square root and division
+    // per evaluation otherwise)
+    const double dx = (double)r.pos[3 * (size_t)i] - (double)r.parent_pos[3 * (size_t)i];
+    const double dy = (double)r.pos[3 * (size_t)i + 1] - (double)r.parent_pos[3 * (size_t)i + 1];
+    const double dz = (double)r.pos[3 * (size_t)i + 2] - (double)r.parent_pos[3 * (size_t)i + 2];
+    const double lenD = sqrt(dx * dx + dy * dy + dz * dz);
+    stg[t][7] = ld3(endN, i, (float)lenD);
+    // what the sorted sub-beam records are made of (sub_hot_kernel), 32 bytes per beam: {p1, bits} {direction, sub-beam
+    // length} -- the fp64 norm and division once per beam instead of once per sub-beam (47 M of them at C3)
+    if (aux) {
+      const double inv = 1.0 / lenD;
+      aux[2 * (size_t)i] = ld3(r.parent_pos, i, __uint_as_float(bits));
+      aux[2 * (size_t)i + 1] = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), (float)lenD / (float)subCounts[i]);
+    }
+  }
+  __syncthreads();
+  const uint32_t base = blockIdx.x * blockDim.x;
+  for (int e = t; e < 64 * GVPM_REC_QUADS; e += 64) {
+    const int rec = e / GVPM_REC_QUADS, part = e % GVPM_REC_QUADS;
+    if (base + (uint32_t)rec < n) cold[(size_t)(base + rec) * GVPM_REC_QUADS + part] = stg[rec][part];
   }
 }
 
@@ -829,7 +839,7 @@ void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n,
   RawPhotons r{raw.pos,        raw.wi,         raw.flux,     raw.parent_pos, raw.parent_n,
                raw.prefix_w,   raw.parent_scat, raw.parent_wi, raw.parent_pdf, raw.edge_pdf,
                raw.parent_rr,  raw.parent_g,   raw.flags,    raw.path_id};
-  hipLaunchKernelGGL(beam_cold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, r, endN, n, cfg, subCounts, cold, aux);
+  hipLaunchKernelGGL(beam_cold_kernel, dim3((n + 63) / 64), dim3(64), 0, s, r, endN, n, cfg, subCounts, cold, aux);
 }
 
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
