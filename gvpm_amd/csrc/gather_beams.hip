@@ -2220,16 +2220,27 @@ __global__ __launch_bounds__(256) void beam_expand_kernel(const float *__restric
 // rounded to float), so that sub-beam ranges agree.
 __global__ __launch_bounds__(256) void sub_hot_kernel(const uint32_t *__restrict__ sortedIds, uint32_t n,
                                                       const float4 *__restrict__ aux, float4 *hot, uint32_t *hotFlags) {
+  // (the two quads of a record go through LDS: consecutive lanes then write consecutive quads -- whole lines -- instead
+  // of every lane its two halves of a 32-byte record)
+  __shared__ float4 stg[256][2];
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t id = sortedIds[j], beam = id & 0xFFFFFFu, sub = id >> 24;
-  // {p1, bits} {direction, sub-beam length} of the beam (beam_cold_kernel): one 32-byte gather; the centre is computed,
-  // not gathered (to a few ulp the one beam_expand_kernel binned: every test downstream carries a margin)
-  const float4 a0 = aux[2 * (size_t)beam], a1 = aux[2 * (size_t)beam + 1];
-  const float t = a1.w * ((float)sub + 0.5f);
-  hot[2 * (size_t)j] = make_float4(a0.x + a1.x * t, a0.y + a1.y * t, a0.z + a1.z * t, __uint_as_float(id));
-  hot[2 * (size_t)j + 1] = a1;
-  hotFlags[j] = __float_as_uint(a0.w);
+  const int t = threadIdx.x;
+  if (j < n) {
+    const uint32_t id = sortedIds[j], beam = id & 0xFFFFFFu, sub = id >> 24;
+    // {p1, bits} {direction, sub-beam length} of the beam (beam_cold_kernel): one 32-byte gather; the centre is computed,
+    // not gathered (to a few ulp the one beam_expand_kernel binned: every test downstream carries a margin)
+    const float4 a0 = aux[2 * (size_t)beam], a1 = aux[2 * (size_t)beam + 1];
+    const float tt = a1.w * ((float)sub + 0.5f);
+    stg[t][0] = make_float4(a0.x + a1.x * tt, a0.y + a1.y * tt, a0.z + a1.z * tt, __uint_as_float(id));
+    stg[t][1] = a1;
+    hotFlags[j] = __float_as_uint(a0.w);
+  }
+  __syncthreads();
+  const size_t base = 2 * (size_t)blockIdx.x * blockDim.x;
+  const float4 *flat = &stg[0][0];
+#pragma unroll
+  for (int e = t; e < 512; e += 256)
+    if (base + (size_t)e < 2 * (size_t)n) hot[base + e] = flat[e];
 }
 
 void launch_beam_subcount(const float *p2, const float *p1, uint32_t n, float ls, uint32_t *counts, uint32_t *maxLs,
