@@ -720,8 +720,9 @@ __device__ __forceinline__ BeamClearTri beamClearTri(const float p1[3], const fl
   return o;
 }
 
-__global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n, const float4 *__restrict__ tri4, uint32_t ntri,
+__global__ __launch_bounds__(128) void beam_near_kernel(float4 *cold, uint32_t n, const float4 *__restrict__ tri4, uint32_t ntri,
                                                         float r, const uint32_t *__restrict__ extentBits, float2 *clear, bool freeCone) {
+  __shared__ float2 ctab[19][128];  // (19: the longest list, BeamNearFmt)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t N = GVPM_REC_QUADS;
@@ -786,19 +787,21 @@ __global__ __launch_bounds__(256) void beam_near_kernel(float4 *cold, uint32_t n
       const float il = rsqrtf(l2);
       bd[0] *= il; bd[1] *= il; bd[2] *= il;
       const float cosSmall = 0.99955f;  // ~0.03 rad: "the beam points at this triangle"
+      // (each listed triangle's {cosT, alongMin} once: parked in this lane's LDS column between the two passes)
       float M1 = INFINITY;
+      uint32_t nl = 0;
       for (uint32_t q = 0; q < fmt.cap; ++q) {
         const uint32_t t = beamNearEntry(fmt, w[0], w[1], w[2], q);
         if (t == fmt.mask) break;
         const BeamClearTri ct = beamClearTri(p1, bd, delta, tri4[3 * t], tri4[3 * t + 1], tri4[3 * t + 2]);
+        ctab[q][threadIdx.x] = make_float2(ct.cosT, ct.alongMin);
+        nl = q + 1;
         if (ct.cosT > cosSmall) M1 = fminf(M1, ct.alongMin);
       }
       float cosA0 = -1.f;
-      for (uint32_t q = 0; q < fmt.cap; ++q) {
-        const uint32_t t = beamNearEntry(fmt, w[0], w[1], w[2], q);
-        if (t == fmt.mask) break;
-        const BeamClearTri ct = beamClearTri(p1, bd, delta, tri4[3 * t], tri4[3 * t + 1], tri4[3 * t + 2]);
-        if (!(ct.alongMin >= M1)) cosA0 = fmaxf(cosA0, ct.cosT);
+      for (uint32_t q = 0; q < nl; ++q) {
+        const float2 ct = ctab[q][threadIdx.x];
+        if (!(ct.y >= M1)) cosA0 = fmaxf(cosA0, ct.x);
       }
       if (M1 > 0.f) cl = make_float2(cosA0 + 1e-5f, M1 * (1.f - 1e-5f) - 1e-6f);
     }
@@ -831,7 +834,7 @@ void launch_beam_near_hist(const float4 *cold, uint32_t n, uint32_t ntri, uint32
 }
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits,
                       float2 *clear, bool freeCone, hipStream_t s) {
-  if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cold, n, tri4, ntri, r, extentBits, clear, freeCone);
+  if (n) hipLaunchKernelGGL(beam_near_kernel, dim3((n + 127) / 128), dim3(128), 0, s, cold, n, tri4, ntri, r, extentBits, clear, freeCone);
 }
 
 void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n, const gvpm_params &cfg,
