@@ -95,6 +95,10 @@ void launch_sub_hot(const uint32_t *sortedIds, uint32_t n, const float4 *aux, fl
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
                            const uint32_t *itemCount, uint32_t itemCap, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
                            uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream);
+void launch_evaluate_beams_split(const GatherArgs &a, uint32_t *qId, uint32_t *qMeta, float4 *qK, float *qU, uint32_t *blkCnt,
+                                 uint4 *runTab, uint32_t *ctl, const uint2 *pairs, const uint32_t *sortedKey,
+                                 const uint32_t *sortedBlock, uint32_t nBlocks, uint32_t *queueHead, uint32_t ncu,
+                                 hipStream_t stream);
 void launch_evaluate_beams(const GatherArgs &a, int beamsPerWave, bool exact, const uint2 *pairs, const uint32_t *sortedKey,
                            const uint32_t *sortedBlock, uint32_t nBlocks, uint32_t *queueHead, uint32_t nwaves,
                            hipStream_t stream);
@@ -329,6 +333,12 @@ struct gvpm_context {
   uint32_t vpmOrderN = 0;      // batches the G-VPM order in blockValB was sorted for (0: none)
   uint32_t vpmLaunches = 0;
   bool vpmNoOrder = false;     // GVPM_VPM_ORDER=0
+  // GVPM_BEAMS_SPLIT=1: the evaluation in two kernels (gather_beams.hip); the reconnection entries between them
+  bool beamsSplit = false;
+  DevBuf<uint32_t> splitId, splitMeta, splitBlkCnt, splitCtl;
+  DevBuf<float4> splitK;
+  DevBuf<float> splitU;
+  DevBuf<uint4> splitRuns;
   float *pinBeams = nullptr;   // the G-Beams driver's: 2 x 6 bounds (floats 0-5, 8-13), counters (uint32 from float 16 on)
 
   // camera beams

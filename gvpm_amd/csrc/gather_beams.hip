@@ -2106,6 +2106,280 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
   }
 }
 
+// ---- evaluation in TWO kernels (GVPM_BEAMS_SPLIT=1; experiment of round 4) ---------------------------------------------
+// evaluate_beams2_kernel holds 253 VGPRs and 19.6 KB of LDS: 8 waves per CU, its vector unit ~65 % busy.  Alone, phase 1
+// (kernel record, base term, null shifts) and phase 2 (reconnections) need fewer registers and far less LDS each, so each
+// can run three waves per SIMD -- at the price of the reconnection entries going through HBM (28 bytes each, SoA) and of
+// every tile being loaded and flushed twice.  Phase 1 works through guided runs of blocks as the fused kernel does; a run
+// reserves room for its worst case (256 entries a block) with one atomic, appends densely, and leaves {first block, blocks,
+// first entry} in a run table and the entries of every block in blkCnt[]; phase 2 takes the runs one at a time and walks
+// their tile segments 64 entries at a time.
+struct SplitQ {
+  uint32_t *id, *meta;  // BeamPQ::id, ::meta
+  float4 *k;
+  float *u;
+  uint32_t *blkCnt;     // entries of block bi (sorted block order)
+  uint4 *runTab;        // {first block, blocks, first entry, -}
+  uint32_t *ctl;        // [0] entry cursor [1] runs [2] phase 2's queue head
+};
+template <int B> struct BeamP1Lds : RayTile<B> {
+  double acc[27][B];
+};
+template <int B> struct BeamP2Lds : RayTile<B> {
+  double acc[27][B];
+  uint32_t vid[128], vmeta[128];
+  float4 vk[128];
+  float vu[128];
+};
+
+#ifndef GVPM_SPLIT_P1_MINW
+#define GVPM_SPLIT_P1_MINW 3
+#endif
+#ifndef GVPM_SPLIT_P2_MINW
+#define GVPM_SPLIT_P2_MINW 3
+#endif
+template <int B>
+__global__ __launch_bounds__(64, GVPM_SPLIT_P1_MINW) void evaluate_beams_p1_kernel(GatherArgs a, SplitQ sq, const uint2 *__restrict__ pairs,
+                                                                  const uint32_t *__restrict__ sortedKey,
+                                                                  const uint32_t *__restrict__ sortedBlock, uint32_t nBlocks,
+                                                                  uint32_t *queueHead) {
+  constexpr uint32_t RUN = GVPM_BEAMS_RUN, RUN_MIN = GVPM_BEAMS_RUN_MIN;
+  __shared__ BeamP1Lds<B> s;
+  const int lane = threadIdx.x;
+  uint32_t nEval = 0, nNull = 0, nFail = 0;
+  uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
+  auto flushTile = [&]() __attribute__((always_inline)) {
+    __syncthreads();
+    if (curBase != 0xFFFFFFFFu) {
+      for (int idx = lane; idx < 27 * B; idx += 64) {
+        const int k = idx / B, bb = idx % B;
+        if ((uint32_t)bb < curNb) {
+          const float v = (float)s.acc[k][bb];
+          if (v != 0.f) {
+            const uint32_t pv = s.pix[bb];
+            const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+            atomicAdd(&a.iter[p * 27 + k], v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  bool firstItem = true;
+  const uint32_t run0 = min(RUN, max(RUN_MIN, nBlocks / (4u * gridDim.x)));
+  const uint32_t firstDyn = gridDim.x * run0;
+  for (;;) {
+    uint32_t b0 = blockIdx.x * run0, cnt = run0;
+    if (!firstItem) {
+      if (lane == 0) {
+        const uint32_t seen = firstDyn + __hip_atomic_load(queueHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t rem = seen < nBlocks ? nBlocks - seen : 0u;
+        cnt = min(RUN, max(RUN_MIN, rem / (2u * gridDim.x)));
+        b0 = firstDyn + atomicAdd(queueHead, cnt);
+      }
+      b0 = __shfl(b0, 0, 64);
+      cnt = __shfl(cnt, 0, 64);
+    }
+    firstItem = false;
+    if (b0 >= nBlocks) break;
+    const uint32_t b1 = min(nBlocks, b0 + cnt);
+    // room for the run's worst case, and its row of the run table
+    uint32_t eBase = 0;
+    if (lane == 0) {
+      eBase = atomicAdd(&sq.ctl[0], (b1 - b0) * 256u);
+      const uint32_t r = atomicAdd(&sq.ctl[1], 1u);
+      sq.runTab[r] = make_uint4(b0, b1 - b0, eBase, 0u);
+    }
+    eBase = __shfl(eBase, 0, 64);
+    uint32_t eCount = 0;  // entries of the run so far (wave-uniform)
+    for (uint32_t bi = b0; bi < b1; ++bi) {
+      const uint32_t setBase = sortedKey[bi];
+      if (setBase != curBase) {
+        flushTile();
+        curBase = setBase;
+        curNb = min((uint32_t)B, a.nsets - setBase);
+        loadTileRays<B>(a, s, setBase, curNb, lane);
+        for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+        relToBase<B>(s, lane);
+        __syncthreads();
+      }
+      const uint2 e = pairs[(size_t)sortedBlock[bi] * 64u + lane];
+      const bool live = e.x != 0xFFFFFFFFu && e.y >= setBase && e.y - setBase < curNb;
+      const uint32_t bIdx = e.y - setBase;
+      BeamP1 st;
+      const bool alive = live && beamBase<B>(a, s, e.x, bIdx, st);
+      if (alive && st.st != 0xFFu) nEval++;
+      const bool primal = a.cfg.reserved[5] != 0;
+      const uint32_t eBlock = eCount;
+#pragma unroll 1
+      for (int i = 0; i < 4; ++i) {
+        bool rec = false;
+        if (alive && !primal) beamShift1<B, false>(a, s, st, bIdx, i, rec, nNull, nFail);
+        const unsigned long long m = __ballot(rec);
+        if (rec) {
+          const size_t slot = (size_t)eBase + eCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          sq.id[slot] = st.id;
+          sq.meta[slot] = bIdx | ((uint32_t)i << 8);
+          sq.k[slot] = make_float4(st.k.tauV, st.k.sigmaW, st.k.pdfEdgeFailure * st.k.pdfKernel, st.k.sc * st.k.weightKernel * st.rr);
+          sq.u[slot] = st.k.u;
+        }
+        eCount += (uint32_t)__popcll(m);
+      }
+      if (lane == 0) sq.blkCnt[bi] = eCount - eBlock;
+    }
+    flushTile();
+    curBase = 0xFFFFFFFFu;
+  }
+  {
+    unsigned long long ev = nEval, nu = nNull, fa = nFail;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ev += __shfl_xor(ev, o, 64);
+      nu += __shfl_xor(nu, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+    }
+    if (lane == 0 && ev) {
+      atomicAdd(&statRow(a)[0], ev);
+      atomicAdd(&statRow(a)[2], nu);
+      atomicAdd(&statRow(a)[4], fa);
+    }
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(64, GVPM_SPLIT_P2_MINW) void evaluate_beams_p2_kernel(GatherArgs a, SplitQ sq, const uint32_t *__restrict__ sortedKey) {
+  __shared__ BeamP2Lds<B> s;
+  extern __shared__ float4 sceneTri[];
+  const int lane = threadIdx.x;
+  const float4 *ldsTri = nullptr;
+  if (a.ntri <= BEAM_LDS_TRIS) {
+    for (uint32_t i = lane; i < 3u * a.ntri; i += 64u) sceneTri[i] = a.tri4[i];
+    ldsTri = sceneTri;
+    __syncthreads();
+  }
+  const uint32_t nRuns = sq.ctl[1];
+  uint32_t nDiff = 0, nFail = 0;
+  uint32_t curBase = 0xFFFFFFFFu, curNb = 0;
+  uint32_t vHead = 0, vCount = 0;  // the deferred ring, wave-uniform
+  auto drainVis = [&](uint32_t n) __attribute__((always_inline)) {
+    __syncthreads();
+    if ((uint32_t)lane < n) {
+      const uint32_t e = (vHead + (uint32_t)lane) & 127u;
+      BeamPQ q;
+      q.id = s.vid[e];
+      q.meta = s.vmeta[e];
+      q.k = s.vk[e];
+      q.u = s.vu[e];
+      bool defer;
+      beamShift2<B, false>(a, s, q, ldsTri, true, defer, nDiff, nFail, curBase);
+    }
+    vHead = (vHead + n) & 127u;
+    vCount -= n;
+  };
+  auto flushTile = [&]() __attribute__((always_inline)) {
+    while (vCount) drainVis(min(vCount, 64u));
+    __syncthreads();
+    if (curBase != 0xFFFFFFFFu) {
+      for (int idx = lane; idx < 27 * B; idx += 64) {
+        const int k = idx / B, bb = idx % B;
+        if ((uint32_t)bb < curNb) {
+          const float v = (float)s.acc[k][bb];
+          if (v != 0.f) {
+            const uint32_t pv = s.pix[bb];
+            const size_t p = (size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu);
+            atomicAdd(&a.iter[p * 27 + k], v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  bool firstItem = true;
+  for (;;) {
+    uint32_t r = blockIdx.x;
+    if (!firstItem) {
+      if (lane == 0) r = gridDim.x + atomicAdd(&sq.ctl[2], 1u);
+      r = __shfl(r, 0, 64);
+    }
+    firstItem = false;
+    if (r >= nRuns) break;
+    const uint4 run = sq.runTab[r];
+    uint32_t ePos = run.z;  // the next block's first entry
+    uint32_t bi = run.x;
+    const uint32_t bEnd = run.x + run.y;
+    while (bi < bEnd) {
+      // the tile segment: consecutive blocks of one tile, their entries laid end to end
+      const uint32_t setBase = sortedKey[bi];
+      const uint32_t segBeg = ePos;
+      while (bi < bEnd && sortedKey[bi] == setBase) ePos += sq.blkCnt[bi++];
+      if (ePos == segBeg) continue;
+      if (setBase != curBase) {
+        flushTile();
+        curBase = setBase;
+        curNb = min((uint32_t)B, a.nsets - setBase);
+        loadTileRays<B>(a, s, setBase, curNb, lane);
+        for (int idx = lane; idx < 27 * B; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+        relToBase<B>(s, lane);
+        __syncthreads();
+      }
+      for (uint32_t e0 = segBeg; e0 < ePos; e0 += 64u) {
+        const uint32_t n = min(64u, ePos - e0);
+        __syncthreads();
+        bool defer = false;
+        BeamPQ q = {};
+        if ((uint32_t)lane < n) {
+          const size_t e = (size_t)e0 + lane;
+          q.id = sq.id[e];
+          q.meta = sq.meta[e];
+          q.k = sq.k[e];
+          q.u = sq.u[e];
+          beamShift2<B, false>(a, s, q, ldsTri, false, defer, nDiff, nFail, curBase);
+        }
+        const unsigned long long dm = __ballot(defer);
+        if (dm) {
+          if (defer) {
+            const uint32_t slot = (vHead + vCount + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))) & 127u;
+            s.vid[slot] = q.id;
+            s.vmeta[slot] = q.meta;
+            s.vk[slot] = q.k;
+            s.vu[slot] = q.u;
+          }
+          vCount += (uint32_t)__popcll(dm);
+          if (vCount >= 64u) drainVis(64u);
+        }
+      }
+    }
+    flushTile();
+    curBase = 0xFFFFFFFFu;
+  }
+  {
+    unsigned long long di = nDiff, fa = nFail;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      di += __shfl_xor(di, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+    }
+    if (lane == 0 && (di | fa)) {
+      atomicAdd(&statRow(a)[3], di);
+      atomicAdd(&statRow(a)[4], fa);
+    }
+  }
+}
+
+// (B = 16 only: the tile size every launch of the product uses; the fused kernel serves the others)
+void launch_evaluate_beams_split(const GatherArgs &a, uint32_t *qId, uint32_t *qMeta, float4 *qK, float *qU, uint32_t *blkCnt,
+                                 uint4 *runTab, uint32_t *ctl, const uint2 *pairs, const uint32_t *sortedKey,
+                                 const uint32_t *sortedBlock, uint32_t nBlocks, uint32_t *queueHead, uint32_t ncu,
+                                 hipStream_t stream) {
+  if (a.nsets == 0 || nBlocks == 0) return;
+  SplitQ sq{qId, qMeta, qK, qU, blkCnt, runTab, ctl};
+  const uint32_t nw = ncu * 4u * GVPM_SPLIT_P1_MINW, nw2 = ncu * 4u * GVPM_SPLIT_P2_MINW;
+  hipLaunchKernelGGL((evaluate_beams_p1_kernel<16>), dim3(nw), dim3(64), 0, stream, a, sq, pairs, sortedKey, sortedBlock, nBlocks,
+                     queueHead);
+  const size_t dyn = a.ntri <= BEAM_LDS_TRIS ? (size_t)a.ntri * 48u : 0u;
+  hipLaunchKernelGGL((evaluate_beams_p2_kernel<16>), dim3(nw2), dim3(64), dyn, stream, a, sq, sortedKey);
+}
+
 void launch_traverse_beams(const GatherArgs &a, const uint32_t *hotFlags, int beamsPerWave, const uint4 *items,
                            const uint32_t *itemCount, uint32_t itemCap, uint32_t *queueHead, uint2 *pairs, uint32_t *pairCount,
                            uint32_t pairCap, uint32_t *blockKey, uint32_t *blockVal, uint32_t nwaves, hipStream_t stream) {

@@ -848,6 +848,22 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
     h->reqOutstanding = true;
     h->reqBeams = true;
   }
+  if (h->beamsSplit && !primal && !h->beamsExact && !a.reqHost && h->beamsPerWave == 16 && nBlocks) {
+    // (experiment: phase 1 and phase 2 as two kernels, the reconnection entries through HBM -- gather_beams.hip)
+    const size_t nEnt = (size_t)nBlocks * 256u;
+    if (nEnt > 0xFFFFFF00ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many blocks for the split evaluation");
+    HIP_TRY(h, h->splitId.ensure(nEnt));
+    HIP_TRY(h, h->splitMeta.ensure(nEnt));
+    HIP_TRY(h, h->splitK.ensure(nEnt));
+    HIP_TRY(h, h->splitU.ensure(nEnt));
+    HIP_TRY(h, h->splitBlkCnt.ensure((size_t)nBlocks + 1));
+    HIP_TRY(h, h->splitRuns.ensure((size_t)nBlocks / 16u + (size_t)h->ncu * 12u + 64u));
+    HIP_TRY(h, h->splitCtl.ensure(4));
+    HIP_TRY(h, hipMemsetAsync(h->splitCtl.p, 0, 16, h->stream));
+    launch_evaluate_beams_split(a, h->splitId.p, h->splitMeta.p, h->splitK.p, h->splitU.p, h->splitBlkCnt.p, h->splitRuns.p,
+                                h->splitCtl.p, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks, h->bs->queueCtl.p + 3,
+                                h->ncu, h->stream);
+  } else
   launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact && !primal, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
                         h->bs->queueCtl.p + 3, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));

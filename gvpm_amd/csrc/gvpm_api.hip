@@ -131,6 +131,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
   if (const char *e = getenv("GVPM_PLAN_BOXES")) h->planBoxHandOff = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
+  if (const char *e = getenv("GVPM_BEAMS_SPLIT")) h->beamsSplit = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BUNDLE")) {
     h->bundleEnabled = atoi(e) != 0;
     h->bundleFromEnv = true;
@@ -212,6 +213,8 @@ int gvpm_destroy(gvpm_context *h) {
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
   if (h->pinBeams) (void)hipHostFree(h->pinBeams);
+  h->splitId.release(); h->splitMeta.release(); h->splitBlkCnt.release(); h->splitCtl.release(); h->splitK.release();
+  h->splitU.release(); h->splitRuns.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->streamB) (void)hipStreamDestroy(h->streamB);
   if (h->streamC) (void)hipStreamDestroy(h->streamC);

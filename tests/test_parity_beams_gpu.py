@@ -205,3 +205,16 @@ def test_free_cone_off_equals_free_cone_on(monkeypatch):
     acc0, _, st0 = device_beams(c)
     assert st0 == st1
     assert np.allclose(acc0, acc1, rtol=1e-5, atol=1e-7 * max(ref[..., 0:3].mean(), 1e-30))
+
+
+@pytest.mark.parametrize("scene,kw", [("laser", dict()), ("cbox", dict(use_shift_null=0)), ("fogroom", dict(path_set=0))])
+def test_split_evaluation_equals_the_fused_one(monkeypatch, scene, kw):
+    """GVPM_BEAMS_SPLIT=1 (round 4, opt-in): phase 1 and phase 2 of the evaluation as two kernels with the reconnection
+    entries in HBM between them -- the same parity bars, the same counters as the fused kernel"""
+    c = make_beam_case(scene, 40, 32, 9000, 3.0, **kw)
+    acc0, ref, st0 = device_beams(c)
+    monkeypatch.setenv("GVPM_BEAMS_SPLIT", "1")
+    acc1, _, st1 = device_beams(c)
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert st1[k] == st0[k], (k, st1, st0)
+    assert np.abs(acc1.astype(np.float64) - acc0).max() <= 2e-5 * np.abs(acc0).max()
