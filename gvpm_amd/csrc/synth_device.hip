@@ -50,15 +50,21 @@ struct PhotonOut {
   float *endN;
 };
 
+// (the path is flattened WHILE it is walked -- StreamPath, synth_core.h: a ring of four vertices instead of the sixteen of
+// an LPath in scratch, 2.7 KB per lane that every light path wrote and read back)
 template <class RL>
 __device__ __forceinline__ void walkAndFlatten(const SceneView &sc, int iteration, uint64_t idx, bool beams, RL &recs,
                                                bool &counted) {
   Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32));
-  LPath path;
-  randomWalk(sc, rng, path);
-  counted = true;
-  if (beams) counted = flattenBeams(sc, path, recs);
-  else flattenPath(sc, path, recs);
+  if (beams) {
+    StreamPath<RL, true> path(sc, recs);
+    randomWalk(sc, rng, path);
+    counted = path.finish();
+  } else {
+    StreamPath<RL, false> path(sc, recs);
+    randomWalk(sc, rng, path);
+    counted = path.finish();
+  }
 }
 
 // the sinks of flattenPath / flattenBeams (synth_core.h): the count pass keeps a number, the write pass stores each record

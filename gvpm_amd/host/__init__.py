@@ -42,6 +42,8 @@ def lib():
         L.gvpm_synth_planes.restype = C.c_uint64
         L.gvpm_synth_planes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.gvpm_synth_bsdfs.restype = C.c_uint32
+        L.gvpm_synth_stream_check.restype = C.c_uint64
+        L.gvpm_synth_stream_check.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
         L.gvpm_synth_bsdfs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.gvpm_synth_sensor.argtypes = [C.c_void_p, C.POINTER(abi.Sensor)]
         L.gvpm_synth_jitter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]

@@ -160,6 +160,44 @@ uint32_t gvpm_synth_bsdfs(const gvpm_synth *s, gvpm_bsdf *out, uint32_t cap) {
   return n;
 }
 
+uint64_t gvpm_synth_stream_check(gvpm_synth *s, int iteration, uint64_t n_paths, int beams, uint64_t *n_records) {
+  using namespace gvpm;
+  if (!s) return ~0ull;
+  const SceneView sc = s->scene.view();
+  uint64_t differ = 0, nrec = 0;
+  LPath path;
+  RecList a, b;
+  for (uint64_t idx = 0; idx < n_paths; ++idx) {
+    Philox r1(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32)), r2 = r1;
+    randomWalk(sc, r1, path);
+    bool ca = true, cb;
+    if (beams) ca = flattenBeams(sc, path, a);
+    else flattenPath(sc, path, a);
+    if (beams) {
+      StreamPath<RecList, true> sp(sc, b);
+      randomWalk(sc, r2, sp);
+      cb = sp.finish();
+    } else {
+      StreamPath<RecList, false> sp(sc, b);
+      randomWalk(sc, r2, sp);
+      cb = sp.finish();
+    }
+    bool same = a.n == b.n && ca == cb;
+    for (int q = 0; same && q < a.n; ++q) {
+      const PhotonRec &x = a.r[q], &y = b.r[q];
+      const V3 *vx[9] = {&x.pos, &x.wi, &x.flux, &x.parentPos, &x.parentN, &x.prefixW, &x.parentScat, &x.parentWi, &x.endN};
+      const V3 *vy[9] = {&y.pos, &y.wi, &y.flux, &y.parentPos, &y.parentN, &y.prefixW, &y.parentScat, &y.parentWi, &y.endN};
+      for (int k = 0; k < (beams ? 9 : 8); ++k) same = same && memcmp(vx[k], vy[k], sizeof(V3)) == 0;  // (endN: beams only)
+      same = same && memcmp(&x.parentPdf, &y.parentPdf, 4) == 0 && memcmp(&x.edgePdf, &y.edgePdf, 4) == 0 &&
+             memcmp(&x.parentRR, &y.parentRR, 4) == 0 && memcmp(&x.parentG, &y.parentG, 4) == 0 && x.flags == y.flags;
+    }
+    nrec += (uint64_t)a.n;
+    if (!same) differ++;
+  }
+  if (n_records) *n_records = nrec;
+  return differ;
+}
+
 int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out) {
   if (!s || !out) return GVPM_ERR_INVALID_ARG;
   memset(out, 0, sizeof(*out));

@@ -32,6 +32,10 @@ uint64_t gvpm_synth_beams(gvpm_synth *s, int it, int x0, int y0, int x1, int y1,
 /* the BSDF table of the scene's glossy (Phong) walls, in the order the photons' parent_g name them (gvpm_upload_bsdfs);
  * returns the number of entries (at most cap are written) */
 uint32_t gvpm_synth_bsdfs(const gvpm_synth *s, gvpm_bsdf *out, uint32_t cap);
+/* self-check of the streaming flattening the device generator uses (StreamPath, synth_core.h) against flattenPath /
+ * flattenBeams on the same `n_paths` light paths of `iteration`: the number of paths whose records differ in any bit
+ * (0 = identical); *n_records: records compared */
+uint64_t gvpm_synth_stream_check(gvpm_synth *s, int iteration, uint64_t n_paths, int beams, uint64_t *n_records);
 /* the scene's pinhole sensor as the compact beam sets take it (gvpm_upload_sensor, include/gvpm_hip.h) */
 int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out);
 /* the fractional film offsets (2 floats per set) the base paths of `rays` (5 per set) of iteration `it` were sampled at:

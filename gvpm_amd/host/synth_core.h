@@ -111,8 +111,32 @@ struct Hit {
 GVPM_HD inline bool closestHit(const SceneView &sc, V3 o, V3 d, double mint, Hit &hit) {
   hit.t = std::numeric_limits<double>::infinity();
   hit.tri = -1;
+#ifdef __HIP_DEVICE_COMPILE__
+  // (device: the ray's directions and origin once in fp32 for the cull below)
+  const float of[3] = {(float)o.x, (float)o.y, (float)o.z}, df[3] = {(float)d.x, (float)d.y, (float)d.z};
+#endif
   for (size_t i = 0; i < (size_t)sc.ntri; ++i) {
     const SynthTri &tr = sc.tris[i];
+#ifdef __HIP_DEVICE_COMPILE__
+    {
+      // A conservative fp32 statement of the two barycentric tests, without the division: a triangle it rejects fails the
+      // fp64 test below by a wide margin (E bounds the fp32 error of the three sums by their operands' magnitudes, x 30),
+      // so the triangles that reach the fp64 test -- one or two of a room's thirty -- decide exactly as the loop over all of
+      // them does on the host: same hit, same order of ties.
+      const float e1[3] = {(float)tr.e1.x, (float)tr.e1.y, (float)tr.e1.z}, e2[3] = {(float)tr.e2.x, (float)tr.e2.y, (float)tr.e2.z};
+      const float tv[3] = {of[0] - (float)tr.v0.x, of[1] - (float)tr.v0.y, of[2] - (float)tr.v0.z};
+      const float px = df[1] * e2[2] - df[2] * e2[1], py = df[2] * e2[0] - df[0] * e2[2], pz = df[0] * e2[1] - df[1] * e2[0];
+      const float qx = tv[1] * e1[2] - tv[2] * e1[1], qy = tv[2] * e1[0] - tv[0] * e1[2], qz = tv[0] * e1[1] - tv[1] * e1[0];
+      const float C = e1[0] * px + e1[1] * py + e1[2] * pz;
+      const float A = tv[0] * px + tv[1] * py + tv[2] * pz;
+      const float Bq = df[0] * qx + df[1] * qy + df[2] * qz;
+      const float l1 = fabsf(px) + fabsf(py) + fabsf(pz), lq = fabsf(qx) + fabsf(qy) + fabsf(qz);
+      const float E = 4e-6f * ((fabsf(tv[0]) + fabsf(tv[1]) + fabsf(tv[2]) + fabsf(e1[0]) + fabsf(e1[1]) + fabsf(e1[2])) * l1 +
+                               (fabsf(df[0]) + fabsf(df[1]) + fabsf(df[2])) * lq) + 1e-30f;
+      const float sg = C < 0.f ? -1.f : 1.f, aC = fabsf(C);
+      if (sg * A < -E || sg * A > aC + E || sg * Bq < -E || sg * (A + Bq) > aC + 2.f * E) continue;
+    }
+#endif
     V3 p = cross(d, tr.e2);
     double det = dot(tr.e1, p);
     if (det == 0.0) continue;
@@ -194,7 +218,9 @@ GVPM_HD inline double hgEval(double g, double cosWiWo) {
 }
 
 // One light path; mirrors Path::randomWalk(scene, sampler, maxDepth, rrDepth, EImportance)
-GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, LPath &path) {
+// (PATH: LPath, or any container with clear() / push_back(const LVertex &) / operator[] over the LAST FOUR vertices --
+// the walk reads path[i - 1], modifies path[i] and appends path[i + 1]: StreamPath below flattens as it goes)
+template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, PATH &path) {
   path.clear();
   const double sigT = sc.medium.sigma_t[1];
   const double msw = sc.medium.medium_sampling_weight;
@@ -457,7 +483,7 @@ struct RecList {
 };
 
 
-GVPM_HD inline void fillParent(const SceneView &sc, const LPath &path, size_t ip, PhotonRec &r,
+template <class PATH> GVPM_HD inline void fillParent(const SceneView &sc, const PATH &path, size_t ip, PhotonRec &r,
                        uint32_t &ptype) {
   const LVertex &par = path[ip];
   r.parentPos = par.pos;
@@ -567,6 +593,117 @@ template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const L
   }
 }
 
+
+// The same two flattenings, done WHILE the path is walked (the device generator, synth_device.hip): vertex idx is flattened
+// when it is appended -- everything flattenPath / flattenBeams read of vertices idx - 1 and idx - 2 is final by then -- so the
+// walk keeps a ring of four vertices instead of the path's sixteen (2.7 KB of scratch per lane, written and read back by
+// every light path).  Statement for statement the arithmetic of the functions above: the running product `w` takes its
+// factors in the same order, typeShift's backward scan becomes the index of the last diffuse vertex seen, and the
+// whole-path rejection (a zero interior pdf) clears the records at the end (finish()).
+template <class RL, bool BEAMS> struct StreamPath {
+  LVertex v[4];
+  int n;
+  const SceneView &sc;
+  RL &recs;
+  V3 w;
+  bool bad, any;
+  int lastDiffuse;  // largest index in [1, n - 2] whose vertex is diffuse (-1: none): typeShift's b for c = n - 1
+  GVPM_HD StreamPath(const SceneView &s_, RL &r_) : n(0), sc(s_), recs(r_), w(1.0), bad(false), any(false), lastDiffuse(-1) {}
+  GVPM_HD size_t size() const { return (size_t)n; }
+  GVPM_HD LVertex &operator[](size_t i) { return v[i & 3]; }
+  GVPM_HD const LVertex &operator[](size_t i) const { return v[i & 3]; }
+  GVPM_HD void clear() {
+    n = 0;
+    w = V3(1.0);
+    bad = any = false;
+    lastDiffuse = -1;
+    recs.clear();
+  }
+  GVPM_HD int shiftCode(size_t c) const {  // typeShift(sc, path, c)
+    const int b = lastDiffuse;
+    if (b == -1) return 0;
+    if ((size_t)b + 1 == c) return 1;
+    if ((*this)[c - 1].type == VT_MEDIUM) return 2;
+    return 3;
+  }
+  GVPM_HD void push_back(const LVertex &x) {
+    if (n >= GVPM_SYNTH_MAXV) return;
+    const size_t idx = (size_t)n;
+    v[idx & 3] = x;
+    ++n;
+    if (idx == 0) return;
+    const StreamPath &path = *this;
+    // an interior vertex (it has a successor now) with a zero pdf rejects the whole path
+    if (idx >= 2 && path[idx - 1].pdf == 0.0) bad = true;
+    const V3 prefix = w;  // prod_{k < idx - 1}
+    w = w * path[idx - 1].weight * path[idx - 1].rr * path[idx - 1].eWeight;
+    if (BEAMS) {
+      // edge i = idx - 1 (flattenBeams)
+      const size_t i = idx - 1, first = (size_t)(sc.minDepth > 1 ? sc.minDepth : 1);
+      if (i >= first && path[i].eMedium) {
+        any = true;
+        if (!cameraHit(sc, path[i].pos, path[i + 1].pos)) {
+          PhotonRec r;
+          uint32_t ptype;
+          fillParent(sc, path, i, r, ptype);
+          r.pos = path[i + 1].pos;
+          r.wi = normalize(path[i].pos - path[i + 1].pos);
+          r.flux = prefix * path[i].weight * path[i].rr;  // without the transmittance of edge i
+          r.prefixW = prefix;
+          r.endN = path[i + 1].type == VT_SURFACE ? path[i + 1].n : V3(0.0);
+          r.flags = GVPM_PF_MAKE(ptype, shiftCode(i + 1), 1, i, GVPM_BSDF_DIFFUSE_REFLECTION);
+          recs.push_back(r);
+        }
+      }
+    } else {
+      // vertex i = idx (flattenPath)
+      const size_t i = idx, startIndex = (size_t)(sc.minDepth + 1 > 2 ? sc.minDepth + 1 : 2);
+      if (i >= startIndex && path[i].type == VT_MEDIUM && !cameraHit(sc, path[i - 1].pos, path[i].pos)) {
+        const LVertex &par = path[i - 1];
+        PhotonRec r;
+        r.pos = path[i].pos;
+        r.wi = normalize(par.pos - path[i].pos);
+        r.flux = w;
+        r.parentPos = par.pos;
+        r.parentN = par.n;
+        r.prefixW = prefix;
+        r.parentScat = V3(0.0);
+        r.parentWi = V3(1.0, 0.0, 0.0);
+        uint32_t ptype = GVPM_PARENT_EMITTER, comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+        r.parentG = sc.medium.g;
+        if (par.type == VT_SURFACE) {
+          if (par.matKind == MAT_MIRROR) comp = 0x00008u;  // BSDF::EDeltaReflection
+          ptype = GVPM_PARENT_SURFACE;
+          r.parentScat = par.albedo;
+          r.parentWi = normalize(path[i - 2].pos - par.pos);
+          if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
+            ptype = GVPM_PARENT_SURFACE_BSDF;
+            r.parentG = (float)sc.mats[par.mat].bsdf;
+            comp = par.comp;
+          }
+        } else if (par.type == VT_MEDIUM) {
+          ptype = GVPM_PARENT_MEDIUM;
+          r.parentScat = V3(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
+          r.parentWi = normalize(path[i - 2].pos - par.pos);
+        }
+        r.parentPdf = (float)par.pdf;
+        r.edgePdf = (float)par.ePdf;
+        r.parentRR = (float)par.rr;
+        r.flags = GVPM_PF_MAKE(ptype, shiftCode(i), par.eMedium ? 1 : 0, i - 1, comp);
+        recs.push_back(r);
+      }
+    }
+    if (vertexIsDiffuse(sc, path[idx])) lastDiffuse = (int)idx;
+  }
+  // after the walk: the whole-path rejection; returns what flattenBeams returns (photons: true)
+  GVPM_HD bool finish() {
+    if (bad) {
+      recs.clear();
+      return true;
+    }
+    return BEAMS ? !(any && recs.empty()) : true;
+  }
+};
 
 // A camera path of the long-beam walk to the first diffuse vertex (randomWalkFromPixelToFirstDiffuse,
 // gvpm_gatherpoint.h:22-170) reduced to what the gather reads: its medium edges (at most two here: a second one behind
