@@ -50,23 +50,6 @@ struct PhotonOut {
   float *endN;
 };
 
-// (the path is flattened WHILE it is walked -- StreamPath, synth_core.h: a ring of four vertices instead of the sixteen of
-// an LPath in scratch, 2.7 KB per lane that every light path wrote and read back)
-template <class RL>
-__device__ __forceinline__ void walkAndFlatten(const SceneView &sc, int iteration, uint64_t idx, bool beams, RL &recs,
-                                               bool &counted) {
-  Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32));
-  if (beams) {
-    StreamPath<RL, true> path(sc, recs);
-    randomWalk(sc, rng, path);
-    counted = path.finish();
-  } else {
-    StreamPath<RL, false> path(sc, recs);
-    randomWalk(sc, rng, path);
-    counted = path.finish();
-  }
-}
-
 // the sinks of flattenPath / flattenBeams (synth_core.h): the count pass keeps a number, the write pass stores each record
 // where it belongs -- neither holds the path's records in (scratch) memory
 struct CountSink {
@@ -107,20 +90,64 @@ struct ParkSink {
   }
 };
 
-__global__ __launch_bounds__(64) void synth_walk_kernel(SceneView sc, int iteration, uint64_t base, uint32_t m, int beams,
-                                                        float *park, int stride, uint32_t *counts, uint32_t *counted,
-                                                        uint32_t *nonEmpty) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= m) return;
+// A wave owns `chunk` consecutive paths of the batch and its lanes REFILL: a lane whose path has ended takes the wave's next
+// path while its neighbours walk on (walkBegin / walkStep, synth_core.h).  With one path per lane a wave ran until its
+// longest path ended -- twelve bounces with the mean near five: less than half of the lane-steps did work.  Where a path's
+// records are parked depends on the path alone, so which lane walks it changes nothing.
+template <bool BEAMS>
+__device__ __forceinline__ void walkChunk(const SceneView &sc, int iteration, uint64_t base, uint32_t k0, uint32_t k1, float *park,
+                                          int stride, uint32_t *counts, uint32_t *counted, uint32_t *nonEmpty) {
+  const int lane = threadIdx.x & 63;
   ParkSink recs;
-  recs.park = park + (size_t)k * stride * PARK_WORDS;
+  recs.park = park;
   recs.stride = stride;
   recs.n = 0;
-  bool c;
-  walkAndFlatten(sc, iteration, base + k, beams != 0, recs, c);
-  counts[k] = (uint32_t)recs.n;
-  counted[k] = c ? 1u : 0u;
-  nonEmpty[k] = recs.n ? 1u : 0u;
+  StreamPath<ParkSink, BEAMS> path(sc, recs);
+  Philox rng(sc.seed, 0x11ffu, (uint32_t)iteration, 0u, 0u);
+  V3 throughput(1.0);
+  uint32_t next = k0;  // wave-uniform
+  uint32_t k = 0;
+  int i = 0;
+  bool active = false;
+  for (;;) {
+    // refill: the idle lanes take the next paths, in lane order
+    const unsigned long long idle = __ballot(!active);
+    if (idle && next < k1) {
+      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+      if (!active && next + rank < k1) {
+        k = next + rank;
+        const uint64_t idx = base + k;
+        rng = Philox(sc.seed, 0x11ffu, (uint32_t)iteration, (uint32_t)idx, (uint32_t)(idx >> 32));
+        recs.park = park + (size_t)k * stride * PARK_WORDS;
+        walkBegin(sc, rng, path, throughput);
+        i = 1;
+        active = true;
+      }
+      next = min(k1, next + (uint32_t)__popcll(idle));
+    }
+    if (!__ballot(active)) break;
+    if (active) {
+      if (i >= sc.maxDepth || !walkStep(sc, rng, path, throughput, i)) {
+        const bool c = path.finish();
+        counts[k] = (uint32_t)recs.n;
+        counted[k] = c ? 1u : 0u;
+        nonEmpty[k] = recs.n ? 1u : 0u;
+        active = false;
+      } else {
+        ++i;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void synth_walk_kernel(SceneView sc, int iteration, uint64_t base, uint32_t m, uint32_t chunk, int beams,
+                                                        float *park, int stride, uint32_t *counts, uint32_t *counted,
+                                                        uint32_t *nonEmpty) {
+  const uint32_t k0 = blockIdx.x * chunk;
+  if (k0 >= m) return;
+  const uint32_t k1 = min(m, k0 + chunk);
+  if (beams) walkChunk<true>(sc, iteration, base, k0, k1, park, stride, counts, counted, nonEmpty);
+  else walkChunk<false>(sc, iteration, base, k0, k1, park, stride, counts, counted, nonEmpty);
 }
 
 // ctl: [0] photons stored before this batch, [1] paths counted before, [2] paths with photons before,
@@ -366,8 +393,10 @@ static int shootCommon(gvpm_devgen *g, int iteration, uint64_t capacity, int bea
   uint64_t base = 0, stored = 0, paths = 0;
   for (int batch = 0; stored < capacity; ++batch) {
     if (batch > 4096) return GVPM_ERR_STATE;  // a scene that stores nothing
-    const unsigned nb = (m + 63) / 64;
-    hipLaunchKernelGGL(synth_walk_kernel, dim3(nb), dim3(64), 0, s, g->view, iteration, base, m, beams, g->park.p, stride,
+    // one round of waves (two per SIMD at this kernel's registers), each walking its share of the batch with refill
+    const uint32_t chunk = std::max(64u, (((m + 2047u) / 2048u) + 63u) & ~63u);  // (1024 / 4096 / 8192 shares: the same)
+    const unsigned nb = (m + chunk - 1) / chunk;
+    hipLaunchKernelGGL(synth_walk_kernel, dim3(nb), dim3(64), 0, s, g->view, iteration, base, m, chunk, beams, g->park.p, stride,
                        g->counts.p, g->counted.p, g->nonEmpty.p);
     SY_TRY(exclusiveSumU32(g->scanTmp, g->counts.p, g->offs.p, m, s));
     SY_TRY(exclusiveSumU32(g->scanTmp, g->counted.p, g->countedOffs.p, m, s));

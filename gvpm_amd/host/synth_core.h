@@ -218,14 +218,11 @@ GVPM_HD inline double hgEval(double g, double cosWiWo) {
 }
 
 // One light path; mirrors Path::randomWalk(scene, sampler, maxDepth, rrDepth, EImportance)
-// (PATH: LPath, or any container with clear() / push_back(const LVertex &) / operator[] over the LAST FOUR vertices --
-// the walk reads path[i - 1], modifies path[i] and appends path[i + 1]: StreamPath below flattens as it goes)
-template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, PATH &path) {
+// The walk in two pieces, so that a GPU lane whose path has ended can begin the next one while its neighbours walk on
+// (synth_device.hip): walkBegin appends the supernode and the emitter vertex, walkStep(i) samples vertex i's direction and
+// appends vertex i + 1 (false: the path ends at vertex i).  randomWalk = walkBegin + walkStep for i = 1 .. maxDepth - 1.
+template <class PATH> GVPM_HD inline void walkBegin(const SceneView &sc, Philox &rng, PATH &path, V3 &throughput) {
   path.clear();
-  const double sigT = sc.medium.sigma_t[1];
-  const double msw = sc.medium.medium_sampling_weight;
-  const V3 sigS(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
-  const double g = sc.medium.g;
 
   LVertex v0;
   v0.type = VT_SUPERNODE;
@@ -249,8 +246,15 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
   path.push_back(v0);
   path.push_back(v1);
 
-  V3 throughput(1.0);  // the supernode case returns before `throughput *= weight`
-  for (int i = 1; i < sc.maxDepth; ++i) {
+  throughput = V3(1.0);  // the supernode case returns before `throughput *= weight`
+}
+
+template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &rng, PATH &path, V3 &throughput, int i) {
+  const double sigT = sc.medium.sigma_t[1];
+  const double msw = sc.medium.medium_sampling_weight;
+  const V3 sigS(sc.medium.sigma_s[0], sc.medium.sigma_s[1], sc.medium.sigma_s[2]);
+  const double g = sc.medium.g;
+  {
     LVertex &cur = path[i];
     V3 wo;
     double mint = kEpsilon;
@@ -263,22 +267,22 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
       wo = toWorld(cur.n, local);
       cur.weight = V3(1.0);
       cur.pdf = local.z * kInvPi;
-      if (cur.pdf <= 0) break;
+      if (cur.pdf <= 0) return false;
     } else if (cur.type == VT_SURFACE) {
       V3 wi = normalize(path[i - 1].pos - cur.pos);
       double a = rng.next1D(), b = rng.next1D();
       if (cur.matKind == MAT_NULL) {
         // index-matched medium boundary: passes straight through and leaves the fog
-        break;
+        return false;
       }
-      if (dot(cur.n, wi) <= 0) break;  // one-sided BSDFs
+      if (dot(cur.n, wi) <= 0) return false;  // one-sided BSDFs
       if (cur.matKind == MAT_MIRROR) {
         // Dirac reflection: weight = reflectance, pdf = 1 in the discrete measure (not converted to area below)
         wo = cur.n * (2.0 * dot(cur.n, wi)) - wi;
         cur.weight = cur.albedo;
         cur.pdf = 1.0;
         solidAngle = false;
-        if (maxc(cur.weight) <= 0) break;
+        if (maxc(cur.weight) <= 0) return false;
       } else if (cur.matKind == MAT_PHONG) {
         // Phong::sample with bRec.component = -1 (phong.cpp:188-247): the sample picks the lobe, weight = eval / pdf of the
         // WHOLE BSDF, pdf = the mixture's (:157-186)
@@ -304,15 +308,15 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
           cur.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
         }
         const double cosWo = dot(cur.n, wo);
-        if (cosWo <= 0) break;
+        if (cosWo <= 0) return false;
         const double alpha = dot(wo, refl);
         const double lobe = alpha > 0 ? std::pow(alpha, e) : 0.0;
         const double pdfW = sw * lobe * (e + 1) / (2.0 * kPi) + (1 - sw) * cosWo * kInvPi;
-        if (pdfW == 0) break;
+        if (pdfW == 0) return false;
         const V3 f = (pm.spec * ((e + 2) / (2.0 * kPi) * lobe) + pm.albedo * kInvPi) * cosWo;
         cur.weight = f * (1.0 / pdfW);
         cur.pdf = pdfW;
-        if (maxc(cur.weight) <= 0) break;
+        if (maxc(cur.weight) <= 0) return false;
       } else if (cur.matKind == MAT_ROUGHCONDUCTOR) {
         // RoughConductor::sample, sampleVisible = false (roughconductor.cpp:321-389 with MicrofacetDistribution::sampleAll,
         // microfacet.h:287-347): half vector m ~ D cos, wo = reflect(wi, m), weight = F D G (wi . m) / (pdf_m cos_i),
@@ -330,13 +334,13 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
           cosThetaM = 1.0 / std::sqrt(1.0 + tanThetaMSqr);
           pdfM = (1.0 - a) / (kPi * alphaSqr * cosThetaM * cosThetaM * cosThetaM);
         }
-        if (!(pdfM >= 1e-20)) break;
+        if (!(pdfM >= 1e-20)) return false;
         const double sinThetaM = std::sqrt(std::fmax(0.0, 1 - cosThetaM * cosThetaM)), phi = 2.0 * kPi * b;
         const V3 m = toWorld(cur.n, V3(sinThetaM * std::cos(phi), sinThetaM * std::sin(phi), cosThetaM));
         const double wiM = dot(wi, m);
         wo = m * (2.0 * wiM) - wi;
         const double cosWo = dot(cur.n, wo);
-        if (cosWo <= 0) break;
+        if (cosWo <= 0) return false;
         const double woM = dot(wo, m);
         const double D = conductorD(pm.distribution, alpha, cosThetaM);
         const double G = conductorG1(pm.distribution, alpha, cosWi, wiM) * conductorG1(pm.distribution, alpha, cosWo, woM);
@@ -345,13 +349,13 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
                         conductorFresnel(wiM, pm.eta.z, pm.k.z) * pm.spec.z) * wgt;
         cur.pdf = pdfM / (4.0 * std::fabs(woM));
         cur.comp = 0x00008u;  // EGlossyReflection
-        if (maxc(cur.weight) <= 0 || !(cur.pdf > 0)) break;
+        if (maxc(cur.weight) <= 0 || !(cur.pdf > 0)) return false;
       } else {
         V3 local = cosineHemisphere(a, b);
         wo = toWorld(cur.n, local);
         cur.weight = cur.albedo;
         cur.pdf = local.z * kInvPi;
-        if (local.z <= 0 || maxc(cur.weight) <= 0) break;
+        if (local.z <= 0 || maxc(cur.weight) <= 0) return false;
       }
     } else {  // medium
       V3 wi = normalize(path[i - 1].pos - cur.pos);
@@ -374,7 +378,7 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
     cur.rr = 1.0;
     if (sc.rrDepth != -1 && i >= sc.rrDepth) {
       double q = std::fmin(maxc(throughput), 0.95);
-      if (rng.next1D() > q) break;
+      if (rng.next1D() > q) return false;
       cur.rr = 1.0 / q;
       throughput = throughput * cur.rr;
     }
@@ -405,14 +409,14 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
       succ.mat = tri.mat;
       succ.albedo = sc.mats[tri.mat].albedo;
     } else {
-      break;
+      return false;
     }
     succ.comp = succ.matKind == MAT_MIRROR ? 0x00008u : GVPM_BSDF_DIFFUSE_REFLECTION;
-    if (len == 0) break;
+    if (len == 0) return false;
     tr = std::exp(-sigT * len);
     pdfSuccess = sigT * tr * msw;
     pdfFailure = tr * msw + (1 - msw);
-    if (tr < 1e-20) break;
+    if (tr < 1e-20) return false;
     cur.eMedium = true;
     cur.ePdf = succ.type == VT_MEDIUM ? pdfSuccess : pdfFailure;
     cur.eWeight = V3(tr / cur.ePdf);
@@ -429,6 +433,16 @@ template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox
     succ.eMedium = false;
     path.push_back(succ);
   }
+  return true;
+}
+
+// (PATH: LPath, or any container with clear() / push_back(const LVertex &) / operator[] over the LAST FOUR vertices --
+// the walk reads path[i - 1], modifies path[i] and appends path[i + 1]: StreamPath below flattens as it goes)
+template <class PATH> GVPM_HD inline void randomWalk(const SceneView &sc, Philox &rng, PATH &path) {
+  V3 throughput;
+  walkBegin(sc, rng, path, throughput);
+  for (int i = 1; i < sc.maxDepth; ++i)
+    if (!walkStep(sc, rng, path, throughput, i)) break;
 }
 
 
