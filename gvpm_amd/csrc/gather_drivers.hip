@@ -553,7 +553,11 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   // maps beyond 2 M photons: the evaluation is the stage the pipelined step waits for (its records no longer fit the
   // Infinity Cache), so it gets its third wave per SIMD; below, the other stages need the room more (measured: +6 % on a
   // rank's step at C4 with 12 waves per CU, -3 % at C2)
-  const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u)
+  // (... when the evaluation is the long stage: a rank that holds an eighth of the frame evaluates for 1.3 ms beside a build of
+  // 1.0 -- with 12 waves per CU the build starves.  C4, rank 0 of N emulated, 8 / 12 waves: N = 2: 7.14 / 6.91 ms per step,
+  // N = 4: 3.94 / 3.93, N = 8: 2.33 / 2.47)
+  const bool smallShare = h->nsets > 0 && (size_t)h->nsets * 6u <= h->npix;
+  const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u && !smallShare)
                               ? std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS) : h->nwaves;
   if (!primal && h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
     // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing
