@@ -399,7 +399,7 @@ struct gvpm_context {
 
   int beamsPerWave = 16;
   float cellScale = 0.f;  // GVPM_CELL_SCALE; 0: the technique's default (buildGrid)
-  uint32_t planTarget = 1024;  // staged photons per work item
+  uint32_t planTarget = 1536;  // staged photons per work item (G-BRE; 1024 until the end of round 4: C2 -0.8 %, C4 whole -1.8 %, a rank of 8 -5 %)
   bool planTargetSet = false;  // GVPM_PLAN_TARGET given (else G-Beams takes its own default)
   uint32_t nwaves = 2048;      // persistent gather waves
   bool nwavesFromEnv = false;
