@@ -646,7 +646,9 @@ static int buildBeamGrid(gvpm_context *h, float r) {
   // build 6.4 -> 4.2 ms, traversal 10.2 -> 9.9 -- and, with them, work items of 4096 staged sub-beams: traversal -> 7.9 ms.
   // Round 2 had measured the opposite (23.5 ms at 0.75 r against 34 at 1.5 r) on a traversal that resolved its candidates
   // one per lane and round: the cost followed the sphere tests then, the walk and the staging now.)
-  float cell = fmaxf(0.75f * (h->cellScale > 0.f ? h->cellScale : 2.0f) * r, ext / 256.f);
+  // (end of round 4, with the build's kernels cheaper per sub-beam and the traversal's parity partition: 2.25 r -- GVPM_CELL_SCALE
+  // 2 / 2.5 / 3 / 3.5 / 4 at C3: 23.19 / 22.80 / 22.72 / 23.15 / 24.0 ms per step)
+  float cell = fmaxf(0.75f * (h->cellScale > 0.f ? h->cellScale : 3.0f) * r, ext / 256.f);
   if (!(cell > 0.f)) cell = 1.f;
   g.cell = cell;
   g.invCell = 1.f / cell;
