@@ -1,5 +1,7 @@
+"""Stress: G-Beams device == fp64 oracle on worst cases for the evaluation's queues (no null shifts, free cone off, both kernels,
+three scenes): python tests/stress_beams.py   (on the GPU box; not collected by pytest)"""
 import os, sys
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from test_oracle_beams import make_beam_case
 from test_parity_beams_gpu import device_beams

@@ -1,7 +1,7 @@
 """Stress: G-BRE device == fp64 oracle over scenes x flags x sharded beam sets (bundle cells with striped counters for the
-shards, 3D grid for the whole frame), several radii.  python scripts/stress_bre.py   (on the GPU box)"""
+shards, 3D grid for the whole frame), several radii.  python tests/stress_bre.py   (on the GPU box)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # (the repository: this file lives in tests/)
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import numpy as np
 import cases
