@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-GVPM_ABI_VERSION = 2
+GVPM_ABI_VERSION = 3
 
 # gvpm_status
 GVPM_OK = 0
@@ -247,4 +247,4 @@ class DevgenScene(C.Structure):
                 ("medium", Medium), ("cam_pos", C.c_double * 3), ("tan_half_fov_x", C.c_double),
                 ("width", C.c_int32), ("height", C.c_int32), ("seed", C.c_uint32), ("camera_inside", C.c_int32),
                 ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("min_depth", C.c_int32),
-                ("camera_sphere", C.c_double)]
+                ("camera_sphere", C.c_double), ("cam_to_world", C.c_double * 9)]

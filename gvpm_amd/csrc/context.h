@@ -36,6 +36,9 @@ void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint
                     const NearGrid &ng, uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
                     uint32_t *origIdx, const uint32_t *sub, uint32_t ncells, hipStream_t s);
 void launch_apply_host_shifts(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s);
+// the exact pass over the shifts the evaluation deferred (exact_shift.hip); totals: {evaluated, lost}
+void launch_exact_pass(const GatherArgs &a, unsigned long long *totals, uint32_t *hostOut, hipStream_t s);
+void launch_capture_notes(const GatherArgs &a, hipStream_t s);
 void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
                       hipStream_t s);
 void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,
@@ -308,13 +311,31 @@ struct gvpm_context {
   DevBuf<float4> reqCtx;
   DevBuf<uint32_t> reqCount;
   DevBuf<gvpm_host_shift> reqResults;
+  // The exact pass (exact_shift.hip; ExEntry in device_types.h): the entries outlive the gathers; the pass runs on the
+  // gather stream when something reads or rescales the sums (gvpm_join_exact: downloads, statistics, all-reduce, a new
+  // scene / medium / BSDF table, another technique) and every exFlushEvery gathers.  exTotals: {evaluated, lost, largest
+  // list, -, by cause ...}.
+  DevBuf<ExEntry> exPay;
+  DevBuf<uint32_t> exPayCount;       // {entries, lost notes, ticket}
+  // the notes of a gather ({count, ticket} + list).  Their copy kernel runs on the gather stream behind the evaluation
+  // (measured at C2: ~25 us of the step; on a stream of its own, ordered by events, the step LOST 6 %)
+  DevBuf<uint4> exOvf;
+  DevBuf<uint32_t> exOvfCount;
+  DevBuf<unsigned long long> exTotals;
+  uint32_t exPayCap = 1u << 20;      // 512 MB, allocated with the first gather that can defer
+  uint32_t exOvfCap = 1u << 18;
+  uint32_t exSince = 0;              // gathers since the last pass
+  uint32_t exFlushEvery = 8;         // paced by what the last pass found (pinExact[0]): the list is kept below a quarter full
+  bool exFlushFixed = false;         // GVPM_EXACT_EVERY
+  uint32_t exSinceAtLast = 8;        // gathers the last pass covered
+  uint32_t *pinExact = nullptr;      // pinned: {entries the last pass found}
   bool reqOutstanding = false;   // a gather recorded requests that were neither answered nor written off yet
   bool reqBeams = false;         // ... of a G-Beams gather (five float4 of context a request, its own apply kernel)
   GatherArgs reqArgs;            // of that gather (medium, film, iteration scale)
   DevBuf<gvpm_material> materials;  // gvpm_upload_materials: the table the packed photon records index
   uint32_t nmaterials = 0;
   std::vector<gvpm_material> materialsHost;  // what the device table holds (append-only growth needs no stream sync)
-  DevBuf<float4> bsdfs;             // gvpm_upload_bsdfs: 2 float4 per glossy surface BSDF
+  DevBuf<float4> bsdfs;             // gvpm_upload_bsdfs: 4 float4 per glossy surface BSDF (device_types.h, GatherArgs::bsdfs)
   uint32_t nbsdfs = 0;
   gvpm_sensor sensor{};             // gvpm_upload_sensor: what the compact beam sets are decoded with
   bool haveSensor = false;
@@ -451,6 +472,8 @@ void launch_unpack_compact_rays(const gvpm_sensor &sensor, const uint32_t *compa
 }  // namespace gvpm
 
 // shared between the files above
+// runs the exact pass over the deferred shifts, if a gather may have left any (before anything reads or rescales the sums)
+int gvpm_join_exact(gvpm_context *h);
 int flushHostShifts(gvpm_context *h);  // unanswered shift requests become failed shifts (before anything reads the film)
 float currentRadius(const gvpm_context *h);
 

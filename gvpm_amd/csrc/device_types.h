@@ -102,6 +102,28 @@ struct MediumDev {
   float g, msw;
 };
 
+// The exact pass (exact_shift.hip).  A shift (or pair) the fp32 kernels cannot decide is NOTED as {set | sample, record,
+// meta, -} -- meta = kind | shift << 8 | cause << 16: one atomic and one 16-byte store in the hot loops.  A small copy
+// kernel behind the gather's kernels (capture_notes_kernel: 16 registers, one workgroup) turns the notes into
+// self-contained 512-byte entries -- everything the evaluation reads of the gather: the record, the five rays, radius,
+// output scale -- which outlive the gather's buffers; the pass itself (fp64, 128 registers a lane) runs when something
+// reads the sums.  Measured at C2: the pass behind every evaluation waits for registers the other streams' persistent
+// kernels hold, +5 % on the step; entries written where the shift is deferred, or through per-wave LDS lists, cost the
+// evaluation's loops registers: +3 % and +17 %.
+#define GVPM_EX_KIND_BRE 0u        /* one shift of a G-BRE pair */
+#define GVPM_EX_KIND_BRE_PAIR 1u   /* a whole G-BRE pair whose HIT the fp32 bands could not decide */
+#define GVPM_EX_KIND_VPM 2u
+#define GVPM_EX_KIND_BEAMS 3u
+struct ExEntry {
+  uint32_t meta, pad0;       // kind | shift << 8 | cause << 16
+  float outScale;            // what the fast kernel multiplies the shift's two sums by when it adds them (G-BRE: 1 / nb_paths)
+  float radius;              // kernel radius of the pair (G-VPM: the pixel's own)
+  float4 rec[GVPM_REC_QUADS];  // the photon's (G-Beams: the beam's) 128-byte record
+  gvpm_camera_ray rays[5];   // the beam set
+  float4 extra[3];           // per technique
+};
+static_assert(sizeof(ExEntry) == 512, "ExEntry is 512 bytes");
+
 struct GatherArgs {
   // photons
   const float4 *hot;
@@ -158,6 +180,16 @@ struct GatherArgs {
   const uint32_t *vpmOrder;
   uint32_t vpmOrderN;        // entries of vpmOrder (a permutation of the last launch's batches; the counts may differ a little)
   uint32_t *vpmCostKey, *vpmCostVal;
+  // Shifts the fp32 kernels could not DECIDE as the reference does (a comparison inside its rigorous error margin): nothing
+  // is added or counted for them by the fast kernels.  exOvf / exOvfCount {count, ticket}: this gather's notes; exPay /
+  // exPayCount {entries, lost notes, ticket}: the exact pass's entries (see ExEntry).  The counters keep counting past
+  // the capacities: the excess is reported as dropped pairs (gvpm_get_stats fails).
+  ExEntry *exPay;
+  uint32_t *exPayCount;
+  uint32_t exPayCap;
+  uint4 *exOvf;
+  uint32_t *exOvfCount;
+  uint32_t exOvfCap;
   // outputs
   float *iter;               // P * 27: this iteration's un-normalised sums (G-BRE: the running SUM over iterations)
   float iterScale;           // G-BRE: 1 / nb_paths of this iteration, applied when a partial sum is added

@@ -157,6 +157,32 @@ __device__ __forceinline__ void hitBand(f3 wv, float disk, float r, float r2f, f
 // band cannot change the reference's decision, otherwise by the reference predicate itself (fp64, uncontracted).
 // Returns 1 (hit), 0 (no hit) or 2: the band cannot decide -- about one candidate in 10^5 at C2, plus the photons
 // that project beyond the beam's end (the own-box test decides those) -- and exactHit() has to.
+// The photon's own sphere box [p - r, p + r] against the ray segment [mint, maxt] (ownBoxHit: what every ancestor box of the
+// reference's BVH implies) with fp32 error bands: 1 the slab test surely passes, 0 surely fails, 2 undecidable.  Only asked
+// for photons that project at or beyond the beam's END (about one candidate in a thousand): between the ends the point of
+// closest approach lies in the sphere, hence in the box, and the test passes by construction.
+__device__ __forceinline__ int ownBoxBand(f3 p, f3 o, f3 d, float r, float mint, float maxt) {
+  float nearT = -INFINITY, farT = INFINITY, eN = 0.f, eF = 0.f;
+  bool open = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float pk = comp(p, k), ok = comp(o, k), dk = comp(d, k);
+    if (dk == 0.f) open = true;  // (the reference branches on an exactly zero component: the exact pass decides)
+    const float rc = frcp(dk);
+    float t1 = ((pk - r) - ok) * rc, t2 = ((pk + r) - ok) * rc;
+    const float lo = fminf(t1, t2), hi = fmaxf(t1, t2);
+    // numerators good to ~3 eps (|p| + |o| + r), the reciprocal to 1 ulp, the product to half an ulp
+    const float e = 4e-7f * (fabsf(pk) + fabsf(ok) + r) * fabsf(rc) + 2e-7f * (fabsf(lo) + fabsf(hi));
+    if (lo > nearT) { nearT = lo; eN = e; } else if (lo + e > nearT - eN) { eN = fmaxf(eN, e + (nearT - lo)); }
+    if (hi < farT) { farT = hi; eF = e; } else if (hi - e < farT + eF) { eF = fmaxf(eF, e + (hi - farT)); }
+  }
+  if (open || !(nearT == nearT) || !(farT == farT)) return 2;
+  const float mE = 2e-7f * (maxt + mint);
+  const bool fail = nearT - eN > farT + eF || farT + eF < mint - mE || nearT - eN > maxt + mE;
+  const bool pass = nearT + eN < farT - eF && farT - eF > mint + mE && nearT + eN < maxt - mE;
+  return pass ? 1 : (fail ? 0 : 2);
+}
+
 __device__ __forceinline__ int decidePair(f3 pos, const RayReg &base, float rnd, float r, float eps, bool use3D) {
   const float r2f = r * r, mint = eps, maxt = base.len - eps;
   const f3 wv = pos - base.o;
@@ -165,9 +191,15 @@ __device__ __forceinline__ int decidePair(f3 pos, const RayReg &base, float rnd,
   const float d2 = dot(v, v);
   float E, band;
   hitBand(wv, disk, r, r2f, E, band);
-  const bool in0 = d2 < r2f - band && disk > mint + E && disk < maxt - E;
+  bool in0 = d2 < r2f - band && disk > mint + E && disk < maxt - E;
   // surely outside: beyond the band of the disk test (the own-box test can only remove more)
   bool outside = d2 > r2f + band || disk < mint - E;
+  if (!outside && disk >= maxt - E && d2 < r2f - band) {
+    // at or beyond the beam's end: the own-box test decides (round 5: with bands, here, instead of in fp64 later)
+    const int bx = ownBoxBand(pos, base.o, base.d, r, mint, maxt);
+    in0 = bx == 1;
+    outside = bx == 0;
+  }
   bool in = in0;
   if (use3D) {
     // t' = (disk - deltaT) + 2 deltaT rnd must lie in [mint, len]: bracket it with deltaT in [dTlo, dTup]
@@ -178,6 +210,34 @@ __device__ __forceinline__ int decidePair(f3 pos, const RayReg &base, float rnd,
     const float tHi = (disk - dTlo) + 2.f * dTup * rnd + slop;
     in = in0 && tLo > mint && tHi < base.len;
     outside = outside || (in0 && (tHi < mint || tLo > base.len));
+  }
+  return in ? 1 : (outside ? 0 : 2);
+}
+// The same decision for a candidate the bands above left open -- almost all of them at the RIM of the kernel: the band of d2
+// is 4 r E with E the rounding of O(1) coordinate differences, 1e-3 of r^2 -- with the difference vector and the projection
+// formed in fp64, as baseTerms forms them, and the perpendicular offset as a small fp32 vector: d2 to ~4e-7 relative, disk
+// and t' to ~1e-15.  What is still inside THAT band (~1e-6 of the candidates) goes to the exact pass.
+__device__ __forceinline__ int decidePairFine(f3 pos, const RayReg &base, float rnd, float r, float eps, bool use3D) {
+  const d3 wD = tod(pos) - tod(base.o), bdD = tod(base.d);
+  const double disk = dot(wD, bdD);
+  const f3 perp = tof(wD - bdD * disk);
+  const float d2 = dot(perp, perp), r2f = r * r;
+  const float band = 2e-6f * r2f;
+  const double mint = (double)eps, maxt = (double)base.len - (double)eps, tE = 1e-12 * (1.0 + fabs(disk));
+  bool in0 = d2 < r2f - band && disk > mint + tE && disk < maxt - tE;
+  bool outside = d2 > r2f + band || disk < mint - tE;
+  if (!outside && disk >= maxt - tE && d2 < r2f - band) {
+    const int bx = ownBoxBand(pos, base.o, base.d, r, eps, base.len - eps);
+    in0 = bx == 1;
+    outside = bx == 0;
+  }
+  bool in = in0;
+  if (use3D) {
+    const float q = r2f - d2;
+    const double dTup = (double)(fsqrt(fmaxf(q + band, 0.f)) * 1.000001f), dTlo = (double)(fsqrt(fmaxf(q - band, 0.f)) * 0.999999f);
+    const double tLo = (disk - dTup) + 2.0 * dTlo * (double)rnd - tE, tHi = (disk - dTlo) + 2.0 * dTup * (double)rnd + tE;
+    in = in0 && tLo > mint && tHi < (double)base.len;
+    outside = outside || (in0 && (tHi < mint || tLo > (double)base.len));
   }
   return in ? 1 : (outside ? 0 : 2);
 }
@@ -235,8 +295,18 @@ __device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const LDS &s
   return t;
 }
 
+
+
 // phase 1: base contribution + the four shift attempts of one pair; reconnections are returned in qMask
 // (HS: manifold-typed shifts are recorded for the host, gvpm_enable_host_shifts -- its own instantiation of the kernel)
+// A shift whose branch fp32 cannot decide as the reference does (round 5) -- the null-shift test |z' - y|^2 < r^2 or t'
+// against the shifted edge's length within the error band of the fp32 quantities (branchAmbiguous) -- adds nothing and
+// counts nothing here: it is QUEUED like a reconnection, and phase 2, which re-derives the test from the same numbers,
+// hands it to the exact pass (one deferral site in the kernel: its copy loops cost registers).
+__device__ __forceinline__ bool branchAmbiguous(const GatherArgs &a, float y2, float r2, float tPf, float shLen) {
+  // y is good to ~2e-7 |y| (the two differences are formed in fp64 / as exact fp32 differences), t' to half an ulp
+  return (a.cfg.use_shift_null && fabsf(y2 - r2) <= 4e-6f * r2) || fabsf(tPf - shLen) <= 4e-7f * (tPf + shLen);
+}
 template <int B, bool HS, typename LDS>
 __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const PhotonFront &ph, const RayReg &base,
                                            uint32_t b, Acc27 &acc, uint32_t &nNull, uint32_t &nFail, uint32_t &qMask) {
@@ -262,7 +332,9 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
     // photon relative to shiftRay(t') = (photon - baseRay(t')) - (shiftRay(t') - baseRay(t'))
     const f3 y = bt.rel - (sh.ro + sh.rd * tPf);
     // shiftNull, shift_volume_photon.cpp:119-158 with the kernel pdfs of :782-801
-    const bool isNull = sh.valid && a.cfg.use_shift_null && dot(y, y) < r2 && tPf < sh.len;
+    const float y2 = dot(y, y);
+    const bool ambBranch = sh.valid && !(HS && st == 3u) && branchAmbiguous(a, y2, r2, tPf, sh.len);
+    const bool isNull = !ambBranch && sh.valid && a.cfg.use_shift_null && y2 < r2 && tPf < sh.len;
     const f3 yp = y - sh.d * dot(y, sh.d);
     const float deltaS = fsqrt(fmaxf(0.f, r2 - dot(yp, yp)));
     const float pdfShiftPos = frcp(fmaxf(2.f * deltaS, 0.0001f));
@@ -273,15 +345,15 @@ __device__ __forceinline__ void evalPhase1(const GatherArgs &a, LDS &s, const Ph
                   : frcp(1.f + sh.sMIS * pdfShiftPos * frcp(bt.pdfCam));
     const f3 nullFlux = photonIn * (bt.tr * phaseEval(a.med.g, ph.wi, -sh.d)) * sh.eye;
     // shiftPhoton dispatch, shift_volume_photon.cpp:49-117: reconnections go to phase 2
-    const bool wantsShift = sh.valid && !isNull && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL;
+    const bool wantsShift = !ambBranch && sh.valid && !isNull && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL;
     // (a manifold-typed photon goes to phase 2 as well when the host answers such shifts: it records the request there)
     const bool queued = wantsShift && (st == 1u || st == 2u || (HS && st == 3u));
     nNull += isNull ? 1u : 0u;
     nFail += (wantsShift && !queued) ? 1u : 0u;
-    qMask |= queued ? (1u << i) : 0u;
+    qMask |= (queued || ambBranch) ? (1u << i) : 0u;
     float w = isNull ? wNull : 1.f;
     borderRule(a, pix, i, w);
-    const float keep = queued ? 0.f : 1.f;         // a queued shift adds nothing here
+    const float keep = (queued || ambBranch) ? 0.f : 1.f;  // a queued / deferred shift adds nothing here
     const float ws = isNull ? w * bt.scale : 0.f;  // only the null shift has a shifted flux in phase 1
     acc.v[3 + 3 * i + 0] += nullFlux.x * ws;
     acc.v[3 + 3 * i + 1] += nullFlux.y * ws;
@@ -406,6 +478,12 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
 
   const f3 basePt = base.o + base.d * (float)tPrime;  // baseRay(t'), absolute (for the segment to the parent)
   const f3 dS = sr.ro + sr.rd * (float)tPrime;  // shiftRay(t') - baseRay(t')
+  // phase 1's branch test from phase 1's numbers (evalPhase1): an undecidable branch was queued to be deferred here
+  uint32_t amb = 0u;
+  if (!(HS && GVPM_PF_SHIFT_TYPE(ph.bits) == 3u)) {
+    const f3 y = rel - dS;
+    amb = branchAmbiguous(a, dot(y, y), r2, (float)tPrime, sh.len) ? 2u : 0u;
+  }
   // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
   f3 offRel = rel;
   if (!use3D) {
@@ -416,7 +494,10 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   }
   if (a.cfg.use_shift_null) {
     const f3 bo = dS + offRel;       // offsetPos - baseRay(t')
-    const float cosD2 = dot(bo, bo) < r2 ? -2.f * dot(dS, offRel) * frcp(dot(dS, dS)) : 0.f;
+    const float bo2 = dot(bo, bo);
+    // (the mirror decision of getShiftPos moves the offset position by up to 2 r: not a counter, but a different shift)
+    amb |= fabsf(bo2 - r2) <= (use3D ? 4e-6f : 2e-5f) * r2 ? 8u : 0u;
+    const float cosD2 = bo2 < r2 ? -2.f * dot(dS, offRel) * frcp(dot(dS, dS)) : 0.f;
     offRel = offRel + dS * cosD2;
   }
   float pdfShiftPos = 1.f;
@@ -441,8 +522,15 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   bool ok = false;
   f3 sflux;
   const f3 dProjU = ((basePt + dS) - ph.parentPos) + offRel;  // offsetPos - parent
+  uint32_t ambVis = 0u;
   float w = shiftDiffuse<FULLVIS>(a, ph, ph.bits, dProjU, sh, base, s.edge[b], trT, pdfCam, pdfShiftPos, sflux, ok, ldsTri,
-                                 sr.sMIS);
+                                 sr.sMIS, &ambVis);
+  if (amb | ambVis) {
+    // fp32 cannot decide this shift as the reference does: the exact pass evaluates it (nothing added, nothing counted)
+    deferNote(a, GVPM_EX_KIND_BRE, a.setPerm[s.setBase + b], pidx, (uint32_t)i, amb | ambVis);
+    sf = wb = mk3(0.f);
+    return;
+  }
   if (ok) nDiff++; else nFail++;
   borderRule(a, s.pix[b], i, w);
   const float ws = w * scale;
@@ -779,7 +867,6 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
 #endif
 constexpr int SEG_STEPS = 16;   // steps per segment (4 bits of a queue entry)
 constexpr int SEG_QCAP = 1024;  // queue entries per wave; a step appends at most 4 * 64
-constexpr int SEG_AMB = 128;    // undecided pairs per segment; a step appends at most 64
 template <int B> struct SegCfg {
   // waves per workgroup: they share nothing but the staged occluders
   static constexpr int WPB = B == 16 ? 4 : (B == 32 ? 2 : 1);
@@ -790,7 +877,6 @@ template <int B> struct SegLds : RayTile<B> {
   double acc[27][B];
   uint32_t boff[B + 1];
   typename SegCfg<B>::Entry q[SEG_QCAP];  // step | lane | shift | beam
-  uint16_t amb[SEG_AMB];                  // pairs the fp32 band could not decide: step << 6 | lane
   uint32_t setBase;                       // of the item (host-shift requests name the beam set)
   // (the shifted rays are kept RELATIVE to their base ray in the ray tile's own slots, with sensorMIS: relToBase)
 };
@@ -918,33 +1004,24 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
       while (s.boff[cur + 1] <= g0) cur++;
 
     for (uint32_t tSeg = 0; tSeg < chunk;) {
-      uint32_t tEnd = tSeg;  // first step of the next segment
-      uint32_t nLate = 0;    // undecided pairs of the segment that the reference predicate accepted
-      uint32_t curKeep = cur;
-      // pass 0: the segment's pairs; pass 1 (rare): its undecided pairs that exactHit() accepted.  Both passes run
-      // the SAME two loops, so the kernel holds one copy of either phase.
-      for (int pass = 0; pass < 2; ++pass) {
-        const bool late = pass == 1;
+      // One pass per segment (round 5): a pair whose HIT the fp32 bands cannot decide (decidePair: ~1e-5 of the candidates)
+      // goes to the exact pass behind this kernel (exact_shift.hip, GVPM_EX_KIND_BRE_PAIR: the reference predicate, the base
+      // term and the four shifts in fp64) instead of through an fp64 predicate and a second round of both loops in here.
+      {
         // ---- decision + phase 1 ----
-        uint32_t qn = 0, an = 0;  // wave-uniform
+        uint32_t qn = 0;  // wave-uniform
         Acc27 acc;
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc.v[k] = 0.f;
         bool dirty = false;  // acc holds sums of beam `cur`
-        const uint32_t tLim = late ? tSeg + (nLate + 63u) / 64u : chunk;
+        const uint32_t tLim = chunk;
         uint32_t t = tSeg;
-        // the pair of a lane at step tt: entry g of the concatenated lists (or a late pair), its beam, its photon index.
+        // the pair of a lane at step tt: entry g of the concatenated lists, its beam, its photon index.
         // The index of step t + 1 is fetched while step t computes: one dependent global load less per step.
         auto locate = [&](uint32_t tt, uint32_t from, bool &hv, uint32_t &gg, uint32_t &bb, uint32_t &pi) {
           gg = g0 + tt;
           hv = gg < g1 && tt < tLim;
-          if (late) {
-            const uint32_t li = (tt - tSeg) * 64u + (uint32_t)lane;
-            hv = li < nLate && tt < tLim;
-            const uint32_t e = s.amb[hv ? li : 0u];
-            gg = r0 + min(n, (e & 63u) * chunk) + tSeg + (e >> 6);
-          }
-          bb = late ? 0u : from;  // (a lane's own pairs come in ascending beam order)
+          bb = from;  // (a lane's own pairs come in ascending beam order)
           pi = 0u;
           if (hv) {
             while (s.boff[bb + 1] <= gg) bb++;
@@ -961,7 +1038,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           locate(t + 1u, bN, haveB, gB, bB, pidxB);
           phN = loadFront(a, pidxN);  // (index 0 when the lane has no pair: a valid record, not used)
         }
-        for (; t < tLim && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP && an + 64u <= (uint32_t)SEG_AMB; ++t) {
+        for (; t < tLim && t - tSeg < (uint32_t)SEG_STEPS && qn + 256u <= (uint32_t)SEG_QCAP; ++t) {
           [[maybe_unused]] const unsigned long long l0 = LTICK();
           const bool have = haveN;
           const uint32_t b = bN, pidx = pidxN;
@@ -976,7 +1053,6 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
           [[maybe_unused]] const unsigned long long l1 = LTICK();
           tk[7] += l1 - l0;
           uint32_t qMask = 0;
-          bool undecided = false;
           [[maybe_unused]] unsigned long long l2 = l1, l3 = l1;
           if (have) {
             if (b != cur) {
@@ -987,8 +1063,8 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             l2 = LTICK();
             const PhotonFront ph = PF ? phCur : loadFront(a, pidx);
             const RayReg base = loadRay(s, 0, cur);
-            const int dec = late ? 1 : decidePair(ph.pos, base, s.rnd[cur], a.radius, a.cfg.epsilon, use3D);
-            undecided = dec == 2;
+            int dec = decidePair(ph.pos, base, s.rnd[cur], a.radius, a.cfg.epsilon, use3D);
+            if (dec == 2) dec = decidePairFine(ph.pos, base, s.rnd[cur], a.radius, a.cfg.epsilon, use3D);
 #ifdef GVPM_EVAL_TIMING
             asm volatile("" :: "v"(dec));
             l3 = LTICK();
@@ -997,12 +1073,10 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
               evalPhase1<B, HS>(a, s, ph, base, cur, acc, nNull, nFail, qMask);
               dirty = true;
               nEval++;
+            } else if (dec == 2) {
+              // the bands cannot decide this pair: the exact pass takes it whole (predicate, base term, four shifts)
+              deferNote(a, GVPM_EX_KIND_BRE_PAIR, a.setPerm[s.setBase + cur], pidx, 0u, 1u);
             }
-          }
-          {
-            const unsigned long long m = __ballot(undecided);
-            if (undecided) s.amb[an + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(((t - tSeg) << 6) | (uint32_t)lane);
-            an += (uint32_t)__popcll(m);
           }
           const uint32_t ent = ((t - tSeg) << (8 + BB)) | ((uint32_t)lane << (2 + BB)) | cur;
 #pragma unroll
@@ -1017,10 +1091,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
 #endif
         }
         if (dirty) flushAcc<B>(s, acc, cur);
-        if (!late) {
-          tEnd = t;
-          curKeep = cur;  // the late pass visits beams in any order: the walk resumes from here
-        }
+        const uint32_t tEnd = t;  // first step of the next segment
         waveLdsSync();
         { [[maybe_unused]] const unsigned long long tn = TICK(); tk[2] += tn - tMark; tMark = tn; }
         // ---- phase 2 over the queue: lane l takes entries [l * cq, (l + 1) * cq) ----
@@ -1037,12 +1108,7 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
             const uint32_t e = s.q[e0 + j];
             bo = e & ((1u << BB) - 1u);
             io = (e >> BB) & 3u;
-            uint32_t ln = (e >> (2 + BB)) & 63u, ts = e >> (8 + BB);
-            if (late) {
-              const uint32_t e2 = s.amb[ts * 64u + ln];
-              ln = e2 & 63u;
-              ts = e2 >> 6;
-            }
+            const uint32_t ln = (e >> (2 + BB)) & 63u, ts = e >> (8 + BB);
             const uint32_t g = r0 + min(n, ln * chunk) + tSeg + ts;
             pi = lists[(size_t)bo * cap + (g - s.boff[bo])];
             k2o = (bo << 2) | io;
@@ -1087,34 +1153,8 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
         }
         waveLdsSync();
         { [[maybe_unused]] const unsigned long long tn = TICK(); tk[3] += tn - tMark; tMark = tn; }
-        if (late || an == 0u) break;
-        // ---- the undecided pairs: the reference predicate (fp64, uncontracted); the accepted ones are compacted
-        // in place into the late list and go through the two loops above once more ----
-        for (uint32_t j0 = 0; j0 < an; j0 += 64u) {
-          const uint32_t j = j0 + (uint32_t)lane;
-          bool ok = false;
-          uint32_t e = 0;
-          if (j < an) {
-            e = s.amb[j];
-            const uint32_t g = r0 + min(n, (e & 63u) * chunk) + tSeg + (e >> 6);
-            uint32_t b = 0;
-            while (s.boff[b + 1] <= g) b++;
-            const uint32_t pidx = lists[(size_t)b * cap + (g - s.boff[b])];
-            const float4 c0 = a.cold[(size_t)pidx * GVPM_REC_QUADS];
-            const RayReg base = loadRay(s, 0, b);
-            ok = exactHit(mk3(c0.x, c0.y, c0.z), base.o, base.d, base.len, a.radius, s.rnd[b], a.cfg.epsilon, use3D);
-          }
-          const unsigned long long m = __ballot(ok);
-          waveLdsSync();  // every lane has read its entry before the compacted ones are written over the list
-          if (ok) s.amb[nLate + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)e;
-          nLate += (uint32_t)__popcll(m);
-        }
-        waveLdsSync();
-        { [[maybe_unused]] const unsigned long long tn = TICK(); tk[4] += tn - tMark; tMark = tn; }
-        if (nLate == 0u) break;
+        tSeg = tEnd;
       }
-      tSeg = tEnd;
-      cur = curKeep;
     }
     // ---- write out: 27 partial sums per beam set into the running sum ----
     for (int idx = lane; idx < 27 * B; idx += 64) {

@@ -366,8 +366,50 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
   a.vpmOrder = nullptr;
   a.vpmOrderN = 0;
   a.vpmCostKey = a.vpmCostVal = nullptr;
+  a.exPay = h->exPay.p;
+  a.exPayCount = h->exPayCount.p;
+  a.exPayCap = h->exPay.p ? h->exPayCap : 0u;
+  a.exOvf = h->exOvf.p;
+  a.exOvfCount = h->exOvfCount.p;
+  a.exOvfCap = a.exOvf ? h->exOvfCap : 0u;
 }
 
+// The exact pass over the shifts the gathers deferred (exact_shift.hip): on the gather stream, when a reader asks
+// (gvpm_join_exact) or every exFlushEvery gathers.
+int gvpm_join_exact(gvpm_context *h) {
+  if (h->exSince == 0) return GVPM_OK;
+  GatherArgs a;
+  fillArgs(h, a, 0.f);
+  a.hot = a.cold = nullptr;
+  a.rays = nullptr;
+  a.iter = h->accum.p;
+  launch_exact_pass(a, h->exTotals.p, h->pinExact, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  h->exSinceAtLast = h->exSince;
+  h->exSince = 0;
+  return GVPM_OK;
+}
+// before a gather that can defer: the lists exist; after its kernels have been queued: the cadence
+static int exactPrepare(gvpm_context *h) {
+  HIP_TRY(h, h->exPay.reserveExact(h->exPayCap));
+  HIP_TRY(h, h->exOvf.reserveExact(h->exOvfCap));
+  if (!h->pinExact) {
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinExact, 64, hipHostMallocMapped));
+    h->pinExact[0] = 0xFFFFFFFFu;  // (no pass has reported yet)
+  }
+  return GVPM_OK;
+}
+static int exactAfterGather(gvpm_context *h) {
+  if (!h->exFlushFixed && h->pinExact[0] != 0xFFFFFFFFu) {
+    // what the last pass found per gather it covered (read without waiting: a stale number only delays the adjustment)
+    const uint32_t perGather = h->pinExact[0] / std::max(1u, h->exSinceAtLast) + 1u;
+    h->exFlushEvery = std::max(1u, std::min(256u, (h->exPayCap / 4u) / perGather));
+    static const bool trace = getenv("GVPM_TRACE_EXACT") != nullptr;
+    if (trace) fprintf(stderr, "[exact] last pass found %u entries over %u gathers -> a pass every %u gathers (since %u)\n", h->pinExact[0], h->exSinceAtLast, h->exFlushEvery, h->exSince);
+  }
+  if (++h->exSince >= h->exFlushEvery) return gvpm_join_exact(h);
+  return GVPM_OK;
+}
 static int nextEvents(gvpm_context *h, std::pair<hipEvent_t, hipEvent_t> **ev, int phase = 0) {
   // HIP events on the handle's stream bracket the dominant kernel (roofline.achieved) and the other phases
   // a ring of at most GVPM_EVENT_RING pairs per phase: a host that never polls gvpm_get_phase_time keeps the timings of
@@ -411,9 +453,13 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   if (h->sumIt != 0 && it - 1 != h->sumIt) {
     // not the successor of the last iteration: the reference's fold (mean * (it - 1) + v) / it then weighs the old
     // mean by (it - 1) / it, i.e. the sum by (it - 1) / last
+    rc = gvpm_join_exact(h);
+    if (rc != GVPM_OK) return rc;
     launch_scale(h->accum.p, h->accum.p, h->npix * 27, (float)((double)(it - 1) / (double)h->sumIt), h->stream);
   }
   h->sumIt = it;
+  rc = exactPrepare(h);
+  if (rc != GVPM_OK) return rc;
   bool rebuilt = false;
   GatherArgs a;
   uint32_t itemCap = 0, blocks = 0, nItems = 0;
@@ -584,6 +630,13 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
                       h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItems, h->persistentEval,
                       h->stream);
   HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
+  // the shifts and pairs the evaluation could not decide in fp32: their records and rays into the handle's list, where they
+  // wait for the exact pass
+  if (!primal) {
+    launch_capture_notes(a, h->stream);
+    rc = exactAfterGather(h);
+    if (rc != GVPM_OK) return rc;
+  }
   HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
   if (h->pipeline) {
     for (int k = 0; k < (h->travStream ? 3 : 2); ++k) {
@@ -768,7 +821,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
   a.nbeams = h->nph;
   a.nph = h->nsub;
   a.beamClear = h->beamClear.p;
-  if (primal) a.cfg.reserved[5] = 1;  // the evaluation stops after the kernel record's base term
+  a.cfg.reserved[5] = primal ? 1 : 0;  // the evaluation stops after the kernel record's base term
   std::pair<hipEvent_t, hipEvent_t> *ev;
   int rc = nextEvents(h, &ev);
   if (rc != GVPM_OK) return rc;
@@ -1124,6 +1177,11 @@ static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) 
   // the streams that read this step's host-uploaded inputs wait for their copies (copy stream)
   // (packed records are decoded here, at the head of the chain that reads them: G-BRE builds on the build stream)
   const bool breTech = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
+  if (!breTech || primal) {
+    // (these gathers fold iter[] into the sums on the gather stream: entries a G-BRE gather deferred are taken first)
+    const int rcj = gvpm_join_exact(h);
+    if (rcj != GVPM_OK) return rcj;
+  }
   hipStream_t us = breTech && h->pipeline ? h->streamB : h->stream, other = us == h->stream ? h->streamB : h->stream;
   if (h->phWait) {
     gvpm_context::PhotonSlot &ps = h->phSlot[h->phCur];

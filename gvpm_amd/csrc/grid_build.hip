@@ -261,11 +261,26 @@ __device__ __forceinline__ void nearVisit(f3 P, const float4 *bvh, const float4 
 // triangles (coplanar with the parent to position rounding, normal parallel to the parent's) were 95 % of S-cbox's list
 // entries: every evaluation wave walked the any-hit loop for tests that cannot succeed.  A medium parent has no normal
 // (zero): nothing is skipped for it.
+// Round 5 -- the skip derived from the segment instead of a tolerance.  The parent's fp32 position lies delta = N . (P - a)
+// off the triangle's plane (rounding: 0 for an axis-aligned wall, a few 1e-7 either way for a tilted one); a segment
+// along an admissible direction d (n_parent . d > 0: the sign test and the cosine tests of the reconnection) meets that
+// plane at t_self = -delta / (N . d).  With the parent ON the plane or on the side its normal points to, t_self <= 0 for
+// every admissible d: the wall can never be hit and is left out.  With the parent BEHIND the plane, directions within
+// |delta| / Epsilon of grazing meet it at t_self >= Epsilon -- the reference's rayIntersect reports that self-hit
+// (shift_volume_photon.cpp:396-398) -- so the wall STAYS in the list and the evaluation decides (triHitChecked,
+// shift_device.h: fp64 where fp32 cannot tell).  delta's sign is pure rounding noise of the inputs: it is taken in fp64
+// from the fp32 data, as the oracle's (and a double-precision reference's) Moeller-Trumbore sees it.
 __device__ __forceinline__ bool ownWall(f3 P, f3 pn, const float4 *tri4, uint32_t i) {
   const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
   const f3 a = mk3(t0.x, t0.y, t0.z), n = mk3(t0.w, t1.w, t2.w);
   const float tol = 1e-6f * (1.f + fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + fabsf(a.x) + fabsf(a.y) + fabsf(a.z));
-  return fabsf(dot(n, pn)) > 0.99999f && fabsf(dot(n, P - a)) <= tol;
+  const float align = dot(n, pn);
+  if (!(fabsf(align) > 0.99999f && fabsf(dot(n, P - a)) <= tol)) return false;
+  // N = e1 x e2 and delta in fp64 (exact products of fp32 data up to the last additions: |error| ~ 1e-16 of O(1) terms)
+  const double e1x = t1.x, e1y = t1.y, e1z = t1.z, e2x = t2.x, e2y = t2.y, e2z = t2.z;
+  const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+  const double delta = nx * ((double)P.x - (double)a.x) + ny * ((double)P.y - (double)a.y) + nz * ((double)P.z - (double)a.z);
+  return align > 0.f ? delta >= 0.0 : delta <= 0.0;
 }
 
 template <int MODE>
@@ -697,6 +712,17 @@ __device__ __forceinline__ BeamClearTri beamClearTri(const float p1[3], const fl
   // the beam's line through the triangle (Moeller-Trumbore from p1 along bd, with slack: a near miss is a hit here)
   const float nrm[3] = {t0.w, t1.w, t2.w};
   const float cn = dot3(bd, nrm), dn = dot3(a, nrm);  // plane: nrm . (x - v0) = 0, a = v0 - p1
+  // The wall the beam STARTS on (p1 within position rounding of the plane; round 5): p1 may lie a few 1e-7 BEHIND it, and a
+  // new beam within |delta| / Epsilon (~ 4e-3 rad) of grazing then meets the plane at t >= Epsilon -- the reference's
+  // rayIntersect reports that hit (shift_volume_beams.cpp:420-426).  The cone such a wall leaves free is drawn 0.02 rad
+  // inside its plane: reconnections in the sliver take the any-hit loop, where triHitChecked decides them in fp64.
+  {
+    const float scale = fabsf(p1[0]) + fabsf(p1[1]) + fabsf(p1[2]) + fabsf(t0.x) + fabsf(t0.y) + fabsf(t0.z);
+    if (fabsf(dn) <= 2e-6f * (1.f + scale) && o.cosT < 1.f) {
+      const float sinT = sqrtf(fmaxf(1.f - o.cosT * o.cosT, 0.f));
+      o.cosT = fminf(1.f, o.cosT * 0.9998f + sinT * 0.02f);  // cos(angle - 0.02)
+    }
+  }
   o.alongMin = -INFINITY;
   // The pierce test runs at ANY incidence: a line that crosses a large triangle at a grazing angle (|cn| <= 0.05) sees it
   // under angle 0 although every edge is far off axis -- filed under "others" with the edges' cosine, such a triangle let

@@ -95,6 +95,9 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_SLAB_LAYERS")) h->cfg.reserved[1] = atoi(e);
   h->cfg.reserved[2] = 0;  // slab layers per step when x is the major axis (0 = default)
   if (const char *e = getenv("GVPM_SLAB_LAYERS_X")) h->cfg.reserved[2] = atoi(e);
+  // (every reserved word is the library's: a caller's struct that was never zeroed must not switch anything -- reserved[5]
+  // is the G-Beams primal pass's flag, set per launch by its driver)
+  h->cfg.reserved[4] = h->cfg.reserved[5] = 0;
   h->cfg.reserved[3] = 0;  // G-BRE traversal: staged photons per box row set from which the staging is lane-coalesced (0 = default)
   if (const char *e = getenv("GVPM_COALESCE_AT")) h->cfg.reserved[3] = atoi(e);
   if (const char *e = getenv("GVPM_PLAN_TARGET")) {
@@ -148,6 +151,13 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
     const long long v = atoll(e);
     if (v >= 1 && v <= ((long long)1 << 30)) h->beamItemsInit = (uint32_t)v;
   }
+  if (const char *e = getenv("GVPM_EXACT_EVERY")) {  // gathers between two exact passes (probes)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 1000000) {
+      h->exFlushEvery = (uint32_t)v;
+      h->exFlushFixed = true;
+    }
+  }
   if (const char *e = getenv("GVPM_CELL_SCALE")) {
     float v = (float)atof(e);
     if (v >= 0.25f && v <= 8.f) h->cellScale = v;
@@ -156,7 +166,8 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (h->accum.ensure(h->npix * 27) != hipSuccess || h->iter.ensure(h->npix * 27) != hipSuccess ||
       h->stats.ensure(8 * GVPM_STAT_ROWS) != hipSuccess || h->scaleVol.ensure(h->npix) != hipSuccess ||
       h->nVol.ensure(h->npix) != hipSuccess || h->mvol.ensure(h->npix) != hipSuccess ||
-      h->maxScaleBits.ensure(2) != hipSuccess) {
+      h->maxScaleBits.ensure(2) != hipSuccess || h->exTotals.ensure(32) != hipSuccess ||
+      h->exPayCount.ensure(4) != hipSuccess || h->exOvfCount.ensure(4) != hipSuccess) {
     gvpm_destroy(h);
     return GVPM_ERR_HIP;
   }
@@ -211,7 +222,9 @@ int gvpm_destroy(gvpm_context *h) {
   h->accumTmp.release();
   h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
+  h->exPay.release(); h->exPayCount.release(); h->exOvf.release(); h->exOvfCount.release(); h->exTotals.release();
   if (h->pinB6) (void)hipHostFree(h->pinB6);
+  if (h->pinExact) (void)hipHostFree(h->pinExact);
   if (h->pinBeams) (void)hipHostFree(h->pinBeams);
   h->splitId.release(); h->splitMeta.release(); h->splitBlkCnt.release(); h->splitCtl.release(); h->splitK.release();
   h->splitU.release(); h->splitRuns.release();
@@ -224,6 +237,19 @@ int gvpm_destroy(gvpm_context *h) {
 
 int gvpm_reset(gvpm_context *h) {
   CHECK_H(h);
+  // Host-shift requests of a gather that were neither answered nor written off are DISCARDED: their base terms belong to
+  // the run that ends here (flushed later they would land in the zeroed accumulators).  The G-VPM batch order is the old
+  // run's too.
+  h->reqOutstanding = false;
+  h->reqBeams = false;
+  if (h->reqCount.p) HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
+  h->vpmOrderN = 0;
+  h->vpmLaunches = 0;
+  // (deferred shifts of the run that ends here are dropped with its sums)
+  HIP_TRY(h, hipMemsetAsync(h->exPayCount.p, 0, 4 * sizeof(uint32_t), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->exOvfCount.p, 0, 4 * sizeof(uint32_t), h->stream));
+  h->exSince = 0;
+  HIP_TRY(h, hipMemsetAsync(h->exTotals.p, 0, 32 * sizeof(unsigned long long), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->accum.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->stats.p, 0, 8 * GVPM_STAT_ROWS * sizeof(unsigned long long), h->stream));
   h->globalScaleVolume = h->cfg.initial_scale_volume;  // gvpm.cpp:291
@@ -251,6 +277,7 @@ int gvpm_reset(gvpm_context *h) {
 
 int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *t) {
   CHECK_H(h);
+  if (int rcj = gvpm_join_exact(h)) return rcj;  // (deferred shifts are evaluated against the scene they met)
   if (!t || (t->n && (!t->v0 || !t->e1 || !t->e2))) return fail(h, GVPM_ERR_INVALID_ARG, "null triangle arrays");
   // occluder BVH on the host; triangles packed {v0,n.x} {e1,n.y} {e2,n.z} in leaf order
   BvhBuild bvh;
@@ -295,6 +322,7 @@ int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *t) {
 
 int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *m) {
   CHECK_H(h);
+  if (int rcj = gvpm_join_exact(h)) return rcj;  // (deferred shifts are evaluated against the scene they met)
   if (!m) return fail(h, GVPM_ERR_INVALID_ARG, "null medium");
   // homogeneous.cpp:196-200: the balance strategy requires equal sigma_t across channels
   if (m->sigma_t[0] != m->sigma_t[1] || m->sigma_t[0] != m->sigma_t[2])
@@ -307,6 +335,7 @@ int gvpm_upload_medium(gvpm_context *h, const gvpm_medium *m) {
 
 int gvpm_upload_bsdfs(gvpm_context *h, const gvpm_bsdf *table, uint32_t n) {
   CHECK_H(h);
+  if (int rcj = gvpm_join_exact(h)) return rcj;  // (deferred shifts are evaluated against the scene they met)
   if (n && !table) return fail(h, GVPM_ERR_INVALID_ARG, "null bsdf table");
   if (n > (1u << 24)) return fail(h, GVPM_ERR_INVALID_ARG, "more than 2^24 bsdfs (the index travels as a float)");
   // four quads per entry: {kind, specular} {exponent | alpha, sampling weight, distribution, sample_visible} {eta, k.x} {k.yz}
@@ -332,9 +361,11 @@ int gvpm_upload_bsdfs(gvpm_context *h, const gvpm_bsdf *table, uint32_t n) {
     rows[4 * i + 2] = make_float4(b.eta[0], b.eta[1], b.eta[2], b.k[0]);
     rows[4 * i + 3] = make_float4(b.k[1], b.k[2], 0.f, 0.f);
   }
-  // once per scene: waits for whatever still reads the old table
+  // once per scene: waits for whatever still reads the old table (as gvpm_upload_materials does)
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->streamB));
+  if (h->streamC) HIP_TRY(h, hipStreamSynchronize(h->streamC));
+  if (h->copyStream) HIP_TRY(h, hipStreamSynchronize(h->copyStream));
   HIP_TRY(h, h->bsdfs.ensure(rows.size()));
   HIP_TRY(h, hipMemcpy(h->bsdfs.p, rows.data(), rows.size() * sizeof(float4), hipMemcpyHostToDevice));
   h->nbsdfs = n;
@@ -362,8 +393,28 @@ int gvpm_set_global_scale(gvpm_context *h, float s) {
   return GVPM_OK;
 }
 
+int gvpm_get_exact_shift_count(gvpm_context *h, uint64_t *evaluated, uint64_t *lost) {
+  CHECK_H(h);
+  if (int rcj = gvpm_join_exact(h)) return rcj;
+  unsigned long long v[32];
+  HIP_TRY(h, hipMemcpyAsync(v, h->exTotals.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (getenv("GVPM_TRACE_EXACT"))
+    fprintf(stderr, "[exact] evaluated %llu lost %llu largest list %llu; by cause: pair %llu branch %llu mirror %llu visibility %llu cosine %llu\n",
+            v[0], v[1], v[2], v[4], v[5], v[7], v[8], v[9]);
+  if (getenv("GVPM_TRACE_EXACT") && (v[16] | v[17] | v[18] | v[19] | v[20]))
+    fprintf(stderr, "[exact] visibility-caused, |cos| < .01 / .03 / .1 / .3 / more: surface parents %llu %llu %llu %llu %llu, medium parents %llu %llu %llu %llu %llu\n",
+            v[16], v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], v[25]);
+  if (getenv("GVPM_TRACE_EXACT") && (v[10] | v[11] | v[12] | v[13]))
+    fprintf(stderr, "[exact] pairs: other %llu, rim of the kernel %llu, beyond the beam's end %llu, t' at an end %llu\n", v[10], v[11], v[12], v[13]);
+  if (evaluated) *evaluated = v[0];
+  if (lost) *lost = v[1];
+  return GVPM_OK;
+}
+
 int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   CHECK_H(h);
+  if (int rcj = gvpm_join_exact(h)) return rcj;
   if (!out) return GVPM_ERR_INVALID_ARG;
   std::vector<unsigned long long> rows(8 * (size_t)GVPM_STAT_ROWS);
   HIP_TRY(h, hipMemcpyAsync(rows.data(), h->stats.p, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -417,7 +468,8 @@ static float accumScale(const gvpm_context *h) { return h->sumMode && h->sumIt >
 int gvpm_download_accum(gvpm_context *h, float *accum) {
   CHECK_H(h);
   {
-    const int rcf = flushHostShifts(h);
+    int rcf = flushHostShifts(h);
+    if (rcf == GVPM_OK) rcf = gvpm_join_exact(h);
     if (rcf != GVPM_OK) return rcf;
   }
   if (!accum) return GVPM_ERR_INVALID_ARG;
@@ -436,7 +488,8 @@ int gvpm_download_accum(gvpm_context *h, float *accum) {
 int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
   CHECK_H(h);
   {
-    const int rcf = flushHostShifts(h);
+    int rcf = flushHostShifts(h);
+    if (rcf == GVPM_OK) rcf = gvpm_join_exact(h);
     if (rcf != GVPM_OK) return rcf;
   }
   if (!accum_dev) return GVPM_ERR_INVALID_ARG;
@@ -448,7 +501,8 @@ int gvpm_download_accum_dev(gvpm_context *h, float *accum_dev) {
 // throughput | dx | dy planes into filmOut (device); emission already on the device or null
 static int filmToDevice(gvpm_context *h, int it, int reuse_primal, const float *emissionDev, float *out) {
   {
-    const int rcf = flushHostShifts(h);
+    int rcf = flushHostShifts(h);
+    if (rcf == GVPM_OK) rcf = gvpm_join_exact(h);
     if (rcf != GVPM_OK) return rcf;
   }
   const size_t n = h->npix * 3;
@@ -569,6 +623,7 @@ int gvpm_comm_init(gvpm_context *h, const void *id128, int rank, int world) {
 
 int gvpm_allreduce_accum(gvpm_context *h) {
   CHECK_H(h);
+  if (int rcj = gvpm_join_exact(h)) return rcj;
   if (!h->comm) return fail(h, GVPM_ERR_STATE, "gvpm_comm_init not called");
   // out of place: the per-rank running means keep their disjoint supports for later iterations
   HIP_TRY(h, h->accumAll.ensure(h->npix * 27));

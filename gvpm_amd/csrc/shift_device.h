@@ -34,31 +34,104 @@ __device__ __forceinline__ void mediumEval(const MediumDev &m, float dist, f3 &t
   tr = mk3(e);
 }
 
-// Moeller-Trumbore, triangle.h:109-145 + interval test skdtree.h:318-320 (branch-free: the tests of the
-// reference are and-ed; a zero determinant gives inf / NaN, which fail the comparisons like the early return)
-__device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt) {
+// Moeller-Trumbore, triangle.h:109-145 + interval test skdtree.h:318-320, in THREE states (round 5).
+//
+// The reference decides  det != 0, 0 <= u <= 1, v >= 0, u + v <= 1, mint <= t <= maxt  with u = A / C, v = B / C, t = T / C,
+// C = e1 . (d x e2), A = tvec . (d x e2), B = d . (tvec x e1), T = e2 . (tvec x e1), tvec = o - v0.  Here the four
+// barycentric comparisons are taken division-free on sg A, sg B, |C| (sg = sign C) and the interval test on the plane
+// distances of the segment's ends (see triHit3), each with a RIGOROUS fp32 error margin: with eps = 2^-24,
+// S = |o|_1 + |v0|_1, L1 = |e1|_1, L2 = |e2|_1 the rounding of the sums above (and the ~1e-7 the device's fp32 direction
+// is off the oracle's) is bounded by  errC <= 5 eps L1 L2,  errA <= 8 eps S L2,  errB <= 18 eps S L1;
+// the margins take 1e-6 ~ 17 eps.  Outside every margin the decision is the one exact arithmetic
+// on the same fp32 data takes -- the fp64 oracle's, and a double-precision reference's.  Inside one:
+//   TRI_AMB -- fp32 cannot tell.  The caller DEFERS the shift to the exact pass (exact_shift.hip: the reference's
+//   statement in uncontracted fp64), or, where no exact pass exists, takes bit 0: the plain fp32 decision.
+// The systematic case is a segment that STARTS within rounding of the triangle's plane -- a parent that fp32 left behind
+// the wall it sits on (grid_build.hip, ownWall) -- along a grazing direction: the plane distance of the start is pure
+// rounding residue and t >= mint is decided by it.  The generic near-threshold cases (a hit within 1e-6 of an edge) go the same way.
+#define GVPM_TRI_MISS 0
+#define GVPM_TRI_HIT 1
+#define GVPM_TRI_AMB 2  /* | fp32 decision in bit 0 */
+// s0 = n . (o - v0), sd = n . d with the stored unit normal (callers have them for the plane-side early-out).  The interval
+// test  mint <= t <= maxt  is the statement "the segment's ends lie on different sides of the triangle's plane":
+// e0 = s0 + sd mint and e1 = s0 + sd maxt, each good to mE ~ 5e-7 (|o|_1 + |v0|_1 + maxt) -- eight times tighter than the
+// same decision through T = e2 . (tvec x e1), whose rounding carries the triangle's extent.
+__device__ __forceinline__ int triHit3(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt, float oAbs1, float s0, float sd) {
   const f3 pvec = cross(d, e2);
-  const float det = dot(e1, pvec);
-  const float inv = frcp(det);
+  const float C = dot(e1, pvec);
   const f3 tvec = o - v0;
-  const float u = dot(tvec, pvec) * inv;
+  const float A = dot(tvec, pvec);
   const f3 qvec = cross(tvec, e1);
-  const float v = dot(d, qvec) * inv;
-  const float t = dot(e2, qvec) * inv;
-  return det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= mint && t <= maxt;
+  const float Bq = dot(d, qvec);
+  const float L1 = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z), L2 = fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z);
+  const float S = oAbs1 + fabsf(v0.x) + fabsf(v0.y) + fabsf(v0.z);
+  const float k = 1e-6f;
+  const float mC = k * L1 * L2, mA = k * S * L2, mB = k * S * L1, mE = 5e-7f * (S + maxt);
+  const float aC = fabsf(C);
+  const float sA = C < 0.f ? -A : A, sB = C < 0.f ? -Bq : Bq;
+  const float s2 = aC - sA, s4 = s2 - sB;
+  const float m2 = mA + mC, m4 = m2 + mB;
+  const float e0 = s0 + sd * mint, e1p = s0 + sd * maxt;
+  const float lo = fminf(e0, e1p), hi = fmaxf(e0, e1p);
+  const bool noCross = lo > mE || hi < -mE, cross = lo < -mE && hi > mE;
+  const bool fail = noCross || sA < -mA || s2 < -m2 || sB < -mB || s4 < -m4;
+  const bool pass = cross && aC > mC && sA > mA && s2 > m2 && sB > mB && s4 > m4;
+  if (fail) return GVPM_TRI_MISS;
+  if (pass) return GVPM_TRI_HIT;
+  // (the plain decision, for callers without an exact pass)
+  const bool plain = C != 0.f && sA >= 0.f && s2 >= 0.f && sB >= 0.f && s4 >= 0.f && lo <= 0.f && hi >= 0.f;
+  return GVPM_TRI_AMB | (plain ? 1 : 0);
+}
+__device__ __forceinline__ int triHit3(const float4 t0, const float4 t1, const float4 t2, f3 o, f3 d, float mint, float maxt, float oAbs1) {
+  const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
+  return triHit3(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt, oAbs1, dot(nrm, o - v0), dot(nrm, d));
+}
+// any-hit over a list: a certain hit settles it; else an undecidable triangle makes the whole answer undecidable
+__device__ __forceinline__ int triCombine(int acc, int t) {
+  // acc, t in {0 miss, 1 hit, 2 amb/miss, 3 amb/hit}
+  if (acc == GVPM_TRI_HIT || t == GVPM_TRI_HIT) return GVPM_TRI_HIT;
+  if ((acc | t) & GVPM_TRI_AMB) return GVPM_TRI_AMB | ((acc | t) & 1);
+  return GVPM_TRI_MISS;
+}
+// the plain fp32 test of a triangle record (the beams' loops, until they defer too)
+__device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt) {
+  const f3 n = cross(e1, e2);
+  const float il = frsq(fmaxf(dot(n, n), 1e-36f));
+  const int t = triHit3(v0, e1, e2, o, d, mint, maxt, fabsf(o.x) + fabsf(o.y) + fabsf(o.z), dot(n, o - v0) * il, dot(n, d) * il);
+  return (t & 1) != 0;
+}
+// The same test in uncontracted fp64, in the operation order of the oracle's (and the reference's) statement.
+__device__ __forceinline__ bool triHitExact(f3 v0f, f3 e1f, f3 e2f, f3 of, d3 dd, double mint, double maxt) {
+#pragma clang fp contract(off)
+  const double e1x = e1f.x, e1y = e1f.y, e1z = e1f.z, e2x = e2f.x, e2y = e2f.y, e2z = e2f.z;
+  const double dx = dd.x, dy = dd.y, dz = dd.z;
+  const double px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+  const double det = e1x * px + e1y * py + e1z * pz;
+  if (det == 0.0) return false;
+  const double inv = 1.0 / det;
+  const double tx = (double)of.x - (double)v0f.x, ty = (double)of.y - (double)v0f.y, tz = (double)of.z - (double)v0f.z;
+  const double u = (tx * px + ty * py + tz * pz) * inv;
+  if (u < 0.0 || u > 1.0) return false;
+  const double qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+  const double v = (dx * qx + dy * qy + dz * qz) * inv;
+  if (!(v >= 0.0 && u + v <= 1.0)) return false;
+  const double t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+  return t >= mint && t <= maxt;
 }
 
 // scene->rayIntersect(ray), any-hit: stack walk of the occluder BVH (scene_bvh.h), triangles as
 // {v0,n.x} {e1,n.y} {e2,n.z} in leaf order.  Deliberately not inlined: it is the rare path (the
 // as-written shadow segment is served by the per-photon near-occluder list below) and inlining
-// it cost the evaluation kernels ~160 VGPRs.
-static __device__ __noinline__ bool anyHitScene(const float4 *bvh, const float4 *tri4, uint32_t ntri, f3 o, f3 d, float mint,
-                                         float maxt) {
-  if (ntri == 0u) return false;
+// it cost the evaluation kernels ~160 VGPRs.  Returns a GVPM_TRI_* state.
+static __device__ __noinline__ int anyHitScene(const float4 *bvh, const float4 *tri4, uint32_t ntri, f3 o, f3 d, float mint,
+                                        float maxt) {
+  if (ntri == 0u) return GVPM_TRI_MISS;
   const f3 inv = mk3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  const float oAbs1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
   uint32_t stack[32];
   int sp = 0;
   uint32_t cur = 0;
+  int res = GVPM_TRI_MISS;
   for (;;) {
     const float4 lo = bvh[2 * (size_t)cur], hi = bvh[2 * (size_t)cur + 1];
     // slab test; fminf/fmaxf drop the NaNs of 0 * inf
@@ -76,13 +149,13 @@ static __device__ __noinline__ bool anyHitScene(const float4 *bvh, const float4 
         descend = true;
       } else {
         for (uint32_t i = first; i < first + count; ++i) {
-          const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
-          if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) return true;
+          res = triCombine(res, triHit3(tri4[3 * (size_t)i], tri4[3 * (size_t)i + 1], tri4[3 * (size_t)i + 2], o, d, mint, maxt, oAbs1));
+          if (res == GVPM_TRI_HIT) return res;
         }
       }
     }
     if (!descend) {
-      if (sp == 0) return false;
+      if (sp == 0) return res;
       cur = stack[--sp];
     }
   }
@@ -97,7 +170,7 @@ static __device__ __noinline__ bool anyHitScene(const float4 *bvh, const float4 
 // Margin of the plane-side early-out in front of a triangle test: the signed distances s0 + sd * t of the segment's
 // two ends to the triangle's plane are fp32 sums of products of O(|o|_1 + |v0|_1) and O(maxt) operands, so their
 // rounding error is a few ulps of that magnitude.  A triangle is skipped only when BOTH ends lie on one side by MORE
-// than this margin; anything closer goes to triHit, which decides as the reference's rayIntersect does.
+// than this margin; anything closer goes to triHit3, which decides as the reference's rayIntersect does -- or says it cannot.
 __device__ __forceinline__ float planeSideMargin(float triAbs1, f3 o, float maxt) {
   return 2e-6f * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + triAbs1 + maxt);
 }
@@ -106,9 +179,10 @@ __device__ __forceinline__ bool planeSideMiss(float s0, float sd, float mint, fl
   return fminf(e0, e1) > margin || fmaxf(e0, e1) < -margin;
 }
 
-__device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
-                                            float mint, float maxt, float margin) {
-  bool hit = false;
+__device__ __forceinline__ int nearListHit(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
+                                           float mint, float maxt, float margin) {
+  int res = GVPM_TRI_MISS;
+  const float oAbs1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
   uint32_t l = nl0;
 #pragma unroll 1
   for (int k = 0; k < 12; ++k) {
@@ -122,42 +196,42 @@ __device__ __forceinline__ bool nearListHit(const float4 *tri, uint32_t nl0, uin
     const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
     const float s0 = dot(nrm, o - v0), sd = dot(nrm, d);
     if (planeSideMiss(s0, sd, mint, maxt, margin)) continue;
-    if (triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+    res = triCombine(res, triHit3(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt, oAbs1, s0, sd));
   }
-  return hit;
+  return res;
 }
 // the same for scenes of more than 254 occluders: six 16-bit indices (grid_build.hip, nearOccluders)
-__device__ __forceinline__ bool nearListHitWide(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
-                                                float mint, float maxt) {
-  bool hit = false;
+__device__ __forceinline__ int nearListHitWide(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
+                                               float mint, float maxt) {
+  int res = GVPM_TRI_MISS;
+  const float oAbs1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
   uint32_t l = nl0;
 #pragma unroll 1
   for (int k = 0; k < 6; ++k) {
     const uint32_t i = l & 0xFFFFu;
     if (i == 0xFFFFu) break;
     l = k == 1 ? nl1 : (k == 3 ? nl2 : (l >> 16) | 0xFFFF0000u);
-    const float4 t0 = tri[3 * (size_t)i], t1 = tri[3 * (size_t)i + 1], t2 = tri[3 * (size_t)i + 2];
-    if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+    res = triCombine(res, triHit3(tri[3 * (size_t)i], tri[3 * (size_t)i + 1], tri[3 * (size_t)i + 2], o, d, mint, maxt, oAbs1));
   }
-  return hit;
+  return res;
 }
 // extension list (lists longer than the inline slots; every list of a scene beyond 16-bit indices)
-__device__ __forceinline__ bool nearListHitExt(const float4 *tri, const uint32_t *ext, uint32_t off, f3 o, f3 d,
-                                               float mint, float maxt) {
-  bool hit = false;
+__device__ __forceinline__ int nearListHitExt(const float4 *tri, const uint32_t *ext, uint32_t off, f3 o, f3 d,
+                                              float mint, float maxt) {
+  int res = GVPM_TRI_MISS;
+  const float oAbs1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
   const uint32_t n = ext[off];
 #pragma unroll 1
   for (uint32_t k = 0; k < n; ++k) {
     const uint32_t i = ext[off + 1u + k];
-    const float4 t0 = tri[3 * (size_t)i], t1 = tri[3 * (size_t)i + 1], t2 = tri[3 * (size_t)i + 2];
-    if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) hit = true;
+    res = triCombine(res, triHit3(tri[3 * (size_t)i], tri[3 * (size_t)i + 1], tri[3 * (size_t)i + 2], o, d, mint, maxt, oAbs1));
   }
-  return hit;
+  return res;
 }
-// ldsTri: the occluders staged in LDS by the kernel (small scenes), or null
+// ldsTri: the occluders staged in LDS by the kernel (small scenes), or null.  Returns a GVPM_TRI_* state.
 template <bool FULLVIS>
-__device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const float4 *ldsTri, uint32_t nl0, uint32_t nl1,
-                                              uint32_t nl2, f3 o, f3 d, float mint, float maxt) {
+__device__ __forceinline__ int shadowBlocked(const GatherArgs &a, const float4 *ldsTri, uint32_t nl0, uint32_t nl1,
+                                             uint32_t nl2, f3 o, f3 d, float mint, float maxt) {
   if (FULLVIS) return anyHitScene(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
   if (a.ntri > GVPM_NEAR_NARROW_MAX) {
     if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
@@ -167,6 +241,20 @@ __device__ __forceinline__ bool shadowBlocked(const GatherArgs &a, const float4 
   const float margin = planeSideMargin(a.triAbs1, o, maxt);
   return ldsTri ? nearListHit(ldsTri, nl0, nl1, nl2, o, d, mint, maxt, margin)
                 : nearListHit(a.tri4, nl0, nl1, nl2, o, d, mint, maxt, margin);
+}
+
+// ---- deferral to the exact pass (device_types.h, ExEntry) ----
+// the hot loops' side: one global atomic and one 16-byte store per deferred shift (rare)
+__device__ __forceinline__ void deferNote(const GatherArgs &a, uint32_t kind, uint32_t set, uint32_t recIdx, uint32_t shift, uint32_t cause) {
+  const uint32_t slot = atomicAdd(a.exOvfCount, 1u);
+  if (slot < a.exOvfCap) a.exOvf[slot] = make_uint4(set, recIdx, kind | (shift << 8) | (cause << 16), 0u);
+}
+// one quad of an entry: 0 header, 1..8 the record, 9..28 the five rays, 29..31 zero
+__device__ __forceinline__ float4 exQuad(const GatherArgs &a, uint32_t set, uint32_t recIdx, uint32_t meta, uint32_t part) {
+  if (part == 0u) return make_float4(__uint_as_float(meta), 0.f, a.iterScale, a.radius);
+  if (part <= GVPM_REC_QUADS) return a.cold[(size_t)recIdx * GVPM_REC_QUADS + (part - 1u)];
+  if (part <= GVPM_REC_QUADS + 20u) return reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5)[part - 1u - GVPM_REC_QUADS];
+  return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // GatherPoint::sensorMIS, gvpm_struct.h:608-631 (sDist == bDist for BRE: same t')
@@ -315,15 +403,19 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
                                               uint32_t bits, f3 dProjU, const RayReg &sh, const RayReg &base,
                                               uint32_t edge, f3 trShift, float pdfBaseRay, float pdfShiftRay,
                                               f3 &shiftedFlux, bool &ok, const float4 *ldsTri = nullptr,
-                                              float sensorMisPre = -1.f) {
+                                              float sensorMisPre = -1.f, uint32_t *amb = nullptr) {
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(bits);
   const float l2Proj = dot(dProjU, dProjU);
   const float lProj = fsqrt(l2Proj);
   const f3 dProj = dProjU * frcp(lProj);
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
-  bool good = !shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
+  // (amb: the caller defers undecidable shifts to the exact pass; without one the plain fp32 decision stands)
+  const int vis = shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
+  bool good = !(vis & 1);
   const float cosWo = dot(ph.parentN, dProj);
+  // (the sign / cosine tests below flip within fp32 rounding of a grazing direction)
+  if (amb) *amb = ((vis & GVPM_TRI_AMB) ? 16u : 0u) | ((GVPM_PF_PARENT_TYPE(bits) != GVPM_PARENT_MEDIUM && fabsf(cosWo) <= 2e-6f) ? 32u : 0u);
   // surface / emitter parents: the offset direction must leave on the side the photon left (sign of
   // dot(n, dProj) / dot(n, -wi))
   const bool isMedium = ptype == GVPM_PARENT_MEDIUM, isGlossy = ptype == GVPM_PARENT_SURFACE_BSDF;

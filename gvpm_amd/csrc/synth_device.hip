@@ -327,6 +327,14 @@ int gvpm_devgen_create(const gvpm_devgen_scene *sc, int device, gvpm_devgen **ou
   v.lightArea = sc->light_area;
   v.medium = sc->medium;
   v.camPos = V3(sc->cam_pos[0], sc->cam_pos[1], sc->cam_pos[2]);
+  {
+    const double *m = sc->cam_to_world;
+    bool zero = true;
+    for (int k = 0; k < 9; ++k) zero = zero && m[k] == 0.0;
+    v.camX = zero ? V3(1, 0, 0) : V3(m[0], m[3], m[6]);
+    v.camY = zero ? V3(0, 1, 0) : V3(m[1], m[4], m[7]);
+    v.camZ = zero ? V3(0, 0, 1) : V3(m[2], m[5], m[8]);
+  }
   v.tanHalfFovX = sc->tan_half_fov_x;
   v.width = sc->width;
   v.height = sc->height;

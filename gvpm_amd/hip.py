@@ -21,7 +21,7 @@ SYMBOLS = [
     "gvpm_upload_photons_dev", "gvpm_upload_camera_beams_dev", "gvpm_upload_vpm_samples",
     "gvpm_upload_beams", "gvpm_upload_beams_dev", "gvpm_upload_planes", "gvpm_upload_planes_dev",
     "gvpm_upload_vpm_samples_dev", "gvpm_download_vpm_state", "gvpm_gather", "gvpm_get_radius",
-    "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_kernel_time", "gvpm_get_phase_time", "gvpm_download_accum",
+    "gvpm_set_global_scale", "gvpm_get_stats", "gvpm_get_exact_shift_count", "gvpm_get_kernel_time", "gvpm_get_phase_time", "gvpm_download_accum",
     "gvpm_download_accum_dev", "gvpm_download_film", "gvpm_synchronize", "gvpm_comm_unique_id", "gvpm_comm_init",
     "gvpm_allreduce_accum", "gvpm_allreduce_film", "gvpm_download_film_dev", "gvpm_devgen_create",
     "gvpm_devgen_destroy", "gvpm_devgen_shoot_photons", "gvpm_devgen_shoot_beams", "gvpm_devgen_camera_beams", "gvpm_devgen_read",
@@ -486,6 +486,12 @@ class Context:
         self._check(lib().gvpm_get_stats(self._h, C.byref(s)))
         return {k: int(getattr(s, k)) for k in
                 ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts")}
+
+    def exact_shifts(self):
+        """(evaluated, lost): the shifts the exact fp64 pass has taken since the last reset (gvpm_get_exact_shift_count)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(lib().gvpm_get_exact_shift_count(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def grid_info(self):
         """G-BRE: (kind, cells) of the last build's photon cells -- kind 1: the ray-bundle cells (gvpm_stats.reserved[0])"""

@@ -68,6 +68,9 @@ int gvpm_synth_devgen_scene(gvpm_synth *s, gvpm_devgen_scene *out) {
   out->camera_inside = sc.cameraInside ? 1 : 0;
   out->max_depth = sc.maxDepth; out->rr_depth = sc.rrDepth; out->min_depth = sc.minDepth;
   out->camera_sphere = sc.cameraSphere;
+  const gvpm::V3 col[3] = {sc.camX, sc.camY, sc.camZ};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out->cam_to_world[3 * r + c] = col[c][r];
   return GVPM_OK;
 }
 
@@ -205,7 +208,9 @@ int gvpm_synth_sensor(const gvpm_synth *s, gvpm_sensor *out) {
   out->pos[0] = sc.camPos.x;
   out->pos[1] = sc.camPos.y;
   out->pos[2] = sc.camPos.z;
-  out->to_world[0] = out->to_world[4] = out->to_world[8] = 1.0;  // the synthetic sensors look along -z, unrotated
+  const gvpm::V3 col[3] = {sc.camX, sc.camY, sc.camZ};  // identity for the axis-aligned scenes (they look along -z)
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out->to_world[3 * r + c] = col[c][r];
   out->tan_half_fov_x = sc.tanHalfFovX;
   out->tan_half_fov_y = sc.tanHalfFovX * sc.height / sc.width;   // traceCamera's `ty`, same operations
   out->width = sc.width;

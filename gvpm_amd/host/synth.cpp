@@ -21,6 +21,7 @@ SceneView SynthScene::view() const {
   v.lightArea = lightArea;
   v.medium = medium;
   v.camPos = camPos;
+  v.camX = camX; v.camY = camY; v.camZ = camZ;
   v.tanHalfFovX = tanHalfFovX;
   v.width = width; v.height = height;
   v.seed = seed;
@@ -36,7 +37,13 @@ double SynthScene::bsphereRadius() const {
   return length(bmax - c);
 }
 
+V3 SynthScene::toWorld(V3 p) const {
+  if (!rotated) return p;  // (the axis-aligned scenes keep their coordinates bit for bit)
+  return V3(dot(rot[0], p), dot(rot[1], p), dot(rot[2], p));
+}
+
 void SynthScene::addQuad(V3 a, V3 b, V3 c, V3 d, int mat) {
+  a = toWorld(a); b = toWorld(b); c = toWorld(c); d = toWorld(d);
   SynthTri t1, t2;
   t1.v0 = a; t1.e1 = b - a; t1.e2 = c - a; t1.n = normalize(cross(t1.e1, t1.e2)); t1.mat = mat;
   t2.v0 = a; t2.e1 = c - a; t2.e2 = d - a; t2.n = normalize(cross(t2.e1, t2.e2)); t2.mat = mat;
@@ -56,17 +63,18 @@ static void addBoxRoom(SynthScene &s, int matFloor, int matCeil, int matBack, in
 }
 
 static void setLight(SynthScene &s, V3 c, double sx, double sz, V3 radiance, int mat) {
-  s.lightC = c;
-  s.lightU = V3(sx, 0, 0);
-  s.lightV = V3(0, 0, sz);
-  s.lightN = V3(0, -1, 0);
+  const V3 u(sx, 0, 0), v(0, 0, sz);
   s.radiance = radiance;
   s.lightArea = sx * sz;
-  V3 a = c - s.lightU * 0.5 - s.lightV * 0.5;
-  V3 b = c + s.lightU * 0.5 - s.lightV * 0.5;
-  V3 cc = c + s.lightU * 0.5 + s.lightV * 0.5;
-  V3 d = c - s.lightU * 0.5 + s.lightV * 0.5;
+  V3 a = c - u * 0.5 - v * 0.5;
+  V3 b = c + u * 0.5 - v * 0.5;
+  V3 cc = c + u * 0.5 + v * 0.5;
+  V3 d = c - u * 0.5 + v * 0.5;
   s.addQuad(a, b, cc, d, mat);  // normal (0,-1,0)
+  s.lightC = s.toWorld(c);
+  s.lightU = s.toWorld(u);
+  s.lightV = s.toWorld(v);
+  s.lightN = s.toWorld(V3(0, -1, 0));
 }
 
 static void setMedium(SynthScene &s, double sigmaS, double sigmaA, double g) {
@@ -90,9 +98,54 @@ static void addInnerBox(SynthScene &s, V3 lo, V3 hi, int mat) {
   s.addQuad(V3(hi.x, lo.y, lo.z), V3(hi.x, hi.y, lo.z), V3(hi.x, hi.y, hi.z), V3(hi.x, lo.y, hi.z), mat);  // +x
 }
 
-bool makeScene(const std::string &name, int width, int height, uint32_t seed, SynthScene &s) {
+// A solid box in GENERAL position: half extents h around `pivot + up * h.y` in its own frame, that frame turned about the
+// pivot by yaw (about y), then leanX (about x), then leanZ (about z) -- no face normal is an axis, no vertex coordinate a
+// round number.  `sink`: how far the box reaches below its pivot (a leaning box on a floor has its base under the floor).
+static void addTiltedBox(SynthScene &s, V3 pivot, V3 h, double yaw, double leanX, double leanZ, double sink, int mat) {
+  const double cy = std::cos(yaw), sy = std::sin(yaw), cx = std::cos(leanX), sx = std::sin(leanX), cz = std::cos(leanZ),
+               sz = std::sin(leanZ);
+  auto turn = [&](V3 p) {
+    p = V3(cy * p.x + sy * p.z, p.y, -sy * p.x + cy * p.z);     // yaw
+    p = V3(p.x, cx * p.y - sx * p.z, sx * p.y + cx * p.z);      // lean about x
+    p = V3(cz * p.x - sz * p.y, sz * p.x + cz * p.y, p.z);      // lean about z
+    return pivot + p;
+  };
+  const V3 lo(-h.x, -sink, -h.z), hi(h.x, 2.0 * h.y, h.z);
+  auto P = [&](double x, double y, double z) { return turn(V3(x, y, z)); };
+  s.addQuad(P(lo.x, lo.y, lo.z), P(hi.x, lo.y, lo.z), P(hi.x, lo.y, hi.z), P(lo.x, lo.y, hi.z), mat);  // -y
+  s.addQuad(P(lo.x, hi.y, lo.z), P(lo.x, hi.y, hi.z), P(hi.x, hi.y, hi.z), P(hi.x, hi.y, lo.z), mat);  // +y
+  s.addQuad(P(lo.x, lo.y, lo.z), P(lo.x, hi.y, lo.z), P(hi.x, hi.y, lo.z), P(hi.x, lo.y, lo.z), mat);  // -z
+  s.addQuad(P(lo.x, lo.y, hi.z), P(hi.x, lo.y, hi.z), P(hi.x, hi.y, hi.z), P(lo.x, hi.y, hi.z), mat);  // +z
+  s.addQuad(P(lo.x, lo.y, lo.z), P(lo.x, lo.y, hi.z), P(lo.x, hi.y, hi.z), P(lo.x, hi.y, lo.z), mat);  // -x
+  s.addQuad(P(hi.x, lo.y, lo.z), P(hi.x, hi.y, lo.z), P(hi.x, hi.y, hi.z), P(hi.x, lo.y, hi.z), mat);  // +x
+}
+
+// the two blocks of a Cornell box, tilted (the `_rot` variants of the cbox scenes)
+static void addCornellBlocks(SynthScene &s, int matShort, int matTall) {
+  const double deg = kPi / 180.0;
+  addTiltedBox(s, V3(0.36, -1.0, 0.31), V3(0.27, 0.29, 0.27), -17.3 * deg, 4.1 * deg, -2.7 * deg, 0.1, matShort);
+  addTiltedBox(s, V3(-0.37, -1.0, -0.33), V3(0.28, 0.61, 0.28), 19.6 * deg, -3.3 * deg, 5.2 * deg, 0.1, matTall);
+}
+
+bool makeScene(const std::string &fullName, int width, int height, uint32_t seed, SynthScene &s) {
   s = SynthScene();
-  s.name = name;
+  s.name = fullName;
+  // `<scene>_rot`: the scene in GENERAL POSITION -- everything (room, light, sensor) under one fixed rotation about the
+  // origin, Euler angles 17 / 31 / 47 degrees (R = Rz Ry Rx), and its inner boxes individually tilted (cbox*: the two
+  // Cornell blocks added; fogroom: each of the 64 boxes with its own yaw and lean).  No surface normal is an axis, no
+  // wall coordinate is exactly representable: what the axis-aligned scenes cannot tell apart from exact arithmetic
+  // (octahedral normals, the own-wall test of the near lists, slab tests with zero direction components, the branches
+  // of coordinateSystem) is exercised here.
+  const bool rot = fullName.size() > 4 && fullName.compare(fullName.size() - 4, 4, "_rot") == 0;
+  const std::string name = rot ? fullName.substr(0, fullName.size() - 4) : fullName;
+  if (rot) {
+    const double ax = 17.0 * kPi / 180.0, ay = 31.0 * kPi / 180.0, az = 47.0 * kPi / 180.0;
+    const double cx = std::cos(ax), sx = std::sin(ax), cy = std::cos(ay), sy = std::sin(ay), cz = std::cos(az), sz = std::sin(az);
+    s.rot[0] = V3(cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx);
+    s.rot[1] = V3(sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx);
+    s.rot[2] = V3(-sy, cy * sx, cy * cx);
+    s.rotated = true;
+  }
   s.width = width;
   s.height = height;
   s.seed = seed;
@@ -122,6 +175,7 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     const int mFloor = phong(V3(0.3, 0.3, 0.3), V3(0.5, 0.5, 0.45), 40.0);
     const int mBack = phong(V3(0.2, 0.25, 0.4), V3(0.3, 0.3, 0.3), 12.0);
     addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
+    if (rot) addCornellBlocks(s, 0, mBack);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, name == "cbox_phong_hg" ? 0.7 : 0.0);
   } else if (name == "cbox_conductor") {
@@ -140,10 +194,12 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     const int mFloor = conductor(V3(0.2004, 0.9240, 1.1022), V3(3.9129, 2.4528, 2.1421), 0.3, GVPM_MICROFACET_BECKMANN);
     const int mBack = conductor(V3(1.6574, 0.8803, 0.5212), V3(9.2238, 6.2695, 4.8370), 0.2, GVPM_MICROFACET_GGX);
     addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
+    if (rot) addCornellBlocks(s, 0, mBack);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, 0.0);
   } else if (name == "cbox") {
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
+    if (rot) addCornellBlocks(s, 0, 0);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, 0.0);
   } else if (name == "cbox_hg") {
@@ -151,6 +207,7 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
     // reconnection branch (g > 0.5 makes medium vertices "glossy",
     // gvpm_struct.h:73-76)
     addBoxRoom(s, 0, 0, 0, 1, 2, 3);
+    if (rot) addCornellBlocks(s, 0, 0);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, 0.7);
   } else if (name == "cbox_in") {
@@ -204,11 +261,31 @@ bool makeScene(const std::string &name, int width, int height, uint32_t seed, Sy
       double cx = -0.85 + 1.7 * rng.next1D(), cz = -0.85 + 1.7 * rng.next1D();
       double hx = 0.04 + 0.06 * rng.next1D(), hz = 0.04 + 0.06 * rng.next1D();
       double hy = 0.1 + 0.5 * rng.next1D();
-      addInnerBox(s, V3(cx - hx, -1.0, cz - hz), V3(cx + hx, -1.0 + hy, cz + hz), 0);
+      if (rot) {
+        const double yaw = 2.0 * kPi * rng.next1D(), lx = (rng.next1D() - 0.5) * 0.4, lz = (rng.next1D() - 0.5) * 0.4;
+        addTiltedBox(s, V3(cx, -1.0, cz), V3(hx, 0.5 * hy, hz), yaw, lx, lz, 0.05, 0);
+      } else {
+        addInnerBox(s, V3(cx - hx, -1.0, cz - hz), V3(cx + hx, -1.0 + hy, cz + hz), 0);
+      }
     }
     setMedium(s, 0.5, 0.5, 0.0);
   } else {
     return false;
+  }
+  if (rot) {
+    // the sensor turns with the room; the scene's AABB (Scene::getAABB: all shapes) is that of the turned geometry
+    s.camPos = s.toWorld(s.camPos);
+    s.camX = s.toWorld(V3(1, 0, 0)); s.camY = s.toWorld(V3(0, 1, 0)); s.camZ = s.toWorld(V3(0, 0, 1));
+    const double inf = std::numeric_limits<double>::infinity();
+    s.bmin = V3(inf, inf, inf);
+    s.bmax = V3(-inf, -inf, -inf);
+    for (const auto &t : s.tris) {
+      const V3 v[3] = {t.v0, t.v0 + t.e1, t.v0 + t.e2};
+      for (const V3 &q : v) {
+        s.bmin = V3(std::fmin(s.bmin.x, q.x), std::fmin(s.bmin.y, q.y), std::fmin(s.bmin.z, q.z));
+        s.bmax = V3(std::fmax(s.bmax.x, q.x), std::fmax(s.bmax.y, q.y), std::fmax(s.bmax.z, q.z));
+      }
+    }
   }
   // gvpm.cpp:162 m_config.cameraSphere = R * cameraSphere(=1) * POURCENTAGE_BS
   s.cameraSphere = s.bsphereRadius() * 1.0 * 0.01;

@@ -34,6 +34,7 @@ struct SynthScene {
   V3 bmin, bmax;
   // pinhole (perspective) sensor
   V3 camPos;
+  V3 camX = V3(1, 0, 0), camY = V3(0, 1, 0), camZ = V3(0, 0, 1);  // camera -> world: right, towards larger rows, BACK (looks along -camZ)
   double tanHalfFovX;
   int width, height;
   uint32_t seed;
@@ -41,6 +42,11 @@ struct SynthScene {
   // light-path walk parameters (GPMConfig maxDepth, rrDepth, minDepth)
   int maxDepth, rrDepth, minDepth;
   double cameraSphere;  // world units, already scaled as in gvpm.cpp:162
+
+  // `_rot` scenes: the rotation every point / direction of the scene description goes through (rows of R)
+  bool rotated = false;
+  V3 rot[3] = {V3(1, 0, 0), V3(0, 1, 0), V3(0, 0, 1)};
+  V3 toWorld(V3 p) const;
 
   double bsphereRadius() const;
   SceneView view() const;  // what the generators (host or device) read

@@ -50,6 +50,7 @@ struct SceneView {
   double lightArea;
   gvpm_medium medium;
   V3 camPos;
+  V3 camX, camY, camZ;  // camera -> world columns; the sensor looks along -camZ (identity for the axis-aligned scenes)
   double tanHalfFovX;
   int width, height;
   uint32_t seed;
@@ -746,7 +747,7 @@ GVPM_HD inline double importance(const SceneView &sc, double sx, double sy, V3 d
   if (sx < 0 || sy < 0 || sx >= sc.width || sy >= sc.height) return 0.0;
   double tx = sc.tanHalfFovX, ty = tx * sc.height / sc.width;
   double area = (2 * tx) * (2 * ty);
-  double cosTheta = -d.z;
+  double cosTheta = -dot(d, sc.camZ);
   if (cosTheta <= 0) return 0.0;
   return 1.0 / (area * cosTheta * cosTheta * cosTheta);
 }
@@ -756,7 +757,9 @@ GVPM_HD inline double importance(const SceneView &sc, double sx, double sy, V3 d
 // (ShiftGatherPoint::trace, shift_cameraPath.h:146-413) and stops where the base path stops.
 GVPM_HD inline void traceCamera(const SceneView &sc, double sx, double sy, CamPath &cp, const CamPath *base = nullptr) {
   double tx = sc.tanHalfFovX, ty = tx * sc.height / sc.width;
-  V3 d = normalize(V3((2 * sx / sc.width - 1) * tx, (2 * sy / sc.height - 1) * ty, -1.0));
+  // (camera space looks along -z; with the identity frame the three sums below are exact)
+  const double cx = (2 * sx / sc.width - 1) * tx, cy = (2 * sy / sc.height - 1) * ty;
+  V3 d = normalize(sc.camX * cx + sc.camY * cy - sc.camZ);
   cp.d = d;
   cp.pdfDir = importance(sc, sx, sy, d);
   cp.hasBeam = false;

@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define GVPM_ABI_VERSION 2  /* 2: gvpm_bsdf grew to 64 bytes (rough conductor), round 4 */
+#define GVPM_ABI_VERSION 3  /* 2: gvpm_bsdf grew to 64 bytes (rough conductor), round 4; 3: gvpm_devgen_scene carries the
+                              sensor's rotation (cam_to_world), round 5 */
 
 /* ---- status codes --------------------------------------------------------*/
 typedef enum gvpm_status {
@@ -307,6 +308,17 @@ int gvpm_abi_version(void);
 /* Reset per-pixel accumulators and the APA radius scale to
  * initialScaleVolume (GPMIntegrator::render, gvpm.cpp:272-291).              */
 int gvpm_reset(gvpm_context *h);
+
+/* Decisions.  Every decision of a shift -- null shift or reconnection, the mirror step of getShiftPos, the triangle tests of
+ * the shadow segment, the sign / cosine tests of the reconnection -- is taken in fp32 WITH a rigorous error margin; a shift
+ * with a comparison inside its margin (~1e-5 of them; for a parent that position rounding left behind the wall it sits
+ * on, the reconnections within a few degrees of grazing) is evaluated by the EXACT PASS instead: the reference's statement
+ * in uncontracted fp64 on the same fp32 inputs (csrc/exact_shift.hip), run behind the gather's kernels.  The shift counters
+ * of gvpm_stats therefore equal those of a double-precision evaluation of the same inputs exactly (G-BRE; the other
+ * techniques as DESIGN.md section 2 states).  evaluated: shifts the exact pass has taken since gvpm_reset; lost: shifts
+ * that did not fit its list (also reported as dropped_pairs: gvpm_get_stats then fails).                                 */
+int gvpm_get_exact_shift_count(gvpm_context *h, uint64_t *evaluated, uint64_t *lost);
+
 
 /* ---- uploads --------------------------------------------------------------*/
 int gvpm_upload_scene(gvpm_context *h, const gvpm_triangles *tris);
@@ -664,6 +676,8 @@ typedef struct gvpm_devgen_scene {
   int32_t camera_inside;     /* sensor inside the medium: edge 1 is the medium edge */
   int32_t max_depth, rr_depth, min_depth;  /* GPMConfig maxDepth, rrDepth, minDepth */
   double camera_sphere;      /* world units (gvpm.cpp:162)                        */
+  double cam_to_world[9];    /* row-major rotation camera -> world (camera space looks along -z, +x to the right of the
+                                film, +y towards larger pixel rows: gvpm_sensor's to_world); ALL ZERO = identity (ABI 3) */
 } gvpm_devgen_scene;
 typedef struct gvpm_devgen gvpm_devgen;
 int gvpm_devgen_create(const gvpm_devgen_scene *scene, int device, gvpm_devgen **out);

@@ -59,11 +59,11 @@ public:
     p.path_set = config.pathSet ? 1 : 0;
     p.power_heuristic = config.powerHeuristic ? 1 : 0;
     p.no_medium_shift = config.noMediumShift ? 1 : 0;
-    p.use_manifold = config.useManifold ? 1 : 0;                    /* the manifold WALK stays on the host: the G-BRE
-                                                                       and G-VPM gathers record a request per such shift
-                                                                       and answerShiftRequests() below answers them; the
-                                                                       beam / plane techniques treat these shifts as
-                                                                       useManifold=false does (:101-104)          */
+    p.use_manifold = config.useManifold ? 1 : 0;                    /* the manifold WALK stays on the host: the G-BRE,
+                                                                       G-VPM and G-Beams gathers record a request per
+                                                                       such shift and answerShiftRequests() /
+                                                                       answerBeamShiftRequests() below answer them;
+                                                                       G-Planes has no manifold shift             */
     p.debug_shift = (int32_t) config.debugShift;                    /* ELightShiftType values kept                */
     p.lighting_interaction_mode = (int32_t) config.lightingInteractionMode;
     p.bsdf_interaction_mode = (int32_t) config.bsdfInteractionMode;

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 SHIFT_COUNTERS = ("null_shifts", "diffuse_shifts", "failed_shifts")
 
 
-def device_beams(c, p=None, rays=None, iters=1):
+def device_beams(c, p=None, rays=None, iters=1, exact=False):
     p = c.p if p is None else p
     ctx = hip.Context(p, device=0)
     ctx.upload_scene(*c.tris)
@@ -44,7 +44,7 @@ def device_beams(c, p=None, rays=None, iters=1):
     # visibility of a reconnection) are fp32: a pair within rounding of one of them may move between counters.
     assert st["evaluations"] == total["evaluations"], (st, total)
     for k in SHIFT_COUNTERS:
-        assert abs(st[k] - total[k]) <= 2, (k, st, total)
+        assert abs(st[k] - total[k]) <= (0 if exact else 2), (k, st, total)
     assert l2(acc, ref, lum) < 2e-4   # (measured 6e-6 .. 6e-5; SURVEY's bar is 1e-3)
     rfilm = O.assemble(ref, iters, True)
     for a, b in zip(film, rfilm):

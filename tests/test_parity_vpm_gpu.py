@@ -11,7 +11,7 @@ from test_parity_gpu import l2, TOL
 pytestmark = pytest.mark.gpu
 
 
-def device_vpm(c, iters=1, p=None, rays=None):
+def device_vpm(c, iters=1, p=None, rays=None, exact=False):
     p = c.p if p is None else p
     ctx = hip.Context(p, device=0)
     ctx.upload_scene(*c.tris)
@@ -19,6 +19,7 @@ def device_vpm(c, iters=1, p=None, rays=None):
     cases.upload_bsdfs(ctx, c)
     ref = sv = nv = None
     total = 0
+    shifts = {k: 0 for k in ("null_shifts", "diffuse_shifts", "failed_shifts")}
     emitted = 0
     for it in range(1, iters + 1):
         if it == 1:
@@ -34,6 +35,8 @@ def device_vpm(c, iters=1, p=None, rays=None):
         ref, sv, nv, cnt, _ = O.gather_vpm(p, c.m, c.tris, ph, r, smp, 64, use_accel=False, accum=ref, scale_vol=sv,
                                            n_vol=nv)
         total += cnt["evaluations"]
+        for k in shifts:
+            shifts[k] += cnt[k]
     acc = ctx.download_accum()
     st = ctx.stats()
     dsv, dnv = ctx.download_vpm_state()
@@ -41,6 +44,8 @@ def device_vpm(c, iters=1, p=None, rays=None):
     ctx.close()
     lum = max(ref[..., 0:3].mean(), 1e-30)
     assert st["evaluations"] == total
+    for k in shifts:
+        assert abs(st[k] - shifts[k]) <= (0 if exact else max(2, 2e-6 * 4 * total)), (k, st, shifts)
     assert l2(acc, ref, lum) < TOL
     assert np.allclose(dsv, sv, rtol=1e-6) and np.allclose(dnv, nv, rtol=1e-6)
     rfilm = O.assemble(ref, iters, True, total_emitted=emitted)
