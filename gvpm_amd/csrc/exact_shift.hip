@@ -427,6 +427,82 @@ __device__ void exactBRE(const GatherArgs &a, const ExEntry &e, int iOnly, uint3
   }
 }
 
+// ---- G-VPM: VolumeGradientPositionQuery::operator(), shift_volume_photon.cpp:489-655, one shift of one (photon, sample) pair ----
+__device__ void exactVPM(const GatherArgs &a, const ExEntry &e, uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+#pragma clang fp contract(off)
+  const double M_PI_D = 3.14159265358979323846;
+  const int i = (int)((e.meta >> 8) & 0xFFu);
+  const gvpm_camera_ray rb = e.rays[0];
+  const RayIn base = loadRayIn(rb), sh = loadRayIn(e.rays[1 + i]);
+  const PhotonCold ph = coldOf(e);
+  const double r = (double)e.radius, r2 = r * r, eps = (double)a.cfg.epsilon;
+  const double rnd = (double)e.extra[0].x, pdfSel = (double)e.extra[0].y;
+  const double sigT = (double)a.med.sigmaT[1];
+  // sampleDistance(Ray(o, d, Epsilon, len), EDistanceAlwaysValid, rand), homogeneous.cpp:293-430 (currentMediumSampling = 1)
+  const double mint = eps, maxt = base.len;
+  const double maxDist = fmax((maxt - mint) - eps, 0.0);
+  const double normalization = 1.0 - exp(-sigT * maxDist);
+  const double sampled = -log(1.0 - rnd * normalization) / sigT;
+  const double t = sampled + mint;  // baseRay.maxt
+  const double nrm2 = 1.0 - exp(-sigT * (maxt - mint));
+  const double tmpB = exp(-sigT * sampled);
+  const double pdfBaseRay = (sigT / nrm2) * tmpB * pdfSel;  // baseDistPDF * pdfSelSection
+  const double trBase = tmpB < 1e-20 ? 0.0 : tmpB;
+  const d3 sigS = mkd(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
+  const d3 flux = tod(ph.flux), wi = tod(ph.wi), pos = tod(ph.pos);
+  const double phB = phaseD((double)a.med.g, wi, -base.d);
+  const d3 baseContrib = mkd(base.eye.x * trBase * (sigS.x * flux.x * phB), base.eye.y * trBase * (sigS.y * flux.y * phB),
+                             base.eye.z * trBase * (sigS.z * flux.z * phB));
+  const double kernelVol = (4.0 / 3.0) * M_PI_D * (r * r * r);
+  const double scale = 1.0 / (kernelVol * pdfBaseRay);
+  ShiftOut out;
+  out.flux = mkd(0, 0, 0);
+  out.weight = 1.0;
+  out.kind = 0;
+  if (sh.valid && sh.len >= t) {
+    // shiftMRec: Medium::eval(Ray(o, d, Epsilon, shiftDistMax), EDistanceAlwaysValid) with mRec.t = baseRay.maxt
+    const double nrmS = 1.0 - exp(-sigT * (sh.len - eps));
+    const double tmpS = exp(-sigT * t);
+    const double pdfShiftRay = (sigT / nrmS) * tmpS * pdfSel;
+    const double trS = tmpS < 1e-20 ? 0.0 : tmpS;
+    const d3 zP = sh.o + sh.d * t, bP = base.o + base.d * t;
+    bool alreadyShifted = false;
+    if (a.cfg.use_shift_null) {
+      const double distSqr = len2d(pos - zP);
+      if (distSqr < r2) {
+        alreadyShifted = true;
+        out.kind = 1;
+        const double phs = phaseD((double)a.med.g, wi, -sh.d);
+        out.flux = mkd(trS * (sigS.x * flux.x * phs) * sh.eye.x, trS * (sigS.y * flux.y * phs) * sh.eye.y, trS * (sigS.z * flux.z * phs) * sh.eye.z);
+        out.weight = 0.5;
+        if (a.cfg.use_mis) {
+          if (pdfShiftRay == 0.0 || pdfBaseRay == 0.0) out.weight = 1.0;
+          else out.weight = 1.0 / (1.0 + sensorMISD(sh, base, base.edge, t, t) * pdfShiftRay / pdfBaseRay);
+        }
+      }
+    }
+    if (!alreadyShifted) {
+      // getShiftPos (coherent = false), :858-896
+      d3 offsetPos = zP + (pos - bP);
+      if (a.cfg.use_shift_null) {
+        const double offDistSqr = len2d(bP - offsetPos);
+        if (offDistSqr < r2) {
+          d3 dShift = zP - bP;
+          dShift = dShift / sqrt(len2d(dShift));
+          const double cosD = dot(dShift, -(offsetPos - zP));
+          offsetPos = offsetPos + dShift * cosD * 2.0;
+        }
+      }
+      if (a.cfg.debug_shift != GVPM_SHIFT_NULL) reconnectExact(a, ph, offsetPos, sh, base, t, t, trS, pdfBaseRay, pdfShiftRay, out);
+    }
+  }
+  nNull += out.kind == 1 ? 1u : 0u;
+  nDiff += out.kind == 2 ? 1u : 0u;
+  nFail += out.kind == 3 ? 1u : 0u;
+  // (G-VPM's accumulators are plain sums over the samples, each weighted 1 / nbCameraSamples: outScale)
+  addShift(a, rb.pixel, i, out.flux, baseContrib, out.weight, scale, e.outScale, a.iter);
+}
+
 // Behind a gather's kernels: its notes become entries (the gather's record and ray buffers are recycled three gathers on).
 // Half a wave per note, a quad per lane; 16 registers: it starts beside the other streams' persistent kernels.
 __global__ __launch_bounds__(256) void capture_notes_kernel(GatherArgs a) {
@@ -467,6 +543,7 @@ __global__ __launch_bounds__(64) void exact_pass_kernel(GatherArgs a, unsigned l
         if ((cause >> c) & 1u) atomicAdd(&totals[4 + c], 1ull);  // by cause: pair, branch, -, mirror, visibility, cosine
     if (kind == GVPM_EX_KIND_BRE) exactBRE(a, e, (int)((e.meta >> 8) & 0xFFu), nEval, nNull, nDiff, nFail);
     else if (kind == GVPM_EX_KIND_BRE_PAIR) exactBRE(a, e, -1, nEval, nNull, nDiff, nFail);
+    else if (kind == GVPM_EX_KIND_VPM) exactVPM(a, e, nNull, nDiff, nFail);
   }
   if (hostOut && blockIdx.x == 0 && threadIdx.x == 0) hostOut[0] = total;  // (pinned: the host paces the passes by it)
   finishPass(a, nEval, nNull, nDiff, nFail, n, total, totals);

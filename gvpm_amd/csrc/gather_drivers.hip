@@ -1031,6 +1031,10 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->maxScaleBits.p, 0, 4, h->stream));
+  {
+    const int rcx = exactPrepare(h);
+    if (rcx != GVPM_OK) return rcx;
+  }
   GatherArgs a;
   fillArgs(h, a, rmax);
   std::pair<hipEvent_t, hipEvent_t> *ev;
@@ -1070,6 +1074,13 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
   launch_gather_vpm(a, needFullVis(h), primal, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  // the shifts the kernel could not decide in fp32: into the handle's list (before the radii of this iteration are updated),
+  // where they wait for the exact pass -- which adds to the plain sums whenever it runs
+  if (!primal) {
+    launch_capture_notes(a, h->stream);
+    rc = exactAfterGather(h);
+    if (rc != GVPM_OK) return rc;
+  }
   // (re-sorted every fourth launch: the heavy pixels stay where they are while the radii shrink)
   if (!h->vpmNoOrder && nBatches > 1024u && (!haveOrder || (h->vpmLaunches & 3u) == 0u)) {
     HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBatches, 20, h->stream));
@@ -1177,10 +1188,14 @@ static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) 
   // the streams that read this step's host-uploaded inputs wait for their copies (copy stream)
   // (packed records are decoded here, at the head of the chain that reads them: G-BRE builds on the build stream)
   const bool breTech = h->cfg.vol_technique == GVPM_VOL_BRE2D || h->cfg.vol_technique == GVPM_VOL_BRE3D;
-  if (!breTech || primal) {
-    // (these gathers fold iter[] into the sums on the gather stream: entries a G-BRE gather deferred are taken first)
-    const int rcj = gvpm_join_exact(h);
-    if (rcj != GVPM_OK) return rcj;
+  {
+    // G-BRE and G-VPM keep plain sums: the exact pass may add its terms whenever it runs.  The beam / plane gathers fold
+    // iter[] into running means on the gather stream: entries that wait are taken first.
+    const bool sums = (breTech || h->cfg.vol_technique == GVPM_DISTANCE) && !primal;
+    if (!sums) {
+      const int rcj = gvpm_join_exact(h);
+      if (rcj != GVPM_OK) return rcj;
+    }
   }
   hipStream_t us = breTech && h->pipeline ? h->streamB : h->stream, other = us == h->stream ? h->streamB : h->stream;
   if (h->phWait) {

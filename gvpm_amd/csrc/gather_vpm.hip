@@ -200,10 +200,22 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
     float w = 1.f;
     f3 sflux = mk3(0.f);
     // validShiftDist: valid edge and shiftDistMax >= baseRay.maxt (shift_volume_photon.cpp:546-566)
+    // (round 5: a shift whose branch fp32 cannot decide -- the distance against the shifted edge's length, the null-shift
+    // test against r^2, within the error band of the fp32 numbers -- is queued like a reconnection; phase 2 re-derives the
+    // test and hands the shift to the exact pass, exact_shift.hip)
+    if (sh.valid && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len)) {
+      qMask |= 1u << i;
+      continue;
+    }
     if (sh.valid && sh.len >= v.tf) {
       const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
       const f3 y = tof(v.pD - zP);
-      if (a.cfg.use_shift_null && dot(y, y) < v.r2) {
+      const float y2 = dot(y, y);
+      if (a.cfg.use_shift_null && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(y2 - v.r2) <= 4e-6f * v.r2) {
+        qMask |= 1u << i;
+        continue;
+      }
+      if (a.cfg.use_shift_null && y2 < v.r2) {
         // shiftNull, shift_volume_photon.cpp:119-158
         // pdfShiftRay = shiftMRec.pdfSuccess * pdfSel, normalised over [Epsilon, shiftDistMax]
         const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
@@ -234,11 +246,17 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
 // shiftPhotonDiffuse) for one queued (photon, sample, shift).
 template <bool FULLVIS, bool HS>
 __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t meta, float norm,
-                                          uint32_t &nDiff, uint32_t &nFail) {
+                                          uint32_t &nDiff, uint32_t &nFail, uint32_t sBase) {
   const uint32_t b = meta & 0xFFu;
   const int i = (int)(meta >> 8);
   const VpmPair v = vpmPair(a, s, pidx, b, norm);
   const RayReg sh = loadRayV(a, s, 1 + i, b);
+  // phase 1's branch tests from phase 1's numbers: an undecidable branch was queued to be deferred here
+  uint32_t amb = 0u;
+  if (!(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u)) {
+    const f3 y = tof(v.pD - (tod(sh.o) + tod(sh.d) * v.t));
+    amb = (fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len) || (a.cfg.use_shift_null && fabsf(dot(y, y) - v.r2) <= 4e-6f * v.r2)) ? 2u : 0u;
+  }
   const float sigT = a.med.sigmaT[0];
   const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
   const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
@@ -247,7 +265,10 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   if (a.cfg.use_shift_null) {
     const f3 dS = tof(zP - v.basePt);
     const f3 bo = dS + offRel;
-    if (dot(bo, bo) < v.r2) offRel = offRel + dS * (-2.f * dot(dS, offRel) / dot(dS, dS));
+    const float bo2 = dot(bo, bo);
+    // (the mirror decision of getShiftPos moves the offset position by up to 2 r: not a counter, but a different shift)
+    amb |= fabsf(bo2 - v.r2) <= 4e-6f * v.r2 ? 8u : 0u;
+    if (bo2 < v.r2) offRel = offRel + dS * (-2.f * dot(dS, offRel) / dot(dS, dS));
   }
   if (HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) {
     // EManifoldShift (shiftPhoton -> shiftPhotonManifold, shift_volume_photon.cpp:49-117,160-295): the walk is the host's.
@@ -264,7 +285,14 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   const f3 dProjU = (tof(zP) - v.ph.parentPos) + offRel;
   bool ok = false;
   f3 sflux = mk3(0.f);
-  const float w = shiftDiffuse<FULLVIS>(a, v.ph, v.ph.bits, dProjU, sh, v.base, v.edge, mk3(v.trS), v.pdfBase, pdfShift, sflux, ok);
+  uint32_t ambVis = 0u;
+  const float w = shiftDiffuse<FULLVIS>(a, v.ph, v.ph.bits, dProjU, sh, v.base, v.edge, mk3(v.trS), v.pdfBase, pdfShift, sflux, ok, nullptr,
+                                        -1.f, &ambVis);
+  if (amb | ambVis) {
+    // fp32 cannot decide this shift as the reference does: the exact pass evaluates it (nothing added, nothing counted)
+    deferNote(a, GVPM_EX_KIND_VPM, sBase + b, pidx, (uint32_t)i, amb | ambVis);
+    return;
+  }
   if (ok) nDiff++; else nFail++;
   vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
 }
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     vpmWaveSync();
     if ((uint32_t)lane < n) {
       const uint2 e = s.rq[(rqHead + lane) % VRQ];
-      vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail);
+      vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail, sBase);
     }
     rqHead = (rqHead + n) % VRQ;
     rqCount -= n;

@@ -249,11 +249,24 @@ __device__ __forceinline__ void deferNote(const GatherArgs &a, uint32_t kind, ui
   const uint32_t slot = atomicAdd(a.exOvfCount, 1u);
   if (slot < a.exOvfCap) a.exOvf[slot] = make_uint4(set, recIdx, kind | (shift << 8) | (cause << 16), 0u);
 }
-// one quad of an entry: 0 header, 1..8 the record, 9..28 the five rays, 29..31 zero
+// one quad of an entry: 0 header, 1..8 the record, 9..28 the five rays, 29 per technique, 30..31 zero
 __device__ __forceinline__ float4 exQuad(const GatherArgs &a, uint32_t set, uint32_t recIdx, uint32_t meta, uint32_t part) {
-  if (part == 0u) return make_float4(__uint_as_float(meta), 0.f, a.iterScale, a.radius);
+  float outScale = a.iterScale, radius = a.radius;
+  float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((meta & 0xFFu) == GVPM_EX_KIND_VPM) {
+    // G-VPM notes name the camera SAMPLE: its beam set, its random number and selection pdf, the pixel's own radius
+    // (querySize = R * POURCENTAGE_BS * gp.scaleVol, gvpm.cpp:1082,1132 -- read before this iteration's update)
+    const gvpm_vpm_sample sm = a.samples[set];
+    set = sm.set;
+    const uint32_t pix = a.rays[(size_t)set * 5].pixel;
+    radius = (a.cfg.bsphere_radius * 0.01f) * a.scaleVol[(size_t)(pix >> 16) * a.cfg.width + (pix & 0xFFFFu)];
+    outScale = 1.f / (float)a.cfg.nb_camera_samples;
+    extra = make_float4(sm.rand, sm.pdf_sel, 0.f, 0.f);
+  }
+  if (part == 0u) return make_float4(__uint_as_float(meta), 0.f, outScale, radius);
   if (part <= GVPM_REC_QUADS) return a.cold[(size_t)recIdx * GVPM_REC_QUADS + (part - 1u)];
   if (part <= GVPM_REC_QUADS + 20u) return reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5)[part - 1u - GVPM_REC_QUADS];
+  if (part == GVPM_REC_QUADS + 21u) return extra;
   return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 

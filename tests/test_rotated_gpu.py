@@ -90,7 +90,11 @@ def test_flag_sweep(rot_case, kw):
 @pytest.mark.parametrize("vis", [1, 0])
 @pytest.mark.parametrize("scene", ["cbox_rot", "cbox_hg_rot", "cbox_phong_rot", "fogroom_rot"])
 def test_vpm(scene, vis):
-    c = make_vpm_case(scene, 32, 28, 40000, 3.0, nb=10, visibility_as_written=vis)
+    # (initialScaleVolume 3.1, not 3.0: at 3.0 one reconnection of pixel (14, 23) has |offsetPos - baseRay(t)|^2 = r^2 (1 - 7.5e-8),
+    # the mirror decision of getShiftPos -- and G-VPM's radius is per-pixel fp32 STATE: R * 0.01 * scaleVol differs by 9e-8
+    # between a float and a double evaluation (gvpm.cpp:1082,1132).  A comparison within 2e-7 of r^2 is a tie of the radius'
+    # own rounding, not a decision the device can share with a double-precision run.)
+    c = make_vpm_case(scene, 32, 28, 40000, 3.1, nb=10, visibility_as_written=vis)
     acc, ref, st = device_vpm(c, exact=True)
     assert st["evaluations"] > 5000
 
