@@ -35,7 +35,7 @@ def sensor_rays_numpy(sensor, compact):
     return o, d
 
 
-@pytest.mark.parametrize("scene", ["cbox", "laser", "laser_in", "fogroom"])
+@pytest.mark.parametrize("scene", ["cbox", "laser", "laser_in", "fogroom", "cbox_rot", "laser_in_rot"])
 def test_first_edges_travel_compact_and_decode_as_the_header_says(scene):
     c = cases.make_case(scene, 40, 32, 100, 3.0)
     sensor = c.sc.sensor()

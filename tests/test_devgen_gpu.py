@@ -31,7 +31,8 @@ def close(a, b):
     return np.allclose(a, b, rtol=2e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("scene,cap", [("cbox", 30000), ("cbox_hg", 9000), ("fogroom", 5000), ("cbox_mirror", 9000)])
+@pytest.mark.parametrize("scene,cap", [("cbox", 30000), ("cbox_hg", 9000), ("fogroom", 5000), ("cbox_mirror", 9000), ("cbox_rot", 9000),
+                                       ("fogroom_rot", 5000)])
 def test_photons_match_the_host_generator(scene, cap):
     sc = SynthScene(scene, 32, 24)
     g = hip.DeviceGenerator(sc)
@@ -46,7 +47,7 @@ def test_photons_match_the_host_generator(scene, cap):
     g.close()
 
 
-@pytest.mark.parametrize("scene,cap", [("cbox", 2500), ("cbox_hg", 1500), ("cbox_mirror", 1500), ("fogroom", 1200)])
+@pytest.mark.parametrize("scene,cap", [("cbox", 2500), ("cbox_hg", 1500), ("cbox_mirror", 1500), ("fogroom", 1200), ("cbox_rot", 1500)])
 def test_device_photons_match_an_independent_implementation(scene, cap):
     """Not a self-comparison: tests/indep_lightpaths.py shares no code with host/synth_core.h, the header both the host
     and the device generator compile (a compiler-dependent evaluation order in that header -- the g++ / clang argument
@@ -87,7 +88,7 @@ def test_beams_and_batches():
 
 
 @pytest.mark.parametrize("scene,mod,rem", [("cbox", 1, 0), ("cbox", 3, 1), ("cbox_in", 1, 0), ("cbox_mirror", 1, 0),
-                                           ("cbox_mirror_side", 2, 1)])
+                                           ("cbox_mirror_side", 2, 1), ("cbox_rot", 1, 0), ("cbox_mirror_rot", 2, 1)])
 def test_camera_beams_match_the_host_generator(scene, mod, rem):
     sc = SynthScene(scene, 44, 36)
     g = hip.DeviceGenerator(sc)

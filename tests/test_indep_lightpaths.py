@@ -17,7 +17,9 @@ def same_photons(got, ref, rtol=0.0):
 
 
 @pytest.mark.parametrize("scene,cap,it", [("cbox", 2500, 1), ("cbox_hg", 1500, 3), ("cbox_in", 1500, 2), ("cbox_mirror", 1500, 2),
-                                          ("fogroom", 1200, 1), ("laser", 600, 4)])
+                                          ("fogroom", 1200, 1), ("laser", 600, 4),
+                                          # general position (round 5): one rotation of everything, inner boxes tilted
+                                          ("cbox_rot", 1500, 1), ("fogroom_rot", 800, 2), ("laser_rot", 400, 3), ("cbox_mirror_rot", 1000, 2)])
 def test_host_generator_equals_the_independent_walk(scene, cap, it):
     sc = SynthScene(scene, 16, 16)
     got, nb = IL.shoot_photons(IL.Scene(sc.devgen_scene()), it, cap)

@@ -24,7 +24,7 @@ def compare(c, tol=1e-9):
     return cnt
 
 
-@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_in", "cbox_mirror"])
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_in", "cbox_mirror", "cbox_rot", "cbox_hg_rot", "cbox_mirror_rot"])
 def test_bre3d_all_27_accumulators(scene):
     c = cases.make_case(scene, 20, 16, 4000, 4.0)
     cnt = compare(c)
@@ -70,7 +70,7 @@ def compare_beams(c, tol=1e-9):
 
 
 @pytest.mark.parametrize("tech", TECHS)
-@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "laser"])
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "laser", "cbox_rot", "laser_rot"])
 def test_beams_all_27_accumulators(tech, scene):
     c = make_beam_case(scene, 12, 10, 1500, 4.0, technique=tech)
     cnt = compare_beams(c)
@@ -97,7 +97,8 @@ def test_beams_fine_image_takes_the_null_shift():
 from test_oracle_planes import make_plane_case  # noqa: E402
 
 
-@pytest.mark.parametrize("scene,g", [("cbox_in", 0.0), ("cbox_in", 0.7), ("laser_in", 0.0), ("laser_in_hg", 0.7)])
+@pytest.mark.parametrize("scene,g", [("cbox_in", 0.0), ("cbox_in", 0.7), ("laser_in", 0.0), ("laser_in_hg", 0.7), ("cbox_in_rot", 0.0),
+                                     ("laser_in_hg_rot", 0.7)])
 @pytest.mark.parametrize("kw", [dict(), dict(use_mis=0)])
 def test_planes_all_27_accumulators(scene, g, kw):
     c = make_plane_case(scene, 16, 12, 1500, **kw)
@@ -117,8 +118,8 @@ def test_planes_all_27_accumulators(scene, g, kw):
 from test_oracle_vpm import make_vpm_case  # noqa: E402
 
 
-@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_mirror"])
-@pytest.mark.parametrize("kw", [dict(), dict(use_mis=0), dict(use_shift_null=0), dict(max_depth=3)])
+@pytest.mark.parametrize("scene,kw", [(s, k) for s in ("cbox", "cbox_hg", "cbox_mirror") for k in (dict(), dict(use_mis=0), dict(use_shift_null=0), dict(max_depth=3))]
+                         + [("cbox_rot", dict()), ("cbox_rot", dict(visibility_as_written=0))])
 def test_vpm_all_27_accumulators(scene, kw):
     c = make_vpm_case(scene, 12, 10, 6000, 8.0, 6, **kw)
     ref, rsv, rnv, cnt, _ = O.gather_vpm(c.p, c.m, c.tris, c.ph, c.rays, c.samples, 64, use_accel=True)
