@@ -117,7 +117,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU under torch.distributed.run as a CHILD process,
+        # before anything in this process has touched the GPU (a process that has initialised the GPU must not exec another
+        # program on this pool); rank 0's JSON line is the child's stdout, its exit code ours
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     # every GVPM_* variable changes what is measured: they are reported, and the evaluation-skipping development
     # switch of round 1 (compiled out since) is refused outright

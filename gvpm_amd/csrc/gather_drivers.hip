@@ -203,7 +203,11 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
   if (deferred && !h->bundleFromEnv) {
-    const bool sharded = h->nsets > 0 && (size_t)h->nsets * 2u <= h->npix;
+    // "a rank's share of an image-sharded frame": the beam sets cover at most half of the pixels.  With hysteresis (ADVICE
+    // round 4): a frame whose medium covers about half the pixels must not flip the cell kind -- and the planner's tuning with
+    // it -- from step to step; the kind is left only beyond 0.6 / below 0.4 of the frame.
+    const size_t twice = (size_t)h->nsets * 2u;
+    const bool sharded = h->nsets > 0 && (h->bundleEnabled ? twice * 5u <= h->npix * 6u : twice * 5u <= h->npix * 4u);
     if (sharded != h->bundleEnabled) {
       h->bundleEnabled = sharded;
       if (sharded && h->bundleState < 0) h->bundleState = 0;  // (a frame that failed earlier is tried again, a few times)

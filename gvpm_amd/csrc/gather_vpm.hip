@@ -218,7 +218,7 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
       if (a.cfg.use_shift_null && y2 < v.r2) {
         // shiftNull, shift_volume_photon.cpp:119-158
         // pdfShiftRay = shiftMRec.pdfSuccess * pdfSel, normalised over [Epsilon, shiftDistMax]
-        const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
+        const float normS = -expm1f(-sigT * (sh.len - a.cfg.epsilon));
         const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
         sflux = mk3(v.trS) * (v.photonIn * phaseEval(a.med.g, v.ph.wi, -sh.d)) * sh.eye;
         w = 0.5f;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
     amb = (fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len) || (a.cfg.use_shift_null && fabsf(dot(y, y) - v.r2) <= 4e-6f * v.r2)) ? 2u : 0u;
   }
   const float sigT = a.med.sigmaT[0];
-  const float normS = 1.f - __expf(-sigT * (sh.len - a.cfg.epsilon));
+  const float normS = -expm1f(-sigT * (sh.len - a.cfg.epsilon));
   const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
   const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
   f3 offRel = v.rel;
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
       // the two results are stored as); the normalisation over the whole edge feeds a float too: one fp64 exponential and
       // one logarithm per sample instead of three and one
       const double e = 1.0 - (double)rnd * normalization;
-      const float nrm2 = 1.f - __expf(-(float)sigT * (float)distSurf);
+      // (1 - exp(-x) as -expm1(-x): in a thin medium, sigma_t d ~ 1e-3, the difference loses four digits -- and all, below 6e-8)
+      const float nrm2 = -expm1f(-(float)sigT * (float)distSurf);
       pdfBase = ((float)sigT / nrm2) * (float)e * pdfSel;  // mRec.pdfSuccess * pdfSel
       trBase = (float)e;
       if (trBase < 1e-20f) trBase = 0.f;

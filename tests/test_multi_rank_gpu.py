@@ -69,6 +69,22 @@ def test_bench_two_ranks_is_the_strong_sharded_c4_shape():
     assert line["roofline"]["kernel_avg_ms"] > 0 and line["config"]["pixels_per_gpu"] == 128 * 128 / 2
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` as the driver spells the N = 1 command (round 5): with WORLD_SIZE
+    unset the script starts torch.distributed.run itself -- as a child process, before it touches the GPU -- and passes on
+    rank 0's line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                          "--single-device", "--frame", "128", "--photons", "60000", "--distinct", "2"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["steps"] == 2
+
+
 def test_bench_eight_ranks_run_to_completion_on_one_gpu():
     """The driver's 8-GPU launch is `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...`: the same
     command here with the eight ranks on GPU 0 over gloo and a small frame, so that the driver's run is not the first

@@ -61,6 +61,18 @@ def test_vpm_matches_fp64_oracle(scene):
     assert st["evaluations"] > 5000
 
 
+def test_vpm_thin_medium():
+    """sigma_t d ~ 1e-3: the distance pdf's normalisation 1 - exp(-sigma_t d) must not be formed as a difference in fp32
+    (1e-4 relative error at sigma_t d = 1e-3, an infinite pdf below 6e-8)"""
+    c = make_vpm_case("cbox", 32, 28, 40000, 5.0, nb=10)
+    for k in range(3):
+        c.m.sigma_s[k] = 2.5e-4
+        c.m.sigma_a[k] = 2.5e-4
+        c.m.sigma_t[k] = 5e-4
+    acc, ref, st = device_vpm(c)
+    assert st["evaluations"] > 5000
+
+
 def test_vpm_three_iterations_sppm_state():
     c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=8)
     device_vpm(c, iters=3)
