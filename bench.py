@@ -598,7 +598,7 @@ def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
     map.  Reported, not targeted."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    cores, physical = host_threads()
     r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
 
     def run(rows, threads):
@@ -627,7 +627,7 @@ def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
         per_row = max(ev / min(8, H), 1.0)
         rows = int(min(H, max(8, (budget_s * gather_rate) / per_row)))
     ev, s, b, nsets = run(rows, cores)
-    out = {"value": ev / s / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
+    out = {"value": ev / s / 1e6, "unit": "Mevals/s", "cores": cores, "physical_cores": physical, "kind": "port",
            "build_s": b, "gather_s": s - b, "gather_only_value": ev / max(s - b, 1e-9) / 1e6,
            "sample": f"iteration 1, the middle {rows} of {H} pixel rows ({nsets} beam sets), the full map through the "
                      f"reference's accelerator; its serial build ({b:.2f} s) + the gather on {cores} threads ({s - b:.2f} s), "
@@ -800,6 +800,17 @@ def parity(hip, metrics, sc, p, m, tris, first, W, H):
     }
 
 
+def host_threads():
+    """(hardware threads, physical cores) of this host"""
+    threads = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or threads
+    except Exception:
+        physical = threads
+    return threads, physical
+
+
 def cpu_baseline(p, m, tris, host0, W, H):
     """The oracle (fp32, fast-math, kd-tree -> BVH walk as the reference) timed on this box's host cores on a bounded
     sample of the same workload.  All cores: the first --cpu-iters iterations (their own photon maps and camera beams),
@@ -808,8 +819,9 @@ def cpu_baseline(p, m, tris, host0, W, H):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
-    cores = os.cpu_count() or 1
+    cores, physical = host_threads()
     evals, secs, nsets, build = 0, 0.0, 0, 0.0
+    cpu0 = time.process_time()
     for ph, nb, rays in host0:
         tm = {}
         _, cnt, s = O.gather_bre(p, m, tris, ph, rays, r, 1, nb, precision=32, use_accel=True, threads=cores, fast=True,
@@ -818,6 +830,7 @@ def cpu_baseline(p, m, tris, host0, W, H):
         secs += s
         build += tm["build_s"]
         nsets += rays.shape[0]
+    cpu_s = time.process_time() - cpu0
     # one thread: iteration 1, a window sized for ~5-10 s (the whole 512x512 frame of C2)
     ph, nb, rays = host0[0]
     w1 = min(W, H, 512)
@@ -830,6 +843,10 @@ def cpu_baseline(p, m, tris, host0, W, H):
                                fast=True, timing=tm1)
     return {
         "value": evals / secs / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
+        # `cores` = the THREADS the gather ran on (hardware threads: os.cpu_count()); physical cores beside it, and how busy
+        # the threads were during the gather (CPU seconds / (threads x gather seconds): the serial build counts for one)
+        "physical_cores": physical,
+        "thread_utilisation": (cpu_s - build) / max(cores * (secs - build), 1e-9),
         # the kd-tree + BVH build is serial in the reference (gvpm.cpp:450-454) and in the port: the split says how much of
         # the all-core figure is that one thread
         "build_s": build, "gather_s": secs - build, "gather_only_value": evals / max(secs - build, 1e-9) / 1e6,

@@ -37,11 +37,12 @@ int gatherBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
   if (threads > 0) omp_set_num_threads(threads);
 #endif
   // BlockScheduler (photonmapper/utilities/block_sched.h:87-113): threads pull
-  // work dynamically; here a work item is a run of 256 consecutive beam sets
+  // work dynamically; here a work item is a run of 16 consecutive beam sets (round 5: runs of 256 left ~4 items a thread on
+  // a 256-thread host over a heavy-tailed load -- 7x on 256 threads)
 #pragma omp parallel
   {
     Counters local;
-#pragma omp for schedule(dynamic, 256)
+#pragma omp for schedule(dynamic, 16)
     for (int64_t s = 0; s < (int64_t)nsets; ++s) g.gatherSetBRE(rays + 5 * s, useAccel != 0, &perSet[(size_t)s * 27], local);
 #pragma omp critical
     total.add(local);
@@ -89,7 +90,7 @@ int gatherPrimalBRE(const gvpm_params *p, const gvpm_medium *m, const gvpm_trian
 #pragma omp parallel
   {
     Counters local;
-#pragma omp for schedule(dynamic, 256)
+#pragma omp for schedule(dynamic, 16)
     for (int64_t s = 0; s < (int64_t)nsets; ++s) gatherBeamPrimalBRE<F>(g, rays[5 * s], useAccel != 0, &perSet[(size_t)s * 3], local);
 #pragma omp critical
     total.add(local);
@@ -140,7 +141,7 @@ int gatherVPM(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *
 #pragma omp parallel
   {
     Counters local;
-#pragma omp for schedule(dynamic, 256)
+#pragma omp for schedule(dynamic, 16)
     for (int64_t s = 0; s < (int64_t)nsamples; ++s) {
       const gvpm_vpm_sample &sm = samples[s];
       if (sm.set >= nsets) { bad = 1; continue; }
