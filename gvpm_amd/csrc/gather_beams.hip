@@ -338,7 +338,7 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
   const double newPBDist = sqrt(len2(newPBDir));
   newPBDir = newPBDir / newPBDist;
   // visibility over the whole new beam [Epsilon, newPBDist], shift_volume_beams.cpp:420-426
-  if (anyHitScene(a.bvh, a.tri4, a.ntri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist) & 1) return 1.0;
+  if (anyHitScene<true>(a.bvh, a.tri4, a.ntri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist) & 1) return 1.0;
   const d3 basePos = b.p1 + b.dir * kRec.v;
   const double pdfKernelAndDist = kpdf(kRec);
   // diffuseReconnectionPhotonBeam, shift_diffuse.cpp:136-268
@@ -762,9 +762,9 @@ __device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const Bea
   const bool ovf = beamNearOverflow(fmt, b.nl0, b.nl2);
   if (!ldsTri) {
     // (more occluders than the kernel's LDS holds: the lists' triangles from global memory; a list that overflowed walks the BVH)
-    if (ovf) return (anyHitScene(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist) & 1) != 0;
+    if (ovf) return (anyHitScene<true>(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist) & 1) != 0;
     if (fmt.bits == 8u)
-      return (nearListHit(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist)) & 1) != 0;
+      return (nearListHit<true>(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist)) & 1) != 0;
     return beamNearLoop(a, fmt, false, b, a.tri4, nd, dist);
   }
   return beamNearLoop(a, fmt, ovf, b, ldsTri, nd, dist);

@@ -99,6 +99,14 @@ __device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s,
   return r;
 }
 
+// 1 - exp(-x), x >= 0, without the cancellation of the difference in a thin medium (sigma_t d ~ 1e-3 loses four digits, below
+// 6e-8 all of them: ADVICE round 4): the series below 1/16, the difference above (relative error < 2e-6 there).  (expm1f is
+// exact to an ulp but costs the C1 kernel 9 %: it sits in every null shift.)
+__device__ __forceinline__ float oneMinusExpNeg(float x) {
+  const float ser = x * (1.f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.0083333333f))));
+  return x < 0.0625f ? ser : 1.f - __expf(-x);
+}
+
 __device__ __forceinline__ void vpmAdd(const GatherArgs &a, VpmLds &s, int k, uint32_t b, float v) {
   const uint32_t r = s.run[b];
   if (r < (uint32_t)VPM_RUNS) {
@@ -204,7 +212,7 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
     // test against r^2, within the error band of the fp32 numbers -- is queued like a reconnection; phase 2 re-derives the
     // test and hands the shift to the exact pass, exact_shift.hip)
     if (sh.valid && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len)) {
-      qMask |= 1u << i;
+      qMask |= 0x11u << i;  // (bit 4 + i: "undecidable", carried to phase 2 in the queue entry)
       continue;
     }
     if (sh.valid && sh.len >= v.tf) {
@@ -212,13 +220,13 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
       const f3 y = tof(v.pD - zP);
       const float y2 = dot(y, y);
       if (a.cfg.use_shift_null && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(y2 - v.r2) <= 4e-6f * v.r2) {
-        qMask |= 1u << i;
+        qMask |= 0x11u << i;
         continue;
       }
       if (a.cfg.use_shift_null && y2 < v.r2) {
         // shiftNull, shift_volume_photon.cpp:119-158
         // pdfShiftRay = shiftMRec.pdfSuccess * pdfSel, normalised over [Epsilon, shiftDistMax]
-        const float normS = -expm1f(-sigT * (sh.len - a.cfg.epsilon));
+        const float normS = oneMinusExpNeg(sigT * (sh.len - a.cfg.epsilon));
         const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
         sflux = mk3(v.trS) * (v.photonIn * phaseEval(a.med.g, v.ph.wi, -sh.d)) * sh.eye;
         w = 0.5f;
@@ -248,17 +256,13 @@ template <bool FULLVIS, bool HS>
 __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t meta, float norm,
                                           uint32_t &nDiff, uint32_t &nFail, uint32_t sBase) {
   const uint32_t b = meta & 0xFFu;
-  const int i = (int)(meta >> 8);
+  const int i = (int)((meta >> 8) & 0xFFu);
+  // (bit 16: phase 1 could not decide this shift's branch and queued it to be deferred here)
+  uint32_t amb = (meta >> 16) & 1u ? 2u : 0u;
   const VpmPair v = vpmPair(a, s, pidx, b, norm);
   const RayReg sh = loadRayV(a, s, 1 + i, b);
-  // phase 1's branch tests from phase 1's numbers: an undecidable branch was queued to be deferred here
-  uint32_t amb = 0u;
-  if (!(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u)) {
-    const f3 y = tof(v.pD - (tod(sh.o) + tod(sh.d) * v.t));
-    amb = (fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len) || (a.cfg.use_shift_null && fabsf(dot(y, y) - v.r2) <= 4e-6f * v.r2)) ? 2u : 0u;
-  }
   const float sigT = a.med.sigmaT[0];
-  const float normS = -expm1f(-sigT * (sh.len - a.cfg.epsilon));
+  const float normS = oneMinusExpNeg(sigT * (sh.len - a.cfg.epsilon));
   const float pdfShift = (sigT / normS) * __expf(-sigT * v.tf) * v.pdfSel;
   const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
   f3 offRel = v.rel;
@@ -394,8 +398,7 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
       // the two results are stored as); the normalisation over the whole edge feeds a float too: one fp64 exponential and
       // one logarithm per sample instead of three and one
       const double e = 1.0 - (double)rnd * normalization;
-      // (1 - exp(-x) as -expm1(-x): in a thin medium, sigma_t d ~ 1e-3, the difference loses four digits -- and all, below 6e-8)
-      const float nrm2 = -expm1f(-(float)sigT * (float)distSurf);
+      const float nrm2 = oneMinusExpNeg((float)sigT * (float)distSurf);
       pdfBase = ((float)sigT / nrm2) * (float)e * pdfSel;  // mRec.pdfSuccess * pdfSel
       trBase = (float)e;
       if (trBase < 1e-20f) trBase = 0.f;
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
       if (m) {
         if (want) {
           const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-          s.rq[(rqHead + rqCount + off) % VRQ] = make_uint2(e.x, e.y | (i << 8));
+          s.rq[(rqHead + rqCount + off) % VRQ] = make_uint2(e.x, e.y | (i << 8) | (((qMask >> (4u + i)) & 1u) << 16));
         }
         rqCount += __popcll(m);
         if (rqCount >= 64u) drain(64u);

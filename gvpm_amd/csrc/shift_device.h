@@ -51,7 +51,7 @@ __device__ __forceinline__ void mediumEval(const MediumDev &m, float dist, f3 &t
 // rounding residue and t >= mint is decided by it.  The generic near-threshold cases (a hit within 1e-6 of an edge) go the same way.
 #define GVPM_TRI_MISS 0
 #define GVPM_TRI_HIT 1
-#define GVPM_TRI_AMB 2  /* | fp32 decision in bit 0 */
+#define GVPM_TRI_AMB 2
 // s0 = n . (o - v0), sd = n . d with the stored unit normal (callers have them for the plane-side early-out).  The interval
 // test  mint <= t <= maxt  is the statement "the segment's ends lie on different sides of the triangle's plane":
 // e0 = s0 + sd mint and e1 = s0 + sd maxt, each good to mE ~ 5e-7 (|o|_1 + |v0|_1 + maxt) -- eight times tighter than the
@@ -76,11 +76,7 @@ __device__ __forceinline__ int triHit3(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mi
   const bool noCross = lo > mE || hi < -mE, cross = lo < -mE && hi > mE;
   const bool fail = noCross || sA < -mA || s2 < -m2 || sB < -mB || s4 < -m4;
   const bool pass = cross && aC > mC && sA > mA && s2 > m2 && sB > mB && s4 > m4;
-  if (fail) return GVPM_TRI_MISS;
-  if (pass) return GVPM_TRI_HIT;
-  // (the plain decision, for callers without an exact pass)
-  const bool plain = C != 0.f && sA >= 0.f && s2 >= 0.f && sB >= 0.f && s4 >= 0.f && lo <= 0.f && hi >= 0.f;
-  return GVPM_TRI_AMB | (plain ? 1 : 0);
+  return fail ? GVPM_TRI_MISS : (pass ? GVPM_TRI_HIT : GVPM_TRI_AMB);
 }
 __device__ __forceinline__ int triHit3(const float4 t0, const float4 t1, const float4 t2, f3 o, f3 d, float mint, float maxt, float oAbs1) {
   const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
@@ -88,17 +84,21 @@ __device__ __forceinline__ int triHit3(const float4 t0, const float4 t1, const f
 }
 // any-hit over a list: a certain hit settles it; else an undecidable triangle makes the whole answer undecidable
 __device__ __forceinline__ int triCombine(int acc, int t) {
-  // acc, t in {0 miss, 1 hit, 2 amb/miss, 3 amb/hit}
   if (acc == GVPM_TRI_HIT || t == GVPM_TRI_HIT) return GVPM_TRI_HIT;
-  if ((acc | t) & GVPM_TRI_AMB) return GVPM_TRI_AMB | ((acc | t) & 1);
-  return GVPM_TRI_MISS;
+  return (acc | t) & GVPM_TRI_AMB;
 }
-// the plain fp32 test of a triangle record (the beams' loops, until they defer too)
+// the plain fp32 test (branch-free: the tests of the reference are and-ed; a zero determinant gives inf / NaN, which fail
+// the comparisons like the early return): the G-Beams loops, whose shifts have no exact pass yet
 __device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt) {
-  const f3 n = cross(e1, e2);
-  const float il = frsq(fmaxf(dot(n, n), 1e-36f));
-  const int t = triHit3(v0, e1, e2, o, d, mint, maxt, fabsf(o.x) + fabsf(o.y) + fabsf(o.z), dot(n, o - v0) * il, dot(n, d) * il);
-  return (t & 1) != 0;
+  const f3 pvec = cross(d, e2);
+  const float det = dot(e1, pvec);
+  const float inv = frcp(det);
+  const f3 tvec = o - v0;
+  const float u = dot(tvec, pvec) * inv;
+  const f3 qvec = cross(tvec, e1);
+  const float v = dot(d, qvec) * inv;
+  const float t = dot(e2, qvec) * inv;
+  return det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= mint && t <= maxt;
 }
 // The same test in uncontracted fp64, in the operation order of the oracle's (and the reference's) statement.
 __device__ __forceinline__ bool triHitExact(f3 v0f, f3 e1f, f3 e2f, f3 of, d3 dd, double mint, double maxt) {
@@ -123,6 +123,7 @@ __device__ __forceinline__ bool triHitExact(f3 v0f, f3 e1f, f3 e2f, f3 of, d3 dd
 // {v0,n.x} {e1,n.y} {e2,n.z} in leaf order.  Deliberately not inlined: it is the rare path (the
 // as-written shadow segment is served by the per-photon near-occluder list below) and inlining
 // it cost the evaluation kernels ~160 VGPRs.  Returns a GVPM_TRI_* state.
+template <bool PLAIN = false>
 static __device__ __noinline__ int anyHitScene(const float4 *bvh, const float4 *tri4, uint32_t ntri, f3 o, f3 d, float mint,
                                         float maxt) {
   if (ntri == 0u) return GVPM_TRI_MISS;
@@ -149,8 +150,14 @@ static __device__ __noinline__ int anyHitScene(const float4 *bvh, const float4 *
         descend = true;
       } else {
         for (uint32_t i = first; i < first + count; ++i) {
-          res = triCombine(res, triHit3(tri4[3 * (size_t)i], tri4[3 * (size_t)i + 1], tri4[3 * (size_t)i + 2], o, d, mint, maxt, oAbs1));
-          if (res == GVPM_TRI_HIT) return res;
+          if (PLAIN) {
+            // (the G-Beams callers: plain fp32 decisions, no exact pass behind them yet)
+            const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
+            if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) return GVPM_TRI_HIT;
+          } else {
+            res = triCombine(res, triHit3(tri4[3 * (size_t)i], tri4[3 * (size_t)i + 1], tri4[3 * (size_t)i + 2], o, d, mint, maxt, oAbs1));
+            if (res == GVPM_TRI_HIT) return res;
+          }
         }
       }
     }
@@ -179,6 +186,7 @@ __device__ __forceinline__ bool planeSideMiss(float s0, float sd, float mint, fl
   return fminf(e0, e1) > margin || fmaxf(e0, e1) < -margin;
 }
 
+template <bool PLAIN = false>
 __device__ __forceinline__ int nearListHit(const float4 *tri, uint32_t nl0, uint32_t nl1, uint32_t nl2, f3 o, f3 d,
                                            float mint, float maxt, float margin) {
   int res = GVPM_TRI_MISS;
@@ -196,7 +204,8 @@ __device__ __forceinline__ int nearListHit(const float4 *tri, uint32_t nl0, uint
     const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
     const float s0 = dot(nrm, o - v0), sd = dot(nrm, d);
     if (planeSideMiss(s0, sd, mint, maxt, margin)) continue;
-    res = triCombine(res, triHit3(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt, oAbs1, s0, sd));
+    if (PLAIN) res |= triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt) ? GVPM_TRI_HIT : GVPM_TRI_MISS;
+    else res = triCombine(res, triHit3(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt, oAbs1, s0, sd));
   }
   return res;
 }
@@ -232,15 +241,16 @@ __device__ __forceinline__ int nearListHitExt(const float4 *tri, const uint32_t 
 template <bool FULLVIS>
 __device__ __forceinline__ int shadowBlocked(const GatherArgs &a, const float4 *ldsTri, uint32_t nl0, uint32_t nl1,
                                              uint32_t nl2, f3 o, f3 d, float mint, float maxt) {
-  if (FULLVIS) return anyHitScene(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
+  constexpr bool PL = false;
+  if (FULLVIS) return anyHitScene<PL>(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
   if (a.ntri > GVPM_NEAR_NARROW_MAX) {
     if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
     return nearListHitWide(a.tri4, nl0, nl1, nl2, o, d, mint, maxt);
   }
   if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
   const float margin = planeSideMargin(a.triAbs1, o, maxt);
-  return ldsTri ? nearListHit(ldsTri, nl0, nl1, nl2, o, d, mint, maxt, margin)
-                : nearListHit(a.tri4, nl0, nl1, nl2, o, d, mint, maxt, margin);
+  return ldsTri ? nearListHit<PL>(ldsTri, nl0, nl1, nl2, o, d, mint, maxt, margin)
+                : nearListHit<PL>(a.tri4, nl0, nl1, nl2, o, d, mint, maxt, margin);
 }
 
 // ---- deferral to the exact pass (device_types.h, ExEntry) ----
@@ -425,7 +435,7 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
   // (amb: the caller defers undecidable shifts to the exact pass; without one the plain fp32 decision stands)
   const int vis = shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
-  bool good = !(vis & 1);
+  bool good = vis == GVPM_TRI_MISS;
   const float cosWo = dot(ph.parentN, dProj);
   // (the sign / cosine tests below flip within fp32 rounding of a grazing direction)
   if (amb) *amb = ((vis & GVPM_TRI_AMB) ? 16u : 0u) | ((GVPM_PF_PARENT_TYPE(bits) != GVPM_PARENT_MEDIUM && fabsf(cosWo) <= 2e-6f) ? 32u : 0u);
