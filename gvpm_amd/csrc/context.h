@@ -323,7 +323,7 @@ struct gvpm_context {
   DevBuf<uint32_t> exOvfCount;
   DevBuf<unsigned long long> exTotals;
   uint32_t exPayCap = 1u << 20;      // 512 MB, allocated with the first gather that can defer
-  uint32_t exOvfCap = 1u << 18;
+  uint32_t exOvfCap = 1u << 20;      // 16 MB of notes per gather
   uint32_t exSince = 0;              // gathers since the last pass
   uint32_t exFlushEvery = 8;         // paced by what the last pass found (pinExact[0]): the list is kept below a quarter full
   bool exFlushFixed = false;         // GVPM_EXACT_EVERY

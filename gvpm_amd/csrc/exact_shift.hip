@@ -241,7 +241,7 @@ __device__ __forceinline__ void finishPass(const GatherArgs &a, uint32_t nEval, 
         atomicMax(&totals[2], (unsigned long long)total);
         if (lost) atomicAdd(&totals[1], lost);
       }
-      if (lost) atomicAdd(&a.stats[5], lost);  // dropped: gvpm_get_stats fails
+      if (lost) atomicAdd(&a.stats[7], lost);  // dropped (gvpm_stats::dropped_pairs): gvpm_get_stats fails
       a.exPayCount[0] = 0u;
       a.exPayCount[1] = 0u;
       a.exPayCount[2] = 0u;

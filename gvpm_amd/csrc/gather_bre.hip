@@ -305,6 +305,9 @@ __device__ __forceinline__ BaseTerms baseTerms(const GatherArgs &a, const LDS &s
 // hands it to the exact pass (one deferral site in the kernel: its copy loops cost registers).
 __device__ __forceinline__ bool branchAmbiguous(const GatherArgs &a, float y2, float r2, float tPf, float shLen) {
   // y is good to ~2e-7 |y| (the two differences are formed in fp64 / as exact fp32 differences), t' to half an ulp
+  // (cfg.reserved[4]: GVPM_EXACT_ALL -- the band widened to everything, so that the exact pass evaluates EVERY shift: a test
+  // of the pass against the oracle on whole frames, tests/test_exact_pass_gpu.py)
+  if (a.cfg.reserved[4]) return true;
   return (a.cfg.use_shift_null && fabsf(y2 - r2) <= 4e-6f * r2) || fabsf(tPf - shLen) <= 4e-7f * (tPf + shLen);
 }
 template <int B, bool HS, typename LDS>

@@ -211,7 +211,8 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
     // (round 5: a shift whose branch fp32 cannot decide -- the distance against the shifted edge's length, the null-shift
     // test against r^2, within the error band of the fp32 numbers -- is queued like a reconnection; phase 2 re-derives the
     // test and hands the shift to the exact pass, exact_shift.hip)
-    if (sh.valid && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len)) {
+    // (cfg.reserved[4]: GVPM_EXACT_ALL -- every shift to the exact pass, tests/test_exact_pass_gpu.py)
+    if (sh.valid && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && (a.cfg.reserved[4] || fabsf(v.tf - sh.len) <= 4e-7f * (v.tf + sh.len))) {
       qMask |= 0x11u << i;  // (bit 4 + i: "undecidable", carried to phase 2 in the queue entry)
       continue;
     }

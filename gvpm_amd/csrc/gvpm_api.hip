@@ -98,6 +98,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   // (every reserved word is the library's: a caller's struct that was never zeroed must not switch anything -- reserved[5]
   // is the G-Beams primal pass's flag, set per launch by its driver)
   h->cfg.reserved[4] = h->cfg.reserved[5] = 0;
+  if (const char *e = getenv("GVPM_EXACT_ALL")) h->cfg.reserved[4] = atoi(e) ? 1 : 0;  // (tests: every shift through the exact pass)
   h->cfg.reserved[3] = 0;  // G-BRE traversal: staged photons per box row set from which the staging is lane-coalesced (0 = default)
   if (const char *e = getenv("GVPM_COALESCE_AT")) h->cfg.reserved[3] = atoi(e);
   if (const char *e = getenv("GVPM_PLAN_TARGET")) {
@@ -434,7 +435,7 @@ int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   out->reserved[1] = v[6];
   if (v[6]) return fail(h, GVPM_ERR_STATE, "packed photon records named materials beyond the uploaded table (decoded as black)");
   // the planner's bound on an item's pair region is exact: a dropped pair means a biased image, not a slow one
-  if (v[7]) return fail(h, GVPM_ERR_STATE, "the G-BRE traversal dropped pairs: planner bound violated");
+  if (v[7]) return fail(h, GVPM_ERR_STATE, "pairs or deferred shifts were dropped (the G-BRE planner's bound violated, or the exact pass's lists full)");
   return GVPM_OK;
 }
 
