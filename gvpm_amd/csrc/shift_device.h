@@ -18,8 +18,11 @@ struct RayReg {
   bool valid;
 };
 
-// g == 0 (isotropic) needs no special case: temp = 1 and the formula returns 1/4pi exactly
+// g == 0: the isotropic plugin's constant (src/phase/isotropic.cpp:76-78) -- the formula returns 1/4pi exactly there too,
+// but g is wave-uniform wherever it is the medium's: a scalar branch instead of a dot product, a square root and a
+// reciprocal per call (six calls an evaluation; C2: -1 % on the step)
 __device__ __forceinline__ float phaseEval(float g, f3 wi, f3 wo) {
+  if (g == 0.f) return INV_FOURPI_F;
   const float temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
   return INV_FOURPI_F * (1.f - g * g) * frcp(temp * fsqrt(temp));
 }
