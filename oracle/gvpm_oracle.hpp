@@ -1063,7 +1063,9 @@ template <typename F> struct PhotonMap {
   // GradientBeamRadianceEstimator::query, gvpm/gvpm_accel.h:268-312
   template <typename Q> void queryBRE(const Ray<F> &ray, Q &queryRequest, F randValue) const {
     if (photons.empty()) return;
-    std::vector<uint32_t> stackStorage(depth + 2);
+    // (one stack per thread, grown on demand: an allocation per query serialised 256 threads in malloc -- 6x on 256)
+    static thread_local std::vector<uint32_t> stackStorage;
+    if (stackStorage.size() < (size_t)depth + 2) stackStorage.resize((size_t)depth + 2);
     uint32_t *stack = stackStorage.data();
     uint32_t index = 0, stackPos = 1;
     while (stackPos > 0) {
@@ -1101,7 +1103,9 @@ template <typename F> struct PhotonMap {
   // Returns the number of functor invocations (MVol).
   template <typename Q> size_t executeQuery(const V &p, F searchRadius, Q &functor) const {
     if (photons.empty()) return 0;
-    std::vector<uint32_t> stackStorage(depth + 2);
+    // (one stack per thread, grown on demand: an allocation per query serialised 256 threads in malloc -- 6x on 256)
+    static thread_local std::vector<uint32_t> stackStorage;
+    if (stackStorage.size() < (size_t)depth + 2) stackStorage.resize((size_t)depth + 2);
     uint32_t *stack = stackStorage.data();
     uint32_t index = 0, stackPos = 1, found = 0;
     F distSquared = searchRadius * searchRadius;

@@ -82,7 +82,9 @@ inline Vec3<F> primalQueryBRE(const Gatherer<F> &g, const Ray<F> &r, int maxDept
   };
   if (map.photons.empty()) return result;
   if (useAccel) {
-    std::vector<uint32_t> stackStorage(map.depth + 2);
+    // (one stack per thread, grown on demand: an allocation per query serialised 256 threads in malloc -- 6x on 256)
+    static thread_local std::vector<uint32_t> stackStorage;
+    if (stackStorage.size() < (size_t)map.depth + 2) stackStorage.resize((size_t)map.depth + 2);
     uint32_t *stack = stackStorage.data();
     uint32_t index = 0, stackPos = 1;
     while (stackPos > 0) {
