@@ -75,23 +75,48 @@ __device__ __forceinline__ f3 atLocal(const LocalRay &r, float sigma) { return r
 
 // cylinderIntersection (pm/beams_3d_intersections.h:77-140) for a view line V + t*dv against the cylinder of
 // radius r around A + z*da, z in [z0, z1]; rel = V - A.  tLo / tHi: the view ray's 0 and maxt, measured from V.
+//
+// amb (round 5, optional): set when one of the function's DECISIONS -- the discriminant's sign, the roots against
+// [tLo, tHi], the ends' heights against [z0, z1] -- lies within the fp32 error of its operands (the caller then hands the
+// shift to the exact pass -- gather_beams.hip, exact_beams_kernel -- and the return value is not used).  The error model,
+// with u = 2^-24 and a safety factor of ~20 on every term: the dot products are good to ~4u of the products' magnitudes, so
+// disc = Bh^2 - A C carries ~4e-7 (Bh^2 + R2), R2 = |rel|^2 + r^2 (A <= 1; its own rounding times |C| <= R2 included);
+// sqrt turns that into eq = err(disc) / (2 sqrt(disc)) on q; x0 = q / A adds A's rounding over A; x1 = C / q adds C's.
 __device__ __forceinline__ bool cylLocal(f3 rel, f3 dv, f3 da, float z0, float z1, float r, float tLo, float tHi,
-                                         float &tN, float &tF) {
+                                         float &tN, float &tF, bool *amb = nullptr) {
   const float dd = dot(dv, da);
   const float rz = dot(rel, da);
   const float A = 1.f - dd * dd;
   const float Bh = dot(rel, dv) - rz * dd;
+  const float R2 = dot(rel, rel) + r * r;
   const float C = dot(rel, rel) - rz * rz - r * r;
   const float disc = Bh * Bh - A * C;
+  const float S = Bh * Bh + R2;
+  if (amb && (A < 1e-6f || fabsf(disc) <= 2e-5f * S)) {
+    *amb = true;
+    return false;
+  }
   if (!(A > 0.f) || !(disc > 0.f)) return false;  // lines farther apart than r (or parallel)
   const float sq = fsqrt(disc);
   const float q = Bh < 0.f ? (sq - Bh) : -(Bh + sq);
   float x0 = fdiv(q, A), x1 = fdiv(C, q);
+  float tE = 0.f;
+  if (amb) {
+    const float eq = fdiv(2e-6f * S, sq), iA = frcp(A), iq = frcp(fabsf(q));
+    tE = fmaxf((eq + 4e-6f * fabsf(x0)) * iA, (2e-6f * R2 + fabsf(x1) * eq) * iq) + 2e-6f * (fabsf(x0) + fabsf(x1));
+  }
   if (x0 > x1) { const float t = x0; x0 = x1; x1 = t; }
   tN = x0;
   tF = x1;
+  // (strict comparisons: an infinite bound -- tHi of a new beam, z1 of the last sub-beam -- is near nothing, inf < inf is false)
+  if (amb && (fabsf(tN - tHi) < tE + 1e-6f * fabsf(tHi) || fabsf(tF - tLo) < tE + 1e-6f * fabsf(tLo))) *amb = true;
   if (tN > tHi || tF < tLo) return false;
   const float zN = rz + dd * tN, zF = rz + dd * tF;
+  if (amb) {
+    const float zE = tE + 2e-6f * (fabsf(rz) + fabsf(tN) + fabsf(tF));
+    const float e0 = zE + 1e-6f * fabsf(z0), e1 = zE + 1e-6f * fabsf(z1);
+    if (fabsf(zN - z0) < e0 || fabsf(zF - z0) < e0 || fabsf(zN - z1) < e1 || fabsf(zF - z1) < e1) *amb = true;
+  }
   if (zN < z0) {
     if (zF < z0) return false;
     tN = tN + (tF - tN) * fdiv(zN - z0, zN - zF);
@@ -105,6 +130,13 @@ __device__ __forceinline__ bool cylLocal(f3 rel, f3 dv, f3 da, float z0, float z
   }
   return false;
 }
+
+// Scale of the pair's LOCAL frame: the kernel, the sub-beam, the base ray's foot all lie within it of the local origin
+__device__ __forceinline__ float beamLocalScale(const GatherArgs &a) { return 4.f * a.kernelRadius + 2.f * a.subLen; }
+// "x < y" between squared lengths of LOCAL vectors cannot be trusted: m2 = the sum of the squared magnitudes of the operands
+// the compared vector was summed from.  A vector summed from operands of total magnitude M is good to ~4u M, its square to
+// 2 |v| 4u M <= 2.4e-7 (|v|^2 + M^2) and M^2 <= 3 m2 for three operands: 1e-5 leaves a factor of ten.
+__device__ __forceinline__ bool nearSq(float x, float y, float m2) { return fabsf(x - y) <= 1e-5f * (x + y + m2); }
 
 struct MRecF {
   float tr, pdfFailure;

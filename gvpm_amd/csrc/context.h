@@ -39,6 +39,7 @@ void launch_apply_host_shifts(const GatherArgs &a, const gvpm_host_shift *result
 // the exact pass over the shifts the evaluation deferred (exact_shift.hip); totals: {evaluated, lost}
 void launch_exact_pass(const GatherArgs &a, unsigned long long *totals, uint32_t *hostOut, hipStream_t s);
 void launch_capture_notes(const GatherArgs &a, hipStream_t s);
+void launch_exact_beams(const GatherArgs &a, unsigned long long *totals, hipStream_t s);
 void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
                       hipStream_t s);
 void launch_beam_count(const gvpm_camera_ray *rays, uint32_t nsets, int width, int tw, int th, uint32_t *keys,

@@ -31,45 +31,6 @@ namespace {
 
 __device__ __forceinline__ double len2d(d3 a) { return dot(a, a); }
 
-// scene->rayIntersect(ray), any-hit, exactly: the occluder BVH's boxes are padded (scene_bvh.cpp), the slab test runs in
-// fp64 on them -- conservative -- and every triangle of a reached leaf takes the reference's test in fp64.
-__device__ bool anyHitExact(const GatherArgs &a, f3 o, d3 d, double mint, double maxt) {
-#pragma clang fp contract(off)
-  if (a.ntri == 0u) return false;
-  const double ox = o.x, oy = o.y, oz = o.z;
-  const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
-  uint32_t stack[32];
-  int sp = 0;
-  uint32_t cur = 0;
-  for (;;) {
-    const float4 lo = a.bvh[2 * (size_t)cur], hi = a.bvh[2 * (size_t)cur + 1];
-    const double tx0 = ((double)lo.x - ox) * ix, tx1 = ((double)hi.x - ox) * ix;
-    const double ty0 = ((double)lo.y - oy) * iy, ty1 = ((double)hi.y - oy) * iy;
-    const double tz0 = ((double)lo.z - oz) * iz, tz1 = ((double)hi.z - oz) * iz;
-    // (fmin / fmax drop the NaNs of 0 * inf; a box is entered when in doubt: slack of 1e-9 on the interval)
-    const double tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmax(fmin(tz0, tz1), mint)) - 1e-9;
-    const double tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmin(fmax(tz0, tz1), maxt)) + 1e-9;
-    bool descend = false;
-    if (tn <= tf) {
-      const uint32_t first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
-      if (count == 0u) {
-        if (sp < 32) stack[sp++] = first + 1u;
-        cur = first;
-        descend = true;
-      } else {
-        for (uint32_t i = first; i < first + count; ++i) {
-          const float4 t0 = a.tri4[3 * (size_t)i], t1 = a.tri4[3 * (size_t)i + 1], t2 = a.tri4[3 * (size_t)i + 2];
-          if (triHitExact(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) return true;
-        }
-      }
-    }
-    if (!descend) {
-      if (sp == 0) return false;
-      cur = stack[--sp];
-    }
-  }
-}
-
 struct RayIn {
   d3 o, d, eye;
   double len, pdf, jac, gop;

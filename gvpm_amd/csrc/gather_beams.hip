@@ -326,7 +326,7 @@ __device__ __forceinline__ d3 getShiftPos3D(const GatherArgs &a, const RayD &bRa
 }
 
 // shiftBeamDiffuse + diffuseReconnectionPhotonBeam.  Returns the MIS weight.
-template <int B>
+template <int B, bool EXV = false>
 __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const TileLds<B> &s, const BeamD &b,
                                                    const RayReg &sh, const RayReg &base, uint32_t edge,
                                                    const RayD &shiftRay, double shiftW, const KRecD &kRec, d3 newPos,
@@ -338,7 +338,10 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
   const double newPBDist = sqrt(len2(newPBDir));
   newPBDir = newPBDir / newPBDist;
   // visibility over the whole new beam [Epsilon, newPBDist], shift_volume_beams.cpp:420-426
-  if (anyHitScene<true>(a.bvh, a.tri4, a.ntri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist) & 1) return 1.0;
+  // (EXV: the exact pass -- every triangle test of the segment in fp64, shift_device.h anyHitExact)
+  if (EXV ? anyHitExact(a, tof(b.p1), newPBDir, (double)a.cfg.epsilon, newPBDist)
+          : (anyHitScene<true>(a.bvh, a.tri4, a.ntri, tof(b.p1), tof(newPBDir), a.cfg.epsilon, (float)newPBDist) & 1) != 0)
+    return 1.0;
   const d3 basePos = b.p1 + b.dir * kRec.v;
   const double pdfKernelAndDist = kpdf(kRec);
   // diffuseReconnectionPhotonBeam, shift_diffuse.cpp:136-268
@@ -506,9 +509,11 @@ __device__ __forceinline__ bool beamPrefilter(const RayReg &base, f3 C, f3 bd, f
 
 // One (camera ray, sub-beam) candidate: BeamGradRadianceQuery::operator().  Returns true when it
 // produced a contribution (an evaluation).
-template <int B>
+// only >= 0 (the exact pass, exact_beams_kernel): shift `only` of a pair the fp32 evaluation has already evaluated -- its
+// terms and its counter, not the base contribution, not the other shifts.
+template <int B, bool EXV = false>
 __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s, uint32_t id, uint32_t bIdx,
-                                             uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail) {
+                                             uint32_t &nNull, uint32_t &nDiff, uint32_t &nFail, int only = -1) {
   const uint32_t beamIdx = id & 0xFFFFFFu, sub = id >> 24;
   const BeamD b = loadBeam(a, beamIdx);
   const RayReg base = loadRay(s, 0, bIdx);
@@ -549,9 +554,11 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
   if (!kRec.valid) return false;
   const d3 eyeB = tod(base.eye);
   const d3 baseContrib = mkd(eyeB.x * kRec.contrib.x, eyeB.y * kRec.contrib.y, eyeB.z * kRec.contrib.z) * kRec.weightKernel;
-  atomicAdd(&s.acc[0][bIdx], (double)(float)(baseContrib.x * rr));
-  atomicAdd(&s.acc[1][bIdx], (double)(float)(baseContrib.y * rr));
-  atomicAdd(&s.acc[2][bIdx], (double)(float)(baseContrib.z * rr));
+  if (only < 0) {
+    atomicAdd(&s.acc[0][bIdx], (double)(float)(baseContrib.x * rr));
+    atomicAdd(&s.acc[1][bIdx], (double)(float)(baseContrib.y * rr));
+    atomicAdd(&s.acc[2][bIdx], (double)(float)(baseContrib.z * rr));
+  }
   const uint32_t st = GVPM_PF_SHIFT_TYPE(b.flags);
   if (a.cfg.debug_shift != GVPM_SHIFT_ALL && a.cfg.debug_shift != GVPM_SHIFT_NULL) {
     const int cur = st == 1u ? GVPM_SHIFT_DIFFUSE : st == 2u ? GVPM_SHIFT_MEDIUM : st == 3u ? GVPM_SHIFT_MANIFOLD : GVPM_SHIFT_INVALID;
@@ -560,6 +567,7 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
   const double radius = kRec.radius;
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
+    if (only >= 0 && i != only) continue;
     const RayReg sh = loadRay(s, 1 + i, bIdx);
     double w = 1.0;
     d3 sflux = mkd(0, 0, 0);
@@ -613,7 +621,7 @@ __device__ __forceinline__ bool evaluateBeam(const GatherArgs &a, TileLds<B> &s,
           } else {
             bool ok = false;
             if (st == 1u || st == 2u)
-              w = shiftBeamDiffuse<B>(a, s, b, sh, base, edge, shiftRay, shiftW, kRec, offsetPos, technique, sflux, ok);
+              w = shiftBeamDiffuse<B, EXV>(a, s, b, sh, base, edge, shiftRay, shiftW, kRec, offsetPos, technique, sflux, ok);
             if (ok) nDiff++; else nFail++;
           }
         }
@@ -728,12 +736,32 @@ constexpr uint32_t SCENE_LDS_TRIS = 128;
 // entering the loop: beamShift2 sends only the reconnections outside their beam's free cone through it.
 // (TRI: the occluders in LDS or in global memory -- one loop for the lanes that walk their beam's list and, in LDS, the lanes
 // whose list overflowed: every occluder)
-__device__ __forceinline__ bool beamNearLoop(const GatherArgs &a, const BeamNearFmt fmt, bool ovf, const BeamF &b, const float4 *tri, f3 nd,
-                                             float dist) {
+// the triangles triHit3 left undecided once more, through the crossing point (shift_device.h, triHitFine).  Rare (a few
+// per cent of the segments that take the loop) and not inlined: inlined, its temporaries cost the evaluation kernel 23 spilled
+// registers.  The new beam's direction is good to ~1e-6 of the reference's, its end point (the offset position) to endErr.
+static __device__ __noinline__ int beamNearRefine(const BeamNearFmt fmt, bool ovf, uint32_t nl0, uint32_t nl1, uint32_t nl2, const float4 *tri,
+                                                  f3 o, f3 nd, float mint, float maxt, float endErr, uint32_t ambMask) {
+  int res = GVPM_TRI_MISS;
+  while (ambMask) {
+    const uint32_t k = (uint32_t)__builtin_ctz(ambMask);
+    ambMask &= ambMask - 1u;
+    const uint32_t i = ovf ? k : beamNearEntry(fmt, nl0, nl1, nl2, k);
+    const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
+    res = triCombine(res, triHitFine(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt, 1e-6f, endErr));
+  }
+  return res;
+}
+// (round 5: three states, shift_device.h triHit3 -- MISS, HIT, or AMB: some listed triangle's test lies inside its fp32 margin
+// and none is a certain hit; the reconnection then goes to the exact pass)
+__device__ __forceinline__ int beamNearLoop(const GatherArgs &a, const BeamNearFmt fmt, bool ovf, const BeamF &b, const float4 *tri, f3 nd,
+                                            float dist) {
   const f3 o = b.p1;
   const float mint = a.cfg.epsilon, maxt = dist;
   const float margin = planeSideMargin(a.triAbs1, o, maxt);
-  bool hit1 = false;
+  const float oAbs1 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
+  bool hit = false;
+  uint32_t ambMask = 0u;  // list positions triHit3 left undecided (a 33rd makes the segment undecidable as a whole)
+  bool ambMore = false;
   bool more1 = true;
 #pragma unroll 1
   for (uint32_t k = 0;; ++k) {
@@ -750,21 +778,30 @@ __device__ __forceinline__ bool beamNearLoop(const GatherArgs &a, const BeamNear
       const float4 t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
       const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
       const float s0 = dot(nrm, o - v0), sd = dot(nrm, nd);
-      if (!planeSideMiss(s0, sd, mint, maxt, margin) && triHit(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt))
-        hit1 = true;
+      if (!planeSideMiss(s0, sd, mint, maxt, margin)) {
+        const int th = triHit3(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, nd, mint, maxt, oAbs1, s0, sd);
+        hit = hit || th == GVPM_TRI_HIT;
+        if (th == GVPM_TRI_AMB) {
+          if (k < 32u) ambMask |= 1u << k; else ambMore = true;
+        }
+      }
     }
   }
-  return hit1;
+  if (hit) return GVPM_TRI_HIT;
+  if (ambMore) return GVPM_TRI_AMB;
+  if (ambMask == 0u) return GVPM_TRI_MISS;
+  return beamNearRefine(fmt, ovf, b.nl0, b.nl1, b.nl2, tri, o, nd, mint, maxt, 1e-6f * (beamLocalScale(a) + dist), ambMask);
 }
 
-__device__ __forceinline__ bool beamShadowBlocked(const GatherArgs &a, const BeamF &b, const float4 *ldsTri, f3 nd, float dist) {
+// a GVPM_TRI_* state
+__device__ __forceinline__ int beamShadowBlocked(const GatherArgs &a, const BeamF &b, const float4 *ldsTri, f3 nd, float dist) {
   const BeamNearFmt fmt = beamNearFmt(a.ntri);  // (wave-uniform)
   const bool ovf = beamNearOverflow(fmt, b.nl0, b.nl2);
   if (!ldsTri) {
     // (more occluders than the kernel's LDS holds: the lists' triangles from global memory; a list that overflowed walks the BVH)
-    if (ovf) return (anyHitScene<true>(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist) & 1) != 0;
+    if (ovf) return anyHitScene<false>(a.bvh, a.tri4, a.ntri, b.p1, nd, a.cfg.epsilon, dist);
     if (fmt.bits == 8u)
-      return (nearListHit<true>(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist)) & 1) != 0;
+      return nearListHit<false>(a.tri4, b.nl0, b.nl1, b.nl2, b.p1, nd, a.cfg.epsilon, dist, planeSideMargin(a.triAbs1, b.p1, dist));
     return beamNearLoop(a, fmt, false, b, a.tri4, nd, dist);
   }
   return beamNearLoop(a, fmt, ovf, b, ldsTri, nd, dist);
@@ -892,7 +929,7 @@ struct BeamRecPair {
 // one reconnection once its new beam p1 -> newPos is known to be unoccluded: nd / dist its direction and length
 __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF &b, const BeamRecPair &pr, f3 shEye, float sMIS,
                                                 const LocalRay &sr, f3 newPos, f3 nd, float dist, int technique,
-                                                f3 &shiftedFlux, bool &ok) {
+                                                f3 &shiftedFlux, bool &ok, bool &amb) {
   ok = false;
   shiftedFlux = mk3(0.f);
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
@@ -900,6 +937,8 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
   float pdfValueSA;
   if (ptype == GVPM_PARENT_SURFACE || ptype == GVPM_PARENT_SURFACE_BSDF) {
     const float cosWo = dot(b.parentN, nd), cosWi = dot(b.parentN, b.parentWi);
+    // (the new beam's direction is good to ~1e-6: a cosine this close to zero is the exact pass's to sign)
+    if (fabsf(cosWo) <= 1e-5f || fabsf(cosWi) <= 1e-5f) amb = true;
     if (cosWi <= 0.f || cosWo <= 0.f) return 1.f;
     thr = b.parentScat * (INV_PI_F * cosWo);
     pdfValueSA = INV_PI_F * cosWo;
@@ -937,8 +976,9 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
     const f3 D0n = q - sr.d * zq;
     const float z0 = (float)(-sr.s0) - zq, z1 = (float)((double)sr.maxt - sr.s0) - zq;
     float tN, tF;
-    if (cylLocal(D0n, nd, sr.d, z0, z1, a.kernelRadius, -dist, INFINITY, tN, tF)) {
+    if (cylLocal(D0n, nd, sr.d, z0, z1, a.kernelRadius, -dist, INFINITY, tN, tF, &amb)) {
       const float radSqr = a.kernelRadius * a.kernelRadius, distSqr = dot(D0n, D0n);
+      if (nearSq(distSqr, radSqr, dot(q, q))) amb = true;
       if (distSqr < radSqr)
         shiftKernelPDF = frcp(fmaxf(tF - tN, 0.0001f)) * frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
     }
@@ -1244,9 +1284,15 @@ __device__ __forceinline__ bool beamBorder(const GatherArgs &a, uint32_t pix, in
 
 // shift i of a pair that passed beamBase: the null shift is evaluated here; `rec`: the shift needs the offset-path
 // reconnection, which phase 2 does (beamShift2)
+// shift i of a pair that passed beamBase: the null shift is evaluated here; `rec`: the shift needs the offset-path
+// reconnection, which phase 2 does (beamShift2).
+// Round 5: every DECISION of the shift -- the shifted edge's length against w, the null-shift test, the shifted kernel's
+// validity (cylLocal), the distance of the beam's origin to the shifted ray -- is taken in fp32 only outside a generous band
+// of its operands' rounding; inside one the shift adds and counts nothing here and is noted for the exact pass
+// (exact_beams_kernel: the fp64 transcription decides and adds it), as G-BRE's and G-VPM's are (shift_device.h, deferNote).
 template <int B, bool HS, typename LDS>
 __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const BeamP1 &o, uint32_t bIdx, int i, bool &rec,
-                                           uint32_t &nNull, uint32_t &nFail) {
+                                           uint32_t &nNull, uint32_t &nFail, uint32_t setBase) {
   rec = false;
   if (o.st == 0xFFu) return;
   const BeamF &b = o.b;
@@ -1257,25 +1303,39 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
   const ShiftRel sh = loadShiftRel(s, i, bIdx, cam.d);
   float w = 1.f;
   f3 sflux = mk3(0.f);
-  if (sh.valid) {
+  bool amb = a.cfg.reserved[4] != 0;  // (GVPM_EXACT_ALL: every shift through the exact pass, tests/test_exact_pass_gpu.py)
+  uint32_t cause = 0u;                // which decision (GVPM_TRACE_EXACT prints the counts): 0 all, 1 w against the edge, 2 null test,
+                                      // 3 shifted kernel, 4 its distance, 5 origin on the ray, 6 mirror, 7 flip, 8 visibility, 9 cosine / new kernel
+  if (sh.valid && !amb) {
     const float shiftDistMAX = sh.len;
+    const float L = beamLocalScale(a);
     float delta;
     const LocalRay sr = shiftedLocal(cam, sh, eps, delta);
     bool alreadyShift = false;
-    if (a.cfg.use_shift_null && !is1D) {
+    // w against the shifted edge [Epsilon, shiftDistMAX]: absolute parameters, w = (float)(s0 + sigma) with sigma local
+    amb = fabsf(k.w - shiftDistMAX) <= 1e-6f * (k.w + shiftDistMAX) + 1e-5f * L || k.w - eps <= 1e-6f * eps + 1e-5f * L;
+    if (amb) cause = 1u;
+    if (a.cfg.use_shift_null && !is1D && !amb) {
       const float sigS_w = k.sigmaW - delta;  // the same distance w on the shifted ray, from its foot point
       const f3 dz = atLocal(sr, sigS_w) - o.kc;
-      if (dot(dz, dz) < r * r && k.w <= shiftDistMAX) {
+      const float dz2 = dot(dz, dz);
+      amb = nearSq(dz2, r * r, sigS_w * sigS_w + dot(sr.D0, sr.D0) + k.tauV * k.tauV);
+      if (amb) cause = 2u;
+      if (!amb && dz2 < r * r && k.w <= shiftDistMAX) {
         // BeamKernelRecord copy-shift constructor (shift_volume_beams.h:40-144) + shiftNull3D (.cpp:748-786)
         float tN, tF;
         const float z0 = (float)((double)eps - sr.s0), z1 = (float)((double)shiftDistMAX - sr.s0);
-        if (cylLocal(sr.D0, b.bd, sr.d, z0, z1, r, -o.tc, b.len - o.tc, tN, tF)) {
+        const bool cylOk = cylLocal(sr.D0, b.bd, sr.d, z0, z1, r, -o.tc, b.len - o.tc, tN, tF, &amb);
+        if (amb) cause = 3u;
+        if (cylOk && !amb) {
           float pdfK = frcp(fmaxf(tF - tN, 0.0001f));
           const float bds = dot(b.bd, sr.d);
           f3 perp = sr.D0 + (b.bd - sr.d * bds) * k.tauV;
           perp = perp - sr.d * dot(perp, sr.d);
           const float distSqr = dot(perp, perp), radSqr = r * r;
-          if (distSqr < radSqr && !(k.w < sr.mint || k.w > sr.maxt)) {
+          amb = nearSq(distSqr, radSqr, dot(sr.D0, sr.D0) + k.tauV * k.tauV);
+          if (amb) cause = 4u;
+          if (!amb && distSqr < radSqr && !(k.w < sr.mint || k.w > sr.maxt)) {
             pdfK *= frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
             nNull++;
             sflux = k.contrib * sh.eye;  // kS.contrib * kpdf(kS) / kpdf(kRec): the pdf ratios cancel
@@ -1289,7 +1349,7 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
         }
       }
     }
-    if (!alreadyShift && k.w <= shiftDistMAX) {
+    if (!amb && !alreadyShift && k.w <= shiftDistMAX) {
       // shiftBeam dispatch, shift_volume_beams.cpp:355-408.  (The reference first asks whether the beam's origin lies ON
       // the shifted ray, `minDistSqr > kRec.u^2` -- no shift then, weight 1: phase 2 asks for the shifts it is given;
       // for a light path that cannot be reconnected the question is asked here)
@@ -1305,11 +1365,18 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
         if (!is1D) {
           f3 pv = o.p1rel + sr.D0;
           pv = pv - sr.d * dot(pv, sr.d);
-          doShift = dot(pv, pv) > k.u * k.u;
+          const float pv2 = dot(pv, pv), u2 = k.u * k.u, e = 3e-5f * (o.tc + L);
+          amb = fabsf(pv2 - u2) <= e * (2.f * fsqrt(fmaxf(pv2, u2)) + e);
+          if (amb) cause = 5u;
+          doShift = pv2 > u2;
         }
-        if (doShift) nFail++;
+        if (doShift && !amb) nFail++;
       }
     }
+  }
+  if (amb) {
+    deferNote(a, GVPM_EX_KIND_BEAMS, a.setPerm[setBase + bIdx], o.id, (uint32_t)i, cause);
+    return;
   }
   if (beamBorder(a, o.pix, i)) w = 1.f;
   const float ws = w * o.rr;
@@ -1330,6 +1397,9 @@ __device__ __forceinline__ void beamShift1(const GatherArgs &a, LDS &s, const Be
 // withVis (wave-uniform) = false: the first round -- a reconnection whose new beam is not inside its beam's free cone
 // (beamClear: inside, nothing can occlude it) is DEFERRED, untouched; true: the second round over the deferred ones,
 // through the any-hit loop.
+// Round 5: its decisions -- the origin's distance to the shifted ray, the mirror test of getShiftPos, the flip of
+// getShiftPos1D, the triangle tests of the new beam's shadow segment (three states), the cosines' signs, the new kernel's
+// validity -- are banded like phase 1's; inside a band the shift is noted for the exact pass and nothing is added or counted.
 template <int B, bool HS, typename LDS>
 __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const BeamPQ &q, const float4 *ldsTri, bool withVis,
                                            bool &defer, uint32_t &nDiff, uint32_t &nFail, uint32_t setBase) {
@@ -1366,12 +1436,18 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
   const float sigS_w = sigmaW - delta;  // the same distance w on the shifted ray, from its foot point
   const f3 shW = atLocal(sr, sigS_w);
   bool doShift = true;
+  bool amb = false;
+  uint32_t cause = 0u;
+  const float L = beamLocalScale(a);
   f3 offsetPos;
   if (!is1D) {
     // distance of the beam's origin to the shifted ray against kRec.u (= 0 for the 3D kernel)
     f3 pv = p1rel + sr.D0;
     pv = pv - sr.d * dot(pv, sr.d);
-    doShift = dot(pv, pv) > q.u * q.u;  // else result.weight = 1
+    const float pv2 = dot(pv, pv), u2 = q.u * q.u, e = 3e-5f * (tc + L);
+    amb = fabsf(pv2 - u2) <= e * (2.f * fsqrt(fmaxf(pv2, u2)) + e);
+    if (amb) cause = 5u;
+    doShift = pv2 > u2;  // else result.weight = 1
     // getShiftPos (3D), shift_volume_beams.cpp:93-137: the kernel offset in the base ray's coherent frame, replayed in
     // the shifted ray's
     const f3 kc = b.bd * tauV;             // kernel centre on the beam, local
@@ -1384,6 +1460,7 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
     offsetPos = shW + (ns * lx + nt * ly + sr.d * lz);
     if (a.cfg.use_shift_null) {
       const f3 dv = camW - offsetPos;
+      if (nearSq(dot(dv, dv), r * r, dot(camW, camW) + dot(shW, shW) + dot(u, u))) { amb = true; cause = 6u; }  // (the mirror decision moves the offset position by up to 2 r)
       if (dot(dv, dv) < r * r) {
         f3 dShift = shW - camW;
         dShift = dShift * frsq(dot(dShift, dShift));
@@ -1395,13 +1472,25 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
     // getShiftPos1D, shift_volume_beams.cpp:81-91
     const f3 aCam = p1rel + cam.D0;  // p1 from the base ray's foot point
     f3 back = shiftPointLocal(cam.d, aCam, q.u, sigmaW, false) - aCam;
-    back = back * frsq(dot(back, back));
+    const float ib = frsq(dot(back, back));
+    back = back * ib;
     const f3 df = back - b.bd;
-    const bool flip = dot(df, df) > 0.001f;
+    // (`back` spans the beam from p1 to the kernel: good to ~2.4e-7 (tc + L), its direction to that over its length -- and df2
+    // genuinely ranges over [0, (2 r / v)^2], which straddles the reference's 0.001: a band of 1e-5 deferred 0.2 % of the 1D
+    // kernel's reconnections, this one 1e-4 of them)
+    const float df2 = dot(df, df), eb = 4e-6f * (tc + L) * ib;
+    if (fabsf(df2 - 0.001f) <= eb * (2.f * fsqrt(fmaxf(df2, 0.001f)) + eb) + 1e-7f) { amb = true; cause = 7u; }
+    const bool flip = df2 > 0.001f;
     offsetPos = shiftPointLocal(sr.d, p1rel + sr.D0, q.u, sigS_w, flip) - sr.D0;
   }
   float w = 1.f;
   f3 sflux = mk3(0.f);
+  // (a manifold-typed beam under gvpm_enable_host_shifts keeps the plain fp32 decisions: its walk is the host's)
+  const bool hostShift = HS && GVPM_PF_SHIFT_TYPE(b.flags) == 3u;
+  if (amb && !hostShift) {
+    deferNote(a, GVPM_EX_KIND_BEAMS, a.setPerm[setBase + bIdx], q.id, (uint32_t)i, cause);
+    return;
+  }
   if (HS && doShift && GVPM_PF_SHIFT_TYPE(b.flags) == 3u) {
     // EManifoldShift -> shiftBeamME (shift_volume_beams.cpp:398-404,601-746): the walk is the host's.  Absolute positions:
     // the local frame's origin O plus the local vectors; the rays at (w - mint), as generateShiftPathME is handed them.
@@ -1429,14 +1518,20 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
         return;
       }
     }
-    if (!withVis || !beamShadowBlocked(a, b, ldsTri, nd, dist)) {
+    const int vis = withVis ? beamShadowBlocked(a, b, ldsTri, nd, dist) : GVPM_TRI_MISS;
+    if (vis & GVPM_TRI_AMB) { amb = true; cause = 8u; }
+    if (vis == GVPM_TRI_MISS) {
       BeamRecPair pr;
       pr.pdfBasePos = b.parentPdf * (b.len * b.len);
       if (b.endOnSurface) pr.pdfBasePos = fdiv(pr.pdfBasePos, fabsf(dot(b.endN, b.bd)));
       pr.pdfBasePos *= frcp(kV * kV);
       pr.trW = mediumEvalF(a.med, kW).tr;
       pr.pdfKernelAndDist = q.k.z;
-      w = reconnectBeamF(a, b, pr, sh.eye, sh.sMIS, sr, offsetPos, nd, dist, technique, sflux, ok);
+      w = reconnectBeamF(a, b, pr, sh.eye, sh.sMIS, sr, offsetPos, nd, dist, technique, sflux, ok, amb);
+    }
+    if (amb) {
+      deferNote(a, GVPM_EX_KIND_BEAMS, a.setPerm[setBase + bIdx], q.id, (uint32_t)i, cause ? cause : 9u);
+      return;
     }
     if (ok) nDiff++; else nFail++;
   }
@@ -1874,6 +1969,77 @@ __global__ __launch_bounds__(64, 1) void evaluate_beams_exact_kernel(GatherArgs 
   }
 }
 
+// ---- the exact pass of G-Beams (round 5) ------------------------------------------------------------------------------------
+// The shifts the fp32 evaluation could not decide (beamShift1 / beamShift2: a decision inside its band) were noted --
+// {beam set, beam | sub << 24, GVPM_EX_KIND_BEAMS | shift << 8 | cause << 16} in a.exOvf -- and added nothing.  This kernel
+// runs BEHIND the evaluation on the same stream, every gather (the beams' build is not pipelined: nothing the notes refer to
+// has moved): a lane per note, the reference's statements in fp64 (evaluateBeam above with the triangle tests of the shadow
+// segment in fp64 too), the shift's terms to the iteration's sums, its counter to the statistics.  A lane's rays and sums
+// live in ITS column of a 64-wide tile.
+__global__ __launch_bounds__(64) void exact_beams_kernel(GatherArgs a, unsigned long long *totals) {
+  __shared__ TileLds<64> s;
+  const int lane = threadIdx.x;
+  const uint32_t total = *a.exOvfCount, n = min(total, a.exOvfCap);
+  uint32_t nNull = 0, nDiff = 0, nFail = 0;
+  for (uint32_t j0 = blockIdx.x * 64u; j0 < n; j0 += gridDim.x * 64u) {
+    const uint32_t j = j0 + (uint32_t)lane;
+    const bool have = j < n;
+    const uint4 note = have ? a.exOvf[j] : make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pix = 0u;
+    for (int k = 0; k < 5; ++k) {
+      float4 q0 = make_float4(0.f, 0.f, 0.f, -1e-30f), q1 = make_float4(0.f, 0.f, 1.f, 0.f), q2 = make_float4(0.f, 0.f, 0.f, 0.f),
+             q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (have) {
+        const gvpm_camera_ray *ray = a.rays + (size_t)note.x * 5 + k;
+        const float4 *rp = reinterpret_cast<const float4 *>(ray);
+        q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3];
+        const float l = fabsf(q0.w);
+        q0.w = GVPM_RAY_VALID(ray->info) != 0 ? l : -fmaxf(l, 1e-30f);  // (the valid bit rides on the sign of len, tile_walk.h)
+      }
+      s.ray4[k][0][lane] = q0;
+      s.ray4[k][1][lane] = q1;
+      s.ray4[k][2][lane] = q2;
+      s.gop[k][lane] = q3.x;
+      if (k == 0) {
+        s.rnd[lane] = q3.z;
+        s.pix[lane] = pix = __float_as_uint(q3.w);
+        s.edge[lane] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
+      }
+    }
+    for (int k = 0; k < 27; ++k) s.acc[k][lane] = 0.0;
+    __syncthreads();
+    if (have) {
+      if (totals) atomicAdd(&totals[4 + min((note.z >> 16) & 0xFFu, 15u)], 1ull);
+      evaluateBeam<64, true>(a, s, note.y, (uint32_t)lane, nNull, nDiff, nFail, (int)((note.z >> 8) & 0xFFu));
+      const size_t p = (size_t)(pix >> 16) * a.cfg.width + (pix & 0xFFFFu);
+      for (int k = 3; k < 27; ++k) {
+        const float v = (float)s.acc[k][lane];
+        if (v != 0.f) atomicAdd(&a.iter[p * 27 + k], v);
+      }
+    }
+    __syncthreads();
+  }
+  if (nNull) atomicAdd(&statRow(a)[2], (unsigned long long)nNull);
+  if (nDiff) atomicAdd(&statRow(a)[3], (unsigned long long)nDiff);
+  if (nFail) atomicAdd(&statRow(a)[4], (unsigned long long)nFail);
+}
+// the list is empty again; totals: {evaluated, lost, largest list} as exact_pass_kernel keeps them (exact_shift.hip)
+__global__ void exact_beams_done_kernel(GatherArgs a, unsigned long long *totals) {
+  const uint32_t total = *a.exOvfCount, n = min(total, a.exOvfCap);
+  if (totals) {
+    totals[0] += n;
+    if (total > n) totals[1] += total - n;
+    if (totals[2] < total) totals[2] = total;
+  }
+  if (total > n) atomicAdd(&a.stats[7], (unsigned long long)(total - n));  // dropped (gvpm_stats::dropped_pairs): gvpm_get_stats fails
+  *a.exOvfCount = 0u;
+}
+void launch_exact_beams(const GatherArgs &a, unsigned long long *totals, hipStream_t stream) {
+  // (a wave per workgroup, 37 KB of LDS each: four per CU resident; the empty ones leave at once)
+  hipLaunchKernelGGL(exact_beams_kernel, dim3(2048), dim3(64), 0, stream, a, totals);
+  hipLaunchKernelGGL(exact_beams_done_kernel, dim3(1), dim3(1), 0, stream, a, totals);
+}
+
 // ---- evaluation, fp32 path: two phases ----------------------------------------------------------------------------
 // As above (blocks of 64 pairs sorted by tile, RUN blocks per reservation), but a block goes through phase 1 only
 // (beamBase + beamShift1: kernel record, base contribution, null shifts); the reconnections it needs are appended to
@@ -2059,7 +2225,7 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         bool rec = false;
-        if (alive && !primal) beamShift1<B, HS>(a, s, st, bIdx, i, rec, nNull, nFail);
+        if (alive && !primal) beamShift1<B, HS>(a, s, st, bIdx, i, rec, nNull, nFail, setBase);
         const unsigned long long m = __ballot(rec);
         if (rec) {
           const uint32_t slot = qCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -2214,7 +2380,7 @@ __global__ __launch_bounds__(64, GVPM_SPLIT_P1_MINW) void evaluate_beams_p1_kern
 #pragma unroll 1
       for (int i = 0; i < 4; ++i) {
         bool rec = false;
-        if (alive && !primal) beamShift1<B, false>(a, s, st, bIdx, i, rec, nNull, nFail);
+        if (alive && !primal) beamShift1<B, false>(a, s, st, bIdx, i, rec, nNull, nFail, setBase);
         const unsigned long long m = __ballot(rec);
         if (rec) {
           const size_t slot = (size_t)eBase + eCount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));

@@ -760,6 +760,7 @@ static int buildBeamGrid(gvpm_context *h, float r) {
 // computeVolumeGradientBeams, gvpm.cpp:880-986
 static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal = false) {
   if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
+  HIP_TRY(h, h->exOvf.reserveExact(h->exOvfCap));  // (the notes of the undecided shifts, exact_beams_kernel)
   h->vpmOrderN = 0;  // (the block-sort buffers below also hold G-VPM's batch order)
   const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
   // phases as for G-BRE (gvpm_get_phase_time): 2 = build (sub-beam grid, beam records, camera-beam sort, near lists),
@@ -931,6 +932,19 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
   launch_evaluate_beams(a, h->beamsPerWave, h->beamsExact && !primal, h->beamPairs.p, h->blockKeyB.p, h->blockValB.p, nBlocks,
                         h->bs->queueCtl.p + 3, h->nwaves, h->stream);
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
+  // the shifts the fp32 evaluation left undecided (gather_beams.hip, exact_beams_kernel): in fp64, behind it, every gather
+  if (!primal && !h->beamsExact) {
+    launch_exact_beams(a, h->exTotals.p, h->stream);
+    static const bool trace = getenv("GVPM_TRACE_EXACT") != nullptr;
+    if (trace) {
+      unsigned long long v[20];
+      HIP_TRY(h, hipMemcpyAsync(v, h->exTotals.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      fprintf(stderr, "[exact beams] so far %llu evaluated, %llu lost, longest list %llu; by cause 0..9:", v[0], v[1], v[2]);
+      for (int k = 0; k < 10; ++k) fprintf(stderr, " %llu", v[4 + k]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (primal) {
     // BeamRadianceQuery takes the camera ray's transmittance over [Epsilon, w] (pm/beams.h:57-61,189-193) where the gradient
     // pass's kernel record takes it over [0, w] (shift_volume_beams.h:167,262): one factor exp(sigma_t Epsilon) on every term

@@ -122,7 +122,6 @@ struct VpmPair {
   PhotonCold ph;
   RayReg base;
   f3 photonIn, baseContrib, rel;
-  d3 pD, basePt;
   double t;
   float tf, r2, pdfBase, pdfSel, scale, trS;
   uint32_t edge;
@@ -149,9 +148,9 @@ __device__ __forceinline__ VpmPair vpmPair(const GatherArgs &a, const VpmLds &s,
   v.scale = norm / (kernelVol * v.pdfBase);
   v.photonIn = sigS * v.ph.flux;
   v.baseContrib = v.base.eye * (v.photonIn * phaseEval(a.med.g, v.ph.wi, -v.base.d)) * s.trBase[b];
-  v.pD = tod(v.ph.pos);
-  v.basePt = tod(v.base.o) + tod(v.base.d) * v.t;  // baseRay(maxt)
-  v.rel = tof(v.pD - v.basePt);
+  // photon relative to baseRay(maxt): the difference formed in fp64, carried as a small fp32 vector (round 5: the two fp64
+  // points themselves are no longer kept -- twelve registers of a kernel that has none to spare)
+  v.rel = tof(tod(v.ph.pos) - (tod(v.base.o) + tod(v.base.d) * v.t));
   // shiftMRec: Medium::eval(shiftRay, EDistanceAlwaysValid) with mRec.t = t: Tr = exp(-sigma_t t)
   v.trS = __expf(-sigT * v.tf);
   if (v.trS < 1e-20f) v.trS = 0.f;
@@ -217,8 +216,8 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
       continue;
     }
     if (sh.valid && sh.len >= v.tf) {
-      const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
-      const f3 y = tof(v.pD - zP);
+      // photon relative to shiftRay(t) = (photon - baseRay(t)) - (shiftRay(t) - baseRay(t)), the second difference in fp64
+      const f3 y = v.rel - tof((tod(sh.o) - tod(v.base.o)) + (tod(sh.d) - tod(v.base.d)) * v.t);
       const float y2 = dot(y, y);
       if (a.cfg.use_shift_null && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(y2 - v.r2) <= 4e-6f * v.r2) {
         qMask |= 0x11u << i;
@@ -268,7 +267,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   const d3 zP = tod(sh.o) + tod(sh.d) * v.t;
   f3 offRel = v.rel;
   if (a.cfg.use_shift_null) {
-    const f3 dS = tof(zP - v.basePt);
+    const f3 dS = tof((tod(sh.o) - tod(v.base.o)) + (tod(sh.d) - tod(v.base.d)) * v.t);  // shiftRay(t) - baseRay(t)
     const f3 bo = dS + offRel;
     const float bo2 = dot(bo, bo);
     // (the mirror decision of getShiftPos moves the offset position by up to 2 r: not a counter, but a different shift)
@@ -279,7 +278,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
     // EManifoldShift (shiftPhoton -> shiftPhotonManifold, shift_volume_photon.cpp:49-117,160-295): the walk is the host's.
     // Recorded with what the device needs to finish the shift (apply_host_shifts_kernel): nothing is added now.  The base
     // contribution rides along already scaled, as G-BRE's does.
-    const f3 zPf = tof(zP), basePtF = tof(v.basePt);
+    const f3 zPf = tof(zP), basePtF = tof(tod(v.base.o) + tod(v.base.d) * v.t);
     if (!recordShiftRequest(reqSink(a), s.radius[b], pidx, s.set[b], i, zPf + offRel, basePtF, zPf, v.tf, v.trS, v.pdfBase, pdfShift,
                             sensorMIS(sh, v.base, v.edge), v.scale, v.baseContrib * v.scale, sh.d, sh.eye, s.pix[b])) {
       nFail++;  // the list is full: a failed shift (weight 1)

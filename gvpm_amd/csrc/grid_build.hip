@@ -270,30 +270,45 @@ __device__ __forceinline__ void nearVisit(f3 P, const float4 *bvh, const float4 
 // (shift_volume_photon.cpp:396-398) -- so the wall STAYS in the list and the evaluation decides (triHitChecked,
 // shift_device.h: fp64 where fp32 cannot tell).  delta's sign is pure rounding noise of the inputs: it is taken in fp64
 // from the fp32 data, as the oracle's (and a double-precision reference's) Moeller-Trumbore sees it.
-__device__ __forceinline__ bool ownWall(f3 P, f3 pn, const float4 *tri4, uint32_t i) {
+// cstar (in / out): for a parent BEHIND the plane the wall is left out all the same and its reach is kept instead --
+// max over the parent's own-wall triangles of |delta| / Epsilon, delta the distance to the triangle's plane (unit normal):
+// the segment along d meets that plane at t_self >= Epsilon  <=>  n . d <= |delta| / Epsilon.  The evaluation compares the
+// reconnection's cosine with it (shiftDiffuse): above, no self-hit is possible; at or below, the shift goes to the exact pass.
+__device__ __forceinline__ bool ownWall(f3 P, f3 pn, const float4 *tri4, uint32_t i, float eps, float &cstar) {
   const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
   const f3 a = mk3(t0.x, t0.y, t0.z), n = mk3(t0.w, t1.w, t2.w);
   const float tol = 1e-6f * (1.f + fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + fabsf(a.x) + fabsf(a.y) + fabsf(a.z));
   const float align = dot(n, pn);
-  if (!(fabsf(align) > 0.99999f && fabsf(dot(n, P - a)) <= tol)) return false;
+  // (parallel to 1e-3 rad: the parent's normal is this triangle's to rounding -- 6e-5 rad through the packed upload's
+  // octahedral code -- and the evaluation's cosine is taken against the PARENT's normal)
+  if (!(fabsf(align) > 0.9999995f && fabsf(dot(n, P - a)) <= tol)) return false;
   // N = e1 x e2 and delta in fp64 (exact products of fp32 data up to the last additions: |error| ~ 1e-16 of O(1) terms)
   const double e1x = t1.x, e1y = t1.y, e1z = t1.z, e2x = t2.x, e2y = t2.y, e2z = t2.z;
   const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
   const double delta = nx * ((double)P.x - (double)a.x) + ny * ((double)P.y - (double)a.y) + nz * ((double)P.z - (double)a.z);
-  return align > 0.f ? delta >= 0.0 : delta <= 0.0;
+  const bool front = align > 0.f ? delta >= 0.0 : delta <= 0.0;
+  if (!front) {
+    const double nl = sqrt(nx * nx + ny * ny + nz * nz);
+    if (nl > 0.0) cstar = fmaxf(cstar, (float)(fabs(delta) / (nl * (double)eps)) * 1.000001f);
+  }
+  return true;
 }
 
 template <int MODE>
+// cstarOut > 0: the parent lies behind a wall it sits on (ownWall); word 2 then carries that reach instead of entries (the
+// inline lists hold 8 / 4 of them; bit 15 of the record's flags says so)
 __device__ __forceinline__ void nearOccluders(f3 P, f3 pn, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
-                                              const NearGrid &ng, uint32_t *ext, uint32_t extCap, uint32_t &w0, uint32_t &w1,
-                                              uint32_t &w2) {
+                                              const NearGrid &ng, uint32_t *ext, uint32_t extCap, float eps, uint32_t &w0, uint32_t &w1,
+                                              uint32_t &w2, float &cstarOut) {
   w0 = w1 = w2 = 0xFFFFFFFFu;
+  cstarOut = 0.f;
   if (ntri == 0u) return;
   const bool narrow = ntri <= GVPM_NEAR_NARROW_MAX, wide = !narrow && ntri <= GVPM_NEAR_WIDE_MAX;
   const uint32_t cap = narrow ? 12u : (wide ? 6u : 0u);
   uint32_t cnt = 0, a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
+  float cstar = 0.f;
   nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) {
-    if (ownWall(P, pn, tri4, i)) return;
+    if (ownWall(P, pn, tri4, i, eps, cstar)) return;
     if (cnt < cap) {
       uint32_t word, sh, m;
       if (narrow) { word = cnt >> 2; sh = 8u * (cnt & 3u); m = ~(0xFFu << sh); }
@@ -305,9 +320,10 @@ __device__ __forceinline__ void nearOccluders(f3 P, f3 pn, const float4 *bvh, co
     }
     cnt++;
   });
-  if (cnt == 0u) return;
-  if (cnt <= cap) {
-    w0 = a0; w1 = a1; w2 = a2;
+  cstarOut = cstar;
+  const uint32_t capC = cstar > 0.f ? (cap * 2u) / 3u : cap;  // (word 2 is taken)
+  if (cnt <= capC) {
+    w0 = a0; w1 = a1; w2 = cstar > 0.f ? __float_as_uint(cstar) : a2;
     return;
   }
   // extension list {count, indices}
@@ -318,11 +334,13 @@ __device__ __forceinline__ void nearOccluders(f3 P, f3 pn, const float4 *bvh, co
   }
   ext[off] = cnt;
   uint32_t k = 0;
+  float dummy = 0.f;
   nearVisit<MODE>(P, bvh, tri4, ntri, dmax, ng, [&](uint32_t i) {
-    if (!ownWall(P, pn, tri4, i)) ext[off + 1u + (k++)] = i;
+    if (!ownWall(P, pn, tri4, i, eps, dummy)) ext[off + 1u + (k++)] = i;
   });
   w0 = 0xFDFFFFFFu;
   w1 = off;
+  if (cstar > 0.f) w2 = __float_as_uint(cstar);
 }
 
 // counting sort, pass 3: photon `src` (reads in upload order: coalesced) goes to slot cellStart[key] + rank
@@ -360,8 +378,12 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
     const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
     uint32_t w0, w1, w2;
     const f3 PN = mk3(r.parent_n[3 * (size_t)src], r.parent_n[3 * (size_t)src + 1], r.parent_n[3 * (size_t)src + 2]);
-    nearOccluders<MODE>(P, PN, bvh, tri4, ntri, dmax, ng, nearExt, extCap, w0, w1, w2);
+    float cstar;
+    nearOccluders<MODE>(P, PN, bvh, tri4, ntri, dmax, ng, nearExt, extCap, cfg.epsilon, w0, w1, w2, cstar);
     if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
+    // (bit 15 of the COLD record's flags only -- the depth field's top bit, which the evaluation does not read: "word 2 of the
+    // near list is the reach of the wall the parent sits behind"; the hot record the traversal filters by keeps the flags)
+    stg[t][0].w = __uint_as_float((bits & ~(1u << 15)) | (cstar > 0.f ? 1u << 15 : 0u));
     stg[t][5] = ld3(r.prefix_w, src, __uint_as_float(w0));
     stg[t][6] = ld3(r.parent_scat, src, __uint_as_float(w1));
     stg[t][7] = ld3(r.parent_wi, src, __uint_as_float(w2));

@@ -85,6 +85,47 @@ __device__ __forceinline__ int triHit3(const float4 t0, const float4 t1, const f
   const f3 v0 = mk3(t0.x, t0.y, t0.z), nrm = mk3(t0.w, t1.w, t2.w);
   return triHit3(v0, mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt, oAbs1, dot(nrm, o - v0), dot(nrm, d));
 }
+// A second opinion on a triangle triHit3 left undecided (the G-Beams shadow segments, gather_beams.hip).  The division-free
+// comparisons above bound the errors of A, B and C independently -- each carries |o - v0| |e|, the distance to the triangle's
+// FAR corner -- although an error of the direction moves A / C only by the lever from the origin to the crossing point.
+// Here the crossing point itself is formed, P = (o - v0) + d t with t = -s0 / sd, and tested against the edges in the
+// triangle's plane: its error is ~4u (|o - v0| + t) of rounding, dirErr t of the direction (the device's fp32 direction
+// against the reference's: dirErr ~ 1e-6) and the plane distance's own error over |sd| -- 1e-6 of the scene where the
+// margins above are 1e-5 |e| / sin(crossing angle): the plate of S-laser, whose thin triangles' edge LINES run through the
+// aperture, went from 2.8 % undecided shadow segments to ~0.03 %.  The normal is recomputed (N = e1 x e2: a point exactly in
+// an axis plane gets a plane distance of exactly zero error).  endErr: absolute error of the segment's end point.
+__device__ __forceinline__ int triHitFine(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt, float dirErr, float endErr) {
+  const f3 tv = o - v0;  // (one rounding per component)
+  const f3 N = cross(e1, e2);
+  const float n1 = fabsf(N.x) + fabsf(N.y) + fabsf(N.z);
+  const float s0 = dot(N, tv), sd = dot(N, d);
+  const float a0 = fabsf(N.x * tv.x) + fabsf(N.y * tv.y) + fabsf(N.z * tv.z);
+  const float t1 = fabsf(tv.x) + fabsf(tv.y) + fabsf(tv.z);
+  const float eS = s0 + sd * mint, eE = s0 + sd * maxt;
+  const float mS = 5e-7f * (a0 + fabsf(sd) * mint) + n1 * dirErr * mint;
+  const float mE = 5e-7f * (a0 + fabsf(sd) * maxt) + n1 * endErr;
+  const bool sP = eS > mS, sN = eS < -mS, eP = eE > mE, eN = eE < -mE;
+  if ((sP && eP) || (sN && eN)) return GVPM_TRI_MISS;
+  if (!((sP && eN) || (sN && eP))) return GVPM_TRI_AMB;
+  const float isd = frcp(sd);
+  const float t = -s0 * isd;
+  const f3 P = tv + d * t;
+  const float p1n = fabsf(P.x) + fabsf(P.y) + fabsf(P.z);
+  // position error of P: rounding of tv + d t, the direction's error over t, the plane distance's error over |sd|
+  const float pe = 3e-7f * (t1 + t + p1n) + dirErr * t + 5e-7f * a0 * fabsf(isd);
+  const float l1 = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z), l2 = fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z);
+  const float NN = dot(N, N);
+  // one edge function per edge, each with the margin of ITS edge (u + v <= 1 taken as 1 - u - v would add the margins of two
+  // nearly parallel edges of a thin triangle: forty times the third edge's own)
+  const f3 e3 = e2 - e1;
+  const float l3 = fabsf(e3.x) + fabsf(e3.y) + fabsf(e3.z);
+  const float uN = dot(cross(P, e2), N), vN = dot(cross(e1, P), N), wN = dot(cross(e3, P - e1), N);
+  const float mu = pe * l2 * n1, mv = pe * l1 * n1, mw = (pe + 2e-7f * l1) * l3 * n1;
+  if (!(NN > 0.f)) return GVPM_TRI_AMB;
+  if (uN < -mu || vN < -mv || wN < -mw) return GVPM_TRI_MISS;
+  if (uN > mu && vN > mv && wN > mw) return GVPM_TRI_HIT;
+  return GVPM_TRI_AMB;
+}
 // any-hit over a list: a certain hit settles it; else an undecidable triangle makes the whole answer undecidable
 __device__ __forceinline__ int triCombine(int acc, int t) {
   if (acc == GVPM_TRI_HIT || t == GVPM_TRI_HIT) return GVPM_TRI_HIT;
@@ -120,6 +161,45 @@ __device__ __forceinline__ bool triHitExact(f3 v0f, f3 e1f, f3 e2f, f3 of, d3 dd
   if (!(v >= 0.0 && u + v <= 1.0)) return false;
   const double t = (e2x * qx + e2y * qy + e2z * qz) * inv;
   return t >= mint && t <= maxt;
+}
+
+// scene->rayIntersect(ray), any-hit, exactly: the occluder BVH's boxes are padded (scene_bvh.cpp), the slab test runs in
+// fp64 on them -- conservative -- and every triangle of a reached leaf takes the reference's test in fp64.
+static __device__ bool anyHitExact(const GatherArgs &a, f3 o, d3 d, double mint, double maxt) {
+#pragma clang fp contract(off)
+  if (a.ntri == 0u) return false;
+  const double ox = o.x, oy = o.y, oz = o.z;
+  const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z;
+  uint32_t stack[32];
+  int sp = 0;
+  uint32_t cur = 0;
+  for (;;) {
+    const float4 lo = a.bvh[2 * (size_t)cur], hi = a.bvh[2 * (size_t)cur + 1];
+    const double tx0 = ((double)lo.x - ox) * ix, tx1 = ((double)hi.x - ox) * ix;
+    const double ty0 = ((double)lo.y - oy) * iy, ty1 = ((double)hi.y - oy) * iy;
+    const double tz0 = ((double)lo.z - oz) * iz, tz1 = ((double)hi.z - oz) * iz;
+    // (fmin / fmax drop the NaNs of 0 * inf; a box is entered when in doubt: slack of 1e-9 on the interval)
+    const double tn = fmax(fmax(fmin(tx0, tx1), fmin(ty0, ty1)), fmax(fmin(tz0, tz1), mint)) - 1e-9;
+    const double tf = fmin(fmin(fmax(tx0, tx1), fmax(ty0, ty1)), fmin(fmax(tz0, tz1), maxt)) + 1e-9;
+    bool descend = false;
+    if (tn <= tf) {
+      const uint32_t first = __float_as_uint(lo.w), count = __float_as_uint(hi.w);
+      if (count == 0u) {
+        if (sp < 32) stack[sp++] = first + 1u;
+        cur = first;
+        descend = true;
+      } else {
+        for (uint32_t i = first; i < first + count; ++i) {
+          const float4 t0 = a.tri4[3 * (size_t)i], t1 = a.tri4[3 * (size_t)i + 1], t2 = a.tri4[3 * (size_t)i + 2];
+          if (triHitExact(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) return true;
+        }
+      }
+    }
+    if (!descend) {
+      if (sp == 0) return false;
+      cur = stack[--sp];
+    }
+  }
 }
 
 // scene->rayIntersect(ray), any-hit: stack walk of the occluder BVH (scene_bvh.h), triangles as
@@ -244,7 +324,11 @@ __device__ __forceinline__ int nearListHitExt(const float4 *tri, const uint32_t 
 template <bool FULLVIS>
 __device__ __forceinline__ int shadowBlocked(const GatherArgs &a, const float4 *ldsTri, uint32_t nl0, uint32_t nl1,
                                              uint32_t nl2, f3 o, f3 d, float mint, float maxt) {
+#ifdef GVPM_PROBE_PLAINVIS
+  constexpr bool PL = true;  // probe builds only: what the three-state test costs
+#else
   constexpr bool PL = false;
+#endif
   if (FULLVIS) return anyHitScene<PL>(a.bvh, a.tri4, a.ntri, o, d, mint, maxt);
   if (a.ntri > GVPM_NEAR_NARROW_MAX) {
     if ((nl0 >> 24) == 0xFDu) return nearListHitExt(a.tri4, a.nearExt, nl1, o, d, mint, maxt);
@@ -437,11 +521,20 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const float eps = a.cfg.epsilon, seps = a.cfg.shadow_epsilon;
   const float vmax = a.cfg.visibility_as_written ? lProj * seps : lProj * (1.f - seps);
   // (amb: the caller defers undecidable shifts to the exact pass; without one the plain fp32 decision stands)
-  const int vis = shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, ph.nl2, ph.parentPos, dProj, eps, vmax);
-  bool good = vis == GVPM_TRI_MISS;
+  // bit 15 of the record's flags: the parent lies behind a wall it sits on, word 2 of its list is that wall's REACH
+  // cstar = |delta| / Epsilon instead of entries (grid_build.hip, ownWall): the wall itself is not listed
+  const bool behind = (bits >> 15) & 1u;
   const float cosWo = dot(ph.parentN, dProj);
+  // (a segment that leaves within cstar of grazing meets the own wall's plane at t >= Epsilon: the exact pass decides; 1.2e-3:
+  // the parent's normal against the triangle's, ownWall's parallel test.  Decided BEFORE the visibility loop: the reach is
+  // not carried across it)
+  const bool ownAmb = behind && cosWo > 0.f && cosWo <= __uint_as_float(ph.nl2) + 1.2e-3f;
+  const int vis = shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, behind ? 0xFFFFFFFFu : ph.nl2, ph.parentPos, dProj, eps, vmax);
+  bool good = vis == GVPM_TRI_MISS;
   // (the sign / cosine tests below flip within fp32 rounding of a grazing direction)
-  if (amb) *amb = ((vis & GVPM_TRI_AMB) ? 16u : 0u) | ((GVPM_PF_PARENT_TYPE(bits) != GVPM_PARENT_MEDIUM && fabsf(cosWo) <= 2e-6f) ? 32u : 0u);
+  if (amb)
+    *amb = (((vis & GVPM_TRI_AMB) || ownAmb) ? 16u : 0u) |
+           ((GVPM_PF_PARENT_TYPE(bits) != GVPM_PARENT_MEDIUM && fabsf(cosWo) <= 2e-6f) ? 32u : 0u);
   // surface / emitter parents: the offset direction must leave on the side the photon left (sign of
   // dot(n, dProj) / dot(n, -wi))
   const bool isMedium = ptype == GVPM_PARENT_MEDIUM, isGlossy = ptype == GVPM_PARENT_SURFACE_BSDF;

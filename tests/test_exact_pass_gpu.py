@@ -9,6 +9,7 @@ import pytest
 import cases
 import oracle_lib as O
 from gvpm_amd import abi, hip
+from test_oracle_beams import make_beam_case, TECHS
 from test_oracle_vpm import make_vpm_case
 from test_parity_gpu import l2
 
@@ -74,3 +75,33 @@ def test_every_vpm_shift_through_the_exact_pass(scene, kw, monkeypatch):
     # (the pass takes the pixel's radius as the fp32 state the device carries: R * 0.01 * scaleVol differs by 1e-7 from the oracle's
     # double product, i.e. 3e-7 in the kernel volume)
     assert l2(acc, ref, lum) < 2e-5, l2(acc, ref, lum)
+
+
+@pytest.mark.parametrize("tech", TECHS)
+@pytest.mark.parametrize("scene,kw", [("cbox", dict()), ("cbox_rot", dict()), ("cbox_hg_rot", dict(use_mis=0)),
+                                      ("cbox_conductor_rot", dict(power_heuristic=1)), ("laser_rot", dict(use_shift_null=0))])
+def test_every_beam_shift_through_the_exact_pass(scene, kw, tech, monkeypatch):
+    """G-Beams (gather_beams.hip, exact_beams_kernel): behind the evaluation, every gather; with GVPM_EXACT_ALL every shift of
+    every evaluated pair is its to decide and to add -- the fp64 transcription with the shadow segment's triangle tests in fp64."""
+    c = make_beam_case(scene, 32, 28, 12000, 1.6 if scene.endswith("_rot") else 2.5, technique=tech, **kw)
+    monkeypatch.setenv("GVPM_EXACT_ALL", "1")
+    ctx = hip.Context(c.p, device=0)
+    monkeypatch.delenv("GVPM_EXACT_ALL")
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    cases.upload_bsdfs(ctx, c)
+    rad = ctx.radius()
+    ctx.upload_beams(c.beams, c.end_n)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(1, c.nb)
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    taken, lost = ctx.exact_shifts()
+    ctx.close()
+    ref, cnt, _ = O.gather_beams(c.p, c.m, c.tris, c.beams, c.end_n, c.rays, rad, 1, c.nb, 64)
+    for k in COUNTERS:
+        assert st[k] == cnt[k], (k, st, cnt)
+    assert lost == 0 and taken == 4 * st["evaluations"] > 20000
+    lum = ref[..., 0:3].mean()
+    # (the transcription keeps the reference's float intermediates and rounds every term to float: measured <= 2.2e-5)
+    assert l2(acc, ref, lum) < 5e-5, l2(acc, ref, lum)

@@ -8,7 +8,7 @@ sensor under one fixed rotation (Euler 17 / 31 / 47 degrees) and tilt every inne
 techniques, the flag sweep and the upload formats through them against the fp64 oracle:
 
   * evaluation count == oracle's, exactly (as everywhere);
-  * SHIFT COUNTERS == oracle's, exactly (G-BRE, G-VPM, G-Planes; G-Beams: <= 2), with the as-written and with the
+  * SHIFT COUNTERS == oracle's, exactly (G-BRE, G-VPM, G-Beams, G-Planes), with the as-written and with the
     intended visibility segment: a parent that rounding left BEHIND the wall it sits on self-hits in the oracle (and in a
     double-precision reference) along directions within |delta| / Epsilon of grazing, and must on the device -- every
     decision of a shift is taken in fp32 with a rigorous error margin and, inside a margin, by the reference's statement
@@ -105,10 +105,9 @@ def test_vpm(scene, vis):
 @pytest.mark.parametrize("scene", ["cbox_rot", "cbox_hg_rot", "laser_rot", "cbox_conductor_rot"])
 def test_beams(tech, scene):
     c = make_beam_case(scene, 32, 28, 12000, 1.6, technique=tech)
-    # (G-Beams: the evaluated set is the oracle's exactly; the SHIFTS' own decisions -- null shift or reconnection, the triangle
-    # tests of the new beam's shadow segment -- are still plain fp32 there: its evaluation kernel has no exact pass yet, and a
-    # parent behind its own wall flips one reconnection in ~1e-5: <= 2 per counter here)
-    acc, ref, st = device_beams(c, exact=False)
+    # (G-Beams: the shifts' decisions are banded too -- gather_beams.hip beamShift1 / beamShift2 -- and the undecided ones go to
+    # exact_beams_kernel behind the evaluation)
+    acc, ref, st = device_beams(c, exact=True)
     assert st["evaluations"] > 10000
 
 
