@@ -340,7 +340,8 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
   const unsigned long long tw0 = wall_clock64();
 #endif
   const uint32_t ns = min(VPM_SPW, a.nsamples - sBase);
-  const float norm = 1.f / (float)a.cfg.nb_camera_samples;
+  // (wave-uniform, but a VALU quotient: handed to the scalar file, or it is carried -- and spilled -- as a vector register)
+  const float norm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.f / (float)a.cfg.nb_camera_samples)));
   const float eps = a.cfg.epsilon;
 
   for (int idx = lane; idx < 27 * VPM_RUNS * VPM_SUB; idx += 64) (&s.acc[0][0])[idx] = 0.0;
@@ -429,8 +430,13 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     bz0 = max(0, (int)floorf((q.z - pad - gr.org[2]) * gr.invCell));
     bz1 = min(gr.dim[2] - 1, (int)floorf((q.z + pad - gr.org[2]) * gr.invCell));
   }
-  const int nyr = by1 - by0 + 1, nzr = bz1 - bz0 + 1;
-  const int nrows = (bx1 >= bx0 && nyr > 0 && nzr > 0) ? nyr * nzr : 0;
+  const int nyr0 = by1 - by0 + 1, nzr = bz1 - bz0 + 1;
+  const int nrows = (bx1 >= bx0 && nyr0 > 0 && nzr > 0) ? nyr0 * nzr : 0;
+  // What the passes below need of this lane's box, in TWO registers (the grid has at most 385 cells an axis: 10 bits each);
+  // the query point and radius come back from s.qr[lane].  Ten registers carried across the whole walk -- with phase 2's
+  // 168 in the way the compiler spilled them, and scratch costs this kernel's 39 k short waves at launch (NB r5).
+  const uint32_t boxA = nrows ? ((uint32_t)bx0 | ((uint32_t)bx1 << 10) | ((uint32_t)by0 << 20)) : 0u;
+  const uint32_t boxB = nrows ? ((uint32_t)bz0 | ((uint32_t)nyr0 << 10) | ((uint32_t)nrows << 14)) : 0u;
   // The wave walks the cells together.  A lane-per-sample walk runs as long as its busiest lane (the candidate counts
   // of the samples of a ray differ by orders of magnitude) and reads 64 scattered lines per trip.  Instead the photon
   // ranges of ALL rows of ALL 64 boxes are laid end to end (round 4: one wave prefix sum over the samples' totals and a
@@ -440,26 +446,36 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
   // offsets, and tests the photon against that sample's sphere.  Consecutive lanes read consecutive photons within a
   // row and every trip but the last is full.
   int maxRows = nrows;
+  {
+    // (its own copy of the lane index: the six permute addresses (lane ^ o) * 4 would otherwise be SHARED with the counters'
+    // reduction at the kernel's end -- and kept, spilled, across everything in between)
+    int laneR = lane;
+    asm volatile("" : "+v"(laneR));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) maxRows = max(maxRows, __shfl_xor(maxRows, o, 64));
+    for (int o = 32; o > 0; o >>= 1) maxRows = max(maxRows, __shfl(maxRows, laneR ^ o, 64));
+  }
   s.qr[lane] = make_float4(q.x, q.y, q.z, radius);
   s.found[lane] = 0u;
   // A row of the box is a run of cells along x at one (y, z): only the part of it the sphere can reach is listed -- the
   // cells of a 3 x 3 x 3 box hold ~6 times the sphere's volume, the trimmed rows ~3 times (C1: 14.6 -> ~8 candidates a
   // sample).  Conservative: the reach carries 1e-4 r + 1e-6 + 2e-4 cells of slack -- a cell's bounds are rebuilt here as
   // org + index * cell, off the build's floor((p - org) * invCell) by up to ~1e-7 * index cells.
-  const float padW = radius * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
   auto rowRange = [&](int r, uint32_t &c, uint32_t &e) __attribute__((always_inline)) {
     c = e = 0u;
-    if (r < nrows) {
-      const int y = by0 + r % nyr, z = bz0 + r / nyr;
+    const int nrowsL = (int)(boxB >> 14);
+    if (r < nrowsL) {
+      const int bx0L = (int)(boxA & 1023u), bx1L = (int)((boxA >> 10) & 1023u), by0L = (int)(boxA >> 20);
+      const int bz0L = (int)(boxB & 1023u), nyr = (int)((boxB >> 10) & 15u);
+      const float4 qr = s.qr[lane];
+      const float padW = qr.w * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
+      const int y = by0L + r % nyr, z = bz0L + r / nyr;
       const float ylo = gr.org[1] + (float)y * gr.cell, zlo = gr.org[2] + (float)z * gr.cell;
-      const float dy = fmaxf(0.f, fmaxf(ylo - q.y, q.y - (ylo + gr.cell))), dz = fmaxf(0.f, fmaxf(zlo - q.z, q.z - (zlo + gr.cell)));
+      const float dy = fmaxf(0.f, fmaxf(ylo - qr.y, qr.y - (ylo + gr.cell))), dz = fmaxf(0.f, fmaxf(zlo - qr.z, qr.z - (zlo + gr.cell)));
       const float h2 = pad2 - (dy * dy + dz * dz);
       if (h2 > 0.f) {
         const float hx = sqrtf(h2) + 1e-6f;
-        const int x0 = max(bx0, (int)floorf((q.x - hx - gr.org[0]) * gr.invCell));
-        const int x1 = min(bx1, (int)floorf((q.x + hx - gr.org[0]) * gr.invCell));
+        const int x0 = max(bx0L, (int)floorf((qr.x - hx - gr.org[0]) * gr.invCell));
+        const int x1 = min(bx1L, (int)floorf((qr.x + hx - gr.org[0]) * gr.invCell));
         if (x1 >= x0) {
           const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
           c = a.cellStart[rb + x0];
@@ -469,8 +485,10 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     }
   };
   uint32_t qHead = 0, qCount = 0, rqHead = 0, rqCount = 0;
-  uint32_t nEval = 0, nNull = 0, nDiff = 0, nFail = 0;
-  unsigned long long nCand = 0;
+  uint32_t nNull = 0, nDiff = 0, nFail = 0;
+  // candidates and evaluations are counted per WAVE, in the scalar file (a trip's candidates: its width; a batch's evaluations:
+  // its ballot): two vector registers less across the walk
+  unsigned long long nCandW = 0, nEvalW = 0;
   auto drain = [&](uint32_t n) __attribute__((always_inline)) {  // phase 2 for the first n <= 64 queued reconnections
     vpmWaveSync();
     if ((uint32_t)lane < n) {
@@ -486,8 +504,8 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     if (valid) {
       if (PRIMAL) vpmPrimalTerm(a, s, e.x, e.y, norm);
       else qMask = vpmPhase1<HS>(a, s, e.x, e.y, norm, nNull, nFail);
-      nEval++;
     }
+    nEvalW += (unsigned long long)__popcll(__ballot(valid));
 #pragma unroll 1
     for (uint32_t i = 0; i < 4u; ++i) {
       const bool want = (qMask >> i) & 1u;
@@ -526,6 +544,7 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     if (lane == 63) s.segOff[64] = total;
     vpmWaveSync();
     for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+      nCandW += min(64u, total - j0);
       const uint32_t j = j0 + (uint32_t)lane;
       const bool have = j < total;
       bool hit = false;
@@ -548,7 +567,6 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
         gi = s.rowStart[row][owner] + (kk - s.rowOff[row][owner]);
         const float4 hp = a.hot[gi];
         const float4 qr = s.qr[owner];
-        nCand++;
         const f3 p = mk3(hp.x, hp.y, hp.z);
         const f3 qo = mk3(qr.x, qr.y, qr.z);
         const float rad = qr.w, r2f = rad * rad;
@@ -620,8 +638,10 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
   }
   {
     // the photon counts M of the samples of a run, combined in the wave (segmented suffix sum keyed by the pixel)
-    const uint32_t prev = __shfl_up(pixv, 1u, 64);
-    const bool head = lane == 0 || prev != pixv;
+    const uint32_t pixE = s.pix[lane];  // (read again: not carried across the walk)
+    const uint32_t pixIdxE = (pixE >> 16) * (uint32_t)a.cfg.width + (pixE & 0xFFFFu);
+    const uint32_t prev = __shfl_up(pixE, 1u, 64);
+    const bool head = lane == 0 || prev != pixE;
     const unsigned long long heads = __ballot(head);
     uint32_t same = 0;  // bit j: no run starts in lanes lane+1 .. lane+2^j, i.e. lane + 2^j is in this lane's run
 #pragma unroll
@@ -635,17 +655,16 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
       const float w = __shfl_down(fv, 1u << j, 64);
       if ((same >> j) & 1u) fv += w;
     }
-    if (head && fv != 0.f) atomicAdd(&a.mvol[pixIdx], fv);
+    if (head && fv != 0.f) atomicAdd(&a.mvol[pixIdxE], fv);
   }
   {
-    unsigned long long ev = nEval, nu = nNull, di = nDiff, fa = nFail, ca = nCand;
+    unsigned long long nu = nNull, di = nDiff, fa = nFail;
+    const unsigned long long ev = nEvalW, ca = nCandW;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      ev += __shfl_xor(ev, o, 64);
       nu += __shfl_xor(nu, o, 64);
       di += __shfl_xor(di, o, 64);
       fa += __shfl_xor(fa, o, 64);
-      ca += __shfl_xor(ca, o, 64);
     }
 #ifdef GVPM_VPM_TIMING
     {

@@ -313,10 +313,11 @@ int gvpm_reset(gvpm_context *h);
  * the shadow segment, the sign / cosine tests of the reconnection -- is taken in fp32 WITH a rigorous error margin; a shift
  * with a comparison inside its margin (~1e-5 of them; for a parent that position rounding left behind the wall it sits
  * on, the reconnections within a few degrees of grazing) is evaluated by the EXACT PASS instead: the reference's statement
- * in uncontracted fp64 on the same fp32 inputs (csrc/exact_shift.hip), run behind the gather's kernels.  The shift counters
- * of gvpm_stats therefore equal those of a double-precision evaluation of the same inputs exactly (G-BRE; the other
- * techniques as DESIGN.md section 2 states).  evaluated: shifts the exact pass has taken since gvpm_reset; lost: shifts
- * that did not fit its list (also reported as dropped_pairs: gvpm_get_stats then fails).                                 */
+ * in fp64 on the same fp32 inputs (csrc/exact_shift.hip for G-BRE and G-VPM, run when the sums are read and every few
+ * gathers; csrc/gather_beams.hip exact_beams_kernel for G-Beams, behind every evaluation), so the shift counters of
+ * gvpm_stats equal those of a double-precision evaluation of the same inputs exactly (all four techniques; limits:
+ * DESIGN.md section 2).  evaluated: shifts the exact passes have taken since gvpm_reset; lost: shifts that did not fit
+ * their list (also reported as dropped_pairs: gvpm_get_stats then fails).                                               */
 int gvpm_get_exact_shift_count(gvpm_context *h, uint64_t *evaluated, uint64_t *lost);
 
 
@@ -384,7 +385,8 @@ int gvpm_prefetch_camera_beams(gvpm_context *h, const gvpm_camera_ray *rays, uin
  *               the derived direction is off by up to ~1e-7 / L rad (L ~ 1e-4, one photon in a thousand at C2: 1e-3 to
  *               1e-2 rad; tests/test_packed_upload.py bounds it).  A host that cannot accept that keeps the SoA upload
  *               (the shim: GVPM_HIP_UPLOAD=soa); parent_n and parent_wi travel as octahedral 2 x snorm16 (axis-aligned vectors are exact,
- *               others are off by < 4e-5 rad; a zero vector stays zero); parent_scat and parent_g become an index into a
+ *               others are off by <= 4.8e-5 rad (parent_n; parent_wi 5.8e-5): in general position -- tests/test_rotated_gpu.py -- the film's L2
+ *               against the fp64 oracle is 8e-6 with packed records, 9e-8 with SoA; a zero vector stays zero); parent_scat and parent_g become an index into a
  *               table of the scene's materials (gvpm_upload_materials); path_id travels as the one bit the gather reads
  *               of it (checkerboard parity, gvpm.cpp:1020-1030) in bit 7 of flags.  Positions, flux, prefix_w and the three
  *               pdfs / weights stay fp32: evaluation counts are those of the SoA upload, bit for bit.
