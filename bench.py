@@ -598,7 +598,7 @@ def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
     map.  Reported, not targeted."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores, physical = host_threads()
+    cores, hw_threads, physical = host_threads()
     r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
 
     def run(rows, threads):
@@ -627,7 +627,7 @@ def cpu_baseline_technique(tech, p, m, tris, first, W, H, budget_s):
         per_row = max(ev / min(8, H), 1.0)
         rows = int(min(H, max(8, (budget_s * gather_rate) / per_row)))
     ev, s, b, nsets = run(rows, cores)
-    out = {"value": ev / s / 1e6, "unit": "Mevals/s", "cores": cores, "physical_cores": physical, "kind": "port",
+    out = {"value": ev / s / 1e6, "unit": "Mevals/s", "cores": cores, "physical_cores": physical, "host_threads": hw_threads, "kind": "port",
            "build_s": b, "gather_s": s - b, "gather_only_value": ev / max(s - b, 1e-9) / 1e6,
            "sample": f"iteration 1, the middle {rows} of {H} pixel rows ({nsets} beam sets), the full map through the "
                      f"reference's accelerator; its serial build ({b:.2f} s) + the gather on {cores} threads ({s - b:.2f} s), "
@@ -801,14 +801,36 @@ def parity(hip, metrics, sc, p, m, tris, first, W, H):
 
 
 def host_threads():
-    """(hardware threads, physical cores) of this host"""
-    threads = os.cpu_count() or 1
+    """(threads this process may actually run on, hardware threads of the host, physical cores).  The first is what the
+    baseline uses: os.cpu_count() is the MACHINE's -- a container's affinity mask or CPU quota (cgroup v2 cpu.max, v1
+    cfs_quota_us) can be far smaller, and a gather spread over 256 threads that share 16 cores measures the scheduler."""
+    hw = os.cpu_count() or 1
+    usable = hw
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        if quota:
+            usable = max(1, min(usable, int(quota + 0.5)))
+    except Exception:
+        pass
     try:
         import psutil
-        physical = psutil.cpu_count(logical=False) or threads
+        physical = psutil.cpu_count(logical=False) or hw
     except Exception:
-        physical = threads
-    return threads, physical
+        physical = hw
+    return usable, hw, physical
 
 
 def cpu_baseline(p, m, tris, host0, W, H):
@@ -819,7 +841,7 @@ def cpu_baseline(p, m, tris, host0, W, H):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     r = float(np.float32(p.bsphere_radius) * np.float32(p.initial_scale_volume) * np.float32(0.01))
-    cores, physical = host_threads()
+    cores, hw_threads, physical = host_threads()
     evals, secs, nsets, build = 0, 0.0, 0, 0.0
     cpu0 = time.process_time()
     for ph, nb, rays in host0:
@@ -843,9 +865,10 @@ def cpu_baseline(p, m, tris, host0, W, H):
                                fast=True, timing=tm1)
     return {
         "value": evals / secs / 1e6, "unit": "Mevals/s", "cores": cores, "kind": "port",
-        # `cores` = the THREADS the gather ran on (hardware threads: os.cpu_count()); physical cores beside it, and how busy
+        # `cores` = the THREADS the gather ran on (what the process may use: affinity mask and CPU quota, host_threads());
+        # the host's hardware threads and physical cores beside it, and how busy
         # the threads were during the gather (CPU seconds / (threads x gather seconds): the serial build counts for one)
-        "physical_cores": physical,
+        "physical_cores": physical, "host_threads": hw_threads,
         "thread_utilisation": (cpu_s - build) / max(cores * (secs - build), 1e-9),
         # the kd-tree + BVH build is serial in the reference (gvpm.cpp:450-454) and in the port: the split says how much of
         # the all-core figure is that one thread

@@ -114,12 +114,15 @@ __device__ void reconnectExact(const GatherArgs &a, const PhotonCold &ph, d3 off
     const double cosWo = dot(pn, dProj), cosWi = dot(pn, pwi);
     f3 f;
     float pdfF;
-    // (values in fp32 -- the table's closed forms, shift_device.h; the DECISIONS around them are taken here)
-    if (cosWi <= 0 || cosWo <= 0 ||
-        !glossyParentEval(a, ph.parentG, ph.parentScat, ph.parentN, ph.parentWi, tof(dProj), (float)cosWi, (float)cosWo, f, pdfF))
-      return;
-    thr = tod(f);
-    pdfValue = pdfF;
+    if (cosWi <= 0 || cosWo <= 0) return;
+    // Phong: in fp64 (a lobe of exponent ~1000 underflows fp32 where the reference's double is still positive, and pdf == 0
+    // is a decision); the rough conductor's values in fp32 -- the table's closed forms, shift_device.h -- the DECISIONS
+    // around them are taken here
+    if (!phongEvalD(a, ph.parentG, scat, pn, pwi, dProj, cosWi, cosWo, thr, pdfValue)) {
+      if (!glossyParentEval(a, ph.parentG, ph.parentScat, ph.parentN, ph.parentWi, tof(dProj), (float)cosWi, (float)cosWo, f, pdfF)) return;
+      thr = tod(f);
+      pdfValue = pdfF;
+    }
   } else if (ptype == GVPM_PARENT_MEDIUM) {
     const double p = phaseD((double)ph.parentG, pwi, dProj);
     thr = scat * p;

@@ -354,19 +354,8 @@ __device__ __forceinline__ double shiftBeamDiffuse(const GatherArgs &a, const Ti
     thr = b.parentScat * (INV_PI * cosWo);
     pdfValueSA = INV_PI * cosWo;
     if (ptype == GVPM_PARENT_SURFACE_BSDF) {
-      // a glossy parent (gvpm_upload_bsdfs): Phong with both components, src/bsdfs/phong.cpp:121-186
-      const uint32_t bi = (uint32_t)b.parentG;
-      if (!(b.parentG >= 0.0) || bi >= a.nbsdfs) return 1.0;
-      const float4 b0 = a.bsdfs[4 * bi], b1 = a.bsdfs[4 * bi + 1];
-      if (__float_as_int(b0.x) == GVPM_BSDF_PHONG) {
-        const double e = b1.x, w = b1.y;
-        const d3 refl = b.parentN * (2.0 * cosWi) - b.parentWi;
-        const double alpha = dot(newPBDir, refl);
-        const double lobe = alpha > 0 ? pow(alpha, e) : 0.0;
-        const double INV_TWOPI = 0.15915494309189533577;
-        thr = (mkd(b0.y, b0.z, b0.w) * ((e + 2.0) * INV_TWOPI * lobe) + b.parentScat * INV_PI) * cosWo;
-        pdfValueSA = w * (lobe * (e + 1.0) * INV_TWOPI) + (1.0 - w) * (INV_PI * cosWo);
-      } else {
+      // a glossy parent (gvpm_upload_bsdfs): Phong in fp64 (src/bsdfs/phong.cpp:121-186,331-342; shift_device.h phongEvalD)
+      if (!phongEvalD(a, (float)b.parentG, b.parentScat, b.parentN, b.parentWi, newPBDir, cosWi, cosWo, thr, pdfValueSA)) {
         // (the other table entries -- the rough conductor -- through the fp32 statement the default path uses)
         f3 ff;
         float pp;
@@ -935,6 +924,7 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
   const uint32_t ptype = GVPM_PF_PARENT_TYPE(b.flags);
   f3 thr;
   float pdfValueSA;
+  bool pdfTiny = false;
   if (ptype == GVPM_PARENT_SURFACE || ptype == GVPM_PARENT_SURFACE_BSDF) {
     const float cosWo = dot(b.parentN, nd), cosWi = dot(b.parentN, b.parentWi);
     // (the new beam's direction is good to ~1e-6: a cosine this close to zero is the exact pass's to sign)
@@ -942,9 +932,15 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
     if (cosWi <= 0.f || cosWo <= 0.f) return 1.f;
     thr = b.parentScat * (INV_PI_F * cosWo);
     pdfValueSA = INV_PI_F * cosWo;
-    if (ptype == GVPM_PARENT_SURFACE_BSDF &&
-        !glossyParentEval(a, b.parentG, b.parentScat, b.parentN, b.parentWi, nd, cosWi, cosWo, thr, pdfValueSA))
-      return 1.f;
+    if (ptype == GVPM_PARENT_SURFACE_BSDF) {
+      uint32_t gst = 0u;
+      if (!glossyParentEval(a, b.parentG, b.parentScat, b.parentN, b.parentWi, nd, cosWi, cosWo, thr, pdfValueSA, &gst)) return 1.f;
+      // (a pdf that underflowed here but not in the reference's double -- the specular component of a Phong wall alone: the
+      // shift succeeds there with weight 1 and a flux that rounds to zero; inside the band of the double's own underflow the
+      // exact pass decides)
+      pdfTiny = (gst & 1u) != 0u;
+      if (gst & 2u) amb = true;
+    }
   } else if (ptype == GVPM_PARENT_MEDIUM) {
     const float ph = phaseEval(b.parentG, b.parentWi, nd);
     thr = b.parentScat * ph;
@@ -964,7 +960,7 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
     sPdf *= m.pdfFailure;
     thr = thr * fdiv(m.tr, pr.pdfKernelAndDist);
   }
-  if (sPdf == 0.f) return 1.f;
+  if (sPdf == 0.f && !pdfTiny) return 1.f;
   // BeamKernelRecord::kernelPDF of the new beam p1 -> newPos against the shifted ray (shift_volume_beams.h:300-336)
   float shiftKernelPDF = 0.f;
   if (technique == GVPM_BEAM_BEAM_1D) {
@@ -992,7 +988,7 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
   if (a.cfg.use_mis) {
     const float basePdf = pr.pdfBasePos * pr.pdfKernelAndDist;
     const float offsetPdf = shiftKernelPDF * sPdf;
-    if (offsetPdf == 0.f || basePdf == 0.f) {
+    if ((offsetPdf == 0.f && !pdfTiny) || basePdf == 0.f) {
       ok = false;
       return 1.f;
     }

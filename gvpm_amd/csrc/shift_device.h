@@ -467,11 +467,17 @@ __device__ __forceinline__ float fresnelConductor(float cI, float eta, float k) 
 // alpha = wo . reflect(wi).  Rough conductor, src/bsdfs/roughconductor.cpp:257-319: eval = F D G / (4 cos_i), pdf = D G1(wi)
 // / (4 cos_i) or D cos_H / (4 |wo . H|) (include/gvpm_hip.h).  cosWi, cosWo > 0 is the caller's test.  False: no such
 // entry (a failed shift).
+// state (optional out, round 5): bit 0 -- the pdf is POSITIVE in double precision although it underflowed here (the
+// specular component of a Phong wall alone, exponent ~1000: alpha^e leaves fp32 below alpha ~ 0.94 and fp64 only below ~0.6;
+// with pdf == 0 the reference fails the shift, with a positive one -- however small -- it succeeds, with weight 1 and a
+// flux that rounds to zero: only the counter tells them apart); bit 1 -- within rounding of the double's own underflow:
+// the exact pass decides, with the lobe in fp64 (phongEvalD).
 __device__ __forceinline__ bool glossyParentEval(const GatherArgs &a, float index, f3 kd, f3 n, f3 wi, f3 wo, float cosWi,
-                                                 float cosWo, f3 &f, float &pdf) {
+                                                 float cosWo, f3 &f, float &pdf, uint32_t *state = nullptr) {
   const uint32_t bi = (uint32_t)index;
   f = mk3(0.f);
   pdf = 0.f;
+  if (state) *state = 0u;
   if (!(index >= 0.f) || bi >= a.nbsdfs) return false;
   const float4 b0 = a.bsdfs[4 * bi], b1 = a.bsdfs[4 * bi + 1];
   const int kind = __float_as_int(b0.x);
@@ -479,10 +485,21 @@ __device__ __forceinline__ bool glossyParentEval(const GatherArgs &a, float inde
     const float e = b1.x, w = b1.y;
     const f3 refl = n * (2.f * cosWi) - wi;
     const float alpha = dot(wo, refl);
-    const float lobe = alpha > 0.f ? __builtin_exp2f(e * __builtin_log2f(alpha)) : 0.f;  // std::pow(alpha, exponent)
+    const float l2 = alpha > 0.f ? e * __builtin_log2f(alpha) : -INFINITY;
+    float lobe = alpha > 0.f ? __builtin_exp2f(l2) : 0.f;  // std::pow(alpha, exponent)
     const float INV_TWOPI_F = 0.15915494309189533577f;
-    f = (mk3(b0.y, b0.z, b0.w) * ((e + 2.f) * INV_TWOPI_F * lobe) + kd * INV_PI_F) * cosWo;
-    pdf = w * (lobe * (e + 1.f) * INV_TWOPI_F) + (1.f - w) * (INV_PI_F * cosWo);
+    // (the entry's component: 0 both, 1 the specular lobe alone, 2 the diffuse one alone -- bRec.component + 1; a component's
+    // pdf times its pdfComponent IS its term of the mixture, phong.cpp:157-186,331-342)
+    const int comp = __float_as_int(b1.z);
+    const float dOn = comp == 1 ? 0.f : 1.f;
+    if (comp == 2) lobe = 0.f;
+    f = (mk3(b0.y, b0.z, b0.w) * ((e + 2.f) * INV_TWOPI_F * lobe) + kd * (INV_PI_F * dOn)) * cosWo;
+    pdf = w * (lobe * (e + 1.f) * INV_TWOPI_F) + (1.f - w) * (INV_PI_F * cosWo * dOn);
+    if (state && comp == 1 && pdf == 0.f && w > 0.f) {
+      // the double's lobe is zero below 2^-1074; the factors beside it (w (e + 1) / 2 pi, 1 / l^2, the medium's pdf) move the
+      // product's own underflow by a few tens of binades: a band of +-64 around it, and |alpha| within rounding of zero
+      *state = (l2 > -1010.f ? 1u : 0u) | ((l2 > -1138.f && l2 <= -1010.f) || fabsf(alpha) <= 1e-6f ? 2u : 0u);
+    }
     return true;
   }
   if (kind == GVPM_BSDF_ROUGHCONDUCTOR) {
@@ -502,6 +519,26 @@ __device__ __forceinline__ bool glossyParentEval(const GatherArgs &a, float inde
     return true;
   }
   return false;
+}
+
+// Phong::eval (x cos) and Phong::pdf x pdfComponent of a table entry in fp64 (phong.cpp:121-186,331-342): what the exact
+// passes and the fp64 transcription of G-Beams evaluate a Phong parent with -- a lobe of exponent ~1000 lives where fp32 has
+// no numbers.  False: not a Phong entry.
+__device__ __forceinline__ bool phongEvalD(const GatherArgs &a, float index, d3 kd, d3 n, d3 wi, d3 wo, double cosWi, double cosWo,
+                                           d3 &f, double &pdf) {
+  const uint32_t bi = (uint32_t)index;
+  if (!(index >= 0.f) || bi >= a.nbsdfs) return false;
+  const float4 b0 = a.bsdfs[4 * bi], b1 = a.bsdfs[4 * bi + 1];
+  if (__float_as_int(b0.x) != GVPM_BSDF_PHONG) return false;
+  const double INV_PI = 0.31830988618379067154, INV_TWOPI = 0.15915494309189533577;
+  const double e = b1.x, w = b1.y;
+  const int comp = __float_as_int(b1.z);  // 0 both, 1 specular only, 2 diffuse only (gvpm_hip.h, gvpm_bsdf)
+  const d3 refl = n * (2.0 * cosWi) - wi;
+  const double alpha = dot(wo, refl);
+  const double lobe = (alpha > 0 && comp != 2) ? pow(alpha, e) : 0.0, dOn = comp == 1 ? 0.0 : 1.0;
+  f = (mkd(b0.y, b0.z, b0.w) * ((e + 2.0) * INV_TWOPI * lobe) + kd * (INV_PI * dOn)) * cosWo;
+  pdf = w * (lobe * (e + 1.0) * INV_TWOPI) + (1.0 - w) * (INV_PI * cosWo * dOn);
+  return true;
 }
 
 // shiftPhotonDiffuse + diffuseReconnection.  Returns the MIS weight, writes the shifted flux.
@@ -547,9 +584,13 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const float pMed = phaseEval(ph.parentG, ph.parentWi, dProj);
   float pdfValue = isMedium ? pMed : lam;
   f3 thr = isSurface ? ph.parentScat * lam : (isMedium ? ph.parentScat * pMed : mk3(lam));
+  bool pdfTiny = false;  // (glossyParentEval: the pdf underflowed HERE, not in the reference's double)
   if (isGlossy) {
     // (a branch of its own: scenes without glossy walls pay one wave-uniform test)
-    if (!glossyParentEval(a, ph.parentG, ph.parentScat, ph.parentN, ph.parentWi, dProj, cosWi, cosWo, thr, pdfValue)) good = false;
+    uint32_t gst = 0u;
+    if (!glossyParentEval(a, ph.parentG, ph.parentScat, ph.parentN, ph.parentWi, dProj, cosWi, cosWo, thr, pdfValue, &gst)) good = false;
+    pdfTiny = (gst & 1u) != 0u;
+    if (amb && (gst & 2u)) *amb |= 32u;
   }
   const float gop = frcp(l2Proj);
   float sPdf = pdfValue * gop;
@@ -562,7 +603,7 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
     sPdf *= pdfSuccess;
     thr = thr * tr * frcp(ph.edgePdf);
   }
-  good = good && sPdf != 0.f;
+  good = good && (sPdf != 0.f || pdfTiny);
   const f3 photonWeight = ph.prefixW * thr;
   const f3 sigS = mk3(a.med.sigmaS[0], a.med.sigmaS[1], a.med.sigmaS[2]);
   const f3 contrib = sigS * photonWeight * phaseEval(a.med.g, -dProj, -sh.d);
@@ -571,7 +612,7 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   if (a.cfg.use_mis) {
     const float basePdf = pdfBaseRay * ph.parentPdf * ph.edgePdf;
     const float offsetPdf = sPdf * pdfShiftRay;
-    misOk = !(offsetPdf == 0.f || basePdf == 0.f);
+    misOk = !((offsetPdf == 0.f && !(pdfTiny && pdfShiftRay != 0.f)) || basePdf == 0.f);
     // (sensorMisPre: the caller's per-(shift, beam) value, when it keeps one)
     const float v = (sensorMisPre >= 0.f ? sensorMisPre : sensorMIS(sh, base, edge)) * fdiv(offsetPdf, basePdf);
     w = a.cfg.power_heuristic ? frcp(1.f + v * v) : frcp(1.f + v);

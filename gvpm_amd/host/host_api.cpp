@@ -141,24 +141,27 @@ uint32_t gvpm_synth_bsdfs(const gvpm_synth *s, gvpm_bsdf *out, uint32_t cap) {
   if (!s) return 0;
   uint32_t n = 0;
   for (const auto &m : s->scene.mats) {
-    if (m.kind != gvpm::MAT_PHONG && m.kind != gvpm::MAT_ROUGHCONDUCTOR) continue;
-    if (out && (uint32_t)m.bsdf < cap) {
-      gvpm_bsdf &b = out[m.bsdf];
-      memset(&b, 0, sizeof(b));
-      b.specular[0] = (float)m.spec.x; b.specular[1] = (float)m.spec.y; b.specular[2] = (float)m.spec.z;
-      b.exponent = (float)m.exponent;
-      if (m.kind == gvpm::MAT_PHONG) {
-        b.kind = GVPM_BSDF_PHONG;
-        b.specular_sampling_weight = (float)m.specWeight;
-      } else {
-        b.kind = GVPM_BSDF_ROUGHCONDUCTOR;
-        b.distribution = m.distribution;
-        b.sample_visible = 0;  // (the host walk samples all normals, synth_core.h)
-        b.eta[0] = (float)m.eta.x; b.eta[1] = (float)m.eta.y; b.eta[2] = (float)m.eta.z;
-        b.k[0] = (float)m.k.x; b.k[1] = (float)m.k.y; b.k[2] = (float)m.k.z;
+    const int entries = gvpm::bsdfEntries(m.kind, m.exponent);
+    for (int c = 0; c < entries; ++c) {
+      if (out && (uint32_t)(m.bsdf + c) < cap) {
+        gvpm_bsdf &b = out[m.bsdf + c];
+        memset(&b, 0, sizeof(b));
+        b.specular[0] = (float)m.spec.x; b.specular[1] = (float)m.spec.y; b.specular[2] = (float)m.spec.z;
+        b.exponent = (float)m.exponent;
+        if (m.kind == gvpm::MAT_PHONG) {
+          b.kind = GVPM_BSDF_PHONG;
+          b.specular_sampling_weight = (float)m.specWeight;
+          b.distribution = entries == 2 ? c + 1 : 0;  // (sampled component + 1; 0: both components, include/gvpm_hip.h)
+        } else {
+          b.kind = GVPM_BSDF_ROUGHCONDUCTOR;
+          b.distribution = m.distribution;
+          b.sample_visible = 0;  // (the host walk samples all normals, synth_core.h)
+          b.eta[0] = (float)m.eta.x; b.eta[1] = (float)m.eta.y; b.eta[2] = (float)m.eta.z;
+          b.k[0] = (float)m.k.x; b.k[1] = (float)m.k.y; b.k[2] = (float)m.k.z;
+        }
       }
+      ++n;
     }
-    ++n;
   }
   return n;
 }

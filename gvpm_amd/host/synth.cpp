@@ -161,19 +161,22 @@ bool makeScene(const std::string &fullName, int width, int height, uint32_t seed
   s.mats.push_back({MAT_LAMBERT, V3(0.63, 0.065, 0.05), V3(0.0), 0.0, 0.0, -1});    // 1 red (left)
   s.mats.push_back({MAT_LAMBERT, V3(0.14, 0.45, 0.091), V3(0.0), 0.0, 0.0, -1});    // 2 green (right)
   s.mats.push_back({MAT_NULL, V3(0, 0, 0), V3(0.0), 0.0, 0.0, -1});                 // 3 medium boundary (front)
-  if (name == "cbox_phong" || name == "cbox_phong_hg") {
+  if (name == "cbox_phong" || name == "cbox_phong_hg" || name == "cbox_phong1") {
     // S-cbox with GLOSSY walls: floor and back wall are Phong surfaces (a polished floor, exponent 40;
     // a satin wall, exponent 12), so that a large part of the photons are re-connected through a non-Lambertian parent
     auto phong = [&](V3 kd, V3 ks, double e) {
       auto lum = [](V3 c) { return 0.212671 * c.x + 0.715160 * c.y + 0.072169 * c.z; };  // Spectrum::getLuminance, RGB
       SynthMat m{MAT_PHONG, kd, ks, e, lum(ks) / (lum(kd) + lum(ks)), 0};
       m.bsdf = 0;
-      for (const auto &q : s.mats) m.bsdf += (q.kind == MAT_PHONG || q.kind == MAT_ROUGHCONDUCTOR) ? 1 : 0;
+      for (const auto &q : s.mats) m.bsdf += bsdfEntries(q.kind, q.exponent);
       s.mats.push_back(m);
       return (int)s.mats.size() - 1;
     };
-    const int mFloor = phong(V3(0.3, 0.3, 0.3), V3(0.5, 0.5, 0.45), 40.0);
-    const int mBack = phong(V3(0.2, 0.25, 0.4), V3(0.3, 0.3, 0.3), 12.0);
+    // `cbox_phong1` (round 5): exponents 1500 and 900, i.e. roughness 0.037 and 0.047 < 0.05 -- sampleNext picks ONE component
+    // per bounce (Phong::sampleComponent) and the reconnection evaluates that component alone
+    const bool one = name == "cbox_phong1";
+    const int mFloor = phong(V3(0.3, 0.3, 0.3), V3(0.5, 0.5, 0.45), one ? 1500.0 : 40.0);
+    const int mBack = phong(V3(0.2, 0.25, 0.4), V3(0.3, 0.3, 0.3), one ? 900.0 : 12.0);
     addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
     if (rot) addCornellBlocks(s, 0, mBack);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
@@ -187,7 +190,7 @@ bool makeScene(const std::string &fullName, int width, int height, uint32_t seed
       m.k = k;
       m.distribution = distribution;
       m.bsdf = 0;
-      for (const auto &q : s.mats) m.bsdf += (q.kind == MAT_PHONG || q.kind == MAT_ROUGHCONDUCTOR) ? 1 : 0;
+      for (const auto &q : s.mats) m.bsdf += bsdfEntries(q.kind, q.exponent);
       s.mats.push_back(m);
       return (int)s.mats.size() - 1;
     };

@@ -23,6 +23,12 @@ namespace gvpm {
 // MAT_ROUGHCONDUCTOR: src/bsdfs/roughconductor.cpp, isotropic Beckmann / GGX, sampled WITHOUT visible normals
 // (sampleVisible = false: MicrofacetDistribution::sampleAll) -- the table's second kind
 enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3, MAT_ROUGHCONDUCTOR = 4 };
+// table entries of a glossy material: PathVertex::sampleNext picks ONE component of a Phong surface below roughness 0.05
+// (vertex.cpp:160-165, Phong::getRoughness = sqrt(2 / (2 + exponent)), phong.cpp:293-300): an entry per component then
+GVPM_HD inline bool phongOneComponent(double exponent) { return sqrt(2.0 / (2.0 + exponent)) < 0.05; }
+GVPM_HD inline int bsdfEntries(int kind, double exponent) {
+  return kind == MAT_PHONG ? (phongOneComponent(exponent) ? 2 : 1) : (kind == MAT_ROUGHCONDUCTOR ? 1 : 0);
+}
 
 struct SynthTri {
   V3 v0, e1, e2, n;  // n: geometric normal (front side)
@@ -34,7 +40,8 @@ struct SynthMat {
   V3 spec;            // Phong: specular reflectance
   double exponent;    // Phong exponent
   double specWeight;  // m_specularSamplingWeight = lum(spec) / (lum(diffuse) + lum(spec)), phong.cpp:93-97
-  int bsdf;           // index in the table of gvpm_upload_bsdfs (-1: none)
+  int bsdf;           // index in the table of gvpm_upload_bsdfs (-1: none); a Phong below roughness 0.05 has TWO entries:
+                      // bsdf = met through its specular component, bsdf + 1 = through its diffuse one (phongEntries)
   // rough conductor: spec = specular reflectance, exponent = alpha
   V3 eta = V3(0.0), k = V3(0.0);
   int distribution = 0;  // GVPM_MICROFACET_*
@@ -174,6 +181,7 @@ struct LVertex {
   int matKind;
   int mat;          // material index of a surface vertex (-1 otherwise)
   uint32_t comp;    // componentType of a sampled surface vertex (BSDF::EBSDFType of the sampled lobe)
+  int compSel;      // sampledComponentIndex: -1 all components, else the one sampleComponent picked (vertex.cpp:160-180)
 };
 
 // a light path: at most maxDepth + 1 vertices
@@ -236,6 +244,7 @@ template <class PATH> GVPM_HD inline void walkBegin(const SceneView &sc, Philox 
   v0.matKind = -1;
   v0.mat = -1;
   v0.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+  v0.compSel = -1;
   double u1 = rng.next1D(), u2 = rng.next1D();
   LVertex v1;
   v1.type = VT_EMITTER;
@@ -244,6 +253,7 @@ template <class PATH> GVPM_HD inline void walkBegin(const SceneView &sc, Philox 
   v1.matKind = -1;
   v1.mat = -1;
   v1.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+  v1.compSel = -1;
   path.push_back(v0);
   path.push_back(v1);
 
@@ -285,18 +295,36 @@ template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &
         solidAngle = false;
         if (maxc(cur.weight) <= 0) return false;
       } else if (cur.matKind == MAT_PHONG) {
-        // Phong::sample with bRec.component = -1 (phong.cpp:188-247): the sample picks the lobe, weight = eval / pdf of the
-        // WHOLE BSDF, pdf = the mixture's (:157-186)
+        // PathVertex::sampleNext (vertex.cpp:160-173): below roughness 0.05 Phong::sampleComponent (phong.cpp:308-329) picks
+        // ONE component first -- and rescales the sample as written there (the specular branch MULTIPLIES by the weight) --,
+        // then Phong::sample (:188-247) with bRec.component: with both components the sample picks the lobe and weight / pdf
+        // are the whole BSDF's; with one, that lobe's alone, then weight /= pdfComponent, pdf *= pdfComponent.
         const SynthMat &pm = sc.mats[cur.mat];
         const double sw = pm.specWeight, e = pm.exponent, cosWi = dot(cur.n, wi);
         const V3 refl = cur.n * (2.0 * cosWi) - wi;  // reflect(wi) in world space
         double sx = a;
-        bool choseSpecular = true;
-        if (sx <= sw) {
-          sx /= sw;
-        } else {
-          sx = (sx - sw) / (1 - sw);
-          choseSpecular = false;
+        int compSel = -1;
+        double pdfComp = 1.0;
+        if (phongOneComponent(e)) {  // Phong::getRoughness (:293-300) against sampleNext's constant
+          if (sx < sw) {
+            compSel = 0;
+            pdfComp = sw;
+            sx *= sw;
+          } else {
+            compSel = 1;
+            pdfComp = 1 - sw;
+            sx = (sx - sw) / (1 - sw);
+          }
+        }
+        const bool hasSpecular = compSel != 1, hasDiffuse = compSel != 0;
+        bool choseSpecular = hasSpecular;
+        if (hasSpecular && hasDiffuse) {
+          if (sx <= sw) {
+            sx /= sw;
+          } else {
+            sx = (sx - sw) / (1 - sw);
+            choseSpecular = false;
+          }
         }
         if (choseSpecular) {
           const double sinAlpha = std::sqrt(std::fmax(0.0, 1 - std::pow(b, 2 / (e + 1))));
@@ -308,14 +336,20 @@ template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &
           wo = toWorld(cur.n, cosineHemisphere(sx, b));
           cur.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
         }
+        cur.compSel = compSel;
         const double cosWo = dot(cur.n, wo);
         if (cosWo <= 0) return false;
         const double alpha = dot(wo, refl);
-        const double lobe = alpha > 0 ? std::pow(alpha, e) : 0.0;
-        const double pdfW = sw * lobe * (e + 1) / (2.0 * kPi) + (1 - sw) * cosWo * kInvPi;
+        const double lobe = (hasSpecular && alpha > 0) ? std::pow(alpha, e) : 0.0;
+        const double specProb = lobe * (e + 1) / (2.0 * kPi), diffProb = hasDiffuse ? cosWo * kInvPi : 0.0;
+        double pdfW = (hasSpecular && hasDiffuse) ? sw * specProb + (1 - sw) * diffProb : (hasDiffuse ? diffProb : specProb);
         if (pdfW == 0) return false;
-        const V3 f = (pm.spec * ((e + 2) / (2.0 * kPi) * lobe) + pm.albedo * kInvPi) * cosWo;
+        const V3 f = (pm.spec * ((e + 2) / (2.0 * kPi) * lobe) + pm.albedo * (hasDiffuse ? kInvPi : 0.0)) * cosWo;
         cur.weight = f * (1.0 / pdfW);
+        if (compSel != -1) {
+          cur.weight = cur.weight * (1.0 / pdfComp);
+          pdfW *= pdfComp;
+        }
         cur.pdf = pdfW;
         if (maxc(cur.weight) <= 0) return false;
       } else if (cur.matKind == MAT_ROUGHCONDUCTOR) {
@@ -413,6 +447,7 @@ template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &
       return false;
     }
     succ.comp = succ.matKind == MAT_MIRROR ? 0x00008u : GVPM_BSDF_DIFFUSE_REFLECTION;
+    succ.compSel = -1;
     if (len == 0) return false;
     tr = std::exp(-sigT * len);
     pdfSuccess = sigT * tr * msw;
@@ -513,7 +548,7 @@ template <class PATH> GVPM_HD inline void fillParent(const SceneView &sc, const 
     r.parentWi = normalize(path[ip - 1].pos - par.pos);
     if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
       ptype = GVPM_PARENT_SURFACE_BSDF;
-      r.parentG = (float)sc.mats[par.mat].bsdf;
+      r.parentG = (float)(sc.mats[par.mat].bsdf + (par.compSel == 1 ? 1 : 0));  // (the entry of the component the vertex was sampled through)
     }
   } else if (par.type == VT_MEDIUM) {
     ptype = GVPM_PARENT_MEDIUM;
@@ -592,7 +627,7 @@ template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const L
       r.parentWi = normalize(path[i - 2].pos - par.pos);
       if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
         ptype = GVPM_PARENT_SURFACE_BSDF;
-        r.parentG = (float)sc.mats[par.mat].bsdf;
+        r.parentG = (float)(sc.mats[par.mat].bsdf + (par.compSel == 1 ? 1 : 0));  // (the entry of the component the vertex was sampled through)
         comp = par.comp;  // the sampled lobe's type: EGlossyReflection or EDiffuseReflection (vertex.cpp:178-179)
       }
     } else if (par.type == VT_MEDIUM) {
@@ -693,7 +728,7 @@ template <class RL, bool BEAMS> struct StreamPath {
           r.parentWi = normalize(path[i - 2].pos - par.pos);
           if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
             ptype = GVPM_PARENT_SURFACE_BSDF;
-            r.parentG = (float)sc.mats[par.mat].bsdf;
+            r.parentG = (float)(sc.mats[par.mat].bsdf + (par.compSel == 1 ? 1 : 0));  // (the entry of the component the vertex was sampled through)
             comp = par.comp;
           }
         } else if (par.type == VT_MEDIUM) {

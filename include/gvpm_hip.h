@@ -186,6 +186,12 @@ typedef struct gvpm_medium {
  *     with alpha = wo . reflect(wi), w = specular_sampling_weight, both zero unless cos(theta_i), cos(theta_o) > 0;
  *     pdfComponent = 1.  Such a vertex classifies as DIFFUSE for every roughness above bounceRoughness (default 0.001,
  *     gvpm_struct.h:66-100,232-236): its photons are re-connected through it like through a Lambertian wall.
+ *     ONE component (round 5): below roughness 0.05 (exponent > 798) sampleNext picks a component first
+ *     (Phong::sampleComponent, phong.cpp:308-329: 0 = the specular lobe with probability w, 1 = the diffuse one) and the
+ *     reconnection evaluates THAT component (bRec.component = sampledComponentIndex): eval = its term alone, pdf = its pdf
+ *     times pdfComponent (w or 1 - w, :331-342) -- which is the matching term of the mixture above.  Such a vertex names an
+ *     entry whose `distribution` field holds component + 1 (0: both, the entries of round 4; 1: specular only; 2: diffuse
+ *     only): a surface that can be met both ways has one entry per way.
  *   GVPM_BSDF_ROUGHCONDUCTOR  src/bsdfs/roughconductor.cpp with an ISOTROPIC Beckmann or GGX distribution (alphaU == alphaV:
  *     the photon record carries the parent's normal, not its tangent frame) -- one component, EGlossyReflection:
  *       H = normalize(wi + wo), D = MicrofacetDistribution::eval (microfacet.h:191-232), G = smithG1(wi, H) smithG1(wo, H)
@@ -202,7 +208,7 @@ typedef struct gvpm_bsdf {    /* 64 bytes */
   float specular[3];          /* m_specularReflectance (Phong: after ensureEnergyConservation, phong.cpp:86-91) */
   float exponent;             /* Phong: m_exponent; rough conductor: alpha                              */
   float specular_sampling_weight; /* Phong: m_specularSamplingWeight, phong.cpp:93-97                   */
-  int32_t distribution;       /* rough conductor: GVPM_MICROFACET_*                                     */
+  int32_t distribution;       /* rough conductor: GVPM_MICROFACET_*; Phong: sampled component + 1 (0 = both) */
   int32_t sample_visible;     /* rough conductor: m_sampleVisible (the pdf's form)                      */
   float eta[3], k[3];         /* rough conductor: m_eta, m_k (relative to the exterior, roughconductor.cpp:181-191) */
   float reserved[2];

@@ -334,8 +334,8 @@ inline std::vector<gvpm_bsdf> &bsdfTable() {
   return t;
 }
 
-// Phong::eval / Phong::pdf, src/bsdfs/phong.cpp:121-186, with bRec.component = -1 (hasSpecular && hasDiffuse) and
-// pdfComponent = 1 (:332-334), in the LOCAL frame of the intersection as the reference evaluates them: Frame(n) with
+// Phong::eval / Phong::pdf * pdfComponent, src/bsdfs/phong.cpp:121-186,331-342, for bRec.component = -1 (both lobes,
+// pdfComponent = 1) or one sampled component (round 5), in the LOCAL frame of the intersection as the reference evaluates them: Frame(n) with
 // coordinateSystem(n) (frame.h:37-80; the value does not depend on the tangents).  wi, wo: world-space unit vectors.
 template <typename F>
 inline bool phongEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n, const Vec3<F> &wiW, const Vec3<F> &woW,
@@ -350,17 +350,24 @@ inline bool phongEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n
   if (wi.z <= 0 || wo.z <= 0) return false;   // Frame::cosTheta(bRec.wi) <= 0 || Frame::cosTheta(bRec.wo) <= 0
   const V refl(-wi.x, -wi.y, wi.z);            // reflect(wi), :117-119
   const F alpha = dot(wo, refl), exponent = (F)b.exponent;
+  // bRec.component = the entry's component (b.distribution - 1: -1 both, 0 specular, 1 diffuse; :131-134,161-164)
+  const int component = b.distribution - 1;
+  const bool hasSpecular = component == -1 || component == 0, hasDiffuse = component == -1 || component == 1;
   V result((F)0);
-  F specProb = 0;
-  if (alpha > 0) {
+  F specProb = 0, diffuseProb = 0;
+  if (hasSpecular && alpha > 0) {
     result += V((F)b.specular[0], (F)b.specular[1], (F)b.specular[2]) * ((exponent + 2) * INV_TWOPI * std::pow(alpha, exponent));
     specProb = std::pow(alpha, exponent) * (exponent + (F)1) / ((F)2 * M_PI_F);
   }
-  result += kd * INV_PI;
+  if (hasDiffuse) {
+    result += kd * INV_PI;
+    diffuseProb = INV_PI * wo.z;               // warp::squareToCosineHemispherePdf
+  }
   f = result * wo.z;
-  const F diffuseProb = INV_PI * wo.z;         // warp::squareToCosineHemispherePdf
   const F w = (F)b.specular_sampling_weight;
-  pdf = w * specProb + (1 - w) * diffuseProb;
+  if (hasDiffuse && hasSpecular) pdf = w * specProb + (1 - w) * diffuseProb;
+  else if (hasDiffuse) pdf = diffuseProb * (1 - w);   // Phong::pdf * pdfComponent (shift_diffuse.cpp:43-44, phong.cpp:331-342)
+  else pdf = specProb * w;
   return true;
 }
 

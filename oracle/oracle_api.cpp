@@ -597,12 +597,17 @@ extern "C" int oracle_phong_sample(const gvpm_bsdf *b, const double *n, const do
   const V wi(dot(wiV, s), dot(wiV, t), dot(wiV, nn));
   double sx = u1, sy = u2;
   const double w = b->specular_sampling_weight, exponent = b->exponent;
-  bool choseSpecular = true;
-  if (sx <= w) {
-    sx /= w;
-  } else {
-    sx = (sx - w) / (1 - w);
-    choseSpecular = false;
+  // (bRec.component = the entry's: with one component there is nothing to choose and the sample is used as it is, :202-211)
+  const int component = b->distribution - 1;
+  const bool hasSpecular = component == -1 || component == 0, hasDiffuse = component == -1 || component == 1;
+  bool choseSpecular = hasSpecular;
+  if (hasDiffuse && hasSpecular) {
+    if (sx <= w) {
+      sx /= w;
+    } else {
+      sx = (sx - w) / (1 - w);
+      choseSpecular = false;
+    }
   }
   V wo;
   if (choseSpecular) {

@@ -480,9 +480,10 @@ private:
 
   /* A surface parent whose BSDF is in the device's table of glossy BSDFs (include/gvpm_hip.h, gvpm_bsdf).  Returns its index
    * (appending the entry on first sight), -1 for every other vertex.
-   * Phong (src/bsdfs/phong.cpp), not textured, sampled with BOTH components (sampledComponentIndex == -1: what
+   * Phong (src/bsdfs/phong.cpp), not textured: sampled with BOTH components (sampledComponentIndex == -1: what
    * PathVertex::sampleNext records when Phong::sampleComponent finds the lobe's roughness >= 0.05, vertex.cpp:160-165,
-   * phong.cpp:311-330).  The exponent and the sampling weight have no getters: they are read back through getRoughness =
+   * phong.cpp:311-330) or -- round 5 -- through ONE of them (0 specular, 1 diffuse): an entry per (BSDF, component), its
+   * `distribution` field = component + 1 (include/gvpm_hip.h).  The exponent and the sampling weight have no getters: they are read back through getRoughness =
    * sqrt(2 / (2 + exponent)) (phong.cpp:293-300) and pdfComponent(component 0) = m_specularSamplingWeight (:332-343).
    * RoughConductor (src/bsdfs/roughconductor.cpp), not textured, isotropic Beckmann or GGX, whose Properties name `eta` and `k`
    * themselves (a `material` preset keeps its spectra in protected members: such a surface stays outside the closed set):
@@ -494,8 +495,11 @@ private:
     const BSDF *bsdf = its.getBSDF();
     const std::string cls = bsdf->getClass()->getName();
     if (bsdf->getType() & BSDF::ESpatiallyVarying) return -1;
-    if (cls == "Phong" ? par->sampledComponentIndex != -1 : cls != "RoughConductor") return -1;
-    auto found = m_bsdfIndex.find(bsdf);
+    if (cls != "Phong" && cls != "RoughConductor") return -1;
+    const int component = cls == "Phong" ? (int) par->sampledComponentIndex : -1;
+    if (component < -1 || component > 1) return -1;
+    const std::pair<const BSDF *, int> key(bsdf, component);
+    auto found = m_bsdfIndex.find(key);
     if (found != m_bsdfIndex.end()) return (int) found->second;
     gvpm_bsdf b;
     memset(&b, 0, sizeof(b));
@@ -509,6 +513,7 @@ private:
       BSDFSamplingRecord bRec(its, its.wi, its.wi, EImportance);
       bRec.component = 0;
       b.specular_sampling_weight = (float) bsdf->pdfComponent(bRec);
+      b.distribution = component + 1;   /* 0: both components; 1: the specular lobe alone; 2: the diffuse one alone */
     } else {
       const Properties &props = bsdf->getProperties();
       if (!props.hasProperty("eta") || !props.hasProperty("k")) return -1;
@@ -528,11 +533,11 @@ private:
     }
     const uint32_t idx = (uint32_t) m_bsdfs.size();
     m_bsdfs.push_back(b);
-    m_bsdfIndex[bsdf] = idx;
+    m_bsdfIndex[key] = idx;
     m_bsdfsDirty = true;
     return (int) idx;
   }
-  std::map<const BSDF *, uint32_t> m_bsdfIndex;
+  std::map<std::pair<const BSDF *, int>, uint32_t> m_bsdfIndex;   /* (BSDF, sampled component) -> table entry */
   std::vector<gvpm_bsdf> m_bsdfs;
   bool m_bsdfsDirty = false;
 
@@ -547,9 +552,11 @@ private:
     const ELightShiftType t = getTypeShift(lt, c, b);
     uint32_t st = t == EDiffuseShift ? 1u : t == EMediumShift ? 2u : t == EManifoldShift ? 3u : 0u;
     const BSDF *parBsdf = par->isSurfaceInteraction() ? par->getIntersection().getBSDF() : nullptr;
-    /* (pushParent ran first: the entry exists; a Phong vertex that sampled ONE lobe is not the table's BSDF) */
-    const bool glossy = m_bsdfIndex.count(parBsdf) != 0 &&
-                        (par->sampledComponentIndex == -1 || m_bsdfs[m_bsdfIndex.at(parBsdf)].kind == GVPM_BSDF_ROUGHCONDUCTOR);
+    /* (pushParent ran first: the entry of this vertex's (BSDF, sampled component) exists if the BSDF is in the closed set;
+     * a rough conductor has one component and one entry, keyed with -1) */
+    const bool glossy = parBsdf != nullptr &&
+                        (m_bsdfIndex.count(std::make_pair(parBsdf, (int) par->sampledComponentIndex)) != 0 ||
+                         m_bsdfIndex.count(std::make_pair(parBsdf, -1)) != 0);
     if (st == 1u || st == 2u) {
       if (par->isSurfaceInteraction() && !glossy) {
         const BSDF *bsdf = par->getIntersection().getBSDF();

@@ -192,7 +192,8 @@ def phong_world(kd, index, n, wi, wo):
     index: the rows' table entries.  Returns (f cos [k, 3], pdf [k], known [k]).
     Phong -- the modified Phong BRDF with both lobes (Lafortune & Willems 1994, as src/bsdfs/phong.cpp implements it):
     f cos = (ks (e + 2) / 2pi max(r . wo, 0)^e + kd / pi) (n . wo), pdf = w (e + 1) / 2pi max(r . wo, 0)^e + (1 - w) (n . wo) / pi,
-    r = 2 (n . wi) n - wi.  Rough conductor -- the Torrance-Sparrow microfacet BRDF (Walter et al. 2007, as
+    r = 2 (n . wi) n - wi; an entry of ONE component (a surface below roughness 0.05 is sampled a component at a time): that term of each.
+    Rough conductor -- the Torrance-Sparrow microfacet BRDF (Walter et al. 2007, as
     src/bsdfs/roughconductor.cpp + microfacet.h implement it, isotropic): f cos = F D G / (4 n . wi) with the half vector
     h = (wi + wo) / |wi + wo|, D Beckmann or GGX in their textbook forms, G = G1(wi) G1(wo) (Beckmann: Walter's rational fit),
     F the unpolarised Fresnel reflectance of a complex index eta + i k computed with COMPLEX arithmetic; pdf = D (n . h) / (4 |wo . h|)
@@ -208,8 +209,13 @@ def phong_world(kd, index, n, wi, wo):
     a = np.maximum((r * wo).sum(-1), 0.0)
     with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
         lobe = np.where(a > 0, a ** e, 0.0)
-        f = (ks * ((e + 2.0) / (2.0 * np.pi) * lobe)[..., None] + kd / np.pi) * co[..., None]
-        pdf = w * (e + 1.0) / (2.0 * np.pi) * lobe + (1.0 - w) * co / np.pi
+        # an entry met through ONE sampled component (distribution = component + 1, round 5): that lobe's term alone, and as
+        # its density the probability of picking the component times the lobe's own -- the matching term of the mixture
+        phong = b["kind"] == abi.GVPM_BSDF_PHONG
+        spec_on = np.where(phong & (b["distribution"] == 2), 0.0, 1.0)
+        diff_on = np.where(phong & (b["distribution"] == 1), 0.0, 1.0)
+        f = (ks * ((e + 2.0) / (2.0 * np.pi) * lobe * spec_on)[..., None] + kd / np.pi * diff_on[..., None]) * co[..., None]
+        pdf = w * (e + 1.0) / (2.0 * np.pi) * lobe * spec_on + (1.0 - w) * co / np.pi * diff_on
         # rough conductor rows
         cond = b["kind"] == abi.GVPM_BSDF_ROUGHCONDUCTOR
         if np.any(cond):
