@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void tr
       it = __shfl(it, 0, 64);
     }
     firstItem = false;
+    it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);  // (wave-uniform: the item's record in scalar registers)
     if (it >= nItems) break;
 #ifdef GVPM_TRAV_TIMING
     nIt++;
@@ -2185,6 +2186,9 @@ __global__ __launch_bounds__(64, B == 64 ? 1 : 2) void evaluate_beams2_kernel(Ga
       b0 = __shfl(b0, 0, 64);
       cnt = __shfl(cnt, 0, 64);
     }
+    // (wave-uniform, and said so: the run's bounds, the blocks' keys and the tile's base then live in scalar registers)
+    b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
     firstItem = false;
     if (b0 >= nBlocks) break;
     const uint32_t b1 = min(nBlocks, b0 + cnt);

@@ -613,6 +613,7 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
       it = __shfl(it, 0, 64);
     }
     firstItem = false;
+    it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);  // (wave-uniform: the item's record and region in scalar registers)
     if (it >= nItems) break;
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y & 0xFFu, chunk = item.y >> 8;
@@ -957,13 +958,16 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
       it = __shfl(it, 0, 64);
     }
     firstItem = false;
+    // (wave-uniform, and SAID so: the item's record, its pair region and everything derived from them then live in scalar
+    // registers -- as vector registers they were ten of the values this kernel spills around its hot loop, round 5)
+    it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
     if (it >= nItems) break;
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y & 0xFFu;
     if (nb == 0) continue;
     const uint32_t cntb = (uint32_t)lane < nb ? pairCnt[(size_t)it * B + lane] : 0u;
     const uint32_t incl = wave_scan_incl(cntb, lane);
-    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total == 0) continue;
     const uint32_t r0 = 0u, n = total;  // (the wave's share of the item's concatenated lists: all of it)
 #ifdef GVPM_EVAL_TIMING

@@ -11,7 +11,7 @@ from test_parity_gpu import l2
 pytestmark = pytest.mark.gpu
 
 
-def device_planes(c, p=None, rays=None, iters=1, exact=False):
+def device_planes(c, p=None, rays=None, iters=1, exact=True):
     p = c.p if p is None else p
     ctx = hip.Context(p, device=0)
     ctx.upload_scene(*c.tris)

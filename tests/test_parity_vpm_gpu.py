@@ -11,7 +11,7 @@ from test_parity_gpu import l2, TOL
 pytestmark = pytest.mark.gpu
 
 
-def device_vpm(c, iters=1, p=None, rays=None, exact=False):
+def device_vpm(c, iters=1, p=None, rays=None, exact=True):
     p = c.p if p is None else p
     ctx = hip.Context(p, device=0)
     ctx.upload_scene(*c.tris)
