@@ -326,6 +326,18 @@ extern "C" int gvpm_debug_vpm_timing(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gvpmVpmLog), sizeof(gvpmVpmLog)) == hipSuccess ? 0 : -1;
 }
 #endif
+// inclusive prefix sum over the wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast 15 (rows 1 and 3 take
+// the last lane of the row before) and row_bcast 31 (rows 2 and 3 take lane 31): GFX9 DPP, no address registers, no LDS traffic
+__device__ __forceinline__ uint32_t waveScanInclDpp(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (uint32_t)x;
+}
 template <bool FULLVIS, bool HS, bool PRIMAL = false>
 __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
   __shared__ VpmLds sAll[VPM_WPB];
@@ -533,13 +545,10 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
       s.rowOff[k][lane] = cnt;
       cnt += res[k] - rcs[k];
     }
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t v = __shfl_up(inc, (unsigned)o, 64);
-      if (lane >= o) inc += v;
-    }
-    const uint32_t total = __shfl(inc, 63, 64);
+    // (the scan through DPP row shifts and broadcasts -- the sequence LLVM's own atomic optimizer emits for wave64 -- instead of
+    // six ds_bpermute: their six address registers were carried, spilled, across the whole walk and reloaded every pass)
+    const uint32_t inc = waveScanInclDpp(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     s.segOff[lane] = inc - cnt;
     if (lane == 63) s.segOff[64] = total;
     vpmWaveSync();
