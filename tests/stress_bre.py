@@ -8,7 +8,9 @@ import cases
 from test_parity_gpu import check
 from gvpm_amd import abi
 n = 0
-for scene in ("cbox", "cbox_hg", "fogroom", "cbox_mirror", "laser", "cbox_phong", "cbox_conductor"):
+for scene in ("cbox", "cbox_hg", "fogroom", "cbox_mirror", "laser", "cbox_phong", "cbox_conductor", "cbox_phong1",
+              # general position (round 5): shift counters exact there too (check() asserts them exactly by default)
+              "cbox_rot", "fogroom_rot", "cbox_mirror_rot", "cbox_phong1_rot", "cbox_conductor_rot"):
     for kw in (dict(), dict(vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0), dict(path_set=0), dict(use_mis=0, max_depth=4)):
         for scale in (1.5, 4.0):
             c = cases.make_case(scene, 48, 40, 25000, scale, **kw)
