@@ -653,11 +653,49 @@ template <typename F> struct VolumeGradientRecord {
     return r;
   }
 
+  // A second stand-in (round 5), this one a REAL specular walk through one planar mirror -- the photon's parent, with its
+  // normal -- so that a test can answer the device from a genuinely different statement of the same walk (a Newton solve on
+  // the half-vector constraint, tests/test_host_shifts_gpu.py) than the one stated here (the image construction).  The
+  // boundary record does not carry vertex c - 2: the walk's fixed end is the point at the photon's own distance from the
+  // mirror point along the recorded direction to it, a = m + parentWi |m - x|.  The new mirror point m' is where the segment
+  // from a to the mirror image of the offset position crosses the plane; lengths unfold: ratio = (|a m| + |m x|) / (|a m'| +
+  // |m' x'|), throughput = prefix * ratio, determinant ratio = ratio^2 (the geometric term of the unfolded path), pdf =
+  // parentPdf * ratio^2, base pdf = parentPdf * edgePdf; fails when an end lies behind the mirror or the path grows 3-fold.
+  static HostShift mirrorManifoldWalk(const V &offsetPos, const V &photonPos, const V &mirrorPos, const V &mirrorN,
+                                      const V &dirToSource, const V &prefixW, F parentPdf, F edgePdf) {
+    HostShift r;
+    const F d2 = (mirrorPos - photonPos).length();
+    const V a = mirrorPos + dirToSource * d2;
+    const F da = dot(mirrorN, a - mirrorPos), dx = dot(mirrorN, offsetPos - mirrorPos);
+    r.ok = da > (F)0 && dx > (F)0;
+    r.throughput = r.wi = V((F)0);
+    r.pdf = r.detRatio = (F)0;
+    r.basePdf = parentPdf * edgePdf;
+    if (!r.ok) return r;
+    const V image = offsetPos - mirrorN * ((F)2 * dx);
+    const V mNew = a + (image - a) * (da / (da + dx));
+    const F d1 = (a - mirrorPos).length(), d1n = (a - mNew).length(), d2n = (mNew - offsetPos).length();
+    const F ratio = (d1 + d2) / (d1n + d2n);
+    r.ok = d1n + d2n < (F)3 * (d1 + d2) && d2n > (F)0;
+    r.wi = d2n > (F)0 ? (mNew - offsetPos) / d2n : V((F)0);
+    r.throughput = prefixW * ratio;
+    r.detRatio = ratio * ratio;
+    r.pdf = parentPdf * ratio * ratio;
+    return r;
+  }
+  // which stand-in answers (test infrastructure, one setting per process): 0 the smooth closed form, 1 the planar mirror
+  static int &manifoldWalkKind() {
+    static int kind = 0;
+    return kind;
+  }
+
   // shiftPhotonManifold, shift_volume_photon.cpp:160-295, from the walk's results on
   bool shiftPhotonManifold(const V &offsetPos, const Photon<F> &ph, const CamRay<F> &shiftGP, const Ray<F> &shiftRay,
                            const MRec<F> &shiftMRec, GradientSamplingResult<F> &result, F pdfBaseRay, F pdfShiftRay,
                            F additionalJacobian) {
-    const HostShift hs = standinManifoldWalk(offsetPos, ph.pos, ph.parentPos, ph.prefixW, ph.parentPdf, ph.edgePdf);
+    const HostShift hs = manifoldWalkKind() == 1
+                             ? mirrorManifoldWalk(offsetPos, ph.pos, ph.parentPos, ph.parentN, ph.parentWi, ph.prefixW, ph.parentPdf, ph.edgePdf)
+                             : standinManifoldWalk(offsetPos, ph.pos, ph.parentPos, ph.prefixW, ph.parentPdf, ph.edgePdf);
     if (!hs.ok) {  // generateShiftPathME / ShiftME failed (:186-203)
       result.weight = 1.0f;
       return false;

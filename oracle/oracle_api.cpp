@@ -404,6 +404,35 @@ int oracle_standin_host_shifts(const gvpm_photon_soa *ph, const gvpm_shift_reque
   return 0;
 }
 
+// the second stand-in (gvpm_oracle.hpp mirrorManifoldWalk: the image construction through the parent's plane) applied to
+// downloaded requests, and the switch that makes the G-BRE gathers that follow answer with it (0: the smooth closed form)
+int oracle_mirror_host_shifts(const gvpm_photon_soa *ph, const gvpm_shift_request *req, uint64_t n, gvpm_host_shift *out) {
+  using R = oracle::VolumeGradientRecord<double>;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint64_t i = req[k].photon;
+    if (i >= ph->n) return 1;
+    auto v3 = [&](const float *a) { return oracle::Vec3<double>(a[3 * i], a[3 * i + 1], a[3 * i + 2]); };
+    const oracle::Vec3<double> off(req[k].offset_pos[0], req[k].offset_pos[1], req[k].offset_pos[2]);
+    const R::HostShift hs = R::mirrorManifoldWalk(off, v3(ph->pos), v3(ph->parent_pos), v3(ph->parent_n), v3(ph->parent_wi),
+                                                  v3(ph->prefix_w), (double)ph->parent_pdf[i], (double)ph->edge_pdf[i]);
+    out[k].ok = hs.ok ? 1u : 0u;
+    for (int c = 0; c < 3; ++c) {
+      out[k].throughput[c] = (float)hs.throughput[c];
+      out[k].wi[c] = (float)hs.wi[c];
+    }
+    out[k].pdf = (float)hs.pdf;
+    out[k].det_ratio = (float)hs.detRatio;
+    out[k].base_pdf = (float)hs.basePdf;
+  }
+  return 0;
+}
+int oracle_set_manifold_walk(int kind) {
+  if (kind != 0 && kind != 1) return GVPM_ERR_INVALID_ARG;
+  oracle::VolumeGradientRecord<double>::manifoldWalkKind() = kind;
+  oracle::VolumeGradientRecord<float>::manifoldWalkKind() = kind;
+  return GVPM_OK;
+}
+
 int oracle_gather_bre_timed(const gvpm_params *p, const gvpm_medium *m, const gvpm_triangles *t,
                             const gvpm_photon_soa *ph, const gvpm_camera_ray *rays, uint64_t nsets, double radius, int it,
                             uint64_t nb_paths, int precision, int use_accel, int threads, double *accum,

@@ -115,6 +115,25 @@ def standin_host_shifts(photons, requests):
     return out
 
 
+def mirror_host_shifts(photons, requests):
+    """The planar-mirror walk (oracle/gvpm_oracle.hpp mirrorManifoldWalk: the image construction) on downloaded requests."""
+    requests = np.ascontiguousarray(requests)
+    out = np.zeros(requests.size, abi.HOST_SHIFT_DTYPE)
+    soa = photons.soa()
+    L = lib()
+    L.oracle_mirror_host_shifts.argtypes = [C.POINTER(abi.PhotonSoA), C.c_void_p, C.c_uint64, C.c_void_p]
+    rc = L.oracle_mirror_host_shifts(C.byref(soa), requests.ctypes.data, requests.size, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("oracle_mirror_host_shifts: a request names a photon outside the map")
+    return out
+
+
+def set_manifold_walk(kind):
+    """Which stand-in the oracle's G-BRE gathers answer manifold shifts with: 0 the smooth closed form, 1 the planar mirror."""
+    if lib().oracle_set_manifold_walk(int(kind)) != 0:
+        raise ValueError(kind)
+
+
 def gather_vpm(params, medium, tris, photons, rays, samples, precision=64, use_accel=True, threads=0, accum=None,
                scale_vol=None, n_vol=None, fast=False, timing=None):
     """One iteration of computeVolumeGradientPhoton (G-VPM) on the CPU.

