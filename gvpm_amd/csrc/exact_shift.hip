@@ -468,8 +468,11 @@ __device__ void exactVPM(const GatherArgs &a, const ExEntry &e, uint32_t &nNull,
 }
 
 // Behind a gather's kernels: its notes become entries (the gather's record and ray buffers are recycled three gathers on).
-// Half a wave per note, a quad per lane; 16 registers: it starts beside the other streams' persistent kernels.
-__global__ __launch_bounds__(256) void capture_notes_kernel(GatherArgs a) {
+// Half a wave per note, a quad per lane; 16 registers.  ONE wave per workgroup: it starts beside the other streams' persistent
+// kernels, and a four-wave workgroup waits there until four slots fall free on one CU at the same moment -- as 64 x 256 threads
+// this kernel took 90-140 us for a few hundred notes between every two evaluations of the C2 pipeline, as 256 x 64: 20-35 us
+// (rocprofv3 kernel trace; the step itself does not move: the other streams fill the gap either way)
+__global__ __launch_bounds__(64) void capture_notes_kernel(GatherArgs a) {
   const uint32_t total = a.exOvfCount[0], n = total < a.exOvfCap ? total : a.exOvfCap;
   const uint32_t part = threadIdx.x & 31u, group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, ngroups = (gridDim.x * blockDim.x) >> 5;
   for (uint32_t e = group; e < n; e += ngroups) {
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256) void capture_notes_kernel(GatherArgs a) {
   }
 }
 void launch_capture_notes(const GatherArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(capture_notes_kernel, dim3(64), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(capture_notes_kernel, dim3(256), dim3(64), 0, s, a);
 }
 
 // One pass over the handle's list

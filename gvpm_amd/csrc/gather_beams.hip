@@ -21,8 +21,9 @@
 // beams are cut.  Traversal, LDS staging, ballot compaction and the work queue are those of the
 // BRE kernel (tile_walk.h).  The evaluation runs in fp32 in a local frame (beams_eval_f32.h), in two
 // phases (base + null shifts, then the queued reconnections); the literal fp64 transcription of the
-// reference with its float intermediates is kept as the on-device cross-check (GVPM_BEAMS_FP64=1) and
-// settles the ownership decisions that fall inside the fp32 error band.
+// reference with its float intermediates is kept as the on-device cross-check (GVPM_BEAMS_FP64=1), settles the ownership
+// decisions that fall inside the fp32 error band and -- round 5 -- is what exact_beams_kernel evaluates, one at a time, the shifts
+// with whose own decisions fp32 cannot be trusted (beamShift1 / beamShift2 note them).
 #include <hip/hip_runtime.h>
 
 #include "beams_eval_f32.h"
@@ -974,7 +975,7 @@ __device__ __forceinline__ float reconnectBeamF(const GatherArgs &a, const BeamF
     float tN, tF;
     if (cylLocal(D0n, nd, sr.d, z0, z1, a.kernelRadius, -dist, INFINITY, tN, tF, &amb)) {
       const float radSqr = a.kernelRadius * a.kernelRadius, distSqr = dot(D0n, D0n);
-      if (nearSq(distSqr, radSqr, dot(q, q))) amb = true;
+      if (nearSq(distSqr, radSqr, distSqr + zq * zq)) amb = true;  // (|q|^2: q = D0n + d zq, D0n perpendicular to d)
       if (distSqr < radSqr)
         shiftKernelPDF = frcp(fmaxf(tF - tN, 0.0001f)) * frcp(fmaxf(2.f * fsqrt(fmaxf(0.f, radSqr - distSqr)), 0.0001f));
     }

@@ -760,7 +760,6 @@ static int buildBeamGrid(gvpm_context *h, float r) {
 // computeVolumeGradientBeams, gvpm.cpp:880-986
 static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal = false) {
   if (!h->haveBeamsMap) return fail(h, GVPM_ERR_STATE, "G-Beams gather needs gvpm_upload_beams");
-  HIP_TRY(h, h->exOvf.reserveExact(h->exOvfCap));  // (the notes of the undecided shifts, exact_beams_kernel)
   h->vpmOrderN = 0;  // (the block-sort buffers below also hold G-VPM's batch order)
   const float r = currentRadius(h);  // beamInitSize, gvpm.cpp:881
   // phases as for G-BRE (gvpm_get_phase_time): 2 = build (sub-beam grid, beam records, camera-beam sort, near lists),
@@ -896,6 +895,15 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
   if (nBlocks)
     HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBlocks,
                             ilog2ceil(h->nsets + 1), h->stream));
+  if (!primal && !h->beamsExact) {
+    // the notes of the shifts the fp32 evaluation cannot decide (exact_beams_kernel, behind it): ~1.2e-3 of the pairs at C3 --
+    // room for a quarter of the pair blocks' count, i.e. for twenty times that rate, and never less than the handle's default
+    const size_t need = std::max<size_t>(h->exOvfCap, (size_t)nBlocks / 4u);
+    if (need > 0xFFFFFF00ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many pair blocks for the note list");
+    HIP_TRY(h, h->exOvf.reserveExact(need));
+    a.exOvf = h->exOvf.p;
+    a.exOvfCap = (uint32_t)need;
+  }
   if (!primal && !h->beamsExact && h->reqCap > 0 && h->cfg.use_manifold) {
     // manifold-typed shifts (shiftBeamME) are recorded for the host instead of failing; the answered terms go straight into
     // the running mean: this iteration's buffer is folded right below, with weight 1 / (nb_paths * it)

@@ -132,7 +132,7 @@ __device__ __forceinline__ int triCombine(int acc, int t) {
   return (acc | t) & GVPM_TRI_AMB;
 }
 // the plain fp32 test (branch-free: the tests of the reference are and-ed; a zero determinant gives inf / NaN, which fail
-// the comparisons like the early return): the G-Beams loops, whose shifts have no exact pass yet
+// the comparisons like the early return): what the literal fp64 cross-check of G-Beams (GVPM_BEAMS_FP64) walks the scene with
 __device__ __forceinline__ bool triHit(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mint, float maxt) {
   const f3 pvec = cross(d, e2);
   const float det = dot(e1, pvec);
@@ -234,7 +234,7 @@ static __device__ __noinline__ int anyHitScene(const float4 *bvh, const float4 *
       } else {
         for (uint32_t i = first; i < first + count; ++i) {
           if (PLAIN) {
-            // (the G-Beams callers: plain fp32 decisions, no exact pass behind them yet)
+            // (PLAIN: the fp64 cross-check of G-Beams -- its shadow segment's direction is the double one, rounded once)
             const float4 t0 = tri4[3 * (size_t)i], t1 = tri4[3 * (size_t)i + 1], t2 = tri4[3 * (size_t)i + 2];
             if (triHit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, mint, maxt)) return GVPM_TRI_HIT;
           } else {

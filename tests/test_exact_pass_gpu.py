@@ -1,5 +1,6 @@
-"""The exact pass (csrc/exact_shift.hip) against the oracle on WHOLE frames.  In a normal gather the pass sees about one shift in
-10^5 -- the ones whose decisions fp32 cannot take -- so the parity suite says little about it.  GVPM_EXACT_ALL=1 widens the
+"""The exact passes (csrc/exact_shift.hip for G-BRE / G-VPM, exact_beams_kernel in csrc/gather_beams.hip) against the oracle on
+WHOLE frames.  In a normal gather a pass sees one shift in 10^4 .. 10^5 -- the ones whose decisions fp32 cannot take -- so the
+parity suite says little about it.  GVPM_EXACT_ALL=1 widens the
 fast kernels' ambiguity band to everything: they add the base terms only, and every one of the four shifts of every pair is
 evaluated by the pass -- the reference's statement in uncontracted fp64.  Bars: counters == the fp64 oracle's exactly, the 27
 accumulators to fp32 accumulation noise (1e-6 of the mean luminance: tighter than the fast path's, whose radiometry is fp32)."""
