@@ -147,7 +147,8 @@ BSDF_DTYPE = np.dtype([("kind", np.int32), ("specular", np.float32, 3), ("expone
                        ("specular_sampling_weight", np.float32), ("distribution", np.int32), ("sample_visible", np.int32),
                        ("eta", np.float32, 3), ("k", np.float32, 3), ("reserved", np.float32, 2)])
 assert BSDF_DTYPE.itemsize == 64
-GVPM_BSDF_PHONG, GVPM_BSDF_ROUGHCONDUCTOR = 1, 2
+GVPM_BSDF_PHONG, GVPM_BSDF_ROUGHCONDUCTOR, GVPM_BSDF_WARD = 1, 2, 3
+GVPM_WARD_WARD, GVPM_WARD_DUER, GVPM_WARD_BALANCED = 0, 1, 2
 GVPM_MICROFACET_BECKMANN, GVPM_MICROFACET_GGX = 0, 1
 
 # compact camera-beam sets (include/gvpm_hip.h, "compact camera-beam sets")

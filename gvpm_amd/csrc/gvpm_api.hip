@@ -354,8 +354,15 @@ int gvpm_upload_bsdfs(gvpm_context *h, const gvpm_bsdf *table, uint32_t n) {
       if (!(b.exponent >= 1e-4f)) return fail(h, GVPM_ERR_INVALID_ARG, "rough conductor: alpha >= 1e-4 (the reference clamps it)");
       if (b.distribution != GVPM_MICROFACET_BECKMANN && b.distribution != GVPM_MICROFACET_GGX)
         return fail(h, GVPM_ERR_UNSUPPORTED, "rough conductor: Beckmann or GGX");
+    } else if (b.kind == GVPM_BSDF_WARD) {
+      // (both components: Ward::sampleComponent picks one below roughness 0.05, ward.cpp:370-389 -- such a surface is outside
+      // the closed set; isotropic by construction: the entry has one alpha)
+      if (!(b.exponent >= 0.05f) || !(b.specular_sampling_weight >= 0.f && b.specular_sampling_weight <= 1.f))
+        return fail(h, GVPM_ERR_INVALID_ARG, "Ward: alpha >= 0.05 (both components) and a sampling weight in [0, 1]");
+      if (b.sample_visible < GVPM_WARD_WARD || b.sample_visible > GVPM_WARD_BALANCED || b.distribution != 0)
+        return fail(h, GVPM_ERR_UNSUPPORTED, "Ward: variant ward / ward-duer / balanced, both components");
     } else {
-      return fail(h, GVPM_ERR_UNSUPPORTED, "bsdf kind outside the device's closed set (Phong, rough conductor)");
+      return fail(h, GVPM_ERR_UNSUPPORTED, "bsdf kind outside the device's closed set (Phong, rough conductor, Ward)");
     }
     rows[4 * i] = make_float4(kindBits, b.specular[0], b.specular[1], b.specular[2]);
     rows[4 * i + 1] = make_float4(b.exponent, b.specular_sampling_weight, distBits, visBits);

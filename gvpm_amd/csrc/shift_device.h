@@ -502,6 +502,26 @@ __device__ __forceinline__ bool glossyParentEval(const GatherArgs &a, float inde
     }
     return true;
   }
+  if (kind == GVPM_BSDF_WARD) {
+    // src/bsdfs/ward.cpp:178-266, isotropic (alphaU == alphaV = b1.x), both components (roughness >= 0.05); H NOT normalised in
+    // eval, as the reference has it; the variant rides in the field the rough conductor uses for its pdf's form
+    const float al = b1.x, w = b1.y, ia2 = frcp(al * al);
+    const int variant = __float_as_int(b1.w);
+    const f3 H = wi + wo;
+    const float HH = dot(H, H), Hz = cosWi + cosWo;
+    const float E = __expf(-(HH - Hz * Hz) * frcp(Hz * Hz) * ia2);
+    const float INV_FOURPI = 0.07957747154594766788f;
+    float factor1;
+    if (variant == GVPM_WARD_WARD) factor1 = INV_FOURPI * ia2 * frsq(cosWi * cosWo);
+    else if (variant == GVPM_WARD_DUER) factor1 = INV_FOURPI * ia2 * frcp(cosWi * cosWo);
+    else factor1 = HH * INV_PI_F * ia2 * frcp(Hz * Hz * Hz * Hz);
+    const float specRef = factor1 * E;
+    f = (mk3(b0.y, b0.z, b0.w) * (specRef > 1e-10f ? specRef : 0.f) + kd * INV_PI_F) * cosWo;
+    // pdf: the normalised half vector; Hn . wi = (1 + wi . wo) / |H|, cos(theta_Hn) = Hz / |H|
+    const float iH = frsq(HH), cH = Hz * iH, wiH = dot(wi, H) * iH;
+    pdf = w * (INV_FOURPI * ia2 * E * frcp(wiH * cH * cH * cH)) + (1.f - w) * (INV_PI_F * cosWo);
+    return true;
+  }
   if (kind == GVPM_BSDF_ROUGHCONDUCTOR) {
     const float4 b2 = a.bsdfs[4 * bi + 2], b3 = a.bsdfs[4 * bi + 3];
     const float alpha = b1.x;

@@ -152,6 +152,10 @@ uint32_t gvpm_synth_bsdfs(const gvpm_synth *s, gvpm_bsdf *out, uint32_t cap) {
           b.kind = GVPM_BSDF_PHONG;
           b.specular_sampling_weight = (float)m.specWeight;
           b.distribution = entries == 2 ? c + 1 : 0;  // (sampled component + 1; 0: both components, include/gvpm_hip.h)
+        } else if (m.kind == gvpm::MAT_WARD) {
+          b.kind = GVPM_BSDF_WARD;
+          b.specular_sampling_weight = (float)m.specWeight;
+          b.sample_visible = m.distribution;  // (the model variant, include/gvpm_hip.h)
         } else {
           b.kind = GVPM_BSDF_ROUGHCONDUCTOR;
           b.distribution = m.distribution;

@@ -181,6 +181,26 @@ bool makeScene(const std::string &fullName, int width, int height, uint32_t seed
     if (rot) addCornellBlocks(s, 0, mBack);
     setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
     setMedium(s, 0.5, 0.5, name == "cbox_phong_hg" ? 0.7 : 0.0);
+  } else if (name == "cbox_ward" || name == "cbox_ward_duer") {
+    // S-cbox with WARD walls (row f4, round 5; src/bsdfs/ward.cpp -- a material of the bathroom scene BASELINE configs[3] is named
+    // after): the floor a balanced Ward lacquer (alpha 0.15, the plugin's default variant), the back wall the original Ward model
+    // (alpha 0.3) -- `_duer`: both with Duer's correction; isotropic, roughness >= 0.05: both components sampled together
+    auto ward = [&](V3 kd, V3 ks, double alpha, int variant) {
+      auto lum = [](V3 c) { return 0.212671 * c.x + 0.715160 * c.y + 0.072169 * c.z; };  // Spectrum::getLuminance, RGB
+      SynthMat m{MAT_WARD, kd, ks, alpha, lum(ks) / (lum(kd) + lum(ks)), 0};
+      m.distribution = variant;
+      m.bsdf = 0;
+      for (const auto &q : s.mats) m.bsdf += bsdfEntries(q.kind, q.exponent);
+      s.mats.push_back(m);
+      return (int)s.mats.size() - 1;
+    };
+    const bool duer = name == "cbox_ward_duer";
+    const int mFloor = ward(V3(0.3, 0.3, 0.3), V3(0.5, 0.5, 0.45), 0.15, duer ? GVPM_WARD_DUER : GVPM_WARD_BALANCED);
+    const int mBack = ward(V3(0.2, 0.25, 0.4), V3(0.3, 0.3, 0.3), 0.3, duer ? GVPM_WARD_DUER : GVPM_WARD_WARD);
+    addBoxRoom(s, mFloor, 0, mBack, 1, 2, 3);
+    if (rot) addCornellBlocks(s, 0, mBack);
+    setLight(s, V3(0, 0.998, 0), 0.5, 0.5, V3(15, 15, 15), 0);
+    setMedium(s, 0.5, 0.5, 0.0);
   } else if (name == "cbox_conductor") {
     // S-cbox with METAL walls (row f4): the floor a rough copper plate (Beckmann, alpha 0.3), the back wall brushed aluminium
     // (GGX, alpha 0.2) -- src/bsdfs/roughconductor.cpp, the table's second kind; eta / k: Mitsuba's Cu and Al at RGB

@@ -22,12 +22,14 @@ namespace gvpm {
 // as diffuse for the reconnection (gvpm_struct.h:66-100) -- the parent type GVPM_PARENT_SURFACE_BSDF of the ABI
 // MAT_ROUGHCONDUCTOR: src/bsdfs/roughconductor.cpp, isotropic Beckmann / GGX, sampled WITHOUT visible normals
 // (sampleVisible = false: MicrofacetDistribution::sampleAll) -- the table's second kind
-enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3, MAT_ROUGHCONDUCTOR = 4 };
+// MAT_WARD (round 5): src/bsdfs/ward.cpp, isotropic (alphaU == alphaV = `exponent`), roughness >= 0.05: both components sampled
+// together; `distribution` holds the model variant (GVPM_WARD_*)
+enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3, MAT_ROUGHCONDUCTOR = 4, MAT_WARD = 5 };
 // table entries of a glossy material: PathVertex::sampleNext picks ONE component of a Phong surface below roughness 0.05
 // (vertex.cpp:160-165, Phong::getRoughness = sqrt(2 / (2 + exponent)), phong.cpp:293-300): an entry per component then
 GVPM_HD inline bool phongOneComponent(double exponent) { return sqrt(2.0 / (2.0 + exponent)) < 0.05; }
 GVPM_HD inline int bsdfEntries(int kind, double exponent) {
-  return kind == MAT_PHONG ? (phongOneComponent(exponent) ? 2 : 1) : (kind == MAT_ROUGHCONDUCTOR ? 1 : 0);
+  return kind == MAT_PHONG ? (phongOneComponent(exponent) ? 2 : 1) : ((kind == MAT_ROUGHCONDUCTOR || kind == MAT_WARD) ? 1 : 0);
 }
 
 struct SynthTri {
@@ -352,6 +354,51 @@ template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &
         }
         cur.pdf = pdfW;
         if (maxc(cur.weight) <= 0) return false;
+      } else if (cur.matKind == MAT_WARD) {
+        // Ward::sample with bRec.component = -1 (ward.cpp:268-327; sampleComponent returns -1 for alpha >= 0.05, :370-376): the
+        // sample picks the lobe; specular: half vector H ~ the Ward lobe (phiH, thetaH as written there), wo = reflect(wi, H);
+        // weight = eval / pdf of the WHOLE BSDF, pdf = the mixture's (:230-266)
+        const SynthMat &pm = sc.mats[cur.mat];
+        const double sw = pm.specWeight, al = pm.exponent, cosWi = dot(cur.n, wi);
+        double sx = a;
+        bool choseSpecular = true;
+        if (sx <= sw) {
+          sx /= sw;
+        } else {
+          sx = (sx - sw) / (1 - sw);
+          choseSpecular = false;
+        }
+        if (choseSpecular) {
+          double phiH = std::atan(std::tan(2.0 * kPi * b));  // (alphaV / alphaU = 1)
+          if (b > 0.5) phiH += kPi;
+          const double cosPhiH = std::cos(phiH), sinPhiH = std::sqrt(std::fmax(0.0, 1.0 - cosPhiH * cosPhiH));
+          const double thetaH = std::atan(std::sqrt(std::fmax(0.0, -std::log(sx) / ((cosPhiH * cosPhiH + sinPhiH * sinPhiH) / (al * al)))));
+          const V3 H = toWorld(cur.n, V3(std::sin(thetaH) * std::cos(phiH), std::sin(thetaH) * std::sin(phiH), std::cos(thetaH)));
+          wo = H * (2.0 * dot(wi, H)) - wi;
+          cur.comp = 0x00008u;  // EGlossyReflection
+        } else {
+          wo = toWorld(cur.n, cosineHemisphere(sx, b));
+          cur.comp = GVPM_BSDF_DIFFUSE_REFLECTION;
+        }
+        const double cosWo = dot(cur.n, wo);
+        if (cosWo <= 0) return false;
+        // eval (H not normalised, as written) and pdf (normalised H)
+        const V3 Hs = wi + wo;
+        const double HH = dot(Hs, Hs), Hz = cosWi + cosWo;
+        const double E = std::exp(-((HH - Hz * Hz) / (al * al)) / (Hz * Hz));
+        double factor1;
+        if (pm.distribution == GVPM_WARD_WARD) factor1 = 1.0 / (4.0 * kPi * al * al * std::sqrt(cosWi * cosWo));
+        else if (pm.distribution == GVPM_WARD_DUER) factor1 = 1.0 / (4.0 * kPi * al * al * cosWi * cosWo);
+        else factor1 = HH / (kPi * al * al * Hz * Hz * Hz * Hz);
+        const double specRef = factor1 * E;
+        const double lenH = std::sqrt(HH), cH = Hz / lenH, wiH = dot(wi, Hs) / lenH;
+        const double specProb = E / (4.0 * kPi * al * al * wiH * cH * cH * cH);
+        const double pdfW = sw * specProb + (1 - sw) * cosWo * kInvPi;
+        if (pdfW == 0) return false;
+        const V3 f = (pm.spec * (specRef > 1e-10 ? specRef : 0.0) + pm.albedo * kInvPi) * cosWo;
+        cur.weight = f * (1.0 / pdfW);
+        cur.pdf = pdfW;
+        if (maxc(cur.weight) <= 0) return false;
       } else if (cur.matKind == MAT_ROUGHCONDUCTOR) {
         // RoughConductor::sample, sampleVisible = false (roughconductor.cpp:321-389 with MicrofacetDistribution::sampleAll,
         // microfacet.h:287-347): half vector m ~ D cos, wo = reflect(wi, m), weight = F D G (wi . m) / (pdf_m cos_i),
@@ -499,7 +546,7 @@ GVPM_HD inline bool vertexIsDiffuse(const SceneView &sc, const LVertex &v) {
     case VT_EMITTER: return true;
     // (Phong: the Beckmann-equivalent roughness sqrt(2 / (2 + exponent)) of its glossy lobe, phong.cpp:293-300, is far
     // above bounceRoughness = 0.001 for every exponent the both-components branch admits)
-    case VT_SURFACE: return v.matKind == MAT_LAMBERT || v.matKind == MAT_PHONG || v.matKind == MAT_ROUGHCONDUCTOR;
+    case VT_SURFACE: return v.matKind == MAT_LAMBERT || v.matKind == MAT_PHONG || v.matKind == MAT_ROUGHCONDUCTOR || v.matKind == MAT_WARD;
     case VT_MEDIUM: return !(sc.medium.g > 0.5);
     default: return false;
   }
@@ -546,7 +593,7 @@ template <class PATH> GVPM_HD inline void fillParent(const SceneView &sc, const 
     ptype = GVPM_PARENT_SURFACE;
     r.parentScat = par.albedo;
     r.parentWi = normalize(path[ip - 1].pos - par.pos);
-    if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
+    if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR || par.matKind == MAT_WARD) {
       ptype = GVPM_PARENT_SURFACE_BSDF;
       r.parentG = (float)(sc.mats[par.mat].bsdf + (par.compSel == 1 ? 1 : 0));  // (the entry of the component the vertex was sampled through)
     }
@@ -625,7 +672,7 @@ template <class RL> GVPM_HD inline void flattenPath(const SceneView &sc, const L
       ptype = GVPM_PARENT_SURFACE;
       r.parentScat = par.albedo;
       r.parentWi = normalize(path[i - 2].pos - par.pos);
-      if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
+      if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR || par.matKind == MAT_WARD) {
         ptype = GVPM_PARENT_SURFACE_BSDF;
         r.parentG = (float)(sc.mats[par.mat].bsdf + (par.compSel == 1 ? 1 : 0));  // (the entry of the component the vertex was sampled through)
         comp = par.comp;  // the sampled lobe's type: EGlossyReflection or EDiffuseReflection (vertex.cpp:178-179)
@@ -726,7 +773,7 @@ template <class RL, bool BEAMS> struct StreamPath {
           ptype = GVPM_PARENT_SURFACE;
           r.parentScat = par.albedo;
           r.parentWi = normalize(path[i - 2].pos - par.pos);
-          if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR) {
+          if (par.matKind == MAT_PHONG || par.matKind == MAT_ROUGHCONDUCTOR || par.matKind == MAT_WARD) {
             ptype = GVPM_PARENT_SURFACE_BSDF;
             r.parentG = (float)(sc.mats[par.mat].bsdf + (par.compSel == 1 ? 1 : 0));  // (the entry of the component the vertex was sampled through)
             comp = par.comp;

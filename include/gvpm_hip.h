@@ -200,16 +200,26 @@ typedef struct gvpm_medium {
  *       pdf(wi, wo)  = D smithG1(wi, H) / (4 cos(theta_i))  [sample_visible]   or   D cos(theta_H) / (4 |wo . H|)  :295-319
  *     both zero unless cos(theta_i), cos(theta_o) > 0; pdfComponent = 1.  `exponent` carries alpha (after the constructor's
  *     clamp to >= 1e-4, microfacet.h:135-136).  Classified like any vertex by its roughness alpha against bounceRoughness.
+ *   GVPM_BSDF_WARD (round 5)  src/bsdfs/ward.cpp with alphaU == alphaV (isotropic: the photon record carries the parent's normal,
+ *     not its tangent frame) and roughness alpha >= 0.05, i.e. BOTH components (Ward::sampleComponent, ward.cpp:370-389): with
+ *     H = wi + wo (NOT normalised, as the reference has it), tan2 = (|H|^2 - H.z^2) / H.z^2, E = exp(-tan2 / alpha^2),
+ *       eval = (specular * factor1 * E [if factor1 * E > 1e-10] + diffuse / pi) cos(theta_o)                            :178-228
+ *         factor1 = 1 / (4 pi alpha^2 sqrt(cos_i cos_o))      variant 0, "ward"
+ *                 = 1 / (4 pi alpha^2 cos_i cos_o)            variant 1, "ward-duer"
+ *                 = |H|^2 / (pi alpha^2 H.z^4)                variant 2, "balanced" (the plugin's default)
+ *       pdf  = w E / (4 pi alpha^2 (Hn . wi) cos^3(theta_Hn)) + (1 - w) cos(theta_o) / pi,  Hn = H / |H|                :230-266
+ *     `exponent` carries alpha, `sample_visible` the variant, `specular_sampling_weight` w; pdfComponent = 1.
  * A surface parent outside the closed set stays what it was: the host flags the photon's shift type 0 (failed shift).   */
-enum { GVPM_BSDF_PHONG = 1, GVPM_BSDF_ROUGHCONDUCTOR = 2 };
+enum { GVPM_BSDF_PHONG = 1, GVPM_BSDF_ROUGHCONDUCTOR = 2, GVPM_BSDF_WARD = 3 };
+enum { GVPM_WARD_WARD = 0, GVPM_WARD_DUER = 1, GVPM_WARD_BALANCED = 2 };
 enum { GVPM_MICROFACET_BECKMANN = 0, GVPM_MICROFACET_GGX = 1 };
 typedef struct gvpm_bsdf {    /* 64 bytes */
   int32_t kind;               /* GVPM_BSDF_*                                                            */
   float specular[3];          /* m_specularReflectance (Phong: after ensureEnergyConservation, phong.cpp:86-91) */
-  float exponent;             /* Phong: m_exponent; rough conductor: alpha                              */
-  float specular_sampling_weight; /* Phong: m_specularSamplingWeight, phong.cpp:93-97                   */
+  float exponent;             /* Phong: m_exponent; rough conductor, Ward: alpha                        */
+  float specular_sampling_weight; /* Phong, Ward: m_specularSamplingWeight, phong.cpp:93-97, ward.cpp:158-162 */
   int32_t distribution;       /* rough conductor: GVPM_MICROFACET_*; Phong: sampled component + 1 (0 = both) */
-  int32_t sample_visible;     /* rough conductor: m_sampleVisible (the pdf's form)                      */
+  int32_t sample_visible;     /* rough conductor: m_sampleVisible (the pdf's form); Ward: GVPM_WARD_* variant */
   float eta[3], k[3];         /* rough conductor: m_eta, m_k (relative to the exterior, roughconductor.cpp:181-191) */
   float reserved[2];
 } gvpm_bsdf;

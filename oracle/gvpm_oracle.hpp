@@ -371,6 +371,52 @@ inline bool phongEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n
   return true;
 }
 
+// Ward::eval / Ward::pdf, src/bsdfs/ward.cpp:178-266, both components (bRec.component = -1: roughness >= 0.05, :370-389),
+// alphaU == alphaV = b.exponent, m_modelVariant = b.sample_visible (EWard 0, EWardDuer 1, EBalanced 2), in the LOCAL frame of
+// the intersection as the reference evaluates them (the values do not depend on the tangents for an isotropic alpha).
+template <typename F>
+inline bool wardEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &n, const Vec3<F> &wiW, const Vec3<F> &woW,
+                        Vec3<F> &f, F &pdf) {
+  typedef Vec3<F> V;
+  const F INV_PI = (F)0.31830988618379067154, M_PI_F = (F)3.14159265358979323846;
+  V s, t;
+  coordinateSystem(n, s, t);
+  const V wi(dot(wiW, s), dot(wiW, t), dot(wiW, n)), wo(dot(woW, s), dot(woW, t), dot(woW, n));
+  f = V((F)0);
+  pdf = 0;
+  if (wi.z <= 0 || wo.z <= 0) return false;
+  const F alphaU = (F)b.exponent, alphaV = (F)b.exponent;
+  V result((F)0);
+  {
+    const V H = wi + wo;
+    F factor1 = 0;
+    switch (b.sample_visible) {
+      case GVPM_WARD_WARD: factor1 = (F)1 / ((F)4 * M_PI_F * alphaU * alphaV * std::sqrt(wi.z * wo.z)); break;
+      case GVPM_WARD_DUER: factor1 = (F)1 / ((F)4 * M_PI_F * alphaU * alphaV * wi.z * wo.z); break;
+      default: factor1 = dot(H, H) / (M_PI_F * alphaU * alphaV * std::pow(H.z, (F)4)); break;
+    }
+    const F factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+    const F exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+    const F specRef = factor1 * std::exp(exponent);
+    if (specRef > (F)1e-10) result += V((F)b.specular[0], (F)b.specular[1], (F)b.specular[2]) * specRef;
+  }
+  result += kd * INV_PI;
+  f = result * wo.z;
+  F specProb;
+  {
+    V H = wi + wo;
+    H = H / H.length();
+    const F factor1 = (F)1 / ((F)4 * M_PI_F * alphaU * alphaV * dot(H, wi) * std::pow(H.z, (F)3));
+    const F factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+    const F exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+    specProb = factor1 * std::exp(exponent);
+  }
+  const F diffuseProb = INV_PI * wo.z;
+  const F w = (F)b.specular_sampling_weight;
+  pdf = w * specProb + (1 - w) * diffuseProb;
+  return true;
+}
+
 // RoughConductor::eval / pdf, src/bsdfs/roughconductor.cpp:257-319 (one component: bRec.component -1 or 0), with
 // MicrofacetDistribution (src/bsdfs/microfacet.h: eval :191-232, pdf :270-275 -> pdfAll = eval * cosTheta / pdfVisible,
 // smithG1 :477-518, G :520-522, projectRoughness = alphaU for an isotropic distribution :541-546) and fresnelConductorExact
@@ -445,6 +491,10 @@ inline bool glossyEvalPdf(const gvpm_bsdf &b, const Vec3<F> &kd, const Vec3<F> &
                           F &pdf) {
   if (b.kind == GVPM_BSDF_PHONG) {
     phongEvalPdf<F>(b, kd, n, wiW, woW, f, pdf);
+    return true;
+  }
+  if (b.kind == GVPM_BSDF_WARD) {
+    wardEvalPdf<F>(b, kd, n, wiW, woW, f, pdf);
     return true;
   }
   if (b.kind == GVPM_BSDF_ROUGHCONDUCTOR) {

@@ -721,6 +721,53 @@ extern "C" int oracle_roughconductor_sample(const gvpm_bsdf *b, const double *n,
   return 1;
 }
 
+// Ward::sample with both components (ward.cpp:268-327, isotropic alpha): the sampled world direction, or 0 (below the horizon)
+extern "C" int oracle_ward_sample(const gvpm_bsdf *b, const double *n, const double *wiW, double u1, double u2, double *woW) {
+  typedef Vec3<double> V;
+  const V nn(n[0], n[1], n[2]);
+  V s, t;
+  coordinateSystem(nn, s, t);
+  const V wiV(wiW[0], wiW[1], wiW[2]);
+  const V wi(dot(wiV, s), dot(wiV, t), dot(wiV, nn));
+  double sx = u1, sy = u2;
+  const double w = b->specular_sampling_weight, alphaU = b->exponent, alphaV = b->exponent;
+  bool choseSpecular = true;
+  if (sx <= w) {
+    sx /= w;
+  } else {
+    sx = (sx - w) / (1 - w);
+    choseSpecular = false;
+  }
+  V wo;
+  if (choseSpecular) {
+    double phiH = std::atan(alphaV / alphaU * std::tan(2.0 * M_PI * sy));
+    if (sy > 0.5) phiH += M_PI;
+    const double cosPhiH = std::cos(phiH), sinPhiH = safe_sqrt(1.0 - cosPhiH * cosPhiH);
+    const double thetaH = std::atan(safe_sqrt(-std::log(sx) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
+    // sphericalDirection(theta, phi), src/libcore/util.cpp
+    const V H(std::sin(thetaH) * std::cos(phiH), std::sin(thetaH) * std::sin(phiH), std::cos(thetaH));
+    wo = H * (2.0 * dot(wi, H)) - wi;
+    if (wo.z <= 0.0) return 0;
+  } else {
+    const double r1 = 2.0 * sx - 1.0, r2 = 2.0 * sy - 1.0;
+    double phi, r;
+    if (r1 == 0 && r2 == 0) {
+      r = phi = 0;
+    } else if (r1 * r1 > r2 * r2) {
+      r = r1;
+      phi = (M_PI / 4.0) * (r2 / r1);
+    } else {
+      r = r2;
+      phi = (M_PI / 2.0) - (r1 / r2) * (M_PI / 4.0);
+    }
+    const double px = r * std::cos(phi), py = r * std::sin(phi);
+    wo = V(px, py, std::sqrt(std::max(0.0, 1.0 - px * px - py * py)));
+  }
+  const V out = s * wo.x + t * wo.y + nn * wo.z;
+  woW[0] = out.x; woW[1] = out.y; woW[2] = out.z;
+  return 1;
+}
+
 extern "C" double oracle_phase_eval(double g, const double *wi, const double *wo) {
   return Medium<double>::phaseEval(g, Vec3<double>(wi[0], wi[1], wi[2]), Vec3<double>(wo[0], wo[1], wo[2]));
 }

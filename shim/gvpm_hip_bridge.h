@@ -23,6 +23,7 @@
 #endif
 
 #include <array>
+#include <cctype>
 #include <map>
 #include <vector>
 
@@ -495,7 +496,11 @@ private:
     const BSDF *bsdf = its.getBSDF();
     const std::string cls = bsdf->getClass()->getName();
     if (bsdf->getType() & BSDF::ESpatiallyVarying) return -1;
-    if (cls != "Phong" && cls != "RoughConductor") return -1;
+    if (cls != "Phong" && cls != "RoughConductor" && cls != "Ward") return -1;
+    /* Ward (src/bsdfs/ward.cpp, round 5): isotropic (no EAnisotropic component: alphaU == alphaV, ward.cpp:144-146) and sampled with
+     * both components (roughness alpha >= 0.05, :370-376); alpha through getRoughness (:360-368), the sampling weight through
+     * pdfComponent(component 0) (:391-402), the model variant from the plugin's own property (default "balanced", :103-113) */
+    if (cls == "Ward" && ((bsdf->getType() & BSDF::EAnisotropic) || par->sampledComponentIndex != -1)) return -1;
     const int component = cls == "Phong" ? (int) par->sampledComponentIndex : -1;
     if (component < -1 || component > 1) return -1;
     const std::pair<const BSDF *, int> key(bsdf, component);
@@ -514,6 +519,15 @@ private:
       bRec.component = 0;
       b.specular_sampling_weight = (float) bsdf->pdfComponent(bRec);
       b.distribution = component + 1;   /* 0: both components; 1: the specular lobe alone; 2: the diffuse one alone */
+    } else if (cls == "Ward") {
+      b.kind = GVPM_BSDF_WARD;
+      b.exponent = (float) bsdf->getRoughness(its, 0);
+      BSDFSamplingRecord bRec(its, its.wi, its.wi, EImportance);
+      bRec.component = 0;
+      b.specular_sampling_weight = (float) bsdf->pdfComponent(bRec);
+      std::string variant = bsdf->getProperties().getString("variant", "balanced");
+      for (char &ch : variant) ch = (char) std::tolower((unsigned char) ch);   /* (boost::to_lower_copy there) */
+      b.sample_visible = variant == "ward" ? GVPM_WARD_WARD : variant == "ward-duer" ? GVPM_WARD_DUER : GVPM_WARD_BALANCED;
     } else {
       const Properties &props = bsdf->getProperties();
       if (!props.hasProperty("eta") || !props.hasProperty("k")) return -1;

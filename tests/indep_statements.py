@@ -216,6 +216,27 @@ def phong_world(kd, index, n, wi, wo):
         diff_on = np.where(phong & (b["distribution"] == 1), 0.0, 1.0)
         f = (ks * ((e + 2.0) / (2.0 * np.pi) * lobe * spec_on)[..., None] + kd / np.pi * diff_on[..., None]) * co[..., None]
         pdf = w * (e + 1.0) / (2.0 * np.pi) * lobe * spec_on + (1.0 - w) * co / np.pi * diff_on
+        # Ward rows (Ward 1992 with Duer's and the energy-balanced variants, as src/bsdfs/ward.cpp implements them; isotropic):
+        # with the half vector h, theta_h its polar angle: lobe = exp(-tan^2(theta_h) / a^2) / (4 pi a^2), specular term
+        # ks lobe / sqrt(ci co) | ks lobe / (ci co) | ks lobe 4 |wi + wo|^2 / (n . (wi + wo))^4, dropped below 1e-10; sampled
+        # density w lobe / ((wi . h) cos^3(theta_h)) + (1 - w) co / pi
+        ward = b["kind"] == abi.GVPM_BSDF_WARD
+        if np.any(ward):
+            al = e  # (the field carries alpha)
+            hs = wi + wo
+            hh = (hs * hs).sum(-1)
+            hz = (n * hs).sum(-1)
+            tan2 = (hh - hz * hz) / (hz * hz)
+            lobe = np.exp(-tan2 / (al * al)) / (4.0 * np.pi * al * al)
+            var = b["sample_visible"]
+            spec = np.where(var == abi.GVPM_WARD_WARD, lobe / np.sqrt(ci * co),
+                            np.where(var == abi.GVPM_WARD_DUER, lobe / (ci * co), lobe * 4.0 * hh / hz ** 4))
+            spec = np.where(spec > 1e-10, spec, 0.0)
+            fw = (ks * spec[..., None] + kd / np.pi) * co[..., None]
+            lh = np.sqrt(hh)
+            pw = w * lobe / (((wi * hs).sum(-1) / lh) * (hz / lh) ** 3) + (1.0 - w) * co / np.pi
+            f = np.where(ward[..., None], fw, f)
+            pdf = np.where(ward, pw, pdf)
         # rough conductor rows
         cond = b["kind"] == abi.GVPM_BSDF_ROUGHCONDUCTOR
         if np.any(cond):

@@ -362,6 +362,17 @@ def bsdf_eval_pdf(bsdf, kd, n, wi, wo):
     return f, float(pdf[0])
 
 
+def ward_sample(bsdf, n, wi, u1, u2):
+    """Ward::sample with both components (ward.cpp:268-327): the sampled world direction, or None (below the horizon)"""
+    L = lib()
+    L.oracle_ward_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    b = np.ascontiguousarray(np.atleast_1d(bsdf), abi.BSDF_DTYPE)
+    n, wi = np.ascontiguousarray(n, np.float64), np.ascontiguousarray(wi, np.float64)
+    wo = np.zeros(3)
+    ok = L.oracle_ward_sample(b.ctypes.data, n.ctypes.data, wi.ctypes.data, float(u1), float(u2), wo.ctypes.data)
+    return wo if ok else None
+
+
 def roughconductor_sample(bsdf, n, wi, u1, u2):
     """RoughConductor::sample without visible-normal sampling: (wo, weight[3], pdf), or None"""
     L = lib()

@@ -37,7 +37,7 @@ def run_bre(c, monkeypatch):
 
 @pytest.mark.parametrize("scene,kw", [("cbox", dict()), ("cbox_hg", dict()), ("cbox_rot", dict(visibility_as_written=0)),
                                       ("fogroom_rot", dict()), ("cbox_phong_rot", dict()), ("cbox_conductor", dict(power_heuristic=1)),
-                                      ("cbox_mirror_rot", dict()), ("cbox", dict(use_mis=0, path_set=0)), ("cbox", dict(use_shift_null=0)),
+                                      ("cbox_mirror_rot", dict()), ("cbox_ward_rot", dict()), ("cbox", dict(use_mis=0, path_set=0)), ("cbox", dict(use_shift_null=0)),
                                       ("cbox_rot", dict(vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0))])
 def test_every_bre_shift_through_the_exact_pass(scene, kw, monkeypatch):
     c = cases.make_case(scene, 40, 36, 30000, 1.6 if scene.endswith("_rot") else 2.5, **kw)
@@ -49,7 +49,7 @@ def test_every_bre_shift_through_the_exact_pass(scene, kw, monkeypatch):
     assert lost == 0 and taken >= st["null_shifts"] + st["diffuse_shifts"] + st["failed_shifts"] > 30000
     lum = ref[..., 0:3].mean()
     # glossy parents: the table's closed forms are evaluated in fp32 by the pass too (values, not decisions)
-    assert l2(acc, ref, lum) < (2e-6 if "phong" not in scene and "conductor" not in scene else 2e-5), l2(acc, ref, lum)
+    assert l2(acc, ref, lum) < (2e-6 if "phong" not in scene and "conductor" not in scene and "ward" not in scene else 2e-5), l2(acc, ref, lum)
 
 
 @pytest.mark.parametrize("scene,kw", [("cbox", dict()), ("cbox_hg", dict(use_mis=0)), ("cbox_rot", dict()), ("fogroom_rot", dict(visibility_as_written=0))])

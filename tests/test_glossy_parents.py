@@ -286,3 +286,105 @@ def test_conductor_sampling_matches_its_pdf_chi_square(distribution):
         chi2 = ((o - e) ** 2 / e).sum()
         pval = 1 - stats.chi2.cdf(chi2, df=e.size - 1)
         assert pval > alpha, (wi, chi2, pval)
+
+
+# ---- Ward (round 5; a material of the bathroom scene BASELINE configs[3] is named after) ------------------------------------
+def test_the_ward_scene_and_its_table():
+    c = cases.make_case("cbox_ward", 20, 16, 20000, 4.0)
+    assert c.bsdfs.size == 2 and (c.bsdfs["kind"] == abi.GVPM_BSDF_WARD).all()
+    assert list(c.bsdfs["sample_visible"]) == [abi.GVPM_WARD_BALANCED, abi.GVPM_WARD_WARD] and (c.bsdfs["exponent"] >= 0.05).all()
+    gl = (c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF
+    assert gl.sum() > 500 and set(np.unique(c.ph.parent_g[gl])) == {0.0, 1.0}
+    assert (((c.ph.flags[gl] >> 2) & 7) == 1).all() and set(np.unique(c.ph.flags[gl] >> 16)) == {0x2, 0x8}
+    d = cases.make_case("cbox_ward_duer", 20, 16, 2000, 4.0)
+    assert (d.bsdfs["sample_visible"] == abi.GVPM_WARD_DUER).all()
+
+
+@pytest.mark.parametrize("scene", ["cbox_ward", "cbox_ward_duer"])
+def test_the_hosts_ward_bounce_is_weight_times_pdf_equals_eval(scene):
+    """as for Phong: flux = prefix * (f cos / pdf) * rr * (Tr / edgePdf) with Ward::sample's weight = eval / pdf (ward.cpp:321-326),
+    against the INDEPENDENT world-space statement; the oracle's local-frame restatement says the same."""
+    c = cases.make_case(scene, 20, 16, 20000, 4.0)
+    I.set_bsdfs(c.bsdfs)
+    gl = np.flatnonzero((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF)[:400]
+    d = c.ph.pos[gl].astype(np.float64) - c.ph.parent_pos[gl]
+    ln = np.linalg.norm(d, axis=1)
+    wo = d / ln[:, None]
+    f, pdf, known = I.phong_world(c.ph.parent_scat[gl].astype(np.float64), c.ph.parent_g[gl].astype(np.int64),
+                                  c.ph.parent_n[gl].astype(np.float64), c.ph.parent_wi[gl].astype(np.float64), wo)
+    assert known.all()
+    assert np.allclose(pdf, c.ph.parent_pdf[gl] * ln * ln, rtol=5e-4)
+    tr = np.exp(-float(c.m.sigma_t[0]) * ln)
+    want = c.ph.prefix_w[gl] * (f / pdf[:, None]) * c.ph.parent_rr[gl][:, None] * (tr / c.ph.edge_pdf[gl])[:, None]
+    assert np.allclose(c.ph.flux[gl], want, rtol=4e-4)
+    for k in range(0, 400, 40):
+        fo, po = O.bsdf_eval_pdf(c.bsdfs[int(c.ph.parent_g[gl][k])], c.ph.parent_scat[gl][k], c.ph.parent_n[gl][k],
+                                 c.ph.parent_wi[gl][k], wo[k])
+        assert np.allclose(fo, f[k], rtol=1e-11, atol=1e-15) and abs(po - pdf[k]) < 1e-11 * pdf[k]
+
+
+@pytest.mark.parametrize("scene", ["cbox_ward", "cbox_ward_duer"])
+def test_ward_bre3d_vpm_and_beams_against_the_numpy_statements(scene):
+    c = cases.make_case(scene, 20, 16, 20000, 4.0)
+    compare(c)
+    cb = make_beam_case(scene, 12, 10, 600, 5.0)
+    assert ((cb.beams.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 30
+    compare_beams(cb)
+    cv = make_vpm_case(scene, 12, 10, 6000, 8.0, 6)
+    ref, rsv, rnv, cnt, _ = O.gather_vpm(cv.p, cv.m, cv.tris, cv.ph, cv.rays, cv.samples, 64, use_accel=True)
+    acc, icnt, mvol = I.vpm_full(cv)
+    for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert icnt[k] == cnt[k], (k, icnt, cnt)
+    lum = ref[..., 0:3].mean()
+    for j in range(9):
+        assert np.abs(acc[..., 3 * j:3 * j + 3] - ref[..., 3 * j:3 * j + 3]).max() / lum < 1e-9, j
+
+
+@pytest.mark.parametrize("variant", [abi.GVPM_WARD_WARD, abi.GVPM_WARD_DUER, abi.GVPM_WARD_BALANCED])
+def test_ward_sampling_matches_its_pdf_chi_square(variant):
+    """src/tests/test_chisquare.cpp (test01_BSDF) for a Ward instance (diffuse 0.2, specular 0.4, alpha 0.2): the histogram of
+    Ward::sample over 10 x 20 (theta, phi) bins against the integral of Ward::pdf (the pdf does not depend on the variant; the
+    sampler neither: the variants differ in eval only -- the test also pins that)."""
+    from scipy import stats
+    b = np.zeros(1, abi.BSDF_DTYPE)
+    b["kind"], b["specular"], b["exponent"], b["sample_visible"] = abi.GVPM_BSDF_WARD, 0.4, 0.2, variant
+    b["specular_sampling_weight"] = 0.4 / 0.6
+    I.set_bsdfs(b)
+    kd = np.full(3, 0.2)
+    n = np.array([0.0, 0.0, 1.0])
+    rng = np.random.default_rng(23)
+    theta_bins, phi_bins, n_wi, n_samples = 10, 20, 6, 30000
+    alpha = 1.0 - (1.0 - 0.01) ** (1.0 / n_wi)
+    for _ in range(n_wi):
+        z = 0.1 + 0.9 * rng.random()
+        ph = 2 * np.pi * rng.random()
+        wi = np.array([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z])
+        wos = [O.ward_sample(b[0], n, wi, *rng.random(2)) for _ in range(n_samples)]
+        lost = sum(w is None for w in wos)
+        wo = np.array([w for w in wos if w is not None])
+        theta = np.arccos(np.clip(wo[:, 2], -1, 1))
+        phi = np.arctan2(wo[:, 1], wo[:, 0]) % (2 * np.pi)
+        obs, _, _ = np.histogram2d(theta, phi, bins=[theta_bins, phi_bins], range=[[0, np.pi], [0, 2 * np.pi]])
+        sub = 16
+        th = (np.arange(theta_bins * sub) + 0.5) * (np.pi / (theta_bins * sub))
+        phs = (np.arange(phi_bins * sub) + 0.5) * (2 * np.pi / (phi_bins * sub))
+        T, Pm = np.meshgrid(th, phs, indexing="ij")
+        dirs = np.stack([np.sin(T) * np.cos(Pm), np.sin(T) * np.sin(Pm), np.cos(T)], -1).reshape(-1, 3)
+        f, pdf, _ = I.phong_world(kd[None, :], np.zeros(len(dirs), np.int64), np.broadcast_to(n, dirs.shape),
+                                  np.broadcast_to(wi, dirs.shape), dirs)
+        for k in (37, 5000, 20011):
+            fo, po = O.bsdf_eval_pdf(b[0], kd, n, wi, dirs[k])
+            assert abs(pdf[k] - po) < 1e-12 + 1e-11 * pdf[k] and np.allclose(fo, f[k], rtol=1e-11, atol=1e-15)
+        pdf = pdf.reshape(theta_bins * sub, phi_bins * sub)
+        cell = np.sin(T) * (np.pi / (theta_bins * sub)) * (2 * np.pi / (phi_bins * sub))
+        exp_ = (pdf * cell).reshape(theta_bins, sub, phi_bins, sub).sum((1, 3)) * n_samples
+        assert abs(exp_.sum() - (n_samples - lost)) < 5 * np.sqrt(n_samples) + 0.01 * n_samples
+        o, e = obs.ravel(), exp_.ravel()
+        order = np.argsort(e)
+        o, e = o[order], e[order]
+        k = int(np.searchsorted(np.cumsum(e), 5.0)) + 1
+        o = np.concatenate([[o[:k].sum()], o[k:]])
+        e = np.concatenate([[e[:k].sum()], e[k:]])
+        chi2 = ((o - e) ** 2 / e).sum()
+        pval = 1 - stats.chi2.cdf(chi2, df=e.size - 1)
+        assert pval > alpha, (wi, chi2, pval)

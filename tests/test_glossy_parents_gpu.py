@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 # (cbox_phong1, round 5: Phong walls below roughness 0.05 -- met one sampled component at a time, two table entries a wall)
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor", "cbox_phong1"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor", "cbox_phong1", "cbox_ward", "cbox_ward_duer"])
 @pytest.mark.parametrize("kw", [dict(), dict(vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0), dict(use_mis=0), dict(power_heuristic=1)])
 def test_bre_matches_fp64_oracle(scene, kw):
     c = cases.make_case(scene, 40, 36, 30000, 2.5, **kw)
@@ -83,7 +83,7 @@ def test_unsupported_table_entries_are_refused():
 
 
 @pytest.mark.parametrize("tech", TECHS)
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor", "cbox_phong1"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor", "cbox_phong1", "cbox_ward", "cbox_ward_duer"])
 def test_beams_match_fp64_oracle(tech, scene):
     c = make_beam_case(scene, 32, 28, 12000, 2.5, technique=tech)
     assert ((c.beams.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 500
@@ -91,14 +91,14 @@ def test_beams_match_fp64_oracle(tech, scene):
     assert st["evaluations"] > 20000 and st["diffuse_shifts"] > 5000
 
 
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_conductor", "cbox_phong1"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_conductor", "cbox_phong1", "cbox_ward"])
 def test_beams_fp64_transcription_agrees(monkeypatch, scene):
     c = make_beam_case(scene, 24, 20, 6000, 3.0)
     monkeypatch.setenv("GVPM_BEAMS_FP64", "1")
     device_beams(c)
 
 
-@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor", "cbox_phong1"])
+@pytest.mark.parametrize("scene", ["cbox_phong", "cbox_phong_hg", "cbox_conductor", "cbox_phong1", "cbox_ward", "cbox_ward_duer"])
 def test_vpm_matches_fp64_oracle(scene):
     c = make_vpm_case(scene, 32, 28, 40000, 5.0, nb=10)
     assert ((c.ph.flags & 3) == abi.GVPM_PARENT_SURFACE_BSDF).sum() > 1000

@@ -30,7 +30,7 @@ from test_parity_planes_gpu import device_planes
 from test_parity_vpm_gpu import device_vpm
 
 pytestmark = pytest.mark.gpu
-ROT = ["cbox_rot", "cbox_hg_rot", "fogroom_rot", "cbox_phong_rot", "cbox_conductor_rot", "cbox_phong1_rot"]
+ROT = ["cbox_rot", "cbox_hg_rot", "fogroom_rot", "cbox_phong_rot", "cbox_conductor_rot", "cbox_phong1_rot", "cbox_ward_rot"]
 COUNTERS = ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts")
 
 
@@ -90,7 +90,7 @@ def test_flag_sweep(rot_case, kw):
 
 
 @pytest.mark.parametrize("vis", [1, 0])
-@pytest.mark.parametrize("scene", ["cbox_rot", "cbox_hg_rot", "cbox_phong_rot", "fogroom_rot", "cbox_phong1_rot"])
+@pytest.mark.parametrize("scene", ["cbox_rot", "cbox_hg_rot", "cbox_phong_rot", "fogroom_rot", "cbox_phong1_rot", "cbox_ward_rot"])
 def test_vpm(scene, vis):
     # (initialScaleVolume 3.1, not 3.0: at 3.0 one reconnection of pixel (14, 23) has |offsetPos - baseRay(t)|^2 = r^2 (1 - 7.5e-8),
     # the mirror decision of getShiftPos -- and G-VPM's radius is per-pixel fp32 STATE: R * 0.01 * scaleVol differs by 9e-8
@@ -102,7 +102,7 @@ def test_vpm(scene, vis):
 
 
 @pytest.mark.parametrize("tech", TECHS)
-@pytest.mark.parametrize("scene", ["cbox_rot", "cbox_hg_rot", "laser_rot", "cbox_conductor_rot", "cbox_phong1_rot"])
+@pytest.mark.parametrize("scene", ["cbox_rot", "cbox_hg_rot", "laser_rot", "cbox_conductor_rot", "cbox_phong1_rot", "cbox_ward_rot"])
 def test_beams(tech, scene):
     c = make_beam_case(scene, 32, 28, 12000, 1.6, technique=tech)
     # (G-Beams: the shifts' decisions are banded too -- gather_beams.hip beamShift1 / beamShift2 -- and the undecided ones go to
