@@ -15,4 +15,4 @@ cp $T/liboracle.so oracle/liboracle.so; cp $T/libgvpm_host.so gvpm_amd/host/libg
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
   python -m pytest tests/test_oracle.py tests/test_oracle_beams.py tests/test_oracle_planes.py tests/test_oracle_vpm.py \
   tests/test_host.py tests/test_camera_paths.py tests/test_oracle_pins.py tests/test_indep_statements.py \
-  tests/test_indep_lightpaths.py tests/test_glossy_parents.py tests/test_primal_bre.py tests/test_oracle_accel.py -x -q -m "not gpu"
+  tests/test_indep_lightpaths.py tests/test_glossy_parents.py tests/test_mirror_walk.py tests/test_primal_bre.py tests/test_oracle_accel.py -x -q -m "not gpu"
