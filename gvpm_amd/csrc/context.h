@@ -81,9 +81,9 @@ void launch_scale(const float *in, float *out, size_t n, float scale, hipStream_
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream_t stream);
-void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
+void launch_vpm_update(float *scaleVol, float *nVol, float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
                        hipStream_t stream);
-void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream);
+void launch_accumulate(float *accum, float *iter, size_t n, uint32_t *zeroWord, hipStream_t stream);
 hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s);
 void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s);
 void launch_beam_near(float4 *cold, uint32_t n, const float4 *tri4, uint32_t ntri, float r, const uint32_t *extentBits, float2 *clear, bool freeCone,
@@ -322,6 +322,9 @@ struct gvpm_context {
   // (measured at C2: ~25 us of the step; on a stream of its own, ordered by events, the step LOST 6 %)
   DevBuf<uint4> exOvf;
   DevBuf<uint32_t> exOvfCount;
+  // G-VPM leaves its per-iteration buffers zeroed behind it (accumulate_kernel, vpm_update_kernel): the next G-VPM gather then
+  // skips three memsets -- 25 us of launches in a 0.6 ms step at C1.  False whenever something else may have written `iter`.
+  bool iterClean = false;
   DevBuf<unsigned long long> exTotals;
   uint32_t exPayCap = 1u << 20;      // 512 MB, allocated with the first gather that can defer
   uint32_t exOvfCap = 1u << 20;      // 16 MB of notes per gather

@@ -811,6 +811,7 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
     }
     h->beamNearStale = false;
   }
+  h->iterClean = false;  // (this gather leaves `iter` written)
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   HIP_TRY(h, hipEventRecord(evBuild->second, h->stream));
   GatherArgs a;
@@ -996,6 +997,7 @@ static int gatherPlanes(gvpm_context *h, int it, uint64_t nb_paths) {
     if (rc != GVPM_OK) return rc;
     h->beamsDirty = false;
   }
+  h->iterClean = false;
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
   GatherArgs a;
   fillArgs(h, a, 0.f);
@@ -1054,9 +1056,13 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     h->photonsDirty = false;
     h->bs->builtRadius = rmax;
   }
-  HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->maxScaleBits.p, 0, 4, h->stream));
+  // (the previous G-VPM gather zeroed `iter` and `mvol` as it folded them, and zeroes the largest-scale word before its update:
+  // accumulate_kernel / vpm_update_kernel; anything else in between -- another technique, a failed gather -- and they are cleared here)
+  if (!h->iterClean) {
+    HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
+  }
+  h->iterClean = false;
   {
     const int rcx = exactPrepare(h);
     if (rcx != GVPM_OK) return rcx;
@@ -1113,9 +1119,10 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     h->vpmOrderN = nBatches;
   }
   h->vpmLaunches++;
-  launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->stream);
+  launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->maxScaleBits.p, h->stream);
   launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
   HIP_TRY(h, hipGetLastError());
+  h->iterClean = true;
   h->totalEmitted += (double)nb_paths;  // m_totalEmittedVolume, gvpm.cpp:434
   return GVPM_OK;
 }

@@ -701,13 +701,15 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
 }
 
 // SPPM statistics of G-VPM, gvpm.cpp:1191-1195 (per pixel) + the largest scale for the next grid
-__global__ __launch_bounds__(256) void vpm_update_kernel(float *scaleVol, float *nVol, const float *mvol, size_t n,
+// (mvol is handed back zeroed: the next gather adds into it without a memset before it)
+__global__ __launch_bounds__(256) void vpm_update_kernel(float *scaleVol, float *nVol, float *mvol, size_t n,
                                                          float alpha, uint32_t *maxScaleBits) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   float sc = 0.f;
   if (i < n) {
     sc = scaleVol[i];
     const float M = mvol[i], N = nVol[i];
+    mvol[i] = 0.f;
     if (M + N != 0.f) {
       const float ratio = (N + alpha * M) / (N + M);
       sc = sc * cbrtf(ratio);
@@ -721,10 +723,16 @@ __global__ __launch_bounds__(256) void vpm_update_kernel(float *scaleVol, float 
     atomicMax(maxScaleBits, __float_as_uint(sc));
 }
 
-__global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ accum, const float *__restrict__ iter,
-                                                         size_t n) {
+// accum += iter, and iter handed back zeroed; zeroWord: the largest-scale word, cleared between the gather that read it (through
+// the host) and the update behind this kernel that writes it again
+__global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ accum, float *__restrict__ iter, size_t n,
+                                                         uint32_t *zeroWord) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) accum[i] += iter[i];
+  if (i < n) {
+    accum[i] += iter[i];
+    iter[i] = 0.f;
+  }
+  if (i == 0 && zeroWord) *zeroWord = 0u;
 }
 
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream_t stream) {
@@ -745,14 +753,14 @@ void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream
   }
 }
 
-void launch_vpm_update(float *scaleVol, float *nVol, const float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
+void launch_vpm_update(float *scaleVol, float *nVol, float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
                        hipStream_t stream) {
   hipLaunchKernelGGL(vpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scaleVol, nVol, mvol, n,
                      alpha, maxScaleBits);
 }
 
-void launch_accumulate(float *accum, const float *iter, size_t n, hipStream_t stream) {
-  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, accum, iter, n);
+void launch_accumulate(float *accum, float *iter, size_t n, uint32_t *zeroWord, hipStream_t stream) {
+  hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, accum, iter, n, zeroWord);
 }
 
 }  // namespace gvpm

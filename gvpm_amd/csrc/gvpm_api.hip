@@ -258,6 +258,8 @@ int gvpm_reset(gvpm_context *h) {
   h->bundleState = 0;
   h->bundleViolations = 0;
   HIP_TRY(h, hipMemsetAsync(h->iter.p, 0, h->npix * 27 * sizeof(float), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->mvol.p, 0, h->npix * sizeof(float), h->stream));
+  h->iterClean = true;
   for (size_t &u : h->eventsHead) u = 0;
   for (size_t &u : h->eventsCount) u = 0;
   h->useAll = false;
