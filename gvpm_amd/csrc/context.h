@@ -22,7 +22,7 @@ namespace gvpm {
 hipError_t sortPairsU32(SortTemp &tmp, const uint32_t *kIn, uint32_t *kOut, const uint32_t *vIn, uint32_t *vOut,
                         uint32_t n, int endBit, hipStream_t s);
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
-                   hipStream_t s);
+                   hipStream_t s, const uint32_t *word = nullptr, uint32_t *wordOut = nullptr);
 hipError_t reserveScanTemp(SortTemp &tmp, uint32_t n);
 void launch_bundle_fit(const gvpm_camera_ray *rays, uint32_t nsets, int pass, const Grid &g, double *out, hipStream_t s);
 void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, const uint32_t *e, uint32_t *hostOut,
@@ -30,7 +30,7 @@ void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, 
 void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStream_t s);
 uint32_t cell_stripes();
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count, uint32_t *sub,
-                       hipStream_t s);
+                       hipStream_t s, uint32_t *zeroWord = nullptr, uint32_t *oneWord = nullptr);
 void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint32_t *rank, const uint32_t *cellStart,
                     uint32_t n, const gvpm_params &cfg, const float4 *bvh, const float4 *tri4, uint32_t ntri, float dmax,
                     const NearGrid &ng, uint32_t *nearExt, uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,

@@ -245,7 +245,13 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
     HIP_TRY(h, hipMemsetAsync(h->bs->cellSub.p, 0, (size_t)cell_stripes() * g.ncells * sizeof(uint32_t), h->bstream));
     sub = h->bs->cellSub.p;
   }
-  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, sub, h->bstream);
+  // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only); word 0 is the
+  // allocation cursor.  The count kernel starts it at 1 and the lists' overflow counter at 0 (two memsets less per build).
+  HIP_TRY(h, h->bs->overflowCtr.ensure(2));
+  const size_t extWant = std::min<size_t>(std::max<size_t>((size_t)n * 8u + 4096u, h->nearExtWant), 0xFFFFFF00u);
+  HIP_TRY(h, h->bs->nearExt.ensure(extWant));
+  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, sub, h->bstream, h->bs->overflowCtr.p,
+                    h->bs->nearExt.p);
   HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
   if (deferred) {
     // G-BRE: summed-volume table for the planner (sized once for the finest grid, like the cell arrays)
@@ -265,15 +271,8 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
     const int rcg = buildNearGrid(h, dmax * 1.5f);
     if (rcg != GVPM_OK) return rcg;
   }
-  HIP_TRY(h, h->bs->overflowCtr.ensure(2));
-  HIP_TRY(h, hipMemsetAsync(h->bs->overflowCtr.p, 0, 4, h->bstream));
   const bool wantOrig = h->reqCap > 0 && h->cfg.use_manifold;  // (host-shift requests name photons by their place in the upload)
   if (wantOrig) HIP_TRY(h, h->bs->origIdx.ensure((size_t)n + 1));
-  // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only);
-  // word 0 is the allocation cursor
-  const size_t extWant = std::min<size_t>(std::max<size_t>((size_t)n * 8u + 4096u, h->nearExtWant), 0xFFFFFF00u);
-  HIP_TRY(h, h->bs->nearExt.ensure(extWant));
-  HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)h->bs->nearExt.p, 1, 1, h->bstream));
   launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
                  h->nearGrid, h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
                  h->bs->cold.p, h->bs->overflowCtr.p, wantOrig ? h->bs->origIdx.p : nullptr, sub, g.ncells, h->bstream);
@@ -1042,9 +1041,11 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   if (wantBounds) {
     HIP_TRY(h, h->bs->boundsPartial.ensure(1024 * 6));
     HIP_TRY(h, h->bs->bounds6.ensure(32));
-    launch_bounds(h->rawDev.pos, h->nph, h->bs->boundsPartial.p, 1024, h->bs->bounds6.p, h->pinB6, h->stream);
+    launch_bounds(h->rawDev.pos, h->nph, h->bs->boundsPartial.p, 1024, h->bs->bounds6.p, h->pinB6, h->stream, h->maxScaleBits.p,
+                  h->pinCtl);
+  } else {
+    launch_export_u32(h->maxScaleBits.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->stream);
   }
-  launch_export_u32(h->maxScaleBits.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->stream);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const uint32_t bits = h->pinCtl[0];
   float maxScale;

@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float *__restrict__ p
 
 // hostOut (optional): device-visible pinned host memory -- the result lands there without a copy
 // operation in the stream (copy engines and the streams' kernels do not overlap reliably)
-__global__ void bounds_final_kernel(const float *partial, int nblocks, float *out6, float *hostOut) {
+// (word / wordOut, optional: one more 32-bit value for the host -- G-VPM's largest scale rides along instead of a launch of its own)
+__global__ void bounds_final_kernel(const float *partial, int nblocks, float *out6, float *hostOut, const uint32_t *word,
+                                    uint32_t *wordOut) {
   const int lane = threadIdx.x;  // one wave
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int b = lane; b < nblocks; b += 64)
@@ -73,6 +75,7 @@ __global__ void bounds_final_kernel(const float *partial, int nblocks, float *ou
         hostOut[3 + c] = hi[c];
       }
     }
+  if (lane == 0 && word && wordOut) wordOut[0] = word[0];
 }
 
 // counters -> pinned host memory (same reason)
@@ -100,9 +103,16 @@ __global__ void export_u32_kernel(const uint32_t *a, const uint32_t *b, const ui
 #define GVPM_CELL_STRIPES 16
 #endif
 constexpr uint32_t CELL_STRIPES = GVPM_CELL_STRIPES;  // (C4, a rank of 8: 4 / 8 / 16 / 32 stripes: 2.57 / 2.58 / 2.48 / 2.55 ms per step; one counter: 2.75)
+// (zeroWord / oneWord, optional: the near lists' overflow counter and the cursor of their extension lists, which the scatter
+// behind this kernel starts from 0 and 1 -- two memsets less in the build chain)
 __global__ __launch_bounds__(256) void cell_count_kernel(const float *__restrict__ pos, uint32_t n, Grid g,
-                                                         uint32_t *keys, uint32_t *rank, uint32_t *count, uint32_t *sub) {
+                                                         uint32_t *keys, uint32_t *rank, uint32_t *count, uint32_t *sub,
+                                                         uint32_t *zeroWord, uint32_t *oneWord) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    if (zeroWord) *zeroWord = 0u;
+    if (oneWord) *oneWord = 1u;
+  }
   if (i >= n) return;
   uint32_t k;
   if (g.mode == 1) {
@@ -894,11 +904,11 @@ void launch_beam_cold(const gvpm_photon_soa &raw, const float *endN, uint32_t n,
 }
 
 void launch_bounds(const float *pos, uint32_t n, float *partial, int nblocks, float *out6, float *hostOut,
-                   hipStream_t s) {
+                   hipStream_t s, const uint32_t *word, uint32_t *wordOut) {
   // single-wave workgroups: beside the traversal's 22 000 one-wave workgroups a 4-wave workgroup waits for four slots
   // to fall free on ONE CU at the same moment -- this 10 us reduction sat 450 us in front of the next build
   hipLaunchKernelGGL(bounds_kernel, dim3(nblocks), dim3(64), 0, s, pos, n, partial);
-  hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6, hostOut);
+  hipLaunchKernelGGL(bounds_final_kernel, dim3(1), dim3(64), 0, s, partial, nblocks, out6, hostOut, word, wordOut);
 }
 
 void launch_export_u32(const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d, const uint32_t *e,
@@ -979,9 +989,9 @@ void launch_sat(const uint32_t *cellStart, const Grid &g, uint32_t *sat, hipStre
 // sub (optional, bundle cells only): CELL_STRIPES x ncells counters, zeroed by the caller like count[]
 uint32_t cell_stripes() { return CELL_STRIPES; }
 void launch_cell_count(const float *pos, uint32_t n, const Grid &g, uint32_t *keys, uint32_t *rank, uint32_t *count, uint32_t *sub,
-                       hipStream_t s) {
+                       hipStream_t s, uint32_t *zeroWord, uint32_t *oneWord) {
   if (g.mode != 1) sub = nullptr;
-  hipLaunchKernelGGL(cell_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, rank, count, sub);
+  hipLaunchKernelGGL(cell_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, g, keys, rank, count, sub, zeroWord, oneWord);
   if (sub) hipLaunchKernelGGL(cell_stripes_kernel, dim3((g.ncells + 255) / 256), dim3(256), 0, s, sub, g.ncells, count);
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bash scripts/shard_probe.sh OUTDIR [which...]: the single-GPU probes of DESIGN.md section 6 (C2, C4 whole, rank 0's share of the 8-GPU runs)
 out=${1:-gpurun_out/shard}; mkdir -p $out; shift
-which=${*:-c2 c2_weak8_rank0 c4_one_gpu c4_strong8_rank0}
+which=${*:-c2 c2_weak8_rank0 c4_one_gpu c4_strong8_rank0 c4_strong2_rank0 c4_strong4_rank0}
 run() { name=$1; shift
   python bench.py --no-cpu-baseline --no-parity --no-upload-inclusive ${ISO---no-isolated} --steps 8 --warmup 2 "$@" 2> $out/$name.err | grep '^{' > $out/$name.json
   python - $out/$name.json $name <<'PY'
@@ -16,5 +16,7 @@ for w in $which; do
     c2_weak8_rank0) run c2_weak8_rank0 --workload c2 --weak --emulate-gpus 8 ;;
     c4_one_gpu) run c4_one_gpu --workload c4 ;;
     c4_strong8_rank0) run c4_strong8_rank0 --workload c4 --emulate-gpus 8 ;;
+    c4_strong2_rank0) run c4_strong2_rank0 --workload c4 --emulate-gpus 2 ;;
+    c4_strong4_rank0) run c4_strong4_rank0 --workload c4 --emulate-gpus 4 ;;
   esac
 done
