@@ -24,6 +24,14 @@ namespace gvpm {
 // (sampleVisible = false: MicrofacetDistribution::sampleAll) -- the table's second kind
 // MAT_WARD (round 5): src/bsdfs/ward.cpp, isotropic (alphaU == alphaV = `exponent`), roughness >= 0.05: both components sampled
 // together; `distribution` holds the model variant (GVPM_WARD_*)
+// The glossy kinds are sampled by the HOST generators only: the device generator's closed set is Lambertian / index-matched /
+// mirror (gvpm_devgen_create refuses the others), and their fp64 pow / atan / log chains cost the device walk a third of its
+// time in registers alone when they were merely compiled in.
+#ifdef __HIP_DEVICE_COMPILE__
+#define GVPM_SYNTH_GLOSSY 0
+#else
+#define GVPM_SYNTH_GLOSSY 1
+#endif
 enum MatKind { MAT_LAMBERT = 0, MAT_NULL = 1, MAT_MIRROR = 2, MAT_PHONG = 3, MAT_ROUGHCONDUCTOR = 4, MAT_WARD = 5 };
 // table entries of a glossy material: PathVertex::sampleNext picks ONE component of a Phong surface below roughness 0.05
 // (vertex.cpp:160-165, Phong::getRoughness = sqrt(2 / (2 + exponent)), phong.cpp:293-300): an entry per component then
@@ -296,6 +304,7 @@ template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &
         cur.pdf = 1.0;
         solidAngle = false;
         if (maxc(cur.weight) <= 0) return false;
+#if GVPM_SYNTH_GLOSSY
       } else if (cur.matKind == MAT_PHONG) {
         // PathVertex::sampleNext (vertex.cpp:160-173): below roughness 0.05 Phong::sampleComponent (phong.cpp:308-329) picks
         // ONE component first -- and rescales the sample as written there (the specular branch MULTIPLIES by the weight) --,
@@ -432,6 +441,7 @@ template <class PATH> GVPM_HD inline bool walkStep(const SceneView &sc, Philox &
         cur.pdf = pdfM / (4.0 * std::fabs(woM));
         cur.comp = 0x00008u;  // EGlossyReflection
         if (maxc(cur.weight) <= 0 || !(cur.pdf > 0)) return false;
+#endif
       } else {
         V3 local = cosineHemisphere(a, b);
         wo = toWorld(cur.n, local);
