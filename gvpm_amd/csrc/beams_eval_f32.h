@@ -182,4 +182,16 @@ __device__ __forceinline__ f3 shiftPointLocal(f3 dr, f3 aRel, float u, float sig
   return dr * sigma + sv * (u * x) + tv * (u * sn);
 }
 
+// What shiftPointLocal's sine can be off by when the distance ly of `a` to the line is good to dly: sn = sqrt(1 - x^2), x = u / ly,
+// has slope x / sn -- unbounded at x = 1, where the clamp takes over (both sides of it must agree with the reference's double:
+// a clamp that is certain costs nothing).
+__device__ __forceinline__ float shiftSinErr(f3 dr, f3 aRel, float u, float dly) {
+  const f3 av = aRel - dr * dot(aRel, dr);
+  const float ly = fsqrt(dot(av, av));
+  const float xr = fdiv(u, ly), dx = fdiv(dly, ly) * fminf(xr, 2.f);
+  if (xr > 1.f + dx) return 0.f;
+  const float x = fminf(1.f, xr), sn2 = fmaxf(0.f, 1.f - x * x);
+  return sn2 > 4.f * dx ? x * dx * frsq(sn2) : fsqrt(6.f * dx);
+}
+
 }  // namespace gvpm

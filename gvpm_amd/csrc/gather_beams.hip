@@ -1475,10 +1475,23 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
     // (`back` spans the beam from p1 to the kernel: good to ~2.4e-7 (tc + L), its direction to that over its length -- and df2
     // genuinely ranges over [0, (2 r / v)^2], which straddles the reference's 0.001: a band of 1e-5 deferred 0.2 % of the 1D
     // kernel's reconnections, this one 1e-4 of them)
-    const float df2 = dot(df, df), eb = 4e-6f * (tc + L) * ib;
-    if (fabsf(df2 - 0.001f) <= eb * (2.f * fsqrt(fmaxf(df2, 0.001f)) + eb) + 1e-7f) { amb = true; cause = 7u; }
+    // (and shift()'s sine, sqrt(1 - (u / ly)^2), loses everything where the point's distance ly to the ray comes down to u --
+    // the kernel at the beam's very origin: |back| ~ 1e-4 with a direction that is noise, found by tests/stress_beams.py on
+    // S-cbox rotated -- : shiftSinErr is that error, on the base side part of the band, on the shifted side a reason to defer
+    // once it exceeds what the decisions behind it allow for)
+    const float dly = 4e-6f * (tc + L);
+    const float df2 = dot(df, df), eb = (dly + q.u * shiftSinErr(cam.d, aCam, q.u, dly)) * ib;
+    if (!(fabsf(df2 - 0.001f) > eb * (2.f * fsqrt(fmaxf(df2, 0.001f)) + eb) + 1e-7f)) { amb = true; cause = 7u; }
     const bool flip = df2 > 0.001f;
     offsetPos = shiftPointLocal(sr.d, p1rel + sr.D0, q.u, sigS_w, flip) - sr.D0;
+    if (!(q.u * shiftSinErr(sr.d, p1rel + sr.D0, q.u, dly) <= 4.f * dly)) { amb = true; cause = 7u; }
+#ifdef GVPM_DBG_SHIFT2
+    {
+      const f3 aS = p1rel + sr.D0, avS = aS - sr.d * dot(aS, sr.d), avC = aCam - cam.d * dot(aCam, cam.d);
+      printf("1D i %d df2 %.9g eb %g flip %d u %.9g lyCam %.9g lySh %.9g |back|^-1 %g tc %g L %g\n", i, df2, eb, (int)flip, q.u, sqrtf(dot(avC, avC)),
+             sqrtf(dot(avS, avS)), ib, tc, L);
+    }
+#endif
   }
   float w = 1.f;
   f3 sflux = mk3(0.f);
@@ -1526,6 +1539,11 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
       pr.pdfKernelAndDist = q.k.z;
       w = reconnectBeamF(a, b, pr, sh.eye, sh.sMIS, sr, offsetPos, nd, dist, technique, sflux, ok, amb);
     }
+#ifdef GVPM_DBG_SHIFT2  // (probe builds: scripts/dbg/beams_bisect.py narrows a counter mismatch down to one pair first)
+    printf("shift2 i %d withVis %d vis %d amb %d ok %d w %g dist %g nd %g %g %g cosWo %g cosWi %g clear %g %g flip-u %g\n", i, (int)withVis, vis,
+           (int)amb, (int)ok, w, dist, nd.x, nd.y, nd.z, dot(b.parentN, nd), dot(b.parentN, b.parentWi), a.beamClear[beamIdx].x,
+           a.beamClear[beamIdx].y, q.u);
+#endif
     if (amb) {
       deferNote(a, GVPM_EX_KIND_BEAMS, a.setPerm[setBase + bIdx], q.id, (uint32_t)i, cause ? cause : 9u);
       return;
