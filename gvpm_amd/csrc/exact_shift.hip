@@ -399,7 +399,10 @@ __device__ void exactVPM(const GatherArgs &a, const ExEntry &e, uint32_t &nNull,
   const gvpm_camera_ray rb = e.rays[0];
   const RayIn base = loadRayIn(rb), sh = loadRayIn(e.rays[1 + i]);
   const PhotonCold ph = coldOf(e);
-  const double r = (double)e.radius, r2 = r * r, eps = (double)a.cfg.epsilon;
+  // querySize = BBPourcentageCONST * gp.scaleVol (gvpm.cpp:1082,1132) as a double product of the parameters -- not the fast
+  // kernel's fp32 product, which is 6e-8 off it: a null-shift test |y|^2 < r^2 that close to equality is exactly what is sent
+  // here (tests/stress_vpm.py found one in 2 10^8 shifts that the rounded radius decided the other way)
+  const double r = ((double)a.cfg.bsphere_radius * 0.01) * (double)e.extra[0].z, r2 = r * r, eps = (double)a.cfg.epsilon;
   const double rnd = (double)e.extra[0].x, pdfSel = (double)e.extra[0].y;
   const double sigT = (double)a.med.sigmaT[1];
   // sampleDistance(Ray(o, d, Epsilon, len), EDistanceAlwaysValid, rand), homogeneous.cpp:293-430 (currentMediumSampling = 1)

@@ -219,6 +219,9 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
       // photon relative to shiftRay(t) = (photon - baseRay(t)) - (shiftRay(t) - baseRay(t)), the second difference in fp64
       const f3 y = v.rel - tof((tod(sh.o) - tod(v.base.o)) + (tod(sh.d) - tod(v.base.d)) * v.t);
       const float y2 = dot(y, y);
+#ifdef GVPM_DBG_SHIFT2
+      printf("vpm phase 1: shift %d tf %.9g sh.len %.9g y2 %.9g r2 %.9g |rel| %.9g t %.12g\n", i, v.tf, sh.len, y2, v.r2, sqrtf(dot(v.rel, v.rel)), v.t);
+#endif
       if (a.cfg.use_shift_null && !(HS && GVPM_PF_SHIFT_TYPE(v.ph.bits) == 3u) && fabsf(y2 - v.r2) <= 4e-6f * v.r2) {
         qMask |= 0x11u << i;
         continue;
@@ -292,6 +295,9 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
   uint32_t ambVis = 0u;
   const float w = shiftDiffuse<FULLVIS>(a, v.ph, v.ph.bits, dProjU, sh, v.base, v.edge, mk3(v.trS), v.pdfBase, pdfShift, sflux, ok, nullptr,
                                         -1.f, &ambVis);
+#ifdef GVPM_DBG_SHIFT2
+  printf("vpm phase 2: shift %d ok %d amb %u ambVis %u w %g tf %.9g sh.len %.9g\n", i, (int)ok, amb, ambVis, w, v.tf, sh.len);
+#endif
   if (amb | ambVis) {
     // fp32 cannot decide this shift as the reference does: the exact pass evaluates it (nothing added, nothing counted)
     deferNote(a, GVPM_EX_KIND_VPM, sBase + b, pidx, (uint32_t)i, amb | ambVis);

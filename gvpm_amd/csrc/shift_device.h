@@ -77,8 +77,12 @@ __device__ __forceinline__ int triHit3(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float mi
   const float e0 = s0 + sd * mint, e1p = s0 + sd * maxt;
   const float lo = fminf(e0, e1p), hi = fmaxf(e0, e1p);
   const bool noCross = lo > mE || hi < -mE, cross = lo < -mE && hi > mE;
-  const bool fail = noCross || sA < -mA || s2 < -m2 || sB < -mB || s4 < -m4;
-  const bool pass = cross && aC > mC && sA > mA && s2 > m2 && sB > mB && s4 > m4;
+  // (an EMPTY interval, mint > maxt -- the as-written visibility of a reconnection shorter than Epsilon / ShadowEpsilon: the
+  // reference's mint <= t <= maxt holds for no t.  The ends' sides are symmetric in the two: a plane certainly crossed between
+  // them is then a certain miss -- found by tests/stress_vpm.py, a medium parent 1e-4 from a wall)
+  const bool empty = mint > maxt;
+  const bool fail = noCross || (cross && empty) || sA < -mA || s2 < -m2 || sB < -mB || s4 < -m4;
+  const bool pass = cross && !empty && aC > mC && sA > mA && s2 > m2 && sB > mB && s4 > m4;
   return fail ? GVPM_TRI_MISS : (pass ? GVPM_TRI_HIT : GVPM_TRI_AMB);
 }
 __device__ __forceinline__ int triHit3(const float4 t0, const float4 t1, const float4 t2, f3 o, f3 d, float mint, float maxt, float oAbs1) {
@@ -107,6 +111,7 @@ __device__ __forceinline__ int triHitFine(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float
   const bool sP = eS > mS, sN = eS < -mS, eP = eE > mE, eN = eE < -mE;
   if ((sP && eP) || (sN && eN)) return GVPM_TRI_MISS;
   if (!((sP && eN) || (sN && eP))) return GVPM_TRI_AMB;
+  if (mint > maxt) return GVPM_TRI_MISS;  // (an empty interval whose ends certainly straddle the plane: see triHit3)
   const float isd = frcp(sd);
   const float t = -s0 * isd;
   const f3 P = tv + d * t;
@@ -356,9 +361,10 @@ __device__ __forceinline__ float4 exQuad(const GatherArgs &a, uint32_t set, uint
     const gvpm_vpm_sample sm = a.samples[set];
     set = sm.set;
     const uint32_t pix = a.rays[(size_t)set * 5].pixel;
-    radius = (a.cfg.bsphere_radius * 0.01f) * a.scaleVol[(size_t)(pix >> 16) * a.cfg.width + (pix & 0xFFFFu)];
+    const float scaleVol = a.scaleVol[(size_t)(pix >> 16) * a.cfg.width + (pix & 0xFFFFu)];
+    radius = (a.cfg.bsphere_radius * 0.01f) * scaleVol;
     outScale = 1.f / (float)a.cfg.nb_camera_samples;
-    extra = make_float4(sm.rand, sm.pdf_sel, 0.f, 0.f);
+    extra = make_float4(sm.rand, sm.pdf_sel, scaleVol, 0.f);  // (the pixel's scale itself: the pass forms the radius in double)
   }
   if (part == 0u) return make_float4(__uint_as_float(meta), 0.f, outScale, radius);
   if (part <= GVPM_REC_QUADS) return a.cold[(size_t)recIdx * GVPM_REC_QUADS + (part - 1u)];
@@ -588,6 +594,11 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const bool ownAmb = behind && cosWo > 0.f && cosWo <= __uint_as_float(ph.nl2) + 1.2e-3f;
   const int vis = shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, behind ? 0xFFFFFFFFu : ph.nl2, ph.parentPos, dProj, eps, vmax);
   bool good = vis == GVPM_TRI_MISS;
+#ifdef GVPM_DBG_SHIFT2  // (probe builds, on a single pair: scripts/dbg/vpm_bisect.py)
+  printf("shiftDiffuse vis %d ownAmb %d behind %d cosWo %g lProj %.9g vmax %.9g lists %08x %08x %08x parent %.9g %.9g %.9g dir %.9g %.9g %.9g\n", vis,
+         (int)ownAmb, (int)behind, cosWo, lProj, vmax, ph.nl0, ph.nl1, ph.nl2, ph.parentPos.x, ph.parentPos.y, ph.parentPos.z, dProj.x, dProj.y,
+         dProj.z);
+#endif
   // (the sign / cosine tests below flip within fp32 rounding of a grazing direction)
   if (amb)
     *amb = (((vis & GVPM_TRI_AMB) || ownAmb) ? 16u : 0u) |

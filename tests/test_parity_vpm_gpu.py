@@ -165,3 +165,20 @@ def test_heaviest_first_batch_order_changes_nothing(monkeypatch):
     for k in ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts"):
         assert s1[k] == s0[k], (k, s1, s0)
     assert np.abs(a1 - a0).max() <= 2e-5 * np.abs(a0).max()  # (the order of the atomics)
+
+
+def test_a_reconnection_shorter_than_the_as_written_visibility_interval():
+    """Found by tests/stress_vpm.py (round 5): a medium parent 1e-4 from a wall of S-cbox rotated, its reconnection 0.056 long --
+    the as-written visibility test runs over [Epsilon, 0.056 ShadowEpsilon] = [1e-4, 5.6e-5], an EMPTY interval: no t satisfies
+    the reference's mint <= t <= maxt (skdtree.h:318-320).  The three-state test phrased the interval as "the ends lie on
+    different sides of the plane", which is symmetric in the two, and called the wall between them a certain hit."""
+    c = make_vpm_case("cbox_rot", 36, 30, 30000, 5.0, nb=4, use_shift_null=0)
+    device_vpm(c, iters=2)
+
+
+def test_a_null_shift_test_at_equality_takes_the_double_radius():
+    """Found by tests/stress_vpm.py (round 5): |y|^2 = 0.019781068 against r^2 = 0.0197810698 -- inside the band, so the exact pass
+    decides; it had the fast kernel's fp32 radius (6e-8 off the double product R * 0.01 * scaleVol, gvpm.cpp:1082,1132) and
+    decided the other way.  The note carries the pixel's scale now and the pass forms the product in double."""
+    c = make_vpm_case("cbox_mirror_rot", 36, 30, 30000, 5.0, nb=10)
+    device_vpm(c)
