@@ -143,19 +143,31 @@ struct KRecD {
 __device__ __forceinline__ double kpdf(const KRecD &k) { return k.pdfEdgeFailure * k.pdfKernel; }
 
 // PhotonBeam::rayIntersectInternal1D, pm/beams_struct.h:250-311 (float intermediates as written)
+// UNCONTRACTED (round 5): the statement rounds its double dot products to float and divides by d1.d2 -- a last-bit difference of a
+// double (an FMA where the oracle's compiler has a multiply and an add) moves a float rounding, and 1 / d1.d2 makes that a
+// different v: tests/stress_beams.py found a pair accepted here at v = 2e-5 that the oracle rejects.
+__device__ __forceinline__ double dotU(d3 a, d3 b) {
+#pragma clang fp contract(off)
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ d3 crossU(d3 a, d3 b) {
+#pragma clang fp contract(off)
+  return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
 __device__ __forceinline__ bool rayIntersect1D(const BeamD &b, double radius, const RayD &ray, double tminBeam,
                                                double tmaxBeam, double &u, double &v, double &w, double &sinTheta) {
-  const d3 d1d2c = crossd(ray.d, b.dir);
-  const float sinThetaSqr = (float)dot(d1d2c, d1d2c);
-  const float ad = (float)dot(b.p1 - ray.o, d1d2c);
+#pragma clang fp contract(off)
+  const d3 d1d2c = crossU(ray.d, b.dir);
+  const float sinThetaSqr = (float)dotU(d1d2c, d1d2c);
+  const float ad = (float)dotU(b.p1 - ray.o, d1d2c);
   if ((double)(ad * ad) >= (radius * radius) * (double)sinThetaSqr) return false;
-  const float d1d2 = (float)dot(ray.d, b.dir);
+  const float d1d2 = (float)dotU(ray.d, b.dir);
   const float d1d2Sqr = d1d2 * d1d2;
   const float d1d2SqrMinus1 = d1d2Sqr - 1.0f;
   if (d1d2SqrMinus1 < 1e-5f && d1d2SqrMinus1 > -1e-5f) return false;
-  const float d1O1 = (float)dot(ray.d, ray.o);
-  const float d1O2 = (float)dot(ray.d, b.p1);
-  w = ((double)(d1O1 - d1O2) - (double)d1d2 * (dot(b.dir, ray.o) - dot(b.dir, b.p1))) / (double)d1d2SqrMinus1;
+  const float d1O1 = (float)dotU(ray.d, ray.o);
+  const float d1O2 = (float)dotU(ray.d, b.p1);
+  w = ((double)(d1O1 - d1O2) - (double)d1d2 * (dotU(b.dir, ray.o) - dotU(b.dir, b.p1))) / (double)d1d2SqrMinus1;
   if (w <= ray.mint || w >= ray.maxt) return false;
   v = (w + (double)d1O1 - (double)d1O2) / (double)d1d2;
   if (v <= 0.0 || v >= b.len || isnan(v)) return false;
@@ -664,7 +676,7 @@ static __device__ __noinline__ bool beamKernelExact(f3 p1f, f3 p2f, f3 of, f3 df
   b.p1 = tod(p1f);
   b.p2 = tod(p2f);
   b.dir = b.p2 - b.p1;
-  b.len = sqrt(len2(b.dir));
+  b.len = sqrt(dotU(b.dir, b.dir));  // (uncontracted: the oracle's length and direction to the bit, see rayIntersect1D)
   b.dir = b.dir / b.len;
   const uint32_t nSub = subBeamCount((float)b.len, subLen);
   const float ls = (float)b.len / (float)nSub;

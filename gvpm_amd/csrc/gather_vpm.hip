@@ -596,7 +596,11 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
           const RayReg bo = loadRayV(a, s, 0, (int)owner);
           const d3 qd = tod(bo.o) + tod(bo.d) * s.t[owner];
           const double dx = (double)p.x - qd.x, dy = (double)p.y - qd.y, dz = (double)p.z - qd.z;
-          inside = dx * dx + dy * dy + dz * dz < (double)rad * (double)rad;
+          // (against the DOUBLE product R * 0.01 * scaleVol, gvpm.cpp:1082,1132 -- `rad` is its fp32 rounding, 6e-8 off: at a
+          // distance that close to the radius it decided one pair in 3 10^7 the other way, tests/stress_vpm.py)
+          const uint32_t pw = s.pix[owner];
+          const double rD = ((double)a.cfg.bsphere_radius * 0.01) * (double)a.scaleVol[(size_t)(pw >> 16) * a.cfg.width + (pw & 0xFFFFu)];
+          inside = dx * dx + dy * dy + dz * dz < rD * rD;
         }
         if (inside) {
           const uint32_t bits = __float_as_uint(hp.w);

@@ -8,7 +8,8 @@ from test_oracle_beams import make_beam_case
 import cases, oracle_lib as O
 scene, tech, scale = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
 os.environ["GVPM_BEAMS_FREE_CONE"] = sys.argv[4] if len(sys.argv) > 4 else "1"
-c = make_beam_case(scene, 40, 32, 9000, scale, technique=tech)
+kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[5:] if "=" in a}
+c = make_beam_case(scene, 40, 32, 9000, scale, technique=tech, it=int(os.environ.get("STRESS_IT", "1")), **kw)
 KEYS = ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts")
 
 def run(rays, beams, en, exact_all=False):
@@ -67,5 +68,5 @@ dbg = os.path.join("build", "variants", "libgvpm_hip_dbg2.so")
 if os.path.exists(dbg):
     import subprocess
     sys.stdout.flush()
-    subprocess.run([sys.executable, __file__] + sys.argv[1:5] + ["--pair", str(int(sidx[0])), str(int(idx[0]))],
+    subprocess.run([sys.executable, __file__] + [a for a in sys.argv[1:] if a != "--pair"] + ["--pair", str(int(sidx[0])), str(int(idx[0]))],
                    env=dict(os.environ, GVPM_HIP_LIB=os.path.abspath(dbg)))

@@ -8,7 +8,7 @@ from test_oracle_vpm import make_vpm_case
 import cases, oracle_lib as O
 scene, scale, nb, iters = sys.argv[1], float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[5:] if "=" in a}
-c = make_vpm_case(scene, 36, 30, 30000, scale, nb=nb, **kw)
+c = make_vpm_case(scene, 36, 30, 30000, scale, nb=nb, it=int(os.environ.get("STRESS_IT", "1")), **kw)
 KEYS = ("evaluations", "null_shifts", "diffuse_shifts", "failed_shifts")
 inputs = {1: (c.ph, c.nb, c.rays, c.samples)}
 for it in range(2, iters + 1):

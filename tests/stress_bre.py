@@ -8,13 +8,14 @@ import cases
 from test_parity_gpu import check
 from gvpm_amd import abi
 n = 0
+IT = int(os.environ.get("STRESS_IT", "1"))  # (the iteration the inputs are generated for: other random streams, another radius)
 SCENES = ("cbox", "cbox_hg", "fogroom", "cbox_mirror", "laser", "cbox_phong", "cbox_conductor", "cbox_phong1",
               # general position (round 5): shift counters exact there too (check() asserts them exactly by default)
               "cbox_rot", "fogroom_rot", "cbox_mirror_rot", "cbox_phong1_rot", "cbox_conductor_rot")
 for scene in (sys.argv[1:] or SCENES):
     for kw in (dict(), dict(vol_technique=abi.GVPM_VOL_BRE2D, use_shift_null=0), dict(path_set=0), dict(use_mis=0, max_depth=4)):
         for scale in (1.5, 4.0):
-            c = cases.make_case(scene, 48, 40, 25000, scale, **kw)
+            c = cases.make_case(scene, 48, 40, 25000, scale, it=IT, **kw)
             for world in (1, 2, 8):
                 for rank in ((0,) if world == 1 else (0, world - 1)):
                     rays = c.sc.camera_beams_interleaved(c.it, world, rank) if world > 1 else c.rays

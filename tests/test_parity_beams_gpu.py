@@ -230,3 +230,13 @@ def test_the_1d_shift_with_its_kernel_at_the_beams_origin(monkeypatch):
     monkeypatch.setenv("GVPM_BEAMS_FREE_CONE", "1")
     c = make_beam_case("cbox_rot", 40, 32, 9000, 3.0, technique=abi.GVPM_BEAM_BEAM_1D)
     device_beams(c)
+
+
+def test_the_1d_intersection_is_uncontracted(monkeypatch):
+    """Found by tests/stress_beams.py on iteration-3 inputs (round 5): rayIntersectInternal1D (pm/beams_struct.h:250-311) rounds
+    its double dot products to float and divides by d1.d2; the device's transcription was compiled with FMA contraction, a
+    last-bit difference of a double moved a float rounding and 1 / d1.d2 made it a different v -- a pair 2e-5 from the beam's
+    origin was evaluated that the oracle rejects.  dotU / crossU: the oracle's operations to the bit."""
+    monkeypatch.setenv("GVPM_BEAMS_FREE_CONE", "1")
+    c = make_beam_case("cbox_rot", 40, 32, 9000, 3.0, technique=abi.GVPM_BEAM_BEAM_1D, it=3, path_set=0)
+    device_beams(c)

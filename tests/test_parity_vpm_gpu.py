@@ -182,3 +182,11 @@ def test_a_null_shift_test_at_equality_takes_the_double_radius():
     decided the other way.  The note carries the pixel's scale now and the pass forms the product in double."""
     c = make_vpm_case("cbox_mirror_rot", 36, 30, 30000, 5.0, nb=10)
     device_vpm(c)
+
+
+def test_a_photon_at_the_radius_takes_the_double_radius():
+    """Found by tests/stress_vpm.py on iteration-3 inputs (round 5): the pair test pointDistSquared < distSquared (kdtree.h:722) is
+    settled in fp64 inside its band -- against the fp32 radius squared, 6e-8 off the reference's double product: one pair in
+    3 10^7 went the other way (`evaluations` off by one).  The in-band test forms R * 0.01 * scaleVol in double now."""
+    c = make_vpm_case("cbox_conductor_rot", 36, 30, 30000, 5.0, nb=4, it=3)
+    device_vpm(c, iters=2)
