@@ -1,7 +1,8 @@
 #!/bin/bash
 # bash scripts/round_profiles.sh rNN: everything the round's figures come from, in one GPU call (run it through gpurun):
 # the GPU suite, smoke, the default bench line, the rotated-scene stress, the rocprof summaries of C2 / C1 / C3 / C5 and the
-# single-GPU shard probes.  Outputs under gpurun_out/rNN/; copy gpurun_out/rNN/rNN_* into profiles/ afterwards.
+# single-GPU shard probes.  Outputs under gpurun_out/rNN/.  Afterwards, here: cp gpurun_out/rNN/rNN_* profiles/ ;
+# python scripts/docs/fill.py (DESIGN.md / README.md figures) ; update profiles/rNN_tests.txt (csrc sha, counts).
 tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/$tag
