@@ -240,3 +240,12 @@ def test_the_1d_intersection_is_uncontracted(monkeypatch):
     monkeypatch.setenv("GVPM_BEAMS_FREE_CONE", "1")
     c = make_beam_case("cbox_rot", 40, 32, 9000, 3.0, technique=abi.GVPM_BEAM_BEAM_1D, it=3, path_set=0)
     device_beams(c)
+
+
+def test_the_1d_kernels_float_division_is_correctly_rounded(monkeypatch):
+    """Found by tests/stress_beams.py on iteration-5 inputs (round 5): u = |ad| / sqrt(sin^2) is a FLOAT division in the reference
+    (pm/beams_struct.h:250-311) and the library is built with fast fp32 division; one ulp of u moved shift()'s sine by 8 % on a
+    pair whose kernel sits 7e-5 from the beam's origin and the exact pass flipped where the oracle does not."""
+    monkeypatch.setenv("GVPM_BEAMS_FREE_CONE", "1")
+    c = make_beam_case("cbox_hg_rot", 40, 32, 9000, 3.0, technique=abi.GVPM_BEAM_BEAM_1D, it=5, path_set=0)
+    device_beams(c)
