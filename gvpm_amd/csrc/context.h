@@ -53,17 +53,27 @@ void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, in
                       uint32_t *vals, hipStream_t s);
 void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uint32_t target, uint4 *items,
                      uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal, uint32_t itemCap, hipStream_t stream);
+// units / unitCtl / unitCap: the evaluation's work units (gather_bre.hip, EVAL_UNIT) -- two lists of unitCap entries, their
+// lengths in unitCtl[0..1] (zero on entry); null: the evaluation takes whole items
+uint32_t eval_unit_pairs();
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
-                         uint32_t nwaves, bool persistent, hipStream_t stream);
+                         uint32_t nwaves, bool persistent, hipStream_t stream, uint2 *units = nullptr, uint32_t *unitCtl = nullptr,
+                         uint32_t unitCap = 0);
 void launch_apply_host_shifts_beams(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s);
 void launch_evaluate_primal(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                             const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
                             uint32_t nwaves, hipStream_t stream);
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
-                         uint32_t nwaves, bool persistent, hipStream_t stream);
+                         uint32_t nwaves, bool persistent, hipStream_t stream, const uint2 *units = nullptr,
+                         const uint32_t *unitCtl = nullptr, uint32_t unitCap = 0);
 uint32_t plan_items_capacity(uint32_t nsets, uint32_t ntiles, int beamsPerWave);
+// the G-BRE build (cells, beam sort, summed-volume table, planner, scatter) as one chain of six launches (grid_build.hip)
+void launch_build_chain(ChainArgs c, const GatherArgs &a, const gvpm_photon_soa &raw, int beamsPerWave, uint32_t target, uint4 *items,
+                        uint2 *itemOff, uint32_t itemCap, float dmax, const NearGrid &ng, uint32_t extCap, uint32_t *origIdx,
+                        uint32_t *hostOut, bool initBuckets, hipStream_t s, uint32_t pairCapBlocks = 0xFFFFFFFFu, uint32_t unitCap = 0,
+                        uint32_t unitPairs = 1, bool fullVis = false);
 struct PoissonGraphCache {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -187,13 +197,17 @@ struct BuildSet {
   DevBuf<uint32_t> bKeysA, bKeysB, bValsA, setPerm, tileStart;
   uint32_t ntiles = 0;
   int tileW = 4, tileH = 4;
-  bool scanSized = false;
+  bool scanSized = false, scanSizedChain = false;
+  bool countsClean = false;  // cellCount is all zero (the build chain hands it back so)
+  DevBuf<uint32_t> chainBuckets;  // the build chain's bounds buckets (64 x 6), reset by the chain itself after the first use
+  bool bucketsInit = false;
   DevBuf<uint4> items;
   DevBuf<uint2> itemOff;
   DevBuf<uint2> planBoxes;  // the planner's slab boxes, read by the traversal (GatherArgs::planBoxes)
   DevBuf<uint32_t> queueCtl;   // [0] itemCount, [1] queueHead, [2] queueHead of the evaluation kernel, [3] pair blocks
   // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
   DevBuf<uint32_t> pairs, pairCnt, nearExt;
+  DevBuf<uint2> units;  // the evaluation's work units: two lists (large parts, small parts), written by the traversal
   hipEvent_t traversed = nullptr;  // recorded on the build stream after the traversal kernel
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
@@ -207,7 +221,7 @@ struct BuildSet {
     GVPM_MIRROR(beamCount); GVPM_MIRROR(beamStart); GVPM_MIRROR(boundsPartial); GVPM_MIRROR(bounds6);
     GVPM_MIRROR(bKeysA); GVPM_MIRROR(bKeysB); GVPM_MIRROR(bValsA); GVPM_MIRROR(setPerm); GVPM_MIRROR(tileStart);
     GVPM_MIRROR(items); GVPM_MIRROR(itemOff); GVPM_MIRROR(planBoxes); GVPM_MIRROR(queueCtl); GVPM_MIRROR(pairs); GVPM_MIRROR(pairCnt);
-    GVPM_MIRROR(nearExt);
+    GVPM_MIRROR(nearExt); GVPM_MIRROR(chainBuckets); GVPM_MIRROR(units);
 #undef GVPM_MIRROR
     return e;
   }
@@ -219,7 +233,7 @@ struct BuildSet {
     if (sortTmp.d) (void)hipFree(sortTmp.d);
     sortTmp.d = nullptr;
     sortTmp.bytes = 0;
-    pairs.release(); pairCnt.release(); nearExt.release();
+    pairs.release(); pairCnt.release(); nearExt.release(); chainBuckets.release(); units.release();
     if (lastUse) (void)hipEventDestroy(lastUse);
     if (traversed) (void)hipEventDestroy(traversed);
     lastUse = traversed = nullptr;
@@ -253,6 +267,8 @@ struct gvpm_context {
   uint32_t lastGridCells = 0;
   float bundleDiv = 2.f;  // level-0 cells per tile width (GVPM_BUNDLE_DIV)
   Grid bundleGrid{};
+  bool buildChain = true;         // G-BRE: the build as one chain of six launches (GVPM_BUILD_CHAIN=0: the separate launches)
+  DevBuf<uint32_t> chainCtl;      // its arrival counters
   bool planBoxHandOff = true;     // G-BRE: the traversal reads the planner's slab boxes (GVPM_PLAN_BOXES=0: computes its own)
   bool beamsFreeCone = true;      // G-Beams: reconnections inside their beam's free cone skip the any-hit loop (GVPM_BEAMS_FREE_CONE=0: none do)
   size_t beamPairsInit = (size_t)16 << 20;  // G-Beams: first capacity of the pair list (GVPM_BEAM_PAIRS_INIT; tests shrink it)
@@ -353,6 +369,9 @@ struct gvpm_context {
   // planner's counters and size the grid of step N+1 (photons outside the grid sit in its border cells)
   float cachedB6[6] = {0, 0, 0, 0, 0, 0};
   bool haveCachedBounds = false, boundsPending = false;
+  // G-BRE: the last step's camera beams' bounds (their base rays' segments), which clip the grid (buildGrid; GVPM_CLIP_GRID=0: off)
+  float beamB6[6] = {0, 0, 0, 0, 0, 0};
+  bool haveBeamBounds = false, clipGrid = true;
   float *pinB6 = nullptr;      // pinned host staging: 6 floats + 2 uint32
   uint32_t *pinCtl = nullptr;
   uint32_t vpmOrderN = 0;      // batches the G-VPM order in blockValB was sorted for (0: none)
@@ -435,6 +454,12 @@ struct gvpm_context {
   // the occluders once), the traversal one item per wave (0.57 against 0.78 ms beside the evaluation: the dispatcher
   // slots its workgroups, and the next build's kernels, in as others retire)
   bool persistentEval = true, persistentTrav = false;
+  // G-BRE: traversal and evaluation are queued behind the build BEFORE the host has read the planner's counters, sized for
+  // what the buffers hold; the build's last block checks (grid_build.hip, TailArgs) and the host queues them again when the
+  // guess was wrong (GVPM_OPTIMISTIC=0: always after the host's wait)
+  bool optimistic = true;
+  uint32_t lastItems = 0;  // the planner's item count of the last G-BRE step (the traversal's grid of an optimistic step)
+  bool evalUnits = true;  // G-BRE: the evaluation's queue serves work units, large parts first (GVPM_EVAL_UNITS=0: whole items in order)
   // per item and beam: photon index lists + their lengths
 
   // reconstruction scratch

@@ -196,6 +196,37 @@ struct GatherArgs {
   unsigned long long *stats; // GVPM_STAT_ROWS rows of 8 counters (gvpm_stats order), summed on read
 };
 
+// The G-BRE build chain (grid_build.hip, launch_build_chain): what its first five launches share.
+struct ChainArgs {
+  // photons -> cells
+  const float *pos;
+  uint32_t n;
+  Grid g;
+  uint32_t *keys, *rank;      // per photon: cell key, arrival rank within the cell
+  // ONE counter array and ONE scan for the cells and the beam sets' tile keys: [0, ncells] the cells (entry ncells stays
+  // 0, so starts[ncells] = photons sorted), [beamOff, beamOff + nkeys] the keys.  counts: zero on entry and again on exit.
+  uint32_t *counts, *starts;
+  uint32_t scanLen;           // beamOff + nkeys + 1
+  uint32_t beamOff;           // ncells + 1
+  uint32_t *sub;              // bundle cells: the striped counters (cell_count_kernel), zeroed by the caller
+  uint32_t *buckets;          // 2 x 64 x 6 order-preserving codes: the photons' bounds, the camera beams' (grid_build.hip, ordCode)
+  float *out6, *hostB6;       // the bounds: device {photons 0-5, beams 6-11}, pinned host {photons 0-5, beams 16-21} (optional)
+  // camera-beam sets -> tiles
+  const gvpm_camera_ray *rays;
+  uint32_t nsets;
+  int width, tw, th;
+  uint32_t tileShift, ntiles;
+  uint32_t *bKeys, *bRank, *setPerm, *tileStart;
+  uint32_t *blockSum;         // the scan's block sums
+  uint32_t *ctl;              // 2 x 65 arrival counters (lastBlockArrives), zero on entry and on exit
+  // words the chain initialises for the kernels behind it
+  uint32_t *queueCtl;         // 8 words -> 0
+  uint32_t *overflowCtr;      // -> 0
+  uint32_t *nearExt;          // word 0 (the extension lists' cursor) -> 1
+  uint32_t *sat;
+  uint32_t nPhBlocks, nBeamBlocks;  // (filled by the launcher)
+};
+
 // Counter rows: a workgroup adds into row blockIdx % GVPM_STAT_ROWS.  One shared row would put every workgroup's
 // atomics on one cache line, and atomics on one address retire at ~11 ns each (41 k workgroups of G-VPM: ~1 ms).
 #define GVPM_STAT_ROWS 8192

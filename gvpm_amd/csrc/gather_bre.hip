@@ -570,6 +570,19 @@ constexpr int TRAV_WPB = GVPM_TRAV_WPB;
 #ifndef GVPM_TRAV_MINW
 #define GVPM_TRAV_MINW 4  // (128 VGPRs; 3 -- 147 -- is 2 % slower on the pipelined C2 step, 5 -- 96, 60 spilled -- equal)
 #endif
+// Work units of the evaluation (round 6).  The planner balances the TRAVERSAL (items of equal staged photons); the pairs an
+// item yields vary by more than ten (C2: mean 450, the items in front of the light 4 500+), and the evaluation took one item per
+// wave at a time in index order: with ~7 items a wave the last one decided when a wave ended -- the waves finished anywhere
+// between 0.47 and 1.19 ms of a 1.19 ms kernel (probe build), mean 0.75: a third of the wave-time was the tail.  The
+// traversal now files every item's pairs as parts of at most EVAL_UNIT pairs in two lists -- parts above EVAL_UNIT_SMALL
+// pairs, and the small ones -- and the evaluation's queue serves the large list first: the units that end the kernel are small.
+#ifndef GVPM_EVAL_UNIT
+#define GVPM_EVAL_UNIT 1280
+#endif
+#ifndef GVPM_EVAL_UNIT_SMALL
+#define GVPM_EVAL_UNIT_SMALL 256
+#endif
+constexpr uint32_t EVAL_UNIT = GVPM_EVAL_UNIT, EVAL_UNIT_SMALL = GVPM_EVAL_UNIT_SMALL;
 // the staged photons, one array per component: a lane tests FOUR consecutive photons against its beam, read with four
 // ds_read_b128 issued together, two photons per packed-fp32 instruction
 struct alignas(16) TravLds {
@@ -585,12 +598,14 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
                                                           const uint2 *__restrict__ itemOff,
                                                           const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
                                                           uint32_t *__restrict__ pairs, uint32_t *__restrict__ pairCnt,
-                                                          uint32_t persistent) {
+                                                          uint32_t persistent, uint2 *__restrict__ units, uint32_t *unitCtl,
+                                                          uint32_t unitCap) {
   constexpr int LPB = 64 / B;
   __shared__ TravLds sAll[TRAV_WPB];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (the compiler must see it is wave-uniform)
   TravLds &s = sAll[wv];
   const int lane = threadIdx.x & 63;
+  if (itemCount[7] != 0u) return;  // an optimistic step whose buffers were too small (grid_build.hip, TailArgs): queued again
   const uint32_t nItems = *itemCount;
   const int b = lane % B, sub = lane / B;
   const float r = a.radius;
@@ -608,7 +623,8 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
   for (;;) {
     uint32_t it = blockIdx.x * TRAV_WPB + (uint32_t)wv;
     if (!firstItem) {
-      if (!persistent) break;
+      // (a grid that covers the items -- the usual case of an optimistic step, whose grid is a guess -- asks the queue nothing)
+      if (!persistent || gridDim.x * TRAV_WPB >= nItems) break;
       if (lane == 0) it = gridDim.x * TRAV_WPB + atomicAdd(queueHead, 1u);
       it = __shfl(it, 0, 64);
     }
@@ -839,6 +855,24 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
       }
     }
     if (sub == 0) pairCnt[(size_t)it * B + b] = (uint32_t)b < nb ? min(mine, cap) : 0u;
+    if (units) {
+      // the evaluation's WORK UNITS (round 6): this item's pairs, cut into parts of at most EVAL_UNIT -- see evaluate_bre_kernel
+      uint32_t tot = (sub == 0 && (uint32_t)b < nb) ? min(mine, cap) : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+      tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot);
+      if (tot) {
+        const uint32_t parts = (tot + EVAL_UNIT - 1u) / EVAL_UNIT;
+        const uint32_t cls = (tot + parts - 1u) / parts > EVAL_UNIT_SMALL ? 0u : 1u;
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(&unitCtl[cls], parts);
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        for (uint32_t pp = (uint32_t)lane; pp < parts; pp += 64u) {
+          if (slot + pp < unitCap) units[(size_t)cls * unitCap + slot + pp] = make_uint2(it, pp | (parts << 16));
+          else nOver++;
+        }
+      }
+    }
     nCand += tested * nb;  // (pairs the 16-beam pass tested)
   }
   {
@@ -923,13 +957,15 @@ __global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WP
 void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const uint2 *__restrict__ itemOff,
                              const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
                              const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ pairCnt,
-                             uint32_t persistent) {
+                             uint32_t persistent, const uint2 *__restrict__ units, const uint32_t *__restrict__ unitCtl,
+                             uint32_t unitCap) {
   constexpr int WPB = SegCfg<B>::WPB;
   constexpr int BB = SegCfg<B>::BEAM_BITS;
   using Entry = typename SegCfg<B>::Entry;
   __shared__ SegLds<B> sAll[WPB];
   extern __shared__ float4 sceneTri[];  // the occluders of a small scene (48 bytes each), shared by the waves
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (itemCount[7] != 0u) return;  // (see traverse_bre_kernel)
   SegLds<B> &s = sAll[wv];
   const float4 *ldsTri = nullptr;
   if (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) {
@@ -948,6 +984,9 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
   unsigned long long wLastStart = 0, lastN = 0, lastUk = 0, wLastEnd = 0, tkLast[6] = {0, 0, 0, 0, 0, 0}, suLast[4] = {0, 0, 0, 0};
 #endif
 
+  // (Measured in round 6 and dropped, as round 3 had for whole items: asking the queue for the NEXT entry while the current one
+  // is evaluated -- the returning atomic is a quarter of a unit's set-up -- leaves every wave sitting on a reserved unit when
+  // the queue runs dry: single stream 0.593 -> 0.636 ms, the waves' end times 0.55-1.09 ms instead of 0.58-0.99.)
   bool firstItem = true;
   for (;;) {
     [[maybe_unused]] const unsigned long long tItem = TICK();
@@ -961,6 +1000,16 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
     // (wave-uniform, and SAID so: the item's record, its pair region and everything derived from them then live in scalar
     // registers -- as vector registers they were ten of the values this kernel spills around its hot loop, round 5)
     it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+    uint32_t part = 0u, parts = 1u;
+    if (units) {
+      // entry `it` of the unit queue: the list of large parts, then the small ones (see EVAL_UNIT)
+      const uint32_t c0 = min(unitCtl[0], unitCap), c1 = min(unitCtl[1], unitCap);
+      if (it >= c0 + c1) break;
+      const uint2 u = it < c0 ? units[it] : units[(size_t)unitCap + (it - c0)];
+      it = u.x;
+      part = u.y & 0xFFFFu;
+      parts = u.y >> 16;
+    }
     if (it >= nItems) break;
     const uint4 item = items[it];
     const uint32_t setBase = item.x, nb = item.y & 0xFFu;
@@ -969,7 +1018,11 @@ void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const ui
     const uint32_t incl = wave_scan_incl(cntb, lane);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total == 0) continue;
-    const uint32_t r0 = 0u, n = total;  // (the wave's share of the item's concatenated lists: all of it)
+    // the wave's share [r0, r0 + n) of the item's concatenated lists
+    const uint32_t per = (total + parts - 1u) / parts;
+    const uint32_t r0 = part * per;
+    if (r0 >= total) continue;
+    const uint32_t n = min(per, total - r0);
 #ifdef GVPM_EVAL_TIMING
     wLastStart = wall_clock64();
     lastN = n;
@@ -1406,45 +1459,49 @@ void launch_plan_bre(const GatherArgs &a, int beamsPerWave, uint32_t ntiles, uin
 }
 
 // queueHead must be zero on entry
+uint32_t eval_unit_pairs() { return EVAL_UNIT; }
 void launch_traverse_bre(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, uint32_t *pairs, uint32_t *pairCnt,
-                         uint32_t nwaves, bool persistent, hipStream_t stream) {
+                         uint32_t nwaves, bool persistent, hipStream_t stream, uint2 *units, uint32_t *unitCtl, uint32_t unitCap) {
   if (a.nsets == 0 || nwaves == 0) return;
   const uint32_t persist = persistent ? 1u : 0u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 64: hipLaunchKernelGGL(traverse_bre_kernel<64>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist, units, unitCtl, unitCap); break;
+    case 32: hipLaunchKernelGGL(traverse_bre_kernel<32>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist, units, unitCtl, unitCap); break;
+    default: hipLaunchKernelGGL(traverse_bre_kernel<16>, dim3((nwaves + TRAV_WPB - 1) / TRAV_WPB), dim3(64 * TRAV_WPB), 0, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist, units, unitCtl, unitCap); break;
   }
 }
 
 template <bool FULLVIS, bool PF, bool HS = false>
 static void launchEvaluate(const GatherArgs &a, int beamsPerWave, const uint4 *items, const uint2 *itemOff,
                            const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
-                           uint32_t nwaves, bool persistent, hipStream_t stream) {
+                           uint32_t nwaves, bool persistent, hipStream_t stream, const uint2 *units, const uint32_t *unitCtl,
+                           uint32_t unitCap) {
   const uint32_t persist = persistent ? 1u : 0u;
   const size_t dyn = (!FULLVIS && a.ntri <= EVAL_LDS_TRIS && !(a.cfg.reserved[0] & 16)) ? (size_t)a.ntri * 48u : 0u;
   switch (beamsPerWave) {
-    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<64>::WPB - 1) / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<32>::WPB - 1) / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
-    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<16>::WPB - 1) / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist); break;
+    case 64: hipLaunchKernelGGL((evaluate_bre_kernel<64, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<64>::WPB - 1) / SegCfg<64>::WPB), dim3(64 * SegCfg<64>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist, units, unitCtl, unitCap); break;
+    case 32: hipLaunchKernelGGL((evaluate_bre_kernel<32, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<32>::WPB - 1) / SegCfg<32>::WPB), dim3(64 * SegCfg<32>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist, units, unitCtl, unitCap); break;
+    default: hipLaunchKernelGGL((evaluate_bre_kernel<16, FULLVIS, PF, HS>), dim3((nwaves + SegCfg<16>::WPB - 1) / SegCfg<16>::WPB), dim3(64 * SegCfg<16>::WPB), dyn, stream, a, items, itemOff, itemCount, queueHead, pairs, pairCnt, persist, units, unitCtl, unitCap); break;
   }
 }
 
 // fullVis: shadow rays walk the occluder BVH (intended visibility, > 254 occluders, near-list overflow)
 void launch_evaluate_bre(const GatherArgs &a, int beamsPerWave, bool fullVis, const uint4 *items, const uint2 *itemOff,
                          const uint32_t *itemCount, uint32_t *queueHead, const uint32_t *pairs, const uint32_t *pairCnt,
-                         uint32_t nwaves, bool persistent, hipStream_t stream) {
+                         uint32_t nwaves, bool persistent, hipStream_t stream, const uint2 *units, const uint32_t *unitCtl,
+                         uint32_t unitCap) {
+  if (!persistent) units = nullptr;  // (one item per wave: the grid is the item count)
   if (a.nsets == 0 || nwaves == 0) return;
   // the record prefetch of phase 1 pays when the records (128 bytes each) no longer fit the 256 MB Infinity Cache: measured
   // +5 % on a rank's step at C4 (4 M photons), -1 % at C2 (1 M).  GVPM_RECORD_PREFETCH=0/1 (cfg.reserved[0] bits 5, 6) forces it.
   const bool pf = (a.cfg.reserved[0] & 32) ? false : ((a.cfg.reserved[0] & 64) ? true : (size_t)a.nph * 128u > ((size_t)256 << 20));
 #define GVPM_LAUNCH_EVAL(FV, P) \
-  launchEvaluate<FV, P>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream)
+  launchEvaluate<FV, P>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream, units, unitCtl, unitCap)
   if (a.reqHost) {
     // manifold-typed shifts go to the host's request list (no record prefetch variant of these)
-    if (fullVis) launchEvaluate<true, false, true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream);
-    else launchEvaluate<false, false, true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream);
+    if (fullVis) launchEvaluate<true, false, true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream, units, unitCtl, unitCap);
+    else launchEvaluate<false, false, true>(a, beamsPerWave, items, itemOff, itemCount, queueHead, pairs, pairCnt, nwaves, persistent, stream, units, unitCtl, unitCap);
   } else if (fullVis) {
     if (pf) GVPM_LAUNCH_EVAL(true, true);
     else GVPM_LAUNCH_EVAL(true, false);

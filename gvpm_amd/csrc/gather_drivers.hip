@@ -14,6 +14,27 @@ static int ilog2ceil(uint32_t v) {
   return b;
 }
 
+// G-BRE's build as one chain of launches (grid_build.hip, launch_build_chain): buildGrid / sortBeams then only size the
+// buffers and the grid and leave here what the chain's launcher needs.
+struct ChainPrep {
+  bool on = false;
+  float dmax = 0.f;
+  bool wantOrig = false;
+  uint32_t *sub = nullptr;
+  uint32_t nkeys = 0, tileShift = 0;  // the beam sort's key space (sortBeams)
+  int tw = 4, th = 4;
+};
+// tile shape and key space of the beam sort for `beamsPerWave` sets per wave
+static void beamTiling(const gvpm_context *h, int beamsPerWave, int &tw, int &th, uint32_t &ntiles, int &tileShift) {
+  tw = 8;
+  th = 4;
+  if (beamsPerWave == 64) th = 8;
+  if (beamsPerWave == 16) tw = 4;
+  const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
+  ntiles = tilesX * tilesY;
+  tileShift = ilog2ceil(tw * th) + 3;
+}
+
 // uniform grid over the photons for kernel radius r.  deferred: use the bounds of the previous
 // photon set when there is one and leave this set's bounds in flight (pinB6) for the caller's sync.
 // The occluder grid of the near-occluder lists (grid_build.hip: near_grid_kernel, nearVisit): count, scan, fill.  Once per
@@ -145,9 +166,12 @@ static Grid bundleCells(const gvpm_context *h, float r, int tileW) {
 }
 
 // knownB6 (optional): the photons' bounds, already on the host (the caller read them back with something else)
-static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force3D = false, const float *knownB6 = nullptr) {
+static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force3D = false, const float *knownB6 = nullptr,
+                     ChainPrep *cp = nullptr) {
   const uint32_t n = h->nph;
   h->boundsPending = false;
+  const bool chain = cp && cp->on && n > 0;
+  if (cp) cp->on = chain;
   if (n == 0) {
     h->bs->grid = Grid{{0, 0, 0}, 1.f, 1.f, {1, 1, 1}, 1};
     HIP_TRY(h, h->bs->cellStart.ensure(2));
@@ -159,11 +183,11 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   HIP_TRY(h, h->bs->bounds6.ensure(32));
   float b6[6];
   if (!h->pinB6) {
-    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   const bool defer = deferred && h->haveCachedBounds;
-  if (!knownB6)
+  if (!knownB6 && !(chain && defer))  // (the chain reduces the bounds in its own first two launches)
     launch_bounds(h->rawDev.pos, n, h->bs->boundsPartial.p, nblocks, h->bs->bounds6.p, defer ? h->pinB6 : nullptr,
                   h->bstream);
   if (knownB6) {
@@ -184,12 +208,38 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
     if (!std::isfinite(b6[c]) || !std::isfinite(b6[3 + c])) return fail(h, GVPM_ERR_INVALID_ARG, "non-finite photon position");
     ext = fmaxf(ext, b6[3 + c] - b6[c]);
   }
+  const float cellScale0 = h->cellScale > 0.f ? h->cellScale : (deferred && n <= 2000000u ? 1.5f : 1.0f);
+  if (deferred && h->clipGrid && h->haveBeamBounds) {
+    // G-BRE (round 6): the grid covers what the camera beams can reach, not what the photons fill.  An open scene's photons
+    // fly far (S-cbox: extents of 2-5 times the box from step to step, 1.5-16 M cells), the beams end on its surfaces: the
+    // cell arrays, their scan and the summed-volume table shrink to the box.  Photons outside sit (clamped) in the border cells,
+    // as photons outside LAST step's bounds always have -- the binning and the footprints clamp alike, so the evaluated set
+    // does not depend on where the grid ends; two cells of margin keep the beams' footprints off those border cells.  The
+    // beams' bounds are the last step's (reduced by its build), like the photons'.
+    float lo[3], hi[3], cell = cellScale0 * r;
+    for (int pass = 0; pass < 2; ++pass) {
+      const float pad = 1.01f * r + 2.f * cell;
+      float e = 0.f;
+      for (int c = 0; c < 3; ++c) {
+        lo[c] = fmaxf(b6[c], h->beamB6[c] - pad);
+        hi[c] = fminf(b6[3 + c], h->beamB6[3 + c] + pad);
+        if (!(lo[c] <= hi[c])) lo[c] = hi[c] = fminf(fmaxf(h->beamB6[c], b6[c]), b6[3 + c]);  // (no photon near the beams)
+        e = fmaxf(e, hi[c] - lo[c]);
+      }
+      cell = fmaxf(cellScale0 * r, e / 384.f);
+      ext = e;
+    }
+    for (int c = 0; c < 3; ++c) {
+      b6[c] = lo[c];
+      b6[3 + c] = hi[c];
+    }
+  }
   Grid g{};
   // cell edge in radii.  G-BRE with maps up to 2 M photons: 1.5 -- the cell arrays (memset, scan, summed-volume table:
   // ~135 of the build's 575 us at C2 with cells of one radius) shrink 3.4x, and there the build is the stage the
   // pipelined step waits for; the traversal tests 1.3x the photons per hit.  Measured at C2: 1.51 -> 1.43-1.445 ms per
   // step.  At C4 (4 M photons) the evaluation is the long stage and the larger cells cost the traversal 1 % of the step.
-  const float cellScale = h->cellScale > 0.f ? h->cellScale : (deferred && n <= 2000000u ? 1.5f : 1.0f);
+  const float cellScale = cellScale0;
   float cell = fmaxf(cellScale * r, ext / 384.f);
   if (!(cell > 0.f)) cell = 1.f;
   g.cell = cell;
@@ -231,13 +281,27 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   // for the finest grid the cell rule allows (386^3 cells, 230 MB each) once -- a regrowth is a hipFree,
   // i.e. a device-wide sync in the middle of the pipeline
   const size_t worstCells = (size_t)386 * 386 * 386 + 2;
-  HIP_TRY(h, h->bs->cellCount.ensure(std::max((size_t)g.ncells + 2, worstCells)));
-  HIP_TRY(h, h->bs->cellStart.ensure(std::max((size_t)g.ncells + 2, worstCells)));
-  if (!h->bs->scanSized) {
-    HIP_TRY(h, reserveScanTemp(h->bs->sortTmp, (uint32_t)worstCells));
-    h->bs->scanSized = true;
+  // (the chain counts and scans the beam sets' tile keys behind the cells, in the same two arrays)
+  const size_t keyRoom = chain ? (size_t)cp->nkeys + 4u : 0u;
+  {
+    const uint32_t *was = h->bs->cellCount.p;
+    HIP_TRY(h, h->bs->cellCount.ensure(std::max((size_t)g.ncells + 2, worstCells) + keyRoom));
+    if (h->bs->cellCount.p != was) h->bs->countsClean = false;
   }
-  HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
+  HIP_TRY(h, h->bs->cellStart.ensure(std::max((size_t)g.ncells + 2, worstCells) + keyRoom));
+  if (!h->bs->scanSized || (chain && !h->bs->scanSizedChain)) {
+    HIP_TRY(h, reserveScanTemp(h->bs->sortTmp, (uint32_t)std::min<size_t>(worstCells + keyRoom, 0x7FFFFFF0u)));
+    h->bs->scanSized = true;
+    h->bs->scanSizedChain = chain;
+  }
+  if (chain) {
+    // the chain hands its counters back zeroed: one memset when the array is new, or was last used by the separate launches
+    if (!h->bs->countsClean) HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, h->bs->cellCount.cap * sizeof(uint32_t), h->bstream));
+    h->bs->countsClean = true;
+  } else {
+    HIP_TRY(h, hipMemsetAsync(h->bs->cellCount.p, 0, ((size_t)g.ncells + 1) * sizeof(uint32_t), h->bstream));
+    h->bs->countsClean = false;
+  }
   // (bundle cells: striped counters, grid_build.hip cell_count_kernel)
   uint32_t *sub = nullptr;
   if (g.mode == 1) {
@@ -250,14 +314,16 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   HIP_TRY(h, h->bs->overflowCtr.ensure(2));
   const size_t extWant = std::min<size_t>(std::max<size_t>((size_t)n * 8u + 4096u, h->nearExtWant), 0xFFFFFF00u);
   HIP_TRY(h, h->bs->nearExt.ensure(extWant));
-  launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, sub, h->bstream, h->bs->overflowCtr.p,
-                    h->bs->nearExt.p);
-  HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
+  if (!chain) {
+    launch_cell_count(h->rawDev.pos, n, g, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellCount.p, sub, h->bstream, h->bs->overflowCtr.p,
+                      h->bs->nearExt.p);
+    HIP_TRY(h, exclusiveSumU32(h->bs->sortTmp, h->bs->cellCount.p, h->bs->cellStart.p, g.ncells + 1, h->bstream));
+  }
   if (deferred) {
     // G-BRE: summed-volume table for the planner (sized once for the finest grid, like the cell arrays)
     const size_t satCells = (size_t)(g.dim[0] + 1) * (g.dim[1] + 1) * (g.dim[2] + 1);
     HIP_TRY(h, h->bs->sat.ensure(std::max(satCells, (size_t)387 * 387 * 387)));
-    launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->bstream);
+    if (!chain) launch_sat(h->bs->cellStart.p, g, h->bs->sat.p, h->bstream);
   }
   // longest possible reconnection segment: diagonal of (occluders U photons), generously padded
   float diag2 = 0.f;
@@ -273,6 +339,13 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   }
   const bool wantOrig = h->reqCap > 0 && h->cfg.use_manifold;  // (host-shift requests name photons by their place in the upload)
   if (wantOrig) HIP_TRY(h, h->bs->origIdx.ensure((size_t)n + 1));
+  if (chain) {
+    cp->dmax = dmax;
+    cp->wantOrig = wantOrig;
+    cp->sub = sub;
+    h->nearOverflow = false;
+    return GVPM_OK;
+  }
   launch_reorder(h->rawDev, h->bs->keysA.p, h->bs->valsA.p, h->bs->cellStart.p, n, h->cfg, h->bvh.p, h->tri4.p, h->ntri, dmax,
                  h->nearGrid, h->bs->nearExt.p, (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), h->bs->hot.p,
                  h->bs->cold.p, h->bs->overflowCtr.p, wantOrig ? h->bs->origIdx.p : nullptr, sub, g.ncells, h->bstream);
@@ -280,7 +353,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   h->nearOverflow = false;
   if (!deferred && h->cfg.visibility_as_written) {
     if (!h->pinB6) {
-      HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+      HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
       h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
     }
     launch_export_u32(h->bs->overflowCtr.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->bstream);
@@ -290,23 +363,22 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   return GVPM_OK;
 }
 
-static int sortBeams(gvpm_context *h, int beamsPerWave = 0) {
+static int sortBeams(gvpm_context *h, int beamsPerWave = 0, const ChainPrep *cp = nullptr) {
   const uint32_t n = h->nsets;
   if (!beamsPerWave) beamsPerWave = h->beamsPerWave;
-  int tw = 8, th = 4;
-  if (beamsPerWave == 64) th = 8;
-  if (beamsPerWave == 16) tw = 4;
-  const uint32_t tilesX = (h->cfg.width + tw - 1) / tw, tilesY = (h->cfg.height + th - 1) / th;
-  h->bs->ntiles = tilesX * tilesY;
+  int tw, th, tileShift;
+  uint32_t ntilesAll;
+  beamTiling(h, beamsPerWave, tw, th, ntilesAll, tileShift);
+  h->bs->ntiles = ntilesAll;
   h->bs->tileW = tw;
   h->bs->tileH = th;
   HIP_TRY(h, h->bs->tileStart.ensure((size_t)h->bs->ntiles + 2));
   HIP_TRY(h, h->bs->bKeysA.ensure(n + 1));
   HIP_TRY(h, h->bs->bValsA.ensure(n + 1));
   HIP_TRY(h, h->bs->setPerm.ensure(n + 1));
+  if (cp && cp->on) return GVPM_OK;  // (counted, scanned and scattered by the build chain)
   if (n) {
     // counting sort by (tile, pixel in tile, edge): count + rank, exclusive scan, scatter
-    const int tileShift = ilog2ceil(tw * th) + 3;
     const uint64_t nkeys = (uint64_t)h->bs->ntiles << tileShift;
     if (nkeys > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "film too large for the beam sort");
     HIP_TRY(h, h->bs->beamCount.ensure(nkeys + 2));
@@ -467,9 +539,99 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   GatherArgs a;
   uint32_t itemCap = 0, blocks = 0, nItems = 0;
   bool force3D = false;
+  const bool prevOverflow = h->nearOverflow;  // (of the last build: what an optimistic step picks its evaluation kernel by)
+  bool chainRan = false;
+  bool queued = false;                        // traversal + evaluation of this step are in their streams already
+
+  // Traversal + evaluation of the built set, for `blocksQ` pair blocks and `nItemsQ` work items.  optimisticQ: queued before the
+  // host has seen the planner's counters -- nothing may be regrown (a regrowth is a device-wide sync), the traversal's grid is a
+  // guess (its waves take what lies beyond it from the queue), and the kernels wait for the build by an event.
+  auto queueGather = [&](uint32_t blocksQ, uint32_t nItemsQ, bool optimisticQ, bool fullVisQ) -> int {
+    int rq = GVPM_OK;
+    if (!optimisticQ) {
+      HIP_TRY(h, h->bs->pairs.ensure((size_t)blocksQ * 64u + 64u));
+      HIP_TRY(h, h->bs->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
+    }
+    rq = nextEvents(h, &evTrav, 1);
+    if (rq == GVPM_OK) rq = nextEvents(h, &evEval, 0);
+    if (rq != GVPM_OK) return rq;
+    // three stages: the traversal has its own stream, so that the build of the NEXT step (which starts on the build
+    // stream as soon as this call returns) overlaps it
+    hipStream_t ts = h->pipeline && h->travStream ? h->streamC : (h->travOnBuild ? h->streamB : h->stream);
+    if (!h->pipeline) ts = h->stream;
+    // the evaluation's work units (gather_bre.hip, EVAL_UNIT): an item yields at most staged x beams pairs, i.e. at most
+    // blocks_i * 64 / unit + 1 parts; their counters are queueCtl[5..6] (zeroed with the queue heads)
+    uint2 *units = nullptr;
+    uint32_t unitCap = 0;
+    if (h->evalUnits && h->persistentEval && !primal) {
+      if (optimisticQ) {
+        unitCap = (uint32_t)std::min<size_t>(h->bs->units.cap / 2u, 0x3FFFFFFFu);
+        units = unitCap ? h->bs->units.p : nullptr;
+      } else {
+        const uint64_t capU = (uint64_t)blocksQ * 64u / eval_unit_pairs() + nItemsQ + 64u;
+        if (capU < 0x3FFFFFFFull) {
+          HIP_TRY(h, h->bs->units.ensure((size_t)capU * 2u));
+          unitCap = (uint32_t)std::min<size_t>(h->bs->units.cap / 2u, 0x3FFFFFFFu);
+          units = h->bs->units.p;
+        }
+      }
+    }
+    if (optimisticQ && ts != h->bstream) HIP_TRY(h, hipStreamWaitEvent(ts, evBuild->second, 0));
+    HIP_TRY(h, hipEventRecord(evTrav->first, ts));
+    launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
+                        h->bs->pairs.p, h->bs->pairCnt.p, h->persistentTrav ? h->nwavesTrav : nItemsQ, h->persistentTrav || optimisticQ, ts,
+                        units, h->bs->queueCtl.p + 5, unitCap);
+    HIP_TRY(h, hipEventRecord(evTrav->second, ts));
+    HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
+    // maps beyond 2 M photons: the evaluation is the stage the pipelined step waits for (its records no longer fit the
+    // Infinity Cache), so it gets its third wave per SIMD; below, the other stages need the room more (measured: +6 % on a
+    // rank's step at C4 with 12 waves per CU, -3 % at C2)
+    // (... when the evaluation is the long stage: a rank that holds an eighth of the frame evaluates for 1.3 ms beside a build of
+    // 1.0 -- with 12 waves per CU the build starves.  C4, rank 0 of N emulated, 8 / 12 waves: N = 2: 7.14 / 6.91 ms per step,
+    // N = 4: 3.94 / 3.93, N = 8: 2.33 / 2.47)
+    const bool smallShare = h->nsets > 0 && (size_t)h->nsets * 6u <= h->npix;
+    const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u && !smallShare)
+                                ? std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS) : h->nwaves;
+    if (!primal && h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
+      // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing
+      HIP_TRY(h, h->reqHost.ensure(h->reqCap));
+      HIP_TRY(h, h->reqCtx.ensure(4 * h->reqCap));
+      HIP_TRY(h, h->reqCount.ensure(2));
+      HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
+      a.reqHost = h->reqHost.p;
+      a.reqCtx = h->reqCtx.p;
+      a.reqCount = h->reqCount.p;
+      a.reqCap = (uint32_t)h->reqCap;
+      a.origIdx = h->bs->origIdx.p;
+      h->reqArgs = a;
+      h->reqOutstanding = true;
+      h->reqBeams = false;
+    }
+    HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
+    if (primal)
+      // the primal beam radiance estimate over the same items and pair lists (gather_bre.hip, evaluate_primal_kernel)
+      launch_evaluate_primal(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 2,
+                             h->bs->pairs.p, h->bs->pairCnt.p, std::max<uint32_t>(1u, std::min<uint32_t>(nItemsQ, h->ncu * 16u)), h->stream);
+    else
+      launch_evaluate_bre(a, h->beamsPerWave, fullVisQ, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
+                          h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItemsQ, h->persistentEval,
+                          h->stream, units, h->bs->queueCtl.p + 5, unitCap);
+    HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
+    // the shifts and pairs the evaluation could not decide in fp32: their records and rays into the handle's list, where they
+    // wait for the exact pass
+    if (!primal) {
+      launch_capture_notes(a, h->stream);
+      rq = exactAfterGather(h);
+      if (rq != GVPM_OK) return rq;
+    }
+    HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
+    return GVPM_OK;
+  };
   // (a second pass only when the planner met a ray outside the bundle the grid was keyed for: rebuilt in 3D)
   for (int attempt = 0;; ++attempt) {
   rebuilt = false;
+  ChainPrep cp;
   if (h->photonsDirty || h->beamsDirty || r != h->bs->builtRadius) {
     // the other set; wait until the kernels that last read it are done
     h->setIdx = (h->setIdx + 1) % (h->pipeline && h->travStream ? 3 : 2);
@@ -477,9 +639,20 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     if (h->bs->used) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
     HIP_TRY(h, hipEventRecord(evBuild->first, h->bstream));
     lap("waitevent");
-    rc = buildGrid(h, r, true, force3D);
+    {
+      // the beam sort's key space rides behind the cells in the chain's counter array: known before the grid is sized
+      int tileShift;
+      uint32_t ntilesAll;
+      beamTiling(h, h->beamsPerWave, cp.tw, cp.th, ntilesAll, tileShift);
+      tileShift -= 3;  // (the chain's keys carry no edge bits: the sets of one pixel keep no order among themselves)
+      const uint64_t nkeys = (uint64_t)ntilesAll << tileShift;
+      cp.on = h->buildChain && h->nph > 0 && h->nsets > 0 && nkeys <= 0x3FFFFFF0ull;
+      cp.nkeys = (uint32_t)nkeys;
+      cp.tileShift = (uint32_t)tileShift;
+    }
+    rc = buildGrid(h, r, true, force3D, nullptr, &cp);
     lap("buildGrid");
-    if (rc == GVPM_OK) rc = sortBeams(h);
+    if (rc == GVPM_OK) rc = sortBeams(h, 0, &cp);
     lap("sortBeams");
     if (rc != GVPM_OK) {
       h->bstream = h->stream;
@@ -520,24 +693,100 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     }
   }
   HIP_TRY(h, h->bs->queueCtl.ensure(8));
-  HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->bstream));
   a.bundleFlag = h->bs->queueCtl.p + 4;
-  launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,
-                  h->bs->queueCtl.p + 3, itemCap, h->bstream);
   // the planner's bound on (photon, beam) pairs sizes the pair buffer (grow only) ...
   // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
   if (!h->pinB6) {
-    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
-  launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, rebuilt ? h->bs->nearExt.p : nullptr,
-                    h->bs->queueCtl.p, h->bs->queueCtl.p + 4, h->pinCtl, h->bstream);
-  HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
+  if (cp.on && rebuilt) {
+    // the whole build -- cells, beam sort, summed-volume table, planner beside the photon scatter -- in six launches
+    if (!h->chainCtl.p) {
+      HIP_TRY(h, h->chainCtl.ensure(192));
+      HIP_TRY(h, hipMemsetAsync(h->chainCtl.p, 0, h->chainCtl.cap * sizeof(uint32_t), h->bstream));
+    }
+    ChainArgs c{};
+    c.pos = h->rawDev.pos;
+    c.n = h->nph;
+    c.g = h->bs->grid;
+    c.keys = h->bs->keysA.p;
+    c.rank = h->bs->valsA.p;
+    c.counts = h->bs->cellCount.p;
+    c.starts = h->bs->cellStart.p;
+    c.beamOff = h->bs->grid.ncells + 1u;
+    c.scanLen = c.beamOff + cp.nkeys + 1u;
+    c.sub = cp.sub;
+    HIP_TRY(h, h->bs->chainBuckets.ensure(768));
+    c.buckets = h->bs->chainBuckets.p;
+    c.out6 = h->bs->bounds6.p;
+    c.hostB6 = h->pinB6;
+    c.rays = h->raysDev;
+    c.nsets = h->nsets;
+    c.width = h->cfg.width;
+    c.tw = cp.tw;
+    c.th = cp.th;
+    c.tileShift = cp.tileShift;
+    c.ntiles = h->bs->ntiles;
+    c.bKeys = h->bs->bKeysA.p;
+    c.bRank = h->bs->bValsA.p;
+    c.setPerm = h->bs->setPerm.p;
+    c.tileStart = h->bs->tileStart.p;
+    c.blockSum = reinterpret_cast<uint32_t *>(h->bs->sortTmp.d);
+    c.ctl = h->chainCtl.p;
+    c.queueCtl = h->bs->queueCtl.p;
+    c.overflowCtr = h->bs->overflowCtr.p;
+    c.nearExt = h->bs->nearExt.p;
+    c.sat = h->bs->sat.p;
+    h->boundsPending = h->haveCachedBounds;  // (the chain's bounds land in pinB6 with the counters)
+    // An OPTIMISTIC step: the pair buffer and the unit lists as the last steps left them (the radius shrinks: what held the
+    // last step holds this one), the traversal's grid from the last item count, the evaluation kernel by the last build's
+    // near lists.  The build's last block checks all of it against what the planner found.
+    const bool optimistic = h->optimistic && h->pipeline && attempt == 0 && !primal && h->persistentEval && h->lastItems > 0 &&
+                            h->bs->pairs.cap >= 128u && h->bs->pairCnt.cap >= (size_t)itemCap * h->beamsPerWave &&
+                            (!h->evalUnits || h->bs->units.cap >= 2u);
+    const bool fullVisOpt = !h->cfg.visibility_as_written || prevOverflow;
+    launch_build_chain(c, a, h->rawDev, h->beamsPerWave, h->planTarget, h->bs->items.p, h->bs->itemOff.p, itemCap, cp.dmax, h->nearGrid,
+                       (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), cp.wantOrig ? h->bs->origIdx.p : nullptr, h->pinCtl,
+                       !h->bs->bucketsInit, h->bstream,
+                       optimistic ? (uint32_t)std::min<size_t>((h->bs->pairs.cap - 64u) / 64u, 0xFFFFFFF0u) : 0xFFFFFFFFu,
+                       optimistic && h->evalUnits ? (uint32_t)std::min<size_t>(h->bs->units.cap / 2u, 0x3FFFFFFFu) : 0u, eval_unit_pairs(),
+                       fullVisOpt);
+    h->bs->bucketsInit = true;
+    chainRan = true;
+    if (optimistic) {
+      HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
+      const uint32_t guess = std::min<uint32_t>(itemCap, h->lastItems + h->lastItems / 8u + 256u);
+      rc = queueGather(0u, guess, true, fullVisOpt);
+      if (rc != GVPM_OK) {
+        h->bstream = h->stream;
+        return rc;
+      }
+      queued = true;
+    }
+  } else {
+    HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p, 0, 8 * sizeof(uint32_t), h->bstream));
+    launch_plan_bre(a, h->beamsPerWave, h->bs->ntiles, h->planTarget, h->bs->items.p, h->bs->queueCtl.p, h->bs->itemOff.p,
+                    h->bs->queueCtl.p + 3, itemCap, h->bstream);
+    launch_export_u32(h->bs->queueCtl.p + 3, rebuilt ? h->bs->overflowCtr.p : nullptr, rebuilt ? h->bs->nearExt.p : nullptr,
+                      h->bs->queueCtl.p, h->bs->queueCtl.p + 4, h->pinCtl, h->bstream);
+  }
+  if (!queued) HIP_TRY(h, hipEventRecord(evBuild->second, h->bstream));
   lap("plan");
   HIP_TRY(h, hipStreamSynchronize(h->bstream));
   lap("syncB");
   blocks = h->pinCtl[0];
   nItems = h->pinCtl[3];
+  if (queued && h->pinCtl[5] != 0u) {
+    // the guess was wrong: both kernels have returned at once (or will); wait for them, then queue them again below, sized
+    if (getenv("GVPM_TRACE_PLAN")) fprintf(stderr, "[plan] optimistic step refused by the build (status %u): queued again\n", h->pinCtl[5]);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->pipeline && h->travStream) HIP_TRY(h, hipStreamSynchronize(h->streamC));
+    HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 1, 0, 2 * sizeof(uint32_t), h->bstream));
+    HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 5, 0, 3 * sizeof(uint32_t), h->bstream));
+    HIP_TRY(h, hipStreamSynchronize(h->bstream));
+    queued = false;
+  }
   if (a.grid.mode == 1 && h->pinCtl[4] != 0u && attempt == 0) {
     // not the bundle the cells were keyed for (another sensor, or later edges of the camera paths among the beams):
     // this step again on the 3D grid; the frame is fitted anew at the next build, a few times
@@ -579,68 +828,19 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
       }
     memcpy(h->cachedB6, h->pinB6, sizeof(h->cachedB6));
   }
-  // the traversal also runs on the build stream (this set's own pair buffer): only the evaluation
-  // kernels of consecutive steps are serialised on the gather stream
-  HIP_TRY(h, h->bs->pairs.ensure((size_t)blocks * 64u + 64u));
-  HIP_TRY(h, h->bs->pairCnt.ensure((size_t)itemCap * h->beamsPerWave));
-  rc = nextEvents(h, &evTrav, 1);
-  if (rc == GVPM_OK) rc = nextEvents(h, &evEval, 0);
-  if (rc != GVPM_OK) {
-    h->bstream = h->stream;
-    return rc;
+  if (rebuilt && chainRan) {
+    // the camera beams' bounds of this step clip the next step's grid
+    bool ok = true;
+    for (int c = 0; c < 6; ++c) ok = ok && std::isfinite(h->pinB6[16 + c]);
+    h->haveBeamBounds = ok;
+    if (ok) memcpy(h->beamB6, h->pinB6 + 16, sizeof(h->beamB6));
   }
-  // three stages: the traversal has its own stream, so that the build of the NEXT step (which starts on the build
-  // stream as soon as this call returns) overlaps it; the build stream is idle here, the host has just synchronised it
-  hipStream_t ts = h->pipeline && h->travStream ? h->streamC : (h->travOnBuild ? h->bstream : h->stream);
-  HIP_TRY(h, hipEventRecord(evTrav->first, ts));
-  launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
-                      h->bs->pairs.p, h->bs->pairCnt.p, h->persistentTrav ? h->nwavesTrav : nItems, h->persistentTrav, ts);
-  HIP_TRY(h, hipEventRecord(evTrav->second, ts));
-  HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
+  h->lastItems = nItems;
   h->bstream = h->stream;
-  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
-  // maps beyond 2 M photons: the evaluation is the stage the pipelined step waits for (its records no longer fit the
-  // Infinity Cache), so it gets its third wave per SIMD; below, the other stages need the room more (measured: +6 % on a
-  // rank's step at C4 with 12 waves per CU, -3 % at C2)
-  // (... when the evaluation is the long stage: a rank that holds an eighth of the frame evaluates for 1.3 ms beside a build of
-  // 1.0 -- with 12 waves per CU the build starves.  C4, rank 0 of N emulated, 8 / 12 waves: N = 2: 7.14 / 6.91 ms per step,
-  // N = 4: 3.94 / 3.93, N = 8: 2.33 / 2.47)
-  const bool smallShare = h->nsets > 0 && (size_t)h->nsets * 6u <= h->npix;
-  const uint32_t nwEval = (h->pipeline && !h->nwavesFromEnv && h->ncu && h->nph > 2000000u && !smallShare)
-                              ? std::min<uint32_t>(h->ncu * 12u, GVPM_STAT_ROWS) : h->nwaves;
-  if (!primal && h->reqCap > 0 && h->cfg.use_manifold && h->bs->origIdx.p) {
-    // manifold-typed shifts are recorded for the host (gvpm_download_shift_requests) instead of failing
-    HIP_TRY(h, h->reqHost.ensure(h->reqCap));
-    HIP_TRY(h, h->reqCtx.ensure(4 * h->reqCap));
-    HIP_TRY(h, h->reqCount.ensure(2));
-    HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
-    a.reqHost = h->reqHost.p;
-    a.reqCtx = h->reqCtx.p;
-    a.reqCount = h->reqCount.p;
-    a.reqCap = (uint32_t)h->reqCap;
-    a.origIdx = h->bs->origIdx.p;
-    h->reqArgs = a;
-    h->reqOutstanding = true;
-    h->reqBeams = false;
-  }
-  HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
-  if (primal)
-    // the primal beam radiance estimate over the same items and pair lists (gather_bre.hip, evaluate_primal_kernel)
-    launch_evaluate_primal(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 2,
-                           h->bs->pairs.p, h->bs->pairCnt.p, std::max<uint32_t>(1u, std::min<uint32_t>(nItems, h->ncu * 16u)), h->stream);
-  else
-  launch_evaluate_bre(a, h->beamsPerWave, needFullVis(h), h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
-                      h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItems, h->persistentEval,
-                      h->stream);
-  HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
-  // the shifts and pairs the evaluation could not decide in fp32: their records and rays into the handle's list, where they
-  // wait for the exact pass
-  if (!primal) {
-    launch_capture_notes(a, h->stream);
-    rc = exactAfterGather(h);
+  if (!queued) {
+    rc = queueGather(blocks, nItems, false, needFullVis(h));
     if (rc != GVPM_OK) return rc;
   }
-  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
   if (h->pipeline) {
     for (int k = 0; k < (h->travStream ? 3 : 2); ++k) {
       BuildSet &other = h->sets[k];
@@ -1034,7 +1234,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   // ONE host round trip for the largest radius and the photons' bounds (each was a D2H copy + a wait of its own: ~30 us of
   // an idle GPU, and C1's step is 0.6 ms): the kernels write them into pinned memory
   if (!h->pinB6) {
-    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 64, hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   const bool wantBounds = h->photonsDirty && h->nph > 0;

@@ -16,6 +16,7 @@
 #include "bundle_grid.h"
 #include "device_types.h"
 #include "shift_device.h"
+#include "tile_walk.h"
 #include "vec.h"
 
 namespace gvpm {
@@ -355,24 +356,37 @@ __device__ __forceinline__ void nearOccluders(f3 P, f3 pn, const float4 *bvh, co
 
 // counting sort, pass 3: photon `src` (reads in upload order: coalesced) goes to slot cellStart[key] + rank
 // (whole 128-byte records: full-line writes)
+struct ReorderLds {
+  float4 stg[64][GVPM_REC_QUADS / 2 + 1];  // half a record a pass; +1: odd stride against bank conflicts (5 KB: one wave a block)
+  uint32_t dstIdx[64];
+};
+// bid: which 64 photons of the upload this wave takes (the kernel's block index, or the block's index among the reorder
+// blocks of the build chain's tail kernel)
 template <int MODE>
-__global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
-                                                      const uint32_t *__restrict__ rank,
-                                                      const uint32_t *__restrict__ cellStart, uint32_t n,
-                                                      gvpm_params cfg, const float4 *bvh, const float4 *tri4,
-                                                      uint32_t ntri, float dmax, NearGrid ng, uint32_t *nearExt,
-                                                      uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
-                                                      uint32_t *origIdx, const uint32_t *__restrict__ sub, uint32_t ncells) {
+__device__ __forceinline__ void reorderBody(const RawPhotons &r, const uint32_t *__restrict__ keys,
+                                            const uint32_t *__restrict__ rank,
+                                            const uint32_t *__restrict__ cellStart, uint32_t n,
+                                            const gvpm_params &cfg, const float4 *bvh, const float4 *tri4,
+                                            uint32_t ntri, float dmax, const NearGrid &ng, uint32_t *nearExt,
+                                            uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
+                                            uint32_t *origIdx, const uint32_t *__restrict__ sub, uint32_t ncells, uint32_t bid,
+                                            uint32_t *counts, ReorderLds &L) {
   // The record is assembled in LDS and written by EIGHT lanes (one 16-byte quad each): a store instruction then
-  // covers eight whole 128-byte lines instead of sixty-four 16-byte pieces of sixty-four lines.
-  __shared__ float4 stg[64][GVPM_REC_QUADS + 1];  // +1: odd stride against bank conflicts (9 KB: one wave a block)
-  __shared__ uint32_t dstIdx[64];
-  const uint32_t src = blockIdx.x * blockDim.x + threadIdx.x;
+  // covers whole 64-byte halves of eight records instead of sixty-four 16-byte pieces of sixty-four lines.  Two passes of four
+  // quads (round 6: 5 KB of LDS a wave instead of 9.5 -- the kernel runs beside the evaluation and the traversal).
+  auto &stg = L.stg;
+  auto &dstIdx = L.dstIdx;
+  const uint32_t src = bid * 64u + threadIdx.x;
   const int t = threadIdx.x;
+  constexpr int HALF = GVPM_REC_QUADS / 2;
   dstIdx[t] = 0xFFFFFFFFu;
-  if (src < n && rank[src] != 0xFFFFFFFFu) {  // (0xFFFFFFFF: outside the bundle, cell_count_kernel)
+  float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), q5 = q4, q6 = q4, q7 = q4;
+  const bool live = src < n && (counts || rank[src] != 0xFFFFFFFFu);  // (0xFFFFFFFF: outside the bundle, cell_count_kernel)
+  if (live) {
     // (sub: the photon's rank counts within its stripe of the cell, cell_count_kernel)
-    const uint32_t i = cellStart[keys[src]] + rank[src] + (sub ? sub[(size_t)(src % CELL_STRIPES) * ncells + keys[src]] : 0u);
+    // (counts: the build chain -- no ranks were taken when the cells were counted; the counter is counted back down here)
+    const uint32_t i = counts ? cellStart[keys[src]] + (atomicSub(&counts[keys[src]], 1u) - 1u)
+                              : cellStart[keys[src]] + rank[src] + (sub ? sub[(size_t)(src % CELL_STRIPES) * ncells + keys[src]] : 0u);
     uint32_t bits = r.flags[src] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
     if (photonContributes(bits, cfg)) bits |= 1u << 6;
     bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
@@ -384,27 +398,52 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
     stg[t][1] = ld3(r.wi, src, r.parent_pdf[src]);
     stg[t][2] = ld3(r.flux, src, r.edge_pdf[src]);
     stg[t][3] = ld3(r.parent_pos, src, r.parent_rr[src]);
-    stg[t][4] = ld3(r.parent_n, src, r.parent_g[src]);
+    q4 = ld3(r.parent_n, src, r.parent_g[src]);
     const f3 P = mk3(r.parent_pos[3 * (size_t)src], r.parent_pos[3 * (size_t)src + 1], r.parent_pos[3 * (size_t)src + 2]);
     uint32_t w0, w1, w2;
-    const f3 PN = mk3(r.parent_n[3 * (size_t)src], r.parent_n[3 * (size_t)src + 1], r.parent_n[3 * (size_t)src + 2]);
+    const f3 PN = mk3(q4.x, q4.y, q4.z);
     float cstar;
     nearOccluders<MODE>(P, PN, bvh, tri4, ntri, dmax, ng, nearExt, extCap, cfg.epsilon, w0, w1, w2, cstar);
     if ((w0 >> 24) == 0xFEu) atomicAdd(overflow, 1u);
     // (bit 15 of the COLD record's flags only -- the depth field's top bit, which the evaluation does not read: "word 2 of the
     // near list is the reach of the wall the parent sits behind"; the hot record the traversal filters by keeps the flags)
     stg[t][0].w = __uint_as_float((bits & ~(1u << 15)) | (cstar > 0.f ? 1u << 15 : 0u));
-    stg[t][5] = ld3(r.prefix_w, src, __uint_as_float(w0));
-    stg[t][6] = ld3(r.parent_scat, src, __uint_as_float(w1));
-    stg[t][7] = ld3(r.parent_wi, src, __uint_as_float(w2));
+    q5 = ld3(r.prefix_w, src, __uint_as_float(w0));
+    q6 = ld3(r.parent_scat, src, __uint_as_float(w1));
+    q7 = ld3(r.parent_wi, src, __uint_as_float(w2));
     dstIdx[t] = i;
   }
   __syncthreads();
-  for (int e = t; e < 64 * GVPM_REC_QUADS; e += 64) {
-    const int rec = e / GVPM_REC_QUADS, part = e % GVPM_REC_QUADS;
+  for (int e = t; e < 64 * HALF; e += 64) {
+    const int rec = e / HALF, part = e % HALF;
     const uint32_t i = dstIdx[rec];
     if (i != 0xFFFFFFFFu) cold[(size_t)i * GVPM_REC_QUADS + part] = stg[rec][part];
   }
+  __syncthreads();
+  if (live) {
+    stg[t][0] = q4;
+    stg[t][1] = q5;
+    stg[t][2] = q6;
+    stg[t][3] = q7;
+  }
+  __syncthreads();
+  for (int e = t; e < 64 * HALF; e += 64) {
+    const int rec = e / HALF, part = e % HALF;
+    const uint32_t i = dstIdx[rec];
+    if (i != 0xFFFFFFFFu) cold[(size_t)i * GVPM_REC_QUADS + HALF + part] = stg[rec][part];
+  }
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ rank,
+                                                      const uint32_t *__restrict__ cellStart, uint32_t n,
+                                                      gvpm_params cfg, const float4 *bvh, const float4 *tri4,
+                                                      uint32_t ntri, float dmax, NearGrid ng, uint32_t *nearExt,
+                                                      uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
+                                                      uint32_t *origIdx, const uint32_t *__restrict__ sub, uint32_t ncells) {
+  __shared__ ReorderLds L;
+  reorderBody<MODE>(r, keys, rank, cellStart, n, cfg, bvh, tri4, ntri, dmax, ng, nearExt, extCap, hot, cold, overflow, origIdx, sub,
+                    ncells, blockIdx.x, nullptr, L);
 }
 
 // ---- the occluder grid of nearVisit: triangle i is listed in every cell its bounding box, grown by `reach`, overlaps and
@@ -1033,6 +1072,404 @@ void launch_beam_keys(const gvpm_camera_ray *rays, uint32_t nsets, int width, in
                       uint32_t *vals, hipStream_t s) {
   hipLaunchKernelGGL(beam_key_kernel, dim3((nsets + 255) / 256), dim3(256), 0, s, rays, nsets, width, tw, th, keys,
                      vals);
+}
+
+// ------------------------------------------------------------------------------------------
+// The G-BRE build as ONE chain of six launches (round 6; until round 5: twenty-three -- bounds x 2, four memsets, count,
+// scan x 3, summed-volume table x 2, scatter, beam count, scan x 3, beam scatter, tile starts, memset, planner, export --
+// 350 us of work that took 860 us of wall beside the other streams' kernels, a launch boundary and a ramp each):
+//   K1 count    photons -> cell keys + ranks, per-block bounds | beam sets -> tile keys + ranks | the control words of the
+//               kernels behind the chain (queue heads, near-list cursor) initialised
+//   K2 reduce   block sums of ONE scan over the concatenated counters [cells | beam keys]; the LAST block to arrive scans
+//               the block sums and reduces the photons' bounds (no block waits for another: see exclusiveSumU32)
+//   K3 down     the scan; the counters are handed back ZEROED (no memset in the next chain)
+//   K4 mid      summed-volume table pass Y | beam scatter | tile starts
+//   K5 sat_z    summed-volume table pass Z
+//   K6 tail     the planner | the photon scatter (whole records + near-occluder lists) side by side -- neither reads the other's
+//               output, the planner is a few thousand latency-bound waves and the scatter is bandwidth: alone 126 + 112 us
+//               one after the other; the last block to arrive exports the counters the host sizes the pair buffer with
+// ------------------------------------------------------------------------------------------
+
+// True in exactly one block of the launch: the last of `nblocks` to get here.  ctl: 65 words, zero on entry, zero again on
+// exit.  Arrivals are spread over up to 64 counters (same-address atomics retire ~11 ns apart: 20 000 blocks on one word
+// would take longer than the kernel).  NO cache write-back rides on an arrival (a release fence is a write-back of the
+// XCD's whole L2: with one per block the tail kernel, which dirties 144 MB, took 800 us instead of 150): what the last
+// block reads of the others must have been written by device-scope ATOMICS (performed at the memory side, past the
+// per-XCD L2s) and is read by atomics; every lane waits for its own to be acknowledged before the block arrives.
+__device__ __forceinline__ bool lastBlockArrives(uint32_t *ctl, uint32_t blockId, uint32_t nblocks) {
+  __shared__ uint32_t isLast;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t S = nblocks < 64u ? nblocks : 64u;
+    const uint32_t sl = blockId % S;
+    const uint32_t expect = (nblocks - sl + S - 1u) / S;  // blocks with this residue
+    uint32_t last = 0u;
+    if (atomicAdd(&ctl[1u + sl], 1u) == expect - 1u) {
+      atomicExch(&ctl[1u + sl], 0u);
+      if (atomicAdd(&ctl[0], 1u) == S - 1u) {
+        atomicExch(&ctl[0], 0u);
+        last = 1u;
+      }
+    }
+    isLast = last;
+  }
+  __syncthreads();
+  return isLast != 0u;
+}
+__device__ __forceinline__ uint32_t coherentRead(uint32_t *p) { return atomicAdd(p, 0u); }
+
+// photon bounds through 64 x 6 buckets of order-preserving unsigned codes (min slots start at 0xFFFFFFFF, max slots at 0):
+// a block's six numbers go to bucket (block % 64) by atomicMin / atomicMax -- sixty atomics an address -- and whoever reduces
+// the buckets at the end reads 384 words instead of six per block, and resets them.
+__device__ __forceinline__ uint32_t ordCode(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordDecode(uint32_t o) { return __uint_as_float((o >> 31) ? (o & 0x7FFFFFFFu) : ~o); }
+__global__ void chain_init_buckets_kernel(uint32_t *buckets) {
+  const uint32_t t = threadIdx.x;  // 768 threads: the photons' buckets, then the camera beams'
+  buckets[t] = (t % 6u) < 3u ? 0xFFFFFFFFu : 0u;
+}
+
+// K1.  Mode 0 and the beam sets only COUNT here (atomics without a return value: nothing waits for them); the arrival rank
+// is taken where the record is scattered, by counting the cell's counter back down to zero (chain_tail / chain_mid) -- which
+// also hands the counters back zeroed.  Bundle cells keep cell_count_kernel's striped ranks.
+__global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs c) {
+  __shared__ float red[6][4];
+  const uint32_t b = blockIdx.x;
+  if (b == 0) {
+    if (threadIdx.x < 8) c.queueCtl[threadIdx.x] = 0u;
+    if (threadIdx.x == 8) *c.overflowCtr = 0u;
+    if (threadIdx.x == 9) c.nearExt[0] = 1u;
+  }
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const bool photons = b < c.nPhBlocks;
+  if (photons) {
+    const uint32_t i = b * 256u + threadIdx.x;
+    if (i < c.n) {
+      const float px = c.pos[3 * (size_t)i + 0], py = c.pos[3 * (size_t)i + 1], pz = c.pos[3 * (size_t)i + 2];
+      mn[0] = px; mn[1] = py; mn[2] = pz;
+      mx[0] = px; mx[1] = py; mx[2] = pz;
+      const Grid &g = c.g;
+      if (g.mode == 1) {
+        const uint32_t k = bundlePhotonKey(g, px, py, pz);
+        c.keys[i] = k;
+        if (k == GVPM_BUNDLE_DUMP_CELL(g.dim[0])) c.rank[i] = 0xFFFFFFFFu;
+        else c.rank[i] = atomicAdd(&c.sub[(size_t)(i % CELL_STRIPES) * g.ncells + k], 1u);
+      } else {
+        const int cx = cellCoord(px, g.org[0], g.invCell, g.dim[0]);
+        const int cy = cellCoord(py, g.org[1], g.invCell, g.dim[1]);
+        const int cz = cellCoord(pz, g.org[2], g.invCell, g.dim[2]);
+        const uint32_t k = ((uint32_t)cz * g.dim[1] + cy) * g.dim[0] + cx;
+        c.keys[i] = k;
+        (void)atomicAdd(&c.counts[k], 1u);
+      }
+    }
+  } else {
+    // the beam sets: key = tile * tilePixels + pixel in tile, counted behind the cells (the sets of one pixel -- one per
+    // medium edge of its camera path -- keep no order among themselves: nothing reads one).  Their base rays' segments give
+    // the region the NEXT build's grid is clipped to (gather_drivers.hip, buildGrid).
+    const uint32_t i = (b - c.nPhBlocks) * 256u + threadIdx.x;
+    if (i < c.nsets) {
+      const gvpm_camera_ray &r = c.rays[(size_t)i * 5];
+      const uint32_t px = r.pixel & 0xFFFFu, py = r.pixel >> 16;
+      const uint32_t tilesX = (c.width + c.tw - 1) / c.tw;
+      const uint32_t tile = (py / c.th) * tilesX + px / c.tw;
+      const uint32_t inTile = (py % c.th) * c.tw + px % c.tw;
+      const uint32_t k = tile * (uint32_t)(c.tw * c.th) + inTile;
+      c.bKeys[i] = k;
+      (void)atomicAdd(&c.counts[(size_t)c.beamOff + k], 1u);
+      if (GVPM_RAY_VALID(r.info)) {
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3) {
+          const float e0 = r.o[k3], e1 = r.o[k3] + r.d[k3] * r.len;
+          mn[k3] = fminf(e0, e1);
+          mx[k3] = fmaxf(e0, e1);
+        }
+      }
+    }
+  }
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lo = wave_min(mn[k]), hi = wave_max(mx[k]);
+    if (lane == 0) {
+      red[k][wave] = lo;
+      red[3 + k][wave] = hi;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    float v = red[k][0];
+    for (int w = 1; w < 4; ++w) v = k < 3 ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+    uint32_t *slot = c.buckets + (photons ? 0u : 384u) + (b % 64u) * 6u + k;
+    if (k < 3) (void)atomicMin(slot, ordCode(v));
+    else (void)atomicMax(slot, ordCode(v));
+  }
+}
+
+// K2: block sums; the last block to arrive turns them into block offsets and reduces the bounds' buckets
+__global__ __launch_bounds__(256) void chain_scan_reduce_kernel(ChainArgs c) {
+  __shared__ uint32_t lds[4];
+  __shared__ float red[6][4];
+  const uint32_t n = c.scanLen;
+  {
+    const uint32_t *__restrict__ counts = c.counts;
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER_THREAD; ++k)
+      if (base + k < n) v += counts[base + k];
+    uint32_t total;
+    (void)block_scan_excl(v, lds, total);
+    if (threadIdx.x == 0) (void)atomicExch(&c.blockSum[blockIdx.x], total);
+  }
+  if (!lastBlockArrives(c.ctl, blockIdx.x, gridDim.x)) return;
+  // the spine, by whoever came last: every thread takes a run of consecutive block sums (all its reads in flight at once)
+  const uint32_t nblocks = gridDim.x;
+  const uint32_t per = (nblocks + SCAN_BLOCK - 1u) / SCAN_BLOCK;
+  const uint32_t i0 = min(nblocks, threadIdx.x * per), i1 = min(nblocks, i0 + per);
+  uint32_t mine = 0;
+  for (uint32_t i = i0; i < i1; ++i) mine += coherentRead(&c.blockSum[i]);
+  uint32_t total;
+  uint32_t run = block_scan_excl(mine, lds, total);
+  for (uint32_t i = i0; i < i1; ++i) {
+    const uint32_t v = coherentRead(&c.blockSum[i]);
+    c.blockSum[i] = run;
+    run += v;
+  }
+  // ... and the bounds: the photons', then the camera beams'
+  for (uint32_t which = 0; which < 2u; ++which) {
+    float v6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float v = k < 3 ? INFINITY : -INFINITY;
+      if (threadIdx.x < 64u) {
+        uint32_t *slot = c.buckets + which * 384u + threadIdx.x * 6u + k;
+        v = ordDecode(coherentRead(slot));
+        *slot = k < 3 ? 0xFFFFFFFFu : 0u;  // handed back reset
+      }
+      v6[k] = v;
+    }
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float a = wave_min(v6[k]), b = wave_max(v6[3 + k]);
+      if (lane == 0) {
+        red[k][wave] = a;
+        red[3 + k][wave] = b;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int k = threadIdx.x;
+      float v = red[k][0];
+      for (int w = 1; w < 4; ++w) v = k < 3 ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+      c.out6[which * 6u + k] = v;
+      if (c.hostB6) c.hostB6[which * 16u + k] = v;
+    }
+  }
+}
+
+// K3: the scan.  (Bundle cells: the cells' counters, written by cell_stripes_kernel, are zeroed here -- everything else is
+// counted back down by the scatters.)
+__global__ __launch_bounds__(256) void chain_scan_down_kernel(ChainArgs c) {
+  __shared__ uint32_t lds[4];
+  const uint32_t n = c.scanLen;
+  uint32_t *__restrict__ counts = c.counts;
+  uint32_t *__restrict__ starts = c.starts;
+  const uint32_t zeroBelow = c.g.mode == 1 ? c.beamOff : 0u;
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t x[SCAN_PER_THREAD], v = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; ++k) {
+    x[k] = base + k < n ? counts[base + k] : 0u;
+    v += x[k];
+  }
+  uint32_t total;
+  uint32_t run = c.blockSum[blockIdx.x] + block_scan_excl(v, lds, total);
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; ++k) {
+    if (base + k < n) {
+      starts[base + k] = run;
+      if (x[k] && base + k < zeroBelow) counts[base + k] = 0u;
+    }
+    run += x[k];
+  }
+}
+
+// K4: three small jobs that need nothing but the scan
+__device__ __forceinline__ void satYBody(const uint32_t *__restrict__ cellStart, const Grid &g, uint32_t *__restrict__ sat, uint32_t t) {
+  const uint32_t nx1 = g.dim[0] + 1, ny1 = g.dim[1] + 1;
+  if (t >= nx1 * (uint32_t)g.dim[2]) return;
+  const uint32_t x = t % nx1, z = t / nx1;
+  uint32_t run = 0;
+  sat[((size_t)z * ny1 + 0) * nx1 + x] = 0u;
+#pragma unroll 8
+  for (int y = 0; y < g.dim[1]; ++y) {
+    const size_t row = ((size_t)z * g.dim[1] + y) * g.dim[0];
+    run += cellStart[row + x] - cellStart[row];
+    sat[((size_t)z * ny1 + (y + 1)) * nx1 + x] = run;
+  }
+}
+__global__ __launch_bounds__(256) void chain_mid_kernel(ChainArgs c, uint32_t nSatBlocks, uint32_t nBeamBlocks) {
+  const uint32_t b = blockIdx.x;
+  if (b < nSatBlocks) {
+    satYBody(c.starts, c.g, c.sat, b * 256u + threadIdx.x);
+    return;
+  }
+  const uint32_t *__restrict__ starts = c.starts;
+  const uint32_t base = starts[c.beamOff];  // every sorted photon lies before the first beam key
+  if (b < nSatBlocks + nBeamBlocks) {
+    const uint32_t i = (b - nSatBlocks) * 256u + threadIdx.x;
+    if (i < c.nsets) {
+      const size_t k = (size_t)c.beamOff + c.bKeys[i];
+      c.setPerm[starts[k] - base + (atomicSub(&c.counts[k], 1u) - 1u)] = i;
+    }
+    return;
+  }
+  const uint32_t t = (b - nSatBlocks - nBeamBlocks) * 256u + threadIdx.x;
+  if (t <= c.ntiles) c.tileStart[t] = starts[(size_t)c.beamOff + ((size_t)t << c.tileShift)] - base;
+}
+
+struct TailArgs {
+  // planner
+  uint32_t ntiles, target, itemCap, nPlan;
+  uint4 *items;
+  uint2 *itemOff;
+  uint32_t *itemCount, *blockTotal;
+  // scatter
+  RawPhotons raw;
+  const uint32_t *keys, *rank, *cellStart, *sub;
+  uint32_t *counts;  // mode 0: the cells' counters, counted back down for the arrival ranks
+  uint32_t n, ncells, extCap;
+  uint32_t every;    // every `every`-th block of the launch is a planner's, until they are nPlan
+  float dmax;
+  NearGrid ng;
+  uint32_t *nearExt, *overflow, *origIdx;
+  float4 *hot, *cold;
+  // export
+  uint32_t *ctl;
+  const uint32_t *bundleFlag;
+  uint32_t *hostOut;
+  // The guard of an OPTIMISTIC step (gather_drivers.hip, gatherBRE): traversal and evaluation are queued behind this launch
+  // before the host has seen its counters, sized for what the buffers hold.  The last block compares and leaves a status in
+  // itemCount[7]; non-zero, both kernels return at once and the host, which reads the same word, queues them again.
+  uint32_t pairCapBlocks;  // 64-entry blocks the pair buffer holds (0xFFFFFFFF: not optimistic, no guard)
+  uint32_t unitCap, unitPairs;  // entries of each unit list (0: none), pairs per unit
+  uint32_t fullVis;        // the evaluation queued walks the BVH (near-list overflows do not matter)
+};
+constexpr uint32_t TAIL_PLAN_STAGE = 128;
+template <int B> constexpr size_t tailLdsBytes() {
+  return sizeof(PlanLds<B, TAIL_PLAN_STAGE>) > sizeof(ReorderLds) ? sizeof(PlanLds<B, TAIL_PLAN_STAGE>) : sizeof(ReorderLds);
+}
+#ifndef GVPM_TAIL_WPE
+#define GVPM_TAIL_WPE 6  // waves per SIMD the tail is compiled for (registers: 512 / this)
+#endif
+template <int B, int MODE> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_TAIL_WPE, GVPM_TAIL_WPE))) void chain_tail_kernel(GatherArgs a, TailArgs t) {
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[tailLdsBytes<B>()];
+  // The two roles INTERLEAVED over the launch (workgroups are dispatched in index order): with the planner's blocks first,
+  // they alone fill the chip -- a few thousand single-wave workgroups of 11 KB -- and the scatter starts when they end.
+  const uint32_t b = blockIdx.x, pslot = b / t.every;
+  if (b % t.every == 0u && pslot < t.nPlan)
+    planBody<B, TAIL_PLAN_STAGE>(a, t.ntiles, t.target, t.items, t.itemCount, t.itemOff, t.blockTotal, t.itemCap, pslot, t.nPlan,
+                                 *reinterpret_cast<PlanLds<B, TAIL_PLAN_STAGE> *>(ldsRaw));
+  else
+    reorderBody<MODE>(t.raw, t.keys, t.rank, t.cellStart, t.n, a.cfg, a.bvh, a.tri4, a.ntri, t.dmax, t.ng, t.nearExt, t.extCap, t.hot,
+                      t.cold, t.overflow, t.origIdx, t.sub, t.ncells, b - min(t.nPlan, (b + t.every - 1u) / t.every), t.counts,
+                      *reinterpret_cast<ReorderLds *>(ldsRaw));
+  if (!lastBlockArrives(t.ctl, blockIdx.x, gridDim.x)) return;
+  if (threadIdx.x == 0) {
+    // what export_u32_kernel handed the host: pair blocks, overflowed near lists, extension cursor, items, bundle flag
+    // (all five are only ever touched by atomics in this launch)
+    t.hostOut[0] = coherentRead(t.blockTotal);
+    t.hostOut[1] = coherentRead(t.overflow);
+    t.hostOut[2] = coherentRead(t.nearExt);
+    t.hostOut[3] = coherentRead(t.itemCount);
+    t.hostOut[4] = t.bundleFlag ? coherentRead(const_cast<uint32_t *>(t.bundleFlag)) : 0u;
+    uint32_t bad = 0u;
+    if (t.pairCapBlocks != 0xFFFFFFFFu) {
+      const uint32_t blocks = t.hostOut[0], nIt = t.hostOut[3];
+      if (blocks > t.pairCapBlocks) bad |= 1u;
+      if (nIt > t.itemCap) bad |= 2u;
+      if (t.unitCap && (unsigned long long)blocks * 64ull / t.unitPairs + nIt + 64ull > (unsigned long long)t.unitCap) bad |= 4u;
+      if (t.hostOut[1] != 0u && !t.fullVis) bad |= 8u;
+      if (t.hostOut[4] != 0u) bad |= 16u;
+    }
+    t.itemCount[7] = bad;
+    t.hostOut[5] = bad;
+    __threadfence_system();
+  }
+}
+
+template <int B>
+static void launchTail(int mode, uint32_t grid, hipStream_t s, const GatherArgs &a, const TailArgs &t) {
+  if (mode == 0) hipLaunchKernelGGL((chain_tail_kernel<B, 0>), dim3(grid), dim3(64), 0, s, a, t);
+  else if (mode == 2) hipLaunchKernelGGL((chain_tail_kernel<B, 2>), dim3(grid), dim3(64), 0, s, a, t);
+  else hipLaunchKernelGGL((chain_tail_kernel<B, 1>), dim3(grid), dim3(64), 0, s, a, t);
+}
+
+void launch_build_chain(ChainArgs c, const GatherArgs &a, const gvpm_photon_soa &raw, int beamsPerWave, uint32_t target, uint4 *items,
+                        uint2 *itemOff, uint32_t itemCap, float dmax, const NearGrid &ng, uint32_t extCap, uint32_t *origIdx,
+                        uint32_t *hostOut, bool initBuckets, hipStream_t s, uint32_t pairCapBlocks, uint32_t unitCap, uint32_t unitPairs,
+                        bool fullVis) {
+  c.nPhBlocks = (c.n + 255u) / 256u;
+  c.nBeamBlocks = (c.nsets + 255u) / 256u;
+  if (initBuckets) hipLaunchKernelGGL(chain_init_buckets_kernel, dim3(1), dim3(768), 0, s, c.buckets);
+  hipLaunchKernelGGL(chain_count_kernel, dim3(c.nPhBlocks + c.nBeamBlocks), dim3(256), 0, s, c);
+  // (bundle cells: the stripes of a cell's counter -> exclusive prefixes within the cell, its total to counts[])
+  if (c.g.mode == 1) hipLaunchKernelGGL(cell_stripes_kernel, dim3((c.g.ncells + 255) / 256), dim3(256), 0, s, c.sub, c.g.ncells, c.counts);
+  const uint32_t nScan = (c.scanLen + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(chain_scan_reduce_kernel, dim3(nScan), dim3(SCAN_BLOCK), 0, s, c);
+  hipLaunchKernelGGL(chain_scan_down_kernel, dim3(nScan), dim3(SCAN_BLOCK), 0, s, c);
+  const uint32_t nx1 = c.g.dim[0] + 1, ny1 = c.g.dim[1] + 1;
+  const uint32_t nSat = (nx1 * (uint32_t)c.g.dim[2] + 255u) / 256u, nTile = (c.ntiles + 1u + 255u) / 256u;
+  hipLaunchKernelGGL(chain_mid_kernel, dim3(nSat + c.nBeamBlocks + nTile), dim3(256), 0, s, c, nSat, c.nBeamBlocks);
+  hipLaunchKernelGGL(sat_z_kernel, dim3((nx1 * ny1 + 255) / 256), dim3(256), 0, s, c.g, c.sat);
+  TailArgs t{};
+  t.ntiles = c.ntiles;
+  t.target = target;
+  t.itemCap = itemCap;
+  t.nPlan = c.ntiles < 4093u ? c.ntiles : 4093u;  // (a prime stride: launch_plan_bre)
+  t.items = items;
+  t.itemOff = itemOff;
+  t.itemCount = c.queueCtl;
+  t.blockTotal = c.queueCtl + 3;
+  t.raw = RawPhotons{raw.pos,       raw.wi,          raw.flux,      raw.parent_pos, raw.parent_n, raw.prefix_w, raw.parent_scat,
+                     raw.parent_wi, raw.parent_pdf,  raw.edge_pdf,  raw.parent_rr,  raw.parent_g, raw.flags,    raw.path_id};
+  t.keys = c.keys;
+  t.rank = c.rank;
+  t.cellStart = c.starts;
+  t.sub = c.g.mode == 1 ? c.sub : nullptr;
+  t.counts = c.g.mode == 1 ? nullptr : c.counts;
+  t.n = c.n;
+  t.ncells = c.g.ncells;
+  t.extCap = extCap;
+  t.dmax = dmax;
+  t.ng = ng;
+  t.nearExt = c.nearExt;
+  t.overflow = c.overflowCtr;
+  t.origIdx = origIdx;
+  t.hot = const_cast<float4 *>(a.hot);
+  t.cold = const_cast<float4 *>(a.cold);
+  t.ctl = c.ctl + 65;
+  t.bundleFlag = a.bundleFlag;
+  t.hostOut = hostOut;
+  t.pairCapBlocks = pairCapBlocks;
+  t.unitCap = unitCap;
+  t.unitPairs = unitPairs ? unitPairs : 1u;
+  t.fullVis = fullVis ? 1u : 0u;
+  const int mode = a.ntri <= 64u ? 0 : (ng.start ? 2 : 1);
+  const uint32_t grid = t.nPlan + (c.n + 63u) / 64u;
+  t.every = std::max(1u, grid / std::max(1u, t.nPlan));
+  switch (beamsPerWave) {
+    case 64: launchTail<64>(mode, grid, s, a, t); break;
+    case 32: launchTail<32>(mode, grid, s, a, t); break;
+    default: launchTail<16>(mode, grid, s, a, t); break;
+  }
 }
 
 }  // namespace gvpm

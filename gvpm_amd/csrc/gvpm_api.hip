@@ -134,6 +134,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_BEAMS_FP64")) h->beamsExact = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BEAMS_FREE_CONE")) h->beamsFreeCone = atoi(e) != 0;
   if (const char *e = getenv("GVPM_PLAN_BOXES")) h->planBoxHandOff = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BUILD_CHAIN")) h->buildChain = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_EVAL_UNITS")) h->evalUnits = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_OPTIMISTIC")) h->optimistic = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_CLIP_GRID")) h->clipGrid = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
   if (const char *e = getenv("GVPM_BEAMS_SPLIT")) h->beamsSplit = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BUNDLE")) {
@@ -221,6 +225,7 @@ int gvpm_destroy(gvpm_context *h) {
   h->samplesOwned.release(); h->scaleVol.release(); h->nVol.release(); h->mvol.release(); h->maxScaleBits.release();
   poisson_graph_release(h->poissonGraph);
   h->accumTmp.release();
+  h->chainCtl.release();
   h->poissonScratch.release(); h->poissonIO.release();
   h->accum.release(); h->accumAll.release(); h->iter.release(); h->filmOut.release(); h->emission.release(); h->stats.release();
   h->exPay.release(); h->exPayCount.release(); h->exOvf.release(); h->exOvfCount.release(); h->exTotals.release();

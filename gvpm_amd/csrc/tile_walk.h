@@ -124,6 +124,7 @@ __device__ __forceinline__ void loadTileRaysNoSync(const GatherArgs &a, RayTile<
     }
   }
 }
+
 template <int B>
 __device__ __forceinline__ void loadTileRays(const GatherArgs &a, RayTile<B> &s, uint32_t setBase, uint32_t nb,
                                              int lane) {
@@ -421,19 +422,29 @@ __device__ __forceinline__ uint32_t boxCount(const GatherArgs &a, const CellBox 
 // tile's beams, held in LDS, and over the cell rows of its own slab box), so the whole walk of a
 // chunk is a handful of dependent steps instead of one per slab.
 // ------------------------------------------------------------------------------------------
-template <int B>
-__global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
-                                                  uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal,
-                                                  uint32_t itemCap) {
+// The planner's LDS (one wave): handed in by the kernel, so that a kernel with other roles beside the planner's (the tail of
+// the G-BRE build chain, grid_build.hip) can lay them over one another.
+// (PLAN_STAGE: the items staged between two flushes, and the most parts a heavy item is split into; 512 in the planner's
+// own kernel, 128 -- 2.5 KB instead of 10 -- where it shares a launch and a CU with everything else: the build chain's tail)
+template <int B, uint32_t PLAN_STAGE = 512> struct PlanLds {
+  uint4 stItem[PLAN_STAGE];
+  uint32_t stStaged[PLAN_STAGE];
+  float pb[8][B];
+  uint32_t pvalid[B];
+};
+// bid / nblk: this wave's index among the planner's waves and their number (tiles are taken with stride nblk)
+template <int B, uint32_t PLAN_STAGE>
+__device__ __forceinline__ void planBody(const GatherArgs &a, uint32_t ntiles, uint32_t target, uint4 *items, uint32_t *itemCount,
+                                         uint2 *itemOff, uint32_t *blockTotal, uint32_t itemCap, uint32_t bid, uint32_t nblk,
+                                         PlanLds<B, PLAN_STAGE> &L) {
   // The finished items are staged in LDS and flushed ~PLAN_STAGE at a time: one pair of global atomics
   // per flush (same-address returning atomics retire one per ~10 ns: one per tile cost 0.35 ms at C2).
-  constexpr uint32_t PLAN_STAGE = 512;
   // (no pair regions to size -- G-Beams -- means heavy items may be split into parts, see below)
   const bool splitHeavy = itemOff == nullptr;
-  __shared__ float pb[8][B];
-  __shared__ uint32_t pvalid[B];
-  __shared__ uint4 stItem[PLAN_STAGE];
-  __shared__ uint32_t stStaged[PLAN_STAGE];
+  auto &pb = L.pb;
+  auto &pvalid = L.pvalid;
+  auto &stItem = L.stItem;
+  auto &stStaged = L.stStaged;
   const int lane = threadIdx.x;
   uint32_t nStaged = 0;  // wave-uniform
   auto flush = [&]() {
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
     nStaged = 0;
     __syncthreads();
   };
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (uint32_t tile = bid; tile < ntiles; tile += nblk) {
   const uint32_t tileBeg = a.tileStart[tile], tileEnd = a.tileStart[tile + 1];
   for (uint32_t setBase = tileBeg; setBase < tileEnd; setBase += B) {
     const uint32_t nb = min((uint32_t)B, tileEnd - setBase);
@@ -494,6 +505,9 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
           float lo, hi;
           slabRange(a, w, cA, cAe, lo, hi);
           float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
+          // (unrolled by 8 the compiler holds 64 prefetched LDS words and the kernel needs 107 VGPRs: beside the persistent
+          // evaluation waves and a traversal wave a SIMD has 48 left)
+#pragma unroll 1
           for (uint32_t j = 0; j < nb; ++j) {
             if (!pvalid[j]) continue;
             const BeamSlab q{pb[0][j], pb[1][j], pb[2][j], pb[3][j], pb[4][j], pb[5][j], pb[6][j], pb[7][j]};
@@ -588,6 +602,13 @@ __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles,
   }
   }
   if (nStaged) flush();
+}
+template <int B>
+__global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
+                                                  uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal,
+                                                  uint32_t itemCap) {
+  __shared__ PlanLds<B, 512> L;
+  planBody<B, 512>(a, ntiles, target, items, itemCount, itemOff, blockTotal, itemCap, blockIdx.x, gridDim.x, L);
 }
 
 }  // namespace gvpm
