@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of step 1 (parity_l2 / relMSE)")
     ap.add_argument("--no-upload-inclusive", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-isolated", action="store_true", help="skip the single-stream leg (kernel_isolated_ms)")
+    ap.add_argument("--other-frame", type=int, default=0, help="tests: frame side of the C1 / C3 / C5 leg (0: the stated sizes)")
+    ap.add_argument("--other-photons", type=int, default=0, help="tests: map records of the C1 / C3 / C5 leg (0: the stated sizes)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the C1 / C3 / C5 leg of the headline run (`other_workloads` in the JSON line)")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs: nothing but warm-up + the timed steps touches the GPU (implies the four --no-* flags)")
     ap.add_argument("--emulate-gpus", type=int, default=0,
@@ -105,7 +109,7 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (smoke test, not a bench line)")
     args = ap.parse_args()
     if args.only_timed:
-        args.no_cpu_baseline = args.no_parity = args.no_upload_inclusive = args.no_isolated = True
+        args.no_cpu_baseline = args.no_parity = args.no_upload_inclusive = args.no_isolated = args.no_other_workloads = True
     if args.primal:
         args.no_cpu_baseline = args.no_upload_inclusive = args.no_isolated = True
     if args.workload in ("c1", "c3", "c5"):
@@ -355,13 +359,21 @@ def main():
             out.update(parity(hip, metrics, sc, p, m, tris, host0[0], W, H))
         if world == 1 and not args.no_cpu_baseline and not gen:
             out["cpu_baseline"] = cpu_baseline(p, m, tris, host0[:args.cpu_iters], W, H)
+        if world == 1 and not gen and not args.primal and args.workload in ("auto", "c2") and not args.no_other_workloads \
+                and (args.other_frame or not (args.photons or args.scene or args.frame or args.emulate_gpus or args.weak)):
+            # the other configs of BASELINE.json (G-VPM, G-Beams, G-Planes at their stated sizes), timed in this process
+            # behind the headline's legs: the same figures `--workload c1|c3|c5 --only-timed` prints (profiles/rNN_c*_bench_line.json)
+            ctx.close()
+            ctx = None
+            out["other_workloads"] = other_workloads(args)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def main_technique(args):
+def main_technique(args, emit=True):
     """--workload c1 | c3 | c5: G-VPM / G-Beams / G-Planes at the size BASELINE.json states, one GPU, the same JSON shape
     as the G-BRE line: a step = one SPPM iteration of the hot path (device build + camera-beam ordering + gather/shift
     kernels + the fold into the film) on inputs already in HBM."""
@@ -529,8 +541,42 @@ def main_technique(args):
         out.update(parity_technique(hip, metrics, tech, p, m, tris, host0[0], W, H))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_technique(tech, p, m, tris, host0[0], W, H, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
     ctx.close()
+    del keep[:]
+    torch.cuda.empty_cache()
+    return out
+
+
+# steps per workload of the headline run's `other_workloads` leg (a G-Beams step is 20 ms, a G-VPM step half a millisecond)
+OTHER_STEPS = {"c1": 24, "c3": 8, "c5": 12}
+
+
+def other_workloads(args):
+    """C1 / C3 / C5 behind the headline: warm-up + timed steps only (no parity, no CPU leg: tests/test_configs_gpu.py and
+    `--workload cN` cover those), one entry per workload with the figures of its own bench line."""
+    import copy
+    res = {}
+    for w in ("c1", "c3", "c5"):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup = w, OTHER_STEPS[w], 2
+        a.no_parity = a.no_cpu_baseline = a.no_upload_inclusive = a.no_isolated = a.only_timed = True
+        a.photons, a.frame, a.distinct = args.other_photons, args.other_frame, 0  # (0: the workload's stated size)
+        a.scene, a.scale, a.technique = "", 0.0, "bre3d"
+        if args.other_frame:
+            a.steps = 3
+        t0 = time.perf_counter()
+        try:
+            o = main_technique(a, emit=False)
+            res[w] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                      "steps": o["steps"], "warmup": o["warmup"], "workload": o["config"]["workload"],
+                      "roofline_frac": o["roofline"]["frac"], "kernel": o["roofline"]["kernel"],
+                      "kernel_avg_ms": o["roofline"]["kernel_avg_ms"], "evaluations": o["config"]["evaluations"],
+                      "csrc_sha": o["config"]["csrc_sha"], "leg_seconds": time.perf_counter() - t0}
+        except Exception as e:  # (the headline line must still be printed)
+            res[w] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 def _window(rays, x0, y0, w, h):

@@ -208,9 +208,14 @@ struct BuildSet {
   // G-BRE: per-beam photon lists between the traversal and the evaluation kernel
   DevBuf<uint32_t> pairs, pairCnt, nearExt;
   DevBuf<uint2> units;  // the evaluation's work units: two lists (large parts, small parts), written by the traversal
+  // the notes of this set's evaluation ({count, ticket} + list; exact_shift.hip): its own, because the evaluations of two sets
+  // may run side by side
+  DevBuf<uint4> notes;
+  DevBuf<uint32_t> notesCount;
   hipEvent_t traversed = nullptr;  // recorded on the build stream after the traversal kernel
   hipEvent_t lastUse = nullptr;  // recorded on the gather stream after the kernels that read this set
   bool used = false;
+  bool lastUseValid = false;  // lastUse has been recorded
   // Give this (so far unused) set the capacities of the set that just ran its first step, so that the second
   // step of a run does not stop for gigabytes of hipMalloc in the middle of the pipeline.
   hipError_t mirrorFrom(const BuildSet &o) {
@@ -233,7 +238,7 @@ struct BuildSet {
     if (sortTmp.d) (void)hipFree(sortTmp.d);
     sortTmp.d = nullptr;
     sortTmp.bytes = 0;
-    pairs.release(); pairCnt.release(); nearExt.release(); chainBuckets.release(); units.release();
+    pairs.release(); pairCnt.release(); nearExt.release(); chainBuckets.release(); units.release(); notes.release(); notesCount.release();
     if (lastUse) (void)hipEventDestroy(lastUse);
     if (traversed) (void)hipEventDestroy(traversed);
     lastUse = traversed = nullptr;
@@ -246,6 +251,16 @@ struct gvpm_context {
   hipStream_t streamB = nullptr;  // build stream of the G-BRE pipeline
   hipStream_t bstream = nullptr;  // where the current gather builds (stream, or streamB for G-BRE)
   hipStream_t streamC = nullptr;  // traversal stream of the three-stage pipeline
+  // G-BRE (round 6): consecutive evaluations on ALTERNATING streams (`stream`, `streamA2`).  They read different build sets and
+  // add to the running sums with atomics, so nothing orders them but the stream -- and on one stream the next evaluation
+  // waited for the last wave of this one (a third of a launch is its tail) plus two kernel boundaries around capture_notes.
+  // Everything that reads or rescales the sums joins both first (gvpm_join_exact).  GVPM_EVAL_ALT=0: one stream.
+  hipStream_t streamA2 = nullptr;
+  bool evalAlt = false;  // (measured at C2, round 6: 1.10-1.12 ms a step either way -- each evaluation then takes 1.4 ms beside the next instead of 1.0 alone)
+  int evalToggle = 0;
+  hipEvent_t exactDone = nullptr;  // behind the last exact pass (gather stream)
+  bool exactDoneValid = false;
+  hipStream_t lastEvalStream = nullptr;  // where the last gather's evaluation went (its camera rays are read until it ends)
   bool travStream = true;         // traversal on its own stream, three build sets (GVPM_TRAV_STREAM=0: two stages)
   BuildSet sets[3];
   BuildSet *bs = &sets[0];
@@ -342,7 +357,7 @@ struct gvpm_context {
   // skips three memsets -- 25 us of launches in a 0.6 ms step at C1.  False whenever something else may have written `iter`.
   bool iterClean = false;
   DevBuf<unsigned long long> exTotals;
-  uint32_t exPayCap = 1u << 20;      // 512 MB, allocated with the first gather that can defer
+  uint32_t exPayCap = 1u << 17;      // 64 MB, allocated with the first gather that can defer; regrown x 4 when a pass finds it a quarter full
   uint32_t exOvfCap = 1u << 20;      // 16 MB of notes per gather
   uint32_t exSince = 0;              // gathers since the last pass
   uint32_t exFlushEvery = 8;         // paced by what the last pass found (pinExact[0]): the list is kept below a quarter full
@@ -503,6 +518,7 @@ void launch_unpack_compact_rays(const gvpm_sensor &sensor, const uint32_t *compa
 // shared between the files above
 // runs the exact pass over the deferred shifts, if a gather may have left any (before anything reads or rescales the sums)
 int gvpm_join_exact(gvpm_context *h);
+int joinEvalStreams(gvpm_context *h);
 int flushHostShifts(gvpm_context *h);  // unanswered shift requests become failed shifts (before anything reads the film)
 float currentRadius(const gvpm_context *h);
 

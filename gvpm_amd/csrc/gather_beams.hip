@@ -1554,7 +1554,7 @@ __device__ __forceinline__ void beamShift2(const GatherArgs &a, LDS &s, const Be
       pr.pdfKernelAndDist = q.k.z;
       w = reconnectBeamF(a, b, pr, sh.eye, sh.sMIS, sr, offsetPos, nd, dist, technique, sflux, ok, amb);
     }
-#ifdef GVPM_DBG_SHIFT2  // (probe builds: scripts/dbg/beams_bisect.py narrows a counter mismatch down to one pair first)
+#ifdef GVPM_DBG_SHIFT2  // (probe builds: scripts/probes_py/beams_bisect.py narrows a counter mismatch down to one pair first)
     printf("shift2 i %d withVis %d vis %d amb %d ok %d w %g dist %g nd %g %g %g cosWo %g cosWi %g clear %g %g flip-u %g\n", i, (int)withVis, vis,
            (int)amb, (int)ok, w, dist, nd.x, nd.y, nd.z, dot(b.parentN, nd), dot(b.parentN, b.parentWi), a.beamClear[beamIdx].x,
            a.beamClear[beamIdx].y, q.u);

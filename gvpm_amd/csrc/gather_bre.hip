@@ -485,7 +485,16 @@ __device__ __forceinline__ void evalPhase2Core(const GatherArgs &a, LDS &s, uint
   uint32_t amb = 0u;
   if (!(HS && GVPM_PF_SHIFT_TYPE(ph.bits) == 3u)) {
     const f3 y = rel - dS;
-    amb = branchAmbiguous(a, dot(y, y), r2, (float)tPrime, sh.len) ? 2u : 0u;
+    const float y2 = dot(y, y), tPf = (float)tPrime;
+    amb = branchAmbiguous(a, y2, r2, tPf, sh.len) ? 2u : 0u;
+    //  Phase 1 queues a shift for two reasons -- it IS a reconnection, or its branch is undecidable -- and
+    // tells phase 2 neither: the test above is re-derived from the same numbers.  Should the two sites ever round differently,
+    // an entry that is neither here -- not ambiguous, yet a null shift, a photon type without a reconnection, or a shifted edge
+    // too short -- was queued as undecidable there: it goes to the exact pass, it is not evaluated as a reconnection.
+    const uint32_t stq = GVPM_PF_SHIFT_TYPE(ph.bits);
+    const bool nullNow = a.cfg.use_shift_null && y2 < r2 && tPf < sh.len;
+    const bool reconnects = sh.valid && !nullNow && sh.len >= tPf && a.cfg.debug_shift != GVPM_SHIFT_NULL && (stq == 1u || stq == 2u);
+    if (!amb && !reconnects) amb = 2u;
   }
   // getShiftPos, shift_volume_photon.cpp:858-896: offsetPos = shiftRay(t') + offRel
   f3 offRel = rel;

@@ -451,7 +451,18 @@ static void fillArgs(const gvpm_context *h, GatherArgs &a, float r) {
 
 // The exact pass over the shifts the gathers deferred (exact_shift.hip): on the gather stream, when a reader asks
 // (gvpm_join_exact) or every exFlushEvery gathers.
+// the evaluations of G-BRE alternate between two streams: whatever reads or rescales the sums on the gather stream waits for both
+int joinEvalStreams(gvpm_context *h) {
+  if (h->streamA2)
+    for (BuildSet &b : h->sets)
+      if (b.lastUseValid && b.lastUse) HIP_TRY(h, hipStreamWaitEvent(h->stream, b.lastUse, 0));
+  return GVPM_OK;
+}
 int gvpm_join_exact(gvpm_context *h) {
+  {
+    const int rcj = joinEvalStreams(h);
+    if (rcj != GVPM_OK) return rcj;
+  }
   if (h->exSince == 0) return GVPM_OK;
   GatherArgs a;
   fillArgs(h, a, 0.f);
@@ -460,12 +471,27 @@ int gvpm_join_exact(gvpm_context *h) {
   a.iter = h->accum.p;
   launch_exact_pass(a, h->exTotals.p, h->pinExact, h->stream);
   HIP_TRY(h, hipGetLastError());
+  // (the pass empties the handle's entry list: the capture kernels of later evaluations, on either stream, come after it)
+  if (!h->exactDone) HIP_TRY(h, hipEventCreateWithFlags(&h->exactDone, hipEventDisableTiming));
+  HIP_TRY(h, hipEventRecord(h->exactDone, h->stream));
+  h->exactDoneValid = true;
   h->exSinceAtLast = h->exSince;
   h->exSince = 0;
   return GVPM_OK;
 }
 // before a gather that can defer: the lists exist; after its kernels have been queued: the cadence
 static int exactPrepare(gvpm_context *h) {
+  // (the list starts at 2^17 entries -- 64 MB, not 512 -- and is regrown, with the pass that empties it in front,
+  // when a pass has found it more than a quarter full; the measured rate is ~1e-5 of the shifts)
+  if (h->exPay.p && h->pinExact && h->pinExact[0] != 0xFFFFFFFFu && h->pinExact[0] > h->exPayCap / 4u && h->exPayCap < (1u << 22)) {
+    const int rcj = gvpm_join_exact(h);
+    if (rcj != GVPM_OK) return rcj;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->streamA2) HIP_TRY(h, hipStreamSynchronize(h->streamA2));
+    h->exPay.release();
+    h->exPayCap *= 4u;
+    h->pinExact[0] = 0u;
+  }
   HIP_TRY(h, h->exPay.reserveExact(h->exPayCap));
   HIP_TRY(h, h->exOvf.reserveExact(h->exOvfCap));
   if (!h->pinExact) {
@@ -576,6 +602,21 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
         }
       }
     }
+    // ... and the evaluation alternates between two (context.h, streamA2)
+    hipStream_t es = h->stream;
+    if (h->evalAlt && h->pipeline && h->streamA2 && !primal && h->reqCap == 0) es = (h->evalToggle++ & 1) ? h->streamA2 : h->stream;
+    h->lastEvalStream = es;
+    if (!primal) {
+      // this set's own note list (exact_shift.hip)
+      if (!h->bs->notes.p) {
+        HIP_TRY(h, h->bs->notes.reserveExact(h->exOvfCap));
+        HIP_TRY(h, h->bs->notesCount.ensure(4));
+        HIP_TRY(h, hipMemsetAsync(h->bs->notesCount.p, 0, 4 * sizeof(uint32_t), es));
+      }
+      a.exOvf = h->bs->notes.p;
+      a.exOvfCount = h->bs->notesCount.p;
+      a.exOvfCap = h->exOvfCap;
+    }
     if (optimisticQ && ts != h->bstream) HIP_TRY(h, hipStreamWaitEvent(ts, evBuild->second, 0));
     HIP_TRY(h, hipEventRecord(evTrav->first, ts));
     launch_traverse_bre(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 1,
@@ -583,7 +624,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
                         units, h->bs->queueCtl.p + 5, unitCap);
     HIP_TRY(h, hipEventRecord(evTrav->second, ts));
     HIP_TRY(h, hipEventRecord(h->bs->traversed, ts));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
+    HIP_TRY(h, hipStreamWaitEvent(es, h->bs->traversed, 0));
     // maps beyond 2 M photons: the evaluation is the stage the pipelined step waits for (its records no longer fit the
     // Infinity Cache), so it gets its third wave per SIMD; below, the other stages need the room more (measured: +6 % on a
     // rank's step at C4 with 12 waves per CU, -3 % at C2)
@@ -598,7 +639,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
       HIP_TRY(h, h->reqHost.ensure(h->reqCap));
       HIP_TRY(h, h->reqCtx.ensure(4 * h->reqCap));
       HIP_TRY(h, h->reqCount.ensure(2));
-      HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
+      HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, es));
       a.reqHost = h->reqHost.p;
       a.reqCtx = h->reqCtx.p;
       a.reqCount = h->reqCount.p;
@@ -608,24 +649,28 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
       h->reqOutstanding = true;
       h->reqBeams = false;
     }
-    HIP_TRY(h, hipEventRecord(evEval->first, h->stream));
+    HIP_TRY(h, hipEventRecord(evEval->first, es));
     if (primal)
       // the primal beam radiance estimate over the same items and pair lists (gather_bre.hip, evaluate_primal_kernel)
       launch_evaluate_primal(a, h->beamsPerWave, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p, h->bs->queueCtl.p + 2,
-                             h->bs->pairs.p, h->bs->pairCnt.p, std::max<uint32_t>(1u, std::min<uint32_t>(nItemsQ, h->ncu * 16u)), h->stream);
+                             h->bs->pairs.p, h->bs->pairCnt.p, std::max<uint32_t>(1u, std::min<uint32_t>(nItemsQ, h->ncu * 16u)), es);
     else
       launch_evaluate_bre(a, h->beamsPerWave, fullVisQ, h->bs->items.p, h->bs->itemOff.p, h->bs->queueCtl.p,
                           h->bs->queueCtl.p + 2, h->bs->pairs.p, h->bs->pairCnt.p, h->persistentEval ? nwEval : nItemsQ, h->persistentEval,
-                          h->stream, units, h->bs->queueCtl.p + 5, unitCap);
-    HIP_TRY(h, hipEventRecord(evEval->second, h->stream));
+                          es, units, h->bs->queueCtl.p + 5, unitCap);
+    HIP_TRY(h, hipEventRecord(evEval->second, es));
     // the shifts and pairs the evaluation could not decide in fp32: their records and rays into the handle's list, where they
     // wait for the exact pass
     if (!primal) {
-      launch_capture_notes(a, h->stream);
-      rq = exactAfterGather(h);
+      if (h->exactDoneValid && es != h->stream) HIP_TRY(h, hipStreamWaitEvent(es, h->exactDone, 0));
+      launch_capture_notes(a, es);
+    }
+    HIP_TRY(h, hipEventRecord(h->bs->lastUse, es));
+    h->bs->lastUseValid = true;
+    if (!primal) {
+      rq = exactAfterGather(h);  // (a pass it starts waits for this evaluation too: after the event above)
       if (rq != GVPM_OK) return rq;
     }
-    HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));
     return GVPM_OK;
   };
   // (a second pass only when the planner met a ray outside the bundle the grid was keyed for: rebuilt in 3D)
@@ -1096,9 +1141,11 @@ static int gatherBeams(gvpm_context *h, int it, uint64_t nb_paths, bool primal =
     HIP_TRY(h, sortPairsU32(h->bs->sortTmp, h->blockKeyA.p, h->blockKeyB.p, h->blockValA.p, h->blockValB.p, nBlocks,
                             ilog2ceil(h->nsets + 1), h->stream));
   if (!primal && !h->beamsExact) {
-    // the notes of the shifts the fp32 evaluation cannot decide (exact_beams_kernel, behind it): ~1.2e-3 of the pairs at C3 --
-    // room for a quarter of the pair blocks' count, i.e. for twenty times that rate, and never less than the handle's default
-    const size_t need = std::max<size_t>(h->exOvfCap, (size_t)nBlocks / 4u);
+    // the notes of the shifts the fp32 evaluation cannot decide (exact_beams_kernel, behind it): ~1.2e-3 of the PAIRS at C3, and
+    // a block holds 64 pairs -- room for four notes a block, i.e. 6 % of the pairs, fifty times that rate (a
+    // quarter of the block count was three times the rate, not twenty), and never less than the handle's default; S-laser's plate
+    // had 2.8 % undecided segments before triHitFine.  Beyond it gvpm_get_stats still fails loudly (the counter keeps counting).
+    const size_t need = std::max<size_t>(h->exOvfCap, (size_t)nBlocks * 4u);
     if (need > 0xFFFFFF00ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many pair blocks for the note list");
     HIP_TRY(h, h->exOvf.reserveExact(need));
     a.exOvf = h->exOvf.p;
@@ -1481,7 +1528,7 @@ static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) 
   if (rc != GVPM_OK) return rc;
   // the kernels just queued on the gather stream are the last readers of this step's camera rays
   if (h->raysOwnedCur) {
-    HIP_TRY(h, hipEventRecord(h->raySlot[h->rayCur].freed, h->stream));
+    HIP_TRY(h, hipEventRecord(h->raySlot[h->rayCur].freed, (breTech && h->lastEvalStream) ? h->lastEvalStream : h->stream));
     h->raySlot[h->rayCur].read = true;
   }
   // ... and of the staged photon arrays (the build on either stream; G-Planes reads them in the gather itself)

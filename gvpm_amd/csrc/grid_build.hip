@@ -1361,10 +1361,13 @@ struct TailArgs {
   uint32_t pairCapBlocks;  // 64-entry blocks the pair buffer holds (0xFFFFFFFF: not optimistic, no guard)
   uint32_t unitCap, unitPairs;  // entries of each unit list (0: none), pairs per unit
   uint32_t fullVis;        // the evaluation queued walks the BVH (near-list overflows do not matter)
+  uint32_t planGroups;     // the 3D grid's planner walks 64 / B chunks side by side (GVPM_PLAN_GROUPS=0: one at a time)
 };
 constexpr uint32_t TAIL_PLAN_STAGE = 128;
 template <int B> constexpr size_t tailLdsBytes() {
-  return sizeof(PlanLds<B, TAIL_PLAN_STAGE>) > sizeof(ReorderLds) ? sizeof(PlanLds<B, TAIL_PLAN_STAGE>) : sizeof(ReorderLds);
+  constexpr size_t pl = sizeof(PlanLds<B, TAIL_PLAN_STAGE>) > sizeof(PlanLdsQ<B, TAIL_PLAN_STAGE>) ? sizeof(PlanLds<B, TAIL_PLAN_STAGE>)
+                                                                                                  : sizeof(PlanLdsQ<B, TAIL_PLAN_STAGE>);
+  return pl > sizeof(ReorderLds) ? pl : sizeof(ReorderLds);
 }
 #ifndef GVPM_TAIL_WPE
 #define GVPM_TAIL_WPE 6  // waves per SIMD the tail is compiled for (registers: 512 / this)
@@ -1374,9 +1377,15 @@ template <int B, int MODE> __global__ __launch_bounds__(64) __attribute__((amdgp
   // The two roles INTERLEAVED over the launch (workgroups are dispatched in index order): with the planner's blocks first,
   // they alone fill the chip -- a few thousand single-wave workgroups of 11 KB -- and the scatter starts when they end.
   const uint32_t b = blockIdx.x, pslot = b / t.every;
-  if (b % t.every == 0u && pslot < t.nPlan)
-    planBody<B, TAIL_PLAN_STAGE>(a, t.ntiles, t.target, t.items, t.itemCount, t.itemOff, t.blockTotal, t.itemCap, pslot, t.nPlan,
-                                 *reinterpret_cast<PlanLds<B, TAIL_PLAN_STAGE> *>(ldsRaw));
+  if (b % t.every == 0u && pslot < t.nPlan) {
+    // (the 3D grid: 64 / B chunks side by side, tile_walk.h planBodyQ; bundle cells: one chunk at a time)
+    if (a.grid.mode != 1 && t.planGroups)
+      planBodyQ<B, TAIL_PLAN_STAGE>(a, t.ntiles, t.target, t.items, t.itemCount, t.itemOff, t.blockTotal, t.itemCap, pslot, t.nPlan,
+                                    *reinterpret_cast<PlanLdsQ<B, TAIL_PLAN_STAGE> *>(ldsRaw));
+    else
+      planBody<B, TAIL_PLAN_STAGE>(a, t.ntiles, t.target, t.items, t.itemCount, t.itemOff, t.blockTotal, t.itemCap, pslot, t.nPlan,
+                                   *reinterpret_cast<PlanLds<B, TAIL_PLAN_STAGE> *>(ldsRaw));
+  }
   else
     reorderBody<MODE>(t.raw, t.keys, t.rank, t.cellStart, t.n, a.cfg, a.bvh, a.tri4, a.ntri, t.dmax, t.ng, t.nearExt, t.extCap, t.hot,
                       t.cold, t.overflow, t.origIdx, t.sub, t.ncells, b - min(t.nPlan, (b + t.every - 1u) / t.every), t.counts,
@@ -1433,7 +1442,13 @@ void launch_build_chain(ChainArgs c, const GatherArgs &a, const gvpm_photon_soa 
   t.ntiles = c.ntiles;
   t.target = target;
   t.itemCap = itemCap;
-  t.nPlan = c.ntiles < 4093u ? c.ntiles : 4093u;  // (a prime stride: launch_plan_bre)
+  t.planGroups = getenv("GVPM_PLAN_GROUPS") ? (atoi(getenv("GVPM_PLAN_GROUPS")) != 0) : 1u;
+  {
+    // planner waves: a prime stride over the tiles (launch_plan_bre); with 64 / B tiles a wave and trip, as many fewer waves
+    const uint32_t per = (t.planGroups && c.g.mode != 1) ? (uint32_t)(64 / (beamsPerWave > 0 ? beamsPerWave : 16)) : 1u;
+    const uint32_t want = (c.ntiles + per - 1u) / per;
+    t.nPlan = want < 4093u ? std::max(1u, want) : 4093u;
+  }
   t.items = items;
   t.itemOff = itemOff;
   t.itemCount = c.queueCtl;

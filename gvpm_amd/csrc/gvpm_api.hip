@@ -58,6 +58,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prA) != hipSuccess ||
       hipStreamCreateWithPriority(&h->streamB, hipStreamNonBlocking, prB) != hipSuccess ||
       hipStreamCreateWithPriority(&h->streamC, hipStreamNonBlocking, prC) != hipSuccess ||
+      hipStreamCreateWithPriority(&h->streamA2, hipStreamNonBlocking, prA) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[0].lastUse, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[1].lastUse, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->sets[2].lastUse, hipEventDisableTiming) != hipSuccess ||
@@ -99,6 +100,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   // is the G-Beams primal pass's flag, set per launch by its driver)
   h->cfg.reserved[4] = h->cfg.reserved[5] = 0;
   if (const char *e = getenv("GVPM_EXACT_ALL")) h->cfg.reserved[4] = atoi(e) ? 1 : 0;  // (tests: every shift through the exact pass)
+  if (h->cfg.reserved[4]) h->exPayCap = 1u << 20;  // (... which then holds every shift of a gather, not one in 1e5)
   h->cfg.reserved[3] = 0;  // G-BRE traversal: staged photons per box row set from which the staging is lane-coalesced (0 = default)
   if (const char *e = getenv("GVPM_COALESCE_AT")) h->cfg.reserved[3] = atoi(e);
   if (const char *e = getenv("GVPM_PLAN_TARGET")) {
@@ -138,6 +140,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_EVAL_UNITS")) h->evalUnits = atoi(e) != 0;
   if (const char *e = getenv("GVPM_OPTIMISTIC")) h->optimistic = atoi(e) != 0;
   if (const char *e = getenv("GVPM_CLIP_GRID")) h->clipGrid = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_EVAL_ALT")) h->evalAlt = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
   if (const char *e = getenv("GVPM_BEAMS_SPLIT")) h->beamsSplit = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BUNDLE")) {
@@ -197,6 +200,7 @@ int gvpm_destroy(gvpm_context *h) {
     }
   if (h->streamB) (void)hipStreamSynchronize(h->streamB);
   if (h->streamC) (void)hipStreamSynchronize(h->streamC);
+  if (h->streamA2) (void)hipStreamSynchronize(h->streamA2);
   for (BuildSet &b : h->sets) b.release();
   h->tri4.release(); h->bvh.release();
   for (auto &ps : h->phSlot) {
@@ -237,6 +241,8 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->streamB) (void)hipStreamDestroy(h->streamB);
   if (h->streamC) (void)hipStreamDestroy(h->streamC);
+  if (h->streamA2) (void)hipStreamDestroy(h->streamA2);
+  if (h->exactDone) (void)hipEventDestroy(h->exactDone);
   delete h;
   return GVPM_OK;
 }
@@ -246,6 +252,10 @@ int gvpm_reset(gvpm_context *h) {
   // Host-shift requests of a gather that were neither answered nor written off are DISCARDED: their base terms belong to
   // the run that ends here (flushed later they would land in the zeroed accumulators).  The G-VPM batch order is the old
   // run's too.
+  {
+    const int rcj = joinEvalStreams(h);  // (evaluations still in flight on either stream add to the sums cleared below)
+    if (rcj != GVPM_OK) return rcj;
+  }
   h->reqOutstanding = false;
   h->reqBeams = false;
   if (h->reqCount.p) HIP_TRY(h, hipMemsetAsync(h->reqCount.p, 0, 8, h->stream));
@@ -414,13 +424,20 @@ int gvpm_get_exact_shift_count(gvpm_context *h, uint64_t *evaluated, uint64_t *l
   unsigned long long v[32];
   HIP_TRY(h, hipMemcpyAsync(v, h->exTotals.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (getenv("GVPM_TRACE_EXACT"))
+  // (the cause slots 4.. are a bit MASK's bits for G-BRE / G-VPM, exact_pass_kernel, and a cause NUMBER 0..9 for
+  // G-Beams, exact_beams_kernel -- the same slots, so each technique's line is printed under its own labels)
+  const bool beamsTech = h->cfg.vol_technique == GVPM_BEAM_BEAM_1D || h->cfg.vol_technique == GVPM_BEAM_BEAM_3D_OPTIMIZED;
+  if (getenv("GVPM_TRACE_EXACT") && beamsTech) {
+    fprintf(stderr, "[exact beams] evaluated %llu lost %llu largest list %llu; by cause number 0..9:", v[0], v[1], v[2]);
+    for (int k = 0; k < 10; ++k) fprintf(stderr, " %llu", v[4 + k]);
+    fprintf(stderr, "\n");
+  } else if (getenv("GVPM_TRACE_EXACT"))
     fprintf(stderr, "[exact] evaluated %llu lost %llu largest list %llu; by cause: pair %llu branch %llu mirror %llu visibility %llu cosine %llu\n",
             v[0], v[1], v[2], v[4], v[5], v[7], v[8], v[9]);
-  if (getenv("GVPM_TRACE_EXACT") && (v[16] | v[17] | v[18] | v[19] | v[20]))
+  if (getenv("GVPM_TRACE_EXACT") && !beamsTech && (v[16] | v[17] | v[18] | v[19] | v[20]))
     fprintf(stderr, "[exact] visibility-caused, |cos| < .01 / .03 / .1 / .3 / more: surface parents %llu %llu %llu %llu %llu, medium parents %llu %llu %llu %llu %llu\n",
             v[16], v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], v[25]);
-  if (getenv("GVPM_TRACE_EXACT") && (v[10] | v[11] | v[12] | v[13]))
+  if (getenv("GVPM_TRACE_EXACT") && !beamsTech && (v[10] | v[11] | v[12] | v[13]))
     fprintf(stderr, "[exact] pairs: other %llu, rim of the kernel %llu, beyond the beam's end %llu, t' at an end %llu\n", v[10], v[11], v[12], v[13]);
   if (evaluated) *evaluated = v[0];
   if (lost) *lost = v[1];

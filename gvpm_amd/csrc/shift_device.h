@@ -594,7 +594,7 @@ __device__ __forceinline__ float shiftDiffuse(const GatherArgs &a, const PhotonC
   const bool ownAmb = behind && cosWo > 0.f && cosWo <= __uint_as_float(ph.nl2) + 1.2e-3f;
   const int vis = shadowBlocked<FULLVIS>(a, ldsTri, ph.nl0, ph.nl1, behind ? 0xFFFFFFFFu : ph.nl2, ph.parentPos, dProj, eps, vmax);
   bool good = vis == GVPM_TRI_MISS;
-#ifdef GVPM_DBG_SHIFT2  // (probe builds, on a single pair: scripts/dbg/vpm_bisect.py)
+#ifdef GVPM_DBG_SHIFT2  // (probe builds, on a single pair: scripts/probes_py/vpm_bisect.py)
   printf("shiftDiffuse vis %d ownAmb %d behind %d cosWo %g lProj %.9g vmax %.9g lists %08x %08x %08x parent %.9g %.9g %.9g dir %.9g %.9g %.9g\n", vis,
          (int)ownAmb, (int)behind, cosWo, lProj, vmax, ph.nl0, ph.nl1, ph.nl2, ph.parentPos.x, ph.parentPos.y, ph.parentPos.z, dProj.x, dProj.y,
          dProj.z);

@@ -603,6 +603,200 @@ __device__ __forceinline__ void planBody(const GatherArgs &a, uint32_t ntiles, u
   }
   if (nStaged) flush();
 }
+// ------------------------------------------------------------------------------------------
+// The same plan with 64 / B tile chunks walked SIDE BY SIDE by one wave (round 6): B lanes a chunk -- its beams during
+// the set-up, its slab steps afterwards.  A chunk of 16 beams has ~13 slab steps at C2: the planner above keeps 13 of 64
+// lanes busy for a chain of dependent loads per chunk, one chunk after the other, in 107 registers.  Everything that was
+// a wave-wide collective there is one over the B lanes of a group here (xor shuffles below B stay inside a group), what was
+// wave-uniform is group-uniform.  3D grid and pair regions only (G-BRE): the bundle cells and G-Beams keep planBody.
+// Same items, same boxes -- but an item does not span groups of B steps (there: of 64).
+// ------------------------------------------------------------------------------------------
+template <int B, uint32_t PLAN_STAGE> struct PlanLdsQ {
+  uint4 stItem[PLAN_STAGE];
+  uint32_t stStaged[PLAN_STAGE];
+  float pb[64 / B][8][B];
+  uint32_t pvalid[64 / B][B];
+};
+template <int B> __device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+  for (int o = B / 2; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <int B> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = B / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <int B, uint32_t PLAN_STAGE>
+__device__ __forceinline__ void planBodyQ(const GatherArgs &a, uint32_t ntiles, uint32_t target, uint4 *items, uint32_t *itemCount,
+                                          uint2 *itemOff, uint32_t *blockTotal, uint32_t itemCap, uint32_t bid, uint32_t nblk,
+                                          PlanLdsQ<B, PLAN_STAGE> &L) {
+  constexpr int G = 64 / B;
+  auto &stItem = L.stItem;
+  auto &stStaged = L.stStaged;
+  const int lane = threadIdx.x, q = lane / B, bl = lane % B;
+  const unsigned long long gm = (B == 64 ? ~0ull : ((1ull << (B & 63)) - 1ull) << (q * B));  // my group's lanes
+  uint32_t nStaged = 0;  // wave-uniform
+  auto flush = [&]() {
+    __syncthreads();
+    for (uint32_t base = 0; base < nStaged; base += 64) {
+      const uint32_t k = base + lane;
+      const bool live = k < nStaged;
+      const uint4 itv = live ? stItem[k] : make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t stg = live ? stStaged[k] : 0u;
+      const uint32_t blocks = live ? (uint32_t)(((unsigned long long)stg * (itv.y & 0xFFu) + 63ull) / 64ull) : 0u;
+      const uint32_t bIncl = wave_scan_incl(blocks, lane);
+      const uint32_t bTotal = __shfl(bIncl, 63, 64);
+      const uint32_t n = min(64u, nStaged - base);
+      uint32_t slot0 = 0, blk0 = 0;
+      if (lane == 0) {
+        slot0 = atomicAdd(itemCount, n);
+        blk0 = atomicAdd(blockTotal, bTotal);
+      }
+      slot0 = __shfl(slot0, 0, 64);
+      blk0 = __shfl(blk0, 0, 64);
+      if (live && slot0 + lane < itemCap) {  // (past the capacity: counted, not written -- the host checks the count)
+        items[slot0 + lane] = itv;
+        itemOff[slot0 + lane] = make_uint2(blk0 + (bIncl - blocks), stg);
+      }
+    }
+    nStaged = 0;
+    __syncthreads();
+  };
+  const float r = a.radius, eps = a.cfg.epsilon;
+  for (uint32_t t0 = bid * G; t0 < ntiles; t0 += nblk * G) {
+    const uint32_t tile = t0 + (uint32_t)q;
+    const bool haveTile = tile < ntiles;
+    const uint32_t tileBeg = haveTile ? a.tileStart[tile] : 0u, tileEnd = haveTile ? a.tileStart[tile + 1] : 0u;
+    for (uint32_t setBase = tileBeg; __ballot(setBase < tileEnd) != 0ull; setBase += B) {
+      const uint32_t nb = setBase < tileEnd ? min((uint32_t)B, tileEnd - setBase) : 0u;
+      BaseInfo bi;
+      const RayReg base = loadBaseDirect<B>(a, setBase, nb, lane, bi);
+      // ---- tileSetupFrom over the group ----
+      const bool beamValid = base.valid;
+      int A;
+      {
+        const float ax = fabsf(base.d.x), ay = fabsf(base.d.y), az = fabsf(base.d.z);
+        const int my = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        const int n0 = __popcll(__ballot(beamValid && my == 0) & gm);
+        const int n1 = __popcll(__ballot(beamValid && my == 1) & gm);
+        const int n2 = __popcll(__ballot(beamValid && my == 2) & gm);
+        A = (n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2);
+      }
+      TileWalk w;
+      w.base = base;
+      w.beamValid = beamValid;
+      w.bundleBad = false;
+      w.A = A;
+      const int U = (A + 1) % 3, V = (A + 2) % 3;
+      w.oA = comp(base.o, A); w.dA = comp(base.d, A);
+      w.oU = comp(base.o, U); w.dU = comp(base.d, U);
+      w.oV = comp(base.o, V); w.dV = comp(base.d, V);
+      const f3 org = mk3(a.grid.org[0], a.grid.org[1], a.grid.org[2]);
+      w.orgA = comp(org, A); w.orgU = comp(org, U); w.orgV = comp(org, V);
+      const int dimA = A == 0 ? a.grid.dim[0] : (A == 1 ? a.grid.dim[1] : a.grid.dim[2]);
+      w.dimU = U == 0 ? a.grid.dim[0] : (U == 1 ? a.grid.dim[1] : a.grid.dim[2]);
+      w.dimV = V == 0 ? a.grid.dim[0] : (V == 1 ? a.grid.dim[1] : a.grid.dim[2]);
+      w.dimA = dimA;
+      w.pad = r * 1.01f + 1e-6f;
+      w.t0 = eps - 2.f * r;
+      w.t1 = (base.len - eps) + 2.f * r;
+      float aLo = INFINITY, aHi = -INFINITY;
+      if (beamValid) {
+        const float e0 = w.oA + w.dA * w.t0, e1 = w.oA + w.dA * w.t1;
+        aLo = fminf(e0, e1) - w.pad;
+        aHi = fmaxf(e0, e1) + w.pad;
+      }
+      aLo = group_min<B>(aLo);
+      aHi = group_max<B>(aHi);
+      w.any = aLo <= aHi && a.nph > 0;
+      w.cA0 = 1;
+      w.cA1 = 0;
+      if (w.any) {
+        w.cA0 = min(max(0, (int)floorf((aLo - w.orgA) * a.grid.invCell)), dimA - 1);
+        w.cA1 = min(max(0, (int)floorf((aHi - w.orgA) * a.grid.invCell)), dimA - 1);
+      }
+      w.K = (A == 0) ? (a.cfg.reserved[2] ? a.cfg.reserved[2] : 8) : (a.cfg.reserved[1] ? a.cfg.reserved[1] : 6);
+      if (__ballot(w.any) == 0ull) continue;  // (wave-uniform)
+      __syncthreads();
+      L.pb[q][0][bl] = w.oA; L.pb[q][1][bl] = w.dA; L.pb[q][2][bl] = w.oU; L.pb[q][3][bl] = w.dU;
+      L.pb[q][4][bl] = w.oV; L.pb[q][5][bl] = w.dV; L.pb[q][6][bl] = w.t0; L.pb[q][7][bl] = w.t1;
+      L.pvalid[q][bl] = beamValid ? 1u : 0u;
+      __syncthreads();
+      const int nsteps = w.any ? (w.cA1 - w.cA0 + w.K) / w.K : 0;
+      int maxSteps = nsteps;
+#pragma unroll
+      for (int o = 32; o >= B; o >>= 1) maxSteps = max(maxSteps, __shfl_xor(maxSteps, o, 64));
+      const uint32_t chunkOrd = setBase / B + tile;
+      for (int sbase = 0; sbase < maxSteps; sbase += B) {
+        const int step = sbase + bl;
+        const bool live = step < nsteps;
+        const int cA = w.cA0 + step * w.K, cAe = min(cA + w.K - 1, w.cA1);
+        uint32_t cnt = 0;
+        if (live) {
+          CellBox bx;
+          float lo, hi;
+          slabRange(a, w, cA, cAe, lo, hi);
+          float uLo = INFINITY, uHi = -INFINITY, vLo = INFINITY, vHi = -INFINITY;
+#pragma unroll 1
+          for (uint32_t j = 0; j < nb; ++j) {
+            if (!L.pvalid[q][j]) continue;
+            const BeamSlab qs{L.pb[q][0][j], L.pb[q][1][j], L.pb[q][2][j], L.pb[q][3][j], L.pb[q][4][j], L.pb[q][5][j], L.pb[q][6][j], L.pb[q][7][j]};
+            float a0, a1, b0, b1;
+            if (beamFootprint(qs, lo, hi, w.pad, a0, a1, b0, b1)) {
+              uLo = fminf(uLo, a0); uHi = fmaxf(uHi, a1);
+              vLo = fminf(vLo, b0); vHi = fmaxf(vHi, b1);
+            }
+          }
+          const bool haveBox = boxFromFootprint(a, w, cA, cAe, uLo, uHi, vLo, vHi, bx);
+          if (a.planBoxes && (uint32_t)step < a.planBoxStride)
+            a.planBoxes[(size_t)chunkOrd * a.planBoxStride + step] = haveBox ? packCellBox(bx) : make_uint2(0xFFFFFFFFu, 0u);
+          if (haveBox) {
+            // photons in the box from the summed-volume table: 8 reads
+            const uint32_t nx1 = a.grid.dim[0] + 1, ny1 = a.grid.dim[1] + 1;
+            const uint32_t *T = a.sat;
+            const size_t z0 = (size_t)bx.bz0 * ny1, z1 = (size_t)(bx.bz1 + 1) * ny1;
+            const uint32_t y0 = bx.by0, y1 = bx.by1 + 1, x0 = bx.bx0, x1 = bx.bx1 + 1;
+            cnt = (T[(z1 + y1) * nx1 + x1] - T[(z1 + y1) * nx1 + x0] - T[(z1 + y0) * nx1 + x1] + T[(z1 + y0) * nx1 + x0]) -
+                  (T[(z0 + y1) * nx1 + x1] - T[(z0 + y1) * nx1 + x0] - T[(z0 + y0) * nx1 + x1] + T[(z0 + y0) * nx1 + x0]);
+          }
+        }
+        // greedy cut over the group's B steps
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < B; o <<= 1) {
+          const uint32_t nv = __shfl_up(incl, o, 64);
+          if (bl >= o) incl += nv;
+        }
+        const uint32_t excl = incl - cnt;
+        const uint32_t id = excl / target;
+        const uint32_t idPrev = __shfl_up(id, 1, 64), idNext = __shfl_down(id, 1, 64);
+        const bool first = live && (bl == 0 || id != idPrev);
+        const bool liveNext = bl < B - 1 && step + 1 < nsteps;
+        const bool closes = live && (!liveNext || idNext != id);
+        const unsigned long long firstMask = __ballot(first) & gm;
+        const unsigned long long below = firstMask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int fl = below ? 63 - __clzll(below) : lane;
+        const uint32_t exclFirst = __shfl(excl, fl, 64);
+        const int cAFirst = __shfl(cA, fl, 64);
+        const uint32_t staged = incl - exclFirst;
+        const bool emit = closes && staged > 0u;
+        const unsigned long long emitMask = __ballot(emit);
+        if (emitMask) {
+          if (nStaged + 64u > PLAN_STAGE) flush();
+          if (emit) {
+            const uint32_t k = nStaged + (uint32_t)__popcll(emitMask & ((1ull << lane) - 1ull));
+            stItem[k] = make_uint4(setBase, nb | (chunkOrd << 8), (uint32_t)cAFirst, (uint32_t)cAe);
+            stStaged[k] = staged;
+          }
+          nStaged += (uint32_t)__popcll(emitMask);
+        }
+      }
+    }
+  }
+  if (nStaged) flush();
+}
+
 template <int B>
 __global__ __launch_bounds__(64) void plan_kernel(GatherArgs a, uint32_t ntiles, uint32_t target, uint4 *items,
                                                   uint32_t *itemCount, uint2 *itemOff, uint32_t *blockTotal,

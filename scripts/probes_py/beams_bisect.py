@@ -1,5 +1,5 @@
 """Find the (camera set, beam) pair on which the device's G-Beams shift counters differ from the oracle's: bisection over the
-camera sets, then over the beams.  python scripts/dbg/beams_bisect.py scene tech scale [free_cone]   (GPU box)"""
+camera sets, then over the beams.  python scripts/probes_py/beams_bisect.py scene tech scale [free_cone]   (GPU box)"""
 import os, sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np

@@ -1,5 +1,5 @@
 """Find the (photon, camera sample) pair on which the device's G-VPM shift counters differ from the oracle's: the iteration first,
-then bisection over the photons, then over the samples.  python scripts/dbg/vpm_bisect.py scene scale nb iters key=value...  (GPU box)"""
+then bisection over the photons, then over the samples.  python scripts/probes_py/vpm_bisect.py scene scale nb iters key=value...  (GPU box)"""
 import os, sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np

@@ -29,6 +29,11 @@ def test_json_line_has_the_contract_keys():
     # round 2: the PCIe-inclusive leg, the parity figures and the 1-thread CPU baseline ride on the same line
     for key in ("upload_inclusive", "parity_l2", "relMSE_throughput_dx_dy", "one_thread", "env", "csrc_sha"):
         assert '"%s"' % key in src, key
+    # round 6: C1 / C3 / C5 ride on the headline's line, one entry each with the figures of their own lines
+    assert 'out["other_workloads"] = other_workloads(args)' in src
+    for key in ("roofline_frac", "kernel_avg_ms", "evaluations", "leg_seconds"):
+        assert '"%s"' % key in src, key
+    assert "--no-other-workloads" in src
 
 
 def test_development_switches_are_refused():

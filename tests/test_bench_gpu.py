@@ -64,3 +64,21 @@ def test_default_workload_reduced():
         assert abs(leg["evals_per_step"] - u["evals_per_step"]) <= 0.1 * u["evals_per_step"]
     assert u["sets"]["compact"] > 0 and u["sets"]["full"] == 0
     assert u["host_bytes_per_step"] < 0.75 * u["packed"]["host_bytes_per_step"] < u["soa"]["host_bytes_per_step"]
+
+
+def test_headline_run_carries_the_other_workloads():
+    """The default command line times C1 / C3 / C5 behind the headline's legs: one entry per
+    workload with the figures of its own line -- here at reduced sizes, which the entries say."""
+    d = run_bench("--steps", "3", "--warmup", "1", "--frame", "96", "--photons", "50000", "--cpu-iters", "1", "--other-frame", "64",
+                  "--other-photons", "4000")
+    check_line(d, 3)
+    ow = d["other_workloads"]
+    assert sorted(ow) == ["c1", "c3", "c5"]
+    for w, kern in (("c1", "gather_vpm_kernel"), ("c3", "evaluate_beams2_kernel"), ("c5", "gather_planes_kernel")):
+        o = ow[w]
+        assert "error" not in o, o
+        for k in ("metric", "value", "unit", "ms_per_step", "steps", "workload", "roofline_frac", "kernel", "kernel_avg_ms",
+                  "evaluations", "csrc_sha"):
+            assert k in o, (w, k)
+        assert o["kernel"] == kern and o["value"] > 0 and o["ms_per_step"] > 0 and o["evaluations"] > 0
+        assert o["workload"].startswith("custom") and o["csrc_sha"] == d["config"]["csrc_sha"]

@@ -59,6 +59,28 @@ def test_library_rccl_collective_single_rank(tmp_path):
     assert np.abs(fa).max() > 0 and np.allclose(fa, fb, rtol=2e-5, atol=2e-6 * np.abs(fa[0]).max())
 
 
+def _gpu_count():
+    # (torch.cuda.device_count() does not initialise the GPU on this image: the ranks are started as children afterwards)
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL with a world of two (VERDICT round 5, next 5)")
+@pytest.mark.parametrize("collective", ["gvpm", "torch"])
+def test_two_gpus_rccl_all_reduce_of_the_film(tmp_path, collective):
+    """Two ranks on TWO GPUs over RCCL -- the library's own gvpm_comm_init / gvpm_allreduce_film (ncclUniqueId handed round
+    by the host) and torch.distributed's nccl backend: the summed film is the single-GPU film.  The first multi-rank RCCL
+    run of this library happens here, not in the driver's 8-GPU bench."""
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    out = subprocess.run([sys.executable, WORKER, "--out", one], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    _launch(2, WORKER, "--out", two, "--backend", "nccl", "--collective", collective)
+    f1, f2 = np.load(one), np.load(two)
+    scale = np.abs(f1[0]).max()
+    assert scale > 0 and np.allclose(f1, f2, rtol=2e-5, atol=2e-6 * scale)
+    assert np.array_equal(f1[0] == 0, f2[0] == 0)
+
+
 def test_bench_two_ranks_is_the_strong_sharded_c4_shape():
     out = _launch(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
                   "--single-device", "--frame", "128", "--photons", "60000", "--distinct", "2")

@@ -78,7 +78,7 @@ def check(out, st, what, slope_tol=0.01, kernel3d=True):
             assert o["rel_l2"] < max(1.5 * o["noise_l2"], 1e-3), (what, key, o["rel_l2"], o["noise_l2"])
         else:
             # The 2D / 1D kernels are biased AT BEAM ENDS in the reference's own statement -- the fp64 oracle through this
-            # very test (scripts/dbg/unbiased_oracle.py, 1500 iterations): the column of pixels beside the frame's first beams
+            # very test (scripts/probes_py/unbiased_oracle.py, 1500 iterations): the column of pixels beside the frame's first beams
             # |z| 3 - 5.7, the pixels under the light 4 - 6, everything else below 4 -- the 2D kernel accepts photons beyond
             # the beam's end (the empty far check, shift_volume_photon.cpp:726-731) where the neighbour's beam is shorter or
             # absent.  Here: the same pixels, and nothing else.
