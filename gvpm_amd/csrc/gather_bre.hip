@@ -912,6 +912,9 @@ __global__ __launch_bounds__(64 * TRAV_WPB) __attribute__((amdgpu_waves_per_eu(G
 #ifndef GVPM_EVAL_MINW
 #define GVPM_EVAL_MINW 3
 #endif
+#ifndef GVPM_EVAL_ATTR
+#define GVPM_EVAL_ATTR
+#endif
 constexpr int SEG_STEPS = 16;   // steps per segment (4 bits of a queue entry)
 constexpr int SEG_QCAP = 1024;  // queue entries per wave; a step appends at most 4 * 64
 template <int B> struct SegCfg {
@@ -962,7 +965,7 @@ __device__ __forceinline__ unsigned long long tickLight() {
 #endif
 
 template <int B, bool FULLVIS, bool PF, bool HS = false>
-__global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 > 0 ? GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 : 1)
+__global__ __launch_bounds__(64 * SegCfg<B>::WPB, GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 > 0 ? GVPM_EVAL_MINW * SegCfg<B>::WPB / 4 : 1) GVPM_EVAL_ATTR
 void evaluate_bre_kernel(GatherArgs a, const uint4 *__restrict__ items, const uint2 *__restrict__ itemOff,
                              const uint32_t *__restrict__ itemCount, uint32_t *queueHead,
                              const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ pairCnt,

@@ -1448,6 +1448,7 @@ void launch_build_chain(ChainArgs c, const GatherArgs &a, const gvpm_photon_soa 
     const uint32_t per = (t.planGroups && c.g.mode != 1) ? (uint32_t)(64 / (beamsPerWave > 0 ? beamsPerWave : 16)) : 1u;
     const uint32_t want = (c.ntiles + per - 1u) / per;
     t.nPlan = want < 4093u ? std::max(1u, want) : 4093u;
+    (void)per;
   }
   t.items = items;
   t.itemOff = itemOff;

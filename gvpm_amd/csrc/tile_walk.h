@@ -664,8 +664,11 @@ __device__ __forceinline__ void planBodyQ(const GatherArgs &a, uint32_t ntiles, 
     __syncthreads();
   };
   const float r = a.radius, eps = a.cfg.epsilon;
-  for (uint32_t t0 = bid * G; t0 < ntiles; t0 += nblk * G) {
-    const uint32_t tile = t0 + (uint32_t)q;
+  // (group q of wave `bid` takes the tiles bid + (trip * G + q) * nblk: the tiles one wave of planBody takes one after the
+  // other -- the items then come out in the order they always had.  With ADJACENT tiles side by side the item list runs over the
+  // image row by row and the traversal, whose workgroup i takes item i, lost a fifth of its speed: 0.33 -> 0.40 ms alone.)
+  for (uint32_t t0 = bid; t0 < ntiles; t0 += nblk * G) {
+    const uint32_t tile = t0 + (uint32_t)q * nblk;
     const bool haveTile = tile < ntiles;
     const uint32_t tileBeg = haveTile ? a.tileStart[tile] : 0u, tileEnd = haveTile ? a.tileStart[tile + 1] : 0u;
     for (uint32_t setBase = tileBeg; __ballot(setBase < tileEnd) != 0ull; setBase += B) {
