@@ -3,7 +3,7 @@
 # the GPU suite, smoke, the default bench line, the rotated-scene stress, the rocprof summaries of C2 / C1 / C3 / C5 and the
 # single-GPU shard probes.  Outputs under gpurun_out/rNN/.  Afterwards, here: cp gpurun_out/rNN/rNN_* profiles/ ;
 # python scripts/docs/fill.py (DESIGN.md / README.md figures) ; update profiles/rNN_tests.txt (csrc sha, counts).
-tag=${1:-r05}
+tag=${1:-r06}
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/$tag
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/$tag/tests_gpu.txt
