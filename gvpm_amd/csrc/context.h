@@ -474,6 +474,7 @@ struct gvpm_context {
   // guess was wrong (GVPM_OPTIMISTIC=0: always after the host's wait)
   bool optimistic = true;
   uint32_t lastItems = 0;  // the planner's item count of the last G-BRE step (the traversal's grid of an optimistic step)
+  uint32_t optRefuseEvery = 0, optSteps = 0, optRefused = 0;  // GVPM_OPTIMISTIC_REFUSE (tests); steps the guard refused
   bool evalUnits = true;  // G-BRE: the evaluation's queue serves work units, large parts first (GVPM_EVAL_UNITS=0: whole items in order)
   // per item and beam: photon index lists + their lengths
 

@@ -791,10 +791,12 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
                             h->bs->pairs.cap >= 128u && h->bs->pairCnt.cap >= (size_t)itemCap * h->beamsPerWave &&
                             (!h->evalUnits || h->bs->units.cap >= 2u);
     const bool fullVisOpt = !h->cfg.visibility_as_written || prevOverflow;
+    // (tests: GVPM_OPTIMISTIC_REFUSE=n makes the guard refuse every n-th optimistic step -- a pair buffer of zero blocks)
+    const bool refuse = optimistic && h->optRefuseEvery > 0 && (++h->optSteps % h->optRefuseEvery) == 0;
     launch_build_chain(c, a, h->rawDev, h->beamsPerWave, h->planTarget, h->bs->items.p, h->bs->itemOff.p, itemCap, cp.dmax, h->nearGrid,
                        (uint32_t)std::min<size_t>(h->bs->nearExt.cap, 0xFFFFFF00u), cp.wantOrig ? h->bs->origIdx.p : nullptr, h->pinCtl,
                        !h->bs->bucketsInit, h->bstream,
-                       optimistic ? (uint32_t)std::min<size_t>((h->bs->pairs.cap - 64u) / 64u, 0xFFFFFFF0u) : 0xFFFFFFFFu,
+                       optimistic ? (refuse ? 0u : (uint32_t)std::min<size_t>((h->bs->pairs.cap - 64u) / 64u, 0xFFFFFFF0u)) : 0xFFFFFFFFu,
                        optimistic && h->evalUnits ? (uint32_t)std::min<size_t>(h->bs->units.cap / 2u, 0x3FFFFFFFu) : 0u, eval_unit_pairs(),
                        fullVisOpt);
     h->bs->bucketsInit = true;
@@ -831,6 +833,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     HIP_TRY(h, hipMemsetAsync(h->bs->queueCtl.p + 5, 0, 3 * sizeof(uint32_t), h->bstream));
     HIP_TRY(h, hipStreamSynchronize(h->bstream));
     queued = false;
+    h->optRefused++;
   }
   if (a.grid.mode == 1 && h->pinCtl[4] != 0u && attempt == 0) {
     // not the bundle the cells were keyed for (another sensor, or later edges of the camera paths among the beams):

@@ -139,6 +139,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_BUILD_CHAIN")) h->buildChain = atoi(e) != 0;
   if (const char *e = getenv("GVPM_EVAL_UNITS")) h->evalUnits = atoi(e) != 0;
   if (const char *e = getenv("GVPM_OPTIMISTIC")) h->optimistic = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_OPTIMISTIC_REFUSE")) h->optRefuseEvery = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("GVPM_CLIP_GRID")) h->clipGrid = atoi(e) != 0;
   if (const char *e = getenv("GVPM_EVAL_ALT")) h->evalAlt = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
@@ -462,7 +463,8 @@ int gvpm_get_stats(gvpm_context *h, gvpm_stats *out) {
   out->diffuse_shifts = v[3];
   out->failed_shifts = v[4];
   out->dropped_pairs = v[7];
-  out->reserved[0] = ((uint64_t)h->lastGridMode << 56) | (uint64_t)h->lastGridCells;
+  // reserved[0]: kind of the last G-BRE grid << 56 | optimistic steps the build refused (24 bits) << 32 | its cells
+  out->reserved[0] = ((uint64_t)h->lastGridMode << 56) | ((uint64_t)(h->optRefused & 0xFFFFFFu) << 32) | (uint64_t)h->lastGridCells;
   out->reserved[1] = v[6];
   if (v[6]) return fail(h, GVPM_ERR_STATE, "packed photon records named materials beyond the uploaded table (decoded as black)");
   // the planner's bound on an item's pair region is exact: a dropped pair means a biased image, not a slow one

@@ -497,7 +497,14 @@ class Context:
         """G-BRE: (kind, cells) of the last build's photon cells -- kind 1: the ray-bundle cells (gvpm_stats.reserved[0])"""
         s = abi.Stats()
         self._check(lib().gvpm_get_stats(self._h, C.byref(s)))
-        return int(s.reserved[0]) >> 56, int(s.reserved[0]) & ((1 << 56) - 1)
+        return int(s.reserved[0]) >> 56, int(s.reserved[0]) & 0xFFFFFFFF
+
+    def refused_steps(self):
+        """G-BRE: optimistic steps whose traversal / evaluation the build's guard refused and the host queued again
+        (gvpm_stats.reserved[0] bits 32-55; GVPM_OPTIMISTIC_REFUSE forces them)"""
+        s = abi.Stats()
+        self._check(lib().gvpm_get_stats(self._h, C.byref(s)))
+        return (int(s.reserved[0]) >> 32) & 0xFFFFFF
 
     def kernel_time(self):
         ms, n = C.c_float(), C.c_uint32()

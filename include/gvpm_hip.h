@@ -306,8 +306,10 @@ typedef struct gvpm_stats {
   uint64_t null_shifts, diffuse_shifts, failed_shifts;
   uint64_t dropped_pairs; /* (photon, beam) pairs the traversal could not store: must be 0 -- gvpm_get_stats returns
                              GVPM_ERR_STATE otherwise (the image would be biased)  */
-  uint64_t reserved[2];   /* [0]: G-BRE, the last build's photon cells: kind << 56 | count; kind 0 = uniform 3D grid,
-                             1 = cells over the (u, v) plane of a single-origin ray bundle;
+  uint64_t reserved[2];   /* [0]: G-BRE, the last build's photon cells: kind << 56 | count (low 32 bits); kind 0 = uniform
+                             3D grid, 1 = cells over the (u, v) plane of a single-origin ray bundle;
+                             bits 32-55: steps whose traversal + evaluation were queued before the planner's counters were
+                             known and had to be queued again (a diagnostic, not an error);
                              [1]: packed photon records whose material index lay beyond the uploaded table (decoded with a
                              black parent): must be 0 -- gvpm_get_stats returns GVPM_ERR_STATE otherwise           */
 } gvpm_stats;

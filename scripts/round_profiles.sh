@@ -12,6 +12,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$tag/smoke.txt 2
 python tests/stress_bre.py cbox_rot fogroom_rot cbox_mirror_rot cbox_phong1_rot cbox_conductor_rot cbox_phong1 > gpurun_out/$tag/stress.txt 2>&1
 python tests/stress_vpm.py > gpurun_out/$tag/stress_vpm.txt 2>&1
 python tests/stress_beams.py > gpurun_out/$tag/stress_beams.txt 2>&1
+python tests/stress_planes.py > gpurun_out/$tag/stress_planes.txt 2>&1
 bash scripts/collect_profiles.sh $tag c2 c1 c3 c5 > gpurun_out/collect_$tag.log 2>&1
 bash scripts/shard_probe.sh gpurun_out/$tag > gpurun_out/$tag/${tag}_shard_probe.txt 2>&1
 cp profiles/${tag}_traffic*.json gpurun_out/$tag/ 2>/dev/null
