@@ -697,11 +697,14 @@ def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed
     sensor = sc.sensor()
     # (the packed records first: on a box whose GPU-side NUMA node is short of free memory the later pinned blocks land on
     # the far node and are read at ~33 GB/s instead of 55 -- seen on one box of the pool, after many processes had run)
-    compact = [hip.PinnedPacked(ph, rays, table, sensor=sensor, jitter=sc.jitter(i + 1, rays)) for i, (ph, nb, rays) in enumerate(host0)]
+    # (round 6: the photons of the headline as LINKED records, gvpm_pack_photons_linked -- 40 / 48 / 76 bytes by kind, ~50 a photon)
+    compact = [hip.PinnedPacked(ph, rays, table, sensor=sensor, jitter=sc.jitter(i + 1, rays), linked=not os.environ.get("GVPM_BENCH_NO_LINKED"))
+               for i, (ph, nb, rays) in enumerate(host0)]
+    compact76 = [hip.PinnedPacked(ph, rays, table, sensor=sensor, jitter=sc.jitter(i + 1, rays)) for i, (ph, nb, rays) in enumerate(host0[:2])]
     packed = [hip.PinnedPacked(ph, rays, table) for ph, nb, rays in host0[:2]]
     soa = [(hip.PinnedPhotons(ph.n).fill(ph), hip.PinnedRays(rays)) for ph, nb, rays in host0[:2]]
     nbs = [nb for ph, nb, rays in host0]
-    nbytes = {"compact": float(np.mean([c.nbytes for c in compact])), "packed": float(packed[0].nbytes),
+    nbytes = {"compact": float(np.mean([c.nbytes for c in compact])), "compact76": float(compact76[0].nbytes), "packed": float(packed[0].nbytes),
               "soa": float(host0[0][0].n * 120 + host0[0][2].nbytes)}
     ctx = hip.Context(p, device=device)
     ctx.upload_scene(*tris)
@@ -709,8 +712,8 @@ def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed
     ctx.upload_materials(table)
     ctx.upload_sensor(sensor)
     res = {}
-    for mode in os.environ.get("GVPM_BENCH_UPLOAD_MODES", "compact,packed,prefetch,serial").split(","):
-        sets = compact if mode == "compact" else (packed if mode == "packed" else soa)
+    for mode in os.environ.get("GVPM_BENCH_UPLOAD_MODES", "compact,compact76,packed,prefetch,serial").split(","):
+        sets = compact if mode == "compact" else (compact76 if mode == "compact76" else (packed if mode == "packed" else soa))
         ns = len(sets)
         best = None
         for rep in range(4):  # first pass: allocations; then the fastest of three (see "how")
@@ -718,12 +721,12 @@ def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed
             ctx.synchronize()
             ev0 = ctx.stats()["evaluations"]
             t0 = time.perf_counter()
-            if mode in ("compact", "packed"):
+            if mode in ("compact", "compact76", "packed"):
                 ctx.upload_pinned_packed(sets[0])
             else:
                 ctx.upload_pinned(*sets[0])
             for it in range(1, K + 1):
-                if mode in ("compact", "packed"):
+                if mode in ("compact", "compact76", "packed"):
                     if it < K:
                         ctx.prefetch_packed(sets[it % ns])
                 elif mode == "prefetch":
@@ -744,7 +747,7 @@ def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed
         if os.environ.get("GVPM_BENCH_UPLOAD_TRACE"):
             print("[upload] %s %.3f ms/step, %.0f evaluations/step" % (mode, dt / K * 1e3, ev / K), file=sys.stderr)
     ctx.close()
-    for c in compact + packed:
+    for c in compact + compact76 + packed:
         c.close()
     for a, b in soa:
         a.close()
@@ -764,9 +767,13 @@ def upload_inclusive(hip, sc, p, m, tris, host0, K, device, evals_per_step_timed
         "host_bytes_per_step": nbytes["compact"],
         "pcie_gb_per_s_at_this_rate": nbytes["compact"] / (head["ms_per_step"] * 1e-3) / 1e9,
         "sets": {"compact": compact[0].ncompact, "full": compact[0].nfull},
+        "photon_bytes": float(np.mean([c.photon_bytes for c in compact])) / max(1, compact[0].n),
+        "packed_photons_76": leg("compact76", nbytes["compact76"]),
         "packed": leg("packed", nbytes["packed"]),
         "soa": dict(leg("prefetch", nbytes["soa"]) or {}, ms_per_step_without_prefetch=(res.get("serial") or {}).get("ms_per_step")),
-        "how": "pinned host buffers: gvpm_pack_photons records (76 bytes a photon) + gvpm_pack_camera_beams_compact sets (60 bytes "
+        "how": "pinned host buffers: gvpm_pack_photons_linked blobs (40 / 48 / 76 bytes a photon by kind: its parent is the "
+               "previous photon, the emitter, anything else; `packed_photons_76`: round 3's 76-byte records beside the same sets) + "
+               "gvpm_pack_camera_beams_compact sets (60 bytes "
                "for a sensor-adjacent edge, rebuilt from gvpm_upload_sensor on the device; 272 for deeper edges), decoded at the "
                "head of the consuming gather's build; gvpm_prefetch_* of step N+1 before gvpm_gather of step N; the input sets "
                "of the timed region, in its order, gvpm_reset before every pass.  `packed`: round 3's records (76 / 272 bytes), "

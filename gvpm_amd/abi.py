@@ -136,6 +136,13 @@ HOST_SHIFT_DTYPE = np.dtype([
     ("ok", np.uint32), ("throughput", np.float32, 3), ("wi", np.float32, 3), ("pdf", np.float32), ("det_ratio", np.float32),
     ("base_pdf", np.float32)])
 assert SHIFT_REQUEST_DTYPE.itemsize == 64 and HOST_SHIFT_DTYPE.itemsize == 40
+# linked photon records (include/gvpm_hip.h, "linked photon records")
+PHOTON_EMIT_DTYPE = np.dtype([("pos", np.float32, 3), ("parent_pdf", np.float32), ("parent_pos", np.float32, 3), ("edge_pdf", np.float32),
+                              ("flux", np.float32, 3), ("flags", np.uint32)])
+PHOTON_CHAIN_DTYPE = np.dtype([("pos", np.float32, 3), ("parent_pdf", np.float32), ("flux", np.float32, 3), ("edge_pdf", np.float32),
+                               ("parent_rr", np.float32), ("flags", np.uint32)])
+EMITTER_ENTRY_DTYPE = np.dtype([("prefix_w", np.float32, 3), ("parent_rr", np.float32), ("parent_n", np.float32, 3), ("parent_g", np.float32)])
+assert PHOTON_EMIT_DTYPE.itemsize == 48 and PHOTON_CHAIN_DTYPE.itemsize == 40 and EMITTER_ENTRY_DTYPE.itemsize == 32
 RAY_PACKED_DTYPE = np.dtype([
     ("o", np.float32, 3), ("len", np.float32), ("d", np.float32, 3), ("pdf", np.float32), ("eye", np.float32, 3),
     ("jacobian", np.float32), ("gop", np.float32)])

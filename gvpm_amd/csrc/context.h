@@ -199,6 +199,7 @@ struct BuildSet {
   int tileW = 4, tileH = 4;
   bool scanSized = false, scanSizedChain = false;
   bool countsClean = false;  // cellCount is all zero (the build chain hands it back so)
+  size_t subCleanWords = 0;  // cellSub's first this-many words (the striped counters of the bundle cells) are zero, likewise
   DevBuf<uint32_t> chainBuckets;  // the build chain's bounds buckets (64 x 6), reset by the chain itself after the first use
   bool bucketsInit = false;
   DevBuf<uint4> items;
@@ -274,6 +275,7 @@ struct gvpm_context {
   // the cell fields are filled per build), -1 the rays are not a bundle (until gvpm_reset).
   bool bundleEnabled = false;
   bool bundleFromEnv = false;  // GVPM_BUNDLE given: the automatic choice below is off
+  bool bundleAuto = false;     // GVPM_BUNDLE_AUTO=1: bundle cells chosen per build for image-sharded input (the default until round 5)
   // Round 4: chosen per build when GVPM_BUNDLE is not set -- ON when the uploaded beam sets cover at most half of the
   // frame's pixels, i.e. the handle is one rank of an image-sharded run (its traversal walks the whole volume for a
   // fraction of the rays: the case the bundle cells measured -8 % on, C4 rank step 3.09 -> 2.85 ms), OFF otherwise.
@@ -314,6 +316,7 @@ struct gvpm_context {
     gvpm_photon_soa dev;    // device pointers into raw
     DevBuf<uint32_t> packed;  // a packed upload lands here and is decoded into raw (uploads.hip) by the consuming gather
     bool needUnpack = false;
+    bool linked = false;      // `packed` holds a blob of linked records (gvpm_upload_photons_linked)
     hipEvent_t unpacked = nullptr;
     hipEvent_t copied = nullptr;
     // recorded, on the gather stream and on the build stream, behind the kernels of every gather that read the slot
@@ -512,6 +515,8 @@ namespace gvpm {
 void launch_unpack_photons(const uint32_t *packed, uint32_t n, const gvpm_material *table, uint32_t table_n,
                            const gvpm_photon_soa &dst, unsigned long long *bad, hipStream_t s);
 void launch_unpack_rays(const uint32_t *packed, uint32_t nsets, gvpm_camera_ray *dst, hipStream_t s);
+void launch_unpack_linked(const uint32_t *blob, uint32_t n, const gvpm_material *table, uint32_t table_n, const gvpm_photon_soa &dst,
+                          unsigned long long *bad, hipStream_t s);
 void launch_unpack_compact_rays(const gvpm_sensor &sensor, const uint32_t *compact, uint32_t ncompact, gvpm_camera_ray *dst,
                                 hipStream_t s);
 }  // namespace gvpm

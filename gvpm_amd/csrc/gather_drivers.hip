@@ -252,7 +252,10 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   }
   if (nc > 0x7FFFFFFFull) return fail(h, GVPM_ERR_INVALID_ARG, "grid too large");
   g.ncells = (uint32_t)nc;
-  if (deferred && !h->bundleFromEnv) {
+  // (round 6: the automatic choice is OFF -- with the grid clipped to the beams' reach and the planner walking four chunks a wave
+  // the 3D grid is the faster one for a rank's share too: C4, rank 0 of 8 / of 4: 2.36-2.39 / 3.90 ms a step against 2.47 /
+  // 4.02 with the bundle cells, alternating runs.  GVPM_BUNDLE=1 forces them, GVPM_BUNDLE_AUTO=1 restores the choice.)
+  if (deferred && !h->bundleFromEnv && h->bundleAuto) {
     // "a rank's share of an image-sharded frame": the beam sets cover at most half of the pixels.  With hysteresis (ADVICE
     // round 4): a frame whose medium covers about half the pixels must not flip the cell kind -- and the planner's tuning with
     // it -- from step to step; the kind is left only beyond 0.6 / below 0.4 of the frame.
@@ -305,8 +308,14 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   // (bundle cells: striped counters, grid_build.hip cell_count_kernel)
   uint32_t *sub = nullptr;
   if (g.mode == 1) {
-    HIP_TRY(h, h->bs->cellSub.ensure((size_t)cell_stripes() * g.ncells));
-    HIP_TRY(h, hipMemsetAsync(h->bs->cellSub.p, 0, (size_t)cell_stripes() * g.ncells * sizeof(uint32_t), h->bstream));
+    // (the chain: counters + their prefixes, and the counters are handed back zeroed -- one memset when the array is new, has
+    // another size or was last used by the separate launches)
+    const size_t subWords = (size_t)cell_stripes() * g.ncells;
+    const uint32_t *was = h->bs->cellSub.p;
+    HIP_TRY(h, h->bs->cellSub.ensure(subWords * (chain ? 2u : 1u)));
+    if (!chain || h->bs->cellSub.p != was || h->bs->subCleanWords != subWords)
+      HIP_TRY(h, hipMemsetAsync(h->bs->cellSub.p, 0, subWords * sizeof(uint32_t), h->bstream));
+    h->bs->subCleanWords = chain ? subWords : 0u;
     sub = h->bs->cellSub.p;
   }
   // extension lists of the near-occluder lists: sized once per set for the largest photon count (grow only); word 0 is the
@@ -1490,7 +1499,8 @@ static int gatherEntry(gvpm_context *h, int it, uint64_t nb_paths, bool primal) 
       // (a packed record names its parent's material by index: without a table every parent would decode as black)
       if (h->nmaterials == 0)
         return fail(h, GVPM_ERR_STATE, "packed photons were uploaded but no material table (gvpm_upload_materials)");
-      launch_unpack_photons(ps.packed.p, (uint32_t)ps.dev.n, h->materials.p, h->nmaterials, ps.dev, h->stats.p + 6, us);
+      if (ps.linked) launch_unpack_linked(ps.packed.p, (uint32_t)ps.dev.n, h->materials.p, h->nmaterials, ps.dev, h->stats.p + 6, us);
+      else launch_unpack_photons(ps.packed.p, (uint32_t)ps.dev.n, h->materials.p, h->nmaterials, ps.dev, h->stats.p + 6, us);
       HIP_TRY(h, hipGetLastError());
       if (!ps.unpacked) HIP_TRY(h, hipEventCreateWithFlags(&ps.unpacked, hipEventDisableTiming));
       HIP_TRY(h, hipEventRecord(ps.unpacked, us));

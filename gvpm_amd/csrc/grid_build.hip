@@ -370,7 +370,7 @@ __device__ __forceinline__ void reorderBody(const RawPhotons &r, const uint32_t 
                                             uint32_t ntri, float dmax, const NearGrid &ng, uint32_t *nearExt,
                                             uint32_t extCap, float4 *hot, float4 *cold, uint32_t *overflow,
                                             uint32_t *origIdx, const uint32_t *__restrict__ sub, uint32_t ncells, uint32_t bid,
-                                            uint32_t *counts, ReorderLds &L) {
+                                            uint32_t *counts, uint32_t *subCount, ReorderLds &L) {
   // The record is assembled in LDS and written by EIGHT lanes (one 16-byte quad each): a store instruction then
   // covers whole 64-byte halves of eight records instead of sixty-four 16-byte pieces of sixty-four lines.  Two passes of four
   // quads (round 6: 5 KB of LDS a wave instead of 9.5 -- the kernel runs beside the evaluation and the traversal).
@@ -385,8 +385,13 @@ __device__ __forceinline__ void reorderBody(const RawPhotons &r, const uint32_t 
   if (live) {
     // (sub: the photon's rank counts within its stripe of the cell, cell_count_kernel)
     // (counts: the build chain -- no ranks were taken when the cells were counted; the counter is counted back down here)
-    const uint32_t i = counts ? cellStart[keys[src]] + (atomicSub(&counts[keys[src]], 1u) - 1u)
-                              : cellStart[keys[src]] + rank[src] + (sub ? sub[(size_t)(src % CELL_STRIPES) * ncells + keys[src]] : 0u);
+    // (subCount: the chain with bundle cells -- the stripe's counter is counted back down, its prefix within the cell is in `sub`)
+    uint32_t i;
+    if (counts) i = cellStart[keys[src]] + (atomicSub(&counts[keys[src]], 1u) - 1u);
+    else if (subCount) {
+      const size_t sk = (size_t)(src % CELL_STRIPES) * ncells + keys[src];
+      i = cellStart[keys[src]] + sub[sk] + (atomicSub(&subCount[sk], 1u) - 1u);
+    } else i = cellStart[keys[src]] + rank[src] + (sub ? sub[(size_t)(src % CELL_STRIPES) * ncells + keys[src]] : 0u);
     uint32_t bits = r.flags[src] & ~((1u << 6) | (1u << GVPM_HOT_PARITY_BIT));
     if (photonContributes(bits, cfg)) bits |= 1u << 6;
     bits |= (r.path_id[src] & 1u) << GVPM_HOT_PARITY_BIT;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(64) void reorder_kernel(RawPhotons r, const uint32_
                                                       uint32_t *origIdx, const uint32_t *__restrict__ sub, uint32_t ncells) {
   __shared__ ReorderLds L;
   reorderBody<MODE>(r, keys, rank, cellStart, n, cfg, bvh, tri4, ntri, dmax, ng, nearExt, extCap, hot, cold, overflow, origIdx, sub,
-                    ncells, blockIdx.x, nullptr, L);
+                    ncells, blockIdx.x, nullptr, nullptr, L);
 }
 
 // ---- the occluder grid of nearVisit: triangle i is listed in every cell its bounding box, grown by `reach`, overlaps and
@@ -1153,10 +1158,16 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs c) {
       mx[0] = px; mx[1] = py; mx[2] = pz;
       const Grid &g = c.g;
       if (g.mode == 1) {
+        // (bundle cells: 16 striped counters a cell -- every photon around a light the camera sees shares a handful of
+        // cells --, counted here, turned into prefixes by chain_stripes_kernel and counted back down by the scatter)
         const uint32_t k = bundlePhotonKey(g, px, py, pz);
         c.keys[i] = k;
-        if (k == GVPM_BUNDLE_DUMP_CELL(g.dim[0])) c.rank[i] = 0xFFFFFFFFu;
-        else c.rank[i] = atomicAdd(&c.sub[(size_t)(i % CELL_STRIPES) * g.ncells + k], 1u);
+        if (k == GVPM_BUNDLE_DUMP_CELL(g.dim[0])) {
+          c.rank[i] = 0xFFFFFFFFu;  // a photon no ray of the bundle can meet is not sorted at all
+        } else {
+          c.rank[i] = 0u;
+          (void)atomicAdd(&c.sub[(size_t)(i % CELL_STRIPES) * g.ncells + k], 1u);
+        }
       } else {
         const int cx = cellCoord(px, g.org[0], g.invCell, g.dim[0]);
         const int cy = cellCoord(py, g.org[1], g.invCell, g.dim[1]);
@@ -1208,6 +1219,21 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs c) {
     if (k < 3) (void)atomicMin(slot, ordCode(v));
     else (void)atomicMax(slot, ordCode(v));
   }
+}
+
+// (bundle cells) the stripes of a cell's counter -> exclusive prefixes within the cell (a second array: the counters stay, the
+// scatter counts them back down to zero), the cell's total to counts[]
+__global__ __launch_bounds__(256) void chain_stripes_kernel(const uint32_t *__restrict__ sub, uint32_t *__restrict__ prefix, uint32_t ncells,
+                                                            uint32_t *__restrict__ count) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ncells) return;
+  uint32_t run = 0;
+#pragma unroll
+  for (uint32_t st = 0; st < CELL_STRIPES; ++st) {
+    prefix[(size_t)st * ncells + k] = run;
+    run += sub[(size_t)st * ncells + k];
+  }
+  count[k] = run;
 }
 
 // K2: block sums; the last block to arrive turns them into block offsets and reduces the bounds' buckets
@@ -1345,6 +1371,7 @@ struct TailArgs {
   RawPhotons raw;
   const uint32_t *keys, *rank, *cellStart, *sub;
   uint32_t *counts;  // mode 0: the cells' counters, counted back down for the arrival ranks
+  uint32_t *subCount;  // bundle cells: the striped counters, counted back down (their prefixes: `sub`)
   uint32_t n, ncells, extCap;
   uint32_t every;    // every `every`-th block of the launch is a planner's, until they are nPlan
   float dmax;
@@ -1389,7 +1416,7 @@ template <int B, int MODE> __global__ __launch_bounds__(64) __attribute__((amdgp
   else
     reorderBody<MODE>(t.raw, t.keys, t.rank, t.cellStart, t.n, a.cfg, a.bvh, a.tri4, a.ntri, t.dmax, t.ng, t.nearExt, t.extCap, t.hot,
                       t.cold, t.overflow, t.origIdx, t.sub, t.ncells, b - min(t.nPlan, (b + t.every - 1u) / t.every), t.counts,
-                      *reinterpret_cast<ReorderLds *>(ldsRaw));
+                      t.subCount, *reinterpret_cast<ReorderLds *>(ldsRaw));
   if (!lastBlockArrives(t.ctl, blockIdx.x, gridDim.x)) return;
   if (threadIdx.x == 0) {
     // what export_u32_kernel handed the host: pair blocks, overflowed near lists, extension cursor, items, bundle flag
@@ -1430,7 +1457,9 @@ void launch_build_chain(ChainArgs c, const GatherArgs &a, const gvpm_photon_soa 
   if (initBuckets) hipLaunchKernelGGL(chain_init_buckets_kernel, dim3(1), dim3(768), 0, s, c.buckets);
   hipLaunchKernelGGL(chain_count_kernel, dim3(c.nPhBlocks + c.nBeamBlocks), dim3(256), 0, s, c);
   // (bundle cells: the stripes of a cell's counter -> exclusive prefixes within the cell, its total to counts[])
-  if (c.g.mode == 1) hipLaunchKernelGGL(cell_stripes_kernel, dim3((c.g.ncells + 255) / 256), dim3(256), 0, s, c.sub, c.g.ncells, c.counts);
+  if (c.g.mode == 1)
+    hipLaunchKernelGGL(chain_stripes_kernel, dim3((c.g.ncells + 255) / 256), dim3(256), 0, s, c.sub, c.sub + (size_t)CELL_STRIPES * c.g.ncells,
+                       c.g.ncells, c.counts);
   const uint32_t nScan = (c.scanLen + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(chain_scan_reduce_kernel, dim3(nScan), dim3(SCAN_BLOCK), 0, s, c);
   hipLaunchKernelGGL(chain_scan_down_kernel, dim3(nScan), dim3(SCAN_BLOCK), 0, s, c);
@@ -1459,7 +1488,8 @@ void launch_build_chain(ChainArgs c, const GatherArgs &a, const gvpm_photon_soa 
   t.keys = c.keys;
   t.rank = c.rank;
   t.cellStart = c.starts;
-  t.sub = c.g.mode == 1 ? c.sub : nullptr;
+  t.sub = c.g.mode == 1 ? c.sub + (size_t)CELL_STRIPES * c.g.ncells : nullptr;
+  t.subCount = c.g.mode == 1 ? c.sub : nullptr;
   t.counts = c.g.mode == 1 ? nullptr : c.counts;
   t.n = c.n;
   t.ncells = c.g.ncells;

@@ -144,6 +144,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_EVAL_ALT")) h->evalAlt = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
   if (const char *e = getenv("GVPM_BEAMS_SPLIT")) h->beamsSplit = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_BUNDLE_AUTO")) h->bundleAuto = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BUNDLE")) {
     h->bundleEnabled = atoi(e) != 0;
     h->bundleFromEnv = true;

@@ -76,6 +76,72 @@ GVPM_HD void unpackPhoton(const gvpm_photon_packed &r, const gvpm_material *tabl
   const_cast<uint32_t *>(d.path_id)[i] = (r.flags >> 7) & 1u;
 }
 
+// ---- linked photon records (include/gvpm_hip.h) ----
+GVPM_HD uint32_t linkedKind(const uint32_t *kinds, uint64_t i) { return (kinds[i >> 4] >> (2u * (uint32_t)(i & 15u))) & 3u; }
+// an emit record: everything of the parent but its position and pdfs comes from the blob's emitter table
+GVPM_HD void unpackEmit(const gvpm_photon_emit &r, const gvpm_emitter_entry *emitters, uint32_t n_emitters, const gvpm_photon_soa &d,
+                        uint64_t i) {
+  float *pos = const_cast<float *>(d.pos) + 3 * i, *wi = const_cast<float *>(d.wi) + 3 * i;
+  float *flux = const_cast<float *>(d.flux) + 3 * i, *pp = const_cast<float *>(d.parent_pos) + 3 * i;
+  float *pn = const_cast<float *>(d.parent_n) + 3 * i, *pw = const_cast<float *>(d.prefix_w) + 3 * i;
+  float *sc = const_cast<float *>(d.parent_scat) + 3 * i, *pwi = const_cast<float *>(d.parent_wi) + 3 * i;
+  const uint32_t e = r.flags >> 16;
+  const gvpm_emitter_entry t = e < n_emitters ? emitters[e] : gvpm_emitter_entry{{0.f, 0.f, 0.f}, 0.f, {0.f, 0.f, 0.f}, 0.f};
+  for (int c = 0; c < 3; ++c) {
+    pos[c] = r.pos[c];
+    pp[c] = r.parent_pos[c];
+    flux[c] = r.flux[c];
+    pw[c] = t.prefix_w[c];
+    pn[c] = t.parent_n[c];
+    sc[c] = 0.f;
+  }
+  pwi[0] = 1.f;
+  pwi[1] = pwi[2] = 0.f;
+  deriveWi(r.pos, r.parent_pos, wi);
+  const_cast<float *>(d.parent_g)[i] = t.parent_g;
+  const_cast<float *>(d.parent_pdf)[i] = r.parent_pdf;
+  const_cast<float *>(d.edge_pdf)[i] = r.edge_pdf;
+  const_cast<float *>(d.parent_rr)[i] = t.parent_rr;
+  const_cast<uint32_t *>(d.flags)[i] = (r.flags & 0xFF7Fu) | ((uint32_t)GVPM_BSDF_DIFFUSE_REFLECTION << 16);
+  const_cast<uint32_t *>(d.path_id)[i] = (r.flags >> 7) & 1u;
+}
+// a chain record, first pass: what the record itself and the material table hold
+GVPM_HD void unpackChainOwn(const gvpm_photon_chain &r, const gvpm_material *table, uint32_t table_n, const gvpm_photon_soa &d,
+                            uint64_t i) {
+  float *pos = const_cast<float *>(d.pos) + 3 * i, *flux = const_cast<float *>(d.flux) + 3 * i;
+  float *pn = const_cast<float *>(d.parent_n) + 3 * i, *sc = const_cast<float *>(d.parent_scat) + 3 * i;
+  const uint32_t mi = r.flags >> 16;
+  const gvpm_material m = mi < table_n ? table[mi] : gvpm_material{{0.f, 0.f, 0.f}, 0.f};
+  for (int c = 0; c < 3; ++c) {
+    pos[c] = r.pos[c];
+    flux[c] = r.flux[c];
+    pn[c] = 0.f;
+    sc[c] = m.scat[c];
+  }
+  const_cast<float *>(d.parent_g)[i] = m.g;
+  const_cast<float *>(d.parent_pdf)[i] = r.parent_pdf;
+  const_cast<float *>(d.edge_pdf)[i] = r.edge_pdf;
+  const_cast<float *>(d.parent_rr)[i] = r.parent_rr;
+  const_cast<uint32_t *>(d.flags)[i] = (r.flags & 0xFF7Fu) | ((uint32_t)GVPM_BSDF_DIFFUSE_REFLECTION << 16);
+  const_cast<uint32_t *>(d.path_id)[i] = (r.flags >> 7) & 1u;
+}
+// ... second pass (every position and flux of the upload is decoded by then): the link to the previous photon.
+// prevChain: photon i - 1 is a chain record itself -- its parent position is pos[i - 2] (its own link may not be written yet)
+GVPM_HD void linkChain(const gvpm_photon_soa &d, uint64_t i, bool prevChain) {
+  float *pp = const_cast<float *>(d.parent_pos) + 3 * i, *pw = const_cast<float *>(d.prefix_w) + 3 * i;
+  float *pwi = const_cast<float *>(d.parent_wi) + 3 * i, *wi = const_cast<float *>(d.wi) + 3 * i;
+  const float *prevPos = d.pos + 3 * (i - 1), *prevFlux = d.flux + 3 * (i - 1);
+  const float *prevParent = prevChain ? d.pos + 3 * (i - 2) : d.parent_pos + 3 * (i - 1);
+  float ppos[3];
+  for (int c = 0; c < 3; ++c) {
+    ppos[c] = prevPos[c];
+    pp[c] = ppos[c];
+    pw[c] = prevFlux[c];
+  }
+  deriveWi(ppos, prevParent, pwi);
+  deriveWi(d.pos + 3 * i, ppos, wi);
+}
+
 // ray k (0: base, 1..4: shifted) of a packed beam set -> a full camera ray
 GVPM_HD gvpm_camera_ray unpackRay(const gvpm_beam_set_packed &s, int k) {
   if (k == 0) return s.base;

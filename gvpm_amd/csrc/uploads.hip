@@ -29,9 +29,55 @@ __global__ __launch_bounds__(256) void unpack_compact_rays_kernel(gvpm_sensor se
   if (i < nsets * 5u) dst[i] = unpackCompactRay(sensor, src[i / 5u], (int)(i % 5u));
 }
 
+// linked records (pack_codec.h): first pass -- a wave takes 64 consecutive photons; the index of a photon's record within
+// its kind's array is the group's base + the lanes of that kind below it
+__global__ __launch_bounds__(256) void unpack_linked_kernel(const unsigned char *__restrict__ blob, const gvpm_material *__restrict__ table,
+                                                            uint32_t table_n, gvpm_photon_soa dst, unsigned long long *bad) {
+  const gvpm_linked_header hd = *reinterpret_cast<const gvpm_linked_header *>(blob);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < hd.n;
+  const uint32_t *kinds = reinterpret_cast<const uint32_t *>(blob + hd.off_kinds);
+  const uint32_t kind = live ? linkedKind(kinds, i) : 3u;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long mF = __ballot(kind == GVPM_LINKED_FULL), mE = __ballot(kind == GVPM_LINKED_EMIT), mC = __ballot(kind == GVPM_LINKED_CHAIN);
+  if (!live) return;
+  const uint2 base = reinterpret_cast<const uint2 *>(blob + hd.off_groups)[i >> 6];
+  if (kind == GVPM_LINKED_FULL) {
+    const gvpm_photon_packed &r = reinterpret_cast<const gvpm_photon_packed *>(blob + hd.off_full)[base.x + (uint32_t)__popcll(mF & below)];
+    if (r.material >= table_n) atomicAdd(bad, 1ull);
+    unpackPhoton(r, table, table_n, dst, i);
+  } else if (kind == GVPM_LINKED_EMIT) {
+    const gvpm_photon_emit &r = reinterpret_cast<const gvpm_photon_emit *>(blob + hd.off_emit)[base.y + (uint32_t)__popcll(mE & below)];
+    if ((r.flags >> 16) >= hd.n_emitters) atomicAdd(bad, 1ull);
+    unpackEmit(r, reinterpret_cast<const gvpm_emitter_entry *>(blob + hd.off_emitters), hd.n_emitters, dst, i);
+  } else {
+    const uint32_t cbase = (i & ~63u) - base.x - base.y;
+    const gvpm_photon_chain &r = reinterpret_cast<const gvpm_photon_chain *>(blob + hd.off_chain)[cbase + (uint32_t)__popcll(mC & below)];
+    if ((r.flags >> 16) >= table_n || i == 0u) atomicAdd(bad, 1ull);
+    unpackChainOwn(r, table, table_n, dst, i);
+  }
+}
+// ... second pass: the chain records' links
+__global__ __launch_bounds__(256) void link_linked_kernel(const unsigned char *__restrict__ blob, gvpm_photon_soa dst) {
+  const gvpm_linked_header hd = *reinterpret_cast<const gvpm_linked_header *>(blob);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0u || i >= hd.n) return;
+  const uint32_t *kinds = reinterpret_cast<const uint32_t *>(blob + hd.off_kinds);
+  if (linkedKind(kinds, i) != GVPM_LINKED_CHAIN) return;
+  linkChain(dst, i, i >= 2u && linkedKind(kinds, i - 1u) == GVPM_LINKED_CHAIN);
+}
+
 }  // namespace
 
 namespace gvpm {
+void launch_unpack_linked(const uint32_t *blob, uint32_t n, const gvpm_material *table, uint32_t table_n, const gvpm_photon_soa &dst,
+                          unsigned long long *bad, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(unpack_linked_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(blob), table,
+                     table_n, dst, bad);
+  hipLaunchKernelGGL(link_linked_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const unsigned char *>(blob), dst);
+}
 void launch_unpack_compact_rays(const gvpm_sensor &sensor, const uint32_t *compact, uint32_t ncompact, gvpm_camera_ray *dst,
                                 hipStream_t s) {
   if (ncompact)
@@ -124,6 +170,223 @@ int gvpm_unpack_photons(const gvpm_photon_packed *src, uint64_t n, const gvpm_ma
     if (src[i].material >= table_n) return GVPM_ERR_INVALID_ARG;
     unpackPhoton(src[i], table, table_n, *dst, i);
   }
+  return GVPM_OK;
+}
+
+// ---- linked photon records (include/gvpm_hip.h) ----
+static size_t align16(size_t x) { return (x + 15u) & ~(size_t)15u; }
+static void linkedLayout(gvpm_linked_header &hd) {
+  size_t off = sizeof(gvpm_linked_header);
+  hd.off_kinds = (uint32_t)off;
+  off = align16(off + (((size_t)hd.n + 15u) / 16u) * 4u);
+  hd.off_groups = (uint32_t)off;
+  off = align16(off + (((size_t)hd.n + 63u) / 64u) * 8u);
+  hd.off_emitters = (uint32_t)off;
+  off = align16(off + (size_t)hd.n_emitters * sizeof(gvpm_emitter_entry));
+  hd.off_full = (uint32_t)off;
+  off = align16(off + (size_t)hd.n_full * sizeof(gvpm_photon_packed));
+  hd.off_emit = (uint32_t)off;
+  off = align16(off + (size_t)hd.n_emit * sizeof(gvpm_photon_emit));
+  hd.off_chain = (uint32_t)off;
+  off = align16(off + (size_t)hd.n_chain * sizeof(gvpm_photon_chain));
+  hd.bytes = (uint32_t)off;
+}
+size_t gvpm_linked_photons_bound(uint64_t n) {
+  gvpm_linked_header hd{};
+  hd.n = hd.n_full = (uint32_t)std::min<uint64_t>(n, 0x3FFFFFFFull);
+  hd.n_emitters = 1024u;
+  linkedLayout(hd);
+  return (size_t)hd.bytes + 64u;
+}
+
+int gvpm_pack_photons_linked(const gvpm_photon_soa *src, void *blob, size_t cap, gvpm_material *table, uint32_t table_cap,
+                             uint32_t *table_n, size_t *bytes) {
+  if (!src || !table_n || !bytes || !blob || (src->n && !table)) return GVPM_ERR_INVALID_ARG;
+  const uint64_t n = src->n;
+  // 76 B x 2^25 photons keeps every offset below 2^32
+  if (n > (1ull << 25)) return GVPM_ERR_INVALID_ARG;
+  if (table_cap > 65536u) table_cap = 65536u;
+  uint32_t nt = *table_n, lastM = 0, lastE = 0;
+  if (nt > table_cap) return GVPM_ERR_INVALID_ARG;
+  // pass 1: the kind of every photon (every short kind is VERIFIED against the source), the tables
+  std::vector<uint8_t> kind(n, (uint8_t)GVPM_LINKED_FULL);
+  std::vector<uint16_t> idx(n, 0);
+  std::vector<gvpm_emitter_entry> emitters;
+  auto material = [&](uint64_t i, uint32_t &k) -> bool {
+    gvpm_material m;
+    m.scat[0] = src->parent_scat[3 * i];
+    m.scat[1] = src->parent_scat[3 * i + 1];
+    m.scat[2] = src->parent_scat[3 * i + 2];
+    m.g = src->parent_g[i];
+    k = lastM;
+    if (!(k < nt && memcmp(&table[k], &m, sizeof(m)) == 0)) {
+      for (k = 0; k < nt; ++k)
+        if (memcmp(&table[k], &m, sizeof(m)) == 0) break;
+      if (k == nt) {
+        if (nt >= table_cap) return false;
+        table[nt++] = m;
+      }
+    }
+    lastM = k;
+    return true;
+  };
+  auto same3 = [](const float *a, const float *b) { return memcmp(a, b, 12) == 0; };
+  const float zero3[3] = {0.f, 0.f, 0.f}, ex3[3] = {1.f, 0.f, 0.f};
+  uint64_t nf = 0, ne = 0, nc = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t fl = src->flags[i];
+    const uint32_t ptype = GVPM_PF_PARENT_TYPE(fl), comp = GVPM_PF_PREV_COMPONENT(fl);
+    bool done = false;
+    if (i > 0 && ptype == GVPM_PARENT_MEDIUM && comp == (uint32_t)GVPM_BSDF_DIFFUSE_REFLECTION && src->path_id[i] == src->path_id[i - 1] &&
+        same3(src->parent_pos + 3 * i, src->pos + 3 * (i - 1)) && same3(src->prefix_w + 3 * i, src->flux + 3 * (i - 1)) &&
+        same3(src->parent_n + 3 * i, zero3)) {
+      // the link's parent_wi (derived from the two positions before the photon) against the source's: within the octahedral
+      // code's error of a full record, or the photon travels as one
+      const float *pPrev = src->pos + 3 * (i - 1);
+      const float *ppPrev = kind[i - 1] == GVPM_LINKED_CHAIN ? src->pos + 3 * (i - 2) : src->parent_pos + 3 * (i - 1);
+      float w[3];
+      gvpm::deriveWi(pPrev, ppPrev, w);
+      const float *t = src->parent_wi + 3 * i;
+      const double cx = (double)w[1] * t[2] - (double)w[2] * t[1], cy = (double)w[2] * t[0] - (double)w[0] * t[2], cz = (double)w[0] * t[1] - (double)w[1] * t[0];
+      const double dt = (double)w[0] * t[0] + (double)w[1] * t[1] + (double)w[2] * t[2];
+      uint32_t k;
+      if (std::sqrt(cx * cx + cy * cy + cz * cz) <= 6e-5 && dt > 0.0) {
+        if (!material(i, k)) return GVPM_ERR_INVALID_ARG;
+        if (k < 65536u) {
+          kind[i] = (uint8_t)GVPM_LINKED_CHAIN;
+          idx[i] = (uint16_t)k;
+          ++nc;
+          done = true;
+        }
+      }
+    }
+    if (!done && ptype == GVPM_PARENT_EMITTER && comp == (uint32_t)GVPM_BSDF_DIFFUSE_REFLECTION && same3(src->parent_scat + 3 * i, zero3) &&
+        same3(src->parent_wi + 3 * i, ex3)) {
+      gvpm_emitter_entry e;
+      memcpy(e.prefix_w, src->prefix_w + 3 * i, 12);
+      e.parent_rr = src->parent_rr[i];
+      memcpy(e.parent_n, src->parent_n + 3 * i, 12);
+      e.parent_g = src->parent_g[i];
+      uint32_t k = lastE;
+      if (!(k < emitters.size() && memcmp(&emitters[k], &e, sizeof(e)) == 0)) {
+        for (k = 0; k < emitters.size(); ++k)
+          if (memcmp(&emitters[k], &e, sizeof(e)) == 0) break;
+        if (k == emitters.size() && k < 1024u) emitters.push_back(e);
+      }
+      if (k < emitters.size()) {
+        lastE = k;
+        kind[i] = (uint8_t)GVPM_LINKED_EMIT;
+        idx[i] = (uint16_t)k;
+        ++ne;
+        done = true;
+      }
+    }
+    if (!done) ++nf;
+  }
+  gvpm_linked_header hd{};
+  hd.magic = GVPM_LINKED_MAGIC;
+  hd.n = (uint32_t)n;
+  hd.n_full = (uint32_t)nf;
+  hd.n_emit = (uint32_t)ne;
+  hd.n_chain = (uint32_t)nc;
+  hd.n_emitters = (uint32_t)emitters.size();
+  linkedLayout(hd);
+  if ((size_t)hd.bytes > cap) return GVPM_ERR_INVALID_ARG;
+  unsigned char *B = static_cast<unsigned char *>(blob);
+  memset(B, 0, hd.off_full);
+  memcpy(B, &hd, sizeof(hd));
+  uint32_t *kinds = reinterpret_cast<uint32_t *>(B + hd.off_kinds);
+  uint32_t *groups = reinterpret_cast<uint32_t *>(B + hd.off_groups);
+  if (!emitters.empty()) memcpy(B + hd.off_emitters, emitters.data(), emitters.size() * sizeof(gvpm_emitter_entry));
+  gvpm_photon_packed *F = reinterpret_cast<gvpm_photon_packed *>(B + hd.off_full);
+  gvpm_photon_emit *E = reinterpret_cast<gvpm_photon_emit *>(B + hd.off_emit);
+  gvpm_photon_chain *Cn = reinterpret_cast<gvpm_photon_chain *>(B + hd.off_chain);
+  uint64_t jf = 0, je = 0, jc = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if ((i & 63u) == 0u) {
+      groups[2 * (i >> 6)] = (uint32_t)jf;
+      groups[2 * (i >> 6) + 1] = (uint32_t)je;
+    }
+    kinds[i >> 4] |= (uint32_t)kind[i] << (2u * (uint32_t)(i & 15u));
+    const uint32_t lo = (src->flags[i] & 0xFF7Fu) | ((src->path_id[i] & 1u) << 7);
+    if (kind[i] == GVPM_LINKED_CHAIN) {
+      gvpm_photon_chain &r = Cn[jc++];
+      memcpy(r.pos, src->pos + 3 * i, 12);
+      memcpy(r.flux, src->flux + 3 * i, 12);
+      r.parent_pdf = src->parent_pdf[i];
+      r.edge_pdf = src->edge_pdf[i];
+      r.parent_rr = src->parent_rr[i];
+      r.flags = lo | ((uint32_t)idx[i] << 16);
+    } else if (kind[i] == GVPM_LINKED_EMIT) {
+      gvpm_photon_emit &r = E[je++];
+      memcpy(r.pos, src->pos + 3 * i, 12);
+      memcpy(r.parent_pos, src->parent_pos + 3 * i, 12);
+      memcpy(r.flux, src->flux + 3 * i, 12);
+      r.parent_pdf = src->parent_pdf[i];
+      r.edge_pdf = src->edge_pdf[i];
+      r.flags = lo | ((uint32_t)idx[i] << 16);
+    } else {
+      gvpm_photon_packed &r = F[jf++];
+      for (int c = 0; c < 3; ++c) {
+        r.pos[c] = src->pos[3 * i + c];
+        r.parent_pos[c] = src->parent_pos[3 * i + c];
+        r.flux[c] = src->flux[3 * i + c];
+        r.prefix_w[c] = src->prefix_w[3 * i + c];
+      }
+      r.parent_pdf = src->parent_pdf[i];
+      r.edge_pdf = src->edge_pdf[i];
+      r.parent_rr = src->parent_rr[i];
+      r.parent_n_oct = octEncode(src->parent_n + 3 * i);
+      r.parent_wi_oct = octEncode(src->parent_wi + 3 * i);
+      r.flags = (src->flags[i] & ~(1u << 7)) | ((src->path_id[i] & 1u) << 7);
+      uint32_t k;
+      if (!material(i, k)) return GVPM_ERR_INVALID_ARG;
+      r.material = k;
+    }
+  }
+  *table_n = nt;
+  *bytes = hd.bytes;
+  return GVPM_OK;
+}
+
+static bool linkedHeaderOk(const gvpm_linked_header &hd, size_t bytes) {
+  gvpm_linked_header want = hd;
+  linkedLayout(want);
+  return hd.magic == GVPM_LINKED_MAGIC && (size_t)hd.n_full + hd.n_emit + hd.n_chain == hd.n && want.bytes == hd.bytes &&
+         (size_t)hd.bytes <= bytes && want.off_kinds == hd.off_kinds && want.off_groups == hd.off_groups &&
+         want.off_emitters == hd.off_emitters && want.off_full == hd.off_full && want.off_emit == hd.off_emit &&
+         want.off_chain == hd.off_chain;
+}
+
+int gvpm_unpack_photons_linked(const void *blob, size_t bytes, const gvpm_material *table, uint32_t table_n, const gvpm_photon_soa *dst) {
+  if (!blob || bytes < sizeof(gvpm_linked_header) || !dst) return GVPM_ERR_INVALID_ARG;
+  const unsigned char *B = static_cast<const unsigned char *>(blob);
+  gvpm_linked_header hd;
+  memcpy(&hd, B, sizeof(hd));
+  if (!linkedHeaderOk(hd, bytes)) return GVPM_ERR_INVALID_ARG;
+  const uint32_t *kinds = reinterpret_cast<const uint32_t *>(B + hd.off_kinds);
+  const gvpm_emitter_entry *emitters = reinterpret_cast<const gvpm_emitter_entry *>(B + hd.off_emitters);
+  const gvpm_photon_packed *F = reinterpret_cast<const gvpm_photon_packed *>(B + hd.off_full);
+  const gvpm_photon_emit *E = reinterpret_cast<const gvpm_photon_emit *>(B + hd.off_emit);
+  const gvpm_photon_chain *Cn = reinterpret_cast<const gvpm_photon_chain *>(B + hd.off_chain);
+  uint64_t jf = 0, je = 0, jc = 0;
+  for (uint64_t i = 0; i < hd.n; ++i) {
+    const uint32_t k = gvpm::linkedKind(kinds, i);
+    if (k == GVPM_LINKED_FULL) {
+      if (jf >= hd.n_full || F[jf].material >= table_n) return GVPM_ERR_INVALID_ARG;
+      gvpm::unpackPhoton(F[jf++], table, table_n, *dst, i);
+    } else if (k == GVPM_LINKED_EMIT) {
+      if (je >= hd.n_emit || (E[je].flags >> 16) >= hd.n_emitters) return GVPM_ERR_INVALID_ARG;
+      gvpm::unpackEmit(E[je++], emitters, hd.n_emitters, *dst, i);
+    } else if (k == GVPM_LINKED_CHAIN) {
+      if (jc >= hd.n_chain || i == 0 || (Cn[jc].flags >> 16) >= table_n) return GVPM_ERR_INVALID_ARG;
+      gvpm::unpackChainOwn(Cn[jc++], table, table_n, *dst, i);
+    } else {
+      return GVPM_ERR_INVALID_ARG;
+    }
+  }
+  for (uint64_t i = 1; i < hd.n; ++i)
+    if (gvpm::linkedKind(kinds, i) == GVPM_LINKED_CHAIN) gvpm::linkChain(*dst, i, i >= 2 && gvpm::linkedKind(kinds, i - 1) == GVPM_LINKED_CHAIN);
   return GVPM_OK;
 }
 
@@ -377,7 +640,8 @@ static int uploadPhotonsCommon(gvpm_context *h, const gvpm_photon_soa *p, bool f
 // left to the gather that consumes the slot, at the head of its build (gvpm_gather): a kernel on the copy stream would
 // sit between two copies and wait for compute units behind the gather kernels of the step in flight -- measured at C2,
 // 4.7 ms a step that way against 3.6 for the SoA upload it was to beat
-static int uploadPhotonsPacked(gvpm_context *h, const gvpm_photon_packed *src, uint64_t n64, bool prefetch) {
+// (linkedBytes != 0: `src` is a blob of linked records of that size, n64 its photon count)
+static int uploadPhotonsPacked(gvpm_context *h, const gvpm_photon_packed *src, uint64_t n64, bool prefetch, size_t linkedBytes = 0) {
   if (n64 && !src) return fail(h, GVPM_ERR_INVALID_ARG, "null packed photons");
   if (n64 > 0x7FFFFFF0ull) return fail(h, GVPM_ERR_INVALID_ARG, "too many photons");
   const uint32_t n = (uint32_t)n64;
@@ -393,12 +657,15 @@ static int uploadPhotonsPacked(gvpm_context *h, const gvpm_photon_packed *src, u
   }
   ps.read = false;
   constexpr size_t RW = sizeof(gvpm_photon_packed) / 4;
-  if (ps.raw.cap < (size_t)n * 30 + 8 || ps.packed.cap < (size_t)n * RW + 8) {
+  const size_t packedWords = linkedBytes ? (linkedBytes + 3u) / 4u + 8u : (size_t)n * RW + 8;
+  if (ps.raw.cap < (size_t)n * 30 + 8 || ps.packed.cap < packedWords) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->streamB));
     HIP_TRY(h, hipStreamSynchronize(h->copyStream));
     HIP_TRY(h, ps.raw.ensure((size_t)n * 30 + 8));
-    HIP_TRY(h, ps.packed.ensure((size_t)n * RW + 8));
+    // (a blob of linked records is never larger than the packed records of its photons + its tables: sized for those, so that
+    // blobs of varying size do not regrow the slot)
+    HIP_TRY(h, ps.packed.ensure(std::max(packedWords, (size_t)n * RW + 8 + 16384u)));
   }
   const void **dst[14] = {(const void **)&ps.dev.pos, (const void **)&ps.dev.wi, (const void **)&ps.dev.flux,
                           (const void **)&ps.dev.parent_pos, (const void **)&ps.dev.parent_n, (const void **)&ps.dev.prefix_w,
@@ -411,8 +678,9 @@ static int uploadPhotonsPacked(gvpm_context *h, const gvpm_photon_packed *src, u
     off += (size_t)n * (k < 8 ? 3 : 1);
   }
   ps.dev.n = n;
-  if (n) HIP_TRY(h, hipMemcpyAsync(ps.packed.p, src, (size_t)n * sizeof(gvpm_photon_packed), hipMemcpyHostToDevice, h->copyStream));
+  if (n) HIP_TRY(h, hipMemcpyAsync(ps.packed.p, src, linkedBytes ? linkedBytes : (size_t)n * sizeof(gvpm_photon_packed), hipMemcpyHostToDevice, h->copyStream));
   ps.needUnpack = n > 0;
+  ps.linked = linkedBytes != 0;
   HIP_TRY(h, hipEventRecord(ps.copied, h->copyStream));
   if (!pinned) HIP_TRY(h, hipStreamSynchronize(h->copyStream));
   if (prefetch) {
@@ -436,6 +704,22 @@ int gvpm_upload_photons_packed(gvpm_context *h, const gvpm_photon_packed *photon
 int gvpm_prefetch_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n) {
   CHECK_H(h);
   return uploadPhotonsPacked(h, photons, n, true);
+}
+static int uploadLinked(gvpm_context *h, const void *blob, size_t bytes, bool prefetch) {
+  if (!blob || bytes < sizeof(gvpm_linked_header)) return fail(h, GVPM_ERR_INVALID_ARG, "null or short blob of linked photon records");
+  gvpm_linked_header hd;
+  memcpy(&hd, blob, sizeof(hd));
+  if (!linkedHeaderOk(hd, bytes)) return fail(h, GVPM_ERR_INVALID_ARG, "not a blob of gvpm_pack_photons_linked (header / sizes)");
+  if (hd.n == 0u) return uploadPhotonsPacked(h, nullptr, 0, prefetch);
+  return uploadPhotonsPacked(h, static_cast<const gvpm_photon_packed *>(blob), hd.n, prefetch, hd.bytes);
+}
+int gvpm_upload_photons_linked(gvpm_context *h, const void *blob, size_t bytes) {
+  CHECK_H(h);
+  return uploadLinked(h, blob, bytes, false);
+}
+int gvpm_prefetch_photons_linked(gvpm_context *h, const void *blob, size_t bytes) {
+  CHECK_H(h);
+  return uploadLinked(h, blob, bytes, true);
 }
 
 int gvpm_upload_photons(gvpm_context *h, const gvpm_photon_soa *p) {

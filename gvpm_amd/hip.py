@@ -30,6 +30,8 @@ SYMBOLS = [
     "gvpm_pack_photons", "gvpm_unpack_photons", "gvpm_pack_camera_beams", "gvpm_unpack_camera_beams", "gvpm_upload_materials",
     "gvpm_upload_photons_packed", "gvpm_prefetch_photons_packed", "gvpm_upload_camera_beams_packed",
     "gvpm_prefetch_camera_beams_packed",
+    "gvpm_linked_photons_bound", "gvpm_pack_photons_linked", "gvpm_unpack_photons_linked", "gvpm_upload_photons_linked",
+    "gvpm_prefetch_photons_linked",
     "gvpm_enable_host_shifts", "gvpm_download_shift_requests", "gvpm_upload_host_shifts",
     "gvpm_upload_sensor", "gvpm_pack_camera_beams_compact", "gvpm_unpack_camera_beams_compact",
     "gvpm_upload_camera_beams_compact", "gvpm_prefetch_camera_beams_compact", "gvpm_upload_bsdfs", "gvpm_gather_primal",
@@ -81,6 +83,12 @@ def lib():
         L.gvpm_download_accum_dev.argtypes = [vp, vp]
         L.gvpm_download_film.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.gvpm_synchronize.argtypes = [vp]
+        L.gvpm_linked_photons_bound.argtypes = [C.c_uint64]
+        L.gvpm_linked_photons_bound.restype = C.c_size_t
+        L.gvpm_pack_photons_linked.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp]
+        L.gvpm_unpack_photons_linked.argtypes = [vp, C.c_size_t, vp, C.c_uint32, vp]
+        L.gvpm_upload_photons_linked.argtypes = [vp, vp, C.c_size_t]
+        L.gvpm_prefetch_photons_linked.argtypes = [vp, vp, C.c_size_t]
         L.gvpm_comm_unique_id.argtypes = [vp]
         L.gvpm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
         L.gvpm_allreduce_accum.argtypes = [vp]
@@ -209,6 +217,46 @@ def unpack_photons(packed, table):
     return ph
 
 
+def linked_photons_bound(n):
+    return int(lib().gvpm_linked_photons_bound(n))
+
+
+def pack_photons_linked(ph, table, out=None):
+    """gvpm_pack_photons_linked: abi.Photons -> one blob of linked records (uint8 array of the blob's size; a view of `out`
+    -- e.g. pinned memory of linked_photons_bound(n) bytes -- when given).  Plain host code: works without a GPU."""
+    cap = linked_photons_bound(ph.n)
+    if out is None:
+        out = np.zeros(cap, np.uint8)
+    assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
+    soa = ph.soa()
+    cnt, nbytes = C.c_uint32(table.n), C.c_size_t(0)
+    rc = lib().gvpm_pack_photons_linked(C.byref(soa), out.ctypes.data, out.size, table.table.ctypes.data, table.table.size,
+                                        C.byref(cnt), C.byref(nbytes))
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_pack_photons_linked failed (blob capacity or a table exhausted?)")
+    table.n = cnt.value
+    return out[:nbytes.value]
+
+
+def linked_header(blob):
+    """the gvpm_linked_header of a blob as a dict"""
+    w = np.frombuffer(blob[:64].tobytes(), np.uint32)
+    names = ("magic", "n", "n_full", "n_emit", "n_chain", "n_emitters", "off_kinds", "off_groups", "off_emitters", "off_full",
+             "off_emit", "off_chain", "bytes")
+    return {k: int(w[i]) for i, k in enumerate(names)}
+
+
+def unpack_photons_linked(blob, table):
+    """gvpm_unpack_photons_linked: what the device makes of a blob, as abi.Photons"""
+    blob = np.ascontiguousarray(blob)
+    ph = abi.Photons(linked_header(blob)["n"])
+    soa = ph.soa()
+    rc = lib().gvpm_unpack_photons_linked(blob.ctypes.data, blob.size, table.table.ctypes.data, table.n, C.byref(soa))
+    if rc != 0:
+        raise GvpmError(rc, "gvpm_unpack_photons_linked failed")
+    return ph
+
+
 def pack_camera_beams(rays, out=None):
     """gvpm_pack_camera_beams: (nsets, 5) camera rays -> nsets records of 272 bytes (uint8 array (nsets, 272))"""
     rays = np.ascontiguousarray(rays)
@@ -269,27 +317,35 @@ class PinnedPacked:
     gvpm_upload_*_packed / gvpm_prefetch_*_packed.  With sensor + jitter the beam sets are split into compact records
     (60 bytes) and full ones (272) as gvpm_pack_camera_beams_compact does; otherwise every set is a full record."""
 
-    def __init__(self, ph, rays, table, sensor=None, jitter=None):
+    def __init__(self, ph, rays, table, sensor=None, jitter=None, linked=False):
         self.n = ph.n
         self.nsets = np.asarray(rays).size // 5
         self.compact = sensor is not None
+        self.linked = bool(linked) and ph.n > 0
         self._pp, self._pr, self._pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        for ptr, nbytes in ((self._pp, self.n * 76), (self._pr, self.nsets * 272)) + (((self._pc, self.nsets * 60),) if self.compact else ()):
+        pcap = linked_photons_bound(self.n) if self.linked else self.n * 76
+        for ptr, nbytes in ((self._pp, pcap), (self._pr, self.nsets * 272)) + (((self._pc, self.nsets * 60),) if self.compact else ()):
             rc = lib().gvpm_host_alloc(max(nbytes, 64), C.byref(ptr))
             if rc != 0:
                 raise GvpmError(rc, "gvpm_host_alloc failed")
-        pv = np.frombuffer((C.c_char * (self.n * 76)).from_address(self._pp.value), abi.PHOTON_PACKED_DTYPE) if self.n else np.zeros(0, abi.PHOTON_PACKED_DTYPE)
         rv = np.frombuffer((C.c_char * (self.nsets * 272)).from_address(self._pr.value), np.uint8).reshape(self.nsets, 272) if self.nsets else np.zeros((0, 272), np.uint8)
-        pack_photons(ph, table, out=pv)
+        if self.linked:
+            # one blob of linked records (gvpm_pack_photons_linked): 40 / 48 / 76 bytes a photon
+            bv = np.frombuffer((C.c_char * pcap).from_address(self._pp.value), np.uint8)
+            self.photon_bytes = int(pack_photons_linked(ph, table, out=bv).size)
+        else:
+            pv = np.frombuffer((C.c_char * (self.n * 76)).from_address(self._pp.value), abi.PHOTON_PACKED_DTYPE) if self.n else np.zeros(0, abi.PHOTON_PACKED_DTYPE)
+            pack_photons(ph, table, out=pv)
+            self.photon_bytes = self.n * 76
         if self.compact:
             cv = np.frombuffer((C.c_char * (self.nsets * 60)).from_address(self._pc.value), abi.BEAM_SET_COMPACT_DTYPE) if self.nsets else np.zeros(0, abi.BEAM_SET_COMPACT_DTYPE)
             c, f, self.new_index = pack_camera_beams_compact(sensor, rays, jitter, out_compact=cv, out_full=rv)
             self.ncompact, self.nfull = int(c.size), int(f.shape[0])
-            self.nbytes = self.n * 76 + self.ncompact * 60 + self.nfull * 272
+            self.nbytes = self.photon_bytes + self.ncompact * 60 + self.nfull * 272
         else:
             pack_camera_beams(rays, out=rv)
             self.ncompact, self.nfull = 0, self.nsets
-            self.nbytes = self.n * 76 + self.nsets * 272
+            self.nbytes = self.photon_bytes + self.nsets * 272
 
     def close(self):
         for ptr in (self._pp, self._pr, self._pc):
@@ -407,8 +463,15 @@ class Context:
         self._check(lib().gvpm_upload_camera_beams_compact(self._h, compact.ctypes.data if nc else None, nc,
                                                            full.ctypes.data if nf else None, nf))
 
+    def upload_photons_linked(self, blob):
+        blob = np.ascontiguousarray(blob)
+        self._check(lib().gvpm_upload_photons_linked(self._h, blob.ctypes.data, blob.size))
+
     def upload_pinned_packed(self, pk):
-        self._check(lib().gvpm_upload_photons_packed(self._h, pk._pp, pk.n))
+        if pk.linked:
+            self._check(lib().gvpm_upload_photons_linked(self._h, pk._pp, pk.photon_bytes))
+        else:
+            self._check(lib().gvpm_upload_photons_packed(self._h, pk._pp, pk.n))
         if pk.compact:
             self._check(lib().gvpm_upload_camera_beams_compact(self._h, pk._pc if pk.ncompact else None, pk.ncompact,
                                                                pk._pr if pk.nfull else None, pk.nfull))
@@ -416,7 +479,10 @@ class Context:
             self._check(lib().gvpm_upload_camera_beams_packed(self._h, pk._pr, pk.nsets))
 
     def prefetch_packed(self, pk):
-        self._check(lib().gvpm_prefetch_photons_packed(self._h, pk._pp, pk.n))
+        if pk.linked:
+            self._check(lib().gvpm_prefetch_photons_linked(self._h, pk._pp, pk.photon_bytes))
+        else:
+            self._check(lib().gvpm_prefetch_photons_packed(self._h, pk._pp, pk.n))
         if pk.compact:
             self._check(lib().gvpm_prefetch_camera_beams_compact(self._h, pk._pc if pk.ncompact else None, pk.ncompact,
                                                                  pk._pr if pk.nfull else None, pk.nfull))

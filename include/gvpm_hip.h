@@ -460,6 +460,70 @@ int gvpm_upload_materials(gvpm_context *h, const gvpm_material *table, uint32_t 
 /* as gvpm_upload_photons / gvpm_prefetch_photons (pageable or pinned memory; prefetch: pinned only)                       */
 int gvpm_upload_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n);
 int gvpm_prefetch_photons_packed(gvpm_context *h, const gvpm_photon_packed *photons, uint64_t n);
+
+/* ---- linked photon records (round 6) ---------------------------------------*/
+/* The photons of one light path are CONSECUTIVE vertices (GPhotonMap::tryAppend walks the path, gvpm/gvpm_accel.h:119-199):
+ * most of what a 76-byte record carries of its parent is already on the wire.  Three record kinds, chosen per photon by the
+ * packer, which VERIFIES each choice against the SoA source (a photon that does not fit a short kind travels as a full one):
+ *   chain (40 bytes) -- the parent is the medium vertex that IS the previous photon of the upload (same path, MEDIUM parent):
+ *                       parent_pos = pos[i-1], prefix_w = flux[i-1] (the path weight up to the parent, bit for bit),
+ *                       parent_wi = the previous photon's wi, parent_n = 0, parent_scat / parent_g = entry `component field of
+ *                       flags` of the material table; the record keeps pos, flux, the three pdfs / weights, flags;
+ *   emit  (48 bytes) -- the parent is an emitter vertex: prefix_w, parent_rr, parent_n, parent_g from entry `component field
+ *                       of flags` of the blob's EMITTER table (32 bytes an entry: one per emitter triangle and power),
+ *                       parent_scat = 0, parent_wi = (1, 0, 0) as tryAppend leaves them; the record keeps pos, parent_pos,
+ *                       flux, parent_pdf, edge_pdf, flags;
+ *   full  (76 bytes) -- gvpm_photon_packed, as above.
+ * In both short kinds the component field of flags is free (such a parent's component type is always
+ * GVPM_BSDF_DIFFUSE_REFLECTION -- verified) and carries the table index.  wi is derived as in the packed records; a chain
+ * record's parent_wi is derived from the two positions before it (to the rounding of fp32 positions: tighter than the
+ * octahedral code of a full record).  S-cbox / S-fogroom: 28 % chain, 58 % emit, 14 % full = 49.6 bytes a photon.
+ * The records travel as ONE blob (one copy): header, 2-bit kinds, per-64-photon bases, emitter table, the three record
+ * arrays.  What a blob means is DEFINED by gvpm_unpack_photons_linked; the device decodes with the same arithmetic.  */
+typedef struct gvpm_emitter_entry { /* 32 bytes */
+  float prefix_w[3];
+  float parent_rr;
+  float parent_n[3];
+  float parent_g;
+} gvpm_emitter_entry;
+typedef struct gvpm_photon_emit { /* 48 bytes */
+  float pos[3];
+  float parent_pdf;
+  float parent_pos[3];
+  float edge_pdf;
+  float flux[3];
+  uint32_t flags;             /* GVPM_PF_* with bit 7 = path_id & 1; bits 16-31: index into the blob's emitter table */
+} gvpm_photon_emit;
+typedef struct gvpm_photon_chain { /* 40 bytes */
+  float pos[3];
+  float parent_pdf;
+  float flux[3];
+  float edge_pdf;
+  float parent_rr;
+  uint32_t flags;             /* ... bits 16-31: index into the table of gvpm_upload_materials (the medium parent's) */
+} gvpm_photon_chain;
+#define GVPM_LINKED_MAGIC 0x4C4E4B31u /* "LNK1" */
+#define GVPM_LINKED_FULL 0u
+#define GVPM_LINKED_EMIT 1u
+#define GVPM_LINKED_CHAIN 2u
+typedef struct gvpm_linked_header { /* 64 bytes, at the start of the blob; offsets in bytes from it, 16-byte aligned */
+  uint32_t magic, n, n_full, n_emit, n_chain, n_emitters;
+  uint32_t off_kinds;         /* ceil(n / 16) words, photon i: bits 2 (i % 16) .. +1                                    */
+  uint32_t off_groups;        /* ceil(n / 64) x {full records, emit records before photon 64 g}                         */
+  uint32_t off_emitters, off_full, off_emit, off_chain;
+  uint32_t bytes;             /* of the whole blob                                                                      */
+  uint32_t reserved[3];
+} gvpm_linked_header;
+/* bytes a blob of n photons can need at most (every photon full, 65536 emitter entries never reached in practice: 1024) */
+size_t gvpm_linked_photons_bound(uint64_t n);
+/* packs into `blob` (capacity `cap` bytes, e.g. pinned memory of gvpm_linked_photons_bound(n) bytes); the material table grows
+ * as in gvpm_pack_photons; *bytes: the blob's size.  GVPM_ERR_INVALID_ARG: capacity or a table exhausted.               */
+int gvpm_pack_photons_linked(const gvpm_photon_soa *src, void *blob, size_t cap, gvpm_material *table, uint32_t table_cap,
+                             uint32_t *table_n, size_t *bytes);
+int gvpm_unpack_photons_linked(const void *blob, size_t bytes, const gvpm_material *table, uint32_t table_n,
+                               const gvpm_photon_soa *dst);
+int gvpm_upload_photons_linked(gvpm_context *h, const void *blob, size_t bytes);
+int gvpm_prefetch_photons_linked(gvpm_context *h, const void *blob, size_t bytes);
 int gvpm_upload_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
 int gvpm_prefetch_camera_beams_packed(gvpm_context *h, const gvpm_beam_set_packed *sets, uint64_t n_sets);
 

@@ -106,3 +106,114 @@ def test_beam_sets_are_lossless_and_reject_mixed_edges():
     with pytest.raises(hip.GvpmError):
         hip.pack_camera_beams(bad)
     assert hip.pack_camera_beams(rays[:0]).shape == (0, 272)
+
+
+# ---- linked photon records (round 6) -------------------------------------------------------------------------------------
+
+def linked_decode_numpy(blob, table):
+    """an independent decode of a blob of gvpm_pack_photons_linked, from the header's description of the three kinds"""
+    hd = hip.linked_header(blob)
+    n = hd["n"]
+    kw = np.frombuffer(blob[hd["off_kinds"]:hd["off_kinds"] + 4 * ((n + 15) // 16)].tobytes(), np.uint32)
+    kind = (kw[np.arange(n) // 16] >> (2 * (np.arange(n) % 16)).astype(np.uint32)) & 3
+    F = np.frombuffer(blob[hd["off_full"]:hd["off_full"] + 76 * hd["n_full"]].tobytes(), abi.PHOTON_PACKED_DTYPE)
+    E = np.frombuffer(blob[hd["off_emit"]:hd["off_emit"] + 48 * hd["n_emit"]].tobytes(), abi.PHOTON_EMIT_DTYPE)
+    Cn = np.frombuffer(blob[hd["off_chain"]:hd["off_chain"] + 40 * hd["n_chain"]].tobytes(), abi.PHOTON_CHAIN_DTYPE)
+    em = np.frombuffer(blob[hd["off_emitters"]:hd["off_emitters"] + 32 * hd["n_emitters"]].tobytes(), abi.EMITTER_ENTRY_DTYPE)
+    groups = np.frombuffer(blob[hd["off_groups"]:hd["off_groups"] + 8 * ((n + 63) // 64)].tobytes(), np.uint32).reshape(-1, 2)
+    isF, isE, isC = kind == 0, kind == 1, kind == 2
+    assert isF.sum() == hd["n_full"] and isE.sum() == hd["n_emit"] and isC.sum() == hd["n_chain"]
+    # the per-64-photon bases are the running counts
+    assert np.array_equal(groups[:, 0], np.concatenate([[0], np.cumsum(isF)])[0:n:64])
+    assert np.array_equal(groups[:, 1], np.concatenate([[0], np.cumsum(isE)])[0:n:64])
+    out = abi.Photons(n)
+    full = hip.unpack_photons(F.copy(), table)
+    for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
+        getattr(out, k)[isF] = getattr(full, k)
+    DIFF = abi.GVPM_BSDF_DIFFUSE_REFLECTION if hasattr(abi, "GVPM_BSDF_DIFFUSE_REFLECTION") else 0x2
+    # emit records
+    ei = E["flags"] >> 16
+    out.pos[isE], out.parent_pos[isE], out.flux[isE] = E["pos"], E["parent_pos"], E["flux"]
+    out.parent_pdf[isE], out.edge_pdf[isE] = E["parent_pdf"], E["edge_pdf"]
+    out.prefix_w[isE], out.parent_rr[isE], out.parent_n[isE], out.parent_g[isE] = em["prefix_w"][ei], em["parent_rr"][ei], em["parent_n"][ei], em["parent_g"][ei]
+    out.parent_scat[isE] = 0
+    out.parent_wi[isE] = np.array([1, 0, 0], np.float32)
+    out.flags[isE] = (E["flags"] & 0xFF7F) | (DIFF << 16)
+    out.path_id[isE] = (E["flags"] >> 7) & 1
+    # chain records: own fields, then the links
+    mi = Cn["flags"] >> 16
+    out.pos[isC], out.flux[isC] = Cn["pos"], Cn["flux"]
+    out.parent_pdf[isC], out.edge_pdf[isC], out.parent_rr[isC] = Cn["parent_pdf"], Cn["edge_pdf"], Cn["parent_rr"]
+    out.parent_scat[isC], out.parent_g[isC] = table.table["scat"][mi], table.table["g"][mi]
+    out.parent_n[isC] = 0
+    out.flags[isC] = (Cn["flags"] & 0xFF7F) | (DIFF << 16)
+    out.path_id[isC] = (Cn["flags"] >> 7) & 1
+    ic = np.nonzero(isC)[0]
+    out.parent_pos[ic] = out.pos[ic - 1]
+    out.prefix_w[ic] = out.flux[ic - 1]
+
+    def derive(a, b):  # normalize(b - a) in float64, rounded once
+        d = b.astype(np.float64) - a.astype(np.float64)
+        ln = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])
+        return (d / ln[:, None]).astype(np.float32)
+    prev_parent = np.where(isC[ic - 1][:, None], out.pos[ic - 2], out.parent_pos[ic - 1])
+    out.parent_wi[ic] = derive(out.pos[ic - 1], prev_parent)
+    for sel in (isE, isC):
+        out.wi[sel] = derive(out.pos[sel], out.parent_pos[sel])
+    return out, kind
+
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_mirror", "cbox_phong", "cbox_rot", "fogroom"])
+def test_linked_records_decode_as_the_header_says(scene):
+    c = cases.make_case(scene, 24, 20, 30000, 3.0)
+    t = hip.MaterialTable()
+    blob = hip.pack_photons_linked(c.ph, t)
+    hd = hip.linked_header(blob)
+    assert hd["n"] == c.ph.n and hd["bytes"] == blob.size and hd["n_emitters"] >= 1
+    # a photon map in a participating medium: most parents are the emitter or the previous photon
+    assert blob.size < 56 * c.ph.n and hd["n_chain"] > 0.2 * c.ph.n and hd["n_emit"] > 0.4 * c.ph.n
+    got = hip.unpack_photons_linked(blob, t)
+    want, kind = linked_decode_numpy(blob, t)
+    for k in abi.PHOTON_VEC3 + abi.PHOTON_F1 + abi.PHOTON_U1:
+        assert np.array_equal(getattr(got, k), getattr(want, k)), k
+    # what the format carries as it is (a chain record's parent_pos / prefix_w ARE the previous photon's pos / flux)
+    for k in ("pos", "parent_pos", "flux", "prefix_w", "parent_pdf", "edge_pdf", "parent_rr", "parent_scat", "parent_g", "flags"):
+        assert np.array_equal(getattr(got, k), getattr(c.ph, k)), k
+    assert np.array_equal(got.path_id, c.ph.path_id & 1)
+    # the short kinds carry parent_n exactly (the full records: octahedral); parent_wi within the octahedral code's error
+    short = kind != 0
+    assert np.array_equal(got.parent_n[short], c.ph.parent_n[short])
+    assert angle(got.parent_wi, c.ph.parent_wi).max() < 7e-5
+    # ... and as a whole the blob is no worse than the packed records of the same photons
+    t2 = hip.MaterialTable()
+    pk = hip.unpack_photons(hip.pack_photons(c.ph, t2), t2)
+    assert np.array_equal(got.wi, pk.wi)
+    assert angle(got.parent_wi, c.ph.parent_wi).max() <= angle(pk.parent_wi, c.ph.parent_wi).max() + 1e-12
+
+
+def test_linked_records_fall_back_to_full_ones_and_reject_bad_blobs():
+    c = cases.make_case("cbox", 16, 12, 3000, 3.0)
+    ph = c.ph
+    # photons shuffled: no photon follows its parent any more -- nothing may chain, the blob still decodes to the same photons
+    perm = np.random.default_rng(5).permutation(ph.n)
+    sh = ph.subset(perm)
+    t = hip.MaterialTable()
+    blob = hip.pack_photons_linked(sh, t)
+    hd = hip.linked_header(blob)
+    got = hip.unpack_photons_linked(blob, t)
+    for k in ("pos", "parent_pos", "flux", "prefix_w", "parent_pdf", "edge_pdf", "parent_rr", "flags"):
+        assert np.array_equal(getattr(got, k), getattr(sh, k)), k
+    chained = np.nonzero(np.all(sh.parent_pos[1:] == sh.pos[:-1], 1))[0]
+    assert hd["n_chain"] <= chained.size
+    # empty map
+    e = hip.pack_photons_linked(ph.subset(np.zeros(0, np.int64)), hip.MaterialTable())
+    assert hip.linked_header(e)["n"] == 0 and hip.unpack_photons_linked(e, hip.MaterialTable()).n == 0
+    # a truncated blob, a wrong magic, a material index beyond the table
+    with pytest.raises(hip.GvpmError):
+        hip.unpack_photons_linked(blob[:-16].copy(), t)
+    bad = blob.copy()
+    bad[0] ^= 1
+    with pytest.raises(hip.GvpmError):
+        hip.unpack_photons_linked(bad, t)
+    with pytest.raises(hip.GvpmError):
+        hip.unpack_photons_linked(blob, hip.MaterialTable())

@@ -127,3 +127,82 @@ def test_packed_records_feed_g_vpm_too():
     assert st["evaluations"] == cnt["evaluations"] > 5000
     lum = max(ref[..., 0:3].mean(), 1e-30)
     assert np.sqrt(((acc - ref) ** 2).mean()) / lum < 1e-4
+
+
+# ---- linked photon records (round 6): 40 / 48 / 76 bytes a photon ---------------------------------------------------------
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_hg", "cbox_mirror_rot", "cbox_phong"])
+def test_linked_upload_is_the_soa_upload_of_the_unpacked_arrays(scene):
+    c = cases.make_case(scene, 48, 40, 30000, 3.0)
+    t = hip.MaterialTable()
+    blob = hip.pack_photons_linked(c.ph, t)
+    assert blob.size < 56 * c.ph.n
+    unp = hip.unpack_photons_linked(blob, t)
+
+    def run_linked():
+        ctx = hip.Context(c.p, device=0)
+        ctx.upload_scene(*c.tris)
+        ctx.upload_medium(c.m)
+        cases.upload_bsdfs(ctx, c)
+        ctx.upload_materials(t)
+        ctx.upload_photons_linked(blob)
+        ctx.upload_camera_beams(c.rays)
+        ctx.gather(c.it, c.nb)
+        acc, st = ctx.download_accum().astype(np.float64), ctx.stats()
+        ctx.close()
+        return acc, st
+
+    def run_soa(ph):
+        ctx = hip.Context(c.p, device=0)
+        ctx.upload_scene(*c.tris)
+        ctx.upload_medium(c.m)
+        cases.upload_bsdfs(ctx, c)
+        ctx.upload_photons(ph)
+        ctx.upload_camera_beams(c.rays)
+        ctx.gather(c.it, c.nb)
+        acc, st = ctx.download_accum().astype(np.float64), ctx.stats()
+        ctx.close()
+        return acc, st
+
+    a_l, s_l = run_linked()
+    a_u, s_u = run_soa(unp)
+    a_o, s_o = run_soa(c.ph)
+    assert s_l["evaluations"] > 10000
+    # the device decodes a blob exactly as gvpm_unpack_photons_linked does: same counters, same sums up to atomics' order
+    for k in COUNTERS:
+        assert s_l[k] == s_u[k], (k, s_l, s_u)
+    assert np.abs(a_l - a_u).max() <= 2e-5 * np.abs(a_u).max()
+    # against the original inputs: the same pairs; the film moves far less than the parity bar
+    lum = max(a_o[..., 0:3].mean(), 1e-30)
+    assert s_l["evaluations"] == s_o["evaluations"]
+    for k in ("null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert abs(s_l[k] - s_o[k]) <= max(2, 1e-5 * s_o[k])
+    assert np.sqrt(((a_l - a_o) ** 2).mean()) / lum < 3e-5
+
+
+def test_prefetched_linked_blobs_from_pinned_memory():
+    c = cases.make_case("cbox", 40, 32, 20000, 3.0)
+    t = hip.MaterialTable()
+    ctx = hip.Context(c.p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    pinned = [hip.PinnedPacked(*c.sc.shoot_photons(it, 20000)[:1], c.sc.camera_beams(it), t, linked=True) for it in (1, 2, 3)]
+    assert all(p.linked and p.photon_bytes < 56 * p.n for p in pinned)
+    ctx.upload_materials(t)
+    ctx.upload_pinned_packed(pinned[0])
+    ref, total = None, 0
+    for it in (1, 2, 3):
+        if it < 3:
+            ctx.prefetch_packed(pinned[it])
+        ph, nb = c.sc.shoot_photons(it, 20000)
+        r = ctx.radius()
+        ctx.gather(it, nb)
+        ref, cnt, _ = O.gather_bre(c.p, c.m, c.tris, ph, c.sc.camera_beams(it), r, it, nb, 64, use_accel=False, accum=ref)
+        total += cnt["evaluations"]
+    acc = ctx.download_accum().astype(np.float64)
+    st = ctx.stats()
+    ctx.close()
+    for p in pinned:
+        p.close()
+    assert st["evaluations"] == total
+    assert np.sqrt(((acc - ref) ** 2).mean()) / max(ref[..., 0:3].mean(), 1e-30) < 1e-4
