@@ -91,6 +91,9 @@ void launch_scale(const float *in, float *out, size_t n, float scale, hipStream_
 void launch_film(const float *acc, const float *emission, int w, int h, int it, int reusePrimal, float invDiv,
                  float *thr, float *dx, float *dy, hipStream_t s);
 void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream_t stream);
+void launch_vpm_find(const GatherArgs &a, const VpmSplit &sp, hipStream_t stream);
+void launch_vpm_redo(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t nwaves, hipStream_t stream);
+void launch_vpm_eval(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t wavesPerShard, hipStream_t stream);
 void launch_vpm_update(float *scaleVol, float *nVol, float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
                        hipStream_t stream);
 void launch_accumulate(float *accum, float *iter, size_t n, uint32_t *zeroWord, hipStream_t stream);
@@ -395,6 +398,15 @@ struct gvpm_context {
   uint32_t vpmOrderN = 0;      // batches the G-VPM order in blockValB was sorted for (0: none)
   uint32_t vpmLaunches = 0;
   bool vpmNoOrder = false;     // GVPM_VPM_ORDER=0
+  // G-VPM as walk + evaluation + redo kernels (gather_vpm.hip; GVPM_VPM_SPLIT=0: the fused kernel)
+  bool vpmSplit = true;
+  uint32_t vpmPoolPerBatch = 4;  // chunks of 64 pairs the pool holds per batch of 64 samples (GVPM_VPM_POOL; tests shrink it so that batches take the redo path)
+  uint32_t vpmRedoWaves = 1024;  // persistent waves of the redo kernel
+  uint32_t vpmEvalWaves = 12288; // ... and of the evaluation (GVPM_VPM_EVAL_WAVES; 3072 / 6144 / 12288 / one a group: 0.413 / 0.388 / 0.362 / 0.362 ms at C1: the waves differ in length)
+  DevBuf<uint2> vpmPairs, vpmChunkMeta;
+  DevBuf<uint32_t> vpmCtl, vpmStatus, vpmRedo;
+  DevBuf<VpmSampleState> vpmState;
+  hipEvent_t vpmFound = nullptr, vpmRedone = nullptr;
   // GVPM_BEAMS_SPLIT=1: the evaluation in two kernels (gather_beams.hip); the reconnection entries between them
   bool beamsSplit = false;
   DevBuf<uint32_t> splitId, splitMeta, splitBlkCnt, splitCtl;

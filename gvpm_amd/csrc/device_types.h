@@ -196,6 +196,31 @@ struct GatherArgs {
   unsigned long long *stats; // GVPM_STAT_ROWS rows of 8 counters (gvpm_stats order), summed on read
 };
 
+// G-VPM as three kernels (gather_vpm.hip, launch_gather_vpm_split): what the walk leaves for the evaluation.
+// state: what the evaluation needs of a camera sample that found photons (written once per sample, by the walk)
+struct alignas(16) VpmSampleState {
+  double t;            // sampled camera distance (mRec.t)
+  float pdfBase;       // mRec.pdfSuccess * pdfSel
+  float trBase;        // exp(-sigma_t (t - mint))
+  float radius;        // R * 0.01 * gp.scaleVol
+  float pdfSel;
+  uint32_t set;        // beam set of the sample
+  uint32_t pix;        // y << 16 | x
+  uint32_t edge;
+  uint32_t pad[3];
+};
+constexpr uint32_t VPM_SHARDS = 64;       // chunk cursors (a cursor per 128-byte line: ctl[shard * 32])
+constexpr uint32_t VPM_CTL_REDO = VPM_SHARDS * 32;  // ctl[VPM_CTL_REDO]: batches in the redo list
+struct VpmSplit {
+  uint2 *pairs;        // chunks of 64 {photon, camera sample}; chunk c of shard k is chunk k * shardChunks + c of the pool
+  uint2 *chunkMeta;    // per chunk {pairs, batch}
+  uint32_t *ctl;       // the shards' cursors and the redo count (zeroed before the walk)
+  uint32_t *status;    // per batch: 1 = its pairs did not fit the pool, the whole batch is the redo kernel's (its chunks are skipped)
+  uint32_t *redo;      // those batches
+  VpmSampleState *state;
+  uint32_t shardChunks, nBatches;
+};
+
 // The G-BRE build chain (grid_build.hip, launch_build_chain): what its first five launches share.
 struct ChainArgs {
   // photons -> cells

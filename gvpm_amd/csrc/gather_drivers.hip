@@ -1364,7 +1364,47 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   a.vpmOrder = haveOrder ? h->blockValB.p : nullptr;
   a.vpmOrderN = haveOrder ? h->vpmOrderN : 0u;
   HIP_TRY(h, hipEventRecord(ev->first, h->stream));
-  launch_gather_vpm(a, needFullVis(h), primal, h->stream);
+  if (h->vpmSplit && !primal) {
+    // walk -> (redo of the heavy batches on a second stream) + evaluation (gather_vpm.hip)
+    VpmSplit sp;
+    // the pool: four chunks a batch (four pairs a sample) unless GVPM_VPM_POOL says otherwise; a step that needs more sends the
+    // batches that find it exhausted through the fused code
+    const uint32_t shardChunks = std::max<uint32_t>(4u, (uint32_t)(((uint64_t)h->vpmPoolPerBatch * nBatches + VPM_SHARDS - 1) / VPM_SHARDS));
+    HIP_TRY(h, h->vpmPairs.ensure((size_t)shardChunks * VPM_SHARDS * 64));
+    HIP_TRY(h, h->vpmChunkMeta.ensure((size_t)shardChunks * VPM_SHARDS));
+    HIP_TRY(h, h->vpmStatus.ensure(nBatches));
+    HIP_TRY(h, h->vpmState.ensure(h->nsamples));
+    HIP_TRY(h, h->vpmRedo.ensure(nBatches));
+    HIP_TRY(h, h->vpmCtl.ensure(VPM_CTL_REDO + 32));
+    HIP_TRY(h, hipMemsetAsync(h->vpmCtl.p, 0, (VPM_CTL_REDO + 32) * sizeof(uint32_t), h->stream));
+    sp.pairs = h->vpmPairs.p;
+    sp.chunkMeta = h->vpmChunkMeta.p;
+    sp.ctl = h->vpmCtl.p;
+    sp.status = h->vpmStatus.p;
+    sp.redo = h->vpmRedo.p;
+    sp.state = h->vpmState.p;
+    sp.shardChunks = shardChunks;
+    sp.nBatches = nBatches;
+    if (!h->vpmFound) {
+      HIP_TRY(h, hipEventCreateWithFlags(&h->vpmFound, hipEventDisableTiming));
+      HIP_TRY(h, hipEventCreateWithFlags(&h->vpmRedone, hipEventDisableTiming));
+    }
+    launch_vpm_find(a, sp, h->stream);
+    const bool side = h->pipeline && h->streamA2;
+    hipStream_t rs = side ? h->streamA2 : h->stream;
+    if (side) {
+      HIP_TRY(h, hipEventRecord(h->vpmFound, h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(rs, h->vpmFound, 0));
+    }
+    launch_vpm_redo(a, sp, needFullVis(h), h->vpmRedoWaves, rs);
+    launch_vpm_eval(a, sp, needFullVis(h), std::max(1u, h->vpmEvalWaves / VPM_SHARDS), h->stream);
+    if (side) {
+      HIP_TRY(h, hipEventRecord(h->vpmRedone, rs));
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->vpmRedone, 0));
+    }
+  } else {
+    launch_gather_vpm(a, needFullVis(h), primal, h->stream);
+  }
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   // the shifts the kernel could not decide in fp32: into the handle's list (before the radii of this iteration are updated),
   // where they wait for the exact pass -- which adds to the plain sums whenever it runs

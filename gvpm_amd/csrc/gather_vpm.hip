@@ -18,6 +18,8 @@
 // (gp.scaleVol), the grid cell is the largest radius of the iteration.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "shift_device.h"
 #include "vec.h"
@@ -48,7 +50,6 @@ constexpr int VPM_ROWS = 9;  // rows of a sample's cell box walked per pass (a b
 // ... and VPM_SUB copies of a run's sums, picked by the adding lane: all 64 lanes on the two or three addresses of one
 // copy serialise in the LDS atomic unit (measured at 4 x the C1 radius, 16 M evaluations: 3.2 -> 3.9 ms with one copy)
 constexpr int VPM_SUB = GVPM_VPM_SUB;
-#define VPM_ADD(k, b, v) vpmAdd(a, s, (k), (b), (v))
 
 // The rays are NOT staged in LDS: the 64 camera samples of a workgroup belong to one or two pixels (40 samples per
 // pixel at C1), i.e. to one or two beam sets, so the 5 x 64 bytes of a set are L1-resident broadcast reads -- and 17 KB
@@ -73,9 +74,14 @@ struct VpmLds {
   uint32_t rowStart[VPM_ROWS][64], rowOff[VPM_ROWS][64];
   uint32_t found[64];  // photons inside the query sphere (M of the SPPM update)
   uint2 rq[VRQ];       // queued reconnections {photon, sample | shift << 8}
+  static constexpr uint32_t RUN_LIMIT = (uint32_t)VPM_RUNS;  // runs below it have LDS sums (vpmAdd)
+  static constexpr bool RAYS_AHEAD = false;
+  __device__ __forceinline__ uint32_t accSlot(uint32_t r) const { return r * VPM_SUB + (threadIdx.x & (VPM_SUB - 1)); }  // (VPM_SUB divides 64)
+  __device__ __forceinline__ uint32_t sampleIndex(uint32_t sBase, uint32_t b) const { return sBase + b; }
 };
 
-__device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const VpmLds &s, int k, int b) {
+template <typename LDS>
+__device__ __forceinline__ RayReg loadRayV(const GatherArgs &a, const LDS &s, int k, int b) {
   RayReg r;
   const uint32_t set = s.set[b];
   if (set == 0xFFFFFFFFu) {
@@ -107,13 +113,28 @@ __device__ __forceinline__ float oneMinusExpNeg(float x) {
   return x < 0.0625f ? ser : 1.f - __expf(-x);
 }
 
-__device__ __forceinline__ void vpmAdd(const GatherArgs &a, VpmLds &s, int k, uint32_t b, float v) {
+// The accumulator column of sample b (its pixel run's, one of the run's copies by the adding lane), or none: decided ONCE per
+// pair -- decided per value, every one of a pair's 27 adds carried a read of s.run, a compare, a branch and its address (a third
+// of phase 1's instructions, round 6)
+constexpr uint32_t VPM_NO_COL = 0xFFFFFFFFu;
+template <typename LDS>
+__device__ __forceinline__ uint32_t vpmColumn(const LDS &s, uint32_t b) {
   const uint32_t r = s.run[b];
-  if (r < (uint32_t)VPM_RUNS) {
-    atomicAdd(&s.acc[k][r * VPM_SUB + (threadIdx.x & (VPM_SUB - 1))], (double)v);  // (VPM_SUB divides 64)
+  return r < LDS::RUN_LIMIT ? s.accSlot(r) : VPM_NO_COL;
+}
+// values k, k + 1, k + 2 of the pair's pixel
+template <typename LDS>
+__device__ __forceinline__ void vpmAdd3(const GatherArgs &a, LDS &s, uint32_t col, int k, uint32_t b, float x, float y, float z) {
+  if (col != VPM_NO_COL) {
+    atomicAdd(&s.acc[k][col], (double)x);
+    atomicAdd(&s.acc[k + 1][col], (double)y);
+    atomicAdd(&s.acc[k + 2][col], (double)z);
   } else {
     const uint32_t pv = s.pix[b];
-    atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v);
+    float *p = &a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k];
+    atomicAdd(p, x);
+    atomicAdd(p + 1, y);
+    atomicAdd(p + 2, z);
   }
 }
 
@@ -124,15 +145,17 @@ struct VpmPair {
   f3 photonIn, baseContrib, rel;
   double t;
   float tf, r2, pdfBase, pdfSel, scale, trS;
-  uint32_t edge;
+  uint32_t edge, col;
   int px, py;
 };
 
-__device__ __forceinline__ VpmPair vpmPair(const GatherArgs &a, const VpmLds &s, uint32_t pidx, uint32_t b, float norm) {
+template <typename LDS>
+__device__ __forceinline__ VpmPair vpmPair(const GatherArgs &a, const LDS &s, uint32_t pidx, uint32_t b, float norm) {
   VpmPair v;
   v.ph = loadCold(a, pidx);
   v.base = loadRayV(a, s, 0, b);
   v.edge = s.edge[b];
+  v.col = vpmColumn(s, b);
   const uint32_t pix = s.pix[b];
   v.px = (int)(pix & 0xFFFFu);
   v.py = (int)(pix >> 16);
@@ -157,18 +180,13 @@ __device__ __forceinline__ VpmPair vpmPair(const GatherArgs &a, const VpmLds &s,
   return v;
 }
 
-__device__ __forceinline__ void vpmAddShift(VpmLds &s, uint32_t b, int i, const f3 &sflux, const f3 &baseContrib, float w,
+template <typename LDS>
+__device__ __forceinline__ void vpmAddShift(LDS &s, uint32_t b, uint32_t col, int i, const f3 &sflux, const f3 &baseContrib, float w,
                                             float scale, int px, int py, const GatherArgs &a) {
   if ((i == GVPM_RIGHT && px == a.cfg.width - 1) || (i == GVPM_TOP && py == a.cfg.height - 1)) w = 1.f;
   const float ws = w * scale;
-  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) {
-    VPM_ADD(3 + 3 * i + 0, b, sflux.x * ws);
-    VPM_ADD(3 + 3 * i + 1, b, sflux.y * ws);
-    VPM_ADD(3 + 3 * i + 2, b, sflux.z * ws);
-  }
-  VPM_ADD(15 + 3 * i + 0, b, baseContrib.x * ws);
-  VPM_ADD(15 + 3 * i + 1, b, baseContrib.y * ws);
-  VPM_ADD(15 + 3 * i + 2, b, baseContrib.z * ws);
+  if (sflux.x != 0.f || sflux.y != 0.f || sflux.z != 0.f) vpmAdd3(a, s, col, 3 + 3 * i, b, sflux.x * ws, sflux.y * ws, sflux.z * ws);
+  vpmAdd3(a, s, col, 15 + 3 * i, b, baseContrib.x * ws, baseContrib.y * ws, baseContrib.z * ws);
 }
 
 // Phase 1 of one evaluation (VolumeGradientPositionQuery::operator() after the filters): the base contribution, and
@@ -177,33 +195,40 @@ __device__ __forceinline__ void vpmAddShift(VpmLds &s, uint32_t b, int i, const 
 // null shifts, but a batch that evaluates in one pass pays for the reconnection code of the few lanes that take it).
 // The PRIMAL point estimate (sppm.cpp:1087-1112 + RadianceQueryVolume, src/librender/photonmap.cpp:277-308): the term of one
 // (photon, sample) pair -- power * phase (no sigma_s) * beam.weight * Tr / (pdfSuccess * sel) * MCNorm / kernelVol
-__device__ __forceinline__ void vpmPrimalTerm(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm) {
+template <typename LDS>
+__device__ __forceinline__ void vpmPrimalTerm(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t b, float norm) {
   const PhotonFront ph = loadFront(a, pidx);
   const RayReg base = loadRayV(a, s, 0, b);
   const float r = s.radius[b];
   const float kernelVol = (4.0f / 3.0f) * 3.14159265358979323846f * r * r * r;
   const float scale = norm / (kernelVol * s.pdfBase[b]);
   const f3 c = base.eye * ph.flux * (phaseEval(a.med.g, ph.wi, -base.d) * s.trBase[b] * scale);
-  VPM_ADD(0, b, c.x);
-  VPM_ADD(1, b, c.y);
-  VPM_ADD(2, b, c.z);
+  vpmAdd3(a, s, vpmColumn(s, b), 0, b, c.x, c.y, c.z);
 }
 
-template <bool HS>
-__device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t b, float norm,
+template <bool HS, typename LDS>
+__device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t b, float norm,
                                               uint32_t &nNull, uint32_t &nFail) {
 #if GVPM_VPM_PROBE == 1
   return 0u;
 #endif
   const VpmPair v = vpmPair(a, s, pidx, b, norm);
-  VPM_ADD(0, b, v.baseContrib.x * v.scale);
-  VPM_ADD(1, b, v.baseContrib.y * v.scale);
-  VPM_ADD(2, b, v.baseContrib.z * v.scale);
+  vpmAdd3(a, s, v.col, 0, b, v.baseContrib.x * v.scale, v.baseContrib.y * v.scale, v.baseContrib.z * v.scale);
   const float sigT = a.med.sigmaT[0];
   uint32_t qMask = 0u;
+  // (the evaluation kernel: shift i + 1's ray is requested while shift i is computed -- four round trips one after the other
+  // were 60 % of its phase 1; the fused kernel has no registers for it)
+  [[maybe_unused]] RayReg shAhead;
+  if constexpr (LDS::RAYS_AHEAD) shAhead = loadRayV(a, s, 1, b);
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
-    const RayReg sh = loadRayV(a, s, 1 + i, b);
+    RayReg sh;
+    if constexpr (LDS::RAYS_AHEAD) {
+      sh = shAhead;
+      if (i < 3) shAhead = loadRayV(a, s, 2 + i, b);
+    } else {
+      sh = loadRayV(a, s, 1 + i, b);
+    }
     float w = 1.f;
     f3 sflux = mk3(0.f);
     // validShiftDist: valid edge and shiftDistMax >= baseRay.maxt (shift_volume_photon.cpp:546-566)
@@ -248,15 +273,15 @@ __device__ __forceinline__ uint32_t vpmPhase1(const GatherArgs &a, VpmLds &s, ui
         nFail++;
       }
     }
-    vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
+    vpmAddShift(s, b, v.col, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
   }
   return qMask;
 }
 
 // Phase 2: the reconnection of shift i (getShiftPos with coherent = false, shift_volume_photon.cpp:858-896, then
 // shiftPhotonDiffuse) for one queued (photon, sample, shift).
-template <bool FULLVIS, bool HS>
-__device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32_t pidx, uint32_t meta, float norm,
+template <bool FULLVIS, bool HS, typename LDS>
+__device__ __forceinline__ void vpmPhase2(const GatherArgs &a, LDS &s, uint32_t pidx, uint32_t meta, float norm,
                                           uint32_t &nDiff, uint32_t &nFail, uint32_t sBase) {
   const uint32_t b = meta & 0xFFu;
   const int i = (int)((meta >> 8) & 0xFFu);
@@ -285,7 +310,7 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
     if (!recordShiftRequest(reqSink(a), s.radius[b], pidx, s.set[b], i, zPf + offRel, basePtF, zPf, v.tf, v.trS, v.pdfBase, pdfShift,
                             sensorMIS(sh, v.base, v.edge), v.scale, v.baseContrib * v.scale, sh.d, sh.eye, s.pix[b])) {
       nFail++;  // the list is full: a failed shift (weight 1)
-      vpmAddShift(s, b, i, mk3(0.f), v.baseContrib, 1.f, v.scale, v.px, v.py, a);
+      vpmAddShift(s, b, v.col, i, mk3(0.f), v.baseContrib, 1.f, v.scale, v.px, v.py, a);
     }
     return;
   }
@@ -300,11 +325,11 @@ __device__ __forceinline__ void vpmPhase2(const GatherArgs &a, VpmLds &s, uint32
 #endif
   if (amb | ambVis) {
     // fp32 cannot decide this shift as the reference does: the exact pass evaluates it (nothing added, nothing counted)
-    deferNote(a, GVPM_EX_KIND_VPM, sBase + b, pidx, (uint32_t)i, amb | ambVis);
+    deferNote(a, GVPM_EX_KIND_VPM, s.sampleIndex(sBase, b), pidx, (uint32_t)i, amb | ambVis);
     return;
   }
   if (ok) nDiff++; else nFail++;
-  vpmAddShift(s, b, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
+  vpmAddShift(s, b, v.col, i, sflux, v.baseContrib, w, v.scale, v.px, v.py, a);
 }
 
 // Waves per workgroup: they share nothing (an LDS slice each, wave-local synchronisation).  One wave per workgroup made the
@@ -344,25 +369,23 @@ __device__ __forceinline__ uint32_t waveScanInclDpp(uint32_t v) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
   return (uint32_t)x;
 }
-template <bool FULLVIS, bool HS, bool PRIMAL = false>
-__global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
-  __shared__ VpmLds sAll[VPM_WPB];
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  VpmLds &s = sAll[wv];
-  const uint32_t slot = blockIdx.x * (uint32_t)VPM_WPB + (uint32_t)wv;
-  // heaviest first (gatherVPM): slots below vpmOrderN take the permutation's batch, the others their own
-  const uint32_t batch = slot < a.vpmOrderN ? a.vpmOrder[slot] : slot;
-  const uint32_t sBase = batch * VPM_SPW;
-  if (sBase >= a.nsamples) return;  // (no workgroup barrier anywhere: the waves run independently)
+// One batch of camera samples [sBase, sBase + ns), ns <= 64, through one wave.
+// MODE 0: walk and evaluation (the fused kernel; the parts of a heavy batch in vpm_redo_kernel).
+// MODE 1: the walk alone (vpm_find_kernel): the pairs that pass the filters go to chunks of VpmSplit::pairs, 64 at a time, the
+// samples that found photons leave their state for vpm_eval_kernel; a batch that finds the pool exhausted is named in the redo
+// list and leaves nothing else behind.
+template <bool FULLVIS, bool HS, bool PRIMAL, int MODE, typename LDS>
+__device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int lane, const uint32_t batch, const uint32_t sBase,
+                                         const uint32_t ns, const bool wholeBatch, const VpmSplit &sp) {
 #ifdef GVPM_VPM_TIMING
   const unsigned long long tw0 = wall_clock64();
 #endif
-  const uint32_t ns = min(VPM_SPW, a.nsamples - sBase);
   // (wave-uniform, but a VALU quotient: handed to the scalar file, or it is carried -- and spilled -- as a vector register)
   const float norm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.f / (float)a.cfg.nb_camera_samples)));
   const float eps = a.cfg.epsilon;
 
-  for (int idx = lane; idx < 27 * VPM_RUNS * VPM_SUB; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+  if constexpr (MODE == 0)
+    for (int idx = lane; idx < 27 * VPM_RUNS * VPM_SUB; idx += 64) (&s.acc[0][0])[idx] = 0.0;
   uint32_t nRuns = 0;  // wave-uniform: runs that have LDS accumulators
 
   // ---- this lane's sample: rays -> LDS, distance sampling ----
@@ -377,25 +400,45 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     if (set >= a.nsets) active = false;
   }
   s.set[lane] = active ? set : 0xFFFFFFFFu;
+  // (the base ray's four quads in one round trip: the pixel and the edge are in its last one)
+  RayReg base;
+  base.o = base.eye = mk3(0.f);
+  base.d = mk3(0.f, 0.f, 1.f);
+  base.len = 1e-30f;
+  base.pdf = base.jac = base.gop = 0.f;
+  base.valid = false;
   {
     float4 q3 = make_float4(0, 0, 0, 0);
-    if (active) q3 = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5)[3];
+    if (active) {
+      const float4 *rp = reinterpret_cast<const float4 *>(a.rays + (size_t)set * 5);
+      const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+      q3 = rp[3];
+      base.o = mk3(q0.x, q0.y, q0.z);
+      base.len = fabsf(q0.w);
+      base.valid = GVPM_RAY_VALID(__float_as_uint(q3.y)) != 0;
+      base.d = mk3(q1.x, q1.y, q1.z);
+      base.pdf = q1.w;
+      base.eye = mk3(q2.x, q2.y, q2.z);
+      base.jac = q2.w;
+      base.gop = q3.x;
+    }
     s.pix[lane] = __float_as_uint(q3.w);
     s.edge[lane] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
     // pixel runs: consecutive lanes of one pixel (the C ABI does not promise that a pixel's samples are adjacent: a
     // pixel that comes back later in the wave is another run)
-    const uint32_t pv = __float_as_uint(q3.w);
-    const uint32_t prev = __shfl_up(pv, 1u, 64);
-    const bool head = lane == 0 || prev != pv;
-    const unsigned long long heads = __ballot(head);
-    const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull)) - 1u;
-    s.run[lane] = run;
-    if (head && run < (uint32_t)VPM_RUNS) s.runPix[run] = pv;
-    if (lane == 0) nRuns = min((uint32_t)__popcll(heads), (uint32_t)VPM_RUNS);
+    if constexpr (MODE == 0) {
+      const uint32_t pv = __float_as_uint(q3.w);
+      const uint32_t prev = __shfl_up(pv, 1u, 64);
+      const bool head = lane == 0 || prev != pv;
+      const unsigned long long heads = __ballot(head);
+      const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull)) - 1u;
+      s.run[lane] = run;
+      if (head && run < (uint32_t)VPM_RUNS) s.runPix[run] = pv;
+      if (lane == 0) nRuns = min((uint32_t)__popcll(heads), (uint32_t)VPM_RUNS);
+    }
   }
-  nRuns = __shfl(nRuns, 0, 64);
+  if constexpr (MODE == 0) nRuns = __shfl(nRuns, 0, 64);
   vpmWaveSync();
-  const RayReg base = loadRayV(a, s, 0, lane);
   active = active && base.valid;
   // HomogeneousMedium::sampleDistance(Ray(o, d, Epsilon, beamDist), EDistanceAlwaysValid, rand),
   // homogeneous.cpp:293-430 (balance strategy, currentMediumSampling = 1)
@@ -428,10 +471,12 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     }
   }
   s.t[lane] = t;
-  s.pdfBase[lane] = pdfBase;
-  s.pdfSel[lane] = pdfSel;
-  s.trBase[lane] = trBase;
-  s.radius[lane] = radius;
+  if constexpr (MODE == 0) {
+    s.pdfBase[lane] = pdfBase;
+    s.pdfSel[lane] = pdfSel;
+    s.trBase[lane] = trBase;
+    s.radius[lane] = radius;
+  }
   vpmWaveSync();
 
   // ---- cell box of the query sphere ----
@@ -478,67 +523,95 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
   // cells of a 3 x 3 x 3 box hold ~6 times the sphere's volume, the trimmed rows ~3 times (C1: 14.6 -> ~8 candidates a
   // sample).  Conservative: the reach carries 1e-4 r + 1e-6 + 2e-4 cells of slack -- a cell's bounds are rebuilt here as
   // org + index * cell, off the build's floor((p - org) * invCell) by up to ~1e-7 * index cells.
+  // (no branch around the two loads: a row that lists nothing reads cell 0 and drops it -- the eighteen loads of a pass are
+  // then issued back to back instead of one round trip after the other behind their conditions)
   auto rowRange = [&](int r, uint32_t &c, uint32_t &e) __attribute__((always_inline)) {
-    c = e = 0u;
     const int nrowsL = (int)(boxB >> 14);
-    if (r < nrowsL) {
-      const int bx0L = (int)(boxA & 1023u), bx1L = (int)((boxA >> 10) & 1023u), by0L = (int)(boxA >> 20);
-      const int bz0L = (int)(boxB & 1023u), nyr = (int)((boxB >> 10) & 15u);
-      const float4 qr = s.qr[lane];
-      const float padW = qr.w * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
-      const int y = by0L + r % nyr, z = bz0L + r / nyr;
-      const float ylo = gr.org[1] + (float)y * gr.cell, zlo = gr.org[2] + (float)z * gr.cell;
-      const float dy = fmaxf(0.f, fmaxf(ylo - qr.y, qr.y - (ylo + gr.cell))), dz = fmaxf(0.f, fmaxf(zlo - qr.z, qr.z - (zlo + gr.cell)));
-      const float h2 = pad2 - (dy * dy + dz * dz);
-      if (h2 > 0.f) {
-        const float hx = sqrtf(h2) + 1e-6f;
-        const int x0 = max(bx0L, (int)floorf((qr.x - hx - gr.org[0]) * gr.invCell));
-        const int x1 = min(bx1L, (int)floorf((qr.x + hx - gr.org[0]) * gr.invCell));
-        if (x1 >= x0) {
-          const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
-          c = a.cellStart[rb + x0];
-          e = a.cellStart[rb + x1 + 1];
-        }
-      }
-    }
+    const int bx0L = (int)(boxA & 1023u), bx1L = (int)((boxA >> 10) & 1023u), by0L = (int)(boxA >> 20);
+    const int bz0L = (int)(boxB & 1023u), nyr = max(1, (int)((boxB >> 10) & 15u));
+    const float4 qr = s.qr[lane];
+    const float padW = qr.w * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
+    const int y = by0L + r % nyr, z = bz0L + r / nyr;
+    const float ylo = gr.org[1] + (float)y * gr.cell, zlo = gr.org[2] + (float)z * gr.cell;
+    const float dy = fmaxf(0.f, fmaxf(ylo - qr.y, qr.y - (ylo + gr.cell))), dz = fmaxf(0.f, fmaxf(zlo - qr.z, qr.z - (zlo + gr.cell)));
+    const float h2 = pad2 - (dy * dy + dz * dz);
+    const float hx = sqrtf(fmaxf(h2, 0.f)) + 1e-6f;
+    const int x0 = max(bx0L, (int)floorf((qr.x - hx - gr.org[0]) * gr.invCell));
+    const int x1 = min(bx1L, (int)floorf((qr.x + hx - gr.org[0]) * gr.invCell));
+    const bool ok = r < nrowsL && h2 > 0.f && x1 >= x0;
+    const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
+    const uint32_t cc = a.cellStart[ok ? rb + x0 : 0u], ee = a.cellStart[ok ? rb + x1 + 1 : 0u];
+    c = ok ? cc : 0u;
+    e = ok ? ee : 0u;
   };
-  uint32_t qHead = 0, qCount = 0, rqHead = 0, rqCount = 0;
+  uint32_t qHead = 0, qCount = 0;
+  [[maybe_unused]] uint32_t rqHead = 0, rqCount = 0;
+  // MODE 1: the pool has no chunk left (wave-uniform); the chunk reserved for the next 64 pairs (lane 0)
+  [[maybe_unused]] bool slotFull = false;
+  [[maybe_unused]] uint32_t chunkAhead = 0;
+  if constexpr (MODE == 1)
+    if (lane == 0) chunkAhead = atomicAdd(&sp.ctl[(blockIdx.x % VPM_SHARDS) * 32u], 1u);
+  [[maybe_unused]] unsigned long long candAtFull = 0;
   uint32_t nNull = 0, nDiff = 0, nFail = 0;
   // candidates and evaluations are counted per WAVE, in the scalar file (a trip's candidates: its width; a batch's evaluations:
   // its ballot): two vector registers less across the walk
   unsigned long long nCandW = 0, nEvalW = 0;
   auto drain = [&](uint32_t n) __attribute__((always_inline)) {  // phase 2 for the first n <= 64 queued reconnections
-    vpmWaveSync();
-    if ((uint32_t)lane < n) {
-      const uint2 e = s.rq[(rqHead + lane) % VRQ];
-      vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail, sBase);
+    if constexpr (MODE == 0) {
+      vpmWaveSync();
+      if ((uint32_t)lane < n) {
+        const uint2 e = s.rq[(rqHead + lane) % VRQ];
+        vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail, sBase);
+      }
+      rqHead = (rqHead + n) % VRQ;
+      rqCount -= n;
+      vpmWaveSync();
     }
-    rqHead = (rqHead + n) % VRQ;
-    rqCount -= n;
-    vpmWaveSync();
   };
   auto evalBatch = [&](bool valid, uint2 e) __attribute__((always_inline)) {  // phase 1 for one (photon, sample) pair per lane
-    uint32_t qMask = 0u;
-    if (valid) {
-      if (PRIMAL) vpmPrimalTerm(a, s, e.x, e.y, norm);
-      else qMask = vpmPhase1<HS>(a, s, e.x, e.y, norm, nNull, nFail);
-    }
-    nEvalW += (unsigned long long)__popcll(__ballot(valid));
+    if constexpr (MODE == 0) {
+      uint32_t qMask = 0u;
+      if (valid) {
+        if (PRIMAL) vpmPrimalTerm(a, s, e.x, e.y, norm);
+        else qMask = vpmPhase1<HS>(a, s, e.x, e.y, norm, nNull, nFail);
+      }
+      nEvalW += (unsigned long long)__popcll(__ballot(valid));
 #pragma unroll 1
-    for (uint32_t i = 0; i < 4u; ++i) {
-      const bool want = (qMask >> i) & 1u;
-      const unsigned long long m = __ballot(want);
-      if (m) {
-        if (want) {
-          const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
-          s.rq[(rqHead + rqCount + off) % VRQ] = make_uint2(e.x, e.y | (i << 8) | (((qMask >> (4u + i)) & 1u) << 16));
+      for (uint32_t i = 0; i < 4u; ++i) {
+        const bool want = (qMask >> i) & 1u;
+        const unsigned long long m = __ballot(want);
+        if (m) {
+          if (want) {
+            const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+            s.rq[(rqHead + rqCount + off) % VRQ] = make_uint2(e.x, e.y | (i << 8) | (((qMask >> (4u + i)) & 1u) << 16));
+          }
+          rqCount += __popcll(m);
+          if (rqCount >= 64u) drain(64u);
         }
-        rqCount += __popcll(m);
-        if (rqCount >= 64u) drain(64u);
+      }
+    } else {
+      // the walk alone: the first n = popcount(valid) queued pairs (the valid lanes are the low ones) to a chunk of the pool
+      // (the chunk was reserved ahead -- at the wave's start, or when the chunk before it was filled -- so that nobody waits
+      // for the cursor's round trip here; the one reserved last and not needed is closed empty at the end)
+      const uint32_t n = (uint32_t)__popcll(__ballot(valid));
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunkAhead);
+      if (c >= sp.shardChunks) {
+        slotFull = true;
+      } else {
+        const uint32_t chunk = (blockIdx.x % VPM_SHARDS) * sp.shardChunks + c;
+        if (valid) sp.pairs[(size_t)chunk * 64u + (uint32_t)lane] = make_uint2(e.x, sBase + e.y);
+        if (lane == 0) {
+          sp.chunkMeta[chunk] = make_uint2(n, batch);
+          chunkAhead = atomicAdd(&sp.ctl[(blockIdx.x % VPM_SHARDS) * 32u], 1u);
+        }
       }
     }
   };
-  for (int r0 = 0; r0 < maxRows; r0 += VPM_ROWS) {
+#ifdef GVPM_VPM_TIMING
+  [[maybe_unused]] const unsigned long long twSetup = wall_clock64();
+  [[maybe_unused]] unsigned long long twRows = 0;
+#endif
+  for (int r0 = 0; r0 < maxRows && !slotFull; r0 += VPM_ROWS) {
     // this lane's rows of the pass: all ranges in flight together, then the lane's own prefix over them
     uint32_t rcs[VPM_ROWS], res[VPM_ROWS];
 #pragma unroll
@@ -558,29 +631,64 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     s.segOff[lane] = inc - cnt;
     if (lane == 63) s.segOff[64] = total;
     vpmWaveSync();
-    for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+#ifdef GVPM_VPM_TIMING
+    if (r0 == 0) twRows = wall_clock64();
+#endif
+    candAtFull = nCandW + total;  // (what the cost key of a batch that stops here says: the pass's whole list)
+    auto locate = [&](uint32_t j, uint32_t &gi, uint32_t &owner) __attribute__((always_inline)) {
+      // the last sample whose offset is <= j (empty lists share the offset of the list after them) ...
+      owner = 0;
+#pragma unroll
+      for (int st = 32; st > 0; st >>= 1)
+        if (s.segOff[owner + st] <= j) owner += st;
+      // ... and the last of its rows whose offset is <= the entry's place in the sample's list
+      const uint32_t kk = j - s.segOff[owner];
+      uint32_t row = 0;
+      if (s.rowOff[8][owner] <= kk) {
+        row = 8;
+      } else {
+#pragma unroll
+        for (int st = 4; st > 0; st >>= 1)
+          if (s.rowOff[row + st][owner] <= kk) row += st;
+      }
+      gi = s.rowStart[row][owner] + (kk - s.rowOff[row][owner]);
+    };
+    // (the walk kernel: the next trip's photon is located and its load issued before this trip's is tested -- a round trip per
+    // trip was most of a wave's life; the fused kernel has no registers for it)
+    [[maybe_unused]] bool haveN = false;
+    [[maybe_unused]] uint32_t giN = 0, ownerN = 0;
+    [[maybe_unused]] float4 hpN = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (MODE == 1) {
+      haveN = (uint32_t)lane < total;
+      if (haveN) {
+        locate((uint32_t)lane, giN, ownerN);
+        hpN = a.hot[giN];
+      }
+    }
+    for (uint32_t j0 = 0; j0 < total && !slotFull; j0 += 64u) {
       nCandW += min(64u, total - j0);
       const uint32_t j = j0 + (uint32_t)lane;
-      const bool have = j < total;
+      bool have = j < total;
       bool hit = false;
       uint32_t gi = 0, owner = 0;
-      if (have) {
-        // the last sample whose offset is <= j (empty lists share the offset of the list after them) ...
-#pragma unroll
-        for (int st = 32; st > 0; st >>= 1)
-          if (s.segOff[owner + st] <= j) owner += st;
-        // ... and the last of its rows whose offset is <= the entry's place in the sample's list
-        const uint32_t kk = j - s.segOff[owner];
-        uint32_t row = 0;
-        if (s.rowOff[8][owner] <= kk) {
-          row = 8;
-        } else {
-#pragma unroll
-          for (int st = 4; st > 0; st >>= 1)
-            if (s.rowOff[row + st][owner] <= kk) row += st;
+      float4 hp = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (MODE == 1) {
+        have = haveN;
+        gi = giN;
+        owner = ownerN;
+        hp = hpN;
+        haveN = j + 64u < total;
+        if (haveN) {
+          locate(j + 64u, giN, ownerN);
+          hpN = a.hot[giN];
         }
-        gi = s.rowStart[row][owner] + (kk - s.rowOff[row][owner]);
-        const float4 hp = a.hot[gi];
+      } else {
+        if (have) {
+          locate(j, gi, owner);
+          hp = a.hot[gi];
+        }
+      }
+      if (have) {
         const float4 qr = s.qr[owner];
         const f3 p = mk3(hp.x, hp.y, hp.z);
         const f3 qo = mk3(qr.x, qr.y, qr.z);
@@ -638,21 +746,61 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
     }
   }
   vpmWaveSync();
-  if (qCount) evalBatch((uint32_t)lane < qCount, s.queue[(qHead + lane) % VQ]);
-  if (rqCount) drain(rqCount);
+#ifdef GVPM_VPM_TIMING
+  [[maybe_unused]] const unsigned long long twTrips = wall_clock64() - tw0;
+#endif
+  if (qCount && !slotFull) evalBatch((uint32_t)lane < qCount, s.queue[(qHead + lane) % VQ]);
+  if constexpr (MODE == 0) {
+    if (rqCount) drain(rqCount);
+  } else {
+    if (slotFull) {
+      // the pool is exhausted: the whole batch is the fused kernel's (vpm_redo_kernel); nothing of this walk counts, the chunks
+      // it has written are skipped
+      if (lane == 0) {
+        if (chunkAhead < sp.shardChunks) sp.chunkMeta[(blockIdx.x % VPM_SHARDS) * sp.shardChunks + chunkAhead] = make_uint2(0u, batch);
+        sp.status[batch] = 1u;
+        sp.redo[atomicAdd(&sp.ctl[VPM_CTL_REDO], 1u)] = batch;
+        if (a.vpmCostKey) {
+          a.vpmCostKey[batch] = 0xFFFFFu - (uint32_t)min(candAtFull, 0xFFFFFull);
+          a.vpmCostVal[batch] = batch;
+        }
+      }
+      return;
+    }
+    if (lane == 0) {
+      sp.status[batch] = 0u;
+      if (chunkAhead < sp.shardChunks) sp.chunkMeta[(blockIdx.x % VPM_SHARDS) * sp.shardChunks + chunkAhead] = make_uint2(0u, batch);
+    }
+    vpmWaveSync();
+    if (s.found[lane] != 0u) {
+      VpmSampleState st;
+      st.t = t;
+      st.pdfBase = pdfBase;
+      st.trBase = trBase;
+      st.radius = radius;
+      st.pdfSel = pdfSel;
+      st.set = set;
+      st.pix = s.pix[lane];
+      st.edge = s.edge[lane];
+      st.pad[0] = st.pad[1] = st.pad[2] = 0u;
+      sp.state[sBase + (uint32_t)lane] = st;
+    }
+  }
   vpmWaveSync();
   // ---- write out ----
   // one global atomic per (run, value): per-sample atomics would put up to 64 operations on one address, and those
   // serialise in L2 (a run that overflowed VPM_RUNS has added to the film directly)
-  for (uint32_t idx = (uint32_t)lane; idx < 27u * nRuns; idx += 64u) {
-    const uint32_t k = idx / nRuns, rr = idx % nRuns;
-    double vd = 0.0;
+  if constexpr (MODE == 0) {
+    for (uint32_t idx = (uint32_t)lane; idx < 27u * nRuns; idx += 64u) {
+      const uint32_t k = idx / nRuns, rr = idx % nRuns;
+      double vd = 0.0;
 #pragma unroll
-    for (int c = 0; c < VPM_SUB; ++c) vd += s.acc[k][rr * VPM_SUB + c];
-    const float v = (float)vd;
-    if (v != 0.f) {
-      const uint32_t pv = s.runPix[rr];
-      atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v);
+      for (int c = 0; c < VPM_SUB; ++c) vd += s.acc[k][rr * VPM_SUB + c];
+      const float v = (float)vd;
+      if (v != 0.f) {
+        const uint32_t pv = s.runPix[rr];
+        atomicAdd(&a.iter[((size_t)(pv >> 16) * a.cfg.width + (pv & 0xFFFFu)) * 27 + k], v);
+      }
     }
   }
   {
@@ -691,18 +839,271 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
       if (lane == 0 && wid < 65536u) {
         gvpmVpmLog[4 * wid] = tw0;
         gvpmVpmLog[4 * wid + 1] = wall_clock64();
+#ifdef GVPM_VPM_TIMING2
+        gvpmVpmLog[4 * wid + 2] = twSetup;
+        gvpmVpmLog[4 * wid + 3] = ((twRows ? twRows - tw0 : 0ull) & 0xFFFFFFFFull) | ((unsigned long long)twTrips << 32);
+#else
         gvpmVpmLog[4 * wid + 2] = ca;
         gvpmVpmLog[4 * wid + 3] = ev;
+#endif
       }
     }
 #endif
-    if (lane == 0 && a.vpmCostKey) {
+    if (lane == 0 && a.vpmCostKey && wholeBatch) {  // (a part of a heavy batch: the walk that sent it to the redo list has said)
       a.vpmCostKey[batch] = 0xFFFFFu - (uint32_t)min(ca, 0xFFFFFull);
       a.vpmCostVal[batch] = batch;
     }
     if (GVPM_VPM_PROBE != 3 && lane == 0 && (ev | ca)) {
       atomicAdd(&statRow(a)[0], ev);
       atomicAdd(&statRow(a)[1], ca);
+      atomicAdd(&statRow(a)[2], nu);
+      atomicAdd(&statRow(a)[3], di);
+      atomicAdd(&statRow(a)[4], fa);
+    }
+  }
+}
+
+template <bool FULLVIS, bool HS, bool PRIMAL = false>
+__global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void gather_vpm_kernel(GatherArgs a) {
+  __shared__ VpmLds sAll[VPM_WPB];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t slot = blockIdx.x * (uint32_t)VPM_WPB + (uint32_t)wv;
+  // heaviest first (gatherVPM): slots below vpmOrderN take the permutation's batch, the others their own
+  const uint32_t batch = slot < a.vpmOrderN ? a.vpmOrder[slot] : slot;
+  const uint32_t sBase = batch * VPM_SPW;
+  if (sBase >= a.nsamples) return;  // (no workgroup barrier anywhere: the waves run independently)
+  vpmBatch<FULLVIS, HS, PRIMAL, 0>(a, sAll[wv], lane, batch, sBase, min(VPM_SPW, a.nsamples - sBase), true, VpmSplit{});
+}
+
+// ---- G-VPM as three kernels (the default; GVPM_VPM_SPLIT=0: the fused kernel above) ---------------------------------------
+// The fused kernel's waves live ~25 us on a chain of dependent loads and evaluate what their 64 samples found -- 43 pairs at
+// C1, in one phase-1 batch two thirds full and one phase-2 batch one third full -- at three waves per SIMD (168 VGPRs: the
+// evaluation's); and the pixels that look at the light (a thousand pairs a batch) are evaluated by ONE wave each, 64 pairs after
+// 64.  Split, as G-BRE's traversal and evaluation are:
+//   vpm_find_kernel   the walk alone (the fused kernel's own code, MODE 1): 62 registers, so five waves per SIMD; 64 pairs at
+//                     a time go to a chunk of a pool (a cursor per shard of the launch: one atomic per chunk), the state of
+//                     every sample that found photons to one 48-byte record;
+//   vpm_eval_kernel   a wave takes VPM_EVAL_CHUNKS consecutive chunks of a shard, lays their pairs end to end and evaluates
+//                     them 64 at a time: at most that many batches a wave, all but its last full -- the heavy pixels'
+//                     pairs spread over as many waves as they fill chunks;
+//   vpm_redo_kernel   the fallback: batches that found the pool exhausted go through the fused code (VPM_REDO_PARTS waves a
+//                     batch, sixteen samples each).  Empty unless a step finds over four times as many pairs as it has
+//                     samples (the pool's size, gatherVPM).
+// The walk decides pairs exactly as the fused kernel does (one source); the evaluation adds the same terms.
+struct VpmFindLds {
+  uint32_t set[64];
+  uint2 queue[VQ];
+  double t[64];
+  uint32_t pix[64];
+  uint32_t edge[64];
+  float4 qr[64];
+  uint32_t segOff[64 + 1];
+  uint32_t rowStart[VPM_ROWS][64], rowOff[VPM_ROWS][64];
+  uint32_t found[64];
+};
+#ifndef GVPM_VPM_FIND_MINW
+#define GVPM_VPM_FIND_MINW 5
+#endif
+#ifndef GVPM_VPM_REDO_PARTS
+#define GVPM_VPM_REDO_PARTS 4
+#endif
+constexpr uint32_t VPM_REDO_PARTS = GVPM_VPM_REDO_PARTS;
+#ifndef GVPM_VPM_EVAL_CHUNKS
+#define GVPM_VPM_EVAL_CHUNKS 4
+#endif
+constexpr int VPM_EVAL_CHUNKS = GVPM_VPM_EVAL_CHUNKS;
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_FIND_MINW))) void vpm_find_kernel(GatherArgs a, VpmSplit sp) {
+  __shared__ VpmFindLds s;
+  const int lane = threadIdx.x;
+  const uint32_t slot = blockIdx.x;
+  const uint32_t batch = slot < a.vpmOrderN ? a.vpmOrder[slot] : slot;
+  const uint32_t sBase = batch * VPM_SPW;
+  if (sBase >= a.nsamples) return;
+  vpmBatch<false, false, false, 1>(a, s, lane, batch, sBase, min(VPM_SPW, a.nsamples - sBase), true, sp);
+}
+
+template <bool FULLVIS, bool HS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void vpm_redo_kernel(GatherArgs a, VpmSplit sp) {
+  __shared__ VpmLds s;
+  const int lane = threadIdx.x;
+  const uint32_t nUnits = __hip_atomic_load(&sp.ctl[VPM_CTL_REDO], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * VPM_REDO_PARTS;
+  constexpr uint32_t PART = VPM_SPW / VPM_REDO_PARTS;
+  for (uint32_t u = blockIdx.x; u < nUnits; u += gridDim.x) {
+    const uint32_t batch = sp.redo[u / VPM_REDO_PARTS];
+    const uint32_t sBase = batch * VPM_SPW + (u % VPM_REDO_PARTS) * PART;
+    // (inlined: a call would take the argument block by address, i.e. through scratch)
+    if (sBase < a.nsamples) vpmBatch<FULLVIS, HS, false, 0>(a, s, lane, batch, sBase, min(PART, a.nsamples - sBase), false, sp);
+    vpmWaveSync();
+  }
+}
+
+// the evaluation's LDS: the sample state of the 64 PAIRS of a batch (lane l's pair, not sample l), 32 accumulator columns
+// shared by the batch's pixel runs (one run: 32 copies of its sums, 16 runs: two each; the 33rd run adds to the film)
+struct VpmEvalLds {
+  uint32_t set[64];
+  double acc[27][32];
+  uint32_t run[64];      // first accumulator column of the pair's run (>= RUN_LIMIT: none)
+  uint32_t runPix[32];
+  double t[64];
+  float pdfBase[64];
+  float pdfSel[64];
+  float trBase[64];
+  float radius[64];
+  uint32_t pix[64];
+  uint32_t edge[64];
+  uint32_t gs[64];       // the pair's camera sample (the exact pass's notes name it)
+  uint32_t segOff[VPM_EVAL_CHUNKS + 1];
+  uint32_t subMask;      // copies per run - 1
+  uint2 rq[VRQ];
+  static constexpr uint32_t RUN_LIMIT = 32u;
+  static constexpr bool RAYS_AHEAD = true;
+  __device__ __forceinline__ uint32_t accSlot(uint32_t r) const { return r + (threadIdx.x & subMask); }
+  __device__ __forceinline__ uint32_t sampleIndex(uint32_t, uint32_t b) const { return gs[b]; }
+};
+
+template <bool FULLVIS, bool HS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MINW))) void vpm_eval_kernel(GatherArgs a, VpmSplit sp) {
+  __shared__ VpmEvalLds s;
+  const int lane = threadIdx.x;
+  // persistent: the launch is a few waves per SIMD (a wave per group of chunks was 39 k waves at C1, two thirds of them
+  // empty: the dispatch alone); wave w of shard k takes the shard's groups w, w + stride, ...
+  const uint32_t shard = blockIdx.x % VPM_SHARDS, gStride = (gridDim.x / VPM_SHARDS) * (uint32_t)VPM_EVAL_CHUNKS;
+  const uint32_t used = min(sp.ctl[shard * 32u], sp.shardChunks);
+  const float norm = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.f / (float)a.cfg.nb_camera_samples)));
+  uint32_t rqHead = 0, rqCount = 0;
+  uint32_t nNull = 0, nDiff = 0, nFail = 0;
+  unsigned long long nEvalW = 0;
+  auto drain = [&](uint32_t n) __attribute__((always_inline)) {
+    vpmWaveSync();
+    if ((uint32_t)lane < n) {
+      const uint2 e = s.rq[(rqHead + lane) % VRQ];
+      vpmPhase2<FULLVIS, HS>(a, s, e.x, e.y, norm, nDiff, nFail, 0u);
+    }
+    rqHead = (rqHead + n) % VRQ;
+    rqCount -= n;
+    vpmWaveSync();
+  };
+#ifdef GVPM_VPM_TIMING2
+  unsigned long long pt[5] = {0, 0, 0, 0, 0};  // load, phase 1, phase 2, flush, batches
+  const unsigned long long ptStart = wall_clock64();
+#define PTICK() wall_clock64()
+#else
+#define PTICK() 0ull
+#endif
+  for (uint32_t c0 = (blockIdx.x / VPM_SHARDS) * (uint32_t)VPM_EVAL_CHUNKS; c0 < used; c0 += gStride) {
+  const uint32_t chunk0 = shard * sp.shardChunks + c0;
+  uint32_t cnt = 0;
+  if (lane < VPM_EVAL_CHUNKS && c0 + (uint32_t)lane < used) {
+    const uint2 m = sp.chunkMeta[chunk0 + (uint32_t)lane];
+    cnt = sp.status[m.y] ? 0u : m.x;  // (a batch that went to the redo list: its chunks are void)
+  }
+  const uint32_t inc = waveScanInclDpp(cnt);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  if (total == 0u) continue;
+  vpmWaveSync();  // (the group before has read its offsets)
+  if (lane <= VPM_EVAL_CHUNKS) s.segOff[lane] = inc - cnt;  // (lane VPM_EVAL_CHUNKS: the total)
+  for (uint32_t j0 = 0; j0 < total; j0 += 64u) {
+    vpmWaveSync();  // (the batch before has read its state and flushed its sums)
+    [[maybe_unused]] const unsigned long long p0 = PTICK();
+    const uint32_t j = j0 + (uint32_t)lane;
+    const bool valid = j < total;
+    uint2 pr = make_uint2(0u, 0u);
+    VpmSampleState st = {};
+    if (valid) {
+      uint32_t sl = 0;
+#pragma unroll
+      for (int stp = VPM_EVAL_CHUNKS / 2; stp > 0; stp >>= 1)
+        if (s.segOff[sl + stp] <= j) sl += stp;
+      pr = sp.pairs[(size_t)(chunk0 + sl) * 64u + (j - s.segOff[sl])];
+      st = sp.state[pr.y];
+    }
+    const uint32_t pv = valid ? st.pix : 0xFFFFFFFFu;
+    s.set[lane] = valid ? st.set : 0xFFFFFFFFu;
+    s.t[lane] = st.t;
+    s.pdfBase[lane] = st.pdfBase;
+    s.pdfSel[lane] = st.pdfSel;
+    s.trBase[lane] = st.trBase;
+    s.radius[lane] = st.radius;
+    s.pix[lane] = pv;
+    s.edge[lane] = st.edge;
+    s.gs[lane] = pr.y;
+    // pixel runs of the batch (the pairs come in sample order within a slot: a pixel's pairs are adjacent); the 32 columns are
+    // dealt out evenly: the largest power of two of copies that gives every run its own
+    const uint32_t prev = __shfl_up(pv, 1u, 64);
+    const bool head = valid && (lane == 0 || prev != pv);
+    const unsigned long long heads = __ballot(head);
+    const uint32_t nRuns = min((uint32_t)__popcll(heads), 32u);
+    uint32_t cp = 32u;
+    while (cp * nRuns > 32u) cp >>= 1;  // (wave-uniform: scalar)
+    const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull)) - 1u;
+    s.run[lane] = valid && run < 32u ? run * cp : 0xFFFFFFFFu;
+    if (head && run < 32u) s.runPix[run] = pv;
+    if (lane == 0) s.subMask = cp - 1u;
+    for (int idx = lane; idx < 27 * 32; idx += 64) (&s.acc[0][0])[idx] = 0.0;
+    vpmWaveSync();
+    [[maybe_unused]] const unsigned long long p1 = PTICK();
+    // phase 1, its reconnections queued; all of them drained before the batch's sums are flushed
+    {
+      uint32_t qMask = 0u;
+      if (valid) qMask = vpmPhase1<HS>(a, s, pr.x, (uint32_t)lane, norm, nNull, nFail);
+      nEvalW += (unsigned long long)__popcll(__ballot(valid));
+#pragma unroll 1
+      for (uint32_t i = 0; i < 4u; ++i) {
+        const bool want = (qMask >> i) & 1u;
+        const unsigned long long m = __ballot(want);
+        if (m) {
+          if (want) {
+            const uint32_t off = __popcll(m & ((1ull << lane) - 1ull));
+            s.rq[(rqHead + rqCount + off) % VRQ] = make_uint2(pr.x, (uint32_t)lane | (i << 8) | (((qMask >> (4u + i)) & 1u) << 16));
+          }
+          rqCount += __popcll(m);
+          if (rqCount >= 64u) drain(64u);
+        }
+      }
+    }
+    [[maybe_unused]] const unsigned long long p2 = PTICK();
+    if (rqCount) drain(rqCount);
+    vpmWaveSync();
+    [[maybe_unused]] const unsigned long long p3 = PTICK();
+    for (uint32_t idx = (uint32_t)lane; idx < 27u * nRuns; idx += 64u) {
+      const uint32_t k = idx / nRuns, rr = idx % nRuns;
+      double vd = 0.0;
+      for (uint32_t c = 0; c < cp; ++c) vd += s.acc[k][rr * cp + c];
+      const float v = (float)vd;
+      if (v != 0.f) {
+        const uint32_t pw = s.runPix[rr];
+        atomicAdd(&a.iter[((size_t)(pw >> 16) * a.cfg.width + (pw & 0xFFFFu)) * 27 + k], v);
+      }
+    }
+#ifdef GVPM_VPM_TIMING2
+    pt[0] += p1 - p0;
+    pt[1] += p2 - p1;
+    pt[2] += p3 - p2;
+    pt[3] += wall_clock64() - p3;
+    pt[4] += 1;
+#endif
+  }
+  }
+#ifdef GVPM_VPM_TIMING2
+  if (lane == 0 && blockIdx.x < 32768u) {
+    unsigned long long *row = gvpmVpmLog + 4 * (32768u + blockIdx.x);  // (the upper half of the log: the walk's rows are below)
+    row[0] = ptStart;
+    row[1] = wall_clock64();
+    row[2] = (pt[0] & 0xFFFFFFFFull) | (pt[1] << 32);
+    row[3] = (pt[2] & 0xFFFFFull) | ((pt[3] & 0xFFFFFull) << 20) | (pt[4] << 40);
+  }
+#endif
+  {
+    unsigned long long nu = nNull, di = nDiff, fa = nFail;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      nu += __shfl_xor(nu, o, 64);
+      di += __shfl_xor(di, o, 64);
+      fa += __shfl_xor(fa, o, 64);
+    }
+    if (lane == 0 && nEvalW) {
+      atomicAdd(&statRow(a)[0], nEvalW);
       atomicAdd(&statRow(a)[2], nu);
       atomicAdd(&statRow(a)[3], di);
       atomicAdd(&statRow(a)[4], fa);
@@ -760,6 +1161,35 @@ void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream
     hipLaunchKernelGGL((gather_vpm_kernel<true, false>), grid, dim3(64 * VPM_WPB), 0, stream, a);
   } else {
     hipLaunchKernelGGL((gather_vpm_kernel<false, false>), grid, dim3(64 * VPM_WPB), 0, stream, a);
+  }
+}
+
+void launch_vpm_find(const GatherArgs &a, const VpmSplit &sp, hipStream_t stream) {
+  if (a.nsamples == 0) return;
+  const uint32_t nwaves = max((a.nsamples + VPM_SPW - 1u) / VPM_SPW, a.vpmOrderN);
+  hipLaunchKernelGGL(vpm_find_kernel, dim3(nwaves), dim3(64), 0, stream, a, sp);
+}
+void launch_vpm_redo(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t nwaves, hipStream_t stream) {
+  if (a.nsamples == 0) return;
+  if (a.reqHost) {
+    if (fullVis) hipLaunchKernelGGL((vpm_redo_kernel<true, true>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+    else hipLaunchKernelGGL((vpm_redo_kernel<false, true>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+  } else if (fullVis) {
+    hipLaunchKernelGGL((vpm_redo_kernel<true, false>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+  } else {
+    hipLaunchKernelGGL((vpm_redo_kernel<false, false>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+  }
+}
+void launch_vpm_eval(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t wavesPerShard, hipStream_t stream) {
+  if (a.nsamples == 0) return;
+  const uint32_t nwaves = VPM_SHARDS * std::min(wavesPerShard, (sp.shardChunks + (uint32_t)VPM_EVAL_CHUNKS - 1u) / (uint32_t)VPM_EVAL_CHUNKS);
+  if (a.reqHost) {
+    if (fullVis) hipLaunchKernelGGL((vpm_eval_kernel<true, true>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+    else hipLaunchKernelGGL((vpm_eval_kernel<false, true>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+  } else if (fullVis) {
+    hipLaunchKernelGGL((vpm_eval_kernel<true, false>), dim3(nwaves), dim3(64), 0, stream, a, sp);
+  } else {
+    hipLaunchKernelGGL((vpm_eval_kernel<false, false>), dim3(nwaves), dim3(64), 0, stream, a, sp);
   }
 }
 

@@ -143,6 +143,10 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_CLIP_GRID")) h->clipGrid = atoi(e) != 0;
   if (const char *e = getenv("GVPM_EVAL_ALT")) h->evalAlt = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
+  if (const char *e = getenv("GVPM_VPM_SPLIT")) h->vpmSplit = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_VPM_POOL")) h->vpmPoolPerBatch = (uint32_t)std::max(0, atoi(e));
+  if (const char *e = getenv("GVPM_VPM_EVAL_WAVES")) h->vpmEvalWaves = (uint32_t)std::max(64, atoi(e));
+  if (const char *e = getenv("GVPM_VPM_REDO_WAVES")) h->vpmRedoWaves = (uint32_t)std::max(1, atoi(e));
   if (const char *e = getenv("GVPM_BEAMS_SPLIT")) h->beamsSplit = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BUNDLE_AUTO")) h->bundleAuto = atoi(e) != 0;
   if (const char *e = getenv("GVPM_BUNDLE")) {
@@ -245,6 +249,9 @@ int gvpm_destroy(gvpm_context *h) {
   if (h->streamC) (void)hipStreamDestroy(h->streamC);
   if (h->streamA2) (void)hipStreamDestroy(h->streamA2);
   if (h->exactDone) (void)hipEventDestroy(h->exactDone);
+  h->vpmPairs.release(); h->vpmChunkMeta.release(); h->vpmCtl.release(); h->vpmStatus.release(); h->vpmRedo.release(); h->vpmState.release();
+  if (h->vpmFound) (void)hipEventDestroy(h->vpmFound);
+  if (h->vpmRedone) (void)hipEventDestroy(h->vpmRedone);
   delete h;
   return GVPM_OK;
 }

@@ -25,7 +25,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     print(f"== {os.path.basename(d)} (per-dispatch averages) ==")
     for k, cs in agg.items():
         n = max(1, len(calls[k]))
-        if not any(t in k for t in ("gather", "reorder", "evaluate", "traverse", "plan_kernel", "reconnect", "chain_")):
+        if not any(t in k for t in ("gather", "reorder", "evaluate", "traverse", "plan_kernel", "reconnect", "chain_", "vpm_")):
             continue
         print("  ", k, f"dispatches={n}")
         for c, v in sorted(cs.items()):

@@ -12,6 +12,7 @@ out = (ctypes.c_ulonglong * (4 * 65536))()
 h.gvpm_debug_vpm_timing(out)
 log = np.array(out[:], dtype=np.float64).reshape(-1, 4)
 log = log[log[:, 1] > 0]
+log = log[log[:, 0] > log[:, 0].max() - 1e5]  # (rows of the last launch only: a millisecond back from the latest start)
 t0 = log[:, 0].min()
 st, en = (log[:, 0] - t0) / 100.0, (log[:, 1] - t0) / 100.0  # microseconds
 life = en - st
