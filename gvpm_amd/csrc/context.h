@@ -38,7 +38,7 @@ void launch_reorder(const gvpm_photon_soa &raw, const uint32_t *keys, const uint
 void launch_apply_host_shifts(const GatherArgs &a, const gvpm_host_shift *results, uint32_t n, hipStream_t s);
 // the exact pass over the shifts the evaluation deferred (exact_shift.hip); totals: {evaluated, lost}
 void launch_exact_pass(const GatherArgs &a, unsigned long long *totals, uint32_t *hostOut, hipStream_t s);
-void launch_capture_notes(const GatherArgs &a, hipStream_t s);
+void launch_capture_notes(const GatherArgs &a, hipStream_t s, uint32_t nblocks = 256);
 void launch_exact_beams(const GatherArgs &a, unsigned long long *totals, hipStream_t s);
 void launch_near_grid(const float4 *tri4, uint32_t ntri, const NearGrid &g, float reach, uint32_t *counts, uint32_t *tris, int mode,
                       hipStream_t s);
@@ -94,8 +94,8 @@ void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream
 void launch_vpm_find(const GatherArgs &a, const VpmSplit &sp, hipStream_t stream);
 void launch_vpm_redo(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t nwaves, hipStream_t stream);
 void launch_vpm_eval(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t wavesPerShard, hipStream_t stream);
-void launch_vpm_update(float *scaleVol, float *nVol, float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
-                       hipStream_t stream);
+void launch_vpm_finish(float *accum, float *iter, float *scaleVol, float *nVol, float *mvol, size_t n, float alpha,
+                       uint32_t *maxScaleBits, hipStream_t stream);
 void launch_accumulate(float *accum, float *iter, size_t n, uint32_t *zeroWord, hipStream_t stream);
 hipError_t exclusiveSumU32(SortTemp &tmp, const uint32_t *in, uint32_t *out, uint32_t n, hipStream_t s);
 void launch_shift_extent(const gvpm_camera_ray *rays, uint32_t nsets, uint32_t *extentBits, hipStream_t s);
@@ -401,7 +401,7 @@ struct gvpm_context {
   // G-VPM as walk + evaluation + redo kernels (gather_vpm.hip; GVPM_VPM_SPLIT=0: the fused kernel)
   bool vpmSplit = true;
   uint32_t vpmPoolPerBatch = 4;  // chunks of 64 pairs the pool holds per batch of 64 samples (GVPM_VPM_POOL; tests shrink it so that batches take the redo path)
-  uint32_t vpmRedoWaves = 1024;  // persistent waves of the redo kernel
+  uint32_t vpmRedoWaves = 256;   // persistent waves of the redo kernel
   uint32_t vpmEvalWaves = 12288; // ... and of the evaluation (GVPM_VPM_EVAL_WAVES; 3072 / 6144 / 12288 / one a group: 0.413 / 0.388 / 0.362 / 0.362 ms at C1: the waves differ in length)
   DevBuf<uint2> vpmPairs, vpmChunkMeta;
   DevBuf<uint32_t> vpmCtl, vpmStatus, vpmRedo;

@@ -219,6 +219,7 @@ struct VpmSplit {
   uint32_t *redo;      // those batches
   VpmSampleState *state;
   uint32_t shardChunks, nBatches;
+  uint32_t *zeroWord;  // cleared by the walk (the largest-scale word)
 };
 
 // The G-BRE build chain (grid_build.hip, launch_build_chain): what its first five launches share.

@@ -495,8 +495,8 @@ __global__ __launch_bounds__(64) void capture_notes_kernel(GatherArgs a) {
     }
   }
 }
-void launch_capture_notes(const GatherArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(capture_notes_kernel, dim3(256), dim3(64), 0, s, a);
+void launch_capture_notes(const GatherArgs &a, hipStream_t s, uint32_t nblocks) {
+  hipLaunchKernelGGL(capture_notes_kernel, dim3(nblocks), dim3(64), 0, s, a);
 }
 
 // One pass over the handle's list

@@ -1389,6 +1389,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
       HIP_TRY(h, hipEventCreateWithFlags(&h->vpmFound, hipEventDisableTiming));
       HIP_TRY(h, hipEventCreateWithFlags(&h->vpmRedone, hipEventDisableTiming));
     }
+    sp.zeroWord = h->maxScaleBits.p;  // (read through the host at the top; the iteration's last kernel reduces the new maximum into it)
     launch_vpm_find(a, sp, h->stream);
     const bool side = h->pipeline && h->streamA2;
     hipStream_t rs = side ? h->streamA2 : h->stream;
@@ -1403,13 +1404,14 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
       HIP_TRY(h, hipStreamWaitEvent(h->stream, h->vpmRedone, 0));
     }
   } else {
+    HIP_TRY(h, hipMemsetAsync(h->maxScaleBits.p, 0, 4, h->stream));
     launch_gather_vpm(a, needFullVis(h), primal, h->stream);
   }
   HIP_TRY(h, hipEventRecord(ev->second, h->stream));
   // the shifts the kernel could not decide in fp32: into the handle's list (before the radii of this iteration are updated),
   // where they wait for the exact pass -- which adds to the plain sums whenever it runs
   if (!primal) {
-    launch_capture_notes(a, h->stream);
+    launch_capture_notes(a, h->stream, 32);  // (a hundred notes an iteration at C1: 256 workgroups spent 8 us on their own hand-off)
     rc = exactAfterGather(h);
     if (rc != GVPM_OK) return rc;
   }
@@ -1419,8 +1421,7 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     h->vpmOrderN = nBatches;
   }
   h->vpmLaunches++;
-  launch_accumulate(h->accum.p, h->iter.p, h->npix * 27, h->maxScaleBits.p, h->stream);
-  launch_vpm_update(h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
+  launch_vpm_finish(h->accum.p, h->iter.p, h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
   HIP_TRY(h, hipGetLastError());
   h->iterClean = true;
   h->totalEmitted += (double)nb_paths;  // m_totalEmittedVolume, gvpm.cpp:434

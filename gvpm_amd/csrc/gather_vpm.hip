@@ -76,6 +76,12 @@ struct VpmLds {
   uint2 rq[VRQ];       // queued reconnections {photon, sample | shift << 8}
   static constexpr uint32_t RUN_LIMIT = (uint32_t)VPM_RUNS;  // runs below it have LDS sums (vpmAdd)
   static constexpr bool RAYS_AHEAD = false;
+  static constexpr uint32_t ROW_LIMIT = 0xFFFFFFFFu;  // candidates one sample may list in a pass
+  __device__ __forceinline__ void initSample(int lane, uint32_t e) { edge[lane] = e; found[lane] = 0u; }
+  __device__ __forceinline__ uint32_t edgeOf(uint32_t b) const { return edge[b]; }
+  __device__ __forceinline__ uint32_t foundOf(uint32_t b) const { return found[b]; }
+  __device__ __forceinline__ void setRowOff(int k, int lane, uint32_t v) { rowOff[k][lane] = v; }
+  __device__ __forceinline__ uint32_t getRowOff(uint32_t k, uint32_t b) const { return rowOff[k][b]; }
   __device__ __forceinline__ uint32_t accSlot(uint32_t r) const { return r * VPM_SUB + (threadIdx.x & (VPM_SUB - 1)); }  // (VPM_SUB divides 64)
   __device__ __forceinline__ uint32_t sampleIndex(uint32_t sBase, uint32_t b) const { return sBase + b; }
 };
@@ -423,7 +429,7 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
       base.gop = q3.x;
     }
     s.pix[lane] = __float_as_uint(q3.w);
-    s.edge[lane] = GVPM_RAY_EDGE(__float_as_uint(q3.y));
+    s.initSample(lane, GVPM_RAY_EDGE(__float_as_uint(q3.y)));  // (the edge; the photon count M at zero)
     // pixel runs: consecutive lanes of one pixel (the C ABI does not promise that a pixel's samples are adjacent: a
     // pixel that comes back later in the wave is another run)
     if constexpr (MODE == 0) {
@@ -518,20 +524,21 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
     for (int o = 32; o > 0; o >>= 1) maxRows = max(maxRows, __shfl(maxRows, laneR ^ o, 64));
   }
   s.qr[lane] = make_float4(q.x, q.y, q.z, radius);
-  s.found[lane] = 0u;
   // A row of the box is a run of cells along x at one (y, z): only the part of it the sphere can reach is listed -- the
   // cells of a 3 x 3 x 3 box hold ~6 times the sphere's volume, the trimmed rows ~3 times (C1: 14.6 -> ~8 candidates a
   // sample).  Conservative: the reach carries 1e-4 r + 1e-6 + 2e-4 cells of slack -- a cell's bounds are rebuilt here as
   // org + index * cell, off the build's floor((p - org) * invCell) by up to ~1e-7 * index cells.
   // (no branch around the two loads: a row that lists nothing reads cell 0 and drops it -- the eighteen loads of a pass are
   // then issued back to back instead of one round trip after the other behind their conditions)
-  auto rowRange = [&](int r, uint32_t &c, uint32_t &e) __attribute__((always_inline)) {
+  // (row r of the box is (yy, zz) = (r % nyr, r / nyr): the caller steps them -- a quotient by a per-lane divisor is twenty
+  // instructions, nine times a pass; the row's base cell through 24-bit multiplies: a grid has at most 385 cells an axis)
+  auto rowRange = [&](int r, int yy, int zz, uint32_t &c, uint32_t &e) __attribute__((always_inline)) {
     const int nrowsL = (int)(boxB >> 14);
     const int bx0L = (int)(boxA & 1023u), bx1L = (int)((boxA >> 10) & 1023u), by0L = (int)(boxA >> 20);
-    const int bz0L = (int)(boxB & 1023u), nyr = max(1, (int)((boxB >> 10) & 15u));
+    const int bz0L = (int)(boxB & 1023u);
     const float4 qr = s.qr[lane];
     const float padW = qr.w * 1.0001f + 1e-6f + 2e-4f * gr.cell, pad2 = padW * padW;
-    const int y = by0L + r % nyr, z = bz0L + r / nyr;
+    const int y = by0L + yy, z = bz0L + zz;
     const float ylo = gr.org[1] + (float)y * gr.cell, zlo = gr.org[2] + (float)z * gr.cell;
     const float dy = fmaxf(0.f, fmaxf(ylo - qr.y, qr.y - (ylo + gr.cell))), dz = fmaxf(0.f, fmaxf(zlo - qr.z, qr.z - (zlo + gr.cell)));
     const float h2 = pad2 - (dy * dy + dz * dz);
@@ -539,7 +546,7 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
     const int x0 = max(bx0L, (int)floorf((qr.x - hx - gr.org[0]) * gr.invCell));
     const int x1 = min(bx1L, (int)floorf((qr.x + hx - gr.org[0]) * gr.invCell));
     const bool ok = r < nrowsL && h2 > 0.f && x1 >= x0;
-    const uint32_t rb = ((uint32_t)z * gr.dim[1] + y) * gr.dim[0];
+    const uint32_t rb = __umul24(__umul24((uint32_t)z, (uint32_t)gr.dim[1]) + (uint32_t)y, (uint32_t)gr.dim[0]);
     const uint32_t cc = a.cellStart[ok ? rb + x0 : 0u], ee = a.cellStart[ok ? rb + x1 + 1 : 0u];
     c = ok ? cc : 0u;
     e = ok ? ee : 0u;
@@ -614,18 +621,33 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
   for (int r0 = 0; r0 < maxRows && !slotFull; r0 += VPM_ROWS) {
     // this lane's rows of the pass: all ranges in flight together, then the lane's own prefix over them
     uint32_t rcs[VPM_ROWS], res[VPM_ROWS];
+    {
+      const int nyr = max(1, (int)((boxB >> 10) & 15u));
+      int yy = r0 ? r0 % nyr : 0, zz = r0 ? r0 / nyr : 0;
 #pragma unroll
-    for (int k = 0; k < VPM_ROWS; ++k) rowRange(r0 + k, rcs[k], res[k]);
+      for (int k = 0; k < VPM_ROWS; ++k) {
+        rowRange(r0 + k, yy, zz, rcs[k], res[k]);
+        if (++yy == nyr) {
+          yy = 0;
+          ++zz;
+        }
+      }
+    }
     vpmWaveSync();  // (the previous pass has read its offsets)
     uint32_t cnt = 0;
 #pragma unroll
     for (int k = 0; k < VPM_ROWS; ++k) {
       s.rowStart[k][lane] = rcs[k];
-      s.rowOff[k][lane] = cnt;
+      s.setRowOff(k, lane, cnt);
       cnt += res[k] - rcs[k];
     }
     // (the scan through DPP row shifts and broadcasts -- the sequence LLVM's own atomic optimizer emits for wave64 -- instead of
     // six ds_bpermute: their six address registers were carried, spilled, across the whole walk and reloaded every pass)
+    if constexpr (MODE == 1)
+      if (__ballot(cnt > LDS::ROW_LIMIT)) {  // (the walk kernel's 16-bit row offsets: the fused code takes the batch)
+        slotFull = true;
+        break;
+      }
     const uint32_t inc = waveScanInclDpp(cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     s.segOff[lane] = inc - cnt;
@@ -644,14 +666,14 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
       // ... and the last of its rows whose offset is <= the entry's place in the sample's list
       const uint32_t kk = j - s.segOff[owner];
       uint32_t row = 0;
-      if (s.rowOff[8][owner] <= kk) {
+      if (s.getRowOff(8, owner) <= kk) {
         row = 8;
       } else {
 #pragma unroll
         for (int st = 4; st > 0; st >>= 1)
-          if (s.rowOff[row + st][owner] <= kk) row += st;
+          if (s.getRowOff(row + st, owner) <= kk) row += st;
       }
-      gi = s.rowStart[row][owner] + (kk - s.rowOff[row][owner]);
+      gi = s.rowStart[row][owner] + (kk - s.getRowOff(row, owner));
     };
     // (the walk kernel: the next trip's photon is located and its load issued before this trip's is tested -- a round trip per
     // trip was most of a wave's life; the fused kernel has no registers for it)
@@ -716,13 +738,13 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
           if (PRIMAL) {
             // RadianceQueryVolume (photonmap.cpp:287-297): radius, then depth against maxDepth = m_maxDepth - beam.depth --
             // `maxDepth > 0 &&` as written: a bound of zero or less filters nothing -- and M counts what passes both
-            const int md = a.cfg.max_depth > 0 ? a.cfg.max_depth - (int)s.edge[owner] : 0x7FFFFFFF;
+            const int md = a.cfg.max_depth > 0 ? a.cfg.max_depth - (int)s.edgeOf(owner) : 0x7FFFFFFF;
             if (md > 0 && (int)GVPM_PF_DEPTH(bits) > md) hit = false;
             if (hit) atomicAdd(&s.found[owner], 1u);
           } else {
             atomicAdd(&s.found[owner], 1u);
             // filters, shift_volume_photon.cpp:503-521 (maxDepth only; no path-set in G-VPM)
-            const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edge[owner];
+            const int depth = (int)GVPM_PF_DEPTH(bits) + (int)s.edgeOf(owner);
             if (a.cfg.max_depth > 0 && depth > a.cfg.max_depth) hit = false;
             if (!((bits >> 6) & 1u)) hit = false;
           }
@@ -772,7 +794,7 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
       if (chunkAhead < sp.shardChunks) sp.chunkMeta[(blockIdx.x % VPM_SHARDS) * sp.shardChunks + chunkAhead] = make_uint2(0u, batch);
     }
     vpmWaveSync();
-    if (s.found[lane] != 0u) {
+    if (s.foundOf(lane) != 0u) {
       VpmSampleState st;
       st.t = t;
       st.pdfBase = pdfBase;
@@ -781,7 +803,7 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
       st.pdfSel = pdfSel;
       st.set = set;
       st.pix = s.pix[lane];
-      st.edge = s.edge[lane];
+      st.edge = s.edgeOf(lane);
       st.pad[0] = st.pad[1] = st.pad[2] = 0u;
       sp.state[sBase + (uint32_t)lane] = st;
     }
@@ -816,7 +838,7 @@ __device__ __forceinline__ void vpmBatch(const GatherArgs &a, LDS &s, const int 
       const int o = 1 << j;
       if (lane + o < 64 && (((heads >> (lane + 1)) & ((1ull << o) - 1ull)) == 0ull)) same |= 1u << j;
     }
-    float fv = (float)s.found[lane];
+    float fv = (float)s.foundOf(lane);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const float w = __shfl_down(fv, 1u << j, 64);
@@ -890,19 +912,30 @@ __global__ __launch_bounds__(64 * VPM_WPB) __attribute__((amdgpu_waves_per_eu(GV
 //                     batch, sixteen samples each).  Empty unless a step finds over four times as many pairs as it has
 //                     samples (the pool's size, gatherVPM).
 // The walk decides pairs exactly as the fused kernel does (one source); the evaluation adds the same terms.
+// (6.9 KB: 22 waves per CU where the fused kernel's layout allowed 18 -- the walk is a chain of round trips, its rate is the
+// number of waves in flight: a row's offset within its sample's list in 16 bits (a sample that lists 65 536 candidates or more
+// in a pass sends its batch to the redo list), the edge in the top byte of the photon count)
 struct VpmFindLds {
   uint32_t set[64];
   uint2 queue[VQ];
   double t[64];
   uint32_t pix[64];
-  uint32_t edge[64];
   float4 qr[64];
   uint32_t segOff[64 + 1];
-  uint32_t rowStart[VPM_ROWS][64], rowOff[VPM_ROWS][64];
-  uint32_t found[64];
+  uint32_t rowStart[VPM_ROWS][64];
+  uint16_t rowOff16[VPM_ROWS - 1][64];  // rows 1 ..: row 0 starts its sample's list
+  uint32_t found[64];                   // photons inside the query sphere | edge << 24
+  static constexpr uint32_t ROW_LIMIT = 0xFFFFu;
+  __device__ __forceinline__ void initSample(int lane, uint32_t e) { found[lane] = e << 24; }
+  __device__ __forceinline__ uint32_t edgeOf(uint32_t b) const { return found[b] >> 24; }
+  __device__ __forceinline__ uint32_t foundOf(uint32_t b) const { return found[b] & 0xFFFFFFu; }
+  __device__ __forceinline__ void setRowOff(int k, int lane, uint32_t v) {
+    if (k > 0) rowOff16[k - 1][lane] = (uint16_t)v;
+  }
+  __device__ __forceinline__ uint32_t getRowOff(uint32_t k, uint32_t b) const { return k ? (uint32_t)rowOff16[k - 1][b] : 0u; }
 };
 #ifndef GVPM_VPM_FIND_MINW
-#define GVPM_VPM_FIND_MINW 5
+#define GVPM_VPM_FIND_MINW 6
 #endif
 #ifndef GVPM_VPM_REDO_PARTS
 #define GVPM_VPM_REDO_PARTS 4
@@ -913,14 +946,20 @@ constexpr uint32_t VPM_REDO_PARTS = GVPM_VPM_REDO_PARTS;
 #endif
 constexpr int VPM_EVAL_CHUNKS = GVPM_VPM_EVAL_CHUNKS;
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_FIND_MINW))) void vpm_find_kernel(GatherArgs a, VpmSplit sp) {
-  __shared__ VpmFindLds s;
-  const int lane = threadIdx.x;
-  const uint32_t slot = blockIdx.x;
+// waves per workgroup of the walk (they share nothing: an LDS slice each, no workgroup barrier)
+#ifndef GVPM_VPM_FIND_WPB
+#define GVPM_VPM_FIND_WPB 1
+#endif
+constexpr uint32_t VPM_FIND_WPB = GVPM_VPM_FIND_WPB;
+__global__ __launch_bounds__(64 * GVPM_VPM_FIND_WPB) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_FIND_MINW))) void vpm_find_kernel(GatherArgs a, VpmSplit sp) {
+  __shared__ VpmFindLds sAll[VPM_FIND_WPB];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t slot = blockIdx.x * VPM_FIND_WPB + (uint32_t)wv;
+  if (slot == 0 && lane == 0 && sp.zeroWord) *sp.zeroWord = 0u;
   const uint32_t batch = slot < a.vpmOrderN ? a.vpmOrder[slot] : slot;
   const uint32_t sBase = batch * VPM_SPW;
   if (sBase >= a.nsamples) return;
-  vpmBatch<false, false, false, 1>(a, s, lane, batch, sBase, min(VPM_SPW, a.nsamples - sBase), true, sp);
+  vpmBatch<false, false, false, 1>(a, sAll[wv], lane, batch, sBase, min(VPM_SPW, a.nsamples - sBase), true, sp);
 }
 
 template <bool FULLVIS, bool HS>
@@ -1111,11 +1150,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GVPM_VPM_MIN
   }
 }
 
-// SPPM statistics of G-VPM, gvpm.cpp:1191-1195 (per pixel) + the largest scale for the next grid
-// (mvol is handed back zeroed: the next gather adds into it without a memset before it)
-__global__ __launch_bounds__(256) void vpm_update_kernel(float *scaleVol, float *nVol, float *mvol, size_t n,
-                                                         float alpha, uint32_t *maxScaleBits) {
+// The end of a G-VPM iteration in ONE launch (two until round 6: 6 + 14 us for 65 k pixels -- the second one a thousand waves'
+// atomicMax on one word, ~11 ns apart):
+//   accum += iter, and iter handed back zeroed (every thread: one of the P * 27 sums);
+//   SPPM statistics, gvpm.cpp:1191-1195 (the threads below P: their pixel) + the largest scale for the next grid, reduced in the
+//   workgroup first; mvol is handed back zeroed: the next gather adds into it without a memset before it.
+// maxScaleBits is zero when the kernel starts: the gather that read it (through the host) lies before, gatherVPM clears it.
+__global__ __launch_bounds__(256) void vpm_finish_kernel(float *__restrict__ accum, float *__restrict__ iter, size_t n27,
+                                                         float *scaleVol, float *nVol, float *mvol, size_t n, float alpha,
+                                                         uint32_t *maxScaleBits) {
+  __shared__ float wmax[4];
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n27) {
+    accum[i] += iter[i];
+    iter[i] = 0.f;
+  }
+  if ((size_t)blockIdx.x * blockDim.x >= n) return;  // (workgroup-uniform: no pixel below this workgroup)
   float sc = 0.f;
   if (i < n) {
     sc = scaleVol[i];
@@ -1129,13 +1179,16 @@ __global__ __launch_bounds__(256) void vpm_update_kernel(float *scaleVol, float 
     }
   }
   sc = wave_max(sc);
-  // positive floats order as uints; a wave first looks whether it would raise the maximum (same-address atomics retire ~11 ns apart)
-  if ((threadIdx.x & 63) == 0 && __float_as_uint(sc) > __hip_atomic_load(maxScaleBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(maxScaleBits, __float_as_uint(sc));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = sc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sc = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    // positive floats order as uints; a workgroup first looks whether it would raise the maximum
+    if (__float_as_uint(sc) > __hip_atomic_load(maxScaleBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxScaleBits, __float_as_uint(sc));
+  }
 }
 
-// accum += iter, and iter handed back zeroed; zeroWord: the largest-scale word, cleared between the gather that read it (through
-// the host) and the update behind this kernel that writes it again
+// accum += iter, and iter handed back zeroed; zeroWord: cleared with it (the other techniques' fold)
 __global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ accum, float *__restrict__ iter, size_t n,
                                                          uint32_t *zeroWord) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1167,7 +1220,7 @@ void launch_gather_vpm(const GatherArgs &a, bool fullVis, bool primal, hipStream
 void launch_vpm_find(const GatherArgs &a, const VpmSplit &sp, hipStream_t stream) {
   if (a.nsamples == 0) return;
   const uint32_t nwaves = max((a.nsamples + VPM_SPW - 1u) / VPM_SPW, a.vpmOrderN);
-  hipLaunchKernelGGL(vpm_find_kernel, dim3(nwaves), dim3(64), 0, stream, a, sp);
+  hipLaunchKernelGGL(vpm_find_kernel, dim3((nwaves + VPM_FIND_WPB - 1u) / VPM_FIND_WPB), dim3(64 * VPM_FIND_WPB), 0, stream, a, sp);
 }
 void launch_vpm_redo(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint32_t nwaves, hipStream_t stream) {
   if (a.nsamples == 0) return;
@@ -1193,10 +1246,11 @@ void launch_vpm_eval(const GatherArgs &a, const VpmSplit &sp, bool fullVis, uint
   }
 }
 
-void launch_vpm_update(float *scaleVol, float *nVol, float *mvol, size_t n, float alpha, uint32_t *maxScaleBits,
-                       hipStream_t stream) {
-  hipLaunchKernelGGL(vpm_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, scaleVol, nVol, mvol, n,
-                     alpha, maxScaleBits);
+void launch_vpm_finish(float *accum, float *iter, float *scaleVol, float *nVol, float *mvol, size_t n, float alpha,
+                       uint32_t *maxScaleBits, hipStream_t stream) {
+  const size_t n27 = n * 27;
+  hipLaunchKernelGGL(vpm_finish_kernel, dim3((unsigned)((n27 + 255) / 256)), dim3(256), 0, stream, accum, iter, n27, scaleVol, nVol, mvol,
+                     n, alpha, maxScaleBits);
 }
 
 void launch_accumulate(float *accum, float *iter, size_t n, uint32_t *zeroWord, hipStream_t stream) {
