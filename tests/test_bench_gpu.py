@@ -49,7 +49,7 @@ def test_other_workloads_emit_the_same_line(wl, extra):
     d = run_bench("--workload", wl, "--steps", "3", "--warmup", "1", "--cpu-seconds", "0.5", *extra)
     check_line(d, 3)
     assert d["config"]["workload"].startswith("custom")  # reduced sizes are not the BASELINE config: the line says so
-    assert d["roofline"]["kernel"] in ("gather_vpm_kernel", "evaluate_beams2_kernel", "gather_planes_kernel")
+    assert d["roofline"]["kernel"] in ("vpm_find_kernel+vpm_eval_kernel", "evaluate_beams2_kernel", "gather_planes_kernel")
 
 
 def test_default_workload_reduced():
@@ -74,7 +74,7 @@ def test_headline_run_carries_the_other_workloads():
     check_line(d, 3)
     ow = d["other_workloads"]
     assert sorted(ow) == ["c1", "c3", "c5"]
-    for w, kern in (("c1", "gather_vpm_kernel"), ("c3", "evaluate_beams2_kernel"), ("c5", "gather_planes_kernel")):
+    for w, kern in (("c1", "vpm_find_kernel+vpm_eval_kernel"), ("c3", "evaluate_beams2_kernel"), ("c5", "gather_planes_kernel")):
         o = ow[w]
         assert "error" not in o, o
         for k in ("metric", "value", "unit", "ms_per_step", "steps", "workload", "roofline_frac", "kernel", "kernel_avg_ms",
