@@ -190,3 +190,20 @@ def test_a_photon_at_the_radius_takes_the_double_radius():
     3 10^7 went the other way (`evaluations` off by one).  The in-band test forms R * 0.01 * scaleVol in double now."""
     c = make_vpm_case("cbox_conductor_rot", 36, 30, 30000, 5.0, nb=4, it=3)
     device_vpm(c, iters=2)
+
+
+@pytest.mark.parametrize("knob", ["GVPM_VPM_POOL=0", "GVPM_VPM_SPLIT=0"])
+def test_vpm_kernel_paths_agree(knob, monkeypatch):
+    """Round 6: the gather is three kernels (the walk, the evaluation over the pool's chunks, the fused code for batches that
+    find the pool exhausted).  With a pool of four chunks per shard nearly every batch takes the fallback; with the split off
+    the fused kernel does everything: counters equal the default path's -- and all of them the oracle's (device_vpm asserts) --
+    and the sums agree to the atomics' order."""
+    c = make_vpm_case("cbox_hg", 32, 28, 40000, 5.0, nb=10)
+    acc0, _, st0 = device_vpm(c, iters=2)
+    name, val = knob.split("=")
+    monkeypatch.setenv(name, val)
+    acc1, ref, st1 = device_vpm(c, iters=2)
+    for k in ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert st0[k] == st1[k], (k, st0[k], st1[k])
+    lum = max(ref[..., 0:3].mean(), 1e-30)
+    assert l2(acc1, acc0, lum) < 1e-6
