@@ -398,6 +398,10 @@ struct gvpm_context {
   uint32_t vpmOrderN = 0;      // batches the G-VPM order in blockValB was sorted for (0: none)
   uint32_t vpmLaunches = 0;
   bool vpmNoOrder = false;     // GVPM_VPM_ORDER=0
+  // G-VPM: a bound on the largest per-pixel scale (gatherVPM: the initial scale, then what the iterations have exported); the
+  // grid of step N + 1 built on the build stream beside the gather of step N (GVPM_VPM_PIPELINE=0: behind it)
+  float vpmScaleBound = 0.f;
+  bool vpmPipeline = true;
   // G-VPM as walk + evaluation + redo kernels (gather_vpm.hip; GVPM_VPM_SPLIT=0: the fused kernel)
   bool vpmSplit = true;
   uint32_t vpmPoolPerBatch = 4;  // chunks of 64 pairs the pool holds per batch of 64 samples (GVPM_VPM_POOL; tests shrink it so that batches take the redo path)

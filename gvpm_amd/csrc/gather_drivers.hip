@@ -184,6 +184,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   float b6[6];
   if (!h->pinB6) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
+    memset(h->pinB6, 0, 256);
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   const bool defer = deferred && h->haveCachedBounds;
@@ -343,6 +344,9 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   const float lmax = 1.25f * sqrtf(diag2) + 8.f * r + 1e-3f;
   const float dmax = h->cfg.shadow_epsilon * lmax * 1.01f + 1e-6f;
   if (h->ntri > 64u && h->useNearGrid && !(dmax <= h->nearGridReach)) {
+    // (the occluder grid belongs to the handle, not to a build set: a gather that still reads it on the other stream ends first)
+    if (h->bstream != h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->streamA2) HIP_TRY(h, hipStreamSynchronize(h->streamA2));
     const int rcg = buildNearGrid(h, dmax * 1.5f);
     if (rcg != GVPM_OK) return rcg;
   }
@@ -363,6 +367,7 @@ static int buildGrid(gvpm_context *h, float r, bool deferred = false, bool force
   if (!deferred && h->cfg.visibility_as_written) {
     if (!h->pinB6) {
       HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
+    memset(h->pinB6, 0, 256);
       h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
     }
     launch_export_u32(h->bs->overflowCtr.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->bstream);
@@ -752,6 +757,7 @@ static int gatherBRE(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   // ... read back in the step's one host sync, with the photon bounds and the near-list overflow count
   if (!h->pinB6) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
+    memset(h->pinB6, 0, 256);
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
   if (cp.on && rebuilt) {
@@ -1289,33 +1295,59 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
   (void)it;
   if (!h->haveSamples) return fail(h, GVPM_ERR_STATE, "G-VPM gather needs gvpm_upload_vpm_samples");
   if (h->cfg.nb_camera_samples <= 0) return fail(h, GVPM_ERR_INVALID_ARG, "nb_camera_samples must be positive");
-  // grid cell = the largest per-pixel radius R * 0.01 * max(scaleVol)
-  // ONE host round trip for the largest radius and the photons' bounds (each was a D2H copy + a wait of its own: ~30 us of
-  // an idle GPU, and C1's step is 0.6 ms): the kernels write them into pinned memory
+  // grid cell = the largest per-pixel radius R * 0.01 * max(scaleVol) -- or anything above it.
+  // Round 6: the step no longer waits for the one before it.  (1) The scale: a pixel's scale only shrinks (ratio <= 1 in the
+  // SPPM update), so the largest scale of ANY earlier iteration bounds this one's: the host keeps such a bound -- the initial
+  // scale at gvpm_reset, then whatever the iterations' last kernels have exported to pinned memory by now, one or two steps
+  // stale -- and the cells are that much larger than they need to be.  (2) The photons' bounds and the grid on the BUILD stream,
+  // into the other build set, while the gather of the step before still runs on the gather stream: the host waits for the
+  // bounds of THIS upload only (a 10 us reduction that depends on nothing else), then for the near lists' overflow word behind
+  // the build.  Until round 6 both waits stood behind the previous gather, the GPU idle for ~25 us of a 0.45 ms step, and the
+  // build's nine small launches (~70 us) ran between two gathers instead of beside one.
   if (!h->pinB6) {
     HIP_TRY(h, hipHostMalloc((void **)&h->pinB6, 256, hipHostMallocMapped));
+    memset(h->pinB6, 0, 256);
     h->pinCtl = reinterpret_cast<uint32_t *>(h->pinB6 + 8);
   }
-  const bool wantBounds = h->photonsDirty && h->nph > 0;
-  if (wantBounds) {
-    HIP_TRY(h, h->bs->boundsPartial.ensure(1024 * 6));
-    HIP_TRY(h, h->bs->bounds6.ensure(32));
-    launch_bounds(h->rawDev.pos, h->nph, h->bs->boundsPartial.p, 1024, h->bs->bounds6.p, h->pinB6, h->stream, h->maxScaleBits.p,
-                  h->pinCtl);
-  } else {
-    launch_export_u32(h->maxScaleBits.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl, h->stream);
+  {
+    const uint32_t bits = reinterpret_cast<volatile uint32_t *>(h->pinCtl)[32];
+    float e;
+    memcpy(&e, &bits, 4);
+    if (bits != 0u && e > 0.f && e < h->vpmScaleBound) h->vpmScaleBound = e;
   }
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  const uint32_t bits = h->pinCtl[0];
-  float maxScale;
-  memcpy(&maxScale, &bits, 4);
+  const float maxScale = h->vpmScaleBound;
+  if (!(maxScale > 0.f)) return fail(h, GVPM_ERR_STATE, "G-VPM gather: no scale bound (gvpm_reset sets it)");
   const float rmax = (h->cfg.bsphere_radius * 0.01f) * maxScale;
-  if (h->photonsDirty || rmax != h->bs->builtRadius) {
+  const bool pipe = h->pipeline && h->vpmPipeline && h->streamB;
+  h->bstream = pipe ? h->streamB : h->stream;
+  const bool rebuild = h->photonsDirty || rmax != h->bs->builtRadius;
+  if (rebuild) {
+    if (pipe) {
+      // the other set; wait (on the build stream) until the gather that last read it is done
+      h->setIdx = (h->setIdx + 1) % 2;
+      h->bs = &h->sets[h->setIdx];
+      if (h->bs->lastUseValid) HIP_TRY(h, hipStreamWaitEvent(h->bstream, h->bs->lastUse, 0));
+    }
+    const bool wantBounds = h->nph > 0;
+    if (wantBounds) {
+      HIP_TRY(h, h->bs->boundsPartial.ensure(1024 * 6));
+      HIP_TRY(h, h->bs->bounds6.ensure(32));
+      launch_bounds(h->rawDev.pos, h->nph, h->bs->boundsPartial.p, 1024, h->bs->bounds6.p, h->pinB6, h->bstream, nullptr, nullptr);
+      HIP_TRY(h, hipStreamSynchronize(h->bstream));
+    }
     int rc = buildGrid(h, rmax, false, false, wantBounds ? h->pinB6 : nullptr);
-    if (rc != GVPM_OK) return rc;
+    if (rc != GVPM_OK) {
+      h->bstream = h->stream;
+      return rc;
+    }
     h->photonsDirty = false;
     h->bs->builtRadius = rmax;
+    if (pipe) {
+      HIP_TRY(h, hipEventRecord(h->bs->traversed, h->bstream));  // (this set's spare event: the build is done)
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->bs->traversed, 0));
+    }
   }
+  h->bstream = h->stream;
   // (the previous G-VPM gather zeroed `iter` and `mvol` as it folded them, and zeroes the largest-scale word before its update:
   // accumulate_kernel / vpm_update_kernel; anything else in between -- another technique, a failed gather -- and they are cleared here)
   if (!h->iterClean) {
@@ -1421,7 +1453,11 @@ static int gatherVPM(gvpm_context *h, int it, uint64_t nb_paths, bool primal = f
     h->vpmOrderN = nBatches;
   }
   h->vpmLaunches++;
+  HIP_TRY(h, hipEventRecord(h->bs->lastUse, h->stream));  // (the kernels above are the last readers of this build set)
+  h->bs->lastUseValid = true;
   launch_vpm_finish(h->accum.p, h->iter.p, h->scaleVol.p, h->nVol.p, h->mvol.p, h->npix, h->cfg.alpha, h->maxScaleBits.p, h->stream);
+  // the new largest scale to pinned memory: a later gather's bound (above)
+  launch_export_u32(h->maxScaleBits.p, nullptr, nullptr, nullptr, nullptr, h->pinCtl + 32, h->stream);
   HIP_TRY(h, hipGetLastError());
   h->iterClean = true;
   h->totalEmitted += (double)nb_paths;  // m_totalEmittedVolume, gvpm.cpp:434

@@ -144,6 +144,7 @@ int gvpm_create(const gvpm_params *params, int device, gvpm_context **out) {
   if (const char *e = getenv("GVPM_EVAL_ALT")) h->evalAlt = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_ORDER")) h->vpmNoOrder = atoi(e) == 0;
   if (const char *e = getenv("GVPM_VPM_SPLIT")) h->vpmSplit = atoi(e) != 0;
+  if (const char *e = getenv("GVPM_VPM_PIPELINE")) h->vpmPipeline = atoi(e) != 0;
   if (const char *e = getenv("GVPM_VPM_POOL")) h->vpmPoolPerBatch = (uint32_t)std::max(0, atoi(e));
   if (const char *e = getenv("GVPM_VPM_EVAL_WAVES")) h->vpmEvalWaves = (uint32_t)std::max(64, atoi(e));
   if (const char *e = getenv("GVPM_VPM_REDO_WAVES")) h->vpmRedoWaves = (uint32_t)std::max(1, atoi(e));
@@ -298,6 +299,9 @@ int gvpm_reset(gvpm_context *h) {
     memcpy(&bits, &sc, 4);
     HIP_TRY(h, hipMemcpyAsync(h->maxScaleBits.p, &bits, 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // (nothing of an earlier run is in flight any more: its exports cannot land behind this)
+    h->vpmScaleBound = sc;
+    if (h->pinCtl) h->pinCtl[32] = 0u;
   }
   return GVPM_OK;
 }
