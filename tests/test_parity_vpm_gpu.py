@@ -192,18 +192,71 @@ def test_a_photon_at_the_radius_takes_the_double_radius():
     device_vpm(c, iters=2)
 
 
-@pytest.mark.parametrize("knob", ["GVPM_VPM_POOL=0", "GVPM_VPM_SPLIT=0"])
+@pytest.mark.parametrize("knob", ["GVPM_VPM_POOL=0", "GVPM_VPM_SPLIT=0", "GVPM_VPM_PIPELINE=0", "GVPM_PIPELINE=0"])
 def test_vpm_kernel_paths_agree(knob, monkeypatch):
     """Round 6: the gather is three kernels (the walk, the evaluation over the pool's chunks, the fused code for batches that
     find the pool exhausted).  With a pool of four chunks per shard nearly every batch takes the fallback; with the split off
-    the fused kernel does everything: counters equal the default path's -- and all of them the oracle's (device_vpm asserts) --
-    and the sums agree to the atomics' order."""
+    the fused kernel does everything; with the pipeline off the grid is built behind the previous gather, on its stream, instead
+    of beside it into the other build set: counters equal the default path's -- and all of them the oracle's (device_vpm
+    asserts) -- and the sums agree to the atomics' order.  Four iterations: both build sets are used twice, and the cell size
+    comes from the host's bound on the largest scale, one or two iterations stale."""
     c = make_vpm_case("cbox_hg", 32, 28, 40000, 5.0, nb=10)
-    acc0, _, st0 = device_vpm(c, iters=2)
+    acc0, _, st0 = device_vpm(c, iters=4)
     name, val = knob.split("=")
     monkeypatch.setenv(name, val)
-    acc1, ref, st1 = device_vpm(c, iters=2)
+    acc1, ref, st1 = device_vpm(c, iters=4)
     for k in ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts"):
         assert st0[k] == st1[k], (k, st0[k], st1[k])
     lum = max(ref[..., 0:3].mean(), 1e-30)
     assert l2(acc1, acc0, lum) < 1e-6
+
+
+def test_vpm_reset_and_same_photons_again():
+    """The pipelined step keeps state on the host (the bound on the largest scale, the build set in use): a handle that is
+    reset in the middle of a run, and one that gathers the SAME photons twice (no rebuild, no rotation), must give what a
+    fresh handle gives."""
+    c = make_vpm_case("cbox", 24, 20, 30000, 5.0, nb=8)
+    p = c.p
+
+    def run(ctx, iters):
+        for it in range(1, iters + 1):
+            if it == 1:
+                ph, nb, r, smp = c.ph, c.nb, c.rays, c.samples
+            else:
+                ph, nb = c.sc.shoot_photons(it, c.ph.n)
+                r, smp = c.sc.camera_beams_and_vpm_samples(it, p.nb_camera_samples)
+            ctx.upload_photons(ph)
+            ctx.upload_camera_beams(r)
+            ctx.upload_vpm_samples(smp)
+            ctx.gather(it, nb)
+        return ctx.download_accum(), ctx.stats()
+
+    ctx = hip.Context(p, device=0)
+    ctx.upload_scene(*c.tris)
+    ctx.upload_medium(c.m)
+    acc_a, st_a = run(ctx, 3)
+    ctx.reset()
+    acc_b, st_b = run(ctx, 3)
+    for k in ("evaluations", "candidates", "null_shifts", "diffuse_shifts", "failed_shifts"):
+        assert st_a[k] == st_b[k], (k, st_a[k], st_b[k])
+    lum = max(acc_a[..., 0:3].mean(), 1e-30)
+    assert l2(acc_b, acc_a, lum) < 1e-6
+    # the same photons and samples again, twice: iterations 4 and 5 of this handle against iteration 4 twice on another
+    ph, nb = c.sc.shoot_photons(4, c.ph.n)
+    r, smp = c.sc.camera_beams_and_vpm_samples(4, p.nb_camera_samples)
+    ctx.upload_photons(ph)
+    ctx.upload_camera_beams(r)
+    ctx.upload_vpm_samples(smp)
+    ctx.gather(4, nb)
+    s4 = ctx.stats()
+    ctx.gather(5, nb)  # (nothing uploaded in between: the grid is kept unless the bound on the radius has moved)
+    s5 = ctx.stats()
+    ctx.close()
+    ref = sv = nv = None
+    total = 0
+    for it, (pp, rr, ss) in enumerate([(c.ph, c.rays, c.samples)] + [(c.sc.shoot_photons(i, c.ph.n)[0],) + c.sc.camera_beams_and_vpm_samples(i, p.nb_camera_samples) for i in (2, 3)] + [(ph, r, smp), (ph, r, smp)], 1):
+        ref, sv, nv, cnt, _ = O.gather_vpm(p, c.m, c.tris, pp, rr, ss, 64, use_accel=False, accum=ref, scale_vol=sv, n_vol=nv)
+        total += cnt["evaluations"]
+        if it == 4:
+            assert s4["evaluations"] == total
+    assert s5["evaluations"] == total
